@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the MaskFusion::processFrame hot path on MI355X (driver contract: see task statement).
+
+Workload (BASELINE.json configs[1]): synthetic 640x480 RGB-D stream, one background model (-static), geometric ICP
+(icpWeight = 100) + surfel fusion, precomputed empty masks.  A "step" = one processFrame over one frame whose rgb /
+depth already sit in HBM.  N > 1 (weak scaling): every rank owns one surfel model (the reference's per-model
+independence) and tracks/fuses it against the frame that rank 0 broadcasts over RCCL each step;
+value = model-frames of all ranks / max-over-ranks time.
+
+The JSON line also carries
+  roofline     -- the dominant kernel (the ICP Gauss-Newton iteration): algorithmic bytes per launch / average launch
+                  duration measured here with HIP events on the library's stream, against the 8 TB/s HBM peak;
+  cpu_baseline -- the oracle (CPU restatement, oracle/) timed on this box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H = 640, 480
+FX = FY = 528.0
+CX, CY = 320.0, 240.0
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def gen_frames(n, seed=1234):
+    from maskfusion_amd import synth
+    st = synth.Stream(W=W, H=H, fx=FX, fy=FY, cx=CX, cy=CY, noise=True, seed=seed)
+    return st, [st.frame(k) for k in range(n)]
+
+
+def pingpong(n_frames, steps):
+    """0,1,..,n-1,n-2,..,1,0,1,.. so that consecutive frames always differ by one camera step."""
+    idx, k, d = [], 0, 1
+    for _ in range(steps):
+        idx.append(k)
+        if k + d < 0 or k + d >= n_frames:
+            d = -d
+        k += d
+    return idx
+
+
+def cpu_baseline(frames, max_seconds=20.0):
+    """Oracle (port) frames/s on the host cores, bounded sample."""
+    from oracle import mfo
+    threads = os.cpu_count() or 1
+    o = mfo.Oracle(W, H, FX, FY, CX, CY, icpWeight=100.0, capacity=1 << 20, so3=0)
+    o.process_frame(frames[0][0], frames[0][1])  # init frame, untimed
+    t0 = time.time()
+    n = 0
+    for k in pingpong(len(frames), 1000)[1:]:
+        o.process_frame(frames[k][0], frames[k][1])
+        n += 1
+        if time.time() - t0 > max_seconds or n >= 40:
+            break
+    dt = time.time() - t0
+    o.close()
+    return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{n} frames of the same 640x480 synthetic stream after 1 init frame (OpenMP oracle, {threads} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--frames", type=int, default=24, help="distinct synthetic frames kept in HBM (ping-ponged)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path); cpu_baseline is only a side measurement")
+    dev = torch.device("cuda", local_rank)
+
+    from maskfusion_amd import MaskFusion
+    st, frames = gen_frames(args.frames)
+    d_rgb = [torch.from_numpy(f[0]).to(dev) for f in frames]
+    d_depth = [torch.from_numpy(f[1]).to(dev) for f in frames]
+    mf = MaskFusion(W, H, FX, FY, CX, CY, icpThresh=100.0, so3=False, device=local_rank, enableMultipleModels=False,
+                    numGSurfels=9437184)
+    # per-step inputs: rank 0 owns the stream; with N > 1 it broadcasts rgb+depth (2.15 MB) to the other ranks
+    buf_rgb = torch.empty_like(d_rgb[0])
+    buf_depth = torch.empty_like(d_depth[0])
+    order = pingpong(args.frames, args.warmup + args.steps)
+
+    def step(i):
+        k = order[i]
+        if world > 1:
+            if rank == 0:
+                buf_rgb.copy_(d_rgb[k]); buf_depth.copy_(d_depth[k])
+            dist.broadcast(buf_rgb, 0); dist.broadcast(buf_depth, 0)
+            torch.cuda.current_stream().synchronize()  # the library runs on its own stream
+            mf.processFrameDevice(buf_rgb.data_ptr(), buf_depth.data_ptr())
+            mf.sync()
+        else:
+            mf.processFrameDevice(d_rgb[k].data_ptr(), d_depth[k].data_ptr())
+
+    def barrier():
+        mf.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    fps = world * args.steps / dt
+
+    # sanity: the tracked pose must still follow the synthetic ground truth (a fast wrong answer is worthless)
+    pose = mf.getCurrPose()
+    gt = st.gt_pose(order[args.warmup + args.steps - 1])
+    drift = float(np.linalg.norm(pose[:3, 3] - gt[:3, 3]))
+    count = mf.getBackgroundModel().lastCount()
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        # instrumented pass over the same steps: per-stage HIP events on the library stream
+        mf.enableTimings(True)
+        acc = {}
+        n = min(args.steps, 100)
+        for i in range(args.warmup, args.warmup + n):
+            step(i)
+            for kx, v in mf.timings().items():
+                acc[kx] = acc.get(kx, 0.0) + v
+        mf.enableTimings(False)
+        stages = {kx: v / n for kx, v in acc.items()}
+        P = W * H
+        icp_bytes = 552 * P          # (10 + 5/4 + 4/16) * 48 B * P per model-frame
+        n_launch = 19
+        t_icp = stages["odom"] * 1e-3 / n_launch   # average ICP-iteration launch incl. its share of the solve prologue
+        achieved = icp_bytes / n_launch / t_icp / 1e9
+        roofline = {"bound": "hbm", "kernel": "k_icp_iter (19 launches/frame, L2:4 L1:5 L0:10)",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None, "stage_ms": stages}
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(frames)
+
+    if rank == 0:
+        out = {
+            "metric": "frames/sec (640x480 RGB-D, single background model, ICP + surfel fusion)",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic 640x480 RGB-D stream (S1, Kinect-like noise), 1 background "
+                                   "model per GPU, icpWeight=100 (geometric ICP 4/5/10 iterations) + surfel fusion, "
+                                   "empty masks", "frames_in_hbm": args.frames, "surfels": count,
+                       "pose_drift_vs_gt_m": drift, "parallelism": f"model-per-gpu x{world}"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

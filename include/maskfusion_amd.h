@@ -1,0 +1,146 @@
+/*
+ * maskfusion_amd.h -- C ABI of the MI355X-native MaskFusion hot path (libmaskfusion_amd.so).
+ *
+ * Drop-in boundary for `MaskFusion::processFrame` and the `Model` operations it drives
+ * (reference: martinruenz/maskfusion, Core/MaskFusion.h:45-307, Core/Model/Model.h:108-268).
+ * The reference exposes a C++14 class over Eigen/OpenCV/OpenGL types; this ABI carries the same
+ * operations over plain pointers and sizes.  include/maskfusion/MaskFusion.h is the header-only C++
+ * facade with the reference's class/method names on top of it; INTEGRATION.md shows the binding a
+ * MaskFusion maintainer adds.
+ *
+ * Conventions
+ *   - 4x4 poses: 16 floats, COLUMN-major (memcpy-compatible with Eigen::Matrix4f::data()).
+ *   - rgb: H*W*3 uint8 (FrameData::rgb, CV_8UC3); depth: H*W float32 metres, 0 = invalid
+ *     (FrameData::depth, CV_32FC1); mask: H*W uint8 model ids (FrameData::mask, CV_8UC1) or NULL.
+ *   - surfel record (Model::SurfelMap, Core/Model/Model.h:193-206): 12 floats
+ *     {x,y,z,conf | colour(24-bit int as float),unused,initTime,lastTime | nx,ny,nz,radius}.
+ *   - every function returns 0 on success or a negative MF_E* code; mf_last_error() has the text.
+ *     No exceptions cross the ABI; a context is thread-compatible (one caller at a time), owns one HIP
+ *     stream on one GPU, and holds no process-global state (unlike the reference's Resolution /
+ *     Intrinsics / GPUSetup singletons, Core/Utils/Resolution.h:24-71, Core/Model/Model.h:54-89).
+ *   - "_dev" entry points take DEVICE pointers (HBM-resident inputs); the others take host pointers.
+ *   - The library needs a gfx950 GPU: mf_create() fails with MF_ENODEV otherwise.  There is no CPU path.
+ */
+#ifndef MASKFUSION_AMD_H_
+#define MASKFUSION_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MF_OK 0
+#define MF_EINVAL (-1)  /* bad argument */
+#define MF_ENODEV (-2)  /* no usable GPU / HIP failure at init */
+#define MF_EHIP (-3)    /* HIP runtime error (text in mf_last_error) */
+#define MF_ENOMEM (-4)
+#define MF_ESTATE (-5)  /* call not valid in this state */
+
+typedef struct mf_ctx mf_ctx;
+
+/* Constructor arguments of MaskFusion (Core/MaskFusion.h:47-53) that are live on the hot path, plus what the
+ * reference reads from the Resolution / Intrinsics singletons (GUI/MainController.cpp:117-128) and the
+ * compile-time surfel budgets (Core/CMakeLists.txt:27-28; Core/Model/Model.cpp:101-108). */
+typedef struct mf_config {
+    int32_t width, height;
+    float fx, fy, cx, cy;
+    int32_t device;               /* HIP device ordinal (MASKFUSION_GPU_SLAM) */
+    int32_t time_delta;           /* timeDelta = 200 */
+    float conf_global;            /* initConfidenceGlobal = 4 */
+    float conf_object;            /* initConfidenceObject = 2 */
+    float depth_cutoff;           /* depthCut = 3 */
+    float icp_weight;             /* icpThresh = 10; >= 100 => geometric term only */
+    int32_t fast_odom;            /* fastOdom = 0 */
+    int32_t so3;                  /* so3 = 1 */
+    int32_t pyramid;              /* pyramid = 1 (MaskFusion.cpp:60) */
+    float max_depth_processed;    /* 20 (MaskFusion.cpp:57) */
+    float outlier_coefficient;    /* Model::GPUSetup::outlierCoefficient = 0.9 (Model.h:85) */
+    int32_t num_gsurfels;         /* MASKFUSION_NUM_GSURFELS = 9437184 */
+    int32_t num_osurfels;         /* MASKFUSION_NUM_OSURFELS = 1048576 */
+    int32_t enable_multiple_models; /* setEnableMultipleModels; 0 == "-static" */
+    int32_t reserved[8];
+} mf_config;
+
+/* Fills *cfg with the reference's constructor defaults for a WxH camera. */
+int mf_default_config(mf_config* cfg, int32_t width, int32_t height, float fx, float fy, float cx, float cy);
+
+/* MaskFusion::MaskFusion (Core/MaskFusion.cpp:24-120) */
+int mf_create(const mf_config* cfg, mf_ctx** out);
+/* MaskFusion::~MaskFusion (Core/MaskFusion.cpp:122-142) */
+void mf_destroy(mf_ctx* ctx);
+const char* mf_last_error(const mf_ctx* ctx);
+
+/* MaskFusion::processFrame (Core/MaskFusion.h:69-70, Core/MaskFusion.cpp:200-607).
+ * mask/class_ids may be NULL (n_masks = 0); in_pose16 may be NULL.  Blocks until the frame is fused. */
+int mf_process_frame(mf_ctx* ctx, const uint8_t* rgb, const float* depth, const uint8_t* mask,
+                     const int32_t* class_ids, int32_t n_masks, int64_t timestamp, const float* in_pose16,
+                     float weight_multiplier, int32_t bootstrap);
+/* Same, inputs already resident in HBM (device pointers); enqueues the whole frame on the context's stream and
+ * returns without waiting.  mf_sync() (or any getter) waits. */
+int mf_process_frame_dev(mf_ctx* ctx, const uint8_t* d_rgb, const float* d_depth, const uint8_t* d_mask,
+                         int64_t timestamp, float weight_multiplier);
+int mf_sync(mf_ctx* ctx);
+
+/* MaskFusion::predict (Core/MaskFusion.h:76) */
+int mf_predict(mf_ctx* ctx);
+
+/* MaskFusion::getTick / getModels().size() / Model::getPose / lastCount / getConfidenceThreshold
+ * (Core/MaskFusion.h:88-90,194; Core/Model/Model.h:180,233) */
+int mf_get_tick(mf_ctx* ctx, int32_t* tick);
+int mf_num_models(mf_ctx* ctx, int32_t* n);
+int mf_get_pose(mf_ctx* ctx, int32_t model, float* out_pose16);
+int mf_get_surfel_count(mf_ctx* ctx, int32_t model, uint32_t* count);
+/* RGBDOdometry::lastICPError / lastICPCount (Core/Utils/RGBDOdometry.h) of `model` */
+int mf_get_icp_stats(mf_ctx* ctx, int32_t model, float* last_error, float* last_count);
+/* Model::downloadMap (Core/Model/Model.h:206, Model.cpp:943-974): out has room for max_count*12 floats */
+int mf_download_map(mf_ctx* ctx, int32_t model, float* out, uint32_t max_count, uint32_t* count);
+/* whether the last tracking step used the fill-in maps (MaskFusion::requiresFillIn, MaskFusion.cpp:630-648) */
+int mf_get_last_fillin(mf_ctx* ctx, int32_t* used);
+
+/* The per-frame setters of MaskFusion (Core/MaskFusion.h:132-182,234-263).  Keys: "depthCutoff", "icpWeight",
+ * "confidenceThreshold" (background), "outlierCoefficient", "fastOdom", "so3", "pyramid", "timeDelta",
+ * "maxDepthProcessed". */
+int mf_set_param(mf_ctx* ctx, const char* key, double value);
+int mf_get_param(mf_ctx* ctx, const char* key, double* value);
+
+/* Stage timings in the reference's Stopwatch label set (Core/Utils/Stopwatch.h:46-121): GPU milliseconds of the
+ * last frame measured with HIP events when enabled by mf_set_param("timings", 1).
+ * labels: 0 Preprocess, 1 odomInit, 2 odom, 3 indexMap, 4 Fuse::Data, 5 Fuse::Update, 6 Fuse::Copy,
+ *         7 IndexMap::ACTIVE, 8 Run */
+#define MF_N_TIMINGS 9
+int mf_get_timings(mf_ctx* ctx, float* ms /* [MF_N_TIMINGS] */);
+/* The context's HIP stream (hipStream_t), for callers that time with their own events. */
+void* mf_get_stream(mf_ctx* ctx);
+
+/* debug / differential-test taps: copy a device-resident intermediate of the last frame to host.
+ * what: "depthF" (H*W f32), "vmap0".."vmap2", "nmap0".."nmap2" (3*h*w f32, current frame),
+ *       "vmap_g0".."vmap_g2", "nmap_g0".."nmap_g2" (model side), "pred_vertex", "pred_normal" (H*W*4 f32),
+ *       "pred_image" (H*W*4 u8), "index" (H*W i32), "icp_log" (19*32 f32: per-iteration A-upper/b/res/inl). */
+int mf_debug_read(mf_ctx* ctx, const char* what, void* out, uint64_t out_bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * Kernel-level entry points (device pointers, launched on `stream`, asynchronous).  Each replaces one reference
+ * CUDA wrapper or GLSL pass; the parity tests call them one by one against oracle/.
+ * ---------------------------------------------------------------------------------------------- */
+/* MaskFusion::filterDepth + depth_bilateral_metric.frag (Core/MaskFusion.cpp:650-657) */
+int mf_k_bilateral(const float* d_depth, float* d_out, int32_t W, int32_t H, void* stream);
+/* pyrDownGaussF (Core/Cuda/cudafuncs.cu:510-532) */
+int mf_k_pyrdown_f(const float* d_src, float* d_dst, int32_t sw, int32_t sh, void* stream);
+/* createVMap + createNMap (Core/Cuda/cudafuncs.cu:136-150,191-205), one level; planar [3][H][W] outputs */
+int mf_k_vmap_nmap(const float* d_depth, float* d_vmap, float* d_nmap, int32_t W, int32_t H, float fx, float fy,
+                   float cx, float cy, float depth_cutoff, void* stream);
+/* RGBDOdometry::initICPModel (Core/Utils/RGBDOdometry.cpp:153-185): copyMaps + resizeVMap/NMap x2 + tranformMaps x3.
+ * d_v4/d_n4: H*W float4 predictions; outputs: 3 levels planar, packed level after level; R row-major 3x3 */
+int mf_k_model_pyramid(const float* d_v4, const float* d_n4, const float* R9, const float* t3, float* d_vmaps,
+                       float* d_nmaps, int32_t W, int32_t H, void* stream);
+/* icpStep (Core/Cuda/reduce.cu:446-525): d_out32 receives {27 upper-tri products, sum r^2, inliers, pad} */
+int mf_k_icp_step(const float* Rcurr9, const float* tcurr3, const float* d_vmap_curr, const float* d_nmap_curr,
+                  const float* Rprev_inv9, const float* tprev3, float fx, float fy, float cx, float cy,
+                  const float* d_vmap_g_prev, const float* d_nmap_g_prev, float dist_thresh, float angle_thresh,
+                  int32_t W, int32_t H, float* d_out32, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MASKFUSION_AMD_H_ */

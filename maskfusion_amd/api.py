@@ -1,0 +1,183 @@
+"""Host-side mirror of the reference's MaskFusion / Model interface for the hot path.
+
+Names and argument meaning follow Core/MaskFusion.h:45-307 and Core/Model/Model.h:108-268 of
+martinruenz/maskfusion, over the C ABI in include/maskfusion_amd.h.  numpy arrays stand in for cv::Mat /
+Eigen::Matrix4f.  Errors raise MFError (the reference throws std::runtime_error / exits on CUDA errors).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import numpy as np
+
+from .lib import load, MFError, Config, MF_N_TIMINGS, TIMING_LABELS
+
+
+class Model:
+    """View of one surfel model (Core/Model/Model.h)."""
+
+    def __init__(self, owner: "MaskFusion", index: int):
+        self._o = owner
+        self._i = index
+
+    def getID(self) -> int:
+        return self._i
+
+    def getPose(self) -> np.ndarray:
+        out = np.zeros(16, np.float32)
+        self._o._chk(self._o._L.mf_get_pose(self._o._h, self._i, out.ctypes.data))
+        return out.reshape(4, 4).T.astype(np.float64)
+
+    def lastCount(self) -> int:
+        n = C.c_uint32(0)
+        self._o._chk(self._o._L.mf_get_surfel_count(self._o._h, self._i, C.byref(n)))
+        return int(n.value)
+
+    def downloadMap(self) -> np.ndarray:
+        """Model::downloadMap -> (count, 12) float32: pos+conf | colour,unused,initTime,lastTime | normal+radius."""
+        n = self.lastCount()
+        out = np.zeros((max(n, 1), 12), np.float32)
+        cnt = C.c_uint32(0)
+        self._o._chk(self._o._L.mf_download_map(self._o._h, self._i, out.ctypes.data, n, C.byref(cnt)))
+        return out[:n]
+
+    def getICPStats(self):
+        e, c = C.c_float(0), C.c_float(0)
+        self._o._chk(self._o._L.mf_get_icp_stats(self._o._h, self._i, C.byref(e), C.byref(c)))
+        return e.value, c.value
+
+
+class MaskFusion:
+    """MaskFusion facade (constructor arguments: Core/MaskFusion.h:47-53; Resolution/Intrinsics are explicit)."""
+
+    def __init__(self, width=640, height=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, *, timeDelta=200,
+                 initConfidenceGlobal=4.0, initConfidenceObject=2.0, depthCut=3.0, icpThresh=10.0, fastOdom=False,
+                 so3=True, device=0, numGSurfels=9437184, numOSurfels=1048576, enableMultipleModels=True,
+                 outlierCoefficient=0.9):
+        self._L = load()
+        cfg = Config()
+        self._L.mf_default_config(C.byref(cfg), width, height, fx, fy, cx, cy)
+        cfg.device = device
+        cfg.time_delta = timeDelta
+        cfg.conf_global = initConfidenceGlobal
+        cfg.conf_object = initConfidenceObject
+        cfg.depth_cutoff = depthCut
+        cfg.icp_weight = icpThresh
+        cfg.fast_odom = int(fastOdom)
+        cfg.so3 = int(so3)
+        cfg.num_gsurfels = numGSurfels
+        cfg.num_osurfels = numOSurfels
+        cfg.enable_multiple_models = int(enableMultipleModels)
+        cfg.outlier_coefficient = outlierCoefficient
+        self.cfg = cfg
+        self.width, self.height = width, height
+        h = C.c_void_p()
+        rc = self._L.mf_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise MFError(f"mf_create failed with code {rc} (needs a gfx950 GPU; there is no CPU path)")
+        self._h = h
+
+    # -- lifetime -----------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self._L.mf_last_error(self._h)
+            raise MFError(f"code {rc}: {msg.decode() if msg else ''}")
+
+    # -- MaskFusion::processFrame ---------------------------------------------------------------
+    def processFrame(self, rgb: np.ndarray, depth: np.ndarray, mask: np.ndarray | None = None, timestamp: int = 0,
+                     inPose=None, weightMultiplier: float = 1.0, bootstrap: bool = False) -> bool:
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        depth = np.ascontiguousarray(depth, np.float32)
+        assert rgb.shape == (self.height, self.width, 3) and depth.shape == (self.height, self.width)
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, np.uint8)
+        pose = None
+        if inPose is not None:
+            pose = np.ascontiguousarray(np.asarray(inPose, np.float32).T.reshape(16))
+        self._chk(self._L.mf_process_frame(self._h, rgb.ctypes.data, depth.ctypes.data,
+                                           m.ctypes.data if m is not None else None, None, 0, timestamp,
+                                           pose.ctypes.data if pose is not None else None, weightMultiplier,
+                                           int(bootstrap)))
+        return False  # the reference always returns false (MaskFusion.cpp:606)
+
+    def processFrameDevice(self, d_rgb: int, d_depth: int, d_mask: int = 0, timestamp: int = 0,
+                           weightMultiplier: float = 1.0):
+        """Inputs already resident in HBM (raw device pointers, e.g. torch tensor.data_ptr()); asynchronous."""
+        self._chk(self._L.mf_process_frame_dev(self._h, d_rgb, d_depth, d_mask or None, timestamp, weightMultiplier))
+
+    def sync(self):
+        self._chk(self._L.mf_sync(self._h))
+
+    def predict(self):
+        self._chk(self._L.mf_predict(self._h))
+
+    # -- getters ----------------------------------------------------------------------------------
+    def getTick(self) -> int:
+        t = C.c_int32(0)
+        self._chk(self._L.mf_get_tick(self._h, C.byref(t)))
+        return t.value
+
+    def getBackgroundModel(self) -> Model:
+        return Model(self, 0)
+
+    def getModels(self):
+        n = C.c_int32(0)
+        self._chk(self._L.mf_num_models(self._h, C.byref(n)))
+        return [Model(self, i) for i in range(n.value)]
+
+    def getCurrPose(self) -> np.ndarray:
+        return self.getBackgroundModel().getPose()
+
+    def getLastFillIn(self) -> bool:
+        u = C.c_int32(0)
+        self._chk(self._L.mf_get_last_fillin(self._h, C.byref(u)))
+        return bool(u.value)
+
+    # -- setters (MaskFusion.h:132-182) --------------------------------------------------------------
+    def setParam(self, key: str, value: float):
+        self._chk(self._L.mf_set_param(self._h, key.encode(), float(value)))
+
+    def setDepthCutoff(self, v): self.setParam("depthCutoff", v)
+    def setIcpWeight(self, v): self.setParam("icpWeight", v)
+    def setConfidenceThreshold(self, v): self.setParam("confidenceThreshold", v)
+    def setOutlierCoefficient(self, v): self.setParam("outlierCoefficient", v)
+    def setFastOdom(self, v): self.setParam("fastOdom", int(v))
+    def setSo3(self, v): self.setParam("so3", int(v))
+    def setPyramid(self, v): self.setParam("pyramid", int(v))
+    def setEnableMultipleModels(self, v): self.setParam("enableMultipleModels", int(v))
+
+    def enableTimings(self, on=True):
+        self.setParam("timings", 1 if on else 0)
+
+    def timings(self) -> dict:
+        t = np.zeros(MF_N_TIMINGS, np.float32)
+        self._chk(self._L.mf_get_timings(self._h, t.ctypes.data))
+        return dict(zip(TIMING_LABELS, t.tolist()))
+
+    def stream(self) -> int:
+        return int(self._L.mf_get_stream(self._h) or 0)
+
+    # -- differential-test taps ----------------------------------------------------------------------
+    def debugRead(self, what: str) -> np.ndarray:
+        W, H = self.width, self.height
+        shapes = {"depthF": ((H, W), np.float32), "pred_vertex": ((H, W, 4), np.float32),
+                  "pred_normal": ((H, W, 4), np.float32), "pred_image": ((H, W, 4), np.uint8),
+                  "index": ((H, W), np.int32), "index_vc": ((H, W, 4), np.float32), "icp_log": ((19, 32), np.float32)}
+        for pre in ("vmap_g", "nmap_g", "vmap", "nmap"):
+            for i in range(3):
+                shapes[f"{pre}{i}"] = ((3, H >> i, W >> i), np.float32)
+        shape, dt = shapes[what]
+        out = np.zeros(shape, dt)
+        self._chk(self._L.mf_debug_read(self._h, what.encode(), out.ctypes.data, out.nbytes))
+        return out

@@ -1,0 +1,101 @@
+// mf_device.h -- device-side helpers (gfx950, wave64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include "mf_internal.h"
+
+namespace mf {
+
+__device__ __forceinline__ float qnan() { return __int_as_float(0x7fffffff); }
+
+__device__ __forceinline__ float3 f3(float x, float y, float z) { return make_float3(x, y, z); }
+__device__ __forceinline__ float3 operator-(float3 a, float3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ float3 operator+(float3 a, float3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ float3 operator*(float3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float3 cross3(float3 a, float3 b) {
+    return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float dot3(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float norm3(float3 a) { return sqrtf(dot3(a, a)); }
+// CUDA-side normalized(): a * rsqrt(dot) (Core/Cuda/operators.cuh:80-84)
+__device__ __forceinline__ float3 normalized_rsqrt(float3 a) { return a * rsqrtf(dot3(a, a)); }
+// GLSL normalize(): a / length(a)
+__device__ __forceinline__ float3 normalize_gl(float3 a) {
+    const float l = sqrtf(dot3(a, a));
+    return f3(a.x / l, a.y / l, a.z / l);
+}
+__device__ __forceinline__ float3 mul33(const float* R, float3 a) {  // row-major
+    return f3(R[0] * a.x + R[1] * a.y + R[2] * a.z, R[3] * a.x + R[4] * a.y + R[5] * a.z,
+              R[6] * a.x + R[7] * a.y + R[8] * a.z);
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// 64-lane sum; result valid in lane 0 (and, with the xor form, in every lane)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// rank of this lane among the set lanes of a ballot (wave64)
+__device__ __forceinline__ int lane_rank(unsigned long long mask) {
+    const int lo = __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0);
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), lo);
+}
+
+// ---- surfel / shader helpers (Core/Shaders/surfels.glsl, color_encoding.glsl, geometry.glsl) ----
+__device__ __forceinline__ float surfel_radius(float depth, float norm_z, Intr k) {  // surfels.glsl:19-34
+    const float camz = 1.0f / k.fx, camw = 1.0f / k.fy;
+    const float meanFocal = ((1.0f / fabsf(camz)) + (1.0f / fabsf(camw))) / 2.0f;
+    const float radius = (depth / meanFocal) * 1.41421356237f;
+    return fminf(2.0f * radius, radius / fabsf(norm_z));
+}
+__device__ __forceinline__ float surfel_confidence(float x, float y, float weighting, Intr k) {  // surfels.glsl:36-46
+    const float dx = x - k.cx, dy = y - k.cy;
+    const float radialDist = sqrtf(dx * dx + dy * dy) / 400.f;
+    return expf(-(radialDist * radialDist) / 0.72f) * weighting;
+}
+__device__ __forceinline__ float encode_color(float r, float g, float b) {  // color_encoding.glsl:19-25
+    int rgb = (int)roundf(r * 255.0f);
+    rgb = (rgb << 8) + (int)roundf(g * 255.0f);
+    rgb = (rgb << 8) + (int)roundf(b * 255.0f);
+    return (float)rgb;
+}
+__device__ __forceinline__ float3 decode_color(float c) {  // color_encoding.glsl:27-34
+    const int ci = (int)c;
+    return f3((float)((ci >> 16) & 0xFF) / 255.0f, (float)((ci >> 8) & 0xFF) / 255.0f, (float)(ci & 0xFF) / 255.0f);
+}
+// nearest fetch, GL_CLAMP_TO_EDGE
+__device__ __forceinline__ float texf(const float* img, int W, int H, int x, int y) {
+    return img[clampi(y, 0, H - 1) * W + clampi(x, 0, W - 1)];
+}
+// geometry.glsl:21-26; cam = (cx, cy, 1/fx, 1/fy)
+__device__ __forceinline__ float3 get_vertex(const float* depth, int W, int H, int px, int py, float x, float y, Intr k) {
+    const float z = texf(depth, W, H, px, py);
+    return f3((x - k.cx) * z * (1.0f / k.fx), (y - k.cy) * z * (1.0f / k.fy), z);
+}
+// geometry.glsl:28-40 (central differences)
+__device__ __forceinline__ float3 get_normal_central(const float* depth, int W, int H, int px, int py, float x, float y,
+                                                     float3 vPos, Intr k) {
+    const float3 xf = get_vertex(depth, W, H, px + 1, py, x + 1, y, k);
+    const float3 xb = get_vertex(depth, W, H, px - 1, py, x - 1, y, k);
+    const float3 yf = get_vertex(depth, W, H, px, py + 1, x, y + 1, k);
+    const float3 yb = get_vertex(depth, W, H, px, py - 1, x, y - 1, k);
+    const float3 del_x = ((xb + vPos) * 0.5f) - ((xf + vPos) * 0.5f);
+    const float3 del_y = ((yb + vPos) * 0.5f) - ((yf + vPos) * 0.5f);
+    return normalize_gl(cross3(del_x, del_y));
+}
+// geometry.glsl:42-62 (forward differences, integer pixel coordinates)
+__device__ __forceinline__ float3 get_normal_forward(const float* depth, int W, int H, int px, int py, float3 vPos, Intr k) {
+    const float3 vx = get_vertex(depth, W, H, px + 1, py, (float)(px + 1), (float)py, k);
+    const float3 vy = get_vertex(depth, W, H, px, py + 1, (float)px, (float)(py + 1), k);
+    return normalize_gl(cross3(vx - vPos, vy - vPos));
+}
+
+}  // namespace mf

@@ -1,0 +1,124 @@
+// mf_internal.h -- shared declarations of the HIP hot path (gfx950 only; no CPU fallback, no CUDA shims).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mf {
+
+constexpr int kLevels = 3;            // RGBDOdometry::NUM_PYRS (Core/Utils/RGBDOdometry.h:81)
+constexpr int kIcpSlots = 32;         // 29 accumulators padded to 32 floats (128 B)
+constexpr int kMaxIcpBlocks = 320;    // upper bound of ICP grid (VGA L0 = 300 blocks of 256 threads x 4 px)
+constexpr int kCompactBlocks = 1024;  // fixed grid of the ordered-compaction passes
+constexpr unsigned long long kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
+constexpr int kNoUpdate = 0x7FFFFFFF;
+
+struct Intr {
+    float fx, fy, cx, cy;
+};
+
+// Device-resident pose block of one model.  Written by kernels only (the Gauss-Newton loop never returns to the
+// host); mirrored to pinned host memory at the end of a frame.
+struct PoseDev {
+    float R[9], t[3];          // model pose (camera -> model frame), row-major
+    float Ri[9], ti[3];        // inverse (t_inv uniform of the reference shaders)
+    float lastR[9], lastT[3];  // Model::lastPose
+    float fusionWeight;        // Model::computeFusionWeight(1.0)
+    float lastICPError, lastICPCount;
+    float pad[3];
+};
+
+// Gauss-Newton state carried from one ICP launch to the next (double-buffered: launch k reads [k-1], block 0 writes [k]).
+struct GNState {
+    double resultRt[16];       // row-major, RGBDOdometry.cpp:336
+    float Rprev[9], tprev[3], Rprev_inv[9];
+    float Rcurr[9], tcurr[3];
+    float lastICPError, lastICPCount;
+    float trR[9], trt[3];      // Isometry3f transform (increment)
+    int valid;
+    int pad;
+};
+
+// Scalars that live on the device so that no kernel launch needs a host round trip.
+struct FrameDev {
+    int tick;                  // MaskFusion::tick
+    int count;                 // Model::count (live surfels)
+    int countNext;             // count produced by the clean pass, committed at the launch boundary
+    int cover;                 // predicted-colour coverage count (requiresFillIn)
+    int useFillIn;             // decision taken for the current tracking step
+    int pad[3];
+};
+
+struct Surfels {               // SoA of float4, 48 B per surfel in three coalesced streams
+    float4* pc;                // position + confidence
+    float4* ct;                // colour, unused, initTime, lastTime
+    float4* nr;                // normal + radius
+    int cap;                   // capacity in surfels (writes beyond it are dropped, like a full transform-feedback buffer)
+};
+
+// ---------------- preprocessing ----------------
+void launch_bilateral(const float* depth, float* out, int W, int H, hipStream_t s);
+void launch_pyrdown_f(const float* src, float* dst, int sw, int sh, hipStream_t s);
+void launch_vmap_nmap(const float* depth, float* vmap, float* nmap, int W, int H, Intr k, float cutoff, hipStream_t s);
+
+// ---------------- odometry ----------------
+// Fused RGBDOdometry::initICPModel.  pose: device PoseDev (R,t used).  fill-in inputs may be null (no fill-in).
+void launch_model_pyramid(const float4* predV, const float4* predN, const float* fillDepth, const FrameDev* frame,
+                          const PoseDev* pose, const float* R9t3_host_or_null, float* const vmaps[3],
+                          float* const nmaps[3], int W, int H, Intr k, hipStream_t s);
+// One Gauss-Newton iteration: [reduce+solve of the previous launch] -> normal equations of this level.
+struct IcpLaunch {
+    const float* vmap_curr; const float* nmap_curr; const float* vmap_prev; const float* nmap_prev;
+    int W, H; Intr k;
+    float distThres, angleThres;
+    const float* partials_in; int nblocks_in;   // previous launch (nullptr/0 for the first)
+    float* partials_out;
+    const GNState* state_in; GNState* state_out;
+    float* log_out;                              // optional [32] floats of the reduced system solved in this launch
+};
+int icp_grid_blocks(int W, int H);
+void launch_icp_iteration(const IcpLaunch& a, hipStream_t s);
+// Seeds GNState from the model pose (Rprev = Rcurr = pose; resultRt = I).
+void launch_icp_begin(const PoseDev* pose, GNState* st, hipStream_t s);
+// Last reduce+solve, then pose / lastPose / inverse / fusion weight update and host mirror.
+void launch_icp_finalize(const float* partials_in, int nblocks_in, const GNState* state_in, PoseDev* pose,
+                         PoseDev* host_mirror, float* log_out, hipStream_t s);
+// Stand-alone icpStep (parity tests): host-provided poses, output 32 floats.
+void launch_icp_step_standalone(const float* Rcurr, const float* tcurr, const float* vc, const float* nc,
+                                const float* Rpi, const float* tprev, Intr k, const float* vp, const float* np,
+                                float distThres, float angleThres, int W, int H, float* partials, GNState* st2,
+                                float* out32, hipStream_t s);
+
+// ---------------- surfels ----------------
+void launch_init_surfels(const uint8_t* rgb, const float* depthRaw, const float* depthF, int W, int H, Intr k,
+                         float maxDepth, const FrameDev* frame, float4* rec /*[P][3]*/, uint8_t* flags, hipStream_t s);
+void launch_index_scatter(Surfels src, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k,
+                          float maxDepth, int timeDelta, unsigned long long* keys, hipStream_t s);
+void launch_index_resolve(Surfels src, const PoseDev* pose, unsigned long long* keys, int W, int H, int* index,
+                          float4* vc, float4* ct, float4* nr, hipStream_t s);
+void launch_fuse_data(const uint8_t* rgb, const float* depthRaw, const float* depthF, const uint8_t* mask,
+                      int maskID, const FrameDev* frame, const PoseDev* pose, float weightMultiplier, float maxDepth,
+                      int W, int H, Intr k, const int* index, const float4* vc, const float4* nr, uint8_t* cand_op,
+                      float4* cand_rec, int* upd_first, hipStream_t s);
+void launch_fuse_update(Surfels src, Surfels dst, const FrameDev* frame, int* upd_first, const float4* cand_rec,
+                        hipStream_t s);
+void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k,
+                  int timeDelta, float confThreshold, float outlierCoeff, int maskID, const int* index,
+                  const float4* vc, const float4* ct, const float* depthF, const uint8_t* mask,
+                  const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags, float* newconf, int* block_counts,
+                  int* host_count_mirror, hipStream_t s);
+// generic ordered compaction of [n_dev] records (3 x float4 each, record-major) -> surfels, sets frame->count
+void launch_compact_records(const float4* rec, const uint8_t* flags, int n, Surfels dst, FrameDev* frame,
+                            int* block_counts, int* host_count_mirror, hipStream_t s);
+void launch_splat_scatter(Surfels src, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k,
+                          float maxDepth, float confThreshold, int timeDelta, unsigned long long* keys,
+                          hipStream_t s);
+void launch_splat_resolve(Surfels src, const PoseDev* pose, unsigned long long* keys, int W, int H, Intr k,
+                          float4* predV, float4* predN, uchar4* predImage, uint16_t* predTime, FrameDev* frame,
+                          hipStream_t s);
+void launch_fill_keys(unsigned long long* keys, int n, hipStream_t s);
+void launch_fill_int(int* p, int v, int n, hipStream_t s);
+// end-of-frame bookkeeping: tick++, cover -> useFillIn decision for the next frame
+void launch_frame_advance(FrameDev* frame, int W, int H, FrameDev* host_mirror, hipStream_t s);
+
+}  // namespace mf

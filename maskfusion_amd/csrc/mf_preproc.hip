@@ -1,0 +1,141 @@
+// mf_preproc.hip -- per-frame image preprocessing on plain HBM arrays.
+//   bilateral depth filter   <- MaskFusion::filterDepth + depth_bilateral_metric.frag (Core/MaskFusion.cpp:650-657)
+//   depth pyramid            <- pyrDownGaussF (Core/Cuda/cudafuncs.cu:333-364, 510-532)
+//   vertex + normal maps     <- createVMap + createNMap (Core/Cuda/cudafuncs.cu:109-205), fused into one pass
+#include "mf_device.h"
+
+namespace mf {
+
+// ------------------------------------------------------------------------------------------------
+// 13x13 bilateral.  One 256-thread workgroup (4 wavefronts, 64 lanes along x) filters a 64x16 tile staged
+// through LDS with a 6-pixel halo: HBM traffic is 4 B in + 4 B out per pixel, the 169 taps come from LDS
+// (row-contiguous ds_read_b32, conflict free).
+// ------------------------------------------------------------------------------------------------
+constexpr int kBR = 6;
+constexpr int kBTileW = 64, kBTileH = 16;
+constexpr int kBLdsW = kBTileW + 2 * kBR;  // 76
+constexpr int kBLdsH = kBTileH + 2 * kBR;  // 28
+
+__global__ __launch_bounds__(256) void k_bilateral(const float* __restrict__ depth, float* __restrict__ out, int W, int H) {
+    __shared__ float tile[kBLdsH * kBLdsW];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int x0 = blockIdx.x * kBTileW, y0 = blockIdx.y * kBTileH;
+    // stage (out-of-image taps get a negative sentinel and are skipped, like the clipped loops of the shader)
+    for (int i = threadIdx.x; i < kBLdsH * kBLdsW; i += 256) {
+        const int ly = i / kBLdsW, lx = i - ly * kBLdsW;
+        const int gx = x0 + lx - kBR, gy = y0 + ly - kBR;
+        tile[i] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? depth[gy * W + gx] : -1.0f;
+    }
+    __syncthreads();
+    const float sigma_space2_inv_half = 0.024691358f;
+    const float sigma_color2_inv_half = 555.556f;
+#pragma unroll 1
+    for (int r = 0; r < kBTileH / 4; ++r) {
+        const int ly = ty + r * 4;
+        const int gx = x0 + tx, gy = y0 + ly;
+        if (gx >= W || gy >= H) continue;
+        const float value = tile[(ly + kBR) * kBLdsW + tx + kBR];
+        float res = 0.f;
+        if (value > 0.03f) {
+            float sum1 = 0.f, sum2 = 0.f;
+            for (int dy = -kBR; dy <= kBR; ++dy) {
+                const float* row = &tile[(ly + kBR + dy) * kBLdsW + tx + kBR];
+                const float fy2 = (float)(dy * dy);
+#pragma unroll
+                for (int dx = -kBR; dx <= kBR; ++dx) {
+                    const float tmp = row[dx];
+                    if (tmp >= 0.f) {
+                        const float space2 = (float)(dx * dx) + fy2;
+                        const float color2 = (value - tmp) * (value - tmp);
+                        const float weight = __expf(-(space2 * sigma_space2_inv_half + color2 * sigma_color2_inv_half));
+                        sum1 += tmp * weight;
+                        sum2 += weight;
+                    }
+                }
+            }
+            res = sum1 / sum2;
+        }
+        out[gy * W + gx] = res;
+    }
+}
+
+void launch_bilateral(const float* depth, float* out, int W, int H, hipStream_t s) {
+    dim3 grid((W + kBTileW - 1) / kBTileW, (H + kBTileH - 1) / kBTileH);
+    hipLaunchKernelGGL(k_bilateral, grid, dim3(256), 0, s, depth, out, W, H);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 5x5 Gaussian half-sampling that skips NaNs, with the reference's border quirk: the upper loop
+// bounds clamp to cols-1 / rows-1 exclusive and the kernel is indexed from the far corner.
+// ------------------------------------------------------------------------------------------------
+__constant__ float c_gauss5[25] = {1, 4, 6, 4, 1, 4, 16, 24, 16, 4, 6, 24, 36, 24, 6, 4, 16, 24, 16, 4, 1, 4, 6, 4, 1};
+
+__global__ __launch_bounds__(256) void k_pyrdown_f(const float* __restrict__ src, float* __restrict__ dst, int sw, int sh) {
+    const int dw = sw >> 1, dh = sh >> 1;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    const int tx = min(2 * x + 3, sw - 1);
+    const int ty = min(2 * y + 3, sh - 1);
+    float sum = 0.f;
+    int count = 0;
+    for (int cy = max(0, 2 * y - 2); cy < ty; ++cy) {
+        for (int cx = max(0, 2 * x - 2); cx < tx; ++cx) {
+            const float v = src[cy * sw + cx];
+            if (!isnan(v)) {
+                const float w = c_gauss5[(ty - cy - 1) * 5 + (tx - cx - 1)];
+                sum += v * w;
+                count += (int)w;
+            }
+        }
+    }
+    dst[y * dw + x] = sum / (float)count;
+}
+
+void launch_pyrdown_f(const float* src, float* dst, int sw, int sh, hipStream_t s) {
+    const int dw = sw / 2, dh = sh / 2;
+    dim3 grid((dw + 63) / 64, (dh + 3) / 4);
+    hipLaunchKernelGGL(k_pyrdown_f, grid, dim3(256), 0, s, src, dst, sw, sh);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Vertex map and normal map of one level in one pass: the three vertices a normal needs are recomputed from
+// depth (bitwise the values createVMap stores), so the normal never waits for a vertex-map round trip.
+// Planar SoA [3][H][W] outputs keep the ICP loads of 64 consecutive lanes on one 256 B line per plane.
+// Invalid pixels get NaN in all three planes (the reference writes x = NaN only; consumers test x only).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool vertex_from_depth(float z, int u, int v, Intr k, float fx_inv, float fy_inv, float cutoff,
+                                                  float3& out) {
+    if (z > 0.0f && z < cutoff) {
+        out = f3(z * ((float)u - k.cx) * fx_inv, z * ((float)v - k.cy) * fy_inv, z);
+        return true;
+    }
+    out = f3(qnan(), qnan(), qnan());
+    return false;
+}
+
+__global__ __launch_bounds__(256) void k_vmap_nmap(const float* __restrict__ depth, float* __restrict__ vmap,
+                                                   float* __restrict__ nmap, int W, int H, Intr k, float cutoff) {
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int v = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u >= W || v >= H) return;
+    const int P = W * H, i = v * W + u;
+    const float fx_inv = 1.f / k.fx, fy_inv = 1.f / k.fy;
+    float3 v00, v01, v10;
+    const bool ok00 = vertex_from_depth(depth[i], u, v, k, fx_inv, fy_inv, cutoff, v00);
+    vmap[i] = v00.x; vmap[P + i] = v00.y; vmap[2 * P + i] = v00.z;
+    float3 n = f3(qnan(), qnan(), qnan());
+    if (u < W - 1 && v < H - 1) {
+        const bool ok01 = vertex_from_depth(depth[i + 1], u + 1, v, k, fx_inv, fy_inv, cutoff, v01);
+        const bool ok10 = vertex_from_depth(depth[i + W], u, v + 1, k, fx_inv, fy_inv, cutoff, v10);
+        if (ok00 && ok01 && ok10) n = normalized_rsqrt(cross3(v01 - v00, v10 - v00));
+    }
+    nmap[i] = n.x; nmap[P + i] = n.y; nmap[2 * P + i] = n.z;
+}
+
+void launch_vmap_nmap(const float* depth, float* vmap, float* nmap, int W, int H, Intr k, float cutoff, hipStream_t s) {
+    dim3 grid((W + 63) / 64, (H + 3) / 4);
+    hipLaunchKernelGGL(k_vmap_nmap, grid, dim3(256), 0, s, depth, vmap, nmap, W, H, k, cutoff);
+}
+
+}  // namespace mf

@@ -1,0 +1,608 @@
+// mf_surfel.hip -- surfel map maintenance on plain HBM arrays (no OpenGL, no transform feedback, no textures).
+//
+// Replaces (reference, relative to /root/reference):
+//   first-frame init         Core/Shaders/vertex_feedback.vert/.geom, init_unstable.vert; Core/Model/Model.cpp:240-285
+//   index map                Core/Shaders/index_map.vert/.frag; Core/Model/ModelProjection.cpp:100-152
+//   data association         Core/Shaders/data.vert/.geom/.frag; Core/Model/Model.cpp:466-581
+//   surfel update            Core/Shaders/update.vert; Core/Model/Model.cpp:583-646
+//   clean / append / decay   Core/Shaders/copy_unstable.vert:53-157, .geom; Core/Model/Model.cpp:649-772
+//   splat prediction         Core/Shaders/splat.vert, combo_splat.frag; Core/Model/ModelProjection.cpp:187-268
+//
+// Design (MI355X):
+//   * surfels are three float4 streams (48 B/surfel, 16 B per lane per stream, fully coalesced), double buffered;
+//   * the GL rasteriser + z-buffer becomes a 64-bit atomicMin on (z bits << 32 | surfel index) per pixel followed by
+//     a per-pixel resolve that recomputes the attributes of the winner (ties go to the lower index = GL order);
+//   * the 453 MB "update map" the reference clears and scatters into every frame becomes one int per surfel that
+//     receives atomicMin(column-major candidate index) -- "first writer wins" without ordering the writers;
+//   * transform feedback (ordered stream compaction) becomes a fixed-grid two-pass compaction: pass 1 writes keep
+//     flags + per-workgroup counts, pass 2 sums the counts of the workgroups before it in its prologue and copies
+//     survivors in order with wavefront ballots.  Surfel order is therefore exactly the reference's (old surfels
+//     first, then new ones in column-major pixel order), and no workgroup ever spins on another.
+//   * every per-surfel grid is fixed-size and bounded by a device-resident count: no host round trip per pass.
+#include "mf_device.h"
+
+namespace mf {
+
+// ------------------------------------------------------------------------------------------------
+// fills
+// ------------------------------------------------------------------------------------------------
+__global__ void k_fill_keys(unsigned long long* keys, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) keys[i] = kEmptyKey;
+}
+void launch_fill_keys(unsigned long long* keys, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_fill_keys, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, keys, n);
+}
+__global__ void k_fill_int(int* p, int v, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
+}
+void launch_fill_int(int* p, int v, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_fill_int, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, p, v, n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ordered compaction machinery (fixed grid of kCompactBlocks workgroups x 256 threads)
+// ------------------------------------------------------------------------------------------------
+// number of quarter-rate candidate pixels of frame `tick` (data.vert:117): x % 2 == y % 2 == tick % 2
+__device__ __forceinline__ int cand_count(int W, int H, int tick) {
+    const int par = tick & 1;
+    return ((W - par + 1) / 2) * ((H - par + 1) / 2);
+}
+
+__device__ __forceinline__ int chunk_size(int n) {
+    const int c = (n + kCompactBlocks - 1) / kCompactBlocks;
+    return ((c + 255) / 256) * 256;
+}
+
+// sum of 256 per-thread ints -> every thread gets the block total; s_w: 4 ints of LDS
+__device__ __forceinline__ int block_sum_i(int v, int* s_w) {
+    v = wave_sum_i(v);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+    return tot;
+}
+
+// exclusive prefix of block_counts for this workgroup (prologue of pass 2)
+__device__ __forceinline__ int block_base(const int* __restrict__ block_counts, int* s_w) {
+    int v = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) v += block_counts[b];
+    return block_sum_i(v, s_w);
+}
+
+// ------------------------------------------------------------------------------------------------
+// first-frame initialisation: one record per pixel in column-major slots + keep flag, then compaction
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_init_records(const uint8_t* __restrict__ rgb, const float* __restrict__ depthRaw,
+                                                      const float* __restrict__ depthF, int W, int H, Intr k, float maxDepth,
+                                                      const FrameDev* __restrict__ frame, float4* __restrict__ rec,
+                                                      uint8_t* __restrict__ flags) {
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= W || j >= H) return;
+    const int slot = i * H + j;  // FeedbackBuffer.cpp:44-50: column-major vertex order
+    const float x = (float)i + 0.5f, y = (float)j + 0.5f;
+    const float3 vraw = get_vertex(depthRaw, W, H, i, j, x, y, k);
+    if (vraw.z <= 0 || vraw.z > maxDepth) { flags[slot] = 0; return; }
+    const float3 vfil = get_vertex(depthF, W, H, i, j, x, y, k);
+    const float3 n = get_normal_central(depthF, W, H, i, j, x, y, vfil, k);
+    const uint8_t* p = rgb + (size_t)(j * W + i) * 3;
+    rec[slot * 3 + 0] = make_float4(vraw.x, vraw.y, vraw.z, surfel_confidence(x, y, 1.0f, k));
+    rec[slot * 3 + 1] = make_float4((float)((p[0] << 16) + (p[1] << 8) + p[2]), 0.f, 1.f, (float)frame->tick);
+    rec[slot * 3 + 2] = make_float4(n.x, n.y, n.z, surfel_radius(vfil.z, n.z, k));
+    flags[slot] = 1;
+}
+
+void launch_init_surfels(const uint8_t* rgb, const float* depthRaw, const float* depthF, int W, int H, Intr k, float maxDepth,
+                         const FrameDev* frame, float4* rec, uint8_t* flags, hipStream_t s) {
+    dim3 grid((W + 63) / 64, (H + 3) / 4);
+    hipLaunchKernelGGL(k_init_records, grid, dim3(256), 0, s, rgb, depthRaw, depthF, W, H, k, maxDepth, frame, rec, flags);
+}
+
+__global__ __launch_bounds__(256) void k_count_flags(const uint8_t* __restrict__ flags, int n, int* __restrict__ block_counts) {
+    __shared__ int s_w[4];
+    const int chunk = chunk_size(n);
+    const int beg = blockIdx.x * chunk, end = min(n, beg + chunk);
+    int v = 0;
+    for (int i = beg + threadIdx.x; i < end; i += 256) v += flags[i] ? 1 : 0;
+    const int tot = block_sum_i(v, s_w);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_compact_records(const float4* __restrict__ rec, const uint8_t* __restrict__ flags, int n,
+                                                         Surfels dst, FrameDev* __restrict__ frame,
+                                                         const int* __restrict__ block_counts, int* __restrict__ host_count) {
+    __shared__ int s_w[4];
+    int base = block_base(block_counts, s_w);
+    const int chunk = chunk_size(n);
+    const int beg = blockIdx.x * chunk, end = min(n, beg + chunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i0 = beg; i0 < end; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        const bool keep = i < end && flags[i];
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_w[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += s_w[w];
+        const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        if (keep) {
+            const int o = off + lane_rank(m);
+            if (o < dst.cap) { dst.pc[o] = rec[i * 3 + 0]; dst.ct[o] = rec[i * 3 + 1]; dst.nr[o] = rec[i * 3 + 2]; }
+        }
+        base += tot;
+        __syncthreads();
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        frame->count = min(base, dst.cap);
+        if (host_count) *host_count = min(base, dst.cap);
+    }
+}
+
+void launch_compact_records(const float4* rec, const uint8_t* flags, int n, Surfels dst, FrameDev* frame, int* block_counts,
+                            int* host_count_mirror, hipStream_t s) {
+    hipLaunchKernelGGL(k_count_flags, dim3(kCompactBlocks), dim3(256), 0, s, flags, n, block_counts);
+    hipLaunchKernelGGL(k_compact_records, dim3(kCompactBlocks), dim3(256), 0, s, rec, flags, n, dst, frame, block_counts,
+                       host_count_mirror);
+}
+
+// ------------------------------------------------------------------------------------------------
+// index map: scatter (z-test as 64-bit atomicMin) + resolve
+// Raster rule: a 1-px point lands in texel (floor(u), floor(v)); LESS on z; lower index wins ties.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_index_scatter(Surfels src, const FrameDev* __restrict__ frame,
+                                                       const PoseDev* __restrict__ pose, int W, int H, Intr k, float maxDepth,
+                                                       int timeDelta, unsigned long long* __restrict__ keys) {
+    const int n = frame->count;
+    const float time = (float)frame->tick;
+    float Ri[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) Ri[q] = pose->Ri[q];
+    const float3 ti = f3(pose->ti[0], pose->ti[1], pose->ti[2]);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float4 pc = src.pc[i];
+        const float lastTime = src.ct[i].w;
+        const float3 h = mul33(Ri, f3(pc.x, pc.y, pc.z)) + ti;
+        if (h.z > maxDepth || h.z <= 0 || time - lastTime > (float)timeDelta) continue;  // index_map.vert:46
+        const float u = ((k.fx * h.x) / h.z) + k.cx;
+        const float v = ((k.fy * h.y) / h.z) + k.cy;
+        if (!(u >= 0.f && u < (float)W && v >= 0.f && v < (float)H)) continue;
+        const int p = (int)floorf(v) * W + (int)floorf(u);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(h.z) << 32) | (unsigned)i;
+        atomicMin(&keys[p], key);
+    }
+}
+
+void launch_index_scatter(Surfels src, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth,
+                          int timeDelta, unsigned long long* keys, hipStream_t s) {
+    hipLaunchKernelGGL(k_index_scatter, dim3(2048), dim3(256), 0, s, src, frame, pose, W, H, k, maxDepth, timeDelta, keys);
+}
+
+__global__ __launch_bounds__(256) void k_index_resolve(Surfels src, const PoseDev* __restrict__ pose,
+                                                       unsigned long long* __restrict__ keys, int P, int* __restrict__ index,
+                                                       float4* __restrict__ vc, float4* __restrict__ ct, float4* __restrict__ nr) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const unsigned long long key = keys[p];
+    keys[p] = kEmptyKey;  // ready for the next scatter: saves a separate clear pass
+    if (key == kEmptyKey) {
+        index[p] = 0;
+        vc[p] = ct[p] = nr[p] = make_float4(0, 0, 0, 0);
+        return;
+    }
+    const int i = (int)(unsigned)(key & 0xFFFFFFFFull);
+    const float4 pc = src.pc[i], c4 = src.ct[i], n4 = src.nr[i];
+    const float3 h = mul33(pose->Ri, f3(pc.x, pc.y, pc.z)) + f3(pose->ti[0], pose->ti[1], pose->ti[2]);
+    const float3 n = normalize_gl(mul33(pose->Ri, f3(n4.x, n4.y, n4.z)));
+    index[p] = i;
+    vc[p] = make_float4(h.x, h.y, h.z, pc.w);
+    ct[p] = c4;
+    nr[p] = make_float4(n.x, n.y, n.z, n4.w);
+}
+
+void launch_index_resolve(Surfels src, const PoseDev* pose, unsigned long long* keys, int W, int H, int* index, float4* vc,
+                          float4* ct, float4* nr, hipStream_t s) {
+    const int P = W * H;
+    hipLaunchKernelGGL(k_index_resolve, dim3((P + 255) / 256), dim3(256), 0, s, src, pose, keys, P, index, vc, ct, nr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// data association (data.vert).  Threads walk candidates row-major (coalesced image reads); the candidate's
+// column-major index c = xi * nyc + yi is only its slot / its priority in the first-writer-wins merge.
+// ------------------------------------------------------------------------------------------------
+struct FuseDataArgs {
+    const uint8_t* rgb; const float* depthRaw; const float* depthF; const uint8_t* mask; int maskID;
+    const FrameDev* frame; const PoseDev* pose; float weightMultiplier; float maxDepth;
+    int W, H; Intr k;
+    const int* index; const float4* vc; const float4* nr;
+    uint8_t* cand_op; float4* cand_rec; int* upd_first;
+};
+
+__global__ __launch_bounds__(256) void k_fuse_data(const FuseDataArgs a) {
+    const int time = a.frame->tick;
+    const int par = time & 1;
+    const int W = a.W, H = a.H;
+    const int nxc = (W - par + 1) / 2, nyc = (H - par + 1) / 2;
+    const int xi = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int yi = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (xi >= nxc || yi >= nyc) return;
+    const int c = xi * nyc + yi;
+    const int px = 2 * xi + par, py = 2 * yi + par;
+    const Intr k = a.k;
+    uint8_t op = 0;
+    const float x = (float)px + 0.5f, y = (float)py + 0.5f;
+    const float3 vLocal = get_vertex(a.depthRaw, W, H, px, py, x, y, k);
+    bool valid = a.mask[py * W + px] == a.maskID;
+    valid = valid && !(texf(a.depthRaw, W, H, px - 1, py) == 0 || texf(a.depthRaw, W, H, px, py - 1) == 0 ||
+                       texf(a.depthRaw, W, H, px + 1, py) == 0 || texf(a.depthRaw, W, H, px, py + 1) == 0);
+    valid = valid && (vLocal.z > 0 && vLocal.z <= a.maxDepth);
+    if (valid) {
+        float R[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) R[q] = a.pose->R[q];
+        const float3 t = f3(a.pose->t[0], a.pose->t[1], a.pose->t[2]);
+        const float3 vGlobal = mul33(R, vLocal) + t;
+        const float3 vF = get_vertex(a.depthF, W, H, px, py, x, y, k);
+        const float3 nLocal = get_normal_central(a.depthF, W, H, px, py, x, y, vF, k);
+        const float3 nGlobal = mul33(R, nLocal);
+        const uint8_t* pc = a.rgb + (size_t)(py * W + px) * 3;
+        const float weighting = a.pose->fusionWeight * a.weightMultiplier;
+
+        const float xl = (x - k.cx) * (1.0f / k.fx), yl = (y - k.cy) * (1.0f / k.fy);
+        const float lambda = sqrtf(xl * xl + yl * yl + 1);
+        const float3 ray = f3(xl, yl, 1);
+        float bestDist = 1000;
+        int best = 0;
+        bool merge = false;
+        // data.vert:139-141 window: pixel-centre offsets {-1,-0.5,0,+0.5} -> texels {x-1,x,x,x+1}; a revisited texel can
+        // never replace itself (strict <), so the 3x3 distinct texels in first-visit order are equivalent.
+#pragma unroll
+        for (int da = -1; da <= 1; ++da) {
+#pragma unroll
+            for (int db = -1; db <= 1; ++db) {
+                const int tp = clampi(py + db, 0, H - 1) * W + clampi(px + da, 0, W - 1);
+                const int current = a.index[tp];
+                if (current > 0) {
+                    const float4 vc = a.vc[tp];
+                    const float zdiff = vc.z - vLocal.z;
+                    if (fabsf(zdiff * lambda) < 0.05f) {
+                        const float dist = norm3(cross3(ray, f3(vc.x, vc.y, vc.z)));
+                        const float4 nr = a.nr[tp];
+                        const float3 nn = f3(nr.x, nr.y, nr.z);
+                        const float ang = acosf(dot3(nn, nLocal) / (norm3(nn) * norm3(nLocal)));
+                        if (dist < bestDist && (fabsf(nr.z) < 0.75f || fabsf(ang) < 0.5f)) {
+                            merge = true; bestDist = dist; best = current;
+                        }
+                    }
+                }
+            }
+        }
+        op = merge ? 1 : 2;
+        a.cand_rec[c * 3 + 0] = make_float4(vGlobal.x, vGlobal.y, vGlobal.z, surfel_confidence(x, y, weighting, k));
+        a.cand_rec[c * 3 + 1] = make_float4((float)((pc[0] << 16) + (pc[1] << 8) + pc[2]), 0.f, (float)time, merge ? -1.f : -2.f);
+        a.cand_rec[c * 3 + 2] = make_float4(nGlobal.x, nGlobal.y, nGlobal.z, surfel_radius(vF.z, nLocal.z, k));
+        if (merge) atomicMin(&a.upd_first[best], c);  // first writer (lowest column-major index) wins
+    }
+    a.cand_op[c] = op;
+}
+
+void launch_fuse_data(const uint8_t* rgb, const float* depthRaw, const float* depthF, const uint8_t* mask, int maskID,
+                      const FrameDev* frame, const PoseDev* pose, float weightMultiplier, float maxDepth, int W, int H, Intr k,
+                      const int* index, const float4* vc, const float4* nr, uint8_t* cand_op, float4* cand_rec, int* upd_first,
+                      hipStream_t s) {
+    FuseDataArgs a{rgb, depthRaw, depthF, mask, maskID, frame, pose, weightMultiplier, maxDepth, W, H, k,
+                   index, vc, nr, cand_op, cand_rec, upd_first};
+    dim3 grid(((W + 1) / 2 + 63) / 64, ((H + 1) / 2 + 3) / 4);
+    hipLaunchKernelGGL(k_fuse_data, grid, dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// surfel update (update.vert): src -> dst, consuming (and resetting) the per-surfel merge slot
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fuse_update(Surfels src, Surfels dst, const FrameDev* __restrict__ frame,
+                                                     int* __restrict__ upd_first, const float4* __restrict__ cand_rec) {
+    const int n = frame->count;
+    const float time = (float)frame->tick;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float4 pc = src.pc[i], ct = src.ct[i], nr = src.nr[i];
+        const int m = upd_first[i];
+        if (m != kNoUpdate) {
+            upd_first[i] = kNoUpdate;
+            const float4 mp = cand_rec[m * 3 + 0], mc = cand_rec[m * 3 + 1], mn = cand_rec[m * 3 + 2];
+            const float c_k = pc.w, a = mp.w;
+            if (mn.w < (1.0f + 0.5f) * nr.w) {
+                pc = make_float4(((c_k * pc.x) + (a * mp.x)) / (c_k + a), ((c_k * pc.y) + (a * mp.y)) / (c_k + a),
+                                 ((c_k * pc.z) + (a * mp.z)) / (c_k + a), c_k + a);
+                const float3 oc = decode_color(ct.x), nc = decode_color(mc.x);
+                ct = make_float4(encode_color(((c_k * oc.x) + (a * nc.x)) / (c_k + a), ((c_k * oc.y) + (a * nc.y)) / (c_k + a),
+                                              ((c_k * oc.z) + (a * nc.z)) / (c_k + a)),
+                                 ct.y, ct.z, time);
+                const float4 av = make_float4(((c_k * nr.x) + (a * mn.x)) / (c_k + a), ((c_k * nr.y) + (a * mn.y)) / (c_k + a),
+                                              ((c_k * nr.z) + (a * mn.z)) / (c_k + a), ((c_k * nr.w) + (a * mn.w)) / (c_k + a));
+                const float3 nn = normalize_gl(f3(av.x, av.y, av.z));
+                nr = make_float4(nn.x, nn.y, nn.z, av.w);
+            } else {
+                pc.w = c_k + a;
+                ct.w = time;
+            }
+        }
+        dst.pc[i] = pc; dst.ct[i] = ct; dst.nr[i] = nr;
+    }
+}
+
+void launch_fuse_update(Surfels src, Surfels dst, const FrameDev* frame, int* upd_first, const float4* cand_rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_fuse_update, dim3(2048), dim3(256), 0, s, src, dst, frame, upd_first, cand_rec);
+}
+
+// ------------------------------------------------------------------------------------------------
+// clean (copy_unstable.vert:53-157): pass 1 = per-element test + new confidence + per-workgroup counts;
+// pass 2 = ordered copy.  Element i < count is an old surfel, element count + c is candidate c (only op == 2 live).
+// ------------------------------------------------------------------------------------------------
+struct CleanArgs {
+    Surfels src, dst; FrameDev* frame; const PoseDev* pose; int W, H; Intr k;
+    int timeDelta; float confThreshold; float outlierCoeff; int maskID;
+    const int* index; const float4* vc; const float4* ct; const float* depthF; const uint8_t* mask;
+    const uint8_t* cand_op; const float4* cand_rec;
+    uint8_t* flags; float* newconf; int* block_counts; int* host_count;
+};
+
+__device__ __forceinline__ bool clean_test(const CleanArgs& a, float4 pc, float4 ct, float4 nr, float time, const float* Ri,
+                                           float3 ti, float& newconf) {
+    const int W = a.W, H = a.H;
+    bool test = true;
+    const float3 lp = mul33(Ri, f3(pc.x, pc.y, pc.z)) + ti;
+    const float x = ((a.k.fx * lp.x) / lp.z) + a.k.cx;
+    const float y = ((a.k.fy * lp.y) / lp.z) + a.k.cy;
+    const float3 ln = normalize_gl(mul33(Ri, f3(nr.x, nr.y, nr.z)));
+    int count = 0, zCount = 0;
+    if (time - ct.w < (float)a.timeDelta && lp.z > 0 && x > 0 && y > 0 && x < (float)W && y < (float)H) {
+        int txs[4], tys[4];
+        txs[0] = clampi((int)floorf(x - 1.0f), 0, W - 1); txs[1] = clampi((int)floorf(x - 0.5f), 0, W - 1);
+        txs[2] = clampi((int)floorf(x), 0, W - 1);        txs[3] = clampi((int)floorf(x + 0.5f), 0, W - 1);
+        tys[0] = clampi((int)floorf(y - 1.0f), 0, H - 1); tys[1] = clampi((int)floorf(y - 0.5f), 0, H - 1);
+        tys[2] = clampi((int)floorf(y), 0, H - 1);        tys[3] = clampi((int)floorf(y + 0.5f), 0, H - 1);
+#pragma unroll
+        for (int ia = 0; ia < 4; ++ia) {
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) {
+                const int tp = tys[ib] * W + txs[ia];
+                if (a.index[tp] > 0) {
+                    const float4 v = a.vc[tp];
+                    const float4 c = a.ct[tp];
+                    const float dx = v.x - lp.x, dy = v.y - lp.y;
+                    if (c.z < ct.z && v.w > a.confThreshold && v.z > lp.z && v.z - lp.z < 0.01f &&
+                        sqrtf(dx * dx + dy * dy) < nr.w * 1.4f)
+                        count++;
+                    if (c.w == time && v.w > a.confThreshold && v.z > lp.z && v.z - lp.z > 0.01f && fabsf(ln.z) > 0.85f)
+                        zCount++;
+                }
+            }
+        }
+    }
+    if (count > 8 || zCount > 4) test = false;
+    float w = ct.w;
+    if (w == -2.f) w = time;
+    if (w == -1.f || ((time - w) > 20 && pc.w < a.confThreshold)) test = false;
+    if (w > 0 && time - w > (float)a.timeDelta) test = true;
+    // mask-disagreement decay, copy_unstable.vert:139-156 (nearest fetch, clamp to edge, NaN -> texel 0)
+    const int fx_ = isnan(x) ? 0 : clampi((int)fminf(fmaxf(floorf(x), -1.f), (float)W), 0, W - 1);
+    const int fy_ = isnan(y) ? 0 : clampi((int)fminf(fmaxf(floorf(y), -1.f), (float)H), 0, H - 1);
+    const float wDepth = a.depthF[fy_ * W + fx_];
+    const int maskValue = a.mask[fy_ * W + fx_];
+    newconf = pc.w;
+    if (maskValue != a.maskID && maskValue < 255 && (wDepth > lp.z - 0.05f && wDepth < lp.z + 0.05f)) {
+        const float kk = 0.5f + 0.5f * (1 - a.outlierCoeff / 10.0f);
+        if (maskValue == 0) newconf *= kk;
+        else if (a.maskID == 0) newconf *= 0.25f * kk;
+        else newconf *= kk;
+    }
+    return test;
+}
+
+__global__ __launch_bounds__(256) void k_clean_flags(const CleanArgs a) {
+    __shared__ int s_w[4];
+    const int count = a.frame->count;
+    const int total = count + cand_count(a.W, a.H, a.frame->tick);
+    const float time = (float)a.frame->tick;
+    float Ri[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) Ri[q] = a.pose->Ri[q];
+    const float3 ti = f3(a.pose->ti[0], a.pose->ti[1], a.pose->ti[2]);
+    const int chunk = chunk_size(total);
+    const int beg = blockIdx.x * chunk, end = min(total, beg + chunk);
+    int kept = 0;
+    for (int i = beg + threadIdx.x; i < end; i += 256) {
+        bool keep = false;
+        float nc = 0.f;
+        if (i < count) {
+            keep = clean_test(a, a.src.pc[i], a.src.ct[i], a.src.nr[i], time, Ri, ti, nc);
+        } else {
+            const int c = i - count;
+            if (a.cand_op[c] == 2)
+                keep = clean_test(a, a.cand_rec[c * 3 + 0], a.cand_rec[c * 3 + 1], a.cand_rec[c * 3 + 2], time, Ri, ti, nc);
+        }
+        a.flags[i] = keep ? 1 : 0;
+        a.newconf[i] = nc;
+        kept += keep ? 1 : 0;
+    }
+    const int tot = block_sum_i(kept, s_w);
+    if (threadIdx.x == 0) a.block_counts[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_clean_compact(const CleanArgs a) {
+    __shared__ int s_w[4];
+    int base = block_base(a.block_counts, s_w);
+    const int count = a.frame->count;
+    const int total = count + cand_count(a.W, a.H, a.frame->tick);
+    const float time = (float)a.frame->tick;
+    const int chunk = chunk_size(total);
+    const int beg = blockIdx.x * chunk, end = min(total, beg + chunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i0 = beg; i0 < end; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        const bool keep = i < end && a.flags[i];
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_w[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += s_w[w];
+        const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        if (keep) {
+            const int o = off + lane_rank(m);
+            float4 pc, ct, nr;
+            if (i < count) { pc = a.src.pc[i]; ct = a.src.ct[i]; nr = a.src.nr[i]; }
+            else { const int c = i - count; pc = a.cand_rec[c * 3 + 0]; ct = a.cand_rec[c * 3 + 1]; nr = a.cand_rec[c * 3 + 2]; }
+            pc.w = a.newconf[i];
+            if (ct.w == -2.f) ct.w = time;  // copy_unstable.vert:131
+            if (o < a.dst.cap) { a.dst.pc[o] = pc; a.dst.ct[o] = ct; a.dst.nr[o] = nr; }
+        }
+        base += tot;
+        __syncthreads();
+    }
+    // frame->count is read by every workgroup of this launch, so the new count is parked in countNext and committed by
+    // a one-thread kernel at the launch boundary (no intra-launch ordering assumption).
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        a.frame->countNext = min(base, a.dst.cap);
+        if (a.host_count) *a.host_count = min(base, a.dst.cap);
+    }
+}
+
+__global__ void k_commit_count(FrameDev* frame) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) frame->count = frame->countNext;
+}
+
+// ------------------------------------------------------------------------------------------------
+// splat prediction: scatter (per-surfel sprite loop, ray-disc test, 64-bit atomicMin) + resolve
+// Raster rule: sprite side s centred on (u,v) covers pixel (px,py) iff u - s/2 <= px + 0.5 < u + s/2; LESS on the
+// corrected z; lower index wins ties; sprites wider than 64 px are clamped.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_splat_scatter(Surfels src, const FrameDev* __restrict__ frame,
+                                                       const PoseDev* __restrict__ pose, int W, int H, Intr k, float maxDepth,
+                                                       float confThreshold, int timeDelta, unsigned long long* __restrict__ keys) {
+    const int n = frame->count;
+    const float time = (float)frame->tick;  // combinedPredict(time = tick, maxTime = tick)
+    float Ri[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) Ri[q] = pose->Ri[q];
+    const float3 ti = f3(pose->ti[0], pose->ti[1], pose->ti[2]);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float4 pc = src.pc[i];
+        if (pc.w < confThreshold) continue;
+        const float lastTime = src.ct[i].w;
+        const float3 h = mul33(Ri, f3(pc.x, pc.y, pc.z)) + ti;
+        if (h.z > maxDepth || h.z < 0 || time - lastTime > (float)timeDelta || lastTime > time) continue;  // splat.vert:58
+        const float u = ((k.fx * h.x) / h.z) + k.cx, v = ((k.fy * h.y) / h.z) + k.cy;
+        if (!(u >= 0.f && u <= (float)W && v >= 0.f && v <= (float)H)) continue;
+        const float4 n4 = src.nr[i];
+        const float3 nrm = normalize_gl(mul33(Ri, f3(n4.x, n4.y, n4.z)));
+        const float rad = n4.w;
+        const float3 x1 = normalize_gl(f3(nrm.y - nrm.z, -nrm.x, nrm.x)) * (rad * 1.41421356f);
+        const float3 y1 = cross3(nrm, x1);
+        float xs0 = INFINITY, xs1 = -INFINITY, ys0 = INFINITY, ys1 = -INFINITY;
+        const float3 corners[4] = {h + x1, h + y1, h - y1, h - x1};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float pxq = ((k.fx * corners[q].x) / corners[q].z) + k.cx;
+            const float pyq = ((k.fy * corners[q].y) / corners[q].z) + k.cy;
+            xs0 = fminf(xs0, pxq); xs1 = fmaxf(xs1, pxq);
+            ys0 = fminf(ys0, pyq); ys1 = fmaxf(ys1, pyq);
+        }
+        float size = fmaxf(0.f, fmaxf(fabsf(xs1 - xs0), fabsf(ys1 - ys0)));
+        if (!(size > 0.f)) continue;
+        size = fminf(size, 64.0f);
+        const float half = size * 0.5f;
+        const int px0 = max(0, (int)ceilf(u - half - 0.5f)), px1 = min(W - 1, (int)ceilf(u + half - 0.5f) - 1);
+        const int py0 = max(0, (int)ceilf(v - half - 0.5f)), py1 = min(H - 1, (int)ceilf(v + half - 0.5f) - 1);
+        const float sqrRad = rad * rad;
+        const float pn = dot3(h, nrm);
+        for (int py = py0; py <= py1; ++py) {
+            for (int px = px0; px <= px1; ++px) {
+                const float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;
+                const float3 l = normalize_gl(f3((fcx - k.cx) / k.fx, (fcy - k.cy) / k.fy, 1.0f));
+                const float3 cp = l * (pn / dot3(l, nrm));
+                const float3 diff = cp - h;
+                if (!(dot3(diff, diff) <= sqrRad)) continue;
+                if (!(cp.z > 0.f)) continue;
+                const unsigned long long key = ((unsigned long long)__float_as_uint(cp.z) << 32) | (unsigned)i;
+                atomicMin(&keys[py * W + px], key);
+            }
+        }
+    }
+}
+
+void launch_splat_scatter(Surfels src, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth,
+                          float confThreshold, int timeDelta, unsigned long long* keys, hipStream_t s) {
+    hipLaunchKernelGGL(k_splat_scatter, dim3(2048), dim3(256), 0, s, src, frame, pose, W, H, k, maxDepth, confThreshold,
+                       timeDelta, keys);
+}
+
+__global__ __launch_bounds__(256) void k_splat_resolve(Surfels src, const PoseDev* __restrict__ pose,
+                                                       unsigned long long* __restrict__ keys, int W, int H, Intr k,
+                                                       float4* __restrict__ predV, float4* __restrict__ predN,
+                                                       uchar4* __restrict__ predImage, uint16_t* __restrict__ predTime,
+                                                       FrameDev* __restrict__ frame) {
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (px >= W || py >= H) return;
+    const int p = py * W + px;
+    const unsigned long long key = keys[p];
+    keys[p] = kEmptyKey;
+    if (key == kEmptyKey) {
+        predV[p] = predN[p] = make_float4(0, 0, 0, 0);
+        predImage[p] = make_uchar4(0, 0, 0, 0);
+        predTime[p] = 0;
+        return;
+    }
+    const int i = (int)(unsigned)(key & 0xFFFFFFFFull);
+    const float z = __uint_as_float((unsigned)(key >> 32));
+    const float4 pc = src.pc[i], c4 = src.ct[i], n4 = src.nr[i];
+    const float3 n = normalize_gl(mul33(pose->Ri, f3(n4.x, n4.y, n4.z)));
+    const float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;
+    predV[p] = make_float4((fcx - k.cx) * z * (1.f / k.fx), (fcy - k.cy) * z * (1.f / k.fy), z, pc.w);  // combo_splat.frag:56
+    predN[p] = make_float4(n.x, n.y, n.z, n4.w);
+    const int ci = (int)c4.x;
+    const uchar4 col = make_uchar4((ci >> 16) & 0xFF, (ci >> 8) & 0xFF, ci & 0xFF, 255);
+    predImage[p] = col;
+    predTime[p] = (uint16_t)(unsigned)c4.z;
+    // MaskFusion::requiresFillIn (MaskFusion.cpp:630-648): nearest sample of the 20x down-sampled colour prediction
+    if ((px % 20) == 10 && (py % 20) == 10 && px / 20 < W / 20 && py / 20 < H / 20 && col.x > 0 && col.y > 0 && col.z > 0)
+        atomicAdd(&frame->cover, 1);
+}
+
+void launch_splat_resolve(Surfels src, const PoseDev* pose, unsigned long long* keys, int W, int H, Intr k, float4* predV,
+                          float4* predN, uchar4* predImage, uint16_t* predTime, FrameDev* frame, hipStream_t s) {
+    dim3 grid((W + 63) / 64, (H + 3) / 4);
+    hipLaunchKernelGGL(k_splat_resolve, grid, dim3(256), 0, s, src, pose, keys, W, H, k, predV, predN, predImage, predTime, frame);
+}
+
+// ------------------------------------------------------------------------------------------------
+// end of frame: tick++ and the fill-in decision for the next tracking step
+// ------------------------------------------------------------------------------------------------
+__global__ void k_frame_advance(FrameDev* frame, int W, int H, FrameDev* host_mirror) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int rw = W / 20, rh = H / 20;
+    frame->pad[0] = frame->useFillIn;  // decision the tracking step of THIS frame ran with (mf_get_last_fillin)
+    frame->useFillIn = ((float)frame->cover / (float)(rw * rh) < 0.75f) ? 1 : 0;
+    frame->cover = 0;
+    frame->tick += 1;
+    if (host_mirror) *host_mirror = *frame;
+}
+void launch_frame_advance(FrameDev* frame, int W, int H, FrameDev* host_mirror, hipStream_t s) {
+    hipLaunchKernelGGL(k_frame_advance, dim3(1), dim3(64), 0, s, frame, W, H, host_mirror);
+}
+
+void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, int timeDelta,
+                  float confThreshold, float outlierCoeff, int maskID, const int* index, const float4* vc, const float4* ct,
+                  const float* depthF, const uint8_t* mask, const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags,
+                  float* newconf, int* block_counts, int* host_count_mirror, hipStream_t s) {
+    CleanArgs a;
+    a.src = src; a.dst = dst; a.frame = frame; a.pose = pose; a.W = W; a.H = H; a.k = k; a.timeDelta = timeDelta;
+    a.confThreshold = confThreshold; a.outlierCoeff = outlierCoeff; a.maskID = maskID; a.index = index; a.vc = vc; a.ct = ct;
+    a.depthF = depthF; a.mask = mask; a.cand_op = cand_op; a.cand_rec = cand_rec;
+    a.flags = flags; a.newconf = newconf; a.block_counts = block_counts; a.host_count = host_count_mirror;
+    hipLaunchKernelGGL(k_clean_flags, dim3(kCompactBlocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_clean_compact, dim3(kCompactBlocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_commit_count, dim3(1), dim3(64), 0, s, frame);
+}
+
+}  // namespace mf

@@ -1,0 +1,81 @@
+"""ctypes loader for libmaskfusion_amd.so (C ABI: include/maskfusion_amd.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmaskfusion_amd.so")
+
+MF_OK = 0
+MF_N_TIMINGS = 9
+TIMING_LABELS = ["Preprocess", "odomInit", "odom", "indexMap", "Fuse::Data", "Fuse::Update", "Fuse::Copy",
+                 "IndexMap::ACTIVE", "Run"]
+
+
+class MFError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    """mf_config (include/maskfusion_amd.h)."""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float), ("device", C.c_int32), ("time_delta", C.c_int32), ("conf_global", C.c_float),
+                ("conf_object", C.c_float), ("depth_cutoff", C.c_float), ("icp_weight", C.c_float),
+                ("fast_odom", C.c_int32), ("so3", C.c_int32), ("pyramid", C.c_int32),
+                ("max_depth_processed", C.c_float), ("outlier_coefficient", C.c_float), ("num_gsurfels", C.c_int32),
+                ("num_osurfels", C.c_int32), ("enable_multiple_models", C.c_int32), ("reserved", C.c_int32 * 8)]
+
+
+# every symbol declared in include/maskfusion_amd.h (tests/test_abi.py checks the header against this table)
+SYMBOLS = {
+    "mf_default_config": (C.c_int, [C.POINTER(Config), C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "mf_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
+    "mf_destroy": (None, [C.c_void_p]),
+    "mf_last_error": (C.c_char_p, [C.c_void_p]),
+    "mf_process_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
+                                   C.c_void_p, C.c_float, C.c_int32]),
+    "mf_process_frame_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float]),
+    "mf_sync": (C.c_int, [C.c_void_p]),
+    "mf_predict": (C.c_int, [C.c_void_p]),
+    "mf_get_tick": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "mf_num_models": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "mf_get_pose": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "mf_get_surfel_count": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint32)]),
+    "mf_get_icp_stats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "mf_download_map": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "mf_get_last_fillin": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "mf_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
+    "mf_get_param": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]),
+    "mf_get_timings": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mf_get_stream": (C.c_void_p, [C.c_void_p]),
+    "mf_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]),
+    "mf_k_bilateral": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "mf_k_pyrdown_f": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "mf_k_vmap_nmap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float,
+                                 C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "mf_k_model_pyramid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                     C.c_int32, C.c_void_p]),
+    "mf_k_icp_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32,
+                                C.c_int32, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the HIP extension.  Raises MFError if it has not been built (python maskfusion_amd/build.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MFError(f"{LIB_PATH} is missing: build it with `python maskfusion_amd/build.py` "
+                      "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)  # AttributeError here = ABI mismatch, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L

@@ -1,0 +1,1242 @@
+/*
+ * mf_oracle.c -- CPU restatement of the MaskFusion::processFrame hot path (see mf_oracle.h).
+ *
+ * TEST INFRASTRUCTURE ONLY -- never linked into or called by the product (maskfusion_amd/).
+ * PARITY UNPINNED by the reference (no tests / golden vectors upstream, reference not buildable here);
+ * pinned by analytic KATs in tests/test_oracle_kat.py.  Citations are relative to /root/reference/.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC mf_oracle.c -lm  (see Makefile)
+ * -ffp-contract=off keeps every float op individually rounded, like a plain reading of the sources.
+ */
+#include "mf_oracle.h"
+
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define MFO_NAN (__builtin_nanf(""))
+
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline int iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static double now_ms(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+/* __float2int_rn: round-to-nearest-even, NaN -> 0, saturating (CUDA semantics; reduce.cu:304-305) */
+static inline int f2i_rn(float v) {
+    if (isnan(v)) return 0;
+    if (v >= 2147483648.0f) return INT_MAX;
+    if (v <= -2147483648.0f) return INT_MIN;
+    return (int)rintf(v);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * small float 3-vector helpers (Core/Cuda/operators.cuh:57-91)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { float x, y, z; } f3;
+static inline f3 f3_make(float x, float y, float z) { f3 r = {x, y, z}; return r; }
+static inline f3 f3_sub(f3 a, f3 b) { return f3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline f3 f3_add(f3 a, f3 b) { return f3_make(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline f3 f3_scale(f3 a, float s) { return f3_make(a.x * s, a.y * s, a.z * s); }
+static inline f3 f3_cross(f3 a, f3 b) {
+    return f3_make(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline float f3_dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline float f3_norm(f3 a) { return sqrtf(f3_dot(a, a)); }
+static inline f3 f3_normalized(f3 a) {
+    const float rn = 1.0f / sqrtf(f3_dot(a, a)); /* rsqrtf */
+    return f3_make(a.x * rn, a.y * rn, a.z * rn);
+}
+/* GLSL normalize(): v / length(v) */
+static inline f3 f3_glnormalize(f3 a) {
+    const float l = sqrtf(f3_dot(a, a));
+    return f3_make(a.x / l, a.y / l, a.z / l);
+}
+static inline f3 m33_mul(const float* R, f3 a) { /* row-major 3x3 */
+    return f3_make(R[0] * a.x + R[1] * a.y + R[2] * a.z, R[3] * a.x + R[4] * a.y + R[5] * a.z,
+                   R[6] * a.x + R[7] * a.y + R[8] * a.z);
+}
+
+/* float 3x3 inverse by cofactors (Eigen fixed-size inverse stand-in; RGBDOdometry.cpp:332) */
+static void m33_inverse(const float* m, float* inv) {
+    const float c00 = m[4] * m[8] - m[5] * m[7];
+    const float c01 = m[5] * m[6] - m[3] * m[8];
+    const float c02 = m[3] * m[7] - m[4] * m[6];
+    const float det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    const float id = 1.0f / det;
+    inv[0] = c00 * id;
+    inv[1] = (m[2] * m[7] - m[1] * m[8]) * id;
+    inv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    inv[3] = c01 * id;
+    inv[4] = (m[0] * m[8] - m[2] * m[6]) * id;
+    inv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    inv[6] = c02 * id;
+    inv[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+    inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+/* column-major 4x4 <-> (R row-major, t) */
+static void pose16_to_Rt(const float* p, float* R, float* t) {
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) R[r * 3 + c] = p[c * 4 + r];
+        t[r] = p[12 + r];
+    }
+}
+static void Rt_to_pose16(const float* R, const float* t, float* p) {
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) p[c * 4 + r] = R[r * 3 + c];
+        p[12 + r] = t[r];
+        p[r * 4 + 3] = 0.f;
+    }
+    p[15] = 1.f;
+}
+/* pose.inverse() for an affine [R|t;0 0 0 1] (Eigen general inverse stand-in; ModelProjection.cpp:114) */
+static void pose_inverse_Rt(const float* R, const float* t, float* Ri, float* ti) {
+    m33_inverse(R, Ri);
+    f3 v = m33_mul(Ri, f3_make(t[0], t[1], t[2]));
+    ti[0] = -v.x; ti[1] = -v.y; ti[2] = -v.z;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a2: bilateral filter (Core/Shaders/depth_bilateral_metric.frag:30-76)
+ * ---------------------------------------------------------------------------------------------- */
+void mfo_bilateral(const float* depth, float* out, int W, int H) {
+    const float sigma_space2_inv_half = 0.024691358f;
+    const float sigma_color2_inv_half = 555.556f;
+    const int R = 6, D = R * 2 + 1;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; ++y) {
+        for (int x = 0; x < W; ++x) {
+            const float value = depth[y * W + x];
+            if (value <= 0.03f) { out[y * W + x] = 0.f; continue; }
+            const int tx = imin(x - D / 2 + D, W);
+            const int ty = imin(y - D / 2 + D, H);
+            float sum1 = 0.f, sum2 = 0.f;
+            for (int cy = imax(y - D / 2, 0); cy < ty; ++cy) {
+                for (int cx = imax(x - D / 2, 0); cx < tx; ++cx) {
+                    const float tmp = depth[cy * W + cx];
+                    const float space2 = ((float)x - (float)cx) * ((float)x - (float)cx) +
+                                         ((float)y - (float)cy) * ((float)y - (float)cy);
+                    const float color2 = (value - tmp) * (value - tmp);
+                    const float weight = expf(-(space2 * sigma_space2_inv_half + color2 * sigma_color2_inv_half));
+                    sum1 += tmp * weight;
+                    sum2 += weight;
+                }
+            }
+            out[y * W + x] = sum1 / sum2;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a3: pyramids + vertex / normal maps
+ * ---------------------------------------------------------------------------------------------- */
+static const float kGauss5[25] = {1, 4, 6, 4, 1, 4, 16, 24, 16, 4, 6, 24, 36, 24, 6, 4, 16, 24, 16, 4, 1, 4, 6, 4, 1};
+
+/* Core/Cuda/cudafuncs.cu:333-364; quirk Q9: upper bounds clamp to cols-1 / rows-1 EXCLUSIVE and the kernel
+ * is indexed from the far corner. */
+void mfo_pyrdown_gauss_f(const float* src, float* dst, int sw, int sh) {
+    const int dw = sw / 2, dh = sh / 2, D = 5;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < dh; ++y) {
+        for (int x = 0; x < dw; ++x) {
+            const int tx = imin(2 * x - D / 2 + D, sw - 1);
+            const int ty = imin(2 * y - D / 2 + D, sh - 1);
+            float sum = 0.f;
+            int count = 0;
+            for (int cy = imax(0, 2 * y - D / 2); cy < ty; ++cy) {
+                for (int cx = imax(0, 2 * x - D / 2); cx < tx; ++cx) {
+                    const float v = src[cy * sw + cx];
+                    if (!isnan(v)) {
+                        const float w = kGauss5[(ty - cy - 1) * 5 + (tx - cx - 1)];
+                        sum += v * w;
+                        count += (int)w;
+                    }
+                }
+            }
+            dst[y * dw + x] = sum / (float)count; /* 0/0 -> NaN, as on the device */
+        }
+    }
+}
+
+/* Core/Cuda/cudafuncs.cu:534-564 */
+void mfo_pyrdown_gauss_u8(const uint8_t* src, uint8_t* dst, int sw, int sh) {
+    const int dw = sw / 2, dh = sh / 2, D = 5;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < dh; ++y) {
+        for (int x = 0; x < dw; ++x) {
+            const int tx = imin(2 * x - D / 2 + D, sw - 1);
+            const int ty = imin(2 * y - D / 2 + D, sh - 1);
+            float sum = 0.f;
+            int count = 0;
+            for (int cy = imax(0, 2 * y - D / 2); cy < ty; ++cy) {
+                for (int cx = imax(0, 2 * x - D / 2); cx < tx; ++cx) {
+                    const uint8_t v = src[cy * sw + cx];
+                    if (v > 0) {
+                        const float w = kGauss5[(ty - cy - 1) * 5 + (tx - cx - 1)];
+                        sum += (float)v * w;
+                        count += (int)w;
+                    }
+                }
+            }
+            /* float -> uchar conversion truncates; 0/0 = NaN converts to 0 on the device */
+            dst[y * dw + x] = count ? (uint8_t)(sum / (float)count) : 0;
+        }
+    }
+}
+
+/* Core/Cuda/cudafuncs.cu:109-134.  Deviation (documented): invalid pixels get NaN in all three planes; the
+ * reference writes x=NaN, z=0 and leaves y stale -- every consumer tests only isnan(x). */
+void mfo_create_vmap(const float* depth, float* vmap, int W, int H, float fx, float fy, float cx, float cy,
+                     float depthCutoff) {
+    const float fx_inv = 1.f / fx, fy_inv = 1.f / fy;
+    const int P = W * H;
+#pragma omp parallel for schedule(static)
+    for (int v = 0; v < H; ++v) {
+        for (int u = 0; u < W; ++u) {
+            const float z = depth[v * W + u];
+            if (z > 0.0f && z < depthCutoff) {
+                vmap[v * W + u] = z * ((float)u - cx) * fx_inv;
+                vmap[P + v * W + u] = z * ((float)v - cy) * fy_inv;
+                vmap[2 * P + v * W + u] = z;
+            } else {
+                vmap[v * W + u] = MFO_NAN;
+                vmap[P + v * W + u] = MFO_NAN;
+                vmap[2 * P + v * W + u] = MFO_NAN;
+            }
+        }
+    }
+}
+
+/* Core/Cuda/cudafuncs.cu:152-189 */
+void mfo_create_nmap(const float* vmap, float* nmap, int W, int H) {
+    const int P = W * H;
+#pragma omp parallel for schedule(static)
+    for (int v = 0; v < H; ++v) {
+        for (int u = 0; u < W; ++u) {
+            const int i = v * W + u;
+            int ok = !(u == W - 1 || v == H - 1);
+            if (ok) {
+                const float x00 = vmap[i], x01 = vmap[i + 1], x10 = vmap[i + W];
+                ok = !isnan(x00) && !isnan(x01) && !isnan(x10);
+            }
+            if (ok) {
+                f3 v00 = f3_make(vmap[i], vmap[P + i], vmap[2 * P + i]);
+                f3 v01 = f3_make(vmap[i + 1], vmap[P + i + 1], vmap[2 * P + i + 1]);
+                f3 v10 = f3_make(vmap[i + W], vmap[P + i + W], vmap[2 * P + i + W]);
+                f3 r = f3_normalized(f3_cross(f3_sub(v01, v00), f3_sub(v10, v00)));
+                nmap[i] = r.x; nmap[P + i] = r.y; nmap[2 * P + i] = r.z;
+            } else {
+                nmap[i] = MFO_NAN; nmap[P + i] = MFO_NAN; nmap[2 * P + i] = MFO_NAN;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a4: model-side maps
+ * ---------------------------------------------------------------------------------------------- */
+/* Core/Cuda/cudafuncs.cu:271-311 */
+void mfo_copy_maps(const float* v4, const float* n4, float* vmap, float* nmap, int W, int H) {
+    const int P = W * H;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; ++i) {
+        const float vx = v4[i * 4 + 0], vy = v4[i * 4 + 1], vz = v4[i * 4 + 2];
+        if (!(vz == 0)) {
+            vmap[i] = vx; vmap[P + i] = vy; vmap[2 * P + i] = vz;
+            nmap[i] = n4[i * 4 + 0]; nmap[P + i] = n4[i * 4 + 1]; nmap[2 * P + i] = n4[i * 4 + 2];
+        } else {
+            vmap[i] = vmap[P + i] = vmap[2 * P + i] = MFO_NAN;
+            nmap[i] = nmap[P + i] = nmap[2 * P + i] = MFO_NAN;
+        }
+    }
+}
+
+/* Core/Cuda/cudafuncs.cu:366-417 */
+void mfo_resize_map(const float* in, float* out, int sw, int sh, int normalize) {
+    const int dw = sw / 2, dh = sh / 2, SP = sw * sh, DP = dw * dh;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < dh; ++y) {
+        for (int x = 0; x < dw; ++x) {
+            const int s = (2 * y) * sw + 2 * x, d = y * dw + x;
+            const float x00 = in[s], x01 = in[s + 1], x10 = in[s + sw], x11 = in[s + sw + 1];
+            if (isnan(x00) || isnan(x01) || isnan(x10) || isnan(x11)) {
+                out[d] = out[DP + d] = out[2 * DP + d] = MFO_NAN;
+                continue;
+            }
+            f3 n;
+            n.x = (x00 + x01 + x10 + x11) / 4;
+            n.y = (in[SP + s] + in[SP + s + 1] + in[SP + s + sw] + in[SP + s + sw + 1]) / 4;
+            n.z = (in[2 * SP + s] + in[2 * SP + s + 1] + in[2 * SP + s + sw] + in[2 * SP + s + sw + 1]) / 4;
+            if (normalize) n = f3_normalized(n);
+            out[d] = n.x; out[DP + d] = n.y; out[2 * DP + d] = n.z;
+        }
+    }
+}
+
+/* Core/Cuda/cudafuncs.cu:207-249 */
+void mfo_transform_maps(const float* vsrc, const float* nsrc, const float* R, const float* t, float* vdst,
+                        float* ndst, int W, int H) {
+    const int P = W * H;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; ++i) {
+        f3 vd = f3_make(MFO_NAN, MFO_NAN, MFO_NAN), nd = vd;
+        if (!isnan(vsrc[i])) {
+            f3 v = m33_mul(R, f3_make(vsrc[i], vsrc[P + i], vsrc[2 * P + i]));
+            vd = f3_make(v.x + t[0], v.y + t[1], v.z + t[2]);
+        }
+        if (!isnan(nsrc[i])) nd = m33_mul(R, f3_make(nsrc[i], nsrc[P + i], nsrc[2 * P + i]));
+        vdst[i] = vd.x; vdst[P + i] = vd.y; vdst[2 * P + i] = vd.z;
+        ndst[i] = nd.x; ndst[P + i] = nd.y; ndst[2 * P + i] = nd.z;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a7: ICP normal equations (Core/Cuda/reduce.cu:259-525).  Sums accumulate in double (the reference's
+ * float tree order is unspecified and fast-math; double is the neutral anchor).
+ * ---------------------------------------------------------------------------------------------- */
+void mfo_icp_step(const float* Rcurr, const float* tcurr, const float* vmap_curr, const float* nmap_curr,
+                  const float* Rprev_inv, const float* tprev, float fx, float fy, float cx, float cy,
+                  const float* vmap_g_prev, const float* nmap_g_prev, float distThres, float angleThres, int W,
+                  int H, float* A, float* b, float* residual) {
+    const int P = W * H;
+    double acc[29];
+    for (int k = 0; k < 29; ++k) acc[k] = 0.0;
+    const f3 tc = f3_make(tcurr[0], tcurr[1], tcurr[2]);
+    const f3 tp = f3_make(tprev[0], tprev[1], tprev[2]);
+
+#pragma omp parallel
+    {
+        double loc[29];
+        for (int k = 0; k < 29; ++k) loc[k] = 0.0;
+#pragma omp for schedule(static) nowait
+        for (int y = 0; y < H; ++y) {
+            for (int x = 0; x < W; ++x) {
+                const int i = y * W + x;
+                /* search(): reduce.cu:292-353 */
+                const f3 vcurr = f3_make(vmap_curr[i], vmap_curr[P + i], vmap_curr[2 * P + i]);
+                const f3 vcurr_g = f3_add(m33_mul(Rcurr, vcurr), tc);
+                const f3 vcurr_cp = m33_mul(Rprev_inv, f3_sub(vcurr_g, tp));
+                const int ux = f2i_rn(vcurr_cp.x * fx / vcurr_cp.z + cx);
+                const int uy = f2i_rn(vcurr_cp.y * fy / vcurr_cp.z + cy);
+                if (ux < 0 || uy < 0 || ux >= W || uy >= H || vcurr_cp.z < 0) continue;
+                const int j = uy * W + ux;
+                const f3 vprev_g = f3_make(vmap_g_prev[j], vmap_g_prev[P + j], vmap_g_prev[2 * P + j]);
+                const f3 ncurr = f3_make(nmap_curr[i], nmap_curr[P + i], nmap_curr[2 * P + i]);
+                const f3 ncurr_g = m33_mul(Rcurr, ncurr);
+                const f3 nprev_g = f3_make(nmap_g_prev[j], nmap_g_prev[P + j], nmap_g_prev[2 * P + j]);
+                const float dist = f3_norm(f3_sub(vprev_g, vcurr_g));
+                const float sine = f3_norm(f3_cross(ncurr_g, nprev_g));
+                if (!(sine < angleThres && dist <= distThres && !isnan(ncurr.x) && !isnan(nprev_g.x))) continue;
+                /* getProducts(): reduce.cu:355-415 */
+                const f3 s_cp = m33_mul(Rprev_inv, f3_sub(vcurr_g, tp));
+                const f3 d_cp = m33_mul(Rprev_inv, f3_sub(vprev_g, tp));
+                const f3 n_cp = m33_mul(Rprev_inv, nprev_g);
+                const f3 sxn = f3_cross(s_cp, n_cp);
+                float row[7];
+                row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z;
+                row[3] = sxn.x; row[4] = sxn.y; row[5] = sxn.z;
+                row[6] = f3_dot(n_cp, f3_sub(s_cp, d_cp));
+                int k = 0;
+                for (int a = 0; a < 7; ++a)
+                    for (int c = a; c < 7; ++c) loc[k++] += (double)(row[a] * row[c]);
+                loc[28] += 1.0;
+            }
+        }
+#pragma omp critical
+        for (int k = 0; k < 29; ++k) acc[k] += loc[k];
+    }
+    /* host unpack: reduce.cu:507-524.  acc order: aa..ag, bb..bg, ..., ff, fg, gg(=residual), inliers */
+    int shift = 0;
+    for (int i = 0; i < 6; ++i) {
+        for (int j = i; j < 7; ++j) {
+            const float value = (float)acc[shift++];
+            if (j == 6) b[i] = value;
+            else A[j * 6 + i] = A[i * 6 + j] = value;
+        }
+    }
+    residual[0] = (float)acc[27];
+    residual[1] = (float)acc[28];
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a11: solve + SE(3) update
+ * ---------------------------------------------------------------------------------------------- */
+/* Symmetric LDL^T with diagonal pivoting, double (stand-in for Eigen::LDLT, RGBDOdometry.cpp:313,447-459).
+ * Like Eigen, a (near-)zero pivot yields a zero component rather than inf. */
+int mfo_ldlt_solve(const double* Ain, const double* bin, double* x, int n) {
+    double A[36], b[6];
+    int perm[6];
+    if (n > 6) return -1;
+    for (int i = 0; i < n * n; ++i) A[i] = Ain[i];
+    for (int i = 0; i < n; ++i) { b[i] = bin[i]; perm[i] = i; }
+    double maxdiag = 0;
+    for (int i = 0; i < n; ++i) maxdiag = fmax(maxdiag, fabs(A[i * n + i]));
+    const double tol = maxdiag * 1e-300 + 1e-300;
+    for (int k = 0; k < n; ++k) {
+        /* pivot: largest remaining |diagonal| */
+        int p = k;
+        for (int i = k + 1; i < n; ++i)
+            if (fabs(A[i * n + i]) > fabs(A[p * n + p])) p = i;
+        if (p != k) {
+            for (int j = 0; j < n; ++j) { double t = A[k * n + j]; A[k * n + j] = A[p * n + j]; A[p * n + j] = t; }
+            for (int j = 0; j < n; ++j) { double t = A[j * n + k]; A[j * n + k] = A[j * n + p]; A[j * n + p] = t; }
+            { double t = b[k]; b[k] = b[p]; b[p] = t; }
+            { int t = perm[k]; perm[k] = perm[p]; perm[p] = t; }
+        }
+        const double d = A[k * n + k];
+        if (fabs(d) <= tol) continue;
+        for (int i = k + 1; i < n; ++i) {
+            const double l = A[i * n + k] / d;
+            for (int j = k + 1; j < n; ++j) A[i * n + j] -= l * A[k * n + j];
+            A[i * n + k] = l; /* store L */
+        }
+    }
+    /* forward: L y = b */
+    double y[6];
+    for (int i = 0; i < n; ++i) {
+        double s = b[i];
+        for (int j = 0; j < i; ++j) s -= A[i * n + j] * y[j];
+        y[i] = s;
+    }
+    /* diagonal */
+    for (int i = 0; i < n; ++i) y[i] = (fabs(A[i * n + i]) > tol) ? y[i] / A[i * n + i] : 0.0;
+    /* backward: L^T z = y */
+    double z[6];
+    for (int i = n - 1; i >= 0; --i) {
+        double s = y[i];
+        for (int j = i + 1; j < n; ++j) s -= A[j * n + i] * z[j];
+        z[i] = s;
+    }
+    for (int i = 0; i < n; ++i) x[perm[i]] = z[i];
+    return 0;
+}
+
+/* Core/Utils/OdometryProvider.h:32-67 */
+void mfo_rodrigues(const double* w, double* R) {
+    for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    double rx = w[0], ry = w[1], rz = w[2];
+    const double theta = sqrt(rx * rx + ry * ry + rz * rz);
+    if (theta >= 2.2204460492503131e-16) {
+        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        const double c = cos(theta), s = sin(theta), c1 = 1. - c;
+        const double itheta = theta ? 1. / theta : 0.;
+        rx *= itheta; ry *= itheta; rz *= itheta;
+        const double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+        const double rx_[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+        for (int k = 0; k < 9; ++k) R[k] = c * I[k] + c1 * rrt[k] + s * rx_[k];
+    }
+}
+
+/* Core/Utils/OdometryProvider.h:69-90 (the float Isometry out-parameter is derived by the caller) */
+void mfo_update_se3(double* resultRt, const double* x6) {
+    double Rt[16], R[9], out[16];
+    mfo_rodrigues(x6 + 3, R);
+    for (int k = 0; k < 16; ++k) Rt[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) Rt[r * 4 + c] = R[r * 3 + c];
+        Rt[r * 4 + 3] = x6[r];
+    }
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            double s = 0;
+            for (int k = 0; k < 4; ++k) s += Rt[r * 4 + k] * resultRt[k * 4 + c];
+            out[r * 4 + c] = s;
+        }
+    memcpy(resultRt, out, sizeof(out));
+}
+
+/* Core/Utils/RGBDOdometry.cpp:227-497, icp && !rgb branch (so3 pre-alignment handled by the caller when the
+ * photometric data exists; here resultRt starts at identity). */
+void mfo_track_icp(const float* const curr_v[3], const float* const curr_n[3], const float* const prev_v[3],
+                   const float* const prev_n[3], int W, int H, float fx, float fy, float cx, float cy,
+                   const mfo_track_opts* o, float* R, float* t, float* out_inc16, float* lastICPError,
+                   float* lastICPCount, mfo_track_log* log) {
+    float Rprev[9], tprev[3], Rcurr[9], tcurr[3], Rprev_inv[9];
+    memcpy(Rprev, R, sizeof(Rprev)); memcpy(tprev, t, sizeof(tprev));
+    memcpy(Rcurr, R, sizeof(Rcurr)); memcpy(tcurr, t, sizeof(tcurr));
+    int iterations[3];
+    iterations[0] = o->fastOdom ? 3 : 10;
+    iterations[1] = o->pyramid ? 5 : 0;
+    iterations[2] = o->pyramid ? 4 : 0;
+    m33_inverse(Rprev, Rprev_inv);
+    double resultRt[16];
+    for (int k = 0; k < 16; ++k) resultRt[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    float trR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, trt[3] = {0, 0, 0}; /* Isometry3f transform */
+    int it = 0;
+    if (log) log->n_iters = 0;
+    for (int i = 2; i >= 0; --i) {
+        const int div = 1 << i;
+        const float lfx = fx / div, lfy = fy / div, lcx = cx / div, lcy = cy / div; /* types.cuh:94-98 */
+        const int lw = W >> i, lh = H >> i;
+        for (int j = 0; j < iterations[i]; ++j) {
+            float A[36], b[6], residual[2];
+            mfo_icp_step(Rcurr, tcurr, curr_v[i], curr_n[i], Rprev_inv, tprev, lfx, lfy, lcx, lcy, prev_v[i],
+                         prev_n[i], o->distThresh, o->angleThresh, lw, lh, A, b, residual);
+            *lastICPError = sqrtf(residual[0]) / residual[1];
+            *lastICPCount = residual[1];
+            double dA[36], db[6], x[6];
+            for (int k = 0; k < 36; ++k) dA[k] = A[k];
+            for (int k = 0; k < 6; ++k) db[k] = b[k];
+            mfo_ldlt_solve(dA, db, x, 6);
+            mfo_update_se3(resultRt, x);
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c) trR[r * 3 + c] = (float)resultRt[r * 4 + c];
+                trt[r] = (float)resultRt[r * 4 + 3];
+            }
+            /* currentT = [Rprev|tprev] * transform.inverse()  (Isometry inverse: R^T, -R^T t) */
+            float iR[9], it3[3];
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) iR[r * 3 + c] = trR[c * 3 + r];
+            f3 itv = m33_mul(iR, f3_make(trt[0], trt[1], trt[2]));
+            it3[0] = -itv.x; it3[1] = -itv.y; it3[2] = -itv.z;
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c)
+                    Rcurr[r * 3 + c] = Rprev[r * 3 + 0] * iR[0 * 3 + c] + Rprev[r * 3 + 1] * iR[1 * 3 + c] +
+                                       Rprev[r * 3 + 2] * iR[2 * 3 + c];
+            }
+            f3 tv = m33_mul(Rprev, f3_make(it3[0], it3[1], it3[2]));
+            tcurr[0] = tv.x + tprev[0]; tcurr[1] = tv.y + tprev[1]; tcurr[2] = tv.z + tprev[2];
+            if (log && it < 19) {
+                memcpy(log->A[it], A, sizeof(A)); memcpy(log->b[it], b, sizeof(b));
+                memcpy(log->residual[it], residual, sizeof(residual)); memcpy(log->x[it], x, sizeof(x));
+                log->n_iters = it + 1;
+            }
+            ++it;
+        }
+    }
+    memcpy(R, Rcurr, sizeof(Rcurr)); memcpy(t, tcurr, sizeof(tcurr));
+    if (out_inc16) Rt_to_pose16(trR, trt, out_inc16);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * surfel helpers (Core/Shaders/color_encoding.glsl, surfels.glsl)
+ * ---------------------------------------------------------------------------------------------- */
+float mfo_encode_color(float r, float g, float b) {
+    int rgb = (int)roundf(r * 255.0f);
+    rgb = (rgb << 8) + (int)roundf(g * 255.0f);
+    rgb = (rgb << 8) + (int)roundf(b * 255.0f);
+    return (float)rgb;
+}
+void mfo_decode_color(float c, float* rgb) {
+    const int ci = (int)c;
+    rgb[0] = (float)((ci >> 16) & 0xFF) / 255.0f;
+    rgb[1] = (float)((ci >> 8) & 0xFF) / 255.0f;
+    rgb[2] = (float)(ci & 0xFF) / 255.0f;
+}
+float mfo_get_radius(float depth, float norm_z, float fx, float fy) {
+    /* cam.z = 1/fx, cam.w = 1/fy  => meanFocal = (fx' + fy')/2 with fx' = 1/(1/fx) */
+    const float camz = 1.0f / fx, camw = 1.0f / fy;
+    const float meanFocal = ((1.0f / fabsf(camz)) + (1.0f / fabsf(camw))) / 2.0f;
+    const float sqrt2 = 1.41421356237f;
+    const float radius = (depth / meanFocal) * sqrt2;
+    float radius_n = radius / fabsf(norm_z);
+    radius_n = fminf(2.0f * radius, radius_n);
+    return radius_n;
+}
+float mfo_confidence(float x, float y, float weighting, float cx, float cy) {
+    const float maxRadDist = 400.f;        /* quirk Q6 */
+    const float twoSigmaSquared = 0.72f;
+    const float dx = x - cx, dy = y - cy;
+    const float radialDist = sqrtf(dx * dx + dy * dy) / maxRadDist;
+    return expf(-(radialDist * radialDist) / twoSigmaSquared) * weighting;
+}
+
+/* nearest fetch with GL_CLAMP_TO_EDGE */
+static inline float texf(const float* img, int W, int H, int x, int y) {
+    return img[iclamp(y, 0, H - 1) * W + iclamp(x, 0, W - 1)];
+}
+/* geometry.glsl:21-26, float-coordinate overload; cam = (cx, cy, 1/fx, 1/fy) */
+static inline f3 get_vertex_f(const float* depth, int W, int H, int px, int py, float x, float y, const mfo_cam* c) {
+    const float z = texf(depth, W, H, px, py);
+    return f3_make((x - c->cx) * z * (1.0f / c->fx), (y - c->cy) * z * (1.0f / c->fy), z);
+}
+/* geometry.glsl:28-40 central differences */
+static inline f3 get_normal_central(const float* depth, const mfo_cam* c, int px, int py, float x, float y, f3 vPos) {
+    const int W = c->W, H = c->H;
+    const f3 xf = get_vertex_f(depth, W, H, px + 1, py, x + 1, y, c);
+    const f3 xb = get_vertex_f(depth, W, H, px - 1, py, x - 1, y, c);
+    const f3 yf = get_vertex_f(depth, W, H, px, py + 1, x, y + 1, c);
+    const f3 yb = get_vertex_f(depth, W, H, px, py - 1, x, y - 1, c);
+    const f3 del_x = f3_sub(f3_scale(f3_add(xb, vPos), 0.5f), f3_scale(f3_add(xf, vPos), 0.5f));
+    const f3 del_y = f3_sub(f3_scale(f3_add(yb, vPos), 0.5f), f3_scale(f3_add(yf, vPos), 0.5f));
+    return f3_glnormalize(f3_cross(del_x, del_y));
+}
+/* geometry.glsl:42-62 int overloads: forward differences */
+static inline f3 get_normal_forward(const float* depth, const mfo_cam* c, int px, int py, f3 vPos) {
+    const int W = c->W, H = c->H;
+    const f3 vx = get_vertex_f(depth, W, H, px + 1, py, (float)(px + 1), (float)py, c);
+    const f3 vy = get_vertex_f(depth, W, H, px, py + 1, (float)px, (float)(py + 1), c);
+    return f3_glnormalize(f3_cross(f3_sub(vx, vPos), f3_sub(vy, vPos)));
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a21: first-frame initialisation
+ * ---------------------------------------------------------------------------------------------- */
+int mfo_init_surfels(const mfo_cam* c, const uint8_t* rgb, const float* depthRaw, const float* depthF, int tick,
+                     float maxDepth, float* surfels, int capacity) {
+    const int W = c->W, H = c->H;
+    int count = 0;
+    for (int i = 0; i < W; ++i) {          /* column-major: FeedbackBuffer.cpp:44-50 */
+        for (int j = 0; j < H; ++j) {
+            const float x = (float)i + 0.5f, y = (float)j + 0.5f;
+            const f3 vraw = get_vertex_f(depthRaw, W, H, i, j, x, y, c);
+            if (vraw.z <= 0 || vraw.z > maxDepth) continue;  /* vertex_feedback.vert:53-60, .geom:35 */
+            if (count >= capacity) return count;
+            const f3 vfil = get_vertex_f(depthF, W, H, i, j, x, y, c);
+            const f3 n = get_normal_central(depthF, c, i, j, x, y, vfil);
+            float* s = surfels + (size_t)count * 12;
+            s[0] = vraw.x; s[1] = vraw.y; s[2] = vraw.z;
+            s[3] = mfo_confidence(x, y, 1.0f, c->cx, c->cy);
+            const uint8_t* p = rgb + (size_t)(j * W + i) * 3;
+            s[4] = (float)((p[0] << 16) + (p[1] << 8) + p[2]); /* encodeColor of c/255 texels */
+            s[5] = 0.f;
+            s[6] = 1.f;            /* init_unstable.vert:34 */
+            s[7] = (float)tick;    /* vertex_feedback.vert:68 */
+            s[8] = n.x; s[9] = n.y; s[10] = n.z;
+            s[11] = mfo_get_radius(vfil.z, n.z, c->fx, c->fy);
+            ++count;
+        }
+    }
+    return count;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a13: index map (index_map.vert/.frag; ModelProjection.cpp:100-152)
+ * Raster rule (documented): 1-px point -> texel floor(u), floor(v); z-test LESS on the float z, first
+ * (lowest index) surfel wins ties.
+ * ---------------------------------------------------------------------------------------------- */
+void mfo_predict_indices(const mfo_cam* c, const float* pose16, const float* surfels, int count, int time,
+                         float maxDepth, int timeDelta, int32_t* index, float* vertConf, float* colorTime,
+                         float* normRad) {
+    const int W = c->W, H = c->H, P = W * H;
+    float R[9], t[3], Ri[9], ti[3];
+    pose16_to_Rt(pose16, R, t);
+    pose_inverse_Rt(R, t, Ri, ti);
+    float* zbuf = (float*)malloc(sizeof(float) * P);
+    for (int i = 0; i < P; ++i) zbuf[i] = INFINITY;
+    memset(index, 0, sizeof(int32_t) * P);
+    memset(vertConf, 0, sizeof(float) * 4 * P);
+    memset(colorTime, 0, sizeof(float) * 4 * P);
+    memset(normRad, 0, sizeof(float) * 4 * P);
+    for (int i = 0; i < count; ++i) {
+        const float* s = surfels + (size_t)i * 12;
+        f3 h = m33_mul(Ri, f3_make(s[0], s[1], s[2]));
+        h = f3_make(h.x + ti[0], h.y + ti[1], h.z + ti[2]);
+        if (h.z > maxDepth || h.z <= 0 || (float)time - s[7] > (float)timeDelta) continue;
+        const float u = ((c->fx * h.x) / h.z) + c->cx;
+        const float v = ((c->fy * h.y) / h.z) + c->cy;
+        if (!(u >= 0.f && u < (float)W && v >= 0.f && v < (float)H)) continue;
+        const int px = (int)floorf(u), py = (int)floorf(v);
+        const int p = py * W + px;
+        if (!(h.z < zbuf[p])) continue;
+        zbuf[p] = h.z;
+        index[p] = i;
+        vertConf[p * 4 + 0] = h.x; vertConf[p * 4 + 1] = h.y; vertConf[p * 4 + 2] = h.z; vertConf[p * 4 + 3] = s[3];
+        memcpy(colorTime + p * 4, s + 4, 4 * sizeof(float));
+        const f3 n = f3_glnormalize(m33_mul(Ri, f3_make(s[8], s[9], s[10])));
+        normRad[p * 4 + 0] = n.x; normRad[p * 4 + 1] = n.y; normRad[p * 4 + 2] = n.z; normRad[p * 4 + 3] = s[11];
+    }
+    free(zbuf);
+}
+
+/* Window rule for data.vert:139-141 (documented oracle rule): pixel-centre offsets
+ * {-1,-0.5,0,+0.5} map to texels {x-1, x, x, x+1}. */
+static const int kWinPix[4] = {-1, 0, 0, 1};
+
+/* ------------------------------------------------------------------------------------------------
+ * a14 part 1: data association (data.vert; Model.cpp:466-581)
+ * Candidate enumeration: quarter-rate pixels (x%2 == t%2 && y%2 == t%2) in column-major order:
+ *   c = xi * nyc + yi, x = 2*xi + (t&1), y = 2*yi + (t&1), nxc = (W - (t&1) + 1)/2, nyc = (H - (t&1) + 1)/2.
+ * ---------------------------------------------------------------------------------------------- */
+void mfo_fuse_data(const mfo_cam* c, const float* pose16, const uint8_t* rgb, const float* depthRaw,
+                   const float* depthF, const uint8_t* mask, int maskID, int time, float weighting, float maxDepth,
+                   const int32_t* index, const float* vertConf, const float* normRad, uint8_t* cand_op,
+                   int32_t* cand_best, float* cand_rec, int* n_cand) {
+    const int W = c->W, H = c->H;
+    const int par = time & 1;
+    const int nxc = (W - par + 1) / 2, nyc = (H - par + 1) / 2;
+    *n_cand = nxc * nyc;
+    float R[9], t[3];
+    pose16_to_Rt(pose16, R, t);
+#pragma omp parallel for schedule(static)
+    for (int xi = 0; xi < nxc; ++xi) {
+        for (int yi = 0; yi < nyc; ++yi) {
+            const int cidx = xi * nyc + yi;
+            const int px = 2 * xi + par, py = 2 * yi + par;
+            cand_op[cidx] = 0;
+            cand_best[cidx] = 0;
+            const float x = (float)px + 0.5f, y = (float)py + 0.5f;
+            const f3 vLocal = get_vertex_f(depthRaw, W, H, px, py, x, y, c);
+            if (mask[py * W + px] != maskID) continue;
+            /* checkNeighbours: data.vert:53-72 */
+            if (texf(depthRaw, W, H, px - 1, py) == 0 || texf(depthRaw, W, H, px, py - 1) == 0 ||
+                texf(depthRaw, W, H, px + 1, py) == 0 || texf(depthRaw, W, H, px, py + 1) == 0)
+                continue;
+            if (!(vLocal.z > 0 && vLocal.z <= maxDepth)) continue;
+
+            const f3 vGlobal3 = m33_mul(R, vLocal);
+            const f3 vGlobal = f3_make(vGlobal3.x + t[0], vGlobal3.y + t[1], vGlobal3.z + t[2]);
+            const f3 vF = get_vertex_f(depthF, W, H, px, py, x, y, c);
+            const f3 nLocal = get_normal_central(depthF, c, px, py, x, y, vF);
+            const f3 nGlobal = m33_mul(R, nLocal);
+            const uint8_t* pc = rgb + (size_t)(py * W + px) * 3;
+
+            float* rec = cand_rec + (size_t)cidx * 12;
+            rec[0] = vGlobal.x; rec[1] = vGlobal.y; rec[2] = vGlobal.z;
+            rec[3] = mfo_confidence(x, y, weighting, c->cx, c->cy);
+            rec[4] = (float)((pc[0] << 16) + (pc[1] << 8) + pc[2]);
+            rec[5] = 0.f;
+            rec[6] = (float)time;
+            rec[8] = nGlobal.x; rec[9] = nGlobal.y; rec[10] = nGlobal.z;
+            rec[11] = mfo_get_radius(vF.z, nLocal.z, c->fx, c->fy);
+
+            const float xl = (x - c->cx) * (1.0f / c->fx), yl = (y - c->cy) * (1.0f / c->fy);
+            const float lambda = sqrtf(xl * xl + yl * yl + 1);
+            const f3 ray = f3_make(xl, yl, 1);
+            float bestDist = 1000;
+            int best = 0, operation = 0;
+            for (int a = 0; a < 4; ++a) {
+                for (int b = 0; b < 4; ++b) {
+                    const int tx = iclamp(px + kWinPix[a], 0, W - 1), ty = iclamp(py + kWinPix[b], 0, H - 1);
+                    const int tp = ty * W + tx;
+                    const int current = index[tp];
+                    if (current > 0) {
+                        const float* vc = vertConf + tp * 4;
+                        const float zdiff = vc[2] - vLocal.z;
+                        if (fabsf(zdiff * lambda) < 0.05f) {
+                            const float dist = f3_norm(f3_cross(ray, f3_make(vc[0], vc[1], vc[2])));
+                            const float* nr = normRad + tp * 4;
+                            const f3 nn = f3_make(nr[0], nr[1], nr[2]);
+                            const float ang = acosf(f3_dot(nn, nLocal) / (f3_norm(nn) * f3_norm(nLocal)));
+                            if (dist < bestDist && (fabsf(nr[2]) < 0.75f || fabsf(ang) < 0.5f)) {
+                                operation = 1; bestDist = dist; best = current;
+                            }
+                        }
+                    }
+                }
+            }
+            if (operation == 1) { cand_op[cidx] = 1; cand_best[cidx] = best; rec[7] = -1.f; }
+            else { cand_op[cidx] = 2; rec[7] = -2.f; }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a14 part 2: update (update.vert; Model.cpp:583-646).  First writer in candidate order wins.
+ * ---------------------------------------------------------------------------------------------- */
+void mfo_fuse_update(const float* src, float* dst, int count, int time, const uint8_t* cand_op,
+                     const int32_t* cand_best, const float* cand_rec, int n_cand) {
+    int32_t* first = (int32_t*)malloc(sizeof(int32_t) * (count > 0 ? count : 1));
+    for (int i = 0; i < count; ++i) first[i] = -1;
+    for (int c = 0; c < n_cand; ++c)
+        if (cand_op[c] == 1) {
+            const int b = cand_best[c];
+            if (b >= 0 && b < count && first[b] < 0) first[b] = c;
+        }
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < count; ++i) {
+        const float* s = src + (size_t)i * 12;
+        float* d = dst + (size_t)i * 12;
+        memcpy(d, s, 12 * sizeof(float));
+        if (first[i] < 0) continue;
+        const float* m = cand_rec + (size_t)first[i] * 12;
+        const float c_k = s[3], a = m[3];
+        if (m[11] < (1.0f + 0.5f) * s[11]) {
+            for (int k = 0; k < 3; ++k) d[k] = ((c_k * s[k]) + (a * m[k])) / (c_k + a);
+            d[3] = c_k + a;
+            float oc[3], nc[3];
+            mfo_decode_color(s[4], oc);
+            mfo_decode_color(m[4], nc);
+            float avg[3];
+            for (int k = 0; k < 3; ++k) avg[k] = ((c_k * oc[k]) + (a * nc[k])) / (c_k + a);
+            d[4] = mfo_encode_color(avg[0], avg[1], avg[2]);
+            d[5] = s[5]; d[6] = s[6]; d[7] = (float)time;
+            float nr[4];
+            for (int k = 0; k < 4; ++k) nr[k] = ((c_k * s[8 + k]) + (a * m[8 + k])) / (c_k + a);
+            const f3 nn = f3_glnormalize(f3_make(nr[0], nr[1], nr[2]));
+            d[8] = nn.x; d[9] = nn.y; d[10] = nn.z; d[11] = nr[3];
+        } else {
+            d[3] = c_k + a;
+            d[7] = (float)time;
+        }
+    }
+    free(first);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a16: clean (copy_unstable.vert:53-157, .geom; Model.cpp:649-772); deformation block inert (nodes == 0).
+ * ---------------------------------------------------------------------------------------------- */
+static int clean_one(const mfo_cam* c, const float* Ri, const float* ti, const float* in, float* out, int time,
+                     int timeDelta, float confThreshold, float outlierCoeff, int maskID, const int32_t* index,
+                     const float* vertConf, const float* colorTime, const float* depthF, const uint8_t* mask) {
+    const int W = c->W, H = c->H;
+    memcpy(out, in, 12 * sizeof(float));
+    int test = 1;
+    f3 lp = m33_mul(Ri, f3_make(in[0], in[1], in[2]));
+    lp = f3_make(lp.x + ti[0], lp.y + ti[1], lp.z + ti[2]);
+    const float x = ((c->fx * lp.x) / lp.z) + c->cx;
+    const float y = ((c->fy * lp.y) / lp.z) + c->cy;
+    const f3 ln = f3_glnormalize(m33_mul(Ri, f3_make(in[8], in[9], in[10])));
+    int count = 0, zCount = 0;
+    if ((float)time - in[7] < (float)timeDelta && lp.z > 0 && x > 0 && y > 0 && x < (float)W && y < (float)H) {
+        static const float off[4] = {-1.0f, -0.5f, 0.0f, 0.5f};
+        for (int a = 0; a < 4; ++a) {
+            for (int b = 0; b < 4; ++b) {
+                const int tx = iclamp((int)floorf(x + off[a]), 0, W - 1);
+                const int ty = iclamp((int)floorf(y + off[b]), 0, H - 1);
+                const int tp = ty * W + tx;
+                if (index[tp] > 0) {
+                    const float* vc = vertConf + tp * 4;
+                    const float* ct = colorTime + tp * 4;
+                    const float dx = vc[0] - lp.x, dy = vc[1] - lp.y;
+                    if (ct[2] < in[6] && vc[3] > confThreshold && vc[2] > lp.z && vc[2] - lp.z < 0.01f &&
+                        sqrtf(dx * dx + dy * dy) < in[11] * 1.4f)
+                        count++;
+                    if (ct[3] == (float)time && vc[3] > confThreshold && vc[2] > lp.z && vc[2] - lp.z > 0.01f &&
+                        fabsf(ln.z) > 0.85f)
+                        zCount++;
+                }
+            }
+        }
+    }
+    if (count > 8 || zCount > 4) test = 0;
+    if (out[7] == -2.f) out[7] = (float)time;
+    if (out[7] == -1.f || (((float)time - out[7]) > 20 && out[3] < confThreshold)) test = 0;
+    if (out[7] > 0 && (float)time - out[7] > (float)timeDelta) test = 1;
+
+    /* mask-disagreement decay (copy_unstable.vert:139-156); nearest fetch, clamp-to-edge, NaN -> texel 0 */
+    int fx_ = isnan(x) ? 0 : iclamp((int)fminf(fmaxf(floorf(x), -1.f), (float)W), 0, W - 1);
+    int fy_ = isnan(y) ? 0 : iclamp((int)fminf(fmaxf(floorf(y), -1.f), (float)H), 0, H - 1);
+    const float wDepth = depthF[fy_ * W + fx_];
+    const int maskValue = mask[fy_ * W + fx_];
+    if (maskValue != maskID && maskValue < 255 && (wDepth > lp.z - 0.05f && wDepth < lp.z + 0.05f)) {
+        const float k = 0.5f + 0.5f * (1 - outlierCoeff / 10.0f);
+        if (maskValue == 0) out[3] *= k;
+        else if (maskID == 0) out[3] *= 0.25f * k;
+        else out[3] *= k;
+    }
+    return test;
+}
+
+int mfo_clean(const mfo_cam* c, const float* pose16, const float* src, int count, const uint8_t* cand_op,
+              const float* cand_rec, int n_cand, int time, int timeDelta, float confThreshold, float maxDepth,
+              float outlierCoeff, int maskID, const int32_t* index, const float* vertConf, const float* colorTime,
+              const float* normRad, const float* depthF, const uint8_t* mask, float* dst, int capacity) {
+    (void)maxDepth; (void)normRad; /* uniforms set but unused by the live part of the shader */
+    float R[9], t[3], Ri[9], ti[3];
+    pose16_to_Rt(pose16, R, t);
+    pose_inverse_Rt(R, t, Ri, ti);
+    const int total = count + n_cand;
+    uint8_t* keep = (uint8_t*)malloc((size_t)(total > 0 ? total : 1));
+    float* tmp = (float*)malloc(sizeof(float) * 12 * (size_t)(total > 0 ? total : 1));
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < total; ++i) {
+        const float* in;
+        if (i < count) in = src + (size_t)i * 12;
+        else {
+            const int cidx = i - count;
+            if (cand_op[cidx] != 2) { keep[i] = 0; continue; } /* op==1 records carry w=-1 and are dropped */
+            in = cand_rec + (size_t)cidx * 12;
+        }
+        keep[i] = (uint8_t)clean_one(c, Ri, ti, in, tmp + (size_t)i * 12, time, timeDelta, confThreshold,
+                                     outlierCoeff, maskID, index, vertConf, colorTime, depthF, mask);
+    }
+    int n = 0;
+    for (int i = 0; i < total && n < capacity; ++i)
+        if (keep[i]) { memcpy(dst + (size_t)n * 12, tmp + (size_t)i * 12, 12 * sizeof(float)); ++n; }
+    free(keep); free(tmp);
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a17: splat prediction (splat.vert:54-88, combo_splat.frag:37-65; ModelProjection.cpp:187-268)
+ * Raster rule (documented): sprite side s centred on the projected centre (u,v) covers pixel (px,py) iff
+ * u - s/2 <= px+0.5 < u + s/2 (same in y); z-test LESS on the corrected z; first surfel wins ties.
+ * Sprites wider than MFO_MAX_SPRITE px are clamped (GL_POINT_SIZE_RANGE stand-in).
+ * ---------------------------------------------------------------------------------------------- */
+#define MFO_MAX_SPRITE 64.0f
+void mfo_combined_predict(const mfo_cam* c, const float* pose16, const float* surfels, int count, float maxDepth,
+                          float confThreshold, int time, int maxTime, int timeDelta, uint8_t* image,
+                          float* vertexConf, float* normalRad, uint16_t* timeMap) {
+    const int W = c->W, H = c->H, P = W * H;
+    float R[9], t[3], Ri[9], ti[3];
+    pose16_to_Rt(pose16, R, t);
+    pose_inverse_Rt(R, t, Ri, ti);
+    float* zbuf = (float*)malloc(sizeof(float) * P);
+    for (int i = 0; i < P; ++i) zbuf[i] = INFINITY;
+    memset(image, 0, (size_t)P * 4);
+    memset(vertexConf, 0, sizeof(float) * 4 * P);
+    memset(normalRad, 0, sizeof(float) * 4 * P);
+    memset(timeMap, 0, sizeof(uint16_t) * P);
+    for (int i = 0; i < count; ++i) {
+        const float* s = surfels + (size_t)i * 12;
+        f3 h = m33_mul(Ri, f3_make(s[0], s[1], s[2]));
+        h = f3_make(h.x + ti[0], h.y + ti[1], h.z + ti[2]);
+        if (h.z > maxDepth || h.z < 0 || s[3] < confThreshold || (float)time - s[7] > (float)timeDelta ||
+            s[7] > (float)maxTime)
+            continue;
+        const float u = ((c->fx * h.x) / h.z) + c->cx, v = ((c->fy * h.y) / h.z) + c->cy;
+        if (!(u >= 0.f && u <= (float)W && v >= 0.f && v <= (float)H)) continue; /* point clipped by centre */
+        const f3 n = f3_glnormalize(m33_mul(Ri, f3_make(s[8], s[9], s[10])));
+        const float rad = s[11];
+        const f3 x1 = f3_scale(f3_glnormalize(f3_make(n.y - n.z, -n.x, n.x)), rad * 1.41421356f);
+        const f3 y1 = f3_cross(n, x1);
+        float xs0 = INFINITY, xs1 = -INFINITY, ys0 = INFINITY, ys1 = -INFINITY;
+        const f3 corners[4] = {f3_add(h, x1), f3_add(h, y1), f3_sub(h, y1), f3_sub(h, x1)};
+        for (int k = 0; k < 4; ++k) {
+            const float pxk = ((c->fx * corners[k].x) / corners[k].z) + c->cx;
+            const float pyk = ((c->fy * corners[k].y) / corners[k].z) + c->cy;
+            xs0 = fminf(xs0, pxk); xs1 = fmaxf(xs1, pxk);
+            ys0 = fminf(ys0, pyk); ys1 = fmaxf(ys1, pyk);
+        }
+        float size = fmaxf(0.f, fmaxf(fabsf(xs1 - xs0), fabsf(ys1 - ys0)));
+        if (!(size > 0.f)) continue; /* also drops NaN sizes */
+        size = fminf(size, MFO_MAX_SPRITE);
+        const float half = size * 0.5f;
+        const int px0 = imax(0, (int)ceilf(u - half - 0.5f)), px1 = imin(W - 1, (int)ceilf(u + half - 0.5f) - 1);
+        const int py0 = imax(0, (int)ceilf(v - half - 0.5f)), py1 = imin(H - 1, (int)ceilf(v + half - 0.5f) - 1);
+        const float sqrRad = rad * rad;
+        const float pn = f3_dot(h, n);
+        for (int py = py0; py <= py1; ++py) {
+            for (int px = px0; px <= px1; ++px) {
+                const float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;
+                const f3 l = f3_glnormalize(f3_make((fcx - c->cx) / c->fx, (fcy - c->cy) / c->fy, 1.0f));
+                const f3 cp = f3_scale(l, pn / f3_dot(l, n));
+                const f3 diff = f3_sub(cp, h);
+                if (!(f3_dot(diff, diff) <= sqrRad)) continue; /* discard if > (NaN discards too: see note) */
+                const float z = cp.z;
+                const int p = py * W + px;
+                if (!(z < zbuf[p])) continue;
+                zbuf[p] = z;
+                const int ci = (int)s[4];
+                image[p * 4 + 0] = (uint8_t)((ci >> 16) & 0xFF);
+                image[p * 4 + 1] = (uint8_t)((ci >> 8) & 0xFF);
+                image[p * 4 + 2] = (uint8_t)(ci & 0xFF);
+                image[p * 4 + 3] = 255;
+                vertexConf[p * 4 + 0] = (fcx - c->cx) * z * (1.f / c->fx);
+                vertexConf[p * 4 + 1] = (fcy - c->cy) * z * (1.f / c->fy);
+                vertexConf[p * 4 + 2] = z;
+                vertexConf[p * 4 + 3] = s[3];
+                normalRad[p * 4 + 0] = n.x; normalRad[p * 4 + 1] = n.y; normalRad[p * 4 + 2] = n.z;
+                normalRad[p * 4 + 3] = rad;
+                timeMap[p] = (uint16_t)(unsigned)s[6];
+            }
+        }
+    }
+    free(zbuf);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a18: fill-in (fill_vertex.frag:37-53, fill_normal.frag:34-50, fill_rgb.frag:29-37; FillIn.cpp)
+ * ---------------------------------------------------------------------------------------------- */
+void mfo_fill_in(const mfo_cam* c, const uint8_t* predImage, const float* predVertex, const float* predNormal,
+                 const uint8_t* rawRgb, const float* rawDepth, int passthrough, uint8_t* fillImage,
+                 float* fillVertex, float* fillNormal) {
+    const int W = c->W, H = c->H;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; ++y) {
+        for (int x = 0; x < W; ++x) {
+            const int p = y * W + x;
+            if (predVertex[p * 4 + 2] == 0 || passthrough) {
+                const float z = rawDepth[p];
+                fillVertex[p * 4 + 0] = ((float)x - c->cx) * z * (1.0f / c->fx);
+                fillVertex[p * 4 + 1] = ((float)y - c->cy) * z * (1.0f / c->fy);
+                fillVertex[p * 4 + 2] = z;
+                fillVertex[p * 4 + 3] = 1.f;
+            } else memcpy(fillVertex + p * 4, predVertex + p * 4, 4 * sizeof(float));
+            if (predNormal[p * 4 + 2] == 0 || passthrough) {
+                const f3 vp = get_vertex_f(rawDepth, W, H, x, y, (float)x, (float)y, c);
+                const f3 n = get_normal_forward(rawDepth, c, x, y, vp);
+                fillNormal[p * 4 + 0] = n.x; fillNormal[p * 4 + 1] = n.y; fillNormal[p * 4 + 2] = n.z;
+                fillNormal[p * 4 + 3] = 1.f;
+            } else memcpy(fillNormal + p * 4, predNormal + p * 4, 4 * sizeof(float));
+            if ((predImage[p * 4] == 0 && predImage[p * 4 + 1] == 0 && predImage[p * 4 + 2] == 0) || passthrough) {
+                fillImage[p * 4 + 0] = rawRgb[p * 3 + 0]; fillImage[p * 4 + 1] = rawRgb[p * 3 + 1];
+                fillImage[p * 4 + 2] = rawRgb[p * 3 + 2]; fillImage[p * 4 + 3] = 255;
+            } else memcpy(fillImage + p * 4, predImage + p * 4, 4);
+        }
+    }
+}
+
+/* MaskFusion.cpp:630-648 + GPUResize::image (nearest; the output texel (i,j) of the W/20 x H/20 target samples
+ * source texel (20i+10, 20j+10)). */
+int mfo_requires_fill_in(const uint8_t* predImage, int W, int H, float ratio) {
+    const int cs = 20, rw = W / cs, rh = H / cs;
+    int sum = 0;
+    for (int j = 0; j < rh; ++j)
+        for (int i = 0; i < rw; ++i) {
+            const uint8_t* p = predImage + (size_t)((j * cs + cs / 2) * W + (i * cs + cs / 2)) * 4;
+            sum += (p[0] > 0 && p[1] > 0 && p[2] > 0);
+        }
+    return (float)sum / (float)(rw * rh) < ratio;
+}
+
+/* Model.cpp:449-464; rodrigues2 :891-932 (the SVD re-orthonormalisation U V^T is replaced by Newton polar
+ * iterations, identical to rounding for the near-rotations that occur). */
+static void rodrigues2(const float* Rin, double* r) {
+    double R[9], Rn[9];
+    for (int k = 0; k < 9; ++k) R[k] = Rin[k];
+    for (int it = 0; it < 4; ++it) { /* R <- (R + R^-T)/2 */
+        const double c00 = R[4] * R[8] - R[5] * R[7], c01 = R[5] * R[6] - R[3] * R[8], c02 = R[3] * R[7] - R[4] * R[6];
+        const double det = R[0] * c00 + R[1] * c01 + R[2] * c02;
+        double cof[9] = {c00, c01, c02,
+                         R[2] * R[7] - R[1] * R[8], R[0] * R[8] - R[2] * R[6], R[1] * R[6] - R[0] * R[7],
+                         R[1] * R[5] - R[2] * R[4], R[2] * R[3] - R[0] * R[5], R[0] * R[4] - R[1] * R[3]};
+        for (int k = 0; k < 9; ++k) Rn[k] = 0.5 * (R[k] + cof[k] / det); /* cof/det = R^-T */
+        memcpy(R, Rn, sizeof(R));
+    }
+    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double cth = (R[0] + R[4] + R[8] - 1) * 0.5;
+    cth = cth > 1. ? 1. : cth < -1. ? -1. : cth;
+    double theta = acos(cth);
+    if (s < 1e-5) {
+        if (cth > 0) rx = ry = rz = 0;
+        else {
+            double tt = (R[0] + 1) * 0.5;
+            rx = sqrt(fmax(tt, 0.0));
+            tt = (R[4] + 1) * 0.5;
+            ry = sqrt(fmax(tt, 0.0)) * (R[1] < 0 ? -1.0 : 1.0);
+            tt = (R[8] + 1) * 0.5;
+            rz = sqrt(fmax(tt, 0.0)) * (R[2] < 0 ? -1.0 : 1.0);
+            if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
+            theta /= sqrt(rx * rx + ry * ry + rz * rz);
+            rx *= theta; ry *= theta; rz *= theta;
+        }
+    } else {
+        const double vth = 1 / (2 * s) * theta;
+        rx *= vth; ry *= vth; rz *= vth;
+    }
+    r[0] = rx; r[1] = ry; r[2] = rz;
+}
+
+float mfo_fusion_weight(const float* pose16, const float* lastPose16, float weightMultiplier) {
+    float R[9], t[3], Rl[9], tl[3], Ri[9], ti[3], Rd[9];
+    pose16_to_Rt(pose16, R, t);
+    pose16_to_Rt(lastPose16, Rl, tl);
+    pose_inverse_Rt(R, t, Ri, ti);
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+            Rd[r * 3 + c] = Ri[r * 3] * Rl[c] + Ri[r * 3 + 1] * Rl[3 + c] + Ri[r * 3 + 2] * Rl[6 + c];
+    f3 td = m33_mul(Ri, f3_make(tl[0], tl[1], tl[2]));
+    td = f3_make(td.x + ti[0], td.y + ti[1], td.z + ti[2]);
+    double rv[3];
+    rodrigues2(Rd, rv);
+    const float rn = (float)sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+    float weighting = fmaxf(f3_norm(td), rn);
+    const float largest = 0.01f, minWeight = 0.5f;
+    if (weighting > largest) weighting = largest;
+    weighting = fmaxf(1.0f - (weighting / largest), minWeight) * weightMultiplier;
+    return weighting;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a1: MaskFusion::processFrame, -static (single background model).  Core/MaskFusion.cpp:200-607.
+ * ---------------------------------------------------------------------------------------------- */
+struct mfo_ctx {
+    mfo_config cfg;
+    mfo_cam cam;
+    int tick;
+    float pose[16], lastPose[16];
+    int count;
+    float* surf[2];
+    int cur; /* index of the live surfel buffer */
+    /* frame images */
+    uint8_t* rgb; float* depth; float* depthF; uint8_t* mask;
+    /* current-frame pyramid (Model::GPUSetup) */
+    float* depthPyr[3]; float* vmap[3]; float* nmap[3];
+    /* model-side pyramid (RGBDOdometry) */
+    float* vmap_g[3]; float* nmap_g[3];
+    /* index map */
+    int32_t* index; float* ivc; float* ict; float* inr;
+    /* splat prediction + fill-in */
+    uint8_t* predImage; float* predVertex; float* predNormal; uint16_t* predTime;
+    uint8_t* fillImage; float* fillVertex; float* fillNormal;
+    /* candidates */
+    uint8_t* cand_op; int32_t* cand_best; float* cand_rec; int n_cand;
+    float lastICPError, lastICPCount;
+    int lastFillIn;
+    double tms[8];
+};
+
+void mfo_default_config(mfo_config* c, int W, int H, float fx, float fy, float cx, float cy) {
+    memset(c, 0, sizeof(*c));
+    c->W = W; c->H = H; c->fx = fx; c->fy = fy; c->cx = cx; c->cy = cy;
+    c->timeDelta = 200; c->confGlobal = 4.f; c->depthCutoff = 3.f; c->icpWeight = 10.f;
+    c->maxDepthProcessed = 20.f; c->outlierCoeff = 0.9f;
+    c->fastOdom = 0; c->pyramid = 1; c->so3 = 1;
+    c->capacity = 3072 * 3072;
+}
+
+mfo_ctx* mfo_create(const mfo_config* cfg) {
+    mfo_ctx* x = (mfo_ctx*)calloc(1, sizeof(mfo_ctx));
+    x->cfg = *cfg;
+    x->cam.W = cfg->W; x->cam.H = cfg->H; x->cam.fx = cfg->fx; x->cam.fy = cfg->fy; x->cam.cx = cfg->cx; x->cam.cy = cfg->cy;
+    const int W = cfg->W, H = cfg->H, P = W * H;
+    x->tick = 1;
+    for (int k = 0; k < 16; ++k) x->pose[k] = x->lastPose[k] = (k % 5 == 0) ? 1.f : 0.f;
+    x->surf[0] = (float*)calloc((size_t)cfg->capacity * 12, sizeof(float));
+    x->surf[1] = (float*)calloc((size_t)cfg->capacity * 12, sizeof(float));
+    x->rgb = (uint8_t*)calloc((size_t)P * 3, 1);
+    x->depth = (float*)calloc(P, sizeof(float));
+    x->depthF = (float*)calloc(P, sizeof(float));
+    x->mask = (uint8_t*)calloc(P, 1);
+    for (int i = 0; i < 3; ++i) {
+        const int lp = (W >> i) * (H >> i);
+        x->depthPyr[i] = (float*)calloc(lp, sizeof(float));
+        x->vmap[i] = (float*)calloc((size_t)lp * 3, sizeof(float));
+        x->nmap[i] = (float*)calloc((size_t)lp * 3, sizeof(float));
+        x->vmap_g[i] = (float*)calloc((size_t)lp * 3, sizeof(float));
+        x->nmap_g[i] = (float*)calloc((size_t)lp * 3, sizeof(float));
+    }
+    x->index = (int32_t*)calloc(P, sizeof(int32_t));
+    x->ivc = (float*)calloc((size_t)P * 4, sizeof(float));
+    x->ict = (float*)calloc((size_t)P * 4, sizeof(float));
+    x->inr = (float*)calloc((size_t)P * 4, sizeof(float));
+    x->predImage = (uint8_t*)calloc((size_t)P * 4, 1);
+    x->predVertex = (float*)calloc((size_t)P * 4, sizeof(float));
+    x->predNormal = (float*)calloc((size_t)P * 4, sizeof(float));
+    x->predTime = (uint16_t*)calloc(P, sizeof(uint16_t));
+    x->fillImage = (uint8_t*)calloc((size_t)P * 4, 1);
+    x->fillVertex = (float*)calloc((size_t)P * 4, sizeof(float));
+    x->fillNormal = (float*)calloc((size_t)P * 4, sizeof(float));
+    const int maxc = ((W + 1) / 2) * ((H + 1) / 2);
+    x->cand_op = (uint8_t*)calloc(maxc, 1);
+    x->cand_best = (int32_t*)calloc(maxc, sizeof(int32_t));
+    x->cand_rec = (float*)calloc((size_t)maxc * 12, sizeof(float));
+    return x;
+}
+
+void mfo_destroy(mfo_ctx* x) {
+    if (!x) return;
+    free(x->surf[0]); free(x->surf[1]); free(x->rgb); free(x->depth); free(x->depthF); free(x->mask);
+    for (int i = 0; i < 3; ++i) { free(x->depthPyr[i]); free(x->vmap[i]); free(x->nmap[i]); free(x->vmap_g[i]); free(x->nmap_g[i]); }
+    free(x->index); free(x->ivc); free(x->ict); free(x->inr);
+    free(x->predImage); free(x->predVertex); free(x->predNormal); free(x->predTime);
+    free(x->fillImage); free(x->fillVertex); free(x->fillNormal);
+    free(x->cand_op); free(x->cand_best); free(x->cand_rec);
+    free(x);
+}
+
+/* MaskFusion::predict (MaskFusion.cpp:616-628) for the background model */
+static void oracle_predict(mfo_ctx* x) {
+    const mfo_config* g = &x->cfg;
+    mfo_combined_predict(&x->cam, x->pose, x->surf[x->cur], x->count, g->maxDepthProcessed, g->confGlobal, x->tick,
+                         x->tick, g->timeDelta, x->predImage, x->predVertex, x->predNormal, x->predTime);
+    /* performFillIn(textureRGB, textureDepthMetricFiltered, frameToFrameRGB=false, lost=false) */
+    mfo_fill_in(&x->cam, x->predImage, x->predVertex, x->predNormal, x->rgb, x->depthF, 0, x->fillImage,
+                x->fillVertex, x->fillNormal);
+}
+
+int mfo_process_frame(mfo_ctx* x, const uint8_t* rgb, const float* depth, float weightMultiplier) {
+    const mfo_config* g = &x->cfg;
+    const int W = g->W, H = g->H, P = W * H;
+    double t0 = now_ms();
+    memcpy(x->rgb, rgb, (size_t)P * 3);
+    memcpy(x->depth, depth, sizeof(float) * P);
+    mfo_bilateral(x->depth, x->depthF, W, H);            /* filterDepth, :217 */
+    memset(x->mask, 0, P);                                /* !enableMultipleModels, :223-230 */
+    x->tms[0] += now_ms() - t0;
+
+    if (x->tick == 1) {
+        /* :235-238 */
+        x->cur = 0;
+        x->count = mfo_init_surfels(&x->cam, x->rgb, x->depth, x->depthF, x->tick, g->maxDepthProcessed,
+                                    x->surf[0], g->capacity);
+    } else {
+        /* Model::generateCUDATextures(depthFiltered, mask, K, depthCutoff), Model.cpp:350-389 */
+        t0 = now_ms();
+        memcpy(x->depthPyr[0], x->depthF, sizeof(float) * P);
+        for (int i = 1; i < 3; ++i) mfo_pyrdown_gauss_f(x->depthPyr[i - 1], x->depthPyr[i], W >> (i - 1), H >> (i - 1));
+        for (int i = 0; i < 3; ++i) {
+            const int div = 1 << i;
+            mfo_create_vmap(x->depthPyr[i], x->vmap[i], W >> i, H >> i, g->fx / div, g->fy / div, g->cx / div,
+                            g->cy / div, g->depthCutoff);
+            mfo_create_nmap(x->vmap[i], x->nmap[i], W >> i, H >> i);
+        }
+        x->tms[0] += now_ms() - t0;
+
+        /* Model::performTracking, Model.cpp:427-447 */
+        t0 = now_ms();
+        memcpy(x->lastPose, x->pose, sizeof(x->pose));
+        const int doFillIn = mfo_requires_fill_in(x->predImage, W, H, 0.75f);
+        x->lastFillIn = doFillIn;
+        /* initICPModel, RGBDOdometry.cpp:153-185 */
+        mfo_copy_maps(doFillIn ? x->fillVertex : x->predVertex, doFillIn ? x->fillNormal : x->predNormal,
+                      x->vmap_g[0], x->nmap_g[0], W, H);
+        for (int i = 1; i < 3; ++i) {
+            mfo_resize_map(x->vmap_g[i - 1], x->vmap_g[i], W >> (i - 1), H >> (i - 1), 0);
+            mfo_resize_map(x->nmap_g[i - 1], x->nmap_g[i], W >> (i - 1), H >> (i - 1), 1);
+        }
+        float R[9], t[3];
+        pose16_to_Rt(x->pose, R, t);
+        for (int i = 0; i < 3; ++i)
+            mfo_transform_maps(x->vmap_g[i], x->nmap_g[i], R, t, x->vmap_g[i], x->nmap_g[i], W >> i, H >> i);
+        x->tms[1] += now_ms() - t0;
+
+        t0 = now_ms();
+        mfo_track_opts o;
+        o.pyramid = g->pyramid; o.fastOdom = g->fastOdom; o.so3 = 0; o.rgbOnly = 0; o.icpWeight = g->icpWeight;
+        o.distThresh = 0.10f; o.angleThresh = sinf(20.f * 3.14159254f / 180.f); /* RGBDOdometry.h:35-36 */
+        const float* cv[3] = {x->vmap[0], x->vmap[1], x->vmap[2]};
+        const float* cn[3] = {x->nmap[0], x->nmap[1], x->nmap[2]};
+        const float* pv[3] = {x->vmap_g[0], x->vmap_g[1], x->vmap_g[2]};
+        const float* pn[3] = {x->nmap_g[0], x->nmap_g[1], x->nmap_g[2]};
+        mfo_track_icp(cv, cn, pv, pn, W, H, g->fx, g->fy, g->cx, g->cy, &o, R, t, NULL, &x->lastICPError,
+                      &x->lastICPCount, NULL);
+        Rt_to_pose16(R, t, x->pose);
+        x->tms[2] += now_ms() - t0;
+
+        /* the predict() at :423 only feeds the dead loop-closure block and is overwritten at :569 -- skipped */
+
+        /* fusion, :539-565 */
+        const int src = x->cur, dst = 1 - x->cur;
+        t0 = now_ms();
+        mfo_predict_indices(&x->cam, x->pose, x->surf[src], x->count, x->tick, g->maxDepthProcessed, g->timeDelta,
+                            x->index, x->ivc, x->ict, x->inr);
+        x->tms[3] += now_ms() - t0;
+        t0 = now_ms();
+        const float weighting = mfo_fusion_weight(x->pose, x->lastPose, weightMultiplier);
+        /* Model::fuse maxDepth uniform: min(depthCutoff, model.maxDepth = FLT_MAX, bb_max_z = FLT_MAX) */
+        mfo_fuse_data(&x->cam, x->pose, x->rgb, x->depth, x->depthF, x->mask, 0, x->tick, weighting, g->depthCutoff,
+                      x->index, x->ivc, x->inr, x->cand_op, x->cand_best, x->cand_rec, &x->n_cand);
+        x->tms[4] += now_ms() - t0;
+        t0 = now_ms();
+        mfo_fuse_update(x->surf[src], x->surf[dst], x->count, x->tick, x->cand_op, x->cand_best, x->cand_rec, x->n_cand);
+        x->tms[5] += now_ms() - t0;
+        t0 = now_ms();
+        mfo_predict_indices(&x->cam, x->pose, x->surf[dst], x->count, x->tick, g->maxDepthProcessed, g->timeDelta,
+                            x->index, x->ivc, x->ict, x->inr);
+        x->tms[3] += now_ms() - t0;
+        t0 = now_ms();
+        x->count = mfo_clean(&x->cam, x->pose, x->surf[dst], x->count, x->cand_op, x->cand_rec, x->n_cand, x->tick,
+                             g->timeDelta, g->confGlobal, g->maxDepthProcessed, g->outlierCoeff, 0, x->index, x->ivc,
+                             x->ict, x->inr, x->depthF, x->mask, x->surf[src], g->capacity);
+        /* two swaps (fuse, clean) leave the live buffer where it started */
+        x->tms[6] += now_ms() - t0;
+    }
+    t0 = now_ms();
+    oracle_predict(x); /* :569 */
+    x->tms[7] += now_ms() - t0;
+    x->tick++;
+    return 0;
+}
+
+void mfo_get_pose(const mfo_ctx* x, float* p) { memcpy(p, x->pose, sizeof(x->pose)); }
+int mfo_get_count(const mfo_ctx* x) { return x->count; }
+int mfo_get_tick(const mfo_ctx* x) { return x->tick; }
+const float* mfo_get_surfels(const mfo_ctx* x) { return x->surf[x->cur]; }
+void mfo_get_icp_stats(const mfo_ctx* x, float* e, float* c) { *e = x->lastICPError; *c = x->lastICPCount; }
+void mfo_get_timings(const mfo_ctx* x, double* ms8) { memcpy(ms8, x->tms, sizeof(x->tms)); }
+const float* mfo_dbg_depthF(const mfo_ctx* x) { return x->depthF; }
+const float* mfo_dbg_pred_vertex(const mfo_ctx* x) { return x->predVertex; }
+const float* mfo_dbg_pred_normal(const mfo_ctx* x) { return x->predNormal; }
+const uint8_t* mfo_dbg_pred_image(const mfo_ctx* x) { return x->predImage; }
+int mfo_dbg_last_fillin(const mfo_ctx* x) { return x->lastFillIn; }

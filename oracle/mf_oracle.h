@@ -1,0 +1,196 @@
+/*
+ * mf_oracle.h -- CPU restatement of the MaskFusion::processFrame hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under maskfusion_amd/ (the product) may include,
+ * link or call this.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg use it, and only as the checker / the timed CPU baseline.
+ *
+ * PARITY UNPINNED: the reference (martinruenz/maskfusion) ships no tests, golden vectors
+ * or fixtures for this path and cannot be built here (CUDA + OpenGL 4.3 + Pangolin +
+ * OpenCV + Eigen).  Every function below therefore follows the cited reference source
+ * line by line, and is pinned by analytic known-answer tests (tests/test_oracle_kat.py)
+ * rather than by reference outputs.  Citations are relative to /root/reference/.
+ *
+ * Conventions
+ *   - images: dense row-major, no pitch.  vmap/nmap: planar [3][H][W] float (x,y,z planes),
+ *     invalid <=> x plane is NaN (the reference leaves y stale / z=0 there; unobservable).
+ *   - 4x4 poses at the API: 16 floats COLUMN-major (Eigen::Matrix4f::data() compatible).
+ *   - surfel record = 12 floats {px,py,pz,conf | colorEnc,unused,initTime,lastTime | nx,ny,nz,radius}
+ *     (Core/Shaders/Vertex.cpp:21-43).
+ */
+#ifndef MF_ORACLE_H_
+#define MF_ORACLE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------- image preprocessing (a2, a3) ---------------- */
+/* Core/Shaders/depth_bilateral_metric.frag:30-76 */
+void mfo_bilateral(const float* depth, float* out, int W, int H);
+/* Core/Cuda/cudafuncs.cu:333-364 (pyrDownKernelGaussF); dst is (sh/2) x (sw/2) */
+void mfo_pyrdown_gauss_f(const float* src, float* dst, int sw, int sh);
+/* Core/Cuda/cudafuncs.cu:534-564 (pyrDownKernelIntensityGauss) */
+void mfo_pyrdown_gauss_u8(const uint8_t* src, uint8_t* dst, int sw, int sh);
+/* Core/Cuda/cudafuncs.cu:109-134 (computeVmapKernel) */
+void mfo_create_vmap(const float* depth, float* vmap, int W, int H,
+                     float fx, float fy, float cx, float cy, float depthCutoff);
+/* Core/Cuda/cudafuncs.cu:152-189 (computeNmapKernel) */
+void mfo_create_nmap(const float* vmap, float* nmap, int W, int H);
+
+/* ---------------- model-side maps (a4) ---------------- */
+/* Core/Cuda/cudafuncs.cu:271-311 (copyMapsKernel): AoS float4 -> planar, z==0 -> NaN */
+void mfo_copy_maps(const float* v4, const float* n4, float* vmap, float* nmap, int W, int H);
+/* Core/Cuda/cudafuncs.cu:366-417 (resizeMapKernel<normalize>) */
+void mfo_resize_map(const float* in, float* out, int sw, int sh, int normalize);
+/* Core/Cuda/cudafuncs.cu:207-249 (tranformMapsKernel), in place allowed; R row-major */
+void mfo_transform_maps(const float* vsrc, const float* nsrc, const float* R, const float* t,
+                        float* vdst, float* ndst, int W, int H);
+
+/* ---------------- odometry (a6, a7, a11) ---------------- */
+/* Core/Cuda/reduce.cu:259-525 (ICPReduction + icpStep host unpack).
+ * Rcurr, Rprev_inv row-major 3x3.  A: 36 floats row-major, b: 6, residual: {sum r^2, inliers}. */
+void mfo_icp_step(const float* Rcurr, const float* tcurr,
+                  const float* vmap_curr, const float* nmap_curr,
+                  const float* Rprev_inv, const float* tprev,
+                  float fx, float fy, float cx, float cy,
+                  const float* vmap_g_prev, const float* nmap_g_prev,
+                  float distThres, float angleThres, int W, int H,
+                  float* A, float* b, float* residual);
+/* Eigen LDLT stand-in (RGBDOdometry.cpp:447-459): symmetric solve in double, n = 3 or 6.
+ * Returns 0 on success. */
+int mfo_ldlt_solve(const double* A, const double* b, double* x, int n);
+/* Core/Utils/OdometryProvider.h:32-67; R row-major 3x3 */
+void mfo_rodrigues(const double* w, double* R);
+/* Core/Utils/OdometryProvider.h:69-90: resultRt <- exp(x) * resultRt (row-major 4x4 double) */
+void mfo_update_se3(double* resultRt, const double* x6);
+
+/* Tracker options (Core/MaskFusion.cpp:57-66, RGBDOdometry.cpp:327-329) */
+typedef struct {
+    int   pyramid;      /* 1 */
+    int   fastOdom;     /* 0 */
+    int   so3;          /* 1 (only used when rgb term is on) */
+    int   rgbOnly;      /* 0 */
+    float icpWeight;    /* 10 core default, 20 GUI; >=100 => ICP only */
+    float distThresh;   /* 0.10 */
+    float angleThresh;  /* sin(20 deg) */
+} mfo_track_opts;
+
+/* Per-iteration log for differential tests */
+typedef struct {
+    int    n_iters;
+    float  A[19][36];
+    float  b[19][6];
+    float  residual[19][2];
+    double x[19][6];
+} mfo_track_log;
+
+/* Core/Utils/RGBDOdometry.cpp:227-497, ICP-only branch (icp && !rgb).
+ * curr_v/curr_n: 3 levels of current-frame maps (camera frame); prev_v/prev_n: 3 levels of model maps in the
+ * global frame.  R (row-major), t: pose in/out.  out_inc16: returned increment (col-major).
+ * Fills lastICPError/lastICPCount.  log may be NULL. */
+void mfo_track_icp(const float* const curr_v[3], const float* const curr_n[3],
+                   const float* const prev_v[3], const float* const prev_n[3],
+                   int W, int H, float fx, float fy, float cx, float cy,
+                   const mfo_track_opts* opts, float* R, float* t, float* out_inc16,
+                   float* lastICPError, float* lastICPCount, mfo_track_log* log);
+
+/* ---------------- surfels (a13..a18, a21) ---------------- */
+typedef struct {
+    int W, H;
+    float fx, fy, cx, cy;
+} mfo_cam;
+
+float mfo_encode_color(float r, float g, float b);            /* color_encoding.glsl:19-25 */
+void  mfo_decode_color(float c, float* rgb);                    /* color_encoding.glsl:27-34 */
+float mfo_get_radius(float depth, float norm_z, float fx, float fy); /* surfels.glsl:19-34 */
+float mfo_confidence(float x, float y, float weighting, float cx, float cy); /* surfels.glsl:36-46 */
+
+/* First frame (MaskFusion.cpp:235-238; vertex_feedback.vert/.geom; init_unstable.vert; Model.cpp:240-285).
+ * Column-major pixel order; returns count.  maxDepth = maxDepthProcessed (20). */
+int mfo_init_surfels(const mfo_cam* cam, const uint8_t* rgb, const float* depthRaw, const float* depthF,
+                     int tick, float maxDepth, float* surfels, int capacity);
+
+/* index_map.vert/.frag + ModelProjection.cpp:100-152.  pose16 col-major (model pose).
+ * Outputs: index (int32, 0 = empty), vertConf/colorTime/normRad float4 maps (camera frame). */
+void mfo_predict_indices(const mfo_cam* cam, const float* pose16, const float* surfels, int count,
+                         int time, float maxDepth, int timeDelta,
+                         int32_t* index, float* vertConf, float* colorTime, float* normRad);
+
+/* data.vert + Model.cpp:466-581.  Writes per-candidate records: cand_op[c] in {0,1,2}, cand_best[c] (surfel idx),
+ * cand_rec[c][12].  Candidate c = xi*(H/2... see mf_oracle.c) enumerates quarter-rate pixels in column-major order. */
+void mfo_fuse_data(const mfo_cam* cam, const float* pose16, const uint8_t* rgb, const float* depthRaw,
+                   const float* depthF, const uint8_t* mask, int maskID, int time, float weighting, float maxDepth,
+                   const int32_t* index, const float* vertConf, const float* normRad,
+                   uint8_t* cand_op, int32_t* cand_best, float* cand_rec, int* n_cand);
+
+/* update.vert + Model.cpp:583-646: applies first-writer-wins merge records to every surfel (src -> dst). */
+void mfo_fuse_update(const float* src, float* dst, int count, int time,
+                     const uint8_t* cand_op, const int32_t* cand_best, const float* cand_rec, int n_cand);
+
+/* copy_unstable.vert:53-157 + .geom + Model.cpp:649-772.  Old surfels then new (op==2) candidates; returns new count. */
+int mfo_clean(const mfo_cam* cam, const float* pose16, const float* src, int count,
+              const uint8_t* cand_op, const float* cand_rec, int n_cand,
+              int time, int timeDelta, float confThreshold, float maxDepth, float outlierCoeff, int maskID,
+              const int32_t* index, const float* vertConf, const float* colorTime, const float* normRad,
+              const float* depthF, const uint8_t* mask, float* dst, int capacity);
+
+/* splat.vert + combo_splat.frag + ModelProjection.cpp:187-268.
+ * Outputs: image RGBA8, vertexConf float4, normalRad float4, time uint16 (0 where empty). */
+void mfo_combined_predict(const mfo_cam* cam, const float* pose16, const float* surfels, int count,
+                          float maxDepth, float confThreshold, int time, int maxTime, int timeDelta,
+                          uint8_t* image, float* vertexConf, float* normalRad, uint16_t* timeMap);
+
+/* fill_vertex/normal/rgb.frag + FillIn.cpp (passthrough = 0|1) */
+void mfo_fill_in(const mfo_cam* cam, const uint8_t* predImage, const float* predVertex, const float* predNormal,
+                 const uint8_t* rawRgb, const float* rawDepth, int passthrough,
+                 uint8_t* fillImage, float* fillVertex, float* fillNormal);
+
+/* MaskFusion.cpp:630-648 (nearest sample of the predicted colour image at 20x down-sampling) */
+int mfo_requires_fill_in(const uint8_t* predImage, int W, int H, float ratio);
+
+/* Model.cpp:449-464 + rodrigues2 :891-932 */
+float mfo_fusion_weight(const float* pose16, const float* lastPose16, float weightMultiplier);
+
+/* ---------------- single-model pipeline (a1) ---------------- */
+typedef struct mfo_ctx mfo_ctx;
+
+typedef struct {
+    int   W, H;
+    float fx, fy, cx, cy;
+    int   timeDelta;          /* 200 core / INT_MAX/2 open loop */
+    float confGlobal;         /* 4 core / 10 GUI */
+    float depthCutoff;        /* 3 core / 4 GUI */
+    float icpWeight;          /* >=100: ICP only */
+    float maxDepthProcessed;  /* 20 */
+    float outlierCoeff;       /* 0.9 core / 0.1 GUI */
+    int   fastOdom, pyramid, so3;
+    int   capacity;           /* max surfels */
+} mfo_config;
+
+void     mfo_default_config(mfo_config* c, int W, int H, float fx, float fy, float cx, float cy);
+mfo_ctx* mfo_create(const mfo_config* c);
+void     mfo_destroy(mfo_ctx* ctx);
+/* MaskFusion::processFrame, -static single background model (Core/MaskFusion.cpp:200-607). */
+int      mfo_process_frame(mfo_ctx* ctx, const uint8_t* rgb, const float* depth, float weightMultiplier);
+void     mfo_get_pose(const mfo_ctx* ctx, float* pose16);
+int      mfo_get_count(const mfo_ctx* ctx);
+int      mfo_get_tick(const mfo_ctx* ctx);
+const float* mfo_get_surfels(const mfo_ctx* ctx);
+void     mfo_get_icp_stats(const mfo_ctx* ctx, float* err, float* count);
+/* per-stage wall-clock (ms) accumulated since create: order = preprocess, odomInit, odom, indexMap, fuseData,
+ * fuseUpdate, clean, predict */
+void     mfo_get_timings(const mfo_ctx* ctx, double* ms8);
+/* intermediate buffers for differential tests (valid after process_frame) */
+const float*   mfo_dbg_depthF(const mfo_ctx* ctx);
+const float*   mfo_dbg_pred_vertex(const mfo_ctx* ctx);
+const float*   mfo_dbg_pred_normal(const mfo_ctx* ctx);
+const uint8_t* mfo_dbg_pred_image(const mfo_ctx* ctx);
+int            mfo_dbg_last_fillin(const mfo_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

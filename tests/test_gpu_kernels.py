@@ -1,0 +1,158 @@
+"""Kernel-level parity: each HIP entry point of include/maskfusion_amd.h against the CPU oracle (oracle/) on the same
+seeded inputs.  Tolerances (fp32 path; the reference itself is nvcc fast-math, so bit equality is undefined):
+  images / maps: 2e-6 relative + 1e-6 absolute;  normal equations: 1e-4 relative to the largest |A| entry."""
+import numpy as np
+import pytest
+
+from gpu_util import dev, empty, host, nan_equal_close, scene_frames
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def frames():
+    st, fr = scene_frames(3, noise=True)
+    return st, fr
+
+
+def test_bilateral(hip, oracle, frames):
+    st, fr = frames
+    depth = fr[0][1].copy()
+    depth[100:140, 200:260] = 0.0          # hole
+    depth[300:304, :] = 0.02               # below the 0.03 gate
+    ref = oracle.bilateral(depth)
+    d = dev(depth)
+    out = empty(depth.shape)
+    assert hip.mf_k_bilateral(d.data_ptr(), out.data_ptr(), st.W, st.H, None) == 0
+    got = host(out)
+    err, bad = nan_equal_close(got, ref, 2e-5, 1e-6)   # __expf vs expf
+    print("bilateral max abs err", err)
+    assert bad == 0
+    assert ((got == 0) == (ref == 0)).all()
+
+
+def test_bilateral_constant_is_identity(hip):
+    depth = np.full((480, 640), 1.5, np.float32)
+    out = empty(depth.shape)
+    assert hip.mf_k_bilateral(dev(depth).data_ptr(), out.data_ptr(), 640, 480, None) == 0
+    assert np.allclose(host(out), 1.5, rtol=1e-6)
+
+
+def test_pyrdown(hip, oracle, frames):
+    st, fr = frames
+    src = oracle.bilateral(fr[0][1])
+    src[50:60, 70:90] = np.nan
+    for _ in range(2):
+        ref = oracle.pyrdown_f(src)
+        out = empty(ref.shape)
+        assert hip.mf_k_pyrdown_f(dev(src).data_ptr(), out.data_ptr(), src.shape[1], src.shape[0], None) == 0
+        err, bad = nan_equal_close(host(out), ref, 2e-6, 1e-7)
+        assert bad == 0
+        src = ref
+
+
+def test_vmap_nmap(hip, oracle, frames):
+    st, fr = frames
+    depth = oracle.bilateral(fr[0][1])
+    for lvl in range(3):
+        W, H = st.W >> lvl, st.H >> lvl
+        k = [st.fx / (1 << lvl), st.fy / (1 << lvl), st.cx / (1 << lvl), st.cy / (1 << lvl)]
+        v_ref = oracle.create_vmap(depth, *k, 3.0)
+        n_ref = oracle.create_nmap(v_ref)
+        v, n = empty((3, H, W)), empty((3, H, W))
+        assert hip.mf_k_vmap_nmap(dev(depth).data_ptr(), v.data_ptr(), n.data_ptr(), W, H, *k, 3.0, None) == 0
+        ev, bv = nan_equal_close(host(v), v_ref, 2e-6, 1e-7)
+        en, bn = nan_equal_close(host(n), n_ref, 2e-5, 2e-6)   # rsqrt vs 1/sqrt
+        print("level", lvl, "vmap err", ev, "nmap err", en)
+        assert bv == 0 and bn == 0
+        depth = oracle.pyrdown_f(depth)
+
+
+def _model_maps(oracle, st, depth, T):
+    """Model-side maps as the oracle builds them from a (fake) prediction = back-projection of `depth`."""
+    H, W = depth.shape
+    v = oracle.create_vmap(depth, st.fx, st.fy, st.cx, st.cy, 20.0)
+    n = oracle.create_nmap(v)
+    v4 = np.zeros((H, W, 4), np.float32)
+    n4 = np.zeros((H, W, 4), np.float32)
+    valid = ~np.isnan(v[0]) & ~np.isnan(n[0])
+    for c in range(3):
+        v4[..., c] = np.where(valid, v[c], 0)
+        n4[..., c] = np.where(valid, n[c], 0)
+    v4[..., 3] = 1
+    n4[..., 3] = 0.01
+    return v4, n4
+
+
+def test_model_pyramid(hip, oracle, frames):
+    from maskfusion_amd import synth
+    st, fr = frames
+    v4, n4 = _model_maps(oracle, st, fr[0][1], None)
+    T = synth.make_pose(synth.rot_xyz(0.02, -0.03, 0.01), [0.05, -0.02, 0.03])
+    R = T[:3, :3].astype(np.float32)
+    t = T[:3, 3].astype(np.float32)
+    # oracle: copyMaps -> resize x2 -> transform x3
+    vs, ns = [None] * 3, [None] * 3
+    vs[0], ns[0] = oracle.copy_maps(v4, n4)
+    for i in (1, 2):
+        vs[i] = oracle.resize_map(vs[i - 1], False)
+        ns[i] = oracle.resize_map(ns[i - 1], True)
+    ref = [oracle.transform_maps(vs[i], ns[i], R, t) for i in range(3)]
+    tot = sum((st.W >> i) * (st.H >> i) * 3 for i in range(3))
+    dv, dn = empty(tot), empty(tot)
+    Rc = np.ascontiguousarray(R.reshape(9))
+    assert hip.mf_k_model_pyramid(dev(v4).data_ptr(), dev(n4).data_ptr(), Rc.ctypes.data, t.ctypes.data,
+                                  dv.data_ptr(), dn.data_ptr(), st.W, st.H, None) == 0
+    gv, gn = host(dv), host(dn)
+    off = 0
+    for i in range(3):
+        sz = (st.W >> i) * (st.H >> i) * 3
+        ev, bv = nan_equal_close(gv[off:off + sz].reshape(ref[i][0].shape), ref[i][0], 2e-6, 2e-6)
+        en, bn = nan_equal_close(gn[off:off + sz].reshape(ref[i][1].shape), ref[i][1], 2e-5, 2e-6)
+        print("level", i, "v err", ev, "n err", en)
+        assert bv == 0 and bn == 0
+        off += sz
+
+
+def test_icp_step(hip, oracle, frames):
+    from maskfusion_amd import synth
+    st, fr = frames
+    dF0 = oracle.bilateral(fr[0][1])
+    dF1 = oracle.bilateral(fr[1][1])
+    for lvl in range(3):
+        W, H = st.W >> lvl, st.H >> lvl
+        k = [st.fx / (1 << lvl), st.fy / (1 << lvl), st.cx / (1 << lvl), st.cy / (1 << lvl)]
+        vc = oracle.create_vmap(dF1, *k, 3.0)
+        nc = oracle.create_nmap(vc)
+        vp = oracle.create_vmap(dF0, *k, 20.0)
+        npv = oracle.create_nmap(vp)
+        T = synth.make_pose(synth.rot_xyz(0.004, -0.003, 0.002), [0.003, -0.002, 0.001])
+        Rcurr = T[:3, :3].astype(np.float32)
+        tcurr = T[:3, 3].astype(np.float32)
+        Rpi = np.eye(3, dtype=np.float32)
+        tprev = np.zeros(3, np.float32)
+        A, b, res = oracle.icp_step(Rcurr, tcurr, vc, nc, Rpi, tprev, *k, vp, npv)
+        out = empty(32)
+        args = [np.ascontiguousarray(x.reshape(-1)) for x in (Rcurr, tcurr, Rpi, tprev)]
+        rc = hip.mf_k_icp_step(args[0].ctypes.data, args[1].ctypes.data, dev(vc).data_ptr(), dev(nc).data_ptr(),
+                               args[2].ctypes.data, args[3].ctypes.data, *k, dev(vp).data_ptr(), dev(npv).data_ptr(),
+                               0.10, float(np.sin(np.float32(20.0 * 3.14159254 / 180.0))), W, H, out.data_ptr(), None)
+        assert rc == 0
+        g = host(out)
+        gA = np.zeros((6, 6))
+        gb = np.zeros(6)
+        s = 0
+        for i in range(6):
+            for j in range(i, 7):
+                if j == 6:
+                    gb[i] = g[s]
+                else:
+                    gA[i, j] = gA[j, i] = g[s]
+                s += 1
+        print("level", lvl, "inliers gpu/oracle", g[28], res[1], "res", g[27], res[0])
+        assert g[28] == res[1], "inlier count must match exactly"
+        scale = np.abs(A).max()
+        assert np.abs(gA - A).max() <= 1e-4 * scale
+        assert np.abs(gb - b).max() <= 1e-4 * max(np.abs(b).max(), 1e-3 * scale)
+        assert abs(g[27] - res[0]) <= 1e-4 * max(res[0], 1e-9)
+        dF0, dF1 = oracle.pyrdown_f(dF0), oracle.pyrdown_f(dF1)

@@ -1,0 +1,76 @@
+"""End-to-end parity of mf_process_frame against the oracle's processFrame on the synthetic S1 stream
+(SURVEY.md 8d), through the C ABI.  Tolerances: pose 1e-4 m / frame vs the oracle (float reduction order differs),
+surfel count within 0.5 % (a handful of z-test / threshold ties flip), ATE vs oracle < 1 mm (north_star)."""
+import numpy as np
+import pytest
+
+from gpu_util import scene_frames, nan_equal_close
+
+pytestmark = pytest.mark.gpu
+
+N_FRAMES = 25
+
+
+@pytest.fixture(scope="module")
+def run(hip, oracle):
+    from maskfusion_amd import MaskFusion
+    st, frames = scene_frames(N_FRAMES, noise=True)
+    cap = 1 << 20
+    o = oracle.Oracle(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpWeight=100.0, capacity=cap, so3=0)
+    m = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=100.0, so3=False, numGSurfels=cap,
+                   enableMultipleModels=False)
+    rec = dict(op=[], gp=[], oc=[], gc=[], ofill=[], gfill=[], gt=[])
+    first = {}
+    for k, (rgb, depth, mask) in enumerate(frames):
+        o.process_frame(rgb, depth)
+        m.processFrame(rgb, depth, timestamp=k)
+        rec["op"].append(o.pose); rec["gp"].append(m.getCurrPose())
+        rec["oc"].append(o.count); rec["gc"].append(m.getBackgroundModel().lastCount())
+        rec["ofill"].append(o.dbg("fillin")); rec["gfill"].append(int(m.getLastFillIn()))
+        rec["gt"].append(st.gt_pose(k))
+        if k == 0:
+            first["o_surf"] = o.surfels(); first["g_surf"] = m.getBackgroundModel().downloadMap()
+            first["o_depthF"] = o.dbg("depthF"); first["g_depthF"] = m.debugRead("depthF")
+        if k == 1:
+            first["log"] = m.debugRead("icp_log")
+    rec["first"] = first
+    rec["o"], rec["m"], rec["st"] = o, m, st
+    return rec
+
+
+def test_first_frame_init(run):
+    f = run["first"]
+    err, bad = nan_equal_close(f["g_depthF"], f["o_depthF"], 2e-5, 1e-6)
+    assert bad == 0
+    assert len(f["g_surf"]) == len(f["o_surf"]) == run["oc"][0]
+    a, b = f["g_surf"], f["o_surf"]
+    assert np.array_equal(a[:, 4:8], b[:, 4:8])                     # colour / times are integer-valued: exact
+    assert np.allclose(a[:, :4], b[:, :4], rtol=2e-5, atol=1e-6)    # position (raw depth) + confidence
+    ok = np.isfinite(b[:, 8:]).all(1)
+    assert np.allclose(a[ok, 8:], b[ok, 8:], rtol=1e-3, atol=1e-4)  # normals from the (approximately equal) filtered depth
+
+
+def test_pose_tracks_oracle(run):
+    from maskfusion_amd import synth
+    gp, op, gt = np.array(run["gp"]), np.array(run["op"]), np.array(run["gt"])
+    d = np.linalg.norm(gp[:, :3, 3] - op[:, :3, 3], axis=1)
+    print("per-frame |t_hip - t_oracle| max", d.max(), "fill-in hip/oracle", run["gfill"], run["ofill"])
+    print("counts hip", run["gc"][-5:], "oracle", run["oc"][-5:])
+    ate_vs_oracle = synth.ate_rmse(gp, op)
+    print("ATE hip vs oracle", ate_vs_oracle, "ATE hip vs GT", synth.ate_rmse(gp, gt), "ATE oracle vs GT", synth.ate_rmse(op, gt))
+    assert ate_vs_oracle < 1e-3
+    assert d.max() < 1e-3
+    assert run["gfill"] == run["ofill"]
+
+
+def test_surfel_counts_track_oracle(run):
+    gc, oc = np.array(run["gc"], float), np.array(run["oc"], float)
+    rel = np.abs(gc - oc) / oc
+    print("count rel diff max", rel.max())
+    assert rel.max() < 5e-3
+
+
+def test_icp_iterations_logged(run):
+    log = run["first"]["log"]
+    assert np.isfinite(log).all()
+    assert (log[:, 28] > 1000).all()      # every one of the 19 iterations saw inliers
