@@ -4,6 +4,10 @@
 //   vertex + normal maps     <- createVMap + createNMap (Core/Cuda/cudafuncs.cu:109-205), fused into one pass
 #include "mf_device.h"
 
+// every float op individually rounded in this file (the preprocessing feeds normals, which amplify 1-ulp depth
+// differences ~1000x; keeping these maps within rounding of a plain reading of the reference keeps parity tight)
+#pragma clang fp contract(off)
+
 namespace mf {
 
 // ------------------------------------------------------------------------------------------------
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(256) void k_bilateral(const float* __restrict__ dep
                     if (tmp >= 0.f) {
                         const float space2 = (float)(dx * dx) + fy2;
                         const float color2 = (value - tmp) * (value - tmp);
-                        const float weight = __expf(-(space2 * sigma_space2_inv_half + color2 * sigma_color2_inv_half));
+                        const float weight = expf(-(space2 * sigma_space2_inv_half + color2 * sigma_color2_inv_half));
                         sum1 += tmp * weight;
                         sum2 += weight;
                     }

@@ -34,7 +34,8 @@ def test_bilateral(hip, oracle, frames):
 def test_bilateral_constant_is_identity(hip):
     depth = np.full((480, 640), 1.5, np.float32)
     out = empty(depth.shape)
-    assert hip.mf_k_bilateral(dev(depth).data_ptr(), out.data_ptr(), 640, 480, None) == 0
+    d = dev(depth)   # keep every device tensor alive until the result is read back
+    assert hip.mf_k_bilateral(d.data_ptr(), out.data_ptr(), 640, 480, None) == 0
     assert np.allclose(host(out), 1.5, rtol=1e-6)
 
 
@@ -45,7 +46,8 @@ def test_pyrdown(hip, oracle, frames):
     for _ in range(2):
         ref = oracle.pyrdown_f(src)
         out = empty(ref.shape)
-        assert hip.mf_k_pyrdown_f(dev(src).data_ptr(), out.data_ptr(), src.shape[1], src.shape[0], None) == 0
+        d = dev(src)
+        assert hip.mf_k_pyrdown_f(d.data_ptr(), out.data_ptr(), src.shape[1], src.shape[0], None) == 0
         err, bad = nan_equal_close(host(out), ref, 2e-6, 1e-7)
         assert bad == 0
         src = ref
@@ -60,7 +62,8 @@ def test_vmap_nmap(hip, oracle, frames):
         v_ref = oracle.create_vmap(depth, *k, 3.0)
         n_ref = oracle.create_nmap(v_ref)
         v, n = empty((3, H, W)), empty((3, H, W))
-        assert hip.mf_k_vmap_nmap(dev(depth).data_ptr(), v.data_ptr(), n.data_ptr(), W, H, *k, 3.0, None) == 0
+        d = dev(depth)
+        assert hip.mf_k_vmap_nmap(d.data_ptr(), v.data_ptr(), n.data_ptr(), W, H, *k, 3.0, None) == 0
         ev, bv = nan_equal_close(host(v), v_ref, 2e-6, 1e-7)
         en, bn = nan_equal_close(host(n), n_ref, 2e-5, 2e-6)   # rsqrt vs 1/sqrt
         print("level", lvl, "vmap err", ev, "nmap err", en)
@@ -101,7 +104,8 @@ def test_model_pyramid(hip, oracle, frames):
     tot = sum((st.W >> i) * (st.H >> i) * 3 for i in range(3))
     dv, dn = empty(tot), empty(tot)
     Rc = np.ascontiguousarray(R.reshape(9))
-    assert hip.mf_k_model_pyramid(dev(v4).data_ptr(), dev(n4).data_ptr(), Rc.ctypes.data, t.ctypes.data,
+    d_v4, d_n4 = dev(v4), dev(n4)
+    assert hip.mf_k_model_pyramid(d_v4.data_ptr(), d_n4.data_ptr(), Rc.ctypes.data, t.ctypes.data,
                                   dv.data_ptr(), dn.data_ptr(), st.W, st.H, None) == 0
     gv, gn = host(dv), host(dn)
     off = 0
@@ -134,8 +138,9 @@ def test_icp_step(hip, oracle, frames):
         A, b, res = oracle.icp_step(Rcurr, tcurr, vc, nc, Rpi, tprev, *k, vp, npv)
         out = empty(32)
         args = [np.ascontiguousarray(x.reshape(-1)) for x in (Rcurr, tcurr, Rpi, tprev)]
-        rc = hip.mf_k_icp_step(args[0].ctypes.data, args[1].ctypes.data, dev(vc).data_ptr(), dev(nc).data_ptr(),
-                               args[2].ctypes.data, args[3].ctypes.data, *k, dev(vp).data_ptr(), dev(npv).data_ptr(),
+        d_vc, d_nc, d_vp, d_np = dev(vc), dev(nc), dev(vp), dev(npv)
+        rc = hip.mf_k_icp_step(args[0].ctypes.data, args[1].ctypes.data, d_vc.data_ptr(), d_nc.data_ptr(),
+                               args[2].ctypes.data, args[3].ctypes.data, *k, d_vp.data_ptr(), d_np.data_ptr(),
                                0.10, float(np.sin(np.float32(20.0 * 3.14159254 / 180.0))), W, H, out.data_ptr(), None)
         assert rc == 0
         g = host(out)
