@@ -173,7 +173,8 @@ class MaskFusion:
         W, H = self.width, self.height
         shapes = {"depthF": ((H, W), np.float32), "pred_vertex": ((H, W, 4), np.float32),
                   "pred_normal": ((H, W, 4), np.float32), "pred_image": ((H, W, 4), np.uint8),
-                  "index": ((H, W), np.int32), "index_vc": ((H, W, 4), np.float32), "icp_log": ((19, 32), np.float32)}
+                  "index": ((H, W), np.int32), "index_vc": ((H, W, 4), np.float32), "icp_log": ((19, 32), np.float32),
+                  "icp_prof": ((19, 8), np.uint64)}
         for pre in ("vmap_g", "nmap_g", "vmap", "nmap"):
             for i in range(3):
                 shapes[f"{pre}{i}"] = ((3, H >> i, W >> i), np.float32)

@@ -37,7 +37,7 @@ struct mf_ctx {
     float4* d_predV = nullptr; float4* d_predN = nullptr; uchar4* d_predImage = nullptr; uint16_t* d_predTime = nullptr;
     uint8_t* d_cand_op = nullptr; float4* d_cand_rec = nullptr; int* d_upd_first = nullptr;
     uint8_t* d_flags = nullptr; float* d_newconf = nullptr; int* d_block_counts = nullptr;
-    FrameDev* d_frame = nullptr; float* d_icp_log = nullptr;
+    FrameDev* d_frame = nullptr; float* d_icp_log = nullptr; unsigned long long* d_icp_prof = nullptr; bool icp_prof_on = false;
     // pinned host mirrors
     PoseDev* h_pose = nullptr; FrameDev* h_frame = nullptr; int* h_count = nullptr;
     // timings
@@ -154,6 +154,7 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     A(dev_alloc(c, &c->d_block_counts, (size_t)kCompactBlocks));
     A(dev_alloc(c, &c->d_frame, 1));
     A(dev_alloc(c, &c->d_icp_log, (size_t)20 * 32));
+    A(dev_alloc(c, &c->d_icp_prof, (size_t)20 * 8));
 #undef A
     launch_fill_int(c->d_upd_first, kNoUpdate, c->cap, c->stream);
     hipLaunchKernelGGL(k_pose_identity, dim3(1), dim3(64), 0, c->stream, c->d_pose);
@@ -253,6 +254,7 @@ extern "C" int mf_process_frame_dev(mf_ctx* c, const uint8_t* d_rgb, const float
                 l.partials_out = c->d_partials[k & 1];
                 l.state_in = &c->d_gn[k & 1]; l.state_out = &c->d_gn[(k + 1) & 1];
                 l.log_out = k > 0 ? c->d_icp_log + 32 * (k - 1) : nullptr;
+                l.prof_out = c->icp_prof_on ? c->d_icp_prof + 8 * k : nullptr;
                 launch_icp_iteration(l, s);
                 nb_prev = icp_grid_blocks(l.W, l.H);
                 ++k;
@@ -412,6 +414,7 @@ static const ParamRef kParams[] = {
 extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!c || !key) return MF_EINVAL;
     if (!strcmp(key, "timings")) { c->timings_on = value != 0; return MF_OK; }
+    if (!strcmp(key, "icpProfile")) { c->icp_prof_on = value != 0; return MF_OK; }
     for (const ParamRef& p : kParams)
         if (!strcmp(key, p.key)) {
             char* base = reinterpret_cast<char*>(&c->cfg);
@@ -467,6 +470,7 @@ extern "C" int mf_debug_read(mf_ctx* c, const char* what, void* out, uint64_t ou
     else if (w == "index") { src = c->d_index; bytes = P * 4; }
     else if (w == "index_vc") { src = c->d_ivc; bytes = P * 16; }
     else if (w == "icp_log") { src = c->d_icp_log; bytes = 19 * 32 * 4; }
+    else if (w == "icp_prof") { src = c->d_icp_prof; bytes = 19 * 8 * 8; }
     else { c->err = "unknown debug tap: " + w; return MF_EINVAL; }
     if (out_bytes < bytes) { c->err = "debug_read: buffer too small"; return MF_EINVAL; }
     MF_HIP(c, hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));

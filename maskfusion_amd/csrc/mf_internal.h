@@ -75,6 +75,7 @@ struct IcpLaunch {
     float* partials_out;
     const GNState* state_in; GNState* state_out;
     float* log_out;                              // optional [32] floats of the reduced system solved in this launch
+    unsigned long long* prof_out = nullptr;      // optional [8] shader-clock stamps (workgroup 0)
 };
 int icp_grid_blocks(int W, int H);
 void launch_icp_iteration(const IcpLaunch& a, hipStream_t s);

@@ -32,126 +32,252 @@ __device__ void m33_inverse_f(const float* m, float* inv) {  // cofactor inverse
     inv[6] = c02 * id; inv[7] = (m[1] * m[6] - m[0] * m[7]) * id; inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
 }
 
-// LDL^T with diagonal pivoting in double; zero pivots give zero components (Eigen::LDLT::solve behaviour).
-__device__ void ldlt6_solve(double* A /*36, destroyed*/, double* b /*6, destroyed*/, double* x) {
-    int perm[6];
-    double maxdiag = 0;
+// fp64 reciprocal / square root from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~2^-26) plus Newton steps: ~8 instructions
+// instead of the ~40 of an IEEE division; last-ulp differences are irrelevant for a Gauss-Newton step.
+__device__ __forceinline__ double rcp_d(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * (2.0 - x * r);
+    r = r * (2.0 - x * r);
+    return r;
+}
+__device__ __forceinline__ double sqrt_d(double x) {  // x > 0
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * (1.5 - 0.5 * x * r * r);
+    r = r * (1.5 - 0.5 * x * r * r);
+    double t = x * r;
+    return t + 0.5 * r * (x - t * t);
+}
+
+// LDL^T in double, fully unrolled so that the 6x6 system lives in registers (a dynamically indexed local array would be
+// spilled to scratch memory and turn this ~200-flop solve into ~40 us of dependent scratch round trips).  Stands in for
+// Eigen::LDLT (RGBDOdometry.cpp:451-459); Eigen pivots on the diagonal, which for these symmetric positive definite
+// systems changes the result only by rounding.  A non-positive / vanishing pivot zeroes that component (Eigen's
+// behaviour for singular systems) instead of dividing by it.
+__device__ __forceinline__ void ldlt6_solve(double (&A)[6][6], const double (&b)[6], double (&x)[6]) {
+    double maxdiag = 0.0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { perm[i] = i; maxdiag = fmax(maxdiag, fabs(A[i * 6 + i])); }
-    const double tol = maxdiag * 1e-300 + 1e-300;
+    for (int i = 0; i < 6; ++i) maxdiag = fmax(maxdiag, fabs(A[i][i]));
+    const double tol = maxdiag * 1e-14;
+    double dinv[6];
+#pragma unroll
     for (int k = 0; k < 6; ++k) {
-        int p = k;
-        for (int i = k + 1; i < 6; ++i)
-            if (fabs(A[i * 6 + i]) > fabs(A[p * 6 + p])) p = i;
-        if (p != k) {
-            for (int j = 0; j < 6; ++j) { double t = A[k * 6 + j]; A[k * 6 + j] = A[p * 6 + j]; A[p * 6 + j] = t; }
-            for (int j = 0; j < 6; ++j) { double t = A[j * 6 + k]; A[j * 6 + k] = A[j * 6 + p]; A[j * 6 + p] = t; }
-            { double t = b[k]; b[k] = b[p]; b[p] = t; }
-            { int t = perm[k]; perm[k] = perm[p]; perm[p] = t; }
-        }
-        const double d = A[k * 6 + k];
-        if (fabs(d) <= tol) continue;
+        const double d = A[k][k];
+        const bool ok = d > tol;
+        dinv[k] = ok ? 1.0 / d : 0.0;
+        // the lower triangle (i >= j) is the working copy; col = column k of the current Schur complement
+        double col[6];
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) col[i] = A[i][k];
+#pragma unroll
         for (int i = k + 1; i < 6; ++i) {
-            const double l = A[i * 6 + k] / d;
-            for (int j = k + 1; j < 6; ++j) A[i * 6 + j] -= l * A[k * 6 + j];
-            A[i * 6 + k] = l;
+            const double l = col[i] * dinv[k];
+#pragma unroll
+            for (int j = k + 1; j <= i; ++j) A[i][j] -= l * col[j];
+            A[i][k] = l;  // L below the diagonal
         }
     }
-    double y[6], z[6];
+    double y[6];
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
         double s = b[i];
-        for (int j = 0; j < i; ++j) s -= A[i * 6 + j] * y[j];
+#pragma unroll
+        for (int j = 0; j < i; ++j) s -= A[i][j] * y[j];
         y[i] = s;
     }
-    for (int i = 0; i < 6; ++i) y[i] = (fabs(A[i * 6 + i]) > tol) ? y[i] / A[i * 6 + i] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) y[i] *= dinv[i];
+#pragma unroll
     for (int i = 5; i >= 0; --i) {
         double s = y[i];
-        for (int j = i + 1; j < 6; ++j) s -= A[j * 6 + i] * z[j];
-        z[i] = s;
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) s -= A[j][i] * x[j];
+        x[i] = s;
     }
-    for (int i = 0; i < 6; ++i) x[perm[i]] = z[i];
 }
 
-// OdometryProvider::rodrigues (Core/Utils/OdometryProvider.h:32-67)
-__device__ void rodrigues_d(const double* w, double* R) {
-    for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
-    double rx = w[0], ry = w[1], rz = w[2];
-    const double theta = sqrt(rx * rx + ry * ry + rz * rz);
+// sin / cos for |th| <= 0.5 by Taylor series (error < 1e-17): keeps libm's large-argument reduction (and its scratch
+// arrays) out of the per-iteration kernel.
+__device__ __forceinline__ void sincos_small(double th, double& s, double& c) {
+    const double t2 = th * th;  // Horner form with reciprocal-factorial coefficients: no fp64 divisions (~40 instructions each)
+    s = th * (1.0 + t2 * (-1.0 / 6 + t2 * (1.0 / 120 + t2 * (-1.0 / 5040 + t2 * (1.0 / 362880 + t2 * (-1.0 / 39916800 +
+        t2 * (1.0 / 6227020800.0 + t2 * (-1.0 / 1307674368000.0))))))));
+    c = 1.0 + t2 * (-0.5 + t2 * (1.0 / 24 + t2 * (-1.0 / 720 + t2 * (1.0 / 40320 + t2 * (-1.0 / 3628800 + t2 * (1.0 / 479001600.0 +
+        t2 * (-1.0 / 87178291200.0 + t2 * (1.0 / 20922789888000.0))))))));
+}
+
+// OdometryProvider::rodrigues (Core/Utils/OdometryProvider.h:32-67).  Rotations beyond 0.5 rad (never produced by a
+// converging Gauss-Newton step) are built by repeated squaring of the rotation by theta / 2^k.
+__device__ __forceinline__ void rodrigues_d(double wx, double wy, double wz, double (&R)[3][3]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) R[r][c] = (r == c) ? 1.0 : 0.0;
+    const double th2 = wx * wx + wy * wy + wz * wz;
+    const double theta = th2 > 0.0 ? sqrt_d(th2) : 0.0;
     if (theta >= 2.2204460492503131e-16) {
-        const double c = cos(theta), s = sin(theta), c1 = 1. - c;
-        const double itheta = 1. / theta;
-        rx *= itheta; ry *= itheta; rz *= itheta;
-        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        const double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
-        const double rx_[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
-        for (int k = 0; k < 9; ++k) R[k] = c * I[k] + c1 * rrt[k] + s * rx_[k];
+        int halvings = 0;
+        double th = theta;
+        while (th > 0.5 && halvings < 64) { th *= 0.5; ++halvings; }
+        double s, c;
+        sincos_small(th, s, c);
+        const double c1 = 1. - c, itheta = rcp_d(theta);
+        const double rx = wx * itheta, ry = wy * itheta, rz = wz * itheta;
+        R[0][0] = c + c1 * rx * rx;      R[0][1] = c1 * rx * ry - s * rz; R[0][2] = c1 * rx * rz + s * ry;
+        R[1][0] = c1 * rx * ry + s * rz; R[1][1] = c + c1 * ry * ry;      R[1][2] = c1 * ry * rz - s * rx;
+        R[2][0] = c1 * rx * rz - s * ry; R[2][1] = c1 * ry * rz + s * rx; R[2][2] = c + c1 * rz * rz;
+        for (int h = 0; h < halvings; ++h) {
+            double Q[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) Q[r][cc] = R[r][0] * R[0][cc] + R[r][1] * R[1][cc] + R[r][2] * R[2][cc];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) R[r][cc] = Q[r][cc];
+        }
     }
 }
 
-// One Gauss-Newton update from the reduced system `sys` (27 upper-tri products, sum r^2, inliers):
-// RGBDOdometry.cpp:428-474 (icp && !rgb branch) + OdometryProvider::computeUpdateSE3.
-__device__ void gn_solve_update(const double* sys, const GNState& in, GNState& out) {
-    out = in;
-    double A[36], b[6], x[6];
-    int shift = 0;
-    for (int i = 0; i < 6; ++i)
-        for (int j = i; j < 7; ++j) {
-            const double value = (double)(float)sys[shift++];  // the reference hands float A/b to the host
-            if (j == 6) b[i] = value;
-            else A[j * 6 + i] = A[i * 6 + j] = value;
-        }
-    const float res = (float)sys[27], inl = (float)sys[28];
+// Wave-parallel 6x6 solve: Gauss-Jordan on the augmented [A|b] with one lane per element (lanes 0..41 of one
+// wavefront, fp64, no pivoting -- the systems are symmetric positive definite; a vanishing pivot zeroes that component
+// like Eigen::LDLT::solve does for singular systems).  Six rank-1 steps of {3 shuffles, 1 fma} replace a ~3 us
+// single-thread LDL^T; the serial ldlt6_solve above is kept as the executable specification (tests compare both).
+// sys: 27 packed upper-triangle products of the 7-vector row (reduce.cu:378-411 order) in LDS.  Returns x in every lane.
+__device__ __forceinline__ void solve6_wave(const double* sys, double (&x)[6]) {
+    const int l = threadIdx.x & 63;
+    const int r = l < 42 ? l / 7 : 0, c = l < 42 ? l % 7 : 0;
+    const int i = r < c ? r : c, j = r < c ? c : r;                 // A is symmetric; column 6 is b
+    const int idx = (c == 6) ? (r * 7 - (r * (r - 1)) / 2 + (6 - r)) : (i * 7 - (i * (i - 1)) / 2 + (j - i));
+    double v = (double)(float)sys[idx];                              // the reference hands float A/b to the host
+    double maxdiag = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) maxdiag = fmax(maxdiag, fabs(__shfl(v, k * 8, 64)));
+    const double tol = maxdiag * 1e-14;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double pivot = __shfl(v, k * 8, 64);
+        const double rowk = __shfl(v, k * 7 + c, 64);
+        const double colk = __shfl(v, r * 7 + k, 64);
+        const double inv = pivot > tol ? rcp_d(pivot) : 0.0;
+        const double scaled = rowk * inv;
+        v = (r == k) ? scaled : v - colk * scaled;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[k] = __shfl(v, k * 7 + 6, 64);
+}
+
+// Pose update from the Gauss-Newton step x: RGBDOdometry.cpp:428-474 (icp && !rgb branch) +
+// OdometryProvider::computeUpdateSE3.  Everything is unrolled with compile-time indices (registers only).
+__device__ __forceinline__ void gn_update_from_x(const double (&x)[6], float res, float inl, const GNState& in, GNState& out) {
     out.lastICPError = sqrtf(res) / inl;
     out.lastICPCount = inl;
-    ldlt6_solve(A, b, x);
     // resultRt <- [exp(w) | t] * resultRt
-    double Rw[9], Rt[16], nr[16];
-    rodrigues_d(x + 3, Rw);
-    for (int k = 0; k < 16; ++k) Rt[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    double Rw[3][3];
+    rodrigues_d(x[3], x[4], x[5], Rw);
+    double nr[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            nr[r][c] = Rw[r][0] * in.resultRt[0 * 4 + c] + Rw[r][1] * in.resultRt[1 * 4 + c] + Rw[r][2] * in.resultRt[2 * 4 + c] +
+                       x[r] * in.resultRt[3 * 4 + c];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out.resultRt[r * 4 + c] = nr[r][c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out.resultRt[12 + c] = in.resultRt[12 + c];
+    float trR[9], trt[3];
+#pragma unroll
     for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c) Rt[r * 4 + c] = Rw[r * 3 + c];
-        Rt[r * 4 + 3] = x[r];
-    }
-    for (int r = 0; r < 4; ++r)
-        for (int c = 0; c < 4; ++c) {
-            double s = 0;
-            for (int k = 0; k < 4; ++k) s += Rt[r * 4 + k] * in.resultRt[k * 4 + c];
-            nr[r * 4 + c] = s;
-        }
-    for (int k = 0; k < 16; ++k) out.resultRt[k] = nr[k];
-    for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c) out.trR[r * 3 + c] = (float)nr[r * 4 + c];
-        out.trt[r] = (float)nr[r * 4 + 3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) trR[r * 3 + c] = (float)nr[r][c];
+        trt[r] = (float)nr[r][3];
     }
     // currentT = [Rprev|tprev] * transform.inverse()
     float iR[9];
+#pragma unroll
     for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) iR[r * 3 + c] = out.trR[c * 3 + r];
-    const float3 itv = mul33(iR, f3(out.trt[0], out.trt[1], out.trt[2]));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) iR[r * 3 + c] = trR[c * 3 + r];
+    const float3 itv = mul33(iR, f3(trt[0], trt[1], trt[2]));
     const float it3[3] = {-itv.x, -itv.y, -itv.z};
+#pragma unroll
     for (int r = 0; r < 3; ++r)
+#pragma unroll
         for (int c = 0; c < 3; ++c)
             out.Rcurr[r * 3 + c] = in.Rprev[r * 3 + 0] * iR[0 * 3 + c] + in.Rprev[r * 3 + 1] * iR[1 * 3 + c] +
                                    in.Rprev[r * 3 + 2] * iR[2 * 3 + c];
     const float3 tv = mul33(in.Rprev, f3(it3[0], it3[1], it3[2]));
     out.tcurr[0] = tv.x + in.tprev[0]; out.tcurr[1] = tv.y + in.tprev[1]; out.tcurr[2] = tv.z + in.tprev[2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { out.Rprev[k] = in.Rprev[k]; out.Rprev_inv[k] = in.Rprev_inv[k]; out.trR[k] = trR[k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { out.tprev[k] = in.tprev[k]; out.trt[k] = trt[k]; }
     out.valid = 1;
+    out.pad = 0;
+}
+
+// Serial form (one thread): unpack -> LDL^T -> update.  Used by tests through mf_k_gn_solve to pin the wave solver.
+__device__ __forceinline__ void gn_solve_update_serial(const double* sys, const GNState& in, GNState& out) {
+    double A[6][6], b[6], x[6];
+    int shift = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 7; ++j) {
+            const double value = (double)(float)sys[shift++];
+            if (j == 6) b[i] = value;
+            else { A[i][j] = value; A[j][i] = value; }
+        }
+    ldlt6_solve(A, b, x);
+    gn_update_from_x(x, (float)sys[27], (float)sys[28], in, out);
+}
+
+// Workgroup-level: wavefront 0 solves in parallel, its lane 0 applies the update.  Call with all threads of the
+// workgroup after reduce_partials(); returns true in the thread that holds `out`.
+__device__ __forceinline__ bool gn_solve_update_wg(const double* s_sys, const GNState& in, GNState& out) {
+    if (threadIdx.x >= 64) return false;
+    double x[6];
+    solve6_wave(s_sys, x);
+    if (threadIdx.x != 0) return false;
+    gn_update_from_x(x, (float)s_sys[27], (float)s_sys[28], in, out);
+    return true;
 }
 
 // Fixed-order reduction of `nb` per-workgroup partials ([nb][32] floats) by a 256-thread workgroup -> sys[32] doubles
-// in LDS.  Thread t sums component (t & 31) over workgroups (t >> 5), (t >> 5) + 8, ...; lanes 0..31 then add the
-// 8 segment sums in order.
-__device__ __forceinline__ void reduce_partials(const float* __restrict__ partials, int nb, double* s_seg /*[8][32]*/,
+// in LDS.  The array is read as float4s with up to 10 independent 16 B loads in flight per lane (a one-load-at-a-time
+// loop cost ~70 cycles per partial: 10 us at 300 workgroups; the partials live in other XCDs' L2s, so every batch is
+// a fabric round trip).  Thread t < 256 owns components 4*(t%8)..+3 of workgroups t/8, t/8 + 32, ...; the 32 row sums
+// per component are then added in row order by lanes 0..31.  Order is fixed, so every workgroup (and every run) gets
+// bit-identical sums.
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ partials, int nb, double* s_seg /*[32][32]*/,
                                                 double* s_sys /*[32]*/) {
-    const int c = threadIdx.x & 31, seg = threadIdx.x >> 5;
-    double acc = 0.0;
-    for (int b = seg; b < nb; b += 8) acc += (double)partials[b * kIcpSlots + c];
-    s_seg[seg * 32 + c] = acc;
+    // The first 256 threads of the workgroup load; any workgroup size that is a multiple of 256 may call this.
+    const float4* __restrict__ p4 = reinterpret_cast<const float4*>(partials);
+    const int n4 = nb * (kIcpSlots / 4);
+    if (threadIdx.x < 256) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int f = threadIdx.x; f < n4; f += 2560) {  // 10 independent 16 B loads in flight per lane
+            float4 v[10];
+#pragma unroll
+            for (int u = 0; u < 10; ++u) v[u] = p4[min(f + 256 * u, n4 - 1)];  // unconditional: all ten issue back to back
+#pragma unroll
+            for (int u = 0; u < 10; ++u) {
+                const bool in = f + 256 * u < n4;
+                a0 += in ? (double)v[u].x : 0.0; a1 += in ? (double)v[u].y : 0.0;
+                a2 += in ? (double)v[u].z : 0.0; a3 += in ? (double)v[u].w : 0.0;
+            }
+        }
+        const int row = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+        s_seg[row * 32 + c4 + 0] = a0; s_seg[row * 32 + c4 + 1] = a1; s_seg[row * 32 + c4 + 2] = a2; s_seg[row * 32 + c4 + 3] = a3;
+    }
     __syncthreads();
     if (threadIdx.x < 32) {
         double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s += s_seg[k * 32 + threadIdx.x];
+        for (int k = 0; k < 32; ++k) s += s_seg[k * 32 + threadIdx.x];
         s_sys[threadIdx.x] = s;
     }
     __syncthreads();
@@ -179,6 +305,36 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
 #endif
 }
 
+// Sum of 29 (padded to 32) accumulators over the 64 lanes of a wavefront by recursive halving: at step s each lane
+// keeps the half of its remaining values selected by bit s of its lane id and hands the other half to lane ^ (1 << s),
+// so 16 + 8 + 4 + 2 + 1 + 1 = 32 cross-lane moves do what 29 x 6 = 174 full-width reductions did (measured: the
+// 174-DPP form cost ~2.2k cycles per wavefront and dominated the launch at 4 wavefronts per SIMD).
+// On return lane l holds the wave total of component bitrev5(l & 31) in v[0] (components >= 29 are zero padding).
+__device__ __forceinline__ int icp_component_of_lane(int lane) {
+    const int l = lane & 31;
+    return ((l & 1) << 4) | ((l & 2) << 2) | (l & 4) | ((l & 8) >> 2) | ((l & 16) >> 4);
+}
+// bitwise select (one v_bfi_b32): written on the bit patterns so that the compiler cannot turn "cond ? v[a] : v[b]" into
+// a dynamically indexed register array (which it lowers to a 32-deep compare/select chain per access).
+__device__ __forceinline__ float bitsel(unsigned mask, float a, float b) {
+    return __uint_as_float((__float_as_uint(a) & mask) | (__float_as_uint(b) & ~mask));
+}
+__device__ __forceinline__ float wave_sum32_halving(float (&v)[32]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int half = 16 >> s;
+        const unsigned up = ((lane >> s) & 1) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+        for (int k = 0; k < half; ++k) {
+            const float send = bitsel(up, v[k], v[k + half]);
+            const float keep = bitsel(up, v[k + half], v[k]);
+            v[k] = keep + __shfl_xor(send, 1 << s, 64);
+        }
+    }
+    return v[0] + __shfl_xor(v[0], 32, 64);
+}
+
 // ------------------------------------------------------------------------------------------------
 // The ICP iteration kernel.  256 threads, 4 consecutive pixels per thread (16 B streamed loads per plane).
 // ------------------------------------------------------------------------------------------------
@@ -190,26 +346,35 @@ struct IcpKArgs {
     float* partials_out;
     const GNState* st_in; GNState* st_out;
     float* log_out;
+    unsigned long long* prof_out;  // optional: 8 shader-clock stamps of workgroup 0 / thread 0
 };
 
-__device__ __forceinline__ void icp_pixel(float vx, float vy, float vz, float nx, float ny, float nz, const float* Rc,
-                                          float3 tc, const float* Rpi, float3 tp, const IcpKArgs& a, int P, float* acc) {
-    // search(): Core/Cuda/reduce.cu:292-353
-    const float3 vcurr = f3(vx, vy, vz);
-    const float3 vcurr_g = mul33(Rc, vcurr) + tc;
-    const float3 vcurr_cp = mul33(Rpi, vcurr_g - tp);
-    const int ux = __float2int_rn(vcurr_cp.x * a.k.fx / vcurr_cp.z + a.k.cx);
-    const int uy = __float2int_rn(vcurr_cp.y * a.k.fy / vcurr_cp.z + a.k.cy);
-    if (ux < 0 || uy < 0 || ux >= a.W || uy >= a.H || vcurr_cp.z < 0) return;
-    const int j = uy * a.W + ux;
-    const float3 vprev_g = f3(a.vp[j], a.vp[P + j], a.vp[2 * P + j]);
-    const float3 nprev_g = f3(a.np[j], a.np[P + j], a.np[2 * P + j]);
-    const float3 ncurr_g = mul33(Rc, f3(nx, ny, nz));
-    const float dist = norm3(vprev_g - vcurr_g);
-    const float sine = norm3(cross3(ncurr_g, nprev_g));
-    if (!(sine < a.angleThres && dist <= a.distThres && !isnan(nx) && !isnan(nprev_g.x))) return;
-    // getProducts(): Core/Cuda/reduce.cu:355-415
-    const float3 s_cp = vcurr_cp;
+// Correspondence search for one pixel, split in two so that the gathers of all four pixels of a thread are in flight
+// together (a per-pixel search-then-accumulate serialises four dependent L2 round trips: ~2 us per launch).
+struct IcpCorr { float3 vcurr_g, vcurr_cp, ncurr_g; int j; bool ok; };
+
+__device__ __forceinline__ IcpCorr icp_project(float vx, float vy, float vz, float nx, float ny, float nz, const float* Rc,
+                                               float3 tc, const float* Rpi, float3 tp, const IcpKArgs& a) {
+    // search(), first half: Core/Cuda/reduce.cu:292-314
+    IcpCorr c;
+    c.vcurr_g = mul33(Rc, f3(vx, vy, vz)) + tc;
+    c.vcurr_cp = mul33(Rpi, c.vcurr_g - tp);
+    const int ux = __float2int_rn(c.vcurr_cp.x * a.k.fx / c.vcurr_cp.z + a.k.cx);
+    const int uy = __float2int_rn(c.vcurr_cp.y * a.k.fy / c.vcurr_cp.z + a.k.cy);
+    c.ok = !(ux < 0 || uy < 0 || ux >= a.W || uy >= a.H || c.vcurr_cp.z < 0) && !isnan(nx);
+    c.j = c.ok ? uy * a.W + ux : 0;
+    c.ncurr_g = mul33(Rc, f3(nx, ny, nz));
+    return c;
+}
+
+__device__ __forceinline__ void icp_accumulate(const IcpCorr& c, float3 vprev_g, float3 nprev_g, const float* Rpi, float3 tp,
+                                               const IcpKArgs& a, float* acc) {
+    // search(), second half + getProducts(): Core/Cuda/reduce.cu:326-415
+    const float dist = norm3(vprev_g - c.vcurr_g);
+    const float sine = norm3(cross3(c.ncurr_g, nprev_g));
+    const bool found = c.ok && sine < a.angleThres && dist <= a.distThres && !isnan(nprev_g.x);
+    if (!found) return;
+    const float3 s_cp = c.vcurr_cp;
     const float3 d_cp = mul33(Rpi, vprev_g - tp);
     const float3 n_cp = mul33(Rpi, nprev_g);
     const float3 sxn = cross3(s_cp, n_cp);
@@ -218,37 +383,48 @@ __device__ __forceinline__ void icp_pixel(float vx, float vy, float vz, float nx
 #pragma unroll
     for (int r = 0; r < 7; ++r)
 #pragma unroll
-        for (int c = r; c < 7; ++c) acc[k++] += row[r] * row[c];
+        for (int cc = r; cc < 7; ++cc) acc[k++] += row[r] * row[cc];
     acc[28] += 1.0f;
 }
 
-__global__ __launch_bounds__(256) void k_icp_iter(const IcpKArgs a) {
-    __shared__ double s_seg[8 * 32];
+// 1024 threads = 16 wavefronts per workgroup, ONE pixel per thread: the per-pixel chain (project -> gather -> gate ->
+// 29 products) is ~250 dependent VALU instructions, so what a launch costs is how well that latency is hidden.  Four
+// wavefronts per SIMD hide it; one wavefront per SIMD with 4 pixels per thread (the 16 B-per-lane variant) measured
+// 2.5x slower for the same bytes.  A wavefront still touches one contiguous 256 B line per streamed plane.
+constexpr int kIcpThreads = 1024;
+
+__global__ __launch_bounds__(kIcpThreads) void k_icp_iter(const IcpKArgs a) {
+    __shared__ double s_seg[32 * 32];
     __shared__ double s_sys[32];
     __shared__ float s_pose[24];  // Rcurr[9] tcurr[3] Rprev_inv[9] tprev[3]
-    __shared__ float s_part[4 * kIcpSlots];
+    __shared__ float s_part[(kIcpThreads / 64) * kIcpSlots];
+    __shared__ GNState s_st;
 
     const int tid = threadIdx.x;
+    // stage the Gauss-Newton state through LDS with one coalesced load (thread 0 would otherwise chase ~80 dependent
+    // scalar loads after the solve)
+    if (tid < (int)(sizeof(GNState) / 4)) reinterpret_cast<uint32_t*>(&s_st)[tid] = reinterpret_cast<const uint32_t*>(a.st_in)[tid];
+    const bool prof = a.prof_out != nullptr && blockIdx.x == 0 && tid == 0;
+    unsigned long long stamp[8];
+    if (prof) stamp[0] = __builtin_amdgcn_s_memtime();
     const int P = a.W * a.H;
-    const int q = blockIdx.x * 256 + tid;  // pixel quad
-    const bool active = q * 4 < P;
+    const int i = blockIdx.x * kIcpThreads + tid;  // pixel
+    const bool active = i < P;
 
     // (1) issue the pose-independent streamed loads first so their latency overlaps the solve below
-    float4 vx, vy, vz, nx, ny, nz;
+    float vx = 0.f, vy = 0.f, vz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
     if (active) {
-        const float4* vc4 = reinterpret_cast<const float4*>(a.vc);
-        const float4* nc4 = reinterpret_cast<const float4*>(a.nc);
-        const int P4 = P >> 2;
-        vx = vc4[q]; vy = vc4[P4 + q]; vz = vc4[2 * P4 + q];
-        nx = nc4[q]; ny = nc4[P4 + q]; nz = nc4[2 * P4 + q];
+        vx = a.vc[i]; vy = a.vc[P + i]; vz = a.vc[2 * P + i];
+        nx = a.nc[i]; ny = a.nc[P + i]; nz = a.nc[2 * P + i];
     }
 
     // (2) prologue: finish the previous iteration (reduce -> solve -> pose), identically in every workgroup
+    if (prof) stamp[1] = __builtin_amdgcn_s_memtime();
     if (a.nb_in > 0) {
         reduce_partials(a.partials_in, a.nb_in, s_seg, s_sys);
-        if (tid == 0) {
-            GNState st;
-            gn_solve_update(s_sys, *a.st_in, st);
+        if (prof) stamp[2] = __builtin_amdgcn_s_memtime();
+        GNState st;
+        if (gn_solve_update_wg(s_sys, s_st, st)) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) { s_pose[k] = st.Rcurr[k]; s_pose[12 + k] = st.Rprev_inv[k]; }
 #pragma unroll
@@ -259,15 +435,20 @@ __global__ __launch_bounds__(256) void k_icp_iter(const IcpKArgs a) {
                     for (int k = 0; k < 32; ++k) a.log_out[k] = (float)s_sys[k];
             }
         }
-    } else if (tid == 0) {
-        const GNState& st = *a.st_in;
+    } else {
+      __syncthreads();
+      if (tid == 0) {
+        const GNState& st = s_st;
 #pragma unroll
         for (int k = 0; k < 9; ++k) { s_pose[k] = st.Rcurr[k]; s_pose[12 + k] = st.Rprev_inv[k]; }
 #pragma unroll
         for (int k = 0; k < 3; ++k) { s_pose[9 + k] = st.tcurr[k]; s_pose[21 + k] = st.tprev[k]; }
         if (blockIdx.x == 0) *a.st_out = st;
+      }
     }
+    if (prof) { if (a.nb_in == 0) stamp[2] = stamp[1]; stamp[3] = __builtin_amdgcn_s_memtime(); }
     __syncthreads();
+    if (prof) stamp[4] = __builtin_amdgcn_s_memtime();
 
     float Rc[9], Rpi[9];
 #pragma unroll
@@ -275,41 +456,49 @@ __global__ __launch_bounds__(256) void k_icp_iter(const IcpKArgs a) {
     const float3 tc = f3(s_pose[9], s_pose[10], s_pose[11]);
     const float3 tp = f3(s_pose[21], s_pose[22], s_pose[23]);
 
-    // (3) normal equations of this thread's 4 pixels
-    float acc[29];
+    // (3) normal equations of this thread's pixel
+    float acc[32];
 #pragma unroll
-    for (int k = 0; k < 29; ++k) acc[k] = 0.f;
+    for (int k = 0; k < 32; ++k) acc[k] = 0.f;
     if (active) {
-        icp_pixel(vx.x, vy.x, vz.x, nx.x, ny.x, nz.x, Rc, tc, Rpi, tp, a, P, acc);
-        icp_pixel(vx.y, vy.y, vz.y, nx.y, ny.y, nz.y, Rc, tc, Rpi, tp, a, P, acc);
-        icp_pixel(vx.z, vy.z, vz.z, nx.z, ny.z, nz.z, Rc, tc, Rpi, tp, a, P, acc);
-        icp_pixel(vx.w, vy.w, vz.w, nx.w, ny.w, nz.w, Rc, tc, Rpi, tp, a, P, acc);
+        const IcpCorr c = icp_project(vx, vy, vz, nx, ny, nz, Rc, tc, Rpi, tp, a);
+        const int j = c.j;
+        const float3 pv = f3(a.vp[j], a.vp[P + j], a.vp[2 * P + j]);
+        const float3 pn = f3(a.np[j], a.np[P + j], a.np[2 * P + j]);
+        icp_accumulate(c, pv, pn, Rpi, tp, a, acc);
     }
 
-    // (4) wavefront reduction (DPP), one LDS stage across the 4 wavefronts, one 128 B partial per workgroup
+    // (4) wavefront reduction (DPP), one LDS stage across the 16 wavefronts, one 128 B partial per workgroup
+    if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[5] = __builtin_amdgcn_s_memtime(); }
     const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int k = 0; k < 29; ++k) {
-        const float s = wave_sum_to_lane63(acc[k]);
-        if (lane == 63) s_part[wave * kIcpSlots + k] = s;
-    }
+    const float wsum = wave_sum32_halving(acc);
+    if (lane < 32) s_part[wave * kIcpSlots + icp_component_of_lane(lane)] = wsum;
     __syncthreads();
+    if (prof) stamp[6] = __builtin_amdgcn_s_memtime();
     if (tid < kIcpSlots) {
         float s = 0.f;
-        if (tid < 29) s = ((s_part[tid] + s_part[kIcpSlots + tid]) + s_part[2 * kIcpSlots + tid]) + s_part[3 * kIcpSlots + tid];
+        if (tid < 29) {
+#pragma unroll
+            for (int w = 0; w < kIcpThreads / 64; ++w) s += s_part[w * kIcpSlots + tid];
+        }
         a.partials_out[blockIdx.x * kIcpSlots + tid] = s;
+    }
+    if (prof) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp[7] = __builtin_amdgcn_s_memtime();
+        for (int k = 0; k < 8; ++k) a.prof_out[k] = stamp[k];
     }
 }
 
-int icp_grid_blocks(int W, int H) { return (W * H / 4 + 255) / 256; }
+int icp_grid_blocks(int W, int H) { return (W * H + kIcpThreads - 1) / kIcpThreads; }
 
 void launch_icp_iteration(const IcpLaunch& l, hipStream_t s) {
     IcpKArgs a;
     a.vc = l.vmap_curr; a.nc = l.nmap_curr; a.vp = l.vmap_prev; a.np = l.nmap_prev;
     a.W = l.W; a.H = l.H; a.k = l.k; a.distThres = l.distThres; a.angleThres = l.angleThres;
     a.partials_in = l.partials_in; a.nb_in = l.nblocks_in; a.partials_out = l.partials_out;
-    a.st_in = l.state_in; a.st_out = l.state_out; a.log_out = l.log_out;
-    hipLaunchKernelGGL(k_icp_iter, dim3(icp_grid_blocks(l.W, l.H)), dim3(256), 0, s, a);
+    a.st_in = l.state_in; a.st_out = l.state_out; a.log_out = l.log_out; a.prof_out = l.prof_out;
+    hipLaunchKernelGGL(k_icp_iter, dim3(icp_grid_blocks(l.W, l.H)), dim3(kIcpThreads), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -394,16 +583,20 @@ __device__ void pose_derive(PoseDev& p) {
 __global__ __launch_bounds__(256) void k_icp_finalize(const float* __restrict__ partials_in, int nb_in,
                                                        const GNState* __restrict__ st_in, PoseDev* __restrict__ pose,
                                                        PoseDev* __restrict__ host_mirror, float* __restrict__ log_out) {
-    __shared__ double s_seg[8 * 32];
+    __shared__ double s_seg[32 * 32];
     __shared__ double s_sys[32];
     GNState st;
-    if (nb_in > 0) reduce_partials(partials_in, nb_in, s_seg, s_sys);
-    if (threadIdx.x == 0) {
-        if (nb_in > 0) {
-            gn_solve_update(s_sys, *st_in, st);
-            if (log_out)
-                for (int k = 0; k < 32; ++k) log_out[k] = (float)s_sys[k];
-        } else st = *st_in;
+    bool mine = false;
+    if (nb_in > 0) {
+        reduce_partials(partials_in, nb_in, s_seg, s_sys);
+        mine = gn_solve_update_wg(s_sys, *st_in, st);
+        if (mine && log_out)
+            for (int k = 0; k < 32; ++k) log_out[k] = (float)s_sys[k];
+    } else if (threadIdx.x == 0) {
+        st = *st_in;
+        mine = true;
+    }
+    if (mine) {
         PoseDev p = *pose;
         for (int k = 0; k < 9; ++k) { p.lastR[k] = st.Rprev[k]; p.R[k] = st.Rcurr[k]; }
         for (int k = 0; k < 3; ++k) { p.lastT[k] = st.tprev[k]; p.t[k] = st.tcurr[k]; }
@@ -423,7 +616,7 @@ void launch_icp_finalize(const float* partials_in, int nblocks_in, const GNState
 
 // stand-alone icpStep for the parity tests: reduce partials to 32 floats
 __global__ __launch_bounds__(256) void k_icp_reduce_only(const float* __restrict__ partials, int nb, float* __restrict__ out32) {
-    __shared__ double s_seg[8 * 32];
+    __shared__ double s_seg[32 * 32];
     __shared__ double s_sys[32];
     reduce_partials(partials, nb, s_seg, s_sys);
     if (threadIdx.x < 32) out32[threadIdx.x] = (float)s_sys[threadIdx.x];
@@ -447,7 +640,7 @@ void launch_icp_step_standalone(const float* Rcurr, const float* tcurr, const fl
     IcpLaunch l;
     l.vmap_curr = vc; l.nmap_curr = nc; l.vmap_prev = vp; l.nmap_prev = np; l.W = W; l.H = H; l.k = k;
     l.distThres = distThres; l.angleThres = angleThres; l.partials_in = nullptr; l.nblocks_in = 0;
-    l.partials_out = partials; l.state_in = st; l.state_out = st + 1; l.log_out = nullptr;
+    l.partials_out = partials; l.state_in = st; l.state_out = st + 1; l.log_out = nullptr; l.prof_out = nullptr;
     launch_icp_iteration(l, s);
     hipLaunchKernelGGL(k_icp_reduce_only, dim3(1), dim3(256), 0, s, partials, icp_grid_blocks(W, H), out32);
 }

@@ -11,14 +11,16 @@
 namespace mf {
 
 // ------------------------------------------------------------------------------------------------
-// 13x13 bilateral.  One 256-thread workgroup (4 wavefronts, 64 lanes along x) filters a 64x16 tile staged
-// through LDS with a 6-pixel halo: HBM traffic is 4 B in + 4 B out per pixel, the 169 taps come from LDS
-// (row-contiguous ds_read_b32, conflict free).
+// 13x13 bilateral.  One 256-thread workgroup (4 wavefronts, 64 lanes along x) filters a 64x4 tile staged through LDS
+// with a 6-pixel halo: HBM/L2 traffic is 4 B out per pixel and the 169 taps come from LDS (row-contiguous ds_read_b32,
+// conflict free).  The kernel is VALU/latency bound (169 exp per pixel), so the tile is kept small: 1200 workgroups
+// give every SIMD 4-5 resident wavefronts to hide the dependent exp/fma chains (a 64x16 tile = 300 workgroups ran 4x
+// slower at one wavefront per SIMD).
 // ------------------------------------------------------------------------------------------------
 constexpr int kBR = 6;
-constexpr int kBTileW = 64, kBTileH = 16;
+constexpr int kBTileW = 64, kBTileH = 4;
 constexpr int kBLdsW = kBTileW + 2 * kBR;  // 76
-constexpr int kBLdsH = kBTileH + 2 * kBR;  // 28
+constexpr int kBLdsH = kBTileH + 2 * kBR;  // 16
 
 __global__ __launch_bounds__(256) void k_bilateral(const float* __restrict__ depth, float* __restrict__ out, int W, int H) {
     __shared__ float tile[kBLdsH * kBLdsW];
@@ -33,34 +35,31 @@ __global__ __launch_bounds__(256) void k_bilateral(const float* __restrict__ dep
     __syncthreads();
     const float sigma_space2_inv_half = 0.024691358f;
     const float sigma_color2_inv_half = 555.556f;
+    const int gx = x0 + tx, gy = y0 + ty;
+    if (gx >= W || gy >= H) return;
+    const float value = tile[(ty + kBR) * kBLdsW + tx + kBR];
+    float res = 0.f;
+    if (value > 0.03f) {
+        float sum1 = 0.f, sum2 = 0.f;
 #pragma unroll 1
-    for (int r = 0; r < kBTileH / 4; ++r) {
-        const int ly = ty + r * 4;
-        const int gx = x0 + tx, gy = y0 + ly;
-        if (gx >= W || gy >= H) continue;
-        const float value = tile[(ly + kBR) * kBLdsW + tx + kBR];
-        float res = 0.f;
-        if (value > 0.03f) {
-            float sum1 = 0.f, sum2 = 0.f;
-            for (int dy = -kBR; dy <= kBR; ++dy) {
-                const float* row = &tile[(ly + kBR + dy) * kBLdsW + tx + kBR];
-                const float fy2 = (float)(dy * dy);
+        for (int dy = -kBR; dy <= kBR; ++dy) {
+            const float* row = &tile[(ty + kBR + dy) * kBLdsW + tx + kBR];
+            const float fy2 = (float)(dy * dy);
 #pragma unroll
-                for (int dx = -kBR; dx <= kBR; ++dx) {
-                    const float tmp = row[dx];
-                    if (tmp >= 0.f) {
-                        const float space2 = (float)(dx * dx) + fy2;
-                        const float color2 = (value - tmp) * (value - tmp);
-                        const float weight = expf(-(space2 * sigma_space2_inv_half + color2 * sigma_color2_inv_half));
-                        sum1 += tmp * weight;
-                        sum2 += weight;
-                    }
+            for (int dx = -kBR; dx <= kBR; ++dx) {
+                const float tmp = row[dx];
+                if (tmp >= 0.f) {
+                    const float space2 = (float)(dx * dx) + fy2;
+                    const float color2 = (value - tmp) * (value - tmp);
+                    const float weight = expf(-(space2 * sigma_space2_inv_half + color2 * sigma_color2_inv_half));
+                    sum1 += tmp * weight;
+                    sum2 += weight;
                 }
             }
-            res = sum1 / sum2;
         }
-        out[gy * W + gx] = res;
+        res = sum1 / sum2;
     }
+    out[gy * W + gx] = res;
 }
 
 void launch_bilateral(const float* depth, float* out, int W, int H, hipStream_t s) {
@@ -72,7 +71,8 @@ void launch_bilateral(const float* depth, float* out, int W, int H, hipStream_t 
 // 5x5 Gaussian half-sampling that skips NaNs, with the reference's border quirk: the upper loop
 // bounds clamp to cols-1 / rows-1 exclusive and the kernel is indexed from the far corner.
 // ------------------------------------------------------------------------------------------------
-__constant__ float c_gauss5[25] = {1, 4, 6, 4, 1, 4, 16, 24, 16, 4, 6, 24, 36, 24, 6, 4, 16, 24, 16, 4, 1, 4, 6, 4, 1};
+// binomial row {1,4,6,4,1}; the 5x5 kernel of pyrDownGaussF (cudafuncs.cu:517-521) is its outer product
+__device__ __forceinline__ float gauss5(int i) { return i == 2 ? 6.f : ((i == 1 || i == 3) ? 4.f : 1.f); }
 
 __global__ __launch_bounds__(256) void k_pyrdown_f(const float* __restrict__ src, float* __restrict__ dst, int sw, int sh) {
     const int dw = sw >> 1, dh = sh >> 1;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_pyrdown_f(const float* __restrict__ src
         for (int cx = max(0, 2 * x - 2); cx < tx; ++cx) {
             const float v = src[cy * sw + cx];
             if (!isnan(v)) {
-                const float w = c_gauss5[(ty - cy - 1) * 5 + (tx - cx - 1)];
+                const float w = gauss5(ty - cy - 1) * gauss5(tx - cx - 1);
                 sum += v * w;
                 count += (int)w;
             }

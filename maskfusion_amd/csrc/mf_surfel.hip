@@ -19,6 +19,11 @@
 //     survivors in order with wavefront ballots.  Surfel order is therefore exactly the reference's (old surfels
 //     first, then new ones in column-major pixel order), and no workgroup ever spins on another.
 //   * every per-surfel grid is fixed-size and bounded by a device-resident count: no host round trip per pass.
+// Every float op individually rounded in this file: several passes re-derive the same quantity in different kernels
+// (a surfel's camera-space position in the index-map resolve and again in the clean pass) and then compare them for
+// strict inequality; with per-kernel FMA contraction those self-comparisons flip at random.  It also keeps these
+// kernels within rounding of a plain reading of the shaders (the oracle is built with -ffp-contract=off).
+#pragma clang fp contract(off)
 #include "mf_device.h"
 
 namespace mf {
@@ -356,25 +361,34 @@ __device__ __forceinline__ bool clean_test(const CleanArgs& a, float4 pc, float4
     const float3 ln = normalize_gl(mul33(Ri, f3(nr.x, nr.y, nr.z)));
     int count = 0, zCount = 0;
     if (time - ct.w < (float)a.timeDelta && lp.z > 0 && x > 0 && y > 0 && x < (float)W && y < (float)H) {
+        // copy_unstable.vert:86-87 samples a 4x4 window at offsets {-1,-0.5,0,+0.5} px; nearest fetches land on only 2 or
+        // 3 distinct texels per axis, so the window is walked as <= 3x3 distinct texels weighted by their multiplicity
+        // (identical counts, ~2.5x fewer gathers).
         int txs[4], tys[4];
         txs[0] = clampi((int)floorf(x - 1.0f), 0, W - 1); txs[1] = clampi((int)floorf(x - 0.5f), 0, W - 1);
         txs[2] = clampi((int)floorf(x), 0, W - 1);        txs[3] = clampi((int)floorf(x + 0.5f), 0, W - 1);
         tys[0] = clampi((int)floorf(y - 1.0f), 0, H - 1); tys[1] = clampi((int)floorf(y - 0.5f), 0, H - 1);
         tys[2] = clampi((int)floorf(y), 0, H - 1);        tys[3] = clampi((int)floorf(y + 0.5f), 0, H - 1);
+        // the four fetches are monotone: t0 <= t1 <= t2 <= t3 and t1 is t0 or t2 -> three static slots {t0, t2, t3}
+        const int ux[3] = {txs[0], txs[2], txs[3]};
+        const int mx[3] = {1 + (txs[1] == txs[0]), 1 + (txs[1] != txs[0]) + (txs[3] == txs[2]), (txs[3] != txs[2]) ? 1 : 0};
+        const int uy[3] = {tys[0], tys[2], tys[3]};
+        const int my[3] = {1 + (tys[1] == tys[0]), 1 + (tys[1] != tys[0]) + (tys[3] == tys[2]), (tys[3] != tys[2]) ? 1 : 0};
 #pragma unroll
-        for (int ia = 0; ia < 4; ++ia) {
+        for (int ia = 0; ia < 3; ++ia) {
 #pragma unroll
-            for (int ib = 0; ib < 4; ++ib) {
-                const int tp = tys[ib] * W + txs[ia];
-                if (a.index[tp] > 0) {
+            for (int ib = 0; ib < 3; ++ib) {
+                const int tp = uy[ib] * W + ux[ia];
+                const int mult = mx[ia] * my[ib];
+                if (mult > 0 && a.index[tp] > 0) {
                     const float4 v = a.vc[tp];
                     const float4 c = a.ct[tp];
                     const float dx = v.x - lp.x, dy = v.y - lp.y;
                     if (c.z < ct.z && v.w > a.confThreshold && v.z > lp.z && v.z - lp.z < 0.01f &&
                         sqrtf(dx * dx + dy * dy) < nr.w * 1.4f)
-                        count++;
+                        count += mult;
                     if (c.w == time && v.w > a.confThreshold && v.z > lp.z && v.z - lp.z > 0.01f && fabsf(ln.z) > 0.85f)
-                        zCount++;
+                        zCount += mult;
                 }
             }
         }

@@ -135,12 +135,23 @@ class Scene:
         return rgb.astype(np.uint8), depth.astype(np.float32), mask
 
 
-def add_sensor_noise(depth: np.ndarray, seed: int, hole_frac: float = 0.02) -> np.ndarray:
-    """Kinect-like axial noise sigma_z = 0.0012 + 0.0019 (z-0.4)^2 plus random holes."""
+def add_sensor_noise(depth: np.ndarray, seed: int, hole_frac: float = 0.02, hole_radius: int = 3) -> np.ndarray:
+    """Kinect-like axial noise sigma_z = 0.0012 + 0.0019 (z-0.4)^2 plus missing-depth holes.
+
+    Holes cover ~`hole_frac` of the image as (2r+1)^2 blobs: real sensors lose depth in patches (edges, specular
+    spots), not in independent pixels -- i.i.d. pixel drop-outs would wipe out the coarse pyramid levels, where one
+    invalid pixel invalidates a whole 4x4 cell (resizeMapKernel, Core/Cuda/cudafuncs.cu:385-389).
+    """
     rng = np.random.RandomState(seed)
     sigma = 0.0012 + 0.0019 * (depth - 0.4) ** 2
     out = depth + rng.standard_normal(depth.shape).astype(np.float32) * sigma
-    holes = rng.uniform(size=depth.shape) < hole_frac
+    holes = np.zeros(depth.shape, bool)
+    side = 2 * hole_radius + 1
+    n_seed = int(hole_frac * depth.size / (side * side))
+    ys = rng.randint(0, depth.shape[0], n_seed)
+    xs = rng.randint(0, depth.shape[1], n_seed)
+    for y, x in zip(ys, xs):
+        holes[max(0, y - hole_radius):y + hole_radius + 1, max(0, x - hole_radius):x + hole_radius + 1] = True
     out = np.where(holes | (depth <= 0), 0.0, out)
     return out.astype(np.float32)
 
