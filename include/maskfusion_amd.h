@@ -59,7 +59,10 @@ typedef struct mf_config {
     int32_t num_gsurfels;         /* MASKFUSION_NUM_GSURFELS = 9437184 */
     int32_t num_osurfels;         /* MASKFUSION_NUM_OSURFELS = 1048576 */
     int32_t enable_multiple_models; /* setEnableMultipleModels; 0 == "-static" */
-    int32_t reserved[8];
+    int32_t model_spawn_offset;   /* modelSpawnOffset = 20 (Core/MaskFusion.h:51) */
+    int32_t track_all_models;     /* MaskFusion::trackAllModels = true (Core/MaskFusion.h:396) */
+    int32_t max_models;           /* upper bound on live models (the reference: 256 ids) */
+    int32_t reserved[5];
 } mf_config;
 
 /* Fills *cfg with the reference's constructor defaults for a WxH camera. */
@@ -86,7 +89,8 @@ int mf_sync(mf_ctx* ctx);
 int mf_predict(mf_ctx* ctx);
 
 /* MaskFusion::getTick / getModels().size() / Model::getPose / lastCount / getConfidenceThreshold
- * (Core/MaskFusion.h:88-90,194; Core/Model/Model.h:180,233) */
+ * (Core/MaskFusion.h:88-90,194; Core/Model/Model.h:180,233).  `model` is the index in the model list (0 = background,
+ * objects in spawn order, MaskFusion::getModels()); mf_model_info gives the Model::getID() behind an index. */
 int mf_get_tick(mf_ctx* ctx, int32_t* tick);
 int mf_num_models(mf_ctx* ctx, int32_t* n);
 int mf_get_pose(mf_ctx* ctx, int32_t model, float* out_pose16);
@@ -95,12 +99,27 @@ int mf_get_surfel_count(mf_ctx* ctx, int32_t model, uint32_t* count);
 int mf_get_icp_stats(mf_ctx* ctx, int32_t model, float* last_error, float* last_count);
 /* Model::downloadMap (Core/Model/Model.h:206, Model.cpp:943-974): out has room for max_count*12 floats */
 int mf_download_map(mf_ctx* ctx, int32_t model, float* out, uint32_t max_count, uint32_t* count);
+/* Model::getID / getClassID / lastCount / getConfidenceThreshold / isNonstatic (Core/Model/Model.h:180,241-268) */
+typedef struct mf_model_info_t {
+    int32_t id, class_id;
+    uint32_t surfels;
+    float confidence_threshold;
+    int32_t is_static;
+    uint32_t age;
+} mf_model_info_t;
+int mf_model_info(mf_ctx* ctx, int32_t model, mf_model_info_t* out);
+/* SegmentationResult::fullSegmentation of the last frame (Core/Segmentation/SegmentationResult.h:35): H*W model ids,
+ * 255 = ignored.  Only meaningful with enable_multiple_models. */
+int mf_download_segmentation(mf_ctx* ctx, uint8_t* out);
 /* whether the last tracking step used the fill-in maps (MaskFusion::requiresFillIn, MaskFusion.cpp:630-648) */
 int mf_get_last_fillin(mf_ctx* ctx, int32_t* used);
 
 /* The per-frame setters of MaskFusion (Core/MaskFusion.h:132-182,234-263).  Keys: "depthCutoff", "icpWeight",
  * "confidenceThreshold" (background), "outlierCoefficient", "fastOdom", "so3", "pyramid", "timeDelta",
- * "maxDepthProcessed". */
+ * "maxDepthProcessed", "enableMultipleModels", "trackAllModels", "modelSpawnOffset",
+ * "newModelMinRelativeSize", "newModelMaxRelativeSize" (SegmentationPerformer.h:36-37) and the MfSegmentation tunables
+ * (MaskFusion.h:234-263 / MfSegmentation.h:42-62): "mfThreshold", "mfWeightDistance", "mfWeightConvexity",
+ * "mfMorphEdgeIterations", "mfMorphEdgeRadius", "mfMorphMaskIterations", "mfMorphMaskRadius". */
 int mf_set_param(mf_ctx* ctx, const char* key, double value);
 int mf_get_param(mf_ctx* ctx, const char* key, double* value);
 
@@ -116,7 +135,8 @@ void* mf_get_stream(mf_ctx* ctx);
 /* debug / differential-test taps: copy a device-resident intermediate of the last frame to host.
  * what: "depthF" (H*W f32), "vmap0".."vmap2", "nmap0".."nmap2" (3*h*w f32, current frame),
  *       "vmap_g0".."vmap_g2", "nmap_g0".."nmap_g2" (model side), "pred_vertex", "pred_normal" (H*W*4 f32),
- *       "pred_image" (H*W*4 u8), "index" (H*W i32), "icp_log" (19*32 f32: per-iteration A-upper/b/res/inl). */
+ *       "pred_image" (H*W*4 u8), "index" (H*W i32), "icp_log" (19*32 f32: per-iteration A-upper/b/res/inl),
+ *       "edge_map" (H*W f32), "edge_binary" (H*W u8), "projected_ids" (H*W u8). */
 int mf_debug_read(mf_ctx* ctx, const char* what, void* out, uint64_t out_bytes);
 
 /* ------------------------------------------------------------------------------------------------
@@ -134,6 +154,21 @@ int mf_k_vmap_nmap(const float* d_depth, float* d_vmap, float* d_nmap, int32_t W
  * d_v4/d_n4: H*W float4 predictions; outputs: 3 levels planar, packed level after level; R row-major 3x3 */
 int mf_k_model_pyramid(const float* d_v4, const float* d_n4, const float* R9, const float* t3, float* d_vmaps,
                        float* d_nmaps, int32_t W, int32_t H, void* stream);
+/* computeGeometricSegmentationMap -> thresholdMap -> morphGeometricSegmentationMap -> invertMap
+ * (Core/Cuda/segmentation.cu:277-354; MfSegmentation.cpp:149-207).  d_vmap/d_nmap: level-0 planar maps;
+ * d_edge: H*W f32 out; d_binary: H*W u8 out (255 = not an edge); d_tmp: H*W u8 scratch */
+int mf_k_geometric_edges(const float* d_vmap, const float* d_nmap, float* d_edge, uint8_t* d_binary, uint8_t* d_tmp,
+                         int32_t W, int32_t H, float w_distance, float w_convexity, float threshold, int32_t morph_radius,
+                         int32_t morph_iterations, void* stream);
+/* Host half of MfSegmentation::performSegmentation (Core/Segmentation/MfSegmentation.cpp:220-522): HOST pointers, no GPU
+ * involved (the reference runs this stage on the CPU too).  binary: 255 = not an edge; params: {threshold, weightDistance,
+ * weightConvexity, morphEdgeIterations, morphEdgeRadius, morphMaskIterations, morphMaskRadius, removeEdges,
+ * minRelSizeNew, maxRelSizeNew, personClassID} (MfSegmentation.h:42-62); ignore_map: persistent H*W in/out. */
+int mf_segmentation_labels(int32_t W, int32_t H, const uint8_t* binary, const float* depth, const uint8_t* mask,
+                           const int32_t* class_ids, int32_t n_masks, const uint8_t* projected_ids, const int32_t* model_ids,
+                           const int32_t* model_class_ids, int32_t n_models, int32_t next_model_id, int32_t allow_new,
+                           const float* params11, uint8_t* ignore_map, uint8_t* full_segmentation, int32_t* has_new_label,
+                           int32_t* new_class_id);
 /* icpStep (Core/Cuda/reduce.cu:446-525): d_out32 receives {27 upper-tri products, sum r^2, inliers, pad} */
 int mf_k_icp_step(const float* Rcurr9, const float* tcurr3, const float* d_vmap_curr, const float* d_nmap_curr,
                   const float* Rprev_inv9, const float* tprev3, float fx, float fy, float cx, float cy,

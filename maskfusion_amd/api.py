@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import numpy as np
 
-from .lib import load, MFError, Config, MF_N_TIMINGS, TIMING_LABELS
+from .lib import load, MFError, Config, ModelInfo, MF_N_TIMINGS, TIMING_LABELS
 
 
 class Model:
@@ -19,8 +19,19 @@ class Model:
         self._o = owner
         self._i = index
 
+    def info(self) -> ModelInfo:
+        out = ModelInfo()
+        self._o._chk(self._o._L.mf_model_info(self._o._h, self._i, C.byref(out)))
+        return out
+
     def getID(self) -> int:
-        return self._i
+        return int(self.info().id)
+
+    def getClassID(self) -> int:
+        return int(self.info().class_id)
+
+    def getConfidenceThreshold(self) -> float:
+        return float(self.info().confidence_threshold)
 
     def getPose(self) -> np.ndarray:
         out = np.zeros(16, np.float32)
@@ -52,7 +63,7 @@ class MaskFusion:
     def __init__(self, width=640, height=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, *, timeDelta=200,
                  initConfidenceGlobal=4.0, initConfidenceObject=2.0, depthCut=3.0, icpThresh=10.0, fastOdom=False,
                  so3=True, device=0, numGSurfels=9437184, numOSurfels=1048576, enableMultipleModels=True,
-                 outlierCoefficient=0.9):
+                 outlierCoefficient=0.9, modelSpawnOffset=20, trackAllModels=True):
         self._L = load()
         cfg = Config()
         self._L.mf_default_config(C.byref(cfg), width, height, fx, fy, cx, cy)
@@ -68,6 +79,8 @@ class MaskFusion:
         cfg.num_osurfels = numOSurfels
         cfg.enable_multiple_models = int(enableMultipleModels)
         cfg.outlier_coefficient = outlierCoefficient
+        cfg.model_spawn_offset = modelSpawnOffset
+        cfg.track_all_models = int(trackAllModels)
         self.cfg = cfg
         self.width, self.height = width, height
         h = C.c_void_p()
@@ -95,7 +108,7 @@ class MaskFusion:
 
     # -- MaskFusion::processFrame ---------------------------------------------------------------
     def processFrame(self, rgb: np.ndarray, depth: np.ndarray, mask: np.ndarray | None = None, timestamp: int = 0,
-                     inPose=None, weightMultiplier: float = 1.0, bootstrap: bool = False) -> bool:
+                     inPose=None, weightMultiplier: float = 1.0, bootstrap: bool = False, classIDs=()) -> bool:
         rgb = np.ascontiguousarray(rgb, np.uint8)
         depth = np.ascontiguousarray(depth, np.float32)
         assert rgb.shape == (self.height, self.width, 3) and depth.shape == (self.height, self.width)
@@ -105,8 +118,10 @@ class MaskFusion:
         pose = None
         if inPose is not None:
             pose = np.ascontiguousarray(np.asarray(inPose, np.float32).T.reshape(16))
+        cid = np.ascontiguousarray(classIDs, np.int32) if len(classIDs) else None
         self._chk(self._L.mf_process_frame(self._h, rgb.ctypes.data, depth.ctypes.data,
-                                           m.ctypes.data if m is not None else None, None, 0, timestamp,
+                                           m.ctypes.data if m is not None else None,
+                                           cid.ctypes.data if cid is not None else None, len(classIDs), timestamp,
                                            pose.ctypes.data if pose is not None else None, weightMultiplier,
                                            int(bootstrap)))
         return False  # the reference always returns false (MaskFusion.cpp:606)
@@ -138,6 +153,12 @@ class MaskFusion:
 
     def getCurrPose(self) -> np.ndarray:
         return self.getBackgroundModel().getPose()
+
+    def downloadSegmentation(self) -> np.ndarray:
+        """SegmentationResult::fullSegmentation of the last frame (model id per pixel, 255 = ignored)."""
+        out = np.zeros((self.height, self.width), np.uint8)
+        self._chk(self._L.mf_download_segmentation(self._h, out.ctypes.data))
+        return out
 
     def getLastFillIn(self) -> bool:
         u = C.c_int32(0)
@@ -174,7 +195,8 @@ class MaskFusion:
         shapes = {"depthF": ((H, W), np.float32), "pred_vertex": ((H, W, 4), np.float32),
                   "pred_normal": ((H, W, 4), np.float32), "pred_image": ((H, W, 4), np.uint8),
                   "index": ((H, W), np.int32), "index_vc": ((H, W, 4), np.float32), "icp_log": ((19, 32), np.float32),
-                  "icp_prof": ((19, 8), np.uint64)}
+                  "icp_prof": ((19, 8), np.uint64), "edge_map": ((H, W), np.float32),
+                  "edge_binary": ((H, W), np.uint8), "projected_ids": ((H, W), np.uint8)}
         for pre in ("vmap_g", "nmap_g", "vmap", "nmap"):
             for i in range(3):
                 shapes[f"{pre}{i}"] = ((3, H >> i, W >> i), np.float32)

@@ -1,18 +1,47 @@
 // mf_context.hip -- the mf_ctx object and the C ABI of include/maskfusion_amd.h.
 //
-// One context = one GPU, one HIP stream, one background model (multi-model sharding: one context per rank, see
-// DESIGN.md section "multi-GPU").  MaskFusion::processFrame (Core/MaskFusion.cpp:200-607) becomes a fixed sequence of
-// asynchronous launches on that stream; the host never reads anything back between them.
+// One context = one GPU, one HIP stream, one model list (background + object models).  MaskFusion::processFrame
+// (Core/MaskFusion.cpp:200-607) becomes a fixed sequence of asynchronous launches on that stream.  With a single model
+// ("-static") the host never reads anything back inside a frame; with multiple models there is exactly one host
+// synchronisation per frame, where the reference also leaves the GPU (MfSegmentation's CPU stage).
 #include "../../include/maskfusion_amd.h"
 #include "mf_internal.h"
+#include "mf_labels.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <memory>
 #include <string>
 #include <vector>
 
 using namespace mf;
+
+namespace {
+
+// One surfel model (Core/Model/Model.h): persistent per-model device state.  Everything else (maps, index map, candidate
+// buffers, z-buffer keys) is scratch shared by all models: the reference's per-model passes never overlap in time.
+struct ModelState {
+    int id = 0, classID = -1;
+    bool isStatic = true, allowFillIn = false;
+    unsigned age = 0;
+    float confThr = 0.f, maxDepth = FLT_MAX;
+    Surfels surf[2];
+    int cur = 0, cap = 0;
+    PoseDev* d_pose = nullptr; FrameDev* d_frame = nullptr;
+    float4* d_predV = nullptr; float4* d_predN = nullptr; uchar4* d_predImage = nullptr; uint16_t* d_predTime = nullptr;
+    PoseDev* h_pose = nullptr; FrameDev* h_frame = nullptr; int* h_count = nullptr;
+    std::vector<void*> allocs;
+    ~ModelState() {
+        for (void* p : allocs) (void)hipFree(p);
+        if (h_pose) (void)hipHostFree(h_pose);
+        if (h_frame) (void)hipHostFree(h_frame);
+        if (h_count) (void)hipHostFree(h_count);
+    }
+};
+
+}  // namespace
 
 struct mf_ctx {
     mf_config cfg;
@@ -21,29 +50,36 @@ struct mf_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     int host_tick = 1;
-    bool timings_on = false;
+    bool timings_on = false, icp_prof_on = false;
 
     // frame-level
-    uint8_t* d_rgb = nullptr; float* d_depth = nullptr; uint8_t* d_mask = nullptr; uint8_t* d_zero_mask = nullptr;
+    uint8_t* d_rgb = nullptr; float* d_depth = nullptr; uint8_t* d_mask_in = nullptr; uint8_t* d_zero_mask = nullptr;
+    uint8_t* d_mask_tex = nullptr;  // textureMask: the last full segmentation (Core/MaskFusion.cpp:297)
     float* d_depthF[2] = {nullptr, nullptr}; int curF = 0;
     float* d_dpyr[3] = {nullptr, nullptr, nullptr};
     float* d_vmap[3]; float* d_nmap[3];
-    // model-level (background model)
-    Surfels surf[2]; int cur = 0; int cap = 0;
-    PoseDev* d_pose = nullptr; GNState* d_gn = nullptr; float* d_partials[2] = {nullptr, nullptr};
+    // shared scratch
+    GNState* d_gn = nullptr; float* d_partials[2] = {nullptr, nullptr};
     float* d_vmap_g[3]; float* d_nmap_g[3];
     unsigned long long* d_keys = nullptr;
     int* d_index = nullptr; float4* d_ivc = nullptr; float4* d_ict = nullptr; float4* d_inr = nullptr;
-    float4* d_predV = nullptr; float4* d_predN = nullptr; uchar4* d_predImage = nullptr; uint16_t* d_predTime = nullptr;
     uint8_t* d_cand_op = nullptr; float4* d_cand_rec = nullptr; int* d_upd_first = nullptr;
     uint8_t* d_flags = nullptr; float* d_newconf = nullptr; int* d_block_counts = nullptr;
-    FrameDev* d_frame = nullptr; float* d_icp_log = nullptr; unsigned long long* d_icp_prof = nullptr; bool icp_prof_on = false;
-    // pinned host mirrors
-    PoseDev* h_pose = nullptr; FrameDev* h_frame = nullptr; int* h_count = nullptr;
-    // timings
+    float* d_icp_log = nullptr; unsigned long long* d_icp_prof = nullptr;
+    // multi-model coupling
+    float* d_edge = nullptr; uint8_t* d_bin = nullptr; uint8_t* d_tmp_u8 = nullptr; uint8_t* d_proj_ids = nullptr;
+    uint8_t* h_bin = nullptr; uint8_t* h_ids = nullptr; float* h_depth = nullptr; uint8_t* h_mask = nullptr; uint8_t* h_full = nullptr;
+    std::vector<uint8_t> ignoreMap;
+    SegParams seg;
+    int nextID = 0, spawnOffset = 0;
+    int cap_max = 0;
+
+    std::vector<std::unique_ptr<ModelState>> models;
+
     hipEvent_t ev[MF_N_TIMINGS + 1] = {};
     float last_ms[MF_N_TIMINGS] = {};
     std::vector<void*> allocs;
+    std::vector<void*> host_allocs;
 };
 
 #define MF_HIP(ctx, call)                                                                         \
@@ -58,11 +94,20 @@ struct mf_ctx {
     } while (0)
 
 template <typename T>
-static int dev_alloc(mf_ctx* c, T** p, size_t n, int fill = 0) {
+static int dev_alloc(mf_ctx* c, std::vector<void*>& owner, T** p, size_t n, int fill = 0) {
     void* q = nullptr;
     MF_HIP(c, hipMalloc(&q, n * sizeof(T)));
     MF_HIP(c, hipMemsetAsync(q, fill, n * sizeof(T), c->stream));
-    c->allocs.push_back(q);
+    owner.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return MF_OK;
+}
+template <typename T>
+static int host_alloc(mf_ctx* c, T** p, size_t n) {
+    void* q = nullptr;
+    MF_HIP(c, hipHostMalloc(&q, n * sizeof(T)));
+    memset(q, 0, n * sizeof(T));
+    c->host_allocs.push_back(q);
     *p = reinterpret_cast<T*>(q);
     return MF_OK;
 }
@@ -77,6 +122,7 @@ extern "C" int mf_default_config(mf_config* cfg, int32_t width, int32_t height, 
     cfg->outlier_coefficient = 0.9f;
     cfg->num_gsurfels = 9437184; cfg->num_osurfels = 1048576;
     cfg->enable_multiple_models = 1;
+    cfg->model_spawn_offset = 20; cfg->track_all_models = 1; cfg->max_models = 32;
     return MF_OK;
 }
 
@@ -84,14 +130,55 @@ static __global__ void k_pose_identity(PoseDev* p) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     PoseDev q;
     memset(&q, 0, sizeof(q));
-    for (int k = 0; k < 9; ++k) q.R[k] = q.Ri[k] = q.lastR[k] = (k % 4 == 0) ? 1.f : 0.f;
+    for (int k = 0; k < 9; ++k) q.R[k] = q.Ri[k] = q.lastR[k] = q.initR[k] = (k % 4 == 0) ? 1.f : 0.f;
     q.fusionWeight = 1.f;
+    q.alive = 1;
     *p = q;
 }
-static __global__ void k_frame_init(FrameDev* f) {
+static __global__ void k_frame_init(FrameDev* f, int tick) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    f->tick = 1; f->count = 0; f->countNext = 0; f->cover = 0; f->useFillIn = 0;
+    f->tick = tick; f->count = 0; f->countNext = 0; f->cover = 0; f->useFillIn = 0;
     f->pad[0] = f->pad[1] = f->pad[2] = 0;
+}
+
+static int surfel_capacity(int num) {  // Model::TEXTURE_DIMENSION_*^2 (Core/Model/Model.cpp:101-105)
+    const int dim = 64 * (int)(sqrt((double)num) / 64);
+    return dim * dim;
+}
+
+// Model::Model (Core/Model/Model.cpp:115-223): buffers of one model
+static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int cap, std::unique_ptr<ModelState>& out) {
+    std::unique_ptr<ModelState> m(new ModelState());
+    m->id = id; m->confThr = confThr; m->allowFillIn = allowFillIn; m->cap = cap;
+    const size_t P = (size_t)c->P;
+    int rc;
+#define A(call) do { rc = (call); if (rc != MF_OK) return rc; } while (0)
+    for (int b = 0; b < 2; ++b) {
+        A(dev_alloc(c, m->allocs, &m->surf[b].pc, (size_t)cap));
+        A(dev_alloc(c, m->allocs, &m->surf[b].ct, (size_t)cap));
+        A(dev_alloc(c, m->allocs, &m->surf[b].nr, (size_t)cap));
+        m->surf[b].cap = cap;
+    }
+    A(dev_alloc(c, m->allocs, &m->d_pose, 1));
+    A(dev_alloc(c, m->allocs, &m->d_frame, 1));
+    A(dev_alloc(c, m->allocs, &m->d_predV, P));
+    A(dev_alloc(c, m->allocs, &m->d_predN, P));
+    A(dev_alloc(c, m->allocs, &m->d_predImage, P));
+    A(dev_alloc(c, m->allocs, &m->d_predTime, P));
+#undef A
+    hipLaunchKernelGGL(k_pose_identity, dim3(1), dim3(64), 0, c->stream, m->d_pose);
+    hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(64), 0, c->stream, m->d_frame, c->host_tick);
+    if (hipHostMalloc((void**)&m->h_pose, sizeof(PoseDev)) != hipSuccess || hipHostMalloc((void**)&m->h_frame, sizeof(FrameDev)) != hipSuccess ||
+        hipHostMalloc((void**)&m->h_count, sizeof(int)) != hipSuccess)
+        return MF_ENOMEM;
+    memset(m->h_pose, 0, sizeof(PoseDev));
+    for (int k = 0; k < 9; ++k) m->h_pose->R[k] = m->h_pose->Ri[k] = (k % 4 == 0) ? 1.f : 0.f;
+    m->h_pose->alive = 1;
+    memset(m->h_frame, 0, sizeof(FrameDev));
+    m->h_frame->tick = c->host_tick;
+    *m->h_count = 0;
+    out = std::move(m);
+    return MF_OK;
 }
 
 extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
@@ -102,72 +189,65 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev) return MF_ENODEV;
     mf_ctx* c = new mf_ctx();
     c->cfg = *cfg;
+    if (c->cfg.model_spawn_offset <= 0) c->cfg.model_spawn_offset = 20;
+    if (c->cfg.max_models <= 0) c->cfg.max_models = 32;
     c->W = cfg->width; c->H = cfg->height; c->P = c->W * c->H;
     c->K = Intr{cfg->fx, cfg->fy, cfg->cx, cfg->cy};
     auto fail = [&](int code) { mf_destroy(c); return code; };
     if (hipSetDevice(cfg->device) != hipSuccess) return fail(MF_ENODEV);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(MF_ENODEV);
     const int W = c->W, H = c->H, P = c->P;
-    // Model::TEXTURE_DIMENSION_GLOBAL^2 (Core/Model/Model.cpp:101-105)
-    const int dim = 64 * (int)(sqrt((double)cfg->num_gsurfels) / 64);
-    c->cap = dim * dim;
-    if (c->cap <= 0) return fail(MF_EINVAL);
+    const int cap_bg = surfel_capacity(cfg->num_gsurfels), cap_obj = surfel_capacity(cfg->num_osurfels);
+    if (cap_bg <= 0 || cap_obj <= 0) return fail(MF_EINVAL);
+    c->cap_max = cap_bg > cap_obj ? cap_bg : cap_obj;
     int rc = MF_OK;
 #define A(call) do { rc = (call); if (rc != MF_OK) return fail(rc); } while (0)
-    A(dev_alloc(c, &c->d_rgb, (size_t)P * 3));
-    A(dev_alloc(c, &c->d_depth, (size_t)P));
-    A(dev_alloc(c, &c->d_mask, (size_t)P));
-    A(dev_alloc(c, &c->d_zero_mask, (size_t)P));
-    A(dev_alloc(c, &c->d_depthF[0], (size_t)P));
-    A(dev_alloc(c, &c->d_depthF[1], (size_t)P));
+    A(dev_alloc(c, c->allocs, &c->d_rgb, (size_t)P * 3));
+    A(dev_alloc(c, c->allocs, &c->d_depth, (size_t)P));
+    A(dev_alloc(c, c->allocs, &c->d_mask_in, (size_t)P));
+    A(dev_alloc(c, c->allocs, &c->d_zero_mask, (size_t)P));
+    A(dev_alloc(c, c->allocs, &c->d_mask_tex, (size_t)P));
+    A(dev_alloc(c, c->allocs, &c->d_depthF[0], (size_t)P));
+    A(dev_alloc(c, c->allocs, &c->d_depthF[1], (size_t)P));
     for (int i = 0; i < 3; ++i) {
         const size_t lp = (size_t)(W >> i) * (H >> i);
-        if (i > 0) A(dev_alloc(c, &c->d_dpyr[i], lp));
-        A(dev_alloc(c, &c->d_vmap[i], lp * 3));
-        A(dev_alloc(c, &c->d_nmap[i], lp * 3));
-        A(dev_alloc(c, &c->d_vmap_g[i], lp * 3));
-        A(dev_alloc(c, &c->d_nmap_g[i], lp * 3));
+        if (i > 0) A(dev_alloc(c, c->allocs, &c->d_dpyr[i], lp));
+        A(dev_alloc(c, c->allocs, &c->d_vmap[i], lp * 3));
+        A(dev_alloc(c, c->allocs, &c->d_nmap[i], lp * 3));
+        A(dev_alloc(c, c->allocs, &c->d_vmap_g[i], lp * 3));
+        A(dev_alloc(c, c->allocs, &c->d_nmap_g[i], lp * 3));
     }
-    for (int b = 0; b < 2; ++b) {
-        A(dev_alloc(c, &c->surf[b].pc, (size_t)c->cap));
-        A(dev_alloc(c, &c->surf[b].ct, (size_t)c->cap));
-        A(dev_alloc(c, &c->surf[b].nr, (size_t)c->cap));
-        c->surf[b].cap = c->cap;
-        A(dev_alloc(c, &c->d_partials[b], (size_t)icp_grid_blocks(W, H) * kIcpSlots));
-    }
-    A(dev_alloc(c, &c->d_pose, 1));
-    A(dev_alloc(c, &c->d_gn, 2));
-    A(dev_alloc(c, &c->d_keys, (size_t)P, 0xFF));
-    A(dev_alloc(c, &c->d_index, (size_t)P));
-    A(dev_alloc(c, &c->d_ivc, (size_t)P));
-    A(dev_alloc(c, &c->d_ict, (size_t)P));
-    A(dev_alloc(c, &c->d_inr, (size_t)P));
-    A(dev_alloc(c, &c->d_predV, (size_t)P));
-    A(dev_alloc(c, &c->d_predN, (size_t)P));
-    A(dev_alloc(c, &c->d_predImage, (size_t)P));
-    A(dev_alloc(c, &c->d_predTime, (size_t)P));
-    A(dev_alloc(c, &c->d_cand_op, (size_t)P));
-    A(dev_alloc(c, &c->d_cand_rec, (size_t)P * 3));
-    A(dev_alloc(c, &c->d_upd_first, (size_t)c->cap));
-    A(dev_alloc(c, &c->d_flags, (size_t)c->cap + P));
-    A(dev_alloc(c, &c->d_newconf, (size_t)c->cap + P));
-    A(dev_alloc(c, &c->d_block_counts, (size_t)kCompactBlocks));
-    A(dev_alloc(c, &c->d_frame, 1));
-    A(dev_alloc(c, &c->d_icp_log, (size_t)20 * 32));
-    A(dev_alloc(c, &c->d_icp_prof, (size_t)20 * 8));
+    for (int b = 0; b < 2; ++b) A(dev_alloc(c, c->allocs, &c->d_partials[b], (size_t)icp_grid_blocks(W, H) * kIcpSlots));
+    A(dev_alloc(c, c->allocs, &c->d_gn, 2));
+    A(dev_alloc(c, c->allocs, &c->d_keys, (size_t)P, 0xFF));
+    A(dev_alloc(c, c->allocs, &c->d_index, (size_t)P));
+    A(dev_alloc(c, c->allocs, &c->d_ivc, (size_t)P));
+    A(dev_alloc(c, c->allocs, &c->d_ict, (size_t)P));
+    A(dev_alloc(c, c->allocs, &c->d_inr, (size_t)P));
+    A(dev_alloc(c, c->allocs, &c->d_cand_op, (size_t)P));
+    A(dev_alloc(c, c->allocs, &c->d_cand_rec, (size_t)P * 3));
+    A(dev_alloc(c, c->allocs, &c->d_upd_first, (size_t)c->cap_max));
+    A(dev_alloc(c, c->allocs, &c->d_flags, (size_t)c->cap_max + P));
+    A(dev_alloc(c, c->allocs, &c->d_newconf, (size_t)c->cap_max + P));
+    A(dev_alloc(c, c->allocs, &c->d_block_counts, (size_t)kCompactBlocks));
+    A(dev_alloc(c, c->allocs, &c->d_icp_log, (size_t)20 * 32));
+    A(dev_alloc(c, c->allocs, &c->d_icp_prof, (size_t)20 * 8));
+    A(dev_alloc(c, c->allocs, &c->d_edge, (size_t)P));
+    A(dev_alloc(c, c->allocs, &c->d_bin, (size_t)P));
+    A(dev_alloc(c, c->allocs, &c->d_tmp_u8, (size_t)P));
+    A(dev_alloc(c, c->allocs, &c->d_proj_ids, (size_t)P));
+    A(host_alloc(c, &c->h_bin, (size_t)P));
+    A(host_alloc(c, &c->h_ids, (size_t)P));
+    A(host_alloc(c, &c->h_depth, (size_t)P));
+    A(host_alloc(c, &c->h_mask, (size_t)P));
+    A(host_alloc(c, &c->h_full, (size_t)P));
+    launch_fill_int(c->d_upd_first, kNoUpdate, c->cap_max, c->stream);
+    // globalModel = Model(getNextModelID(true), initConfidenceGlobal, fillIn = true) (Core/MaskFusion.cpp:80)
+    std::unique_ptr<ModelState> bg;
+    A(create_model(c, c->nextID++, cfg->conf_global, true, cap_bg, bg));
+    c->models.push_back(std::move(bg));
 #undef A
-    launch_fill_int(c->d_upd_first, kNoUpdate, c->cap, c->stream);
-    hipLaunchKernelGGL(k_pose_identity, dim3(1), dim3(64), 0, c->stream, c->d_pose);
-    hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(64), 0, c->stream, c->d_frame);
-    if (hipHostMalloc((void**)&c->h_pose, sizeof(PoseDev)) != hipSuccess ||
-        hipHostMalloc((void**)&c->h_frame, sizeof(FrameDev)) != hipSuccess ||
-        hipHostMalloc((void**)&c->h_count, sizeof(int)) != hipSuccess)
-        return fail(MF_ENOMEM);
-    memset(c->h_pose, 0, sizeof(PoseDev));
-    for (int k = 0; k < 9; ++k) c->h_pose->R[k] = c->h_pose->Ri[k] = (k % 4 == 0) ? 1.f : 0.f;
-    memset(c->h_frame, 0, sizeof(FrameDev));
-    c->h_frame->tick = 1;
-    *c->h_count = 0;
+    c->ignoreMap.assign(P, 0);
     for (int i = 0; i <= MF_N_TIMINGS; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) return fail(MF_EHIP);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(MF_EHIP);
@@ -177,52 +257,131 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
 
 extern "C" void mf_destroy(mf_ctx* c) {
     if (!c) return;
-    if (c->stream) hipStreamSynchronize(c->stream);
-    for (void* p : c->allocs) hipFree(p);
-    if (c->h_pose) hipHostFree(c->h_pose);
-    if (c->h_frame) hipHostFree(c->h_frame);
-    if (c->h_count) hipHostFree(c->h_count);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->models.clear();
+    for (void* p : c->allocs) (void)hipFree(p);
+    for (void* p : c->host_allocs) (void)hipHostFree(p);
     for (int i = 0; i <= MF_N_TIMINGS; ++i)
-        if (c->ev[i]) hipEventDestroy(c->ev[i]);
-    if (c->stream) hipStreamDestroy(c->stream);
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
 extern "C" const char* mf_last_error(const mf_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
-// MaskFusion::predict for the background model: combinedPredict(maxDepthProcessed, tick, tick, timeDelta) -- the fill-in
-// half (performFillIn) is evaluated lazily by the next tracking step from the retained filtered depth.
-static void enqueue_predict(mf_ctx* c) {
-    launch_splat_scatter(c->surf[c->cur], c->d_frame, c->d_pose, c->W, c->H, c->K, c->cfg.max_depth_processed,
-                         c->cfg.conf_global, c->cfg.time_delta, c->d_keys, c->stream);
-    launch_splat_resolve(c->surf[c->cur], c->d_pose, c->d_keys, c->W, c->H, c->K, c->d_predV, c->d_predN, c->d_predImage,
-                         c->d_predTime, c->d_frame, c->stream);
-}
-
 static void mark(mf_ctx* c, int i) {
-    if (c->timings_on) hipEventRecord(c->ev[i], c->stream);
+    if (c->timings_on) (void)hipEventRecord(c->ev[i], c->stream);
 }
 
-extern "C" int mf_process_frame_dev(mf_ctx* c, const uint8_t* d_rgb, const float* d_depth, const uint8_t* d_mask,
-                                    int64_t timestamp, float weight_multiplier) {
-    (void)timestamp;
-    if (!c || !d_rgb || !d_depth) return MF_EINVAL;
+// ------------------------------------------------------------------------------------------------
+// per-model stages
+// ------------------------------------------------------------------------------------------------
+// Model::performTracking (Core/Model/Model.cpp:427-447): initICPModel (+ fill-in) then the Gauss-Newton loop
+static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, float jump_limit) {
+    const mf_config& g = c->cfg;
     const int W = c->W, H = c->H;
     hipStream_t s = c->stream;
+    launch_model_pyramid(m.d_predV, m.d_predN, m.allowFillIn ? fillDepth : nullptr, m.d_frame, m.d_pose, nullptr, c->d_vmap_g,
+                         c->d_nmap_g, W, H, c->K, s);
+    launch_icp_begin(m.d_pose, &c->d_gn[0], s);
+    const int iters[3] = {g.fast_odom ? 3 : 10, g.pyramid ? 5 : 0, g.pyramid ? 4 : 0};  // RGBDOdometry.cpp:327-329
+    int k = 0, nb_prev = 0;
+    for (int lvl = 2; lvl >= 0; --lvl) {
+        const float div = (float)(1 << lvl);
+        for (int j = 0; j < iters[lvl]; ++j) {
+            IcpLaunch l;
+            l.vmap_curr = c->d_vmap[lvl]; l.nmap_curr = c->d_nmap[lvl];
+            l.vmap_prev = c->d_vmap_g[lvl]; l.nmap_prev = c->d_nmap_g[lvl];
+            l.W = W >> lvl; l.H = H >> lvl; l.k = Intr{g.fx / div, g.fy / div, g.cx / div, g.cy / div};
+            l.distThres = 0.10f; l.angleThres = sinf(20.f * 3.14159254f / 180.f);  // RGBDOdometry.h:35-36
+            l.partials_in = nb_prev ? c->d_partials[(k + 1) & 1] : nullptr;
+            l.nblocks_in = nb_prev;
+            l.partials_out = c->d_partials[k & 1];
+            l.state_in = &c->d_gn[k & 1]; l.state_out = &c->d_gn[(k + 1) & 1];
+            l.log_out = (k > 0 && m.id == 0) ? c->d_icp_log + 32 * (k - 1) : nullptr;
+            l.prof_out = (c->icp_prof_on && m.id == 0) ? c->d_icp_prof + 8 * k : nullptr;
+            launch_icp_iteration(l, s);
+            nb_prev = icp_grid_blocks(l.W, l.H);
+            ++k;
+        }
+    }
+    launch_icp_finalize(nb_prev ? c->d_partials[(k + 1) & 1] : nullptr, nb_prev, &c->d_gn[k & 1], m.d_pose, m.h_pose,
+                        (k > 0 && m.id == 0) ? c->d_icp_log + 32 * (k - 1) : nullptr, jump_limit, s);
+}
+
+// predictIndices -> fuse -> [predictIndices] -> clean for one model (Core/MaskFusion.cpp:541-563 / :344-353)
+static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, const float* d_depth, const float* depthF,
+                               const uint8_t* mask, float fuseDepthCutoff, float weightMultiplier, bool secondIndexPass, bool marks) {
     const mf_config& g = c->cfg;
+    const int W = c->W, H = c->H;
+    hipStream_t s = c->stream;
+    const int src = m.cur, dst = 1 - m.cur;
+    launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, s);
+    launch_index_resolve(m.surf[src], m.d_pose, c->d_keys, W, H, c->d_index, c->d_ivc, c->d_ict, c->d_inr, s);
+    if (marks) mark(c, 4);
+    // Model::fuse maxDepth uniform: min(depthCutoff, model.maxDepth, bb_max_z = FLT_MAX without the GUI) (Model.cpp:527)
+    launch_fuse_data(d_rgb, d_depth, depthF, mask, m.id, m.d_frame, m.d_pose, weightMultiplier, fminf(fuseDepthCutoff, m.maxDepth), W, H,
+                     c->K, c->d_index, c->d_ivc, c->d_inr, c->d_cand_op, c->d_cand_rec, c->d_upd_first, s);
+    if (marks) mark(c, 5);
+    launch_fuse_update(m.surf[src], m.surf[dst], m.d_frame, c->d_upd_first, c->d_cand_rec, s);
+    if (marks) mark(c, 6);
+    if (secondIndexPass) {
+        launch_index_scatter(m.surf[dst], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, s);
+        launch_index_resolve(m.surf[dst], m.d_pose, c->d_keys, W, H, c->d_index, c->d_ivc, c->d_ict, c->d_inr, s);
+    }
+    launch_clean(m.surf[dst], m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.time_delta, m.confThr, g.outlier_coefficient, m.id,
+                 c->d_index, c->d_ivc, c->d_ict, depthF, mask, c->d_cand_op, c->d_cand_rec, c->d_flags, c->d_newconf,
+                 c->d_block_counts, m.h_count, s);
+    // two swaps (fuse, clean) leave the live buffer where it started
+}
+
+// MaskFusion::predict for one model: combinedPredict(maxDepthProcessed, tick, tick, timeDelta) -- the fill-in half
+// (performFillIn) is evaluated lazily by the next tracking step from the retained filtered depth.
+static void enqueue_predict(mf_ctx* c, ModelState& m) {
+    launch_splat_scatter(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, c->cfg.max_depth_processed, m.confThr,
+                         c->cfg.time_delta, c->d_keys, c->stream);
+    launch_splat_resolve(m.surf[m.cur], m.d_pose, c->d_keys, c->W, c->H, c->K, m.d_predV, m.d_predN, m.d_predImage, m.d_predTime,
+                         m.d_frame, c->stream);
+}
+
+static int check_launch(mf_ctx* c) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { c->err = std::string("launch failed: ") + hipGetErrorString(e); return MF_EHIP; }
+    return MF_OK;
+}
+
+// getNextModelID(true) (Core/MaskFusion.cpp:715-731)
+static int take_next_model_id(mf_ctx* c) {
+    const int next = c->nextID;
+    for (;;) {
+        c->nextID = (c->nextID + 1) & 255;
+        bool occupied = false;
+        for (auto& m : c->models) occupied |= (m->id == c->nextID);
+        if (!occupied) break;
+    }
+    return next;
+}
+
+static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_depth, const uint8_t* d_mask_in,
+                              const int32_t* class_ids, int n_masks, float weight_multiplier) {
+    const int W = c->W, H = c->H, P = c->P;
+    hipStream_t s = c->stream;
+    const mf_config& g = c->cfg;
+    const bool multi = g.enable_multiple_models != 0;
     // -static (enableMultipleModels == false): everything is background (MaskFusion.cpp:223-230)
-    const uint8_t* mask = (g.enable_multiple_models && d_mask) ? d_mask : c->d_zero_mask;
+    const uint8_t* mask = multi ? c->d_mask_tex : c->d_zero_mask;
     float* depthF = c->d_depthF[c->curF];
     float* depthF_prev = c->d_depthF[1 - c->curF];
+    ModelState& bg = *c->models[0];
 
     mark(c, 0);
     launch_bilateral(d_depth, depthF, W, H, s);  // filterDepth, :217
     if (c->host_tick == 1) {
         mark(c, 1); mark(c, 2); mark(c, 3); mark(c, 4); mark(c, 5); mark(c, 6);
         // :235-238
-        launch_init_surfels(d_rgb, d_depth, depthF, W, H, c->K, g.max_depth_processed, c->d_frame, c->d_cand_rec, c->d_flags, s);
-        c->cur = 0;
-        launch_compact_records(c->d_cand_rec, c->d_flags, c->P, c->surf[0], c->d_frame, c->d_block_counts, c->h_count, s);
+        launch_init_surfels(d_rgb, d_depth, depthF, W, H, c->K, g.max_depth_processed, bg.d_frame, c->d_cand_rec, c->d_flags, s);
+        bg.cur = 0;
+        launch_compact_records(c->d_cand_rec, c->d_flags, P, bg.surf[0], bg.d_frame, c->d_block_counts, bg.h_count, s);
         mark(c, 7);
     } else {
         // Model::generateCUDATextures (Model.cpp:350-389)
@@ -230,74 +389,103 @@ extern "C" int mf_process_frame_dev(mf_ctx* c, const uint8_t* d_rgb, const float
         for (int i = 1; i < 3; ++i) launch_pyrdown_f(c->d_dpyr[i - 1], c->d_dpyr[i], W >> (i - 1), H >> (i - 1), s);
         for (int i = 0; i < 3; ++i) {
             const float div = (float)(1 << i);
-            const Intr ki{g.fx / div, g.fy / div, g.cx / div, g.cy / div};
-            launch_vmap_nmap(c->d_dpyr[i], c->d_vmap[i], c->d_nmap[i], W >> i, H >> i, ki, g.depth_cutoff, s);
+            launch_vmap_nmap(c->d_dpyr[i], c->d_vmap[i], c->d_nmap[i], W >> i, H >> i, Intr{g.fx / div, g.fy / div, g.cx / div, g.cy / div},
+                             g.depth_cutoff, s);
         }
         mark(c, 1);
-        // Model::performTracking (Model.cpp:427-447): initICPModel (+ fill-in) then the Gauss-Newton loop
-        launch_model_pyramid(c->d_predV, c->d_predN, depthF_prev, c->d_frame, c->d_pose, nullptr, c->d_vmap_g, c->d_nmap_g, W, H,
-                             c->K, s);
         mark(c, 2);
-        launch_icp_begin(c->d_pose, &c->d_gn[0], s);
-        int iters[3] = {g.fast_odom ? 3 : 10, g.pyramid ? 5 : 0, g.pyramid ? 4 : 0};  // RGBDOdometry.cpp:327-329
-        int k = 0, nb_prev = 0;
-        for (int lvl = 2; lvl >= 0; --lvl) {
-            const float div = (float)(1 << lvl);
-            for (int j = 0; j < iters[lvl]; ++j) {
-                IcpLaunch l;
-                l.vmap_curr = c->d_vmap[lvl]; l.nmap_curr = c->d_nmap[lvl];
-                l.vmap_prev = c->d_vmap_g[lvl]; l.nmap_prev = c->d_nmap_g[lvl];
-                l.W = W >> lvl; l.H = H >> lvl; l.k = Intr{g.fx / div, g.fy / div, g.cx / div, g.cy / div};
-                l.distThres = 0.10f; l.angleThres = sinf(20.f * 3.14159254f / 180.f);  // RGBDOdometry.h:35-36
-                l.partials_in = nb_prev ? c->d_partials[(k + 1) & 1] : nullptr;
-                l.nblocks_in = nb_prev;
-                l.partials_out = c->d_partials[k & 1];
-                l.state_in = &c->d_gn[k & 1]; l.state_out = &c->d_gn[(k + 1) & 1];
-                l.log_out = k > 0 ? c->d_icp_log + 32 * (k - 1) : nullptr;
-                l.prof_out = c->icp_prof_on ? c->d_icp_prof + 8 * k : nullptr;
-                launch_icp_iteration(l, s);
-                nb_prev = icp_grid_blocks(l.W, l.H);
-                ++k;
-            }
+        // tracking, :247-276
+        enqueue_track(c, bg, depthF_prev, 0.f);
+        for (size_t i = 1; i < c->models.size(); ++i) {
+            ModelState& m = *c->models[i];
+            if (!m.isStatic || g.track_all_models) enqueue_track(c, m, nullptr, 0.2f);  // jump rule, :268-272
+            else launch_static_pose(m.d_pose, bg.d_pose, m.h_pose, s);                  // updateStaticPose, :274
         }
-        launch_icp_finalize(nb_prev ? c->d_partials[(k + 1) & 1] : nullptr, nb_prev, &c->d_gn[k & 1], c->d_pose, c->h_pose,
-                            k > 0 ? c->d_icp_log + 32 * (k - 1) : nullptr, s);
         mark(c, 3);
+
+        if (multi) {
+            // GlobalProjection::project(models, tick, tick, timeDelta, depthCutoff) (:289) with its fixed threshold 12
+            for (size_t i = 0; i < c->models.size(); ++i) {
+                ModelState& m = *c->models[i];
+                launch_global_scatter(m.surf[m.cur], m.d_frame, m.d_pose, W, H, c->K, g.depth_cutoff, 12.0f, g.time_delta, (int)i, m.id,
+                                      c->d_keys, s);
+            }
+            launch_global_resolve(c->d_keys, c->d_proj_ids, P, s);
+            // MfSegmentation::performSegmentation, device half (MfSegmentation.cpp:149-208)
+            launch_edge_map(c->d_vmap[0], c->d_nmap[0], c->d_edge, W, H, c->seg.weightDistance, c->seg.weightConvexity, s);
+            launch_edge_binary(c->d_edge, c->d_bin, c->d_tmp_u8, W, H, c->seg.threshold, c->seg.morphEdgeRadius,
+                               c->seg.morphEdgeIterations, s);
+            MF_HIP(c, hipMemcpyAsync(c->h_bin, c->d_bin, (size_t)P, hipMemcpyDeviceToHost, s));
+            MF_HIP(c, hipMemcpyAsync(c->h_ids, c->d_proj_ids, (size_t)P, hipMemcpyDeviceToHost, s));
+            MF_HIP(c, hipMemcpyAsync(c->h_depth, d_depth, (size_t)P * sizeof(float), hipMemcpyDeviceToHost, s));
+            const bool haveMasks = d_mask_in && class_ids && n_masks > 0;
+            if (haveMasks) MF_HIP(c, hipMemcpyAsync(c->h_mask, d_mask_in, (size_t)P, hipMemcpyDeviceToHost, s));
+            MF_HIP(c, hipStreamSynchronize(s));  // the one host visit of a multi-model frame (the reference leaves the GPU here too)
+
+            // inactivateModel for objects the jump rule dropped (:268-272); data is deleted (no re-detection upstream)
+            for (size_t i = 1; i < c->models.size();) {
+                if (c->models[i]->h_pose->alive == 0) c->models.erase(c->models.begin() + i);
+                else ++i;
+            }
+            if (c->spawnOffset < g.model_spawn_offset) c->spawnOffset++;  // :294
+            std::vector<SegModelInfo> infos;
+            for (auto& m : c->models) infos.push_back(SegModelInfo{m->id, m->classID});
+            SegResult res;
+            static const int32_t kNoClass[1] = {0};
+            segmentation_host(c->seg, W, H, c->h_bin, c->h_depth, c->h_mask, haveMasks ? class_ids : kNoClass, haveMasks ? n_masks : 0,
+                              c->h_ids, infos, c->nextID, c->spawnOffset >= g.model_spawn_offset, c->ignoreMap, c->h_full, res);
+            MF_HIP(c, hipMemcpyAsync(c->d_mask_tex, c->h_full, (size_t)P, hipMemcpyHostToDevice, s));  // :297
+            bool spawned = false;
+            if (res.hasNewLabel && (int)c->models.size() < g.max_models) {
+                // spawnObjectModel (:671-684): pose = I, makeStatic(globalPose); moveNewModelToList
+                std::unique_ptr<ModelState> nm;
+                const int id = take_next_model_id(c);
+                int rc = create_model(c, id, g.conf_object, false, surfel_capacity(g.num_osurfels), nm);
+                if (rc != MF_OK) return rc;
+                nm->classID = res.newClassID;
+                launch_spawn_pose(nm->d_pose, bg.d_pose, nm->d_frame, bg.d_frame, nm->h_pose, s);
+                c->models.push_back(std::move(nm));
+                c->spawnOffset = 0;
+                spawned = true;
+            }
+            for (size_t i = 1; i < c->models.size(); ++i) c->models[i]->maxDepth = 30.f + 30.f * 1.2f;  // :335-339 (depthMean = depthStd = 30)
+            if (spawned)  // :342-353: predictIndices; fuse(maxDepthProcessed, weight 100); clean (no second index pass)
+                enqueue_fuse_clean(c, *c->models.back(), d_rgb, d_depth, depthF, mask, g.max_depth_processed, 100.f, false, false);
+            for (size_t i = 1; i < c->models.size(); ++i)  // :369-374
+                c->models[i]->confThr = fminf(4.5f, (float)c->models[i]->age / 25.0f);
+        }
         // (the predict() at MaskFusion.cpp:423 only feeds the dead loop-closure block and is overwritten at :569)
         // fusion, :539-565
-        const int src = c->cur, dst = 1 - c->cur;
-        launch_index_scatter(c->surf[src], c->d_frame, c->d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, s);
-        launch_index_resolve(c->surf[src], c->d_pose, c->d_keys, W, H, c->d_index, c->d_ivc, c->d_ict, c->d_inr, s);
-        mark(c, 4);
-        launch_fuse_data(d_rgb, d_depth, depthF, mask, 0, c->d_frame, c->d_pose, weight_multiplier, g.depth_cutoff, W, H, c->K,
-                         c->d_index, c->d_ivc, c->d_inr, c->d_cand_op, c->d_cand_rec, c->d_upd_first, s);
-        mark(c, 5);
-        launch_fuse_update(c->surf[src], c->surf[dst], c->d_frame, c->d_upd_first, c->d_cand_rec, s);
-        mark(c, 6);
-        launch_index_scatter(c->surf[dst], c->d_frame, c->d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, s);
-        launch_index_resolve(c->surf[dst], c->d_pose, c->d_keys, W, H, c->d_index, c->d_ivc, c->d_ict, c->d_inr, s);
-        launch_clean(c->surf[dst], c->surf[src], c->d_frame, c->d_pose, W, H, c->K, g.time_delta, g.conf_global,
-                     g.outlier_coefficient, 0, c->d_index, c->d_ivc, c->d_ict, depthF, mask, c->d_cand_op, c->d_cand_rec,
-                     c->d_flags, c->d_newconf, c->d_block_counts, c->h_count, s);
+        for (size_t i = 0; i < c->models.size(); ++i)
+            enqueue_fuse_clean(c, *c->models[i], d_rgb, d_depth, depthF, mask, g.depth_cutoff, weight_multiplier, true, i == 0);
         mark(c, 7);
     }
-    enqueue_predict(c);  // :569
-    launch_frame_advance(c->d_frame, W, H, c->h_frame, s);
+    for (auto& m : c->models) {  // predict(), :569 ; tick++, :573
+        enqueue_predict(c, *m);
+        launch_frame_advance(m->d_frame, W, H, m->h_frame, s);
+        m->age++;  // incrementAge, :600
+    }
     mark(c, 8);
     c->curF = 1 - c->curF;
     c->host_tick++;
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { c->err = std::string("launch failed: ") + hipGetErrorString(e); return MF_EHIP; }
-    return MF_OK;
+    return check_launch(c);
+}
+
+extern "C" int mf_process_frame_dev(mf_ctx* c, const uint8_t* d_rgb, const float* d_depth, const uint8_t* d_mask, int64_t timestamp,
+                                    float weight_multiplier) {
+    (void)timestamp;
+    if (!c || !d_rgb || !d_depth) return MF_EINVAL;
+    // device-resident masks carry no class ids over this entry point: every mask id is class 0 ("object")
+    std::vector<int32_t> cls;
+    if (d_mask && c->cfg.enable_multiple_models) cls.assign(256, 0);
+    return process_frame_impl(c, d_rgb, d_depth, d_mask, cls.empty() ? nullptr : cls.data(), (int)cls.size(), weight_multiplier);
 }
 
 extern "C" int mf_sync(mf_ctx* c) {
     if (!c) return MF_EINVAL;
     MF_HIP(c, hipStreamSynchronize(c->stream));
     if (c->timings_on) {
-        // event i marks the START of stage i; stage i lasts until event i+1.  Stage map (see header):
-        // ev0 Preprocess(bilateral+pyramid+maps) ev1 odomInit ev2 odom ev3 indexMap ev4 Fuse::Data ev5 Fuse::Update
-        // ev6 indexMap#2 + Fuse::Copy ev7 IndexMap::ACTIVE ev8 end
+        // event i marks the START of stage i; stage i lasts until event i+1 (labels: see the header)
         float t[MF_N_TIMINGS] = {};
         for (int i = 0; i < 8; ++i) {
             float ms = 0.f;
@@ -311,23 +499,22 @@ extern "C" int mf_sync(mf_ctx* c) {
 }
 
 extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* depth, const uint8_t* mask, const int32_t* class_ids,
-                                int32_t n_masks, int64_t timestamp, const float* in_pose16, float weight_multiplier,
-                                int32_t bootstrap) {
-    (void)class_ids; (void)n_masks;
+                                int32_t n_masks, int64_t timestamp, const float* in_pose16, float weight_multiplier, int32_t bootstrap) {
+    (void)timestamp;
     if (!c || !rgb || !depth) return MF_EINVAL;
     if (in_pose16 || bootstrap) { c->err = "in_pose / bootstrap not supported yet"; return MF_ESTATE; }
     MF_HIP(c, hipMemcpyAsync(c->d_rgb, rgb, (size_t)c->P * 3, hipMemcpyHostToDevice, c->stream));
     MF_HIP(c, hipMemcpyAsync(c->d_depth, depth, (size_t)c->P * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    if (mask) MF_HIP(c, hipMemcpyAsync(c->d_mask, mask, (size_t)c->P, hipMemcpyHostToDevice, c->stream));
-    int rc = mf_process_frame_dev(c, c->d_rgb, c->d_depth, mask ? c->d_mask : nullptr, timestamp, weight_multiplier);
+    if (mask) MF_HIP(c, hipMemcpyAsync(c->d_mask_in, mask, (size_t)c->P, hipMemcpyHostToDevice, c->stream));
+    int rc = process_frame_impl(c, c->d_rgb, c->d_depth, mask ? c->d_mask_in : nullptr, class_ids, n_masks, weight_multiplier);
     if (rc != MF_OK) return rc;
     return mf_sync(c);
 }
 
 extern "C" int mf_predict(mf_ctx* c) {
     if (!c) return MF_EINVAL;
-    enqueue_predict(c);
-    return MF_OK;
+    for (auto& m : c->models) enqueue_predict(c, *m);
+    return check_launch(c);
 }
 
 extern "C" int mf_get_tick(mf_ctx* c, int32_t* tick) {
@@ -337,14 +524,19 @@ extern "C" int mf_get_tick(mf_ctx* c, int32_t* tick) {
 }
 extern "C" int mf_num_models(mf_ctx* c, int32_t* n) {
     if (!c || !n) return MF_EINVAL;
-    *n = 1;
+    *n = (int32_t)c->models.size();
     return MF_OK;
 }
+static ModelState* model_at(mf_ctx* c, int32_t i) {
+    if (!c || i < 0 || i >= (int32_t)c->models.size()) return nullptr;
+    return c->models[i].get();
+}
 extern "C" int mf_get_pose(mf_ctx* c, int32_t model, float* out) {
-    if (!c || !out || model != 0) return MF_EINVAL;
+    ModelState* m = model_at(c, model);
+    if (!m || !out) return MF_EINVAL;
     int rc = mf_sync(c);
     if (rc != MF_OK) return rc;
-    const PoseDev& p = *c->h_pose;
+    const PoseDev& p = *m->h_pose;
     for (int r = 0; r < 3; ++r) {
         for (int col = 0; col < 3; ++col) out[col * 4 + r] = p.R[r * 3 + col];
         out[12 + r] = p.t[r];
@@ -354,39 +546,57 @@ extern "C" int mf_get_pose(mf_ctx* c, int32_t model, float* out) {
     return MF_OK;
 }
 extern "C" int mf_get_surfel_count(mf_ctx* c, int32_t model, uint32_t* count) {
-    if (!c || !count || model != 0) return MF_EINVAL;
+    ModelState* m = model_at(c, model);
+    if (!m || !count) return MF_EINVAL;
     int rc = mf_sync(c);
     if (rc != MF_OK) return rc;
-    *count = (uint32_t)*c->h_count;
+    *count = (uint32_t)*m->h_count;
+    return MF_OK;
+}
+extern "C" int mf_model_info(mf_ctx* c, int32_t model, mf_model_info_t* out) {
+    ModelState* m = model_at(c, model);
+    if (!m || !out) return MF_EINVAL;
+    int rc = mf_sync(c);
+    if (rc != MF_OK) return rc;
+    out->id = m->id; out->class_id = m->classID; out->surfels = (uint32_t)*m->h_count; out->confidence_threshold = m->confThr;
+    out->is_static = m->isStatic ? 1 : 0; out->age = m->age;
     return MF_OK;
 }
 extern "C" int mf_get_icp_stats(mf_ctx* c, int32_t model, float* e, float* n) {
-    if (!c || !e || !n || model != 0) return MF_EINVAL;
+    ModelState* m = model_at(c, model);
+    if (!m || !e || !n) return MF_EINVAL;
     int rc = mf_sync(c);
     if (rc != MF_OK) return rc;
-    *e = c->h_pose->lastICPError; *n = c->h_pose->lastICPCount;
+    *e = m->h_pose->lastICPError; *n = m->h_pose->lastICPCount;
     return MF_OK;
 }
 extern "C" int mf_get_last_fillin(mf_ctx* c, int32_t* used) {
     if (!c || !used) return MF_EINVAL;
     int rc = mf_sync(c);
     if (rc != MF_OK) return rc;
-    // h_frame mirrors the state AFTER frame_advance: useFillIn there is the decision for the NEXT frame, pad[0] the
-    // decision the last tracking step ran with.
-    *used = c->h_frame->pad[0];
+    // h_frame mirrors the state AFTER frame_advance: pad[0] is the decision the last tracking step ran with
+    *used = c->models[0]->h_frame->pad[0];
+    return MF_OK;
+}
+extern "C" int mf_download_segmentation(mf_ctx* c, uint8_t* out) {
+    if (!c || !out) return MF_EINVAL;
+    int rc = mf_sync(c);
+    if (rc != MF_OK) return rc;
+    MF_HIP(c, hipMemcpy(out, c->d_mask_tex, (size_t)c->P, hipMemcpyDeviceToHost));
     return MF_OK;
 }
 
 extern "C" int mf_download_map(mf_ctx* c, int32_t model, float* out, uint32_t max_count, uint32_t* count) {
-    if (!c || !out || !count || model != 0) return MF_EINVAL;
+    ModelState* ms = model_at(c, model);
+    if (!ms || !out || !count) return MF_EINVAL;
     int rc = mf_sync(c);
     if (rc != MF_OK) return rc;
-    const uint32_t n = (uint32_t)*c->h_count;
+    const uint32_t n = (uint32_t)*ms->h_count;
     *count = n;
     const uint32_t m = n < max_count ? n : max_count;
     if (m == 0) return MF_OK;
     std::vector<float4> a(m), b(m), d(m);
-    const Surfels& s = c->surf[c->cur];
+    const Surfels& s = ms->surf[ms->cur];
     MF_HIP(c, hipMemcpy(a.data(), s.pc, m * sizeof(float4), hipMemcpyDeviceToHost));
     MF_HIP(c, hipMemcpy(b.data(), s.ct, m * sizeof(float4), hipMemcpyDeviceToHost));
     MF_HIP(c, hipMemcpy(d.data(), s.nr, m * sizeof(float4), hipMemcpyDeviceToHost));
@@ -398,11 +608,13 @@ extern "C" int mf_download_map(mf_ctx* c, int32_t model, float* out, uint32_t ma
     return MF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// parameters
+// ------------------------------------------------------------------------------------------------
 struct ParamRef { const char* key; int kind; size_t off; };  // kind 0 float, 1 int
 static const ParamRef kParams[] = {
     {"depthCutoff", 0, offsetof(mf_config, depth_cutoff)},
     {"icpWeight", 0, offsetof(mf_config, icp_weight)},
-    {"confidenceThreshold", 0, offsetof(mf_config, conf_global)},
     {"outlierCoefficient", 0, offsetof(mf_config, outlier_coefficient)},
     {"maxDepthProcessed", 0, offsetof(mf_config, max_depth_processed)},
     {"fastOdom", 1, offsetof(mf_config, fast_odom)},
@@ -410,11 +622,27 @@ static const ParamRef kParams[] = {
     {"pyramid", 1, offsetof(mf_config, pyramid)},
     {"timeDelta", 1, offsetof(mf_config, time_delta)},
     {"enableMultipleModels", 1, offsetof(mf_config, enable_multiple_models)},
+    {"trackAllModels", 1, offsetof(mf_config, track_all_models)},
+    {"modelSpawnOffset", 1, offsetof(mf_config, model_spawn_offset)},
 };
+struct SegRef { const char* key; int kind; size_t off; };  // kind 0 float, 1 int
+static const SegRef kSegParams[] = {
+    {"mfThreshold", 0, offsetof(SegParams, threshold)},
+    {"mfWeightDistance", 0, offsetof(SegParams, weightDistance)},
+    {"mfWeightConvexity", 0, offsetof(SegParams, weightConvexity)},
+    {"mfMorphEdgeIterations", 1, offsetof(SegParams, morphEdgeIterations)},
+    {"mfMorphEdgeRadius", 1, offsetof(SegParams, morphEdgeRadius)},
+    {"mfMorphMaskIterations", 1, offsetof(SegParams, morphMaskIterations)},
+    {"mfMorphMaskRadius", 1, offsetof(SegParams, morphMaskRadius)},
+    {"newModelMinRelativeSize", 0, offsetof(SegParams, minRelSizeNew)},
+    {"newModelMaxRelativeSize", 0, offsetof(SegParams, maxRelSizeNew)},
+};
+
 extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!c || !key) return MF_EINVAL;
     if (!strcmp(key, "timings")) { c->timings_on = value != 0; return MF_OK; }
     if (!strcmp(key, "icpProfile")) { c->icp_prof_on = value != 0; return MF_OK; }
+    if (!strcmp(key, "confidenceThreshold")) { c->cfg.conf_global = (float)value; c->models[0]->confThr = (float)value; return MF_OK; }
     for (const ParamRef& p : kParams)
         if (!strcmp(key, p.key)) {
             char* base = reinterpret_cast<char*>(&c->cfg);
@@ -422,16 +650,29 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
             else *reinterpret_cast<int32_t*>(base + p.off) = (int32_t)value;
             return MF_OK;
         }
+    for (const SegRef& p : kSegParams)
+        if (!strcmp(key, p.key)) {
+            char* base = reinterpret_cast<char*>(&c->seg);
+            if (p.kind == 0) *reinterpret_cast<float*>(base + p.off) = (float)value;
+            else *reinterpret_cast<int*>(base + p.off) = (int)value;
+            return MF_OK;
+        }
     c->err = std::string("unknown parameter: ") + key;
     return MF_EINVAL;
 }
 extern "C" int mf_get_param(mf_ctx* c, const char* key, double* value) {
     if (!c || !key || !value) return MF_EINVAL;
+    if (!strcmp(key, "confidenceThreshold")) { *value = c->models[0]->confThr; return MF_OK; }
     for (const ParamRef& p : kParams)
         if (!strcmp(key, p.key)) {
             const char* base = reinterpret_cast<const char*>(&c->cfg);
-            *value = p.kind == 0 ? (double)*reinterpret_cast<const float*>(base + p.off)
-                                 : (double)*reinterpret_cast<const int32_t*>(base + p.off);
+            *value = p.kind == 0 ? (double)*reinterpret_cast<const float*>(base + p.off) : (double)*reinterpret_cast<const int32_t*>(base + p.off);
+            return MF_OK;
+        }
+    for (const SegRef& p : kSegParams)
+        if (!strcmp(key, p.key)) {
+            const char* base = reinterpret_cast<const char*>(&c->seg);
+            *value = p.kind == 0 ? (double)*reinterpret_cast<const float*>(base + p.off) : (double)*reinterpret_cast<const int*>(base + p.off);
             return MF_OK;
         }
     return MF_EINVAL;
@@ -454,6 +695,7 @@ extern "C" int mf_debug_read(mf_ctx* c, const char* what, void* out, uint64_t ou
     size_t bytes = 0;
     const size_t P = (size_t)c->P;
     std::string w(what);
+    ModelState& bg = *c->models[0];
     auto lvl = [&](const std::string& pre, float* const arr[3]) -> bool {
         for (int i = 0; i < 3; ++i)
             if (w == pre + std::to_string(i)) {
@@ -464,13 +706,16 @@ extern "C" int mf_debug_read(mf_ctx* c, const char* what, void* out, uint64_t ou
     };
     if (w == "depthF") { src = c->d_depthF[1 - c->curF]; bytes = P * 4; }  // curF was flipped at the end of the frame
     else if (lvl("vmap_g", c->d_vmap_g) || lvl("nmap_g", c->d_nmap_g) || lvl("vmap", c->d_vmap) || lvl("nmap", c->d_nmap)) {}
-    else if (w == "pred_vertex") { src = c->d_predV; bytes = P * 16; }
-    else if (w == "pred_normal") { src = c->d_predN; bytes = P * 16; }
-    else if (w == "pred_image") { src = c->d_predImage; bytes = P * 4; }
+    else if (w == "pred_vertex") { src = bg.d_predV; bytes = P * 16; }
+    else if (w == "pred_normal") { src = bg.d_predN; bytes = P * 16; }
+    else if (w == "pred_image") { src = bg.d_predImage; bytes = P * 4; }
     else if (w == "index") { src = c->d_index; bytes = P * 4; }
     else if (w == "index_vc") { src = c->d_ivc; bytes = P * 16; }
     else if (w == "icp_log") { src = c->d_icp_log; bytes = 19 * 32 * 4; }
     else if (w == "icp_prof") { src = c->d_icp_prof; bytes = 19 * 8 * 8; }
+    else if (w == "edge_map") { src = c->d_edge; bytes = P * 4; }
+    else if (w == "edge_binary") { src = c->d_bin; bytes = P; }
+    else if (w == "projected_ids") { src = c->d_proj_ids; bytes = P; }
     else { c->err = "unknown debug tap: " + w; return MF_EINVAL; }
     if (out_bytes < bytes) { c->err = "debug_read: buffer too small"; return MF_EINVAL; }
     MF_HIP(c, hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
@@ -509,10 +754,42 @@ extern "C" int mf_k_model_pyramid(const float* d_v4, const float* d_n4, const fl
         vm[i] = d_vmaps + off; nm[i] = d_nmaps + off;
         off += (size_t)(W >> i) * (H >> i) * 3;
     }
-    launch_model_pyramid((const float4*)d_v4, (const float4*)d_n4, nullptr, nullptr, nullptr, Rt, vm, nm, W, H,
-                         Intr{1, 1, 0, 0}, (hipStream_t)stream);
+    launch_model_pyramid((const float4*)d_v4, (const float4*)d_n4, nullptr, nullptr, nullptr, Rt, vm, nm, W, H, Intr{1, 1, 0, 0},
+                         (hipStream_t)stream);
     return launch_rc();
 }
+extern "C" int mf_k_geometric_edges(const float* d_vmap, const float* d_nmap, float* d_edge, uint8_t* d_binary, uint8_t* d_tmp, int32_t W,
+                                    int32_t H, float w_distance, float w_convexity, float threshold, int32_t morph_radius,
+                                    int32_t morph_iterations, void* stream) {
+    if (!d_vmap || !d_nmap || !d_edge || !d_binary || !d_tmp || W <= 2 || H <= 2) return MF_EINVAL;
+    launch_edge_map(d_vmap, d_nmap, d_edge, W, H, w_distance, w_convexity, (hipStream_t)stream);
+    launch_edge_binary(d_edge, d_binary, d_tmp, W, H, threshold, morph_radius, morph_iterations, (hipStream_t)stream);
+    return launch_rc();
+}
+extern "C" int mf_segmentation_labels(int32_t W, int32_t H, const uint8_t* binary, const float* depth, const uint8_t* mask,
+                                      const int32_t* class_ids, int32_t n_masks, const uint8_t* projected_ids, const int32_t* model_ids,
+                                      const int32_t* model_class_ids, int32_t n_models, int32_t next_model_id, int32_t allow_new,
+                                      const float* p, uint8_t* ignore_map, uint8_t* full, int32_t* has_new, int32_t* new_class) {
+    if (!binary || !depth || !projected_ids || !model_ids || !model_class_ids || n_models < 1 || !p || !ignore_map || !full || !has_new ||
+        !new_class || W <= 2 || H <= 2 || (n_masks > 0 && (!mask || !class_ids)))
+        return MF_EINVAL;
+    SegParams prm;
+    prm.threshold = p[0]; prm.weightDistance = p[1]; prm.weightConvexity = p[2];
+    prm.morphEdgeIterations = (int)p[3]; prm.morphEdgeRadius = (int)p[4]; prm.morphMaskIterations = (int)p[5]; prm.morphMaskRadius = (int)p[6];
+    prm.removeEdges = p[7] != 0.f; prm.minRelSizeNew = p[8]; prm.maxRelSizeNew = p[9]; prm.personClassID = (int)p[10];
+    std::vector<SegModelInfo> infos;
+    for (int i = 0; i < n_models; ++i) infos.push_back(SegModelInfo{model_ids[i], model_class_ids[i]});
+    std::vector<uint8_t> ign(ignore_map, ignore_map + (size_t)W * H);
+    SegResult res;
+    static const int32_t kNoClass[1] = {0};
+    segmentation_host(prm, W, H, binary, depth, mask, n_masks > 0 ? class_ids : kNoClass, n_masks, projected_ids, infos, next_model_id,
+                      allow_new != 0, ign, full, res);
+    memcpy(ignore_map, ign.data(), ign.size());
+    *has_new = res.hasNewLabel ? 1 : 0;
+    *new_class = res.newClassID;
+    return MF_OK;
+}
+
 extern "C" int mf_k_icp_step(const float* Rcurr9, const float* tcurr3, const float* d_vc, const float* d_nc, const float* Rpi9,
                              const float* tprev3, float fx, float fy, float cx, float cy, const float* d_vp, const float* d_np,
                              float dist_thresh, float angle_thresh, int32_t W, int32_t H, float* d_out32, void* stream) {
@@ -529,11 +806,11 @@ extern "C" int mf_k_icp_step(const float* Rcurr9, const float* tcurr3, const flo
     float* dpose = reinterpret_cast<float*>(base + o + 2 * sizeof(GNState));
     float hp[24];
     memcpy(hp, Rcurr9, 36); memcpy(hp + 9, tcurr3, 12); memcpy(hp + 12, Rpi9, 36); memcpy(hp + 21, tprev3, 12);
-    hipMemcpyAsync(dpose, hp, sizeof(hp), hipMemcpyHostToDevice, s);
-    hipStreamSynchronize(s);  // hp is a stack buffer
+    (void)hipMemcpyAsync(dpose, hp, sizeof(hp), hipMemcpyHostToDevice, s);
+    (void)hipStreamSynchronize(s);  // hp is a stack buffer
     launch_icp_step_standalone(dpose, dpose + 9, d_vc, d_nc, dpose + 12, dpose + 21, Intr{fx, fy, cx, cy}, d_vp, d_np, dist_thresh,
                                angle_thresh, W, H, scratch, st, d_out32, s);
-    hipStreamSynchronize(s);
-    hipFree(scratch);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(scratch);
     return launch_rc();
 }

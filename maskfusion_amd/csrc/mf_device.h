@@ -98,4 +98,79 @@ __device__ __forceinline__ float3 get_normal_forward(const float* depth, int W, 
     return normalize_gl(cross3(vx - vPos, vy - vPos));
 }
 
+// ---- pose math shared by the odometry and the object-model kernels ----
+__device__ inline void m33_inverse_f(const float* m, float* inv) {  // cofactor inverse (Eigen fixed-size stand-in)
+    const float c00 = m[4] * m[8] - m[5] * m[7];
+    const float c01 = m[5] * m[6] - m[3] * m[8];
+    const float c02 = m[3] * m[7] - m[4] * m[6];
+    const float det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    const float id = 1.0f / det;
+    inv[0] = c00 * id; inv[1] = (m[2] * m[7] - m[1] * m[8]) * id; inv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    inv[3] = c01 * id; inv[4] = (m[0] * m[8] - m[2] * m[6]) * id; inv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    inv[6] = c02 * id; inv[7] = (m[1] * m[6] - m[0] * m[7]) * id; inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+
+// Model::rodrigues2 (Core/Model/Model.cpp:891-932); the SVD re-orthonormalisation U V^T is done by Newton polar
+// iterations (identical to rounding for near-rotations).
+__device__ inline void rodrigues2_d(const float* Rin, double* r) {
+    double R[9], Rn[9];
+    for (int k = 0; k < 9; ++k) R[k] = Rin[k];
+    for (int it = 0; it < 4; ++it) {
+        const double c00 = R[4] * R[8] - R[5] * R[7], c01 = R[5] * R[6] - R[3] * R[8], c02 = R[3] * R[7] - R[4] * R[6];
+        const double det = R[0] * c00 + R[1] * c01 + R[2] * c02;
+        const double cof[9] = {c00, c01, c02,
+                               R[2] * R[7] - R[1] * R[8], R[0] * R[8] - R[2] * R[6], R[1] * R[6] - R[0] * R[7],
+                               R[1] * R[5] - R[2] * R[4], R[2] * R[3] - R[0] * R[5], R[0] * R[4] - R[1] * R[3]};
+        for (int k = 0; k < 9; ++k) Rn[k] = 0.5 * (R[k] + cof[k] / det);
+        for (int k = 0; k < 9; ++k) R[k] = Rn[k];
+    }
+    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double cth = (R[0] + R[4] + R[8] - 1) * 0.5;
+    cth = cth > 1. ? 1. : cth < -1. ? -1. : cth;
+    double theta = acos(cth);
+    if (s < 1e-5) {
+        if (cth > 0) rx = ry = rz = 0;
+        else {
+            double tt = (R[0] + 1) * 0.5;
+            rx = sqrt(fmax(tt, 0.0));
+            tt = (R[4] + 1) * 0.5;
+            ry = sqrt(fmax(tt, 0.0)) * (R[1] < 0 ? -1.0 : 1.0);
+            tt = (R[8] + 1) * 0.5;
+            rz = sqrt(fmax(tt, 0.0)) * (R[2] < 0 ? -1.0 : 1.0);
+            if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
+            theta /= sqrt(rx * rx + ry * ry + rz * rz);
+            rx *= theta; ry *= theta; rz *= theta;
+        }
+    } else {
+        const double vth = 1 / (2 * s) * theta;
+        rx *= vth; ry *= vth; rz *= vth;
+    }
+    r[0] = rx; r[1] = ry; r[2] = rz;
+}
+
+// Derived members of PoseDev from (R,t) and (lastR,lastT): inverse and Model::computeFusionWeight(1.0)
+// (Core/Model/Model.cpp:449-464).
+__device__ inline void pose_derive(PoseDev& p) {
+    m33_inverse_f(p.R, p.Ri);
+    const float3 v = mul33(p.Ri, f3(p.t[0], p.t[1], p.t[2]));
+    p.ti[0] = -v.x; p.ti[1] = -v.y; p.ti[2] = -v.z;
+    // getLastTransform() = pose^-1 * lastPose
+    float Rd[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+            Rd[r * 3 + c] = p.Ri[r * 3] * p.lastR[c] + p.Ri[r * 3 + 1] * p.lastR[3 + c] + p.Ri[r * 3 + 2] * p.lastR[6 + c];
+    float3 td = mul33(p.Ri, f3(p.lastT[0], p.lastT[1], p.lastT[2]));
+    td = f3(td.x + p.ti[0], td.y + p.ti[1], td.z + p.ti[2]);
+    double rv[3];
+    rodrigues2_d(Rd, rv);
+    const float rn = (float)sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+    float weighting = fmaxf(norm3(td), rn);
+    const float largest = 0.01f, minWeight = 0.5f;
+    if (weighting > largest) weighting = largest;
+    p.fusionWeight = fmaxf(1.0f - (weighting / largest), minWeight);
+}
+
+
 }  // namespace mf

@@ -25,7 +25,10 @@ struct PoseDev {
     float lastR[9], lastT[3];  // Model::lastPose
     float fusionWeight;        // Model::computeFusionWeight(1.0)
     float lastICPError, lastICPCount;
-    float pad[3];
+    float initR[9], initT[3];  // Model::initialC2Winv (objects; Model.h:263-264)
+    float incT[3];             // translation of the last tracking increment (MaskFusion.cpp:268)
+    int alive;                 // 0 once the 0.2 m jump test dropped the model in this frame
+    int pad[2];
 };
 
 // Gauss-Newton state carried from one ICP launch to the next (double-buffered: launch k reads [k-1], block 0 writes [k]).
@@ -82,8 +85,9 @@ void launch_icp_iteration(const IcpLaunch& a, hipStream_t s);
 // Seeds GNState from the model pose (Rprev = Rcurr = pose; resultRt = I).
 void launch_icp_begin(const PoseDev* pose, GNState* st, hipStream_t s);
 // Last reduce+solve, then pose / lastPose / inverse / fusion weight update and host mirror.
+// jump_limit > 0: object-model rule of MaskFusion.cpp:268-272 (|increment translation| > limit => pose->alive = 0)
 void launch_icp_finalize(const float* partials_in, int nblocks_in, const GNState* state_in, PoseDev* pose,
-                         PoseDev* host_mirror, float* log_out, hipStream_t s);
+                         PoseDev* host_mirror, float* log_out, float jump_limit, hipStream_t s);
 // Stand-alone icpStep (parity tests): host-provided poses, output 32 floats.
 void launch_icp_step_standalone(const float* Rcurr, const float* tcurr, const float* vc, const float* nc,
                                 const float* Rpi, const float* tprev, Intr k, const float* vp, const float* np,
@@ -119,6 +123,17 @@ void launch_splat_resolve(Surfels src, const PoseDev* pose, unsigned long long* 
                           hipStream_t s);
 void launch_fill_keys(unsigned long long* keys, int n, hipStream_t s);
 void launch_fill_int(int* p, int v, int n, hipStream_t s);
+// ---------------- multi-model coupling (mf_segment.hip) ----------------
+void launch_edge_map(const float* vmap, const float* nmap, float* out, int W, int H, float wD, float wC, hipStream_t s);
+void launch_edge_binary(const float* edge, uint8_t* out, uint8_t* tmp, int W, int H, float threshold, int radius,
+                        int iterations, hipStream_t s);
+void launch_global_scatter(Surfels src, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth,
+                           float confThreshold, int timeDelta, int order, int id, unsigned long long* keys, hipStream_t s);
+void launch_global_resolve(unsigned long long* keys, uint8_t* ids, int P, hipStream_t s);
+void launch_spawn_pose(PoseDev* obj, const PoseDev* bg, FrameDev* objFrame, const FrameDev* bgFrame, PoseDev* host_mirror,
+                       hipStream_t s);
+void launch_static_pose(PoseDev* obj, const PoseDev* bg, PoseDev* host_mirror, hipStream_t s);
+
 // end-of-frame bookkeeping: tick++, cover -> useFillIn decision for the next frame
 void launch_frame_advance(FrameDev* frame, int W, int H, FrameDev* host_mirror, hipStream_t s);
 

@@ -1,0 +1,31 @@
+// mf_labels.h -- host half of MfSegmentation (see mf_labels.hip)
+#pragma once
+#include <stdint.h>
+#include <vector>
+
+namespace mf {
+
+// MfSegmentation parameters (Core/Segmentation/MfSegmentation.h:42-62, SegmentationPerformer.h:41-42)
+struct SegParams {
+    float threshold = 0.1f, weightDistance = 1.f, weightConvexity = 1.f;
+    int morphEdgeIterations = 3, morphEdgeRadius = 1;
+    int morphMaskIterations = 3, morphMaskRadius = 1;
+    bool removeEdges = true;
+    float minRelSizeNew = 0.07f, maxRelSizeNew = 0.4f;
+    int personClassID = 255;
+    float minMaskModelOverlap = 0.05f;   // MfSegmentation.cpp:43
+    int minMappedComponentSize = 160;    // MfSegmentation.cpp:43
+};
+
+struct SegModelInfo { int id; int classID; };
+struct SegResult { bool hasNewLabel = false; int newClassID = -1; };
+
+// binary: 255 = not an edge (threshold -> closing -> invert); depth: raw metric depth; mask / classIDs: the frame's instance
+// masks (mask values index classIDs, nMasks = number of class ids, 0 = no masks); projectedIDs: GlobalProjection output;
+// models: the model list in order (index 0 = background); ignoreMap: persistent semanticIgnoreMap; full: out, model id per
+// pixel (255 = ignore).
+void segmentation_host(const SegParams& prm, int W, int H, const uint8_t* binary, const float* depth, const uint8_t* mask,
+                       const int32_t* classIDs, int nMasks, const uint8_t* projectedIDs, const std::vector<SegModelInfo>& models,
+                       int nextModelID, bool allowNew, std::vector<uint8_t>& ignoreMap, uint8_t* full, SegResult& result);
+
+}  // namespace mf

@@ -21,17 +21,6 @@ namespace mf {
 // ------------------------------------------------------------------------------------------------
 // small fp64 / fp32 linear algebra for the per-iteration solve (single thread)
 // ------------------------------------------------------------------------------------------------
-__device__ void m33_inverse_f(const float* m, float* inv) {  // cofactor inverse (Eigen fixed-size stand-in)
-    const float c00 = m[4] * m[8] - m[5] * m[7];
-    const float c01 = m[5] * m[6] - m[3] * m[8];
-    const float c02 = m[3] * m[7] - m[4] * m[6];
-    const float det = m[0] * c00 + m[1] * c01 + m[2] * c02;
-    const float id = 1.0f / det;
-    inv[0] = c00 * id; inv[1] = (m[2] * m[7] - m[1] * m[8]) * id; inv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
-    inv[3] = c01 * id; inv[4] = (m[0] * m[8] - m[2] * m[6]) * id; inv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
-    inv[6] = c02 * id; inv[7] = (m[1] * m[6] - m[0] * m[7]) * id; inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
-}
-
 // fp64 reciprocal / square root from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~2^-26) plus Newton steps: ~8 instructions
 // instead of the ~40 of an IEEE division; last-ulp differences are irrelevant for a Gauss-Newton step.
 __device__ __forceinline__ double rcp_d(double x) {
@@ -519,70 +508,10 @@ void launch_icp_begin(const PoseDev* pose, GNState* st, hipStream_t s) {
     hipLaunchKernelGGL(k_icp_begin, dim3(1), dim3(64), 0, s, pose, st);
 }
 
-// Model::rodrigues2 (Core/Model/Model.cpp:891-932); the SVD re-orthonormalisation U V^T is done by Newton polar
-// iterations (identical to rounding for near-rotations).
-__device__ void rodrigues2_d(const float* Rin, double* r) {
-    double R[9], Rn[9];
-    for (int k = 0; k < 9; ++k) R[k] = Rin[k];
-    for (int it = 0; it < 4; ++it) {
-        const double c00 = R[4] * R[8] - R[5] * R[7], c01 = R[5] * R[6] - R[3] * R[8], c02 = R[3] * R[7] - R[4] * R[6];
-        const double det = R[0] * c00 + R[1] * c01 + R[2] * c02;
-        const double cof[9] = {c00, c01, c02,
-                               R[2] * R[7] - R[1] * R[8], R[0] * R[8] - R[2] * R[6], R[1] * R[6] - R[0] * R[7],
-                               R[1] * R[5] - R[2] * R[4], R[2] * R[3] - R[0] * R[5], R[0] * R[4] - R[1] * R[3]};
-        for (int k = 0; k < 9; ++k) Rn[k] = 0.5 * (R[k] + cof[k] / det);
-        for (int k = 0; k < 9; ++k) R[k] = Rn[k];
-    }
-    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
-    const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
-    double cth = (R[0] + R[4] + R[8] - 1) * 0.5;
-    cth = cth > 1. ? 1. : cth < -1. ? -1. : cth;
-    double theta = acos(cth);
-    if (s < 1e-5) {
-        if (cth > 0) rx = ry = rz = 0;
-        else {
-            double tt = (R[0] + 1) * 0.5;
-            rx = sqrt(fmax(tt, 0.0));
-            tt = (R[4] + 1) * 0.5;
-            ry = sqrt(fmax(tt, 0.0)) * (R[1] < 0 ? -1.0 : 1.0);
-            tt = (R[8] + 1) * 0.5;
-            rz = sqrt(fmax(tt, 0.0)) * (R[2] < 0 ? -1.0 : 1.0);
-            if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
-            theta /= sqrt(rx * rx + ry * ry + rz * rz);
-            rx *= theta; ry *= theta; rz *= theta;
-        }
-    } else {
-        const double vth = 1 / (2 * s) * theta;
-        rx *= vth; ry *= vth; rz *= vth;
-    }
-    r[0] = rx; r[1] = ry; r[2] = rz;
-}
-
-// Derived members of PoseDev from (R,t) and (lastR,lastT): inverse and Model::computeFusionWeight(1.0)
-// (Core/Model/Model.cpp:449-464).
-__device__ void pose_derive(PoseDev& p) {
-    m33_inverse_f(p.R, p.Ri);
-    const float3 v = mul33(p.Ri, f3(p.t[0], p.t[1], p.t[2]));
-    p.ti[0] = -v.x; p.ti[1] = -v.y; p.ti[2] = -v.z;
-    // getLastTransform() = pose^-1 * lastPose
-    float Rd[9];
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c)
-            Rd[r * 3 + c] = p.Ri[r * 3] * p.lastR[c] + p.Ri[r * 3 + 1] * p.lastR[3 + c] + p.Ri[r * 3 + 2] * p.lastR[6 + c];
-    float3 td = mul33(p.Ri, f3(p.lastT[0], p.lastT[1], p.lastT[2]));
-    td = f3(td.x + p.ti[0], td.y + p.ti[1], td.z + p.ti[2]);
-    double rv[3];
-    rodrigues2_d(Rd, rv);
-    const float rn = (float)sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
-    float weighting = fmaxf(norm3(td), rn);
-    const float largest = 0.01f, minWeight = 0.5f;
-    if (weighting > largest) weighting = largest;
-    p.fusionWeight = fmaxf(1.0f - (weighting / largest), minWeight);
-}
-
 __global__ __launch_bounds__(256) void k_icp_finalize(const float* __restrict__ partials_in, int nb_in,
                                                        const GNState* __restrict__ st_in, PoseDev* __restrict__ pose,
-                                                       PoseDev* __restrict__ host_mirror, float* __restrict__ log_out) {
+                                                       PoseDev* __restrict__ host_mirror, float* __restrict__ log_out,
+                                                       float jump_limit) {
     __shared__ double s_seg[32 * 32];
     __shared__ double s_sys[32];
     GNState st;
@@ -602,6 +531,8 @@ __global__ __launch_bounds__(256) void k_icp_finalize(const float* __restrict__ 
         for (int k = 0; k < 3; ++k) { p.lastT[k] = st.tprev[k]; p.t[k] = st.tcurr[k]; }
         p.lastICPError = st.lastICPError;
         p.lastICPCount = st.lastICPCount;
+        for (int k = 0; k < 3; ++k) p.incT[k] = st.trt[k];
+        if (jump_limit > 0.f && norm3(f3(st.trt[0], st.trt[1], st.trt[2])) > jump_limit) p.alive = 0;
         pose_derive(p);
         *pose = p;
         if (host_mirror) *host_mirror = p;
@@ -609,9 +540,9 @@ __global__ __launch_bounds__(256) void k_icp_finalize(const float* __restrict__ 
 }
 
 void launch_icp_finalize(const float* partials_in, int nblocks_in, const GNState* state_in, PoseDev* pose,
-                         PoseDev* host_mirror, float* log_out, hipStream_t s) {
+                         PoseDev* host_mirror, float* log_out, float jump_limit, hipStream_t s) {
     hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(256), 0, s, partials_in, nblocks_in, state_in, pose, host_mirror,
-                       log_out);
+                       log_out, jump_limit);
 }
 
 // stand-alone icpStep for the parity tests: reduce partials to 32 floats

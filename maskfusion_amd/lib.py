@@ -17,6 +17,12 @@ class MFError(RuntimeError):
     pass
 
 
+class ModelInfo(C.Structure):
+    """mf_model_info_t"""
+    _fields_ = [("id", C.c_int32), ("class_id", C.c_int32), ("surfels", C.c_uint32), ("confidence_threshold", C.c_float),
+                ("is_static", C.c_int32), ("age", C.c_uint32)]
+
+
 class Config(C.Structure):
     """mf_config (include/maskfusion_amd.h)."""
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
@@ -24,7 +30,8 @@ class Config(C.Structure):
                 ("conf_object", C.c_float), ("depth_cutoff", C.c_float), ("icp_weight", C.c_float),
                 ("fast_odom", C.c_int32), ("so3", C.c_int32), ("pyramid", C.c_int32),
                 ("max_depth_processed", C.c_float), ("outlier_coefficient", C.c_float), ("num_gsurfels", C.c_int32),
-                ("num_osurfels", C.c_int32), ("enable_multiple_models", C.c_int32), ("reserved", C.c_int32 * 8)]
+                ("num_osurfels", C.c_int32), ("enable_multiple_models", C.c_int32), ("model_spawn_offset", C.c_int32),
+                ("track_all_models", C.c_int32), ("max_models", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 # every symbol declared in include/maskfusion_amd.h (tests/test_abi.py checks the header against this table)
@@ -45,6 +52,13 @@ SYMBOLS = {
     "mf_get_icp_stats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mf_download_map": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "mf_get_last_fillin": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "mf_model_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "mf_download_segmentation": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mf_segmentation_labels": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "mf_k_geometric_edges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                       C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
     "mf_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "mf_get_param": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]),
     "mf_get_timings": (C.c_int, [C.c_void_p, C.c_void_p]),

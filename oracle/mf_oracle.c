@@ -862,19 +862,15 @@ int mfo_clean(const mfo_cam* c, const float* pose16, const float* src, int count
  * Sprites wider than MFO_MAX_SPRITE px are clamped (GL_POINT_SIZE_RANGE stand-in).
  * ---------------------------------------------------------------------------------------------- */
 #define MFO_MAX_SPRITE 64.0f
-void mfo_combined_predict(const mfo_cam* c, const float* pose16, const float* surfels, int count, float maxDepth,
-                          float confThreshold, int time, int maxTime, int timeDelta, uint8_t* image,
-                          float* vertexConf, float* normalRad, uint16_t* timeMap) {
-    const int W = c->W, H = c->H, P = W * H;
+/* z-buffered splat of one surfel buffer.  zbuf / winner (surfel index, -1 = none) / owner (caller tag per pixel, may be
+ * NULL) are in-out so that several models can share one z-buffer (GlobalProjection). */
+static void splat_zbuffer(const mfo_cam* c, const float* pose16, const float* surfels, int count, float maxDepth,
+                          float confThreshold, int time, int maxTime, int timeDelta, float* zbuf, int32_t* winner,
+                          uint8_t* owner, uint8_t tag) {
+    const int W = c->W, H = c->H;
     float R[9], t[3], Ri[9], ti[3];
     pose16_to_Rt(pose16, R, t);
     pose_inverse_Rt(R, t, Ri, ti);
-    float* zbuf = (float*)malloc(sizeof(float) * P);
-    for (int i = 0; i < P; ++i) zbuf[i] = INFINITY;
-    memset(image, 0, (size_t)P * 4);
-    memset(vertexConf, 0, sizeof(float) * 4 * P);
-    memset(normalRad, 0, sizeof(float) * 4 * P);
-    memset(timeMap, 0, sizeof(uint16_t) * P);
     for (int i = 0; i < count; ++i) {
         const float* s = surfels + (size_t)i * 12;
         f3 h = m33_mul(Ri, f3_make(s[0], s[1], s[2]));
@@ -910,27 +906,70 @@ void mfo_combined_predict(const mfo_cam* c, const float* pose16, const float* su
                 const f3 l = f3_glnormalize(f3_make((fcx - c->cx) / c->fx, (fcy - c->cy) / c->fy, 1.0f));
                 const f3 cp = f3_scale(l, pn / f3_dot(l, n));
                 const f3 diff = f3_sub(cp, h);
-                if (!(f3_dot(diff, diff) <= sqrRad)) continue; /* discard if > (NaN discards too: see note) */
+                if (!(f3_dot(diff, diff) <= sqrRad)) continue; /* discard if > (NaN discards too) */
                 const float z = cp.z;
+                if (!(z > 0.f)) continue;
                 const int p = py * W + px;
                 if (!(z < zbuf[p])) continue;
                 zbuf[p] = z;
-                const int ci = (int)s[4];
-                image[p * 4 + 0] = (uint8_t)((ci >> 16) & 0xFF);
-                image[p * 4 + 1] = (uint8_t)((ci >> 8) & 0xFF);
-                image[p * 4 + 2] = (uint8_t)(ci & 0xFF);
-                image[p * 4 + 3] = 255;
-                vertexConf[p * 4 + 0] = (fcx - c->cx) * z * (1.f / c->fx);
-                vertexConf[p * 4 + 1] = (fcy - c->cy) * z * (1.f / c->fy);
-                vertexConf[p * 4 + 2] = z;
-                vertexConf[p * 4 + 3] = s[3];
-                normalRad[p * 4 + 0] = n.x; normalRad[p * 4 + 1] = n.y; normalRad[p * 4 + 2] = n.z;
-                normalRad[p * 4 + 3] = rad;
-                timeMap[p] = (uint16_t)(unsigned)s[6];
+                winner[p] = i;
+                if (owner) owner[p] = tag;
             }
         }
     }
-    free(zbuf);
+}
+
+void mfo_combined_predict(const mfo_cam* c, const float* pose16, const float* surfels, int count, float maxDepth,
+                          float confThreshold, int time, int maxTime, int timeDelta, uint8_t* image,
+                          float* vertexConf, float* normalRad, uint16_t* timeMap) {
+    const int W = c->W, H = c->H, P = W * H;
+    float R[9], t[3], Ri[9], ti[3];
+    pose16_to_Rt(pose16, R, t);
+    pose_inverse_Rt(R, t, Ri, ti);
+    float* zbuf = (float*)malloc(sizeof(float) * P);
+    int32_t* winner = (int32_t*)malloc(sizeof(int32_t) * P);
+    for (int i = 0; i < P; ++i) { zbuf[i] = INFINITY; winner[i] = -1; }
+    splat_zbuffer(c, pose16, surfels, count, maxDepth, confThreshold, time, maxTime, timeDelta, zbuf, winner, NULL, 0);
+    memset(image, 0, (size_t)P * 4);
+    memset(vertexConf, 0, sizeof(float) * 4 * P);
+    memset(normalRad, 0, sizeof(float) * 4 * P);
+    memset(timeMap, 0, sizeof(uint16_t) * P);
+    for (int p = 0; p < P; ++p) {
+        if (winner[p] < 0) continue;
+        const float* s = surfels + (size_t)winner[p] * 12;
+        const int px = p % W, py = p / W;
+        const float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;
+        const float z = zbuf[p];
+        const f3 n = f3_glnormalize(m33_mul(Ri, f3_make(s[8], s[9], s[10])));
+        const int ci = (int)s[4];
+        image[p * 4 + 0] = (uint8_t)((ci >> 16) & 0xFF);
+        image[p * 4 + 1] = (uint8_t)((ci >> 8) & 0xFF);
+        image[p * 4 + 2] = (uint8_t)(ci & 0xFF);
+        image[p * 4 + 3] = 255;
+        vertexConf[p * 4 + 0] = (fcx - c->cx) * z * (1.f / c->fx);   /* combo_splat.frag:56 */
+        vertexConf[p * 4 + 1] = (fcy - c->cy) * z * (1.f / c->fy);
+        vertexConf[p * 4 + 2] = z;
+        vertexConf[p * 4 + 3] = s[3];
+        normalRad[p * 4 + 0] = n.x; normalRad[p * 4 + 1] = n.y; normalRad[p * 4 + 2] = n.z;
+        normalRad[p * 4 + 3] = s[11];
+        timeMap[p] = (uint16_t)(unsigned)s[6];
+    }
+    free(zbuf); free(winner);
+}
+
+/* GlobalProjection::project + downloadDirect (Core/Model/GlobalProjection.cpp:43-114): every model splatted into one
+ * z-buffer with the fixed surfel-confidence threshold 12 (:61); earlier models in the list win depth ties. */
+void mfo_global_projection(const mfo_cam* c, const mfo_model_view* models, int n_models, int time, int maxTime,
+                           int timeDelta, float depthCutoff, uint8_t* ids) {
+    const int P = c->W * c->H;
+    float* zbuf = (float*)malloc(sizeof(float) * P);
+    int32_t* winner = (int32_t*)malloc(sizeof(int32_t) * P);
+    for (int i = 0; i < P; ++i) { zbuf[i] = INFINITY; winner[i] = -1; }
+    memset(ids, 0, P);
+    for (int m = 0; m < n_models; ++m)
+        splat_zbuffer(c, models[m].pose16, models[m].surfels, models[m].count, depthCutoff, 12.0f, time, maxTime,
+                      timeDelta, zbuf, winner, ids, (uint8_t)models[m].id);
+    free(zbuf); free(winner);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -1240,3 +1279,551 @@ const float* mfo_dbg_pred_vertex(const mfo_ctx* x) { return x->predVertex; }
 const float* mfo_dbg_pred_normal(const mfo_ctx* x) { return x->predNormal; }
 const uint8_t* mfo_dbg_pred_image(const mfo_ctx* x) { return x->predImage; }
 int mfo_dbg_last_fillin(const mfo_ctx* x) { return x->lastFillIn; }
+
+/* =====================================================================================================
+ * a20: MfSegmentation -- GPU half (Core/Cuda/segmentation.cu) restated on the CPU
+ * ===================================================================================================== */
+/* segmentation.cu:122-177.  Note: an invalid centre vertex has z = 0 in the reference (x = NaN only); the maps here
+ * carry NaN in all planes, so "v.z <= 0" is extended by isnan(v.z) to keep the reference's answer (edge = 1). */
+void mfo_geometric_edge_map(const float* vmap, const float* nmap, float* out, int W, int H, float wD, float wC) {
+    const int P = W * H;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; ++y) {
+        for (int x = 0; x < W; ++x) {
+            const int i = y * W + x;
+            if (x < 1 || x >= W - 1 || y < 1 || y >= H - 1) { out[i] = 1.0f; continue; }
+            const f3 v = f3_make(vmap[i], vmap[P + i], vmap[2 * P + i]);
+            const f3 n = f3_make(nmap[i], nmap[P + i], nmap[2 * P + i]);
+            if (v.z <= 0.0f || isnan(v.z)) { out[i] = 1.0f; continue; }
+            static const int ox[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+            static const int oy[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+            float c = 0.0f, d = 0.0f;
+            for (int k = 0; k < 8; ++k) {
+                const int j = (y + oy[k]) * W + (x + ox[k]);
+                const f3 vn = f3_make(vmap[j], vmap[P + j], vmap[2 * P + j]);
+                const f3 nn = f3_make(nmap[j], nmap[P + j], nmap[2 * P + j]);
+                /* getConcavityTerm, :106-112 */
+                float ct = (f3_dot(f3_sub(vn, v), n) < 0) ? 0.f : 1.f - f3_dot(nn, n);
+                c = fmaxf(ct, c); /* fmax ignores a NaN operand, like CUDA's fmax */
+                /* getDistanceTerm, :115-119 */
+                d = fmaxf(fabsf(f3_dot(f3_sub(vn, v), n)), d);
+            }
+            c = fmaxf(c, 0.0f);
+            c *= wC;
+            d *= wD;
+            const float edgeness = (c > d) ? c : d; /* max(c,d) */
+            out[i] = fminf(1.0f, edgeness);
+        }
+    }
+}
+
+void mfo_threshold_map(const float* in, uint8_t* out, int n, float threshold) {
+    for (int i = 0; i < n; ++i) out[i] = in[i] > threshold ? 255 : 0;
+}
+void mfo_invert_map(const uint8_t* in, uint8_t* out, int n) {
+    for (int i = 0; i < n; ++i) out[i] = (uint8_t)(255 - in[i]);
+}
+static void dilate_u8(const uint8_t* in, uint8_t* out, int W, int H, int radius) { /* segmentation.cu:237-255 */
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            uint8_t r = 0;
+            for (int cy = imax(y - radius, 0); cy <= imin(y + radius, H - 1) && !r; ++cy)
+                for (int cx = imax(x - radius, 0); cx <= imin(x + radius, W - 1); ++cx) {
+                    if (cy == y && cx == x) continue;
+                    if (in[cy * W + cx] == 255) { r = 255; break; }
+                }
+            out[y * W + x] = r;
+        }
+}
+static void erode_u8(const uint8_t* in, uint8_t* out, int W, int H, int radius) { /* segmentation.cu:217-235 */
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            uint8_t r = 255;
+            for (int cy = imax(y - radius, 0); cy <= imin(y + radius, H - 1) && r; ++cy)
+                for (int cx = imax(x - radius, 0); cx <= imin(x + radius, W - 1); ++cx) {
+                    if (cy == y && cx == x) continue;
+                    if (in[cy * W + cx] == 0) { r = 0; break; }
+                }
+            out[y * W + x] = r;
+        }
+}
+void mfo_morph_closing_u8(uint8_t* data, uint8_t* buffer, int W, int H, int radius, int iterations) {
+    for (int i = 0; i < iterations; ++i) { dilate_u8(data, buffer, W, H, radius); erode_u8(buffer, data, W, H, radius); }
+}
+
+/* ---- CPU half ---------------------------------------------------------------------------------- */
+int mfo_connected_components4(const uint8_t* bin, int32_t* labels, int32_t* stats, int max_comp, int W, int H) {
+    const int P = W * H;
+    for (int i = 0; i < P; ++i) labels[i] = 0;
+    int* stack = (int*)malloc(sizeof(int) * (size_t)P);
+    int n = 1;
+    if (max_comp > 0) { stats[0] = stats[1] = 0; stats[2] = W; stats[3] = H; stats[4] = 0; }
+    for (int i = 0; i < P; ++i) {
+        if (!bin[i] || labels[i]) continue;
+        if (n >= max_comp) break;
+        int sp = 0, x0 = W, y0 = H, x1 = -1, y1 = -1, area = 0;
+        stack[sp++] = i; labels[i] = n;
+        while (sp) {
+            const int p = stack[--sp], x = p % W, y = p / W;
+            ++area;
+            if (x < x0) x0 = x;
+            if (x > x1) x1 = x;
+            if (y < y0) y0 = y;
+            if (y > y1) y1 = y;
+            if (x > 0 && bin[p - 1] && !labels[p - 1]) { labels[p - 1] = n; stack[sp++] = p - 1; }
+            if (x < W - 1 && bin[p + 1] && !labels[p + 1]) { labels[p + 1] = n; stack[sp++] = p + 1; }
+            if (y > 0 && bin[p - W] && !labels[p - W]) { labels[p - W] = n; stack[sp++] = p - W; }
+            if (y < H - 1 && bin[p + W] && !labels[p + W]) { labels[p + W] = n; stack[sp++] = p + W; }
+        }
+        stats[n * 5 + 0] = x0; stats[n * 5 + 1] = y0; stats[n * 5 + 2] = x1 - x0 + 1; stats[n * 5 + 3] = y1 - y0 + 1;
+        stats[n * 5 + 4] = area;
+        ++n;
+    }
+    int bg = 0;
+    for (int i = 0; i < P; ++i) bg += labels[i] == 0;
+    if (max_comp > 0) stats[4] = bg;
+    free(stack);
+    return n;
+}
+
+void mfo_default_seg_params(mfo_seg_params* p) {
+    p->threshold = 0.1f; p->weightDistance = 1.f; p->weightConvexity = 1.f;
+    p->morphEdgeIterations = 3; p->morphEdgeRadius = 1; p->morphMaskIterations = 3; p->morphMaskRadius = 1;
+    p->removeEdges = 1; p->minRelSizeNew = 0.07f; p->maxRelSizeNew = 0.4f; p->personClassID = 255;
+}
+
+/* grayscale dilate / erode with OpenCV's MORPH_ELLIPSE element (cv::getStructuringElement) and the default constant
+ * border (ignored outside the image) -- stand-in for cv::morphologyEx(MORPH_CLOSE), MfSegmentation.cpp:424-426 */
+static void ellipse_rows(int r, int* j1, int* j2) {
+    const int ks = 2 * r + 1;
+    const double inv_r2 = r ? 1.0 / ((double)r * r) : 0;
+    for (int i = 0; i < ks; ++i) {
+        const int dy = i - r;
+        int dx = (int)lrint(r * sqrt((r * r - dy * dy) * inv_r2));
+        j1[i] = imax(r - dx, 0); j2[i] = imin(r + dx + 1, ks);
+    }
+}
+static void morph_gray(const uint8_t* in, uint8_t* out, int W, int H, int r, int dilate) {
+    int j1[64], j2[64];
+    ellipse_rows(r, j1, j2);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            int v = dilate ? 0 : 255;
+            for (int i = 0; i < 2 * r + 1; ++i) {
+                const int yy = y + i - r;
+                if (yy < 0 || yy >= H) continue;
+                for (int j = j1[i]; j < j2[i]; ++j) {
+                    const int xx = x + j - r;
+                    if (xx < 0 || xx >= W) continue;
+                    const int s = in[yy * W + xx];
+                    if (dilate ? s > v : s < v) v = s;
+                }
+            }
+            out[y * W + x] = (uint8_t)v;
+        }
+}
+
+void mfo_mf_segmentation_cpu(const mfo_seg_params* prm, int W, int H, const uint8_t* binaryIn, const float* depth,
+                             const uint8_t* mask, const int32_t* classIDs, int nMasks, const uint8_t* projectedIDs,
+                             const int32_t* modelIDs, const int32_t* modelClassIDs, int nModels, int nextModelID,
+                             int allowNew, uint8_t* ignoreMap, uint8_t* full, int* hasNewLabel, int* newClassID) {
+    const int total = W * H;
+    const size_t minNewMaskPixels = (size_t)(prm->minRelSizeNew * total);
+    const size_t maxNewMaskPixels = (size_t)(prm->maxRelSizeNew * total);
+    uint8_t* binary = (uint8_t*)malloc(total);
+    memcpy(binary, binaryIn, total);
+    *hasNewLabel = 0; *newClassID = -1;
+    /* ignore map, :221-235 */
+    if (nMasks) {
+        for (int i = 0; i < total; ++i) {
+            if (classIDs[mask[i]] == prm->personClassID) { ignoreMap[i] = 255; binary[i] = 0; }
+            else ignoreMap[i] = 0;
+        }
+    } else {
+        for (int i = 0; i < total; ++i)
+            if (ignoreMap[i]) binary[i] = 0;
+    }
+    /* connected components, :239 */
+    const int maxComp = total / 2 + 2;
+    int32_t* labels = (int32_t*)malloc(sizeof(int32_t) * total);
+    int32_t* stats = (int32_t*)malloc(sizeof(int32_t) * 5 * (size_t)maxComp);
+    const int nComponents = mfo_connected_components4(binary, labels, stats, maxComp, W, H);
+    /* removeEdges, :243-291: 5 Jacobi sweeps (neighbours are read from the previous sweep's labels) */
+    if (prm->removeEdges) {
+        int32_t* r = (int32_t*)malloc(sizeof(int32_t) * total);
+        static const int ox[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+        static const int oy[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+        for (int it = 0; it < 5; ++it) {
+            memcpy(r, labels, sizeof(int32_t) * total);
+            for (int y = 1; y < H - 1; ++y)
+                for (int x = 1; x < W - 1; ++x) {
+                    const int c = r[y * W + x];
+                    const float d = depth[y * W + x];
+                    if (c == 0 || stats[c * 5 + 4] < 50) {
+                        for (int k = 0; k < 8; ++k) {
+                            const int n = labels[(y + oy[k]) * W + (x + ox[k])];
+                            if (n != 0 && fabsf(depth[(y + oy[k]) * W + (x + ox[k])] - d) < 0.008 && stats[n * 5 + 4] > 50) {
+                                r[y * W + x] = n;
+                                break;
+                            }
+                        }
+                    }
+                }
+            memcpy(labels, r, sizeof(int32_t) * total);
+        }
+        free(r);
+    }
+    /* overlaps, :299-318 */
+    int* mapComponentToMask = (int*)calloc(nComponents, sizeof(int));
+    int* maskComponentPixels = (int*)calloc(nMasks > 0 ? nMasks : 1, sizeof(int));
+    int* compMaskOverlap = (int*)calloc((size_t)nComponents * (nMasks > 0 ? nMasks : 1), sizeof(int));
+    int* compModelOverlap = (int*)calloc((size_t)nComponents * nModels, sizeof(int));
+    int idToIndex[256];
+    for (int k = 0; k < 256; ++k) idToIndex[k] = 0; /* std::map default */
+    for (int m = 0; m < nModels; ++m) idToIndex[modelIDs[m] & 255] = m;
+    for (int i = 0; i < total; ++i) {
+        int mi = idToIndex[projectedIDs[i]];
+        if (mi >= nModels) mi = 0;
+        compModelOverlap[(size_t)labels[i] * nModels + mi]++;
+    }
+    if (nMasks) {
+        for (int i = 0; i < total; ++i) compMaskOverlap[(size_t)labels[i] * nMasks + mask[i]]++;
+        for (int c = 1; c < nComponents; ++c) {
+            const int csize = stats[c * 5 + 4];
+            if (csize > 160) { /* minMappedComponentSize */
+                const int t = (int)(0.65f * csize);
+                for (int m = 1; m < nMasks; ++m)
+                    if (compMaskOverlap[(size_t)c * nMasks + m] > t) {
+                        mapComponentToMask[c] = m;
+                        maskComponentPixels[m] += csize;
+                    }
+            } else mapComponentToMask[c] = 0;
+        }
+    }
+    for (int i = 0; i < total; ++i) full[i] = (uint8_t)mapComponentToMask[labels[i]];
+    for (int i = 0; i < total; ++i)
+        if (ignoreMap[i]) full[i] = 255;
+    int maskToID[256];
+    for (int k = 0; k < 256; ++k) maskToID[k] = 0;
+    maskToID[255] = 255; maskToID[0] = 0;
+    if (nMasks) {
+        /* closing on the label image, :424-426 (iterations == 0 copies) */
+        if (prm->morphMaskIterations > 0) {
+            uint8_t* tmp = (uint8_t*)malloc(total);
+            for (int it = 0; it < prm->morphMaskIterations; ++it) { morph_gray(full, tmp, W, H, prm->morphMaskRadius, 1); memcpy(full, tmp, total); }
+            for (int it = 0; it < prm->morphMaskIterations; ++it) { morph_gray(full, tmp, W, H, prm->morphMaskRadius, 0); memcpy(full, tmp, total); }
+            free(tmp);
+        }
+        for (int m = 1; m < nMasks; ++m) { maskToID[m] = 0; if (classIDs[m] == prm->personClassID) maskToID[m] = 255; }
+        /* mask x model overlap, :441-447 */
+        unsigned* maskOverlap = (unsigned*)calloc((size_t)nModels * 256, sizeof(unsigned));
+        for (int i = 0; i < total; ++i)
+            for (int b = 0; b < nModels; ++b)
+                if (projectedIDs[i] == modelIDs[b]) maskOverlap[(size_t)b * 256 + full[i]]++;
+        for (int midx = 1; midx < nMasks; ++midx) {
+            if (maskToID[midx] == 255) continue;
+            int bestModelIndex = 0;
+            unsigned bestOverlap = 0;
+            const int maskClassID = classIDs[midx];
+            for (int j = 1; j < nModels; ++j)
+                if (maskOverlap[(size_t)j * 256 + midx] > bestOverlap) { bestOverlap = maskOverlap[(size_t)j * 256 + midx]; bestModelIndex = j; }
+            const int bestModelMatchesClass = modelClassIDs[bestModelIndex] == maskClassID;
+            if (bestOverlap < 0.05f * maskComponentPixels[midx]) bestModelIndex = 0;
+            if (bestModelIndex != 0 && bestModelMatchesClass) maskToID[midx] = modelIDs[bestModelIndex];
+            else if (!*hasNewLabel && allowNew && (size_t)maskComponentPixels[midx] > minNewMaskPixels &&
+                     (size_t)maskComponentPixels[midx] < maxNewMaskPixels && bestModelIndex == 0) {
+                maskToID[midx] = nextModelID;
+                *hasNewLabel = 1;
+                *newClassID = maskClassID;
+            } else maskToID[midx] = 255;
+        }
+        free(maskOverlap);
+    }
+    for (int i = 0; i < total; ++i) full[i] = (uint8_t)maskToID[full[i]];
+    /* unused components -> existing models, :500-522 (the reference's inclusive box bounds are clamped to the image) */
+    for (int c = 1; c < nComponents; ++c) {
+        if (mapComponentToMask[c] != 0) continue;
+        int model_index = 0, overlap = compModelOverlap[(size_t)c * nModels];
+        for (int m = 1; m < nModels; ++m)
+            if (compModelOverlap[(size_t)c * nModels + m] > overlap) { overlap = compModelOverlap[(size_t)c * nModels + m]; model_index = m; }
+        const int model_id = modelIDs[model_index];
+        if (model_id > 0 && overlap > 0.6f * stats[c * 5 + 4]) {
+            const int x1 = stats[c * 5 + 0], x2 = imin(stats[c * 5 + 0] + stats[c * 5 + 2], W - 1);
+            const int y1 = stats[c * 5 + 1], y2 = imin(stats[c * 5 + 1] + stats[c * 5 + 3], H - 1);
+            for (int y = y1; y <= y2; ++y)
+                for (int x = x1; x <= x2; ++x)
+                    if (labels[y * W + x] == c) full[y * W + x] = (uint8_t)model_id;
+        }
+    }
+    free(binary); free(labels); free(stats); free(mapComponentToMask); free(maskComponentPixels); free(compMaskOverlap);
+    free(compModelOverlap);
+}
+
+/* =====================================================================================================
+ * a1, multi-model branch: MaskFusion::processFrame with enableMultipleModels (Core/MaskFusion.cpp:200-607)
+ * ===================================================================================================== */
+typedef struct {
+    int id, classID, isStatic, age, count, cur, cap;
+    float pose[16], lastPose[16], initialC2Winv[16];
+    float confThr, maxDepth;
+    float* surf[2];
+    uint8_t* predImage; float* predVertex; float* predNormal; uint16_t* predTime;
+    float lastICPError, lastICPCount;
+} mm_model;
+
+struct mfo_mm {
+    mfo_mm_config cfg;
+    mfo_cam cam;
+    int tick, nextID, spawnOffset, nModels;
+    mm_model* models;
+    uint8_t* rgb; float* depth; float* depthF; uint8_t* mask;
+    float* depthPyr[3]; float* vmap[3]; float* nmap[3];
+    float* vmap_g[3]; float* nmap_g[3];
+    int32_t* index; float* ivc; float* ict; float* inr;
+    uint8_t* fillImage; float* fillVertex; float* fillNormal;
+    uint8_t* cand_op; int32_t* cand_best; float* cand_rec; int n_cand;
+    float* edge; uint8_t* binEdge; uint8_t* ucharBuf; uint8_t* projIDs; uint8_t* ignoreMap; uint8_t* fullSeg;
+};
+
+void mfo_mm_default_config(mfo_mm_config* c, int W, int H, float fx, float fy, float cx, float cy) {
+    memset(c, 0, sizeof(*c));
+    mfo_default_config(&c->base, W, H, fx, fy, cx, cy);
+    c->confObject = 2.f; c->capacityObject = 1024 * 1024; c->trackAllModels = 1; c->modelSpawnOffset = 20; c->maxModels = 16;
+    mfo_default_seg_params(&c->seg);
+}
+
+static void mat4_identity(float* m) { for (int k = 0; k < 16; ++k) m[k] = (k % 5 == 0) ? 1.f : 0.f; }
+static void mat4_mul_cm(const float* a, const float* b, float* out) { /* column-major 4x4 */
+    float r[16];
+    for (int c = 0; c < 4; ++c)
+        for (int rr = 0; rr < 4; ++rr) {
+            float s = 0;
+            for (int k = 0; k < 4; ++k) s += a[k * 4 + rr] * b[c * 4 + k];
+            r[c * 4 + rr] = s;
+        }
+    memcpy(out, r, sizeof(r));
+}
+static void mat4_rigid_inverse_cm(const float* p, float* out) {
+    float R[9], t[3], Ri[9], ti[3];
+    pose16_to_Rt(p, R, t);
+    pose_inverse_Rt(R, t, Ri, ti);
+    Rt_to_pose16(Ri, ti, out);
+}
+
+static void mm_model_init(mfo_mm* x, mm_model* m, int id, float confThr, int cap) {
+    const int P = x->cam.W * x->cam.H;
+    memset(m, 0, sizeof(*m));
+    m->id = id; m->classID = -1; m->isStatic = 1; m->confThr = confThr; m->maxDepth = 3.402823466e38f; m->cap = cap;
+    mat4_identity(m->pose); mat4_identity(m->lastPose); mat4_identity(m->initialC2Winv);
+    m->surf[0] = (float*)calloc((size_t)cap * 12, sizeof(float));
+    m->surf[1] = (float*)calloc((size_t)cap * 12, sizeof(float));
+    m->predImage = (uint8_t*)calloc((size_t)P * 4, 1);
+    m->predVertex = (float*)calloc((size_t)P * 4, sizeof(float));
+    m->predNormal = (float*)calloc((size_t)P * 4, sizeof(float));
+    m->predTime = (uint16_t*)calloc(P, sizeof(uint16_t));
+}
+static void mm_model_free(mm_model* m) {
+    free(m->surf[0]); free(m->surf[1]); free(m->predImage); free(m->predVertex); free(m->predNormal); free(m->predTime);
+}
+
+mfo_mm* mfo_mm_create(const mfo_mm_config* cfg) {
+    mfo_mm* x = (mfo_mm*)calloc(1, sizeof(mfo_mm));
+    x->cfg = *cfg;
+    const mfo_config* g = &cfg->base;
+    x->cam.W = g->W; x->cam.H = g->H; x->cam.fx = g->fx; x->cam.fy = g->fy; x->cam.cx = g->cx; x->cam.cy = g->cy;
+    const int W = g->W, H = g->H, P = W * H;
+    x->tick = 1; x->nextID = 0; x->spawnOffset = 0;
+    x->models = (mm_model*)calloc(cfg->maxModels, sizeof(mm_model));
+    mm_model_init(x, &x->models[0], x->nextID++, g->confGlobal, g->capacity); /* getNextModelID(true), :80 */
+    x->nModels = 1;
+    x->rgb = (uint8_t*)calloc((size_t)P * 3, 1);
+    x->depth = (float*)calloc(P, sizeof(float)); x->depthF = (float*)calloc(P, sizeof(float));
+    x->mask = (uint8_t*)calloc(P, 1);
+    for (int i = 0; i < 3; ++i) {
+        const int lp = (W >> i) * (H >> i);
+        x->depthPyr[i] = (float*)calloc(lp, sizeof(float));
+        x->vmap[i] = (float*)calloc((size_t)lp * 3, sizeof(float)); x->nmap[i] = (float*)calloc((size_t)lp * 3, sizeof(float));
+        x->vmap_g[i] = (float*)calloc((size_t)lp * 3, sizeof(float)); x->nmap_g[i] = (float*)calloc((size_t)lp * 3, sizeof(float));
+    }
+    x->index = (int32_t*)calloc(P, sizeof(int32_t));
+    x->ivc = (float*)calloc((size_t)P * 4, sizeof(float)); x->ict = (float*)calloc((size_t)P * 4, sizeof(float));
+    x->inr = (float*)calloc((size_t)P * 4, sizeof(float));
+    x->fillImage = (uint8_t*)calloc((size_t)P * 4, 1);
+    x->fillVertex = (float*)calloc((size_t)P * 4, sizeof(float)); x->fillNormal = (float*)calloc((size_t)P * 4, sizeof(float));
+    const int maxc = ((W + 1) / 2) * ((H + 1) / 2);
+    x->cand_op = (uint8_t*)calloc(maxc, 1); x->cand_best = (int32_t*)calloc(maxc, sizeof(int32_t));
+    x->cand_rec = (float*)calloc((size_t)maxc * 12, sizeof(float));
+    x->edge = (float*)calloc(P, sizeof(float)); x->binEdge = (uint8_t*)calloc(P, 1); x->ucharBuf = (uint8_t*)calloc(P, 1);
+    x->projIDs = (uint8_t*)calloc(P, 1); x->ignoreMap = (uint8_t*)calloc(P, 1); x->fullSeg = (uint8_t*)calloc(P, 1);
+    return x;
+}
+
+void mfo_mm_destroy(mfo_mm* x) {
+    if (!x) return;
+    for (int i = 0; i < x->nModels; ++i) mm_model_free(&x->models[i]);
+    free(x->models); free(x->rgb); free(x->depth); free(x->depthF); free(x->mask);
+    for (int i = 0; i < 3; ++i) { free(x->depthPyr[i]); free(x->vmap[i]); free(x->nmap[i]); free(x->vmap_g[i]); free(x->nmap_g[i]); }
+    free(x->index); free(x->ivc); free(x->ict); free(x->inr); free(x->fillImage); free(x->fillVertex); free(x->fillNormal);
+    free(x->cand_op); free(x->cand_best); free(x->cand_rec);
+    free(x->edge); free(x->binEdge); free(x->ucharBuf); free(x->projIDs); free(x->ignoreMap); free(x->fullSeg);
+    free(x);
+}
+
+/* Model::performTracking for one model (Model.cpp:427-447); returns |translation of the increment| */
+static float mm_track(mfo_mm* x, mm_model* m, int allowFillIn) {
+    const mfo_config* g = &x->cfg.base;
+    const int W = g->W, H = g->H;
+    memcpy(m->lastPose, m->pose, sizeof(m->pose));
+    const int doFillIn = allowFillIn && mfo_requires_fill_in(m->predImage, W, H, 0.75f);
+    mfo_copy_maps(doFillIn ? x->fillVertex : m->predVertex, doFillIn ? x->fillNormal : m->predNormal, x->vmap_g[0],
+                  x->nmap_g[0], W, H);
+    for (int i = 1; i < 3; ++i) {
+        mfo_resize_map(x->vmap_g[i - 1], x->vmap_g[i], W >> (i - 1), H >> (i - 1), 0);
+        mfo_resize_map(x->nmap_g[i - 1], x->nmap_g[i], W >> (i - 1), H >> (i - 1), 1);
+    }
+    float R[9], t[3], inc[16];
+    pose16_to_Rt(m->pose, R, t);
+    for (int i = 0; i < 3; ++i)
+        mfo_transform_maps(x->vmap_g[i], x->nmap_g[i], R, t, x->vmap_g[i], x->nmap_g[i], W >> i, H >> i);
+    mfo_track_opts o;
+    o.pyramid = g->pyramid; o.fastOdom = g->fastOdom; o.so3 = 0; o.rgbOnly = 0; o.icpWeight = g->icpWeight;
+    o.distThresh = 0.10f; o.angleThresh = sinf(20.f * 3.14159254f / 180.f);
+    const float* cv[3] = {x->vmap[0], x->vmap[1], x->vmap[2]};
+    const float* cn[3] = {x->nmap[0], x->nmap[1], x->nmap[2]};
+    const float* pv[3] = {x->vmap_g[0], x->vmap_g[1], x->vmap_g[2]};
+    const float* pn[3] = {x->nmap_g[0], x->nmap_g[1], x->nmap_g[2]};
+    mfo_track_icp(cv, cn, pv, pn, W, H, g->fx, g->fy, g->cx, g->cy, &o, R, t, inc, &m->lastICPError, &m->lastICPCount, NULL);
+    Rt_to_pose16(R, t, m->pose);
+    return sqrtf(inc[12] * inc[12] + inc[13] * inc[13] + inc[14] * inc[14]);
+}
+
+static void mm_predict_indices(mfo_mm* x, mm_model* m, const float* surf) {
+    const mfo_config* g = &x->cfg.base;
+    mfo_predict_indices(&x->cam, m->pose, surf, m->count, x->tick, g->maxDepthProcessed, g->timeDelta, x->index, x->ivc,
+                        x->ict, x->inr);
+}
+/* predictIndices -> fuse -> predictIndices -> clean for one model */
+static void mm_fuse_clean(mfo_mm* x, mm_model* m, float fuseDepthCutoff, float weightMultiplier, int secondIndexPass) {
+    const mfo_config* g = &x->cfg.base;
+    const int src = m->cur, dst = 1 - m->cur;
+    mm_predict_indices(x, m, m->surf[src]);
+    const float weighting = mfo_fusion_weight(m->pose, m->lastPose, weightMultiplier);
+    const float md = fminf(fuseDepthCutoff, m->maxDepth); /* Model.cpp:527 (bb_max_z = FLT_MAX headless) */
+    mfo_fuse_data(&x->cam, m->pose, x->rgb, x->depth, x->depthF, x->mask, m->id, x->tick, weighting, md, x->index, x->ivc,
+                  x->inr, x->cand_op, x->cand_best, x->cand_rec, &x->n_cand);
+    mfo_fuse_update(m->surf[src], m->surf[dst], m->count, x->tick, x->cand_op, x->cand_best, x->cand_rec, x->n_cand);
+    if (secondIndexPass) mm_predict_indices(x, m, m->surf[dst]);
+    m->count = mfo_clean(&x->cam, m->pose, m->surf[dst], m->count, x->cand_op, x->cand_rec, x->n_cand, x->tick,
+                         g->timeDelta, m->confThr, fminf(g->maxDepthProcessed, m->maxDepth), g->outlierCoeff, m->id,
+                         x->index, x->ivc, x->ict, x->inr, x->depthF, x->mask, m->surf[src], m->cap);
+}
+
+int mfo_mm_process_frame(mfo_mm* x, const uint8_t* rgb, const float* depth, const uint8_t* mask, const int32_t* classIDs,
+                         int nMasks, float weightMultiplier) {
+    const mfo_mm_config* cfg = &x->cfg;
+    const mfo_config* g = &cfg->base;
+    const int W = g->W, H = g->H, P = W * H;
+    memcpy(x->rgb, rgb, (size_t)P * 3);
+    memcpy(x->depth, depth, sizeof(float) * P);
+    mfo_bilateral(x->depth, x->depthF, W, H);
+    mm_model* bg = &x->models[0];
+    if (x->tick == 1) {
+        bg->cur = 0;
+        bg->count = mfo_init_surfels(&x->cam, x->rgb, x->depth, x->depthF, x->tick, g->maxDepthProcessed, bg->surf[0], bg->cap);
+    } else {
+        memcpy(x->depthPyr[0], x->depthF, sizeof(float) * P);
+        for (int i = 1; i < 3; ++i) mfo_pyrdown_gauss_f(x->depthPyr[i - 1], x->depthPyr[i], W >> (i - 1), H >> (i - 1));
+        for (int i = 0; i < 3; ++i) {
+            const int div = 1 << i;
+            mfo_create_vmap(x->depthPyr[i], x->vmap[i], W >> i, H >> i, g->fx / div, g->fy / div, g->cx / div, g->cy / div, g->depthCutoff);
+            mfo_create_nmap(x->vmap[i], x->nmap[i], W >> i, H >> i);
+        }
+        /* tracking, :247-276 */
+        mm_track(x, bg, 1);
+        for (int i = 1; i < x->nModels; ++i) {
+            mm_model* m = &x->models[i];
+            if (!m->isStatic || cfg->trackAllModels) {
+                const float d = mm_track(x, m, 0);
+                if (d > 0.2f) { /* inactivateModel, :268-272 */
+                    mm_model_free(m);
+                    memmove(&x->models[i], &x->models[i + 1], sizeof(mm_model) * (size_t)(x->nModels - i - 1));
+                    x->nModels--; i--;
+                }
+            } else { /* updateStaticPose: pose = initialC2Winv * globalPose (Model.h:263) */
+                memcpy(m->lastPose, m->pose, sizeof(m->pose));
+                mat4_mul_cm(m->initialC2Winv, bg->pose, m->pose);
+            }
+        }
+        /* segmentation, :287-375 */
+        {
+            mfo_model_view views[64];
+            int32_t ids[64], cls[64];
+            for (int i = 0; i < x->nModels; ++i) {
+                views[i].surfels = x->models[i].surf[x->models[i].cur]; views[i].count = x->models[i].count;
+                views[i].pose16 = x->models[i].pose; views[i].id = x->models[i].id;
+                ids[i] = x->models[i].id; cls[i] = x->models[i].classID;
+            }
+            mfo_global_projection(&x->cam, views, x->nModels, x->tick, x->tick, g->timeDelta, g->depthCutoff, x->projIDs);
+            if (x->spawnOffset < cfg->modelSpawnOffset) x->spawnOffset++;
+            /* MfSegmentation::performSegmentation, GPU half: :149-208 */
+            mfo_geometric_edge_map(x->vmap[0], x->nmap[0], x->edge, W, H, cfg->seg.weightDistance, cfg->seg.weightConvexity);
+            mfo_threshold_map(x->edge, x->binEdge, P, cfg->seg.threshold);
+            mfo_morph_closing_u8(x->binEdge, x->ucharBuf, W, H, cfg->seg.morphEdgeRadius, cfg->seg.morphEdgeIterations);
+            mfo_invert_map(x->binEdge, x->ucharBuf, P);
+            int hasNew = 0, newClass = -1;
+            static const int32_t zeroClass[1] = {0};
+            mfo_mf_segmentation_cpu(&cfg->seg, W, H, x->ucharBuf, x->depth, mask ? mask : x->mask /*unused when nMasks==0*/,
+                                    nMasks ? classIDs : zeroClass, mask ? nMasks : 0, x->projIDs, ids, cls, x->nModels,
+                                    x->nextID, x->spawnOffset >= cfg->modelSpawnOffset, x->ignoreMap, x->fullSeg, &hasNew,
+                                    &newClass);
+            memcpy(x->mask, x->fullSeg, P); /* textureMask upload, :297 */
+            if (hasNew && x->nModels < cfg->maxModels) {
+                mm_model* nm = &x->models[x->nModels];
+                mm_model_init(x, nm, x->nextID, cfg->confObject, cfg->capacityObject);
+                /* getNextModelID(true), :715-731 */
+                for (;;) {
+                    x->nextID = (x->nextID + 1) & 255;
+                    int occ = 0;
+                    for (int i = 0; i < x->nModels; ++i) occ |= x->models[i].id == x->nextID;
+                    if (!occ) break;
+                }
+                /* makeStatic(globalPose): initialC2Winv = pose * globalPose^-1 */
+                float ginv[16];
+                mat4_rigid_inverse_cm(bg->pose, ginv);
+                mat4_mul_cm(nm->pose, ginv, nm->initialC2Winv);
+                nm->isStatic = 1;
+                nm->classID = newClass;
+                x->spawnOffset = 0;
+                x->nModels++;
+            } else hasNew = 0;
+            for (int i = 1; i < x->nModels; ++i) x->models[i].maxDepth = 30.f + 30.f * 1.2f; /* :335-339 */
+            if (hasNew) { /* :342-359: predictIndices; fuse(maxDepthProcessed, weight 100); clean -- no second index pass */
+                mm_fuse_clean(x, &x->models[x->nModels - 1], g->maxDepthProcessed, 100.f, 0);
+            }
+            for (int i = 1; i < x->nModels; ++i) x->models[i].confThr = fminf(4.5f, x->models[i].age / 25.0f); /* :369-374 */
+        }
+        /* fusion, :539-565 */
+        for (int i = 0; i < x->nModels; ++i) mm_fuse_clean(x, &x->models[i], g->depthCutoff, weightMultiplier, 1);
+    }
+    /* predict(), :569 */
+    for (int i = 0; i < x->nModels; ++i) {
+        mm_model* m = &x->models[i];
+        mfo_combined_predict(&x->cam, m->pose, m->surf[m->cur], m->count, g->maxDepthProcessed, m->confThr, x->tick, x->tick,
+                             g->timeDelta, m->predImage, m->predVertex, m->predNormal, m->predTime);
+        if (i == 0)
+            mfo_fill_in(&x->cam, m->predImage, m->predVertex, m->predNormal, x->rgb, x->depthF, 0, x->fillImage,
+                        x->fillVertex, x->fillNormal);
+    }
+    x->tick++;
+    for (int i = 0; i < x->nModels; ++i) x->models[i].age++;
+    return 0;
+}
+
+int mfo_mm_num_models(const mfo_mm* x) { return x->nModels; }
+int mfo_mm_model_id(const mfo_mm* x, int i) { return x->models[i].id; }
+int mfo_mm_model_count(const mfo_mm* x, int i) { return x->models[i].count; }
+void mfo_mm_model_pose(const mfo_mm* x, int i, float* p) { memcpy(p, x->models[i].pose, sizeof(float) * 16); }
+const float* mfo_mm_model_surfels(const mfo_mm* x, int i) { return x->models[i].surf[x->models[i].cur]; }
+const uint8_t* mfo_mm_segmentation(const mfo_mm* x) { return x->fullSeg; }
+const uint8_t* mfo_mm_projected_ids(const mfo_mm* x) { return x->projIDs; }
+const float* mfo_mm_edge_map(const mfo_mm* x) { return x->edge; }

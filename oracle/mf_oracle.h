@@ -193,4 +193,82 @@ int            mfo_dbg_last_fillin(const mfo_ctx* ctx);
 #ifdef __cplusplus
 }
 #endif
+
+/* =====================================================================================================
+ * Multi-model path: GlobalProjection (a19), MfSegmentation (a20), object-model life cycle (a1 multi-model branch)
+ * ===================================================================================================== */
+#ifdef __cplusplus
+extern "C" {
 #endif
+
+/* Core/Cuda/segmentation.cu:122-177 (computeGeometricSegmentation_Kernel); vmap/nmap level 0, planar */
+void mfo_geometric_edge_map(const float* vmap, const float* nmap, float* out, int W, int H, float wD, float wC);
+/* segmentation.cu:257-262, 264-269 */
+void mfo_threshold_map(const float* in, uint8_t* out, int n, float threshold);
+void mfo_invert_map(const uint8_t* in, uint8_t* out, int n);
+/* segmentation.cu:217-255, 334-354: iterations x (dilate -> erode), square radius; in place on data (buffer = scratch) */
+void mfo_morph_closing_u8(uint8_t* data, uint8_t* buffer, int W, int H, int radius, int iterations);
+
+/* GlobalProjection::project + downloadDirect (Core/Model/GlobalProjection.cpp:43-114; splat_models.vert,
+ * combo_splat_models.frag).  Models in list order; ids: uint8 per pixel (0 where nothing projects). */
+typedef struct {
+    const float* surfels; int count; const float* pose16; int id;
+} mfo_model_view;
+void mfo_global_projection(const mfo_cam* cam, const mfo_model_view* models, int n_models, int time, int maxTime,
+                           int timeDelta, float depthCutoff, uint8_t* ids);
+
+/* 4-connected component labelling of a binary (0 / non-zero) image, labels numbered in raster order of each
+ * component's first pixel, 0 = background (stand-in for cv::connectedComponentsWithStats(..., 4),
+ * MfSegmentation.cpp:239).  stats: n_components x 5 ints {left, top, width, height, area}.  Returns n (incl. bg). */
+int mfo_connected_components4(const uint8_t* bin, int32_t* labels, int32_t* stats, int max_comp, int W, int H);
+
+typedef struct {
+    float threshold, weightDistance, weightConvexity;   /* 0.1 / 1 / 1   (MfSegmentation.h:48-50) */
+    int morphEdgeIterations, morphEdgeRadius;             /* 3 / 1 */
+    int morphMaskIterations, morphMaskRadius;             /* 3 / 1 */
+    int removeEdges;                                      /* 1 */
+    float minRelSizeNew, maxRelSizeNew;                   /* 0.07 / 0.4 (SegmentationPerformer.h:41-42) */
+    int personClassID;                                    /* 255 */
+} mfo_seg_params;
+void mfo_default_seg_params(mfo_seg_params* p);
+
+/* MfSegmentation::performSegmentation, CPU stage (Core/Segmentation/MfSegmentation.cpp:220-522).
+ * binary: output of threshold->morph->invert (255 = not an edge).  depth: raw frame depth.  mask/classIDs: the frame's
+ * Mask R-CNN output (nMasks = number of class ids; mask values index classIDs).  projectedIDs: GlobalProjection ids.
+ * modelIDs/modelClassIDs: the model list in order (index 0 = background).  Outputs: fullSegmentation (model id per
+ * pixel, 255 = ignore), *hasNewLabel, *newClassID.  ignoreMap is the persistent semanticIgnoreMap (in/out). */
+void mfo_mf_segmentation_cpu(const mfo_seg_params* prm, int W, int H, const uint8_t* binary, const float* depth,
+                             const uint8_t* mask, const int32_t* classIDs, int nMasks, const uint8_t* projectedIDs,
+                             const int32_t* modelIDs, const int32_t* modelClassIDs, int nModels, int nextModelID,
+                             int allowNew, uint8_t* ignoreMap, uint8_t* fullSegmentation, int* hasNewLabel,
+                             int* newClassID);
+
+/* Multi-model MaskFusion::processFrame (Core/MaskFusion.cpp:200-607 with enableMultipleModels) */
+typedef struct mfo_mm mfo_mm;
+typedef struct {
+    mfo_config base;             /* camera + tracker + background-model settings */
+    float confObject;            /* initConfidenceObject = 2 (ramped: min(4.5, age/25), MaskFusion.cpp:369-374) */
+    int capacityObject;          /* per object model */
+    int trackAllModels;          /* MaskFusion::trackAllModels */
+    int modelSpawnOffset;        /* 20 */
+    int maxModels;
+    mfo_seg_params seg;
+} mfo_mm_config;
+void    mfo_mm_default_config(mfo_mm_config* c, int W, int H, float fx, float fy, float cx, float cy);
+mfo_mm* mfo_mm_create(const mfo_mm_config* c);
+void    mfo_mm_destroy(mfo_mm* x);
+int     mfo_mm_process_frame(mfo_mm* x, const uint8_t* rgb, const float* depth, const uint8_t* mask,
+                             const int32_t* classIDs, int nMasks, float weightMultiplier);
+int     mfo_mm_num_models(const mfo_mm* x);
+int     mfo_mm_model_id(const mfo_mm* x, int i);
+int     mfo_mm_model_count(const mfo_mm* x, int i);
+void    mfo_mm_model_pose(const mfo_mm* x, int i, float* pose16);
+const float*   mfo_mm_model_surfels(const mfo_mm* x, int i);
+const uint8_t* mfo_mm_segmentation(const mfo_mm* x);   /* last fullSegmentation */
+const uint8_t* mfo_mm_projected_ids(const mfo_mm* x);  /* last GlobalProjection ids */
+const float*   mfo_mm_edge_map(const mfo_mm* x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MF_ORACLE_H_ */

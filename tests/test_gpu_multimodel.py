@@ -1,0 +1,114 @@
+"""Multi-model path on the GPU (GlobalProjection, geometric-edge segmentation, object spawning / tracking / fusion) against the
+oracle's restatement on the synthetic S2-style stream (moving boxes with instance masks)."""
+import numpy as np
+import pytest
+
+from gpu_util import dev, empty, host, nan_equal_close
+
+pytestmark = pytest.mark.gpu
+
+SEG = dict(threshold=0.3, weightDistance=150.0, weightConvexity=2.8, morphEdgeIterations=0, morphMaskIterations=0,
+           minRelSizeNew=0.004)   # the GUI defaults (GUI/Tools/GUI.h:345-374) with a smaller new-model size for VGA toys
+
+
+def _stream(n_frames, n_objects=2):
+    from maskfusion_amd import synth
+    st = synth.Stream(W=640, H=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, n_objects=n_objects, noise=True)
+    return st, [st.frame(k) for k in range(n_frames)]
+
+
+def test_geometric_edges_kernel(hip, oracle):
+    from oracle import mfo_mm
+    st, fr = _stream(1)
+    dF = oracle.bilateral(fr[0][1])
+    v = oracle.create_vmap(dF, st.fx, st.fy, st.cx, st.cy, 3.0)
+    n = oracle.create_nmap(v)
+    for (wD, wC, thr, rad, it) in ((150.0, 2.8, 0.3, 1, 0), (1.0, 1.0, 0.1, 1, 3), (150.0, 2.8, 0.3, 2, 1)):
+        e_ref = mfo_mm.geometric_edge_map(v, n, wD, wC)
+        _, inv_ref = mfo_mm.edge_binary(e_ref, thr, rad, it)
+        d_v, d_n = dev(v), dev(n)
+        d_e = empty((st.H, st.W))
+        import torch
+        d_b = empty((st.H, st.W), torch.uint8)
+        d_t = empty((st.H, st.W), torch.uint8)
+        assert hip.mf_k_geometric_edges(d_v.data_ptr(), d_n.data_ptr(), d_e.data_ptr(), d_b.data_ptr(), d_t.data_ptr(), st.W, st.H,
+                                        wD, wC, thr, rad, it, None) == 0
+        e, b = host(d_e), host(d_b)
+        err, bad = nan_equal_close(e, e_ref, 1e-4, 1e-5)
+        # the binary map may flip only where the edge value sits within rounding of the threshold
+        flips = (b != inv_ref)
+        near = np.abs(e_ref - thr) < 1e-4
+        print("edge err", err, "binary flips", int(flips.sum()))
+        assert bad == 0
+        if it == 0:
+            assert not (flips & ~near).any()
+        else:
+            assert flips.mean() < 1e-4
+
+
+@pytest.fixture(scope="module")
+def mm_run(hip, oracle):
+    from maskfusion_amd import MaskFusion
+    from oracle import mfo_mm
+    st, frames = _stream(14)
+    cls = [0, 41, 42]
+    o = mfo_mm.OracleMM(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpWeight=100.0, capacity=1 << 20, capacityObject=1 << 18,
+                        modelSpawnOffset=3, seg=SEG)
+    m = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=100.0, so3=False, numGSurfels=1 << 20, numOSurfels=1 << 18,
+                   enableMultipleModels=True, modelSpawnOffset=3)
+    for k, v in (("mfThreshold", SEG["threshold"]), ("mfWeightDistance", SEG["weightDistance"]),
+                 ("mfWeightConvexity", SEG["weightConvexity"]), ("mfMorphEdgeIterations", 0), ("mfMorphMaskIterations", 0),
+                 ("newModelMinRelativeSize", SEG["minRelSizeNew"])):
+        m.setParam(k, v)
+    rec = []
+    for k, (rgb, depth, mask) in enumerate(frames):
+        o.process_frame(rgb, depth, mask, cls)
+        m.processFrame(rgb, depth, mask=mask, classIDs=cls, timestamp=k)
+        gm = m.getModels()
+        rec.append(dict(o_n=o.n_models, g_n=len(gm), o_ids=[o.model_id(i) for i in range(o.n_models)], g_ids=[x.getID() for x in gm],
+                        o_cnt=[o.model_count(i) for i in range(o.n_models)], g_cnt=[x.lastCount() for x in gm],
+                        o_seg=o.segmentation(), g_seg=m.downloadSegmentation(), o_proj=o.projected_ids(),
+                        g_proj=m.debugRead("projected_ids") if k > 0 else o.projected_ids(),
+                        o_pose=[o.model_pose(i) for i in range(o.n_models)], g_pose=[x.getPose() for x in gm], gt_mask=mask))
+    o.close(); m.close()
+    return rec
+
+
+# Object models are a few thousand surfels on small moving boxes: their ICP is a chaotic system, so discrete decisions
+# (spawn / drop) agree with the oracle only for a bounded horizon.  The strict comparisons use the first STRICT frames
+# (which cover two spawns, one drop-by-jump and one re-spawn); afterwards only the invariants are checked.
+STRICT = 11
+
+
+def test_models_spawn_like_the_oracle(mm_run):
+    for k, r in enumerate(mm_run):
+        print(k, "models oracle/hip", r["o_ids"], r["g_ids"], "counts", r["o_cnt"], r["g_cnt"])
+        if k < STRICT:
+            assert r["o_ids"] == r["g_ids"], f"frame {k}"
+        assert r["g_ids"][0] == 0 and len(set(r["g_ids"])) == len(r["g_ids"])
+    assert max(r["o_n"] for r in mm_run[:STRICT]) >= 3, "the scenario must spawn object models"
+
+
+def test_segmentation_and_projection_agree(mm_run):
+    for k, r in enumerate(mm_run[:STRICT]):
+        seg_diff = (r["o_seg"] != r["g_seg"]).mean()
+        proj_diff = (r["o_proj"] != r["g_proj"]).mean()
+        print(k, "seg pixel diff", seg_diff, "projected-id diff", proj_diff)
+        assert seg_diff < 5e-3 and proj_diff < 1e-2   # a one-pixel shift of an object's silhouette is ~0.5 % of the image
+    # and the label image does isolate the moving boxes (semantic check against the synthetic ground truth)
+    last = mm_run[-1]
+    labelled = last["g_seg"] > 0
+    assert (last["gt_mask"][labelled & (last["g_seg"] != 255)] > 0).mean() > 0.9
+
+
+def test_poses_and_counts_track_oracle(mm_run):
+    for k, r in enumerate(mm_run[:STRICT]):
+        d_bg = np.abs(r["o_pose"][0] - r["g_pose"][0]).max()
+        assert d_bg < 2e-4, f"frame {k}: background pose differs by {d_bg}"
+        for i in range(len(r["o_cnt"])):
+            oc, gc = r["o_cnt"][i], r["g_cnt"][i]
+            assert abs(oc - gc) <= max(20, 0.02 * oc), (k, i, oc, gc)
+        if k <= 5:   # the first object (spawned at frame 3) during its first frames: its ICP is weakly constrained (a ~3k-surfel
+            for i in range(1, len(r["o_pose"])):   # box), so the two executions drift apart by centimetres within a few frames
+                d = np.abs(r["o_pose"][i] - r["g_pose"][i]).max()
+                assert d < 1e-2, (k, i, d)
