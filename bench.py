@@ -98,22 +98,27 @@ def main():
     d_depth = [torch.from_numpy(f[1]).to(dev) for f in frames]
     mf = MaskFusion(W, H, FX, FY, CX, CY, icpThresh=100.0, so3=False, device=local_rank, enableMultipleModels=False,
                     numGSurfels=9437184)
-    # per-step inputs: rank 0 owns the stream; with N > 1 it broadcasts rgb+depth (2.15 MB) to the other ranks
-    buf_rgb = torch.empty_like(d_rgb[0])
-    buf_depth = torch.empty_like(d_depth[0])
-    order = pingpong(args.frames, args.warmup + args.steps)
+    # Every rank owns one model.  Rank 0 owns the input stream and publishes frame k to all ranks (RCCL broadcast over xGMI
+    # when N > 1); each rank then enqueues processFrame on the library's stream, which is also torch's current stream here so
+    # that the collectives and the kernels are ordered by the stream (no host synchronisation inside the timed region); the
+    # per-model state record is gathered to rank 0 every step.
+    from maskfusion_amd import dist as mfd
+    order = pingpong(args.frames, args.warmup + args.steps + 128)
+    ext = torch.cuda.ExternalStream(mf.stream(), device=dev)
+    cursor = [0]
 
-    def step(i):
-        k = order[i]
+    def get_frame(_i):
+        k = order[cursor[0]]
+        return d_rgb[k], d_depth[k]
+
+    def model_step(rgb, depth, stats):
+        mf.processFrameDevice(rgb.data_ptr(), depth.data_ptr())
         if world > 1:
-            if rank == 0:
-                buf_rgb.copy_(d_rgb[k]); buf_depth.copy_(d_depth[k])
-            dist.broadcast(buf_rgb, 0); dist.broadcast(buf_depth, 0)
-            torch.cuda.current_stream().synchronize()  # the library runs on its own stream
-            mf.processFrameDevice(buf_rgb.data_ptr(), buf_depth.data_ptr())
-            mf.sync()
-        else:
-            mf.processFrameDevice(d_rgb[k].data_ptr(), d_depth[k].data_ptr())
+            mf.modelStateDevice(0, stats.data_ptr())   # 64 B record for the gather; single GPU reads the pinned mirror
+        cursor[0] += 1
+
+    def run(n):
+        return mfd.run_steps(get_frame, model_step, n, H, W, dev, stream_ctx=torch.cuda.stream(ext))
 
     def barrier():
         mf.sync()
@@ -121,23 +126,18 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for i in range(args.warmup):
-        step(i)
+    run(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        step(i)
+    gathered = run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = mfd.max_over_ranks(dt, dev)
     fps = world * args.steps / dt
 
     # sanity: the tracked pose must still follow the synthetic ground truth (a fast wrong answer is worthless)
     pose = mf.getCurrPose()
-    gt = st.gt_pose(order[args.warmup + args.steps - 1])
+    gt = st.gt_pose(order[cursor[0] - 1])
     drift = float(np.linalg.norm(pose[:3, 3] - gt[:3, 3]))
     count = mf.getBackgroundModel().lastCount()
 
@@ -147,8 +147,10 @@ def main():
         mf.enableTimings(True)
         acc = {}
         n = min(args.steps, 100)
-        for i in range(args.warmup, args.warmup + n):
-            step(i)
+        for i in range(n):
+            k = order[cursor[0]]
+            cursor[0] += 1
+            mf.processFrameDevice(d_rgb[k].data_ptr(), d_depth[k].data_ptr())
             for kx, v in mf.timings().items():
                 acc[kx] = acc.get(kx, 0.0) + v
         mf.enableTimings(False)

@@ -95,6 +95,10 @@ int mf_get_tick(mf_ctx* ctx, int32_t* tick);
 int mf_num_models(mf_ctx* ctx, int32_t* n);
 int mf_get_pose(mf_ctx* ctx, int32_t model, float* out_pose16);
 int mf_get_surfel_count(mf_ctx* ctx, int32_t model, uint32_t* count);
+/* Asynchronous device-side copy of a model's state into a caller-owned DEVICE buffer of 16 floats
+ * {R row-major (9), t (3), lastICPError, lastICPCount, surfel count, alive}: what the multi-GPU gather ships per rank
+ * (the reference logs the same per model, Core/MaskFusion.cpp:580-602) without a host round trip. */
+int mf_model_state_dev(mf_ctx* ctx, int32_t model, float* d_out16);
 /* RGBDOdometry::lastICPError / lastICPCount (Core/Utils/RGBDOdometry.h) of `model` */
 int mf_get_icp_stats(mf_ctx* ctx, int32_t model, float* last_error, float* last_count);
 /* Model::downloadMap (Core/Model/Model.h:206, Model.cpp:943-974): out has room for max_count*12 floats */

@@ -131,6 +131,10 @@ class MaskFusion:
         """Inputs already resident in HBM (raw device pointers, e.g. torch tensor.data_ptr()); asynchronous."""
         self._chk(self._L.mf_process_frame_dev(self._h, d_rgb, d_depth, d_mask or None, timestamp, weightMultiplier))
 
+    def modelStateDevice(self, model: int, d_out16: int):
+        """Enqueue a copy of {R, t, ICP error, inliers, surfels, alive} of `model` into a 16-float device buffer."""
+        self._chk(self._L.mf_model_state_dev(self._h, model, d_out16))
+
     def sync(self):
         self._chk(self._L.mf_sync(self._h))
 

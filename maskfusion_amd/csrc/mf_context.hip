@@ -562,6 +562,12 @@ extern "C" int mf_model_info(mf_ctx* c, int32_t model, mf_model_info_t* out) {
     out->is_static = m->isStatic ? 1 : 0; out->age = m->age;
     return MF_OK;
 }
+extern "C" int mf_model_state_dev(mf_ctx* c, int32_t model, float* d_out16) {
+    ModelState* m = model_at(c, model);
+    if (!m || !d_out16) return MF_EINVAL;
+    launch_model_state(m->d_pose, m->d_frame, d_out16, c->stream);
+    return check_launch(c);
+}
 extern "C" int mf_get_icp_stats(mf_ctx* c, int32_t model, float* e, float* n) {
     ModelState* m = model_at(c, model);
     if (!m || !e || !n) return MF_EINVAL;

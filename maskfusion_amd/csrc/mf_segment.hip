@@ -211,4 +211,15 @@ void launch_static_pose(PoseDev* obj, const PoseDev* bg, PoseDev* host_mirror, h
     hipLaunchKernelGGL(k_static_pose, dim3(1), dim3(64), 0, s, obj, bg, host_mirror);
 }
 
+// 16-float per-model record for the multi-GPU gather: R(9) t(3) lastICPError lastICPCount surfels alive
+__global__ void k_model_state(const PoseDev* pose, const FrameDev* frame, float* out16) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int k = 0; k < 9; ++k) out16[k] = pose->R[k];
+    for (int k = 0; k < 3; ++k) out16[9 + k] = pose->t[k];
+    out16[12] = pose->lastICPError; out16[13] = pose->lastICPCount; out16[14] = (float)frame->count; out16[15] = (float)pose->alive;
+}
+void launch_model_state(const PoseDev* pose, const FrameDev* frame, float* out16, hipStream_t s) {
+    hipLaunchKernelGGL(k_model_state, dim3(1), dim3(64), 0, s, pose, frame, out16);
+}
+
 }  // namespace mf

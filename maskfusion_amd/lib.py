@@ -49,6 +49,7 @@ SYMBOLS = {
     "mf_num_models": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "mf_get_pose": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "mf_get_surfel_count": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint32)]),
+    "mf_model_state_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "mf_get_icp_stats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mf_download_map": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "mf_get_last_fillin": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
