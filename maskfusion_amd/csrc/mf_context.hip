@@ -283,7 +283,6 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
     hipStream_t s = c->stream;
     launch_model_pyramid(m.d_predV, m.d_predN, m.allowFillIn ? fillDepth : nullptr, m.d_frame, m.d_pose, nullptr, c->d_vmap_g,
                          c->d_nmap_g, W, H, c->K, s);
-    launch_icp_begin(m.d_pose, &c->d_gn[0], s);
     const int iters[3] = {g.fast_odom ? 3 : 10, g.pyramid ? 5 : 0, g.pyramid ? 4 : 0};  // RGBDOdometry.cpp:327-329
     int k = 0, nb_prev = 0;
     for (int lvl = 2; lvl >= 0; --lvl) {
@@ -300,6 +299,7 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
             l.state_in = &c->d_gn[k & 1]; l.state_out = &c->d_gn[(k + 1) & 1];
             l.log_out = (k > 0 && m.id == 0) ? c->d_icp_log + 32 * (k - 1) : nullptr;
             l.prof_out = (c->icp_prof_on && m.id == 0) ? c->d_icp_prof + 8 * k : nullptr;
+            l.pose_in = (k == 0) ? m.d_pose : nullptr;
             launch_icp_iteration(l, s);
             nb_prev = icp_grid_blocks(l.W, l.H);
             ++k;

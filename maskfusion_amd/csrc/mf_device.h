@@ -49,6 +49,12 @@ __device__ __forceinline__ int lane_rank(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), lo);
 }
 
+// z-buffer update: one 64-bit atomicMin.  (Measured: pre-testing with a relaxed read to skip losing fragments made the
+// scatter passes 5-15 % SLOWER -- the atomics are not what bounds them.)
+__device__ __forceinline__ void zmin_key(unsigned long long* addr, unsigned long long key) {
+    atomicMin(addr, key);
+}
+
 // ---- surfel / shader helpers (Core/Shaders/surfels.glsl, color_encoding.glsl, geometry.glsl) ----
 __device__ __forceinline__ float surfel_radius(float depth, float norm_z, Intr k) {  // surfels.glsl:19-34
     const float camz = 1.0f / k.fx, camw = 1.0f / k.fy;
@@ -99,6 +105,22 @@ __device__ __forceinline__ float3 get_normal_forward(const float* depth, int W, 
 }
 
 // ---- pose math shared by the odometry and the object-model kernels ----
+// fp64 reciprocal / square root from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~2^-26) plus Newton steps: ~8 instructions
+// instead of the ~40 of an IEEE division; last-ulp differences are irrelevant for a Gauss-Newton step.
+__device__ __forceinline__ double rcp_d(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * (2.0 - x * r);
+    r = r * (2.0 - x * r);
+    return r;
+}
+__device__ __forceinline__ double sqrt_d(double x) {  // x > 0
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * (1.5 - 0.5 * x * r * r);
+    r = r * (1.5 - 0.5 * x * r * r);
+    double t = x * r;
+    return t + 0.5 * r * (x - t * t);
+}
+
 __device__ inline void m33_inverse_f(const float* m, float* inv) {  // cofactor inverse (Eigen fixed-size stand-in)
     const float c00 = m[4] * m[8] - m[5] * m[7];
     const float c01 = m[5] * m[6] - m[3] * m[8];
@@ -122,14 +144,21 @@ __device__ inline void rodrigues2_d(const float* Rin, double* r) {
         const double cof[9] = {c00, c01, c02,
                                R[2] * R[7] - R[1] * R[8], R[0] * R[8] - R[2] * R[6], R[1] * R[6] - R[0] * R[7],
                                R[1] * R[5] - R[2] * R[4], R[2] * R[3] - R[0] * R[5], R[0] * R[4] - R[1] * R[3]};
-        for (int k = 0; k < 9; ++k) Rn[k] = 0.5 * (R[k] + cof[k] / det);
+        const double idet = rcp_d(det);
+        for (int k = 0; k < 9; ++k) Rn[k] = 0.5 * (R[k] + cof[k] * idet);
         for (int k = 0; k < 9; ++k) R[k] = Rn[k];
     }
     double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
-    const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    const double s2 = (rx * rx + ry * ry + rz * rz) * 0.25;
+    const double s = s2 > 0.0 ? sqrt_d(s2) : 0.0;
     double cth = (R[0] + R[4] + R[8] - 1) * 0.5;
     cth = cth > 1. ? 1. : cth < -1. ? -1. : cth;
-    double theta = acos(cth);
+    // asin series for the usual small inter-frame rotation (error < 1e-15 below 0.1 rad); libm acos otherwise
+    double theta;
+    if (s < 0.1 && cth > 0) {
+        const double q = s * s;
+        theta = s * (1.0 + q * (1.0 / 6 + q * (3.0 / 40 + q * (15.0 / 336 + q * (105.0 / 3456 + q * (945.0 / 42240 + q * (10395.0 / 599040)))))));
+    } else theta = acos(cth);
     if (s < 1e-5) {
         if (cth > 0) rx = ry = rz = 0;
         else {
@@ -144,7 +173,7 @@ __device__ inline void rodrigues2_d(const float* Rin, double* r) {
             rx *= theta; ry *= theta; rz *= theta;
         }
     } else {
-        const double vth = 1 / (2 * s) * theta;
+        const double vth = rcp_d(2 * s) * theta;
         rx *= vth; ry *= vth; rz *= vth;
     }
     r[0] = rx; r[1] = ry; r[2] = rz;

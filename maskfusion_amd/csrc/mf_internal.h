@@ -46,7 +46,8 @@ struct GNState {
 struct FrameDev {
     int tick;                  // MaskFusion::tick
     int count;                 // Model::count (live surfels)
-    int countNext;             // count produced by the clean pass, committed at the launch boundary
+    int countNext;             // snapshot of `count` taken by clean pass 1 and read by pass 2, whose last workgroup then
+                               // rewrites `count` (no workgroup of pass 2 reads `count`, so no intra-launch ordering is assumed)
     int cover;                 // predicted-colour coverage count (requiresFillIn)
     int useFillIn;             // decision taken for the current tracking step
     int pad[3];
@@ -79,6 +80,7 @@ struct IcpLaunch {
     const GNState* state_in; GNState* state_out;
     float* log_out;                              // optional [32] floats of the reduced system solved in this launch
     unsigned long long* prof_out = nullptr;      // optional [8] shader-clock stamps (workgroup 0)
+    const PoseDev* pose_in = nullptr;            // first launch only: seed the Gauss-Newton state from this pose
 };
 int icp_grid_blocks(int W, int H);
 void launch_icp_iteration(const IcpLaunch& a, hipStream_t s);

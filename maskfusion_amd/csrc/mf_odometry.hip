@@ -21,22 +21,6 @@ namespace mf {
 // ------------------------------------------------------------------------------------------------
 // small fp64 / fp32 linear algebra for the per-iteration solve (single thread)
 // ------------------------------------------------------------------------------------------------
-// fp64 reciprocal / square root from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~2^-26) plus Newton steps: ~8 instructions
-// instead of the ~40 of an IEEE division; last-ulp differences are irrelevant for a Gauss-Newton step.
-__device__ __forceinline__ double rcp_d(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = r * (2.0 - x * r);
-    r = r * (2.0 - x * r);
-    return r;
-}
-__device__ __forceinline__ double sqrt_d(double x) {  // x > 0
-    double r = __builtin_amdgcn_rsq(x);
-    r = r * (1.5 - 0.5 * x * r * r);
-    r = r * (1.5 - 0.5 * x * r * r);
-    double t = x * r;
-    return t + 0.5 * r * (x - t * t);
-}
-
 // LDL^T in double, fully unrolled so that the 6x6 system lives in registers (a dynamically indexed local array would be
 // spilled to scratch memory and turn this ~200-flop solve into ~40 us of dependent scratch round trips).  Stands in for
 // Eigen::LDLT (RGBDOdometry.cpp:451-459); Eigen pivots on the diagonal, which for these symmetric positive definite
@@ -336,6 +320,7 @@ struct IcpKArgs {
     const GNState* st_in; GNState* st_out;
     float* log_out;
     unsigned long long* prof_out;  // optional: 8 shader-clock stamps of workgroup 0 / thread 0
+    const PoseDev* pose_in;        // first launch of a tracking step: seed the state from the model pose
 };
 
 // Correspondence search for one pixel, split in two so that the gathers of all four pixels of a thread are in flight
@@ -376,11 +361,25 @@ __device__ __forceinline__ void icp_accumulate(const IcpCorr& c, float3 vprev_g,
     acc[28] += 1.0f;
 }
 
+__device__ __forceinline__ void seed_state(const PoseDev& pose, GNState& s) {
+    for (int k = 0; k < 16; ++k) s.resultRt[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    for (int k = 0; k < 9; ++k) { s.Rprev[k] = pose.R[k]; s.Rcurr[k] = pose.R[k]; s.trR[k] = (k % 4 == 0) ? 1.f : 0.f; }
+    for (int k = 0; k < 3; ++k) { s.tprev[k] = pose.t[k]; s.tcurr[k] = pose.t[k]; s.trt[k] = 0.f; }
+    m33_inverse_f(s.Rprev, s.Rprev_inv);  // RGBDOdometry.cpp:332
+    s.lastICPError = 0.f; s.lastICPCount = 0.f; s.valid = 0; s.pad = 0;
+}
+
 // 1024 threads = 16 wavefronts per workgroup, ONE pixel per thread: the per-pixel chain (project -> gather -> gate ->
 // 29 products) is ~250 dependent VALU instructions, so what a launch costs is how well that latency is hidden.  Four
 // wavefronts per SIMD hide it; one wavefront per SIMD with 4 pixels per thread (the 16 B-per-lane variant) measured
 // 2.5x slower for the same bytes.  A wavefront still touches one contiguous 256 B line per streamed plane.
 constexpr int kIcpThreads = 1024;
+constexpr int kIcpMaxBlocks = 240;  // <= one 1024-thread workgroup per CU (256 CUs) with a little slack for busy CUs
+
+__host__ __device__ inline int icp_chunk(int P, int nblocks) {
+    const int c = (P + nblocks - 1) / nblocks;
+    return ((c + 63) / 64) * 64;
+}
 
 __global__ __launch_bounds__(kIcpThreads) void k_icp_iter(const IcpKArgs a) {
     __shared__ double s_seg[32 * 32];
@@ -392,19 +391,33 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp_iter(const IcpKArgs a) {
     const int tid = threadIdx.x;
     // stage the Gauss-Newton state through LDS with one coalesced load (thread 0 would otherwise chase ~80 dependent
     // scalar loads after the solve)
-    if (tid < (int)(sizeof(GNState) / 4)) reinterpret_cast<uint32_t*>(&s_st)[tid] = reinterpret_cast<const uint32_t*>(a.st_in)[tid];
+    if (a.pose_in == nullptr) {
+        if (tid < (int)(sizeof(GNState) / 4)) reinterpret_cast<uint32_t*>(&s_st)[tid] = reinterpret_cast<const uint32_t*>(a.st_in)[tid];
+    } else if (tid == 0) {
+        seed_state(*a.pose_in, s_st);   // RGBDOdometry.cpp:239-243,332-336: Rprev = Rcurr = pose, resultRt = I
+    }
     const bool prof = a.prof_out != nullptr && blockIdx.x == 0 && tid == 0;
     unsigned long long stamp[8];
     if (prof) stamp[0] = __builtin_amdgcn_s_memtime();
     const int P = a.W * a.H;
-    const int i = blockIdx.x * kIcpThreads + tid;  // pixel
-    const bool active = i < P;
+    // A workgroup owns a contiguous chunk of <= 2 * kIcpThreads pixels (icp_grid_blocks keeps the grid <= one workgroup
+    // per CU so that a launch is ONE round of workgroups: 300 workgroups of 1024 px on 256 CUs ran as two rounds and
+    // doubled the level-0 launch time).  Thread t handles pixel beg + t and, if the chunk is longer, beg + 1024 + t.
+    const int chunk = icp_chunk(P, gridDim.x);
+    const int beg = blockIdx.x * chunk, end = min(P, beg + chunk);
+    const int i0 = beg + tid, i1 = beg + kIcpThreads + tid;
+    const bool act0 = i0 < end, act1 = i1 < end;
 
     // (1) issue the pose-independent streamed loads first so their latency overlaps the solve below
-    float vx = 0.f, vy = 0.f, vz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
-    if (active) {
-        vx = a.vc[i]; vy = a.vc[P + i]; vz = a.vc[2 * P + i];
-        nx = a.nc[i]; ny = a.nc[P + i]; nz = a.nc[2 * P + i];
+    float vx0 = 0.f, vy0 = 0.f, vz0 = 0.f, nx0 = 0.f, ny0 = 0.f, nz0 = 0.f;
+    float vx1 = 0.f, vy1 = 0.f, vz1 = 0.f, nx1 = 0.f, ny1 = 0.f, nz1 = 0.f;
+    if (act0) {
+        vx0 = a.vc[i0]; vy0 = a.vc[P + i0]; vz0 = a.vc[2 * P + i0];
+        nx0 = a.nc[i0]; ny0 = a.nc[P + i0]; nz0 = a.nc[2 * P + i0];
+    }
+    if (act1) {
+        vx1 = a.vc[i1]; vy1 = a.vc[P + i1]; vz1 = a.vc[2 * P + i1];
+        nx1 = a.nc[i1]; ny1 = a.nc[P + i1]; nz1 = a.nc[2 * P + i1];
     }
 
     // (2) prologue: finish the previous iteration (reduce -> solve -> pose), identically in every workgroup
@@ -449,8 +462,15 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp_iter(const IcpKArgs a) {
     float acc[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) acc[k] = 0.f;
-    if (active) {
-        const IcpCorr c = icp_project(vx, vy, vz, nx, ny, nz, Rc, tc, Rpi, tp, a);
+    if (act0) {
+        const IcpCorr c = icp_project(vx0, vy0, vz0, nx0, ny0, nz0, Rc, tc, Rpi, tp, a);
+        const int j = c.j;
+        const float3 pv = f3(a.vp[j], a.vp[P + j], a.vp[2 * P + j]);
+        const float3 pn = f3(a.np[j], a.np[P + j], a.np[2 * P + j]);
+        icp_accumulate(c, pv, pn, Rpi, tp, a, acc);
+    }
+    if (act1) {
+        const IcpCorr c = icp_project(vx1, vy1, vz1, nx1, ny1, nz1, Rc, tc, Rpi, tp, a);
         const int j = c.j;
         const float3 pv = f3(a.vp[j], a.vp[P + j], a.vp[2 * P + j]);
         const float3 pn = f3(a.np[j], a.np[P + j], a.np[2 * P + j]);
@@ -479,14 +499,22 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp_iter(const IcpKArgs a) {
     }
 }
 
-int icp_grid_blocks(int W, int H) { return (W * H + kIcpThreads - 1) / kIcpThreads; }
+int icp_grid_blocks(int W, int H) {
+    const int P = W * H;
+    int nb = (P + kIcpThreads - 1) / kIcpThreads;
+    if (nb > kIcpMaxBlocks) {
+        nb = kIcpMaxBlocks;
+        while (icp_chunk(P, nb) > 2 * kIcpThreads) ++nb;  // larger images: more than one round, still <= 2 px per thread
+    }
+    return nb;
+}
 
 void launch_icp_iteration(const IcpLaunch& l, hipStream_t s) {
     IcpKArgs a;
     a.vc = l.vmap_curr; a.nc = l.nmap_curr; a.vp = l.vmap_prev; a.np = l.nmap_prev;
     a.W = l.W; a.H = l.H; a.k = l.k; a.distThres = l.distThres; a.angleThres = l.angleThres;
     a.partials_in = l.partials_in; a.nb_in = l.nblocks_in; a.partials_out = l.partials_out;
-    a.st_in = l.state_in; a.st_out = l.state_out; a.log_out = l.log_out; a.prof_out = l.prof_out;
+    a.st_in = l.state_in; a.st_out = l.state_out; a.log_out = l.log_out; a.prof_out = l.prof_out; a.pose_in = l.pose_in;
     hipLaunchKernelGGL(k_icp_iter, dim3(icp_grid_blocks(l.W, l.H)), dim3(kIcpThreads), 0, s, a);
 }
 
@@ -496,11 +524,7 @@ void launch_icp_iteration(const IcpLaunch& l, hipStream_t s) {
 __global__ void k_icp_begin(const PoseDev* __restrict__ pose, GNState* __restrict__ st) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     GNState s;
-    for (int k = 0; k < 16; ++k) s.resultRt[k] = (k % 5 == 0) ? 1.0 : 0.0;
-    for (int k = 0; k < 9; ++k) { s.Rprev[k] = pose->R[k]; s.Rcurr[k] = pose->R[k]; s.trR[k] = (k % 4 == 0) ? 1.f : 0.f; }
-    for (int k = 0; k < 3; ++k) { s.tprev[k] = pose->t[k]; s.tcurr[k] = pose->t[k]; s.trt[k] = 0.f; }
-    m33_inverse_f(s.Rprev, s.Rprev_inv);  // RGBDOdometry.cpp:332
-    s.lastICPError = 0.f; s.lastICPCount = 0.f; s.valid = 0; s.pad = 0;
+    seed_state(*pose, s);
     *st = s;
 }
 

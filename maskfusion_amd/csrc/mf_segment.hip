@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_global_scatter(Surfels src, const Frame
                 const float3 diff = cp - h;
                 if (!(dot3(diff, diff) <= sqrRad)) continue;
                 if (!(cp.z > 0.f)) continue;
-                atomicMin(&keys[py * W + px], ((unsigned long long)__float_as_uint(cp.z) << 32) | payload);
+                zmin_key(&keys[py * W + px], ((unsigned long long)__float_as_uint(cp.z) << 32) | payload);
             }
     }
 }

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_index_scatter(Surfels src, const FrameD
         if (!(u >= 0.f && u < (float)W && v >= 0.f && v < (float)H)) continue;
         const int p = (int)floorf(v) * W + (int)floorf(u);
         const unsigned long long key = ((unsigned long long)__float_as_uint(h.z) << 32) | (unsigned)i;
-        atomicMin(&keys[p], key);
+        zmin_key(&keys[p], key);
     }
 }
 
@@ -440,13 +440,16 @@ __global__ __launch_bounds__(256) void k_clean_flags(const CleanArgs a) {
         kept += keep ? 1 : 0;
     }
     const int tot = block_sum_i(kept, s_w);
-    if (threadIdx.x == 0) a.block_counts[blockIdx.x] = tot;
+    if (threadIdx.x == 0) {
+        a.block_counts[blockIdx.x] = tot;
+        if (blockIdx.x == 0) a.frame->countNext = count;  // snapshot for pass 2 (see FrameDev)
+    }
 }
 
 __global__ __launch_bounds__(256) void k_clean_compact(const CleanArgs a) {
     __shared__ int s_w[4];
     int base = block_base(a.block_counts, s_w);
-    const int count = a.frame->count;
+    const int count = a.frame->countNext;
     const int total = count + cand_count(a.W, a.H, a.frame->tick);
     const float time = (float)a.frame->tick;
     const int chunk = chunk_size(total);
@@ -473,16 +476,10 @@ __global__ __launch_bounds__(256) void k_clean_compact(const CleanArgs a) {
         base += tot;
         __syncthreads();
     }
-    // frame->count is read by every workgroup of this launch, so the new count is parked in countNext and committed by
-    // a one-thread kernel at the launch boundary (no intra-launch ordering assumption).
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-        a.frame->countNext = min(base, a.dst.cap);
+        a.frame->count = min(base, a.dst.cap);
         if (a.host_count) *a.host_count = min(base, a.dst.cap);
     }
-}
-
-__global__ void k_commit_count(FrameDev* frame) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) frame->count = frame->countNext;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -538,7 +535,7 @@ __global__ __launch_bounds__(256) void k_splat_scatter(Surfels src, const FrameD
                 if (!(dot3(diff, diff) <= sqrRad)) continue;
                 if (!(cp.z > 0.f)) continue;
                 const unsigned long long key = ((unsigned long long)__float_as_uint(cp.z) << 32) | (unsigned)i;
-                atomicMin(&keys[py * W + px], key);
+                zmin_key(&keys[py * W + px], key);
             }
         }
     }
@@ -616,7 +613,6 @@ void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose
     a.flags = flags; a.newconf = newconf; a.block_counts = block_counts; a.host_count = host_count_mirror;
     hipLaunchKernelGGL(k_clean_flags, dim3(kCompactBlocks), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_clean_compact, dim3(kCompactBlocks), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_commit_count, dim3(1), dim3(64), 0, s, frame);
 }
 
 }  // namespace mf

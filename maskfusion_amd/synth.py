@@ -58,7 +58,7 @@ class Box:
 class Scene:
     """Room [-2.5,2.5] x [-1.5,1.2] x [-1.0, zback] seen from around the origin looking down +z (y down)."""
 
-    def __init__(self, n_objects: int = 0, seed: int = 1234, zback: float = 2.8):
+    def __init__(self, n_objects: int = 0, seed: int = 1234, zback: float = 2.8, object_motion: float = 1.0):
         rng = np.random.RandomState(seed)
         self.zback = zback
         self.planes = [  # (axis, value, base colour)
@@ -82,8 +82,8 @@ class Scene:
             c = np.array([1.1 * np.cos(ang) * 0.9, 0.15 + 0.45 * np.sin(ang), 1.45 + 0.25 * np.cos(2 * ang)])
             h = rng.uniform(0.10, 0.18, 3)
             self.boxes.append(Box(c, h, rng.uniform(60, 240, 3), instance=k + 1,
-                                  vel=rng.uniform(-0.12, 0.12, 3), freq=rng.uniform(0.6, 1.4),
-                                  spin=rng.uniform(0.1, 0.4)))
+                                  vel=rng.uniform(-0.12, 0.12, 3) * object_motion, freq=rng.uniform(0.6, 1.4),
+                                  spin=rng.uniform(0.1, 0.4) * object_motion))
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
@@ -169,9 +169,10 @@ class Stream:
     noise: bool = False
     speed: float = 1.0
     max_depth: float = 0.0
+    object_motion: float = 1.0   # 0 = the instance-masked boxes stand still
 
     def __post_init__(self):
-        self.scene = Scene(self.n_objects, self.seed)
+        self.scene = Scene(self.n_objects, self.seed, object_motion=self.object_motion)
 
     def gt_pose(self, frame: int) -> np.ndarray:
         return camera_pose(frame, self.speed)

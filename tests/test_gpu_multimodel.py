@@ -46,16 +46,16 @@ def test_geometric_edges_kernel(hip, oracle):
             assert flips.mean() < 1e-4
 
 
-@pytest.fixture(scope="module")
-def mm_run(hip, oracle):
-    from maskfusion_amd import MaskFusion
+def _run_pair(oracle, n_frames, track_all, object_motion):
+    from maskfusion_amd import MaskFusion, synth
     from oracle import mfo_mm
-    st, frames = _stream(14)
+    st = synth.Stream(W=640, H=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, n_objects=2, noise=True, object_motion=object_motion)
+    frames = [st.frame(k) for k in range(n_frames)]
     cls = [0, 41, 42]
     o = mfo_mm.OracleMM(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpWeight=100.0, capacity=1 << 20, capacityObject=1 << 18,
-                        modelSpawnOffset=3, seg=SEG)
+                        modelSpawnOffset=3, trackAllModels=int(track_all), seg=SEG)
     m = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=100.0, so3=False, numGSurfels=1 << 20, numOSurfels=1 << 18,
-                   enableMultipleModels=True, modelSpawnOffset=3)
+                   enableMultipleModels=True, modelSpawnOffset=3, trackAllModels=track_all)
     for k, v in (("mfThreshold", SEG["threshold"]), ("mfWeightDistance", SEG["weightDistance"]),
                  ("mfWeightConvexity", SEG["weightConvexity"]), ("mfMorphEdgeIterations", 0), ("mfMorphMaskIterations", 0),
                  ("newModelMinRelativeSize", SEG["minRelSizeNew"])):
@@ -74,41 +74,53 @@ def mm_run(hip, oracle):
     return rec
 
 
-# Object models are a few thousand surfels on small moving boxes: their ICP is a chaotic system, so discrete decisions
-# (spawn / drop) agree with the oracle only for a bounded horizon.  The strict comparisons use the first STRICT frames
-# (which cover two spawns, one drop-by-jump and one re-spawn); afterwards only the invariants are checked.
-STRICT = 11
+@pytest.fixture(scope="module")
+def mm_static(hip, oracle):
+    """Standing boxes, object models follow the camera pose (MaskFusion's shipped default: objects stay static unless someone
+    calls makeNonStatic / setTrackAllModels): no object ICP, so the whole multi-model state machine (projection,
+    edges, labels, spawn, masked fusion / clean, confidence ramp) is deterministic enough to compare frame by frame."""
+    return _run_pair(oracle, 14, False, 0.0)
 
 
-def test_models_spawn_like_the_oracle(mm_run):
-    for k, r in enumerate(mm_run):
+@pytest.fixture(scope="module")
+def mm_tracked(hip, oracle):
+    """Moving boxes with trackAllModels: object ICP on ~3k-surfel boxes is chaotic, only a short horizon is comparable."""
+    return _run_pair(oracle, 10, True, 1.0)
+
+
+def test_static_objects_spawn_like_the_oracle(mm_static):
+    for k, r in enumerate(mm_static):
         print(k, "models oracle/hip", r["o_ids"], r["g_ids"], "counts", r["o_cnt"], r["g_cnt"])
-        if k < STRICT:
-            assert r["o_ids"] == r["g_ids"], f"frame {k}"
-        assert r["g_ids"][0] == 0 and len(set(r["g_ids"])) == len(r["g_ids"])
-    assert max(r["o_n"] for r in mm_run[:STRICT]) >= 3, "the scenario must spawn object models"
+        assert r["o_ids"] == r["g_ids"], f"frame {k}"
+    assert max(r["o_n"] for r in mm_static) >= 3, "the scenario must spawn both object models"
 
 
-def test_segmentation_and_projection_agree(mm_run):
-    for k, r in enumerate(mm_run[:STRICT]):
+def test_static_objects_segmentation_projection_counts(mm_static):
+    for k, r in enumerate(mm_static):
         seg_diff = (r["o_seg"] != r["g_seg"]).mean()
         proj_diff = (r["o_proj"] != r["g_proj"]).mean()
         print(k, "seg pixel diff", seg_diff, "projected-id diff", proj_diff)
-        assert seg_diff < 5e-3 and proj_diff < 1e-2   # a one-pixel shift of an object's silhouette is ~0.5 % of the image
-    # and the label image does isolate the moving boxes (semantic check against the synthetic ground truth)
-    last = mm_run[-1]
-    labelled = last["g_seg"] > 0
-    assert (last["gt_mask"][labelled & (last["g_seg"] != 255)] > 0).mean() > 0.9
-
-
-def test_poses_and_counts_track_oracle(mm_run):
-    for k, r in enumerate(mm_run[:STRICT]):
-        d_bg = np.abs(r["o_pose"][0] - r["g_pose"][0]).max()
-        assert d_bg < 2e-4, f"frame {k}: background pose differs by {d_bg}"
+        assert seg_diff < 2e-3 and proj_diff < 2e-3
+        for i in range(len(r["o_pose"])):
+            assert np.abs(r["o_pose"][i] - r["g_pose"][i]).max() < 2e-4, (k, i)
         for i in range(len(r["o_cnt"])):
             oc, gc = r["o_cnt"][i], r["g_cnt"][i]
-            assert abs(oc - gc) <= max(20, 0.02 * oc), (k, i, oc, gc)
-        if k <= 5:   # the first object (spawned at frame 3) during its first frames: its ICP is weakly constrained (a ~3k-surfel
-            for i in range(1, len(r["o_pose"])):   # box), so the two executions drift apart by centimetres within a few frames
-                d = np.abs(r["o_pose"][i] - r["g_pose"][i]).max()
-                assert d < 1e-2, (k, i, d)
+            assert abs(oc - gc) <= max(20, 0.01 * oc), (k, i, oc, gc)
+    # and the label image does isolate the boxes (semantic check against the synthetic ground truth)
+    last = mm_static[-1]
+    labelled = (last["g_seg"] > 0) & (last["g_seg"] != 255)
+    assert labelled.sum() > 1000 and (last["gt_mask"][labelled] > 0).mean() > 0.9
+
+
+def test_tracked_objects_short_horizon(mm_tracked):
+    strict = 6   # first object spawns at frame 3; afterwards the two executions of its ICP drift apart
+    for k, r in enumerate(mm_tracked):
+        print(k, "models oracle/hip", r["o_ids"], r["g_ids"], "counts", r["o_cnt"], r["g_cnt"])
+        assert r["g_ids"][0] == 0 and len(set(r["g_ids"])) == len(r["g_ids"])
+        assert np.abs(r["o_pose"][0] - r["g_pose"][0]).max() < 2e-4, f"background pose, frame {k}"
+        if k < strict:
+            assert r["o_ids"] == r["g_ids"], f"frame {k}"
+            assert (r["o_seg"] != r["g_seg"]).mean() < 2e-3
+            for i in range(1, len(r["o_pose"])):
+                assert np.abs(r["o_pose"][i] - r["g_pose"][i]).max() < 1e-2, (k, i)
+    assert max(r["g_n"] for r in mm_tracked) >= 2
