@@ -99,12 +99,14 @@ def main():
     mf = MaskFusion(W, H, FX, FY, CX, CY, icpThresh=100.0, so3=False, device=local_rank, enableMultipleModels=False,
                     numGSurfels=9437184)
     # Every rank owns one model.  Rank 0 owns the input stream and publishes frame k to all ranks (RCCL broadcast over xGMI
-    # when N > 1); each rank then enqueues processFrame on the library's stream, which is also torch's current stream here so
-    # that the collectives and the kernels are ordered by the stream (no host synchronisation inside the timed region); the
-    # per-model state record is gathered to rank 0 every step.
+    # when N > 1) on the library's INPUT stream into a ring of 3 buffers; each rank then enqueues processFrame, whose main
+    # stream is torch's current stream for the gather of the per-model state record.  Collectives and kernels are ordered
+    # by the streams alone (no host synchronisation inside the timed region).
     from maskfusion_amd import dist as mfd
     order = pingpong(args.frames, args.warmup + args.steps + 128)
     ext = torch.cuda.ExternalStream(mf.stream(), device=dev)
+    ext_in = torch.cuda.ExternalStream(mf.inputStream(), device=dev)
+    loop_state = {}
     cursor = [0]
 
     def get_frame(_i):
@@ -118,7 +120,8 @@ def main():
         cursor[0] += 1
 
     def run(n):
-        return mfd.run_steps(get_frame, model_step, n, H, W, dev, stream_ctx=torch.cuda.stream(ext))
+        return mfd.run_steps(get_frame, model_step, n, H, W, dev, stream_ctx=lambda: torch.cuda.stream(ext),
+                             input_stream_ctx=lambda: torch.cuda.stream(ext_in), state=loop_state)
 
     def barrier():
         mf.sync()

@@ -135,6 +135,15 @@ int mf_get_param(mf_ctx* ctx, const char* key, double* value);
 int mf_get_timings(mf_ctx* ctx, float* ms /* [MF_N_TIMINGS] */);
 /* The context's HIP stream (hipStream_t), for callers that time with their own events. */
 void* mf_get_stream(mf_ctx* ctx);
+/* Stream on which rgb/depth/mask handed to mf_process_frame_dev are first read.  By default this is the main stream
+ * (mf_get_stream): producers ordered on it need no further synchronisation.  With mf_set_param("overlapPreprocessing", 1)
+ * the pose-independent preprocessing (bilateral filter, depth pyramid, vertex/normal maps) of frame k+1 runs on a second
+ * stream under the tracking/fusion of frame k; the contract for device buffers then becomes:
+ *   - their producers are complete, or ordered on the input stream, when the call is made;
+ *   - they stay unmodified until that frame has completed on the main stream (producers ordered on the input stream may
+ *     reuse a buffer three frames later -- a ring of 3 -- without further synchronisation).
+ * Query the input stream AFTER setting the parameter.  (On MI355X the overlap measured no gain; see DESIGN.md.) */
+void* mf_get_input_stream(mf_ctx* ctx);
 
 /* debug / differential-test taps: copy a device-resident intermediate of the last frame to host.
  * what: "depthF" (H*W f32), "vmap0".."vmap2", "nmap0".."nmap2" (3*h*w f32, current frame),

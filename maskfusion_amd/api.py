@@ -193,6 +193,10 @@ class MaskFusion:
     def stream(self) -> int:
         return int(self._L.mf_get_stream(self._h) or 0)
 
+    def inputStream(self) -> int:
+        """hipStream_t on which frames handed to processFrameDevice are first read (see include/maskfusion_amd.h)."""
+        return int(self._L.mf_get_input_stream(self._h) or 0)
+
     # -- differential-test taps ----------------------------------------------------------------------
     def debugRead(self, what: str) -> np.ndarray:
         W, H = self.width, self.height

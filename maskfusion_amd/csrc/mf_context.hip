@@ -47,7 +47,17 @@ struct mf_ctx {
     mf_config cfg;
     int W, H, P;
     Intr K;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // tracking + fusion (everything that depends on the pose)
+    hipStream_t stream_pre = nullptr;  // per-frame preprocessing, which depends on nothing but the frame: it runs one frame
+                                       // ahead under the latency-bound Gauss-Newton loop of the previous frame
+    hipEvent_t ev_pre_done[2] = {nullptr, nullptr};    // preprocessing of frame k finished      (pre -> main)
+    hipEvent_t ev_main_done[2] = {nullptr, nullptr};   // frame k finished tracking (so k-1 is complete)  (main -> pre)
+    long frame_no = 0;
+    int lastF = 0;
+    int overlap = 0;                   // 1: preprocessing on stream_pre, one frame ahead ("overlapPreprocessing").  Measured on
+                                       // MI355X (tools/host_rate.py, same box A/B): 473-483 us/frame either way -- the filter's
+                                       // waves delay the whole-CU Gauss-Newton / fusion workgroups (+30 us on the main chain)
+                                       // and the two cross-queue barriers cost the rest, so it is off by default.
     std::string err;
     int host_tick = 1;
     bool timings_on = false, icp_prof_on = false;
@@ -55,9 +65,9 @@ struct mf_ctx {
     // frame-level
     uint8_t* d_rgb = nullptr; float* d_depth = nullptr; uint8_t* d_mask_in = nullptr; uint8_t* d_zero_mask = nullptr;
     uint8_t* d_mask_tex = nullptr;  // textureMask: the last full segmentation (Core/MaskFusion.cpp:297)
-    float* d_depthF[2] = {nullptr, nullptr}; int curF = 0;
-    float* d_dpyr[3] = {nullptr, nullptr, nullptr};
-    float* d_vmap[3]; float* d_nmap[3];
+    float* d_depthF[3] = {nullptr, nullptr, nullptr};  // ring: frame k filters into [k % 3], fill-in reads [(k - 1) % 3]
+    float* d_dpyr[2][3] = {};                            // two sets (frame parity) of the current-frame pyramid
+    float* d_vmap[2][3] = {}; float* d_nmap[2][3] = {};
     // shared scratch
     GNState* d_gn = nullptr; float* d_partials[2] = {nullptr, nullptr};
     float* d_vmap_g[3]; float* d_nmap_g[3];
@@ -196,6 +206,11 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     auto fail = [&](int code) { mf_destroy(c); return code; };
     if (hipSetDevice(cfg->device) != hipSuccess) return fail(MF_ENODEV);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(MF_ENODEV);
+    if (hipStreamCreateWithFlags(&c->stream_pre, hipStreamNonBlocking) != hipSuccess) return fail(MF_ENODEV);
+    for (int i = 0; i < 2; ++i)
+        if (hipEventCreateWithFlags(&c->ev_pre_done[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_main_done[i], hipEventDisableTiming) != hipSuccess)
+            return fail(MF_ENODEV);
     const int W = c->W, H = c->H, P = c->P;
     const int cap_bg = surfel_capacity(cfg->num_gsurfels), cap_obj = surfel_capacity(cfg->num_osurfels);
     if (cap_bg <= 0 || cap_obj <= 0) return fail(MF_EINVAL);
@@ -207,13 +222,14 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     A(dev_alloc(c, c->allocs, &c->d_mask_in, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_zero_mask, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_mask_tex, (size_t)P));
-    A(dev_alloc(c, c->allocs, &c->d_depthF[0], (size_t)P));
-    A(dev_alloc(c, c->allocs, &c->d_depthF[1], (size_t)P));
+    for (int b = 0; b < 3; ++b) A(dev_alloc(c, c->allocs, &c->d_depthF[b], (size_t)P));
     for (int i = 0; i < 3; ++i) {
         const size_t lp = (size_t)(W >> i) * (H >> i);
-        if (i > 0) A(dev_alloc(c, c->allocs, &c->d_dpyr[i], lp));
-        A(dev_alloc(c, c->allocs, &c->d_vmap[i], lp * 3));
-        A(dev_alloc(c, c->allocs, &c->d_nmap[i], lp * 3));
+        for (int set = 0; set < 2; ++set) {
+            if (i > 0) A(dev_alloc(c, c->allocs, &c->d_dpyr[set][i], lp));
+            A(dev_alloc(c, c->allocs, &c->d_vmap[set][i], lp * 3));
+            A(dev_alloc(c, c->allocs, &c->d_nmap[set][i], lp * 3));
+        }
         A(dev_alloc(c, c->allocs, &c->d_vmap_g[i], lp * 3));
         A(dev_alloc(c, c->allocs, &c->d_nmap_g[i], lp * 3));
     }
@@ -257,20 +273,26 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
 
 extern "C" void mf_destroy(mf_ctx* c) {
     if (!c) return;
+    if (c->stream_pre) (void)hipStreamSynchronize(c->stream_pre);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->models.clear();
     for (void* p : c->allocs) (void)hipFree(p);
     for (void* p : c->host_allocs) (void)hipHostFree(p);
     for (int i = 0; i <= MF_N_TIMINGS; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 2; ++i) {
+        if (c->ev_pre_done[i]) (void)hipEventDestroy(c->ev_pre_done[i]);
+        if (c->ev_main_done[i]) (void)hipEventDestroy(c->ev_main_done[i]);
+    }
+    if (c->stream_pre) (void)hipStreamDestroy(c->stream_pre);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
 extern "C" const char* mf_last_error(const mf_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
-static void mark(mf_ctx* c, int i) {
-    if (c->timings_on) (void)hipEventRecord(c->ev[i], c->stream);
+static void mark(mf_ctx* c, int i, hipStream_t s = nullptr) {
+    if (c->timings_on) (void)hipEventRecord(c->ev[i], s ? s : c->stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -279,6 +301,8 @@ static void mark(mf_ctx* c, int i) {
 // Model::performTracking (Core/Model/Model.cpp:427-447): initICPModel (+ fill-in) then the Gauss-Newton loop
 static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, float jump_limit) {
     const mf_config& g = c->cfg;
+    float* const* cur_vmap = c->d_vmap[c->frame_no & 1];
+    float* const* cur_nmap = c->d_nmap[c->frame_no & 1];
     const int W = c->W, H = c->H;
     hipStream_t s = c->stream;
     launch_model_pyramid(m.d_predV, m.d_predN, m.allowFillIn ? fillDepth : nullptr, m.d_frame, m.d_pose, nullptr, c->d_vmap_g,
@@ -289,7 +313,7 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
         const float div = (float)(1 << lvl);
         for (int j = 0; j < iters[lvl]; ++j) {
             IcpLaunch l;
-            l.vmap_curr = c->d_vmap[lvl]; l.nmap_curr = c->d_nmap[lvl];
+            l.vmap_curr = cur_vmap[lvl]; l.nmap_curr = cur_nmap[lvl];
             l.vmap_prev = c->d_vmap_g[lvl]; l.nmap_prev = c->d_nmap_g[lvl];
             l.W = W >> lvl; l.H = H >> lvl; l.k = Intr{g.fx / div, g.fy / div, g.cx / div, g.cy / div};
             l.distThres = 0.10f; l.angleThres = sinf(20.f * 3.14159254f / 180.f);  // RGBDOdometry.h:35-36
@@ -370,29 +394,43 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
     const bool multi = g.enable_multiple_models != 0;
     // -static (enableMultipleModels == false): everything is background (MaskFusion.cpp:223-230)
     const uint8_t* mask = multi ? c->d_mask_tex : c->d_zero_mask;
-    float* depthF = c->d_depthF[c->curF];
-    float* depthF_prev = c->d_depthF[1 - c->curF];
+    const long k = c->frame_no;
+    const int set = (int)(k & 1);
+    float* depthF = c->d_depthF[k % 3];
+    float* depthF_prev = c->d_depthF[(k + 2) % 3];
     ModelState& bg = *c->models[0];
 
-    mark(c, 0);
-    launch_bilateral(d_depth, depthF, W, H, s);  // filterDepth, :217
+    // ---- preprocessing on its own stream: filterDepth (:217) + Model::generateCUDATextures (Model.cpp:350-389).
+    // It starts when frame k-1 has finished TRACKING: frame k-2 (the last user of this buffer set and of depthF[k % 3]) is
+    // then complete, and the filter overlaps the atomic-/latency-bound fusion kernels of frame k-1 rather than its
+    // Gauss-Newton launches, which need a whole CU per workgroup and stall behind resident filter waves.
+    hipStream_t sp = c->overlap ? c->stream_pre : s;
+    if (c->overlap) MF_HIP(c, hipStreamWaitEvent(sp, c->ev_main_done[set ^ 1], 0));
+    mark(c, 0, sp);
+    launch_bilateral(d_depth, depthF, W, H, sp);
+    if (c->host_tick > 1) {
+        c->d_dpyr[set][0] = depthF;
+        for (int i = 1; i < 3; ++i) launch_pyrdown_f(c->d_dpyr[set][i - 1], c->d_dpyr[set][i], W >> (i - 1), H >> (i - 1), sp);
+        for (int i = 0; i < 3; ++i) {
+            const float div = (float)(1 << i);
+            launch_vmap_nmap(c->d_dpyr[set][i], c->d_vmap[set][i], c->d_nmap[set][i], W >> i, H >> i,
+                             Intr{g.fx / div, g.fy / div, g.cx / div, g.cy / div}, g.depth_cutoff, sp);
+        }
+    }
+    mark(c, 1, sp);
+    if (c->overlap) {
+        MF_HIP(c, hipEventRecord(c->ev_pre_done[set], sp));
+        MF_HIP(c, hipStreamWaitEvent(s, c->ev_pre_done[set], 0));
+    }
+
     if (c->host_tick == 1) {
-        mark(c, 1); mark(c, 2); mark(c, 3); mark(c, 4); mark(c, 5); mark(c, 6);
+        mark(c, 2); mark(c, 3); mark(c, 4); mark(c, 5); mark(c, 6);
         // :235-238
         launch_init_surfels(d_rgb, d_depth, depthF, W, H, c->K, g.max_depth_processed, bg.d_frame, c->d_cand_rec, c->d_flags, s);
         bg.cur = 0;
         launch_compact_records(c->d_cand_rec, c->d_flags, P, bg.surf[0], bg.d_frame, c->d_block_counts, bg.h_count, s);
         mark(c, 7);
     } else {
-        // Model::generateCUDATextures (Model.cpp:350-389)
-        c->d_dpyr[0] = depthF;
-        for (int i = 1; i < 3; ++i) launch_pyrdown_f(c->d_dpyr[i - 1], c->d_dpyr[i], W >> (i - 1), H >> (i - 1), s);
-        for (int i = 0; i < 3; ++i) {
-            const float div = (float)(1 << i);
-            launch_vmap_nmap(c->d_dpyr[i], c->d_vmap[i], c->d_nmap[i], W >> i, H >> i, Intr{g.fx / div, g.fy / div, g.cx / div, g.cy / div},
-                             g.depth_cutoff, s);
-        }
-        mark(c, 1);
         mark(c, 2);
         // tracking, :247-276
         enqueue_track(c, bg, depthF_prev, 0.f);
@@ -402,6 +440,7 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
             else launch_static_pose(m.d_pose, bg.d_pose, m.h_pose, s);                  // updateStaticPose, :274
         }
         mark(c, 3);
+        if (c->overlap) MF_HIP(c, hipEventRecord(c->ev_main_done[set], s));
 
         if (multi) {
             // GlobalProjection::project(models, tick, tick, timeDelta, depthCutoff) (:289) with its fixed threshold 12
@@ -412,7 +451,7 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
             }
             launch_global_resolve(c->d_keys, c->d_proj_ids, P, s);
             // MfSegmentation::performSegmentation, device half (MfSegmentation.cpp:149-208)
-            launch_edge_map(c->d_vmap[0], c->d_nmap[0], c->d_edge, W, H, c->seg.weightDistance, c->seg.weightConvexity, s);
+            launch_edge_map(c->d_vmap[set][0], c->d_nmap[set][0], c->d_edge, W, H, c->seg.weightDistance, c->seg.weightConvexity, s);
             launch_edge_binary(c->d_edge, c->d_bin, c->d_tmp_u8, W, H, c->seg.threshold, c->seg.morphEdgeRadius,
                                c->seg.morphEdgeIterations, s);
             MF_HIP(c, hipMemcpyAsync(c->h_bin, c->d_bin, (size_t)P, hipMemcpyDeviceToHost, s));
@@ -466,7 +505,9 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
         m->age++;  // incrementAge, :600
     }
     mark(c, 8);
-    c->curF = 1 - c->curF;
+    if (c->host_tick == 1 && c->overlap) MF_HIP(c, hipEventRecord(c->ev_main_done[set], s));
+    c->lastF = (int)(k % 3);
+    c->frame_no++;
     c->host_tick++;
     return check_launch(c);
 }
@@ -491,8 +532,9 @@ extern "C" int mf_sync(mf_ctx* c) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) t[i] = ms;
         }
-        float run = 0.f;
-        if (hipEventElapsedTime(&run, c->ev[0], c->ev[8]) == hipSuccess) t[8] = run;
+        float run = 0.f;  // "Run" = the pose-dependent chain on the main stream; preprocessing overlaps the previous frame
+        if (hipEventElapsedTime(&run, c->ev[2], c->ev[8]) == hipSuccess) t[8] = run;
+        t[1] = 0.f;
         memcpy(c->last_ms, t, sizeof(t));
     }
     return MF_OK;
@@ -503,9 +545,11 @@ extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* dept
     (void)timestamp;
     if (!c || !rgb || !depth) return MF_EINVAL;
     if (in_pose16 || bootstrap) { c->err = "in_pose / bootstrap not supported yet"; return MF_ESTATE; }
-    MF_HIP(c, hipMemcpyAsync(c->d_rgb, rgb, (size_t)c->P * 3, hipMemcpyHostToDevice, c->stream));
-    MF_HIP(c, hipMemcpyAsync(c->d_depth, depth, (size_t)c->P * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    if (mask) MF_HIP(c, hipMemcpyAsync(c->d_mask_in, mask, (size_t)c->P, hipMemcpyHostToDevice, c->stream));
+    // staged on the input stream (the frame is first read there); the previous frame has completed (this call syncs)
+    hipStream_t sin = c->overlap ? c->stream_pre : c->stream;
+    MF_HIP(c, hipMemcpyAsync(c->d_rgb, rgb, (size_t)c->P * 3, hipMemcpyHostToDevice, sin));
+    MF_HIP(c, hipMemcpyAsync(c->d_depth, depth, (size_t)c->P * sizeof(float), hipMemcpyHostToDevice, sin));
+    if (mask) MF_HIP(c, hipMemcpyAsync(c->d_mask_in, mask, (size_t)c->P, hipMemcpyHostToDevice, sin));
     int rc = process_frame_impl(c, c->d_rgb, c->d_depth, mask ? c->d_mask_in : nullptr, class_ids, n_masks, weight_multiplier);
     if (rc != MF_OK) return rc;
     return mf_sync(c);
@@ -648,6 +692,12 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!c || !key) return MF_EINVAL;
     if (!strcmp(key, "timings")) { c->timings_on = value != 0; return MF_OK; }
     if (!strcmp(key, "icpProfile")) { c->icp_prof_on = value != 0; return MF_OK; }
+    if (!strcmp(key, "overlapPreprocessing")) {
+        (void)hipStreamSynchronize(c->stream_pre);
+        (void)hipStreamSynchronize(c->stream);
+        c->overlap = value != 0;
+        return MF_OK;
+    }
     if (!strcmp(key, "confidenceThreshold")) { c->cfg.conf_global = (float)value; c->models[0]->confThr = (float)value; return MF_OK; }
     for (const ParamRef& p : kParams)
         if (!strcmp(key, p.key)) {
@@ -692,6 +742,7 @@ extern "C" int mf_get_timings(mf_ctx* c, float* ms) {
     return MF_OK;
 }
 extern "C" void* mf_get_stream(mf_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" void* mf_get_input_stream(mf_ctx* c) { return c ? (void*)(c->overlap ? c->stream_pre : c->stream) : nullptr; }
 
 extern "C" int mf_debug_read(mf_ctx* c, const char* what, void* out, uint64_t out_bytes) {
     if (!c || !what || !out) return MF_EINVAL;
@@ -710,8 +761,9 @@ extern "C" int mf_debug_read(mf_ctx* c, const char* what, void* out, uint64_t ou
             }
         return false;
     };
-    if (w == "depthF") { src = c->d_depthF[1 - c->curF]; bytes = P * 4; }  // curF was flipped at the end of the frame
-    else if (lvl("vmap_g", c->d_vmap_g) || lvl("nmap_g", c->d_nmap_g) || lvl("vmap", c->d_vmap) || lvl("nmap", c->d_nmap)) {}
+    const int lastSet = (int)((c->frame_no + 1) & 1);  // buffer set of the last processed frame
+    if (w == "depthF") { src = c->d_depthF[c->lastF]; bytes = P * 4; }
+    else if (lvl("vmap_g", c->d_vmap_g) || lvl("nmap_g", c->d_nmap_g) || lvl("vmap", c->d_vmap[lastSet]) || lvl("nmap", c->d_nmap[lastSet])) {}
     else if (w == "pred_vertex") { src = bg.d_predV; bytes = P * 16; }
     else if (w == "pred_normal") { src = bg.d_predN; bytes = P * 16; }
     else if (w == "pred_image") { src = bg.d_predImage; bytes = P * 4; }

@@ -26,11 +26,14 @@ STATS_WIDTH = 16  # R(9) t(3) icpError icpCount surfels alive
 class FrameBroadcaster:
     """Owns the per-rank frame buffers and moves frame k from rank `src` to every rank."""
 
+    RING = 3  # the library may still read frame k-2 while frame k is published (include/maskfusion_amd.h, input stream)
+
     def __init__(self, height: int, width: int, device: torch.device, src: int = 0):
         self.src = src
         self.device = device
-        self.rgb = torch.empty((height, width, 3), dtype=torch.uint8, device=device)
-        self.depth = torch.empty((height, width), dtype=torch.float32, device=device)
+        self.rgbs = [torch.empty((height, width, 3), dtype=torch.uint8, device=device) for _ in range(self.RING)]
+        self.depths = [torch.empty((height, width), dtype=torch.float32, device=device) for _ in range(self.RING)]
+        self.k = 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
 
@@ -39,12 +42,14 @@ class FrameBroadcaster:
         every rank, ordered on the current stream."""
         if self.world == 1:
             return rgb, depth          # nothing to move: the model reads the caller's buffers
+        r, d = self.rgbs[self.k % self.RING], self.depths[self.k % self.RING]
+        self.k += 1
         if self.rank == self.src:
-            self.rgb.copy_(rgb, non_blocking=True)
-            self.depth.copy_(depth, non_blocking=True)
-        dist.broadcast(self.rgb, self.src)
-        dist.broadcast(self.depth, self.src)
-        return self.rgb, self.depth
+            r.copy_(rgb, non_blocking=True)
+            d.copy_(depth, non_blocking=True)
+        dist.broadcast(r, self.src)
+        dist.broadcast(d, self.src)
+        return r, d
 
 
 class StatsGatherer:
@@ -66,17 +71,25 @@ class StatsGatherer:
 
 
 def run_steps(frames: Callable[[int], tuple], model_step: Callable[[torch.Tensor, torch.Tensor, torch.Tensor], None],
-              n_steps: int, height: int, width: int, device: torch.device, stream_ctx=None, gather_every: int = 1):
-    """The loop bench.py times: for each step rank 0 publishes frame(i), every rank runs model_step(rgb, depth, stats_out),
-    stats are gathered to rank 0.  Returns the list of gathered stats (rank 0) of the LAST step, or None."""
-    bc = FrameBroadcaster(height, width, device)
-    sg = StatsGatherer(device)
-    ctx = stream_ctx if stream_ctx is not None else contextlib.nullcontext()
+              n_steps: int, height: int, width: int, device: torch.device, stream_ctx=None, input_stream_ctx=None,
+              gather_every: int = 1, state=None):
+    """The loop bench.py times: for each step rank 0 publishes frame(i) (on the library's input stream), every rank runs
+    model_step(rgb, depth, stats_out), stats are gathered to rank 0 (on the library's main stream).  `stream_ctx` /
+    `input_stream_ctx` are callables returning a context manager that makes the respective stream torch's current one.
+    Returns the list of gathered stats (rank 0) of the LAST step, or None."""
+    if state is None:
+        state = {}
+    bc = state.setdefault("bc", FrameBroadcaster(height, width, device))
+    sg = state.setdefault("sg", StatsGatherer(device))
+    null = contextlib.nullcontext
+    main_ctx = stream_ctx if stream_ctx is not None else null
+    in_ctx = input_stream_ctx if input_stream_ctx is not None else main_ctx
     last = None
-    with ctx:
-        for i in range(n_steps):
+    for i in range(n_steps):
+        with in_ctx():
             rgb, depth = frames(i) if bc.rank == bc.src else (None, None)
             r, d = bc.publish(rgb, depth)
+        with main_ctx():
             model_step(r, d, sg.mine)
             if gather_every and (i % gather_every == gather_every - 1 or i == n_steps - 1):
                 last = sg.gather()

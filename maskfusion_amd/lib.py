@@ -64,6 +64,7 @@ SYMBOLS = {
     "mf_get_param": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]),
     "mf_get_timings": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mf_get_stream": (C.c_void_p, [C.c_void_p]),
+    "mf_get_input_stream": (C.c_void_p, [C.c_void_p]),
     "mf_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]),
     "mf_k_bilateral": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "mf_k_pyrdown_f": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
