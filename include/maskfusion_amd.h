@@ -62,7 +62,8 @@ typedef struct mf_config {
     int32_t model_spawn_offset;   /* modelSpawnOffset = 20 (Core/MaskFusion.h:51) */
     int32_t track_all_models;     /* MaskFusion::trackAllModels = true (Core/MaskFusion.h:396) */
     int32_t max_models;           /* upper bound on live models (the reference: 256 ids) */
-    int32_t reserved[5];
+    int32_t rgb_only;             /* rgbOnly = 0 (Core/MaskFusion.h:169): photometric term only */
+    int32_t reserved[4];
 } mf_config;
 
 /* Fills *cfg with the reference's constructor defaults for a WxH camera. */
@@ -99,6 +100,9 @@ int mf_get_surfel_count(mf_ctx* ctx, int32_t model, uint32_t* count);
  * {R row-major (9), t (3), lastICPError, lastICPCount, surfel count, alive}: what the multi-GPU gather ships per rank
  * (the reference logs the same per model, Core/MaskFusion.cpp:580-602) without a host round trip. */
 int mf_model_state_dev(mf_ctx* ctx, int32_t model, float* d_out16);
+/* {lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count, so3 iterations, rejected by the
+ * 0.3 m rule} of the last tracking step of model i (RGBDOdometry.h:68-75, RGBDOdometry.cpp:477-481) */
+int mf_get_track_stats(mf_ctx* ctx, int32_t model, float* out8);
 /* RGBDOdometry::lastICPError / lastICPCount (Core/Utils/RGBDOdometry.h) of `model` */
 int mf_get_icp_stats(mf_ctx* ctx, int32_t model, float* last_error, float* last_count);
 /* Model::downloadMap (Core/Model/Model.h:206, Model.cpp:943-974): out has room for max_count*12 floats */
@@ -182,6 +186,29 @@ int mf_segmentation_labels(int32_t W, int32_t H, const uint8_t* binary, const fl
                            const int32_t* model_class_ids, int32_t n_models, int32_t next_model_id, int32_t allow_new,
                            const float* params11, uint8_t* ignore_map, uint8_t* full_segmentation, int32_t* has_new_label,
                            int32_t* new_class_id);
+/* imageBGRToIntensity (Core/Cuda/cudafuncs.cu:626-654); channels = 3 or 4, the first three are used as stored */
+int mf_k_intensity(const uint8_t* d_img, int32_t channels, uint8_t* d_out, int32_t n, void* stream);
+/* pyrDownUcharGauss (Core/Cuda/cudafuncs.cu:534-588) */
+int mf_k_pyrdown_u8(const uint8_t* d_src, uint8_t* d_dst, int32_t sw, int32_t sh, void* stream);
+/* computeDerivativeImages (Core/Cuda/cudafuncs.cu:658-718) */
+int mf_k_derivative_images(const uint8_t* d_src, int16_t* d_dx, int16_t* d_dy, int32_t W, int32_t H, void* stream);
+/* The SO(3) block of RGBDOdometry::getIncrementalTransformation (Core/Utils/RGBDOdometry.cpp:264-324) with so3Step
+ * (Core/Cuda/reduce.cu:999-1202) inside: level-2 images and intrinsics in, resultR (row-major double, host) and
+ * {lastSO3Error, lastSO3Count, iterations} out.  Synchronous. */
+int mf_k_so3_prealign(const uint8_t* d_last, const uint8_t* d_next, int32_t W, int32_t H, float fx, float fy, float cx,
+                      float cy, double* R9, float* stats3, void* stream);
+/* computeRgbResidual (Core/Cuda/reduce.cu:774-997).  d_corres: W*H records {int16 u0, int16 v0, float diff}
+ * (u0 < 0: none) = DataTerm without the redundant fields; count_sigma2 (host) = {count, sum diff^2 as int32}.
+ * Synchronous. */
+int mf_k_rgb_residual(float min_scale, const int16_t* d_dIdx, const int16_t* d_dIdy, const float* d_last_depth,
+                      const float* d_next_depth, const uint8_t* d_last_image, const uint8_t* d_next_image,
+                      float max_depth_delta, const float* kt3, const float* krkinv9, int32_t W, int32_t H, void* d_corres,
+                      int32_t* count_sigma2, void* stream);
+/* rgbStep (Core/Cuda/reduce.cu:529-713) with projectToPointCloud (Core/Cuda/cudafuncs.cu:722-751) evaluated on the
+ * fly from d_last_depth; out32 (host, double) = {27 upper-tri products, row6^2, inliers, pad}.  Synchronous. */
+int mf_k_rgb_step(const void* d_corres, float sigma, const float* d_last_depth, float fx, float fy, float cx, float cy,
+                  const int16_t* d_dIdx, const int16_t* d_dIdy, float sobel_scale, int32_t W, int32_t H, double* out32,
+                  void* stream);
 /* icpStep (Core/Cuda/reduce.cu:446-525): d_out32 receives {27 upper-tri products, sum r^2, inliers, pad} */
 int mf_k_icp_step(const float* Rcurr9, const float* tcurr3, const float* d_vmap_curr, const float* d_nmap_curr,
                   const float* Rprev_inv9, const float* tprev3, float fx, float fy, float cx, float cy,

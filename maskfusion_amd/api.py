@@ -63,7 +63,7 @@ class MaskFusion:
     def __init__(self, width=640, height=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, *, timeDelta=200,
                  initConfidenceGlobal=4.0, initConfidenceObject=2.0, depthCut=3.0, icpThresh=10.0, fastOdom=False,
                  so3=True, device=0, numGSurfels=9437184, numOSurfels=1048576, enableMultipleModels=True,
-                 outlierCoefficient=0.9, modelSpawnOffset=20, trackAllModels=True):
+                 outlierCoefficient=0.9, modelSpawnOffset=20, trackAllModels=True, rgbOnly=False):
         self._L = load()
         cfg = Config()
         self._L.mf_default_config(C.byref(cfg), width, height, fx, fy, cx, cy)
@@ -75,6 +75,7 @@ class MaskFusion:
         cfg.icp_weight = icpThresh
         cfg.fast_odom = int(fastOdom)
         cfg.so3 = int(so3)
+        cfg.rgb_only = int(rgbOnly)
         cfg.num_gsurfels = numGSurfels
         cfg.num_osurfels = numOSurfels
         cfg.enable_multiple_models = int(enableMultipleModels)
@@ -179,6 +180,15 @@ class MaskFusion:
     def setOutlierCoefficient(self, v): self.setParam("outlierCoefficient", v)
     def setFastOdom(self, v): self.setParam("fastOdom", int(v))
     def setSo3(self, v): self.setParam("so3", int(v))
+    def setRgbOnly(self, v): self.setParam("rgbOnly", int(v))
+
+    def trackStats(self, model: int = 0) -> dict:
+        """Statistics of the last tracking step (RGBDOdometry.h:68-75)."""
+        out = np.zeros(8, np.float32)
+        self._chk(self._L.mf_get_track_stats(self._h, model, out.ctypes.data))
+        keys = ("lastICPError", "lastICPCount", "lastRGBError", "lastRGBCount", "lastSO3Error", "lastSO3Count", "so3Iterations",
+                "rejected")
+        return dict(zip(keys, out.tolist()))
     def setPyramid(self, v): self.setParam("pyramid", int(v))
     def setEnableMultipleModels(self, v): self.setParam("enableMultipleModels", int(v))
 

@@ -31,6 +31,7 @@ struct ModelState {
     int cur = 0, cap = 0;
     PoseDev* d_pose = nullptr; FrameDev* d_frame = nullptr;
     float4* d_predV = nullptr; float4* d_predN = nullptr; uchar4* d_predImage = nullptr; uint16_t* d_predTime = nullptr;
+    uint8_t* d_predGray = nullptr; uint8_t* d_fillGray = nullptr;  // intensity of the RGB projection / of the fill-in image
     PoseDev* h_pose = nullptr; FrameDev* h_frame = nullptr; int* h_count = nullptr;
     std::vector<void*> allocs;
     ~ModelState() {
@@ -70,6 +71,14 @@ struct mf_ctx {
     float* d_vmap[2][3] = {}; float* d_nmap[2][3] = {};
     // shared scratch
     GNState* d_gn = nullptr; float* d_partials[2] = {nullptr, nullptr};
+    // photometric term + SO(3) (a5, a8-a10, a12)
+    uint8_t* d_gray[2][3] = {};            // intensity pyramid of the frame, by frame parity ([prev] = lastNextImage)
+    long gray_frame[2] = {-1, -1};         // frame_no each set was computed for
+    int16_t* d_dIdx[3] = {}; int16_t* d_dIdy[3] = {};
+    float* d_lastDepth[3] = {}; uint8_t* d_lastImage[3] = {};   // per-model scratch: populateRGBDData(last)
+    RgbCorr* d_corres = nullptr; float* d_rgb_partials[2] = {nullptr, nullptr}; int2* d_cnt[2] = {nullptr, nullptr};
+    So3Result* d_so3 = nullptr;
+    const uint8_t* cur_rgb = nullptr;      // device rgb of the frame being processed (fill-in intensity at predict time)
     float* d_vmap_g[3]; float* d_nmap_g[3];
     unsigned long long* d_keys = nullptr;
     int* d_index = nullptr; float4* d_ivc = nullptr; float4* d_ict = nullptr; float4* d_inr = nullptr;
@@ -175,6 +184,8 @@ static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int 
     A(dev_alloc(c, m->allocs, &m->d_predN, P));
     A(dev_alloc(c, m->allocs, &m->d_predImage, P));
     A(dev_alloc(c, m->allocs, &m->d_predTime, P));
+    A(dev_alloc(c, m->allocs, &m->d_predGray, P));
+    if (allowFillIn) A(dev_alloc(c, m->allocs, &m->d_fillGray, P));
 #undef A
     hipLaunchKernelGGL(k_pose_identity, dim3(1), dim3(64), 0, c->stream, m->d_pose);
     hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(64), 0, c->stream, m->d_frame, c->host_tick);
@@ -235,6 +246,20 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     }
     for (int b = 0; b < 2; ++b) A(dev_alloc(c, c->allocs, &c->d_partials[b], (size_t)icp_grid_blocks(W, H) * kIcpSlots));
     A(dev_alloc(c, c->allocs, &c->d_gn, 2));
+    for (int i = 0; i < 3; ++i) {
+        const size_t lp = (size_t)(W >> i) * (H >> i);
+        for (int set = 0; set < 2; ++set) A(dev_alloc(c, c->allocs, &c->d_gray[set][i], lp));
+        A(dev_alloc(c, c->allocs, &c->d_dIdx[i], lp));
+        A(dev_alloc(c, c->allocs, &c->d_dIdy[i], lp));
+        A(dev_alloc(c, c->allocs, &c->d_lastDepth[i], lp));
+        A(dev_alloc(c, c->allocs, &c->d_lastImage[i], lp));
+    }
+    A(dev_alloc(c, c->allocs, &c->d_corres, (size_t)P));
+    for (int b = 0; b < 2; ++b) {
+        A(dev_alloc(c, c->allocs, &c->d_rgb_partials[b], (size_t)icp_grid_blocks(W, H) * kIcpSlots));
+        A(dev_alloc(c, c->allocs, &c->d_cnt[b], (size_t)icp_grid_blocks(W, H)));
+    }
+    A(dev_alloc(c, c->allocs, &c->d_so3, 1));
     A(dev_alloc(c, c->allocs, &c->d_keys, (size_t)P, 0xFF));
     A(dev_alloc(c, c->allocs, &c->d_index, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_ivc, (size_t)P));
@@ -298,17 +323,41 @@ static void mark(mf_ctx* c, int i, hipStream_t s = nullptr) {
 // ------------------------------------------------------------------------------------------------
 // per-model stages
 // ------------------------------------------------------------------------------------------------
-// Model::performTracking (Core/Model/Model.cpp:427-447): initICPModel (+ fill-in) then the Gauss-Newton loop
+// rgb = rgbOnly || icpWeight < 100 (RGBDOdometry.cpp:238)
+static bool photometric_on(const mf_ctx* c) { return c->cfg.rgb_only != 0 || c->cfg.icp_weight < 100.f; }
+
+// Model::performTracking (Core/Model/Model.cpp:427-447): initICP (model pyramid + fill-in, RGB pyramids), the optional
+// SO(3) pre-alignment, then the Gauss-Newton loop (ICP only: one launch per iteration; with the photometric term: two).
 static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, float jump_limit) {
     const mf_config& g = c->cfg;
-    float* const* cur_vmap = c->d_vmap[c->frame_no & 1];
-    float* const* cur_nmap = c->d_nmap[c->frame_no & 1];
+    const int set = (int)(c->frame_no & 1);
+    float* const* cur_vmap = c->d_vmap[set];
+    float* const* cur_nmap = c->d_nmap[set];
     const int W = c->W, H = c->H;
     hipStream_t s = c->stream;
     launch_model_pyramid(m.d_predV, m.d_predN, m.allowFillIn ? fillDepth : nullptr, m.d_frame, m.d_pose, nullptr, c->d_vmap_g,
                          c->d_nmap_g, W, H, c->K, s);
+    const bool rgb = photometric_on(c);
+    const bool icp = !g.rgb_only && g.icp_weight > 0.f;
+    // the previous frame's intensity pyramid is RGBDOdometry::lastNextImage (identical for every tracked model)
+    const bool so3 = g.so3 != 0 && c->gray_frame[set ^ 1] == c->frame_no - 1 && c->gray_frame[set] == c->frame_no;
+    if (so3)
+        launch_so3_prealign(c->d_gray[set ^ 1][2], c->d_gray[set][2], W >> 2, H >> 2, Intr{g.fx / 4, g.fy / 4, g.cx / 4, g.cy / 4},
+                            c->d_so3, s);
+    const So3Result* so3_seed = so3 ? c->d_so3 : nullptr;
+    if (rgb) {
+        // initRGBModel + initRGB (Model.cpp:395-406; Q1: both depth pyramids come from the vertex map initICPModel was given)
+        launch_rgbd_last_l0(m.d_predV, m.allowFillIn ? fillDepth : nullptr, m.d_predGray, m.d_fillGray, m.d_frame, c->d_lastDepth[0],
+                            c->d_lastImage[0], W * H, s);
+        for (int i = 0; i + 1 < 3; ++i) {
+            launch_pyrdown_f(c->d_lastDepth[i], c->d_lastDepth[i + 1], W >> i, H >> i, s);
+            launch_pyrdown_u8(c->d_lastImage[i], c->d_lastImage[i + 1], W >> i, H >> i, s);
+        }
+    }
     const int iters[3] = {g.fast_odom ? 3 : 10, g.pyramid ? 5 : 0, g.pyramid ? 4 : 0};  // RGBDOdometry.cpp:327-329
-    int k = 0, nb_prev = 0;
+    const float minGrad[3] = {5.f, 3.f, 1.f};                                            // RGBDOdometry.cpp:102-105
+    const float sobelScale = 1.0f / 8.0f;                                                // 1 / 2^sobelSize, :31-32
+    int k = 0, nb_prev = 0, prev_level = -1;
     for (int lvl = 2; lvl >= 0; --lvl) {
         const float div = (float)(1 << lvl);
         for (int j = 0; j < iters[lvl]; ++j) {
@@ -322,15 +371,43 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
             l.partials_out = c->d_partials[k & 1];
             l.state_in = &c->d_gn[k & 1]; l.state_out = &c->d_gn[(k + 1) & 1];
             l.log_out = (k > 0 && m.id == 0) ? c->d_icp_log + 32 * (k - 1) : nullptr;
-            l.prof_out = (c->icp_prof_on && m.id == 0) ? c->d_icp_prof + 8 * k : nullptr;
+            l.prof_out = (c->icp_prof_on && m.id == 0 && !rgb) ? c->d_icp_prof + 8 * k : nullptr;
             l.pose_in = (k == 0) ? m.d_pose : nullptr;
-            launch_icp_iteration(l, s);
+            l.so3_in = (k == 0) ? so3_seed : nullptr;
+            if (!rgb) {
+                launch_icp_iteration(l, s);
+            } else {
+                RgbdLaunch r;
+                r.icp = l;
+                r.L.dIdx = c->d_dIdx[lvl]; r.L.dIdy = c->d_dIdy[lvl];
+                r.L.lastDepth = c->d_lastDepth[lvl]; r.L.nextDepth = c->d_lastDepth[lvl];
+                r.L.lastImage = c->d_lastImage[lvl]; r.L.nextImage = c->d_gray[set][lvl];
+                r.L.W = l.W; r.L.H = l.H;
+                r.L.minScale = (float)(pow((double)minGrad[lvl], 2.0) / pow((double)sobelScale, 2.0));
+                r.L.maxDepthDelta = 0.07f;                                          // maxDepthDeltaRGB, :33
+                r.corres = c->d_corres;
+                r.rgb_partials_in = nb_prev ? c->d_rgb_partials[(k + 1) & 1] : nullptr;
+                r.rgb_partials_out = c->d_rgb_partials[k & 1];
+                r.cnt_in = nb_prev ? c->d_cnt[(k + 1) & 1] : nullptr;
+                r.cnt_out = c->d_cnt[k & 1];
+                r.icpWeight = g.icp_weight; r.icpOn = icp ? 1 : 0; r.rgbOnly = g.rgb_only ? 1 : 0; r.sobelScale = sobelScale;
+                r.level = lvl; r.prev_level = (prev_level < 0) ? lvl : prev_level;
+                r.so3_in = l.so3_in;
+                launch_rgbd_iteration(r, s);
+            }
             nb_prev = icp_grid_blocks(l.W, l.H);
+            prev_level = lvl;
             ++k;
         }
     }
-    launch_icp_finalize(nb_prev ? c->d_partials[(k + 1) & 1] : nullptr, nb_prev, &c->d_gn[k & 1], m.d_pose, m.h_pose,
-                        (k > 0 && m.id == 0) ? c->d_icp_log + 32 * (k - 1) : nullptr, jump_limit, s);
+    float* log_out = (k > 0 && m.id == 0) ? c->d_icp_log + 32 * (k - 1) : nullptr;
+    if (!rgb)
+        launch_icp_finalize(nb_prev ? c->d_partials[(k + 1) & 1] : nullptr, nb_prev, &c->d_gn[k & 1], m.d_pose, m.h_pose, log_out,
+                            jump_limit, so3_seed, s);
+    else
+        launch_rgbd_finalize(nb_prev ? c->d_partials[(k + 1) & 1] : nullptr, nb_prev ? c->d_rgb_partials[(k + 1) & 1] : nullptr,
+                             nb_prev ? c->d_cnt[(k + 1) & 1] : nullptr, nb_prev, g.icp_weight, icp ? 1 : 0, g.rgb_only ? 1 : 0, 1,
+                             prev_level, &c->d_gn[k & 1], so3_seed, m.d_pose, m.h_pose, log_out, jump_limit, s);
 }
 
 // predictIndices -> fuse -> [predictIndices] -> clean for one model (Core/MaskFusion.cpp:541-563 / :344-353)
@@ -364,8 +441,9 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
 static void enqueue_predict(mf_ctx* c, ModelState& m) {
     launch_splat_scatter(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, c->cfg.max_depth_processed, m.confThr,
                          c->cfg.time_delta, c->d_keys, c->stream);
+    const bool gray = photometric_on(c) ;
     launch_splat_resolve(m.surf[m.cur], m.d_pose, c->d_keys, c->W, c->H, c->K, m.d_predV, m.d_predN, m.d_predImage, m.d_predTime,
-                         m.d_frame, c->stream);
+                         m.d_frame, c->cur_rgb, gray ? m.d_predGray : nullptr, gray ? m.d_fillGray : nullptr, c->stream);
 }
 
 static int check_launch(mf_ctx* c) {
@@ -416,6 +494,16 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
             launch_vmap_nmap(c->d_dpyr[set][i], c->d_vmap[set][i], c->d_nmap[set][i], W >> i, H >> i,
                              Intr{g.fx / div, g.fy / div, g.cx / div, g.cy / div}, g.depth_cutoff, sp);
         }
+    }
+    c->cur_rgb = d_rgb;
+    if (photometric_on(c) || g.so3) {
+        // imageBGRToIntensity + pyrDownUcharGauss of the frame (initRGB / initFirstRGB) and, for the photometric term,
+        // computeDerivativeImages (RGBDOdometry.cpp:245-250)
+        launch_intensity(d_rgb, 3, c->d_gray[set][0], P, sp);
+        for (int i = 0; i + 1 < 3; ++i) launch_pyrdown_u8(c->d_gray[set][i], c->d_gray[set][i + 1], W >> i, H >> i, sp);
+        c->gray_frame[set] = k;
+        if (photometric_on(c))
+            for (int i = 0; i < 3; ++i) launch_derivative(c->d_gray[set][i], c->d_dIdx[i], c->d_dIdy[i], W >> i, H >> i, sp);
     }
     mark(c, 1, sp);
     if (c->overlap) {
@@ -557,7 +645,10 @@ extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* dept
 
 extern "C" int mf_predict(mf_ctx* c) {
     if (!c) return MF_EINVAL;
+    const uint8_t* keep = c->cur_rgb;
+    c->cur_rgb = nullptr;  // the caller's frame buffer may be gone: the fill-in intensity keeps its last contents
     for (auto& m : c->models) enqueue_predict(c, *m);
+    c->cur_rgb = keep;
     return check_launch(c);
 }
 
@@ -620,6 +711,16 @@ extern "C" int mf_get_icp_stats(mf_ctx* c, int32_t model, float* e, float* n) {
     *e = m->h_pose->lastICPError; *n = m->h_pose->lastICPCount;
     return MF_OK;
 }
+extern "C" int mf_get_track_stats(mf_ctx* c, int32_t model, float* out8) {
+    ModelState* m = model_at(c, model);
+    if (!m || !out8) return MF_EINVAL;
+    int rc = mf_sync(c);
+    if (rc != MF_OK) return rc;
+    const PoseDev& p = *m->h_pose;
+    out8[0] = p.lastICPError; out8[1] = p.lastICPCount; out8[2] = p.lastRGBError; out8[3] = p.lastRGBCount;
+    out8[4] = p.lastSO3Error; out8[5] = p.lastSO3Count; out8[6] = (float)p.so3Iterations; out8[7] = (float)p.rejected;
+    return MF_OK;
+}
 extern "C" int mf_get_last_fillin(mf_ctx* c, int32_t* used) {
     if (!c || !used) return MF_EINVAL;
     int rc = mf_sync(c);
@@ -669,6 +770,7 @@ static const ParamRef kParams[] = {
     {"maxDepthProcessed", 0, offsetof(mf_config, max_depth_processed)},
     {"fastOdom", 1, offsetof(mf_config, fast_odom)},
     {"so3", 1, offsetof(mf_config, so3)},
+    {"rgbOnly", 1, offsetof(mf_config, rgb_only)},
     {"pyramid", 1, offsetof(mf_config, pyramid)},
     {"timeDelta", 1, offsetof(mf_config, time_delta)},
     {"enableMultipleModels", 1, offsetof(mf_config, enable_multiple_models)},
@@ -794,6 +896,84 @@ extern "C" int mf_k_pyrdown_f(const float* d_src, float* d_dst, int32_t sw, int3
     if (!d_src || !d_dst || sw < 2 || sh < 2) return MF_EINVAL;
     launch_pyrdown_f(d_src, d_dst, sw, sh, (hipStream_t)stream);
     return launch_rc();
+}
+extern "C" int mf_k_intensity(const uint8_t* d_img, int32_t channels, uint8_t* d_out, int32_t n, void* stream) {
+    if (!d_img || !d_out || n <= 0 || (channels != 3 && channels != 4)) return MF_EINVAL;
+    launch_intensity(d_img, channels, d_out, n, (hipStream_t)stream);
+    return launch_rc();
+}
+extern "C" int mf_k_pyrdown_u8(const uint8_t* d_src, uint8_t* d_dst, int32_t sw, int32_t sh, void* stream) {
+    if (!d_src || !d_dst || sw < 2 || sh < 2) return MF_EINVAL;
+    launch_pyrdown_u8(d_src, d_dst, sw, sh, (hipStream_t)stream);
+    return launch_rc();
+}
+extern "C" int mf_k_derivative_images(const uint8_t* d_src, int16_t* d_dx, int16_t* d_dy, int32_t W, int32_t H, void* stream) {
+    if (!d_src || !d_dx || !d_dy || W <= 0 || H <= 0) return MF_EINVAL;
+    launch_derivative(d_src, d_dx, d_dy, W, H, (hipStream_t)stream);
+    return launch_rc();
+}
+extern "C" int mf_k_so3_prealign(const uint8_t* d_last, const uint8_t* d_next, int32_t W, int32_t H, float fx, float fy, float cx, float cy,
+                                 double* R9, float* stats3, void* stream) {
+    if (!d_last || !d_next || !R9 || !stats3 || W < 3 || H < 3) return MF_EINVAL;
+    So3Result* d = nullptr;
+    if (hipMalloc((void**)&d, sizeof(So3Result)) != hipSuccess) return MF_ENOMEM;
+    launch_so3_prealign(d_last, d_next, W, H, Intr{fx, fy, cx, cy}, d, (hipStream_t)stream);
+    So3Result h;
+    const hipError_t e = hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return MF_EHIP;
+    memcpy(R9, h.R, sizeof(h.R));
+    stats3[0] = h.error; stats3[1] = h.count; stats3[2] = (float)h.iterations;
+    return MF_OK;
+}
+static RgbLevel make_level(const int16_t* dIdx, const int16_t* dIdy, const float* lastDepth, const float* nextDepth, const uint8_t* lastImage,
+                           const uint8_t* nextImage, int W, int H, float minScale, float maxDepthDelta) {
+    RgbLevel L;
+    L.dIdx = dIdx; L.dIdy = dIdy; L.lastDepth = lastDepth; L.nextDepth = nextDepth; L.lastImage = lastImage; L.nextImage = nextImage;
+    L.W = W; L.H = H; L.minScale = minScale; L.maxDepthDelta = maxDepthDelta;
+    return L;
+}
+extern "C" int mf_k_rgb_residual(float min_scale, const int16_t* d_dIdx, const int16_t* d_dIdy, const float* d_last_depth,
+                                 const float* d_next_depth, const uint8_t* d_last_image, const uint8_t* d_next_image, float max_depth_delta,
+                                 const float* kt3, const float* krkinv9, int32_t W, int32_t H, void* d_corres, int32_t* count_sigma2,
+                                 void* stream) {
+    if (!d_dIdx || !d_dIdy || !d_last_depth || !d_next_depth || !d_last_image || !d_next_image || !kt3 || !krkinv9 || !d_corres ||
+        !count_sigma2)
+        return MF_EINVAL;
+    float h[12];
+    memcpy(h, krkinv9, 36); memcpy(h + 9, kt3, 12);
+    char* scratch = nullptr;
+    if (hipMalloc((void**)&scratch, 64) != hipSuccess) return MF_ENOMEM;
+    float* d_k = reinterpret_cast<float*>(scratch);
+    int* d_sums = reinterpret_cast<int*>(scratch + 48);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemcpyAsync(d_k, h, 48, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_sums, 0, 8, s);
+    if (e == hipSuccess) {
+        launch_rgb_residual_only(make_level(d_dIdx, d_dIdy, d_last_depth, d_next_depth, d_last_image, d_next_image, W, H, min_scale,
+                                            max_depth_delta), d_k, reinterpret_cast<RgbCorr*>(d_corres), d_sums, s);
+        e = hipMemcpyAsync(count_sigma2, d_sums, 8, hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(scratch);
+    return e == hipSuccess ? MF_OK : MF_EHIP;
+}
+extern "C" int mf_k_rgb_step(const void* d_corres, float sigma, const float* d_last_depth, float fx, float fy, float cx, float cy,
+                             const int16_t* d_dIdx, const int16_t* d_dIdy, float sobel_scale, int32_t W, int32_t H, double* out32,
+                             void* stream) {
+    if (!d_corres || !d_last_depth || !d_dIdx || !d_dIdy || !out32) return MF_EINVAL;
+    double* d_out = nullptr;
+    if (hipMalloc((void**)&d_out, 32 * sizeof(double)) != hipSuccess) return MF_ENOMEM;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(d_out, 0, 32 * sizeof(double), s);
+    if (e == hipSuccess) {
+        launch_rgb_step_only(make_level(d_dIdx, d_dIdy, d_last_depth, d_last_depth, nullptr, nullptr, W, H, 0.f, 0.f),
+                             reinterpret_cast<const RgbCorr*>(d_corres), sigma, Intr{fx, fy, cx, cy}, sobel_scale, d_out, s);
+        e = hipMemcpyAsync(out32, d_out, 32 * sizeof(double), hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_out);
+    return e == hipSuccess ? MF_OK : MF_EHIP;
 }
 extern "C" int mf_k_vmap_nmap(const float* d_depth, float* d_vmap, float* d_nmap, int32_t W, int32_t H, float fx, float fy, float cx,
                               float cy, float depth_cutoff, void* stream) {

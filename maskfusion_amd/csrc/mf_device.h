@@ -202,4 +202,49 @@ __device__ inline void pose_derive(PoseDev& p) {
 }
 
 
+// sin / cos for |th| <= 0.5 by Taylor series (error < 1e-17): keeps libm's large-argument reduction (and its scratch
+// arrays) out of the per-iteration kernel.
+__device__ __forceinline__ void sincos_small(double th, double& s, double& c) {
+    const double t2 = th * th;  // Horner form with reciprocal-factorial coefficients: no fp64 divisions (~40 instructions each)
+    s = th * (1.0 + t2 * (-1.0 / 6 + t2 * (1.0 / 120 + t2 * (-1.0 / 5040 + t2 * (1.0 / 362880 + t2 * (-1.0 / 39916800 +
+        t2 * (1.0 / 6227020800.0 + t2 * (-1.0 / 1307674368000.0))))))));
+    c = 1.0 + t2 * (-0.5 + t2 * (1.0 / 24 + t2 * (-1.0 / 720 + t2 * (1.0 / 40320 + t2 * (-1.0 / 3628800 + t2 * (1.0 / 479001600.0 +
+        t2 * (-1.0 / 87178291200.0 + t2 * (1.0 / 20922789888000.0))))))));
+}
+
+// OdometryProvider::rodrigues (Core/Utils/OdometryProvider.h:32-67).  Rotations beyond 0.5 rad (never produced by a
+// converging Gauss-Newton step) are built by repeated squaring of the rotation by theta / 2^k.
+__device__ __forceinline__ void rodrigues_d(double wx, double wy, double wz, double (&R)[3][3]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) R[r][c] = (r == c) ? 1.0 : 0.0;
+    const double th2 = wx * wx + wy * wy + wz * wz;
+    const double theta = th2 > 0.0 ? sqrt_d(th2) : 0.0;
+    if (theta >= 2.2204460492503131e-16) {
+        int halvings = 0;
+        double th = theta;
+        while (th > 0.5 && halvings < 64) { th *= 0.5; ++halvings; }
+        double s, c;
+        sincos_small(th, s, c);
+        const double c1 = 1. - c, itheta = rcp_d(theta);
+        const double rx = wx * itheta, ry = wy * itheta, rz = wz * itheta;
+        R[0][0] = c + c1 * rx * rx;      R[0][1] = c1 * rx * ry - s * rz; R[0][2] = c1 * rx * rz + s * ry;
+        R[1][0] = c1 * rx * ry + s * rz; R[1][1] = c + c1 * ry * ry;      R[1][2] = c1 * ry * rz - s * rx;
+        R[2][0] = c1 * rx * rz - s * ry; R[2][1] = c1 * ry * rz + s * rx; R[2][2] = c + c1 * rz * rz;
+        for (int h = 0; h < halvings; ++h) {
+            double Q[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) Q[r][cc] = R[r][0] * R[0][cc] + R[r][1] * R[1][cc] + R[r][2] * R[2][cc];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) R[r][cc] = Q[r][cc];
+        }
+    }
+}
+
+
 }  // namespace mf

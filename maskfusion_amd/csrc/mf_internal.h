@@ -28,7 +28,16 @@ struct PoseDev {
     float initR[9], initT[3];  // Model::initialC2Winv (objects; Model.h:263-264)
     float incT[3];             // translation of the last tracking increment (MaskFusion.cpp:268)
     int alive;                 // 0 once the 0.2 m jump test dropped the model in this frame
-    int pad[2];
+    int rejected;              // 1 if the last tracking step was reverted by the 0.3 m rule (RGBDOdometry.cpp:477-481)
+    float lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count;
+    int so3Iterations;
+};
+
+// Result of the SO(3) pre-alignment kernel (RGBDOdometry.cpp:264-324); seeds resultRt of the Gauss-Newton loop.
+struct So3Result {
+    double R[9];
+    float error, count;
+    int iterations, pad;
 };
 
 // Gauss-Newton state carried from one ICP launch to the next (double-buffered: launch k reads [k-1], block 0 writes [k]).
@@ -39,7 +48,8 @@ struct GNState {
     float lastICPError, lastICPCount;
     float trR[9], trt[3];      // Isometry3f transform (increment)
     int valid;
-    int pad;
+    int levelDone;             // pyramid level whose loop was left early (rgbOnly rule, RGBDOdometry.cpp:392-394); -1: none
+    float lastRGBError, lastRGBCount;
 };
 
 // Scalars that live on the device so that no kernel launch needs a host round trip.
@@ -81,6 +91,7 @@ struct IcpLaunch {
     float* log_out;                              // optional [32] floats of the reduced system solved in this launch
     unsigned long long* prof_out = nullptr;      // optional [8] shader-clock stamps (workgroup 0)
     const PoseDev* pose_in = nullptr;            // first launch only: seed the Gauss-Newton state from this pose
+    const So3Result* so3_in = nullptr;           // first launch only: SO(3) pre-alignment seeds resultRt's rotation
 };
 int icp_grid_blocks(int W, int H);
 void launch_icp_iteration(const IcpLaunch& a, hipStream_t s);
@@ -89,12 +100,49 @@ void launch_icp_begin(const PoseDev* pose, GNState* st, hipStream_t s);
 // Last reduce+solve, then pose / lastPose / inverse / fusion weight update and host mirror.
 // jump_limit > 0: object-model rule of MaskFusion.cpp:268-272 (|increment translation| > limit => pose->alive = 0)
 void launch_icp_finalize(const float* partials_in, int nblocks_in, const GNState* state_in, PoseDev* pose,
-                         PoseDev* host_mirror, float* log_out, float jump_limit, hipStream_t s);
+                         PoseDev* host_mirror, float* log_out, float jump_limit, const So3Result* so3, hipStream_t s);
 // Stand-alone icpStep (parity tests): host-provided poses, output 32 floats.
 void launch_icp_step_standalone(const float* Rcurr, const float* tcurr, const float* vc, const float* nc,
                                 const float* Rpi, const float* tprev, Intr k, const float* vp, const float* np,
                                 float distThres, float angleThres, int W, int H, float* partials, GNState* st2,
                                 float* out32, hipStream_t s);
+
+struct RgbCorr { int16_t u0, v0; float diff; };  // DataTerm (types.cuh:75-81) packed to 8 B; u0 < 0: no correspondence
+
+struct RgbLevel {  // one pyramid level of RGBDOdometry's photometric inputs
+    const int16_t* dIdx; const int16_t* dIdy;          // nextdIdx / nextdIdy
+    const float* lastDepth; const float* nextDepth;    // Q1: both come from the model prediction
+    const uint8_t* lastImage; const uint8_t* nextImage;
+    int W, H;
+    float minScale;        // minimumGradientMagnitudes[level]^2 / sobelScale^2
+    float maxDepthDelta;   // 0.07
+};
+
+// ---------------- photometric term + SO(3) (mf_rgbd.hip, mf_odometry.hip) ----------------
+void launch_intensity(const uint8_t* img, int channels, uint8_t* dst, int n, hipStream_t s);
+void launch_pyrdown_u8(const uint8_t* src, uint8_t* dst, int sw, int sh, hipStream_t s);
+void launch_derivative(const uint8_t* src, int16_t* dx, int16_t* dy, int W, int H, hipStream_t s);
+// level 0 of a model's "last" depth / intensity pyramids (populateRGBDData of initRGBModel; Q1: initRGB re-uses the depth)
+void launch_rgbd_last_l0(const float4* predV, const float* fillDepth, const uint8_t* predGray, const uint8_t* fillGray,
+                         const FrameDev* frame, float* depth0, uint8_t* image0, int n, hipStream_t s);
+void launch_so3_prealign(const uint8_t* lastImage2, const uint8_t* nextImage2, int W2, int H2, Intr k2, So3Result* out, hipStream_t s);
+void launch_rgb_residual_only(const RgbLevel& L, const float* krk_kt, RgbCorr* corres, int* sums, hipStream_t s);
+void launch_rgb_step_only(const RgbLevel& L, const RgbCorr* corres, float sigma, Intr k, float sobelScale, double* out32, hipStream_t s);
+// One RGB-D Gauss-Newton iteration = two launches (see mf_odometry.hip)
+struct RgbdLaunch {
+    IcpLaunch icp;
+    RgbLevel L;
+    RgbCorr* corres;
+    const float* rgb_partials_in; float* rgb_partials_out;
+    const int2* cnt_in; int2* cnt_out;
+    float icpWeight; int icpOn; int rgbOnly; float sobelScale;
+    int level, prev_level;
+    const So3Result* so3_in;
+};
+void launch_rgbd_iteration(const RgbdLaunch& l, hipStream_t s);
+void launch_rgbd_finalize(const float* icp_partials, const float* rgb_partials, const int2* cnt, int nb, float icpWeight, int icpOn,
+                          int rgbOnly, int rgbOn, int prev_level, const GNState* st_in, const So3Result* so3, PoseDev* pose,
+                          PoseDev* host_mirror, float* log_out, float jump_limit, hipStream_t s);
 
 // ---------------- surfels ----------------
 void launch_init_surfels(const uint8_t* rgb, const float* depthRaw, const float* depthF, int W, int H, Intr k,
@@ -122,6 +170,7 @@ void launch_splat_scatter(Surfels src, const FrameDev* frame, const PoseDev* pos
                           hipStream_t s);
 void launch_splat_resolve(Surfels src, const PoseDev* pose, unsigned long long* keys, int W, int H, Intr k,
                           float4* predV, float4* predN, uchar4* predImage, uint16_t* predTime, FrameDev* frame,
+                          const uint8_t* rgb /*or null*/, uint8_t* predGray /*or null*/, uint8_t* fillGray /*or null*/,
                           hipStream_t s);
 void launch_fill_keys(unsigned long long* keys, int n, hipStream_t s);
 void launch_fill_int(int* p, int v, int n, hipStream_t s);

@@ -14,7 +14,9 @@
 // the kernel boundary only), then streams the current vertex/normal planes (16 B per lane), gathers the model
 // planes, and reduces 29 accumulators with DPP row operations + one LDS stage.  No host round trip, no atomics,
 // bit-reproducible run to run.
+#include "mf_internal.h"
 #include "mf_device.h"
+#include "mf_rgbd_device.h"
 
 namespace mf {
 
@@ -68,61 +70,18 @@ __device__ __forceinline__ void ldlt6_solve(double (&A)[6][6], const double (&b)
     }
 }
 
-// sin / cos for |th| <= 0.5 by Taylor series (error < 1e-17): keeps libm's large-argument reduction (and its scratch
-// arrays) out of the per-iteration kernel.
-__device__ __forceinline__ void sincos_small(double th, double& s, double& c) {
-    const double t2 = th * th;  // Horner form with reciprocal-factorial coefficients: no fp64 divisions (~40 instructions each)
-    s = th * (1.0 + t2 * (-1.0 / 6 + t2 * (1.0 / 120 + t2 * (-1.0 / 5040 + t2 * (1.0 / 362880 + t2 * (-1.0 / 39916800 +
-        t2 * (1.0 / 6227020800.0 + t2 * (-1.0 / 1307674368000.0))))))));
-    c = 1.0 + t2 * (-0.5 + t2 * (1.0 / 24 + t2 * (-1.0 / 720 + t2 * (1.0 / 40320 + t2 * (-1.0 / 3628800 + t2 * (1.0 / 479001600.0 +
-        t2 * (-1.0 / 87178291200.0 + t2 * (1.0 / 20922789888000.0))))))));
-}
-
-// OdometryProvider::rodrigues (Core/Utils/OdometryProvider.h:32-67).  Rotations beyond 0.5 rad (never produced by a
-// converging Gauss-Newton step) are built by repeated squaring of the rotation by theta / 2^k.
-__device__ __forceinline__ void rodrigues_d(double wx, double wy, double wz, double (&R)[3][3]) {
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) R[r][c] = (r == c) ? 1.0 : 0.0;
-    const double th2 = wx * wx + wy * wy + wz * wz;
-    const double theta = th2 > 0.0 ? sqrt_d(th2) : 0.0;
-    if (theta >= 2.2204460492503131e-16) {
-        int halvings = 0;
-        double th = theta;
-        while (th > 0.5 && halvings < 64) { th *= 0.5; ++halvings; }
-        double s, c;
-        sincos_small(th, s, c);
-        const double c1 = 1. - c, itheta = rcp_d(theta);
-        const double rx = wx * itheta, ry = wy * itheta, rz = wz * itheta;
-        R[0][0] = c + c1 * rx * rx;      R[0][1] = c1 * rx * ry - s * rz; R[0][2] = c1 * rx * rz + s * ry;
-        R[1][0] = c1 * rx * ry + s * rz; R[1][1] = c + c1 * ry * ry;      R[1][2] = c1 * ry * rz - s * rx;
-        R[2][0] = c1 * rx * rz - s * ry; R[2][1] = c1 * ry * rz + s * rx; R[2][2] = c + c1 * rz * rz;
-        for (int h = 0; h < halvings; ++h) {
-            double Q[3][3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int cc = 0; cc < 3; ++cc) Q[r][cc] = R[r][0] * R[0][cc] + R[r][1] * R[1][cc] + R[r][2] * R[2][cc];
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int cc = 0; cc < 3; ++cc) R[r][cc] = Q[r][cc];
-        }
-    }
-}
-
 // Wave-parallel 6x6 solve: Gauss-Jordan on the augmented [A|b] with one lane per element (lanes 0..41 of one
 // wavefront, fp64, no pivoting -- the systems are symmetric positive definite; a vanishing pivot zeroes that component
 // like Eigen::LDLT::solve does for singular systems).  Six rank-1 steps of {3 shuffles, 1 fma} replace a ~3 us
 // single-thread LDL^T; the serial ldlt6_solve above is kept as the executable specification (tests compare both).
 // sys: 27 packed upper-triangle products of the 7-vector row (reduce.cu:378-411 order) in LDS.  Returns x in every lane.
-__device__ __forceinline__ void solve6_wave(const double* sys, double (&x)[6]) {
+__device__ __forceinline__ int solve6_lane_index(int& r, int& c) {
     const int l = threadIdx.x & 63;
-    const int r = l < 42 ? l / 7 : 0, c = l < 42 ? l % 7 : 0;
+    r = l < 42 ? l / 7 : 0; c = l < 42 ? l % 7 : 0;
     const int i = r < c ? r : c, j = r < c ? c : r;                 // A is symmetric; column 6 is b
-    const int idx = (c == 6) ? (r * 7 - (r * (r - 1)) / 2 + (6 - r)) : (i * 7 - (i * (i - 1)) / 2 + (j - i));
-    double v = (double)(float)sys[idx];                              // the reference hands float A/b to the host
+    return (c == 6) ? (r * 7 - (r * (r - 1)) / 2 + (6 - r)) : (i * 7 - (i * (i - 1)) / 2 + (j - i));
+}
+__device__ __forceinline__ void solve6_wave_core(double v, int r, int c, double (&x)[6]) {
     double maxdiag = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) maxdiag = fmax(maxdiag, fabs(__shfl(v, k * 8, 64)));
@@ -138,6 +97,19 @@ __device__ __forceinline__ void solve6_wave(const double* sys, double (&x)[6]) {
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) x[k] = __shfl(v, k * 7 + 6, 64);
+}
+__device__ __forceinline__ void solve6_wave(const double* sys, double (&x)[6]) {
+    int r, c;
+    const int idx = solve6_lane_index(r, c);
+    const double v = (double)(float)sys[idx];                        // the reference hands float A/b to the host
+    solve6_wave_core(v, r, c, x);
+}
+// lastA = A_rgbd + w^2 A_icp, lastb = b_rgbd + w b_icp (RGBDOdometry.cpp:447-452; sic -- the ICP step is scaled by 1/w)
+__device__ __forceinline__ void solve6_wave_rgbd(const double* sysIcp, const double* sysRgb, double wA, double wb, double (&x)[6]) {
+    int r, c;
+    const int idx = solve6_lane_index(r, c);
+    const double v = (double)(float)sysRgb[idx] + ((c == 6) ? wb : wA) * (double)(float)sysIcp[idx];
+    solve6_wave_core(v, r, c, x);
 }
 
 // Pose update from the Gauss-Newton step x: RGBDOdometry.cpp:428-474 (icp && !rgb branch) +
@@ -189,7 +161,7 @@ __device__ __forceinline__ void gn_update_from_x(const double (&x)[6], float res
 #pragma unroll
     for (int k = 0; k < 3; ++k) { out.tprev[k] = in.tprev[k]; out.trt[k] = trt[k]; }
     out.valid = 1;
-    out.pad = 0;
+    out.levelDone = in.levelDone; out.lastRGBError = in.lastRGBError; out.lastRGBCount = in.lastRGBCount;
 }
 
 // Serial form (one thread): unpack -> LDL^T -> update.  Used by tests through mf_k_gn_solve to pin the wave solver.
@@ -321,6 +293,7 @@ struct IcpKArgs {
     float* log_out;
     unsigned long long* prof_out;  // optional: 8 shader-clock stamps of workgroup 0 / thread 0
     const PoseDev* pose_in;        // first launch of a tracking step: seed the state from the model pose
+    const So3Result* so3_in;       // ... and resultRt's rotation from the SO(3) pre-alignment (RGBDOdometry.cpp:338-344)
 };
 
 // Correspondence search for one pixel, split in two so that the gathers of all four pixels of a thread are in flight
@@ -366,7 +339,8 @@ __device__ __forceinline__ void seed_state(const PoseDev& pose, GNState& s) {
     for (int k = 0; k < 9; ++k) { s.Rprev[k] = pose.R[k]; s.Rcurr[k] = pose.R[k]; s.trR[k] = (k % 4 == 0) ? 1.f : 0.f; }
     for (int k = 0; k < 3; ++k) { s.tprev[k] = pose.t[k]; s.tcurr[k] = pose.t[k]; s.trt[k] = 0.f; }
     m33_inverse_f(s.Rprev, s.Rprev_inv);  // RGBDOdometry.cpp:332
-    s.lastICPError = 0.f; s.lastICPCount = 0.f; s.valid = 0; s.pad = 0;
+    s.lastICPError = 0.f; s.lastICPCount = 0.f; s.valid = 0;
+    s.levelDone = -1; s.lastRGBError = 3.4028234664e38f; s.lastRGBCount = 0.f;
 }
 
 // 1024 threads = 16 wavefronts per workgroup, ONE pixel per thread: the per-pixel chain (project -> gather -> gate ->
@@ -395,6 +369,9 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp_iter(const IcpKArgs a) {
         if (tid < (int)(sizeof(GNState) / 4)) reinterpret_cast<uint32_t*>(&s_st)[tid] = reinterpret_cast<const uint32_t*>(a.st_in)[tid];
     } else if (tid == 0) {
         seed_state(*a.pose_in, s_st);   // RGBDOdometry.cpp:239-243,332-336: Rprev = Rcurr = pose, resultRt = I
+        if (a.so3_in)
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) s_st.resultRt[r * 4 + c] = a.so3_in->R[r * 3 + c];
     }
     const bool prof = a.prof_out != nullptr && blockIdx.x == 0 && tid == 0;
     unsigned long long stamp[8];
@@ -515,6 +492,7 @@ void launch_icp_iteration(const IcpLaunch& l, hipStream_t s) {
     a.W = l.W; a.H = l.H; a.k = l.k; a.distThres = l.distThres; a.angleThres = l.angleThres;
     a.partials_in = l.partials_in; a.nb_in = l.nblocks_in; a.partials_out = l.partials_out;
     a.st_in = l.state_in; a.st_out = l.state_out; a.log_out = l.log_out; a.prof_out = l.prof_out; a.pose_in = l.pose_in;
+    a.so3_in = l.so3_in;
     hipLaunchKernelGGL(k_icp_iter, dim3(icp_grid_blocks(l.W, l.H)), dim3(kIcpThreads), 0, s, a);
 }
 
@@ -535,7 +513,7 @@ void launch_icp_begin(const PoseDev* pose, GNState* st, hipStream_t s) {
 __global__ __launch_bounds__(256) void k_icp_finalize(const float* __restrict__ partials_in, int nb_in,
                                                        const GNState* __restrict__ st_in, PoseDev* __restrict__ pose,
                                                        PoseDev* __restrict__ host_mirror, float* __restrict__ log_out,
-                                                       float jump_limit) {
+                                                       float jump_limit, const So3Result* __restrict__ so3) {
     __shared__ double s_seg[32 * 32];
     __shared__ double s_sys[32];
     GNState st;
@@ -555,6 +533,9 @@ __global__ __launch_bounds__(256) void k_icp_finalize(const float* __restrict__ 
         for (int k = 0; k < 3; ++k) { p.lastT[k] = st.tprev[k]; p.t[k] = st.tcurr[k]; }
         p.lastICPError = st.lastICPError;
         p.lastICPCount = st.lastICPCount;
+        p.rejected = 0; p.lastRGBError = 0.f; p.lastRGBCount = 0.f;
+        if (so3) { p.lastSO3Error = so3->error; p.lastSO3Count = so3->count; p.so3Iterations = so3->iterations; }
+        else { p.lastSO3Error = 0.f; p.lastSO3Count = 0.f; p.so3Iterations = 0; }
         for (int k = 0; k < 3; ++k) p.incT[k] = st.trt[k];
         if (jump_limit > 0.f && norm3(f3(st.trt[0], st.trt[1], st.trt[2])) > jump_limit) p.alive = 0;
         pose_derive(p);
@@ -564,9 +545,9 @@ __global__ __launch_bounds__(256) void k_icp_finalize(const float* __restrict__ 
 }
 
 void launch_icp_finalize(const float* partials_in, int nblocks_in, const GNState* state_in, PoseDev* pose,
-                         PoseDev* host_mirror, float* log_out, float jump_limit, hipStream_t s) {
+                         PoseDev* host_mirror, float* log_out, float jump_limit, const So3Result* so3, hipStream_t s) {
     hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(256), 0, s, partials_in, nblocks_in, state_in, pose, host_mirror,
-                       log_out, jump_limit);
+                       log_out, jump_limit, so3);
 }
 
 // stand-alone icpStep for the parity tests: reduce partials to 32 floats
@@ -583,7 +564,7 @@ __global__ void k_state_from_args(GNState* st, const float* Rc, const float* tc,
     for (int k = 0; k < 16; ++k) s.resultRt[k] = (k % 5 == 0) ? 1.0 : 0.0;
     for (int k = 0; k < 9; ++k) { s.Rcurr[k] = Rc[k]; s.Rprev_inv[k] = Rpi[k]; s.Rprev[k] = 0.f; s.trR[k] = 0.f; }
     for (int k = 0; k < 3; ++k) { s.tcurr[k] = tc[k]; s.tprev[k] = tp[k]; s.trt[k] = 0.f; }
-    s.lastICPError = s.lastICPCount = 0.f; s.valid = 0; s.pad = 0;
+    s.lastICPError = s.lastICPCount = 0.f; s.valid = 0; s.levelDone = -1; s.lastRGBError = 3.4028234664e38f; s.lastRGBCount = 0.f;
     *st = s;
 }
 
@@ -598,6 +579,296 @@ void launch_icp_step_standalone(const float* Rcurr, const float* tcurr, const fl
     l.partials_out = partials; l.state_in = st; l.state_out = st + 1; l.log_out = nullptr; l.prof_out = nullptr;
     launch_icp_iteration(l, s);
     hipLaunchKernelGGL(k_icp_reduce_only, dim3(1), dim3(256), 0, s, partials, icp_grid_blocks(W, H), out32);
+}
+
+// ------------------------------------------------------------------------------------------------
+// RGB-D Gauss-Newton loop (icpWeight < 100 or rgbOnly): two launches per iteration.
+//   A  k_rgbd_iter : [finish the previous iteration: reduce ICP + RGB partials, combine, solve, pose] ->
+//                    ICP normal equations + photometric correspondences (RgbCorr per pixel, count / sum diff^2)
+//   B  k_rgb_step  : [sigma = reduced count] -> photometric normal equations from the correspondences
+// B exists because the photometric weight 1 / (count + |diff|) needs the GLOBAL correspondence count of the same
+// iteration (RGBDOdometry.cpp:389-401,436); a launch boundary is the only grid-wide ordering point used here.
+// The ICP-only loop keeps its own tuned kernel (k_icp_iter).
+// ------------------------------------------------------------------------------------------------
+struct RgbdKArgs {
+    IcpKArgs icp;                 // maps, intrinsics, thresholds, ICP partials in/out, state in/out, pose_in
+    RgbLevel L;                   // photometric inputs of THIS launch's level
+    RgbCorr* corres;              // [W*H] out
+    const float* rgb_partials_in; // [nb_in][32]  (B of the previous iteration)
+    const int2* cnt_in;           // [nb_in]      (A of the previous iteration): {count, sum diff^2}
+    int2* cnt_out;                // [gridDim.x]
+    float icpWeight; int icpOn; int rgbOnly;
+    int level, prev_level;
+    const So3Result* so3_in;      // first launch: rotation seed of resultRt (nullptr: identity)
+};
+
+// Sum of nb int2 records by the first wavefront; result broadcast through LDS (s_cnt[2]).  int32 wrap-around like the
+// reference's int2 sums (reduce.cu:716-772).
+__device__ __forceinline__ void reduce_counts(const int2* __restrict__ cnt, int nb, int* s_cnt) {
+    if (threadIdx.x < 64) {
+        unsigned c = 0, g = 0;
+        for (int i = threadIdx.x; i < nb; i += 64) { const int2 v = cnt[i]; c += (unsigned)v.x; g += (unsigned)v.y; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { c += (unsigned)__shfl_xor((int)c, o, 64); g += (unsigned)__shfl_xor((int)g, o, 64); }
+        if (threadIdx.x == 0) { s_cnt[0] = (int)c; s_cnt[1] = (int)g; }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ float rgb_tmp_error(int count, int sigma) {  // RGBDOdometry.cpp:389
+    return (float)(sqrt((double)sigma) / (double)count);
+}
+
+// Finishes the iteration whose partial sums are given; every workgroup calls it with all threads and gets the same
+// answer.  Returns true in the one thread (0) that holds `out`.
+__device__ __forceinline__ bool finish_rgbd_iteration(const float* icp_partials, const float* rgb_partials, const int2* cnt, int nb,
+                                                      float icpWeight, int icpOn, int rgbOnly, int prev_level, const GNState& in,
+                                                      GNState& out, double* s_seg, double* s_sys, double* s_sys2, int* s_cnt,
+                                                      float* log_out) {
+    reduce_partials(icp_partials, nb, s_seg, s_sys);
+    reduce_partials(rgb_partials, nb, s_seg, s_sys2);
+    reduce_counts(cnt, nb, s_cnt);
+    if (threadIdx.x >= 64) return false;
+    double x[6];
+    const double w = (double)icpWeight;
+    solve6_wave_rgbd(s_sys, s_sys2, icpOn ? w * w : 0.0, icpOn ? w : 0.0, x);
+    if (threadIdx.x != 0) return false;
+    if (in.levelDone == prev_level) { out = in; return true; }             // that level's loop was already left
+    const int count = s_cnt[0], sigma = s_cnt[1];
+    const float tmpError = rgb_tmp_error(count, sigma);
+    if (rgbOnly && tmpError > in.lastRGBError) {                            // RGBDOdometry.cpp:392-394: break
+        out = in;
+        out.levelDone = prev_level;
+        return true;
+    }
+    gn_update_from_x(x, (float)s_sys[27], (float)s_sys[28], in, out);
+    if (!icpOn) { out.lastICPError = in.lastICPError; out.lastICPCount = in.lastICPCount; }
+    out.lastRGBError = tmpError;
+    out.lastRGBCount = (float)count;
+    if (log_out)
+        for (int k = 0; k < 32; ++k) log_out[k] = (float)s_sys2[k];
+    return true;
+}
+
+__global__ __launch_bounds__(kIcpThreads) void k_rgbd_iter(const RgbdKArgs a) {
+    __shared__ double s_seg[32 * 32];
+    __shared__ double s_sys[32];
+    __shared__ double s_sys2[32];
+    __shared__ float s_pose[24];   // Rcurr[9] tcurr[3] Rprev_inv[9] tprev[3]
+    __shared__ float s_krk[12];    // K R K^-1 [9], K t [3] of this iteration
+    __shared__ float s_part[(kIcpThreads / 64) * kIcpSlots];
+    __shared__ int s_cnt[2];
+    __shared__ int s_icnt[(kIcpThreads / 64) * 2];
+    __shared__ int s_skip;
+    __shared__ GNState s_st;
+
+    const int tid = threadIdx.x;
+    const IcpKArgs& ia = a.icp;
+    if (ia.pose_in == nullptr) {
+        if (tid < (int)(sizeof(GNState) / 4)) reinterpret_cast<uint32_t*>(&s_st)[tid] = reinterpret_cast<const uint32_t*>(ia.st_in)[tid];
+    } else if (tid == 0) {
+        seed_state(*ia.pose_in, s_st);
+        if (a.so3_in)  // RGBDOdometry.cpp:338-344
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) s_st.resultRt[r * 4 + c] = a.so3_in->R[r * 3 + c];
+    }
+    __syncthreads();
+    const int P = ia.W * ia.H;
+    const int chunk = icp_chunk(P, gridDim.x);
+    const int beg = blockIdx.x * chunk, end = min(P, beg + chunk);
+
+    // prologue: finish the previous iteration, then derive what this iteration needs
+    GNState st;
+    bool mine;
+    if (ia.nb_in > 0) {
+        mine = finish_rgbd_iteration(ia.partials_in, a.rgb_partials_in, a.cnt_in, ia.nb_in, a.icpWeight, a.icpOn, a.rgbOnly, a.prev_level,
+                                     s_st, st, s_seg, s_sys, s_sys2, s_cnt, (blockIdx.x == 0) ? ia.log_out : nullptr);
+    } else {
+        mine = tid == 0;
+        if (mine) st = s_st;
+    }
+    if (mine) {
+        if (a.level != a.prev_level) st.lastRGBError = 3.4028234664e38f;   // RGBDOdometry.cpp:359
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { s_pose[k] = st.Rcurr[k]; s_pose[12 + k] = st.Rprev_inv[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { s_pose[9 + k] = st.tcurr[k]; s_pose[21 + k] = st.tprev[k]; }
+        float krk[9], kt[3];
+        krk_from_result(st.resultRt, ia.k, krk, kt);
+        for (int k = 0; k < 9; ++k) s_krk[k] = krk[k];
+        for (int k = 0; k < 3; ++k) s_krk[9 + k] = kt[k];
+        s_skip = st.levelDone == a.level;
+        if (blockIdx.x == 0) *ia.st_out = st;
+    }
+    __syncthreads();
+    const bool skip = s_skip != 0;
+    const int lane = tid & 63, wave = tid >> 6;
+
+    // ---- ICP normal equations (as k_icp_iter, <= 2 px per thread)
+    float acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = 0.f;
+    if (a.icpOn && !skip) {
+        float Rc[9], Rpi[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { Rc[k] = s_pose[k]; Rpi[k] = s_pose[12 + k]; }
+        const float3 tc = f3(s_pose[9], s_pose[10], s_pose[11]);
+        const float3 tp = f3(s_pose[21], s_pose[22], s_pose[23]);
+        for (int i = beg + tid; i < end; i += kIcpThreads) {
+            const IcpCorr c = icp_project(ia.vc[i], ia.vc[P + i], ia.vc[2 * P + i], ia.nc[i], ia.nc[P + i], ia.nc[2 * P + i], Rc, tc, Rpi,
+                                          tp, ia);
+            const int j = c.j;
+            const float3 pv = f3(ia.vp[j], ia.vp[P + j], ia.vp[2 * P + j]);
+            const float3 pn = f3(ia.np[j], ia.np[P + j], ia.np[2 * P + j]);
+            icp_accumulate(c, pv, pn, Rpi, tp, ia, acc);
+        }
+    }
+    const float wsum = wave_sum32_halving(acc);
+    if (lane < 32) s_part[wave * kIcpSlots + icp_component_of_lane(lane)] = wsum;
+
+    // ---- photometric correspondences of this iteration
+    unsigned cnt = 0, sig = 0;
+    if (!skip) {
+        float krk[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) krk[k] = s_krk[k];
+        const float3 kt = f3(s_krk[9], s_krk[10], s_krk[11]);
+        for (int i = beg + tid; i < end; i += kIcpThreads) {
+            const int y = i / a.L.W, x = i - y * a.L.W;
+            RgbCorr c;
+            if (rgb_residual_px(a.L, krk, kt, x, y, c)) { cnt += 1u; sig += (unsigned)(int)(c.diff * c.diff); }
+            a.corres[i] = c;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cnt += (unsigned)__shfl_xor((int)cnt, o, 64); sig += (unsigned)__shfl_xor((int)sig, o, 64); }
+    if (lane == 0) { s_icnt[wave * 2] = (int)cnt; s_icnt[wave * 2 + 1] = (int)sig; }
+    __syncthreads();
+    if (tid < kIcpSlots) {
+        float sv = 0.f;
+        if (tid < 29) {
+#pragma unroll
+            for (int w = 0; w < kIcpThreads / 64; ++w) sv += s_part[w * kIcpSlots + tid];
+        }
+        ia.partials_out[blockIdx.x * kIcpSlots + tid] = sv;
+    }
+    if (tid == 0) {
+        unsigned c = 0, g = 0;
+        for (int w = 0; w < kIcpThreads / 64; ++w) { c += (unsigned)s_icnt[w * 2]; g += (unsigned)s_icnt[w * 2 + 1]; }
+        a.cnt_out[blockIdx.x] = make_int2((int)c, (int)g);
+    }
+}
+
+struct RgbStepKArgs {
+    RgbLevel L; Intr k; int level;
+    const RgbCorr* corres; const int2* cnt_in; int nb;   // of the A launch of the same iteration
+    const GNState* st;                                    // state written by that launch
+    int rgbOnly; float sobelScale;
+    float* partials_out;                                  // [gridDim.x][32]
+};
+
+__global__ __launch_bounds__(kIcpThreads) void k_rgb_step(const RgbStepKArgs a) {
+    __shared__ float s_part[(kIcpThreads / 64) * kIcpSlots];
+    __shared__ int s_cnt[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    reduce_counts(a.cnt_in, a.nb, s_cnt);
+    const int count = s_cnt[0], sigma = s_cnt[1];
+    const float tmpError = rgb_tmp_error(count, sigma);
+    float sigmaVal = (tmpError == 0.f) ? 1.f : (float)count;   // RGBDOdometry.cpp:390
+    if (a.rgbOnly) sigmaVal = -1.f;                             // :399-401
+    const bool skip = a.st->levelDone == a.level;
+    const int P = a.L.W * a.L.H;
+    const int chunk = icp_chunk(P, gridDim.x);
+    const int beg = blockIdx.x * chunk, end = min(P, beg + chunk);
+    float acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = 0.f;
+    if (!skip) {
+        for (int i = beg + tid; i < end; i += kIcpThreads) {
+            const RgbCorr c = a.corres[i];
+            if (c.u0 < 0) continue;
+            const int y = i / a.L.W, x = i - y * a.L.W;
+            rgb_step_px(a.L, c, x, y, sigmaVal, a.k, a.sobelScale, acc);
+        }
+    }
+    const float wsum = wave_sum32_halving(acc);
+    if (lane < 32) s_part[wave * kIcpSlots + icp_component_of_lane(lane)] = wsum;
+    __syncthreads();
+    if (tid < kIcpSlots) {
+        float sv = 0.f;
+        if (tid < 29) {
+#pragma unroll
+            for (int w = 0; w < kIcpThreads / 64; ++w) sv += s_part[w * kIcpSlots + tid];
+        }
+        a.partials_out[blockIdx.x * kIcpSlots + tid] = sv;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rgbd_finalize(const float* __restrict__ icp_partials, const float* __restrict__ rgb_partials,
+                                                        const int2* __restrict__ cnt, int nb, float icpWeight, int icpOn, int rgbOnly,
+                                                        int rgbOn, int prev_level, const GNState* __restrict__ st_in,
+                                                        const So3Result* __restrict__ so3, PoseDev* __restrict__ pose,
+                                                        PoseDev* __restrict__ host_mirror, float* __restrict__ log_out, float jump_limit) {
+    __shared__ double s_seg[32 * 32];
+    __shared__ double s_sys[32];
+    __shared__ double s_sys2[32];
+    __shared__ int s_cnt[2];
+    __shared__ GNState s_st;
+    if (threadIdx.x < (int)(sizeof(GNState) / 4)) reinterpret_cast<uint32_t*>(&s_st)[threadIdx.x] = reinterpret_cast<const uint32_t*>(st_in)[threadIdx.x];
+    __syncthreads();
+    GNState st;
+    bool mine;
+    if (nb > 0) {
+        mine = finish_rgbd_iteration(icp_partials, rgb_partials, cnt, nb, icpWeight, icpOn, rgbOnly, prev_level, s_st, st, s_seg, s_sys,
+                                     s_sys2, s_cnt, log_out);
+    } else {
+        mine = threadIdx.x == 0;
+        if (mine) st = s_st;
+    }
+    if (!mine) return;
+    PoseDev p = *pose;
+    p.rejected = 0;
+    const float dx = st.tcurr[0] - st.tprev[0], dy = st.tcurr[1] - st.tprev[1], dz = st.tcurr[2] - st.tprev[2];
+    if (rgbOn && sqrtf(dx * dx + dy * dy + dz * dz) > 0.3f) {   // RGBDOdometry.cpp:477-481
+        for (int k = 0; k < 9; ++k) st.Rcurr[k] = st.Rprev[k];
+        for (int k = 0; k < 3; ++k) { st.tcurr[k] = st.tprev[k]; st.trt[k] = 0.f; }
+        p.rejected = 1;
+    }
+    for (int k = 0; k < 9; ++k) { p.lastR[k] = st.Rprev[k]; p.R[k] = st.Rcurr[k]; }
+    for (int k = 0; k < 3; ++k) { p.lastT[k] = st.tprev[k]; p.t[k] = st.tcurr[k]; }
+    p.lastICPError = st.lastICPError; p.lastICPCount = st.lastICPCount;
+    p.lastRGBError = st.lastRGBError; p.lastRGBCount = st.lastRGBCount;
+    if (so3) { p.lastSO3Error = so3->error; p.lastSO3Count = so3->count; p.so3Iterations = so3->iterations; }
+    else { p.lastSO3Error = 0.f; p.lastSO3Count = 0.f; p.so3Iterations = 0; }
+    for (int k = 0; k < 3; ++k) p.incT[k] = st.trt[k];
+    if (jump_limit > 0.f && norm3(f3(st.trt[0], st.trt[1], st.trt[2])) > jump_limit) p.alive = 0;
+    pose_derive(p);
+    *pose = p;
+    if (host_mirror) *host_mirror = p;
+}
+
+void launch_rgbd_iteration(const RgbdLaunch& l, hipStream_t s) {
+    RgbdKArgs a;
+    const IcpLaunch& il = l.icp;
+    a.icp.vc = il.vmap_curr; a.icp.nc = il.nmap_curr; a.icp.vp = il.vmap_prev; a.icp.np = il.nmap_prev;
+    a.icp.W = il.W; a.icp.H = il.H; a.icp.k = il.k; a.icp.distThres = il.distThres; a.icp.angleThres = il.angleThres;
+    a.icp.partials_in = il.partials_in; a.icp.nb_in = il.nblocks_in; a.icp.partials_out = il.partials_out;
+    a.icp.st_in = il.state_in; a.icp.st_out = il.state_out; a.icp.log_out = il.log_out; a.icp.prof_out = nullptr; a.icp.pose_in = il.pose_in; a.icp.so3_in = nullptr;
+    a.L = l.L; a.corres = l.corres; a.rgb_partials_in = l.rgb_partials_in; a.cnt_in = l.cnt_in; a.cnt_out = l.cnt_out;
+    a.icpWeight = l.icpWeight; a.icpOn = l.icpOn; a.rgbOnly = l.rgbOnly; a.level = l.level; a.prev_level = l.prev_level; a.so3_in = l.so3_in;
+    const int nb = icp_grid_blocks(il.W, il.H);
+    hipLaunchKernelGGL(k_rgbd_iter, dim3(nb), dim3(kIcpThreads), 0, s, a);
+    RgbStepKArgs b;
+    b.L = l.L; b.k = il.k; b.level = l.level; b.corres = l.corres; b.cnt_in = l.cnt_out; b.nb = nb; b.st = il.state_out;
+    b.rgbOnly = l.rgbOnly; b.sobelScale = l.sobelScale; b.partials_out = l.rgb_partials_out;
+    hipLaunchKernelGGL(k_rgb_step, dim3(nb), dim3(kIcpThreads), 0, s, b);
+}
+
+void launch_rgbd_finalize(const float* icp_partials, const float* rgb_partials, const int2* cnt, int nb, float icpWeight, int icpOn,
+                          int rgbOnly, int rgbOn, int prev_level, const GNState* st_in, const So3Result* so3, PoseDev* pose,
+                          PoseDev* host_mirror, float* log_out, float jump_limit, hipStream_t s) {
+    hipLaunchKernelGGL(k_rgbd_finalize, dim3(1), dim3(256), 0, s, icp_partials, rgb_partials, cnt, nb, icpWeight, icpOn, rgbOnly, rgbOn,
+                       prev_level, st_in, so3, pose, host_mirror, log_out, jump_limit);
 }
 
 // ------------------------------------------------------------------------------------------------

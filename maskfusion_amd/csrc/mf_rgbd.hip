@@ -1,0 +1,244 @@
+// mf_rgbd.hip -- image-side kernels of the photometric term and the SO(3) pre-alignment.
+//
+// Replaces (reference, relative to /root/reference):
+//   RGBDOdometry::populateRGBDData / initRGBModel / initRGB / initFirstRGB   Core/Utils/RGBDOdometry.cpp:187-225
+//     verticesToDepth, imageBGRToIntensity, pyrDownUcharGauss                  Core/Cuda/cudafuncs.cu:602-639,534-588
+//   computeDerivativeImages                                                   Core/Cuda/cudafuncs.cu:658-718
+//   the SO(3) block of getIncrementalTransformation + so3Step                 RGBDOdometry.cpp:264-324, reduce.cu:999-1202
+//
+// The ten SO(3) iterations (19 200 px at VGA level 2) run inside ONE launch of one 1024-thread workgroup: reduction,
+// 3x3 solve, rotation update and the convergence tests stay in LDS/registers instead of ten {kernel, reduce kernel,
+// sync, D2H, host solve} rounds.
+#pragma clang fp contract(off)  // before the headers: their inline helpers must not be fused either
+
+#include "mf_internal.h"
+#include "mf_rgbd_device.h"
+
+namespace mf {
+
+// ---------------- intensity ----------------
+__global__ __launch_bounds__(256) void k_intensity(const uint8_t* __restrict__ img, int channels, uint8_t* __restrict__ dst, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* p = img + (size_t)i * channels;
+    dst[i] = intensity_of((float)p[0], (float)p[1], (float)p[2]);
+}
+void launch_intensity(const uint8_t* img, int channels, uint8_t* dst, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_intensity, dim3((n + 255) / 256), dim3(256), 0, s, img, channels, dst, n);
+}
+
+// Level 0 of the "last" pyramids of one model: depth from the vertex map initICPModel was given (prediction, or the
+// fill-in where the prediction is empty), intensity from the matching image (written at predict time).
+__global__ __launch_bounds__(256) void k_rgbd_last_l0(const float4* __restrict__ predV, const float* __restrict__ fillDepth,
+                                                      const uint8_t* __restrict__ predGray, const uint8_t* __restrict__ fillGray,
+                                                      const FrameDev* __restrict__ frame, float cutOff, float* __restrict__ depth0,
+                                                      uint8_t* __restrict__ image0, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const bool useFill = fillDepth != nullptr && frame->useFillIn != 0;
+    float z = predV[i].z;
+    if (useFill && z == 0) z = fillDepth[i];                       // fill_vertex.frag:37-53
+    depth0[i] = (z > cutOff || z <= 0) ? qnan() : z;               // verticesToDepthKernel
+    image0[i] = useFill ? fillGray[i] : predGray[i];
+}
+void launch_rgbd_last_l0(const float4* predV, const float* fillDepth, const uint8_t* predGray, const uint8_t* fillGray,
+                         const FrameDev* frame, float* depth0, uint8_t* image0, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_rgbd_last_l0, dim3((n + 255) / 256), dim3(256), 0, s, predV, fillDepth, predGray, fillGray, frame, 6.0f,
+                       depth0, image0, n);  // maxDepthRGB = 6, RGBDOdometry.cpp:34
+}
+
+// ---------------- pyrDownUcharGauss (cudafuncs.cu:534-588; border quirk Q9, zero texels skipped) ----------------
+__device__ __forceinline__ float gauss5w(int r, int c) {
+    const int a = (r == 0 || r == 4) ? 1 : ((r == 2) ? 6 : 4);
+    const int b = (c == 0 || c == 4) ? 1 : ((c == 2) ? 6 : 4);
+    return (float)(a * b);
+}
+__global__ __launch_bounds__(256) void k_pyrdown_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int sw, int sh) {
+    const int dw = sw / 2, dh = sh / 2;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    const int D = 5;
+    const int tx = min(2 * x - D / 2 + D, sw - 1), ty = min(2 * y - D / 2 + D, sh - 1);
+    float sum = 0.f;
+    int count = 0;
+    for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
+        for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
+            const int v = src[cy * sw + cx];
+            if (v > 0) {
+                const float w = gauss5w(ty - cy - 1, tx - cx - 1);
+                sum += (float)v * w;
+                count += (int)w;
+            }
+        }
+    const float r = sum / (float)count;             // 0 / 0 -> NaN -> 0 (cvt semantics of the reference)
+    dst[y * dw + x] = isnan(r) ? (uint8_t)0 : (uint8_t)(int)r;
+}
+void launch_pyrdown_u8(const uint8_t* src, uint8_t* dst, int sw, int sh, hipStream_t s) {
+    dim3 grid((sw / 2 + 63) / 64, (sh / 2 + 3) / 4);
+    hipLaunchKernelGGL(k_pyrdown_u8, grid, dim3(256), 0, s, src, dst, sw, sh);
+}
+
+// ---------------- computeDerivativeImages ----------------
+__global__ __launch_bounds__(256) void k_derivative(const uint8_t* __restrict__ src, int16_t* __restrict__ dx,
+                                                    int16_t* __restrict__ dy, int W, int H) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const float gx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
+    const float gy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
+    float dxVal = 0.f, dyVal = 0.f;
+    int k = 8;
+    for (int j = max(y - 1, 0); j <= min(y + 1, H - 1); ++j)
+        for (int i = max(x - 1, 0); i <= min(x + 1, W - 1); ++i) {
+            const float sv = (float)src[j * W + i];
+            // the kernel index walks backwards over the CLAMPED window (border quirk); selects instead of a dynamically
+            // indexed constant array
+            float wx = 0.f, wy = 0.f;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) { wx = (q == k) ? gx[q] : wx; wy = (q == k) ? gy[q] : wy; }
+            dxVal = fmaf(sv, wx, dxVal);
+            dyVal = fmaf(sv, wy, dyVal);
+            --k;
+        }
+    dx[y * W + x] = (int16_t)dxVal;
+    dy[y * W + x] = (int16_t)dyVal;
+}
+void launch_derivative(const uint8_t* src, int16_t* dx, int16_t* dy, int W, int H, hipStream_t s) {
+    dim3 grid((W + 63) / 64, (H + 3) / 4);
+    hipLaunchKernelGGL(k_derivative, grid, dim3(256), 0, s, src, dx, dy, W, H);
+}
+
+// ---------------- SO(3) pre-alignment: all iterations in one workgroup ----------------
+__device__ __forceinline__ void so3_bases(const double* R, Intr k, float* basis) {  // RGBDOdometry.cpp:290-302
+    const double K[9] = {(double)k.fx, 0, (double)k.cx, 0, (double)k.fy, (double)k.cy, 0, 0, 1};
+    const double Ki[9] = {1.0 / (double)k.fx, 0, -(double)k.cx / (double)k.fx, 0, 1.0 / (double)k.fy, -(double)k.cy / (double)k.fy, 0, 0, 1};
+    double KR[9], H[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) KR[r * 3 + c] = K[r * 3 + 0] * R[0 * 3 + c] + K[r * 3 + 1] * R[1 * 3 + c] + K[r * 3 + 2] * R[2 * 3 + c];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) H[r * 3 + c] = KR[r * 3 + 0] * Ki[0 * 3 + c] + KR[r * 3 + 1] * Ki[1 * 3 + c] + KR[r * 3 + 2] * Ki[2 * 3 + c];
+    for (int q = 0; q < 9; ++q) { basis[q] = (float)H[q]; basis[9 + q] = (float)Ki[q]; basis[18 + q] = (float)KR[q]; }
+}
+
+// Symmetric 3x3 solve.  Eigen's float LDLT (RGBDOdometry.cpp:313) is replaced by the closed form in double, rounded to
+// float: it differs from the float factorisation by rounding only (the oracle keeps the float LDLT).
+__device__ __forceinline__ void solve3(const float* A, const float* b, float* x) {
+    const double a00 = A[0], a01 = A[1], a02 = A[2], a11 = A[4], a12 = A[5], a22 = A[8];
+    const double c00 = a11 * a22 - a12 * a12, c01 = a12 * a02 - a01 * a22, c02 = a01 * a12 - a11 * a02;
+    const double c11 = a00 * a22 - a02 * a02, c12 = a01 * a02 - a00 * a12, c22 = a00 * a11 - a01 * a01;
+    const double det = a00 * c00 + a01 * c01 + a02 * c02;
+    if (!(fabs(det) > 0.0)) { x[0] = x[1] = x[2] = 0.f; return; }
+    const double id = 1.0 / det;
+    x[0] = (float)((c00 * b[0] + c01 * b[1] + c02 * b[2]) * id);
+    x[1] = (float)((c01 * b[0] + c11 * b[1] + c12 * b[2]) * id);
+    x[2] = (float)((c02 * b[0] + c12 * b[1] + c22 * b[2]) * id);
+}
+
+constexpr int kSo3Threads = 1024;
+
+__global__ __launch_bounds__(kSo3Threads) void k_so3_prealign(const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage,
+                                                               int W, int H, Intr k, So3Result* __restrict__ out) {
+    __shared__ float s_basis[27];
+    __shared__ float s_red[(kSo3Threads / 64) * 12];
+    __shared__ int s_stop;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = W * H;
+    // state of the outer loop lives in thread 0
+    double resultR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, lastResultR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    float R_lr[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    float lastError = 3.4028234664e38f / 2, lastCount = 3.4028234664e38f / 2;
+    float so3Error = 0.f, so3Count = 0.f;
+    int iters = 0;
+    for (int it = 0; it < 10; ++it) {
+        if (tid == 0) { so3_bases(resultR, k, s_basis); s_stop = 0; }
+        __syncthreads();
+        float acc[11];
+#pragma unroll
+        for (int q = 0; q < 11; ++q) acc[q] = 0.f;
+        for (int p = tid; p < P; p += kSo3Threads) {
+            const int y = p / W, x = p - y * W;
+            so3_px(lastImage, nextImage, W, H, s_basis, x, y, acc);
+        }
+#pragma unroll
+        for (int q = 0; q < 11; ++q) {
+            float v = acc[q];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) s_red[wave * 12 + q] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float sum[11];
+            for (int q = 0; q < 11; ++q) {
+                float v = 0.f;
+                for (int w = 0; w < kSo3Threads / 64; ++w) v += s_red[w * 12 + q];
+                sum[q] = v;
+            }
+            ++iters;
+            const float jtj[9] = {sum[0], sum[1], sum[2], sum[1], sum[4], sum[5], sum[2], sum[5], sum[7]};
+            const float jtr[3] = {sum[3], sum[6], sum[8]};
+            so3Error = sqrtf(sum[9]) / sum[10];
+            so3Count = sum[10];
+            if (so3Error < lastError && fabsf(lastError - so3Count) < 0.001f) {            // sic (RGBDOdometry.cpp:305)
+                s_stop = 1;
+            } else if (so3Error > lastError + 0.001f) {                                       // diverging, :307-312
+                so3Error = lastError; so3Count = lastCount;
+                for (int q = 0; q < 9; ++q) resultR[q] = lastResultR[q];
+                s_stop = 1;
+            } else {
+                lastError = so3Error; lastCount = so3Count;
+                for (int q = 0; q < 9; ++q) lastResultR[q] = resultR[q];
+                float delta[3];
+                solve3(jtj, jtr, delta);
+                double Rw[3][3];
+                rodrigues_d((double)delta[0], (double)delta[1], (double)delta[2], Rw);
+                float nl[9];
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c)
+                        nl[r * 3 + c] = (float)Rw[r][0] * R_lr[0 * 3 + c] + (float)Rw[r][1] * R_lr[1 * 3 + c] + (float)Rw[r][2] * R_lr[2 * 3 + c];
+                for (int q = 0; q < 9; ++q) { R_lr[q] = nl[q]; resultR[q] = (double)nl[q]; }
+            }
+        }
+        __syncthreads();
+        if (s_stop) break;
+    }
+    if (tid == 0) {
+        for (int q = 0; q < 9; ++q) out->R[q] = resultR[q];
+        out->error = so3Error; out->count = so3Count; out->iterations = iters; out->pad = 0;
+    }
+}
+void launch_so3_prealign(const uint8_t* lastImage2, const uint8_t* nextImage2, int W2, int H2, Intr k2, So3Result* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_so3_prealign, dim3(1), dim3(kSo3Threads), 0, s, lastImage2, nextImage2, W2, H2, k2, out);
+}
+
+// ---------------- stand-alone residual / step (parity tests; the tracking loop uses the fused kernels) ----------------
+__global__ __launch_bounds__(256) void k_rgb_residual_only(const RgbLevel L, const float* __restrict__ krk_kt, RgbCorr* __restrict__ corres,
+                                                           int* __restrict__ sums /*[2]: count, sigma (pre-zeroed)*/) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= L.W * L.H) return;
+    const int y = i / L.W, x = i - y * L.W;
+    float krk[9];
+    for (int q = 0; q < 9; ++q) krk[q] = krk_kt[q];
+    RgbCorr c;
+    const bool ok = rgb_residual_px(L, krk, f3(krk_kt[9], krk_kt[10], krk_kt[11]), x, y, c);
+    corres[i] = c;
+    if (ok) { atomicAdd(&sums[0], 1); atomicAdd(&sums[1], (int)(c.diff * c.diff)); }
+}
+__global__ __launch_bounds__(256) void k_rgb_step_only(const RgbLevel L, const RgbCorr* __restrict__ corres, float sigma, Intr k,
+                                                       float sobelScale, double* __restrict__ out32 /*pre-zeroed*/) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= L.W * L.H) return;
+    const RgbCorr c = corres[i];
+    if (c.u0 < 0) return;
+    float acc[32];
+    for (int q = 0; q < 32; ++q) acc[q] = 0.f;
+    rgb_step_px(L, c, i % L.W, i / L.W, sigma, k, sobelScale, acc);
+    for (int q = 0; q < 29; ++q) atomicAdd(&out32[q], (double)acc[q]);
+}
+void launch_rgb_residual_only(const RgbLevel& L, const float* krk_kt, RgbCorr* corres, int* sums, hipStream_t s) {
+    hipLaunchKernelGGL(k_rgb_residual_only, dim3((L.W * L.H + 255) / 256), dim3(256), 0, s, L, krk_kt, corres, sums);
+}
+void launch_rgb_step_only(const RgbLevel& L, const RgbCorr* corres, float sigma, Intr k, float sobelScale, double* out32, hipStream_t s) {
+    hipLaunchKernelGGL(k_rgb_step_only, dim3((L.W * L.H + 255) / 256), dim3(256), 0, s, L, corres, sigma, k, sobelScale, out32);
+}
+
+}  // namespace mf

@@ -25,6 +25,7 @@
 // kernels within rounding of a plain reading of the shaders (the oracle is built with -ffp-contract=off).
 #pragma clang fp contract(off)
 #include "mf_device.h"
+#include "mf_rgbd_device.h"
 
 namespace mf {
 
@@ -551,7 +552,8 @@ __global__ __launch_bounds__(256) void k_splat_resolve(Surfels src, const PoseDe
                                                        unsigned long long* __restrict__ keys, int W, int H, Intr k,
                                                        float4* __restrict__ predV, float4* __restrict__ predN,
                                                        uchar4* __restrict__ predImage, uint16_t* __restrict__ predTime,
-                                                       FrameDev* __restrict__ frame) {
+                                                       FrameDev* __restrict__ frame, const uint8_t* __restrict__ rgb,
+                                                       uint8_t* __restrict__ predGray, uint8_t* __restrict__ fillGray) {
     const int px = blockIdx.x * 64 + (threadIdx.x & 63);
     const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (px >= W || py >= H) return;
@@ -562,6 +564,10 @@ __global__ __launch_bounds__(256) void k_splat_resolve(Surfels src, const PoseDe
         predV[p] = predN[p] = make_float4(0, 0, 0, 0);
         predImage[p] = make_uchar4(0, 0, 0, 0);
         predTime[p] = 0;
+        // intensity images for the photometric term of the NEXT tracking step (imageBGRToIntensity of the RGB projection,
+        // and of the fill-in image: fill_rgb.frag takes the raw frame where the projection is empty)
+        if (predGray) predGray[p] = 0;
+        if (fillGray && rgb) fillGray[p] = intensity_of((float)rgb[p * 3], (float)rgb[p * 3 + 1], (float)rgb[p * 3 + 2]);
         return;
     }
     const int i = (int)(unsigned)(key & 0xFFFFFFFFull);
@@ -575,15 +581,25 @@ __global__ __launch_bounds__(256) void k_splat_resolve(Surfels src, const PoseDe
     const uchar4 col = make_uchar4((ci >> 16) & 0xFF, (ci >> 8) & 0xFF, ci & 0xFF, 255);
     predImage[p] = col;
     predTime[p] = (uint16_t)(unsigned)c4.z;
+    if (predGray || fillGray) {
+        const uint8_t gv = intensity_of((float)col.x, (float)col.y, (float)col.z);
+        if (predGray) predGray[p] = gv;
+        if (fillGray) {
+            const bool empty = col.x == 0 && col.y == 0 && col.z == 0;
+            fillGray[p] = (empty && rgb) ? intensity_of((float)rgb[p * 3], (float)rgb[p * 3 + 1], (float)rgb[p * 3 + 2]) : gv;
+        }
+    }
     // MaskFusion::requiresFillIn (MaskFusion.cpp:630-648): nearest sample of the 20x down-sampled colour prediction
     if ((px % 20) == 10 && (py % 20) == 10 && px / 20 < W / 20 && py / 20 < H / 20 && col.x > 0 && col.y > 0 && col.z > 0)
         atomicAdd(&frame->cover, 1);
 }
 
 void launch_splat_resolve(Surfels src, const PoseDev* pose, unsigned long long* keys, int W, int H, Intr k, float4* predV,
-                          float4* predN, uchar4* predImage, uint16_t* predTime, FrameDev* frame, hipStream_t s) {
+                          float4* predN, uchar4* predImage, uint16_t* predTime, FrameDev* frame, const uint8_t* rgb,
+                          uint8_t* predGray, uint8_t* fillGray, hipStream_t s) {
     dim3 grid((W + 63) / 64, (H + 3) / 4);
-    hipLaunchKernelGGL(k_splat_resolve, grid, dim3(256), 0, s, src, pose, keys, W, H, k, predV, predN, predImage, predTime, frame);
+    hipLaunchKernelGGL(k_splat_resolve, grid, dim3(256), 0, s, src, pose, keys, W, H, k, predV, predN, predImage, predTime, frame, rgb,
+                       predGray, fillGray);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -31,7 +31,8 @@ class Config(C.Structure):
                 ("fast_odom", C.c_int32), ("so3", C.c_int32), ("pyramid", C.c_int32),
                 ("max_depth_processed", C.c_float), ("outlier_coefficient", C.c_float), ("num_gsurfels", C.c_int32),
                 ("num_osurfels", C.c_int32), ("enable_multiple_models", C.c_int32), ("model_spawn_offset", C.c_int32),
-                ("track_all_models", C.c_int32), ("max_models", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("track_all_models", C.c_int32), ("max_models", C.c_int32), ("rgb_only", C.c_int32),
+                ("reserved", C.c_int32 * 4)]
 
 
 # every symbol declared in include/maskfusion_amd.h (tests/test_abi.py checks the header against this table)
@@ -51,6 +52,16 @@ SYMBOLS = {
     "mf_get_surfel_count": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint32)]),
     "mf_model_state_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "mf_get_icp_stats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "mf_get_track_stats": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "mf_k_intensity": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "mf_k_pyrdown_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "mf_k_derivative_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "mf_k_so3_prealign": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mf_k_rgb_residual": (C.c_int, [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                    C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mf_k_rgb_step": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mf_download_map": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "mf_get_last_fillin": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "mf_model_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),

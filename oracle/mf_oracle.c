@@ -515,6 +515,485 @@ void mfo_track_icp(const float* const curr_v[3], const float* const curr_n[3], c
     if (out_inc16) Rt_to_pose16(trR, trt, out_inc16);
 }
 
+/* =====================================================================================================
+ * a5, a8-a10, a12: photometric term + SO(3) pre-alignment (Core/Utils/RGBDOdometry.cpp, Core/Cuda/reduce.cu,
+ * Core/Cuda/cudafuncs.cu).  Where a float expression feeds an integer truncation / rounding the nvcc-style fused
+ * form (fmaf) is written out explicitly; the HIP kernels use the same form.
+ * ===================================================================================================== */
+/* verticesToDepthKernel, cudafuncs.cu:602-614 (v4: float4 per pixel) */
+void mfo_vertices_to_depth(const float* v4, float* depth, int n, float cutOff) {
+    for (int i = 0; i < n; ++i) {
+        const float z = v4[(size_t)i * 4 + 2];
+        depth[i] = (z > cutOff || z <= 0) ? MFO_NAN : z;
+    }
+}
+
+/* bgr2IntensityKernel, cudafuncs.cu:626-639: int(x * 0.114 + y * 0.299 + z * 0.587) on the first three channels AS STORED
+ * (the frame texture holds R,G,B, so red gets the blue weight -- reproduced). */
+void mfo_image_to_intensity(const uint8_t* img, int channels, uint8_t* dst, int n) {
+    for (int i = 0; i < n; ++i) {
+        const uint8_t* p = img + (size_t)i * channels;
+        const float v = fmaf((float)p[2], 0.587f, fmaf((float)p[1], 0.299f, (float)p[0] * 0.114f));
+        dst[i] = (uint8_t)(int)v;
+    }
+}
+
+/* applyKernel, cudafuncs.cu:658-683 (kernel walked backwards from index 8 over the CLAMPED window -- border quirk) */
+void mfo_derivative_images(const uint8_t* src, int16_t* dx, int16_t* dy, int W, int H) {
+    static const float gx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
+    static const float gy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            float dxVal = 0, dyVal = 0;
+            int k = 8;
+            for (int j = imax(y - 1, 0); j <= imin(y + 1, H - 1); ++j)
+                for (int i = imax(x - 1, 0); i <= imin(x + 1, W - 1); ++i) {
+                    const float s = (float)src[j * W + i];
+                    dxVal = fmaf(s, gx[k], dxVal);
+                    dyVal = fmaf(s, gy[k], dyVal);
+                    --k;
+                }
+            dx[y * W + x] = (int16_t)dxVal;  /* float -> short: truncation (|value| < 470) */
+            dy[y * W + x] = (int16_t)dyVal;
+        }
+}
+
+/* projectPointsKernel, cudafuncs.cu:722-738 */
+void mfo_project_to_cloud(const float* depth, float* cloud3, int W, int H, float fx, float fy, float cx, float cy) {
+    const float invFx = 1.0f / fx, invFy = 1.0f / fy;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const float z = depth[y * W + x];
+            float* c = cloud3 + (size_t)(y * W + x) * 3;
+            c[0] = ((float)x - cx) * z * invFx;
+            c[1] = ((float)y - cy) * z * invFy;
+            c[2] = z;
+        }
+}
+
+/* RGBResidual::getProducts + computeRgbResidual, reduce.cu:812-997 (MASK_RGB_RESIDUAL is not defined upstream: the
+ * mask pyramids are allocated but never consulted).  count / sigmaSum are int32 with wrap-around like the int2 sums. */
+void mfo_rgb_residual(float minScale, const int16_t* dIdx, const int16_t* dIdy, const float* lastDepth,
+                      const float* nextDepth, const uint8_t* lastImage, const uint8_t* nextImage, mfo_dataterm* corres,
+                      float maxDepthDelta, const float* kt, const float* krkinv, int W, int H, int32_t* sigmaSum,
+                      int32_t* count) {
+    uint32_t cnt = 0, sig = 0;
+    for (int i = 0; i < H; ++i)
+        for (int j0 = 0; j0 < W; ++j0) {
+            mfo_dataterm c;
+            memset(&c, 0, sizeof(c));
+            if (j0 < W - 5 && i < H - 1) {
+                int valid = 1;
+                for (int u = imax(i - 2, 0); u < imin(i + 2, H); ++u)
+                    for (int v = imax(j0 - 2, 0); v < imin(j0 + 2, W); ++v) valid = valid && (nextImage[u * W + v] > 0);
+                if (valid) {
+                    const int valx = dIdx[i * W + j0], valy = dIdy[i * W + j0];
+                    const float mTwo = (float)((valx * valx) + (valy * valy));
+                    if (mTwo >= minScale) {
+                        const int y = i, x = j0;
+                        const float d1 = nextDepth[y * W + x];
+                        if (!isnan(d1)) {
+                            const float fx_ = (float)x, fy_ = (float)y;
+                            const float l2 = fmaf(krkinv[7], fy_, krkinv[6] * fx_) + krkinv[8];
+                            const float l0 = fmaf(krkinv[1], fy_, krkinv[0] * fx_) + krkinv[2];
+                            const float l1 = fmaf(krkinv[4], fy_, krkinv[3] * fx_) + krkinv[5];
+                            const float td1 = fmaf(d1, l2, kt[2]);
+                            const int u0 = f2i_rn(fmaf(d1, l0, kt[0]) / td1);
+                            const int v0 = f2i_rn(fmaf(d1, l1, kt[1]) / td1);
+                            if (u0 >= 0 && v0 >= 0 && u0 < W && v0 < H) {
+                                const float d0 = lastDepth[v0 * W + u0];
+                                if (d0 > 0 && fabsf(td1 - d0) <= maxDepthDelta && lastImage[v0 * W + u0] != 0) {
+                                    c.zx = (int16_t)u0; c.zy = (int16_t)v0; c.ox = (int16_t)x; c.oy = (int16_t)y;
+                                    c.diff = (float)nextImage[y * W + x] - (float)lastImage[v0 * W + u0];
+                                    c.valid = 1;
+                                    cnt += 1u;
+                                    sig += (uint32_t)(int32_t)(c.diff * c.diff);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            corres[i * W + j0] = c;
+        }
+    *count = (int32_t)cnt;
+    *sigmaSum = (int32_t)sig;
+}
+
+/* RGBReduction::getProducts + rgbStep, reduce.cu:529-713.  Sums in double, handed back as float like the device. */
+void mfo_rgb_step(const mfo_dataterm* corres, float sigma, const float* cloud3, float fx, float fy, const int16_t* dIdx,
+                  const int16_t* dIdy, float sobelScale, int W, int H, float* A, float* b) {
+    double acc[29];
+    for (int k = 0; k < 29; ++k) acc[k] = 0;
+    for (int i = 0; i < W * H; ++i) {
+        const mfo_dataterm* c = &corres[i];
+        if (!c->valid) continue;
+        float w = sigma + fabsf(c->diff);
+        w = w > 1.1920929e-07f ? 1.0f / w : 1.0f;
+        if (sigma == -1) w = 1;
+        float row[7];
+        row[6] = -w * c->diff;
+        const float* cp = cloud3 + (size_t)(c->zy * W + c->zx) * 3;
+        const float invz = (float)(1.0 / cp[2]);
+        const float dI_dx_val = w * sobelScale * (float)dIdx[c->oy * W + c->ox];
+        const float dI_dy_val = w * sobelScale * (float)dIdy[c->oy * W + c->ox];
+        const float v0 = dI_dx_val * fx * invz;
+        const float v1 = dI_dy_val * fy * invz;
+        const float v2 = -(v0 * cp[0] + v1 * cp[1]) * invz;
+        row[0] = v0; row[1] = v1; row[2] = v2;
+        row[3] = -cp[2] * v1 + cp[1] * v2;
+        row[4] = cp[2] * v0 - cp[0] * v2;
+        row[5] = -cp[1] * v0 + cp[0] * v1;
+        int k = 0;
+        for (int r = 0; r < 7; ++r)
+            for (int cc = r; cc < 7; ++cc) acc[k++] += (double)(row[r] * row[cc]);
+        acc[28] += 1.0;
+    }
+    int shift = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 7; ++j) {
+            const float value = (float)acc[shift++];
+            if (j == 6) b[i] = value;
+            else A[j * 6 + i] = A[i * 6 + j] = value;
+        }
+}
+
+static inline float u8at(const uint8_t* img, int W, int x, int y) { return (float)img[y * W + x]; }
+static inline void so3_gradient(const uint8_t* img, int W, int x, int y, float* gx, float* gy) { /* reduce.cu:1015-1031 */
+    const float actu = u8at(img, W, x, y);
+    float back = u8at(img, W, x - 1, y), fore = u8at(img, W, x + 1, y);
+    *gx = ((back + actu) / 2.0f) - ((fore + actu) / 2.0f);
+    back = u8at(img, W, x, y - 1); fore = u8at(img, W, x, y + 1);
+    *gy = ((back + actu) / 2.0f) - ((fore + actu) / 2.0f);
+}
+
+/* SO3Reduction::getProducts + so3Step, reduce.cu:999-1202.  A: 3x3 row-major, b: 3, residual = {sum r^2, inliers}. */
+void mfo_so3_step(const uint8_t* lastImage, const uint8_t* nextImage, const float* imageBasis, const float* kinv,
+                  const float* krlr, int W, int H, float* A, float* b, float* residual) {
+    double acc[11];
+    for (int k = 0; k < 11; ++k) acc[k] = 0;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const f3 p = f3_make((float)x, (float)y, 1.0f);
+            const f3 wp = m33_mul(imageBasis, p);
+            const int wx = f2i_rn(wp.x / wp.z), wy = f2i_rn(wp.y / wp.z);
+            if (!(wx >= 1 && wx < W - 1 && wy >= 1 && wy < H - 1 && x >= 1 && x < W - 1 && y >= 1 && y < H - 1)) continue;
+            float gnx, gny, glx, gly;
+            so3_gradient(nextImage, W, wx, wy, &gnx, &gny);
+            so3_gradient(lastImage, W, x, y, &glx, &gly);
+            const float gx = (gnx + glx) / 2.0f, gy = (gny + gly) / 2.0f;
+            const f3 point = m33_mul(kinv, p);
+            const float z2 = point.z * point.z;
+            const float a = krlr[0], b_ = krlr[1], c = krlr[2], d = krlr[3], e = krlr[4], f = krlr[5], g = krlr[6], h = krlr[7],
+                        i_ = krlr[8];
+            const float fy_ = (float)y, fx_ = (float)x;
+            const f3 left = f3_make(((point.z * (d * gy + a * gx)) - (gy * g * fy_) - (gx * g * fx_)) / z2,
+                                    ((point.z * (e * gy + b_ * gx)) - (gy * h * fy_) - (gx * h * fx_)) / z2,
+                                    ((point.z * (f * gy + c * gx)) - (gy * i_ * fy_) - (gx * i_ * fx_)) / z2);
+            const f3 jac = f3_cross(left, point);
+            const float row[4] = {jac.x, jac.y, jac.z, -(u8at(nextImage, W, wx, wy) - u8at(lastImage, W, x, y))};
+            int k = 0;
+            for (int r = 0; r < 3; ++r)
+                for (int cc = r; cc < 4; ++cc) acc[k++] += (double)(row[r] * row[cc]);
+            acc[9] += (double)(row[3] * row[3]);
+            acc[10] += 1.0;
+        }
+    int shift = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 4; ++j) {
+            const float value = (float)acc[shift++];
+            if (j == 3) b[i] = value;
+            else A[j * 3 + i] = A[i * 3 + j] = value;
+        }
+    residual[0] = (float)acc[9];
+    residual[1] = (float)acc[10];
+}
+
+/* Eigen::Matrix3f::ldlt().solve() stand-in (RGBDOdometry.cpp:313): float, diagonal pivoting */
+void mfo_ldlt3f_solve(const float* Ain, const float* bin, float* x) {
+    float A[9], b[3];
+    int perm[3] = {0, 1, 2};
+    memcpy(A, Ain, sizeof(A)); memcpy(b, bin, sizeof(b));
+    for (int k = 0; k < 3; ++k) {
+        int p = k;
+        for (int i = k + 1; i < 3; ++i)
+            if (fabsf(A[i * 3 + i]) > fabsf(A[p * 3 + p])) p = i;
+        if (p != k) {
+            for (int j = 0; j < 3; ++j) { float t = A[k * 3 + j]; A[k * 3 + j] = A[p * 3 + j]; A[p * 3 + j] = t; }
+            for (int j = 0; j < 3; ++j) { float t = A[j * 3 + k]; A[j * 3 + k] = A[j * 3 + p]; A[j * 3 + p] = t; }
+            { float t = b[k]; b[k] = b[p]; b[p] = t; }
+            { int t = perm[k]; perm[k] = perm[p]; perm[p] = t; }
+        }
+        const float d = A[k * 3 + k];
+        if (d == 0.f) continue;
+        for (int i = k + 1; i < 3; ++i) {
+            const float l = A[i * 3 + k] / d;
+            for (int j = k + 1; j < 3; ++j) A[i * 3 + j] -= l * A[k * 3 + j];
+            A[i * 3 + k] = l;
+        }
+    }
+    float y[3], z[3];
+    for (int i = 0; i < 3; ++i) {
+        float s = b[i];
+        for (int j = 0; j < i; ++j) s -= A[i * 3 + j] * y[j];
+        y[i] = s;
+    }
+    for (int i = 0; i < 3; ++i) y[i] = (A[i * 3 + i] != 0.f) ? y[i] / A[i * 3 + i] : 0.f;
+    for (int i = 2; i >= 0; --i) {
+        float s = y[i];
+        for (int j = i + 1; j < 3; ++j) s -= A[j * 3 + i] * z[j];
+        z[i] = s;
+    }
+    for (int i = 0; i < 3; ++i) x[perm[i]] = z[i];
+}
+
+static void m33d_mul(const double* a, const double* b, double* out) {
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) out[r * 3 + c] = a[r * 3 + 0] * b[0 * 3 + c] + a[r * 3 + 1] * b[1 * 3 + c] + a[r * 3 + 2] * b[2 * 3 + c];
+}
+static void m33d_inverse(const double* m, double* inv) {
+    const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+    const double det = m[0] * c00 + m[1] * c01 + m[2] * c02, id = 1.0 / det;
+    inv[0] = c00 * id; inv[1] = (m[2] * m[7] - m[1] * m[8]) * id; inv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    inv[3] = c01 * id; inv[4] = (m[0] * m[8] - m[2] * m[6]) * id; inv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    inv[6] = c02 * id; inv[7] = (m[1] * m[6] - m[0] * m[7]) * id; inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+static void k_matrix(double* K, double* Kinv, float fx, float fy, float cx, float cy) {
+    const double k[9] = {fx, 0, cx, 0, fy, cy, 0, 0, 1};
+    memcpy(K, k, sizeof(k));
+    const double ki[9] = {1.0 / fx, 0, -(double)cx / fx, 0, 1.0 / fy, -(double)cy / fy, 0, 0, 1};
+    memcpy(Kinv, ki, sizeof(ki));
+}
+
+/* SO(3) pre-alignment, RGBDOdometry.cpp:264-324 (level-2 images and intrinsics); resultR row-major double out */
+void mfo_so3_prealign(const uint8_t* lastNext2, const uint8_t* next2, int W2, int H2, float fx2, float fy2, float cx2,
+                      float cy2, double* resultR, float* lastSO3Error, float* lastSO3Count, int* iterations_run) {
+    double K[9], Kinv[9];
+    k_matrix(K, Kinv, fx2, fy2, cx2, cy2);
+    for (int k = 0; k < 9; ++k) resultR[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    float R_lr[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    float lastError = 3.4028234664e38f / 2, lastCount = 3.4028234664e38f / 2;
+    double lastResultR[9];
+    memcpy(lastResultR, resultR, sizeof(lastResultR));
+    *lastSO3Error = 0; *lastSO3Count = 0;
+    int it = 0;
+    for (int i = 0; i < 10; ++i) {
+        double tmp[9], hom[9], krl[9];
+        m33d_mul(K, resultR, krl);
+        m33d_mul(krl, Kinv, hom);
+        (void)tmp;
+        float imageBasis[9], kinv[9], krlr[9];
+        for (int k = 0; k < 9; ++k) { imageBasis[k] = (float)hom[k]; kinv[k] = (float)Kinv[k]; krlr[k] = (float)krl[k]; }
+        float jtj[9], jtr[3], residual[2];
+        mfo_so3_step(lastNext2, next2, imageBasis, kinv, krlr, W2, H2, jtj, jtr, residual);
+        ++it;
+        *lastSO3Error = sqrtf(residual[0]) / residual[1];
+        *lastSO3Count = residual[1];
+        if (*lastSO3Error < lastError && fabsf(lastError - *lastSO3Count) < 0.001f) break;  /* sic: error vs count */
+        else if (*lastSO3Error > lastError + 0.001f) {
+            *lastSO3Error = lastError; *lastSO3Count = lastCount;
+            memcpy(resultR, lastResultR, sizeof(lastResultR));
+            break;
+        }
+        lastError = *lastSO3Error; lastCount = *lastSO3Count;
+        memcpy(lastResultR, resultR, sizeof(lastResultR));
+        float delta[3];
+        mfo_ldlt3f_solve(jtj, jtr, delta);
+        const double dd[3] = {delta[0], delta[1], delta[2]};
+        double rotUpdate[9];
+        mfo_rodrigues(dd, rotUpdate);
+        float ru[9], nl[9];
+        for (int k = 0; k < 9; ++k) ru[k] = (float)rotUpdate[k];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) nl[r * 3 + c] = ru[r * 3 + 0] * R_lr[0 * 3 + c] + ru[r * 3 + 1] * R_lr[1 * 3 + c] + ru[r * 3 + 2] * R_lr[2 * 3 + c];
+        memcpy(R_lr, nl, sizeof(nl));
+        for (int k = 0; k < 9; ++k) resultR[k] = R_lr[k];
+    }
+    if (iterations_run) *iterations_run = it;
+}
+
+/* RGBDOdometry::getIncrementalTransformation (RGBDOdometry.cpp:227-497), all branches.
+ * in->lastDepth/nextDepth/lastImage/nextImage: 3-level pyramids (populateRGBDData); lastNextImage2: level-2 intensity
+ * of the previous frame (so3).  Fills the derivative images / cloud scratch itself. */
+void mfo_track_rgbd(const float* const curr_v[3], const float* const curr_n[3], const float* const prev_v[3],
+                    const float* const prev_n[3], const mfo_rgbd_inputs* in, int W, int H, float fx, float fy, float cx,
+                    float cy, const mfo_track_opts* o, float* R, float* t, float* out_inc16, mfo_track_stats* st) {
+    const int icp = !o->rgbOnly && o->icpWeight > 0;
+    const int rgb = o->rgbOnly || o->icpWeight < 100;
+    float Rprev[9], tprev[3], Rcurr[9], tcurr[3], Rprev_inv[9];
+    memcpy(Rprev, R, sizeof(Rprev)); memcpy(tprev, t, sizeof(tprev));
+    memcpy(Rcurr, R, sizeof(Rcurr)); memcpy(tcurr, t, sizeof(tcurr));
+    memset(st, 0, sizeof(*st));
+    const float sobelScale = (float)(1.0 / 8.0);      /* 1 / 2^sobelSize, RGBDOdometry.cpp:31-32 */
+    const float maxDepthDeltaRGB = 0.07f;              /* :33 */
+    const float minGrad[3] = {5.f, 3.f, 1.f};          /* :102-105 */
+    int16_t* dIdx[3] = {0, 0, 0}; int16_t* dIdy[3] = {0, 0, 0};
+    float* cloud = NULL; mfo_dataterm* corres = NULL;
+    if (rgb) {
+        for (int i = 0; i < 3; ++i) {
+            const int lp = (W >> i) * (H >> i);
+            dIdx[i] = (int16_t*)malloc(sizeof(int16_t) * lp); dIdy[i] = (int16_t*)malloc(sizeof(int16_t) * lp);
+            mfo_derivative_images(in->nextImage[i], dIdx[i], dIdy[i], W >> i, H >> i);
+        }
+        cloud = (float*)malloc(sizeof(float) * 3 * W * H);
+        corres = (mfo_dataterm*)malloc(sizeof(mfo_dataterm) * W * H);
+    }
+    double resultR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (o->so3)
+        mfo_so3_prealign(in->lastNextImage2, in->nextImage[2], W >> 2, H >> 2, fx / 4, fy / 4, cx / 4, cy / 4, resultR,
+                         &st->lastSO3Error, &st->lastSO3Count, &st->so3Iterations);
+    int iterations[3];
+    iterations[0] = o->fastOdom ? 3 : 10;
+    iterations[1] = o->pyramid ? 5 : 0;
+    iterations[2] = o->pyramid ? 4 : 0;
+    m33_inverse(Rprev, Rprev_inv);
+    double resultRt[16];
+    for (int k = 0; k < 16; ++k) resultRt[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    if (o->so3)
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) resultRt[r * 4 + c] = resultR[r * 3 + c];
+    float trR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, trt[3] = {0, 0, 0};
+    for (int i = 2; i >= 0; --i) {
+        const int div = 1 << i;
+        const float lfx = fx / div, lfy = fy / div, lcx = cx / div, lcy = cy / div;
+        const int lw = W >> i, lh = H >> i;
+        if (rgb) mfo_project_to_cloud(in->lastDepth[i], cloud, lw, lh, lfx, lfy, lcx, lcy);
+        double K[9], Kinv[9];
+        k_matrix(K, Kinv, lfx, lfy, lcx, lcy);
+        st->lastRGBError = 3.4028234664e38f;
+        for (int j = 0; j < iterations[i]; ++j) {
+            /* Rt = resultRt.inverse() (rigid: general inverse of the 3x3 block, -Rinv * t) */
+            double Rr[9], Ri[9], ti[3];
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) Rr[r * 3 + c] = resultRt[r * 4 + c];
+            m33d_inverse(Rr, Ri);
+            for (int r = 0; r < 3; ++r)
+                ti[r] = -(Ri[r * 3 + 0] * resultRt[3] + Ri[r * 3 + 1] * resultRt[7] + Ri[r * 3 + 2] * resultRt[11]);
+            double KR[9], KRK[9];
+            m33d_mul(K, Ri, KR);
+            m33d_mul(KR, Kinv, KRK);
+            float krkInv[9], kt[3];
+            for (int k = 0; k < 9; ++k) krkInv[k] = (float)KRK[k];
+            for (int r = 0; r < 3; ++r) kt[r] = (float)(K[r * 3 + 0] * ti[0] + K[r * 3 + 1] * ti[1] + K[r * 3 + 2] * ti[2]);
+            int32_t sigma = 0, rgbSize = 0;
+            if (rgb)
+                mfo_rgb_residual((float)(pow(minGrad[i], 2.0) / pow(sobelScale, 2.0)), dIdx[i], dIdy[i], in->lastDepth[i],
+                                 in->nextDepth[i], in->lastImage[i], in->nextImage[i], corres, maxDepthDeltaRGB, kt, krkInv,
+                                 lw, lh, &sigma, &rgbSize);
+            const float tmpError = (float)(sqrt((double)sigma) / (double)rgbSize);
+            float sigmaVal = (tmpError == 0) ? 1.f : (float)rgbSize;
+            if (o->rgbOnly && tmpError > st->lastRGBError) break;
+            st->lastRGBError = tmpError;
+            st->lastRGBCount = (float)rgbSize;
+            if (o->rgbOnly) sigmaVal = -1;
+            float A_icp[36], b_icp[6], residual[2] = {0, 0};
+            memset(A_icp, 0, sizeof(A_icp)); memset(b_icp, 0, sizeof(b_icp));
+            if (icp) {
+                mfo_icp_step(Rcurr, tcurr, curr_v[i], curr_n[i], Rprev_inv, tprev, lfx, lfy, lcx, lcy, prev_v[i], prev_n[i],
+                             o->distThresh, o->angleThresh, lw, lh, A_icp, b_icp, residual);
+                st->lastICPError = sqrtf(residual[0]) / residual[1];
+                st->lastICPCount = residual[1];
+            }
+            float A_rgbd[36], b_rgbd[6];
+            memset(A_rgbd, 0, sizeof(A_rgbd)); memset(b_rgbd, 0, sizeof(b_rgbd));
+            if (rgb) mfo_rgb_step(corres, sigmaVal, cloud, lfx, lfy, dIdx[i], dIdy[i], sobelScale, lw, lh, A_rgbd, b_rgbd);
+            double dA[36], db[6], x[6];
+            if (icp && rgb) {
+                const double w = o->icpWeight;
+                for (int k = 0; k < 36; ++k) dA[k] = (double)A_rgbd[k] + w * w * (double)A_icp[k];
+                for (int k = 0; k < 6; ++k) db[k] = (double)b_rgbd[k] + w * (double)b_icp[k];
+            } else if (icp) {
+                for (int k = 0; k < 36; ++k) dA[k] = A_icp[k];
+                for (int k = 0; k < 6; ++k) db[k] = b_icp[k];
+            } else {
+                for (int k = 0; k < 36; ++k) dA[k] = A_rgbd[k];
+                for (int k = 0; k < 6; ++k) db[k] = b_rgbd[k];
+            }
+            mfo_ldlt_solve(dA, db, x, 6);
+            mfo_update_se3(resultRt, x);
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c) trR[r * 3 + c] = (float)resultRt[r * 4 + c];
+                trt[r] = (float)resultRt[r * 4 + 3];
+            }
+            float iR[9], it3[3];
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) iR[r * 3 + c] = trR[c * 3 + r];
+            f3 itv = m33_mul(iR, f3_make(trt[0], trt[1], trt[2]));
+            it3[0] = -itv.x; it3[1] = -itv.y; it3[2] = -itv.z;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c)
+                    Rcurr[r * 3 + c] = Rprev[r * 3 + 0] * iR[0 * 3 + c] + Rprev[r * 3 + 1] * iR[1 * 3 + c] + Rprev[r * 3 + 2] * iR[2 * 3 + c];
+            f3 tv = m33_mul(Rprev, f3_make(it3[0], it3[1], it3[2]));
+            tcurr[0] = tv.x + tprev[0]; tcurr[1] = tv.y + tprev[1]; tcurr[2] = tv.z + tprev[2];
+            st->iterationsRun++;
+        }
+    }
+    if (rgb) {
+        const float dx = tcurr[0] - tprev[0], dy = tcurr[1] - tprev[1], dz = tcurr[2] - tprev[2];
+        if (sqrtf(dx * dx + dy * dy + dz * dz) > 0.3f) {  /* RGBDOdometry.cpp:477-481 */
+            memcpy(Rcurr, Rprev, sizeof(Rprev)); memcpy(tcurr, tprev, sizeof(tprev));
+            const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            memcpy(trR, I, sizeof(I)); trt[0] = trt[1] = trt[2] = 0;
+            st->rejected = 1;
+        }
+    }
+    memcpy(R, Rcurr, sizeof(Rcurr)); memcpy(t, tcurr, sizeof(tcurr));
+    if (out_inc16) Rt_to_pose16(trR, trt, out_inc16);
+    for (int i = 0; i < 3; ++i) { free(dIdx[i]); free(dIdy[i]); }
+    free(cloud); free(corres);
+}
+
+/* RGBDOdometry::populateRGBDData (RGBDOdometry.cpp:187-204) without the (unused) mask pyramid.  v4: the vertex map that
+ * initICPModel copied into vmaps_tmp (Q1: BOTH the "last" and the "next" depth come from it); img/channels: the image. */
+void mfo_populate_rgbd(const float* v4, const uint8_t* img, int channels, int W, int H, float* depth[3], uint8_t* image[3]) {
+    mfo_vertices_to_depth(v4, depth[0], W * H, 6.0f);  /* maxDepthRGB, RGBDOdometry.cpp:34 */
+    for (int i = 0; i + 1 < 3; ++i) mfo_pyrdown_gauss_f(depth[i], depth[i + 1], W >> i, H >> i);
+    mfo_image_to_intensity(img, channels, image[0], W * H);
+    for (int i = 0; i + 1 < 3; ++i) mfo_pyrdown_gauss_u8(image[i], image[i + 1], W >> i, H >> i);
+}
+
+/* ---- per-context scratch for populateRGBDData + the per-model "lastNextImage" pyramid (RGBDOdometry.h:120-135) ---- */
+typedef struct { float* lastDepth[3]; uint8_t* lastImage[3]; uint8_t* nextImage[3]; } rgbd_scratch;
+static void pyr_u8_alloc(uint8_t* p[3], int W, int H) { for (int i = 0; i < 3; ++i) p[i] = (uint8_t*)calloc((size_t)(W >> i) * (H >> i), 1); }
+static void pyr_u8_free(uint8_t* p[3]) { for (int i = 0; i < 3; ++i) { free(p[i]); p[i] = NULL; } }
+static void rgbd_scratch_alloc(rgbd_scratch* r, int W, int H) {
+    for (int i = 0; i < 3; ++i) r->lastDepth[i] = (float*)calloc((size_t)(W >> i) * (H >> i), sizeof(float));
+    pyr_u8_alloc(r->lastImage, W, H); pyr_u8_alloc(r->nextImage, W, H);
+}
+static void rgbd_scratch_free(rgbd_scratch* r) {
+    for (int i = 0; i < 3; ++i) free(r->lastDepth[i]);
+    pyr_u8_free(r->lastImage); pyr_u8_free(r->nextImage);
+}
+/* RGBDOdometry::initFirstRGB, RGBDOdometry.cpp:216-225 */
+static void first_rgb(const uint8_t* rgb, int W, int H, uint8_t* lastNext[3]) {
+    mfo_image_to_intensity(rgb, 3, lastNext[0], W * H);
+    for (int i = 0; i + 1 < 3; ++i) mfo_pyrdown_gauss_u8(lastNext[i], lastNext[i + 1], W >> i, H >> i);
+}
+/* Model::initICP's RGB half (Model.cpp:391-409) + getIncrementalTransformation + the lastNextImage swap (:483-487).
+ * v4src / lastImg: what initICPModel / initRGBModel were given (prediction, or fill-in when doFillIn). */
+static void track_model(const mfo_config* g, rgbd_scratch* rs, const float* const cv[3], const float* const cn[3],
+                        const float* const pv[3], const float* const pn[3], const float* v4src, const uint8_t* lastImgRGBA,
+                        const uint8_t* rgb, uint8_t* lastNext[3], float* R, float* t, float* inc16, mfo_track_stats* st) {
+    const int W = g->W, H = g->H;
+    mfo_track_opts o;
+    o.pyramid = g->pyramid; o.fastOdom = g->fastOdom; o.so3 = g->so3; o.rgbOnly = g->rgbOnly; o.icpWeight = g->icpWeight;
+    o.distThresh = 0.10f; o.angleThresh = sinf(20.f * 3.14159254f / 180.f); /* RGBDOdometry.h:35-36 */
+    /* initRGBModel then initRGB: both read vmaps_tmp (Q1) -> nextDepth == lastDepth */
+    mfo_populate_rgbd(v4src, lastImgRGBA, 4, W, H, rs->lastDepth, rs->lastImage);
+    mfo_image_to_intensity(rgb, 3, rs->nextImage[0], W * H);
+    for (int i = 0; i + 1 < 3; ++i) mfo_pyrdown_gauss_u8(rs->nextImage[i], rs->nextImage[i + 1], W >> i, H >> i);
+    mfo_rgbd_inputs in;
+    for (int i = 0; i < 3; ++i) {
+        in.lastDepth[i] = rs->lastDepth[i]; in.nextDepth[i] = rs->lastDepth[i];
+        in.lastImage[i] = rs->lastImage[i]; in.nextImage[i] = rs->nextImage[i];
+    }
+    in.lastNextImage2 = lastNext[2];
+    mfo_track_rgbd(cv, cn, pv, pn, &in, W, H, g->fx, g->fy, g->cx, g->cy, &o, R, t, inc16, st);
+    if (o.so3)
+        for (int i = 0; i < 3; ++i) memcpy(lastNext[i], rs->nextImage[i], (size_t)(W >> i) * (H >> i));
+}
+
 /* ------------------------------------------------------------------------------------------------
  * surfel helpers (Core/Shaders/color_encoding.glsl, surfels.glsl)
  * ---------------------------------------------------------------------------------------------- */
@@ -1103,6 +1582,7 @@ struct mfo_ctx {
     float lastICPError, lastICPCount;
     int lastFillIn;
     double tms[8];
+    rgbd_scratch rs; uint8_t* lastNext[3]; mfo_track_stats stats;
 };
 
 void mfo_default_config(mfo_config* c, int W, int H, float fx, float fy, float cx, float cy) {
@@ -1150,11 +1630,13 @@ mfo_ctx* mfo_create(const mfo_config* cfg) {
     x->cand_op = (uint8_t*)calloc(maxc, 1);
     x->cand_best = (int32_t*)calloc(maxc, sizeof(int32_t));
     x->cand_rec = (float*)calloc((size_t)maxc * 12, sizeof(float));
+    rgbd_scratch_alloc(&x->rs, W, H); pyr_u8_alloc(x->lastNext, W, H);
     return x;
 }
 
 void mfo_destroy(mfo_ctx* x) {
     if (!x) return;
+    rgbd_scratch_free(&x->rs); pyr_u8_free(x->lastNext);
     free(x->surf[0]); free(x->surf[1]); free(x->rgb); free(x->depth); free(x->depthF); free(x->mask);
     for (int i = 0; i < 3; ++i) { free(x->depthPyr[i]); free(x->vmap[i]); free(x->nmap[i]); free(x->vmap_g[i]); free(x->nmap_g[i]); }
     free(x->index); free(x->ivc); free(x->ict); free(x->inr);
@@ -1189,6 +1671,7 @@ int mfo_process_frame(mfo_ctx* x, const uint8_t* rgb, const float* depth, float 
         x->cur = 0;
         x->count = mfo_init_surfels(&x->cam, x->rgb, x->depth, x->depthF, x->tick, g->maxDepthProcessed,
                                     x->surf[0], g->capacity);
+        first_rgb(x->rgb, W, H, x->lastNext);             /* initFirstRGB, :238 */
     } else {
         /* Model::generateCUDATextures(depthFiltered, mask, K, depthCutoff), Model.cpp:350-389 */
         t0 = now_ms();
@@ -1221,15 +1704,14 @@ int mfo_process_frame(mfo_ctx* x, const uint8_t* rgb, const float* depth, float 
         x->tms[1] += now_ms() - t0;
 
         t0 = now_ms();
-        mfo_track_opts o;
-        o.pyramid = g->pyramid; o.fastOdom = g->fastOdom; o.so3 = 0; o.rgbOnly = 0; o.icpWeight = g->icpWeight;
-        o.distThresh = 0.10f; o.angleThresh = sinf(20.f * 3.14159254f / 180.f); /* RGBDOdometry.h:35-36 */
         const float* cv[3] = {x->vmap[0], x->vmap[1], x->vmap[2]};
         const float* cn[3] = {x->nmap[0], x->nmap[1], x->nmap[2]};
         const float* pv[3] = {x->vmap_g[0], x->vmap_g[1], x->vmap_g[2]};
         const float* pn[3] = {x->nmap_g[0], x->nmap_g[1], x->nmap_g[2]};
-        mfo_track_icp(cv, cn, pv, pn, W, H, g->fx, g->fy, g->cx, g->cy, &o, R, t, NULL, &x->lastICPError,
-                      &x->lastICPCount, NULL);
+        /* frameToFrameRGB = false: initRGBModel(doFillIn ? fill-in image : RGB projection), Model.cpp:395-401 */
+        track_model(g, &x->rs, cv, cn, pv, pn, doFillIn ? x->fillVertex : x->predVertex, doFillIn ? x->fillImage : x->predImage,
+                    x->rgb, x->lastNext, R, t, NULL, &x->stats);
+        x->lastICPError = x->stats.lastICPError; x->lastICPCount = x->stats.lastICPCount;
         Rt_to_pose16(R, t, x->pose);
         x->tms[2] += now_ms() - t0;
 
@@ -1273,6 +1755,7 @@ int mfo_get_count(const mfo_ctx* x) { return x->count; }
 int mfo_get_tick(const mfo_ctx* x) { return x->tick; }
 const float* mfo_get_surfels(const mfo_ctx* x) { return x->surf[x->cur]; }
 void mfo_get_icp_stats(const mfo_ctx* x, float* e, float* c) { *e = x->lastICPError; *c = x->lastICPCount; }
+void mfo_get_track_stats(const mfo_ctx* x, mfo_track_stats* out) { *out = x->stats; }
 void mfo_get_timings(const mfo_ctx* x, double* ms8) { memcpy(ms8, x->tms, sizeof(x->tms)); }
 const float* mfo_dbg_depthF(const mfo_ctx* x) { return x->depthF; }
 const float* mfo_dbg_pred_vertex(const mfo_ctx* x) { return x->predVertex; }
@@ -1569,6 +2052,7 @@ typedef struct {
     float* surf[2];
     uint8_t* predImage; float* predVertex; float* predNormal; uint16_t* predTime;
     float lastICPError, lastICPCount;
+    uint8_t* lastNext[3];
 } mm_model;
 
 struct mfo_mm {
@@ -1582,6 +2066,7 @@ struct mfo_mm {
     int32_t* index; float* ivc; float* ict; float* inr;
     uint8_t* fillImage; float* fillVertex; float* fillNormal;
     uint8_t* cand_op; int32_t* cand_best; float* cand_rec; int n_cand;
+    rgbd_scratch rs;
     float* edge; uint8_t* binEdge; uint8_t* ucharBuf; uint8_t* projIDs; uint8_t* ignoreMap; uint8_t* fullSeg;
 };
 
@@ -1621,8 +2106,10 @@ static void mm_model_init(mfo_mm* x, mm_model* m, int id, float confThr, int cap
     m->predVertex = (float*)calloc((size_t)P * 4, sizeof(float));
     m->predNormal = (float*)calloc((size_t)P * 4, sizeof(float));
     m->predTime = (uint16_t*)calloc(P, sizeof(uint16_t));
+    pyr_u8_alloc(m->lastNext, x->cam.W, x->cam.H);
 }
 static void mm_model_free(mm_model* m) {
+    pyr_u8_free(m->lastNext);
     free(m->surf[0]); free(m->surf[1]); free(m->predImage); free(m->predVertex); free(m->predNormal); free(m->predTime);
 }
 
@@ -1655,6 +2142,7 @@ mfo_mm* mfo_mm_create(const mfo_mm_config* cfg) {
     x->cand_rec = (float*)calloc((size_t)maxc * 12, sizeof(float));
     x->edge = (float*)calloc(P, sizeof(float)); x->binEdge = (uint8_t*)calloc(P, 1); x->ucharBuf = (uint8_t*)calloc(P, 1);
     x->projIDs = (uint8_t*)calloc(P, 1); x->ignoreMap = (uint8_t*)calloc(P, 1); x->fullSeg = (uint8_t*)calloc(P, 1);
+    rgbd_scratch_alloc(&x->rs, W, H);
     return x;
 }
 
@@ -1666,6 +2154,7 @@ void mfo_mm_destroy(mfo_mm* x) {
     free(x->index); free(x->ivc); free(x->ict); free(x->inr); free(x->fillImage); free(x->fillVertex); free(x->fillNormal);
     free(x->cand_op); free(x->cand_best); free(x->cand_rec);
     free(x->edge); free(x->binEdge); free(x->ucharBuf); free(x->projIDs); free(x->ignoreMap); free(x->fullSeg);
+    rgbd_scratch_free(&x->rs);
     free(x);
 }
 
@@ -1685,14 +2174,14 @@ static float mm_track(mfo_mm* x, mm_model* m, int allowFillIn) {
     pose16_to_Rt(m->pose, R, t);
     for (int i = 0; i < 3; ++i)
         mfo_transform_maps(x->vmap_g[i], x->nmap_g[i], R, t, x->vmap_g[i], x->nmap_g[i], W >> i, H >> i);
-    mfo_track_opts o;
-    o.pyramid = g->pyramid; o.fastOdom = g->fastOdom; o.so3 = 0; o.rgbOnly = 0; o.icpWeight = g->icpWeight;
-    o.distThresh = 0.10f; o.angleThresh = sinf(20.f * 3.14159254f / 180.f);
     const float* cv[3] = {x->vmap[0], x->vmap[1], x->vmap[2]};
     const float* cn[3] = {x->nmap[0], x->nmap[1], x->nmap[2]};
     const float* pv[3] = {x->vmap_g[0], x->vmap_g[1], x->vmap_g[2]};
     const float* pn[3] = {x->nmap_g[0], x->nmap_g[1], x->nmap_g[2]};
-    mfo_track_icp(cv, cn, pv, pn, W, H, g->fx, g->fy, g->cx, g->cy, &o, R, t, inc, &m->lastICPError, &m->lastICPCount, NULL);
+    mfo_track_stats st;
+    track_model(g, &x->rs, cv, cn, pv, pn, doFillIn ? x->fillVertex : m->predVertex, doFillIn ? x->fillImage : m->predImage,
+                x->rgb, m->lastNext, R, t, inc, &st);
+    m->lastICPError = st.lastICPError; m->lastICPCount = st.lastICPCount;
     Rt_to_pose16(R, t, m->pose);
     return sqrtf(inc[12] * inc[12] + inc[13] * inc[13] + inc[14] * inc[14]);
 }
@@ -1730,6 +2219,7 @@ int mfo_mm_process_frame(mfo_mm* x, const uint8_t* rgb, const float* depth, cons
     if (x->tick == 1) {
         bg->cur = 0;
         bg->count = mfo_init_surfels(&x->cam, x->rgb, x->depth, x->depthF, x->tick, g->maxDepthProcessed, bg->surf[0], bg->cap);
+        first_rgb(x->rgb, W, H, bg->lastNext);
     } else {
         memcpy(x->depthPyr[0], x->depthF, sizeof(float) * P);
         for (int i = 1; i < 3; ++i) mfo_pyrdown_gauss_f(x->depthPyr[i - 1], x->depthPyr[i], W >> (i - 1), H >> (i - 1));
@@ -1793,6 +2283,7 @@ int mfo_mm_process_frame(mfo_mm* x, const uint8_t* rgb, const float* depth, cons
                 mat4_mul_cm(nm->pose, ginv, nm->initialC2Winv);
                 nm->isStatic = 1;
                 nm->classID = newClass;
+                first_rgb(x->rgb, W, H, nm->lastNext);  /* spawnObjectModel: initFirstRGB, :680 */
                 x->spawnOffset = 0;
                 x->nModels++;
             } else hasNew = 0;

@@ -71,7 +71,7 @@ void mfo_update_se3(double* resultRt, const double* x6);
 typedef struct {
     int   pyramid;      /* 1 */
     int   fastOdom;     /* 0 */
-    int   so3;          /* 1 (only used when rgb term is on) */
+    int   so3;          /* 1: SO(3) photometric pre-alignment at level 2 */
     int   rgbOnly;      /* 0 */
     float icpWeight;    /* 10 core default, 20 GUI; >=100 => ICP only */
     float distThresh;   /* 0.10 */
@@ -96,6 +96,47 @@ void mfo_track_icp(const float* const curr_v[3], const float* const curr_n[3],
                    int W, int H, float fx, float fy, float cx, float cy,
                    const mfo_track_opts* opts, float* R, float* t, float* out_inc16,
                    float* lastICPError, float* lastICPCount, mfo_track_log* log);
+
+/* ---------------- photometric term + SO(3) pre-alignment (a5, a8-a10, a12) ---------------- */
+typedef struct { int16_t zx, zy, ox, oy; float diff; int32_t valid; } mfo_dataterm;   /* DataTerm, types.cuh:75-81 */
+typedef struct {
+    const float* lastDepth[3]; const float* nextDepth[3];       /* populateRGBDData pyramids (NaN = invalid) */
+    const uint8_t* lastImage[3]; const uint8_t* nextImage[3];
+    const uint8_t* lastNextImage2;                               /* level-2 intensity of the previous frame (so3) */
+} mfo_rgbd_inputs;
+typedef struct {
+    float lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count;
+    int so3Iterations, iterationsRun, rejected;
+} mfo_track_stats;
+/* cudafuncs.cu:602-614 */
+void mfo_vertices_to_depth(const float* v4, float* depth, int n, float cutOff);
+/* cudafuncs.cu:626-639; channels = 3 (frame) or 4 (predicted / fill-in image) */
+void mfo_image_to_intensity(const uint8_t* img, int channels, uint8_t* dst, int n);
+/* cudafuncs.cu:658-718 */
+void mfo_derivative_images(const uint8_t* src, int16_t* dx, int16_t* dy, int W, int H);
+/* cudafuncs.cu:722-751; cloud3: 3 floats per pixel */
+void mfo_project_to_cloud(const float* depth, float* cloud3, int W, int H, float fx, float fy, float cx, float cy);
+/* reduce.cu:774-997 */
+void mfo_rgb_residual(float minScale, const int16_t* dIdx, const int16_t* dIdy, const float* lastDepth,
+                      const float* nextDepth, const uint8_t* lastImage, const uint8_t* nextImage, mfo_dataterm* corres,
+                      float maxDepthDelta, const float* kt, const float* krkinv, int W, int H, int32_t* sigmaSum,
+                      int32_t* count);
+/* reduce.cu:529-713; A 6x6 row-major, b 6 */
+void mfo_rgb_step(const mfo_dataterm* corres, float sigma, const float* cloud3, float fx, float fy, const int16_t* dIdx,
+                  const int16_t* dIdy, float sobelScale, int W, int H, float* A, float* b);
+/* reduce.cu:999-1202; A 3x3 row-major, b 3, residual {sum r^2, inliers} */
+void mfo_so3_step(const uint8_t* lastImage, const uint8_t* nextImage, const float* imageBasis, const float* kinv,
+                  const float* krlr, int W, int H, float* A, float* b, float* residual);
+void mfo_ldlt3f_solve(const float* A, const float* b, float* x);
+/* RGBDOdometry.cpp:264-324 */
+void mfo_so3_prealign(const uint8_t* lastNext2, const uint8_t* next2, int W2, int H2, float fx2, float fy2, float cx2,
+                      float cy2, double* resultR, float* lastSO3Error, float* lastSO3Count, int* iterations_run);
+/* RGBDOdometry.cpp:227-497, every branch (icp / rgb / rgbOnly / so3) */
+void mfo_track_rgbd(const float* const curr_v[3], const float* const curr_n[3], const float* const prev_v[3],
+                    const float* const prev_n[3], const mfo_rgbd_inputs* in, int W, int H, float fx, float fy, float cx,
+                    float cy, const mfo_track_opts* opts, float* R, float* t, float* out_inc16, mfo_track_stats* stats);
+/* RGBDOdometry.cpp:187-204 */
+void mfo_populate_rgbd(const float* v4, const uint8_t* img, int channels, int W, int H, float* depth[3], uint8_t* image[3]);
 
 /* ---------------- surfels (a13..a18, a21) ---------------- */
 typedef struct {
@@ -168,6 +209,7 @@ typedef struct {
     float outlierCoeff;       /* 0.9 core / 0.1 GUI */
     int   fastOdom, pyramid, so3;
     int   capacity;           /* max surfels */
+    int   rgbOnly;            /* 0 */
 } mfo_config;
 
 void     mfo_default_config(mfo_config* c, int W, int H, float fx, float fy, float cx, float cy);
@@ -180,6 +222,7 @@ int      mfo_get_count(const mfo_ctx* ctx);
 int      mfo_get_tick(const mfo_ctx* ctx);
 const float* mfo_get_surfels(const mfo_ctx* ctx);
 void     mfo_get_icp_stats(const mfo_ctx* ctx, float* err, float* count);
+void     mfo_get_track_stats(const mfo_ctx* ctx, mfo_track_stats* out);
 /* per-stage wall-clock (ms) accumulated since create: order = preprocess, odomInit, odom, indexMap, fuseData,
  * fuseUpdate, clean, predict */
 void     mfo_get_timings(const mfo_ctx* ctx, double* ms8);

@@ -52,7 +52,8 @@ class Config(C.Structure):
     _fields_ = [("W", C.c_int), ("H", C.c_int), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
                 ("cy", C.c_float), ("timeDelta", C.c_int), ("confGlobal", C.c_float), ("depthCutoff", C.c_float),
                 ("icpWeight", C.c_float), ("maxDepthProcessed", C.c_float), ("outlierCoeff", C.c_float),
-                ("fastOdom", C.c_int), ("pyramid", C.c_int), ("so3", C.c_int), ("capacity", C.c_int)]
+                ("fastOdom", C.c_int), ("pyramid", C.c_int), ("so3", C.c_int), ("capacity", C.c_int),
+                ("rgbOnly", C.c_int)]
 
 
 def lib():

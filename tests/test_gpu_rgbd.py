@@ -1,0 +1,179 @@
+"""-m gpu parity of the photometric term and the SO(3) pre-alignment through the C ABI.
+
+Integer outputs (intensity, pyramids, derivative images, correspondences, count / sum diff^2) must be bit-exact; float
+reductions are compared with a relative tolerance (the oracle accumulates in double, the device in float partials)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CORR = np.dtype([("u0", np.int16), ("v0", np.int16), ("diff", np.float32)])
+
+
+def _frames(n, W=320, H=240):
+    from maskfusion_amd import synth
+    f = 528.0 * W / 640.0
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=False)
+    return st, [st.frame(k) for k in range(n)]
+
+
+def test_intensity_pyramid_derivatives(hip, oracle):
+    from oracle import mfo_rgbd
+    from gpu_util import dev, empty, host
+    import torch
+    L = hip
+    rng = np.random.default_rng(3)
+    W, H = 320, 240
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    img[40:60, 100:180] = 0                      # an empty region (zero texels are skipped by the pyramid)
+    g = np.tile(np.arange(256, dtype=np.uint8), 3)[:W]
+    img[0, :, :] = g[:, None]                    # grey ramp: the sensitive x * 0.114 + y * 0.299 + z * 0.587 case
+    for ch, src in ((3, img), (4, np.concatenate([img, np.full((H, W, 1), 255, np.uint8)], axis=2))):
+        d_img, d_out = dev(src), empty((H, W), torch.uint8)
+        assert L.mf_k_intensity(d_img.data_ptr(), ch, d_out.data_ptr(), W * H, None) == 0
+        ref = mfo_rgbd.image_to_intensity(src)
+        assert np.array_equal(host(d_out), ref)
+    gray = ref
+    d_g = dev(gray)
+    d_p1, d_p2 = empty((H // 2, W // 2), torch.uint8), empty((H // 4, W // 4), torch.uint8)
+    assert L.mf_k_pyrdown_u8(d_g.data_ptr(), d_p1.data_ptr(), W, H, None) == 0
+    assert L.mf_k_pyrdown_u8(d_p1.data_ptr(), d_p2.data_ptr(), W // 2, H // 2, None) == 0
+    r1 = oracle.pyrdown_u8(gray)
+    r2 = oracle.pyrdown_u8(r1)
+    assert np.array_equal(host(d_p1), r1) and np.array_equal(host(d_p2), r2)
+    d_dx, d_dy = empty((H, W), torch.int16), empty((H, W), torch.int16)
+    assert L.mf_k_derivative_images(d_g.data_ptr(), d_dx.data_ptr(), d_dy.data_ptr(), W, H, None) == 0
+    rdx, rdy = mfo_rgbd.derivative_images(gray)
+    assert np.array_equal(host(d_dx), rdx) and np.array_equal(host(d_dy), rdy)
+
+
+def test_so3_prealign(hip, oracle):
+    from oracle import mfo_rgbd
+    from gpu_util import dev
+    L = hip
+    st, fr = _frames(4, 640, 480)
+    pyr = [mfo_rgbd.u8_pyramid(mfo_rgbd.image_to_intensity(f[0])) for f in fr]
+    k2 = (st.fx / 4, st.fy / 4, st.cx / 4, st.cy / 4)
+    for a, b in ((0, 1), (1, 3)):
+        last2, next2 = pyr[a][2], pyr[b][2]
+        Rr, er, cr, itr = mfo_rgbd.so3_prealign(last2, next2, *k2)
+        R = np.zeros(9, np.float64)
+        stats = np.zeros(3, np.float32)
+        d_l, d_n = dev(last2), dev(next2)
+        H2, W2 = last2.shape
+        assert L.mf_k_so3_prealign(d_l.data_ptr(), d_n.data_ptr(), W2, H2, *[C.c_float(v) for v in k2], R.ctypes.data,
+                                   stats.ctypes.data, None) == 0
+        assert int(stats[2]) == itr
+        assert stats[1] == cr
+        assert abs(stats[0] - er) <= 1e-5 * max(er, 1e-6)
+        assert np.abs(R.reshape(3, 3) - Rr).max() < 2e-6
+
+
+def _residual_case(oracle, W=320, H=240):
+    """Two consecutive synthetic frames: last = frame 0 (depth NaN where invalid), next = frame 1."""
+    from oracle import mfo_rgbd
+    st, fr = _frames(2, W, H)
+    last_img = mfo_rgbd.image_to_intensity(fr[0][0])
+    next_img = mfo_rgbd.image_to_intensity(fr[1][0])
+    depth = fr[0][1].astype(np.float32).copy()
+    depth[(depth <= 0) | (depth > 6)] = np.nan
+    dx, dy = mfo_rgbd.derivative_images(next_img)
+    # a small camera motion: Rt = inverse of the increment (RGBDOdometry.cpp:361-373)
+    T = np.linalg.inv(st.gt_pose(0)) @ st.gt_pose(1)
+    K = np.array([[st.fx, 0, st.cx], [0, st.fy, st.cy], [0, 0, 1.0]])
+    krk = (K @ T[:3, :3] @ np.linalg.inv(K)).astype(np.float32)
+    kt = (K @ T[:3, 3]).astype(np.float32)
+    return st, last_img, next_img, depth, dx, dy, krk, kt
+
+
+def test_rgb_residual_and_step(hip, oracle):
+    from oracle import mfo_rgbd
+    from gpu_util import dev, empty, host
+    import torch
+    L = hip
+    st, last_img, next_img, depth, dx, dy, krk, kt = _residual_case(oracle)
+    H, W = next_img.shape
+    min_scale = 576.0  # level-1 threshold: keeps a few thousand pixels of the value-noise texture
+    cor, sig, cnt = mfo_rgbd.rgb_residual(min_scale, dx, dy, depth, depth, last_img, next_img, kt, krk)
+    assert cnt > 500
+    d = {k: dev(v) for k, v in dict(dx=dx, dy=dy, depth=depth, last=last_img, next=next_img).items()}
+    d_cor = empty((W * H * 8,), torch.uint8)
+    sums = np.zeros(2, np.int32)
+    assert L.mf_k_rgb_residual(min_scale, d["dx"].data_ptr(), d["dy"].data_ptr(), d["depth"].data_ptr(), d["depth"].data_ptr(),
+                               d["last"].data_ptr(), d["next"].data_ptr(), 0.07, kt.ctypes.data, krk.ctypes.data, W, H,
+                               d_cor.data_ptr(), sums.ctypes.data, None) == 0
+    got = host(d_cor).view(CORR)
+    assert int(sums[0]) == cnt and int(sums[1]) == sig
+    valid = cor["valid"] != 0
+    assert np.array_equal(got["u0"] >= 0, valid)
+    assert np.array_equal(got["u0"][valid], cor["zx"][valid]) and np.array_equal(got["v0"][valid], cor["zy"][valid])
+    assert np.array_equal(got["diff"][valid], cor["diff"][valid])
+    # rgbStep: both weightings (sigma = count, and -1 = rgbOnly)
+    cloud = mfo_rgbd.project_to_cloud(depth, st.fx, st.fy, st.cx, st.cy)
+    for sigma in (float(cnt), -1.0):
+        A, b = mfo_rgbd.rgb_step(cor, sigma, cloud, st.fx, st.fy, dx, dy, W, H)
+        out = np.zeros(32, np.float64)
+        assert L.mf_k_rgb_step(d_cor.data_ptr(), sigma, d["depth"].data_ptr(), st.fx, st.fy, st.cx, st.cy, d["dx"].data_ptr(),
+                               d["dy"].data_ptr(), 0.125, W, H, out.ctypes.data, None) == 0
+        A2 = np.zeros((6, 6)); b2 = np.zeros(6)
+        k = 0
+        for i in range(6):
+            for j in range(i, 7):
+                if j == 6: b2[i] = out[k]
+                else: A2[i, j] = A2[j, i] = out[k]
+                k += 1
+        assert out[28] == cnt
+        scale = np.sqrt(np.outer(np.diag(A), np.diag(A))) + 1e-30
+        assert (np.abs(A2 - A) / scale).max() < 1e-5
+        assert np.abs(b2 - b).max() <= 1e-5 * np.abs(b).max() + 1e-12
+
+
+def _run_pair(oracle, n, W, H, **cfg):
+    from maskfusion_amd import MaskFusion
+    from oracle import mfo_rgbd
+    st, fr = _frames(n, W, H)
+    o = oracle.Oracle(st.W, st.H, st.fx, st.fy, st.cx, st.cy, capacity=1 << 19, icpWeight=cfg.get("icpWeight", 10.0),
+                      so3=int(cfg.get("so3", 1)), rgbOnly=int(cfg.get("rgbOnly", 0)))
+    mf = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=cfg.get("icpWeight", 10.0), so3=bool(cfg.get("so3", 1)),
+                    rgbOnly=bool(cfg.get("rgbOnly", 0)), enableMultipleModels=False, numGSurfels=1 << 19)
+    rows = []
+    for k in range(n):
+        o.process_frame(fr[k][0], fr[k][1])
+        mf.processFrame(fr[k][0], fr[k][1])
+        so = mfo_rgbd.track_stats(o)
+        sh = mf.trackStats(0)
+        rows.append((o.pose, mf.getCurrPose(), so, sh, o.count, mf.getBackgroundModel().lastCount()))
+    o.close(); mf.close()
+    return rows
+
+
+@pytest.mark.parametrize("cfg", [dict(icpWeight=10.0, so3=1), dict(icpWeight=10.0, so3=0), dict(icpWeight=100.0, so3=1)])
+def test_pipeline_rgbd_matches_oracle(hip, oracle, cfg):
+    """Reference defaults (icpWeight 10 + SO(3)), the photometric term alone, and SO(3) in front of the ICP-only loop."""
+    rows = _run_pair(oracle, 8, 320, 240, **cfg)
+    for k, (po, ph, so, sh, co, ch) in enumerate(rows):
+        dt = np.linalg.norm(po[:3, 3] - ph[:3, 3])
+        dR = np.abs(po[:3, :3] - ph[:3, :3]).max()
+        assert dt < 1e-4 and dR < 1e-4, (k, dt, dR)
+        if k == 0:
+            continue
+        assert int(sh["so3Iterations"]) == so.so3Iterations, (k, sh, so.so3Iterations)
+        if cfg["so3"]:
+            assert abs(sh["lastSO3Count"] - so.lastSO3Count) <= 2
+        if cfg["icpWeight"] < 100:
+            assert abs(sh["lastRGBCount"] - so.lastRGBCount) <= 0.01 * so.lastRGBCount + 5, (k, sh, so.lastRGBCount)
+            assert abs(sh["lastRGBError"] - so.lastRGBError) <= 0.02 * so.lastRGBError
+        assert abs(sh["lastICPCount"] - so.lastICPCount) <= 0.002 * so.lastICPCount
+        assert abs(co - ch) <= 0.005 * co
+
+
+def test_pipeline_rgb_only_runs(hip, oracle):
+    """rgbOnly: nearest-pixel photometric alignment is coarse and its early-exit rule is a float comparison, so the two
+    trajectories are only required to stay close for the first frames and to agree on the bookkeeping."""
+    rows = _run_pair(oracle, 3, 320, 240, icpWeight=10.0, so3=0, rgbOnly=1)
+    po, ph, so, sh, _, _ = rows[1]
+    assert np.linalg.norm(po[:3, 3] - ph[:3, 3]) < 2e-3
+    assert abs(sh["lastRGBCount"] - so.lastRGBCount) <= 0.02 * so.lastRGBCount + 5
+    assert sh["lastICPCount"] == 0.0
