@@ -63,7 +63,8 @@ typedef struct mf_config {
     int32_t track_all_models;     /* MaskFusion::trackAllModels = true (Core/MaskFusion.h:396) */
     int32_t max_models;           /* upper bound on live models (the reference: 256 ids) */
     int32_t rgb_only;             /* rgbOnly = 0 (Core/MaskFusion.h:169): photometric term only */
-    int32_t reserved[4];
+    int32_t pose_log_capacity;    /* enablePoseLogging (Core/MaskFusion.h:402): entries kept per model; 0 = off */
+    int32_t reserved[3];
 } mf_config;
 
 /* Fills *cfg with the reference's constructor defaults for a WxH camera. */
@@ -100,6 +101,15 @@ int mf_get_surfel_count(mf_ctx* ctx, int32_t model, uint32_t* count);
  * {R row-major (9), t (3), lastICPError, lastICPCount, surfel count, alive}: what the multi-GPU gather ships per rank
  * (the reference logs the same per model, Core/MaskFusion.cpp:580-602) without a host round trip. */
 int mf_model_state_dev(mf_ctx* ctx, int32_t model, float* d_out16);
+/* Model::getPoseLog (Core/Model/Model.h:257-262) of model i, chronological: ts[e] = the frame's timestamp, p7[e] =
+ * {tx ty tz qx qy qz qw} of cam->world (background) or obj->world (objects), Core/MaskFusion.cpp:580-596.
+ * ts/p7 may be NULL to query *count only. */
+int mf_get_pose_log(mf_ctx* ctx, int32_t model, int64_t* ts, float* p7, uint32_t max_entries, uint32_t* count);
+/* MaskFusion::exportPoses (Core/MaskFusion.cpp:851-879): writes <export_dir>poses-<id>.txt ("ts[s] tx ty tz qx qy qz qw",
+ * 6 decimals; ts = timestamp * 1e-6) for every live and dropped model */
+int mf_export_poses(mf_ctx* ctx, const char* export_dir);
+/* MaskFusion::savePly (Core/MaskFusion.cpp:733-849): writes <export_dir>cloud-<id>.ply per live model */
+int mf_save_ply(mf_ctx* ctx, const char* export_dir);
 /* {lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count, so3 iterations, rejected by the
  * 0.3 m rule} of the last tracking step of model i (RGBDOdometry.h:68-75, RGBDOdometry.cpp:477-481) */
 int mf_get_track_stats(mf_ctx* ctx, int32_t model, float* out8);

@@ -142,6 +142,23 @@ class MaskFusion:
     def predict(self):
         self._chk(self._L.mf_predict(self._h))
 
+    # -- exports (Core/MaskFusion.h:282-284) --------------------------------------------------------
+    def savePly(self, exportDir: str):
+        self._chk(self._L.mf_save_ply(self._h, exportDir.encode()))
+
+    def exportPoses(self, exportDir: str):
+        self._chk(self._L.mf_export_poses(self._h, exportDir.encode()))
+
+    def getPoseLog(self, model: int = 0):
+        """(timestamps int64[n], poses float32[n, 7] = tx ty tz qx qy qz qw), Model::getPoseLog."""
+        n = C.c_uint32(0)
+        self._chk(self._L.mf_get_pose_log(self._h, model, None, None, 0, C.byref(n)))
+        ts = np.zeros(n.value, np.int64)
+        p = np.zeros((n.value, 7), np.float32)
+        if n.value:
+            self._chk(self._L.mf_get_pose_log(self._h, model, ts.ctypes.data, p.ctypes.data, n.value, C.byref(n)))
+        return ts, p
+
     # -- getters ----------------------------------------------------------------------------------
     def getTick(self) -> int:
         t = C.c_int32(0)

@@ -32,6 +32,8 @@ struct ModelState {
     PoseDev* d_pose = nullptr; FrameDev* d_frame = nullptr;
     float4* d_predV = nullptr; float4* d_predN = nullptr; uchar4* d_predImage = nullptr; uint16_t* d_predTime = nullptr;
     uint8_t* d_predGray = nullptr; uint8_t* d_fillGray = nullptr;  // intensity of the RGB projection / of the fill-in image
+    float* d_poselog = nullptr;            // Model::poseLog on the device: ring of [cap][8] floats (t, q xyzw, pad)
+    std::vector<int64_t> log_ts;           // timestamps of the entries (host side of PoseLogItem)
     PoseDev* h_pose = nullptr; FrameDev* h_frame = nullptr; int* h_count = nullptr;
     std::vector<void*> allocs;
     ~ModelState() {
@@ -79,6 +81,8 @@ struct mf_ctx {
     RgbCorr* d_corres = nullptr; float* d_rgb_partials[2] = {nullptr, nullptr}; int2* d_cnt[2] = {nullptr, nullptr};
     So3Result* d_so3 = nullptr;
     const uint8_t* cur_rgb = nullptr;      // device rgb of the frame being processed (fill-in intensity at predict time)
+    struct RetiredLog { int id; std::vector<int64_t> ts; std::vector<float> p; };
+    std::vector<RetiredLog> retired;       // pose logs of dropped models (MaskFusion::inactiveModels, exportPoses)
     float* d_vmap_g[3]; float* d_nmap_g[3];
     unsigned long long* d_keys = nullptr;
     int* d_index = nullptr; float4* d_ivc = nullptr; float4* d_ict = nullptr; float4* d_inr = nullptr;
@@ -142,6 +146,8 @@ extern "C" int mf_default_config(mf_config* cfg, int32_t width, int32_t height, 
     cfg->num_gsurfels = 9437184; cfg->num_osurfels = 1048576;
     cfg->enable_multiple_models = 1;
     cfg->model_spawn_offset = 20; cfg->track_all_models = 1; cfg->max_models = 32;
+    cfg->rgb_only = 0;
+    cfg->pose_log_capacity = 65536;   // enablePoseLogging = true (Core/MaskFusion.h:402)
     return MF_OK;
 }
 
@@ -186,6 +192,7 @@ static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int 
     A(dev_alloc(c, m->allocs, &m->d_predTime, P));
     A(dev_alloc(c, m->allocs, &m->d_predGray, P));
     if (allowFillIn) A(dev_alloc(c, m->allocs, &m->d_fillGray, P));
+    if (c->cfg.pose_log_capacity > 0) A(dev_alloc(c, m->allocs, &m->d_poselog, (size_t)c->cfg.pose_log_capacity * 8));
 #undef A
     hipLaunchKernelGGL(k_pose_identity, dim3(1), dim3(64), 0, c->stream, m->d_pose);
     hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(64), 0, c->stream, m->d_frame, c->host_tick);
@@ -464,8 +471,11 @@ static int take_next_model_id(mf_ctx* c) {
     return next;
 }
 
+static int download_pose_log(mf_ctx* c, ModelState& m, std::vector<int64_t>& ts, std::vector<float>& p7);
+
 static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_depth, const uint8_t* d_mask_in,
-                              const int32_t* class_ids, int n_masks, float weight_multiplier) {
+                              const int32_t* class_ids, int n_masks, float weight_multiplier, int64_t timestamp = 0,
+                              const float* in_pose16 = nullptr, bool bootstrap = false) {
     const int W = c->W, H = c->H, P = c->P;
     hipStream_t s = c->stream;
     const mf_config& g = c->cfg;
@@ -518,10 +528,20 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
         bg.cur = 0;
         launch_compact_records(c->d_cand_rec, c->d_flags, P, bg.surf[0], bg.d_frame, c->d_block_counts, bg.h_count, s);
         mark(c, 7);
+    } else if (in_pose16 && !bootstrap) {
+        // the caller supplies the camera pose: no tracking, no segmentation, object poses untouched
+        // (MaskFusion.cpp:243,413-415 -- the whole "regular" block is skipped)
+        mark(c, 2);
+        launch_override_pose(bg.d_pose, in_pose16, 0, bg.h_pose, s);
+        mark(c, 3); mark(c, 4);
+        for (size_t i = 0; i < c->models.size(); ++i)
+            enqueue_fuse_clean(c, *c->models[i], d_rgb, d_depth, depthF, mask, g.depth_cutoff, weight_multiplier, true, i == 0);
+        mark(c, 7);
     } else {
         mark(c, 2);
         // tracking, :247-276
         enqueue_track(c, bg, depthF_prev, 0.f);
+        if (bootstrap && in_pose16) launch_override_pose(bg.d_pose, in_pose16, 1, bg.h_pose, s);   // :280-283
         for (size_t i = 1; i < c->models.size(); ++i) {
             ModelState& m = *c->models[i];
             if (!m.isStatic || g.track_all_models) enqueue_track(c, m, nullptr, 0.2f);  // jump rule, :268-272
@@ -551,8 +571,12 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
 
             // inactivateModel for objects the jump rule dropped (:268-272); data is deleted (no re-detection upstream)
             for (size_t i = 1; i < c->models.size();) {
-                if (c->models[i]->h_pose->alive == 0) c->models.erase(c->models.begin() + i);
-                else ++i;
+                if (c->models[i]->h_pose->alive == 0) {
+                    mf_ctx::RetiredLog r;
+                    r.id = c->models[i]->id;
+                    if (download_pose_log(c, *c->models[i], r.ts, r.p) == MF_OK && !r.ts.empty()) c->retired.push_back(std::move(r));
+                    c->models.erase(c->models.begin() + i);
+                } else ++i;
             }
             if (c->spawnOffset < g.model_spawn_offset) c->spawnOffset++;  // :294
             std::vector<SegModelInfo> infos;
@@ -589,7 +613,12 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
     }
     for (auto& m : c->models) {  // predict(), :569 ; tick++, :573
         enqueue_predict(c, *m);
-        launch_frame_advance(m->d_frame, W, H, m->h_frame, s);
+        float* slot = nullptr;
+        if (m->d_poselog) {  // MaskFusion.cpp:580-596
+            slot = m->d_poselog + (m->log_ts.size() % (size_t)g.pose_log_capacity) * 8;
+            m->log_ts.push_back(timestamp);
+        }
+        launch_frame_advance(m->d_frame, W, H, m->h_frame, m->d_pose, m.get() == c->models[0].get() ? nullptr : bg.d_pose, slot, s);
         m->age++;  // incrementAge, :600
     }
     mark(c, 8);
@@ -602,12 +631,12 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
 
 extern "C" int mf_process_frame_dev(mf_ctx* c, const uint8_t* d_rgb, const float* d_depth, const uint8_t* d_mask, int64_t timestamp,
                                     float weight_multiplier) {
-    (void)timestamp;
     if (!c || !d_rgb || !d_depth) return MF_EINVAL;
     // device-resident masks carry no class ids over this entry point: every mask id is class 0 ("object")
     std::vector<int32_t> cls;
     if (d_mask && c->cfg.enable_multiple_models) cls.assign(256, 0);
-    return process_frame_impl(c, d_rgb, d_depth, d_mask, cls.empty() ? nullptr : cls.data(), (int)cls.size(), weight_multiplier);
+    return process_frame_impl(c, d_rgb, d_depth, d_mask, cls.empty() ? nullptr : cls.data(), (int)cls.size(), weight_multiplier,
+                              timestamp);
 }
 
 extern "C" int mf_sync(mf_ctx* c) {
@@ -630,15 +659,15 @@ extern "C" int mf_sync(mf_ctx* c) {
 
 extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* depth, const uint8_t* mask, const int32_t* class_ids,
                                 int32_t n_masks, int64_t timestamp, const float* in_pose16, float weight_multiplier, int32_t bootstrap) {
-    (void)timestamp;
     if (!c || !rgb || !depth) return MF_EINVAL;
-    if (in_pose16 || bootstrap) { c->err = "in_pose / bootstrap not supported yet"; return MF_ESTATE; }
+    if (bootstrap && !in_pose16) { c->err = "bootstrap needs in_pose (MaskFusion.cpp:281)"; return MF_EINVAL; }
     // staged on the input stream (the frame is first read there); the previous frame has completed (this call syncs)
     hipStream_t sin = c->overlap ? c->stream_pre : c->stream;
     MF_HIP(c, hipMemcpyAsync(c->d_rgb, rgb, (size_t)c->P * 3, hipMemcpyHostToDevice, sin));
     MF_HIP(c, hipMemcpyAsync(c->d_depth, depth, (size_t)c->P * sizeof(float), hipMemcpyHostToDevice, sin));
     if (mask) MF_HIP(c, hipMemcpyAsync(c->d_mask_in, mask, (size_t)c->P, hipMemcpyHostToDevice, sin));
-    int rc = process_frame_impl(c, c->d_rgb, c->d_depth, mask ? c->d_mask_in : nullptr, class_ids, n_masks, weight_multiplier);
+    int rc = process_frame_impl(c, c->d_rgb, c->d_depth, mask ? c->d_mask_in : nullptr, class_ids, n_masks, weight_multiplier, timestamp,
+                                in_pose16, bootstrap != 0);
     if (rc != MF_OK) return rc;
     return mf_sync(c);
 }
@@ -709,6 +738,101 @@ extern "C" int mf_get_icp_stats(mf_ctx* c, int32_t model, float* e, float* n) {
     int rc = mf_sync(c);
     if (rc != MF_OK) return rc;
     *e = m->h_pose->lastICPError; *n = m->h_pose->lastICPCount;
+    return MF_OK;
+}
+// Model::getPoseLog: entries in chronological order (the device ring keeps the last pose_log_capacity of them)
+static int download_pose_log(mf_ctx* c, ModelState& m, std::vector<int64_t>& ts, std::vector<float>& p7) {
+    ts.clear(); p7.clear();
+    if (!m.d_poselog || m.log_ts.empty()) return MF_OK;
+    MF_HIP(c, hipStreamSynchronize(c->stream));
+    const size_t cap = (size_t)c->cfg.pose_log_capacity, n = m.log_ts.size(), keep = n < cap ? n : cap;
+    std::vector<float> raw(cap * 8);
+    MF_HIP(c, hipMemcpy(raw.data(), m.d_poselog, cap * 8 * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t e = n - keep; e < n; ++e) {
+        ts.push_back(m.log_ts[e]);
+        const float* r = raw.data() + (e % cap) * 8;
+        p7.insert(p7.end(), r, r + 7);
+    }
+    return MF_OK;
+}
+extern "C" int mf_get_pose_log(mf_ctx* c, int32_t model, int64_t* ts, float* p7, uint32_t max_entries, uint32_t* count) {
+    ModelState* m = model_at(c, model);
+    if (!m || !count) return MF_EINVAL;
+    std::vector<int64_t> t; std::vector<float> p;
+    int rc = download_pose_log(c, *m, t, p);
+    if (rc != MF_OK) return rc;
+    *count = (uint32_t)t.size();
+    if (ts && p7) {
+        const size_t n = t.size() < max_entries ? t.size() : max_entries;
+        memcpy(ts, t.data(), n * sizeof(int64_t));
+        memcpy(p7, p.data(), n * 7 * sizeof(float));
+    }
+    return MF_OK;
+}
+static int write_pose_file(mf_ctx* c, const std::string& dir, int id, const std::vector<int64_t>& ts, const std::vector<float>& p) {
+    const std::string fn = dir + "poses-" + std::to_string(id) + ".txt";
+    FILE* f = fopen(fn.c_str(), "w");
+    if (!f) { c->err = "cannot write " + fn; return MF_EINVAL; }
+    for (size_t e = 0; e < ts.size(); ++e) {  // std::fixed << std::setprecision(6): timestamp [us] * 1e-6, then t and q (xyzw)
+        fprintf(f, "%.6f", (double)ts[e] * 1e-6);
+        for (int k = 0; k < 7; ++k) fprintf(f, " %.6f", (double)p[e * 7 + k]);
+        fputc('\n', f);
+    }
+    fclose(f);
+    return MF_OK;
+}
+// MaskFusion::exportPoses (Core/MaskFusion.cpp:851-879): poses-<id>.txt for live and dropped models
+extern "C" int mf_export_poses(mf_ctx* c, const char* export_dir) {
+    if (!c || !export_dir) return MF_EINVAL;
+    const std::string dir(export_dir);
+    for (auto& m : c->models) {
+        std::vector<int64_t> t; std::vector<float> p;
+        int rc = download_pose_log(c, *m, t, p);
+        if (rc != MF_OK) return rc;
+        if (!m->d_poselog) continue;
+        rc = write_pose_file(c, dir, m->id, t, p);
+        if (rc != MF_OK) return rc;
+    }
+    for (auto& r : c->retired) {
+        int rc = write_pose_file(c, dir, r.id, r.ts, r.p);
+        if (rc != MF_OK) return rc;
+    }
+    return MF_OK;
+}
+// MaskFusion::savePly (Core/MaskFusion.cpp:733-849): cloud-<id>.ply, binary little endian, model frame, normals negated,
+// only surfels whose confidence exceeds the model's threshold
+extern "C" int mf_save_ply(mf_ctx* c, const char* export_dir) {
+    if (!c || !export_dir) return MF_EINVAL;
+    int rc = mf_sync(c);
+    if (rc != MF_OK) return rc;
+    for (auto& m : c->models) {
+        const uint32_t n = (uint32_t)*m->h_count;
+        std::vector<float> data((size_t)n * 12);
+        uint32_t got = 0;
+        int idx = 0;
+        for (size_t i = 0; i < c->models.size(); ++i) if (c->models[i].get() == m.get()) idx = (int)i;
+        rc = mf_download_map(c, idx, data.data(), n, &got);
+        if (rc != MF_OK) return rc;
+        uint32_t valid = 0;
+        for (uint32_t i = 0; i < got; ++i) valid += data[(size_t)i * 12 + 3] > m->confThr;
+        const std::string fn = std::string(export_dir) + "cloud-" + std::to_string(m->id) + ".ply";
+        FILE* f = fopen(fn.c_str(), "wb");
+        if (!f) { c->err = "cannot write " + fn; return MF_EINVAL; }
+        fprintf(f, "ply\nformat binary_little_endian 1.0\nelement vertex %u\nproperty float x\nproperty float y\nproperty float z"
+                   "\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nproperty float nx\nproperty float ny"
+                   "\nproperty float nz\nproperty float radius\nend_header\n", valid);
+        for (uint32_t i = 0; i < got; ++i) {
+            const float* s12 = data.data() + (size_t)i * 12;
+            if (!(s12[3] > m->confThr)) continue;
+            fwrite(s12, sizeof(float), 3, f);
+            const int col = (int)s12[4];
+            const unsigned char rgb[3] = {(unsigned char)(col >> 16 & 0xFF), (unsigned char)(col >> 8 & 0xFF), (unsigned char)(col & 0xFF)};
+            fwrite(rgb, 1, 3, f);
+            const float nr[4] = {-s12[8], -s12[9], -s12[10], s12[11]};
+            fwrite(nr, sizeof(float), 4, f);
+        }
+        fclose(f);
+    }
     return MF_OK;
 }
 extern "C" int mf_get_track_stats(mf_ctx* c, int32_t model, float* out8) {

@@ -202,6 +202,44 @@ __device__ inline void pose_derive(PoseDev& p) {
 }
 
 
+// Pose log entry (MaskFusion.cpp:580-596): cam->world for the background, obj->world = globalPose * pose^-1 for objects;
+// translation + Eigen::Quaternionf(rotation) as x y z w.  Kept on the device so that logging costs no host visit.
+__device__ inline void quat_from_rot(const float* m /*row-major*/, float* q /*x y z w*/) {  // Eigen/src/Geometry/Quaternion.h
+    float t = m[0] + m[4] + m[8];
+    if (t > 0.f) {
+        t = sqrtf(t + 1.0f);
+        q[3] = 0.5f * t;
+        t = 0.5f / t;
+        q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[i * 3 + i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrtf(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0f);
+        q[i] = 0.5f * t;
+        t = 0.5f / t;
+        q[3] = (m[k * 3 + j] - m[j * 3 + k]) * t;
+        q[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
+        q[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+    }
+}
+__device__ inline void pose_log_entry(const PoseDev* pose, const PoseDev* bg /*nullptr for the background itself*/, float* o /*[8]*/) {
+    float R[9], t[3];
+    if (!bg) {
+        for (int k = 0; k < 9; ++k) R[k] = pose->R[k];
+        for (int k = 0; k < 3; ++k) t[k] = pose->t[k];
+    } else {
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) R[r * 3 + c] = bg->R[r * 3] * pose->Ri[c] + bg->R[r * 3 + 1] * pose->Ri[3 + c] + bg->R[r * 3 + 2] * pose->Ri[6 + c];
+        const float3 v = mul33(bg->R, f3(pose->ti[0], pose->ti[1], pose->ti[2]));
+        t[0] = v.x + bg->t[0]; t[1] = v.y + bg->t[1]; t[2] = v.z + bg->t[2];
+    }
+    o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
+    quat_from_rot(R, o + 3);
+    o[7] = 0.f;
+}
+
 // sin / cos for |th| <= 0.5 by Taylor series (error < 1e-17): keeps libm's large-argument reduction (and its scratch
 // arrays) out of the per-iteration kernel.
 __device__ __forceinline__ void sincos_small(double th, double& s, double& c) {

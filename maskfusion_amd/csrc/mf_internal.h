@@ -184,9 +184,12 @@ void launch_global_resolve(unsigned long long* keys, uint8_t* ids, int P, hipStr
 void launch_spawn_pose(PoseDev* obj, const PoseDev* bg, FrameDev* objFrame, const FrameDev* bgFrame, PoseDev* host_mirror,
                        hipStream_t s);
 void launch_static_pose(PoseDev* obj, const PoseDev* bg, PoseDev* host_mirror, hipStream_t s);
+void launch_override_pose(PoseDev* pose, const float* in_pose16_colmajor, int mode, PoseDev* host_mirror, hipStream_t s);
 void launch_model_state(const PoseDev* pose, const FrameDev* frame, float* out16, hipStream_t s);
 
 // end-of-frame bookkeeping: tick++, cover -> useFillIn decision for the next frame
-void launch_frame_advance(FrameDev* frame, int W, int H, FrameDev* host_mirror, hipStream_t s);
+// ... and the pose-log entry of this frame (MaskFusion.cpp:580-596) when log != nullptr
+void launch_frame_advance(FrameDev* frame, int W, int H, FrameDev* host_mirror, const PoseDev* pose, const PoseDev* bg_pose,
+                          float* log_slot, hipStream_t s);
 
 }  // namespace mf

@@ -211,6 +211,38 @@ void launch_static_pose(PoseDev* obj, const PoseDev* bg, PoseDev* host_mirror, h
     hipLaunchKernelGGL(k_static_pose, dim3(1), dim3(64), 0, s, obj, bg, host_mirror);
 }
 
+// Model::overridePose (Core/Model/Model.h:235-238): lastPose = pose; pose = in  (mode 0: inPose replaces tracking,
+// MaskFusion.cpp:413-415) or pose = pose * in (mode 1: bootstrap, :280-283).  in: row-major R, t.
+struct PoseArg { float R[9]; float t[3]; };
+__global__ void k_override_pose(PoseDev* pose, PoseArg in, int mode, PoseDev* host_mirror) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    PoseDev p = *pose;
+    for (int k = 0; k < 9; ++k) p.lastR[k] = p.R[k];
+    for (int k = 0; k < 3; ++k) p.lastT[k] = p.t[k];
+    if (mode == 0) {
+        for (int k = 0; k < 9; ++k) p.R[k] = in.R[k];
+        for (int k = 0; k < 3; ++k) p.t[k] = in.t[k];
+    } else {
+        float R[9];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) R[r * 3 + c] = p.lastR[r * 3] * in.R[c] + p.lastR[r * 3 + 1] * in.R[3 + c] + p.lastR[r * 3 + 2] * in.R[6 + c];
+        const float3 t = mul33(p.lastR, f3(in.t[0], in.t[1], in.t[2]));
+        for (int k = 0; k < 9; ++k) p.R[k] = R[k];
+        p.t[0] = t.x + p.lastT[0]; p.t[1] = t.y + p.lastT[1]; p.t[2] = t.z + p.lastT[2];
+    }
+    pose_derive(p);
+    *pose = p;
+    if (host_mirror) *host_mirror = p;
+}
+void launch_override_pose(PoseDev* pose, const float* in_pose16_colmajor, int mode, PoseDev* host_mirror, hipStream_t s) {
+    PoseArg a;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) a.R[r * 3 + c] = in_pose16_colmajor[c * 4 + r];
+        a.t[r] = in_pose16_colmajor[12 + r];
+    }
+    hipLaunchKernelGGL(k_override_pose, dim3(1), dim3(64), 0, s, pose, a, mode, host_mirror);
+}
+
 // 16-float per-model record for the multi-GPU gather: R(9) t(3) lastICPError lastICPCount surfels alive
 __global__ void k_model_state(const PoseDev* pose, const FrameDev* frame, float* out16) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;

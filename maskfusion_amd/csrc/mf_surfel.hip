@@ -605,8 +605,10 @@ void launch_splat_resolve(Surfels src, const PoseDev* pose, unsigned long long* 
 // ------------------------------------------------------------------------------------------------
 // end of frame: tick++ and the fill-in decision for the next tracking step
 // ------------------------------------------------------------------------------------------------
-__global__ void k_frame_advance(FrameDev* frame, int W, int H, FrameDev* host_mirror) {
+__global__ void k_frame_advance(FrameDev* frame, int W, int H, FrameDev* host_mirror, const PoseDev* pose, const PoseDev* bg_pose,
+                                float* log_slot) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (log_slot) pose_log_entry(pose, bg_pose, log_slot);
     const int rw = W / 20, rh = H / 20;
     frame->pad[0] = frame->useFillIn;  // decision the tracking step of THIS frame ran with (mf_get_last_fillin)
     frame->useFillIn = ((float)frame->cover / (float)(rw * rh) < 0.75f) ? 1 : 0;
@@ -614,8 +616,9 @@ __global__ void k_frame_advance(FrameDev* frame, int W, int H, FrameDev* host_mi
     frame->tick += 1;
     if (host_mirror) *host_mirror = *frame;
 }
-void launch_frame_advance(FrameDev* frame, int W, int H, FrameDev* host_mirror, hipStream_t s) {
-    hipLaunchKernelGGL(k_frame_advance, dim3(1), dim3(64), 0, s, frame, W, H, host_mirror);
+void launch_frame_advance(FrameDev* frame, int W, int H, FrameDev* host_mirror, const PoseDev* pose, const PoseDev* bg_pose,
+                          float* log_slot, hipStream_t s) {
+    hipLaunchKernelGGL(k_frame_advance, dim3(1), dim3(64), 0, s, frame, W, H, host_mirror, pose, bg_pose, log_slot);
 }
 
 void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, int timeDelta,

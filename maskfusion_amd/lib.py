@@ -32,7 +32,7 @@ class Config(C.Structure):
                 ("max_depth_processed", C.c_float), ("outlier_coefficient", C.c_float), ("num_gsurfels", C.c_int32),
                 ("num_osurfels", C.c_int32), ("enable_multiple_models", C.c_int32), ("model_spawn_offset", C.c_int32),
                 ("track_all_models", C.c_int32), ("max_models", C.c_int32), ("rgb_only", C.c_int32),
-                ("reserved", C.c_int32 * 4)]
+                ("pose_log_capacity", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 # every symbol declared in include/maskfusion_amd.h (tests/test_abi.py checks the header against this table)
@@ -53,6 +53,9 @@ SYMBOLS = {
     "mf_model_state_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "mf_get_icp_stats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mf_get_track_stats": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "mf_get_pose_log": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "mf_export_poses": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "mf_save_ply": (C.c_int, [C.c_void_p, C.c_char_p]),
     "mf_k_intensity": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "mf_k_pyrdown_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "mf_k_derivative_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

@@ -1656,7 +1656,53 @@ static void oracle_predict(mfo_ctx* x) {
                 x->fillVertex, x->fillNormal);
 }
 
+/* fusion, Core/MaskFusion.cpp:539-565 (single model) */
+static void oracle_fuse(mfo_ctx* x, float weightMultiplier) {
+    const mfo_config* g = &x->cfg;
+    double t0;
+    /* (the predict() at :423 only feeds the dead loop-closure block and is overwritten at :569 -- skipped) */
+    const int src = x->cur, dst = 1 - x->cur;
+    t0 = now_ms();
+    mfo_predict_indices(&x->cam, x->pose, x->surf[src], x->count, x->tick, g->maxDepthProcessed, g->timeDelta,
+                        x->index, x->ivc, x->ict, x->inr);
+    x->tms[3] += now_ms() - t0;
+    t0 = now_ms();
+    const float weighting = mfo_fusion_weight(x->pose, x->lastPose, weightMultiplier);
+    /* Model::fuse maxDepth uniform: min(depthCutoff, model.maxDepth = FLT_MAX, bb_max_z = FLT_MAX) */
+    mfo_fuse_data(&x->cam, x->pose, x->rgb, x->depth, x->depthF, x->mask, 0, x->tick, weighting, g->depthCutoff,
+                  x->index, x->ivc, x->inr, x->cand_op, x->cand_best, x->cand_rec, &x->n_cand);
+    x->tms[4] += now_ms() - t0;
+    t0 = now_ms();
+    mfo_fuse_update(x->surf[src], x->surf[dst], x->count, x->tick, x->cand_op, x->cand_best, x->cand_rec, x->n_cand);
+    x->tms[5] += now_ms() - t0;
+    t0 = now_ms();
+    mfo_predict_indices(&x->cam, x->pose, x->surf[dst], x->count, x->tick, g->maxDepthProcessed, g->timeDelta,
+                        x->index, x->ivc, x->ict, x->inr);
+    x->tms[3] += now_ms() - t0;
+    t0 = now_ms();
+    x->count = mfo_clean(&x->cam, x->pose, x->surf[dst], x->count, x->cand_op, x->cand_rec, x->n_cand, x->tick,
+                         g->timeDelta, g->confGlobal, g->maxDepthProcessed, g->outlierCoeff, 0, x->index, x->ivc,
+                         x->ict, x->inr, x->depthF, x->mask, x->surf[src], g->capacity);
+    /* two swaps (fuse, clean) leave the live buffer where it started */
+    x->tms[6] += now_ms() - t0;
+}
+
+static void mat4_mul_cm_early(const float* a, const float* b, float* out) { /* column-major 4x4 */
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) {
+            float sum = 0;
+            for (int k = 0; k < 4; ++k) sum += a[k * 4 + r] * b[c * 4 + k];
+            out[c * 4 + r] = sum;
+        }
+}
+
 int mfo_process_frame(mfo_ctx* x, const uint8_t* rgb, const float* depth, float weightMultiplier) {
+    return mfo_process_frame_ex(x, rgb, depth, weightMultiplier, NULL, 0);
+}
+
+/* processFrame(frame, inPose, weightMultiplier, bootstrap), Core/MaskFusion.cpp:200-607; inPose16 column-major or NULL */
+int mfo_process_frame_ex(mfo_ctx* x, const uint8_t* rgb, const float* depth, float weightMultiplier, const float* inPose16,
+                         int bootstrap) {
     const mfo_config* g = &x->cfg;
     const int W = g->W, H = g->H, P = W * H;
     double t0 = now_ms();
@@ -1672,6 +1718,11 @@ int mfo_process_frame(mfo_ctx* x, const uint8_t* rgb, const float* depth, float 
         x->count = mfo_init_surfels(&x->cam, x->rgb, x->depth, x->depthF, x->tick, g->maxDepthProcessed,
                                     x->surf[0], g->capacity);
         first_rgb(x->rgb, W, H, x->lastNext);             /* initFirstRGB, :238 */
+    } else if (inPose16 && !bootstrap) {
+        /* :413-415 -- Model::overridePose (Model.h:235-238): lastPose = pose; pose = inPose.  No tracking. */
+        memcpy(x->lastPose, x->pose, sizeof(x->pose));
+        memcpy(x->pose, inPose16, sizeof(x->pose));
+        oracle_fuse(x, weightMultiplier);
     } else {
         /* Model::generateCUDATextures(depthFiltered, mask, K, depthCutoff), Model.cpp:350-389 */
         t0 = now_ms();
@@ -1715,33 +1766,13 @@ int mfo_process_frame(mfo_ctx* x, const uint8_t* rgb, const float* depth, float 
         Rt_to_pose16(R, t, x->pose);
         x->tms[2] += now_ms() - t0;
 
-        /* the predict() at :423 only feeds the dead loop-closure block and is overwritten at :569 -- skipped */
-
-        /* fusion, :539-565 */
-        const int src = x->cur, dst = 1 - x->cur;
-        t0 = now_ms();
-        mfo_predict_indices(&x->cam, x->pose, x->surf[src], x->count, x->tick, g->maxDepthProcessed, g->timeDelta,
-                            x->index, x->ivc, x->ict, x->inr);
-        x->tms[3] += now_ms() - t0;
-        t0 = now_ms();
-        const float weighting = mfo_fusion_weight(x->pose, x->lastPose, weightMultiplier);
-        /* Model::fuse maxDepth uniform: min(depthCutoff, model.maxDepth = FLT_MAX, bb_max_z = FLT_MAX) */
-        mfo_fuse_data(&x->cam, x->pose, x->rgb, x->depth, x->depthF, x->mask, 0, x->tick, weighting, g->depthCutoff,
-                      x->index, x->ivc, x->inr, x->cand_op, x->cand_best, x->cand_rec, &x->n_cand);
-        x->tms[4] += now_ms() - t0;
-        t0 = now_ms();
-        mfo_fuse_update(x->surf[src], x->surf[dst], x->count, x->tick, x->cand_op, x->cand_best, x->cand_rec, x->n_cand);
-        x->tms[5] += now_ms() - t0;
-        t0 = now_ms();
-        mfo_predict_indices(&x->cam, x->pose, x->surf[dst], x->count, x->tick, g->maxDepthProcessed, g->timeDelta,
-                            x->index, x->ivc, x->ict, x->inr);
-        x->tms[3] += now_ms() - t0;
-        t0 = now_ms();
-        x->count = mfo_clean(&x->cam, x->pose, x->surf[dst], x->count, x->cand_op, x->cand_rec, x->n_cand, x->tick,
-                             g->timeDelta, g->confGlobal, g->maxDepthProcessed, g->outlierCoeff, 0, x->index, x->ivc,
-                             x->ict, x->inr, x->depthF, x->mask, x->surf[src], g->capacity);
-        /* two swaps (fuse, clean) leave the live buffer where it started */
-        x->tms[6] += now_ms() - t0;
+        if (bootstrap && inPose16) { /* :280-283: overridePose(pose * inPose) */
+            float np[16];
+            memcpy(x->lastPose, x->pose, sizeof(x->pose));
+            mat4_mul_cm_early(x->pose, inPose16, np);
+            memcpy(x->pose, np, sizeof(np));
+        }
+        oracle_fuse(x, weightMultiplier);
     }
     t0 = now_ms();
     oracle_predict(x); /* :569 */

@@ -217,6 +217,8 @@ mfo_ctx* mfo_create(const mfo_config* c);
 void     mfo_destroy(mfo_ctx* ctx);
 /* MaskFusion::processFrame, -static single background model (Core/MaskFusion.cpp:200-607). */
 int      mfo_process_frame(mfo_ctx* ctx, const uint8_t* rgb, const float* depth, float weightMultiplier);
+int      mfo_process_frame_ex(mfo_ctx* ctx, const uint8_t* rgb, const float* depth, float weightMultiplier,
+                              const float* inPose16 /*column-major or NULL*/, int bootstrap);
 void     mfo_get_pose(const mfo_ctx* ctx, float* pose16);
 int      mfo_get_count(const mfo_ctx* ctx);
 int      mfo_get_tick(const mfo_ctx* ctx);

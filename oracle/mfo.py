@@ -108,6 +108,8 @@ def lib():
     L.mfo_destroy.argtypes = [C.c_void_p]
     L.mfo_process_frame.argtypes = [C.c_void_p, u8p, f32p, C.c_float]
     L.mfo_process_frame.restype = C.c_int
+    L.mfo_process_frame_ex.argtypes = [C.c_void_p, u8p, f32p, C.c_float, f32p, C.c_int]
+    L.mfo_process_frame_ex.restype = C.c_int
     L.mfo_get_pose.argtypes = [C.c_void_p, f32p]
     L.mfo_get_count.argtypes = [C.c_void_p]
     L.mfo_get_count.restype = C.c_int
@@ -265,9 +267,13 @@ class Oracle:
     def __del__(self):
         self.close()
 
-    def process_frame(self, rgb, depth, weight_multiplier=1.0):
-        return lib().mfo_process_frame(self.h, np.ascontiguousarray(rgb, np.uint8),
-                                       np.ascontiguousarray(depth, np.float32), weight_multiplier)
+    def process_frame(self, rgb, depth, weight_multiplier=1.0, in_pose=None, bootstrap=False):
+        if in_pose is None:
+            return lib().mfo_process_frame(self.h, np.ascontiguousarray(rgb, np.uint8),
+                                           np.ascontiguousarray(depth, np.float32), weight_multiplier)
+        p = pose16(in_pose)
+        return lib().mfo_process_frame_ex(self.h, np.ascontiguousarray(rgb, np.uint8), np.ascontiguousarray(depth, np.float32),
+                                          weight_multiplier, p, int(bootstrap))
 
     @property
     def pose(self):

@@ -1,0 +1,93 @@
+"""-m gpu tests of the remaining processFrame arguments and exports of the drop-in boundary:
+inPose / bootstrap (Core/MaskFusion.cpp:243,280-283,413-415), the pose log and exportPoses (:580-596,:851-879),
+savePly (:733-849)."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(n, W=320, H=240):
+    from maskfusion_amd import synth
+    f = 528.0 * W / 640.0
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=False)
+    return st, [st.frame(k) for k in range(n)]
+
+
+def _quat_xyzw(R):
+    from scipy.spatial.transform import Rotation
+    return Rotation.from_matrix(R).as_quat()
+
+
+def test_in_pose_and_bootstrap_match_oracle(hip, oracle):
+    from maskfusion_amd import MaskFusion, synth
+    st, fr = _frames(7)
+    o = oracle.Oracle(st.W, st.H, st.fx, st.fy, st.cx, st.cy, capacity=1 << 19, icpWeight=100.0, so3=0)
+    mf = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=100.0, so3=False, enableMultipleModels=False,
+                    numGSurfels=1 << 19)
+    nudge = synth.make_pose(synth.rot_xyz(0.001, -0.002, 0.0005), [0.001, 0.0, -0.002])
+    for k in range(7):
+        kw = {}
+        if k in (2, 3):
+            kw = dict(in_pose=st.gt_pose(k).astype(np.float32))              # pose supplied, no tracking
+        elif k == 5:
+            kw = dict(in_pose=nudge.astype(np.float32), bootstrap=True)       # tracked pose * inPose
+        o.process_frame(fr[k][0], fr[k][1], **kw)
+        mf.processFrame(fr[k][0], fr[k][1], timestamp=1000 * k, inPose=kw.get("in_pose"), bootstrap=kw.get("bootstrap", False))
+        po, ph = o.pose, mf.getCurrPose()
+        assert np.abs(po - ph).max() < 1e-4, k
+        if k in (2, 3):
+            assert np.abs(ph - st.gt_pose(k)).max() < 1e-6
+        assert abs(o.count - mf.getBackgroundModel().lastCount()) <= max(20, 0.005 * o.count), k
+    with pytest.raises(Exception):
+        mf.processFrame(fr[0][0], fr[0][1], bootstrap=True)   # bootstrap without inPose (assert at MaskFusion.cpp:281)
+    o.close(); mf.close()
+
+
+def test_pose_log_exports_and_ply(hip, oracle, tmp_path):
+    from maskfusion_amd import MaskFusion
+    st, fr = _frames(6)
+    mf = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=100.0, so3=False, enableMultipleModels=False,
+                    numGSurfels=1 << 19)
+    poses = []
+    for k in range(6):
+        mf.processFrame(fr[k][0], fr[k][1], timestamp=33333 * (k + 1))
+        poses.append(mf.getCurrPose())
+    ts, p = mf.getPoseLog(0)
+    assert ts.tolist() == [33333 * (k + 1) for k in range(6)]
+    for k in range(6):
+        assert np.abs(p[k, :3] - poses[k][:3, 3]).max() < 1e-6
+        q = _quat_xyzw(poses[k][:3, :3])
+        assert min(np.abs(p[k, 3:] - q).max(), np.abs(p[k, 3:] + q).max()) < 1e-5
+        assert p[k, 6] > 0   # Eigen's conversion: w >= 0 when the trace is positive
+    d = str(tmp_path) + os.sep
+    mf.exportPoses(d)
+    rows = [l.split() for l in open(d + "poses-0.txt").read().strip().split("\n")]
+    assert len(rows) == 6 and all(len(r) == 8 for r in rows)
+    assert rows[2][0] == "%.6f" % (33333 * 3 * 1e-6)
+    assert np.allclose(np.array(rows, np.float64)[:, 1:], p, atol=1e-6)
+    # PLY: header + one 31-byte record per surfel above the confidence threshold, normals negated
+    mf.savePly(d)
+    raw = open(d + "cloud-0.ply", "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    lines = head.decode().split("\n")
+    assert lines[0] == "ply" and lines[1] == "format binary_little_endian 1.0"
+    n = int([l for l in lines if l.startswith("element vertex")][0].split()[2])
+    assert [l for l in lines if l.startswith("property")] == [
+        "property float x", "property float y", "property float z", "property uchar red", "property uchar green",
+        "property uchar blue", "property float nx", "property float ny", "property float nz", "property float radius"]
+    assert len(body) == n * 31
+    m = mf.getBackgroundModel().downloadMap()
+    thr = mf.getBackgroundModel().getConfidenceThreshold()
+    keep = m[:, 3] > thr
+    assert n == int(keep.sum())
+    if n:
+        rec = struct.unpack("<3f3B4f", body[:31])
+        s0 = m[keep][0]
+        assert np.allclose(rec[:3], s0[:3]) and np.allclose(rec[6:9], -s0[8:11]) and np.isclose(rec[9], s0[11])
+        col = int(s0[4])
+        assert rec[3:6] == ((col >> 16) & 255, (col >> 8) & 255, col & 255)
+    mf.close()
