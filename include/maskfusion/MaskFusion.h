@@ -43,10 +43,15 @@ public:
                 if ((*data)[i * 12 + 3] > confThres) numValid++;
         }
     };
+    struct PoseLogItem {  // Model.h:257-260 (p = tx ty tz qx qy qz qw)
+        int64_t ts;
+        float p[7];
+    };
     unsigned getID() const { return id_; }
     inline Matrix4f getPose() const;
     inline unsigned lastCount() const;
     inline SurfelMap downloadMap() const;
+    inline std::vector<PoseLogItem> getPoseLog() const;  // Model.h:262
 
 private:
     friend class MaskFusion;
@@ -63,7 +68,9 @@ public:
                float /*errThresh*/ = 5e-05f, float /*covThresh*/ = 1e-05f, bool /*closeLoops*/ = false, bool /*iclnuim*/ = false,
                bool /*reloc*/ = false, float /*photoThresh*/ = 115, float initConfidenceGlobal = 4, float initConfidenceObject = 2,
                float depthCut = 3, float icpThresh = 10, bool fastOdom = false, float /*fernThresh*/ = 0.3095f, bool so3 = true,
-               bool /*frameToFrameRGB*/ = false, unsigned /*modelSpawnOffset*/ = 20, int device = 0) {
+               bool /*frameToFrameRGB*/ = false, unsigned modelSpawnOffset = 20, const std::string& exportDirectory = "",
+               int device = 0)
+        : exportDir_(exportDirectory) {
         mf_config cfg;
         mf_default_config(&cfg, width, height, fx, fy, cx, cy);
         cfg.time_delta = timeDelta;
@@ -73,6 +80,7 @@ public:
         cfg.icp_weight = icpThresh;
         cfg.fast_odom = fastOdom;
         cfg.so3 = so3;
+        cfg.model_spawn_offset = (int32_t)modelSpawnOffset;
         cfg.device = device;
         const int rc = mf_create(&cfg, &ctx_);
         if (rc != MF_OK) throw std::runtime_error("mf_create failed with code " + std::to_string(rc));
@@ -89,6 +97,8 @@ public:
         return false;
     }
     void predict() { check(mf_predict(ctx_)); }  // MaskFusion.h:76
+    void savePly() { check(mf_save_ply(ctx_, exportDir_.c_str())); }          // MaskFusion.h:282
+    void exportPoses() { check(mf_export_poses(ctx_, exportDir_.c_str())); }  // MaskFusion.h:284
 
     Model getBackgroundModel() { return Model(ctx_, 0); }  // MaskFusion.h:88
     std::vector<Model> getModels() {                        // MaskFusion.h:90
@@ -108,6 +118,8 @@ public:
     void setOutlierCoefficient(const float& v) { set("outlierCoefficient", v); }
     void setFastOdom(const bool& v) { set("fastOdom", v); }
     void setSo3(const bool& v) { set("so3", v); }
+    void setRgbOnly(const bool& v) { set("rgbOnly", v); }
+    void setTrackAllModels(bool v) { set("trackAllModels", v); }
     void setPyramid(const bool& v) { set("pyramid", v); }
     void setEnableMultipleModels(bool v) { set("enableMultipleModels", v); }
 
@@ -119,7 +131,22 @@ private:
         if (rc != MF_OK) throw std::runtime_error(std::string("maskfusion_amd: ") + mf_last_error(ctx_));
     }
     mf_ctx* ctx_ = nullptr;
+    std::string exportDir_;
 };
+
+inline std::vector<Model::PoseLogItem> Model::getPoseLog() const {
+    uint32_t n = 0;
+    if (mf_get_pose_log(ctx_, id_, nullptr, nullptr, 0, &n) != MF_OK) throw std::runtime_error(mf_last_error(ctx_));
+    std::vector<int64_t> ts(n);
+    std::vector<float> p((size_t)n * 7);
+    if (n && mf_get_pose_log(ctx_, id_, ts.data(), p.data(), n, &n) != MF_OK) throw std::runtime_error(mf_last_error(ctx_));
+    std::vector<PoseLogItem> out(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        out[i].ts = ts[i];
+        for (int k = 0; k < 7; ++k) out[i].p[k] = p[(size_t)i * 7 + k];
+    }
+    return out;
+}
 
 inline Matrix4f Model::getPose() const {
     Matrix4f p;

@@ -80,6 +80,7 @@ struct mf_ctx {
     float* d_lastDepth[3] = {}; uint8_t* d_lastImage[3] = {};   // per-model scratch: populateRGBDData(last)
     RgbCorr* d_corres = nullptr; float* d_rgb_partials[2] = {nullptr, nullptr}; int2* d_cnt[2] = {nullptr, nullptr};
     So3Result* d_so3 = nullptr;
+    bool index_transposed = false;         // layout of d_index / d_ivc / d_ict / d_inr left by the last index pass
     const uint8_t* cur_rgb = nullptr;      // device rgb of the frame being processed (fill-in intensity at predict time)
     struct RetiredLog { int id; std::vector<int64_t> ts; std::vector<float> p; };
     std::vector<RetiredLog> retired;       // pose logs of dropped models (MaskFusion::inactiveModels, exportPoses)
@@ -424,7 +425,7 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
     const int W = c->W, H = c->H;
     hipStream_t s = c->stream;
     const int src = m.cur, dst = 1 - m.cur;
-    launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, s);
+    launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, false, s);
     launch_index_resolve(m.surf[src], m.d_pose, c->d_keys, W, H, c->d_index, c->d_ivc, c->d_ict, c->d_inr, s);
     if (marks) mark(c, 4);
     // Model::fuse maxDepth uniform: min(depthCutoff, model.maxDepth, bb_max_z = FLT_MAX without the GUI) (Model.cpp:527)
@@ -434,12 +435,13 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
     launch_fuse_update(m.surf[src], m.surf[dst], m.d_frame, c->d_upd_first, c->d_cand_rec, s);
     if (marks) mark(c, 6);
     if (secondIndexPass) {
-        launch_index_scatter(m.surf[dst], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, s);
+        launch_index_scatter(m.surf[dst], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, true, s);
         launch_index_resolve(m.surf[dst], m.d_pose, c->d_keys, W, H, c->d_index, c->d_ivc, c->d_ict, c->d_inr, s);
     }
     launch_clean(m.surf[dst], m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.time_delta, m.confThr, g.outlier_coefficient, m.id,
                  c->d_index, c->d_ivc, c->d_ict, depthF, mask, c->d_cand_op, c->d_cand_rec, c->d_flags, c->d_newconf,
-                 c->d_block_counts, m.h_count, s);
+                 c->d_block_counts, m.h_count, secondIndexPass, s);
+    c->index_transposed = secondIndexPass;
     // two swaps (fuse, clean) leave the live buffer where it started
 }
 
@@ -1003,6 +1005,13 @@ extern "C" int mf_debug_read(mf_ctx* c, const char* what, void* out, uint64_t ou
     else { c->err = "unknown debug tap: " + w; return MF_EINVAL; }
     if (out_bytes < bytes) { c->err = "debug_read: buffer too small"; return MF_EINVAL; }
     MF_HIP(c, hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+    if ((w == "index" || w == "index_vc") && c->index_transposed) {  // hand the map out row-major
+        const size_t es = (w == "index") ? 4 : 16;
+        std::vector<char> tmp((const char*)out, (const char*)out + bytes);
+        for (int x = 0; x < c->W; ++x)
+            for (int y = 0; y < c->H; ++y)
+                memcpy((char*)out + ((size_t)y * c->W + x) * es, tmp.data() + ((size_t)x * c->H + y) * es, es);
+    }
     return MF_OK;
 }
 

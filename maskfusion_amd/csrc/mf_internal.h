@@ -148,7 +148,7 @@ void launch_rgbd_finalize(const float* icp_partials, const float* rgb_partials, 
 void launch_init_surfels(const uint8_t* rgb, const float* depthRaw, const float* depthF, int W, int H, Intr k,
                          float maxDepth, const FrameDev* frame, float4* rec /*[P][3]*/, uint8_t* flags, hipStream_t s);
 void launch_index_scatter(Surfels src, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k,
-                          float maxDepth, int timeDelta, unsigned long long* keys, hipStream_t s);
+                          float maxDepth, int timeDelta, unsigned long long* keys, bool transposed, hipStream_t s);
 void launch_index_resolve(Surfels src, const PoseDev* pose, unsigned long long* keys, int W, int H, int* index,
                           float4* vc, float4* ct, float4* nr, hipStream_t s);
 void launch_fuse_data(const uint8_t* rgb, const float* depthRaw, const float* depthF, const uint8_t* mask,
@@ -161,7 +161,7 @@ void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose
                   int timeDelta, float confThreshold, float outlierCoeff, int maskID, const int* index,
                   const float4* vc, const float4* ct, const float* depthF, const uint8_t* mask,
                   const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags, float* newconf, int* block_counts,
-                  int* host_count_mirror, hipStream_t s);
+                  int* host_count_mirror, bool transposed /*layout of index/vc/ct*/, hipStream_t s);
 // generic ordered compaction of [n_dev] records (3 x float4 each, record-major) -> surfels, sets frame->count
 void launch_compact_records(const float4* rec, const uint8_t* flags, int n, Surfels dst, FrameDev* frame,
                             int* block_counts, int* host_count_mirror, hipStream_t s);
