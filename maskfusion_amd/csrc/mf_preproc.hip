@@ -22,6 +22,11 @@ constexpr int kBTileW = 64, kBTileH = 4;
 constexpr int kBLdsW = kBTileW + 2 * kBR;  // 76
 constexpr int kBLdsH = kBTileH + 2 * kBR;  // 16
 
+// The range/space weight exp(-(s2 * a + c2 * b)) is evaluated as 2^-(s2 * a' + c2 * b') with log2(e) folded into the
+// constants and the hardware v_exp_f32 (1 ulp on 2^t; the argument carries |t| * 2^-24 <= 1e-6 relative for every weight
+// above 1e-6).  libm's expf cost ~25 instructions x 169 taps and made the kernel VALU bound at 40 us.  The filter output
+// is a weighted MEAN of nearly equal depths, so a 1e-6 relative weight error moves it by ~1e-9 relative: the measured
+// difference to the oracle's expf path is a few ulp (tests/test_gpu_kernels.py::test_bilateral).
 __global__ __launch_bounds__(256) void k_bilateral(const float* __restrict__ depth, float* __restrict__ out, int W, int H) {
     __shared__ float tile[kBLdsH * kBLdsW];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -33,15 +38,15 @@ __global__ __launch_bounds__(256) void k_bilateral(const float* __restrict__ dep
         tile[i] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? depth[gy * W + gx] : -1.0f;
     }
     __syncthreads();
-    const float sigma_space2_inv_half = 0.024691358f;
-    const float sigma_color2_inv_half = 555.556f;
+    const float sigma_space2_inv_half = 0.024691358f * 1.44269504088896340736f;   // x log2(e)
+    const float sigma_color2_inv_half = 555.556f * 1.44269504088896340736f;
     const int gx = x0 + tx, gy = y0 + ty;
     if (gx >= W || gy >= H) return;
     const float value = tile[(ty + kBR) * kBLdsW + tx + kBR];
     float res = 0.f;
     if (value > 0.03f) {
         float sum1 = 0.f, sum2 = 0.f;
-#pragma unroll 1
+#pragma unroll
         for (int dy = -kBR; dy <= kBR; ++dy) {
             const float* row = &tile[(ty + kBR + dy) * kBLdsW + tx + kBR];
             const float fy2 = (float)(dy * dy);
@@ -49,9 +54,9 @@ __global__ __launch_bounds__(256) void k_bilateral(const float* __restrict__ dep
             for (int dx = -kBR; dx <= kBR; ++dx) {
                 const float tmp = row[dx];
                 if (tmp >= 0.f) {
-                    const float space2 = (float)(dx * dx) + fy2;
+                    const float space_term = -(((float)(dx * dx) + fy2) * sigma_space2_inv_half);   // compile-time constant
                     const float color2 = (value - tmp) * (value - tmp);
-                    const float weight = expf(-(space2 * sigma_space2_inv_half + color2 * sigma_color2_inv_half));
+                    const float weight = __builtin_amdgcn_exp2f(space_term - color2 * sigma_color2_inv_half);
                     sum1 += tmp * weight;
                     sum2 += weight;
                 }
