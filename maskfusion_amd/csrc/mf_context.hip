@@ -69,7 +69,6 @@ struct mf_ctx {
     uint8_t* d_rgb = nullptr; float* d_depth = nullptr; uint8_t* d_mask_in = nullptr; uint8_t* d_zero_mask = nullptr;
     uint8_t* d_mask_tex = nullptr;  // textureMask: the last full segmentation (Core/MaskFusion.cpp:297)
     float* d_depthF[3] = {nullptr, nullptr, nullptr};  // ring: frame k filters into [k % 3], fill-in reads [(k - 1) % 3]
-    float* d_dpyr[2][3] = {};                            // two sets (frame parity) of the current-frame pyramid
     float* d_vmap[2][3] = {}; float* d_nmap[2][3] = {};
     // shared scratch
     GNState* d_gn = nullptr; float* d_partials[2] = {nullptr, nullptr};
@@ -245,7 +244,6 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     for (int i = 0; i < 3; ++i) {
         const size_t lp = (size_t)(W >> i) * (H >> i);
         for (int set = 0; set < 2; ++set) {
-            if (i > 0) A(dev_alloc(c, c->allocs, &c->d_dpyr[set][i], lp));
             A(dev_alloc(c, c->allocs, &c->d_vmap[set][i], lp * 3));
             A(dev_alloc(c, c->allocs, &c->d_nmap[set][i], lp * 3));
         }
@@ -499,13 +497,7 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
     mark(c, 0, sp);
     launch_bilateral(d_depth, depthF, W, H, sp);
     if (c->host_tick > 1) {
-        c->d_dpyr[set][0] = depthF;
-        for (int i = 1; i < 3; ++i) launch_pyrdown_f(c->d_dpyr[set][i - 1], c->d_dpyr[set][i], W >> (i - 1), H >> (i - 1), sp);
-        for (int i = 0; i < 3; ++i) {
-            const float div = (float)(1 << i);
-            launch_vmap_nmap(c->d_dpyr[set][i], c->d_vmap[set][i], c->d_nmap[set][i], W >> i, H >> i,
-                             Intr{g.fx / div, g.fy / div, g.cx / div, g.cy / div}, g.depth_cutoff, sp);
-        }
+        launch_frame_pyramid(depthF, c->d_vmap[set], c->d_nmap[set], W, H, c->K, g.depth_cutoff, sp);
     }
     c->cur_rgb = d_rgb;
     if (photometric_on(c) || g.so3) {

@@ -74,6 +74,9 @@ struct Surfels {               // SoA of float4, 48 B per surfel in three coales
 void launch_bilateral(const float* depth, float* out, int W, int H, hipStream_t s);
 void launch_pyrdown_f(const float* src, float* dst, int sw, int sh, hipStream_t s);
 void launch_vmap_nmap(const float* depth, float* vmap, float* nmap, int W, int H, Intr k, float cutoff, hipStream_t s);
+// depth pyramid (2 x pyrDownGaussF) + vertex/normal maps of the three levels in one launch; k: level-0 intrinsics
+void launch_frame_pyramid(const float* depth, float* const vmap[3], float* const nmap[3], int W, int H, Intr k, float cutoff,
+                          hipStream_t s);
 
 // ---------------- odometry ----------------
 // Fused RGBDOdometry::initICPModel.  pose: device PoseDev (R,t used).  fill-in inputs may be null (no fill-in).

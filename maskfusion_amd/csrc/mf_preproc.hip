@@ -147,4 +147,109 @@ void launch_vmap_nmap(const float* depth, float* vmap, float* nmap, int W, int H
     hipLaunchKernelGGL(k_vmap_nmap, grid, dim3(256), 0, s, depth, vmap, nmap, W, H, k, cutoff);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Model::generateCUDATextures in ONE launch (Core/Model/Model.cpp:350-389): pyrDownGaussF x2 + createVMap/createNMap x3.
+// A 256-thread workgroup owns an 8x8 tile of level 2 = 16x16 of level 1 = 32x32 of level 0.  It stages the 45x45 level-0
+// depths those need (5x5 taps of 5x5 taps + the +1 neighbours of the normals), builds the 21x21 level-1 and 9x9 level-2
+// depths in LDS with exactly the per-pixel expressions of k_pyrdown_f (same loop bounds, same summation order: results are
+// bit-identical to the level-by-level kernels), and writes the six planar maps.  Five dependent launches (2 x 7.8 us +
+// 3 x 4.8 us: each one launch-latency bound) become one; the two smaller depth levels never visit HBM.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pyrdown_px(const float* __restrict__ src /*LDS*/, int ldw, int ox, int oy, int x, int y, int sw, int sh) {
+    const int tx = min(2 * x + 3, sw - 1);
+    const int ty = min(2 * y + 3, sh - 1);
+    float sum = 0.f;
+    int count = 0;
+    for (int cy = max(0, 2 * y - 2); cy < ty; ++cy) {
+        for (int cx = max(0, 2 * x - 2); cx < tx; ++cx) {
+            const float v = src[(cy - oy) * ldw + (cx - ox)];
+            if (!isnan(v)) {
+                const float w = gauss5(ty - cy - 1) * gauss5(tx - cx - 1);
+                sum += v * w;
+                count += (int)w;
+            }
+        }
+    }
+    return sum / (float)count;
+}
+
+__device__ __forceinline__ void vmap_nmap_px(const float* __restrict__ d /*LDS*/, int ldw, int ox, int oy, int u, int v, int W, int H,
+                                             Intr k, float cutoff, float* __restrict__ vmap, float* __restrict__ nmap) {
+    const int P = W * H, i = v * W + u;
+    const float fx_inv = 1.f / k.fx, fy_inv = 1.f / k.fy;
+    const float* p = d + (v - oy) * ldw + (u - ox);
+    float3 v00, v01, v10;
+    const bool ok00 = vertex_from_depth(p[0], u, v, k, fx_inv, fy_inv, cutoff, v00);
+    vmap[i] = v00.x; vmap[P + i] = v00.y; vmap[2 * P + i] = v00.z;
+    float3 n = f3(qnan(), qnan(), qnan());
+    if (u < W - 1 && v < H - 1) {
+        const bool ok01 = vertex_from_depth(p[1], u + 1, v, k, fx_inv, fy_inv, cutoff, v01);
+        const bool ok10 = vertex_from_depth(p[ldw], u, v + 1, k, fx_inv, fy_inv, cutoff, v10);
+        if (ok00 && ok01 && ok10) n = normalized_rsqrt(cross3(v01 - v00, v10 - v00));
+    }
+    nmap[i] = n.x; nmap[P + i] = n.y; nmap[2 * P + i] = n.z;
+}
+
+struct FramePyrArgs {
+    const float* depth; int W, H; Intr k; float cutoff;
+    float* vmap[3]; float* nmap[3];
+};
+
+constexpr int kFpL0 = 45, kFpL1 = 21, kFpL2 = 9;
+
+__global__ __launch_bounds__(256) void k_frame_pyramid(const FramePyrArgs a) {
+    __shared__ float s0[kFpL0 * kFpL0];
+    __shared__ float s1[kFpL1 * kFpL1];
+    __shared__ float s2[kFpL2 * kFpL2];
+    const int W0 = a.W, H0 = a.H, W1 = W0 >> 1, H1 = H0 >> 1, W2 = W0 >> 2, H2 = H0 >> 2;
+    const int X2 = blockIdx.x * 8, Y2 = blockIdx.y * 8;          // tile origin at level 2
+    const int ox1 = 2 * X2 - 2, oy1 = 2 * Y2 - 2;                // LDS origins (may be negative)
+    const int ox0 = 2 * ox1 - 2, oy0 = 2 * oy1 - 2;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < kFpL0 * kFpL0; i += 256) {
+        const int ly = i / kFpL0, lx = i - ly * kFpL0;
+        const int gx = ox0 + lx, gy = oy0 + ly;
+        s0[i] = (gx >= 0 && gx < W0 && gy >= 0 && gy < H0) ? a.depth[gy * W0 + gx] : qnan();
+    }
+    __syncthreads();
+    for (int i = tid; i < kFpL1 * kFpL1; i += 256) {
+        const int ly = i / kFpL1, lx = i - ly * kFpL1;
+        const int gx = ox1 + lx, gy = oy1 + ly;
+        s1[i] = (gx >= 0 && gx < W1 && gy >= 0 && gy < H1) ? pyrdown_px(s0, kFpL0, ox0, oy0, gx, gy, W0, H0) : qnan();
+    }
+    __syncthreads();
+    if (tid < kFpL2 * kFpL2) {
+        const int ly = tid / kFpL2, lx = tid - ly * kFpL2;
+        const int gx = X2 + lx, gy = Y2 + ly;
+        s2[tid] = (gx < W2 && gy < H2) ? pyrdown_px(s1, kFpL1, ox1, oy1, gx, gy, W1, H1) : qnan();
+    }
+    __syncthreads();
+    // vertex / normal maps of the three tiles
+    const Intr k0 = a.k;
+    const Intr k1 = Intr{a.k.fx / 2.f, a.k.fy / 2.f, a.k.cx / 2.f, a.k.cy / 2.f};
+    const Intr k2 = Intr{a.k.fx / 4.f, a.k.fy / 4.f, a.k.cx / 4.f, a.k.cy / 4.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int l = q * 256 + tid, u = 4 * X2 + (l & 31), v = 4 * Y2 + (l >> 5);
+        if (u < W0 && v < H0) vmap_nmap_px(s0, kFpL0, ox0, oy0, u, v, W0, H0, k0, a.cutoff, a.vmap[0], a.nmap[0]);
+    }
+    {
+        const int u = 2 * X2 + (tid & 15), v = 2 * Y2 + (tid >> 4);
+        if (u < W1 && v < H1) vmap_nmap_px(s1, kFpL1, ox1, oy1, u, v, W1, H1, k1, a.cutoff, a.vmap[1], a.nmap[1]);
+    }
+    if (tid < 64) {
+        const int u = X2 + (tid & 7), v = Y2 + (tid >> 3);
+        if (u < W2 && v < H2) vmap_nmap_px(s2, kFpL2, X2, Y2, u, v, W2, H2, k2, a.cutoff, a.vmap[2], a.nmap[2]);
+    }
+}
+
+void launch_frame_pyramid(const float* depth, float* const vmap[3], float* const nmap[3], int W, int H, Intr k, float cutoff,
+                          hipStream_t s) {
+    FramePyrArgs a;
+    a.depth = depth; a.W = W; a.H = H; a.k = k; a.cutoff = cutoff;
+    for (int i = 0; i < 3; ++i) { a.vmap[i] = vmap[i]; a.nmap[i] = nmap[i]; }
+    dim3 grid(((W >> 2) + 7) / 8, ((H >> 2) + 7) / 8);
+    hipLaunchKernelGGL(k_frame_pyramid, grid, dim3(256), 0, s, a);
+}
+
 }  // namespace mf
