@@ -79,6 +79,9 @@ struct mf_ctx {
     float* d_lastDepth[3] = {}; uint8_t* d_lastImage[3] = {};   // per-model scratch: populateRGBDData(last)
     RgbCorr* d_corres = nullptr; float* d_rgb_partials[2] = {nullptr, nullptr}; int2* d_cnt[2] = {nullptr, nullptr};
     So3Result* d_so3 = nullptr;
+    // tiled splat prediction (mf_splat.hip)
+    int* d_tile_count = nullptr; int* d_tile_cursor = nullptr; int* d_tile_base = nullptr; int* d_tile_entries = nullptr;
+    void* d_tile_bbox = nullptr; int tile_entries_cap = 0; int splat_tiles = 1;
     bool index_transposed = false;         // layout of d_index / d_ivc / d_ict / d_inr left by the last index pass
     const uint8_t* cur_rgb = nullptr;      // device rgb of the frame being processed (fill-in intensity at predict time)
     struct RetiredLog { int id; std::vector<int64_t> ts; std::vector<float> p; };
@@ -266,6 +269,18 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
         A(dev_alloc(c, c->allocs, &c->d_cnt[b], (size_t)icp_grid_blocks(W, H)));
     }
     A(dev_alloc(c, c->allocs, &c->d_so3, 1));
+    {
+        const size_t nt = splat_tiles_scratch_ints(W, H);
+        const size_t maxcap = (size_t)std::max(surfel_capacity(cfg->num_gsurfels), surfel_capacity(cfg->num_osurfels));
+        A(dev_alloc(c, c->allocs, &c->d_tile_count, nt));
+        A(dev_alloc(c, c->allocs, &c->d_tile_cursor, nt));
+        A(dev_alloc(c, c->allocs, &c->d_tile_base, nt + 1));
+        c->tile_entries_cap = (int)std::min<size_t>(4 * maxcap, (size_t)1 << 30);   // a surfel overlaps 1-4 tiles (sprites <= 64 px)
+        A(dev_alloc(c, c->allocs, &c->d_tile_entries, (size_t)c->tile_entries_cap));
+        uint2* bb = nullptr;
+        A(dev_alloc(c, c->allocs, &bb, maxcap));
+        c->d_tile_bbox = bb;
+    }
     A(dev_alloc(c, c->allocs, &c->d_keys, (size_t)P, 0xFF));
     A(dev_alloc(c, c->allocs, &c->d_index, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_ivc, (size_t)P));
@@ -446,6 +461,14 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
 // MaskFusion::predict for one model: combinedPredict(maxDepthProcessed, tick, tick, timeDelta) -- the fill-in half
 // (performFillIn) is evaluated lazily by the next tracking step from the retained filtered depth.
 static void enqueue_predict(mf_ctx* c, ModelState& m) {
+    if (c->splat_tiles) {
+        const bool gray = photometric_on(c);
+        if (launch_splat_tiled(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, c->cfg.max_depth_processed, m.confThr,
+                               c->cfg.time_delta, c->d_tile_count, c->d_tile_cursor, c->d_tile_base, c->d_tile_entries,
+                               c->tile_entries_cap, c->d_tile_bbox, m.d_predV, m.d_predN, m.d_predImage, m.d_predTime, c->cur_rgb,
+                               gray ? m.d_predGray : nullptr, gray ? m.d_fillGray : nullptr, c->stream) == 0)
+            return;
+    }
     launch_splat_scatter(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, c->cfg.max_depth_processed, m.confThr,
                          c->cfg.time_delta, c->d_keys, c->stream);
     const bool gray = photometric_on(c) ;
@@ -636,6 +659,8 @@ extern "C" int mf_process_frame_dev(mf_ctx* c, const uint8_t* d_rgb, const float
 extern "C" int mf_sync(mf_ctx* c) {
     if (!c) return MF_EINVAL;
     MF_HIP(c, hipStreamSynchronize(c->stream));
+    for (auto& m : c->models)
+        if (m->h_frame->pad[1]) { c->err = "splat tile lists overflowed (raise the surfel capacity)"; return MF_ESTATE; }
     if (c->timings_on) {
         // event i marks the START of stage i; stage i lasts until event i+1 (labels: see the header)
         float t[MF_N_TIMINGS] = {};
@@ -912,6 +937,7 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!c || !key) return MF_EINVAL;
     if (!strcmp(key, "timings")) { c->timings_on = value != 0; return MF_OK; }
     if (!strcmp(key, "icpProfile")) { c->icp_prof_on = value != 0; return MF_OK; }
+    if (!strcmp(key, "splatTiles")) { c->splat_tiles = value != 0; return MF_OK; }   // 0: scatter + resolve form (specification)
     if (!strcmp(key, "overlapPreprocessing")) {
         (void)hipStreamSynchronize(c->stream_pre);
         (void)hipStreamSynchronize(c->stream);

@@ -175,6 +175,14 @@ void launch_splat_resolve(Surfels src, const PoseDev* pose, unsigned long long* 
                           float4* predV, float4* predN, uchar4* predImage, uint16_t* predTime, FrameDev* frame,
                           const uint8_t* rgb /*or null*/, uint8_t* predGray /*or null*/, uint8_t* fillGray /*or null*/,
                           hipStream_t s);
+// Tiled form of scatter + resolve (mf_splat.hip): bins surfels to 16x16 tiles, z-test in LDS, writes the maps directly.
+// tile_count must be zero on the first call (it is left zero).  Returns -1 if the image has too many tiles for the LDS
+// histograms (use the scatter form then).
+size_t splat_tiles_scratch_ints(int W, int H);
+int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
+                       int timeDelta, int* tile_count, int* tile_cursor, int* tile_base, int* entries, int entries_cap, void* bbox,
+                       float4* predV, float4* predN, uchar4* predImage, uint16_t* predTime, const uint8_t* rgb, uint8_t* predGray,
+                       uint8_t* fillGray, hipStream_t s);
 void launch_fill_keys(unsigned long long* keys, int n, hipStream_t s);
 void launch_fill_int(int* p, int v, int n, hipStream_t s);
 // ---------------- multi-model coupling (mf_segment.hip) ----------------

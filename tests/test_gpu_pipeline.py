@@ -110,3 +110,25 @@ def test_icp_iterations_logged(run):
     log = run["first"]["log"]
     assert np.isfinite(log).all()
     assert (log[:, 28] > 100).all()       # every one of the 19 iterations saw inliers
+
+
+def test_tiled_splat_equals_scatter_form(hip):
+    """The tiled prediction (mf_splat.hip: binning + LDS z-test, no key buffer) and the scatter + resolve form (global 64-bit
+    atomicMin; the executable specification) produce bit-identical maps, so the whole pipeline state stays bit-identical."""
+    from maskfusion_amd import MaskFusion
+    st, fr = scene_frames(10, noise=True)
+    runs = []
+    for tiles in (1, 0):
+        mf = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=10.0, so3=True, enableMultipleModels=False,
+                        numGSurfels=1 << 20, initConfidenceGlobal=2.0)
+        mf.setParam("splatTiles", tiles)
+        for k in range(10):
+            mf.processFrame(fr[k][0], fr[k][1])
+        runs.append(dict(pose=mf.getCurrPose(), count=mf.getBackgroundModel().lastCount(),
+                         v=mf.debugRead("pred_vertex"), n=mf.debugRead("pred_normal"), img=mf.debugRead("pred_image"),
+                         stats=mf.trackStats(0)))
+        mf.close()
+    a, b = runs
+    assert (a["v"][..., 2] > 0).mean() > 0.3          # the prediction is populated (confidence threshold 2)
+    assert np.array_equal(a["v"], b["v"]) and np.array_equal(a["n"], b["n"]) and np.array_equal(a["img"], b["img"])
+    assert np.array_equal(a["pose"], b["pose"]) and a["count"] == b["count"] and a["stats"] == b["stats"]
