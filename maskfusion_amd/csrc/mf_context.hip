@@ -80,8 +80,7 @@ struct mf_ctx {
     RgbCorr* d_corres = nullptr; float* d_rgb_partials[2] = {nullptr, nullptr}; int2* d_cnt[2] = {nullptr, nullptr};
     So3Result* d_so3 = nullptr;
     // tiled splat prediction (mf_splat.hip)
-    int* d_tile_count = nullptr; int* d_tile_cursor = nullptr; int* d_tile_base = nullptr; int* d_tile_entries = nullptr;
-    void* d_tile_bbox = nullptr; int tile_entries_cap = 0; int splat_tiles = 1;
+    int* d_tile_count = nullptr; int* d_tile_entries = nullptr; int tile_entries_cap = 0; int splat_tiles = 1;
     bool index_transposed = false;         // layout of d_index / d_ivc / d_ict / d_inr left by the last index pass
     const uint8_t* cur_rgb = nullptr;      // device rgb of the frame being processed (fill-in intensity at predict time)
     struct RetiredLog { int id; std::vector<int64_t> ts; std::vector<float> p; };
@@ -273,13 +272,10 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
         const size_t nt = splat_tiles_scratch_ints(W, H);
         const size_t maxcap = (size_t)std::max(surfel_capacity(cfg->num_gsurfels), surfel_capacity(cfg->num_osurfels));
         A(dev_alloc(c, c->allocs, &c->d_tile_count, nt));
-        A(dev_alloc(c, c->allocs, &c->d_tile_cursor, nt));
-        A(dev_alloc(c, c->allocs, &c->d_tile_base, nt + 1));
-        c->tile_entries_cap = (int)std::min<size_t>(4 * maxcap, (size_t)1 << 30);   // a surfel overlaps 1-4 tiles (sprites <= 64 px)
+        // every tile owns entries_cap / tiles list slots: 4x the surfel capacity in total (a surfel overlaps 1-4 tiles), i.e.
+        // room for every surfel of a full map to land in a quarter of the image (an overflow is an error, never a drop)
+        c->tile_entries_cap = (int)std::min<size_t>(4 * maxcap, (size_t)1 << 30);
         A(dev_alloc(c, c->allocs, &c->d_tile_entries, (size_t)c->tile_entries_cap));
-        uint2* bb = nullptr;
-        A(dev_alloc(c, c->allocs, &bb, maxcap));
-        c->d_tile_bbox = bb;
     }
     A(dev_alloc(c, c->allocs, &c->d_keys, (size_t)P, 0xFF));
     A(dev_alloc(c, c->allocs, &c->d_index, (size_t)P));
@@ -464,8 +460,7 @@ static void enqueue_predict(mf_ctx* c, ModelState& m) {
     if (c->splat_tiles) {
         const bool gray = photometric_on(c);
         if (launch_splat_tiled(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, c->cfg.max_depth_processed, m.confThr,
-                               c->cfg.time_delta, c->d_tile_count, c->d_tile_cursor, c->d_tile_base, c->d_tile_entries,
-                               c->tile_entries_cap, c->d_tile_bbox, m.d_predV, m.d_predN, m.d_predImage, m.d_predTime, c->cur_rgb,
+                               c->cfg.time_delta, c->d_tile_count, c->d_tile_entries, c->tile_entries_cap, m.d_predV, m.d_predN, m.d_predImage, m.d_predTime, c->cur_rgb,
                                gray ? m.d_predGray : nullptr, gray ? m.d_fillGray : nullptr, c->stream) == 0)
             return;
     }

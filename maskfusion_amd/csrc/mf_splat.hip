@@ -61,109 +61,69 @@ __device__ __forceinline__ bool splat_setup(const Surfels& src, int i, float tim
 struct BinArgs {
     Surfels src; const FrameDev* frame; const PoseDev* pose; int W, H; Intr k; float maxDepth, confThreshold; int timeDelta;
     int tilesX, tilesY;
-    int* tile_count;      // [tiles]   zero on entry (each tile workgroup re-zeroes its own counter when it is done)
-    int* tile_cursor;     // [tiles]   zeroed by pass 1, used by pass 2
-    int* tile_base;       // [tiles+1] exclusive scan of tile_count, written by pass 2 for pass 3
-    int* entries;         // [entries_cap]
-    int entries_cap;
-    short4* bbox;         // [surfels] px0, px1, py0, py1 (px0 > px1: culled)
+    int* tile_count;      // [tiles]  zero on entry (each tile workgroup re-zeroes its own counter when it is done)
+    int* entries;         // [tiles][tile_cap]
+    int tile_cap;
     FrameDev* frame_rw;   // overflow flag (pad[1])
 };
 
-// Pass 1: per-surfel sprite box + per-tile counts (LDS histogram per 1024-thread workgroup, flushed with one global atomic
-// per touched tile).
-__global__ __launch_bounds__(kBinThreads) void k_splat_bin_count(const BinArgs a) {
-    extern __shared__ int s_hist[];
+// Binning in one pass: every tile owns a fixed slice of `entries`, so no scan is needed.  A 1024-thread workgroup counts
+// its entries per tile in LDS, reserves a contiguous range per touched tile with ONE global atomicAdd (~13 k per frame
+// instead of one global atomic per covered pixel), then hands out slots inside the range with LDS atomics.  The order of
+// a tile's list is not deterministic; the z-test that consumes it is order independent.
+__global__ __launch_bounds__(kBinThreads) void k_splat_bin(const BinArgs a) {
+    extern __shared__ int s_mem[];
     const int nt = a.tilesX * a.tilesY;
-    for (int t = threadIdx.x; t < nt; t += kBinThreads) s_hist[t] = 0;
-    if (blockIdx.x == 0)
-        for (int t = threadIdx.x; t < nt; t += kBinThreads) a.tile_cursor[t] = 0;
-    __syncthreads();
-    const int n = a.frame->count;
+    int* s_cnt = s_mem;           // [nt] this workgroup's entries per tile, then the start of its reserved range
+    int* s_fill = s_mem + nt;     // [nt] slots handed out
+    const int n = a.frame->count;     // device-resident: the grid is fixed and walks the buffer in chunks of 2048 surfels
     const float time = (float)a.frame->tick;
     float Ri[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) Ri[q] = a.pose->Ri[q];
     const float3 ti = f3(a.pose->ti[0], a.pose->ti[1], a.pose->ti[2]);
-    for (int i = blockIdx.x * kBinThreads + threadIdx.x; i < n; i += gridDim.x * kBinThreads) {
-        SplatSetup su;
-        short4 bb = make_short4(1, 0, 1, 0);
-        if (splat_setup(a.src, i, time, Ri, ti, a.W, a.H, a.k, a.maxDepth, a.confThreshold, a.timeDelta, su)) {
-            bb = make_short4((short)su.px0, (short)su.px1, (short)su.py0, (short)su.py1);
-            for (int ty = su.py0 / kTile; ty <= su.py1 / kTile; ++ty)
-                for (int tx = su.px0 / kTile; tx <= su.px1 / kTile; ++tx) atomicAdd(&s_hist[ty * a.tilesX + tx], 1);
-        }
-        a.bbox[i] = bb;
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < nt; t += kBinThreads)
-        if (s_hist[t]) atomicAdd(&a.tile_count[t], s_hist[t]);
-}
-
-// Exclusive scan of the tile counts by one workgroup (nt <= kMaxTiles) into LDS; returns nothing, fills s_base[0..nt].
-__device__ __forceinline__ void scan_tiles(const int* __restrict__ counts, int nt, int* s_base, int* s_tmp, int nthreads) {
-    // each thread sums a contiguous chunk, one warp-free serial scan over the (<= 1024) chunk sums by thread 0 is avoided by
-    // a Hillis-Steele pass in LDS
-    const int per = (nt + nthreads - 1) / nthreads;
-    const int b = threadIdx.x * per, e = min(nt, b + per);
-    int sum = 0;
-    for (int t = b; t < e; ++t) sum += counts[t];
-    s_tmp[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < nthreads; off <<= 1) {
-        const int v = (threadIdx.x >= off) ? s_tmp[threadIdx.x - off] : 0;
-        __syncthreads();
-        s_tmp[threadIdx.x] += v;
-        __syncthreads();
-    }
-    int run = s_tmp[threadIdx.x] - sum;   // exclusive prefix of this thread's chunk
-    for (int t = b; t < e; ++t) { s_base[t] = run; run += counts[t]; }
-    if (threadIdx.x == nthreads - 1) s_base[nt] = s_tmp[nthreads - 1];
-    __syncthreads();
-}
-
-// Pass 2: fill the per-tile surfel lists.  A workgroup counts its own entries per tile in LDS, reserves a contiguous
-// range per touched tile with ONE global atomicAdd, then hands out slots inside the range with LDS atomics.
-__global__ __launch_bounds__(kBinThreads) void k_splat_bin_fill(const BinArgs a) {
-    extern __shared__ int s_mem[];
-    const int nt = a.tilesX * a.tilesY;
-    int* s_base = s_mem;                 // [nt + 1] exclusive scan of tile_count
-    int* s_cnt = s_mem + (nt + 1);       // [nt] this workgroup's entries per tile, then its reserved start
-    int* s_fill = s_cnt + nt;            // [nt] slots handed out
-    int* s_tmp = s_fill + nt;            // [kBinThreads]
-    scan_tiles(a.tile_count, nt, s_base, s_tmp, kBinThreads);
-    if (blockIdx.x == 0)
-        for (int t = threadIdx.x; t <= nt; t += kBinThreads) a.tile_base[t] = s_base[t];
+  for (int chunk = blockIdx.x; chunk * 2 * kBinThreads < n; chunk += gridDim.x) {
     for (int t = threadIdx.x; t < nt; t += kBinThreads) { s_cnt[t] = 0; s_fill[t] = 0; }
     __syncthreads();
-    const int n = a.frame->count;
-    for (int i = blockIdx.x * kBinThreads + threadIdx.x; i < n; i += gridDim.x * kBinThreads) {
-        const short4 bb = a.bbox[i];
-        if (bb.x > bb.y) continue;
-        for (int ty = bb.z / kTile; ty <= bb.w / kTile; ++ty)
-            for (int tx = bb.x / kTile; tx <= bb.y / kTile; ++tx) atomicAdd(&s_cnt[ty * a.tilesX + tx], 1);
+    // 2 surfels per thread; their sprite boxes stay in registers between the two phases
+    int idx[2]; short4 bb[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = (chunk * 2 + r) * kBinThreads + threadIdx.x;
+        idx[r] = i;
+        bb[r] = make_short4(1, 0, 1, 0);
+        if (i < n) {
+            SplatSetup su;
+            if (splat_setup(a.src, i, time, Ri, ti, a.W, a.H, a.k, a.maxDepth, a.confThreshold, a.timeDelta, su)) {
+                bb[r] = make_short4((short)su.px0, (short)su.px1, (short)su.py0, (short)su.py1);
+                for (int ty = su.py0 / kTile; ty <= su.py1 / kTile; ++ty)
+                    for (int tx = su.px0 / kTile; tx <= su.px1 / kTile; ++tx) atomicAdd(&s_cnt[ty * a.tilesX + tx], 1);
+            }
+        }
     }
     __syncthreads();
     for (int t = threadIdx.x; t < nt; t += kBinThreads)
-        if (s_cnt[t]) s_cnt[t] = s_base[t] + atomicAdd(&a.tile_cursor[t], s_cnt[t]);
+        if (s_cnt[t]) s_cnt[t] = atomicAdd(&a.tile_count[t], s_cnt[t]);
     __syncthreads();
-    for (int i = blockIdx.x * kBinThreads + threadIdx.x; i < n; i += gridDim.x * kBinThreads) {
-        const short4 bb = a.bbox[i];
-        if (bb.x > bb.y) continue;
-        for (int ty = bb.z / kTile; ty <= bb.w / kTile; ++ty)
-            for (int tx = bb.x / kTile; tx <= bb.y / kTile; ++tx) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (bb[r].x > bb[r].y) continue;
+        for (int ty = bb[r].z / kTile; ty <= bb[r].w / kTile; ++ty)
+            for (int tx = bb[r].x / kTile; tx <= bb[r].y / kTile; ++tx) {
                 const int t = ty * a.tilesX + tx;
                 const int slot = s_cnt[t] + atomicAdd(&s_fill[t], 1);
-                if (slot < a.entries_cap) a.entries[slot] = i;
+                if (slot < a.tile_cap) a.entries[(size_t)t * a.tile_cap + slot] = idx[r];
                 else a.frame_rw->pad[1] = 1;   // list overflow: reported by mf_sync (never silently dropped)
             }
     }
+    __syncthreads();
+  }
 }
 
 struct TileArgs {
     Surfels src; FrameDev* frame; const PoseDev* pose; int W, H; Intr k; float maxDepth, confThreshold; int timeDelta;
     int tilesX, tilesY;
-    int* tile_count; const int* tile_base; const int* entries; int entries_cap;
+    int* tile_count; const int* entries; int tile_cap;
     float4* predV; float4* predN; uchar4* predImage; uint16_t* predTime;
     const uint8_t* rgb; uint8_t* predGray; uint8_t* fillGray;
 };
@@ -173,7 +133,7 @@ struct TileArgs {
 __global__ __launch_bounds__(256) void k_splat_tile(const TileArgs a) {
     __shared__ unsigned long long s_key[kTile * kTile];
     __shared__ float4 s_ray[kTile * kTile];
-    __shared__ int s_range[2];
+    __shared__ int s_range[1];
     const int tile = blockIdx.x;
     const int tx0 = (tile % a.tilesX) * kTile, ty0 = (tile / a.tilesX) * kTile;
     s_key[threadIdx.x] = kEmptyKey;
@@ -184,12 +144,12 @@ __global__ __launch_bounds__(256) void k_splat_tile(const TileArgs a) {
         s_ray[threadIdx.x] = make_float4(l.x, l.y, l.z, 0.f);
     }
     if (threadIdx.x == 0) {
-        s_range[0] = a.tile_base[tile];
-        s_range[1] = a.tile_count[tile];
-        a.tile_count[tile] = 0;   // consumed: pass 1 of the next prediction starts from zero
+        s_range[0] = a.tile_count[tile];
+        a.tile_count[tile] = 0;   // consumed: the binning pass of the next prediction starts from zero
     }
     __syncthreads();
-    const int beg = s_range[0], cnt = min(s_range[1], max(0, a.entries_cap - s_range[0]));
+    const int cnt = min(s_range[0], a.tile_cap);
+    const int* __restrict__ list = a.entries + (size_t)tile * a.tile_cap;
     const float time = (float)a.frame->tick;
     float Ri[9];
 #pragma unroll
@@ -197,7 +157,7 @@ __global__ __launch_bounds__(256) void k_splat_tile(const TileArgs a) {
     const float3 ti = f3(a.pose->ti[0], a.pose->ti[1], a.pose->ti[2]);
     const Intr k = a.k;
     for (int e = threadIdx.x; e < cnt; e += 256) {
-        const int i = a.entries[beg + e];
+        const int i = list[e];
         SplatSetup su;
         if (!splat_setup(a.src, i, time, Ri, ti, a.W, a.H, k, a.maxDepth, a.confThreshold, a.timeDelta, su)) continue;
         const int x0 = max(su.px0, tx0), x1 = min(su.px1, tx0 + kTile - 1);
@@ -256,23 +216,20 @@ __global__ __launch_bounds__(256) void k_splat_tile(const TileArgs a) {
 size_t splat_tiles_scratch_ints(int W, int H) { return (size_t)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile); }
 
 int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
-                       int timeDelta, int* tile_count, int* tile_cursor, int* tile_base, int* entries, int entries_cap, void* bbox,
-                       float4* predV,
-                       float4* predN, uchar4* predImage, uint16_t* predTime, const uint8_t* rgb, uint8_t* predGray, uint8_t* fillGray,
-                       hipStream_t s) {
+                       int timeDelta, int* tile_count, int* entries, int entries_cap, float4* predV, float4* predN, uchar4* predImage,
+                       uint16_t* predTime, const uint8_t* rgb, uint8_t* predGray, uint8_t* fillGray, hipStream_t s) {
     const int tilesX = (W + kTile - 1) / kTile, tilesY = (H + kTile - 1) / kTile, nt = tilesX * tilesY;
     if (nt > kMaxTiles) return -1;
     BinArgs b;
     b.src = src; b.frame = frame; b.pose = pose; b.W = W; b.H = H; b.k = k; b.maxDepth = maxDepth; b.confThreshold = confThreshold;
-    b.timeDelta = timeDelta; b.tilesX = tilesX; b.tilesY = tilesY; b.tile_count = tile_count; b.tile_cursor = tile_cursor;
-    b.tile_base = tile_base; b.entries = entries; b.entries_cap = entries_cap; b.bbox = reinterpret_cast<short4*>(bbox); b.frame_rw = frame;
-    const int nblocks = 256;
-    hipLaunchKernelGGL(k_splat_bin_count, dim3(nblocks), dim3(kBinThreads), (size_t)nt * sizeof(int), s, b);
-    hipLaunchKernelGGL(k_splat_bin_fill, dim3(nblocks), dim3(kBinThreads), (size_t)(3 * nt + 1 + kBinThreads) * sizeof(int), s, b);
+    b.timeDelta = timeDelta; b.tilesX = tilesX; b.tilesY = tilesY; b.tile_count = tile_count;
+    b.entries = entries; b.tile_cap = entries_cap / nt; b.frame_rw = frame;
+    const int nblocks = min(256, (src.cap + 2 * kBinThreads - 1) / (2 * kBinThreads));
+    hipLaunchKernelGGL(k_splat_bin, dim3(nblocks), dim3(kBinThreads), (size_t)2 * nt * sizeof(int), s, b);
     TileArgs t;
     t.src = src; t.frame = frame; t.pose = pose; t.W = W; t.H = H; t.k = k; t.maxDepth = maxDepth; t.confThreshold = confThreshold;
-    t.timeDelta = timeDelta; t.tilesX = tilesX; t.tilesY = tilesY; t.tile_count = tile_count; t.tile_base = tile_base;
-    t.entries = entries; t.entries_cap = entries_cap;
+    t.timeDelta = timeDelta; t.tilesX = tilesX; t.tilesY = tilesY; t.tile_count = tile_count;
+    t.entries = entries; t.tile_cap = b.tile_cap;
     t.predV = predV; t.predN = predN; t.predImage = predImage; t.predTime = predTime; t.rgb = rgb; t.predGray = predGray;
     t.fillGray = fillGray;
     hipLaunchKernelGGL(k_splat_tile, dim3(nt), dim3(256), 0, s, t);
