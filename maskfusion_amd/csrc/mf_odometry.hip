@@ -264,19 +264,42 @@ __device__ __forceinline__ int icp_component_of_lane(int lane) {
 __device__ __forceinline__ float bitsel(unsigned mask, float a, float b) {
     return __uint_as_float((__float_as_uint(a) & mask) | (__float_as_uint(b) & ~mask));
 }
+// Cross-lane fetch "value of lane (lane ^ kXor)".  xor 1 / 2 are quad permutes, xor 8 a 16-lane row rotation, xor 4 two row
+// rotations and a select -- all DPP modifiers on VALU instructions (no LDS crossbar traffic); only xor 16 / 32 cross a DPP row
+// and go through ds_bpermute.  30 of the 32 exchanges of the halving tree are xor 1..8: with every exchange on the
+// bpermute path the tree cost ~5 k cycles per launch at 16 wavefronts per CU (the crossbar serialises them).
+template <int kXor>
+__device__ __forceinline__ float lane_xor(float v, int lane) {
+    const int iv = __float_as_int(v);
+    if constexpr (kXor == 1) return __int_as_float(__builtin_amdgcn_update_dpp(0, iv, 0xB1, 0xf, 0xf, false));   // quad_perm:[1,0,3,2]
+    else if constexpr (kXor == 2) return __int_as_float(__builtin_amdgcn_update_dpp(0, iv, 0x4E, 0xf, 0xf, false));   // quad_perm:[2,3,0,1]
+    else if constexpr (kXor == 4) {
+        const int dn = __builtin_amdgcn_update_dpp(0, iv, 0x124, 0xf, 0xf, false);   // row_ror:4  -> lane i reads i - 4 (mod 16)
+        const int up = __builtin_amdgcn_update_dpp(0, iv, 0x12C, 0xf, 0xf, false);   // row_ror:12 -> lane i reads i + 4 (mod 16)
+        return __int_as_float((lane & 4) ? dn : up);
+    } else if constexpr (kXor == 8) return __int_as_float(__builtin_amdgcn_update_dpp(0, iv, 0x128, 0xf, 0xf, false));   // row_ror:8
+    else return __shfl_xor(v, kXor, 64);
+}
+
+template <int kStep>
+__device__ __forceinline__ void halving_step(float (&v)[32], int lane) {
+    constexpr int half = 16 >> kStep;
+    const unsigned up = ((lane >> kStep) & 1) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+    for (int k = 0; k < half; ++k) {
+        const float send = bitsel(up, v[k], v[k + half]);
+        const float keep = bitsel(up, v[k + half], v[k]);
+        v[k] = keep + lane_xor<(1 << kStep)>(send, lane);
+    }
+}
+
 __device__ __forceinline__ float wave_sum32_halving(float (&v)[32]) {
     const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int s = 0; s < 5; ++s) {
-        const int half = 16 >> s;
-        const unsigned up = ((lane >> s) & 1) ? 0xFFFFFFFFu : 0u;
-#pragma unroll
-        for (int k = 0; k < half; ++k) {
-            const float send = bitsel(up, v[k], v[k + half]);
-            const float keep = bitsel(up, v[k + half], v[k]);
-            v[k] = keep + __shfl_xor(send, 1 << s, 64);
-        }
-    }
+    halving_step<0>(v, lane);
+    halving_step<1>(v, lane);
+    halving_step<2>(v, lane);
+    halving_step<3>(v, lane);
+    halving_step<4>(v, lane);
     return v[0] + __shfl_xor(v[0], 32, 64);
 }
 
@@ -343,12 +366,15 @@ __device__ __forceinline__ void seed_state(const PoseDev& pose, GNState& s) {
     s.levelDone = -1; s.lastRGBError = 3.4028234664e38f; s.lastRGBCount = 0.f;
 }
 
-// 1024 threads = 16 wavefronts per workgroup, ONE pixel per thread: the per-pixel chain (project -> gather -> gate ->
-// 29 products) is ~250 dependent VALU instructions, so what a launch costs is how well that latency is hidden.  Four
-// wavefronts per SIMD hide it; one wavefront per SIMD with 4 pixels per thread (the 16 B-per-lane variant) measured
-// 2.5x slower for the same bytes.  A wavefront still touches one contiguous 256 B line per streamed plane.
-constexpr int kIcpThreads = 1024;
-constexpr int kIcpMaxBlocks = 240;  // <= one 1024-thread workgroup per CU (256 CUs) with a little slack for busy CUs
+// Workgroup shape.  Per launch a CU spends its time in three VALU-throughput-bound stretches (one VALU instruction per 4
+// cycles per SIMD, 4 SIMDs): the per-pixel chain (project -> gather -> gate -> 29 products, ~250 instructions per 64
+// pixels), the 32-value halving reduction (~300 instructions PER WAVEFRONT, however few pixels it carried) and the
+// single-wavefront solve.  With 16 wavefronts per CU at one pixel per thread the reduction alone was 16 x 300 x 4 / 4 =
+// 4 800 cycles of every launch; 8 wavefronts carrying up to 3 pixels per thread halve that while two wavefronts per SIMD
+// plus all gathers of a thread in flight together still hide the gather latency.
+constexpr int kIcpThreads = 512;
+constexpr int kIcpPx = 3;           // pixel slots per thread (a workgroup's chunk is <= kIcpPx * kIcpThreads pixels)
+constexpr int kIcpMaxBlocks = 240;  // <= one workgroup per CU (256 CUs) with a little slack for busy CUs
 
 __host__ __device__ inline int icp_chunk(int P, int nblocks) {
     const int c = (P + nblocks - 1) / nblocks;
@@ -377,24 +403,25 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp_iter(const IcpKArgs a) {
     unsigned long long stamp[8];
     if (prof) stamp[0] = __builtin_amdgcn_s_memtime();
     const int P = a.W * a.H;
-    // A workgroup owns a contiguous chunk of <= 2 * kIcpThreads pixels (icp_grid_blocks keeps the grid <= one workgroup
+    // A workgroup owns a contiguous chunk of <= kIcpPx * kIcpThreads pixels (icp_grid_blocks keeps the grid <= one workgroup
     // per CU so that a launch is ONE round of workgroups: 300 workgroups of 1024 px on 256 CUs ran as two rounds and
     // doubled the level-0 launch time).  Thread t handles pixel beg + t and, if the chunk is longer, beg + 1024 + t.
     const int chunk = icp_chunk(P, gridDim.x);
     const int beg = blockIdx.x * chunk, end = min(P, beg + chunk);
-    const int i0 = beg + tid, i1 = beg + kIcpThreads + tid;
-    const bool act0 = i0 < end, act1 = i1 < end;
 
     // (1) issue the pose-independent streamed loads first so their latency overlaps the solve below
-    float vx0 = 0.f, vy0 = 0.f, vz0 = 0.f, nx0 = 0.f, ny0 = 0.f, nz0 = 0.f;
-    float vx1 = 0.f, vy1 = 0.f, vz1 = 0.f, nx1 = 0.f, ny1 = 0.f, nz1 = 0.f;
-    if (act0) {
-        vx0 = a.vc[i0]; vy0 = a.vc[P + i0]; vz0 = a.vc[2 * P + i0];
-        nx0 = a.nc[i0]; ny0 = a.nc[P + i0]; nz0 = a.nc[2 * P + i0];
-    }
-    if (act1) {
-        vx1 = a.vc[i1]; vy1 = a.vc[P + i1]; vz1 = a.vc[2 * P + i1];
-        nx1 = a.nc[i1]; ny1 = a.nc[P + i1]; nz1 = a.nc[2 * P + i1];
+    int idx[kIcpPx]; bool act[kIcpPx];
+    float vx[kIcpPx], vy[kIcpPx], vz[kIcpPx], nx[kIcpPx], ny[kIcpPx], nz[kIcpPx];
+#pragma unroll
+    for (int q = 0; q < kIcpPx; ++q) {
+        idx[q] = beg + q * kIcpThreads + tid;
+        act[q] = idx[q] < end;
+        vx[q] = vy[q] = vz[q] = nx[q] = ny[q] = nz[q] = 0.f;
+        if (act[q]) {
+            const int i = idx[q];
+            vx[q] = a.vc[i]; vy[q] = a.vc[P + i]; vz[q] = a.vc[2 * P + i];
+            nx[q] = a.nc[i]; ny[q] = a.nc[P + i]; nz[q] = a.nc[2 * P + i];
+        }
     }
 
     // (2) prologue: finish the previous iteration (reduce -> solve -> pose), identically in every workgroup
@@ -439,20 +466,22 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp_iter(const IcpKArgs a) {
     float acc[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) acc[k] = 0.f;
-    if (act0) {
-        const IcpCorr c = icp_project(vx0, vy0, vz0, nx0, ny0, nz0, Rc, tc, Rpi, tp, a);
-        const int j = c.j;
-        const float3 pv = f3(a.vp[j], a.vp[P + j], a.vp[2 * P + j]);
-        const float3 pn = f3(a.np[j], a.np[P + j], a.np[2 * P + j]);
-        icp_accumulate(c, pv, pn, Rpi, tp, a, acc);
-    }
-    if (act1) {
-        const IcpCorr c = icp_project(vx1, vy1, vz1, nx1, ny1, nz1, Rc, tc, Rpi, tp, a);
-        const int j = c.j;
-        const float3 pv = f3(a.vp[j], a.vp[P + j], a.vp[2 * P + j]);
-        const float3 pn = f3(a.np[j], a.np[P + j], a.np[2 * P + j]);
-        icp_accumulate(c, pv, pn, Rpi, tp, a, acc);
-    }
+    // all projections, then all gathers (independent loads in flight together), then the products
+    IcpCorr cor[kIcpPx];
+    float3 pv[kIcpPx], pn[kIcpPx];
+#pragma unroll
+    for (int q = 0; q < kIcpPx; ++q)
+        if (act[q]) cor[q] = icp_project(vx[q], vy[q], vz[q], nx[q], ny[q], nz[q], Rc, tc, Rpi, tp, a);
+#pragma unroll
+    for (int q = 0; q < kIcpPx; ++q)
+        if (act[q]) {
+            const int j = cor[q].j;
+            pv[q] = f3(a.vp[j], a.vp[P + j], a.vp[2 * P + j]);
+            pn[q] = f3(a.np[j], a.np[P + j], a.np[2 * P + j]);
+        }
+#pragma unroll
+    for (int q = 0; q < kIcpPx; ++q)
+        if (act[q]) icp_accumulate(cor[q], pv[q], pn[q], Rpi, tp, a, acc);
 
     // (4) wavefront reduction (DPP), one LDS stage across the 16 wavefronts, one 128 B partial per workgroup
     if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[5] = __builtin_amdgcn_s_memtime(); }
@@ -481,7 +510,7 @@ int icp_grid_blocks(int W, int H) {
     int nb = (P + kIcpThreads - 1) / kIcpThreads;
     if (nb > kIcpMaxBlocks) {
         nb = kIcpMaxBlocks;
-        while (icp_chunk(P, nb) > 2 * kIcpThreads) ++nb;  // larger images: more than one round, still <= 2 px per thread
+        while (icp_chunk(P, nb) > kIcpPx * kIcpThreads) ++nb;  // larger images: more than one round of workgroups
     }
     return nb;
 }

@@ -12,10 +12,10 @@ pytestmark = pytest.mark.gpu
 CORR = np.dtype([("u0", np.int16), ("v0", np.int16), ("diff", np.float32)])
 
 
-def _frames(n, W=320, H=240):
+def _frames(n, W=320, H=240, noise=False):
     from maskfusion_amd import synth
     f = 528.0 * W / 640.0
-    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=False)
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=noise)
     return st, [st.frame(k) for k in range(n)]
 
 
@@ -133,7 +133,9 @@ def test_rgb_residual_and_step(hip, oracle):
 def _run_pair(oracle, n, W, H, **cfg):
     from maskfusion_amd import MaskFusion
     from oracle import mfo_rgbd
-    st, fr = _frames(n, W, H)
+    # sensor noise on: on noise-free synthetic planes the z-tests of the surfel passes hit exact depth ties, whose outcome
+    # flips with the last bit of the pose and makes surfel COUNTS chaotic (poses still agree to microns)
+    st, fr = _frames(n, W, H, noise=True)
     o = oracle.Oracle(st.W, st.H, st.fx, st.fy, st.cx, st.cy, capacity=1 << 19, icpWeight=cfg.get("icpWeight", 10.0),
                       so3=int(cfg.get("so3", 1)), rgbOnly=int(cfg.get("rgbOnly", 0)))
     mf = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=cfg.get("icpWeight", 10.0), so3=bool(cfg.get("so3", 1)),
