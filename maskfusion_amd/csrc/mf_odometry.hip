@@ -951,11 +951,25 @@ struct PyrArgs {
     int W, H; Intr k;
 };
 
+// value of lane (quad base + kB) for every lane of a quad: one DPP quad_perm broadcast, no LDS traffic
+template <int kB>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), kB | (kB << 2) | (kB << 4) | (kB << 6), 0xf, 0xf, false));
+}
+template <int kB>
+__device__ __forceinline__ float3 quad_bcast3(float3 v) { return f3(quad_bcast<kB>(v.x), quad_bcast<kB>(v.y), quad_bcast<kB>(v.z)); }
+
+// One thread per LEVEL-1 pixel (2x2 level-0 pixels); the four lanes of a DPP quad hold the 2x2 level-1 block of one level-2
+// pixel and exchange their values with quad broadcasts, so the averages keep the reference's operation order
+// ((x00 + x01 + x10 + x11) / 4, level 2 from level-1 values).  (A thread per level-2 pixel -- 19 200 threads walking 16
+// pixels each -- left three quarters of the CUs idle: 15 us.)
 __global__ __launch_bounds__(256) void k_model_pyramid(const PyrArgs a) {
     const int W2 = a.W >> 2, H2 = a.H >> 2;
-    const int x2 = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y2 = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x2 >= W2 || y2 >= H2) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = lane & 3, bx = b & 1, by = b >> 1;
+    const int x2 = blockIdx.x * 16 + (lane >> 2);
+    const int y2 = blockIdx.y * 4 + wave;
+    const bool inside = x2 < W2 && y2 < H2;   // whole quads are in or out: the DPP exchanges below stay well defined
     float R[9]; float3 t;
     if (a.hostPose) {
 #pragma unroll
@@ -970,43 +984,42 @@ __global__ __launch_bounds__(256) void k_model_pyramid(const PyrArgs a) {
     const int W = a.W, H = a.H, W1 = W >> 1, H1 = H >> 1;
     const int P0 = W * H, P1 = W1 * H1, P2 = W2 * H2;
 
-    float3 v1[4], n1[4]; bool v1ok[4], n1ok[4];
+    float3 v1 = f3(qnan(), qnan(), qnan()), n1 = v1;
+    bool v1ok = false, n1ok = false;
+    if (inside) {
+        MapPx px[4];
 #pragma unroll
-    for (int by = 0; by < 2; ++by) {
+        for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-        for (int bx = 0; bx < 2; ++bx) {
-            MapPx px[4];
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    const int x = 4 * x2 + 2 * bx + dx, y = 4 * y2 + 2 * by + dy;
-                    px[dy * 2 + dx] = load_model_px(a.predV, a.predN, a.fillDepth, useFill, x, y, W, H, a.k);
-                    store_tx(a.vm[0], a.nm[0], P0, y * W + x, px[dy * 2 + dx].v, px[dy * 2 + dx].vok, px[dy * 2 + dx].n,
-                             px[dy * 2 + dx].nok, R, t);
-                }
-            // resizeMapKernel<false/true>, cudafuncs.cu:366-417: order x00 + x01 + x10 + x11
-            const int b = by * 2 + bx;
-            v1ok[b] = px[0].vok && px[1].vok && px[2].vok && px[3].vok;
-            n1ok[b] = px[0].nok && px[1].nok && px[2].nok && px[3].nok;
-            v1[b] = f3((px[0].v.x + px[1].v.x + px[2].v.x + px[3].v.x) / 4, (px[0].v.y + px[1].v.y + px[2].v.y + px[3].v.y) / 4,
-                       (px[0].v.z + px[1].v.z + px[2].v.z + px[3].v.z) / 4);
-            n1[b] = normalized_rsqrt(f3((px[0].n.x + px[1].n.x + px[2].n.x + px[3].n.x) / 4,
-                                        (px[0].n.y + px[1].n.y + px[2].n.y + px[3].n.y) / 4,
-                                        (px[0].n.z + px[1].n.z + px[2].n.z + px[3].n.z) / 4));
-            if (!v1ok[b]) v1[b] = f3(qnan(), qnan(), qnan());
-            if (!n1ok[b]) n1[b] = f3(qnan(), qnan(), qnan());
-            n1ok[b] = n1ok[b] && !isnan(n1[b].x);
-            const int x1 = 2 * x2 + bx, y1 = 2 * y2 + by;
-            store_tx(a.vm[1], a.nm[1], P1, y1 * W1 + x1, v1[b], v1ok[b], n1[b], n1ok[b], R, t);
-        }
+            for (int dx = 0; dx < 2; ++dx) {
+                const int x = 4 * x2 + 2 * bx + dx, y = 4 * y2 + 2 * by + dy;
+                px[dy * 2 + dx] = load_model_px(a.predV, a.predN, a.fillDepth, useFill, x, y, W, H, a.k);
+                store_tx(a.vm[0], a.nm[0], P0, y * W + x, px[dy * 2 + dx].v, px[dy * 2 + dx].vok, px[dy * 2 + dx].n,
+                         px[dy * 2 + dx].nok, R, t);
+            }
+        // resizeMapKernel<false/true>, cudafuncs.cu:366-417: order x00 + x01 + x10 + x11
+        v1ok = px[0].vok && px[1].vok && px[2].vok && px[3].vok;
+        n1ok = px[0].nok && px[1].nok && px[2].nok && px[3].nok;
+        v1 = f3((px[0].v.x + px[1].v.x + px[2].v.x + px[3].v.x) / 4, (px[0].v.y + px[1].v.y + px[2].v.y + px[3].v.y) / 4,
+                (px[0].v.z + px[1].v.z + px[2].v.z + px[3].v.z) / 4);
+        n1 = normalized_rsqrt(f3((px[0].n.x + px[1].n.x + px[2].n.x + px[3].n.x) / 4,
+                                 (px[0].n.y + px[1].n.y + px[2].n.y + px[3].n.y) / 4,
+                                 (px[0].n.z + px[1].n.z + px[2].n.z + px[3].n.z) / 4));
+        if (!v1ok) v1 = f3(qnan(), qnan(), qnan());
+        if (!n1ok) n1 = f3(qnan(), qnan(), qnan());
+        n1ok = n1ok && !isnan(n1.x);
+        const int x1 = 2 * x2 + bx, y1 = 2 * y2 + by;
+        store_tx(a.vm[1], a.nm[1], P1, y1 * W1 + x1, v1, v1ok, n1, n1ok, R, t);
     }
-    const bool v2ok = v1ok[0] && v1ok[1] && v1ok[2] && v1ok[3];
-    bool n2ok = n1ok[0] && n1ok[1] && n1ok[2] && n1ok[3];
-    float3 v2 = f3((v1[0].x + v1[1].x + v1[2].x + v1[3].x) / 4, (v1[0].y + v1[1].y + v1[2].y + v1[3].y) / 4,
-                   (v1[0].z + v1[1].z + v1[2].z + v1[3].z) / 4);
-    float3 n2 = normalized_rsqrt(f3((n1[0].x + n1[1].x + n1[2].x + n1[3].x) / 4, (n1[0].y + n1[1].y + n1[2].y + n1[3].y) / 4,
-                                    (n1[0].z + n1[1].z + n1[2].z + n1[3].z) / 4));
+    // level 2: the quad's four level-1 values in block order b = by * 2 + bx (executed by every lane: DPP needs them active)
+    const float okv = v1ok ? 1.f : 0.f, okn = n1ok ? 1.f : 0.f;
+    const float3 va = quad_bcast3<0>(v1), vb = quad_bcast3<1>(v1), vc = quad_bcast3<2>(v1), vd = quad_bcast3<3>(v1);
+    const float3 na = quad_bcast3<0>(n1), nb = quad_bcast3<1>(n1), nc = quad_bcast3<2>(n1), nd = quad_bcast3<3>(n1);
+    const bool v2ok = quad_bcast<0>(okv) != 0.f && quad_bcast<1>(okv) != 0.f && quad_bcast<2>(okv) != 0.f && quad_bcast<3>(okv) != 0.f;
+    bool n2ok = quad_bcast<0>(okn) != 0.f && quad_bcast<1>(okn) != 0.f && quad_bcast<2>(okn) != 0.f && quad_bcast<3>(okn) != 0.f;
+    if (!inside || b != 0) return;
+    float3 v2 = f3((va.x + vb.x + vc.x + vd.x) / 4, (va.y + vb.y + vc.y + vd.y) / 4, (va.z + vb.z + vc.z + vd.z) / 4);
+    float3 n2 = normalized_rsqrt(f3((na.x + nb.x + nc.x + nd.x) / 4, (na.y + nb.y + nc.y + nd.y) / 4, (na.z + nb.z + nc.z + nd.z) / 4));
     if (!v2ok) v2 = f3(qnan(), qnan(), qnan());
     if (!n2ok) n2 = f3(qnan(), qnan(), qnan());
     n2ok = n2ok && !isnan(n2.x);
@@ -1023,7 +1036,7 @@ void launch_model_pyramid(const float4* predV, const float4* predN, const float*
     for (int i = 0; i < 3; ++i) a.t[i] = a.hostPose ? R9t3_host_or_null[9 + i] : 0.f;
     for (int i = 0; i < 3; ++i) { a.vm[i] = vmaps[i]; a.nm[i] = nmaps[i]; }
     a.W = W; a.H = H; a.k = k;
-    dim3 grid(((W >> 2) + 63) / 64, ((H >> 2) + 3) / 4);
+    dim3 grid(((W >> 2) + 15) / 16, ((H >> 2) + 3) / 4);
     hipLaunchKernelGGL(k_model_pyramid, grid, dim3(256), 0, s, a);
 }
 

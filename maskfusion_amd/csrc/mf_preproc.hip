@@ -149,9 +149,9 @@ void launch_vmap_nmap(const float* depth, float* vmap, float* nmap, int W, int H
 
 // ------------------------------------------------------------------------------------------------
 // Model::generateCUDATextures in ONE launch (Core/Model/Model.cpp:350-389): pyrDownGaussF x2 + createVMap/createNMap x3.
-// A 256-thread workgroup owns an 8x8 tile of level 2 = 16x16 of level 1 = 32x32 of level 0.  It stages the 45x45 level-0
-// depths those need (5x5 taps of 5x5 taps + the +1 neighbours of the normals), builds the 21x21 level-1 and 9x9 level-2
-// depths in LDS with exactly the per-pixel expressions of k_pyrdown_f (same loop bounds, same summation order: results are
+// A 256-thread workgroup owns a 4x4 tile of level 2 = 8x8 of level 1 = 16x16 of level 0 (1200 workgroups at VGA; 8x8 tiles
+// = 300 workgroups left the chip half empty: 17 us).  It stages the 29x29 level-0 depths those need (5x5 taps of 5x5 taps
+// + the +1 neighbours of the normals), builds the 13x13 level-1 and 5x5 level-2 depths in LDS with exactly the per-pixel expressions of k_pyrdown_f (same loop bounds, same summation order: results are
 // bit-identical to the level-by-level kernels), and writes the six planar maps.  Five dependent launches (2 x 7.8 us +
 // 3 x 4.8 us: each one launch-latency bound) become one; the two smaller depth levels never visit HBM.
 // ------------------------------------------------------------------------------------------------
@@ -195,14 +195,15 @@ struct FramePyrArgs {
     float* vmap[3]; float* nmap[3];
 };
 
-constexpr int kFpL0 = 45, kFpL1 = 21, kFpL2 = 9;
+constexpr int kFpT2 = 4;                                   // level-2 tile side of a workgroup (16x16 level-0 pixels)
+constexpr int kFpL2 = kFpT2 + 1, kFpL1 = 2 * kFpT2 + 5, kFpL0 = 2 * kFpL1 + 3;   // 5, 13, 29 with their halos
 
 __global__ __launch_bounds__(256) void k_frame_pyramid(const FramePyrArgs a) {
     __shared__ float s0[kFpL0 * kFpL0];
     __shared__ float s1[kFpL1 * kFpL1];
     __shared__ float s2[kFpL2 * kFpL2];
     const int W0 = a.W, H0 = a.H, W1 = W0 >> 1, H1 = H0 >> 1, W2 = W0 >> 2, H2 = H0 >> 2;
-    const int X2 = blockIdx.x * 8, Y2 = blockIdx.y * 8;          // tile origin at level 2
+    const int X2 = blockIdx.x * kFpT2, Y2 = blockIdx.y * kFpT2;  // tile origin at level 2
     const int ox1 = 2 * X2 - 2, oy1 = 2 * Y2 - 2;                // LDS origins (may be negative)
     const int ox0 = 2 * ox1 - 2, oy0 = 2 * oy1 - 2;
     const int tid = threadIdx.x;
@@ -218,27 +219,26 @@ __global__ __launch_bounds__(256) void k_frame_pyramid(const FramePyrArgs a) {
         s1[i] = (gx >= 0 && gx < W1 && gy >= 0 && gy < H1) ? pyrdown_px(s0, kFpL0, ox0, oy0, gx, gy, W0, H0) : qnan();
     }
     __syncthreads();
-    if (tid < kFpL2 * kFpL2) {
-        const int ly = tid / kFpL2, lx = tid - ly * kFpL2;
+    for (int i = tid; i < kFpL2 * kFpL2; i += 256) {
+        const int ly = i / kFpL2, lx = i - ly * kFpL2;
         const int gx = X2 + lx, gy = Y2 + ly;
-        s2[tid] = (gx < W2 && gy < H2) ? pyrdown_px(s1, kFpL1, ox1, oy1, gx, gy, W1, H1) : qnan();
+        s2[i] = (gx < W2 && gy < H2) ? pyrdown_px(s1, kFpL1, ox1, oy1, gx, gy, W1, H1) : qnan();
     }
     __syncthreads();
     // vertex / normal maps of the three tiles
     const Intr k0 = a.k;
     const Intr k1 = Intr{a.k.fx / 2.f, a.k.fy / 2.f, a.k.cx / 2.f, a.k.cy / 2.f};
     const Intr k2 = Intr{a.k.fx / 4.f, a.k.fy / 4.f, a.k.cx / 4.f, a.k.cy / 4.f};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int l = q * 256 + tid, u = 4 * X2 + (l & 31), v = 4 * Y2 + (l >> 5);
+    for (int l = tid; l < 16 * kFpT2 * kFpT2; l += 256) {
+        const int u = 4 * X2 + l % (4 * kFpT2), v = 4 * Y2 + l / (4 * kFpT2);
         if (u < W0 && v < H0) vmap_nmap_px(s0, kFpL0, ox0, oy0, u, v, W0, H0, k0, a.cutoff, a.vmap[0], a.nmap[0]);
     }
-    {
-        const int u = 2 * X2 + (tid & 15), v = 2 * Y2 + (tid >> 4);
+    for (int l = tid; l < 4 * kFpT2 * kFpT2; l += 256) {
+        const int u = 2 * X2 + l % (2 * kFpT2), v = 2 * Y2 + l / (2 * kFpT2);
         if (u < W1 && v < H1) vmap_nmap_px(s1, kFpL1, ox1, oy1, u, v, W1, H1, k1, a.cutoff, a.vmap[1], a.nmap[1]);
     }
-    if (tid < 64) {
-        const int u = X2 + (tid & 7), v = Y2 + (tid >> 3);
+    for (int l = tid; l < kFpT2 * kFpT2; l += 256) {
+        const int u = X2 + l % kFpT2, v = Y2 + l / kFpT2;
         if (u < W2 && v < H2) vmap_nmap_px(s2, kFpL2, X2, Y2, u, v, W2, H2, k2, a.cutoff, a.vmap[2], a.nmap[2]);
     }
 }
@@ -248,7 +248,7 @@ void launch_frame_pyramid(const float* depth, float* const vmap[3], float* const
     FramePyrArgs a;
     a.depth = depth; a.W = W; a.H = H; a.k = k; a.cutoff = cutoff;
     for (int i = 0; i < 3; ++i) { a.vmap[i] = vmap[i]; a.nmap[i] = nmap[i]; }
-    dim3 grid(((W >> 2) + 7) / 8, ((H >> 2) + 7) / 8);
+    dim3 grid(((W >> 2) + kFpT2 - 1) / kFpT2, ((H >> 2) + kFpT2 - 1) / kFpT2);
     hipLaunchKernelGGL(k_frame_pyramid, grid, dim3(256), 0, s, a);
 }
 
