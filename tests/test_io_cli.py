@@ -1,0 +1,103 @@
+"""Readers of the reference's input formats and the flag handling of the headless driver.  CPU only
+(the GPU run of the driver is tests/test_gpu_api.py::test_cli_runs_image_directory)."""
+import os
+
+import numpy as np
+import pytest
+
+from maskfusion_amd import cli
+from maskfusion_amd.io import ImageLogReader, KlgLogReader, load_calibration, open_log, write_image_dir, write_klg
+
+W, H = 64, 48
+
+
+def _frames(n=4, seed=0):
+    rng = np.random.default_rng(seed)
+    return [(33333 * k, rng.integers(0, 255, (H, W, 3), dtype=np.uint8),
+             np.round(rng.uniform(0.5, 4, (H, W)), 3).astype(np.float32)) for k in range(n)]
+
+
+@pytest.mark.parametrize("compress", [True, False])
+def test_klg_round_trip(tmp_path, compress):
+    fr = _frames()
+    p = str(tmp_path / "a.klg")
+    write_klg(p, fr, compress_depth=compress)
+    r = KlgLogReader(p, W, H)
+    assert r.getNumFrames() == 4
+    out = list(r)
+    assert len(out) == 3          # hasMore() is "currentFrame + 1 < numFrames": upstream never delivers the last frame
+    for f, (ts, rgb, depth) in zip(out, fr):
+        assert f.timestamp == ts and np.array_equal(f.rgb, rgb)
+        assert np.array_equal(f.depth, (np.rint(depth.astype(np.float64) * 1000).astype(np.uint16)).astype(np.float32) * np.float32(0.001))
+    r2 = KlgLogReader(p, W, H, flipColors=True)
+    assert np.array_equal(r2.getNext().rgb, fr[0][1][..., ::-1])
+    with pytest.raises(FileNotFoundError):
+        KlgLogReader(str(tmp_path / "missing.klg"))
+
+
+def test_klg_jpeg_frames(tmp_path):
+    import io
+    import struct
+    import zlib
+    from PIL import Image
+    rgb = np.zeros((H, W, 3), np.uint8); rgb[:, :, 0] = 200; rgb[10:20, 10:30, 1] = 180
+    buf = io.BytesIO(); Image.fromarray(rgb).save(buf, "JPEG", quality=95)
+    d16 = zlib.compress(np.full((H, W), 1500, np.uint16).tobytes())
+    p = str(tmp_path / "j.klg")
+    with open(p, "wb") as f:
+        f.write(struct.pack("<i", 2))
+        for k in range(2):
+            f.write(struct.pack("<qii", k, len(d16), len(buf.getvalue()))); f.write(d16); f.write(buf.getvalue())
+    fr = KlgLogReader(p, W, H).getNext()
+    assert np.allclose(fr.depth, 1.5) and np.abs(fr.rgb.astype(int) - rgb.astype(int)).mean() < 4
+
+
+def test_image_directory(tmp_path):
+    fr = _frames()
+    masks = [np.zeros((H, W), np.uint8) for _ in fr]
+    masks[1][5:20, 8:30] = 1
+    d = str(tmp_path / "seq") + os.sep
+    write_image_dir(d, [(a, b) for _, a, b in fr], masks=masks, class_ids=[[0, 41]] * 4, calibration=(50.5, 51.5, 32, 24, W, H))
+    r = ImageLogReader(d)
+    assert r.getNumFrames() == 4 and r.startIndex == 0 and r.hasMasksGT and r.calibrationFile.endswith("calibration.txt")
+    out = list(r)
+    assert len(out) == 4
+    assert np.array_equal(out[2].rgb, fr[2][1]) and np.abs(out[2].depth - fr[2][2]).max() < 6e-4
+    assert out[1].classIDs == [0, 41] and np.array_equal(out[1].mask, masks[1])
+    assert out[3].timestamp == int(3 * 1000.0 / 24.0)        # ImageLogReader.cpp:280, rateHz = 24
+    assert load_calibration(r.calibrationFile) == (50.5, 51.5, 32.0, 24.0, W, H)
+    assert isinstance(open_log(d), ImageLogReader)
+    # start index 1 and a missing depth image
+    d2 = str(tmp_path / "seq1") + os.sep
+    write_image_dir(d2, [(a, b) for _, a, b in fr], start_index=1)
+    r2 = ImageLogReader(d2)
+    assert r2.startIndex == 1 and not r2.hasMasksGT and np.array_equal(r2.getNext().rgb, fr[0][1])
+    os.remove(d2 + "Depth0002.png")
+    with pytest.raises(ValueError):
+        ImageLogReader(d2)
+
+
+def test_mask_description_file(tmp_path):
+    p = tmp_path / "Mask0000.txt"
+    p.write_text("41 64\n10 20 110 220\n5 6 50 60\n")
+    ids, rois = ImageLogReader.loadMaskIDs(str(p))
+    assert ids == [0, 41, 64] and rois == [(20, 10, 200, 100), (6, 5, 54, 45)]   # cv::Rect(b, a, d - b, c - a)
+    p.write_text("41 64\n10 20 110 220\n")
+    with pytest.raises(ValueError):
+        ImageLogReader.loadMaskIDs(str(p))
+
+
+def test_cli_flags_and_defaults():
+    f = cli.parse(["-dir", "seq/", "-tum3", "-run", "-q", "-ep", "-em", "-static", "-i", "100", "-nso", "-exportdir", "out"])
+    st = cli.settings(f)
+    assert (st["W"], st["H"], st["fx"], st["fy"], st["cx"], st["cy"]) == (640, 480, 535.4, 539.2, 320.1, 247.6)
+    assert st["icpWeight"] == 100.0 and not st["so3"] and not st["multi"] and st["depthCutoff"] == 4.0
+    d = cli.settings(cli.parse(["-l", "x.klg"]))
+    # the values the GUI pushes into the core every frame (GUI.h:188-196,347; MainController.cpp:215-228)
+    assert (d["depthCutoff"], d["icpWeight"], d["outlierCoefficient"], d["confGlobal"], d["confObject"], d["modelSpawnOffset"]) == \
+        (4.0, 20.0, 0.1, 10.0, 0.01, 22)
+    assert d["so3"] and d["multi"] and d["timeDelta"] == (2 ** 31 - 1) // 2 and (d["fx"], d["cx"]) == (528.0, 320.0)
+    with pytest.raises(SystemExit):
+        cli.parse(["-bogus"])
+    with pytest.raises(SystemExit):
+        cli.parse(["-l"])
