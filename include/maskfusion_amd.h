@@ -196,6 +196,13 @@ int mf_segmentation_labels(int32_t W, int32_t H, const uint8_t* binary, const fl
                            const int32_t* model_class_ids, int32_t n_models, int32_t next_model_id, int32_t allow_new,
                            const float* params11, uint8_t* ignore_map, uint8_t* full_segmentation, int32_t* has_new_label,
                            int32_t* new_class_id);
+/* The same stage on the device (what mf_process_frame uses unless mf_set_param("gpuLabels", 0)): identical
+ * arguments and results, HOST pointers (staged internally). */
+int mf_k_segmentation_labels(int32_t W, int32_t H, const uint8_t* binary, const float* depth, const uint8_t* mask,
+                           const int32_t* class_ids, int32_t n_masks, const uint8_t* projected_ids, const int32_t* model_ids,
+                           const int32_t* model_class_ids, int32_t n_models, int32_t next_model_id, int32_t allow_new,
+                           const float* params11, uint8_t* ignore_map, uint8_t* full_segmentation, int32_t* has_new_label,
+                           int32_t* new_class_id);
 /* imageBGRToIntensity (Core/Cuda/cudafuncs.cu:626-654); channels = 3 or 4, the first three are used as stored */
 int mf_k_intensity(const uint8_t* d_img, int32_t channels, uint8_t* d_out, int32_t n, void* stream);
 /* pyrDownUcharGauss (Core/Cuda/cudafuncs.cu:534-588) */

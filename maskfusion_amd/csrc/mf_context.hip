@@ -44,6 +44,69 @@ struct ModelState {
     }
 };
 
+// Device scratch of the GPU label stage (mf_labels_gpu.hip)
+struct LabelsScratch {
+    int P = 0, table_cap = 0;
+    uint8_t* ignoreMap = nullptr; uint8_t* tmp_u8 = nullptr;
+    int* L = nullptr; int* compId = nullptr; int* area = nullptr; int* lab[2] = {nullptr, nullptr}; int* blockCounts = nullptr;
+    int4* bbox = nullptr;
+    int* compMask = nullptr; int* compModel = nullptr; int* compToMask = nullptr; int* compFollow = nullptr;
+    unsigned* overlap = nullptr; void* tables = nullptr;
+    int* d_small = nullptr;      // class ids [256] | model ids [64] | model classes [64]
+    const PoseDev** d_poses = nullptr;   // [64]
+    int* h_small = nullptr; const PoseDev** h_poses = nullptr; int* h_result = nullptr;   // pinned
+    std::vector<void*> dev, host;
+    ~LabelsScratch() {
+        for (void* p : dev) (void)hipFree(p);
+        for (void* p : host) (void)hipHostFree(p);
+    }
+    template <typename T> bool dalloc(T** p, size_t n) {
+        void* q = nullptr;
+        if (hipMalloc(&q, n * sizeof(T)) != hipSuccess) return false;
+        if (hipMemset(q, 0, n * sizeof(T)) != hipSuccess) return false;
+        dev.push_back(q); *p = reinterpret_cast<T*>(q);
+        return true;
+    }
+    template <typename T> bool halloc(T** p, size_t n) {
+        void* q = nullptr;
+        if (hipHostMalloc(&q, n * sizeof(T)) != hipSuccess) return false;
+        memset(q, 0, n * sizeof(T));
+        host.push_back(q); *p = reinterpret_cast<T*>(q);
+        return true;
+    }
+    bool init(int P_) {
+        P = P_;
+        table_cap = 8 << 20;   // components x (masks | models) entries per vote table; exceeding it is reported, never truncated
+        return dalloc(&ignoreMap, (size_t)P) && dalloc(&tmp_u8, (size_t)P) && dalloc(&L, (size_t)P) && dalloc(&compId, (size_t)P) &&
+               dalloc(&area, (size_t)P + 1) && dalloc(&bbox, (size_t)P + 1) && dalloc(&lab[0], (size_t)P) && dalloc(&lab[1], (size_t)P) &&
+               dalloc(&blockCounts, (size_t)(P + 255) / 256) && dalloc(&compMask, (size_t)table_cap) &&
+               dalloc(&compModel, (size_t)table_cap) && dalloc(&compToMask, (size_t)P + 1) && dalloc(&compFollow, (size_t)P + 1) &&
+               dalloc(&overlap, (size_t)64 * 256) && dalloc((char**)&tables, labels_gpu_table_bytes()) && dalloc(&d_small, 384) &&
+               dalloc(&d_poses, 64) && halloc(&h_small, 384) && halloc(&h_poses, 64) && halloc(&h_result, 4);
+    }
+    // uploads the small per-frame tables and enqueues the stage; models: {id, classID, device pose}
+    int enqueue(const SegParams& prm, int W, int H, const uint8_t* d_binary, const float* d_depth, const uint8_t* d_mask,
+                const int32_t* class_ids, int n_masks, const uint8_t* d_proj, const std::vector<SegModelInfo>& models,
+                const std::vector<const PoseDev*>& poses, int nextModelID, bool allowNew, uint8_t* d_full, hipStream_t s) {
+        if (models.size() > 64 || n_masks > 256) return MF_EINVAL;
+        memset(h_small, 0, 384 * sizeof(int));
+        for (int k = 0; k < n_masks; ++k) h_small[k] = class_ids[k];
+        for (size_t m = 0; m < models.size(); ++m) { h_small[256 + m] = models[m].id; h_small[320 + m] = models[m].classID; h_poses[m] = poses[m]; }
+        if (hipMemcpyAsync(d_small, h_small, 384 * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(d_poses, h_poses, 64 * sizeof(PoseDev*), hipMemcpyHostToDevice, s) != hipSuccess)
+            return MF_EHIP;
+        LabelsGpuArgs a;
+        a.prm = prm; a.W = W; a.H = H; a.binary = d_binary; a.depth = d_depth; a.mask = d_mask; a.proj = d_proj;
+        a.class_ids = d_small; a.nMasks = n_masks; a.model_ids = d_small + 256; a.model_cls = d_small + 320; a.model_poses = d_poses;
+        a.nModels = (int)models.size(); a.nextModelID = nextModelID; a.allowNew = allowNew; a.ignoreMap = ignoreMap; a.full = d_full;
+        a.tmp_u8 = tmp_u8; a.L = L; a.compId = compId; a.area = area; a.bbox = bbox; a.lab[0] = lab[0]; a.lab[1] = lab[1]; a.blockCounts = blockCounts;
+        a.compMask = compMask; a.compModel = compModel; a.table_cap = table_cap; a.compToMask = compToMask; a.compFollow = compFollow;
+        a.overlap = overlap; a.tables = tables; a.result_host = h_result;
+        launch_labels_gpu(a, s);
+        return MF_OK;
+    }
+};
+
 }  // namespace
 
 struct mf_ctx {
@@ -95,6 +158,8 @@ struct mf_ctx {
     float* d_edge = nullptr; uint8_t* d_bin = nullptr; uint8_t* d_tmp_u8 = nullptr; uint8_t* d_proj_ids = nullptr;
     uint8_t* h_bin = nullptr; uint8_t* h_ids = nullptr; float* h_depth = nullptr; uint8_t* h_mask = nullptr; uint8_t* h_full = nullptr;
     std::vector<uint8_t> ignoreMap;
+    std::unique_ptr<LabelsScratch> labels;   // device label stage ("gpuLabels", default on)
+    int gpu_labels = 1;
     SegParams seg;
     int nextID = 0, spawnOffset = 0;
     int cap_max = 0;
@@ -306,6 +371,8 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     c->models.push_back(std::move(bg));
 #undef A
     c->ignoreMap.assign(P, 0);
+    c->labels.reset(new LabelsScratch());
+    if (!c->labels->init(P)) return fail(MF_ENOMEM);
     for (int i = 0; i <= MF_N_TIMINGS; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) return fail(MF_EHIP);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(MF_EHIP);
@@ -574,12 +641,32 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
             launch_edge_map(c->d_vmap[set][0], c->d_nmap[set][0], c->d_edge, W, H, c->seg.weightDistance, c->seg.weightConvexity, s);
             launch_edge_binary(c->d_edge, c->d_bin, c->d_tmp_u8, W, H, c->seg.threshold, c->seg.morphEdgeRadius,
                                c->seg.morphEdgeIterations, s);
-            MF_HIP(c, hipMemcpyAsync(c->h_bin, c->d_bin, (size_t)P, hipMemcpyDeviceToHost, s));
-            MF_HIP(c, hipMemcpyAsync(c->h_ids, c->d_proj_ids, (size_t)P, hipMemcpyDeviceToHost, s));
-            MF_HIP(c, hipMemcpyAsync(c->h_depth, d_depth, (size_t)P * sizeof(float), hipMemcpyDeviceToHost, s));
             const bool haveMasks = d_mask_in && class_ids && n_masks > 0;
-            if (haveMasks) MF_HIP(c, hipMemcpyAsync(c->h_mask, d_mask_in, (size_t)P, hipMemcpyDeviceToHost, s));
-            MF_HIP(c, hipStreamSynchronize(s));  // the one host visit of a multi-model frame (the reference leaves the GPU here too)
+            static const int32_t kNoClass[1] = {0};
+            SegResult res;
+            if (c->gpu_labels) {
+                // label stage on the device (mf_labels_gpu.hip): the model table still holds the objects the jump rule may
+                // have dropped in this frame -- the kernels read their `alive` flags -- and the only host visit of the frame
+                // reads back the new-model decision and those flags
+                if (c->spawnOffset < g.model_spawn_offset) c->spawnOffset++;  // :294
+                std::vector<SegModelInfo> infos;
+                std::vector<const PoseDev*> poses;
+                for (auto& m : c->models) { infos.push_back(SegModelInfo{m->id, m->classID}); poses.push_back(m->d_pose); }
+                int rc = c->labels->enqueue(c->seg, W, H, c->d_bin, d_depth, haveMasks ? d_mask_in : nullptr, haveMasks ? class_ids : kNoClass,
+                                            haveMasks ? n_masks : 0, c->d_proj_ids, infos, poses, c->nextID,
+                                            c->spawnOffset >= g.model_spawn_offset, c->d_mask_tex, s);   // writes textureMask (:297)
+                if (rc != MF_OK) return rc;
+                MF_HIP(c, hipStreamSynchronize(s));
+                if (c->labels->h_result[2]) { c->err = "label stage: vote tables overflowed (too many components x masks)"; return MF_ESTATE; }
+                res.hasNewLabel = c->labels->h_result[0] != 0;
+                res.newClassID = c->labels->h_result[1];
+            } else {
+                MF_HIP(c, hipMemcpyAsync(c->h_bin, c->d_bin, (size_t)P, hipMemcpyDeviceToHost, s));
+                MF_HIP(c, hipMemcpyAsync(c->h_ids, c->d_proj_ids, (size_t)P, hipMemcpyDeviceToHost, s));
+                MF_HIP(c, hipMemcpyAsync(c->h_depth, d_depth, (size_t)P * sizeof(float), hipMemcpyDeviceToHost, s));
+                if (haveMasks) MF_HIP(c, hipMemcpyAsync(c->h_mask, d_mask_in, (size_t)P, hipMemcpyDeviceToHost, s));
+                MF_HIP(c, hipStreamSynchronize(s));  // the one host visit of a multi-model frame (the reference leaves the GPU here too)
+            }
 
             // inactivateModel for objects the jump rule dropped (:268-272); data is deleted (no re-detection upstream)
             for (size_t i = 1; i < c->models.size();) {
@@ -590,14 +677,14 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
                     c->models.erase(c->models.begin() + i);
                 } else ++i;
             }
-            if (c->spawnOffset < g.model_spawn_offset) c->spawnOffset++;  // :294
-            std::vector<SegModelInfo> infos;
-            for (auto& m : c->models) infos.push_back(SegModelInfo{m->id, m->classID});
-            SegResult res;
-            static const int32_t kNoClass[1] = {0};
-            segmentation_host(c->seg, W, H, c->h_bin, c->h_depth, c->h_mask, haveMasks ? class_ids : kNoClass, haveMasks ? n_masks : 0,
-                              c->h_ids, infos, c->nextID, c->spawnOffset >= g.model_spawn_offset, c->ignoreMap, c->h_full, res);
-            MF_HIP(c, hipMemcpyAsync(c->d_mask_tex, c->h_full, (size_t)P, hipMemcpyHostToDevice, s));  // :297
+            if (!c->gpu_labels) {
+                if (c->spawnOffset < g.model_spawn_offset) c->spawnOffset++;  // :294
+                std::vector<SegModelInfo> infos;
+                for (auto& m : c->models) infos.push_back(SegModelInfo{m->id, m->classID});
+                segmentation_host(c->seg, W, H, c->h_bin, c->h_depth, c->h_mask, haveMasks ? class_ids : kNoClass, haveMasks ? n_masks : 0,
+                                  c->h_ids, infos, c->nextID, c->spawnOffset >= g.model_spawn_offset, c->ignoreMap, c->h_full, res);
+                MF_HIP(c, hipMemcpyAsync(c->d_mask_tex, c->h_full, (size_t)P, hipMemcpyHostToDevice, s));  // :297
+            }
             bool spawned = false;
             if (res.hasNewLabel && (int)c->models.size() < g.max_models) {
                 // spawnObjectModel (:671-684): pose = I, makeStatic(globalPose); moveNewModelToList
@@ -932,6 +1019,7 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!c || !key) return MF_EINVAL;
     if (!strcmp(key, "timings")) { c->timings_on = value != 0; return MF_OK; }
     if (!strcmp(key, "icpProfile")) { c->icp_prof_on = value != 0; return MF_OK; }
+    if (!strcmp(key, "gpuLabels")) { c->gpu_labels = value != 0; return MF_OK; }   // 0: host label stage (specification)
     if (!strcmp(key, "splatTiles")) { c->splat_tiles = value != 0; return MF_OK; }   // 0: scatter + resolve form (specification)
     if (!strcmp(key, "overlapPreprocessing")) {
         (void)hipStreamSynchronize(c->stream_pre);
@@ -1171,6 +1259,51 @@ extern "C" int mf_segmentation_labels(int32_t W, int32_t H, const uint8_t* binar
     memcpy(ignore_map, ign.data(), ign.size());
     *has_new = res.hasNewLabel ? 1 : 0;
     *new_class = res.newClassID;
+    return MF_OK;
+}
+
+// Device twin of mf_segmentation_labels (same arguments, HOST pointers; the images are staged to the device, the stage runs
+// in mf_labels_gpu.hip, the outputs come back) -- the parity tests run both against the oracle.
+static __global__ void k_alive_pose(PoseDev* p) { if (threadIdx.x == 0 && blockIdx.x == 0) p->alive = 1; }
+extern "C" int mf_k_segmentation_labels(int32_t W, int32_t H, const uint8_t* binary, const float* depth, const uint8_t* mask,
+                                        const int32_t* class_ids, int32_t n_masks, const uint8_t* projected_ids, const int32_t* model_ids,
+                                        const int32_t* model_class_ids, int32_t n_models, int32_t next_model_id, int32_t allow_new,
+                                        const float* p, uint8_t* ignore_map, uint8_t* full, int32_t* has_new, int32_t* new_class) {
+    if (!binary || !depth || !projected_ids || !model_ids || !model_class_ids || n_models < 1 || n_models > 64 || !p || !ignore_map ||
+        !full || !has_new || !new_class || W <= 2 || H <= 2 || (n_masks > 0 && (!mask || !class_ids)) || n_masks > 256)
+        return MF_EINVAL;
+    SegParams prm;
+    prm.threshold = p[0]; prm.weightDistance = p[1]; prm.weightConvexity = p[2];
+    prm.morphEdgeIterations = (int)p[3]; prm.morphEdgeRadius = (int)p[4]; prm.morphMaskIterations = (int)p[5]; prm.morphMaskRadius = (int)p[6];
+    prm.removeEdges = p[7] != 0.f; prm.minRelSizeNew = p[8]; prm.maxRelSizeNew = p[9]; prm.personClassID = (int)p[10];
+    const size_t P = (size_t)W * H;
+    LabelsScratch sc;
+    if (!sc.init((int)P)) return MF_ENOMEM;
+    uint8_t *d_bin = nullptr, *d_mask = nullptr, *d_proj = nullptr, *d_full = nullptr; float* d_depth = nullptr; PoseDev* d_pose = nullptr;
+    if (!sc.dalloc(&d_bin, P) || !sc.dalloc(&d_mask, P) || !sc.dalloc(&d_proj, P) || !sc.dalloc(&d_full, P) || !sc.dalloc(&d_depth, P) ||
+        !sc.dalloc(&d_pose, 1))
+        return MF_ENOMEM;
+    hipStream_t s = nullptr;
+    hipError_t e = hipMemcpy(d_bin, binary, P, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_proj, projected_ids, P, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_depth, depth, P * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_masks > 0) e = hipMemcpy(d_mask, mask, P, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(sc.ignoreMap, ignore_map, P, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return MF_EHIP;
+    hipLaunchKernelGGL(k_alive_pose, dim3(1), dim3(64), 0, s, d_pose);
+    std::vector<SegModelInfo> infos;
+    std::vector<const PoseDev*> poses;
+    for (int i = 0; i < n_models; ++i) { infos.push_back(SegModelInfo{model_ids[i], model_class_ids[i]}); poses.push_back(d_pose); }
+    static const int32_t kNoClass[1] = {0};
+    int rc = sc.enqueue(prm, W, H, d_bin, d_depth, n_masks > 0 ? d_mask : nullptr, n_masks > 0 ? class_ids : kNoClass, n_masks, d_proj, infos,
+                        poses, next_model_id, allow_new != 0, d_full, s);
+    if (rc != MF_OK) return rc;
+    if (hipDeviceSynchronize() != hipSuccess) return MF_EHIP;
+    if (sc.h_result[2]) return MF_ESTATE;
+    if (hipMemcpy(full, d_full, P, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(ignore_map, sc.ignoreMap, P, hipMemcpyDeviceToHost) != hipSuccess)
+        return MF_EHIP;
+    *has_new = sc.h_result[0];
+    *new_class = sc.h_result[1];
     return MF_OK;
 }
 

@@ -1,5 +1,6 @@
 // mf_labels.h -- host half of MfSegmentation (see mf_labels.hip)
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <vector>
 
@@ -27,5 +28,27 @@ struct SegResult { bool hasNewLabel = false; int newClassID = -1; };
 void segmentation_host(const SegParams& prm, int W, int H, const uint8_t* binary, const float* depth, const uint8_t* mask,
                        const int32_t* classIDs, int nMasks, const uint8_t* projectedIDs, const std::vector<SegModelInfo>& models,
                        int nextModelID, bool allowNew, std::vector<uint8_t>& ignoreMap, uint8_t* full, SegResult& result);
+
+// Device form of the same stage (mf_labels_gpu.hip).  All pointers are device memory unless noted.
+struct PoseDev;
+struct LabelsGpuArgs {
+    SegParams prm; int W, H;
+    const uint8_t* binary; const float* depth; const uint8_t* mask; const uint8_t* proj;   // mask may be null when nMasks == 0
+    const int* class_ids; int nMasks;                       // device copy of the frame's class ids
+    const int* model_ids; const int* model_cls; const PoseDev* const* model_poses; int nModels;   // models before the jump-rule drop
+    int nextModelID; bool allowNew;
+    uint8_t* ignoreMap;                                     // persistent semanticIgnoreMap
+    uint8_t* full;                                          // out: model id per pixel (255 = ignore) == textureMask
+    uint8_t* tmp_u8;
+    int* L; int* compId; int* area; int* lab[2]; int* blockCounts;      // [P], [P], [P + 1], 2 x [P], [(P + 255) / 256]
+    int4* bbox;                                             // [P + 1] left, top, right, bottom of each component
+    int* compMask; int* compModel; int table_cap;           // [table_cap] each
+    int* compToMask; int* compFollow;                       // [P + 1]
+    unsigned* overlap;                                      // [64 * 256]
+    void* tables;                                           // labels_gpu_table_bytes()
+    int* result_host;                                       // pinned host: {hasNewLabel, newClassID, overflow, nComponents}
+};
+size_t labels_gpu_table_bytes();
+void launch_labels_gpu(const LabelsGpuArgs& a, hipStream_t s);
 
 }  // namespace mf
