@@ -28,7 +28,19 @@ sys.path.insert(0, ROOT)
 W, H = 640, 480
 FX = FY = 528.0
 CX, CY = 320.0, 240.0
+SURFELS = 9437184      # MASKFUSION_NUM_GSURFELS default
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+WORKLOAD = ("configs[1]: synthetic 640x480 RGB-D stream (S1, Kinect-like noise), 1 background model per GPU, icpWeight=100 "
+            "(geometric ICP 4/5/10 iterations) + surfel fusion, empty masks")
+
+
+def select_config(n):
+    """--config 4: the per-GPU share of BASELINE.json configs[4] (1280x960 stream, NUM_GSURFELS = 32M); default configs[1]."""
+    global W, H, FX, FY, CX, CY, SURFELS, WORKLOAD
+    if n == 4:
+        W, H, FX, FY, CX, CY, SURFELS = 1280, 960, 1056.0, 1056.0, 640.0, 480.0, 32 * 1024 * 1024
+        WORKLOAD = ("configs[4] (per GPU): synthetic 1280x960 RGB-D stream (S3 scaling of S1), 1 model per GPU, NUM_GSURFELS=32M, "
+                    "icpWeight=100 + surfel fusion, empty masks")
 
 
 def gen_frames(n, seed=1234):
@@ -52,7 +64,7 @@ def cpu_baseline(frames, max_seconds=20.0):
     """Oracle (port) frames/s on the host cores, bounded sample."""
     from oracle import mfo
     threads = os.cpu_count() or 1
-    o = mfo.Oracle(W, H, FX, FY, CX, CY, icpWeight=100.0, capacity=1 << 20, so3=0)
+    o = mfo.Oracle(W, H, FX, FY, CX, CY, icpWeight=100.0, capacity=(1 << 20) * (W * H // 307200), so3=0)
     o.process_frame(frames[0][0], frames[0][1])  # init frame, untimed
     t0 = time.time()
     n = 0
@@ -73,9 +85,11 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--frames", type=int, default=24, help="distinct synthetic frames kept in HBM (ping-ponged)")
+    ap.add_argument("--config", type=int, default=1, choices=(1, 4), help="BASELINE.json config (1 = the metric's; 4 = 1280x960 stress)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    select_config(args.config)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -97,7 +111,7 @@ def main():
     d_rgb = [torch.from_numpy(f[0]).to(dev) for f in frames]
     d_depth = [torch.from_numpy(f[1]).to(dev) for f in frames]
     mf = MaskFusion(W, H, FX, FY, CX, CY, icpThresh=100.0, so3=False, device=local_rank, enableMultipleModels=False,
-                    numGSurfels=9437184)
+                    numGSurfels=SURFELS)
     # Every rank owns one model.  Rank 0 owns the input stream and publishes frame k to all ranks (RCCL broadcast over xGMI
     # when N > 1) on the library's INPUT stream into a ring of 3 buffers; each rank then enqueues processFrame, whose main
     # stream is torch's current stream for the gather of the per-model state record.  Collectives and kernels are ordered
@@ -173,13 +187,11 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "frames/sec (640x480 RGB-D, single background model, ICP + surfel fusion)",
+            "metric": f"frames/sec ({W}x{H} RGB-D, single background model, ICP + surfel fusion)",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: synthetic 640x480 RGB-D stream (S1, Kinect-like noise), 1 background "
-                                   "model per GPU, icpWeight=100 (geometric ICP 4/5/10 iterations) + surfel fusion, "
-                                   "empty masks", "frames_in_hbm": args.frames, "surfels": count,
+            "config": {"workload": WORKLOAD, "frames_in_hbm": args.frames, "surfels": count,
                        "pose_drift_vs_gt_m": drift, "parallelism": f"model-per-gpu x{world}"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -144,13 +144,13 @@ struct mf_ctx {
     So3Result* d_so3 = nullptr;
     // tiled splat prediction (mf_splat.hip)
     int* d_tile_count = nullptr; int* d_tile_entries = nullptr; int tile_entries_cap = 0; int splat_tiles = 1;
-    bool index_transposed = false;         // layout of d_index / d_ivc / d_ict / d_inr left by the last index pass
     const uint8_t* cur_rgb = nullptr;      // device rgb of the frame being processed (fill-in intensity at predict time)
     struct RetiredLog { int id; std::vector<int64_t> ts; std::vector<float> p; };
     std::vector<RetiredLog> retired;       // pose logs of dropped models (MaskFusion::inactiveModels, exportPoses)
     float* d_vmap_g[3]; float* d_nmap_g[3];
     unsigned long long* d_keys = nullptr;
     int* d_index = nullptr; float4* d_ivc = nullptr; float4* d_ict = nullptr; float4* d_inr = nullptr;
+    float4* d_iclean = nullptr;            // packed column-major index map of the clean pass: 2 x float4 per texel
     uint8_t* d_cand_op = nullptr; float4* d_cand_rec = nullptr; int* d_upd_first = nullptr;
     uint8_t* d_flags = nullptr; float* d_newconf = nullptr; int* d_block_counts = nullptr;
     float* d_icp_log = nullptr; unsigned long long* d_icp_prof = nullptr;
@@ -346,6 +346,7 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     A(dev_alloc(c, c->allocs, &c->d_index, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_ivc, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_ict, (size_t)P));
+    A(dev_alloc(c, c->allocs, &c->d_iclean, (size_t)P * 2));
     A(dev_alloc(c, c->allocs, &c->d_inr, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_cand_op, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_cand_rec, (size_t)P * 3));
@@ -502,7 +503,8 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
     hipStream_t s = c->stream;
     const int src = m.cur, dst = 1 - m.cur;
     launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, false, s);
-    launch_index_resolve(m.surf[src], m.d_pose, c->d_keys, W, H, c->d_index, c->d_ivc, c->d_ict, c->d_inr, s);
+    launch_index_resolve(m.surf[src], m.d_pose, c->d_keys, W, H, c->d_index, c->d_ivc, c->d_inr, secondIndexPass ? nullptr : c->d_ict,
+                         nullptr, s);
     if (marks) mark(c, 4);
     // Model::fuse maxDepth uniform: min(depthCutoff, model.maxDepth, bb_max_z = FLT_MAX without the GUI) (Model.cpp:527)
     launch_fuse_data(d_rgb, d_depth, depthF, mask, m.id, m.d_frame, m.d_pose, weightMultiplier, fminf(fuseDepthCutoff, m.maxDepth), W, H,
@@ -512,12 +514,11 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
     if (marks) mark(c, 6);
     if (secondIndexPass) {
         launch_index_scatter(m.surf[dst], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, true, s);
-        launch_index_resolve(m.surf[dst], m.d_pose, c->d_keys, W, H, c->d_index, c->d_ivc, c->d_ict, c->d_inr, s);
+        launch_index_resolve(m.surf[dst], m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, s);
     }
     launch_clean(m.surf[dst], m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.time_delta, m.confThr, g.outlier_coefficient, m.id,
-                 c->d_index, c->d_ivc, c->d_ict, depthF, mask, c->d_cand_op, c->d_cand_rec, c->d_flags, c->d_newconf,
+                 c->d_index, c->d_ivc, c->d_ict, secondIndexPass ? c->d_iclean : nullptr, depthF, mask, c->d_cand_op, c->d_cand_rec, c->d_flags, c->d_newconf,
                  c->d_block_counts, m.h_count, secondIndexPass, s);
-    c->index_transposed = secondIndexPass;
     // two swaps (fuse, clean) leave the live buffer where it started
 }
 
@@ -1106,13 +1107,8 @@ extern "C" int mf_debug_read(mf_ctx* c, const char* what, void* out, uint64_t ou
     else { c->err = "unknown debug tap: " + w; return MF_EINVAL; }
     if (out_bytes < bytes) { c->err = "debug_read: buffer too small"; return MF_EINVAL; }
     MF_HIP(c, hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
-    if ((w == "index" || w == "index_vc") && c->index_transposed) {  // hand the map out row-major
-        const size_t es = (w == "index") ? 4 : 16;
-        std::vector<char> tmp((const char*)out, (const char*)out + bytes);
-        for (int x = 0; x < c->W; ++x)
-            for (int y = 0; y < c->H; ++y)
-                memcpy((char*)out + ((size_t)y * c->W + x) * es, tmp.data() + ((size_t)x * c->H + y) * es, es);
-    }
+    // "index" / "index_vc" are the row-major images of the pre-fusion index pass; the post-fusion pass that feeds clean()
+    // lives in the packed column-major d_iclean
     return MF_OK;
 }
 

@@ -152,8 +152,9 @@ void launch_init_surfels(const uint8_t* rgb, const float* depthRaw, const float*
                          float maxDepth, const FrameDev* frame, float4* rec /*[P][3]*/, uint8_t* flags, hipStream_t s);
 void launch_index_scatter(Surfels src, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k,
                           float maxDepth, int timeDelta, unsigned long long* keys, bool transposed, hipStream_t s);
+// packed == nullptr: index / vertConf / normRad (+ colorTime if ct != nullptr) images; else one 32 B record per texel
 void launch_index_resolve(Surfels src, const PoseDev* pose, unsigned long long* keys, int W, int H, int* index,
-                          float4* vc, float4* ct, float4* nr, hipStream_t s);
+                          float4* vc, float4* nr, float4* ct /*or null*/, float4* packed /*or null*/, hipStream_t s);
 void launch_fuse_data(const uint8_t* rgb, const float* depthRaw, const float* depthF, const uint8_t* mask,
                       int maskID, const FrameDev* frame, const PoseDev* pose, float weightMultiplier, float maxDepth,
                       int W, int H, Intr k, const int* index, const float4* vc, const float4* nr, uint8_t* cand_op,
@@ -162,7 +163,7 @@ void launch_fuse_update(Surfels src, Surfels dst, const FrameDev* frame, int* up
                         hipStream_t s);
 void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k,
                   int timeDelta, float confThreshold, float outlierCoeff, int maskID, const int* index,
-                  const float4* vc, const float4* ct, const float* depthF, const uint8_t* mask,
+                  const float4* vc, const float4* ct, const float4* packed /*or null*/, const float* depthF, const uint8_t* mask,
                   const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags, float* newconf, int* block_counts,
                   int* host_count_mirror, bool transposed /*layout of index/vc/ct*/, hipStream_t s);
 // generic ordered compaction of [n_dev] records (3 x float4 each, record-major) -> surfels, sets frame->count

@@ -188,32 +188,47 @@ void launch_index_scatter(Surfels src, const FrameDev* frame, const PoseDev* pos
                        transposed ? 1 : 0);
 }
 
+// Two consumers, two output shapes (the index_map.frag attachments that each of them samples):
+//   packed == nullptr (the pass that feeds fuse): index + vertConf + normRad as separate images;
+//   packed != nullptr (the pass that feeds clean): ONE 32 B record per texel {vertConf.xyzw | colorTime.z, colorTime.w,
+//     index bits, 0} -- clean gathers 9 texels per surfel, and three separate images cost it three cache lines per tap.
 __global__ __launch_bounds__(256) void k_index_resolve(Surfels src, const PoseDev* __restrict__ pose,
                                                        unsigned long long* __restrict__ keys, int P, int* __restrict__ index,
-                                                       float4* __restrict__ vc, float4* __restrict__ ct, float4* __restrict__ nr) {
+                                                       float4* __restrict__ vc, float4* __restrict__ nr, float4* __restrict__ ct,
+                                                       float4* __restrict__ packed) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= P) return;
     const unsigned long long key = keys[p];
     keys[p] = kEmptyKey;  // ready for the next scatter: saves a separate clear pass
     if (key == kEmptyKey) {
-        index[p] = 0;
-        vc[p] = ct[p] = nr[p] = make_float4(0, 0, 0, 0);
+        if (packed) { packed[2 * p] = packed[2 * p + 1] = make_float4(0, 0, 0, 0); }
+        else {
+            index[p] = 0; vc[p] = nr[p] = make_float4(0, 0, 0, 0);
+            if (ct) ct[p] = make_float4(0, 0, 0, 0);
+        }
         return;
     }
     const int i = (int)(unsigned)(key & 0xFFFFFFFFull);
-    const float4 pc = src.pc[i], c4 = src.ct[i], n4 = src.nr[i];
+    const float4 pc = src.pc[i];
     const float3 h = mul33(pose->Ri, f3(pc.x, pc.y, pc.z)) + f3(pose->ti[0], pose->ti[1], pose->ti[2]);
-    const float3 n = normalize_gl(mul33(pose->Ri, f3(n4.x, n4.y, n4.z)));
-    index[p] = i;
-    vc[p] = make_float4(h.x, h.y, h.z, pc.w);
-    ct[p] = c4;
-    nr[p] = make_float4(n.x, n.y, n.z, n4.w);
+    if (packed) {
+        const float4 c4 = src.ct[i];
+        packed[2 * p] = make_float4(h.x, h.y, h.z, pc.w);
+        packed[2 * p + 1] = make_float4(c4.z, c4.w, __int_as_float(i), 0.f);
+    } else {
+        const float4 n4 = src.nr[i];
+        const float3 n = normalize_gl(mul33(pose->Ri, f3(n4.x, n4.y, n4.z)));
+        index[p] = i;
+        vc[p] = make_float4(h.x, h.y, h.z, pc.w);
+        nr[p] = make_float4(n.x, n.y, n.z, n4.w);
+        if (ct) ct[p] = src.ct[i];   // colorTime image: only the clean pass of a freshly spawned model reads it from here
+    }
 }
 
 void launch_index_resolve(Surfels src, const PoseDev* pose, unsigned long long* keys, int W, int H, int* index, float4* vc,
-                          float4* ct, float4* nr, hipStream_t s) {
+                          float4* nr, float4* ct, float4* packed, hipStream_t s) {
     const int P = W * H;
-    hipLaunchKernelGGL(k_index_resolve, dim3((P + 255) / 256), dim3(256), 0, s, src, pose, keys, P, index, vc, ct, nr);
+    hipLaunchKernelGGL(k_index_resolve, dim3((P + 255) / 256), dim3(256), 0, s, src, pose, keys, P, index, vc, nr, ct, packed);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -351,7 +366,9 @@ void launch_fuse_update(Surfels src, Surfels dst, const FrameDev* frame, int* up
 struct CleanArgs {
     Surfels src, dst; FrameDev* frame; const PoseDev* pose; int W, H; Intr k;
     int timeDelta; float confThreshold; float outlierCoeff; int maskID; int transposed;
-    const int* index; const float4* vc; const float4* ct; const float* depthF; const uint8_t* mask;
+    const int* index; const float4* vc; const float4* ct;   // separate images (only when the packed map is absent)
+    const float4* packed;                                    // {vertConf | initTime, lastTime, index, 0} per texel
+    const float* depthF; const uint8_t* mask;
     const uint8_t* cand_op; const float4* cand_rec;
     uint8_t* flags; float* newconf; int* block_counts; int* host_count;
 };
@@ -385,9 +402,20 @@ __device__ __forceinline__ bool clean_test(const CleanArgs& a, float4 pc, float4
             for (int ib = 0; ib < 3; ++ib) {
                 const int tp = a.transposed ? ux[ia] * H + uy[ib] : uy[ib] * W + ux[ia];
                 const int mult = mx[ia] * my[ib];
-                if (mult > 0 && a.index[tp] > 0) {
-                    const float4 v = a.vc[tp];
-                    const float4 c = a.ct[tp];
+                if (mult <= 0) continue;
+                float4 v, c;
+                int idx;
+                if (a.packed) {
+                    v = a.packed[2 * tp];
+                    const float4 r1 = a.packed[2 * tp + 1];
+                    c = make_float4(0.f, 0.f, r1.x, r1.y);
+                    idx = __float_as_int(r1.z);
+                } else {
+                    idx = a.index[tp];
+                    v = a.vc[tp];
+                    c = a.ct[tp];
+                }
+                if (idx > 0) {
                     const float dx = v.x - lp.x, dy = v.y - lp.y;
                     if (c.z < ct.z && v.w > a.confThreshold && v.z > lp.z && v.z - lp.z < 0.01f &&
                         sqrtf(dx * dx + dy * dy) < nr.w * 1.4f)
@@ -627,12 +655,13 @@ void launch_frame_advance(FrameDev* frame, int W, int H, FrameDev* host_mirror, 
 
 void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, int timeDelta,
                   float confThreshold, float outlierCoeff, int maskID, const int* index, const float4* vc, const float4* ct,
-                  const float* depthF, const uint8_t* mask, const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags,
+                  const float4* packed, const float* depthF, const uint8_t* mask, const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags,
                   float* newconf, int* block_counts, int* host_count_mirror, bool transposed, hipStream_t s) {
     CleanArgs a;
     a.transposed = transposed ? 1 : 0;
     a.src = src; a.dst = dst; a.frame = frame; a.pose = pose; a.W = W; a.H = H; a.k = k; a.timeDelta = timeDelta;
     a.confThreshold = confThreshold; a.outlierCoeff = outlierCoeff; a.maskID = maskID; a.index = index; a.vc = vc; a.ct = ct;
+    a.packed = packed;
     a.depthF = depthF; a.mask = mask; a.cand_op = cand_op; a.cand_rec = cand_rec;
     a.flags = flags; a.newconf = newconf; a.block_counts = block_counts; a.host_count = host_count_mirror;
     hipLaunchKernelGGL(k_clean_flags, dim3(kCompactBlocks), dim3(256), 0, s, a);

@@ -132,3 +132,20 @@ def test_tiled_splat_equals_scatter_form(hip):
     assert (a["v"][..., 2] > 0).mean() > 0.3          # the prediction is populated (confidence threshold 2)
     assert np.array_equal(a["v"], b["v"]) and np.array_equal(a["n"], b["n"]) and np.array_equal(a["img"], b["img"])
     assert np.array_equal(a["pose"], b["pose"]) and a["count"] == b["count"] and a["stats"] == b["stats"]
+
+
+def test_pipeline_1280x960(hip, oracle):
+    """BASELINE.json configs[4] resolution: tiles, grids and list capacities scale (4 800 splat tiles, multi-round ICP grid)."""
+    from maskfusion_amd import MaskFusion, synth
+    W, H = 1280, 960
+    st = synth.Stream(W=W, H=H, fx=1056.0, fy=1056.0, cx=640.0, cy=480.0, noise=True)
+    fr = [st.frame(k) for k in range(4)]
+    o = oracle.Oracle(W, H, st.fx, st.fy, st.cx, st.cy, icpWeight=100.0, capacity=1 << 21, so3=0)
+    mf = MaskFusion(W, H, st.fx, st.fy, st.cx, st.cy, icpThresh=100.0, so3=False, enableMultipleModels=False, numGSurfels=1 << 21)
+    for k in range(4):
+        o.process_frame(fr[k][0], fr[k][1])
+        mf.processFrame(fr[k][0], fr[k][1])
+        assert np.abs(o.pose - mf.getCurrPose()).max() < 1e-4, k
+        assert abs(o.count - mf.getBackgroundModel().lastCount()) <= max(20, 0.005 * o.count), k
+    assert o.count > 1_000_000
+    o.close(); mf.close()
