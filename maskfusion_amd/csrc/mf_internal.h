@@ -8,8 +8,7 @@ namespace mf {
 
 constexpr int kLevels = 3;            // RGBDOdometry::NUM_PYRS (Core/Utils/RGBDOdometry.h:81)
 constexpr int kIcpSlots = 32;         // 29 accumulators padded to 32 floats (128 B)
-constexpr int kMaxIcpBlocks = 320;    // upper bound of ICP grid (VGA L0 = 300 blocks of 256 threads x 4 px)
-constexpr int kCompactBlocks = 1024;  // fixed grid of the ordered-compaction passes
+constexpr int kCompactBlocks = 2048;  // fixed grid of the ordered-compaction passes (a VGA map: one 256-element slice per workgroup)
 constexpr unsigned long long kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
 constexpr int kNoUpdate = 0x7FFFFFFF;
 
@@ -98,8 +97,6 @@ struct IcpLaunch {
 };
 int icp_grid_blocks(int W, int H);
 void launch_icp_iteration(const IcpLaunch& a, hipStream_t s);
-// Seeds GNState from the model pose (Rprev = Rcurr = pose; resultRt = I).
-void launch_icp_begin(const PoseDev* pose, GNState* st, hipStream_t s);
 // Last reduce+solve, then pose / lastPose / inverse / fusion weight update and host mirror.
 // jump_limit > 0: object-model rule of MaskFusion.cpp:268-272 (|increment translation| > limit => pose->alive = 0)
 void launch_icp_finalize(const float* partials_in, int nblocks_in, const GNState* state_in, PoseDev* pose,

@@ -11,9 +11,9 @@
 // Here one launch per iteration does everything: its prologue reduces the previous launch's per-workgroup
 // partial sums in a fixed order, solves the 6x6 system in fp64 and updates the pose (every workgroup does this
 // redundantly and identically, so no workgroup ever waits on another inside a launch -- visibility comes from
-// the kernel boundary only), then streams the current vertex/normal planes (16 B per lane), gathers the model
-// planes, and reduces 29 accumulators with DPP row operations + one LDS stage.  No host round trip, no atomics,
-// bit-reproducible run to run.
+// the kernel boundary only), then streams the current vertex/normal planes, gathers the model planes, and reduces 29
+// accumulators with a recursive-halving tree (DPP exchanges) + one LDS stage.  No host round trip, no atomics,
+// bit-reproducible run to run.  With the photometric term an iteration is two launches (k_rgbd_iter, k_rgb_step).
 #include "mf_internal.h"
 #include "mf_device.h"
 #include "mf_rgbd_device.h"
@@ -228,28 +228,6 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ partia
     __syncthreads();
 }
 
-// ------------------------------------------------------------------------------------------------
-// wave64 sum via DPP row operations (one VALU op per step); the total lands in lane 63.
-// ------------------------------------------------------------------------------------------------
-template <int kCtrl>
-__device__ __forceinline__ float dpp_add(float v) {
-    const int o = __builtin_amdgcn_update_dpp(0, __float_as_int(v), kCtrl, 0xf, 0xf, false);
-    return v + __int_as_float(o);
-}
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-#if defined(MF_REDUCE_SHFL)
-    return wave_sum(v);
-#else
-    v = dpp_add<0xb1>(v);   // quad_perm:[1,0,3,2]
-    v = dpp_add<0x4e>(v);   // quad_perm:[2,3,0,1]
-    v = dpp_add<0x124>(v);  // row_ror:4
-    v = dpp_add<0x128>(v);  // row_ror:8
-    v = dpp_add<0x142>(v);  // row_bcast:15
-    v = dpp_add<0x143>(v);  // row_bcast:31
-    return v;
-#endif
-}
-
 // Sum of 29 (padded to 32) accumulators over the 64 lanes of a wavefront by recursive halving: at step s each lane
 // keeps the half of its remaining values selected by bit s of its lane id and hands the other half to lane ^ (1 << s),
 // so 16 + 8 + 4 + 2 + 1 + 1 = 32 cross-lane moves do what 29 x 6 = 174 full-width reductions did (measured: the
@@ -304,7 +282,7 @@ __device__ __forceinline__ float wave_sum32_halving(float (&v)[32]) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// The ICP iteration kernel.  256 threads, 4 consecutive pixels per thread (16 B streamed loads per plane).
+// The ICP iteration kernel.
 // ------------------------------------------------------------------------------------------------
 struct IcpKArgs {
     const float* vc; const float* nc; const float* vp; const float* np;
@@ -405,7 +383,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp_iter(const IcpKArgs a) {
     const int P = a.W * a.H;
     // A workgroup owns a contiguous chunk of <= kIcpPx * kIcpThreads pixels (icp_grid_blocks keeps the grid <= one workgroup
     // per CU so that a launch is ONE round of workgroups: 300 workgroups of 1024 px on 256 CUs ran as two rounds and
-    // doubled the level-0 launch time).  Thread t handles pixel beg + t and, if the chunk is longer, beg + 1024 + t.
+    // doubled the level-0 launch time).  Thread t handles pixels beg + t + q * kIcpThreads, q < kIcpPx.
     const int chunk = icp_chunk(P, gridDim.x);
     const int beg = blockIdx.x * chunk, end = min(P, beg + chunk);
 
@@ -483,7 +461,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp_iter(const IcpKArgs a) {
     for (int q = 0; q < kIcpPx; ++q)
         if (act[q]) icp_accumulate(cor[q], pv[q], pn[q], Rpi, tp, a, acc);
 
-    // (4) wavefront reduction (DPP), one LDS stage across the 16 wavefronts, one 128 B partial per workgroup
+    // (4) wavefront reduction (halving tree), one LDS stage across the wavefronts, one 128 B partial per workgroup
     if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[5] = __builtin_amdgcn_s_memtime(); }
     const int lane = tid & 63, wave = tid >> 6;
     const float wsum = wave_sum32_halving(acc);
@@ -528,17 +506,6 @@ void launch_icp_iteration(const IcpLaunch& l, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // begin / finalize
 // ------------------------------------------------------------------------------------------------
-__global__ void k_icp_begin(const PoseDev* __restrict__ pose, GNState* __restrict__ st) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    GNState s;
-    seed_state(*pose, s);
-    *st = s;
-}
-
-void launch_icp_begin(const PoseDev* pose, GNState* st, hipStream_t s) {
-    hipLaunchKernelGGL(k_icp_begin, dim3(1), dim3(64), 0, s, pose, st);
-}
-
 __global__ __launch_bounds__(256) void k_icp_finalize(const float* __restrict__ partials_in, int nb_in,
                                                        const GNState* __restrict__ st_in, PoseDev* __restrict__ pose,
                                                        PoseDev* __restrict__ host_mirror, float* __restrict__ log_out,
