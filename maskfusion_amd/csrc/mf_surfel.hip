@@ -481,16 +481,29 @@ __global__ __launch_bounds__(256) void k_clean_flags(const CleanArgs a) {
 
 __global__ __launch_bounds__(256) void k_clean_compact(const CleanArgs a) {
     __shared__ int s_w[4];
-    int base = block_base(a.block_counts, s_w);
     const int count = a.frame->countNext;
     const int total = count + cand_count(a.W, a.H, a.frame->tick);
     const float time = (float)a.frame->tick;
     const int chunk = chunk_size(total);
     const int beg = blockIdx.x * chunk, end = min(total, beg + chunk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int base = 0;
     for (int i0 = beg; i0 < end; i0 += 256) {
+        // every load of the slice is issued before anything depends on one of them (the keep flag, the record, the new
+        // confidence, and -- first slice -- the workgroup's base offset): one memory latency per slice instead of three
         const int i = i0 + threadIdx.x;
-        const bool keep = i < end && a.flags[i];
+        const bool in = i < end;
+        uint8_t flag = 0;
+        float nc = 0.f;
+        float4 pc = make_float4(0, 0, 0, 0), ct = pc, nr = pc;
+        if (in) {
+            flag = a.flags[i];
+            nc = a.newconf[i];
+            if (i < count) { pc = a.src.pc[i]; ct = a.src.ct[i]; nr = a.src.nr[i]; }
+            else { const int c = i - count; pc = a.cand_rec[c * 3 + 0]; ct = a.cand_rec[c * 3 + 1]; nr = a.cand_rec[c * 3 + 2]; }
+        }
+        if (i0 == beg) base = block_base(a.block_counts, s_w);
+        const bool keep = in && flag;
         const unsigned long long m = __ballot(keep);
         if (lane == 0) s_w[wave] = __popcll(m);
         __syncthreads();
@@ -499,17 +512,16 @@ __global__ __launch_bounds__(256) void k_clean_compact(const CleanArgs a) {
         const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
         if (keep) {
             const int o = off + lane_rank(m);
-            float4 pc, ct, nr;
-            if (i < count) { pc = a.src.pc[i]; ct = a.src.ct[i]; nr = a.src.nr[i]; }
-            else { const int c = i - count; pc = a.cand_rec[c * 3 + 0]; ct = a.cand_rec[c * 3 + 1]; nr = a.cand_rec[c * 3 + 2]; }
-            pc.w = a.newconf[i];
+            pc.w = nc;
             if (ct.w == -2.f) ct.w = time;  // copy_unstable.vert:131
             if (o < a.dst.cap) { a.dst.pc[o] = pc; a.dst.ct[o] = ct; a.dst.nr[o] = nr; }
         }
         base += tot;
         __syncthreads();
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    if (blockIdx.x != gridDim.x - 1) return;
+    if (beg >= end) base = block_base(a.block_counts, s_w);   // the last workgroup owns no elements: all threads take part
+    if (threadIdx.x == 0) {
         a.frame->count = min(base, a.dst.cap);
         if (a.host_count) *a.host_count = min(base, a.dst.cap);
     }
