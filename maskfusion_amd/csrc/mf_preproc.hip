@@ -27,6 +27,8 @@ constexpr int kBLdsH = kBTileH + 2 * kBR;  // 16
 // above 1e-6).  libm's expf cost ~25 instructions x 169 taps and made the kernel VALU bound at 40 us.  The filter output
 // is a weighted MEAN of nearly equal depths, so a 1e-6 relative weight error moves it by ~1e-9 relative: the measured
 // difference to the oracle's expf path is a few ulp (tests/test_gpu_kernels.py::test_bilateral).
+// (Two pixels per thread with 2-wide packed fp32 math -- 6.5 instead of 10 VALU instructions per tap -- was tried: 31 us
+// against 19 us; half as many wavefronts left the exp / LDS latencies exposed.)
 __global__ __launch_bounds__(256) void k_bilateral(const float* __restrict__ depth, float* __restrict__ out, int W, int H) {
     __shared__ float tile[kBLdsH * kBLdsW];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
