@@ -97,6 +97,7 @@ public:
         return false;
     }
     void predict() { check(mf_predict(ctx_)); }  // MaskFusion.h:76
+    void preallocateModels(unsigned count) { check(mf_preallocate_models(ctx_, count)); }  // MaskFusion.h:57
     void savePly() { check(mf_save_ply(ctx_, exportDir_.c_str())); }          // MaskFusion.h:282
     void exportPoses() { check(mf_export_poses(ctx_, exportDir_.c_str())); }  // MaskFusion.h:284
 

@@ -142,6 +142,9 @@ class MaskFusion:
     def predict(self):
         self._chk(self._L.mf_predict(self._h))
 
+    def preallocateModels(self, count: int):
+        self._chk(self._L.mf_preallocate_models(self._h, count))
+
     # -- exports (Core/MaskFusion.h:282-284) --------------------------------------------------------
     def savePly(self, exportDir: str):
         self._chk(self._L.mf_save_ply(self._h, exportDir.encode()))

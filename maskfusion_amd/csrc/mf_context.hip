@@ -147,6 +147,7 @@ struct mf_ctx {
     const uint8_t* cur_rgb = nullptr;      // device rgb of the frame being processed (fill-in intensity at predict time)
     struct RetiredLog { int id; std::vector<int64_t> ts; std::vector<float> p; };
     std::vector<RetiredLog> retired;       // pose logs of dropped models (MaskFusion::inactiveModels, exportPoses)
+    std::vector<std::unique_ptr<ModelState>> pool;   // MaskFusion::preallocatedModels (buffers allocated ahead of the spawn)
     float* d_vmap_g[3]; float* d_nmap_g[3];
     unsigned long long* d_keys = nullptr;
     int* d_index = nullptr; float4* d_ivc = nullptr; float4* d_ict = nullptr; float4* d_inr = nullptr;
@@ -691,8 +692,18 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
                 // spawnObjectModel (:671-684): pose = I, makeStatic(globalPose); moveNewModelToList
                 std::unique_ptr<ModelState> nm;
                 const int id = take_next_model_id(c);
-                int rc = create_model(c, id, g.conf_object, false, surfel_capacity(g.num_osurfels), nm);
-                if (rc != MF_OK) return rc;
+                if (!c->pool.empty()) {   // spawnObjectModel, :673-676: take a preallocated model
+                    nm = std::move(c->pool.front());
+                    c->pool.erase(c->pool.begin());
+                    nm->id = id;
+                    nm->confThr = g.conf_object;
+                    hipLaunchKernelGGL(k_pose_identity, dim3(1), dim3(64), 0, s, nm->d_pose);
+                    hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(64), 0, s, nm->d_frame, c->host_tick);
+                    nm->h_frame->tick = c->host_tick;
+                } else {
+                    int rc = create_model(c, id, g.conf_object, false, surfel_capacity(g.num_osurfels), nm);
+                    if (rc != MF_OK) return rc;
+                }
                 nm->classID = res.newClassID;
                 launch_spawn_pose(nm->d_pose, bg.d_pose, nm->d_frame, bg.d_frame, nm->h_pose, s);
                 c->models.push_back(std::move(nm));
@@ -780,6 +791,19 @@ extern "C" int mf_predict(mf_ctx* c) {
     c->cur_rgb = nullptr;  // the caller's frame buffer may be gone: the fill-in intensity keeps its last contents
     for (auto& m : c->models) enqueue_predict(c, *m);
     c->cur_rgb = keep;
+    return check_launch(c);
+}
+
+// MaskFusion::preallocateModels (Core/MaskFusion.cpp:144-149): object-model buffers allocated ahead of time, so that a spawn
+// inside a frame costs two tiny kernels instead of ~100 MB of hipMalloc + memset
+extern "C" int mf_preallocate_models(mf_ctx* c, uint32_t count) {
+    if (!c) return MF_EINVAL;
+    for (uint32_t i = 0; i < count; ++i) {
+        std::unique_ptr<ModelState> m;
+        int rc = create_model(c, -1, c->cfg.conf_object, false, surfel_capacity(c->cfg.num_osurfels), m);
+        if (rc != MF_OK) return rc;
+        c->pool.push_back(std::move(m));
+    }
     return check_launch(c);
 }
 

@@ -91,6 +91,8 @@ def test_pipeline_device_labels_equal_host_labels(hip):
         for k, v in dict(mfThreshold=0.3, mfWeightDistance=150.0, mfWeightConvexity=2.8, mfMorphEdgeIterations=0,
                          mfMorphMaskIterations=1, newModelMinRelativeSize=0.004, gpuLabels=gpu).items():
             m.setParam(k, v)
+        if gpu:
+            m.preallocateModels(2)   # MaskFusion::preallocateModels: spawning from the pool must not change anything
         out = []
         for k in range(10):
             m.processFrame(frames[k][0], frames[k][1], mask=frames[k][2], classIDs=(0, 41, 42))
