@@ -214,24 +214,52 @@ __global__ __launch_bounds__(kRelabelThreads) void k_lab_relabel(const int* __re
     }
 }
 
-// removeEdges, MfSegmentation.cpp:243-291 (one sweep; neighbours are read from the previous sweep)
-__global__ __launch_bounds__(256) void k_lab_sweep(const int* __restrict__ in, int* __restrict__ out, const int* __restrict__ area,
-                                                   const float* __restrict__ depth, int W, int H) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
-    const int i = y * W + x;
-    int c = in[i];
-    if (x >= 1 && x < W - 1 && y >= 1 && y < H - 1 && !(c != 0 && area[c] >= 50)) {
-        const float d = depth[i];
-        const int ox[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, oy[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int j = (y + oy[k]) * W + (x + ox[k]);
-            const int n = in[j];
-            if (n != 0 && (double)fabsf(depth[j] - d) < 0.008 && area[n] > 50) { c = n; break; }
-        }
+// removeEdges, MfSegmentation.cpp:243-291: a pixel that is edge (0) or in a < 50 px component takes the label of the first
+// 8-neighbour (row-major order) within 8 mm whose component has > 50 px; neighbours are read from the previous sweep.
+// The five sweeps in one launch: a workgroup stages a 32x8 tile with a 5-pixel halo (labels + depth) in LDS and iterates
+// on a region that shrinks by one pixel per sweep, so every output pixel sees exactly the five Jacobi steps of the
+// launch-per-sweep form (5 x 7.5 us -> one launch).
+constexpr int kSwTW = 32, kSwTH = 8, kSwHalo = 5;
+constexpr int kSwLW = kSwTW + 2 * kSwHalo, kSwLH = kSwTH + 2 * kSwHalo;   // 42 x 18
+__global__ __launch_bounds__(256) void k_lab_sweep5(const int* __restrict__ in, int* __restrict__ out, const int* __restrict__ area,
+                                                    const float* __restrict__ depth, int W, int H) {
+    __shared__ int s_lab[2][kSwLH * kSwLW];
+    __shared__ float s_d[kSwLH * kSwLW];
+    const int x0 = blockIdx.x * kSwTW - kSwHalo, y0 = blockIdx.y * kSwTH - kSwHalo;
+    for (int i = threadIdx.x; i < kSwLH * kSwLW; i += 256) {
+        const int ly = i / kSwLW, lx = i - ly * kSwLW;
+        const int gx = x0 + lx, gy = y0 + ly;
+        const bool inside = gx >= 0 && gx < W && gy >= 0 && gy < H;
+        s_lab[0][i] = inside ? in[gy * W + gx] : 0;
+        s_d[i] = inside ? depth[gy * W + gx] : 0.f;
     }
-    out[i] = c;
+    __syncthreads();
+    int cur = 0;
+    for (int it = 1; it <= 5; ++it) {
+        const int rw = kSwLW - 2 * it, rh = kSwLH - 2 * it;   // region still exact after `it` sweeps
+        for (int i = threadIdx.x; i < rw * rh; i += 256) {
+            const int ly = it + i / rw, lx = it + i % rw;
+            const int gx = x0 + lx, gy = y0 + ly;
+            const int li = ly * kSwLW + lx;
+            int c = s_lab[cur][li];
+            if (gx >= 1 && gx < W - 1 && gy >= 1 && gy < H - 1 && !(c != 0 && area[c] >= 50)) {
+                const float d = s_d[li];
+                const int ox[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, oy[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int lj = (ly + oy[k]) * kSwLW + (lx + ox[k]);
+                    const int n = s_lab[cur][lj];
+                    if (n != 0 && (double)fabsf(s_d[lj] - d) < 0.008 && area[n] > 50) { c = n; break; }
+                }
+            }
+            s_lab[1 - cur][li] = c;
+        }
+        __syncthreads();
+        cur = 1 - cur;
+    }
+    const int lx = kSwHalo + (threadIdx.x & 31), ly = kSwHalo + (threadIdx.x >> 5);
+    const int gx = x0 + lx, gy = y0 + ly;
+    if (gx < W && gy < H) out[gy * W + gx] = s_lab[cur][ly * kSwLW + lx];
 }
 
 __global__ __launch_bounds__(256) void k_lab_zero_tables(LabTables* T, int* compMask, int* compModel, int* compToMask, int* compFollow,
@@ -393,11 +421,11 @@ void launch_labels_gpu(const LabelsGpuArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_lab_relabel, dim3((P + kRelabelThreads - 1) / kRelabelThreads), dim3(kRelabelThreads), 0, s, a.L, a.compId, a.lab[0],
                        a.area, a.bbox, a.W, P);
     int cur = 0;
-    if (a.prm.removeEdges)
-        for (int it = 0; it < 5; ++it) {
-            hipLaunchKernelGGL(k_lab_sweep, g2, dim3(256), 0, s, a.lab[cur], a.lab[1 - cur], a.area, a.depth, a.W, a.H);
-            cur = 1 - cur;
-        }
+    if (a.prm.removeEdges) {
+        const dim3 gs((a.W + kSwTW - 1) / kSwTW, (a.H + kSwTH - 1) / kSwTH);
+        hipLaunchKernelGGL(k_lab_sweep5, gs, dim3(256), 0, s, a.lab[0], a.lab[1], a.area, a.depth, a.W, a.H);
+        cur = 1;
+    }
     const int* lab = a.lab[cur];
     hipLaunchKernelGGL(k_lab_zero_tables, dim3(512), dim3(256), 0, s, T, a.compMask, a.compModel, a.compToMask, a.compFollow, a.overlap,
                        a.table_cap);
