@@ -175,7 +175,7 @@ def main():
         P = W * H
         icp_bytes = 552 * P          # (10 + 5/4 + 4/16) * 48 B * P per model-frame
         n_launch = 19
-        t_icp = stages["odom"] * 1e-3 / n_launch   # average ICP-iteration launch incl. its share of the solve prologue
+        t_icp = stages["icpIterations"] * 1e-3 / n_launch   # HIP events around the 19 iteration launches on the library's stream
         achieved = icp_bytes / n_launch / t_icp / 1e9
         roofline = {"bound": "hbm", "kernel": "k_icp_iter (19 launches/frame, L2:4 L1:5 L0:10)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -168,6 +168,7 @@ struct mf_ctx {
     std::vector<std::unique_ptr<ModelState>> models;
 
     hipEvent_t ev[MF_N_TIMINGS + 1] = {};
+    hipEvent_t ev_icp[2] = {nullptr, nullptr};   // first / after-last Gauss-Newton launch of the background model
     float last_ms[MF_N_TIMINGS] = {};
     std::vector<void*> allocs;
     std::vector<void*> host_allocs;
@@ -377,6 +378,8 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     if (!c->labels->init(P)) return fail(MF_ENOMEM);
     for (int i = 0; i <= MF_N_TIMINGS; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) return fail(MF_EHIP);
+    for (int i = 0; i < 2; ++i)
+        if (hipEventCreate(&c->ev_icp[i]) != hipSuccess) return fail(MF_EHIP);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(MF_EHIP);
     *out = c;
     return MF_OK;
@@ -391,6 +394,8 @@ extern "C" void mf_destroy(mf_ctx* c) {
     for (void* p : c->host_allocs) (void)hipHostFree(p);
     for (int i = 0; i <= MF_N_TIMINGS; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 2; ++i)
+        if (c->ev_icp[i]) (void)hipEventDestroy(c->ev_icp[i]);
     for (int i = 0; i < 2; ++i) {
         if (c->ev_pre_done[i]) (void)hipEventDestroy(c->ev_pre_done[i]);
         if (c->ev_main_done[i]) (void)hipEventDestroy(c->ev_main_done[i]);
@@ -443,6 +448,8 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
     const int iters[3] = {g.fast_odom ? 3 : 10, g.pyramid ? 5 : 0, g.pyramid ? 4 : 0};  // RGBDOdometry.cpp:327-329
     const float minGrad[3] = {5.f, 3.f, 1.f};                                            // RGBDOdometry.cpp:102-105
     const float sobelScale = 1.0f / 8.0f;                                                // 1 / 2^sobelSize, :31-32
+    const bool timed = c->timings_on && &m == c->models[0].get();
+    if (timed) (void)hipEventRecord(c->ev_icp[0], s);
     int k = 0, nb_prev = 0, prev_level = -1;
     for (int lvl = 2; lvl >= 0; --lvl) {
         const float div = (float)(1 << lvl);
@@ -486,6 +493,7 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
             ++k;
         }
     }
+    if (timed) (void)hipEventRecord(c->ev_icp[1], s);
     float* log_out = (k > 0 && m.id == 0) ? c->d_icp_log + 32 * (k - 1) : nullptr;
     if (!rgb)
         launch_icp_finalize(nb_prev ? c->d_partials[(k + 1) & 1] : nullptr, nb_prev, &c->d_gn[k & 1], m.d_pose, m.h_pose, log_out,
@@ -764,7 +772,10 @@ extern "C" int mf_sync(mf_ctx* c) {
         }
         float run = 0.f;  // "Run" = the pose-dependent chain on the main stream; preprocessing overlaps the previous frame
         if (hipEventElapsedTime(&run, c->ev[2], c->ev[8]) == hipSuccess) t[8] = run;
+        float init = 0.f, iters = 0.f;
         t[1] = 0.f;
+        if (c->host_tick > 2 && hipEventElapsedTime(&init, c->ev[2], c->ev_icp[0]) == hipSuccess) t[1] = init;
+        if (c->host_tick > 2 && hipEventElapsedTime(&iters, c->ev_icp[0], c->ev_icp[1]) == hipSuccess) t[9] = iters;
         memcpy(c->last_ms, t, sizeof(t));
     }
     return MF_OK;

@@ -8,9 +8,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmaskfusion_amd.so")
 
 MF_OK = 0
-MF_N_TIMINGS = 9
+MF_N_TIMINGS = 10
 TIMING_LABELS = ["Preprocess", "odomInit", "odom", "indexMap", "Fuse::Data", "Fuse::Update", "Fuse::Copy",
-                 "IndexMap::ACTIVE", "Run"]
+                 "IndexMap::ACTIVE", "Run", "icpIterations"]
 
 
 class MFError(RuntimeError):
