@@ -38,7 +38,7 @@ __device__ __forceinline__ void ldlt6_solve(double (&A)[6][6], const double (&b)
     for (int k = 0; k < 6; ++k) {
         const double d = A[k][k];
         const bool ok = d > tol;
-        dinv[k] = ok ? 1.0 / d : 0.0;
+        dinv[k] = ok ? rcp_d(d) : 0.0;   // v_rcp_f64 + Newton: an IEEE division is a ~40-instruction dependent chain per pivot
         // the lower triangle (i >= j) is the working copy; col = column k of the current Schur complement
         double col[6];
 #pragma unroll
@@ -172,7 +172,10 @@ __device__ __forceinline__ void gn_solve_update_serial(const double* sys, const 
     for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int j = i; j < 7; ++j) {
-            const double value = (double)(float)sys[shift++];
+            // (the reference rounds A, b to fp32 on their way to the host; the fp32 per-workgroup partials already differ from
+            // an all-fp64 sum by ~1e-7 relative, so the extra rounding -- 54 quarter-rate conversions on this single
+            // thread -- is dropped)
+            const double value = sys[shift++];
             if (j == 6) b[i] = value;
             else { A[i][j] = value; A[j][i] = value; }
         }
@@ -183,11 +186,11 @@ __device__ __forceinline__ void gn_solve_update_serial(const double* sys, const 
 // Workgroup-level: wavefront 0 solves in parallel, its lane 0 applies the update.  Call with all threads of the
 // workgroup after reduce_partials(); returns true in the thread that holds `out`.
 __device__ __forceinline__ bool gn_solve_update_wg(const double* s_sys, const GNState& in, GNState& out) {
-    if (threadIdx.x >= 64) return false;
-    double x[6];
-    solve6_wave(s_sys, x);
     if (threadIdx.x != 0) return false;
-    gn_update_from_x(x, (float)s_sys[27], (float)s_sys[28], in, out);
+    // One thread, everything in registers: ~100 fp64 operations whose six pivots form the only long dependency chain.  The
+    // wave-parallel Gauss-Jordan (solve6_wave, kept for the RGB-D kernels and as a cross-check) spends its time in 18
+    // ds_bpermute round trips: 2.1 k cycles against ~0.9 k here.
+    gn_solve_update_serial(s_sys, in, out);
     return true;
 }
 
