@@ -341,7 +341,8 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
         A(dev_alloc(c, c->allocs, &c->d_tile_count, nt));
         // every tile owns entries_cap / tiles list slots: 4x the surfel capacity in total (a surfel overlaps 1-4 tiles), i.e.
         // room for every surfel of a full map to land in a quarter of the image (an overflow is an error, never a drop)
-        c->tile_entries_cap = (int)std::min<size_t>(4 * maxcap, (size_t)1 << 30);
+        // ... and never less than 16 list slots per pixel of a tile, so that small maps can still pile up in one place
+        c->tile_entries_cap = (int)std::min<size_t>(std::max<size_t>(4 * maxcap, (size_t)16 * P), (size_t)1 << 30);
         A(dev_alloc(c, c->allocs, &c->d_tile_entries, (size_t)c->tile_entries_cap));
     }
     A(dev_alloc(c, c->allocs, &c->d_keys, (size_t)P, 0xFF));
