@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--frames", type=int, default=24, help="distinct synthetic frames kept in HBM (ping-ponged)")
     ap.add_argument("--config", type=int, default=1, choices=(1, 4), help="BASELINE.json config (1 = the metric's; 4 = 1280x960 stress)")
+    ap.add_argument("--icp-weight", type=float, default=100.0, help="icpWeight (>= 100: geometric term only, the metric's setting; "
+                    "the reference GUI default is 20: photometric term on, two launches per Gauss-Newton iteration)")
+    ap.add_argument("--so3", action="store_true", help="SO(3) photometric pre-alignment (reference default: on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -110,7 +113,7 @@ def main():
     st, frames = gen_frames(args.frames)
     d_rgb = [torch.from_numpy(f[0]).to(dev) for f in frames]
     d_depth = [torch.from_numpy(f[1]).to(dev) for f in frames]
-    mf = MaskFusion(W, H, FX, FY, CX, CY, icpThresh=100.0, so3=False, device=local_rank, enableMultipleModels=False,
+    mf = MaskFusion(W, H, FX, FY, CX, CY, icpThresh=args.icp_weight, so3=args.so3, device=local_rank, enableMultipleModels=False,
                     numGSurfels=SURFELS)
     # Every rank owns one model.  Rank 0 owns the input stream and publishes frame k to all ranks (RCCL broadcast over xGMI
     # when N > 1) on the library's INPUT stream into a ring of 3 buffers; each rank then enqueues processFrame, whose main
@@ -159,7 +162,7 @@ def main():
     count = mf.getBackgroundModel().lastCount()
 
     roofline = None
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and args.icp_weight >= 100.0:
         # instrumented pass over the same steps: per-stage HIP events on the library stream
         mf.enableTimings(True)
         acc = {}
@@ -191,7 +194,9 @@ def main():
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOAD, "frames_in_hbm": args.frames, "surfels": count,
+            "config": {"workload": WORKLOAD + ("" if args.icp_weight >= 100.0 and not args.so3 else
+                                               f" [variant: icpWeight={args.icp_weight:g}, so3={int(args.so3)}]"),
+                       "frames_in_hbm": args.frames, "surfels": count,
                        "pose_drift_vs_gt_m": drift, "parallelism": f"model-per-gpu x{world}"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
