@@ -141,7 +141,7 @@ struct mf_ctx {
     int16_t* d_dIdx[3] = {}; int16_t* d_dIdy[3] = {};
     float* d_lastDepth[3] = {}; uint8_t* d_lastImage[3] = {};   // per-model scratch: populateRGBDData(last)
     RgbCorr* d_corres = nullptr; float* d_rgb_partials[2] = {nullptr, nullptr}; int2* d_cnt[2] = {nullptr, nullptr};
-    So3Result* d_so3 = nullptr;
+    So3Result* d_so3 = nullptr; char* d_so3_scratch = nullptr;
     // tiled splat prediction (mf_splat.hip)
     int* d_tile_count = nullptr; int* d_tile_entries = nullptr; int tile_entries_cap = 0; int splat_tiles = 1;
     const uint8_t* cur_rgb = nullptr;      // device rgb of the frame being processed (fill-in intensity at predict time)
@@ -335,6 +335,7 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
         A(dev_alloc(c, c->allocs, &c->d_cnt[b], (size_t)icp_grid_blocks(W, H)));
     }
     A(dev_alloc(c, c->allocs, &c->d_so3, 1));
+    A(dev_alloc(c, c->allocs, &c->d_so3_scratch, so3_scratch_bytes(W >> 2, H >> 2)));
     {
         const size_t nt = splat_tiles_scratch_ints(W, H);
         const size_t maxcap = (size_t)std::max(surfel_capacity(cfg->num_gsurfels), surfel_capacity(cfg->num_osurfels));
@@ -434,8 +435,8 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
     // the previous frame's intensity pyramid is RGBDOdometry::lastNextImage (identical for every tracked model)
     const bool so3 = g.so3 != 0 && c->gray_frame[set ^ 1] == c->frame_no - 1 && c->gray_frame[set] == c->frame_no;
     if (so3)
-        launch_so3_prealign(c->d_gray[set ^ 1][2], c->d_gray[set][2], W >> 2, H >> 2, Intr{g.fx / 4, g.fy / 4, g.cx / 4, g.cy / 4},
-                            c->d_so3, s);
+        (void)launch_so3_prealign(c->d_gray[set ^ 1][2], c->d_gray[set][2], W >> 2, H >> 2, Intr{g.fx / 4, g.fy / 4, g.cx / 4, g.cy / 4},
+                                  c->d_so3, c->d_so3_scratch, s);
     const So3Result* so3_seed = so3 ? c->d_so3 : nullptr;
     if (rgb) {
         // initRGBModel + initRGB (Model.cpp:395-406; Q1: both depth pyramids come from the vertex map initICPModel was given)
@@ -1181,12 +1182,18 @@ extern "C" int mf_k_derivative_images(const uint8_t* d_src, int16_t* d_dx, int16
 extern "C" int mf_k_so3_prealign(const uint8_t* d_last, const uint8_t* d_next, int32_t W, int32_t H, float fx, float fy, float cx, float cy,
                                  double* R9, float* stats3, void* stream) {
     if (!d_last || !d_next || !R9 || !stats3 || W < 3 || H < 3) return MF_EINVAL;
-    So3Result* d = nullptr;
-    if (hipMalloc((void**)&d, sizeof(So3Result)) != hipSuccess) return MF_ENOMEM;
-    launch_so3_prealign(d_last, d_next, W, H, Intr{fx, fy, cx, cy}, d, (hipStream_t)stream);
+    char* buf = nullptr;
+    const size_t sb = so3_scratch_bytes(W, H);
+    if (hipMalloc((void**)&buf, sb + sizeof(So3Result)) != hipSuccess) return MF_ENOMEM;
+    So3Result* d = reinterpret_cast<So3Result*>(buf);
+    if (launch_so3_prealign(d_last, d_next, W, H, Intr{fx, fy, cx, cy}, d, buf + sizeof(So3Result), (hipStream_t)stream) != 0) {
+        (void)hipFree(buf);
+        return MF_EINVAL;
+    }
     So3Result h;
+    (void)hipStreamSynchronize((hipStream_t)stream);
     const hipError_t e = hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
-    (void)hipFree(d);
+    (void)hipFree(buf);
     if (e != hipSuccess) return MF_EHIP;
     memcpy(R9, h.R, sizeof(h.R));
     stats3[0] = h.error; stats3[1] = h.count; stats3[2] = (float)h.iterations;

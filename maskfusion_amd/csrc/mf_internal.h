@@ -125,7 +125,10 @@ void launch_derivative(const uint8_t* src, int16_t* dx, int16_t* dy, int W, int 
 // level 0 of a model's "last" depth / intensity pyramids (populateRGBDData of initRGBModel; Q1: initRGB re-uses the depth)
 void launch_rgbd_last_l0(const float4* predV, const float* fillDepth, const uint8_t* predGray, const uint8_t* fillGray,
                          const FrameDev* frame, float* depth0, uint8_t* image0, int n, hipStream_t s);
-void launch_so3_prealign(const uint8_t* lastImage2, const uint8_t* nextImage2, int W2, int H2, Intr k2, So3Result* out, hipStream_t s);
+// scratch: so3_scratch_bytes(W2, H2) of device memory; returns -1 if the image needs more workgroups than the staging allows
+size_t so3_scratch_bytes(int W2, int H2);
+int launch_so3_prealign(const uint8_t* lastImage2, const uint8_t* nextImage2, int W2, int H2, Intr k2, So3Result* out, void* scratch,
+                        hipStream_t s);
 void launch_rgb_residual_only(const RgbLevel& L, const float* krk_kt, RgbCorr* corres, int* sums, hipStream_t s);
 void launch_rgb_step_only(const RgbLevel& L, const RgbCorr* corres, float sigma, Intr k, float sobelScale, double* out32, hipStream_t s);
 // One RGB-D Gauss-Newton iteration = two launches (see mf_odometry.hip)

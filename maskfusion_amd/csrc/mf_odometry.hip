@@ -231,6 +231,50 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ partia
     __syncthreads();
 }
 
+// Two partial arrays (ICP and photometric) and the correspondence counts in ONE memory latency: threads 0..255 reduce the
+// first array, threads 256..511 the second, wavefront 0 issues the count loads ahead of its partial loads.  Needs a
+// workgroup of >= 512 threads (the kernels here have exactly that); bit-identical sums to two reduce_partials calls.
+__device__ __forceinline__ void reduce_partials_pair(const float* __restrict__ pa, const float* __restrict__ pb, const int2* __restrict__ cnt,
+                                                     int nb, double* s_segA, double* s_segB, double* s_sysA, double* s_sysB, int* s_cnt) {
+    const int half = threadIdx.x >> 8, t = threadIdx.x & 255;
+    unsigned c = 0, g = 0;
+    if (threadIdx.x < 64)
+        for (int i = threadIdx.x; i < nb; i += 64) { const int2 v = cnt[i]; c += (unsigned)v.x; g += (unsigned)v.y; }
+    if (half < 2) {
+        const float4* __restrict__ p4 = reinterpret_cast<const float4*>(half ? pb : pa);
+        double* s_seg = half ? s_segB : s_segA;
+        const int n4 = nb * (kIcpSlots / 4);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int f = t; f < n4; f += 2560) {
+            float4 v[10];
+#pragma unroll
+            for (int u = 0; u < 10; ++u) v[u] = p4[min(f + 256 * u, n4 - 1)];
+#pragma unroll
+            for (int u = 0; u < 10; ++u) {
+                const bool in = f + 256 * u < n4;
+                a0 += in ? (double)v[u].x : 0.0; a1 += in ? (double)v[u].y : 0.0;
+                a2 += in ? (double)v[u].z : 0.0; a3 += in ? (double)v[u].w : 0.0;
+            }
+        }
+        const int row = t >> 3, c4 = (t & 7) * 4;
+        s_seg[row * 32 + c4 + 0] = a0; s_seg[row * 32 + c4 + 1] = a1; s_seg[row * 32 + c4 + 2] = a2; s_seg[row * 32 + c4 + 3] = a3;
+    }
+    if (threadIdx.x < 64) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { c += (unsigned)__shfl_xor((int)c, o, 64); g += (unsigned)__shfl_xor((int)g, o, 64); }
+        if (threadIdx.x == 0) { s_cnt[0] = (int)c; s_cnt[1] = (int)g; }
+    }
+    __syncthreads();
+    if (t < 32 && half < 2) {
+        const double* s_seg = half ? s_segB : s_segA;
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) sum += s_seg[k * 32 + t];
+        (half ? s_sysB : s_sysA)[t] = sum;
+    }
+    __syncthreads();
+}
+
 // Sum of 29 (padded to 32) accumulators over the 64 lanes of a wavefront by recursive halving: at step s each lane
 // keeps the half of its remaining values selected by bit s of its lane id and hands the other half to lane ^ (1 << s),
 // so 16 + 8 + 4 + 2 + 1 + 1 = 32 cross-lane moves do what 29 x 6 = 174 full-width reductions did (measured: the
@@ -622,11 +666,15 @@ __device__ __forceinline__ float rgb_tmp_error(int count, int sigma) {  // RGBDO
 // answer.  Returns true in the one thread (0) that holds `out`.
 __device__ __forceinline__ bool finish_rgbd_iteration(const float* icp_partials, const float* rgb_partials, const int2* cnt, int nb,
                                                       float icpWeight, int icpOn, int rgbOnly, int prev_level, const GNState& in,
-                                                      GNState& out, double* s_seg, double* s_sys, double* s_sys2, int* s_cnt,
-                                                      float* log_out) {
-    reduce_partials(icp_partials, nb, s_seg, s_sys);
-    reduce_partials(rgb_partials, nb, s_seg, s_sys2);
-    reduce_counts(cnt, nb, s_cnt);
+                                                      GNState& out, double* s_seg, double* s_seg2, double* s_sys, double* s_sys2,
+                                                      int* s_cnt, float* log_out) {
+    if (blockDim.x >= 512) {
+        reduce_partials_pair(icp_partials, rgb_partials, cnt, nb, s_seg, s_seg2, s_sys, s_sys2, s_cnt);
+    } else {
+        reduce_partials(icp_partials, nb, s_seg, s_sys);
+        reduce_partials(rgb_partials, nb, s_seg, s_sys2);
+        reduce_counts(cnt, nb, s_cnt);
+    }
     if (threadIdx.x >= 64) return false;
     double x[6];
     const double w = (double)icpWeight;
@@ -651,6 +699,7 @@ __device__ __forceinline__ bool finish_rgbd_iteration(const float* icp_partials,
 
 __global__ __launch_bounds__(kIcpThreads) void k_rgbd_iter(const RgbdKArgs a) {
     __shared__ double s_seg[32 * 32];
+    __shared__ double s_seg2[32 * 32];
     __shared__ double s_sys[32];
     __shared__ double s_sys2[32];
     __shared__ float s_pose[24];   // Rcurr[9] tcurr[3] Rprev_inv[9] tprev[3]
@@ -681,7 +730,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_rgbd_iter(const RgbdKArgs a) {
     bool mine;
     if (ia.nb_in > 0) {
         mine = finish_rgbd_iteration(ia.partials_in, a.rgb_partials_in, a.cnt_in, ia.nb_in, a.icpWeight, a.icpOn, a.rgbOnly, a.prev_level,
-                                     s_st, st, s_seg, s_sys, s_sys2, s_cnt, (blockIdx.x == 0) ? ia.log_out : nullptr);
+                                     s_st, st, s_seg, s_seg2, s_sys, s_sys2, s_cnt, (blockIdx.x == 0) ? ia.log_out : nullptr);
     } else {
         mine = tid == 0;
         if (mine) st = s_st;
@@ -818,8 +867,8 @@ __global__ __launch_bounds__(256) void k_rgbd_finalize(const float* __restrict__
     GNState st;
     bool mine;
     if (nb > 0) {
-        mine = finish_rgbd_iteration(icp_partials, rgb_partials, cnt, nb, icpWeight, icpOn, rgbOnly, prev_level, s_st, st, s_seg, s_sys,
-                                     s_sys2, s_cnt, log_out);
+        mine = finish_rgbd_iteration(icp_partials, rgb_partials, cnt, nb, icpWeight, icpOn, rgbOnly, prev_level, s_st, st, s_seg, s_seg,
+                                     s_sys, s_sys2, s_cnt, log_out);
     } else {
         mine = threadIdx.x == 0;
         if (mine) st = s_st;

@@ -6,9 +6,9 @@
 //   computeDerivativeImages                                                   Core/Cuda/cudafuncs.cu:658-718
 //   the SO(3) block of getIncrementalTransformation + so3Step                 RGBDOdometry.cpp:264-324, reduce.cu:999-1202
 //
-// The ten SO(3) iterations (19 200 px at VGA level 2) run inside ONE launch of one 1024-thread workgroup: reduction,
-// 3x3 solve, rotation update and the convergence tests stay in LDS/registers instead of ten {kernel, reduce kernel,
-// sync, D2H, host solve} rounds.
+// The SO(3) loop (19 200 px at VGA level 2, <= 10 iterations) never leaves the device: each iteration is one launch whose
+// prologue finishes the previous one (reduction, 3x3 solve, rotation update, convergence tests), instead of ten {kernel,
+// reduce kernel, sync, D2H, host solve} rounds.
 #pragma clang fp contract(off)  // before the headers: their inline helpers must not be fused either
 
 #include "mf_internal.h"
@@ -133,81 +133,150 @@ __device__ __forceinline__ void solve3(const float* A, const float* b, float* x)
     x[2] = (float)((c02 * b[0] + c12 * b[1] + c22 * b[2]) * id);
 }
 
-constexpr int kSo3Threads = 1024;
+// One launch per SO(3) iteration, structured like the ICP loop: the prologue of launch j (every workgroup, redundantly and
+// bit-identically) finishes iteration j-1 -- reduces its per-workgroup partial sums in workgroup order, applies the
+// convergence / divergence rules, solves the 3x3 system and updates the rotation -- then the pixels of iteration j are spread
+// over ~75 workgroups.  Once the loop has ended (`done`), the remaining launches only forward the state (~2.5 us each).
+// (All iterations inside ONE 1024-thread workgroup cost 186 us per frame: 19 200 pixels x ~200 instructions on a single CU.)
+constexpr int kSo3Threads = 256;
+constexpr int kSo3Slots = 12;   // 11 accumulators padded
 
-__global__ __launch_bounds__(kSo3Threads) void k_so3_prealign(const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage,
-                                                               int W, int H, Intr k, So3Result* __restrict__ out) {
-    __shared__ float s_basis[27];
-    __shared__ float s_red[(kSo3Threads / 64) * 12];
-    __shared__ int s_stop;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int P = W * H;
-    // state of the outer loop lives in thread 0
-    double resultR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, lastResultR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    float R_lr[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    float lastError = 3.4028234664e38f / 2, lastCount = 3.4028234664e38f / 2;
-    float so3Error = 0.f, so3Count = 0.f;
-    int iters = 0;
-    for (int it = 0; it < 10; ++it) {
-        if (tid == 0) { so3_bases(resultR, k, s_basis); s_stop = 0; }
-        __syncthreads();
-        float acc[11];
-#pragma unroll
-        for (int q = 0; q < 11; ++q) acc[q] = 0.f;
-        for (int p = tid; p < P; p += kSo3Threads) {
-            const int y = p / W, x = p - y * W;
-            so3_px(lastImage, nextImage, W, H, s_basis, x, y, acc);
-        }
-#pragma unroll
-        for (int q = 0; q < 11; ++q) {
-            float v = acc[q];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (lane == 0) s_red[wave * 12 + q] = v;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            float sum[11];
-            for (int q = 0; q < 11; ++q) {
-                float v = 0.f;
-                for (int w = 0; w < kSo3Threads / 64; ++w) v += s_red[w * 12 + q];
-                sum[q] = v;
-            }
-            ++iters;
-            const float jtj[9] = {sum[0], sum[1], sum[2], sum[1], sum[4], sum[5], sum[2], sum[5], sum[7]};
-            const float jtr[3] = {sum[3], sum[6], sum[8]};
-            so3Error = sqrtf(sum[9]) / sum[10];
-            so3Count = sum[10];
-            if (so3Error < lastError && fabsf(lastError - so3Count) < 0.001f) {            // sic (RGBDOdometry.cpp:305)
-                s_stop = 1;
-            } else if (so3Error > lastError + 0.001f) {                                       // diverging, :307-312
-                so3Error = lastError; so3Count = lastCount;
-                for (int q = 0; q < 9; ++q) resultR[q] = lastResultR[q];
-                s_stop = 1;
-            } else {
-                lastError = so3Error; lastCount = so3Count;
-                for (int q = 0; q < 9; ++q) lastResultR[q] = resultR[q];
-                float delta[3];
-                solve3(jtj, jtr, delta);
-                double Rw[3][3];
-                rodrigues_d((double)delta[0], (double)delta[1], (double)delta[2], Rw);
-                float nl[9];
-                for (int r = 0; r < 3; ++r)
-                    for (int c = 0; c < 3; ++c)
-                        nl[r * 3 + c] = (float)Rw[r][0] * R_lr[0 * 3 + c] + (float)Rw[r][1] * R_lr[1 * 3 + c] + (float)Rw[r][2] * R_lr[2 * 3 + c];
-                for (int q = 0; q < 9; ++q) { R_lr[q] = nl[q]; resultR[q] = (double)nl[q]; }
-            }
-        }
-        __syncthreads();
-        if (s_stop) break;
-    }
-    if (tid == 0) {
-        for (int q = 0; q < 9; ++q) out->R[q] = resultR[q];
-        out->error = so3Error; out->count = so3Count; out->iterations = iters; out->pad = 0;
+struct So3State {
+    double R[9], lastR[9];
+    float R_lr[9];
+    float lastError, lastCount, err, cnt;
+    int iters, done;
+};
+
+__device__ __forceinline__ void so3_state_init(So3State& st) {
+    for (int q = 0; q < 9; ++q) { st.R[q] = st.lastR[q] = (q % 4 == 0) ? 1.0 : 0.0; st.R_lr[q] = (q % 4 == 0) ? 1.f : 0.f; }
+    st.lastError = st.lastCount = 3.4028234664e38f / 2;
+    st.err = st.cnt = 0.f; st.iters = 0; st.done = 0;
+}
+
+// end of one iteration (RGBDOdometry.cpp:301-323) given the reduced sums
+__device__ __forceinline__ void so3_finish_iteration(const float* sum, So3State& st) {
+    ++st.iters;
+    const float jtj[9] = {sum[0], sum[1], sum[2], sum[1], sum[4], sum[5], sum[2], sum[5], sum[7]};
+    const float jtr[3] = {sum[3], sum[6], sum[8]};
+    st.err = sqrtf(sum[9]) / sum[10];
+    st.cnt = sum[10];
+    if (st.err < st.lastError && fabsf(st.lastError - st.cnt) < 0.001f) {            // sic (RGBDOdometry.cpp:305)
+        st.done = 1;
+    } else if (st.err > st.lastError + 0.001f) {                                        // diverging, :307-312
+        st.err = st.lastError; st.cnt = st.lastCount;
+        for (int q = 0; q < 9; ++q) st.R[q] = st.lastR[q];
+        st.done = 1;
+    } else {
+        st.lastError = st.err; st.lastCount = st.cnt;
+        for (int q = 0; q < 9; ++q) st.lastR[q] = st.R[q];
+        float delta[3];
+        solve3(jtj, jtr, delta);
+        double Rw[3][3];
+        rodrigues_d((double)delta[0], (double)delta[1], (double)delta[2], Rw);
+        float nl[9];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c)
+                nl[r * 3 + c] = (float)Rw[r][0] * st.R_lr[0 * 3 + c] + (float)Rw[r][1] * st.R_lr[1 * 3 + c] + (float)Rw[r][2] * st.R_lr[2 * 3 + c];
+        for (int q = 0; q < 9; ++q) { st.R_lr[q] = nl[q]; st.R[q] = (double)nl[q]; }
     }
 }
-void launch_so3_prealign(const uint8_t* lastImage2, const uint8_t* nextImage2, int W2, int H2, Intr k2, So3Result* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_so3_prealign, dim3(1), dim3(kSo3Threads), 0, s, lastImage2, nextImage2, W2, H2, k2, out);
+
+// loads the state, finishes the previous iteration from its partials; returns with the state in s_st (all threads synced)
+__device__ __forceinline__ void so3_prologue(const So3State* __restrict__ st_in, const float* __restrict__ part_in, int nb_in, int first,
+                                             So3State& s_st, float* s_p /*[nb_in * kSo3Slots]*/, float* s_sum /*[12]*/) {
+    const int tid = threadIdx.x;
+    if (first) {
+        if (tid == 0) so3_state_init(s_st);
+    } else {
+        if (tid < (int)(sizeof(So3State) / 4)) reinterpret_cast<uint32_t*>(&s_st)[tid] = reinterpret_cast<const uint32_t*>(st_in)[tid];
+        for (int i = tid; i < nb_in * kSo3Slots; i += kSo3Threads) s_p[i] = part_in[i];
+    }
+    __syncthreads();
+    if (!first && !s_st.done) {
+        if (tid < 11) {
+            float v = 0.f;
+            for (int b = 0; b < nb_in; ++b) v += s_p[b * kSo3Slots + tid];
+            s_sum[tid] = v;
+        }
+        __syncthreads();
+        if (tid == 0) so3_finish_iteration(s_sum, s_st);
+    }
+    __syncthreads();
+}
+
+constexpr int kSo3MaxBlocks = 512;   // LDS staging of the previous launch's partials
+
+__global__ __launch_bounds__(kSo3Threads) void k_so3_iter(const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage,
+                                                           int W, int H, Intr k, const So3State* __restrict__ st_in,
+                                                           So3State* __restrict__ st_out, const float* __restrict__ part_in, int nb_in,
+                                                           float* __restrict__ part_out, int first) {
+    __shared__ So3State s_st;
+    __shared__ float s_p[kSo3MaxBlocks * kSo3Slots];
+    __shared__ float s_sum[kSo3Slots];
+    __shared__ float s_basis[27];
+    __shared__ float s_red[(kSo3Threads / 64) * kSo3Slots];
+    so3_prologue(st_in, part_in, nb_in, first, s_st, s_p, s_sum);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool done = s_st.done != 0;
+    if (tid == 0) {
+        if (!done) so3_bases(s_st.R, k, s_basis);
+        if (blockIdx.x == 0) *st_out = s_st;
+    }
+    if (done) return;
+    __syncthreads();
+    float acc[11];
+#pragma unroll
+    for (int q = 0; q < 11; ++q) acc[q] = 0.f;
+    const int p = blockIdx.x * kSo3Threads + tid;
+    if (p < W * H) {
+        const int y = p / W, x = p - y * W;
+        so3_px(lastImage, nextImage, W, H, s_basis, x, y, acc);
+    }
+#pragma unroll
+    for (int q = 0; q < 11; ++q) {
+        float v = acc[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) s_red[wave * kSo3Slots + q] = v;
+    }
+    __syncthreads();
+    if (tid < kSo3Slots) {
+        float v = 0.f;
+        if (tid < 11)
+            for (int w = 0; w < kSo3Threads / 64; ++w) v += s_red[w * kSo3Slots + tid];
+        part_out[blockIdx.x * kSo3Slots + tid] = v;
+    }
+}
+
+__global__ __launch_bounds__(kSo3Threads) void k_so3_final(const So3State* __restrict__ st_in, const float* __restrict__ part_in, int nb_in,
+                                                            So3Result* __restrict__ out) {
+    __shared__ So3State s_st;
+    __shared__ float s_p[kSo3MaxBlocks * kSo3Slots];
+    __shared__ float s_sum[kSo3Slots];
+    so3_prologue(st_in, part_in, nb_in, 0, s_st, s_p, s_sum);
+    if (threadIdx.x == 0) {
+        for (int q = 0; q < 9; ++q) out->R[q] = s_st.R[q];
+        out->error = s_st.err; out->count = s_st.cnt; out->iterations = s_st.iters; out->pad = 0;
+    }
+}
+
+size_t so3_scratch_bytes(int W2, int H2) {
+    const size_t nb = ((size_t)W2 * H2 + kSo3Threads - 1) / kSo3Threads;
+    return 2 * sizeof(So3State) + 2 * nb * kSo3Slots * sizeof(float) + 64;
+}
+
+int launch_so3_prealign(const uint8_t* lastImage2, const uint8_t* nextImage2, int W2, int H2, Intr k2, So3Result* out, void* scratch,
+                        hipStream_t s) {
+    const int nb = (W2 * H2 + kSo3Threads - 1) / kSo3Threads;
+    if (nb > kSo3MaxBlocks) return -1;
+    So3State* st = reinterpret_cast<So3State*>(scratch);
+    float* part = reinterpret_cast<float*>(st + 2);
+    for (int j = 0; j < 10; ++j)   // RGBDOdometry.cpp:283: at most ten iterations
+        hipLaunchKernelGGL(k_so3_iter, dim3(nb), dim3(kSo3Threads), 0, s, lastImage2, nextImage2, W2, H2, k2, st + (j & 1), st + ((j + 1) & 1),
+                           part + (size_t)((j + 1) & 1) * nb * kSo3Slots, nb, part + (size_t)(j & 1) * nb * kSo3Slots, j == 0 ? 1 : 0);
+    hipLaunchKernelGGL(k_so3_final, dim3(1), dim3(kSo3Threads), 0, s, st + 0, part + (size_t)1 * nb * kSo3Slots, nb, out);
+    return 0;
 }
 
 // ---------------- stand-alone residual / step (parity tests; the tracking loop uses the fused kernels) ----------------
