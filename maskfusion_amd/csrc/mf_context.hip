@@ -138,7 +138,7 @@ struct mf_ctx {
     // photometric term + SO(3) (a5, a8-a10, a12)
     uint8_t* d_gray[2][3] = {};            // intensity pyramid of the frame, by frame parity ([prev] = lastNextImage)
     long gray_frame[2] = {-1, -1};         // frame_no each set was computed for
-    int16_t* d_dIdx[3] = {}; int16_t* d_dIdy[3] = {};
+    int16_t* d_dIdx[3] = {}; int16_t* d_dIdy[3] = {}; uint8_t* d_rgb_gate[3] = {};
     float* d_lastDepth[3] = {}; uint8_t* d_lastImage[3] = {};   // per-model scratch: populateRGBDData(last)
     RgbCorr* d_corres = nullptr; float* d_rgb_partials[2] = {nullptr, nullptr}; int2* d_cnt[2] = {nullptr, nullptr};
     So3Result* d_so3 = nullptr; char* d_so3_scratch = nullptr;
@@ -326,6 +326,7 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
         for (int set = 0; set < 2; ++set) A(dev_alloc(c, c->allocs, &c->d_gray[set][i], lp));
         A(dev_alloc(c, c->allocs, &c->d_dIdx[i], lp));
         A(dev_alloc(c, c->allocs, &c->d_dIdy[i], lp));
+        A(dev_alloc(c, c->allocs, &c->d_rgb_gate[i], lp));
         A(dev_alloc(c, c->allocs, &c->d_lastDepth[i], lp));
         A(dev_alloc(c, c->allocs, &c->d_lastImage[i], lp));
     }
@@ -416,6 +417,12 @@ static void mark(mf_ctx* c, int i, hipStream_t s = nullptr) {
 // ------------------------------------------------------------------------------------------------
 // per-model stages
 // ------------------------------------------------------------------------------------------------
+// minimumGradientMagnitudes[level]^2 / sobelScale^2 (RGBDOdometry.cpp:31-32,102-105,381)
+static float rgb_min_scale(int level) {
+    const double minGrad[3] = {5.0, 3.0, 1.0}, sobelScale = 1.0 / 8.0;
+    return (float)(pow(minGrad[level], 2.0) / pow(sobelScale, 2.0));
+}
+
 // rgb = rgbOnly || icpWeight < 100 (RGBDOdometry.cpp:238)
 static bool photometric_on(const mf_ctx* c) { return c->cfg.rgb_only != 0 || c->cfg.icp_weight < 100.f; }
 
@@ -448,7 +455,6 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
         }
     }
     const int iters[3] = {g.fast_odom ? 3 : 10, g.pyramid ? 5 : 0, g.pyramid ? 4 : 0};  // RGBDOdometry.cpp:327-329
-    const float minGrad[3] = {5.f, 3.f, 1.f};                                            // RGBDOdometry.cpp:102-105
     const float sobelScale = 1.0f / 8.0f;                                                // 1 / 2^sobelSize, :31-32
     const bool timed = c->timings_on && &m == c->models[0].get();
     if (timed) (void)hipEventRecord(c->ev_icp[0], s);
@@ -478,7 +484,8 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
                 r.L.lastDepth = c->d_lastDepth[lvl]; r.L.nextDepth = c->d_lastDepth[lvl];
                 r.L.lastImage = c->d_lastImage[lvl]; r.L.nextImage = c->d_gray[set][lvl];
                 r.L.W = l.W; r.L.H = l.H;
-                r.L.minScale = (float)(pow((double)minGrad[lvl], 2.0) / pow((double)sobelScale, 2.0));
+                r.L.minScale = rgb_min_scale(lvl);
+                r.L.gate = c->d_rgb_gate[lvl];
                 r.L.maxDepthDelta = 0.07f;                                          // maxDepthDeltaRGB, :33
                 r.corres = c->d_corres;
                 r.rgb_partials_in = nb_prev ? c->d_rgb_partials[(k + 1) & 1] : nullptr;
@@ -604,7 +611,8 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
         for (int i = 0; i + 1 < 3; ++i) launch_pyrdown_u8(c->d_gray[set][i], c->d_gray[set][i + 1], W >> i, H >> i, sp);
         c->gray_frame[set] = k;
         if (photometric_on(c))
-            for (int i = 0; i < 3; ++i) launch_derivative(c->d_gray[set][i], c->d_dIdx[i], c->d_dIdy[i], W >> i, H >> i, sp);
+            for (int i = 0; i < 3; ++i)
+                launch_derivative(c->d_gray[set][i], c->d_dIdx[i], c->d_dIdy[i], W >> i, H >> i, rgb_min_scale(i), c->d_rgb_gate[i], sp);
     }
     mark(c, 1, sp);
     if (c->overlap) {
@@ -1176,7 +1184,7 @@ extern "C" int mf_k_pyrdown_u8(const uint8_t* d_src, uint8_t* d_dst, int32_t sw,
 }
 extern "C" int mf_k_derivative_images(const uint8_t* d_src, int16_t* d_dx, int16_t* d_dy, int32_t W, int32_t H, void* stream) {
     if (!d_src || !d_dx || !d_dy || W <= 0 || H <= 0) return MF_EINVAL;
-    launch_derivative(d_src, d_dx, d_dy, W, H, (hipStream_t)stream);
+    launch_derivative(d_src, d_dx, d_dy, W, H, 0.f, nullptr, (hipStream_t)stream);
     return launch_rc();
 }
 extern "C" int mf_k_so3_prealign(const uint8_t* d_last, const uint8_t* d_next, int32_t W, int32_t H, float fx, float fy, float cx, float cy,
@@ -1203,7 +1211,7 @@ static RgbLevel make_level(const int16_t* dIdx, const int16_t* dIdy, const float
                            const uint8_t* nextImage, int W, int H, float minScale, float maxDepthDelta) {
     RgbLevel L;
     L.dIdx = dIdx; L.dIdy = dIdy; L.lastDepth = lastDepth; L.nextDepth = nextDepth; L.lastImage = lastImage; L.nextImage = nextImage;
-    L.W = W; L.H = H; L.minScale = minScale; L.maxDepthDelta = maxDepthDelta;
+    L.W = W; L.H = H; L.minScale = minScale; L.maxDepthDelta = maxDepthDelta; L.gate = nullptr;
     return L;
 }
 extern "C" int mf_k_rgb_residual(float min_scale, const int16_t* d_dIdx, const int16_t* d_dIdy, const float* d_last_depth,

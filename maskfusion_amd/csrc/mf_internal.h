@@ -116,12 +116,15 @@ struct RgbLevel {  // one pyramid level of RGBDOdometry's photometric inputs
     int W, H;
     float minScale;        // minimumGradientMagnitudes[level]^2 / sobelScale^2
     float maxDepthDelta;   // 0.07
+    const uint8_t* gate;   // optional: 1 where the iteration-independent tests of RGBResidual pass (border, 4x4 window of the
+                           // next image > 0, gradient magnitude), written once per frame by the derivative kernel; nullptr =
+                           // evaluate them per pixel
 };
 
 // ---------------- photometric term + SO(3) (mf_rgbd.hip, mf_odometry.hip) ----------------
 void launch_intensity(const uint8_t* img, int channels, uint8_t* dst, int n, hipStream_t s);
 void launch_pyrdown_u8(const uint8_t* src, uint8_t* dst, int sw, int sh, hipStream_t s);
-void launch_derivative(const uint8_t* src, int16_t* dx, int16_t* dy, int W, int H, hipStream_t s);
+void launch_derivative(const uint8_t* src, int16_t* dx, int16_t* dy, int W, int H, float minScale, uint8_t* gate /*or null*/, hipStream_t s);
 // level 0 of a model's "last" depth / intensity pyramids (populateRGBDData of initRGBModel; Q1: initRGB re-uses the depth)
 void launch_rgbd_last_l0(const float4* predV, const float* fillDepth, const uint8_t* predGray, const uint8_t* fillGray,
                          const FrameDev* frame, float* depth0, uint8_t* image0, int n, hipStream_t s);

@@ -80,7 +80,7 @@ void launch_pyrdown_u8(const uint8_t* src, uint8_t* dst, int sw, int sh, hipStre
 
 // ---------------- computeDerivativeImages ----------------
 __global__ __launch_bounds__(256) void k_derivative(const uint8_t* __restrict__ src, int16_t* __restrict__ dx,
-                                                    int16_t* __restrict__ dy, int W, int H) {
+                                                    int16_t* __restrict__ dy, int W, int H, float minScale, uint8_t* __restrict__ gate) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     const float gx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
@@ -99,12 +99,14 @@ __global__ __launch_bounds__(256) void k_derivative(const uint8_t* __restrict__ 
             dyVal = fmaf(sv, wy, dyVal);
             --k;
         }
-    dx[y * W + x] = (int16_t)dxVal;
-    dy[y * W + x] = (int16_t)dyVal;
+    const int16_t sx = (int16_t)dxVal, sy = (int16_t)dyVal;
+    dx[y * W + x] = sx;
+    dy[y * W + x] = sy;
+    if (gate) gate[y * W + x] = rgb_gate_px(src, sx, sy, minScale, W, H, x, y) ? 1 : 0;
 }
-void launch_derivative(const uint8_t* src, int16_t* dx, int16_t* dy, int W, int H, hipStream_t s) {
+void launch_derivative(const uint8_t* src, int16_t* dx, int16_t* dy, int W, int H, float minScale, uint8_t* gate, hipStream_t s) {
     dim3 grid((W + 63) / 64, (H + 3) / 4);
-    hipLaunchKernelGGL(k_derivative, grid, dim3(256), 0, s, src, dx, dy, W, H);
+    hipLaunchKernelGGL(k_derivative, grid, dim3(256), 0, s, src, dx, dy, W, H, minScale, gate);
 }
 
 // ---------------- SO(3) pre-alignment: all iterations in one workgroup ----------------

@@ -21,20 +21,28 @@ __device__ __forceinline__ uint8_t intensity_of(float c0, float c1, float c2) {
     return (uint8_t)(int)v;
 }
 
+// The tests of RGBResidual::getProducts that do not depend on the pose (reduce.cu:823-851): border, 4x4 window of the next
+// image all > 0, squared gradient magnitude >= minScale.
+__device__ __forceinline__ bool rgb_gate_px(const uint8_t* __restrict__ nextImage, int valx, int valy, float minScale, int W, int H,
+                                            int x, int y) {
+    if (!(x < W - 5 && y < H - 1)) return false;
+    bool valid = true;
+    for (int u = max(y - 2, 0); u < min(y + 2, H); ++u)
+        for (int v = max(x - 2, 0); v < min(x + 2, W); ++v) valid = valid && (nextImage[u * W + v] > 0);
+    if (!valid) return false;
+    const float mTwo = (float)((valx * valx) + (valy * valy));
+    return mTwo >= minScale;
+}
+
 // Returns true (and fills c) iff pixel (x, y) of the next image finds a photometric correspondence in the last image.
 __device__ __forceinline__ bool rgb_residual_px(const RgbLevel& L, const float* __restrict__ krk, float3 kt, int x, int y,
                                                 RgbCorr& c) {
 #pragma clang fp contract(off)
     c.u0 = -1; c.v0 = -1; c.diff = 0.f;
     const int W = L.W, H = L.H;
-    if (!(x < W - 5 && y < H - 1)) return false;
-    bool valid = true;
-    for (int u = max(y - 2, 0); u < min(y + 2, H); ++u)
-        for (int v = max(x - 2, 0); v < min(x + 2, W); ++v) valid = valid && (L.nextImage[u * W + v] > 0);
-    if (!valid) return false;
-    const int valx = L.dIdx[y * W + x], valy = L.dIdy[y * W + x];
-    const float mTwo = (float)((valx * valx) + (valy * valy));
-    if (!(mTwo >= L.minScale)) return false;
+    if (L.gate) {
+        if (!L.gate[y * W + x]) return false;   // the same three tests, evaluated once per frame (rgb_gate_px)
+    } else if (!rgb_gate_px(L.nextImage, L.dIdx[y * W + x], L.dIdy[y * W + x], L.minScale, W, H, x, y)) return false;
     const float d1 = L.nextDepth[y * W + x];
     if (isnan(d1)) return false;
     const float fx_ = (float)x, fy_ = (float)y;

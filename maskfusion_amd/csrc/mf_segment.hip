@@ -90,7 +90,7 @@ void launch_edge_binary(const float* edge, uint8_t* out, uint8_t* tmp, int W, in
         hipLaunchKernelGGL(k_morph<false>, grid, dim3(256), 0, s, tmp, out, W, H, radius);
     }
     hipLaunchKernelGGL(k_invert, dim3(blocks), dim3(256), 0, s, out, tmp, n);
-    hipMemcpyAsync(out, tmp, n, hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(out, tmp, n, hipMemcpyDeviceToDevice, s);
 }
 
 // ------------------------------------------------------------------------------------------------
