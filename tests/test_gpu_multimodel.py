@@ -46,15 +46,15 @@ def test_geometric_edges_kernel(hip, oracle):
             assert flips.mean() < 1e-4
 
 
-def _run_pair(oracle, n_frames, track_all, object_motion):
+def _run_pair(oracle, n_frames, track_all, object_motion, icp_weight=100.0, so3=False):
     from maskfusion_amd import MaskFusion, synth
     from oracle import mfo_mm
     st = synth.Stream(W=640, H=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, n_objects=2, noise=True, object_motion=object_motion)
     frames = [st.frame(k) for k in range(n_frames)]
     cls = [0, 41, 42]
-    o = mfo_mm.OracleMM(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpWeight=100.0, capacity=1 << 20, capacityObject=1 << 18,
-                        modelSpawnOffset=3, trackAllModels=int(track_all), seg=SEG)
-    m = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=100.0, so3=False, numGSurfels=1 << 20, numOSurfels=1 << 18,
+    o = mfo_mm.OracleMM(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpWeight=icp_weight, so3=int(so3), capacity=1 << 20,
+                        capacityObject=1 << 18, modelSpawnOffset=3, trackAllModels=int(track_all), seg=SEG)
+    m = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=icp_weight, so3=so3, numGSurfels=1 << 20, numOSurfels=1 << 18,
                    enableMultipleModels=True, modelSpawnOffset=3, trackAllModels=track_all)
     for k, v in (("mfThreshold", SEG["threshold"]), ("mfWeightDistance", SEG["weightDistance"]),
                  ("mfWeightConvexity", SEG["weightConvexity"]), ("mfMorphEdgeIterations", 0), ("mfMorphMaskIterations", 0),
@@ -126,3 +126,16 @@ def test_tracked_objects_short_horizon(mm_tracked):
                 # 1e-7 preprocessing differences to centimetres within two frames -- bounded here, compared strictly in mm_static
                 assert np.abs(r["o_pose"][i] - r["g_pose"][i]).max() < 4e-2, (k, i)
     assert max(r["g_n"] for r in mm_tracked) >= 2
+
+
+def test_multimodel_with_reference_default_tracking(hip, oracle):
+    """The reference's default tracking (icpWeight 20 + SO(3), GUI.h:189-195) in the multi-model path: per-model photometric
+    pyramids, the shared lastNextImage, spawn with initFirstRGB -- same models, labels and camera poses as the oracle."""
+    rec = _run_pair(oracle, 8, False, 0.0, icp_weight=20.0, so3=True)
+    for k, r in enumerate(rec):
+        assert r["o_ids"] == r["g_ids"], f"frame {k}"
+        assert np.abs(r["o_pose"][0] - r["g_pose"][0]).max() < 2e-4, f"background pose, frame {k}"
+        assert (r["o_seg"] != r["g_seg"]).mean() < 2e-3
+        for a, b in zip(r["o_cnt"], r["g_cnt"]):
+            assert abs(a - b) <= max(20, 0.01 * a)
+    assert max(r["o_n"] for r in rec) >= 3
