@@ -528,10 +528,11 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
     launch_fuse_data(d_rgb, d_depth, depthF, mask, m.id, m.d_frame, m.d_pose, weightMultiplier, fminf(fuseDepthCutoff, m.maxDepth), W, H,
                      c->K, c->d_index, c->d_ivc, c->d_inr, c->d_cand_op, c->d_cand_rec, c->d_upd_first, s);
     if (marks) mark(c, 5);
-    launch_fuse_update(m.surf[src], m.surf[dst], m.d_frame, c->d_upd_first, c->d_cand_rec, s);
+    // the scatter half of the second predictIndices (:556) rides on the update pass
+    launch_fuse_update(m.surf[src], m.surf[dst], m.d_frame, c->d_upd_first, c->d_cand_rec, m.d_pose, W, H, c->K, g.max_depth_processed,
+                       g.time_delta, secondIndexPass ? c->d_keys : nullptr, true, s);
     if (marks) mark(c, 6);
     if (secondIndexPass) {
-        launch_index_scatter(m.surf[dst], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, true, s);
         launch_index_resolve(m.surf[dst], m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, s);
     }
     launch_clean(m.surf[dst], m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.time_delta, m.confThr, g.outlier_coefficient, m.id,

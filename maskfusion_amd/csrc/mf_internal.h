@@ -162,7 +162,9 @@ void launch_fuse_data(const uint8_t* rgb, const float* depthRaw, const float* de
                       int maskID, const FrameDev* frame, const PoseDev* pose, float weightMultiplier, float maxDepth,
                       int W, int H, Intr k, const int* index, const float4* vc, const float4* nr, uint8_t* cand_op,
                       float4* cand_rec, int* upd_first, hipStream_t s);
-void launch_fuse_update(Surfels src, Surfels dst, const FrameDev* frame, int* upd_first, const float4* cand_rec,
+// keys_or_null != nullptr: also scatters the updated surfels into the index-map keys (the pass that feeds clean)
+void launch_fuse_update(Surfels src, Surfels dst, const FrameDev* frame, int* upd_first, const float4* cand_rec, const PoseDev* pose,
+                        int W, int H, Intr k, float maxDepth, int timeDelta, unsigned long long* keys_or_null, bool transposed,
                         hipStream_t s);
 void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k,
                   int timeDelta, float confThreshold, float outlierCoeff, int maskID, const int* index,

@@ -331,10 +331,22 @@ void launch_fuse_data(const uint8_t* rgb, const float* depthRaw, const float* de
 // ------------------------------------------------------------------------------------------------
 // surfel update (update.vert): src -> dst, consuming (and resetting) the per-surfel merge slot
 // ------------------------------------------------------------------------------------------------
+// idx != nullptr: the index-map scatter of the pass that feeds clean() (predictIndices after fuse, MaskFusion.cpp:556) is done
+// right here on the values just written, instead of a separate launch re-reading the buffer.
+struct IndexScatterArgs { const PoseDev* pose; int W, H; Intr k; float maxDepth; int timeDelta; unsigned long long* keys; int transposed; };
+
 __global__ __launch_bounds__(256) void k_fuse_update(Surfels src, Surfels dst, const FrameDev* __restrict__ frame,
-                                                     int* __restrict__ upd_first, const float4* __restrict__ cand_rec) {
+                                                     int* __restrict__ upd_first, const float4* __restrict__ cand_rec,
+                                                     const IndexScatterArgs ix) {
     const int n = frame->count;
     const float time = (float)frame->tick;
+    float Ri[9];
+    float3 ti = f3(0, 0, 0);
+    if (ix.keys) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) Ri[q] = ix.pose->Ri[q];
+        ti = f3(ix.pose->ti[0], ix.pose->ti[1], ix.pose->ti[2]);
+    }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         float4 pc = src.pc[i], ct = src.ct[i], nr = src.nr[i];
         const int m = upd_first[i];
@@ -359,11 +371,25 @@ __global__ __launch_bounds__(256) void k_fuse_update(Surfels src, Surfels dst, c
             }
         }
         dst.pc[i] = pc; dst.ct[i] = ct; dst.nr[i] = nr;
+        if (ix.keys) {   // k_index_scatter on the updated surfel (index_map.vert:40-60)
+            const float3 h = mul33(Ri, f3(pc.x, pc.y, pc.z)) + ti;
+            if (!(h.z > ix.maxDepth || h.z <= 0 || time - ct.w > (float)ix.timeDelta)) {
+                const float u = ((ix.k.fx * h.x) / h.z) + ix.k.cx;
+                const float v = ((ix.k.fy * h.y) / h.z) + ix.k.cy;
+                if (u >= 0.f && u < (float)ix.W && v >= 0.f && v < (float)ix.H) {
+                    const int p = ix.transposed ? (int)floorf(u) * ix.H + (int)floorf(v) : (int)floorf(v) * ix.W + (int)floorf(u);
+                    zmin_key(&ix.keys[p], ((unsigned long long)__float_as_uint(h.z) << 32) | (unsigned)i);
+                }
+            }
+        }
     }
 }
 
-void launch_fuse_update(Surfels src, Surfels dst, const FrameDev* frame, int* upd_first, const float4* cand_rec, hipStream_t s) {
-    hipLaunchKernelGGL(k_fuse_update, dim3(2048), dim3(256), 0, s, src, dst, frame, upd_first, cand_rec);
+void launch_fuse_update(Surfels src, Surfels dst, const FrameDev* frame, int* upd_first, const float4* cand_rec, const PoseDev* pose,
+                        int W, int H, Intr k, float maxDepth, int timeDelta, unsigned long long* keys_or_null, bool transposed,
+                        hipStream_t s) {
+    IndexScatterArgs ix{pose, W, H, k, maxDepth, timeDelta, keys_or_null, transposed ? 1 : 0};
+    hipLaunchKernelGGL(k_fuse_update, dim3(2048), dim3(256), 0, s, src, dst, frame, upd_first, cand_rec, ix);
 }
 
 // ------------------------------------------------------------------------------------------------
