@@ -111,6 +111,7 @@ public:
     }
     Matrix4f getCurrPose() { return getBackgroundModel().getPose(); }  // MaskFusion.h:218
     int getTick() { int32_t t = 0; check(mf_get_tick(ctx_, &t)); return t; }  // MaskFusion.h:194
+    void setTick(const int& val) { check(mf_set_tick(ctx_, val)); }            // MaskFusion.h:206
 
     // per-frame setters, MaskFusion.h:132-182
     void setDepthCutoff(const float& v) { set("depthCutoff", v); }

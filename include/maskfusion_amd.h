@@ -87,6 +87,8 @@ int mf_process_frame_dev(mf_ctx* ctx, const uint8_t* d_rgb, const float* d_depth
                          int64_t timestamp, float weight_multiplier);
 int mf_sync(mf_ctx* ctx);
 
+/* MaskFusion::setTick (Core/MaskFusion.h:206); only after the first frame (tick 1 initialises the map) */
+int mf_set_tick(mf_ctx* ctx, int32_t tick);
 /* MaskFusion::preallocateModels (Core/MaskFusion.h:57, Core/MaskFusion.cpp:144-149) */
 int mf_preallocate_models(mf_ctx* ctx, uint32_t count);
 /* MaskFusion::predict (Core/MaskFusion.h:76) */

@@ -168,6 +168,9 @@ class MaskFusion:
         self._chk(self._L.mf_get_tick(self._h, C.byref(t)))
         return t.value
 
+    def setTick(self, tick: int):
+        self._chk(self._L.mf_set_tick(self._h, int(tick)))
+
     def getBackgroundModel(self) -> Model:
         return Model(self, 0)
 

@@ -829,6 +829,20 @@ extern "C" int mf_preallocate_models(mf_ctx* c, uint32_t count) {
     return check_launch(c);
 }
 
+static __global__ void k_set_tick(FrameDev* f, int tick, FrameDev* host_mirror) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    f->tick = tick;
+    if (host_mirror) *host_mirror = *f;
+}
+// MaskFusion::setTick (Core/MaskFusion.h:206): the run loop uses it to start at / skip to a frame number
+extern "C" int mf_set_tick(mf_ctx* c, int32_t tick) {
+    if (!c || tick < 1) return MF_EINVAL;
+    if (c->host_tick == 1 && tick != 1) { c->err = "setTick before the first frame would skip the map initialisation"; return MF_ESTATE; }
+    c->host_tick = tick;
+    for (auto& m : c->models) hipLaunchKernelGGL(k_set_tick, dim3(1), dim3(64), 0, c->stream, m->d_frame, tick, m->h_frame);
+    return check_launch(c);
+}
+
 extern "C" int mf_get_tick(mf_ctx* c, int32_t* tick) {
     if (!c || !tick) return MF_EINVAL;
     *tick = c->host_tick;

@@ -47,6 +47,7 @@ SYMBOLS = {
     "mf_sync": (C.c_int, [C.c_void_p]),
     "mf_predict": (C.c_int, [C.c_void_p]),
     "mf_preallocate_models": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "mf_set_tick": (C.c_int, [C.c_void_p, C.c_int32]),
     "mf_get_tick": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "mf_num_models": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "mf_get_pose": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),

@@ -109,3 +109,22 @@ def test_cli_runs_image_directory(hip, tmp_path, capsys):
     assert np.linalg.norm(rows[-1, 1:4] - gt[:3, 3]) < 6e-3         # depth quantised to millimetres by the 16-bit PNGs (3.7 mm here)
     assert os.path.getsize(out + "cloud-0.ply") > 1000
     assert "processed 8 frames" in capsys.readouterr().out
+
+
+def test_set_tick_skips_frame_numbers(hip):
+    """MaskFusion::setTick: surfel time stamps continue from the new tick, the pipeline keeps tracking."""
+    from maskfusion_amd import MaskFusion
+    st, fr = _frames(5)
+    mf = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=100.0, so3=False, enableMultipleModels=False, numGSurfels=1 << 19)
+    with pytest.raises(Exception):
+        mf.setTick(50)                      # not before the map exists
+    mf.processFrame(fr[0][0], fr[0][1])
+    mf.processFrame(fr[1][0], fr[1][1])
+    assert mf.getTick() == 3
+    mf.setTick(50)
+    mf.processFrame(fr[2][0], fr[2][1])
+    assert mf.getTick() == 51
+    m = mf.getBackgroundModel().downloadMap()
+    assert m[:, 7].max() == 50.0 and m[:, 6].max() == 50.0    # lastTime / initTime of surfels touched / created at tick 50
+    assert np.linalg.norm(mf.getCurrPose()[:3, 3] - st.gt_pose(2)[:3, 3]) < 5e-3
+    mf.close()
