@@ -104,3 +104,32 @@ def test_pipeline_device_labels_equal_host_labels(hip):
         assert a[1] == b[1], (k, a[1], b[1])
         assert np.array_equal(a[0], b[0]), (k, int((a[0] != b[0]).sum()))
         assert np.array_equal(a[2], b[2])
+
+
+def test_device_label_stage_odd_width(hip, oracle):
+    """Width 328: a wavefront of the run detection covers the end of one row and the start of the next."""
+    from oracle import mfo_mm
+    old = (tsh.W, tsh.H)
+    tsh.W, tsh.H = 328, 248
+    try:
+        W, H = tsh.W, tsh.H
+        rng = np.random.default_rng(11)
+        binary = (rng.random((H, W)) < 0.7).astype(np.uint8) * 255
+        binary[:, -3:] = 255; binary[:, :2] = 255          # runs that touch both image borders
+        binary[60:90, 100:220] = 0
+        depth = (2.0 + 0.001 * rng.random((H, W))).astype(np.float32)
+        n, labels, stats = mfo_mm.connected_components4(binary)
+        big = [c for c in range(1, n) if stats[c][4] > 300][:60]
+        mask = np.zeros((H, W), np.uint8)
+        for k, c in enumerate(big):
+            mask[labels == c] = k + 1
+        cls = [0] + [41 + (k % 7) for k in range(len(big))]
+        proj = np.zeros((H, W), np.uint8); proj[100:200, 30:90] = 4
+        prm = mfo_mm.default_seg_params(morphMaskIterations=1, minRelSizeNew=0.002)
+        ign_o, ign_d = np.zeros((H, W), np.uint8), np.zeros((H, W), np.uint8)
+        ref = mfo_mm.mf_segmentation_cpu(W, H, binary, depth, mask, cls, proj, [0, 4], [-1, 43], 5, True, ign_o, prm)
+        got = _device_labels(hip, binary, depth, mask, cls, proj, [0, 4], [-1, 43], 5, True, prm, ign_d)
+        assert got[1] == ref[1] and got[2] == ref[2]
+        assert np.array_equal(got[0], ref[0]), f"{int((got[0] != ref[0]).sum())} pixels differ"
+    finally:
+        tsh.W, tsh.H = old

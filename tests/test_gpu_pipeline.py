@@ -149,3 +149,21 @@ def test_pipeline_1280x960(hip, oracle):
         assert abs(o.count - mf.getBackgroundModel().lastCount()) <= max(20, 0.005 * o.count), k
     assert o.count > 1_000_000
     o.close(); mf.close()
+
+
+def test_pipeline_width_not_multiple_of_64(hip, oracle):
+    """328 x 248 (multiples of 8 only): wavefronts straddle image rows in the per-pixel kernels, partial tiles everywhere."""
+    from maskfusion_amd import MaskFusion, synth
+    W, H, f = 328, 248, 270.0
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
+    fr = [st.frame(k) for k in range(6)]
+    for cfg in (dict(icpWeight=100.0, so3=0), dict(icpWeight=20.0, so3=1)):
+        o = oracle.Oracle(W, H, f, f, W / 2.0, H / 2.0, capacity=1 << 19, **cfg)
+        mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=cfg["icpWeight"], so3=bool(cfg["so3"]), enableMultipleModels=False,
+                        numGSurfels=1 << 19)
+        for k in range(6):
+            o.process_frame(fr[k][0], fr[k][1])
+            mf.processFrame(fr[k][0], fr[k][1])
+            assert np.abs(o.pose - mf.getCurrPose()).max() < 1e-4, (cfg, k)
+            assert abs(o.count - mf.getBackgroundModel().lastCount()) <= max(20, 0.005 * o.count), (cfg, k)
+        o.close(); mf.close()
