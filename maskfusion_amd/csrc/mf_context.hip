@@ -144,6 +144,7 @@ struct mf_ctx {
     So3Result* d_so3 = nullptr; char* d_so3_scratch = nullptr;
     // tiled splat prediction (mf_splat.hip)
     int* d_tile_count = nullptr; int* d_tile_entries = nullptr; int tile_entries_cap = 0; int splat_tiles = 1;
+    float4* d_splat_rec0 = nullptr; float4* d_splat_rec1 = nullptr; uint2* d_splat_bbox = nullptr;   // per-surfel sprite set-up
     const uint8_t* cur_rgb = nullptr;      // device rgb of the frame being processed (fill-in intensity at predict time)
     struct RetiredLog { int id; std::vector<int64_t> ts; std::vector<float> p; };
     std::vector<RetiredLog> retired;       // pose logs of dropped models (MaskFusion::inactiveModels, exportPoses)
@@ -346,6 +347,9 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
         // ... and never less than 16 list slots per pixel of a tile, so that small maps can still pile up in one place
         c->tile_entries_cap = (int)std::min<size_t>(std::max<size_t>(4 * maxcap, (size_t)16 * P), (size_t)1 << 30);
         A(dev_alloc(c, c->allocs, &c->d_tile_entries, (size_t)c->tile_entries_cap));
+        A(dev_alloc(c, c->allocs, &c->d_splat_rec0, maxcap));
+        A(dev_alloc(c, c->allocs, &c->d_splat_rec1, maxcap));
+        A(dev_alloc(c, c->allocs, &c->d_splat_bbox, maxcap));
     }
     A(dev_alloc(c, c->allocs, &c->d_keys, (size_t)P, 0xFF));
     A(dev_alloc(c, c->allocs, &c->d_index, (size_t)P));
@@ -547,7 +551,8 @@ static void enqueue_predict(mf_ctx* c, ModelState& m) {
     if (c->splat_tiles) {
         const bool gray = photometric_on(c);
         if (launch_splat_tiled(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, c->cfg.max_depth_processed, m.confThr,
-                               c->cfg.time_delta, c->d_tile_count, c->d_tile_entries, c->tile_entries_cap, m.d_predV, m.d_predN, m.d_predImage, m.d_predTime, c->cur_rgb,
+                               c->cfg.time_delta, c->d_tile_count, c->d_tile_entries, c->tile_entries_cap, c->d_splat_rec0, c->d_splat_rec1,
+                               c->d_splat_bbox, m.d_predV, m.d_predN, m.d_predImage, m.d_predTime, c->cur_rgb,
                                gray ? m.d_predGray : nullptr, gray ? m.d_fillGray : nullptr, c->stream) == 0)
             return;
     }

@@ -186,9 +186,9 @@ void launch_splat_resolve(Surfels src, const PoseDev* pose, unsigned long long* 
 // histograms (use the scatter form then).
 size_t splat_tiles_scratch_ints(int W, int H);
 int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
-                       int timeDelta, int* tile_count, int* entries /*[tiles][entries_cap / tiles]*/, int entries_cap, float4* predV,
-                       float4* predN, uchar4* predImage, uint16_t* predTime, const uint8_t* rgb, uint8_t* predGray, uint8_t* fillGray,
-                       hipStream_t s);
+                       int timeDelta, int* tile_count, int* entries /*[tiles][entries_cap / tiles]*/, int entries_cap,
+                       float4* rec0 /*[src.cap]*/, float4* rec1 /*[src.cap]*/, void* bbox /*[src.cap] x 8 B*/, float4* predV, float4* predN,
+                       uchar4* predImage, uint16_t* predTime, const uint8_t* rgb, uint8_t* predGray, uint8_t* fillGray, hipStream_t s);
 void launch_fill_keys(unsigned long long* keys, int n, hipStream_t s);
 void launch_fill_int(int* p, int v, int n, hipStream_t s);
 // ---------------- multi-model coupling (mf_segment.hip) ----------------

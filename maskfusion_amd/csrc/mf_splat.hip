@@ -65,6 +65,7 @@ struct BinArgs {
     int* entries;         // [tiles][tile_cap]
     int tile_cap;
     FrameDev* frame_rw;   // overflow flag (pad[1])
+    float4* rec0; float4* rec1; short4* bbox;   // [surfels] sprite set-up kept for the tile pass: {h, r^2}, {n, h.n}, pixel box
 };
 
 // Binning in one pass: every tile owns a fixed slice of `entries`, so no scan is needed.  A 1024-thread workgroup counts
@@ -96,6 +97,11 @@ __global__ __launch_bounds__(kBinThreads) void k_splat_bin(const BinArgs a) {
             SplatSetup su;
             if (splat_setup(a.src, i, time, Ri, ti, a.W, a.H, a.k, a.maxDepth, a.confThreshold, a.timeDelta, su)) {
                 bb[r] = make_short4((short)su.px0, (short)su.px1, (short)su.py0, (short)su.py1);
+                // the tile pass meets this surfel ~1.8 times (once per overlapped tile): it reads the set-up instead of
+                // repeating its ~300 instructions (ten IEEE divisions) each time
+                a.rec0[i] = make_float4(su.h.x, su.h.y, su.h.z, su.sqrRad);
+                a.rec1[i] = make_float4(su.nrm.x, su.nrm.y, su.nrm.z, su.pn);
+                a.bbox[i] = bb[r];
                 for (int ty = su.py0 / kTile; ty <= su.py1 / kTile; ++ty)
                     for (int tx = su.px0 / kTile; tx <= su.px1 / kTile; ++tx) atomicAdd(&s_cnt[ty * a.tilesX + tx], 1);
             }
@@ -124,6 +130,7 @@ struct TileArgs {
     Surfels src; FrameDev* frame; const PoseDev* pose; int W, H; Intr k; float maxDepth, confThreshold; int timeDelta;
     int tilesX, tilesY;
     int* tile_count; const int* entries; int tile_cap;
+    const float4* rec0; const float4* rec1; const short4* bbox;
     float4* predV; float4* predN; uchar4* predImage; uint16_t* predTime;
     const uint8_t* rgb; uint8_t* predGray; uint8_t* fillGray;
 };
@@ -158,8 +165,11 @@ __global__ __launch_bounds__(256) void k_splat_tile(const TileArgs a) {
     const Intr k = a.k;
     for (int e = threadIdx.x; e < cnt; e += 256) {
         const int i = list[e];
+        const float4 r0 = a.rec0[i], r1 = a.rec1[i];
+        const short4 bb = a.bbox[i];
         SplatSetup su;
-        if (!splat_setup(a.src, i, time, Ri, ti, a.W, a.H, k, a.maxDepth, a.confThreshold, a.timeDelta, su)) continue;
+        su.h = f3(r0.x, r0.y, r0.z); su.sqrRad = r0.w; su.nrm = f3(r1.x, r1.y, r1.z); su.pn = r1.w;
+        su.px0 = bb.x; su.px1 = bb.y; su.py0 = bb.z; su.py1 = bb.w;
         const int x0 = max(su.px0, tx0), x1 = min(su.px1, tx0 + kTile - 1);
         const int y0 = max(su.py0, ty0), y1 = min(su.py1, ty0 + kTile - 1);
         for (int py = y0; py <= y1; ++py) {
@@ -216,20 +226,21 @@ __global__ __launch_bounds__(256) void k_splat_tile(const TileArgs a) {
 size_t splat_tiles_scratch_ints(int W, int H) { return (size_t)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile); }
 
 int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
-                       int timeDelta, int* tile_count, int* entries, int entries_cap, float4* predV, float4* predN, uchar4* predImage,
-                       uint16_t* predTime, const uint8_t* rgb, uint8_t* predGray, uint8_t* fillGray, hipStream_t s) {
+                       int timeDelta, int* tile_count, int* entries, int entries_cap, float4* rec0, float4* rec1, void* bbox, float4* predV,
+                       float4* predN, uchar4* predImage, uint16_t* predTime, const uint8_t* rgb, uint8_t* predGray, uint8_t* fillGray, hipStream_t s) {
     const int tilesX = (W + kTile - 1) / kTile, tilesY = (H + kTile - 1) / kTile, nt = tilesX * tilesY;
     if (nt > kMaxTiles) return -1;
     BinArgs b;
     b.src = src; b.frame = frame; b.pose = pose; b.W = W; b.H = H; b.k = k; b.maxDepth = maxDepth; b.confThreshold = confThreshold;
     b.timeDelta = timeDelta; b.tilesX = tilesX; b.tilesY = tilesY; b.tile_count = tile_count;
     b.entries = entries; b.tile_cap = entries_cap / nt; b.frame_rw = frame;
+    b.rec0 = rec0; b.rec1 = rec1; b.bbox = reinterpret_cast<short4*>(bbox);
     const int nblocks = min(256, (src.cap + 2 * kBinThreads - 1) / (2 * kBinThreads));
     hipLaunchKernelGGL(k_splat_bin, dim3(nblocks), dim3(kBinThreads), (size_t)2 * nt * sizeof(int), s, b);
     TileArgs t;
     t.src = src; t.frame = frame; t.pose = pose; t.W = W; t.H = H; t.k = k; t.maxDepth = maxDepth; t.confThreshold = confThreshold;
     t.timeDelta = timeDelta; t.tilesX = tilesX; t.tilesY = tilesY; t.tile_count = tile_count;
-    t.entries = entries; t.tile_cap = b.tile_cap;
+    t.entries = entries; t.tile_cap = b.tile_cap; t.rec0 = rec0; t.rec1 = rec1; t.bbox = reinterpret_cast<const short4*>(bbox);
     t.predV = predV; t.predN = predN; t.predImage = predImage; t.predTime = predTime; t.rgb = rgb; t.predGray = predGray;
     t.fillGray = fillGray;
     hipLaunchKernelGGL(k_splat_tile, dim3(nt), dim3(256), 0, s, t);
