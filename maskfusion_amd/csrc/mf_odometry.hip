@@ -406,11 +406,14 @@ __host__ __device__ inline int icp_chunk(int P, int nblocks) {
     return ((c + 63) / 64) * 64;
 }
 
-__global__ __launch_bounds__(kIcpThreads) void k_icp_iter(const IcpKArgs a) {
+// kT: threads per workgroup (512 at level 0; 256 at the coarse levels, where there are fewer 512-pixel chunks than CUs:
+// twice the workgroups, half the wavefronts per CU -> half the per-CU halving-reduction time)
+template <int kT>
+__global__ __launch_bounds__(kT) void k_icp_iter(const IcpKArgs a) {
     __shared__ double s_seg[32 * 32];
     __shared__ double s_sys[32];
     __shared__ float s_pose[24];  // Rcurr[9] tcurr[3] Rprev_inv[9] tprev[3]
-    __shared__ float s_part[(kIcpThreads / 64) * kIcpSlots];
+    __shared__ float s_part[(kT / 64) * kIcpSlots];
     __shared__ GNState s_st;
 
     const int tid = threadIdx.x;
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp_iter(const IcpKArgs a) {
     const int P = a.W * a.H;
     // A workgroup owns a contiguous chunk of <= kIcpPx * kIcpThreads pixels (icp_grid_blocks keeps the grid <= one workgroup
     // per CU so that a launch is ONE round of workgroups: 300 workgroups of 1024 px on 256 CUs ran as two rounds and
-    // doubled the level-0 launch time).  Thread t handles pixels beg + t + q * kIcpThreads, q < kIcpPx.
+    // doubled the level-0 launch time).  Thread t handles pixels beg + t + q * kT, q < kIcpPx.
     const int chunk = icp_chunk(P, gridDim.x);
     const int beg = blockIdx.x * chunk, end = min(P, beg + chunk);
 
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp_iter(const IcpKArgs a) {
     float vx[kIcpPx], vy[kIcpPx], vz[kIcpPx], nx[kIcpPx], ny[kIcpPx], nz[kIcpPx];
 #pragma unroll
     for (int q = 0; q < kIcpPx; ++q) {
-        idx[q] = beg + q * kIcpThreads + tid;
+        idx[q] = beg + q * kT + tid;
         act[q] = idx[q] < end;
         vx[q] = vy[q] = vz[q] = nx[q] = ny[q] = nz[q] = 0.f;
         if (act[q]) {
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp_iter(const IcpKArgs a) {
         float s = 0.f;
         if (tid < 29) {
 #pragma unroll
-            for (int w = 0; w < kIcpThreads / 64; ++w) s += s_part[w * kIcpSlots + tid];
+            for (int w = 0; w < kT / 64; ++w) s += s_part[w * kIcpSlots + tid];
         }
         a.partials_out[blockIdx.x * kIcpSlots + tid] = s;
     }
@@ -530,12 +533,16 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp_iter(const IcpKArgs a) {
     }
 }
 
+// threads per workgroup of the ICP-only kernel for an image of P pixels
+static int icp_threads_for(int P) { return ((P + kIcpThreads - 1) / kIcpThreads < kIcpMaxBlocks) ? 256 : kIcpThreads; }
+
 int icp_grid_blocks(int W, int H) {
     const int P = W * H;
-    int nb = (P + kIcpThreads - 1) / kIcpThreads;
+    const int T = icp_threads_for(P);
+    int nb = (P + T - 1) / T;
     if (nb > kIcpMaxBlocks) {
         nb = kIcpMaxBlocks;
-        while (icp_chunk(P, nb) > kIcpPx * kIcpThreads) ++nb;  // larger images: more than one round of workgroups
+        while (icp_chunk(P, nb) > kIcpPx * T) ++nb;  // larger images: more than one round of workgroups
     }
     return nb;
 }
@@ -547,7 +554,8 @@ void launch_icp_iteration(const IcpLaunch& l, hipStream_t s) {
     a.partials_in = l.partials_in; a.nb_in = l.nblocks_in; a.partials_out = l.partials_out;
     a.st_in = l.state_in; a.st_out = l.state_out; a.log_out = l.log_out; a.prof_out = l.prof_out; a.pose_in = l.pose_in;
     a.so3_in = l.so3_in;
-    hipLaunchKernelGGL(k_icp_iter, dim3(icp_grid_blocks(l.W, l.H)), dim3(kIcpThreads), 0, s, a);
+    if (icp_threads_for(l.W * l.H) == 256) hipLaunchKernelGGL(k_icp_iter<256>, dim3(icp_grid_blocks(l.W, l.H)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_icp_iter<kIcpThreads>, dim3(icp_grid_blocks(l.W, l.H)), dim3(kIcpThreads), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
