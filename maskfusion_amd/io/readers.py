@@ -183,11 +183,16 @@ class ImageLogReader:
             if not os.path.exists(p):
                 raise FileNotFoundError(f"Could not find {what}-image file: {p}")
         rgb = np.asarray(Image.open(cpath).convert("RGB"), np.uint8)   # imread (BGR) + flipColors() == RGB
+        d = dimg = None
         if self.dext == ".exr":
-            raise ValueError("OpenEXR depth needs an EXR decoder; convert to 16-bit PNG (millimetres)")
-        dimg = Image.open(dpath)
-        d = np.asarray(dimg)
-        if d.dtype == np.uint16 or d.dtype == np.int32 or dimg.mode in ("I;16", "I"):
+            from .exr import read_exr_depth
+            depth = read_exr_depth(dpath)        # CV_32FC1, or channel 0 (blue) of CV_32FC3: ImageLogReader.cpp:250-260
+        else:
+            dimg = Image.open(dpath)
+            d = np.asarray(dimg)
+        if d is None:
+            pass
+        elif d.dtype == np.uint16 or d.dtype == np.int32 or dimg.mode in ("I;16", "I"):
             depth = d.astype(np.float32) * np.float32(0.001)            # CV_16UC1 branch, ImageLogReader.cpp:262-268
         elif d.dtype == np.float32:
             depth = d if d.ndim == 2 else d[..., 0]

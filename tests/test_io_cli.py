@@ -101,3 +101,37 @@ def test_cli_flags_and_defaults():
         cli.parse(["-bogus"])
     with pytest.raises(SystemExit):
         cli.parse(["-l"])
+
+
+@pytest.mark.parametrize("compression", [0, 2, 3])
+@pytest.mark.parametrize("half", [False, True])
+def test_exr_round_trip(tmp_path, compression, half):
+    from maskfusion_amd.io import read_exr, read_exr_depth, write_exr
+    rng = np.random.default_rng(3)
+    d = rng.uniform(0.3, 5, (37, 53)).astype(np.float32)      # odd sizes: the last ZIP chunk is short
+    p = str(tmp_path / "d.exr")
+    write_exr(p, {"Z": d}, compression, half)
+    tol = 4e-3 if half else 0.0
+    assert np.abs(read_exr_depth(p) - d).max() <= tol
+    write_exr(p, {"R": d, "G": 2 * d, "B": 3 * d}, compression, half)
+    ch = read_exr(p)
+    assert sorted(ch) == ["B", "G", "R"] and np.abs(ch["G"] - 2 * d).max() <= 2 * tol
+    assert np.abs(read_exr_depth(p) - 3 * d).max() <= 3 * tol     # blue = OpenCV channel 0 (ImageLogReader.cpp:252-256)
+    with pytest.raises(ValueError):
+        open(p, "wb").write(b"not an exr file")
+        read_exr(p)
+
+
+def test_image_directory_with_exr_depth(tmp_path):
+    from PIL import Image
+    from maskfusion_amd.io import write_exr
+    fr = _frames(3)
+    d = str(tmp_path / "seq") + os.sep
+    os.makedirs(d)
+    for i, (_, rgb, depth) in enumerate(fr):
+        Image.fromarray(rgb, "RGB").save(f"{d}Color{i:04d}.png")
+        write_exr(f"{d}Depth{i:04d}.exr", {"R": depth, "G": depth, "B": depth})
+    r = ImageLogReader(d)
+    assert r.dext == ".exr"
+    out = list(r)
+    assert len(out) == 3 and np.array_equal(out[1].depth, fr[1][2]) and np.array_equal(out[1].rgb, fr[1][1])
