@@ -102,3 +102,41 @@ def max_over_ranks(value: float, device: torch.device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ------------------------------------------------------------------------------------------------
+# Multi-model scenes sharded by model (SURVEY.md 8e couplings 2 and 3): the z-merged model-id image and the label image.
+# The library's projection keys are uint64 (float_bits(z) << 32 | order << 8 | id) with z > 0, i.e. always below 2^63, and
+# 0xFFFF...F for "empty"; as int64 the empty key would be -1 and win every MIN, so it is mapped to INT64_MAX for the wire.
+# ------------------------------------------------------------------------------------------------
+EMPTY_KEY_U64 = 0xFFFFFFFFFFFFFFFF
+INT64_MAX = 0x7FFFFFFFFFFFFFFF
+
+
+def keys_to_wire(keys_u64: torch.Tensor) -> torch.Tensor:
+    """uint64 projection keys (viewed as int64 by torch) -> int64 values whose MIN is the nearest surface."""
+    k = keys_u64.view(torch.int64)
+    return torch.where(k < 0, torch.full_like(k, INT64_MAX), k)
+
+
+def merge_projection_keys(keys_wire: torch.Tensor) -> torch.Tensor:
+    """GlobalProjection across ranks: every rank scatters ITS models into a private key image; one all-reduce(MIN) of
+    8 B x P (2.46 MB at VGA: ~28 us of ring time over xGMI) gives every rank the z-merged image."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(keys_wire, op=dist.ReduceOp.MIN)
+    return keys_wire
+
+
+def ids_from_keys(keys_wire: torch.Tensor) -> torch.Tensor:
+    """model id per pixel (0 where nothing projects), as k_global_resolve does on one GPU."""
+    ids = (keys_wire & 0xFF).to(torch.uint8)
+    return torch.where(keys_wire == INT64_MAX, torch.zeros_like(ids), ids)
+
+
+def broadcast_labels(labels_u8: torch.Tensor, bg_pose16: torch.Tensor, src: int = 0):
+    """Rank `src` (background model + label stage) publishes the label image (P bytes) and the camera pose (64 B): static
+    objects follow it (Model.h:263), every rank fuses / cleans its models against the labels."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(labels_u8, src)
+        dist.broadcast(bg_pose16, src)
+    return labels_u8, bg_pose16

@@ -86,3 +86,39 @@ def test_single_process_path():
     out = mfd.run_steps(frame, step, 3, 4, 8, dev)
     assert seen == [(0, 0.0), (1, 1.0), (2, 2.0)]
     assert float(out[0][0]) == 2.0
+
+
+def _merge_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from maskfusion_amd import dist as mfd
+    Hh, Ww = 24, 32
+    rng = np.random.default_rng(100 + rank)
+    # every rank projects ITS model: depth image with holes, model id = rank + 1, order = rank
+    z = rng.uniform(0.5, 4.0, (Hh, Ww)).astype(np.float32)
+    hole = rng.random((Hh, Ww)) < 0.3
+    key = (z.view(np.uint32).astype(np.uint64) << np.uint64(32)) | np.uint64((rank << 8) | (rank + 1))
+    key[hole] = np.uint64(mfd.EMPTY_KEY_U64)
+    wire = mfd.keys_to_wire(torch.from_numpy(key.view(np.int64).copy()))
+    merged = mfd.merge_projection_keys(wire)
+    ids = mfd.ids_from_keys(merged).numpy()
+    labels = torch.from_numpy((ids * 3).astype(np.uint8)) if rank == 0 else torch.zeros((Hh, Ww), dtype=torch.uint8)
+    pose = torch.arange(16, dtype=torch.float32) if rank == 0 else torch.zeros(16)
+    labels, pose = mfd.broadcast_labels(labels, pose, 0)
+    np.savez(os.path.join(out_dir, f"merge{rank}.npz"), z=z, hole=hole, ids=ids, labels=labels.numpy(), pose=pose.numpy())
+    dist.destroy_process_group()
+
+
+def test_projection_merge_and_label_broadcast_world2(tmp_path):
+    """SURVEY.md 8e couplings 2 + 3 on two ranks: all-reduce(MIN) of the packed z/id keys == the nearest model per pixel,
+    the label image and the camera pose reach every rank."""
+    mp.spawn(_merge_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "merge0.npz"), np.load(tmp_path / "merge1.npz")
+    assert np.array_equal(a["ids"], b["ids"]) and np.array_equal(a["labels"], b["labels"]) and np.array_equal(a["pose"], b["pose"])
+    z0 = np.where(a["hole"], np.inf, a["z"]); z1 = np.where(b["hole"], np.inf, b["z"])
+    expect = np.where(np.isinf(z0) & np.isinf(z1), 0, np.where(z0 <= z1, 1, 2)).astype(np.uint8)
+    assert np.array_equal(a["ids"], expect)
+    assert np.array_equal(a["labels"], expect * 3) and a["pose"].tolist() == list(range(16))
