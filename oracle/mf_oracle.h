@@ -5,11 +5,17 @@
  * link or call this.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
  * leg use it, and only as the checker / the timed CPU baseline.
  *
- * PARITY UNPINNED: the reference (martinruenz/maskfusion) ships no tests, golden vectors
- * or fixtures for this path and cannot be built here (CUDA + OpenGL 4.3 + Pangolin +
- * OpenCV + Eigen).  Every function below therefore follows the cited reference source
- * line by line, and is pinned by analytic known-answer tests (tests/test_oracle_kat.py)
- * rather than by reference outputs.  Citations are relative to /root/reference/.
+ * PARITY PIN: the reference (martinruenz/maskfusion) ships no tests, golden vectors or fixtures for this path and its
+ * build (CUDA + OpenGL 4.3 + Pangolin + OpenCV + Eigen) cannot run here.  Two halves:
+ *   - everything restated from Core/Cuda/{reduce,cudafuncs,segmentation}.cu (rows a3-a5, a7-a10, a12 and the device half
+ *     of a20 in SURVEY.md section 8) IS pinned: oracle/build_ref.py compiles those translation units for the CPU
+ *     (oracle/_ref/libmf_ref.so), tests/golden/ref_vectors.npz holds their outputs on seeded inputs, and
+ *     tests/test_ref_pin.py requires this file to reproduce them (bit-exact for integer / per-pixel float results,
+ *     1e-5 for reduced sums whose summation order is a launch-shape detail);
+ *   - everything restated from GLSL shaders, the OpenGL rasteriser, Eigen and OpenCV (a2, a6, a11, a13-a19, a21 and the
+ *     host half of a20) is PARITY UNPINNED: it follows the cited source line by line and is pinned only by analytic
+ *     known-answer tests (tests/test_oracle_kat.py, tests/test_oracle_rgbd_kat.py).
+ * Citations are relative to /root/reference/.
  *
  * Conventions
  *   - images: dense row-major, no pitch.  vmap/nmap: planar [3][H][W] float (x,y,z planes),
