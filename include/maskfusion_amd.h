@@ -168,9 +168,65 @@ void* mf_get_input_stream(mf_ctx* ctx);
 /* debug / differential-test taps: copy a device-resident intermediate of the last frame to host.
  * what: "depthF" (H*W f32), "vmap0".."vmap2", "nmap0".."nmap2" (3*h*w f32, current frame),
  *       "vmap_g0".."vmap_g2", "nmap_g0".."nmap_g2" (model side), "pred_vertex", "pred_normal" (H*W*4 f32),
- *       "pred_image" (H*W*4 u8), "index" (H*W i32), "icp_log" (19*32 f32: per-iteration A-upper/b/res/inl),
- *       "edge_map" (H*W f32), "edge_binary" (H*W u8), "projected_ids" (H*W u8). */
+ *       "pred_image" (H*W*4 u8), "pred_time" (H*W u16), "icp_log" (19*32 f32: per-iteration A-upper/b/res/inl),
+ *       "edge_map" (H*W f32), "edge_binary" (H*W u8), "projected_ids" (H*W u8);
+ *       index map of the last (pre-fusion) index pass, index_map.frag's attachments: "index" (H*W i32), "index_vc", "index_nr",
+ *       "index_ct" (H*W*4 f32), "index_packed" (post-fusion pass: 2 float4 per texel, column-major texel order);
+ *       Model::fuse / clean intermediates (variable length: as many bytes as asked for, at most the buffer): "cand_op" (u8 per
+ *       quarter-rate pixel in column-major order: 0 none, 1 merge, 2 new), "cand_rec" (3 float4 per candidate), "clean_flags"
+ *       (u8 keep flag per old surfel, then per candidate), "clean_newconf" (f32, same indexing). */
 int mf_debug_read(mf_ctx* ctx, const char* what, void* out, uint64_t out_bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * Model-level entry points: the public operations of Model (Core/Model/Model.h:126-162,233-268), one call each, on a
+ * frame staged with mf_stage_frame.  MaskFusion::processFrame is a fixed composition of them (mf_process_frame enqueues the
+ * same kernels); they let a caller drive a model the way the reference's callers do, and let every surfel pass be compared
+ * with the oracle in isolation.  `model` is the index in the model list (as in mf_get_pose).  All calls are asynchronous on
+ * the context's stream except where noted.  The index map, the association candidates and the new-surfel records are
+ * scratch shared by all models: predictIndices -> fuse -> [predictIndices] -> clean of ONE model must not be interleaved
+ * with another model's (the reference keeps those buffers per model, ModelProjection / Model::newUnstableBuffer).
+ * ---------------------------------------------------------------------------------------------- */
+/* Everything of processFrame that touches no model: upload, MaskFusion::filterDepth (Core/MaskFusion.cpp:217,650-657),
+ * Model::generateCUDATextures (Core/Model/Model.h:128, Model.cpp:350-389), the intensity pyramid / derivative images
+ * (RGBDOdometry::initRGB).  mask = model id per pixel as textureMask holds it for fuse / clean (Core/MaskFusion.cpp:297);
+ * NULL = all background.  Host pointers; synchronous. */
+int mf_stage_frame(mf_ctx* ctx, const uint8_t* rgb, const float* depth, const uint8_t* mask);
+/* The tail of processFrame (Core/MaskFusion.cpp:569-602) for a frame driven through the calls below: tick++, the
+ * requiresFillIn decision for the next tracking step, the pose-log entry with `timestamp`, age++ */
+int mf_end_frame(mf_ctx* ctx, int64_t timestamp);
+/* Model::initialise (Core/Model/Model.h:126, Model.cpp:240-285) from the staged frame */
+int mf_model_initialise(mf_ctx* ctx, int32_t model);
+/* Model::overridePose (Core/Model/Model.h:235-238): lastPose = pose; pose = pose16 */
+int mf_model_override_pose(mf_ctx* ctx, int32_t model, const float* pose16);
+/* Model::computeFusionWeight(weightMultiplier) (Core/Model/Model.cpp:449-464) of the model's pose / lastPose.  Synchronous. */
+int mf_model_fusion_weight(mf_ctx* ctx, int32_t model, float weight_multiplier, float* out);
+/* Model::performTracking (Core/Model/Model.h:135-136, Model.cpp:427-447); frame_to_frame_rgb must be 0 (never enabled
+ * upstream, Core/MaskFusion.cpp:248); the rgb texture is the staged frame's */
+int mf_model_perform_tracking(mf_ctx* ctx, int32_t model, int32_t frame_to_frame_rgb, int32_t rgb_only, float icp_weight,
+                              int32_t pyramid, int32_t fast_odom, int32_t so3, float max_depth_processed, int64_t log_timestamp,
+                              int32_t try_fill_in);
+/* Model::predictIndices(time, maxDepth, timeDelta) (Core/Model/Model.h:162, ModelProjection.cpp:100-152) */
+int mf_model_predict_indices(mf_ctx* ctx, int32_t model, int32_t time, float max_depth, int32_t time_delta);
+/* Model::fuse(time, rgb, mask, depthRaw, depthFiltered, depthCutoff, weightMultiplier) (Core/Model/Model.h:142-143,
+ * Model.cpp:466-647); the four textures are the staged frame's */
+int mf_model_fuse(mf_ctx* ctx, int32_t model, int32_t time, float depth_cutoff, float weight_multiplier);
+/* Model::clean(time, graph, timeDelta, depthCutoff, isFern, depthFiltered, mask) (Core/Model/Model.h:146-147,
+ * Model.cpp:649-772); no deformation graph, isFern = false (loop closure is dead code upstream) */
+int mf_model_clean(mf_ctx* ctx, int32_t model, int32_t time, int32_t time_delta, float depth_cutoff);
+/* Model::combinedPredict(maxDepth, time, maxTime, timeDelta, ACTIVE) (Core/Model/Model.h:158, ModelProjection.cpp:187-268);
+ * time must equal max_time (the only form the reference calls, Core/MaskFusion.cpp:616-628) */
+int mf_model_combined_predict(mf_ctx* ctx, int32_t model, float max_depth, int32_t time, int32_t max_time, int32_t time_delta);
+/* No upstream twin (tests, tooling): replace the surfel buffer of `model` with `count` records in mf_download_map's layout.
+ * Host pointer; synchronous. */
+int mf_model_upload_map(mf_ctx* ctx, int32_t model, const float* surfels12, uint32_t count);
+/* Model::makeNonStatic / makeStatic(globalPose) (Core/Model/Model.h:263-266): a non-static object model is tracked even with
+ * trackAllModels off (Core/MaskFusion.cpp:263); makeStatic re-anchors it to the background's current pose */
+int mf_make_nonstatic(mf_ctx* ctx, int32_t model);
+int mf_make_static(mf_ctx* ctx, int32_t model);
+/* MaskFusion::setTrackableClassIds (Core/MaskFusion.h:246, MaskFusion.cpp:261,940); n = 0: every class is trackable */
+int mf_set_trackable_class_ids(mf_ctx* ctx, const int32_t* ids, int32_t n);
+/* mf_debug_read for the per-model taps ("pred_vertex", "pred_normal", "pred_image", "pred_time") of model `model` */
+int mf_debug_read_model(mf_ctx* ctx, int32_t model, const char* what, void* out, uint64_t out_bytes);
 
 /* ------------------------------------------------------------------------------------------------
  * Kernel-level entry points (device pointers, launched on `stream`, asynchronous).  Each replaces one reference

@@ -56,6 +56,53 @@ class Model:
         self._o._chk(self._o._L.mf_get_icp_stats(self._o._h, self._i, C.byref(e), C.byref(c)))
         return e.value, c.value
 
+    # -- the per-model operations of Core/Model/Model.h:126-162,233-268, on the frame staged with MaskFusion.stageFrame ----
+    def initialise(self):
+        self._o._chk(self._o._L.mf_model_initialise(self._o._h, self._i))
+
+    def overridePose(self, pose):
+        p = np.ascontiguousarray(np.asarray(pose, np.float32).T.reshape(16))
+        self._o._chk(self._o._L.mf_model_override_pose(self._o._h, self._i, p.ctypes.data))
+
+    def computeFusionWeight(self, weightMultiplier: float = 1.0) -> float:
+        out = C.c_float(0)
+        self._o._chk(self._o._L.mf_model_fusion_weight(self._o._h, self._i, weightMultiplier, C.byref(out)))
+        return out.value
+
+    def performTracking(self, frameToFrameRGB=False, rgbOnly=False, icpWeight=10.0, pyramid=True, fastOdom=False, so3=True,
+                        maxDepthProcessed=20.0, logTimestamp=0, tryFillIn=False):
+        self._o._chk(self._o._L.mf_model_perform_tracking(self._o._h, self._i, int(frameToFrameRGB), int(rgbOnly), icpWeight,
+                                                          int(pyramid), int(fastOdom), int(so3), maxDepthProcessed, logTimestamp,
+                                                          int(tryFillIn)))
+
+    def predictIndices(self, time: int, maxDepth: float, timeDelta: int):
+        self._o._chk(self._o._L.mf_model_predict_indices(self._o._h, self._i, time, maxDepth, timeDelta))
+
+    def fuse(self, time: int, depthCutoff: float, weightMultiplier: float = 1.0):
+        self._o._chk(self._o._L.mf_model_fuse(self._o._h, self._i, time, depthCutoff, weightMultiplier))
+
+    def clean(self, time: int, timeDelta: int, depthCutoff: float):
+        self._o._chk(self._o._L.mf_model_clean(self._o._h, self._i, time, timeDelta, depthCutoff))
+
+    def combinedPredict(self, maxDepth: float, time: int, maxTime: int, timeDelta: int):
+        self._o._chk(self._o._L.mf_model_combined_predict(self._o._h, self._i, maxDepth, time, maxTime, timeDelta))
+
+    def uploadMap(self, surfels: np.ndarray):
+        s = np.ascontiguousarray(surfels, np.float32).reshape(-1, 12)
+        self._o._chk(self._o._L.mf_model_upload_map(self._o._h, self._i, s.ctypes.data, len(s)))
+
+    def makeNonStatic(self):
+        self._o._chk(self._o._L.mf_make_nonstatic(self._o._h, self._i))
+
+    def makeStatic(self):
+        self._o._chk(self._o._L.mf_make_static(self._o._h, self._i))
+
+    def isNonstatic(self) -> bool:
+        return not bool(self.info().is_static)
+
+    def debugRead(self, what: str) -> np.ndarray:
+        return self._o.debugRead(what, model=self._i)
+
 
 class MaskFusion:
     """MaskFusion facade (constructor arguments: Core/MaskFusion.h:47-53; Resolution/Intrinsics are explicit)."""
@@ -139,6 +186,20 @@ class MaskFusion:
     def sync(self):
         self._chk(self._L.mf_sync(self._h))
 
+    def stageFrame(self, rgb: np.ndarray, depth: np.ndarray, mask: np.ndarray | None = None):
+        """upload + filterDepth + Model::generateCUDATextures + intensity pyramid: what processFrame does before it touches a model"""
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        depth = np.ascontiguousarray(depth, np.float32)
+        m = np.ascontiguousarray(mask, np.uint8) if mask is not None else None
+        self._chk(self._L.mf_stage_frame(self._h, rgb.ctypes.data, depth.ctypes.data, m.ctypes.data if m is not None else None))
+
+    def endFrame(self, timestamp: int = 0):
+        self._chk(self._L.mf_end_frame(self._h, timestamp))
+
+    def setTrackableClassIds(self, ids):
+        a = np.ascontiguousarray(list(ids), np.int32)
+        self._chk(self._L.mf_set_trackable_class_ids(self._h, a.ctypes.data if len(a) else None, len(a)))
+
     def predict(self):
         self._chk(self._L.mf_predict(self._h))
 
@@ -197,6 +258,11 @@ class MaskFusion:
     def setParam(self, key: str, value: float):
         self._chk(self._L.mf_set_param(self._h, key.encode(), float(value)))
 
+    def getParam(self, key: str) -> float:
+        v = C.c_double(0)
+        self._chk(self._L.mf_get_param(self._h, key.encode(), C.byref(v)))
+        return v.value
+
     def setDepthCutoff(self, v): self.setParam("depthCutoff", v)
     def setIcpWeight(self, v): self.setParam("icpWeight", v)
     def setConfidenceThreshold(self, v): self.setParam("confidenceThreshold", v)
@@ -231,17 +297,22 @@ class MaskFusion:
         return int(self._L.mf_get_input_stream(self._h) or 0)
 
     # -- differential-test taps ----------------------------------------------------------------------
-    def debugRead(self, what: str) -> np.ndarray:
+    def debugRead(self, what: str, model: int = 0, count: int | None = None) -> np.ndarray:
+        """count: number of records for the variable-length taps (cand_op, cand_rec, clean_flags, clean_newconf)"""
         W, H = self.width, self.height
         shapes = {"depthF": ((H, W), np.float32), "pred_vertex": ((H, W, 4), np.float32),
-                  "pred_normal": ((H, W, 4), np.float32), "pred_image": ((H, W, 4), np.uint8),
-                  "index": ((H, W), np.int32), "index_vc": ((H, W, 4), np.float32), "icp_log": ((19, 32), np.float32),
+                  "pred_normal": ((H, W, 4), np.float32), "pred_image": ((H, W, 4), np.uint8), "pred_time": ((H, W), np.uint16),
+                  "index": ((H, W), np.int32), "index_vc": ((H, W, 4), np.float32), "index_nr": ((H, W, 4), np.float32),
+                  "index_ct": ((H, W, 4), np.float32), "index_packed": ((W, H, 2, 4), np.float32), "icp_log": ((19, 32), np.float32),
                   "icp_prof": ((19, 8), np.uint64), "edge_map": ((H, W), np.float32),
                   "edge_binary": ((H, W), np.uint8), "projected_ids": ((H, W), np.uint8)}
+        if count is not None:
+            shapes.update({"cand_op": ((count,), np.uint8), "cand_rec": ((count, 12), np.float32),
+                           "clean_flags": ((count,), np.uint8), "clean_newconf": ((count,), np.float32)})
         for pre in ("vmap_g", "nmap_g", "vmap", "nmap"):
             for i in range(3):
                 shapes[f"{pre}{i}"] = ((3, H >> i, W >> i), np.float32)
         shape, dt = shapes[what]
         out = np.zeros(shape, dt)
-        self._chk(self._L.mf_debug_read(self._h, what.encode(), out.ctypes.data, out.nbytes))
+        self._chk(self._L.mf_debug_read_model(self._h, model, what.encode(), out.ctypes.data, out.nbytes))
         return out

@@ -143,9 +143,12 @@ struct mf_ctx {
     RgbCorr* d_corres = nullptr; float* d_rgb_partials[2] = {nullptr, nullptr}; int2* d_cnt[2] = {nullptr, nullptr};
     So3Result* d_so3 = nullptr; char* d_so3_scratch = nullptr;
     // tiled splat prediction (mf_splat.hip)
-    int* d_tile_count = nullptr; int* d_tile_entries = nullptr; int tile_entries_cap = 0; int splat_tiles = 1;
+    int* d_tile_count = nullptr; int* d_tile_entries = nullptr; int tile_entries_cap = 0; int tile_entries_alloc = 0; int splat_tiles = 1;
     float4* d_splat_rec0 = nullptr; float4* d_splat_rec1 = nullptr; uint2* d_splat_bbox = nullptr;   // per-surfel sprite set-up
     const uint8_t* cur_rgb = nullptr;      // device rgb of the frame being processed (fill-in intensity at predict time)
+    const float* cur_depth = nullptr;      // device raw depth of the frame being processed / staged (Model-level entry points)
+    int model_api_packed = 0;              // mf_model_predict_indices also builds the packed column-major map clean() uses in-frame
+    std::vector<int> trackable;            // MaskFusion::trackableClassIds (empty: every class is trackable)
     struct RetiredLog { int id; std::vector<int64_t> ts; std::vector<float> p; };
     std::vector<RetiredLog> retired;       // pose logs of dropped models (MaskFusion::inactiveModels, exportPoses)
     std::vector<std::unique_ptr<ModelState>> pool;   // MaskFusion::preallocatedModels (buffers allocated ahead of the spawn)
@@ -346,6 +349,7 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
         // room for every surfel of a full map to land in a quarter of the image (an overflow is an error, never a drop)
         // ... and never less than 16 list slots per pixel of a tile, so that small maps can still pile up in one place
         c->tile_entries_cap = (int)std::min<size_t>(std::max<size_t>(4 * maxcap, (size_t)16 * P), (size_t)1 << 30);
+        c->tile_entries_alloc = c->tile_entries_cap;
         A(dev_alloc(c, c->allocs, &c->d_tile_entries, (size_t)c->tile_entries_cap));
         A(dev_alloc(c, c->allocs, &c->d_splat_rec0, maxcap));
         A(dev_alloc(c, c->allocs, &c->d_splat_rec1, maxcap));
@@ -432,9 +436,9 @@ static bool photometric_on(const mf_ctx* c) { return c->cfg.rgb_only != 0 || c->
 
 // Model::performTracking (Core/Model/Model.cpp:427-447): initICP (model pyramid + fill-in, RGB pyramids), the optional
 // SO(3) pre-alignment, then the Gauss-Newton loop (ICP only: one launch per iteration; with the photometric term: two).
-static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, float jump_limit) {
+static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, float jump_limit, long frame_k) {
     const mf_config& g = c->cfg;
-    const int set = (int)(c->frame_no & 1);
+    const int set = (int)(frame_k & 1);
     float* const* cur_vmap = c->d_vmap[set];
     float* const* cur_nmap = c->d_nmap[set];
     const int W = c->W, H = c->H;
@@ -444,7 +448,7 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
     const bool rgb = photometric_on(c);
     const bool icp = !g.rgb_only && g.icp_weight > 0.f;
     // the previous frame's intensity pyramid is RGBDOdometry::lastNextImage (identical for every tracked model)
-    const bool so3 = g.so3 != 0 && c->gray_frame[set ^ 1] == c->frame_no - 1 && c->gray_frame[set] == c->frame_no;
+    const bool so3 = g.so3 != 0 && c->gray_frame[set ^ 1] == frame_k - 1 && c->gray_frame[set] == frame_k;
     if (so3)
         (void)launch_so3_prealign(c->d_gray[set ^ 1][2], c->d_gray[set][2], W >> 2, H >> 2, Intr{g.fx / 4, g.fy / 4, g.cx / 4, g.cy / 4},
                                   c->d_so3, c->d_so3_scratch, s);
@@ -581,6 +585,45 @@ static int take_next_model_id(mf_ctx* c) {
     return next;
 }
 
+// filterDepth (Core/MaskFusion.cpp:217) + Model::generateCUDATextures (Model.cpp:350-389) + the frame's intensity pyramid and
+// derivative images, for frame index k (buffer set k & 1, filtered-depth ring slot k % 3).
+// With overlapPreprocessing it runs on its own stream and starts when frame k-1 has finished TRACKING: frame k-2 (the last
+// user of this buffer set and of depthF[k % 3]) is then complete, and the filter overlaps the atomic-/latency-bound fusion
+// kernels of frame k-1 rather than its Gauss-Newton launches, which need a whole CU per workgroup and stall behind resident
+// filter waves.
+static int enqueue_preprocess(mf_ctx* c, const uint8_t* d_rgb, const float* d_depth, long k) {
+    const int W = c->W, H = c->H, P = c->P;
+    hipStream_t s = c->stream;
+    const mf_config& g = c->cfg;
+    const int set = (int)(k & 1);
+    float* depthF = c->d_depthF[k % 3];
+    hipStream_t sp = c->overlap ? c->stream_pre : s;
+    if (c->overlap) MF_HIP(c, hipStreamWaitEvent(sp, c->ev_main_done[set ^ 1], 0));
+    mark(c, 0, sp);
+    launch_bilateral(d_depth, depthF, W, H, sp);
+    if (c->host_tick > 1) {
+        launch_frame_pyramid(depthF, c->d_vmap[set], c->d_nmap[set], W, H, c->K, g.depth_cutoff, sp);
+    }
+    c->cur_rgb = d_rgb;
+    c->cur_depth = d_depth;
+    if (photometric_on(c) || g.so3) {
+        // imageBGRToIntensity + pyrDownUcharGauss of the frame (initRGB / initFirstRGB) and, for the photometric term,
+        // computeDerivativeImages (RGBDOdometry.cpp:245-250)
+        launch_intensity(d_rgb, 3, c->d_gray[set][0], P, sp);
+        for (int i = 0; i + 1 < 3; ++i) launch_pyrdown_u8(c->d_gray[set][i], c->d_gray[set][i + 1], W >> i, H >> i, sp);
+        c->gray_frame[set] = k;
+        if (photometric_on(c))
+            for (int i = 0; i < 3; ++i)
+                launch_derivative(c->d_gray[set][i], c->d_dIdx[i], c->d_dIdy[i], W >> i, H >> i, rgb_min_scale(i), c->d_rgb_gate[i], sp);
+    }
+    mark(c, 1, sp);
+    if (c->overlap) {
+        MF_HIP(c, hipEventRecord(c->ev_pre_done[set], sp));
+        MF_HIP(c, hipStreamWaitEvent(s, c->ev_pre_done[set], 0));
+    }
+    return MF_OK;
+}
+
 static int download_pose_log(mf_ctx* c, ModelState& m, std::vector<int64_t>& ts, std::vector<float>& p7);
 
 static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_depth, const uint8_t* d_mask_in,
@@ -597,34 +640,10 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
     float* depthF = c->d_depthF[k % 3];
     float* depthF_prev = c->d_depthF[(k + 2) % 3];
     ModelState& bg = *c->models[0];
+    bool main_done_recorded = false;
 
-    // ---- preprocessing on its own stream: filterDepth (:217) + Model::generateCUDATextures (Model.cpp:350-389).
-    // It starts when frame k-1 has finished TRACKING: frame k-2 (the last user of this buffer set and of depthF[k % 3]) is
-    // then complete, and the filter overlaps the atomic-/latency-bound fusion kernels of frame k-1 rather than its
-    // Gauss-Newton launches, which need a whole CU per workgroup and stall behind resident filter waves.
-    hipStream_t sp = c->overlap ? c->stream_pre : s;
-    if (c->overlap) MF_HIP(c, hipStreamWaitEvent(sp, c->ev_main_done[set ^ 1], 0));
-    mark(c, 0, sp);
-    launch_bilateral(d_depth, depthF, W, H, sp);
-    if (c->host_tick > 1) {
-        launch_frame_pyramid(depthF, c->d_vmap[set], c->d_nmap[set], W, H, c->K, g.depth_cutoff, sp);
-    }
-    c->cur_rgb = d_rgb;
-    if (photometric_on(c) || g.so3) {
-        // imageBGRToIntensity + pyrDownUcharGauss of the frame (initRGB / initFirstRGB) and, for the photometric term,
-        // computeDerivativeImages (RGBDOdometry.cpp:245-250)
-        launch_intensity(d_rgb, 3, c->d_gray[set][0], P, sp);
-        for (int i = 0; i + 1 < 3; ++i) launch_pyrdown_u8(c->d_gray[set][i], c->d_gray[set][i + 1], W >> i, H >> i, sp);
-        c->gray_frame[set] = k;
-        if (photometric_on(c))
-            for (int i = 0; i < 3; ++i)
-                launch_derivative(c->d_gray[set][i], c->d_dIdx[i], c->d_dIdy[i], W >> i, H >> i, rgb_min_scale(i), c->d_rgb_gate[i], sp);
-    }
-    mark(c, 1, sp);
-    if (c->overlap) {
-        MF_HIP(c, hipEventRecord(c->ev_pre_done[set], sp));
-        MF_HIP(c, hipStreamWaitEvent(s, c->ev_pre_done[set], 0));
-    }
+    int prc = enqueue_preprocess(c, d_rgb, d_depth, k);
+    if (prc != MF_OK) return prc;
 
     if (c->host_tick == 1) {
         mark(c, 2); mark(c, 3); mark(c, 4); mark(c, 5); mark(c, 6);
@@ -639,21 +658,25 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
         mark(c, 2);
         launch_override_pose(bg.d_pose, in_pose16, 0, bg.h_pose, s);
         mark(c, 3); mark(c, 4);
-        for (size_t i = 0; i < c->models.size(); ++i)
+        if (!g.rgb_only)   // :539
+          for (size_t i = 0; i < c->models.size(); ++i)
             enqueue_fuse_clean(c, *c->models[i], d_rgb, d_depth, depthF, mask, g.depth_cutoff, weight_multiplier, true, i == 0);
         mark(c, 7);
     } else {
         mark(c, 2);
         // tracking, :247-276
-        enqueue_track(c, bg, depthF_prev, 0.f);
+        enqueue_track(c, bg, depthF_prev, 0.f, k);
         if (bootstrap && in_pose16) launch_override_pose(bg.d_pose, in_pose16, 1, bg.h_pose, s);   // :280-283
         for (size_t i = 1; i < c->models.size(); ++i) {
             ModelState& m = *c->models[i];
-            if (!m.isStatic || g.track_all_models) enqueue_track(c, m, nullptr, 0.2f);  // jump rule, :268-272
+            // trackable = trackableClassIds.empty() || trackableClassIds.count(classID), :261
+            bool trackable = c->trackable.empty();
+            for (int id : c->trackable) trackable |= (id == m.classID);
+            if ((!m.isStatic || g.track_all_models) && trackable) enqueue_track(c, m, nullptr, 0.2f, k);  // jump rule, :268-272
             else launch_static_pose(m.d_pose, bg.d_pose, m.h_pose, s);                  // updateStaticPose, :274
         }
         mark(c, 3);
-        if (c->overlap) MF_HIP(c, hipEventRecord(c->ev_main_done[set], s));
+        if (c->overlap) { MF_HIP(c, hipEventRecord(c->ev_main_done[set], s)); main_done_recorded = true; }
 
         if (multi) {
             // GlobalProjection::project(models, tick, tick, timeDelta, depthCutoff) (:289) with its fixed threshold 12
@@ -741,8 +764,9 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
                 c->models[i]->confThr = fminf(4.5f, (float)c->models[i]->age / 25.0f);
         }
         // (the predict() at MaskFusion.cpp:423 only feeds the dead loop-closure block and is overwritten at :569)
-        // fusion, :539-565
-        for (size_t i = 0; i < c->models.size(); ++i)
+        // fusion, :539-565: if (!rgbOnly && trackingOk && !lost)
+        if (!g.rgb_only)
+          for (size_t i = 0; i < c->models.size(); ++i)
             enqueue_fuse_clean(c, *c->models[i], d_rgb, d_depth, depthF, mask, g.depth_cutoff, weight_multiplier, true, i == 0);
         mark(c, 7);
     }
@@ -757,7 +781,8 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
         m->age++;  // incrementAge, :600
     }
     mark(c, 8);
-    if (c->host_tick == 1 && c->overlap) MF_HIP(c, hipEventRecord(c->ev_main_done[set], s));
+    // every branch records the event (the caller-supplied-pose branch and the first frame do it here, at the end of the frame)
+    if (c->overlap && !main_done_recorded) MF_HIP(c, hipEventRecord(c->ev_main_done[set], s));
     c->lastF = (int)(k % 3);
     c->frame_no++;
     c->host_tick++;
@@ -777,8 +802,6 @@ extern "C" int mf_process_frame_dev(mf_ctx* c, const uint8_t* d_rgb, const float
 extern "C" int mf_sync(mf_ctx* c) {
     if (!c) return MF_EINVAL;
     MF_HIP(c, hipStreamSynchronize(c->stream));
-    for (auto& m : c->models)
-        if (m->h_frame->pad[1]) { c->err = "splat tile lists overflowed (raise the surfel capacity)"; return MF_ESTATE; }
     if (c->timings_on) {
         // event i marks the START of stage i; stage i lasts until event i+1 (labels: see the header)
         float t[MF_N_TIMINGS] = {};
@@ -812,11 +835,29 @@ extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* dept
     return mf_sync(c);
 }
 
+// the coverage count behind MaskFusion::requiresFillIn belongs to ONE projection: a prediction outside processFrame starts it over
+// (inside a frame k_frame_advance has already consumed and zeroed it)
+static __global__ void k_reset_cover(FrameDev* f) { if (threadIdx.x == 0 && blockIdx.x == 0) f->cover = 0; }
+// ... and re-takes the decision k_frame_advance took for the next tracking step (MaskFusion::requiresFillIn, :630-648)
+static __global__ void k_fillin_decision(FrameDev* f, int W, int H, FrameDev* host_mirror) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    f->useFillIn = ((float)f->cover / (float)((W / 20) * (H / 20)) < 0.75f) ? 1 : 0;
+    f->cover = 0;
+    if (host_mirror) *host_mirror = *f;
+}
+static void launch_fillin_decision(FrameDev* f, int W, int H, FrameDev* host_mirror, hipStream_t s) {
+    hipLaunchKernelGGL(k_fillin_decision, dim3(1), dim3(64), 0, s, f, W, H, host_mirror);
+}
+
 extern "C" int mf_predict(mf_ctx* c) {
     if (!c) return MF_EINVAL;
     const uint8_t* keep = c->cur_rgb;
     c->cur_rgb = nullptr;  // the caller's frame buffer may be gone: the fill-in intensity keeps its last contents
-    for (auto& m : c->models) enqueue_predict(c, *m);
+    for (auto& m : c->models) {
+        hipLaunchKernelGGL(k_reset_cover, dim3(1), dim3(64), 0, c->stream, m->d_frame);
+        enqueue_predict(c, *m);
+    }
+    for (auto& m : c->models) launch_fillin_decision(m->d_frame, c->W, c->H, m->h_frame, c->stream);
     c->cur_rgb = keep;
     return check_launch(c);
 }
@@ -846,6 +887,236 @@ extern "C" int mf_set_tick(mf_ctx* c, int32_t tick) {
     c->host_tick = tick;
     for (auto& m : c->models) hipLaunchKernelGGL(k_set_tick, dim3(1), dim3(64), 0, c->stream, m->d_frame, tick, m->h_frame);
     return check_launch(c);
+}
+
+static ModelState* model_at(mf_ctx* c, int32_t i);
+
+// ------------------------------------------------------------------------------------------------
+// Model-level entry points: the public operations of Model (Core/Model/Model.h:126-162,233-268) one by one, on a frame
+// staged with mf_stage_frame.  MaskFusion::processFrame is a fixed composition of these (mf_process_frame enqueues the
+// same launches); they exist so that a caller can drive a model the way the reference's own callers do, and so that each
+// surfel pass can be compared with the oracle in isolation.
+// ------------------------------------------------------------------------------------------------
+static __global__ void k_set_count(FrameDev* f, int count, int* host_count) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    f->count = count; f->countNext = count;
+    if (host_count) *host_count = count;
+}
+static void set_model_tick(mf_ctx* c, ModelState& m, int tick) {
+    hipLaunchKernelGGL(k_set_tick, dim3(1), dim3(64), 0, c->stream, m.d_frame, tick, m.h_frame);
+}
+static long staged_frame(const mf_ctx* c) { return c->frame_no - 1; }   // index of the frame staged / processed last
+static const uint8_t* current_mask(const mf_ctx* c) { return c->cfg.enable_multiple_models ? c->d_mask_tex : c->d_zero_mask; }
+
+// upload + MaskFusion::filterDepth (:217) + Model::generateCUDATextures (Model.cpp:350-389) + intensity pyramid: everything of
+// processFrame that does not touch a model.  mask: model id per pixel = what textureMask holds for fuse / clean (NULL: zeros)
+extern "C" int mf_stage_frame(mf_ctx* c, const uint8_t* rgb, const float* depth, const uint8_t* mask) {
+    if (!c || !rgb || !depth) return MF_EINVAL;
+    hipStream_t sin = c->overlap ? c->stream_pre : c->stream;
+    MF_HIP(c, hipStreamSynchronize(c->stream));
+    MF_HIP(c, hipMemcpyAsync(c->d_rgb, rgb, (size_t)c->P * 3, hipMemcpyHostToDevice, sin));
+    MF_HIP(c, hipMemcpyAsync(c->d_depth, depth, (size_t)c->P * sizeof(float), hipMemcpyHostToDevice, sin));
+    if (mask) MF_HIP(c, hipMemcpyAsync(c->d_mask_tex, mask, (size_t)c->P, hipMemcpyHostToDevice, sin));
+    else MF_HIP(c, hipMemsetAsync(c->d_mask_tex, 0, (size_t)c->P, sin));
+    // the vertex / normal maps are only skipped for the frame that initialises the map (tick 1); a staged frame always has them
+    const int keep = c->host_tick;
+    if (c->host_tick == 1) c->host_tick = 2;
+    int rc = enqueue_preprocess(c, c->d_rgb, c->d_depth, c->frame_no);
+    c->host_tick = keep;
+    if (rc != MF_OK) return rc;
+    c->lastF = (int)(c->frame_no % 3);
+    c->frame_no++;
+    return mf_sync(c);
+}
+
+// Model::initialise (Core/Model/Model.cpp:240-285): the map of `model` becomes the staged frame's point cloud
+extern "C" int mf_model_initialise(mf_ctx* c, int32_t model) {
+    ModelState* m = model_at(c, model);
+    if (!m || c->frame_no == 0) return MF_EINVAL;
+    const long k = staged_frame(c);
+    launch_init_surfels(c->cur_rgb, c->cur_depth, c->d_depthF[k % 3], c->W, c->H, c->K, c->cfg.max_depth_processed, m->d_frame, c->d_cand_rec,
+                        c->d_flags, c->stream);
+    launch_compact_records(c->d_cand_rec, c->d_flags, c->P, m->surf[m->cur], m->d_frame, c->d_block_counts, m->h_count, c->stream);
+    if (c->host_tick == 1) c->host_tick = 2;
+    return check_launch(c);
+}
+
+// test / tooling tap with no upstream twin: replace the surfel buffer of `model` (count records of 12 floats, mf_download_map's layout)
+extern "C" int mf_model_upload_map(mf_ctx* c, int32_t model, const float* surfels, uint32_t count) {
+    ModelState* m = model_at(c, model);
+    if (!m || (!surfels && count) || (int)count > m->cap) return MF_EINVAL;
+    MF_HIP(c, hipStreamSynchronize(c->stream));
+    std::vector<float4> a(count), b(count), d(count);
+    for (uint32_t i = 0; i < count; ++i) {
+        memcpy(&a[i], surfels + (size_t)i * 12, 16);
+        memcpy(&b[i], surfels + (size_t)i * 12 + 4, 16);
+        memcpy(&d[i], surfels + (size_t)i * 12 + 8, 16);
+    }
+    const Surfels& s = m->surf[m->cur];
+    if (count) {
+        MF_HIP(c, hipMemcpy(s.pc, a.data(), count * sizeof(float4), hipMemcpyHostToDevice));
+        MF_HIP(c, hipMemcpy(s.ct, b.data(), count * sizeof(float4), hipMemcpyHostToDevice));
+        MF_HIP(c, hipMemcpy(s.nr, d.data(), count * sizeof(float4), hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(k_set_count, dim3(1), dim3(64), 0, c->stream, m->d_frame, (int)count, m->h_count);
+    if (c->host_tick == 1) c->host_tick = 2;   // the map exists: the next mf_process_frame tracks instead of initialising
+    return check_launch(c);
+}
+
+// Model::overridePose (Core/Model/Model.h:235-238): lastPose = pose; pose = p
+extern "C" int mf_model_override_pose(mf_ctx* c, int32_t model, const float* pose16) {
+    ModelState* m = model_at(c, model);
+    if (!m || !pose16) return MF_EINVAL;
+    launch_override_pose(m->d_pose, pose16, 0, m->h_pose, c->stream);
+    return check_launch(c);
+}
+
+// Model::computeFusionWeight(weightMultiplier) (Core/Model/Model.cpp:449-464) from the model's pose and lastPose
+extern "C" int mf_model_fusion_weight(mf_ctx* c, int32_t model, float weight_multiplier, float* out) {
+    ModelState* m = model_at(c, model);
+    if (!m || !out) return MF_EINVAL;
+    int rc = mf_sync(c);
+    if (rc != MF_OK) return rc;
+    *out = m->h_pose->fusionWeight * weight_multiplier;
+    return MF_OK;
+}
+
+// Model::performTracking(frameToFrameRGB, rgbOnly, icpWeight, pyramid, fastOdom, so3, maxDepthProcessed, rgb, logTimestamp,
+// tryFillIn) (Core/Model/Model.h:135-136, Model.cpp:427-447) against the staged frame.  frameToFrameRGB must be 0 (the
+// reference's only caller passes false, MaskFusion.cpp:248).
+extern "C" int mf_model_perform_tracking(mf_ctx* c, int32_t model, int32_t frame_to_frame_rgb, int32_t rgb_only, float icp_weight,
+                                         int32_t pyramid, int32_t fast_odom, int32_t so3, float max_depth_processed, int64_t log_timestamp,
+                                         int32_t try_fill_in) {
+    ModelState* m = model_at(c, model);
+    (void)log_timestamp;   // only forwarded to a debug print upstream
+    if (!m || c->frame_no == 0) return MF_EINVAL;
+    if (frame_to_frame_rgb) { c->err = "frameToFrameRGB is not supported (never enabled upstream)"; return MF_EINVAL; }
+    const mf_config keep = c->cfg;
+    c->cfg.rgb_only = rgb_only; c->cfg.icp_weight = icp_weight; c->cfg.pyramid = pyramid; c->cfg.fast_odom = fast_odom; c->cfg.so3 = so3;
+    c->cfg.max_depth_processed = max_depth_processed;
+    const long k = staged_frame(c);
+    // tryFillIn = MaskFusion::requiresFillIn(model) (:630-648): the decision itself is taken on the device from the coverage of the
+    // last prediction; here it only gates whether the fill-in source (the previous frame's filtered depth) is offered at all
+    enqueue_track(c, *m, (try_fill_in && m->allowFillIn) ? c->d_depthF[(k + 2) % 3] : nullptr, 0.f, k);
+    c->cfg = keep;
+    return check_launch(c);
+}
+
+// Model::predictIndices(time, maxDepth, timeDelta) (Core/Model/Model.h:162, ModelProjection.cpp:100-152)
+extern "C" int mf_model_predict_indices(mf_ctx* c, int32_t model, int32_t time, float max_depth, int32_t time_delta) {
+    ModelState* m = model_at(c, model);
+    if (!m) return MF_EINVAL;
+    hipStream_t s = c->stream;
+    set_model_tick(c, *m, time);
+    launch_index_scatter(m->surf[m->cur], m->d_frame, m->d_pose, c->W, c->H, c->K, max_depth, time_delta, c->d_keys, false, s);
+    launch_index_resolve(m->surf[m->cur], m->d_pose, c->d_keys, c->W, c->H, c->d_index, c->d_ivc, c->d_inr, c->d_ict, nullptr, s);
+    if (c->model_api_packed) {   // the layout mf_process_frame feeds clean() with: packed records, column-major
+        launch_index_scatter(m->surf[m->cur], m->d_frame, m->d_pose, c->W, c->H, c->K, max_depth, time_delta, c->d_keys, true, s);
+        launch_index_resolve(m->surf[m->cur], m->d_pose, c->d_keys, c->W, c->H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, s);
+    }
+    return check_launch(c);
+}
+
+// Model::fuse(time, rgb, mask, depthRaw, depthFiltered, depthCutoff, weightMultiplier) (Core/Model/Model.h:142-143,
+// Model.cpp:466-647) with the staged frame's textures: data association against the index map of the last
+// mf_model_predict_indices of THIS model, then the update pass; the live buffer flips.
+extern "C" int mf_model_fuse(mf_ctx* c, int32_t model, int32_t time, float depth_cutoff, float weight_multiplier) {
+    ModelState* m = model_at(c, model);
+    if (!m || c->frame_no == 0) return MF_EINVAL;
+    hipStream_t s = c->stream;
+    const long k = staged_frame(c);
+    set_model_tick(c, *m, time);
+    const int src = m->cur, dst = 1 - m->cur;
+    launch_fuse_data(c->cur_rgb, c->cur_depth, c->d_depthF[k % 3], current_mask(c), m->id, m->d_frame, m->d_pose, weight_multiplier,
+                     fminf(depth_cutoff, m->maxDepth), c->W, c->H, c->K, c->d_index, c->d_ivc, c->d_inr, c->d_cand_op, c->d_cand_rec,
+                     c->d_upd_first, s);
+    launch_fuse_update(m->surf[src], m->surf[dst], m->d_frame, c->d_upd_first, c->d_cand_rec, m->d_pose, c->W, c->H, c->K,
+                       c->cfg.max_depth_processed, c->cfg.time_delta, nullptr, false, s);
+    m->cur = dst;
+    return check_launch(c);
+}
+
+// Model::clean(time, graph, timeDelta, depthCutoff, isFern, depthFiltered, mask) (Core/Model/Model.h:146-147, Model.cpp:649-772):
+// uses the index map of the last mf_model_predict_indices and the new-surfel records of the last mf_model_fuse of THIS model
+extern "C" int mf_model_clean(mf_ctx* c, int32_t model, int32_t time, int32_t time_delta, float depth_cutoff) {
+    ModelState* m = model_at(c, model);
+    (void)depth_cutoff;   // the maxDepth uniform of copy_unstable.vert is never read (:53-157)
+    if (!m || c->frame_no == 0) return MF_EINVAL;
+    const long k = staged_frame(c);
+    set_model_tick(c, *m, time);
+    const int src = m->cur, dst = 1 - m->cur;
+    const bool packed = c->model_api_packed != 0;
+    launch_clean(m->surf[src], m->surf[dst], m->d_frame, m->d_pose, c->W, c->H, c->K, time_delta, m->confThr, c->cfg.outlier_coefficient, m->id,
+                 c->d_index, c->d_ivc, c->d_ict, packed ? c->d_iclean : nullptr, c->d_depthF[k % 3], current_mask(c), c->d_cand_op, c->d_cand_rec,
+                 c->d_flags, c->d_newconf, c->d_block_counts, m->h_count, packed, c->stream);
+    m->cur = dst;
+    return check_launch(c);
+}
+
+// Model::combinedPredict(maxDepth, time, maxTime, timeDelta, ACTIVE) (Core/Model/Model.h:158, ModelProjection.cpp:187-268);
+// the reference only ever calls it with time == maxTime (MaskFusion.cpp:616-628)
+extern "C" int mf_model_combined_predict(mf_ctx* c, int32_t model, float max_depth, int32_t time, int32_t max_time, int32_t time_delta) {
+    ModelState* m = model_at(c, model);
+    if (!m || time != max_time) return MF_EINVAL;
+    set_model_tick(c, *m, time);
+    const mf_config keep = c->cfg;
+    c->cfg.max_depth_processed = max_depth; c->cfg.time_delta = time_delta;
+    hipLaunchKernelGGL(k_reset_cover, dim3(1), dim3(64), 0, c->stream, m->d_frame);
+    enqueue_predict(c, *m);
+    c->cfg = keep;
+    return check_launch(c);
+}
+
+// the tail of processFrame for a frame driven through the Model-level calls: tick++ (:573), fill-in decision for the next
+// tracking step (requiresFillIn), pose log entry (:580-596), age++ (:600)
+extern "C" int mf_end_frame(mf_ctx* c, int64_t timestamp) {
+    if (!c) return MF_EINVAL;
+    ModelState& bg = *c->models[0];
+    for (auto& m : c->models) {
+        float* slot = nullptr;
+        if (m->d_poselog) {
+            slot = m->d_poselog + (m->log_ts.size() % (size_t)c->cfg.pose_log_capacity) * 8;
+            m->log_ts.push_back(timestamp);
+        }
+        launch_frame_advance(m->d_frame, c->W, c->H, m->h_frame, m->d_pose, m.get() == &bg ? nullptr : bg.d_pose, slot, c->stream);
+        m->age++;
+    }
+    c->host_tick++;
+    return check_launch(c);
+}
+
+// Model::makeNonStatic / makeStatic(globalPose) / isNonstatic (Core/Model/Model.h:263-268): a non-static object model is
+// tracked even when trackAllModels is off; makeStatic re-anchors it to the background's current pose
+extern "C" int mf_make_nonstatic(mf_ctx* c, int32_t model) {
+    ModelState* m = model_at(c, model);
+    if (!m) return MF_EINVAL;
+    m->isStatic = false;
+    return MF_OK;
+}
+static __global__ void k_make_static(PoseDev* obj, const PoseDev* bg, PoseDev* host_mirror) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // initialC2Winv = pose * globalPose^-1
+    PoseDev p = *obj;
+    for (int r = 0; r < 3; ++r)
+        for (int col = 0; col < 3; ++col)
+            p.initR[r * 3 + col] = p.R[r * 3] * bg->Ri[col] + p.R[r * 3 + 1] * bg->Ri[3 + col] + p.R[r * 3 + 2] * bg->Ri[6 + col];
+    for (int r = 0; r < 3; ++r)
+        p.initT[r] = p.R[r * 3] * bg->ti[0] + p.R[r * 3 + 1] * bg->ti[1] + p.R[r * 3 + 2] * bg->ti[2] + p.t[r];
+    *obj = p;
+    if (host_mirror) *host_mirror = p;
+}
+extern "C" int mf_make_static(mf_ctx* c, int32_t model) {
+    ModelState* m = model_at(c, model);
+    if (!m || model == 0) return MF_EINVAL;
+    hipLaunchKernelGGL(k_make_static, dim3(1), dim3(64), 0, c->stream, m->d_pose, c->models[0]->d_pose, m->h_pose);
+    m->isStatic = true;
+    return check_launch(c);
+}
+// MaskFusion::setTrackableClassIds (Core/MaskFusion.h:246, MaskFusion.cpp:261,940); n = 0 clears the set (everything trackable)
+extern "C" int mf_set_trackable_class_ids(mf_ctx* c, const int32_t* ids, int32_t n) {
+    if (!c || n < 0 || (n > 0 && !ids)) return MF_EINVAL;
+    c->trackable.assign(ids, ids + n);
+    return MF_OK;
 }
 
 extern "C" int mf_get_tick(mf_ctx* c, int32_t* tick) {
@@ -1086,7 +1357,14 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!strcmp(key, "timings")) { c->timings_on = value != 0; return MF_OK; }
     if (!strcmp(key, "icpProfile")) { c->icp_prof_on = value != 0; return MF_OK; }
     if (!strcmp(key, "gpuLabels")) { c->gpu_labels = value != 0; return MF_OK; }   // 0: host label stage (specification)
-    if (!strcmp(key, "splatTiles")) { c->splat_tiles = value != 0; return MF_OK; }   // 0: scatter + resolve form (specification)
+    if (!strcmp(key, "splatTiles")) { c->splat_tiles = value != 0; return MF_OK; }
+    if (!strcmp(key, "splatTileEntries")) {   // test knob: shrink the tile lists (never beyond what was allocated) to force the overflow path
+        const long long v = (long long)value;
+        if (v < 1 || v > c->tile_entries_alloc) return MF_EINVAL;
+        c->tile_entries_cap = (int)v;
+        return MF_OK;
+    }
+    if (!strcmp(key, "modelApiPackedIndex")) { c->model_api_packed = value != 0; return MF_OK; }   // 0: scatter + resolve form (specification)
     if (!strcmp(key, "overlapPreprocessing")) {
         (void)hipStreamSynchronize(c->stream_pre);
         (void)hipStreamSynchronize(c->stream);
@@ -1114,6 +1392,7 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
 extern "C" int mf_get_param(mf_ctx* c, const char* key, double* value) {
     if (!c || !key || !value) return MF_EINVAL;
     if (!strcmp(key, "confidenceThreshold")) { *value = c->models[0]->confThr; return MF_OK; }
+    if (!strcmp(key, "splatTileEntries")) { *value = c->tile_entries_cap; return MF_OK; }
     for (const ParamRef& p : kParams)
         if (!strcmp(key, p.key)) {
             const char* base = reinterpret_cast<const char*>(&c->cfg);
@@ -1139,15 +1418,14 @@ extern "C" int mf_get_timings(mf_ctx* c, float* ms) {
 extern "C" void* mf_get_stream(mf_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" void* mf_get_input_stream(mf_ctx* c) { return c ? (void*)(c->overlap ? c->stream_pre : c->stream) : nullptr; }
 
-extern "C" int mf_debug_read(mf_ctx* c, const char* what, void* out, uint64_t out_bytes) {
-    if (!c || !what || !out) return MF_EINVAL;
+static int debug_read_impl(mf_ctx* c, ModelState& mdl, const char* what, void* out, uint64_t out_bytes) {
     int rc = mf_sync(c);
     if (rc != MF_OK) return rc;
     const void* src = nullptr;
     size_t bytes = 0;
+    bool variable = false;   // taps whose meaningful length depends on the frame: copy as much as the caller asked for
     const size_t P = (size_t)c->P;
     std::string w(what);
-    ModelState& bg = *c->models[0];
     auto lvl = [&](const std::string& pre, float* const arr[3]) -> bool {
         for (int i = 0; i < 3; ++i)
             if (w == pre + std::to_string(i)) {
@@ -1156,25 +1434,44 @@ extern "C" int mf_debug_read(mf_ctx* c, const char* what, void* out, uint64_t ou
             }
         return false;
     };
-    const int lastSet = (int)((c->frame_no + 1) & 1);  // buffer set of the last processed frame
+    const int lastSet = (int)((c->frame_no + 1) & 1);  // buffer set of the last processed / staged frame
     if (w == "depthF") { src = c->d_depthF[c->lastF]; bytes = P * 4; }
     else if (lvl("vmap_g", c->d_vmap_g) || lvl("nmap_g", c->d_nmap_g) || lvl("vmap", c->d_vmap[lastSet]) || lvl("nmap", c->d_nmap[lastSet])) {}
-    else if (w == "pred_vertex") { src = bg.d_predV; bytes = P * 16; }
-    else if (w == "pred_normal") { src = bg.d_predN; bytes = P * 16; }
-    else if (w == "pred_image") { src = bg.d_predImage; bytes = P * 4; }
+    else if (w == "pred_vertex") { src = mdl.d_predV; bytes = P * 16; }
+    else if (w == "pred_normal") { src = mdl.d_predN; bytes = P * 16; }
+    else if (w == "pred_image") { src = mdl.d_predImage; bytes = P * 4; }
+    else if (w == "pred_time") { src = mdl.d_predTime; bytes = P * 2; }
     else if (w == "index") { src = c->d_index; bytes = P * 4; }
     else if (w == "index_vc") { src = c->d_ivc; bytes = P * 16; }
+    else if (w == "index_nr") { src = c->d_inr; bytes = P * 16; }
+    else if (w == "index_ct") { src = c->d_ict; bytes = P * 16; }
+    else if (w == "index_packed") { src = c->d_iclean; bytes = P * 32; }
+    else if (w == "cand_op") { src = c->d_cand_op; bytes = P; variable = true; }
+    else if (w == "cand_rec") { src = c->d_cand_rec; bytes = P * 48; variable = true; }
+    else if (w == "clean_flags") { src = c->d_flags; bytes = (size_t)c->cap_max + P; variable = true; }
+    else if (w == "clean_newconf") { src = c->d_newconf; bytes = ((size_t)c->cap_max + P) * 4; variable = true; }
     else if (w == "icp_log") { src = c->d_icp_log; bytes = 19 * 32 * 4; }
     else if (w == "icp_prof") { src = c->d_icp_prof; bytes = 19 * 8 * 8; }
     else if (w == "edge_map") { src = c->d_edge; bytes = P * 4; }
     else if (w == "edge_binary") { src = c->d_bin; bytes = P; }
     else if (w == "projected_ids") { src = c->d_proj_ids; bytes = P; }
     else { c->err = "unknown debug tap: " + w; return MF_EINVAL; }
+    if (variable) bytes = out_bytes < bytes ? (size_t)out_bytes : bytes;
     if (out_bytes < bytes) { c->err = "debug_read: buffer too small"; return MF_EINVAL; }
     MF_HIP(c, hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
-    // "index" / "index_vc" are the row-major images of the pre-fusion index pass; the post-fusion pass that feeds clean()
-    // lives in the packed column-major d_iclean
+    // "index" / "index_vc" / "index_nr" / "index_ct" are the row-major images of the pre-fusion index pass (and of
+    // mf_model_predict_indices); inside mf_process_frame the post-fusion pass that feeds clean() lives in "index_packed"
+    // (column-major texel order, two float4 per texel: {vertConf | initTime, lastTime, index bits, 0})
     return MF_OK;
+}
+extern "C" int mf_debug_read(mf_ctx* c, const char* what, void* out, uint64_t out_bytes) {
+    if (!c || !what || !out) return MF_EINVAL;
+    return debug_read_impl(c, *c->models[0], what, out, out_bytes);
+}
+extern "C" int mf_debug_read_model(mf_ctx* c, int32_t model, const char* what, void* out, uint64_t out_bytes) {
+    ModelState* m = model_at(c, model);
+    if (!m || !what || !out) return MF_EINVAL;
+    return debug_read_impl(c, *m, what, out, out_bytes);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -15,6 +15,12 @@ __device__ __forceinline__ float3 operator*(float3 a, float s) { return f3(a.x *
 __device__ __forceinline__ float3 cross3(float3 a, float3 b) {
     return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
+// every product rounded on its own: cross(v, v) is then EXACTLY zero (with fused multiply-adds it is a rounding residual pointing
+// anywhere), which is what turns a degenerate depth neighbourhood into a NaN normal -- the "invalid" mark of every map here
+__device__ __forceinline__ float3 cross3_exact(float3 a, float3 b) {
+#pragma clang fp contract(off)
+    return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
 __device__ __forceinline__ float dot3(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ float norm3(float3 a) { return sqrtf(dot3(a, a)); }
 // CUDA-side normalized(): a * rsqrt(dot) (Core/Cuda/operators.cuh:80-84)
@@ -55,6 +61,43 @@ __device__ __forceinline__ void zmin_key(unsigned long long* addr, unsigned long
     atomicMin(addr, key);
 }
 
+// ---- exp() and acos() of the surfel shaders (surfels.glsl:44, data.vert:167): GLSL leaves their last bits to the GPU vendor.
+// This library and the CPU checker the parity tests compare it with evaluate them with the SAME
+// sequence of individually rounded fp32 operations (Cephes-style range reduction + polynomial, <= 2 ulp), so that a confidence
+// or an angle test can never differ between them in the last bit -- which the life cycle of a surfel would amplify into a
+// different keep / merge decision a few frames later. ----
+__device__ __forceinline__ float shader_exp(float x) {
+#pragma clang fp contract(off)
+    // x <= 0 here (the argument is -(r/400)^2 / 0.72); valid for |x| < 87 
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = x - n * 0.693359375f;
+    r = r - n * -2.12194440e-4f;
+    float p = 1.9875691500E-4f;
+    p = p * r + 1.3981999507E-3f;
+    p = p * r + 8.3334519073E-3f;
+    p = p * r + 4.1665795894E-2f;
+    p = p * r + 1.6666665459E-1f;
+    p = p * r + 5.0000001201E-1f;
+    const float y = p * (r * r) + r + 1.0f;
+    return y * __uint_as_float((unsigned)((int)n + 127) << 23);   // exact scaling by 2^n 
+}
+__device__ __forceinline__ float shader_asin_core(float a) {
+#pragma clang fp contract(off)
+    const float z = a * a;
+    float p = 4.2163199048E-2f;
+    p = p * z + 2.4181311049E-2f;
+    p = p * z + 4.5470025998E-2f;
+    p = p * z + 7.4953002686E-2f;
+    p = p * z + 1.6666752422E-1f;
+    return p * z * a + a;
+}
+__device__ __forceinline__ float shader_acos(float x) {
+#pragma clang fp contract(off)
+    if (x > 0.5f) return 2.0f * shader_asin_core(sqrtf(0.5f * (1.0f - x)));
+    if (x < -0.5f) return 3.14159265358979323846f - 2.0f * shader_asin_core(sqrtf(0.5f * (1.0f + x)));
+    return 1.57079632679489661923f - shader_asin_core(x);   // NaN falls through to here and stays NaN 
+}
+
 // ---- surfel / shader helpers (Core/Shaders/surfels.glsl, color_encoding.glsl, geometry.glsl) ----
 __device__ __forceinline__ float surfel_radius(float depth, float norm_z, Intr k) {  // surfels.glsl:19-34
     const float camz = 1.0f / k.fx, camw = 1.0f / k.fy;
@@ -65,7 +108,7 @@ __device__ __forceinline__ float surfel_radius(float depth, float norm_z, Intr k
 __device__ __forceinline__ float surfel_confidence(float x, float y, float weighting, Intr k) {  // surfels.glsl:36-46
     const float dx = x - k.cx, dy = y - k.cy;
     const float radialDist = sqrtf(dx * dx + dy * dy) / 400.f;
-    return expf(-(radialDist * radialDist) / 0.72f) * weighting;
+    return shader_exp(-(radialDist * radialDist) / 0.72f) * weighting;
 }
 __device__ __forceinline__ float encode_color(float r, float g, float b) {  // color_encoding.glsl:19-25
     int rgb = (int)roundf(r * 255.0f);
@@ -82,7 +125,10 @@ __device__ __forceinline__ float texf(const float* img, int W, int H, int x, int
     return img[clampi(y, 0, H - 1) * W + clampi(x, 0, W - 1)];
 }
 // geometry.glsl:21-26; cam = (cx, cy, 1/fx, 1/fy)
+// (products rounded before anything is subtracted from them: the normals below difference two vertices a pixel apart -- ~1e-3 of
+// their magnitude -- so a product fused into that subtraction shows up as 1e-4 in the normal)
 __device__ __forceinline__ float3 get_vertex(const float* depth, int W, int H, int px, int py, float x, float y, Intr k) {
+#pragma clang fp contract(off)
     const float z = texf(depth, W, H, px, py);
     return f3((x - k.cx) * z * (1.0f / k.fx), (y - k.cy) * z * (1.0f / k.fy), z);
 }
@@ -95,13 +141,13 @@ __device__ __forceinline__ float3 get_normal_central(const float* depth, int W, 
     const float3 yb = get_vertex(depth, W, H, px, py - 1, x, y - 1, k);
     const float3 del_x = ((xb + vPos) * 0.5f) - ((xf + vPos) * 0.5f);
     const float3 del_y = ((yb + vPos) * 0.5f) - ((yf + vPos) * 0.5f);
-    return normalize_gl(cross3(del_x, del_y));
+    return normalize_gl(cross3_exact(del_x, del_y));
 }
 // geometry.glsl:42-62 (forward differences, integer pixel coordinates)
 __device__ __forceinline__ float3 get_normal_forward(const float* depth, int W, int H, int px, int py, float3 vPos, Intr k) {
     const float3 vx = get_vertex(depth, W, H, px + 1, py, (float)(px + 1), (float)py, k);
     const float3 vy = get_vertex(depth, W, H, px, py + 1, (float)px, (float)(py + 1), k);
-    return normalize_gl(cross3(vx - vPos, vy - vPos));
+    return normalize_gl(cross3_exact(vx - vPos, vy - vPos));
 }
 
 // ---- pose math shared by the odometry and the object-model kernels ----

@@ -101,10 +101,10 @@ __global__ __launch_bounds__(kBinThreads) void k_splat_bin(const BinArgs a) {
                 // repeating its ~300 instructions (ten IEEE divisions) each time
                 a.rec0[i] = make_float4(su.h.x, su.h.y, su.h.z, su.sqrRad);
                 a.rec1[i] = make_float4(su.nrm.x, su.nrm.y, su.nrm.z, su.pn);
-                a.bbox[i] = bb[r];
                 for (int ty = su.py0 / kTile; ty <= su.py1 / kTile; ++ty)
                     for (int tx = su.px0 / kTile; tx <= su.px1 / kTile; ++tx) atomicAdd(&s_cnt[ty * a.tilesX + tx], 1);
             }
+            a.bbox[i] = bb[r];   // also for surfels that draw nothing (empty box): the overflow path of the tile pass scans every box
         }
     }
     __syncthreads();
@@ -118,8 +118,10 @@ __global__ __launch_bounds__(kBinThreads) void k_splat_bin(const BinArgs a) {
             for (int tx = bb[r].x / kTile; tx <= bb[r].y / kTile; ++tx) {
                 const int t = ty * a.tilesX + tx;
                 const int slot = s_cnt[t] + atomicAdd(&s_fill[t], 1);
+                // a full list is not an error and drops nothing: tile_count keeps counting, and a tile whose count exceeds its
+                // slice scans the sprite boxes of the whole map instead of its list (k_splat_tile); pad[1] only records that it happened
                 if (slot < a.tile_cap) a.entries[(size_t)t * a.tile_cap + slot] = idx[r];
-                else a.frame_rw->pad[1] = 1;   // list overflow: reported by mf_sync (never silently dropped)
+                else a.frame_rw->pad[1] = 1;
             }
     }
     __syncthreads();
@@ -155,23 +157,19 @@ __global__ __launch_bounds__(256) void k_splat_tile(const TileArgs a) {
         a.tile_count[tile] = 0;   // consumed: the binning pass of the next prediction starts from zero
     }
     __syncthreads();
-    const int cnt = min(s_range[0], a.tile_cap);
+    const bool overflow = s_range[0] > a.tile_cap;   // more sprites than list slots (the reference has no such limit): scan every box
+    const int cnt = overflow ? a.frame->count : s_range[0];
     const int* __restrict__ list = a.entries + (size_t)tile * a.tile_cap;
-    const float time = (float)a.frame->tick;
-    float Ri[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) Ri[q] = a.pose->Ri[q];
-    const float3 ti = f3(a.pose->ti[0], a.pose->ti[1], a.pose->ti[2]);
     const Intr k = a.k;
     for (int e = threadIdx.x; e < cnt; e += 256) {
-        const int i = list[e];
-        const float4 r0 = a.rec0[i], r1 = a.rec1[i];
+        const int i = overflow ? e : list[e];
         const short4 bb = a.bbox[i];
+        const int x0 = max((int)bb.x, tx0), x1 = min((int)bb.y, tx0 + kTile - 1);
+        const int y0 = max((int)bb.z, ty0), y1 = min((int)bb.w, ty0 + kTile - 1);
+        if (x0 > x1 || y0 > y1) continue;
+        const float4 r0 = a.rec0[i], r1 = a.rec1[i];
         SplatSetup su;
         su.h = f3(r0.x, r0.y, r0.z); su.sqrRad = r0.w; su.nrm = f3(r1.x, r1.y, r1.z); su.pn = r1.w;
-        su.px0 = bb.x; su.px1 = bb.y; su.py0 = bb.z; su.py1 = bb.w;
-        const int x0 = max(su.px0, tx0), x1 = min(su.px1, tx0 + kTile - 1);
-        const int y0 = max(su.py0, ty0), y1 = min(su.py1, ty0 + kTile - 1);
         for (int py = y0; py <= y1; ++py) {
             for (int px = x0; px <= x1; ++px) {
                 const int lp = (py - ty0) * kTile + (px - tx0);

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void k_fuse_data(const FuseDataArgs a) {
                     const float dist = norm3(cross3(ray, f3(vc.x, vc.y, vc.z)));
                     const float4 nr = nr9[q];
                     const float3 nn = f3(nr.x, nr.y, nr.z);
-                    const float ang = acosf(dot3(nn, nLocal) / (norm3(nn) * norm3(nLocal)));
+                    const float ang = shader_acos(dot3(nn, nLocal) / (norm3(nn) * norm3(nLocal)));
                     if (dist < bestDist && (fabsf(nr.z) < 0.75f || fabsf(ang) < 0.5f)) {
                         merge = true; bestDist = dist; best = current;
                     }

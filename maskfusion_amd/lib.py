@@ -85,6 +85,22 @@ SYMBOLS = {
     "mf_get_stream": (C.c_void_p, [C.c_void_p]),
     "mf_get_input_stream": (C.c_void_p, [C.c_void_p]),
     "mf_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]),
+    "mf_debug_read_model": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_void_p, C.c_uint64]),
+    "mf_stage_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mf_end_frame": (C.c_int, [C.c_void_p, C.c_int64]),
+    "mf_model_initialise": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mf_model_override_pose": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "mf_model_fusion_weight": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.POINTER(C.c_float)]),
+    "mf_model_perform_tracking": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_int32,
+                                            C.c_float, C.c_int64, C.c_int32]),
+    "mf_model_predict_indices": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32]),
+    "mf_model_fuse": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float]),
+    "mf_model_clean": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float]),
+    "mf_model_combined_predict": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_int32]),
+    "mf_model_upload_map": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32]),
+    "mf_make_nonstatic": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mf_make_static": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mf_set_trackable_class_ids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "mf_k_bilateral": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "mf_k_pyrdown_f": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "mf_k_vmap_nmap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float,

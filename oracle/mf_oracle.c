@@ -1019,12 +1019,50 @@ float mfo_get_radius(float depth, float norm_z, float fx, float fy) {
     radius_n = fminf(2.0f * radius, radius_n);
     return radius_n;
 }
+/* ---- exp() and acos() of the surfel shaders (surfels.glsl:44, data.vert:167): GLSL leaves their last bits to the GPU vendor.
+ * Both sides of the parity tests (oracle/mf_oracle.c and maskfusion_amd/csrc/mf_device.h) evaluate them with the SAME
+ * sequence of individually rounded fp32 operations (Cephes-style range reduction + polynomial, <= 2 ulp), so that a confidence
+ * or an angle test can never differ between them in the last bit -- which the life cycle of a surfel would amplify into a
+ * different keep / merge decision a few frames later. ---- */
+static inline float bits_to_float_(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline float shader_exp(float x) {
+    /* x <= 0 here (the argument is -(r/400)^2 / 0.72); valid for |x| < 87 */
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = x - n * 0.693359375f;
+    r = r - n * -2.12194440e-4f;
+    float p = 1.9875691500E-4f;
+    p = p * r + 1.3981999507E-3f;
+    p = p * r + 8.3334519073E-3f;
+    p = p * r + 4.1665795894E-2f;
+    p = p * r + 1.6666665459E-1f;
+    p = p * r + 5.0000001201E-1f;
+    const float y = p * (r * r) + r + 1.0f;
+    return y * bits_to_float_((unsigned)((int)n + 127) << 23);   /* exact scaling by 2^n */
+}
+static inline float shader_asin_core(float a) {
+    const float z = a * a;
+    float p = 4.2163199048E-2f;
+    p = p * z + 2.4181311049E-2f;
+    p = p * z + 4.5470025998E-2f;
+    p = p * z + 7.4953002686E-2f;
+    p = p * z + 1.6666752422E-1f;
+    return p * z * a + a;
+}
+static inline float shader_acos(float x) {
+    if (x > 0.5f) return 2.0f * shader_asin_core(sqrtf(0.5f * (1.0f - x)));
+    if (x < -0.5f) return 3.14159265358979323846f - 2.0f * shader_asin_core(sqrtf(0.5f * (1.0f + x)));
+    return 1.57079632679489661923f - shader_asin_core(x);   /* NaN falls through to here and stays NaN */
+}
+
+float mfo_shader_exp(float x) { return shader_exp(x); }
+float mfo_shader_acos(float x) { return shader_acos(x); }
+
 float mfo_confidence(float x, float y, float weighting, float cx, float cy) {
     const float maxRadDist = 400.f;        /* quirk Q6 */
     const float twoSigmaSquared = 0.72f;
     const float dx = x - cx, dy = y - cy;
     const float radialDist = sqrtf(dx * dx + dy * dy) / maxRadDist;
-    return expf(-(radialDist * radialDist) / twoSigmaSquared) * weighting;
+    return shader_exp(-(radialDist * radialDist) / twoSigmaSquared) * weighting;
 }
 
 /* nearest fetch with GL_CLAMP_TO_EDGE */
@@ -1193,7 +1231,7 @@ void mfo_fuse_data(const mfo_cam* c, const float* pose16, const uint8_t* rgb, co
                             const float dist = f3_norm(f3_cross(ray, f3_make(vc[0], vc[1], vc[2])));
                             const float* nr = normRad + tp * 4;
                             const f3 nn = f3_make(nr[0], nr[1], nr[2]);
-                            const float ang = acosf(f3_dot(nn, nLocal) / (f3_norm(nn) * f3_norm(nLocal)));
+                            const float ang = shader_acos(f3_dot(nn, nLocal) / (f3_norm(nn) * f3_norm(nLocal)));
                             if (dist < bestDist && (fabsf(nr[2]) < 0.75f || fabsf(ang) < 0.5f)) {
                                 operation = 1; bestDist = dist; best = current;
                             }
@@ -1583,6 +1621,7 @@ struct mfo_ctx {
     int lastFillIn;
     double tms[8];
     rgbd_scratch rs; uint8_t* lastNext[3]; mfo_track_stats stats;
+    const float* depthF_override;   /* test isolation: see mfo_override_filtered_depth */
 };
 
 void mfo_default_config(mfo_config* c, int W, int H, float fx, float fy, float cx, float cy) {
@@ -1708,7 +1747,8 @@ int mfo_process_frame_ex(mfo_ctx* x, const uint8_t* rgb, const float* depth, flo
     double t0 = now_ms();
     memcpy(x->rgb, rgb, (size_t)P * 3);
     memcpy(x->depth, depth, sizeof(float) * P);
-    mfo_bilateral(x->depth, x->depthF, W, H);            /* filterDepth, :217 */
+    if (x->depthF_override) { memcpy(x->depthF, x->depthF_override, sizeof(float) * P); x->depthF_override = NULL; }
+    else mfo_bilateral(x->depth, x->depthF, W, H);        /* filterDepth, :217 */
     memset(x->mask, 0, P);                                /* !enableMultipleModels, :223-230 */
     x->tms[0] += now_ms() - t0;
 
@@ -1722,7 +1762,7 @@ int mfo_process_frame_ex(mfo_ctx* x, const uint8_t* rgb, const float* depth, flo
         /* :413-415 -- Model::overridePose (Model.h:235-238): lastPose = pose; pose = inPose.  No tracking. */
         memcpy(x->lastPose, x->pose, sizeof(x->pose));
         memcpy(x->pose, inPose16, sizeof(x->pose));
-        oracle_fuse(x, weightMultiplier);
+        if (!g->rgbOnly) oracle_fuse(x, weightMultiplier);   /* :539: if (!rgbOnly && trackingOk && !lost) */
     } else {
         /* Model::generateCUDATextures(depthFiltered, mask, K, depthCutoff), Model.cpp:350-389 */
         t0 = now_ms();
@@ -1772,7 +1812,7 @@ int mfo_process_frame_ex(mfo_ctx* x, const uint8_t* rgb, const float* depth, flo
             mat4_mul_cm_early(x->pose, inPose16, np);
             memcpy(x->pose, np, sizeof(np));
         }
-        oracle_fuse(x, weightMultiplier);
+        if (!g->rgbOnly) oracle_fuse(x, weightMultiplier);   /* :539: if (!rgbOnly && trackingOk && !lost) */
     }
     t0 = now_ms();
     oracle_predict(x); /* :569 */
@@ -1780,6 +1820,11 @@ int mfo_process_frame_ex(mfo_ctx* x, const uint8_t* rgb, const float* depth, flo
     x->tick++;
     return 0;
 }
+
+/* Test isolation: the NEXT mfo_process_frame takes this image as the bilateral filter's output instead of running the filter
+ * (so that a pipeline-level comparison of the surfel life cycle is not perturbed by the 1e-6 difference between two exp()
+ * implementations; the filter itself is compared on its own).  The pointer must stay valid during that call. */
+void mfo_override_filtered_depth(mfo_ctx* x, const float* depthF) { x->depthF_override = depthF; }
 
 void mfo_get_pose(const mfo_ctx* x, float* p) { memcpy(p, x->pose, sizeof(x->pose)); }
 int mfo_get_count(const mfo_ctx* x) { return x->count; }
@@ -2325,7 +2370,8 @@ int mfo_mm_process_frame(mfo_mm* x, const uint8_t* rgb, const float* depth, cons
             for (int i = 1; i < x->nModels; ++i) x->models[i].confThr = fminf(4.5f, x->models[i].age / 25.0f); /* :369-374 */
         }
         /* fusion, :539-565 */
-        for (int i = 0; i < x->nModels; ++i) mm_fuse_clean(x, &x->models[i], g->depthCutoff, weightMultiplier, 1);
+        if (!g->rgbOnly)   /* :539: if (!rgbOnly && trackingOk && !lost); the spawn-frame fuse above is not under this guard */
+            for (int i = 0; i < x->nModels; ++i) mm_fuse_clean(x, &x->models[i], g->depthCutoff, weightMultiplier, 1);
     }
     /* predict(), :569 */
     for (int i = 0; i < x->nModels; ++i) {

@@ -150,6 +150,9 @@ typedef struct {
     float fx, fy, cx, cy;
 } mfo_cam;
 
+/* exp() / acos() as both sides of the parity tests evaluate them for surfels.glsl:44 and data.vert:167 (<= 2 ulp; see mf_oracle.c) */
+float mfo_shader_exp(float x);
+float mfo_shader_acos(float x);
 float mfo_encode_color(float r, float g, float b);            /* color_encoding.glsl:19-25 */
 void  mfo_decode_color(float c, float* rgb);                    /* color_encoding.glsl:27-34 */
 float mfo_get_radius(float depth, float norm_z, float fx, float fy); /* surfels.glsl:19-34 */
@@ -225,6 +228,8 @@ void     mfo_destroy(mfo_ctx* ctx);
 int      mfo_process_frame(mfo_ctx* ctx, const uint8_t* rgb, const float* depth, float weightMultiplier);
 int      mfo_process_frame_ex(mfo_ctx* ctx, const uint8_t* rgb, const float* depth, float weightMultiplier,
                               const float* inPose16 /*column-major or NULL*/, int bootstrap);
+/* test isolation: the next mfo_process_frame uses depthF (W*H) as the bilateral filter's output */
+void     mfo_override_filtered_depth(mfo_ctx* ctx, const float* depthF);
 void     mfo_get_pose(const mfo_ctx* ctx, float* pose16);
 int      mfo_get_count(const mfo_ctx* ctx);
 int      mfo_get_tick(const mfo_ctx* ctx);

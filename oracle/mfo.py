@@ -110,6 +110,7 @@ def lib():
     L.mfo_process_frame.restype = C.c_int
     L.mfo_process_frame_ex.argtypes = [C.c_void_p, u8p, f32p, C.c_float, f32p, C.c_int]
     L.mfo_process_frame_ex.restype = C.c_int
+    L.mfo_override_filtered_depth.argtypes = [C.c_void_p, f32p]
     L.mfo_get_pose.argtypes = [C.c_void_p, f32p]
     L.mfo_get_count.argtypes = [C.c_void_p]
     L.mfo_get_count.restype = C.c_int
@@ -267,7 +268,10 @@ class Oracle:
     def __del__(self):
         self.close()
 
-    def process_frame(self, rgb, depth, weight_multiplier=1.0, in_pose=None, bootstrap=False):
+    def process_frame(self, rgb, depth, weight_multiplier=1.0, in_pose=None, bootstrap=False, depth_filtered=None):
+        if depth_filtered is not None:   # test isolation: this frame's bilateral output is given (see mf_oracle.h)
+            self._dF = np.ascontiguousarray(depth_filtered, np.float32)
+            lib().mfo_override_filtered_depth(self.h, self._dF)
         if in_pose is None:
             return lib().mfo_process_frame(self.h, np.ascontiguousarray(rgb, np.uint8),
                                            np.ascontiguousarray(depth, np.float32), weight_multiplier)
@@ -319,3 +323,78 @@ class Oracle:
         if what == "fillin":
             return L.mfo_dbg_last_fillin(self.h)
         raise KeyError(what)
+
+
+# ------------------------------------------------------------------------------------------------
+# surfel passes, one call each (for the per-pass differential tests)
+# ------------------------------------------------------------------------------------------------
+def predict_indices(camera: Cam, T, surfels, count, time, max_depth, time_delta):
+    """-> index (H,W) int32, vertConf, colorTime, normRad (H,W,4) float32"""
+    H, W = camera.H, camera.W
+    idx = np.zeros((H, W), np.int32)
+    vc, ct, nr = (np.zeros((H, W, 4), np.float32) for _ in range(3))
+    lib().mfo_predict_indices(C.byref(camera), pose16(T), np.ascontiguousarray(surfels, np.float32).reshape(-1), count, time,
+                              max_depth, time_delta, idx, vc.reshape(-1), ct.reshape(-1), nr.reshape(-1))
+    return idx, vc, ct, nr
+
+
+def n_candidates(W, H, time):
+    par = time & 1
+    return ((W - par + 1) // 2) * ((H - par + 1) // 2)
+
+
+def fuse_data(camera: Cam, T, rgb, depth_raw, depth_f, mask, mask_id, time, weighting, max_depth, idx, vc, nr):
+    """-> cand_op (n,), cand_best (n,), cand_rec (n,12); candidates in column-major order of the quarter-rate pixels"""
+    maxc = ((camera.W + 1) // 2) * ((camera.H + 1) // 2)
+    op = np.zeros(maxc, np.uint8)
+    best = np.zeros(maxc, np.int32)
+    rec = np.zeros((maxc, 12), np.float32)
+    n = C.c_int(0)
+    lib().mfo_fuse_data(C.byref(camera), pose16(T), np.ascontiguousarray(rgb, np.uint8).reshape(-1), np.ascontiguousarray(depth_raw, np.float32).reshape(-1),
+                        np.ascontiguousarray(depth_f, np.float32).reshape(-1), np.ascontiguousarray(mask, np.uint8).reshape(-1), mask_id, time,
+                        weighting, max_depth, np.ascontiguousarray(idx, np.int32).reshape(-1), np.ascontiguousarray(vc, np.float32).reshape(-1),
+                        np.ascontiguousarray(nr, np.float32).reshape(-1), op, best, rec.reshape(-1), C.byref(n))
+    return op[:n.value], best[:n.value], rec[:n.value]
+
+
+def fuse_update(surfels, count, time, op, best, rec):
+    src = np.ascontiguousarray(surfels, np.float32).reshape(-1)
+    dst = np.zeros_like(src)
+    lib().mfo_fuse_update(src, dst, count, time, np.ascontiguousarray(op), np.ascontiguousarray(best), np.ascontiguousarray(rec, np.float32).reshape(-1),
+                          len(op))
+    return dst.reshape(-1, 12)
+
+
+def clean(camera: Cam, T, surfels, count, op, rec, time, time_delta, conf_threshold, max_depth, outlier_coeff, mask_id, idx, vc, ct, nr,
+          depth_f, mask, capacity):
+    dst = np.zeros((capacity, 12), np.float32)
+    g = lambda a, t: np.ascontiguousarray(a, t).reshape(-1)
+    n = lib().mfo_clean(C.byref(camera), pose16(T), g(surfels, np.float32), count, np.ascontiguousarray(op), g(rec, np.float32), len(op), time,
+                        time_delta, conf_threshold, max_depth, outlier_coeff, mask_id, g(idx, np.int32), g(vc, np.float32), g(ct, np.float32),
+                        g(nr, np.float32), g(depth_f, np.float32), g(mask, np.uint8), dst.reshape(-1), capacity)
+    return dst[:n].copy(), n
+
+
+def combined_predict(camera: Cam, T, surfels, count, max_depth, conf_threshold, time, max_time, time_delta):
+    """-> image (H,W,4) u8, vertexConf, normalRad (H,W,4) f32, time (H,W) u16"""
+    H, W = camera.H, camera.W
+    img = np.zeros((H, W, 4), np.uint8)
+    v, n = np.zeros((H, W, 4), np.float32), np.zeros((H, W, 4), np.float32)
+    tm = np.zeros((H, W), np.uint16)
+    lib().mfo_combined_predict(C.byref(camera), pose16(T), np.ascontiguousarray(surfels, np.float32).reshape(-1), count, max_depth, conf_threshold,
+                               time, max_time, time_delta, img.reshape(-1), v.reshape(-1), n.reshape(-1), tm.reshape(-1))
+    return img, v, n, tm
+
+
+def fill_in(camera: Cam, pred_image, pred_vertex, pred_normal, raw_rgb, raw_depth, passthrough=False):
+    H, W = camera.H, camera.W
+    fi = np.zeros((H, W, 4), np.uint8)
+    fv, fn = np.zeros((H, W, 4), np.float32), np.zeros((H, W, 4), np.float32)
+    g = lambda a, t: np.ascontiguousarray(a, t).reshape(-1)
+    lib().mfo_fill_in(C.byref(camera), g(pred_image, np.uint8), g(pred_vertex, np.float32), g(pred_normal, np.float32), g(raw_rgb, np.uint8),
+                      g(raw_depth, np.float32), int(passthrough), fi.reshape(-1), fv.reshape(-1), fn.reshape(-1))
+    return fi, fv, fn
+
+
+def fusion_weight(T, T_last, weight_multiplier=1.0) -> float:
+    return float(lib().mfo_fusion_weight(pose16(T), pose16(T_last), weight_multiplier))

@@ -95,7 +95,7 @@ def test_pose_tracks_oracle(run):
     # frame over frame, so the per-frame gate applies to the first frames and the sequence gate is the north-star one.
     assert d[:4].max() < 1e-4                      # first tracked frames: within float noise of the oracle
     assert abs(ate_g - ate_o) < 1e-3               # north_star: ATE RMSE delta < 1 mm
-    assert ate_vs_oracle < 2e-3
+    assert ate_vs_oracle < 1e-3                    # ... and the HIP trajectory itself within 1 mm RMSE of the oracle's
     assert run["gfill"] == run["ofill"]
 
 
@@ -167,3 +167,90 @@ def test_pipeline_width_not_multiple_of_64(hip, oracle):
             assert np.abs(o.pose - mf.getCurrPose()).max() < 1e-4, (cfg, k)
             assert abs(o.count - mf.getBackgroundModel().lastCount()) <= max(20, 0.005 * o.count), (cfg, k)
         o.close(); mf.close()
+
+
+def _cloud_run(oracle, res, noise, n_frames, shared_filter):
+    from maskfusion_amd import MaskFusion
+    W, H = res
+    st, frames = scene_frames(n_frames, W=W, H=H, noise=noise)
+    cap = 1 << (20 if W == 640 else 22)
+    o = oracle.Oracle(W, H, st.fx, st.fy, st.cx, st.cy, icpWeight=100.0, capacity=cap, so3=0, confGlobal=2.0)
+    m = MaskFusion(W, H, st.fx, st.fy, st.cx, st.cy, icpThresh=100.0, so3=False, numGSurfels=cap, enableMultipleModels=False,
+                   initConfidenceGlobal=2.0)
+    for k, (rgb, depth, _) in enumerate(frames):
+        T = st.gt_pose(k).astype(np.float32)
+        m.processFrame(rgb, depth, inPose=T if k else None, timestamp=k)
+        o.process_frame(rgb, depth, in_pose=T if k else None, depth_filtered=m.debugRead("depthF") if shared_filter else None)
+        yield k, m.getBackgroundModel(), o
+    o.close(); m.close()
+
+
+@pytest.mark.parametrize("res", [(640, 480), (1280, 960)], ids=["vga", "1280x960"])
+@pytest.mark.parametrize("noise", [False, True], ids=["clean", "noisy"])
+def test_fused_cloud_matches_oracle_with_given_poses(hip, oracle, res, noise):
+    """north_star "fused surfel clouds match": both sides are handed the SAME camera pose every frame (processFrame's inPose,
+    MaskFusion.cpp:413-415) and the same bilateral-filter output (the oracle takes the device's; the filter is compared on its
+    own to 2e-5, and the next test shows what its last-bit differences do), so the whole surfel life cycle -- index map,
+    association, update, clean, compaction order -- must produce the same cloud: count exact on EVERY frame, every surfel in
+    the same slot with position / confidence / normal / radius to 1e-6 and colour / time stamps exact."""
+    W, H = res
+    n_frames = 25 if W == 640 else 12
+    counts = []
+    for k, bg, o in _cloud_run(oracle, res, noise, n_frames, True):
+        gc, oc = bg.lastCount(), o.count
+        counts.append((gc, oc))
+        assert gc == oc, (k, counts)
+        if k in (1, n_frames // 2, n_frames - 1):
+            a, b = bg.downloadMap(), o.surfels()
+            assert np.array_equal(a[:, 4:8], b[:, 4:8]), k
+            assert np.abs(a[:, :4] - b[:, :4]).max() <= 1e-6 * max(1.0, np.abs(b[:, :4]).max()), k
+            ok = np.isfinite(b[:, 8:]).all(1)
+            assert np.array_equal(ok, np.isfinite(a[:, 8:]).all(1))
+            assert np.abs(a[ok, 8:] - b[ok, 8:]).max() <= 1e-6, k
+    print("counts (hip, oracle)", counts[-3:])
+    assert counts[-1][1] > (300_000 if W == 640 else 1_000_000)
+
+
+@pytest.mark.parametrize("noise", [False, True], ids=["clean", "noisy"])
+def test_fused_cloud_with_own_filters_differs_only_by_threshold_flips(hip, oracle, noise):
+    """Same run with each side filtering the depth itself (v_exp_f32 vs libm expf: <= 2e-5 relative): the clouds then differ,
+    but only by surfels whose keep / merge decision sat on a threshold -- a few per 100 000 -- and every surfel the two maps
+    share agrees to float noise.  This is the whole effect behind the count drift the round-1 pipeline test saw."""
+    n_frames = 12
+    for k, bg, o in _cloud_run(oracle, (640, 480), noise, n_frames, False):
+        gc, oc = bg.lastCount(), o.count
+        assert abs(gc - oc) <= 1e-2 * oc, (k, gc, oc)
+        if k == n_frames - 1:
+            a, b = bg.downloadMap(), o.surfels()
+            from collections import Counter
+            key = lambda s: Counter(map(tuple, np.concatenate([s[:, [4, 6]], np.round(s[:, :3] * 500.0)], axis=1).astype(np.int64).tolist()))
+            ka, kb = key(a), key(b)          # (colour, initTime, position to 2 mm): surfels present on both sides cancel
+            one_sided = sum(((ka - kb) + (kb - ka)).values())
+            kp = lambda s: Counter(map(tuple, np.round(s[:, :3] * 100.0).astype(np.int64).tolist()))
+            pa, pb = kp(a), kp(b)            # occupancy of 1 cm cells: the two maps cover the same surface
+            cells = sum(((pa - pb) + (pb - pa)).values())
+            print("own filters: hip", gc, "oracle", oc, "surfels without a twin on the other side", one_sided, "occupancy difference", cells)
+            assert cells < 3e-2 * oc
+            if noise:   # the noise-free stream is made of exact depth / colour ties, where a last-bit change re-times thousands of surfels
+                assert one_sided < 1e-2 * oc
+
+
+def test_rgb_only_skips_fusion(hip, oracle):
+    """MaskFusion.cpp:539: `if (!rgbOnly && trackingOk && !lost)` -- with rgbOnly the map is neither fused nor cleaned: the
+    surfel buffer stays what the first frame made it, on both sides."""
+    from maskfusion_amd import MaskFusion
+    st, frames = scene_frames(4, noise=True)
+    o = oracle.Oracle(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpWeight=10.0, capacity=1 << 20, so3=0, rgbOnly=1)
+    m = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=10.0, so3=False, numGSurfels=1 << 20, enableMultipleModels=False,
+                   rgbOnly=True)
+    first = None
+    for k, (rgb, depth, _) in enumerate(frames):
+        o.process_frame(rgb, depth)
+        m.processFrame(rgb, depth)
+        cloud = m.getBackgroundModel().downloadMap()
+        if first is None:
+            first = cloud
+        assert o.count == len(first) == m.getBackgroundModel().lastCount()
+        assert np.array_equal(cloud, first, equal_nan=True)
+    assert np.abs(m.getCurrPose() - o.pose).max() < 1e-3
+    o.close(); m.close()

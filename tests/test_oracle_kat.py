@@ -4,6 +4,7 @@ The reference ships no tests / golden vectors and cannot be built here (SURVEY.m
 by closed-form answers that follow from the reference's formulas (cited per test), not by reference outputs.
 All tests run on CPU in seconds.
 """
+import ctypes as C
 import numpy as np
 import pytest
 
@@ -349,3 +350,23 @@ def test_pipeline_tracks_ground_truth(oracle):
     assert synth.ate_rmse(np.array(est), np.array(gt)) < 2e-3
     assert o.tick == 13 and o.count > W * H
     o.close()
+
+
+def test_shader_exp_and_acos_are_accurate(oracle):
+    """The shared deterministic exp / acos of the surfel shaders (surfels.glsl:44, data.vert:167) stay within 2 ulp of the
+    correctly rounded functions over the ranges the shaders use."""
+    L = oracle.lib()
+    for f in (L.mfo_shader_exp, L.mfo_shader_acos):
+        f.restype = C.c_float
+        f.argtypes = [C.c_float]
+    rs = np.random.RandomState(3)
+    xs = -(rs.rand(20000).astype(np.float32) * 30)
+    e = np.array([L.mfo_shader_exp(float(x)) for x in xs], np.float32)
+    ref = np.exp(xs.astype(np.float64))
+    assert (np.abs(e - ref) / np.spacing(ref.astype(np.float32))).max() < 2.0
+    cs = rs.rand(20000).astype(np.float32) * 2 - 1
+    a = np.array([L.mfo_shader_acos(float(c)) for c in cs], np.float32)
+    ref = np.arccos(cs.astype(np.float64))
+    assert (np.abs(a - ref) / np.spacing(ref.astype(np.float32))).max() < 2.0
+    assert L.mfo_shader_exp(0.0) == 1.0 and L.mfo_shader_acos(1.0) == 0.0
+    assert np.isnan(L.mfo_shader_acos(float("nan"))) and np.isnan(L.mfo_shader_acos(1.5))
