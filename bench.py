@@ -1,21 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of the MaskFusion::processFrame hot path on MI355X (driver contract: see task statement).
 
-Workload (BASELINE.json configs[1]): synthetic 640x480 RGB-D stream, one background model (-static), geometric ICP
-(icpWeight = 100) + surfel fusion, precomputed empty masks.  A "step" = one processFrame over one frame whose rgb /
-depth already sit in HBM.  N > 1 (weak scaling): every rank owns one surfel model (the reference's per-model
-independence) and tracks/fuses it against the frame that rank 0 broadcasts over RCCL each step;
-value = model-frames of all ranks / max-over-ranks time.
+Workloads (BASELINE.json `configs`):
+  --config 1  (default, the metric's) synthetic 640x480 RGB-D stream S1 (600 frames, Kinect-like noise), one
+              background model (-static), geometric ICP (icpWeight = 100) + surfel fusion, precomputed empty masks.
+  --config 2s S2 on ONE GPU: the same room with 8 rigid moving objects and their instance masks; background + 8 object
+              models, trackAllModels, geometric ICP -- the multi-model path (global projection, label stage, per-model fusion)
+              with the Gauss-Newton loops of all 9 models batched into one launch per iteration.
+  --config 4  the per-GPU share of configs[4]: 1280x960 stream, NUM_GSURFELS = 32M.
+A "step" = one processFrame over one frame whose rgb / depth (/ mask) already sit in HBM.  The timed region is `--steps` steps,
+repeated as a whole until it has lasted at least `--min-seconds` (a 6 ms region says little); `steps` in the JSON line is the
+number of steps actually timed.  N > 1 (weak scaling): every rank owns one surfel model (the reference's per-model independence,
+SURVEY.md 8e) and tracks / fuses it against the frame rank 0 broadcasts over RCCL each step; value = model-frames of all ranks
+/ max-over-ranks time.
 
 The JSON line also carries
-  roofline     -- the dominant kernel (the ICP Gauss-Newton iteration): algorithmic bytes per launch / average launch
-                  duration measured here with HIP events on the library's stream, against the 8 TB/s HBM peak;
-  cpu_baseline -- the oracle (CPU restatement, oracle/) timed on this box's host cores on a bounded sample.
+  roofline       -- the dominant kernel (the ICP Gauss-Newton iteration): algorithmic bytes per launch / average launch duration
+                    measured here with HIP events on the library's stream, against the 8 TB/s HBM peak; `traffic` = HBM bytes
+                    per launch from the committed PMC profile (profiles/r02_pmc.json) when it was taken on this kernel;
+  roofline_frame -- the same for the whole frame: (741 P + 192 N) algorithmic bytes / frame time;
+  host_input     -- frames/s through mf_process_frame (host pointers: 2.15 MB of H2D per frame + one sync), beside `value`;
+  cpu_baseline   -- the oracle (CPU restatement, oracle/; a -O3 -march=native timing build) on this box's host cores.
 """
 from __future__ import annotations
 
 import argparse
 import json
+import multiprocessing as mp
 import os
 import sys
 import time
@@ -25,28 +36,41 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-W, H = 640, 480
-FX = FY = 528.0
-CX, CY = 320.0, 240.0
-SURFELS = 9437184      # MASKFUSION_NUM_GSURFELS default
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-WORKLOAD = ("configs[1]: synthetic 640x480 RGB-D stream (S1, Kinect-like noise), 1 background model per GPU, icpWeight=100 "
-            "(geometric ICP 4/5/10 iterations) + surfel fusion, empty masks")
+
+CONFIGS = {
+    "1": dict(W=640, H=480, f=528.0, surfels=9437184, n_objects=0, frames=600,
+              workload="configs[1]: synthetic 640x480 RGB-D stream (S1: 600 frames, Kinect-like noise), 1 background model per GPU, "
+                       "icpWeight=100 (geometric ICP 4/5/10 iterations) + surfel fusion, empty masks"),
+    "2s": dict(W=640, H=480, f=528.0, surfels=9437184, n_objects=8, frames=120,
+               workload="S2 on one GPU (SURVEY.md 8d): synthetic 640x480 RGB-D stream, 8 rigid moving objects with instance masks, "
+                        "background + 8 object models, trackAllModels, icpWeight=100, global projection + label stage + per-model fusion"),
+    "4": dict(W=1280, H=960, f=1056.0, surfels=32 * 1024 * 1024, n_objects=0, frames=200,
+              workload="configs[4] (per GPU): synthetic 1280x960 RGB-D stream (S3 scaling of S1), 1 model per GPU, NUM_GSURFELS=32M, "
+                       "icpWeight=100 + surfel fusion, empty masks"),
+}
 
 
-def select_config(n):
-    """--config 4: the per-GPU share of BASELINE.json configs[4] (1280x960 stream, NUM_GSURFELS = 32M); default configs[1]."""
-    global W, H, FX, FY, CX, CY, SURFELS, WORKLOAD
-    if n == 4:
-        W, H, FX, FY, CX, CY, SURFELS = 1280, 960, 1056.0, 1056.0, 640.0, 480.0, 32 * 1024 * 1024
-        WORKLOAD = ("configs[4] (per GPU): synthetic 1280x960 RGB-D stream (S3 scaling of S1), 1 model per GPU, NUM_GSURFELS=32M, "
-                    "icpWeight=100 + surfel fusion, empty masks")
-
-
-def gen_frames(n, seed=1234):
+def _render(args):
+    cfg, k = args
     from maskfusion_amd import synth
-    st = synth.Stream(W=W, H=H, fx=FX, fy=FY, cx=CX, cy=CY, noise=True, seed=seed)
-    return st, [st.frame(k) for k in range(n)]
+    st = synth.Stream(W=cfg["W"], H=cfg["H"], fx=cfg["f"], fy=cfg["f"], cx=cfg["W"] / 2.0, cy=cfg["H"] / 2.0, noise=True,
+                      n_objects=cfg["n_objects"], seed=1234)
+    return st.frame(k)
+
+
+def gen_frames(cfg, n):
+    """n frames of the synthetic stream, ray-cast in parallel on the host cores (must run before CUDA is initialised: fork)."""
+    from maskfusion_amd import synth
+    st = synth.Stream(W=cfg["W"], H=cfg["H"], fx=cfg["f"], fy=cfg["f"], cx=cfg["W"] / 2.0, cy=cfg["H"] / 2.0, noise=True,
+                      n_objects=cfg["n_objects"], seed=1234)
+    workers = max(1, min(48, (os.cpu_count() or 1) - 2, n))
+    if workers > 1:
+        with mp.get_context("fork").Pool(workers) as pool:
+            frames = pool.map(_render, [(cfg, k) for k in range(n)], chunksize=max(1, n // (4 * workers)))
+    else:
+        frames = [st.frame(k) for k in range(n)]
+    return st, frames
 
 
 def pingpong(n_frames, steps):
@@ -60,66 +84,94 @@ def pingpong(n_frames, steps):
     return idx
 
 
-def cpu_baseline(frames, max_seconds=20.0):
-    """Oracle (port) frames/s on the host cores, bounded sample.  The OpenMP thread count is calibrated first (the oracle's
-    parallel regions are short per-kernel loops: on a 256-thread box fewer threads can be faster than all of them)."""
+def cpu_baseline(cfg, frames, max_seconds=20.0):
+    """Oracle (port) frames/s on the host cores, bounded sample, from a separate -O3 -march=native build (oracle/mfo.py:
+    build_fast; the parity build keeps -O2 -ffp-contract=off).  The OpenMP thread count is swept up to every hardware thread on
+    2-frame probes first: the oracle's parallel regions are short per-kernel loops, more threads are not always faster."""
     import ctypes
     from oracle import mfo
+    W, H, F = cfg["W"], cfg["H"], cfg["f"]
+    fast = mfo.use_fast_build()
     ncpu = os.cpu_count() or 1
     try:
         gomp = ctypes.CDLL("libgomp.so.1")
     except OSError:
         gomp = None
-    o = mfo.Oracle(W, H, FX, FY, CX, CY, icpWeight=100.0, capacity=(1 << 20) * (W * H // 307200), so3=0)
+    o = mfo.Oracle(W, H, F, F, W / 2.0, H / 2.0, icpWeight=100.0, capacity=(1 << 20) * (W * H // 307200), so3=0)
     o.process_frame(frames[0][0], frames[0][1])  # init frame, untimed
     order = pingpong(len(frames), 1000)[1:]
     pos = 0
     threads = ncpu
-    if gomp is not None and ncpu > 8:
+    sweep = {}
+    if gomp is not None and ncpu > 4:
         best = None
-        for cand in sorted({min(ncpu, c) for c in (8, 32, 96)} | {ncpu}):
+        for cand in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)} | {ncpu}):
             gomp.omp_set_num_threads(cand)
             t0 = time.time()
             for _ in range(2):
                 k = order[pos]; pos += 1
                 o.process_frame(frames[k][0], frames[k][1])
             dt = time.time() - t0
+            sweep[cand] = round(2.0 / dt, 2)
             if best is None or dt < best[0]:
                 best = (dt, cand)
         threads = best[1]
         gomp.omp_set_num_threads(threads)
     t0 = time.time()
     n = 0
-    while n < 40 and time.time() - t0 < max_seconds:
+    while n < 60 and time.time() - t0 < max_seconds:
         k = order[pos]; pos += 1
         o.process_frame(frames[k][0], frames[k][1])
         n += 1
     dt = time.time() - t0
     o.close()
     return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{n} frames of the same {W}x{H} synthetic stream after 1 init frame (OpenMP oracle, {threads} of {ncpu} "
-                      f"hardware threads, thread count calibrated on 2-frame probes)"}
+            "sample": f"{n} frames of the same {W}x{H} synthetic stream after 1 init frame; OpenMP oracle, "
+                      f"{'-O3 -march=native build' if fast else 'parity build (-O2, no -march)'}, {threads} of {ncpu} hardware threads "
+                      f"(sweep frames/s by thread count: {sweep})"}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (separate rocprofv3 --pmc passes, gfx950 corrections applied
+    when the file was written; see profiles/README.md).  None when there is no such record."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+    try:
+        rec = json.load(open(path))["kernels"][kernel]
+        return {"bytes_per_launch": rec["fetch_bytes"] + rec["write_bytes"], "fetch_bytes": rec["fetch_bytes"], "write_bytes": rec["write_bytes"],
+                "source": f"profiles/r02_pmc.json ({rec.get('note', '')})"}
+    except Exception:
+        return None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--frames", type=int, default=24, help="distinct synthetic frames kept in HBM (ping-ponged)")
-    ap.add_argument("--config", type=int, default=1, choices=(1, 4), help="BASELINE.json config (1 = the metric's; 4 = 1280x960 stress)")
+    ap.add_argument("--steps", type=int, default=600)
+    ap.add_argument("--warmup", type=int, default=60)
+    ap.add_argument("--frames", type=int, default=0, help="distinct synthetic frames kept in HBM (0: the config's default; ping-ponged)")
+    ap.add_argument("--config", default="1", choices=tuple(CONFIGS), help="workload (1 = the metric's)")
+    ap.add_argument("--min-seconds", type=float, default=2.0, help="the timed region is repeated until it has lasted this long")
     ap.add_argument("--icp-weight", type=float, default=100.0, help="icpWeight (>= 100: geometric term only, the metric's setting; "
                     "the reference GUI default is 20: photometric term on, two launches per Gauss-Newton iteration)")
     ap.add_argument("--so3", action="store_true", help="SO(3) photometric pre-alignment (reference default: on)")
+    ap.add_argument("--no-batch", action="store_true", help="config 2s: track the models one after the other (A/B of the batched loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-host-input", action="store_true")
     args = ap.parse_args()
-    select_config(args.config)
+    cfg = CONFIGS[args.config]
+    W, H, F = cfg["W"], cfg["H"], cfg["f"]
+    CX, CY = W / 2.0, H / 2.0
+    multi = cfg["n_objects"] > 0
+    n_frames = args.frames or cfg["frames"]
 
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # the stream is ray-cast before CUDA exists in this process (the generator forks); only rank 0 owns frames
+    st, frames = gen_frames(cfg, n_frames) if rank == 0 else (None, None)
+
+    import torch
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -132,28 +184,46 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from maskfusion_amd import MaskFusion
-    st, frames = gen_frames(args.frames)
-    d_rgb = [torch.from_numpy(f[0]).to(dev) for f in frames]
-    d_depth = [torch.from_numpy(f[1]).to(dev) for f in frames]
-    mf = MaskFusion(W, H, FX, FY, CX, CY, icpThresh=args.icp_weight, so3=args.so3, device=local_rank, enableMultipleModels=False,
-                    numGSurfels=SURFELS)
-    # Every rank owns one model.  Rank 0 owns the input stream and publishes frame k to all ranks (RCCL broadcast over xGMI
+    d_rgb = d_depth = d_mask = None
+    if rank == 0:
+        d_rgb = [torch.from_numpy(f[0]).to(dev) for f in frames]
+        d_depth = [torch.from_numpy(f[1]).to(dev) for f in frames]
+        if multi:
+            d_mask = [torch.from_numpy(f[2]).to(dev) for f in frames]
+    if multi:
+        # trackAllModels, confO = 0.01, confG = 10; the GUI's segmentation parameters (GUI/Tools/GUI.h:367-374) with
+        # a new-model size that fits 0.2-0.35 m boxes at VGA; a short spawn offset so that all objects exist after the warm-up
+        mf = MaskFusion(W, H, F, F, CX, CY, icpThresh=args.icp_weight, so3=args.so3, device=local_rank, enableMultipleModels=True,
+                        numGSurfels=cfg["surfels"], numOSurfels=1 << 20, trackAllModels=True, modelSpawnOffset=2, initConfidenceGlobal=10.0,
+                        initConfidenceObject=0.01)
+        for k, v in (("mfThreshold", 0.3), ("mfWeightDistance", 150.0), ("mfWeightConvexity", 2.8), ("mfMorphEdgeIterations", 0),
+                     ("mfMorphMaskIterations", 0), ("newModelMinRelativeSize", 0.004), ("batchTracking", 0 if args.no_batch else 1)):
+            mf.setParam(k, v)
+        mf.preallocateModels(cfg["n_objects"])
+        mf.setMaskClassIDs([0] + [41 + i for i in range(cfg["n_objects"])])
+    else:
+        mf = MaskFusion(W, H, F, F, CX, CY, icpThresh=args.icp_weight, so3=args.so3, device=local_rank, enableMultipleModels=False,
+                        numGSurfels=cfg["surfels"])
+    # Every rank owns one context.  Rank 0 owns the input stream and publishes frame k to all ranks (RCCL broadcast over xGMI
     # when N > 1) on the library's INPUT stream into a ring of 3 buffers; each rank then enqueues processFrame, whose main
     # stream is torch's current stream for the gather of the per-model state record.  Collectives and kernels are ordered
     # by the streams alone (no host synchronisation inside the timed region).
     from maskfusion_amd import dist as mfd
-    order = pingpong(args.frames, args.warmup + args.steps + 128)
+    order = pingpong(n_frames, 1 << 16)
     ext = torch.cuda.ExternalStream(mf.stream(), device=dev)
     ext_in = torch.cuda.ExternalStream(mf.inputStream(), device=dev)
     loop_state = {}
     cursor = [0]
 
     def get_frame(_i):
-        k = order[cursor[0]]
+        k = order[cursor[0] % len(order)]
         return d_rgb[k], d_depth[k]
 
     def model_step(rgb, depth, stats):
-        mf.processFrameDevice(rgb.data_ptr(), depth.data_ptr())
+        if multi:
+            mf.processFrameDevice(rgb.data_ptr(), depth.data_ptr(), d_mask[order[cursor[0] % len(order)]].data_ptr())
+        else:
+            mf.processFrameDevice(rgb.data_ptr(), depth.data_ptr())
         if world > 1:
             mf.modelStateDevice(0, stats.data_ptr())   # 64 B record for the gather; single GPU reads the pinned mirror
         cursor[0] += 1
@@ -170,57 +240,100 @@ def main():
 
     run(args.warmup)
     barrier()
-    t0 = time.perf_counter()
-    gathered = run(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    dt = mfd.max_over_ranks(dt, dev)
-    fps = world * args.steps / dt
+    # timed region: `steps` steps between barriers, repeated (each repetition bracketed the same way) until min_seconds have passed;
+    # every rank runs the same number of repetitions (the decision is taken on the max-over-ranks time)
+    total_steps, total_dt = 0, 0.0
+    while True:
+        barrier()
+        t0 = time.perf_counter()
+        run(args.steps)
+        barrier()
+        dt = mfd.max_over_ranks(time.perf_counter() - t0, dev)
+        total_steps += args.steps
+        total_dt += dt
+        if total_dt >= args.min_seconds or total_steps >= 200 * args.steps:
+            break
+    fps = world * total_steps / total_dt
 
-    # sanity: the tracked pose must still follow the synthetic ground truth (a fast wrong answer is worthless)
-    pose = mf.getCurrPose()
-    gt = st.gt_pose(order[cursor[0] - 1])
-    drift = float(np.linalg.norm(pose[:3, 3] - gt[:3, 3]))
-    count = mf.getBackgroundModel().lastCount()
+    n_models = len(mf.getModels())
+    count = sum(m.lastCount() for m in mf.getModels())
+    drift = None
+    if rank == 0:
+        # sanity: the tracked pose must still follow the synthetic ground truth (a fast wrong answer is worthless)
+        pose = mf.getCurrPose()
+        gt = st.gt_pose(order[(cursor[0] - 1) % len(order)])
+        drift = float(np.linalg.norm(pose[:3, 3] - gt[:3, 3]))
 
-    roofline = None
+    roofline = roofline_frame = None
+    P = W * H
     if rank == 0 and not args.no_roofline and args.icp_weight >= 100.0:
-        # instrumented pass over the same steps: per-stage HIP events on the library stream
+        # instrumented pass over the same stream: per-stage HIP events on the library's own stream
         mf.enableTimings(True)
         acc = {}
-        n = min(args.steps, 100)
+        n = 100
+        t_frames = 0.0
         for i in range(n):
-            k = order[cursor[0]]
+            k = order[cursor[0] % len(order)]
             cursor[0] += 1
-            mf.processFrameDevice(d_rgb[k].data_ptr(), d_depth[k].data_ptr())
+            if multi:
+                mf.processFrameDevice(d_rgb[k].data_ptr(), d_depth[k].data_ptr(), d_mask[k].data_ptr())
+            else:
+                mf.processFrameDevice(d_rgb[k].data_ptr(), d_depth[k].data_ptr())
             for kx, v in mf.timings().items():
                 acc[kx] = acc.get(kx, 0.0) + v
         mf.enableTimings(False)
         stages = {kx: v / n for kx, v in acc.items()}
-        P = W * H
-        icp_bytes = 552 * P          # (10 + 5/4 + 4/16) * 48 B * P per model-frame
+        n_tracked = len(mf.getModels())            # config 1 / 4: the background; 2s: every model (trackAllModels)
+        icp_bytes = 552 * P * n_tracked            # (10 + 5/4 + 4/16) * 48 B * P per model-frame
         n_launch = 19
-        t_icp = stages["icpIterations"] * 1e-3 / n_launch   # HIP events around the 19 iteration launches on the library's stream
+        t_icp = stages["icpIterations"] * 1e-3 / n_launch   # HIP events around the 19 iterations on the library's stream
         achieved = icp_bytes / n_launch / t_icp / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_icp_iter (19 launches/frame, L2:4 L1:5 L0:10)",
+        batched = multi and not args.no_batch
+        kname = "k_icp_batch_solve + k_icp_batch_pixels" if batched else "k_icp_iter"
+        roofline = {"bound": "hbm", "kernel": f"{kname} (19 iterations/frame, L2:4 L1:5 L0:10; {n_tracked} model(s) per launch)" if batched
+                    else f"{kname} (19 launches per model and frame, L2:4 L1:5 L0:10)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None, "stage_ms": stages}
+                    "algorithmic_bytes_per_launch": icp_bytes / n_launch, "us_per_launch": t_icp * 1e6,
+                    "traffic": pmc_traffic("k_icp_iter") if not batched else pmc_traffic("k_icp_batch_pixels"), "stage_ms": stages}
+        frame_bytes = 741 * P * n_tracked + 192 * count
+        roofline_frame = {"bound": "hbm", "algorithmic_bytes": frame_bytes, "ms": 1e3 * total_dt / total_steps,
+                          "achieved": frame_bytes / (total_dt / total_steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": frame_bytes / (total_dt / total_steps) / 1e9 / HBM_PEAK_GBS,
+                          "note": "(741 P per tracked model + 192 N) bytes per frame, SURVEY.md 8d; N = live surfels of all models"}
+
+    host_input = None
+    if rank == 0 and world == 1 and not args.no_host_input:
+        # the reference's own boundary: FrameData in host memory (MaskFusion.cpp:212-216 uploads it every frame)
+        n = 150
+        ks = [order[(cursor[0] + i) % len(order)] for i in range(n)]
+        cursor[0] += n
+        cls = [0] + [41 + i for i in range(cfg["n_objects"])]
+        mf.sync()
+        t0 = time.perf_counter()
+        for k in ks:
+            if multi:
+                mf.processFrame(frames[k][0], frames[k][1], mask=frames[k][2], classIDs=cls)
+            else:
+                mf.processFrame(frames[k][0], frames[k][1])
+        dt_h = time.perf_counter() - t0
+        host_input = {"value": n / dt_h, "unit": "frames/s", "ms_per_step": 1e3 * dt_h / n,
+                      "note": f"mf_process_frame with host pointers: {(7 + (1 if multi else 0)) * P / 1e6:.2f} MB H2D per frame + one synchronisation per frame"}
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(frames)
+    if rank == 0 and not args.no_cpu_baseline and not multi:
+        cpu = cpu_baseline(cfg, frames)
 
     if rank == 0:
+        variant = "" if args.icp_weight >= 100.0 and not args.so3 else f" [variant: icpWeight={args.icp_weight:g}, so3={int(args.so3)}]"
         out = {
-            "metric": f"frames/sec ({W}x{H} RGB-D, single background model, ICP + surfel fusion)",
-            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOAD + ("" if args.icp_weight >= 100.0 and not args.so3 else
-                                               f" [variant: icpWeight={args.icp_weight:g}, so3={int(args.so3)}]"),
-                       "frames_in_hbm": args.frames, "surfels": count,
-                       "pose_drift_vs_gt_m": drift, "parallelism": f"model-per-gpu x{world}"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "metric": f"frames/sec ({W}x{H} RGB-D, " + (f"background + {n_models - 1} object models" if multi else "single background model") +
+                      ", ICP + surfel fusion)",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": total_steps, "steps_requested": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * total_dt / total_steps, "timed_seconds": total_dt, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["workload"] + variant, "frames_in_hbm": n_frames, "models": n_models, "surfels": count,
+                       "pose_drift_vs_gt_m": drift, "parallelism": f"context-per-gpu x{world}"},
+            "roofline": roofline, "roofline_frame": roofline_frame, "host_input": host_input, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if world > 1:

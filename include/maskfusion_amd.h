@@ -85,6 +85,9 @@ int mf_process_frame(mf_ctx* ctx, const uint8_t* rgb, const float* depth, const 
  * returns without waiting.  mf_sync() (or any getter) waits. */
 int mf_process_frame_dev(mf_ctx* ctx, const uint8_t* d_rgb, const float* d_depth, const uint8_t* d_mask,
                          int64_t timestamp, float weight_multiplier);
+/* FrameData::classIDs (Core/FrameData.h:25-48) of the masks handed to mf_process_frame_dev: class_ids[v] = class of mask value v
+ * (n <= 256; until it is called every mask value is class 0) */
+int mf_set_mask_class_ids(mf_ctx* ctx, const int32_t* class_ids, int32_t n);
 int mf_sync(mf_ctx* ctx);
 
 /* MaskFusion::setTick (Core/MaskFusion.h:206); only after the first frame (tick 1 initialises the map) */

@@ -179,6 +179,11 @@ class MaskFusion:
         """Inputs already resident in HBM (raw device pointers, e.g. torch tensor.data_ptr()); asynchronous."""
         self._chk(self._L.mf_process_frame_dev(self._h, d_rgb, d_depth, d_mask or None, timestamp, weightMultiplier))
 
+    def setMaskClassIDs(self, classIDs):
+        """FrameData::classIDs for the frames handed to processFrameDevice (class of mask value v = classIDs[v])"""
+        a = np.ascontiguousarray(list(classIDs), np.int32)
+        self._chk(self._L.mf_set_mask_class_ids(self._h, a.ctypes.data if len(a) else None, len(a)))
+
     def modelStateDevice(self, model: int, d_out16: int):
         """Enqueue a copy of {R, t, ICP error, inliers, surfels, alive} of `model` into a 16-float device buffer."""
         self._chk(self._L.mf_model_state_dev(self._h, model, d_out16))

@@ -32,9 +32,13 @@ struct ModelState {
     PoseDev* d_pose = nullptr; FrameDev* d_frame = nullptr;
     float4* d_predV = nullptr; float4* d_predN = nullptr; uchar4* d_predImage = nullptr; uint16_t* d_predTime = nullptr;
     uint8_t* d_predGray = nullptr; uint8_t* d_fillGray = nullptr;  // intensity of the RGB projection / of the fill-in image
+    // RGBDOdometry of the model (Model::frameToModel): model-side pyramid, Gauss-Newton state, per-workgroup partial sums
+    float* d_vmap_g[3] = {}; float* d_nmap_g[3] = {}; GNState* d_gn = nullptr; float* d_partials[2] = {nullptr, nullptr};
+    TrackModelDev* d_track = nullptr;      // the block the batched tracker kernels find all of that through
     float* d_poselog = nullptr;            // Model::poseLog on the device: ring of [cap][8] floats (t, q xyzw, pad)
     std::vector<int64_t> log_ts;           // timestamps of the entries (host side of PoseLogItem)
     PoseDev* h_pose = nullptr; FrameDev* h_frame = nullptr; int* h_count = nullptr;
+    TrackModelDev track_host;              // host copy of *d_track (pose_host is filled in once h_pose exists)
     std::vector<void*> allocs;
     ~ModelState() {
         for (void* p : allocs) (void)hipFree(p);
@@ -134,7 +138,6 @@ struct mf_ctx {
     float* d_depthF[3] = {nullptr, nullptr, nullptr};  // ring: frame k filters into [k % 3], fill-in reads [(k - 1) % 3]
     float* d_vmap[2][3] = {}; float* d_nmap[2][3] = {};
     // shared scratch
-    GNState* d_gn = nullptr; float* d_partials[2] = {nullptr, nullptr};
     // photometric term + SO(3) (a5, a8-a10, a12)
     uint8_t* d_gray[2][3] = {};            // intensity pyramid of the frame, by frame parity ([prev] = lastNextImage)
     long gray_frame[2] = {-1, -1};         // frame_no each set was computed for
@@ -147,12 +150,13 @@ struct mf_ctx {
     float4* d_splat_rec0 = nullptr; float4* d_splat_rec1 = nullptr; uint2* d_splat_bbox = nullptr;   // per-surfel sprite set-up
     const uint8_t* cur_rgb = nullptr;      // device rgb of the frame being processed (fill-in intensity at predict time)
     const float* cur_depth = nullptr;      // device raw depth of the frame being processed / staged (Model-level entry points)
+    int batch_tracking = 1;                // 0: track the models one after the other even when a batch is possible ("batchTracking")
     int model_api_packed = 0;              // mf_model_predict_indices also builds the packed column-major map clean() uses in-frame
+    std::vector<int32_t> mask_classes;     // FrameData::classIDs for mf_process_frame_dev (mf_set_mask_class_ids)
     std::vector<int> trackable;            // MaskFusion::trackableClassIds (empty: every class is trackable)
     struct RetiredLog { int id; std::vector<int64_t> ts; std::vector<float> p; };
     std::vector<RetiredLog> retired;       // pose logs of dropped models (MaskFusion::inactiveModels, exportPoses)
     std::vector<std::unique_ptr<ModelState>> pool;   // MaskFusion::preallocatedModels (buffers allocated ahead of the spawn)
-    float* d_vmap_g[3]; float* d_nmap_g[3];
     unsigned long long* d_keys = nullptr;
     int* d_index = nullptr; float4* d_ivc = nullptr; float4* d_ict = nullptr; float4* d_inr = nullptr;
     float4* d_iclean = nullptr;            // packed column-major index map of the clean pass: 2 x float4 per texel
@@ -266,7 +270,29 @@ static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int 
     A(dev_alloc(c, m->allocs, &m->d_predGray, P));
     if (allowFillIn) A(dev_alloc(c, m->allocs, &m->d_fillGray, P));
     if (c->cfg.pose_log_capacity > 0) A(dev_alloc(c, m->allocs, &m->d_poselog, (size_t)c->cfg.pose_log_capacity * 8));
+    for (int i = 0; i < 3; ++i) {
+        const size_t lp = (size_t)(c->W >> i) * (c->H >> i);
+        A(dev_alloc(c, m->allocs, &m->d_vmap_g[i], lp * 3));
+        A(dev_alloc(c, m->allocs, &m->d_nmap_g[i], lp * 3));
+    }
+    {
+        const size_t nbmax = (size_t)std::max(icp_grid_blocks(c->W, c->H), icp_batch_max_blocks(c->W, c->H));
+        for (int b = 0; b < 2; ++b) A(dev_alloc(c, m->allocs, &m->d_partials[b], nbmax * kIcpSlots));
+    }
+    A(dev_alloc(c, m->allocs, &m->d_gn, 2));
+    A(dev_alloc(c, m->allocs, &m->d_track, 1));
 #undef A
+    {
+        TrackModelDev t;
+        memset(&t, 0, sizeof(t));
+        t.predV = m->d_predV; t.predN = m->d_predN; t.pose = m->d_pose; t.frame = m->d_frame;
+        for (int i = 0; i < 3; ++i) { t.vm[i] = m->d_vmap_g[i]; t.nm[i] = m->d_nmap_g[i]; }
+        t.partials[0] = m->d_partials[0]; t.partials[1] = m->d_partials[1]; t.st = m->d_gn;
+        t.log = allowFillIn ? c->d_icp_log : nullptr;             // only the background model (the one with fill-in) is logged
+        t.jump_limit = allowFillIn ? 0.f : 0.2f;                   // MaskFusion.cpp:268-272 applies to object models
+        t.allow_fill = allowFillIn ? 1 : 0;
+        m->track_host = t;
+    }
     hipLaunchKernelGGL(k_pose_identity, dim3(1), dim3(64), 0, c->stream, m->d_pose);
     hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(64), 0, c->stream, m->d_frame, c->host_tick);
     if (hipHostMalloc((void**)&m->h_pose, sizeof(PoseDev)) != hipSuccess || hipHostMalloc((void**)&m->h_frame, sizeof(FrameDev)) != hipSuccess ||
@@ -278,6 +304,9 @@ static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int 
     memset(m->h_frame, 0, sizeof(FrameDev));
     m->h_frame->tick = c->host_tick;
     *m->h_count = 0;
+    m->track_host.pose_host = m->h_pose;
+    MF_HIP(c, hipMemcpyAsync(m->d_track, &m->track_host, sizeof(TrackModelDev), hipMemcpyHostToDevice, c->stream));
+    MF_HIP(c, hipStreamSynchronize(c->stream));   // track_host is pageable: the copy must not outlive a moved ModelState
     out = std::move(m);
     return MF_OK;
 }
@@ -320,11 +349,7 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
             A(dev_alloc(c, c->allocs, &c->d_vmap[set][i], lp * 3));
             A(dev_alloc(c, c->allocs, &c->d_nmap[set][i], lp * 3));
         }
-        A(dev_alloc(c, c->allocs, &c->d_vmap_g[i], lp * 3));
-        A(dev_alloc(c, c->allocs, &c->d_nmap_g[i], lp * 3));
     }
-    for (int b = 0; b < 2; ++b) A(dev_alloc(c, c->allocs, &c->d_partials[b], (size_t)icp_grid_blocks(W, H) * kIcpSlots));
-    A(dev_alloc(c, c->allocs, &c->d_gn, 2));
     for (int i = 0; i < 3; ++i) {
         const size_t lp = (size_t)(W >> i) * (H >> i);
         for (int set = 0; set < 2; ++set) A(dev_alloc(c, c->allocs, &c->d_gray[set][i], lp));
@@ -443,8 +468,8 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
     float* const* cur_nmap = c->d_nmap[set];
     const int W = c->W, H = c->H;
     hipStream_t s = c->stream;
-    launch_model_pyramid(m.d_predV, m.d_predN, m.allowFillIn ? fillDepth : nullptr, m.d_frame, m.d_pose, nullptr, c->d_vmap_g,
-                         c->d_nmap_g, W, H, c->K, s);
+    launch_model_pyramid(m.d_predV, m.d_predN, m.allowFillIn ? fillDepth : nullptr, m.d_frame, m.d_pose, nullptr, m.d_vmap_g,
+                         m.d_nmap_g, W, H, c->K, s);
     const bool rgb = photometric_on(c);
     const bool icp = !g.rgb_only && g.icp_weight > 0.f;
     // the previous frame's intensity pyramid is RGBDOdometry::lastNextImage (identical for every tracked model)
@@ -472,13 +497,13 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
         for (int j = 0; j < iters[lvl]; ++j) {
             IcpLaunch l;
             l.vmap_curr = cur_vmap[lvl]; l.nmap_curr = cur_nmap[lvl];
-            l.vmap_prev = c->d_vmap_g[lvl]; l.nmap_prev = c->d_nmap_g[lvl];
+            l.vmap_prev = m.d_vmap_g[lvl]; l.nmap_prev = m.d_nmap_g[lvl];
             l.W = W >> lvl; l.H = H >> lvl; l.k = Intr{g.fx / div, g.fy / div, g.cx / div, g.cy / div};
             l.distThres = 0.10f; l.angleThres = sinf(20.f * 3.14159254f / 180.f);  // RGBDOdometry.h:35-36
-            l.partials_in = nb_prev ? c->d_partials[(k + 1) & 1] : nullptr;
+            l.partials_in = nb_prev ? m.d_partials[(k + 1) & 1] : nullptr;
             l.nblocks_in = nb_prev;
-            l.partials_out = c->d_partials[k & 1];
-            l.state_in = &c->d_gn[k & 1]; l.state_out = &c->d_gn[(k + 1) & 1];
+            l.partials_out = m.d_partials[k & 1];
+            l.state_in = &m.d_gn[k & 1]; l.state_out = &m.d_gn[(k + 1) & 1];
             l.log_out = (k > 0 && m.id == 0) ? c->d_icp_log + 32 * (k - 1) : nullptr;
             l.prof_out = (c->icp_prof_on && m.id == 0 && !rgb) ? c->d_icp_prof + 8 * k : nullptr;
             l.pose_in = (k == 0) ? m.d_pose : nullptr;
@@ -513,12 +538,49 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
     if (timed) (void)hipEventRecord(c->ev_icp[1], s);
     float* log_out = (k > 0 && m.id == 0) ? c->d_icp_log + 32 * (k - 1) : nullptr;
     if (!rgb)
-        launch_icp_finalize(nb_prev ? c->d_partials[(k + 1) & 1] : nullptr, nb_prev, &c->d_gn[k & 1], m.d_pose, m.h_pose, log_out,
+        launch_icp_finalize(nb_prev ? m.d_partials[(k + 1) & 1] : nullptr, nb_prev, &m.d_gn[k & 1], m.d_pose, m.h_pose, log_out,
                             jump_limit, so3_seed, s);
     else
-        launch_rgbd_finalize(nb_prev ? c->d_partials[(k + 1) & 1] : nullptr, nb_prev ? c->d_rgb_partials[(k + 1) & 1] : nullptr,
+        launch_rgbd_finalize(nb_prev ? m.d_partials[(k + 1) & 1] : nullptr, nb_prev ? c->d_rgb_partials[(k + 1) & 1] : nullptr,
                              nb_prev ? c->d_cnt[(k + 1) & 1] : nullptr, nb_prev, g.icp_weight, icp ? 1 : 0, g.rgb_only ? 1 : 0, 1,
-                             prev_level, &c->d_gn[k & 1], so3_seed, m.d_pose, m.h_pose, log_out, jump_limit, s);
+                             prev_level, &m.d_gn[k & 1], so3_seed, m.d_pose, m.h_pose, log_out, jump_limit, s);
+}
+
+// The same for several models at once (geometric term only; MaskFusion.cpp:247-276 tracks the models one after the other, their
+// steps are independent): the model pyramid, every Gauss-Newton iteration and the final pose update of ALL of them are one
+// launch each, so that a frame with M tracked models costs ~40 launches instead of M x 21 latency-bound ones.
+static void enqueue_track_batch(mf_ctx* c, const std::vector<ModelState*>& ms, const float* fillDepth, long frame_k) {
+    const mf_config& g = c->cfg;
+    const int set = (int)(frame_k & 1);
+    const int W = c->W, H = c->H;
+    hipStream_t s = c->stream;
+    TrackBatch b;
+    memset(&b, 0, sizeof(b));
+    b.n = (int)ms.size();
+    for (int i = 0; i < b.n; ++i) b.m[i] = ms[i]->d_track;
+    launch_model_pyramid_batch(b, fillDepth, W, H, c->K, s);
+    const bool so3 = g.so3 != 0 && c->gray_frame[set ^ 1] == frame_k - 1 && c->gray_frame[set] == frame_k;
+    if (so3)   // one pre-alignment serves every model: it only looks at the two frames (RGBDOdometry.cpp:264-324)
+        (void)launch_so3_prealign(c->d_gray[set ^ 1][2], c->d_gray[set][2], W >> 2, H >> 2, Intr{g.fx / 4, g.fy / 4, g.cx / 4, g.cy / 4},
+                                  c->d_so3, c->d_so3_scratch, s);
+    const So3Result* so3_seed = so3 ? c->d_so3 : nullptr;
+    const int iters[3] = {g.fast_odom ? 3 : 10, g.pyramid ? 5 : 0, g.pyramid ? 4 : 0};
+    const bool timed = c->timings_on && ms[0] == c->models[0].get();
+    if (timed) (void)hipEventRecord(c->ev_icp[0], s);
+    int it = 0, nb_prev = 0;
+    for (int lvl = 2; lvl >= 0; --lvl) {
+        const float div = (float)(1 << lvl);
+        for (int j = 0; j < iters[lvl]; ++j) {
+            launch_icp_batch_solve(b, it, nb_prev, it == 0 ? so3_seed : nullptr, s);
+            launch_icp_batch_pixels(b, it, lvl, c->d_vmap[set][lvl], c->d_nmap[set][lvl], W >> lvl, H >> lvl,
+                                    Intr{g.fx / div, g.fy / div, g.cx / div, g.cy / div}, 0.10f, sinf(20.f * 3.14159254f / 180.f), s);
+            nb_prev = icp_batch_blocks(W >> lvl, H >> lvl, b.n);
+            ++it;
+        }
+    }
+    if (timed) (void)hipEventRecord(c->ev_icp[1], s);
+    if (it == 0) launch_icp_batch_solve(b, 0, 0, so3_seed, s);   // no iterations at all: the states still have to exist
+    launch_icp_batch_finalize(b, it, nb_prev, so3_seed, s);
 }
 
 // predictIndices -> fuse -> [predictIndices] -> clean for one model (Core/MaskFusion.cpp:541-563 / :344-353)
@@ -664,17 +726,24 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
         mark(c, 7);
     } else {
         mark(c, 2);
-        // tracking, :247-276
-        enqueue_track(c, bg, depthF_prev, 0.f, k);
-        if (bootstrap && in_pose16) launch_override_pose(bg.d_pose, in_pose16, 1, bg.h_pose, s);   // :280-283
+        // tracking, :247-276.  Every model that is tracked this frame goes into one batch (geometric term) or is tracked on its
+        // own (photometric term: its scratch images are shared); static objects then follow the background's NEW pose
+        std::vector<ModelState*> tracked{&bg}, follow;
         for (size_t i = 1; i < c->models.size(); ++i) {
             ModelState& m = *c->models[i];
             // trackable = trackableClassIds.empty() || trackableClassIds.count(classID), :261
             bool trackable = c->trackable.empty();
             for (int id : c->trackable) trackable |= (id == m.classID);
-            if ((!m.isStatic || g.track_all_models) && trackable) enqueue_track(c, m, nullptr, 0.2f, k);  // jump rule, :268-272
-            else launch_static_pose(m.d_pose, bg.d_pose, m.h_pose, s);                  // updateStaticPose, :274
+            if ((!m.isStatic || g.track_all_models) && trackable) tracked.push_back(&m);   // jump rule of :268-272 in the finalize step
+            else follow.push_back(&m);
         }
+        if (!photometric_on(c) && tracked.size() >= 2 && (int)tracked.size() <= kMaxTrackBatch && c->batch_tracking) {
+            enqueue_track_batch(c, tracked, depthF_prev, k);
+        } else {
+            for (size_t i = 0; i < tracked.size(); ++i) enqueue_track(c, *tracked[i], i == 0 ? depthF_prev : nullptr, i == 0 ? 0.f : 0.2f, k);
+        }
+        for (ModelState* m : follow) launch_static_pose(m->d_pose, bg.d_pose, m->h_pose, s);   // updateStaticPose, :274
+        if (bootstrap && in_pose16) launch_override_pose(bg.d_pose, in_pose16, 1, bg.h_pose, s);   // :280-283 (after the object loop)
         mark(c, 3);
         if (c->overlap) { MF_HIP(c, hipEventRecord(c->ev_main_done[set], s)); main_done_recorded = true; }
 
@@ -792,11 +861,21 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
 extern "C" int mf_process_frame_dev(mf_ctx* c, const uint8_t* d_rgb, const float* d_depth, const uint8_t* d_mask, int64_t timestamp,
                                     float weight_multiplier) {
     if (!c || !d_rgb || !d_depth) return MF_EINVAL;
-    // device-resident masks carry no class ids over this entry point: every mask id is class 0 ("object")
+    // FrameData::classIDs of device-resident masks: the table of mf_set_mask_class_ids (every id class 0 until it is set)
     std::vector<int32_t> cls;
-    if (d_mask && c->cfg.enable_multiple_models) cls.assign(256, 0);
+    if (d_mask && c->cfg.enable_multiple_models) {
+        if (c->mask_classes.empty()) cls.assign(256, 0);
+        else cls = c->mask_classes;
+    }
     return process_frame_impl(c, d_rgb, d_depth, d_mask, cls.empty() ? nullptr : cls.data(), (int)cls.size(), weight_multiplier,
                               timestamp);
+}
+
+// FrameData::classIDs (Core/FrameData.h:25-48) for frames handed over as device pointers: class_ids[v] is the class of mask value v
+extern "C" int mf_set_mask_class_ids(mf_ctx* c, const int32_t* class_ids, int32_t n) {
+    if (!c || n < 0 || n > 256 || (n > 0 && !class_ids)) return MF_EINVAL;
+    c->mask_classes.assign(class_ids, class_ids + n);
+    return MF_OK;
 }
 
 extern "C" int mf_sync(mf_ctx* c) {
@@ -1364,6 +1443,7 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
         c->tile_entries_cap = (int)v;
         return MF_OK;
     }
+    if (!strcmp(key, "batchTracking")) { c->batch_tracking = value != 0; return MF_OK; }
     if (!strcmp(key, "modelApiPackedIndex")) { c->model_api_packed = value != 0; return MF_OK; }   // 0: scatter + resolve form (specification)
     if (!strcmp(key, "overlapPreprocessing")) {
         (void)hipStreamSynchronize(c->stream_pre);
@@ -1436,7 +1516,7 @@ static int debug_read_impl(mf_ctx* c, ModelState& mdl, const char* what, void* o
     };
     const int lastSet = (int)((c->frame_no + 1) & 1);  // buffer set of the last processed / staged frame
     if (w == "depthF") { src = c->d_depthF[c->lastF]; bytes = P * 4; }
-    else if (lvl("vmap_g", c->d_vmap_g) || lvl("nmap_g", c->d_nmap_g) || lvl("vmap", c->d_vmap[lastSet]) || lvl("nmap", c->d_nmap[lastSet])) {}
+    else if (lvl("vmap_g", mdl.d_vmap_g) || lvl("nmap_g", mdl.d_nmap_g) || lvl("vmap", c->d_vmap[lastSet]) || lvl("nmap", c->d_nmap[lastSet])) {}
     else if (w == "pred_vertex") { src = mdl.d_predV; bytes = P * 16; }
     else if (w == "pred_normal") { src = mdl.d_predN; bytes = P * 16; }
     else if (w == "pred_image") { src = mdl.d_predImage; bytes = P * 4; }

@@ -69,6 +69,20 @@ struct Surfels {               // SoA of float4, 48 B per surfel in three coales
     int cap;                   // capacity in surfels (writes beyond it are dropped, like a full transform-feedback buffer)
 };
 
+// Persistent per-model block of the tracker (device memory, written once when the model is created): what the batched
+// Gauss-Newton kernels need to find a model's maps, state and partial sums from blockIdx alone.
+struct TrackModelDev {
+    const float4* predV; const float4* predN;    // prediction consumed by initICPModel
+    PoseDev* pose; PoseDev* pose_host; const FrameDev* frame;
+    float* vm[3]; float* nm[3];                   // model-side vertex / normal pyramid (global frame)
+    float* partials[2]; GNState* st;              // ping-pong per-workgroup partial sums [nb][32]; st[0], st[1]
+    float* log;                                   // [19][32] reduced systems (background model) or nullptr
+    float jump_limit;                             // object models: 0.2 m rule of MaskFusion.cpp:268-272; background: 0
+    int allow_fill;                               // Model::allowsFillIn (background only)
+};
+constexpr int kMaxTrackBatch = 32;
+struct TrackBatch { const TrackModelDev* m[kMaxTrackBatch]; int n; };   // by value in the kernel arguments
+
 // ---------------- preprocessing ----------------
 void launch_bilateral(const float* depth, float* out, int W, int H, hipStream_t s);
 void launch_pyrdown_f(const float* src, float* dst, int sw, int sh, hipStream_t s);
@@ -97,6 +111,19 @@ struct IcpLaunch {
 };
 int icp_grid_blocks(int W, int H);
 void launch_icp_iteration(const IcpLaunch& a, hipStream_t s);
+// ---- the same loop for SEVERAL models at once (MaskFusion.cpp:247-276 tracks them one after the other): one launch serves
+// iteration k of every tracked model.  Split in two kernels per iteration -- "solve" (one workgroup per model: reduce the
+// previous iteration's partials, LDL^T, pose) and "pixels" (grid.y = model, no prologue, any number of workgroup rounds) --
+// because the redundant per-workgroup prologue of k_icp_iter would be paid once per model and per round.
+int icp_batch_max_blocks(int W, int H);                       // upper bound of workgroups per model of launch_icp_batch_pixels
+int icp_batch_blocks(int W, int H, int n_models);             // workgroups per model it will use for this image size
+void launch_model_pyramid_batch(const TrackBatch& b, const float* fillDepth, int W, int H, Intr k, hipStream_t s);
+// it = 0 seeds the states from the model poses (+ SO(3) rotation); it >= 1 finishes iteration it-1 whose pixel pass used nb_in blocks
+void launch_icp_batch_solve(const TrackBatch& b, int it, int nb_in, const So3Result* so3_or_null, hipStream_t s);
+void launch_icp_batch_pixels(const TrackBatch& b, int it, int level, const float* vmap_curr, const float* nmap_curr, int W, int H, Intr k,
+                             float distThres, float angleThres, hipStream_t s);
+// last solve (iteration n_it - 1) + Model pose / lastPose / statistics / jump rule
+void launch_icp_batch_finalize(const TrackBatch& b, int n_it, int nb_in, const So3Result* so3_or_null, hipStream_t s);
 // Last reduce+solve, then pose / lastPose / inverse / fusion weight update and host mirror.
 // jump_limit > 0: object-model rule of MaskFusion.cpp:268-272 (|increment translation| > limit => pose->alive = 0)
 void launch_icp_finalize(const float* partials_in, int nblocks_in, const GNState* state_in, PoseDev* pose,

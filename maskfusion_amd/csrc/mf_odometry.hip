@@ -14,6 +14,8 @@
 // the kernel boundary only), then streams the current vertex/normal planes, gathers the model planes, and reduces 29
 // accumulators with a recursive-halving tree (DPP exchanges) + one LDS stage.  No host round trip, no atomics,
 // bit-reproducible run to run.  With the photometric term an iteration is two launches (k_rgbd_iter, k_rgb_step).
+#include <string.h>
+
 #include "mf_internal.h"
 #include "mf_device.h"
 #include "mf_rgbd_device.h"
@@ -348,8 +350,9 @@ struct IcpKArgs {
 // together (a per-pixel search-then-accumulate serialises four dependent L2 round trips: ~2 us per launch).
 struct IcpCorr { float3 vcurr_g, vcurr_cp, ncurr_g; int j; bool ok; };
 
+template <class Args>
 __device__ __forceinline__ IcpCorr icp_project(float vx, float vy, float vz, float nx, float ny, float nz, const float* Rc,
-                                               float3 tc, const float* Rpi, float3 tp, const IcpKArgs& a) {
+                                               float3 tc, const float* Rpi, float3 tp, const Args& a) {
     // search(), first half: Core/Cuda/reduce.cu:292-314
     IcpCorr c;
     c.vcurr_g = mul33(Rc, f3(vx, vy, vz)) + tc;
@@ -362,8 +365,9 @@ __device__ __forceinline__ IcpCorr icp_project(float vx, float vy, float vz, flo
     return c;
 }
 
+template <class Args>
 __device__ __forceinline__ void icp_accumulate(const IcpCorr& c, float3 vprev_g, float3 nprev_g, const float* Rpi, float3 tp,
-                                               const IcpKArgs& a, float* acc) {
+                                               const Args& a, float* acc) {
     // search(), second half + getProducts(): Core/Cuda/reduce.cu:326-415
     const float dist = norm3(vprev_g - c.vcurr_g);
     const float sine = norm3(cross3(c.ncurr_g, nprev_g));
@@ -561,12 +565,11 @@ void launch_icp_iteration(const IcpLaunch& l, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // begin / finalize
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_icp_finalize(const float* __restrict__ partials_in, int nb_in,
-                                                       const GNState* __restrict__ st_in, PoseDev* __restrict__ pose,
-                                                       PoseDev* __restrict__ host_mirror, float* __restrict__ log_out,
-                                                       float jump_limit, const So3Result* __restrict__ so3) {
-    __shared__ double s_seg[32 * 32];
-    __shared__ double s_sys[32];
+// last reduce + solve of a tracking step, then Model::pose / lastPose / statistics (RGBDOdometry.cpp:476-496, Model.cpp:437-446)
+// and the object-model jump rule.  Called by all 256 threads of a workgroup.
+__device__ __forceinline__ void icp_finalize_body(const float* __restrict__ partials_in, int nb_in, const GNState* __restrict__ st_in,
+                                                  PoseDev* __restrict__ pose, PoseDev* __restrict__ host_mirror, float* __restrict__ log_out,
+                                                  float jump_limit, const So3Result* __restrict__ so3, double* s_seg, double* s_sys) {
     GNState st;
     bool mine = false;
     if (nb_in > 0) {
@@ -595,10 +598,162 @@ __global__ __launch_bounds__(256) void k_icp_finalize(const float* __restrict__ 
     }
 }
 
+__global__ __launch_bounds__(256) void k_icp_finalize(const float* __restrict__ partials_in, int nb_in,
+                                                       const GNState* __restrict__ st_in, PoseDev* __restrict__ pose,
+                                                       PoseDev* __restrict__ host_mirror, float* __restrict__ log_out,
+                                                       float jump_limit, const So3Result* __restrict__ so3) {
+    __shared__ double s_seg[32 * 32];
+    __shared__ double s_sys[32];
+    icp_finalize_body(partials_in, nb_in, st_in, pose, host_mirror, log_out, jump_limit, so3, s_seg, s_sys);
+}
+
 void launch_icp_finalize(const float* partials_in, int nblocks_in, const GNState* state_in, PoseDev* pose,
                          PoseDev* host_mirror, float* log_out, float jump_limit, const So3Result* so3, hipStream_t s) {
     hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(256), 0, s, partials_in, nblocks_in, state_in, pose, host_mirror,
                        log_out, jump_limit, so3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched Gauss-Newton loop: iteration k of ALL tracked models per launch (see mf_internal.h).
+// ------------------------------------------------------------------------------------------------
+struct IcpSolveArgs { TrackBatch b; int it; int nb_in; const So3Result* so3; };
+
+__global__ __launch_bounds__(256) void k_icp_batch_solve(const IcpSolveArgs a) {
+    __shared__ double s_seg[32 * 32];
+    __shared__ double s_sys[32];
+    __shared__ GNState s_st;
+    const TrackModelDev* __restrict__ md = a.b.m[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (a.it == 0) {   // RGBDOdometry.cpp:239-243,332-344: Rprev = Rcurr = pose, resultRt = I (or the SO(3) rotation)
+        if (tid == 0) {
+            GNState s;
+            seed_state(*md->pose, s);
+            if (a.so3)
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c) s.resultRt[r * 4 + c] = a.so3->R[r * 3 + c];
+            md->st[0] = s;
+        }
+        return;
+    }
+    const int prev = (a.it - 1) & 1;
+    if (tid < (int)(sizeof(GNState) / 4)) reinterpret_cast<uint32_t*>(&s_st)[tid] = reinterpret_cast<const uint32_t*>(md->st + prev)[tid];
+    reduce_partials(md->partials[prev], a.nb_in, s_seg, s_sys);   // (its barriers also publish s_st)
+    GNState out;
+    if (gn_solve_update_wg(s_sys, s_st, out)) {
+        md->st[a.it & 1] = out;
+        if (md->log)
+            for (int k = 0; k < 32; ++k) md->log[32 * (a.it - 1) + k] = (float)s_sys[k];
+    }
+}
+
+struct IcpPxArgs {
+    TrackBatch b;
+    const float* vc; const float* nc;
+    int W, H; Intr k;
+    float distThres, angleThres;
+    int level, parity, chunk;
+};
+constexpr int kBatchThreads = 256;
+constexpr int kBatchPx = 3;   // pixels per thread and round: all their gathers are in flight together
+
+__global__ __launch_bounds__(kBatchThreads) void k_icp_batch_pixels(const IcpPxArgs a) {
+    __shared__ float s_part[(kBatchThreads / 64) * kIcpSlots];
+    const TrackModelDev* __restrict__ md = a.b.m[blockIdx.y];
+    const GNState* __restrict__ st = md->st + a.parity;
+    const float* __restrict__ vp = md->vm[a.level];
+    const float* __restrict__ np = md->nm[a.level];
+    float Rc[9], Rpi[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { Rc[k] = st->Rcurr[k]; Rpi[k] = st->Rprev_inv[k]; }
+    const float3 tc = f3(st->tcurr[0], st->tcurr[1], st->tcurr[2]);
+    const float3 tp = f3(st->tprev[0], st->tprev[1], st->tprev[2]);
+    const int tid = threadIdx.x;
+    const int P = a.W * a.H;
+    const int beg = blockIdx.x * a.chunk, end = min(P, beg + a.chunk);
+    float acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = 0.f;
+    for (int base = beg; base < end; base += kBatchPx * kBatchThreads) {
+        bool act[kBatchPx];
+        float vx[kBatchPx], vy[kBatchPx], vz[kBatchPx], nx[kBatchPx], ny[kBatchPx], nz[kBatchPx];
+#pragma unroll
+        for (int q = 0; q < kBatchPx; ++q) {
+            const int i = base + q * kBatchThreads + tid;
+            act[q] = i < end;
+            vx[q] = vy[q] = vz[q] = nx[q] = ny[q] = nz[q] = 0.f;
+            if (act[q]) {
+                vx[q] = a.vc[i]; vy[q] = a.vc[P + i]; vz[q] = a.vc[2 * P + i];
+                nx[q] = a.nc[i]; ny[q] = a.nc[P + i]; nz[q] = a.nc[2 * P + i];
+            }
+        }
+        IcpCorr cor[kBatchPx];
+        float3 pv[kBatchPx], pn[kBatchPx];
+#pragma unroll
+        for (int q = 0; q < kBatchPx; ++q)
+            if (act[q]) cor[q] = icp_project(vx[q], vy[q], vz[q], nx[q], ny[q], nz[q], Rc, tc, Rpi, tp, a);
+#pragma unroll
+        for (int q = 0; q < kBatchPx; ++q)
+            if (act[q]) {
+                const int j = cor[q].j;
+                pv[q] = f3(vp[j], vp[P + j], vp[2 * P + j]);
+                pn[q] = f3(np[j], np[P + j], np[2 * P + j]);
+            }
+#pragma unroll
+        for (int q = 0; q < kBatchPx; ++q)
+            if (act[q]) icp_accumulate(cor[q], pv[q], pn[q], Rpi, tp, a, acc);
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    const float wsum = wave_sum32_halving(acc);
+    if (lane < 32) s_part[wave * kIcpSlots + icp_component_of_lane(lane)] = wsum;
+    __syncthreads();
+    if (tid < kIcpSlots) {
+        float s = 0.f;
+        if (tid < 29) {
+#pragma unroll
+            for (int w = 0; w < kBatchThreads / 64; ++w) s += s_part[w * kIcpSlots + tid];
+        }
+        md->partials[a.parity][blockIdx.x * kIcpSlots + tid] = s;
+    }
+}
+
+struct IcpFinArgs { TrackBatch b; int n_it; int nb_in; const So3Result* so3; };
+__global__ __launch_bounds__(256) void k_icp_batch_finalize(const IcpFinArgs a) {
+    __shared__ double s_seg[32 * 32];
+    __shared__ double s_sys[32];
+    const TrackModelDev* __restrict__ md = a.b.m[blockIdx.x];
+    const int last = (a.n_it - 1) & 1;
+    icp_finalize_body(a.n_it > 0 ? md->partials[last] : nullptr, a.n_it > 0 ? a.nb_in : 0, md->st + (a.n_it > 0 ? last : 0), md->pose, md->pose_host,
+                      (md->log && a.n_it > 0) ? md->log + 32 * (a.n_it - 1) : nullptr, md->jump_limit, a.so3, s_seg, s_sys);
+}
+
+// Workgroups per model of the pixel pass: enough of them over all models to fill the GPU a few times over (there is no
+// per-workgroup prologue to amortise, only one 32-value halving tree per wavefront), never less than one round of pixels.
+int icp_batch_max_blocks(int W, int H) { return (W * H + kBatchPx * kBatchThreads - 1) / (kBatchPx * kBatchThreads); }
+static int icp_batch_chunk(int P, int n_models) {
+    const int round = kBatchPx * kBatchThreads;
+    int per_model = (768 + n_models - 1) / n_models;                  // ~3 workgroups per CU in total
+    int chunk = (P + per_model - 1) / per_model;
+    chunk = ((chunk + round - 1) / round) * round;
+    return chunk < round ? round : chunk;
+}
+int icp_batch_blocks(int W, int H, int n_models) {
+    const int P = W * H, chunk = icp_batch_chunk(P, n_models);
+    return (P + chunk - 1) / chunk;
+}
+void launch_icp_batch_solve(const TrackBatch& b, int it, int nb_in, const So3Result* so3, hipStream_t s) {
+    IcpSolveArgs a{b, it, nb_in, so3};
+    hipLaunchKernelGGL(k_icp_batch_solve, dim3(b.n), dim3(256), 0, s, a);
+}
+void launch_icp_batch_pixels(const TrackBatch& b, int it, int level, const float* vmap_curr, const float* nmap_curr, int W, int H, Intr k,
+                             float distThres, float angleThres, hipStream_t s) {
+    IcpPxArgs a;
+    a.b = b; a.vc = vmap_curr; a.nc = nmap_curr; a.W = W; a.H = H; a.k = k; a.distThres = distThres; a.angleThres = angleThres;
+    a.level = level; a.parity = it & 1; a.chunk = icp_batch_chunk(W * H, b.n);
+    hipLaunchKernelGGL(k_icp_batch_pixels, dim3(icp_batch_blocks(W, H, b.n), b.n), dim3(kBatchThreads), 0, s, a);
+}
+void launch_icp_batch_finalize(const TrackBatch& b, int n_it, int nb_in, const So3Result* so3, hipStream_t s) {
+    IcpFinArgs a{b, n_it, nb_in, so3};
+    hipLaunchKernelGGL(k_icp_batch_finalize, dim3(b.n), dim3(256), 0, s, a);
 }
 
 // stand-alone icpStep for the parity tests: reduce partials to 32 floats
@@ -976,6 +1131,7 @@ struct PyrArgs {
     float R[9]; float t[3]; int hostPose;
     float* vm[3]; float* nm[3];
     int W, H; Intr k;
+    TrackBatch b;   // b.n > 0: grid.z = model, everything but fillDepth / W / H / k comes from the model's block
 };
 
 // value of lane (quad base + kB) for every lane of a quad: one DPP quad_perm broadcast, no LDS traffic
@@ -990,7 +1146,15 @@ __device__ __forceinline__ float3 quad_bcast3(float3 v) { return f3(quad_bcast<k
 // pixel and exchange their values with quad broadcasts, so the averages keep the reference's operation order
 // ((x00 + x01 + x10 + x11) / 4, level 2 from level-1 values).  (A thread per level-2 pixel -- 19 200 threads walking 16
 // pixels each -- left three quarters of the CUs idle: 15 us.)
-__global__ __launch_bounds__(256) void k_model_pyramid(const PyrArgs a) {
+__global__ __launch_bounds__(256) void k_model_pyramid(const PyrArgs a0) {
+    PyrArgs a = a0;
+    if (a0.b.n > 0) {
+        const TrackModelDev* __restrict__ md = a0.b.m[blockIdx.z];
+        a.predV = md->predV; a.predN = md->predN; a.frame = md->frame; a.pose = md->pose; a.hostPose = 0;
+        a.fillDepth = md->allow_fill ? a0.fillDepth : nullptr;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { a.vm[i] = md->vm[i]; a.nm[i] = md->nm[i]; }
+    }
     const int W2 = a.W >> 2, H2 = a.H >> 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = lane & 3, bx = b & 1, by = b >> 1;
@@ -1063,7 +1227,16 @@ void launch_model_pyramid(const float4* predV, const float4* predN, const float*
     for (int i = 0; i < 3; ++i) a.t[i] = a.hostPose ? R9t3_host_or_null[9 + i] : 0.f;
     for (int i = 0; i < 3; ++i) { a.vm[i] = vmaps[i]; a.nm[i] = nmaps[i]; }
     a.W = W; a.H = H; a.k = k;
+    a.b.n = 0;
     dim3 grid(((W >> 2) + 15) / 16, ((H >> 2) + 3) / 4);
+    hipLaunchKernelGGL(k_model_pyramid, grid, dim3(256), 0, s, a);
+}
+
+void launch_model_pyramid_batch(const TrackBatch& b, const float* fillDepth, int W, int H, Intr k, hipStream_t s) {
+    PyrArgs a;
+    memset(&a, 0, sizeof(a));
+    a.fillDepth = fillDepth; a.W = W; a.H = H; a.k = k; a.b = b;
+    dim3 grid(((W >> 2) + 15) / 16, ((H >> 2) + 3) / 4, b.n);
     hipLaunchKernelGGL(k_model_pyramid, grid, dim3(256), 0, s, a);
 }
 

@@ -45,6 +45,7 @@ SYMBOLS = {
                                    C.c_void_p, C.c_float, C.c_int32]),
     "mf_process_frame_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float]),
     "mf_sync": (C.c_int, [C.c_void_p]),
+    "mf_set_mask_class_ids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "mf_predict": (C.c_int, [C.c_void_p]),
     "mf_preallocate_models": (C.c_int, [C.c_void_p, C.c_uint32]),
     "mf_set_tick": (C.c_int, [C.c_void_p, C.c_int32]),

@@ -25,6 +25,31 @@ def build(force: bool = False) -> str:
 
 
 _lib = None
+_FAST_PATH = os.path.join(_HERE, "libmf_oracle_fast.so")
+
+
+def use_fast_build() -> bool:
+    """bench.py's cpu_baseline leg only: switch this process to a -O3 -march=native build of the same source (compiled HERE, for
+    this machine's cores; the parity build stays -O2 -ffp-contract=off with no -march so that it is the same everywhere).
+    Returns False -- and keeps the parity build -- if the compile fails.  Must be called before the library is first used."""
+    global _LIB_PATH, _lib
+    if _lib is not None:
+        return _LIB_PATH == _FAST_PATH
+    try:
+        src = os.path.join(_HERE, "mf_oracle.c")
+        tag = _FAST_PATH + ".host"
+        host = open("/proc/cpuinfo").read().split("model name", 1)[-1].split("\n", 1)[0] if os.path.exists("/proc/cpuinfo") else "?"
+        stale = (not os.path.exists(_FAST_PATH)) or os.path.getmtime(src) > os.path.getmtime(_FAST_PATH) or \
+            (not os.path.exists(tag)) or open(tag).read() != host
+        if stale:
+            subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-std=gnu11", "-shared", "-o", _FAST_PATH, src, "-lm"],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            open(tag, "w").write(host)
+        _LIB_PATH = _FAST_PATH
+        return True
+    except Exception:
+        return False
+
 
 f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -60,7 +85,8 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    build()
+    if _LIB_PATH != _FAST_PATH:
+        build()
     L = C.CDLL(_LIB_PATH)
     L.mfo_bilateral.argtypes = [f32p, f32p, C.c_int, C.c_int]
     L.mfo_pyrdown_gauss_f.argtypes = [f32p, f32p, C.c_int, C.c_int]

@@ -139,3 +139,38 @@ def test_multimodel_with_reference_default_tracking(hip, oracle):
         for a, b in zip(r["o_cnt"], r["g_cnt"]):
             assert abs(a - b) <= max(20, 0.01 * a)
     assert max(r["o_n"] for r in rec) >= 3
+
+
+def test_batched_tracking_matches_model_by_model_tracking(hip):
+    """The batched Gauss-Newton loop (one launch serves iteration k of every tracked model; mf_odometry.hip) against the
+    model-by-model loop it replaces ("batchTracking" = 0): same models, and poses equal up to the float summation order of the
+    normal equations (different workgroup tiling) -- 1e-5 for the background, and for each object in the frame after its spawn."""
+    from maskfusion_amd import MaskFusion, synth
+    st = synth.Stream(W=640, H=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, n_objects=2, noise=True, object_motion=1.0)
+    frames = [st.frame(k) for k in range(9)]
+    runs = []
+    for batch in (1, 0):
+        m = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=100.0, so3=False, numGSurfels=1 << 20, numOSurfels=1 << 18,
+                       enableMultipleModels=True, modelSpawnOffset=3, trackAllModels=True)
+        for k, v in (("mfThreshold", SEG["threshold"]), ("mfWeightDistance", SEG["weightDistance"]), ("mfWeightConvexity", SEG["weightConvexity"]),
+                     ("mfMorphEdgeIterations", 0), ("mfMorphMaskIterations", 0), ("newModelMinRelativeSize", SEG["minRelSizeNew"]),
+                     ("batchTracking", batch)):
+            m.setParam(k, v)
+        rec = []
+        for k, (rgb, depth, mask) in enumerate(frames):
+            m.processFrame(rgb, depth, mask=mask, classIDs=[0, 41, 42], timestamp=k)
+            gm = m.getModels()
+            rec.append(dict(ids=[x.getID() for x in gm], poses=[x.getPose() for x in gm], stats=[x.getICPStats() for x in gm]))
+        m.close()
+        runs.append(rec)
+    born = {}
+    for k, (a, b) in enumerate(zip(*runs)):
+        print(k, a["ids"], [round(float(np.abs(p - q).max()), 7) for p, q in zip(a["poses"], b["poses"])])
+        assert a["ids"] == b["ids"], k
+        assert np.abs(a["poses"][0] - b["poses"][0]).max() < 1e-5, k
+        for i, mid in enumerate(a["ids"][1:], start=1):
+            born.setdefault(mid, k)
+            if k <= born[mid] + 1:
+                assert np.abs(a["poses"][i] - b["poses"][i]).max() < 1e-4, (k, mid)
+                assert a["stats"][i][1] == b["stats"][i][1] or abs(a["stats"][i][1] - b["stats"][i][1]) <= 2   # inlier counts
+    assert max(len(r["ids"]) for r in runs[0]) >= 2
