@@ -192,7 +192,7 @@ int mf_debug_read(mf_ctx* ctx, const char* what, void* out, uint64_t out_bytes);
 /* Everything of processFrame that touches no model: upload, MaskFusion::filterDepth (Core/MaskFusion.cpp:217,650-657),
  * Model::generateCUDATextures (Core/Model/Model.h:128, Model.cpp:350-389), the intensity pyramid / derivative images
  * (RGBDOdometry::initRGB).  mask = model id per pixel as textureMask holds it for fuse / clean (Core/MaskFusion.cpp:297);
- * NULL = all background.  Host pointers; synchronous. */
+ * NULL = leave textureMask as it is (all background in a fresh context).  Host pointers; synchronous. */
 int mf_stage_frame(mf_ctx* ctx, const uint8_t* rgb, const float* depth, const uint8_t* mask);
 /* The tail of processFrame (Core/MaskFusion.cpp:569-602) for a frame driven through the calls below: tick++, the
  * requiresFillIn decision for the next tracking step, the pose-log entry with `timestamp`, age++ */
@@ -230,6 +230,40 @@ int mf_make_static(mf_ctx* ctx, int32_t model);
 int mf_set_trackable_class_ids(mf_ctx* ctx, const int32_t* ids, int32_t n);
 /* mf_debug_read for the per-model taps ("pred_vertex", "pred_normal", "pred_image", "pred_time") of model `model` */
 int mf_debug_read_model(mf_ctx* ctx, int32_t model, const char* what, void* out, uint64_t out_bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * Model-sharded scenes: several contexts -- one per GPU -- each own some of the models of ONE scene.  What
+ * MaskFusion::processFrame couples between models crosses the contexts through these calls: the z-merged model-id image
+ * (GlobalProjection, Core/Model/GlobalProjection.cpp:43-114), the label image (Core/MaskFusion.cpp:289-297) and the background
+ * pose (static objects follow it, Core/Model/Model.h:263-264; mf_model_override_pose(ctx, 0, pose) installs it on a context
+ * that does not own the background).  maskfusion_amd/sharded.py sequences them with the Model-level calls above and with
+ * collectives (all-reduce(MIN) of the keys, broadcast of labels + pose + control record, gather of per-model state).
+ * ---------------------------------------------------------------------------------------------- */
+/* GlobalProjection::project of this context's models only.  d_keys_out: width*height uint64 = float_bits(z) << 32 | order << 8 | id,
+ * all ones = empty; the per-pixel minimum over contexts is the merged image.  orders[i]: position of local model i in the GLOBAL
+ * model list (the GL draw order that breaks exact depth ties), < 0: do not draw it (a background stand-in). */
+int mf_export_projection_keys_dev(mf_ctx* ctx, const int32_t* orders, int32_t n_orders, uint64_t* d_keys_out);
+/* GlobalProjection::downloadDirect of a merged key image: sets the projected-id image of the next mf_perform_segmentation */
+int mf_import_projection_keys_dev(mf_ctx* ctx, const uint64_t* d_keys);
+/* MaskFusion::performSegmentation (Core/MaskFusion.h:59; MfSegmentation.cpp:83-538) on the staged frame.  mask: host, H*W mask ids
+ * or NULL.  model_ids NULL: this context's model list; else the GLOBAL list in order (index 0 = background) with next_model_id
+ * = MaskFusion::getNextModelID().  Result -> textureMask; *has_new_label / *new_class_id = SegmentationResult::hasNewLabel and
+ * the class of the new label.  Synchronous. */
+int mf_perform_segmentation(mf_ctx* ctx, const uint8_t* mask, const int32_t* class_ids, int32_t n_masks, const int32_t* model_ids,
+                            const int32_t* model_class_ids, int32_t n_models, int32_t next_model_id, int32_t allow_new,
+                            int32_t* has_new_label, int32_t* new_class_id);
+/* SegmentationResult::fullSegmentation as device memory: out of the context that ran the label stage, into the others
+ * (textureMask->Upload, Core/MaskFusion.cpp:297) */
+int mf_export_segmentation_dev(mf_ctx* ctx, uint8_t* d_out);
+int mf_import_segmentation_dev(mf_ctx* ctx, const uint8_t* d_in);
+/* MaskFusion::spawnObjectModel (Core/MaskFusion.cpp:671-684) with the id the label-stage owner allocated */
+int mf_spawn_object_model(mf_ctx* ctx, int32_t id, int32_t class_id);
+/* MaskFusion::inactivateModel (Core/MaskFusion.cpp:686-713) */
+int mf_drop_model(mf_ctx* ctx, int32_t model);
+/* Model::updateStaticPose(globalPose) (Core/Model/Model.h:263) with this context's background pose */
+int mf_model_update_static_pose(mf_ctx* ctx, int32_t model);
+/* Model::setMaxDepth + the object confidence ramp of processFrame (Core/MaskFusion.cpp:335-339,369-374) for the local objects */
+int mf_update_object_params(mf_ctx* ctx);
 
 /* ------------------------------------------------------------------------------------------------
  * Kernel-level entry points (device pointers, launched on `stream`, asynchronous).  Each replaces one reference

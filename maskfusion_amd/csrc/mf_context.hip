@@ -130,6 +130,8 @@ struct mf_ctx {
                                        // and the two cross-queue barriers cost the rest, so it is off by default.
     std::string err;
     int host_tick = 1;
+    bool map_ready = false;            // the background map exists (first frame processed, Model::initialise or an uploaded map)
+    bool tracked_once = false;         // a tracking step has run (its stage timings are meaningful)
     bool timings_on = false, icp_prof_on = false;
 
     // frame-level
@@ -490,7 +492,7 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
     const int iters[3] = {g.fast_odom ? 3 : 10, g.pyramid ? 5 : 0, g.pyramid ? 4 : 0};  // RGBDOdometry.cpp:327-329
     const float sobelScale = 1.0f / 8.0f;                                                // 1 / 2^sobelSize, :31-32
     const bool timed = c->timings_on && &m == c->models[0].get();
-    if (timed) (void)hipEventRecord(c->ev_icp[0], s);
+    if (timed) { (void)hipEventRecord(c->ev_icp[0], s); c->tracked_once = true; }
     int k = 0, nb_prev = 0, prev_level = -1;
     for (int lvl = 2; lvl >= 0; --lvl) {
         const float div = (float)(1 << lvl);
@@ -566,7 +568,7 @@ static void enqueue_track_batch(mf_ctx* c, const std::vector<ModelState*>& ms, c
     const So3Result* so3_seed = so3 ? c->d_so3 : nullptr;
     const int iters[3] = {g.fast_odom ? 3 : 10, g.pyramid ? 5 : 0, g.pyramid ? 4 : 0};
     const bool timed = c->timings_on && ms[0] == c->models[0].get();
-    if (timed) (void)hipEventRecord(c->ev_icp[0], s);
+    if (timed) { (void)hipEventRecord(c->ev_icp[0], s); c->tracked_once = true; }
     int it = 0, nb_prev = 0;
     for (int lvl = 2; lvl >= 0; --lvl) {
         const float div = (float)(1 << lvl);
@@ -653,7 +655,7 @@ static int take_next_model_id(mf_ctx* c) {
 // user of this buffer set and of depthF[k % 3]) is then complete, and the filter overlaps the atomic-/latency-bound fusion
 // kernels of frame k-1 rather than its Gauss-Newton launches, which need a whole CU per workgroup and stall behind resident
 // filter waves.
-static int enqueue_preprocess(mf_ctx* c, const uint8_t* d_rgb, const float* d_depth, long k) {
+static int enqueue_preprocess(mf_ctx* c, const uint8_t* d_rgb, const float* d_depth, long k, bool with_maps) {
     const int W = c->W, H = c->H, P = c->P;
     hipStream_t s = c->stream;
     const mf_config& g = c->cfg;
@@ -663,7 +665,7 @@ static int enqueue_preprocess(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
     if (c->overlap) MF_HIP(c, hipStreamWaitEvent(sp, c->ev_main_done[set ^ 1], 0));
     mark(c, 0, sp);
     launch_bilateral(d_depth, depthF, W, H, sp);
-    if (c->host_tick > 1) {
+    if (with_maps) {   // the frame that initialises the map is never tracked against: no vertex / normal maps needed
         launch_frame_pyramid(depthF, c->d_vmap[set], c->d_nmap[set], W, H, c->K, g.depth_cutoff, sp);
     }
     c->cur_rgb = d_rgb;
@@ -688,6 +690,31 @@ static int enqueue_preprocess(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
 
 static int download_pose_log(mf_ctx* c, ModelState& m, std::vector<int64_t>& ts, std::vector<float>& p7);
 
+// spawnObjectModel (Core/MaskFusion.cpp:671-684): pose = I, makeStatic(globalPose); moveNewModelToList
+static int spawn_object(mf_ctx* c, int id, int classID) {
+    const mf_config& g = c->cfg;
+    hipStream_t s = c->stream;
+    ModelState& bg = *c->models[0];
+    std::unique_ptr<ModelState> nm;
+    if (!c->pool.empty()) {   // :673-676: take a preallocated model
+        nm = std::move(c->pool.front());
+        c->pool.erase(c->pool.begin());
+        nm->id = id;
+        nm->confThr = g.conf_object;
+        nm->age = 0; nm->isStatic = true; nm->log_ts.clear(); nm->cur = 0;
+        hipLaunchKernelGGL(k_pose_identity, dim3(1), dim3(64), 0, s, nm->d_pose);
+        hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(64), 0, s, nm->d_frame, c->host_tick);
+        nm->h_frame->tick = c->host_tick;
+    } else {
+        int rc = create_model(c, id, g.conf_object, false, surfel_capacity(g.num_osurfels), nm);
+        if (rc != MF_OK) return rc;
+    }
+    nm->classID = classID;
+    launch_spawn_pose(nm->d_pose, bg.d_pose, nm->d_frame, bg.d_frame, nm->h_pose, s);
+    c->models.push_back(std::move(nm));
+    return MF_OK;
+}
+
 static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_depth, const uint8_t* d_mask_in,
                               const int32_t* class_ids, int n_masks, float weight_multiplier, int64_t timestamp = 0,
                               const float* in_pose16 = nullptr, bool bootstrap = false) {
@@ -704,10 +731,11 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
     ModelState& bg = *c->models[0];
     bool main_done_recorded = false;
 
-    int prc = enqueue_preprocess(c, d_rgb, d_depth, k);
+    int prc = enqueue_preprocess(c, d_rgb, d_depth, k, c->map_ready);
     if (prc != MF_OK) return prc;
 
-    if (c->host_tick == 1) {
+    if (!c->map_ready) {
+        c->map_ready = true;
         mark(c, 2); mark(c, 3); mark(c, 4); mark(c, 5); mark(c, 6);
         // :235-238
         launch_init_surfels(d_rgb, d_depth, depthF, W, H, c->K, g.max_depth_processed, bg.d_frame, c->d_cand_rec, c->d_flags, s);
@@ -805,24 +833,8 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
             }
             bool spawned = false;
             if (res.hasNewLabel && (int)c->models.size() < g.max_models) {
-                // spawnObjectModel (:671-684): pose = I, makeStatic(globalPose); moveNewModelToList
-                std::unique_ptr<ModelState> nm;
-                const int id = take_next_model_id(c);
-                if (!c->pool.empty()) {   // spawnObjectModel, :673-676: take a preallocated model
-                    nm = std::move(c->pool.front());
-                    c->pool.erase(c->pool.begin());
-                    nm->id = id;
-                    nm->confThr = g.conf_object;
-                    hipLaunchKernelGGL(k_pose_identity, dim3(1), dim3(64), 0, s, nm->d_pose);
-                    hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(64), 0, s, nm->d_frame, c->host_tick);
-                    nm->h_frame->tick = c->host_tick;
-                } else {
-                    int rc = create_model(c, id, g.conf_object, false, surfel_capacity(g.num_osurfels), nm);
-                    if (rc != MF_OK) return rc;
-                }
-                nm->classID = res.newClassID;
-                launch_spawn_pose(nm->d_pose, bg.d_pose, nm->d_frame, bg.d_frame, nm->h_pose, s);
-                c->models.push_back(std::move(nm));
+                int rc = spawn_object(c, take_next_model_id(c), res.newClassID);
+                if (rc != MF_OK) return rc;
                 c->spawnOffset = 0;
                 spawned = true;
             }
@@ -892,8 +904,8 @@ extern "C" int mf_sync(mf_ctx* c) {
         if (hipEventElapsedTime(&run, c->ev[2], c->ev[8]) == hipSuccess) t[8] = run;
         float init = 0.f, iters = 0.f;
         t[1] = 0.f;
-        if (c->host_tick > 2 && hipEventElapsedTime(&init, c->ev[2], c->ev_icp[0]) == hipSuccess) t[1] = init;
-        if (c->host_tick > 2 && hipEventElapsedTime(&iters, c->ev_icp[0], c->ev_icp[1]) == hipSuccess) t[9] = iters;
+        if (c->tracked_once && hipEventElapsedTime(&init, c->ev[2], c->ev_icp[0]) == hipSuccess) t[1] = init;
+        if (c->tracked_once && hipEventElapsedTime(&iters, c->ev_icp[0], c->ev_icp[1]) == hipSuccess) t[9] = iters;
         memcpy(c->last_ms, t, sizeof(t));
     }
     return MF_OK;
@@ -962,7 +974,7 @@ static __global__ void k_set_tick(FrameDev* f, int tick, FrameDev* host_mirror) 
 // MaskFusion::setTick (Core/MaskFusion.h:206): the run loop uses it to start at / skip to a frame number
 extern "C" int mf_set_tick(mf_ctx* c, int32_t tick) {
     if (!c || tick < 1) return MF_EINVAL;
-    if (c->host_tick == 1 && tick != 1) { c->err = "setTick before the first frame would skip the map initialisation"; return MF_ESTATE; }
+    if (!c->map_ready && tick != 1) { c->err = "setTick before the first frame would skip the map initialisation"; return MF_ESTATE; }
     c->host_tick = tick;
     for (auto& m : c->models) hipLaunchKernelGGL(k_set_tick, dim3(1), dim3(64), 0, c->stream, m->d_frame, tick, m->h_frame);
     return check_launch(c);
@@ -988,7 +1000,7 @@ static long staged_frame(const mf_ctx* c) { return c->frame_no - 1; }   // index
 static const uint8_t* current_mask(const mf_ctx* c) { return c->cfg.enable_multiple_models ? c->d_mask_tex : c->d_zero_mask; }
 
 // upload + MaskFusion::filterDepth (:217) + Model::generateCUDATextures (Model.cpp:350-389) + intensity pyramid: everything of
-// processFrame that does not touch a model.  mask: model id per pixel = what textureMask holds for fuse / clean (NULL: zeros)
+// processFrame that does not touch a model.  mask: model id per pixel = what textureMask holds for fuse / clean (NULL: left as it is)
 extern "C" int mf_stage_frame(mf_ctx* c, const uint8_t* rgb, const float* depth, const uint8_t* mask) {
     if (!c || !rgb || !depth) return MF_EINVAL;
     hipStream_t sin = c->overlap ? c->stream_pre : c->stream;
@@ -996,12 +1008,7 @@ extern "C" int mf_stage_frame(mf_ctx* c, const uint8_t* rgb, const float* depth,
     MF_HIP(c, hipMemcpyAsync(c->d_rgb, rgb, (size_t)c->P * 3, hipMemcpyHostToDevice, sin));
     MF_HIP(c, hipMemcpyAsync(c->d_depth, depth, (size_t)c->P * sizeof(float), hipMemcpyHostToDevice, sin));
     if (mask) MF_HIP(c, hipMemcpyAsync(c->d_mask_tex, mask, (size_t)c->P, hipMemcpyHostToDevice, sin));
-    else MF_HIP(c, hipMemsetAsync(c->d_mask_tex, 0, (size_t)c->P, sin));
-    // the vertex / normal maps are only skipped for the frame that initialises the map (tick 1); a staged frame always has them
-    const int keep = c->host_tick;
-    if (c->host_tick == 1) c->host_tick = 2;
-    int rc = enqueue_preprocess(c, c->d_rgb, c->d_depth, c->frame_no);
-    c->host_tick = keep;
+    int rc = enqueue_preprocess(c, c->d_rgb, c->d_depth, c->frame_no, true);   // a staged frame always has its vertex / normal maps
     if (rc != MF_OK) return rc;
     c->lastF = (int)(c->frame_no % 3);
     c->frame_no++;
@@ -1016,7 +1023,7 @@ extern "C" int mf_model_initialise(mf_ctx* c, int32_t model) {
     launch_init_surfels(c->cur_rgb, c->cur_depth, c->d_depthF[k % 3], c->W, c->H, c->K, c->cfg.max_depth_processed, m->d_frame, c->d_cand_rec,
                         c->d_flags, c->stream);
     launch_compact_records(c->d_cand_rec, c->d_flags, c->P, m->surf[m->cur], m->d_frame, c->d_block_counts, m->h_count, c->stream);
-    if (c->host_tick == 1) c->host_tick = 2;
+    if (model == 0) c->map_ready = true;
     return check_launch(c);
 }
 
@@ -1038,7 +1045,7 @@ extern "C" int mf_model_upload_map(mf_ctx* c, int32_t model, const float* surfel
         MF_HIP(c, hipMemcpy(s.nr, d.data(), count * sizeof(float4), hipMemcpyHostToDevice));
     }
     hipLaunchKernelGGL(k_set_count, dim3(1), dim3(64), 0, c->stream, m->d_frame, (int)count, m->h_count);
-    if (c->host_tick == 1) c->host_tick = 2;   // the map exists: the next mf_process_frame tracks instead of initialising
+    if (model == 0) c->map_ready = true;   // the map exists: the next mf_process_frame tracks instead of initialising
     return check_launch(c);
 }
 
@@ -1076,7 +1083,8 @@ extern "C" int mf_model_perform_tracking(mf_ctx* c, int32_t model, int32_t frame
     const long k = staged_frame(c);
     // tryFillIn = MaskFusion::requiresFillIn(model) (:630-648): the decision itself is taken on the device from the coverage of the
     // last prediction; here it only gates whether the fill-in source (the previous frame's filtered depth) is offered at all
-    enqueue_track(c, *m, (try_fill_in && m->allowFillIn) ? c->d_depthF[(k + 2) % 3] : nullptr, 0.f, k);
+    // object models carry the 0.2 m jump rule of the caller (MaskFusion.cpp:268-272): pose->alive = 0 marks "remove this model"
+    enqueue_track(c, *m, (try_fill_in && m->allowFillIn) ? c->d_depthF[(k + 2) % 3] : nullptr, model == 0 ? 0.f : 0.2f, k);
     c->cfg = keep;
     return check_launch(c);
 }
@@ -1195,6 +1203,119 @@ extern "C" int mf_make_static(mf_ctx* c, int32_t model) {
 extern "C" int mf_set_trackable_class_ids(mf_ctx* c, const int32_t* ids, int32_t n) {
     if (!c || n < 0 || (n > 0 && !ids)) return MF_EINVAL;
     c->trackable.assign(ids, ids + n);
+    return MF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Model-sharded scenes: several contexts (one per GPU) each own some of the models of ONE scene.  The couplings
+// of MaskFusion::processFrame between models -- the z-merged model-id image (GlobalProjection), the label image and the
+// background pose -- cross the contexts through these calls; maskfusion_amd/sharded.py sequences them with RCCL collectives.
+// ------------------------------------------------------------------------------------------------
+// GlobalProjection::project (Core/Model/GlobalProjection.cpp:43-107) of this context's models only
+extern "C" int mf_export_projection_keys_dev(mf_ctx* c, const int32_t* orders, int32_t n_orders, uint64_t* d_keys_out) {
+    if (!c || !d_keys_out || n_orders != (int32_t)c->models.size() || (n_orders > 0 && !orders)) return MF_EINVAL;
+    hipStream_t s = c->stream;
+    for (size_t i = 0; i < c->models.size(); ++i) {
+        ModelState& m = *c->models[i];
+        if (orders[i] < 0) continue;   // a stand-in (e.g. the background on a rank that only holds objects): not drawn
+        launch_global_scatter(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, c->cfg.depth_cutoff, 12.0f, c->cfg.time_delta, orders[i], m.id,
+                              c->d_keys, s);
+    }
+    MF_HIP(c, hipMemcpyAsync(d_keys_out, c->d_keys, (size_t)c->P * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+    launch_fill_keys(c->d_keys, c->P, s);
+    return check_launch(c);
+}
+// GlobalProjection::downloadDirect (:109-114) of a key image merged over all contexts (per-pixel minimum)
+extern "C" int mf_import_projection_keys_dev(mf_ctx* c, const uint64_t* d_keys) {
+    if (!c || !d_keys) return MF_EINVAL;
+    MF_HIP(c, hipMemcpyAsync(c->d_keys, d_keys, (size_t)c->P * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
+    launch_global_resolve(c->d_keys, c->d_proj_ids, c->P, c->stream);   // leaves the key image empty again
+    return check_launch(c);
+}
+// MaskFusion::performSegmentation (Core/MaskFusion.h:59; MfSegmentation::performSegmentation, MfSegmentation.cpp:83-538) on the
+// staged frame: geometric edges of its vertex / normal maps, then the label stage against `mask` (host, may be NULL) and the
+// projected-id image of the last global projection.  model_ids == NULL: this context's own model list; otherwise the GLOBAL list
+// (index 0 = background).  The result becomes textureMask (mf_download_segmentation / mf_export_segmentation_dev).  Synchronous.
+extern "C" int mf_perform_segmentation(mf_ctx* c, const uint8_t* mask, const int32_t* class_ids, int32_t n_masks, const int32_t* model_ids,
+                                       const int32_t* model_class_ids, int32_t n_models, int32_t next_model_id, int32_t allow_new,
+                                       int32_t* has_new_label, int32_t* new_class_id) {
+    if (!c || !has_new_label || !new_class_id || c->frame_no == 0 || (model_ids && (!model_class_ids || n_models < 1))) return MF_EINVAL;
+    if (n_masks < 0 || n_masks > 256 || (n_masks > 0 && (!mask || !class_ids))) return MF_EINVAL;
+    hipStream_t s = c->stream;
+    const int set = (int)(staged_frame(c) & 1);
+    launch_edge_map(c->d_vmap[set][0], c->d_nmap[set][0], c->d_edge, c->W, c->H, c->seg.weightDistance, c->seg.weightConvexity, s);
+    launch_edge_binary(c->d_edge, c->d_bin, c->d_tmp_u8, c->W, c->H, c->seg.threshold, c->seg.morphEdgeRadius, c->seg.morphEdgeIterations, s);
+    if (n_masks > 0) MF_HIP(c, hipMemcpyAsync(c->d_mask_in, mask, (size_t)c->P, hipMemcpyHostToDevice, s));
+    std::vector<SegModelInfo> infos;
+    std::vector<const PoseDev*> poses;
+    if (model_ids) {
+        for (int i = 0; i < n_models; ++i) {
+            infos.push_back(SegModelInfo{model_ids[i], model_class_ids[i]});
+            const PoseDev* p = c->models[0]->d_pose;   // models that live in another context: "alive" (the background never dies)
+            for (auto& m : c->models) if (m->id == model_ids[i]) p = m->d_pose;
+            poses.push_back(p);
+        }
+    } else {
+        for (auto& m : c->models) { infos.push_back(SegModelInfo{m->id, m->classID}); poses.push_back(m->d_pose); }
+        next_model_id = c->nextID;
+    }
+    static const int32_t kNoClass[1] = {0};
+    int rc = c->labels->enqueue(c->seg, c->W, c->H, c->d_bin, c->cur_depth, n_masks > 0 ? c->d_mask_in : nullptr, n_masks > 0 ? class_ids : kNoClass,
+                                n_masks, c->d_proj_ids, infos, poses, next_model_id, allow_new != 0, c->d_mask_tex, s);
+    if (rc != MF_OK) return rc;
+    MF_HIP(c, hipStreamSynchronize(s));
+    if (c->labels->h_result[2]) { c->err = "label stage: vote tables overflowed (too many components x masks)"; return MF_ESTATE; }
+    *has_new_label = c->labels->h_result[0] != 0;
+    *new_class_id = c->labels->h_result[1];
+    return MF_OK;
+}
+extern "C" int mf_export_segmentation_dev(mf_ctx* c, uint8_t* d_out) {
+    if (!c || !d_out) return MF_EINVAL;
+    MF_HIP(c, hipMemcpyAsync(d_out, c->d_mask_tex, (size_t)c->P, hipMemcpyDeviceToDevice, c->stream));
+    return MF_OK;
+}
+// textureMask->Upload(fullSegmentation) (Core/MaskFusion.cpp:297) with a label image computed by another context
+extern "C" int mf_import_segmentation_dev(mf_ctx* c, const uint8_t* d_in) {
+    if (!c || !d_in) return MF_EINVAL;
+    MF_HIP(c, hipMemcpyAsync(c->d_mask_tex, d_in, (size_t)c->P, hipMemcpyDeviceToDevice, c->stream));
+    return MF_OK;
+}
+// spawnObjectModel (Core/MaskFusion.cpp:671-684) with an id chosen by the caller (the context that runs the label stage owns
+// getNextModelID); the new model is appended to this context's list, anchored to its background pose
+extern "C" int mf_spawn_object_model(mf_ctx* c, int32_t id, int32_t class_id) {
+    if (!c || id < 0 || id > 255) return MF_EINVAL;
+    for (auto& m : c->models) if (m->id == id) { c->err = "model id in use"; return MF_EINVAL; }
+    int rc = spawn_object(c, id, class_id);
+    if (rc != MF_OK) return rc;
+    c->models.back()->maxDepth = 30.f + 30.f * 1.2f;   // :335-339 (depthMean = depthStd = 30)
+    return check_launch(c);
+}
+// inactivateModel (Core/MaskFusion.cpp:686-713): the model leaves the list, its pose log is kept for exportPoses
+extern "C" int mf_drop_model(mf_ctx* c, int32_t model) {
+    ModelState* m = model_at(c, model);
+    if (!m || model == 0) return MF_EINVAL;
+    mf_ctx::RetiredLog r;
+    r.id = m->id;
+    if (download_pose_log(c, *m, r.ts, r.p) == MF_OK && !r.ts.empty()) c->retired.push_back(std::move(r));
+    MF_HIP(c, hipStreamSynchronize(c->stream));
+    c->models.erase(c->models.begin() + model);
+    return MF_OK;
+}
+// Model::updateStaticPose(globalPose) (Core/Model/Model.h:263): pose = initialC2Winv * background pose
+extern "C" int mf_model_update_static_pose(mf_ctx* c, int32_t model) {
+    ModelState* m = model_at(c, model);
+    if (!m || model == 0) return MF_EINVAL;
+    launch_static_pose(m->d_pose, c->models[0]->d_pose, m->h_pose, c->stream);
+    return check_launch(c);
+}
+// the per-frame object bookkeeping of processFrame for this context's object models: setMaxDepth (Core/MaskFusion.cpp:335-339)
+// and the confidence ramp min(4.5, age / 25) (:369-374)
+extern "C" int mf_update_object_params(mf_ctx* c) {
+    if (!c) return MF_EINVAL;
+    for (size_t i = 1; i < c->models.size(); ++i) {
+        c->models[i]->maxDepth = 30.f + 30.f * 1.2f;
+        c->models[i]->confThr = fminf(4.5f, (float)c->models[i]->age / 25.0f);
+    }
     return MF_OK;
 }
 

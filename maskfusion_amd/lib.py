@@ -99,6 +99,16 @@ SYMBOLS = {
     "mf_model_clean": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float]),
     "mf_model_combined_predict": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_int32]),
     "mf_model_upload_map": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32]),
+    "mf_export_projection_keys_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "mf_import_projection_keys_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mf_perform_segmentation": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "mf_export_segmentation_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mf_import_segmentation_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mf_spawn_object_model": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "mf_drop_model": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mf_model_update_static_pose": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mf_update_object_params": (C.c_int, [C.c_void_p]),
     "mf_make_nonstatic": (C.c_int, [C.c_void_p, C.c_int32]),
     "mf_make_static": (C.c_int, [C.c_void_p, C.c_int32]),
     "mf_set_trackable_class_ids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),

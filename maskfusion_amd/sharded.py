@@ -1,0 +1,332 @@
+"""One multi-model scene sharded BY MODEL over several contexts (one per GPU): SURVEY.md 8e, BASELINE.json configs[3] / [4].
+
+MaskFusion's per-model state (surfel map, tracker pyramids, pose) is independent (Core/Model/Model.h:271-323).  What
+MaskFusion::processFrame couples between models crosses the contexts here:
+
+  frame                      rank 0 -> all     broadcast rgb + depth (7 P bytes); every rank filters / builds its own pyramids
+  background pose            rank 0 -> all     broadcast 64 B (static objects follow it, Model.h:263; spawn anchors to it)
+  z-merged model-id image    all   -> all      all-reduce(MIN) of the uint64 projection keys (GlobalProjection.cpp:43-114)
+  per-model state            all   -> rank 0   gather {pose, ICP error, inliers, surfels, alive} (the 0.2 m jump rule, logging)
+  label image + control      rank 0 -> all     broadcast P bytes + {has_new, new id, new class, owner rank} (MaskFusion.cpp:289-297)
+
+Rank 0 owns the background model, the label stage and the model-id allocator; an object model lives on the rank chosen when it
+is spawned (the rank with the fewest models; rank 0 only when it is alone).  The frame logic is written as three phases per rank
+(`phase_track`, `phase_segment` on rank 0, `phase_fuse`) so that the same code runs
+  * SPMD, one process per GPU, with torch.distributed collectives between the phases (`ShardedMaskFusion.process_frame`), and
+  * in ONE process over several contexts on one GPU, the "collectives" being plain tensor ops (`LocalGroup`): the parity test
+    compares that with the single-context multi-model run bit for bit.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .api import MaskFusion
+from . import dist as mfd
+
+STATE_W = mfd.STATS_WIDTH        # R(9) t(3) icpError icpCount surfels alive
+MAX_LOCAL = 32                   # object models per rank in the gathered state block
+
+
+@dataclass
+class GlobalModel:
+    """one entry of MaskFusion::models as rank 0 sees it"""
+    id: int
+    class_id: int
+    rank: int
+
+
+@dataclass
+class Control:
+    """what rank 0 tells everybody after the label stage (16 int32 on the wire)"""
+    has_new: int = 0
+    new_id: int = 0
+    new_class: int = -1
+    owner: int = 0
+    order: List[int] = field(default_factory=list)     # global list (ids in order) after drops, before the spawn
+
+
+class Shard:
+    """One rank: a context plus the bookkeeping of which global models it holds."""
+
+    def __init__(self, rank: int, world: int, mf: MaskFusion, device: torch.device):
+        self.rank, self.world, self.mf, self.device = rank, world, mf, device
+        P = mf.width * mf.height
+        self.keys = torch.empty(P, dtype=torch.int64, device=device)
+        self.labels = torch.empty(P, dtype=torch.uint8, device=device)
+        self.bg_pose = torch.zeros(16, dtype=torch.float32, device=device)
+        self.state = torch.zeros((MAX_LOCAL + 1, STATE_W), dtype=torch.float32, device=device)
+        # rank 0 only
+        self.table: List[GlobalModel] = [GlobalModel(0, -1, 0)]
+        self.next_id = 1
+        self.spawn_offset = 0
+        self.tick = 1
+
+    # ---------------------------------------------------------------------------------------------
+    def local_ids(self) -> List[int]:
+        return [m.getID() for m in self.mf.getModels()]
+
+    def owns_background(self) -> bool:
+        return self.rank == 0
+
+    # ---- phase 1: everything up to the global projection ---------------------------------------------
+    def phase_track(self, rgb: np.ndarray, depth: np.ndarray, order_of_id: dict, cfg: dict, first: bool, bg_pose16: Optional[np.ndarray] = None):
+        """stage the frame, track the local models, scatter them into this rank's key image.  bg_pose16: the background's NEW pose,
+        needed here only by ranks that hold static objects (they follow it before they are projected, MaskFusion.cpp:274,289)"""
+        mf = self.mf
+        mf.stageFrame(rgb, depth)
+        models = mf.getModels()
+        if first:
+            if self.owns_background():
+                models[0].initialise()
+            return
+        if not self.owns_background() and bg_pose16 is not None:
+            mf._chk(mf._L.mf_model_override_pose(mf._h, 0, np.ascontiguousarray(bg_pose16, np.float32).ctypes.data))
+        for i, m in enumerate(models):
+            if i == 0 and not self.owns_background():
+                continue                                  # the background stand-in
+            info = m.info()
+            if i == 0 or (not info.is_static) or cfg["trackAllModels"]:
+                m.performTracking(False, cfg["rgbOnly"], cfg["icpWeight"], True, cfg["fastOdom"], cfg["so3"], cfg["maxDepthProcessed"], 0, i == 0)
+            else:
+                mf._chk(mf._L.mf_model_update_static_pose(mf._h, i))     # updateStaticPose(globalPose), :274
+        orders = np.array([order_of_id.get(mid, -1) if (i > 0 or self.owns_background()) else -1 for i, mid in enumerate(self.local_ids())], np.int32)
+        mf._chk(mf._L.mf_export_projection_keys_dev(mf._h, orders.ctypes.data, len(orders), self.keys.data_ptr()))
+        for i in range(len(models)):
+            mf.modelStateDevice(i, self.state[i].data_ptr())
+
+    # ---- phase 2 (rank 0): label stage on the merged projection ---------------------------------------
+    def phase_segment(self, mask: Optional[np.ndarray], class_ids: Sequence[int], merged_keys: torch.Tensor, alive_of_id: dict, cfg: dict) -> Control:
+        mf = self.mf
+        import ctypes as C
+        # inactivateModel for objects the jump rule dropped on their ranks (MaskFusion.cpp:268-272)
+        self.table = [g for g in self.table if g.id == 0 or alive_of_id.get(g.id, 1)]
+        mf._chk(mf._L.mf_import_projection_keys_dev(mf._h, merged_keys.data_ptr()))
+        if self.spawn_offset < cfg["modelSpawnOffset"]:
+            self.spawn_offset += 1                          # :294
+        ids = np.array([g.id for g in self.table], np.int32)
+        cls = np.array([g.class_id for g in self.table], np.int32)
+        has_new, new_cls = C.c_int32(0), C.c_int32(-1)
+        m = np.ascontiguousarray(mask, np.uint8) if mask is not None and len(class_ids) else None
+        cid = np.ascontiguousarray(class_ids, np.int32) if m is not None else None
+        mf._chk(mf._L.mf_perform_segmentation(mf._h, m.ctypes.data if m is not None else None, cid.ctypes.data if cid is not None else None,
+                                              len(class_ids) if m is not None else 0, ids.ctypes.data, cls.ctypes.data, len(ids), self.next_id,
+                                              int(self.spawn_offset >= cfg["modelSpawnOffset"]), C.byref(has_new), C.byref(new_cls)))
+        ctl = Control(order=[g.id for g in self.table])
+        if has_new.value and len(self.table) < cfg["maxModels"]:
+            ctl.has_new, ctl.new_id, ctl.new_class = 1, self.next_id, new_cls.value
+            load = [sum(1 for g in self.table if g.rank == r) for r in range(self.world)]
+            ctl.owner = 0 if self.world == 1 else 1 + int(np.argmin(load[1:]))
+            self.table.append(GlobalModel(ctl.new_id, ctl.new_class, ctl.owner))
+            used = {g.id for g in self.table}
+            while True:                                     # getNextModelID (MaskFusion.cpp:715-731)
+                self.next_id = (self.next_id + 1) & 255
+                if self.next_id not in used:
+                    break
+            self.spawn_offset = 0
+        mf._chk(mf._L.mf_export_segmentation_dev(mf._h, self.labels.data_ptr()))
+        return ctl
+
+    # ---- phase 3: labels + control in, fuse / clean / predict the local models -------------------------
+    def phase_fuse(self, ctl: Control, bg_pose16: np.ndarray, cfg: dict, weight_multiplier: float, timestamp: int, first: bool):
+        mf = self.mf
+        t = self.tick
+        if first:
+            if self.owns_background():
+                mf.getBackgroundModel().combinedPredict(cfg["maxDepthProcessed"], t, t, cfg["timeDelta"])
+            mf.endFrame(timestamp)
+            self.tick += 1
+            return
+        if not self.owns_background():
+            mf._chk(mf._L.mf_import_segmentation_dev(mf._h, self.labels.data_ptr()))
+            mf._chk(mf._L.mf_model_override_pose(mf._h, 0, np.ascontiguousarray(bg_pose16, np.float32).ctypes.data))
+        # drops decided by the jump rule: the list rank 0 kept
+        keep = set(ctl.order)
+        for i in reversed(range(1, len(mf.getModels()))):
+            if mf.getModels()[i].getID() not in keep:
+                mf._chk(mf._L.mf_drop_model(mf._h, i))
+        spawned = None
+        if ctl.has_new and ctl.owner == self.rank:
+            mf._chk(mf._L.mf_spawn_object_model(mf._h, ctl.new_id, ctl.new_class))
+            spawned = len(mf.getModels()) - 1
+        models = mf.getModels()
+        if spawned is not None:      # :342-353: predictIndices; fuse(maxDepthProcessed, weight 100); clean (no second index pass)
+            nm = models[spawned]
+            nm.predictIndices(t, cfg["maxDepthProcessed"], cfg["timeDelta"])
+            nm.fuse(t, cfg["maxDepthProcessed"], 100.0)
+            nm.clean(t, cfg["timeDelta"], cfg["maxDepthProcessed"])
+        mf._chk(mf._L.mf_update_object_params(mf._h))      # :335-339, :369-374 (after the spawn-frame fuse, which runs with initConfidenceObject)
+        first_local = 0 if self.owns_background() else 1
+        if not cfg["rgbOnly"]:       # :539-565
+            for m in models[first_local:]:
+                m.predictIndices(t, cfg["maxDepthProcessed"], cfg["timeDelta"])
+                m.fuse(t, cfg["depthCutoff"], weight_multiplier)
+                m.predictIndices(t, cfg["maxDepthProcessed"], cfg["timeDelta"])
+                m.clean(t, cfg["timeDelta"], cfg["maxDepthProcessed"])
+        for m in models[first_local:]:   # predict(), :569
+            m.combinedPredict(cfg["maxDepthProcessed"], t, t, cfg["timeDelta"])
+        mf.endFrame(timestamp)
+        self.tick += 1
+
+
+def default_cfg(**kw) -> dict:
+    cfg = dict(trackAllModels=True, rgbOnly=False, icpWeight=100.0, fastOdom=False, so3=False, maxDepthProcessed=20.0, depthCutoff=3.0,
+               timeDelta=200, modelSpawnOffset=20, maxModels=32)
+    cfg.update(kw)
+    return cfg
+
+
+def _alive_from_states(states: Sequence[torch.Tensor], ids_per_rank: Sequence[Sequence[int]]) -> dict:
+    """{model id: alive} from the gathered per-rank state blocks"""
+    out = {}
+    for st, ids in zip(states, ids_per_rank):
+        a = st.cpu().numpy()
+        for i, mid in enumerate(ids):
+            out[mid] = int(a[i, 15] != 0)
+    return out
+
+
+class LocalGroup:
+    """All shards in one process (one GPU): the parity-test form.  Collectives are tensor ops on the same device."""
+
+    def __init__(self, shards: Sequence[Shard], cfg: dict):
+        self.shards, self.cfg = list(shards), cfg
+        self.frame = 0
+
+    def process_frame(self, rgb, depth, mask=None, class_ids=(), weight_multiplier=1.0, timestamp=0):
+        first = self.frame == 0
+        s0 = self.shards[0]
+        order_of_id = {g.id: i for i, g in enumerate(s0.table)}
+        s0.phase_track(rgb, depth, order_of_id, self.cfg, first)
+        early_pose = None
+        if not first and not self.cfg["trackAllModels"]:
+            s0.mf.sync()
+            early_pose = np.ascontiguousarray(s0.mf.getCurrPose().astype(np.float32).T.reshape(16))
+        for s in self.shards[1:]:
+            s.phase_track(rgb, depth, order_of_id, self.cfg, first, early_pose)
+        ctl = Control(order=[g.id for g in s0.table])
+        bg_pose = np.eye(4, dtype=np.float32).T.reshape(16)
+        if not first:
+            for s in self.shards:
+                s.mf.sync()
+            merged = mfd.keys_to_wire(self.shards[0].keys).clone()
+            for s in self.shards[1:]:
+                merged = torch.minimum(merged, mfd.keys_to_wire(s.keys))
+            merged = _wire_to_keys(merged)
+            torch.cuda.synchronize()
+            alive = _alive_from_states([s.state for s in self.shards], [s.local_ids() for s in self.shards])
+            for s in self.shards[1:]:
+                alive.pop(0, None)       # the background stand-ins of the object ranks say nothing about the background
+            alive[0] = 1
+            ctl = s0.phase_segment(mask, class_ids, merged, alive, self.cfg)
+            s0.mf.sync()
+            bg_pose = np.ascontiguousarray(s0.mf.getCurrPose().astype(np.float32).T.reshape(16))
+            for s in self.shards[1:]:
+                s.labels.copy_(s0.labels)
+            torch.cuda.synchronize()
+        for s in self.shards:
+            s.phase_fuse(ctl, bg_pose, self.cfg, weight_multiplier, timestamp, first)
+        self.frame += 1
+        return ctl
+
+
+def _wire_to_keys(wire: torch.Tensor) -> torch.Tensor:
+    """int64 wire values back to the library's uint64 keys (INT64_MAX -> all ones)"""
+    return torch.where(wire == mfd.INT64_MAX, torch.full_like(wire, -1), wire)
+
+
+class ShardedMaskFusion:
+    """SPMD form: one process per GPU, torch.distributed (RCCL) between the phases.  Every rank calls process_frame with the same
+    arguments; only rank 0's rgb / depth / mask are used (the others may pass None)."""
+
+    def __init__(self, mf: MaskFusion, device: torch.device, cfg: dict):
+        import torch.distributed as dist
+        self.dist = dist
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.shard = Shard(self.rank, self.world, mf, device)
+        self.cfg = cfg
+        self.device = device
+        H, W = mf.height, mf.width
+        self.rgb = torch.empty((H, W, 3), dtype=torch.uint8, device=device)
+        self.depth = torch.empty((H, W), dtype=torch.float32, device=device)
+        self.ctl = torch.zeros(8 + 64, dtype=torch.int32, device=device)
+        self.frame = 0
+
+    def process_frame(self, rgb=None, depth=None, mask=None, class_ids=(), weight_multiplier=1.0, timestamp=0):
+        dist, s, first = self.dist, self.shard, self.frame == 0
+        if self.rank == 0:
+            self.rgb.copy_(torch.from_numpy(np.ascontiguousarray(rgb, np.uint8)))
+            self.depth.copy_(torch.from_numpy(np.ascontiguousarray(depth, np.float32)))
+        if self.world > 1:
+            dist.broadcast(self.rgb, 0)
+            dist.broadcast(self.depth, 0)
+        rgb_h, depth_h = self.rgb.cpu().numpy(), self.depth.cpu().numpy()
+        # the global list as of the end of the previous frame travels in the control record
+        order = [int(x) for x in self.ctl[8:8 + int(self.ctl[7].item())].tolist()] if self.frame else [0]
+        order_of_id = {mid: i for i, mid in enumerate(order)}
+        if first or self.cfg["trackAllModels"] or self.world == 1:
+            s.phase_track(rgb_h, depth_h, order_of_id, self.cfg, first)
+        else:
+            # static objects are projected with the background's NEW pose: rank 0 tracks first and publishes it (64 B)
+            if self.rank == 0:
+                s.phase_track(rgb_h, depth_h, order_of_id, self.cfg, first)
+                s.mf.sync()
+                s.bg_pose.copy_(torch.from_numpy(np.ascontiguousarray(s.mf.getCurrPose().astype(np.float32).T.reshape(16))))
+            dist.broadcast(s.bg_pose, 0)
+            if self.rank != 0:
+                s.phase_track(rgb_h, depth_h, order_of_id, self.cfg, first, s.bg_pose.cpu().numpy())
+        ctl = Control(order=order)
+        bg_pose = np.eye(4, dtype=np.float32).T.reshape(16)
+        if not first:
+            s.mf.sync()
+            wire = mfd.merge_projection_keys(mfd.keys_to_wire(s.keys).clone())
+            ids_block = torch.full((MAX_LOCAL + 1,), -1, dtype=torch.float32, device=self.device)
+            ids = s.local_ids()
+            ids_block[:len(ids)] = torch.tensor(ids, dtype=torch.float32)
+            send = torch.cat([s.state.reshape(-1), ids_block])
+            if self.world > 1:
+                recv = [torch.empty_like(send) for _ in range(self.world)] if self.rank == 0 else None
+                dist.gather(send, recv, dst=0)
+            else:
+                recv = [send]
+            torch.cuda.synchronize()
+            if self.rank == 0:
+                alive = {}
+                for r, blk in enumerate(recv):
+                    b = blk.cpu().numpy()
+                    st = b[:(MAX_LOCAL + 1) * STATE_W].reshape(MAX_LOCAL + 1, STATE_W)
+                    for i, mid in enumerate(b[(MAX_LOCAL + 1) * STATE_W:]):
+                        if mid >= 0 and not (r > 0 and i == 0):
+                            alive[int(mid)] = int(st[i, 15] != 0)
+                alive[0] = 1
+                keys = _wire_to_keys(wire)
+                torch.cuda.synchronize()
+                ctl = s.phase_segment(mask, class_ids, keys, alive, self.cfg)
+                s.mf.sync()
+                bg_pose = np.ascontiguousarray(s.mf.getCurrPose().astype(np.float32).T.reshape(16))
+                rec = [ctl.has_new, ctl.new_id, ctl.new_class, ctl.owner, 0, 0, 0, len(ctl.order)] + ctl.order
+                self.ctl.zero_()
+                self.ctl[:len(rec)] = torch.tensor(rec, dtype=torch.int32)
+                s.bg_pose.copy_(torch.from_numpy(bg_pose))
+            if self.world > 1:
+                mfd.broadcast_labels(s.labels, s.bg_pose, 0)
+                dist.broadcast(self.ctl, 0)
+            torch.cuda.synchronize()
+            c = self.ctl.cpu().numpy()
+            ctl = Control(int(c[0]), int(c[1]), int(c[2]), int(c[3]), [int(x) for x in c[8:8 + int(c[7])]])
+            bg_pose = s.bg_pose.cpu().numpy()
+        s.phase_fuse(ctl, bg_pose, self.cfg, weight_multiplier, timestamp, first)
+        if not first and ctl.has_new:
+            # the list that the NEXT frame's projection orders by includes the new model
+            c = self.ctl.cpu().numpy()
+            n = int(c[7])
+            self.ctl[8 + n] = ctl.new_id
+            self.ctl[7] = n + 1
+        elif first:
+            self.ctl[7] = 1
+        self.frame += 1
+        return ctl

@@ -100,11 +100,17 @@ def _merge_worker(rank, world, port, out_dir):
     # every rank projects ITS model: depth image with holes, model id = rank + 1, order = rank
     z = rng.uniform(0.5, 4.0, (Hh, Ww)).astype(np.float32)
     hole = rng.random((Hh, Ww)) < 0.3
+    # the library's key layout (include/maskfusion_amd.h, mf_export_projection_keys_dev): float_bits(z) << 32 | order << 8 | id
+    z[0, :4] = 1.25                       # an exact depth tie between the ranks: the earlier model in the list (lower order) wins
+    hole[0, :4] = False
     key = (z.view(np.uint32).astype(np.uint64) << np.uint64(32)) | np.uint64((rank << 8) | (rank + 1))
     key[hole] = np.uint64(mfd.EMPTY_KEY_U64)
     wire = mfd.keys_to_wire(torch.from_numpy(key.view(np.int64).copy()))
     merged = mfd.merge_projection_keys(wire)
     ids = mfd.ids_from_keys(merged).numpy()
+    from maskfusion_amd import sharded
+    back = sharded._wire_to_keys(merged).numpy().view(np.uint64)      # what mf_import_projection_keys_dev receives
+    assert np.array_equal(back == np.uint64(mfd.EMPTY_KEY_U64), ids == 0) and np.array_equal((back & np.uint64(0xFF)).astype(np.uint8)[ids > 0], ids[ids > 0])
     labels = torch.from_numpy((ids * 3).astype(np.uint8)) if rank == 0 else torch.zeros((Hh, Ww), dtype=torch.uint8)
     pose = torch.arange(16, dtype=torch.float32) if rank == 0 else torch.zeros(16)
     labels, pose = mfd.broadcast_labels(labels, pose, 0)
@@ -120,5 +126,5 @@ def test_projection_merge_and_label_broadcast_world2(tmp_path):
     assert np.array_equal(a["ids"], b["ids"]) and np.array_equal(a["labels"], b["labels"]) and np.array_equal(a["pose"], b["pose"])
     z0 = np.where(a["hole"], np.inf, a["z"]); z1 = np.where(b["hole"], np.inf, b["z"])
     expect = np.where(np.isinf(z0) & np.isinf(z1), 0, np.where(z0 <= z1, 1, 2)).astype(np.uint8)
-    assert np.array_equal(a["ids"], expect)
+    assert np.array_equal(a["ids"], expect) and (a["ids"][0, :4] == 1).all()
     assert np.array_equal(a["labels"], expect * 3) and a["pose"].tolist() == list(range(16))

@@ -1,0 +1,71 @@
+"""-m gpu: a multi-model scene sharded BY MODEL over two contexts in one process (maskfusion_amd/sharded.py: the background and
+the label stage on context 0, every object model on context 1, the couplings through mf_export/import_projection_keys_dev,
+mf_perform_segmentation, mf_export/import_segmentation_dev and the background pose) against the single-context multi-model run
+(model-by-model tracking): label images, poses, model ids and surfel clouds must be BIT-IDENTICAL -- sharding moves models, it
+does not change a single operation (GlobalProjection.cpp:43-114, MaskFusion.cpp:289-297, Model.h:263-264)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEG = dict(mfThreshold=0.3, mfWeightDistance=150.0, mfWeightConvexity=2.8, mfMorphEdgeIterations=0, mfMorphMaskIterations=0,
+           newModelMinRelativeSize=0.004)
+N_FRAMES = 12
+
+
+def _make(track_all):
+    from maskfusion_amd import MaskFusion
+    m = MaskFusion(640, 480, 528.0, 528.0, 320.0, 240.0, icpThresh=100.0, so3=False, numGSurfels=1 << 20, numOSurfels=1 << 18,
+                   enableMultipleModels=True, modelSpawnOffset=3, trackAllModels=track_all)
+    for k, v in SEG.items():
+        m.setParam(k, v)
+    m.setParam("batchTracking", 0)
+    return m
+
+
+@pytest.mark.parametrize("track_all", [True, False], ids=["tracked-objects", "static-objects"])
+def test_two_contexts_equal_one_context(hip, track_all):
+    import torch
+    from maskfusion_amd import synth, sharded
+    st = synth.Stream(W=640, H=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, n_objects=2, noise=True, object_motion=1.0 if track_all else 0.0)
+    frames = [st.frame(k) for k in range(N_FRAMES)]
+    cls = [0, 41, 42]
+    # ---- reference: one context holds every model ----
+    one = _make(track_all)
+    ref = []
+    for k, (rgb, depth, mask) in enumerate(frames):
+        one.processFrame(rgb, depth, mask=mask, classIDs=cls, timestamp=k)
+        ms = one.getModels()
+        ref.append(dict(ids=[m.getID() for m in ms], cls=[m.getClassID() for m in ms], poses=[m.getPose() for m in ms],
+                        counts=[m.lastCount() for m in ms], seg=one.downloadSegmentation(), clouds=[m.downloadMap() for m in ms] if k == N_FRAMES - 1 else None))
+    one.close()
+    # ---- sharded: context 0 = background + label stage, context 1 = all object models ----
+    dev = torch.device("cuda", 0)
+    ctxs = [_make(track_all), _make(track_all)]
+    shards = [sharded.Shard(r, 2, ctxs[r], dev) for r in range(2)]
+    grp = sharded.LocalGroup(shards, sharded.default_cfg(trackAllModels=track_all, modelSpawnOffset=3))
+    for k, (rgb, depth, mask) in enumerate(frames):
+        grp.process_frame(rgb, depth, mask, cls, 1.0, k)
+        got = {}
+        for r, c in enumerate(ctxs):
+            for i, m in enumerate(c.getModels()):
+                if r > 0 and i == 0:
+                    continue       # the background stand-in of the object context
+                got[m.getID()] = dict(cls=m.getClassID(), pose=m.getPose(), count=m.lastCount(), cloud=m.downloadMap() if k == N_FRAMES - 1 else None)
+        want = ref[k]
+        print(k, "ids one-context", want["ids"], "sharded", sorted(got), "counts", want["counts"], [got[i]["count"] for i in want["ids"] if i in got])
+        assert sorted(got) == sorted(want["ids"]), k
+        assert [g.id for g in shards[0].table] == want["ids"], k
+        assert np.array_equal(ctxs[0].downloadSegmentation(), want["seg"]), k
+        if k > 0:
+            assert np.array_equal(ctxs[1].downloadSegmentation(), want["seg"]), k      # the label image reached the object context
+        for i, mid in enumerate(want["ids"]):
+            assert got[mid]["cls"] == want["cls"][i], (k, mid)
+            assert np.array_equal(got[mid]["pose"], want["poses"][i]), (k, mid, np.abs(got[mid]["pose"] - want["poses"][i]).max())
+            assert got[mid]["count"] == want["counts"][i], (k, mid)
+            if want["clouds"] is not None:
+                assert np.array_equal(got[mid]["cloud"], want["clouds"][i], equal_nan=True), (k, mid)
+    assert max(len(r["ids"]) for r in ref) >= 3, "the scenario must spawn both object models"
+    assert len(ctxs[1].getModels()) >= 3 and len(ctxs[0].getModels()) == 1      # objects live on context 1 only
+    for c in ctxs:
+        c.close()
