@@ -136,6 +136,9 @@ int mf_model_info(mf_ctx* ctx, int32_t model, mf_model_info_t* out);
 /* SegmentationResult::fullSegmentation of the last frame (Core/Segmentation/SegmentationResult.h:35): H*W model ids,
  * 255 = ignored.  Only meaningful with enable_multiple_models. */
 int mf_download_segmentation(mf_ctx* ctx, uint8_t* out);
+/* The exportSegmentation branch of processFrame (Core/MaskFusion.cpp:299-303): the label image of the last frame with 255 (ignored)
+ * zeroed, as an 8-bit greyscale PNG at `path` (upstream: exportDir + "Segmentation<tick>.png") */
+int mf_export_segmentation_png(mf_ctx* ctx, const char* path);
 /* whether the last tracking step used the fill-in maps (MaskFusion::requiresFillIn, MaskFusion.cpp:630-648) */
 int mf_get_last_fillin(mf_ctx* ctx, int32_t* used);
 

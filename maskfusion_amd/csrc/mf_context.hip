@@ -1499,6 +1499,70 @@ extern "C" int mf_download_segmentation(mf_ctx* c, uint8_t* out) {
     return MF_OK;
 }
 
+// MaskFusion.cpp:299-303: cv::threshold(fullSegmentation, out, 254, 255, THRESH_TOZERO_INV) (255 = ignored -> 0) then
+// cv::imwrite(exportDir + "Segmentation<tick>.png").  An 8-bit greyscale PNG with stored (uncompressed) deflate blocks: any
+// reader decodes it to the same pixels as OpenCV's file.
+static uint32_t png_crc(uint32_t crc, const uint8_t* p, size_t n) {
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t v = i;
+            for (int k = 0; k < 8; ++k) v = (v & 1) ? 0xEDB88320u ^ (v >> 1) : v >> 1;
+            table[i] = v;
+        }
+        init = true;
+    }
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 255] ^ (crc >> 8);
+    return crc;
+}
+static void png_chunk(std::vector<uint8_t>& f, const char* tag, const std::vector<uint8_t>& body) {
+    auto be32 = [&](uint32_t v) { for (int k = 3; k >= 0; --k) f.push_back((uint8_t)(v >> (8 * k))); };
+    be32((uint32_t)body.size());
+    const size_t at = f.size();
+    f.insert(f.end(), tag, tag + 4);
+    f.insert(f.end(), body.begin(), body.end());
+    be32(png_crc(0xFFFFFFFFu, f.data() + at, f.size() - at) ^ 0xFFFFFFFFu);
+}
+extern "C" int mf_export_segmentation_png(mf_ctx* c, const char* path) {
+    if (!c || !path) return MF_EINVAL;
+    std::vector<uint8_t> img((size_t)c->P);
+    int rc = mf_download_segmentation(c, img.data());
+    if (rc != MF_OK) return rc;
+    const int W = c->W, H = c->H;
+    std::vector<uint8_t> raw;   // filter byte 0 + row
+    raw.reserve((size_t)(W + 1) * H);
+    for (int y = 0; y < H; ++y) {
+        raw.push_back(0);
+        for (int x = 0; x < W; ++x) { const uint8_t v = img[(size_t)y * W + x]; raw.push_back(v > 254 ? 0 : v); }
+    }
+    std::vector<uint8_t> z = {0x78, 0x01};
+    uint32_t a = 1, b = 0;
+    for (uint8_t v : raw) { a = (a + v) % 65521u; b = (b + a) % 65521u; }
+    for (size_t off = 0; off < raw.size(); off += 65535) {
+        const size_t n = std::min<size_t>(65535, raw.size() - off);
+        z.push_back(off + n == raw.size() ? 1 : 0);
+        z.push_back((uint8_t)(n & 255)); z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 255)); z.push_back((uint8_t)((~n >> 8) & 255));
+        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+    }
+    const uint32_t adler = (b << 16) | a;
+    for (int k = 3; k >= 0; --k) z.push_back((uint8_t)(adler >> (8 * k)));
+    std::vector<uint8_t> f = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    std::vector<uint8_t> hdr;
+    for (uint32_t v : {(uint32_t)W, (uint32_t)H}) for (int k = 3; k >= 0; --k) hdr.push_back((uint8_t)(v >> (8 * k)));
+    hdr.insert(hdr.end(), {8, 0, 0, 0, 0});   // 8-bit, greyscale, deflate, no filter, no interlace
+    png_chunk(f, "IHDR", hdr);
+    png_chunk(f, "IDAT", z);
+    png_chunk(f, "IEND", {});
+    FILE* fp = fopen(path, "wb");
+    if (!fp) { c->err = std::string("cannot write ") + path; return MF_EINVAL; }
+    const bool ok = fwrite(f.data(), 1, f.size(), fp) == f.size();
+    fclose(fp);
+    if (!ok) { c->err = std::string("short write to ") + path; return MF_EINVAL; }
+    return MF_OK;
+}
+
 extern "C" int mf_download_map(mf_ctx* c, int32_t model, float* out, uint32_t max_count, uint32_t* count) {
     ModelState* ms = model_at(c, model);
     if (!ms || !out || !count) return MF_EINVAL;

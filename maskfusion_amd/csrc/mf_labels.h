@@ -18,6 +18,11 @@ struct SegParams {
     int minMappedComponentSize = 160;    // MfSegmentation.cpp:43
 };
 
+// A mask value that has no class id (FrameData::classIDs shorter than the ids the mask image uses, e.g. a 255 "ignore" label in a
+// precomputed Mask####.png) counts as "no mask" (0).  Upstream indexes classIDs[mask] unchecked (MfSegmentation.cpp:226,311), an
+// out-of-bounds read there; here every table indexed by a mask value goes through this.
+__host__ __device__ inline int mask_id(int value, int nMasks) { return value < nMasks ? value : 0; }
+
 struct SegModelInfo { int id; int classID; };
 struct SegResult { bool hasNewLabel = false; int newClassID = -1; };
 

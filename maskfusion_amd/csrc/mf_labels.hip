@@ -119,7 +119,7 @@ void segmentation_host(const SegParams& prm, int W, int H, const uint8_t* binary
     std::vector<uint8_t> binary(binaryIn, binaryIn + total);
     if (nMasks) {
         for (int i = 0; i < total; ++i) {
-            const bool person = classIDs[mask[i]] == prm.personClassID;
+            const bool person = classIDs[mask_id(mask[i], nMasks)] == prm.personClassID;
             ignoreMap[i] = person ? 255 : 0;
             if (person) binary[i] = 0;
         }
@@ -169,7 +169,7 @@ void segmentation_host(const SegParams& prm, int W, int H, const uint8_t* binary
     std::vector<int> maskPixels(std::max(nMasks, 1), 0);
     if (nMasks) {
         std::vector<int> compMask((size_t)nComponents * nMasks, 0);
-        for (int i = 0; i < total; ++i) compMask[(size_t)labels[i] * nMasks + mask[i]]++;
+        for (int i = 0; i < total; ++i) compMask[(size_t)labels[i] * nMasks + mask_id(mask[i], nMasks)]++;
         for (int c = 1; c < nComponents; ++c) {
             const int csize = stats[c].area;
             if (csize <= prm.minMappedComponentSize) continue;  // tiny components stay background

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_lab_init(const uint8_t* __restrict__ bi
     if (i < P) {
         b = binIn[i];
         if (T->nMasks) {   // MfSegmentation.cpp:221-235
-            const bool person = T->classIDs[mask[i]] == personClassID;
+            const bool person = T->classIDs[mask_id(mask[i], T->nMasks)] == personClassID;
             ignoreMap[i] = person ? 255 : 0;
             if (person) b = 0;
         } else if (ignoreMap[i]) b = 0;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void k_lab_hist(const int* __restrict__ lab, c
     const bool in = i < P;
     const int c = in ? lab[i] : 0;
     const int mi = in ? T->idToIndex[proj[i]] : 0;
-    const int mv = (in && T->nMasks) ? mask[i] : 0;
+    const int mv = (in && T->nMasks) ? mask_id(mask[i], T->nMasks) : 0;
     // row 0 of both tables (the background "component") is never read
     const int len = run_length(in && c != 0, ((unsigned long long)c << 16) | ((unsigned long long)mi << 8) | (unsigned long long)mv, false);
     if (len) {

@@ -72,6 +72,7 @@ SYMBOLS = {
     "mf_get_last_fillin": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "mf_model_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "mf_download_segmentation": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mf_export_segmentation_png": (C.c_int, [C.c_void_p, C.c_char_p]),
     "mf_segmentation_labels": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

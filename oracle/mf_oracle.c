@@ -1982,6 +1982,10 @@ static void morph_gray(const uint8_t* in, uint8_t* out, int W, int H, int r, int
         }
 }
 
+/* mask values without a class id count as "no mask" (0): upstream reads classIDs[mask] unchecked (MfSegmentation.cpp:226,311),
+ * which is undefined for such inputs; the product and this restatement define it the same way */
+static inline int mask_id(int value, int nMasks) { return value < nMasks ? value : 0; }
+
 void mfo_mf_segmentation_cpu(const mfo_seg_params* prm, int W, int H, const uint8_t* binaryIn, const float* depth,
                              const uint8_t* mask, const int32_t* classIDs, int nMasks, const uint8_t* projectedIDs,
                              const int32_t* modelIDs, const int32_t* modelClassIDs, int nModels, int nextModelID,
@@ -1995,7 +1999,7 @@ void mfo_mf_segmentation_cpu(const mfo_seg_params* prm, int W, int H, const uint
     /* ignore map, :221-235 */
     if (nMasks) {
         for (int i = 0; i < total; ++i) {
-            if (classIDs[mask[i]] == prm->personClassID) { ignoreMap[i] = 255; binary[i] = 0; }
+            if (classIDs[mask_id(mask[i], nMasks)] == prm->personClassID) { ignoreMap[i] = 255; binary[i] = 0; }
             else ignoreMap[i] = 0;
         }
     } else {
@@ -2046,7 +2050,7 @@ void mfo_mf_segmentation_cpu(const mfo_seg_params* prm, int W, int H, const uint
         compModelOverlap[(size_t)labels[i] * nModels + mi]++;
     }
     if (nMasks) {
-        for (int i = 0; i < total; ++i) compMaskOverlap[(size_t)labels[i] * nMasks + mask[i]]++;
+        for (int i = 0; i < total; ++i) compMaskOverlap[(size_t)labels[i] * nMasks + mask_id(mask[i], nMasks)]++;
         for (int c = 1; c < nComponents; ++c) {
             const int csize = stats[c * 5 + 4];
             if (csize > 160) { /* minMappedComponentSize */

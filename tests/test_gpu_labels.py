@@ -44,7 +44,7 @@ def test_device_label_stage_matches_oracle(hip, oracle, case):
     proj = np.zeros((H, W), np.uint8)
     if case["proj"] is not None:
         proj[mask == case["proj"]] = case["models"][1]
-    m_in = mask if len(case["cls"]) else np.zeros_like(mask)
+    m_in = tsh.case_mask(case, mask)
     ign_o, ign_d = np.zeros((H, W), np.uint8), np.zeros((H, W), np.uint8)
     ref = mfo_mm.mf_segmentation_cpu(W, H, inv, depth, m_in, case["cls"], proj, case["models"], case["mcls"], case["next_id"],
                                      case["allow"], ign_o, prm)

@@ -58,7 +58,21 @@ CASES = [
          seg=dict(morphMaskIterations=0, removeEdges=0, minRelSizeNew=0.001)),
     dict(cls=[0, 41, 42, 43], models=[0], mcls=[-1], proj=None, next_id=1, allow=True,
          seg=dict(morphMaskIterations=2, morphMaskRadius=2, minRelSizeNew=0.001)),
+    # mask values without a class id (object 3 and a 255 "ignore" patch, as a precomputed Mask####.png may carry) count as "no mask":
+    # upstream reads classIDs[mask] out of bounds there (MfSegmentation.cpp:226,311); round-1 code wrote past its vote table
+    dict(cls=[0, 41, 42], models=[0], mcls=[-1], proj=None, next_id=1, allow=True, seg=dict(minRelSizeNew=0.001), out_of_range=True),
 ]
+
+
+def case_mask(case, mask):
+    if not len(case["cls"]):
+        return np.zeros_like(mask)
+    if case.get("out_of_range"):
+        m = mask.copy()
+        m[10:40, 10:80] = 255
+        assert (m >= len(case["cls"])).sum() > 2000
+        return m
+    return mask
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -70,7 +84,7 @@ def test_label_propagation_matches_oracle(oracle, scene, case):
     if case["proj"] is not None:
         obj = mask == case["proj"]
         proj[obj] = case["models"][1]          # the existing model projects where that object is
-    m_in = mask if len(case["cls"]) else np.zeros_like(mask)
+    m_in = case_mask(case, mask)
     ign_o = np.zeros((H, W), np.uint8)
     ign_p = np.zeros((H, W), np.uint8)
     ref = mfo_mm.mf_segmentation_cpu(W, H, inv, depth, m_in, case["cls"], proj, case["models"], case["mcls"], case["next_id"],
@@ -85,6 +99,11 @@ def test_label_propagation_matches_oracle(oracle, scene, case):
         assert (got[0][mask == person] == 255).all()
     if case["allow"] and case["cls"] and case["proj"] is None and ref[1]:
         assert (got[0] == case["next_id"]).sum() > 0
+    if case.get("out_of_range"):   # the same labels as if those pixels had carried no mask at all
+        clean = np.where(m_in >= len(case["cls"]), 0, m_in).astype(np.uint8)
+        again = _product_labels(inv, depth, clean, case["cls"], proj, case["models"], case["mcls"], case["next_id"], case["allow"], prm,
+                                np.zeros((H, W), np.uint8))
+        assert np.array_equal(again[0], got[0])
 
 
 def test_connected_components_numbering(oracle):
