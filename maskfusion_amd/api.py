@@ -254,6 +254,10 @@ class MaskFusion:
         self._chk(self._L.mf_download_segmentation(self._h, out.ctypes.data))
         return out
 
+    def exportSegmentation(self, path: str):
+        """the exportSegmentation branch of processFrame (MaskFusion.cpp:299-303): label image, 255 zeroed, as an 8-bit PNG"""
+        self._chk(self._L.mf_export_segmentation_png(self._h, path.encode()))
+
     def getLastFillIn(self) -> bool:
         u = C.c_int32(0)
         self._chk(self._L.mf_get_last_fillin(self._h, C.byref(u)))

@@ -97,6 +97,18 @@ def test_cli_flags_and_defaults():
     assert (d["depthCutoff"], d["icpWeight"], d["outlierCoefficient"], d["confGlobal"], d["confObject"], d["modelSpawnOffset"]) == \
         (4.0, 20.0, 0.1, 10.0, 0.01, 22)
     assert d["so3"] and d["multi"] and d["timeDelta"] == (2 ** 31 - 1) // 2 and (d["fx"], d["cx"]) == (528.0, 320.0)
+    # SURVEY.md 2.4, "Effective (GUI/CLI) default" column, row by row (GUI/Tools/GUI.h:342-347,367-374; MainController.cpp:215-246)
+    assert d["trackAllModels"] is False
+    assert d["mf"] == dict(mfThreshold=0.3, mfWeightDistance=150.0, mfWeightConvexity=2.8, mfMorphEdgeIterations=0, mfMorphEdgeRadius=1,
+                           mfMorphMaskIterations=0, mfMorphMaskRadius=2, newModelMinRelativeSize=0.015, newModelMaxRelativeSize=0.4)
+    assert (d["frameQueueRequested"], d["frameQueue"], d["preallocate"], d["start"], d["end"]) == (30, 0, 0, 1, 65535)
+    assert not d["fastOdom"] and not d["rgbOnly"] and not d["exportSegmentation"]
+    e = cli.settings(cli.parse(["-l", "x.klg", "-segMinNew", "0.02", "-segMaxNew", "0.5", "-offset", "5", "-a", "3", "-frameQ", "10", "-es",
+                                "-thNew", "5", "-method", "maskfusion", "-fo", "-keep"]))
+    assert (e["mf"]["newModelMinRelativeSize"], e["mf"]["newModelMaxRelativeSize"], e["modelSpawnOffset"], e["preallocate"]) == (0.02, 0.5, 5, 3)
+    assert e["frameQueueRequested"] == 10 and e["frameQueue"] == 0 and e["exportSegmentation"] and e["fastOdom"]
+    with pytest.raises(SystemExit):
+        cli.settings(cli.parse(["-l", "x.klg", "-method", "cofusion"]))
     with pytest.raises(SystemExit):
         cli.parse(["-bogus"])
     with pytest.raises(SystemExit):
@@ -135,3 +147,11 @@ def test_image_directory_with_exr_depth(tmp_path):
     assert r.dext == ".exr"
     out = list(r)
     assert len(out) == 3 and np.array_equal(out[1].depth, fr[1][2]) and np.array_equal(out[1].rgb, fr[1][1])
+
+
+def test_trackable_classes_from_config_toml(tmp_path):
+    """MainController.cpp:273-287: trackable ids = positions of [MaskRCNN].trackable_classes in class_names"""
+    cfg = tmp_path / "config.toml"
+    cfg.write_text('[MaskRCNN]\nclass_names = ["BG", "person", "bicycle", "teddy bear", "bottle"]\ntrackable_classes = ["teddy bear", "bottle"]\n')
+    assert cli.trackable_class_ids(str(cfg)) == [3, 4]
+    assert cli.trackable_class_ids(str(tmp_path / "missing.toml")) is None
