@@ -7,6 +7,10 @@ Workloads (BASELINE.json `configs`):
   --config 2s S2 on ONE GPU: the same room with 8 rigid moving objects and their instance masks; background + 8 object
               models, trackAllModels, geometric ICP -- the multi-model path (global projection, label stage, per-model fusion)
               with the Gauss-Newton loops of all 9 models batched into one launch per iteration.
+  --config 3  configs[3], ONE scene sharded BY MODEL over the N ranks (maskfusion_amd/sharded.py): S2's 8 objects, rank 0
+              owns the background + the label stage, object models live on the other ranks; per frame: frame broadcast, all-reduce(MIN)
+              of the projection keys, gather of per-model state, broadcast of the label image + background pose + control record.
+              STRONG scaling: value = scene frames/s.  (N = 1: every model on rank 0 through the same three phases.)
   --config 4  the per-GPU share of configs[4]: 1280x960 stream, NUM_GSURFELS = 32M.
 A "step" = one processFrame over one frame whose rgb / depth (/ mask) already sit in HBM.  The timed region is `--steps` steps,
 repeated as a whole until it has lasted at least `--min-seconds` (a 6 ms region says little); `steps` in the JSON line is the
@@ -45,6 +49,9 @@ CONFIGS = {
     "2s": dict(W=640, H=480, f=528.0, surfels=9437184, n_objects=8, frames=120,
                workload="S2 on one GPU (SURVEY.md 8d): synthetic 640x480 RGB-D stream, 8 rigid moving objects with instance masks, "
                         "background + 8 object models, trackAllModels, icpWeight=100, global projection + label stage + per-model fusion"),
+    "3": dict(W=640, H=480, f=528.0, surfels=9437184, n_objects=8, frames=120,
+              workload="configs[3]: S2 synthetic 640x480 RGB-D stream with 8 rigid moving objects, ONE scene sharded by model over the ranks "
+                       "(rank 0: background + label stage; objects on the other ranks), trackAllModels, icpWeight=100"),
     "4": dict(W=1280, H=960, f=1056.0, surfels=32 * 1024 * 1024, n_objects=0, frames=200,
               workload="configs[4] (per GPU): synthetic 1280x960 RGB-D stream (S3 scaling of S1), 1 model per GPU, NUM_GSURFELS=32M, "
                        "icpWeight=100 + surfel fusion, empty masks"),
@@ -143,6 +150,79 @@ def pmc_traffic(kernel):
         return None
 
 
+def run_sharded(args, cfg, rank, local_rank, world, st, frames):
+    """--config 3: the model-sharded scene.  Every rank calls process_frame for every frame (SPMD); rank 0 holds the inputs."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    from maskfusion_amd import MaskFusion, sharded
+    from maskfusion_amd import dist as mfd
+    W, H, F = cfg["W"], cfg["H"], cfg["f"]
+    mf = MaskFusion(W, H, F, F, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, device=local_rank, enableMultipleModels=True,
+                    numGSurfels=cfg["surfels"] if rank == 0 else 1 << 20, numOSurfels=1 << 20, trackAllModels=True, modelSpawnOffset=2,
+                    initConfidenceGlobal=10.0, initConfidenceObject=0.01)
+    for k, v in (("mfThreshold", 0.3), ("mfWeightDistance", 150.0), ("mfWeightConvexity", 2.8), ("mfMorphEdgeIterations", 0),
+                 ("mfMorphMaskIterations", 0), ("newModelMinRelativeSize", 0.004)):
+        mf.setParam(k, v)
+    scfg = sharded.default_cfg(trackAllModels=True, modelSpawnOffset=2, depthCutoff=3.0)
+    smf = sharded.ShardedMaskFusion(mf, dev, scfg)
+    cls = [0] + [41 + i for i in range(cfg["n_objects"])]
+    order = pingpong(len(frames) if frames else cfg["frames"], 1 << 16)
+    cursor = [0]
+
+    def run(n):
+        for _ in range(n):
+            k = order[cursor[0] % len(order)]
+            cursor[0] += 1
+            if rank == 0:
+                smf.process_frame(frames[k][0], frames[k][1], frames[k][2], cls, 1.0, cursor[0])
+            else:
+                smf.process_frame(None, None, None, cls, 1.0, cursor[0])
+
+    def barrier():
+        mf.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    run(args.warmup)
+    total_steps, total_dt = 0, 0.0
+    while True:
+        barrier()
+        t0 = time.perf_counter()
+        run(args.steps)
+        barrier()
+        dt = mfd.max_over_ranks(time.perf_counter() - t0, dev)
+        total_steps += args.steps
+        total_dt += dt
+        if total_dt >= args.min_seconds or total_steps >= 200 * args.steps:
+            break
+    local = [(m.getID(), m.lastCount()) for i, m in enumerate(mf.getModels()) if rank == 0 or i > 0]
+    counts = torch.zeros(world, 2, dtype=torch.float32, device=dev)
+    counts[rank, 0], counts[rank, 1] = len(local), sum(c for _, c in local)
+    if world > 1:
+        dist.all_reduce(counts)
+    if rank == 0:
+        drift = float(np.linalg.norm(mf.getCurrPose()[:3, 3] - st.gt_pose(order[(cursor[0] - 1) % len(order)])[:3, 3]))
+        per_rank = counts.cpu().numpy()
+        out = {"metric": f"frames/sec ({W}x{H} RGB-D, one scene: background + {int(per_rank[:, 0].sum()) - 1} object models sharded by model over {world} GPU(s))",
+               "value": total_steps / total_dt, "unit": "frames/s", "n_gpus": world, "steps": total_steps, "steps_requested": args.steps,
+               "warmup": args.warmup, "ms_per_step": 1e3 * total_dt / total_steps, "timed_seconds": total_dt, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": cfg["workload"], "frames_in_hbm": 0, "models": int(per_rank[:, 0].sum()), "surfels": int(per_rank[:, 1].sum()),
+                          "models_per_rank": [int(x) for x in per_rank[:, 0]], "pose_drift_vs_gt_m": drift,
+                          "parallelism": f"model-sharded x{world} (RCCL: frame broadcast, key all-reduce(MIN), state gather, label broadcast)",
+                          "note": "host-pointer frames (the reference's FrameData boundary): H2D + broadcast per frame are inside the timed region"},
+               "roofline": None, "roofline_frame": None, "host_input": None, "cpu_baseline": None}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,6 +250,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # the stream is ray-cast before CUDA exists in this process (the generator forks); only rank 0 owns frames
     st, frames = gen_frames(cfg, n_frames) if rank == 0 else (None, None)
+    if args.config == "3":
+        if args.steps == 600:
+            args.steps = 120
+        return run_sharded(args, cfg, rank, local_rank, world, st, frames)
 
     import torch
     dist = None

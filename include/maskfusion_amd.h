@@ -328,6 +328,15 @@ int mf_k_rgb_residual(float min_scale, const int16_t* d_dIdx, const int16_t* d_d
 int mf_k_rgb_step(const void* d_corres, float sigma, const float* d_last_depth, float fx, float fy, float cx, float cy,
                   const int16_t* d_dIdx, const int16_t* d_dIdy, float sobel_scale, int32_t W, int32_t H, double* out32,
                   void* stream);
+/* One Gauss-Newton update exactly as the iteration kernels run it: the host side of getIncrementalTransformation
+ * (Core/Utils/RGBDOdometry.cpp:428-474: Eigen LDLT solve of the 6x6 system in double, OdometryProvider::computeUpdateSE3 /
+ * rodrigues, Core/Utils/OdometryProvider.h:32-90, currentT = [Rprev|tprev] * transform^-1) moved to the device.  HOST pointers.
+ * sys29: the 27 upper-triangle products of the 7-vector row in reduce.cu:378-411 order, then sum r^2, then the inlier count;
+ * result_rt16: resultRt before the step (row-major 4x4 double); Rprev9 / tprev3: the model pose the frame is tracked against.
+ * Out: x6_serial (the production one-thread LDL^T), x6_wave (the wave-parallel Gauss-Jordan the RGB-D kernels use), the updated
+ * resultRt, Rcurr / tcurr, stats2 = {lastICPError = sqrt(sum r^2) / inliers, lastICPCount}.  Synchronous. */
+int mf_k_gn_solve(const double* sys29, const double* result_rt16, const float* Rprev9, const float* tprev3, double* x6_serial,
+                  double* x6_wave, double* result_rt16_out, float* Rcurr9, float* tcurr3, float* stats2, void* stream);
 /* icpStep (Core/Cuda/reduce.cu:446-525): d_out32 receives {27 upper-tri products, sum r^2, inliers, pad} */
 int mf_k_icp_step(const float* Rcurr9, const float* tcurr3, const float* d_vmap_curr, const float* d_nmap_curr,
                   const float* Rprev_inv9, const float* tprev3, float fx, float fy, float cx, float cy,

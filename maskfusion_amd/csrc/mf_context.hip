@@ -122,6 +122,9 @@ struct mf_ctx {
                                        // ahead under the latency-bound Gauss-Newton loop of the previous frame
     hipEvent_t ev_pre_done[2] = {nullptr, nullptr};    // preprocessing of frame k finished      (pre -> main)
     hipEvent_t ev_main_done[2] = {nullptr, nullptr};   // frame k finished tracking (so k-1 is complete)  (main -> pre)
+    bool global_tiles = true;                          // A/B + test knob ("globalTiles"): 0 = every model through k_global_scatter
+    bool early_bg_fusion = true;                       // A/B knob ("earlyBackgroundFusion"): 0 = the host visit drains the stream
+    hipEvent_t ev_labels = nullptr;                    // the label stage of this frame has written its result words
     long frame_no = 0;
     int lastF = 0;
     int overlap = 0;                   // 1: preprocessing on stream_pre, one frame ahead ("overlapPreprocessing").  Measured on
@@ -438,6 +441,7 @@ extern "C" void mf_destroy(mf_ctx* c) {
         if (c->ev_pre_done[i]) (void)hipEventDestroy(c->ev_pre_done[i]);
         if (c->ev_main_done[i]) (void)hipEventDestroy(c->ev_main_done[i]);
     }
+    if (c->ev_labels) (void)hipEventDestroy(c->ev_labels);
     if (c->stream_pre) (void)hipStreamDestroy(c->stream_pre);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -690,6 +694,19 @@ static int enqueue_preprocess(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
 
 static int download_pose_log(mf_ctx* c, ModelState& m, std::vector<int64_t>& ts, std::vector<float>& p7);
 
+// GlobalProjection::project for one model (fixed confidence threshold 12, GlobalProjection.cpp:43-107).  The background model goes
+// through the tile lists (its ~10^5..10^6 sprites cover millions of pixels: one memory-side atomic each in the scatter form);
+// object models (a few thousand sprites) keep the scatter form, which costs them one short launch.  Both write the same keys.
+static void enqueue_global_projection(mf_ctx* c, ModelState& m, int order) {
+    const mf_config& g = c->cfg;
+    if (m.id == 0 && c->splat_tiles && c->global_tiles &&
+        launch_global_tiled(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, g.depth_cutoff, 12.0f, g.time_delta, order, m.id, c->d_tile_count,
+                            c->d_tile_entries, c->tile_entries_cap, c->d_splat_rec0, c->d_splat_rec1, c->d_splat_bbox, c->d_keys, c->stream) == 0)
+        return;
+    launch_global_scatter(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, g.depth_cutoff, 12.0f, g.time_delta, order, m.id, c->d_keys,
+                          c->stream);
+}
+
 // spawnObjectModel (Core/MaskFusion.cpp:671-684): pose = I, makeStatic(globalPose); moveNewModelToList
 static int spawn_object(mf_ctx* c, int id, int classID) {
     const mf_config& g = c->cfg;
@@ -730,6 +747,7 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
     float* depthF_prev = c->d_depthF[(k + 2) % 3];
     ModelState& bg = *c->models[0];
     bool main_done_recorded = false;
+    bool bg_fused = false;
 
     int prc = enqueue_preprocess(c, d_rgb, d_depth, k, c->map_ready);
     if (prc != MF_OK) return prc;
@@ -777,11 +795,7 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
 
         if (multi) {
             // GlobalProjection::project(models, tick, tick, timeDelta, depthCutoff) (:289) with its fixed threshold 12
-            for (size_t i = 0; i < c->models.size(); ++i) {
-                ModelState& m = *c->models[i];
-                launch_global_scatter(m.surf[m.cur], m.d_frame, m.d_pose, W, H, c->K, g.depth_cutoff, 12.0f, g.time_delta, (int)i, m.id,
-                                      c->d_keys, s);
-            }
+            for (size_t i = 0; i < c->models.size(); ++i) enqueue_global_projection(c, *c->models[i], (int)i);
             launch_global_resolve(c->d_keys, c->d_proj_ids, P, s);
             // MfSegmentation::performSegmentation, device half (MfSegmentation.cpp:149-208)
             launch_edge_map(c->d_vmap[set][0], c->d_nmap[set][0], c->d_edge, W, H, c->seg.weightDistance, c->seg.weightConvexity, s);
@@ -802,7 +816,20 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
                                             haveMasks ? n_masks : 0, c->d_proj_ids, infos, poses, c->nextID,
                                             c->spawnOffset >= g.model_spawn_offset, c->d_mask_tex, s);   // writes textureMask (:297)
                 if (rc != MF_OK) return rc;
-                MF_HIP(c, hipStreamSynchronize(s));
+                // The host has to look at the label stage's decision (new model? which objects did the jump rule drop?) before it
+                // can enqueue the objects' fusion -- but not before the BACKGROUND's: that model is never spawned or dropped and its
+                // fusion only reads the label image on the stream.  So it goes in first and the host waits on an event recorded
+                // right behind the label stage: by the time it wakes up and has enqueued the object work, the GPU is still busy
+                // with the background's fuse / clean passes (~0.15 ms at VGA) -- the stream never drains inside a frame.  (Model
+                // order inside the fusion loop is free: every model's passes run back to back on one stream and touch only its own
+                // surfels; upstream fuses the new model first, MaskFusion.cpp:342-353,539-565.)
+                if (!c->ev_labels) MF_HIP(c, hipEventCreateWithFlags(&c->ev_labels, hipEventDisableTiming));
+                MF_HIP(c, hipEventRecord(c->ev_labels, s));
+                if (!g.rgb_only && c->early_bg_fusion) {
+                    enqueue_fuse_clean(c, bg, d_rgb, d_depth, depthF, mask, g.depth_cutoff, weight_multiplier, true, true);
+                    bg_fused = true;
+                }
+                MF_HIP(c, hipEventSynchronize(c->ev_labels));
                 if (c->labels->h_result[2]) { c->err = "label stage: vote tables overflowed (too many components x masks)"; return MF_ESTATE; }
                 res.hasNewLabel = c->labels->h_result[0] != 0;
                 res.newClassID = c->labels->h_result[1];
@@ -847,7 +874,7 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
         // (the predict() at MaskFusion.cpp:423 only feeds the dead loop-closure block and is overwritten at :569)
         // fusion, :539-565: if (!rgbOnly && trackingOk && !lost)
         if (!g.rgb_only)
-          for (size_t i = 0; i < c->models.size(); ++i)
+          for (size_t i = bg_fused ? 1 : 0; i < c->models.size(); ++i)
             enqueue_fuse_clean(c, *c->models[i], d_rgb, d_depth, depthF, mask, g.depth_cutoff, weight_multiplier, true, i == 0);
         mark(c, 7);
     }
@@ -1218,8 +1245,7 @@ extern "C" int mf_export_projection_keys_dev(mf_ctx* c, const int32_t* orders, i
     for (size_t i = 0; i < c->models.size(); ++i) {
         ModelState& m = *c->models[i];
         if (orders[i] < 0) continue;   // a stand-in (e.g. the background on a rank that only holds objects): not drawn
-        launch_global_scatter(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, c->cfg.depth_cutoff, 12.0f, c->cfg.time_delta, orders[i], m.id,
-                              c->d_keys, s);
+        enqueue_global_projection(c, m, orders[i]);
     }
     MF_HIP(c, hipMemcpyAsync(d_keys_out, c->d_keys, (size_t)c->P * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
     launch_fill_keys(c->d_keys, c->P, s);
@@ -1629,6 +1655,8 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
         return MF_OK;
     }
     if (!strcmp(key, "batchTracking")) { c->batch_tracking = value != 0; return MF_OK; }
+    if (!strcmp(key, "globalTiles")) { c->global_tiles = value != 0; return MF_OK; }
+    if (!strcmp(key, "earlyBackgroundFusion")) { c->early_bg_fusion = value != 0; return MF_OK; }
     if (!strcmp(key, "modelApiPackedIndex")) { c->model_api_packed = value != 0; return MF_OK; }   // 0: scatter + resolve form (specification)
     if (!strcmp(key, "overlapPreprocessing")) {
         (void)hipStreamSynchronize(c->stream_pre);
@@ -1936,6 +1964,12 @@ extern "C" int mf_k_segmentation_labels(int32_t W, int32_t H, const uint8_t* bin
     return MF_OK;
 }
 
+extern "C" int mf_k_gn_solve(const double* sys29, const double* result_rt16, const float* Rprev9, const float* tprev3, double* x6_serial,
+                             double* x6_wave, double* result_rt16_out, float* Rcurr9, float* tcurr3, float* stats2, void* stream) {
+    if (!sys29 || !result_rt16 || !Rprev9 || !tprev3 || !x6_serial || !x6_wave || !result_rt16_out || !Rcurr9 || !tcurr3 || !stats2) return MF_EINVAL;
+    const int rc = gn_solve_standalone(sys29, result_rt16, Rprev9, tprev3, x6_serial, x6_wave, result_rt16_out, Rcurr9, tcurr3, stats2, (hipStream_t)stream);
+    return rc == 0 ? MF_OK : (rc == -1 ? MF_ENOMEM : MF_EHIP);
+}
 extern "C" int mf_k_icp_step(const float* Rcurr9, const float* tcurr3, const float* d_vc, const float* d_nc, const float* Rpi9,
                              const float* tprev3, float fx, float fy, float cx, float cy, const float* d_vp, const float* d_np,
                              float dist_thresh, float angle_thresh, int32_t W, int32_t H, float* d_out32, void* stream) {

@@ -299,11 +299,31 @@ __device__ __forceinline__ void sincos_small(double th, double& s, double& c) {
 // OdometryProvider::rodrigues (Core/Utils/OdometryProvider.h:32-67).  Rotations beyond 0.5 rad (never produced by a
 // converging Gauss-Newton step) are built by repeated squaring of the rotation by theta / 2^k.
 __device__ __forceinline__ void rodrigues_d(double wx, double wy, double wz, double (&R)[3][3]) {
+    const double xx = wx * wx, yy = wy * wy, zz = wz * wz;
+    const double th2 = xx + yy + zz;
+    if (th2 <= 0.25) {
+        // The case every converging Gauss-Newton step is in.  R = I + A [w]x + B [w]x^2 with A = sin(th)/th and B = (1 - cos th)/th^2,
+        // both even power series in th -- so no square root, no reciprocal and no sin / cos of th itself: this function sits on the
+        // one-thread dependency chain every iteration launch waits for (solve -> pose), where each of those cost a dozen dependent
+        // fp64 operations.  Nine terms each (truncation < 1e-19 at th^2 = 0.25), evaluated in Estrin form (depth 5 instead of 9).
+        const double u = th2, u2 = u * u, u4 = u2 * u2;
+        const double A = ((1.0 + u * (-1.0 / 6)) + u2 * (1.0 / 120 + u * (-1.0 / 5040))) +
+                         u4 * (((1.0 / 362880 + u * (-1.0 / 39916800)) + u2 * (1.0 / 6227020800.0 + u * (-1.0 / 1307674368000.0))) +
+                               u4 * (1.0 / 355687428096000.0));
+        const double B = ((0.5 + u * (-1.0 / 24)) + u2 * (1.0 / 720 + u * (-1.0 / 40320))) +
+                         u4 * (((1.0 / 3628800 + u * (-1.0 / 479001600.0)) + u2 * (1.0 / 87178291200.0 + u * (-1.0 / 20922789888000.0))) +
+                               u4 * (1.0 / 6402373705728000.0));
+        const double xy = B * (wx * wy), xz = B * (wx * wz), yz = B * (wy * wz);
+        const double ax = A * wx, ay = A * wy, az = A * wz;
+        R[0][0] = 1.0 - B * (yy + zz); R[0][1] = xy - az;             R[0][2] = xz + ay;
+        R[1][0] = xy + az;             R[1][1] = 1.0 - B * (xx + zz); R[1][2] = yz - ax;
+        R[2][0] = xz - ay;             R[2][1] = yz + ax;             R[2][2] = 1.0 - B * (xx + yy);
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) R[r][c] = (r == c) ? 1.0 : 0.0;
-    const double th2 = wx * wx + wy * wy + wz * wz;
     const double theta = th2 > 0.0 ? sqrt_d(th2) : 0.0;
     if (theta >= 2.2204460492503131e-16) {
         int halvings = 0;

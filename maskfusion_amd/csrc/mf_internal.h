@@ -225,6 +225,11 @@ void launch_edge_binary(const float* edge, uint8_t* out, uint8_t* tmp, int W, in
 void launch_global_scatter(Surfels src, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth,
                            float confThreshold, int timeDelta, int order, int id, unsigned long long* keys, hipStream_t s);
 void launch_global_resolve(unsigned long long* keys, uint8_t* ids, int P, hipStream_t s);
+int gn_solve_standalone(const double* sys29, const double* resultRt16, const float* Rprev9, const float* tprev3, double* x_serial, double* x_wave,
+                        double* resultRt_out, float* Rcurr9, float* tcurr3, float* stats2, hipStream_t s);
+int launch_global_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
+                        int timeDelta, int order, int id, int* tile_count, int* entries, int entries_cap, float4* rec0, float4* rec1, void* bbox,
+                        unsigned long long* keys, hipStream_t s);
 void launch_spawn_pose(PoseDev* obj, const PoseDev* bg, FrameDev* objFrame, const FrameDev* bgFrame, PoseDev* host_mirror,
                        hipStream_t s);
 void launch_static_pose(PoseDev* obj, const PoseDev* bg, PoseDev* host_mirror, hipStream_t s);

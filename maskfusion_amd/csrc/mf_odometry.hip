@@ -166,7 +166,8 @@ __device__ __forceinline__ void gn_update_from_x(const double (&x)[6], float res
     out.levelDone = in.levelDone; out.lastRGBError = in.lastRGBError; out.lastRGBCount = in.lastRGBCount;
 }
 
-// Serial form (one thread): unpack -> LDL^T -> update.  Used by tests through mf_k_gn_solve to pin the wave solver.
+// Serial form (one thread): unpack -> LDL^T -> update.  mf_k_gn_solve (tests/test_gpu_kernels.py) runs it next to the wave solver
+// and the oracle's restatement of Eigen's LDLT / OdometryProvider::rodrigues / computeUpdateSE3.
 __device__ __forceinline__ void gn_solve_update_serial(const double* sys, const GNState& in, GNState& out) {
     double A[6][6], b[6], x[6];
     int shift = 0;
@@ -330,6 +331,40 @@ __device__ __forceinline__ float wave_sum32_halving(float (&v)[32]) {
     return v[0] + __shfl_xor(v[0], 32, 64);
 }
 
+// Sum of the 29 accumulators over ALL kT threads of a workgroup through LDS, in a fixed order: lane pairs first (one DPP add per
+// accumulator), even lanes store column-wise [component][kT / 2] (consecutive lanes -> consecutive banks), then component c is
+// summed by G = kT / 32 neighbouring threads (16 values each, read as four conflict-free float4 rows) and a G-lane DPP butterfly.
+// ~85 instructions per wavefront and 60 KB of LDS traffic per 512-thread workgroup against ~300 instructions per wavefront for
+// the register halving tree above (which stays for the RGB-D kernels): the tree was 2.4 k of the 15 k cycles of a level-0 launch.
+// out: the workgroup's 32-float partial (components >= 29 are written as zeros).
+template <int kT>
+__device__ __forceinline__ void block_sum29_lds(const float (&acc)[32], float* s_red /*[29][kT / 2]*/, float* __restrict__ out) {
+    constexpr int kHalf = kT / 2, G = kT / 32;
+    static_assert(G == 8 || G == 16, "kT must be 256 or 512");
+    const int tid = threadIdx.x, lane = tid & 63;
+#pragma unroll
+    for (int c = 0; c < 29; ++c) {
+        const float v = acc[c] + lane_xor<1>(acc[c], lane);
+        if ((lane & 1) == 0) s_red[c * kHalf + (tid >> 1)] = v;
+    }
+    __syncthreads();
+    const int c = tid / G, g = tid % G;
+    float s = 0.f;
+    if (c < 29) {
+        const float4* __restrict__ row = reinterpret_cast<const float4*>(s_red + c * kHalf);
+        float4 v[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) v[m] = row[m * G + g];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) s += (v[m].x + v[m].y) + (v[m].z + v[m].w);
+    }
+    s += lane_xor<1>(s, lane);
+    s += lane_xor<2>(s, lane);
+    s += lane_xor<4>(s, lane);
+    if (G == 16) s += lane_xor<8>(s, lane);
+    if (g == 0) out[c] = s;
+}
+
 // ------------------------------------------------------------------------------------------------
 // The ICP iteration kernel.
 // ------------------------------------------------------------------------------------------------
@@ -417,8 +452,9 @@ __global__ __launch_bounds__(kT) void k_icp_iter(const IcpKArgs a) {
     __shared__ double s_seg[32 * 32];
     __shared__ double s_sys[32];
     __shared__ float s_pose[24];  // Rcurr[9] tcurr[3] Rprev_inv[9] tprev[3]
-    __shared__ float s_part[(kT / 64) * kIcpSlots];
+    __shared__ float s_red[29 * (kT / 2)];
     __shared__ GNState s_st;
+    __shared__ GNState s_st_new;  // workgroup 0: the updated state on its way to global memory
 
     const int tid = threadIdx.x;
     // stage the Gauss-Newton state through LDS with one coalesced load (thread 0 would otherwise chase ~80 dependent
@@ -467,11 +503,10 @@ __global__ __launch_bounds__(kT) void k_icp_iter(const IcpKArgs a) {
             for (int k = 0; k < 9; ++k) { s_pose[k] = st.Rcurr[k]; s_pose[12 + k] = st.Rprev_inv[k]; }
 #pragma unroll
             for (int k = 0; k < 3; ++k) { s_pose[9 + k] = st.tcurr[k]; s_pose[21 + k] = st.tprev[k]; }
-            if (blockIdx.x == 0) {
-                *a.st_out = st;
-                if (a.log_out)
-                    for (int k = 0; k < 32; ++k) a.log_out[k] = (float)s_sys[k];
-            }
+            // workgroup 0 publishes the state (84 words) and the iteration log (32 floats): through LDS, stored after the barrier
+            // by 84 + 32 lanes in one instruction each.  (Thread 0 used to issue those ~115 scalar stores itself, BEFORE the barrier
+            // every other thread of the slowest workgroup of the launch was waiting at: ~1.2 k cycles of every launch.)
+            if (blockIdx.x == 0) s_st_new = st;
         }
     } else {
       __syncthreads();
@@ -481,12 +516,18 @@ __global__ __launch_bounds__(kT) void k_icp_iter(const IcpKArgs a) {
         for (int k = 0; k < 9; ++k) { s_pose[k] = st.Rcurr[k]; s_pose[12 + k] = st.Rprev_inv[k]; }
 #pragma unroll
         for (int k = 0; k < 3; ++k) { s_pose[9 + k] = st.tcurr[k]; s_pose[21 + k] = st.tprev[k]; }
-        if (blockIdx.x == 0) *a.st_out = st;
       }
     }
     if (prof) { if (a.nb_in == 0) stamp[2] = stamp[1]; stamp[3] = __builtin_amdgcn_s_memtime(); }
     __syncthreads();
     if (prof) stamp[4] = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 0) {
+        constexpr int kWords = (int)(sizeof(GNState) / 4);
+        static_assert(kWords + 32 <= kT, "state + log lanes");
+        const GNState* src = a.nb_in > 0 ? &s_st_new : &s_st;
+        if (tid < kWords) reinterpret_cast<uint32_t*>(a.st_out)[tid] = reinterpret_cast<const uint32_t*>(src)[tid];
+        else if (tid < kWords + 32 && a.log_out && a.nb_in > 0) a.log_out[tid - kWords] = (float)s_sys[tid - kWords];
+    }
 
     float Rc[9], Rpi[9];
 #pragma unroll
@@ -517,19 +558,8 @@ __global__ __launch_bounds__(kT) void k_icp_iter(const IcpKArgs a) {
 
     // (4) wavefront reduction (halving tree), one LDS stage across the wavefronts, one 128 B partial per workgroup
     if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[5] = __builtin_amdgcn_s_memtime(); }
-    const int lane = tid & 63, wave = tid >> 6;
-    const float wsum = wave_sum32_halving(acc);
-    if (lane < 32) s_part[wave * kIcpSlots + icp_component_of_lane(lane)] = wsum;
-    __syncthreads();
+    block_sum29_lds<kT>(acc, s_red, a.partials_out + blockIdx.x * kIcpSlots);
     if (prof) stamp[6] = __builtin_amdgcn_s_memtime();
-    if (tid < kIcpSlots) {
-        float s = 0.f;
-        if (tid < 29) {
-#pragma unroll
-            for (int w = 0; w < kT / 64; ++w) s += s_part[w * kIcpSlots + tid];
-        }
-        a.partials_out[blockIdx.x * kIcpSlots + tid] = s;
-    }
     if (prof) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp[7] = __builtin_amdgcn_s_memtime();
@@ -639,11 +669,12 @@ __global__ __launch_bounds__(256) void k_icp_batch_solve(const IcpSolveArgs a) {
     if (tid < (int)(sizeof(GNState) / 4)) reinterpret_cast<uint32_t*>(&s_st)[tid] = reinterpret_cast<const uint32_t*>(md->st + prev)[tid];
     reduce_partials(md->partials[prev], a.nb_in, s_seg, s_sys);   // (its barriers also publish s_st)
     GNState out;
-    if (gn_solve_update_wg(s_sys, s_st, out)) {
-        md->st[a.it & 1] = out;
-        if (md->log)
-            for (int k = 0; k < 32; ++k) md->log[32 * (a.it - 1) + k] = (float)s_sys[k];
-    }
+    if (gn_solve_update_wg(s_sys, s_st, out)) s_st = out;   // (thread 0 is the only reader of s_st)
+    __syncthreads();
+    // state (84 words) and log (32 floats) leave through one store instruction each instead of ~115 scalar stores of thread 0
+    constexpr int kWords = (int)(sizeof(GNState) / 4);
+    if (tid < kWords) reinterpret_cast<uint32_t*>(md->st + (a.it & 1))[tid] = reinterpret_cast<const uint32_t*>(&s_st)[tid];
+    else if (tid < kWords + 32 && md->log) md->log[32 * (a.it - 1) + tid - kWords] = (float)s_sys[tid - kWords];
 }
 
 struct IcpPxArgs {
@@ -657,7 +688,7 @@ constexpr int kBatchThreads = 256;
 constexpr int kBatchPx = 3;   // pixels per thread and round: all their gathers are in flight together
 
 __global__ __launch_bounds__(kBatchThreads) void k_icp_batch_pixels(const IcpPxArgs a) {
-    __shared__ float s_part[(kBatchThreads / 64) * kIcpSlots];
+    __shared__ float s_red[29 * (kBatchThreads / 2)];
     const TrackModelDev* __restrict__ md = a.b.m[blockIdx.y];
     const GNState* __restrict__ st = md->st + a.parity;
     const float* __restrict__ vp = md->vm[a.level];
@@ -702,18 +733,7 @@ __global__ __launch_bounds__(kBatchThreads) void k_icp_batch_pixels(const IcpPxA
         for (int q = 0; q < kBatchPx; ++q)
             if (act[q]) icp_accumulate(cor[q], pv[q], pn[q], Rpi, tp, a, acc);
     }
-    const int lane = tid & 63, wave = tid >> 6;
-    const float wsum = wave_sum32_halving(acc);
-    if (lane < 32) s_part[wave * kIcpSlots + icp_component_of_lane(lane)] = wsum;
-    __syncthreads();
-    if (tid < kIcpSlots) {
-        float s = 0.f;
-        if (tid < 29) {
-#pragma unroll
-            for (int w = 0; w < kBatchThreads / 64; ++w) s += s_part[w * kIcpSlots + tid];
-        }
-        md->partials[a.parity][blockIdx.x * kIcpSlots + tid] = s;
-    }
+    block_sum29_lds<kBatchThreads>(acc, s_red, md->partials[a.parity] + blockIdx.x * kIcpSlots);
 }
 
 struct IcpFinArgs { TrackBatch b; int n_it; int nb_in; const So3Result* so3; };
@@ -754,6 +774,65 @@ void launch_icp_batch_pixels(const TrackBatch& b, int it, int level, const float
 void launch_icp_batch_finalize(const TrackBatch& b, int n_it, int nb_in, const So3Result* so3, hipStream_t s) {
     IcpFinArgs a{b, n_it, nb_in, so3};
     hipLaunchKernelGGL(k_icp_batch_finalize, dim3(b.n), dim3(256), 0, s, a);
+}
+
+// stand-alone Gauss-Newton update for the parity tests (mf_k_gn_solve): the production one-thread path (unpack -> LDL^T -> exp ->
+// pose composition) and the wave-parallel Gauss-Jordan of the RGB-D kernels on the same system
+struct GnSolveOut { double x_serial[6], x_wave[6], resultRt[16]; float Rcurr[9], tcurr[3], trR[9], trt[3], lastICPError, lastICPCount; };
+__global__ __launch_bounds__(64) void k_gn_solve_test(const double* __restrict__ sys29, const double* __restrict__ resultRt,
+                                                      const float* __restrict__ Rprev, const float* __restrict__ tprev, GnSolveOut* out) {
+    __shared__ double s_sys[32];
+    if (threadIdx.x < 32) s_sys[threadIdx.x] = threadIdx.x < 29 ? sys29[threadIdx.x] : 0.0;
+    __syncthreads();
+    double xw[6];
+    solve6_wave(s_sys, xw);
+    if (threadIdx.x != 0) return;
+    GNState in, st;
+    for (int k = 0; k < 16; ++k) in.resultRt[k] = resultRt[k];
+    for (int k = 0; k < 9; ++k) { in.Rprev[k] = Rprev[k]; in.Rcurr[k] = Rprev[k]; in.trR[k] = 0.f; }
+    for (int k = 0; k < 3; ++k) { in.tprev[k] = tprev[k]; in.tcurr[k] = tprev[k]; in.trt[k] = 0.f; }
+    m33_inverse_f(in.Rprev, in.Rprev_inv);
+    in.lastICPError = in.lastICPCount = 0.f; in.valid = 0; in.levelDone = -1; in.lastRGBError = 0.f; in.lastRGBCount = 0.f;
+    double A[6][6], b[6], x[6];
+    int shift = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 7; ++j) {
+            const double value = s_sys[shift++];
+            if (j == 6) b[i] = value;
+            else { A[i][j] = value; A[j][i] = value; }
+        }
+    ldlt6_solve(A, b, x);
+    gn_solve_update_serial(s_sys, in, st);     // what k_icp_iter / k_icp_batch_solve / k_icp_finalize call
+    for (int k = 0; k < 6; ++k) { out->x_serial[k] = x[k]; out->x_wave[k] = xw[k]; }
+    for (int k = 0; k < 16; ++k) out->resultRt[k] = st.resultRt[k];
+    for (int k = 0; k < 9; ++k) { out->Rcurr[k] = st.Rcurr[k]; out->trR[k] = st.trR[k]; }
+    for (int k = 0; k < 3; ++k) { out->tcurr[k] = st.tcurr[k]; out->trt[k] = st.trt[k]; }
+    out->lastICPError = st.lastICPError; out->lastICPCount = st.lastICPCount;
+}
+int gn_solve_standalone(const double* sys29, const double* resultRt16, const float* Rprev9, const float* tprev3, double* x_serial, double* x_wave,
+                        double* resultRt_out, float* Rcurr9, float* tcurr3, float* stats2, hipStream_t s) {
+    char* buf = nullptr;
+    const size_t in_bytes = 29 * 8 + 16 * 8 + 12 * 4;
+    if (hipMalloc((void**)&buf, in_bytes + sizeof(GnSolveOut)) != hipSuccess) return -1;
+    double* d_sys = reinterpret_cast<double*>(buf);
+    double* d_rt = d_sys + 29;
+    float* d_R = reinterpret_cast<float*>(d_rt + 16);
+    GnSolveOut* d_out = reinterpret_cast<GnSolveOut*>(buf + in_bytes);
+    GnSolveOut h;
+    bool ok = hipMemcpyAsync(d_sys, sys29, 29 * 8, hipMemcpyHostToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(d_rt, resultRt16, 16 * 8, hipMemcpyHostToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(d_R, Rprev9, 36, hipMemcpyHostToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(d_R + 9, tprev3, 12, hipMemcpyHostToDevice, s) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_gn_solve_test, dim3(1), dim3(64), 0, s, d_sys, d_rt, d_R, d_R + 9, d_out);
+        ok = hipMemcpyAsync(&h, d_out, sizeof(h), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    }
+    (void)hipFree(buf);
+    if (!ok) return -2;
+    memcpy(x_serial, h.x_serial, 48); memcpy(x_wave, h.x_wave, 48); memcpy(resultRt_out, h.resultRt, 128);
+    memcpy(Rcurr9, h.Rcurr, 36); memcpy(tcurr3, h.tcurr, 12);
+    stats2[0] = h.lastICPError; stats2[1] = h.lastICPCount;
+    return 0;
 }
 
 // stand-alone icpStep for the parity tests: reduce partials to 32 floats

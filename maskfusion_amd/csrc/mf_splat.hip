@@ -137,37 +137,37 @@ struct TileArgs {
     const uint8_t* rgb; uint8_t* predGray; uint8_t* fillGray;
 };
 
-// Pass 3: one 256-thread workgroup per 16x16 tile: LDS z-test over the tile's surfel list, then the fragment outputs
-// (combo_splat.frag) of every pixel of the tile.
-__global__ __launch_bounds__(256) void k_splat_tile(const TileArgs a) {
-    __shared__ unsigned long long s_key[kTile * kTile];
-    __shared__ float4 s_ray[kTile * kTile];
-    __shared__ int s_range[1];
-    const int tile = blockIdx.x;
-    const int tx0 = (tile % a.tilesX) * kTile, ty0 = (tile / a.tilesX) * kTile;
+// The z-test of one 16x16 tile in LDS, shared by the prediction (payload = surfel index) and the global projection (payload =
+// model order / id): rays of the tile's pixels, the tile's sprite list (or, after a list overflow, every sprite box of the map),
+// ds_min_u64 per covered pixel.  On return s_key[pixel of the tile] holds the winning key (all threads have passed a barrier).
+template <bool kIndexPayload>
+__device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* tile_count, const int* entries, int tile_cap,
+                                           const FrameDev* frame, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
+                                           const short4* __restrict__ bbox, unsigned payload, unsigned long long* s_key, float4* s_ray,
+                                           int* s_range) {
+    const int tx0 = (tile % tilesX) * kTile, ty0 = (tile / tilesX) * kTile;
     s_key[threadIdx.x] = kEmptyKey;
     {   // the viewing ray of every pixel of the tile, once (combo_splat.frag:40-42); the per-surfel loops below re-used to
         // spend two thirds of their instructions recomputing it (two divisions + a normalisation per covered pixel)
         const float fcx = (float)(tx0 + (threadIdx.x & (kTile - 1))) + 0.5f, fcy = (float)(ty0 + (threadIdx.x >> 4)) + 0.5f;
-        const float3 l = normalize_gl(f3((fcx - a.k.cx) / a.k.fx, (fcy - a.k.cy) / a.k.fy, 1.0f));
+        const float3 l = normalize_gl(f3((fcx - k.cx) / k.fx, (fcy - k.cy) / k.fy, 1.0f));
         s_ray[threadIdx.x] = make_float4(l.x, l.y, l.z, 0.f);
     }
     if (threadIdx.x == 0) {
-        s_range[0] = a.tile_count[tile];
-        a.tile_count[tile] = 0;   // consumed: the binning pass of the next prediction starts from zero
+        s_range[0] = tile_count[tile];
+        tile_count[tile] = 0;   // consumed: the next binning pass starts from zero
     }
     __syncthreads();
-    const bool overflow = s_range[0] > a.tile_cap;   // more sprites than list slots (the reference has no such limit): scan every box
-    const int cnt = overflow ? a.frame->count : s_range[0];
-    const int* __restrict__ list = a.entries + (size_t)tile * a.tile_cap;
-    const Intr k = a.k;
+    const bool overflow = s_range[0] > tile_cap;   // more sprites than list slots (the reference has no such limit): scan every box
+    const int cnt = overflow ? frame->count : s_range[0];
+    const int* __restrict__ list = entries + (size_t)tile * tile_cap;
     for (int e = threadIdx.x; e < cnt; e += 256) {
         const int i = overflow ? e : list[e];
-        const short4 bb = a.bbox[i];
+        const short4 bb = bbox[i];
         const int x0 = max((int)bb.x, tx0), x1 = min((int)bb.y, tx0 + kTile - 1);
         const int y0 = max((int)bb.z, ty0), y1 = min((int)bb.w, ty0 + kTile - 1);
         if (x0 > x1 || y0 > y1) continue;
-        const float4 r0 = a.rec0[i], r1 = a.rec1[i];
+        const float4 r0 = rec0[i], r1 = rec1[i];
         SplatSetup su;
         su.h = f3(r0.x, r0.y, r0.z); su.sqrRad = r0.w; su.nrm = f3(r1.x, r1.y, r1.z); su.pn = r1.w;
         for (int py = y0; py <= y1; ++py) {
@@ -179,12 +179,24 @@ __global__ __launch_bounds__(256) void k_splat_tile(const TileArgs a) {
                 const float3 diff = cp - su.h;
                 if (!(dot3(diff, diff) <= su.sqrRad)) continue;
                 if (!(cp.z > 0.f)) continue;
-                const unsigned long long key = ((unsigned long long)__float_as_uint(cp.z) << 32) | (unsigned)i;
+                const unsigned long long key = ((unsigned long long)__float_as_uint(cp.z) << 32) | (kIndexPayload ? (unsigned)i : payload);
                 atomicMin(&s_key[lp], key);
             }
         }
     }
     __syncthreads();
+}
+
+// Pass 3: one 256-thread workgroup per 16x16 tile: LDS z-test over the tile's surfel list, then the fragment outputs
+// (combo_splat.frag) of every pixel of the tile.
+__global__ __launch_bounds__(256) void k_splat_tile(const TileArgs a) {
+    __shared__ unsigned long long s_key[kTile * kTile];
+    __shared__ float4 s_ray[kTile * kTile];
+    __shared__ int s_range[1];
+    const int tile = blockIdx.x;
+    const int tx0 = (tile % a.tilesX) * kTile, ty0 = (tile / a.tilesX) * kTile;
+    const Intr k = a.k;
+    tile_ztest<true>(tile, a.tilesX, k, a.tile_count, a.entries, a.tile_cap, a.frame, a.rec0, a.rec1, a.bbox, 0u, s_key, s_ray, s_range);
     const int px = tx0 + (threadIdx.x & (kTile - 1)), py = ty0 + (threadIdx.x >> 4);
     if (px >= a.W || py >= a.H) return;
     const int p = py * a.W + px;
@@ -219,6 +231,51 @@ __global__ __launch_bounds__(256) void k_splat_tile(const TileArgs a) {
     // MaskFusion::requiresFillIn (MaskFusion.cpp:630-648): nearest sample of the 20x down-sampled colour prediction
     if ((px % 20) == 10 && (py % 20) == 10 && px / 20 < a.W / 20 && py / 20 < a.H / 20 && col.x > 0 && col.y > 0 && col.z > 0)
         atomicAdd(&a.frame->cover, 1);
+}
+
+// GlobalProjection (Core/Model/GlobalProjection.cpp:43-114, splat_models.vert / combo_splat_models.frag) of ONE model through the
+// same tile lists: the z-test winner of every pixel of the tile is merged into the key image with a plain read-modify-write --
+// a pixel belongs to exactly one workgroup of this launch, and the other models' launches are ordered on the stream.  Same keys
+// as k_global_scatter (mf_segment.hip), which stays for small (object) models: one global atomic per covered pixel is memory-side
+// work (see the header) and cost ~170 us per frame for a 250 k-surfel background model against ~25 us here.
+struct GlobalTileArgs {
+    const FrameDev* frame; int W, H; Intr k; int tilesX;
+    int* tile_count; const int* entries; int tile_cap;
+    const float4* rec0; const float4* rec1; const short4* bbox;
+    unsigned payload; unsigned long long* keys;
+};
+__global__ __launch_bounds__(256) void k_global_tile(const GlobalTileArgs a) {
+    __shared__ unsigned long long s_key[kTile * kTile];
+    __shared__ float4 s_ray[kTile * kTile];
+    __shared__ int s_range[1];
+    const int tile = blockIdx.x;
+    tile_ztest<false>(tile, a.tilesX, a.k, a.tile_count, a.entries, a.tile_cap, a.frame, a.rec0, a.rec1, a.bbox, a.payload, s_key, s_ray, s_range);
+    const int px = (tile % a.tilesX) * kTile + (threadIdx.x & (kTile - 1)), py = (tile / a.tilesX) * kTile + (threadIdx.x >> 4);
+    if (px >= a.W || py >= a.H) return;
+    const unsigned long long key = s_key[threadIdx.x];
+    if (key == kEmptyKey) return;
+    const int p = py * a.W + px;
+    if (key < a.keys[p]) a.keys[p] = key;
+}
+
+int launch_global_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
+                        int timeDelta, int order, int id, int* tile_count, int* entries, int entries_cap, float4* rec0, float4* rec1, void* bbox,
+                        unsigned long long* keys, hipStream_t s) {
+    const int tilesX = (W + kTile - 1) / kTile, tilesY = (H + kTile - 1) / kTile, nt = tilesX * tilesY;
+    if (nt > kMaxTiles) return -1;
+    BinArgs b;
+    b.src = src; b.frame = frame; b.pose = pose; b.W = W; b.H = H; b.k = k; b.maxDepth = maxDepth; b.confThreshold = confThreshold;
+    b.timeDelta = timeDelta; b.tilesX = tilesX; b.tilesY = tilesY; b.tile_count = tile_count;
+    b.entries = entries; b.tile_cap = entries_cap / nt; b.frame_rw = frame;
+    b.rec0 = rec0; b.rec1 = rec1; b.bbox = reinterpret_cast<short4*>(bbox);
+    const int nblocks = min(256, (src.cap + 2 * kBinThreads - 1) / (2 * kBinThreads));
+    hipLaunchKernelGGL(k_splat_bin, dim3(nblocks), dim3(kBinThreads), (size_t)2 * nt * sizeof(int), s, b);
+    GlobalTileArgs t;
+    t.frame = frame; t.W = W; t.H = H; t.k = k; t.tilesX = tilesX; t.tile_count = tile_count; t.entries = entries; t.tile_cap = b.tile_cap;
+    t.rec0 = rec0; t.rec1 = rec1; t.bbox = reinterpret_cast<const short4*>(bbox);
+    t.payload = ((unsigned)order << 8) | ((unsigned)id & 255u); t.keys = keys;
+    hipLaunchKernelGGL(k_global_tile, dim3(nt), dim3(256), 0, s, t);
+    return 0;
 }
 
 size_t splat_tiles_scratch_ints(int W, int H) { return (size_t)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile); }

@@ -119,6 +119,7 @@ SYMBOLS = {
                                  C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "mf_k_model_pyramid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                      C.c_int32, C.c_void_p]),
+    "mf_k_gn_solve": (C.c_int, [C.c_void_p] * 10 + [C.c_void_p]),
     "mf_k_icp_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                 C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32,
                                 C.c_int32, C.c_void_p, C.c_void_p]),

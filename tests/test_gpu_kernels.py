@@ -161,3 +161,75 @@ def test_icp_step(hip, oracle, frames):
         assert np.abs(gb - b).max() <= 1e-4 * max(np.abs(b).max(), 1e-3 * scale)
         assert abs(g[27] - res[0]) <= 1e-4 * max(res[0], 1e-9)
         dF0, dF1 = oracle.pyrdown_f(dF0), oracle.pyrdown_f(dF1)
+
+
+def test_gn_solve_update(hip, oracle):
+    """SURVEY 8a row a11: the device-side stand-ins for Eigen's LDLT (RGBDOdometry.cpp:447-459), OdometryProvider::rodrigues /
+    computeUpdateSE3 (OdometryProvider.h:32-90) and the pose composition of RGBDOdometry.cpp:461-474, through mf_k_gn_solve:
+    the production one-thread LDL^T and the wave-parallel Gauss-Jordan agree with each other, with the oracle's restatement and
+    with numpy / SciPy, on real ICP systems (well and badly conditioned) and on rotations from 1e-9 to 0.4 rad."""
+    import ctypes as C
+    from scipy.spatial.transform import Rotation as Rot
+    L = oracle.lib()
+    rng = np.random.default_rng(5)
+
+    def pack(A, b, res, inl):
+        out = []
+        for i in range(6):
+            for j in range(i, 7):
+                out.append(b[i] if j == 6 else A[i, j])
+        return np.array(out + [res, inl], np.float64)
+
+    cases = []
+    st, fr = scene_frames(2, noise=True)
+    dF0, dF1 = oracle.bilateral(fr[0][1]), oracle.bilateral(fr[1][1])
+    K = (st.fx, st.fy, st.cx, st.cy)
+    v0 = oracle.create_vmap(dF0, *K, 3.0); n0 = oracle.create_nmap(v0)
+    v1 = oracle.create_vmap(dF1, *K, 3.0); n1 = oracle.create_nmap(v1)
+    A, b, res = oracle.icp_step(np.eye(3, dtype=np.float32), np.zeros(3, np.float32), v1, n1, np.eye(3, dtype=np.float32),
+                                np.zeros(3, np.float32), *K, v0, n0, 0.10, float(np.sin(np.deg2rad(20.0))))
+    cases.append((np.asarray(A, np.float64).reshape(6, 6), np.asarray(b, np.float64), float(res[0]), float(res[1])))   # a real frame pair
+    for scale in (1e-9, 1e-4, 1e-2, 0.4):                      # synthetic SPD systems whose solution has a rotation of `scale` rad
+        M = rng.normal(size=(40, 6))
+        A_ = M.T @ M * rng.uniform(1.0, 1e4)
+        x_ = np.concatenate([rng.normal(size=3) * 0.01, scale * np.array([0.6, -0.64, 0.48])])
+        cases.append((A_, A_ @ x_, 12.5, 1000.0))
+    Mi = rng.normal(size=(6, 6))                               # condition number ~1e10 (a corridor-like degenerate scene)
+    Ai = Mi @ np.diag([1e6, 1e5, 1e3, 10.0, 1e-2, 1e-4]) @ Mi.T
+    cases.append((Ai, Ai @ np.array([0.01, -0.02, 0.005, 1e-3, 2e-3, -1e-3]), 3.0, 500.0))
+
+    Rprev = Rot.from_rotvec([0.2, -0.1, 0.05]).as_matrix().astype(np.float32)
+    tprev = np.array([0.3, -0.2, 1.1], np.float32)
+    rt0 = np.eye(4)
+    rt0[:3, :3] = Rot.from_rotvec([0.01, 0.02, -0.015]).as_matrix(); rt0[:3, 3] = [0.004, -0.002, 0.001]
+    for ci, (A_, b_, res_, inl_) in enumerate(cases):
+        sys29 = pack(A_, b_, res_, inl_)
+        xs, xw, rt = np.zeros(6), np.zeros(6), np.zeros(16)
+        Rc, tc, stats = np.zeros(9, np.float32), np.zeros(3, np.float32), np.zeros(2, np.float32)
+        rt_in = np.ascontiguousarray(rt0.reshape(16))
+        rc = hip.mf_k_gn_solve(sys29.ctypes.data, rt_in.ctypes.data, Rprev.ctypes.data, tprev.ctypes.data, xs.ctypes.data, xw.ctypes.data,
+                               rt.ctypes.data, Rc.ctypes.data, tc.ctypes.data, stats.ctypes.data, None)
+        assert rc == 0
+        # (1) the solve: serial LDL^T == wave Gauss-Jordan == oracle (pivoted LDLT restatement) == numpy, relative to |x|
+        xo = np.zeros(6)
+        assert L.mfo_ldlt_solve(np.ascontiguousarray(A_).ctypes.data_as(C.POINTER(C.c_double)), np.ascontiguousarray(b_).ctypes.data_as(C.POINTER(C.c_double)),
+                                xo.ctypes.data_as(C.POINTER(C.c_double)), 6) == 0
+        xn = np.linalg.solve(A_, b_)
+        cond = np.linalg.cond(A_)
+        tol = max(1e-12, 50 * cond * 2.2e-16) * np.abs(xn).max()
+        # the wave solver rounds A, b to fp32 first (as the reference does on the way to the host): its tolerance carries that rounding
+        tol_w = max(tol, 50 * cond * 6e-8 * np.abs(xn).max())
+        assert np.abs(xs - xn).max() <= tol and np.abs(xs - xo).max() <= tol, (ci, xs, xo, xn)
+        assert np.abs(xw - xn).max() <= tol_w, (ci, xw, xn)
+        # (2) exp + composition: resultRt <- [exp(w) | t] * resultRt, against the oracle's computeUpdateSE3 and against SciPy
+        rto = np.ascontiguousarray(rt0.reshape(16).copy())
+        L.mfo_update_se3(rto.ctypes.data_as(C.POINTER(C.c_double)), np.ascontiguousarray(xs).ctypes.data_as(C.POINTER(C.c_double)))
+        T = np.eye(4); T[:3, :3] = Rot.from_rotvec(xs[3:]).as_matrix(); T[:3, 3] = xs[:3]
+        want = T @ rt0
+        assert np.abs(rt.reshape(4, 4) - want).max() < 1e-14 and np.abs(rt - rto).max() < 1e-14, ci
+        # (3) currentT = [Rprev | tprev] * transform^-1 in float (RGBDOdometry.cpp:461-474)
+        inc = want.astype(np.float32)
+        iR = inc[:3, :3].T
+        it = -(iR @ inc[:3, 3])
+        assert np.abs(Rc.reshape(3, 3) - Rprev @ iR).max() < 2e-6 and np.abs(tc - (Rprev @ it + tprev)).max() < 2e-6, ci
+        assert abs(stats[0] - np.sqrt(np.float32(res_)) / np.float32(inl_)) < 1e-9 and stats[1] == np.float32(inl_)

@@ -174,3 +174,35 @@ def test_batched_tracking_matches_model_by_model_tracking(hip):
                 assert np.abs(a["poses"][i] - b["poses"][i]).max() < 1e-4, (k, mid)
                 assert a["stats"][i][1] == b["stats"][i][1] or abs(a["stats"][i][1] - b["stats"][i][1]) <= 2   # inlier counts
     assert max(len(r["ids"]) for r in runs[0]) >= 2
+
+
+def test_tiled_global_projection_equals_scatter_form(hip):
+    """GlobalProjection of the background model through the tile lists (mf_splat.hip: k_global_tile) against the scatter form
+    (k_global_scatter, one global atomicMin per covered pixel; the executable specification): the projected-id image, the label
+    image and the whole multi-model state stay bit-identical, frame by frame -- also with the confidence threshold 12 of
+    GlobalProjection.cpp:43 reached on part of the map (confidence grows by ~1 per frame: 16 frames)."""
+    from maskfusion_amd import MaskFusion, synth
+    st = synth.Stream(W=640, H=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, n_objects=2, noise=True, object_motion=0.0)
+    frames = [st.frame(k) for k in range(16)]
+    runs = []
+    for tiles in (1, 0):
+        m = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=100.0, so3=False, numGSurfels=1 << 20, numOSurfels=1 << 18,
+                       enableMultipleModels=True, modelSpawnOffset=3, trackAllModels=False)
+        for k, v in (("mfThreshold", SEG["threshold"]), ("mfWeightDistance", SEG["weightDistance"]), ("mfWeightConvexity", SEG["weightConvexity"]),
+                     ("mfMorphEdgeIterations", 0), ("mfMorphMaskIterations", 0), ("newModelMinRelativeSize", SEG["minRelSizeNew"]),
+                     ("globalTiles", tiles)):
+            m.setParam(k, v)
+        rec = []
+        for k, (rgb, depth, mask) in enumerate(frames):
+            m.processFrame(rgb, depth, mask=mask, classIDs=[0, 41, 42], timestamp=k)
+            if k > 0:
+                rec.append((m.debugRead("projected_ids"), m.downloadSegmentation(), [x.getID() for x in m.getModels()],
+                            [x.lastCount() for x in m.getModels()], m.getCurrPose()))
+        runs.append(rec)
+        m.close()
+    nonzero = 0
+    for k, (a, b) in enumerate(zip(*runs)):
+        assert np.array_equal(a[0], b[0]), f"projected ids differ in frame {k + 1}: {int((a[0] != b[0]).sum())} pixels"
+        assert np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3] and np.array_equal(a[4], b[4]), k + 1
+        nonzero = max(nonzero, int((a[0] != 0).sum()))
+    assert len(runs[0][-1][2]) >= 2 and nonzero > 500, "objects must spawn and project"

@@ -12,6 +12,10 @@ m = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=100.0, so3=Fals
                enableMultipleModels=True, modelSpawnOffset=3, trackAllModels=False)
 for k, v in SEG.items():
     m.setParam(k, v)
+if len(sys.argv) > 1:   # A/B: python tools/mm_rate.py earlyBackgroundFusion=0
+    for kv in sys.argv[1:]:
+        key, val = kv.split("=")
+        m.setParam(key, float(val))
 cls = (0, 41, 42)
 for k in range(12):
     m.processFrame(frames[k][0], frames[k][1], mask=frames[k][2], classIDs=cls)
