@@ -66,12 +66,13 @@ def _render(args):
     return st.frame(k)
 
 
-def gen_frames(cfg, n):
-    """n frames of the synthetic stream, ray-cast in parallel on the host cores (must run before CUDA is initialised: fork)."""
+def gen_frames(cfg, n, workers=0):
+    """n frames of the synthetic stream, ray-cast in parallel on the host cores (must run before CUDA is initialised: fork).
+    workers = 1: no fork at all (under rocprofv3 --pmc the tool has initialised HSA before Python starts; forked workers hang at exit)."""
     from maskfusion_amd import synth
     st = synth.Stream(W=cfg["W"], H=cfg["H"], fx=cfg["f"], fy=cfg["f"], cx=cfg["W"] / 2.0, cy=cfg["H"] / 2.0, noise=True,
                       n_objects=cfg["n_objects"], seed=1234)
-    workers = max(1, min(48, (os.cpu_count() or 1) - 2, n))
+    workers = workers or max(1, min(48, (os.cpu_count() or 1) - 2, n))
     if workers > 1:
         with mp.get_context("fork").Pool(workers) as pool:
             frames = pool.map(_render, [(cfg, k) for k in range(n)], chunksize=max(1, n // (4 * workers)))
@@ -235,6 +236,7 @@ def main():
                     "the reference GUI default is 20: photometric term on, two launches per Gauss-Newton iteration)")
     ap.add_argument("--so3", action="store_true", help="SO(3) photometric pre-alignment (reference default: on)")
     ap.add_argument("--no-batch", action="store_true", help="config 2s: track the models one after the other (A/B of the batched loop)")
+    ap.add_argument("--gen-workers", type=int, default=0, help="processes that ray-cast the synthetic frames (0: auto; 1: no fork, for profiler runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host-input", action="store_true")
@@ -249,7 +251,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # the stream is ray-cast before CUDA exists in this process (the generator forks); only rank 0 owns frames
-    st, frames = gen_frames(cfg, n_frames) if rank == 0 else (None, None)
+    st, frames = gen_frames(cfg, n_frames, args.gen_workers) if rank == 0 else (None, None)
     if args.config == "3":
         if args.steps == 600:
             args.steps = 120

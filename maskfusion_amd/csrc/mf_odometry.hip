@@ -385,39 +385,65 @@ struct IcpKArgs {
 // together (a per-pixel search-then-accumulate serialises four dependent L2 round trips: ~2 us per launch).
 struct IcpCorr { float3 vcurr_g, vcurr_cp, ncurr_g; int j; bool ok; };
 
+// Per-pixel arithmetic of the ICP kernels with every fused multiply-add SPELLED OUT and contraction off: k_icp_iter<512>,
+// k_icp_iter<256>, k_icp_batch_pixels and k_rgbd_iter are separate functions, and left to itself the compiler contracts a * b + c
+// differently in each (and differently again with other flags).  The 1e-7 relative spread that causes is invisible for a
+// room-sized model, but a freshly spawned object (2 000 pixels on two box faces: a 6x6 system with condition ~1e5) turns it into
+// millimetres of pose -- the batched loop and the model-by-model loop must agree pixel for pixel, so that only the summation
+// order of the block partials is left between them (tests/test_gpu_multimodel.py::test_batched_tracking_...).
+__device__ __forceinline__ float3 icp_mul33(const float* R, float3 v) {
+#pragma clang fp contract(off)
+    return f3(fmaf(R[2], v.z, fmaf(R[1], v.y, R[0] * v.x)), fmaf(R[5], v.z, fmaf(R[4], v.y, R[3] * v.x)),
+              fmaf(R[8], v.z, fmaf(R[7], v.y, R[6] * v.x)));
+}
+__device__ __forceinline__ float icp_dot3(float3 a, float3 b) {
+#pragma clang fp contract(off)
+    return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x));
+}
+__device__ __forceinline__ float3 icp_cross3(float3 a, float3 b) {
+#pragma clang fp contract(off)
+    return f3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+
 template <class Args>
 __device__ __forceinline__ IcpCorr icp_project(float vx, float vy, float vz, float nx, float ny, float nz, const float* Rc,
                                                float3 tc, const float* Rpi, float3 tp, const Args& a) {
+#pragma clang fp contract(off)
     // search(), first half: Core/Cuda/reduce.cu:292-314
     IcpCorr c;
-    c.vcurr_g = mul33(Rc, f3(vx, vy, vz)) + tc;
-    c.vcurr_cp = mul33(Rpi, c.vcurr_g - tp);
-    const int ux = __float2int_rn(c.vcurr_cp.x * a.k.fx / c.vcurr_cp.z + a.k.cx);
-    const int uy = __float2int_rn(c.vcurr_cp.y * a.k.fy / c.vcurr_cp.z + a.k.cy);
+    const float3 g = icp_mul33(Rc, f3(vx, vy, vz));
+    c.vcurr_g = f3(g.x + tc.x, g.y + tc.y, g.z + tc.z);
+    c.vcurr_cp = icp_mul33(Rpi, f3(c.vcurr_g.x - tp.x, c.vcurr_g.y - tp.y, c.vcurr_g.z - tp.z));
+    const int ux = __float2int_rn((c.vcurr_cp.x * a.k.fx) / c.vcurr_cp.z + a.k.cx);
+    const int uy = __float2int_rn((c.vcurr_cp.y * a.k.fy) / c.vcurr_cp.z + a.k.cy);
     c.ok = !(ux < 0 || uy < 0 || ux >= a.W || uy >= a.H || c.vcurr_cp.z < 0) && !isnan(nx);
     c.j = c.ok ? uy * a.W + ux : 0;
-    c.ncurr_g = mul33(Rc, f3(nx, ny, nz));
+    c.ncurr_g = icp_mul33(Rc, f3(nx, ny, nz));
     return c;
 }
 
 template <class Args>
 __device__ __forceinline__ void icp_accumulate(const IcpCorr& c, float3 vprev_g, float3 nprev_g, const float* Rpi, float3 tp,
                                                const Args& a, float* acc) {
+#pragma clang fp contract(off)
     // search(), second half + getProducts(): Core/Cuda/reduce.cu:326-415
-    const float dist = norm3(vprev_g - c.vcurr_g);
-    const float sine = norm3(cross3(c.ncurr_g, nprev_g));
+    const float3 dv = f3(vprev_g.x - c.vcurr_g.x, vprev_g.y - c.vcurr_g.y, vprev_g.z - c.vcurr_g.z);
+    const float dist = sqrtf(icp_dot3(dv, dv));
+    const float3 cr = icp_cross3(c.ncurr_g, nprev_g);
+    const float sine = sqrtf(icp_dot3(cr, cr));
     const bool found = c.ok && sine < a.angleThres && dist <= a.distThres && !isnan(nprev_g.x);
     if (!found) return;
     const float3 s_cp = c.vcurr_cp;
-    const float3 d_cp = mul33(Rpi, vprev_g - tp);
-    const float3 n_cp = mul33(Rpi, nprev_g);
-    const float3 sxn = cross3(s_cp, n_cp);
-    const float row[7] = {n_cp.x, n_cp.y, n_cp.z, sxn.x, sxn.y, sxn.z, dot3(n_cp, s_cp - d_cp)};
+    const float3 d_cp = icp_mul33(Rpi, f3(vprev_g.x - tp.x, vprev_g.y - tp.y, vprev_g.z - tp.z));
+    const float3 n_cp = icp_mul33(Rpi, nprev_g);
+    const float3 sxn = icp_cross3(s_cp, n_cp);
+    const float row[7] = {n_cp.x, n_cp.y, n_cp.z, sxn.x, sxn.y, sxn.z,
+                          icp_dot3(n_cp, f3(s_cp.x - d_cp.x, s_cp.y - d_cp.y, s_cp.z - d_cp.z))};
     int k = 0;
 #pragma unroll
     for (int r = 0; r < 7; ++r)
 #pragma unroll
-        for (int cc = r; cc < 7; ++cc) acc[k++] += row[r] * row[cc];
+        for (int cc = r; cc < 7; ++cc) { acc[k] = fmaf(row[r], row[cc], acc[k]); ++k; }
     acc[28] += 1.0f;
 }
 
@@ -482,14 +508,13 @@ __global__ __launch_bounds__(kT) void k_icp_iter(const IcpKArgs a) {
     float vx[kIcpPx], vy[kIcpPx], vz[kIcpPx], nx[kIcpPx], ny[kIcpPx], nz[kIcpPx];
 #pragma unroll
     for (int q = 0; q < kIcpPx; ++q) {
+        // slots past the end of the chunk re-read its last pixel and are masked out of the sums below: no divergent control flow
+        // around the loads / projections / gathers of the three slots (the exec-mask bookkeeping was ~10 % of the pixel phase)
         idx[q] = beg + q * kT + tid;
         act[q] = idx[q] < end;
-        vx[q] = vy[q] = vz[q] = nx[q] = ny[q] = nz[q] = 0.f;
-        if (act[q]) {
-            const int i = idx[q];
-            vx[q] = a.vc[i]; vy[q] = a.vc[P + i]; vz[q] = a.vc[2 * P + i];
-            nx[q] = a.nc[i]; ny[q] = a.nc[P + i]; nz[q] = a.nc[2 * P + i];
-        }
+        const int i = min(idx[q], P - 1);
+        vx[q] = a.vc[i]; vy[q] = a.vc[P + i]; vz[q] = a.vc[2 * P + i];
+        nx[q] = a.nc[i]; ny[q] = a.nc[P + i]; nz[q] = a.nc[2 * P + i];
     }
 
     // (2) prologue: finish the previous iteration (reduce -> solve -> pose), identically in every workgroup
@@ -543,18 +568,19 @@ __global__ __launch_bounds__(kT) void k_icp_iter(const IcpKArgs a) {
     IcpCorr cor[kIcpPx];
     float3 pv[kIcpPx], pn[kIcpPx];
 #pragma unroll
-    for (int q = 0; q < kIcpPx; ++q)
-        if (act[q]) cor[q] = icp_project(vx[q], vy[q], vz[q], nx[q], ny[q], nz[q], Rc, tc, Rpi, tp, a);
+    for (int q = 0; q < kIcpPx; ++q) {
+        cor[q] = icp_project(vx[q], vy[q], vz[q], nx[q], ny[q], nz[q], Rc, tc, Rpi, tp, a);
+        cor[q].ok = cor[q].ok && act[q];
+        cor[q].j = cor[q].ok ? cor[q].j : 0;
+    }
 #pragma unroll
-    for (int q = 0; q < kIcpPx; ++q)
-        if (act[q]) {
-            const int j = cor[q].j;
-            pv[q] = f3(a.vp[j], a.vp[P + j], a.vp[2 * P + j]);
-            pn[q] = f3(a.np[j], a.np[P + j], a.np[2 * P + j]);
-        }
+    for (int q = 0; q < kIcpPx; ++q) {
+        const int j = cor[q].j;
+        pv[q] = f3(a.vp[j], a.vp[P + j], a.vp[2 * P + j]);
+        pn[q] = f3(a.np[j], a.np[P + j], a.np[2 * P + j]);
+    }
 #pragma unroll
-    for (int q = 0; q < kIcpPx; ++q)
-        if (act[q]) icp_accumulate(cor[q], pv[q], pn[q], Rpi, tp, a, acc);
+    for (int q = 0; q < kIcpPx; ++q) icp_accumulate(cor[q], pv[q], pn[q], Rpi, tp, a, acc);
 
     // (4) wavefront reduction (halving tree), one LDS stage across the wavefronts, one 128 B partial per workgroup
     if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[5] = __builtin_amdgcn_s_memtime(); }
@@ -709,29 +735,28 @@ __global__ __launch_bounds__(kBatchThreads) void k_icp_batch_pixels(const IcpPxA
         float vx[kBatchPx], vy[kBatchPx], vz[kBatchPx], nx[kBatchPx], ny[kBatchPx], nz[kBatchPx];
 #pragma unroll
         for (int q = 0; q < kBatchPx; ++q) {
-            const int i = base + q * kBatchThreads + tid;
-            act[q] = i < end;
-            vx[q] = vy[q] = vz[q] = nx[q] = ny[q] = nz[q] = 0.f;
-            if (act[q]) {
-                vx[q] = a.vc[i]; vy[q] = a.vc[P + i]; vz[q] = a.vc[2 * P + i];
-                nx[q] = a.nc[i]; ny[q] = a.nc[P + i]; nz[q] = a.nc[2 * P + i];
-            }
+            const int i0 = base + q * kBatchThreads + tid;
+            act[q] = i0 < end;
+            const int i = min(i0, P - 1);      // masked slots re-read a valid pixel: no divergent control flow (see k_icp_iter)
+            vx[q] = a.vc[i]; vy[q] = a.vc[P + i]; vz[q] = a.vc[2 * P + i];
+            nx[q] = a.nc[i]; ny[q] = a.nc[P + i]; nz[q] = a.nc[2 * P + i];
         }
         IcpCorr cor[kBatchPx];
         float3 pv[kBatchPx], pn[kBatchPx];
 #pragma unroll
-        for (int q = 0; q < kBatchPx; ++q)
-            if (act[q]) cor[q] = icp_project(vx[q], vy[q], vz[q], nx[q], ny[q], nz[q], Rc, tc, Rpi, tp, a);
+        for (int q = 0; q < kBatchPx; ++q) {
+            cor[q] = icp_project(vx[q], vy[q], vz[q], nx[q], ny[q], nz[q], Rc, tc, Rpi, tp, a);
+            cor[q].ok = cor[q].ok && act[q];
+            cor[q].j = cor[q].ok ? cor[q].j : 0;
+        }
 #pragma unroll
-        for (int q = 0; q < kBatchPx; ++q)
-            if (act[q]) {
-                const int j = cor[q].j;
-                pv[q] = f3(vp[j], vp[P + j], vp[2 * P + j]);
-                pn[q] = f3(np[j], np[P + j], np[2 * P + j]);
-            }
+        for (int q = 0; q < kBatchPx; ++q) {
+            const int j = cor[q].j;
+            pv[q] = f3(vp[j], vp[P + j], vp[2 * P + j]);
+            pn[q] = f3(np[j], np[P + j], np[2 * P + j]);
+        }
 #pragma unroll
-        for (int q = 0; q < kBatchPx; ++q)
-            if (act[q]) icp_accumulate(cor[q], pv[q], pn[q], Rpi, tp, a, acc);
+        for (int q = 0; q < kBatchPx; ++q) icp_accumulate(cor[q], pv[q], pn[q], Rpi, tp, a, acc);
     }
     block_sum29_lds<kBatchThreads>(acc, s_red, md->partials[a.parity] + blockIdx.x * kIcpSlots);
 }

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_global_scatter(Surfels src, const Frame
         }
         float size = fmaxf(0.f, fmaxf(fabsf(xs1 - xs0), fabsf(ys1 - ys0)));
         if (!(size > 0.f)) continue;
-        size = fminf(size, 64.0f);
+        size = fminf(fmaxf(size, 1.0f), 64.0f);   // GL clamps gl_PointSize to the point size range: at least 1 px (see mf_splat.hip)
         const float half = size * 0.5f;
         const int px0 = max(0, (int)ceilf(u - half - 0.5f)), px1 = min(W - 1, (int)ceilf(u + half - 0.5f) - 1);
         const int py0 = max(0, (int)ceilf(v - half - 0.5f)), py1 = min(H - 1, (int)ceilf(v + half - 0.5f) - 1);

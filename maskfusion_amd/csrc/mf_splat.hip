@@ -49,7 +49,9 @@ __device__ __forceinline__ bool splat_setup(const Surfels& src, int i, float tim
     }
     float size = fmaxf(0.f, fmaxf(fabsf(xs1 - xs0), fabsf(ys1 - ys0)));
     if (!(size > 0.f)) return false;
-    size = fminf(size, 64.0f);
+    // gl_PointSize is clamped to the implementation's point size range (OpenGL 3.3 core, 3.4 "Points"; NVIDIA: [1, 2047]): a sprite
+    // smaller than a pixel -- a surfel seen from more than ~4x its creation distance -- still covers the pixel its centre falls into
+    size = fminf(fmaxf(size, 1.0f), 64.0f);
     const float half = size * 0.5f;
     o.px0 = max(0, (int)ceilf(u - half - 0.5f)); o.px1 = min(W - 1, (int)ceilf(u + half - 0.5f) - 1);
     o.py0 = max(0, (int)ceilf(v - half - 0.5f)); o.py1 = min(H - 1, (int)ceilf(v + half - 0.5f) - 1);

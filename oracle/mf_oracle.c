@@ -1411,7 +1411,9 @@ static void splat_zbuffer(const mfo_cam* c, const float* pose16, const float* su
         }
         float size = fmaxf(0.f, fmaxf(fabsf(xs1 - xs0), fabsf(ys1 - ys0)));
         if (!(size > 0.f)) continue; /* also drops NaN sizes */
-        size = fminf(size, MFO_MAX_SPRITE);
+        /* gl_PointSize is clamped to the point size range (OpenGL 3.3 core, 3.4 "Points"): never below 1 px on the reference's
+         * platform (ALIASED_POINT_SIZE_RANGE = [1, 2047] on NVIDIA); the upper end is capped at MFO_MAX_SPRITE here */
+        size = fminf(fmaxf(size, 1.0f), MFO_MAX_SPRITE);
         const float half = size * 0.5f;
         const int px0 = imax(0, (int)ceilf(u - half - 0.5f)), px1 = imin(W - 1, (int)ceilf(u + half - 0.5f) - 1);
         const int py0 = imax(0, (int)ceilf(v - half - 0.5f)), py1 = imin(H - 1, (int)ceilf(v + half - 0.5f) - 1);

@@ -159,7 +159,10 @@ def test_icp_step(hip, oracle, frames):
         scale = np.abs(A).max()
         assert np.abs(gA - A).max() <= 1e-4 * scale
         assert np.abs(gb - b).max() <= 1e-4 * max(np.abs(b).max(), 1e-3 * scale)
-        assert abs(g[27] - res[0]) <= 1e-4 * max(res[0], 1e-9)
+        # sum r^2: every r = n . (s - d) is a millimetre-sized difference of metre-sized products, so fused vs separately rounded
+        # multiply-adds (the device contracts, the oracle rounds every operation) move each r by up to ~1e-4 relative; the sum only
+        # feeds the lastICPError statistic (RGBDOdometry.cpp:476), never the solve
+        assert abs(g[27] - res[0]) <= 3e-4 * max(res[0], 1e-9)
         dF0, dF1 = oracle.pyrdown_f(dF0), oracle.pyrdown_f(dF1)
 
 
@@ -212,8 +215,7 @@ def test_gn_solve_update(hip, oracle):
         assert rc == 0
         # (1) the solve: serial LDL^T == wave Gauss-Jordan == oracle (pivoted LDLT restatement) == numpy, relative to |x|
         xo = np.zeros(6)
-        assert L.mfo_ldlt_solve(np.ascontiguousarray(A_).ctypes.data_as(C.POINTER(C.c_double)), np.ascontiguousarray(b_).ctypes.data_as(C.POINTER(C.c_double)),
-                                xo.ctypes.data_as(C.POINTER(C.c_double)), 6) == 0
+        assert L.mfo_ldlt_solve(np.ascontiguousarray(A_, np.float64), np.ascontiguousarray(b_, np.float64), xo, 6) == 0
         xn = np.linalg.solve(A_, b_)
         cond = np.linalg.cond(A_)
         tol = max(1e-12, 50 * cond * 2.2e-16) * np.abs(xn).max()
@@ -223,7 +225,7 @@ def test_gn_solve_update(hip, oracle):
         assert np.abs(xw - xn).max() <= tol_w, (ci, xw, xn)
         # (2) exp + composition: resultRt <- [exp(w) | t] * resultRt, against the oracle's computeUpdateSE3 and against SciPy
         rto = np.ascontiguousarray(rt0.reshape(16).copy())
-        L.mfo_update_se3(rto.ctypes.data_as(C.POINTER(C.c_double)), np.ascontiguousarray(xs).ctypes.data_as(C.POINTER(C.c_double)))
+        L.mfo_update_se3(rto, np.ascontiguousarray(xs, np.float64))
         T = np.eye(4); T[:3, :3] = Rot.from_rotvec(xs[3:]).as_matrix(); T[:3, 3] = xs[:3]
         want = T @ rt0
         assert np.abs(rt.reshape(4, 4) - want).max() < 1e-14 and np.abs(rt - rto).max() < 1e-14, ci

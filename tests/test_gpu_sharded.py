@@ -44,8 +44,10 @@ def test_two_contexts_equal_one_context(hip, track_all):
     ctxs = [_make(track_all), _make(track_all)]
     shards = [sharded.Shard(r, 2, ctxs[r], dev) for r in range(2)]
     grp = sharded.LocalGroup(shards, sharded.default_cfg(trackAllModels=track_all, modelSpawnOffset=3))
+    most_objects = 0
     for k, (rgb, depth, mask) in enumerate(frames):
         grp.process_frame(rgb, depth, mask, cls, 1.0, k)
+        most_objects = max(most_objects, len(ctxs[1].getModels()) - 1)
         got = {}
         for r, c in enumerate(ctxs):
             for i, m in enumerate(c.getModels()):
@@ -66,6 +68,8 @@ def test_two_contexts_equal_one_context(hip, track_all):
             if want["clouds"] is not None:
                 assert np.array_equal(got[mid]["cloud"], want["clouds"][i], equal_nan=True), (k, mid)
     assert max(len(r["ids"]) for r in ref) >= 3, "the scenario must spawn both object models"
-    assert len(ctxs[1].getModels()) >= 3 and len(ctxs[0].getModels()) == 1      # objects live on context 1 only
+    # objects live on context 1 only (tracked boxes may be dropped by the 0.2 m jump rule and re-spawned along the way -- identically
+    # on both sides, which is the point -- so the count is taken over the run, not at its end)
+    assert most_objects >= 2 and len(ctxs[0].getModels()) == 1
     for c in ctxs:
         c.close()

@@ -3,7 +3,7 @@ sys.path.insert(0,'.')
 import torch
 from maskfusion_amd import MaskFusion
 import bench
-st, frames = bench.gen_frames(bench.CONFIGS["1"], 12)
+st, frames = bench.gen_frames(bench.CONFIGS["1"], 12, 1)
 mf = MaskFusion(640,480,528,528,320,240, icpThresh=100.0, so3=False, enableMultipleModels=False)
 mf.setParam("icpProfile", 1)
 acc=[]
