@@ -406,7 +406,7 @@ def main():
                       "note": f"mf_process_frame with host pointers: {(7 + (1 if multi else 0)) * P / 1e6:.2f} MB H2D per frame + one synchronisation per frame"}
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline and not multi:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not multi:   # rank 0 at N = 1 only (the other ranks would sit in a collective)
         cpu = cpu_baseline(cfg, frames)
 
     if rank == 0:

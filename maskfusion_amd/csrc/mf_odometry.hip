@@ -385,24 +385,27 @@ struct IcpKArgs {
 // together (a per-pixel search-then-accumulate serialises four dependent L2 round trips: ~2 us per launch).
 struct IcpCorr { float3 vcurr_g, vcurr_cp, ncurr_g; int j; bool ok; };
 
-// Per-pixel arithmetic of the ICP kernels with every fused multiply-add SPELLED OUT and contraction off: k_icp_iter<512>,
-// k_icp_iter<256>, k_icp_batch_pixels and k_rgbd_iter are separate functions, and left to itself the compiler contracts a * b + c
-// differently in each (and differently again with other flags).  The 1e-7 relative spread that causes is invisible for a
-// room-sized model, but a freshly spawned object (2 000 pixels on two box faces: a 6x6 system with condition ~1e5) turns it into
-// millimetres of pose -- the batched loop and the model-by-model loop must agree pixel for pixel, so that only the summation
-// order of the block partials is left between them (tests/test_gpu_multimodel.py::test_batched_tracking_...).
+// Per-pixel arithmetic of the ICP kernels, every operation rounded on its own and in the oracle's order (oracle/mf_oracle.c
+// m33_mul / f3_dot / f3_cross: a plain reading of Core/Cuda/reduce.cu:292-415), contraction off.  Two reasons:
+//  * everything that DECIDES something -- the rounded projection (ux, uy), the 0.10 m distance gate, the sin 20 degrees gate, the
+//    NaN tests -- is then bit-identical to the oracle, so the inlier set (not just its size) matches by construction, and the
+//    seven row entries of every inlier do too; only the accumulation of the 28 products differs (fp32 block sums here, double there);
+//  * k_icp_iter<512>, k_icp_iter<256>, k_icp_batch_pixels and k_rgbd_iter are separate functions, and left to itself the compiler
+//    contracts a * b + c differently in each.  The 1e-7 relative spread that causes is invisible for a room-sized model, but a freshly
+//    spawned object (2 000 pixels on two box faces: a 6x6 system with condition ~1e5) turns it into millimetres of pose: the batched
+//    loop and the model-by-model loop must agree pixel for pixel (tests/test_gpu_multimodel.py::test_batched_tracking_...).
+// Cost: ~20 instructions per pixel (3 mul + 2 add instead of 1 mul + 2 fma per matrix row).
 __device__ __forceinline__ float3 icp_mul33(const float* R, float3 v) {
 #pragma clang fp contract(off)
-    return f3(fmaf(R[2], v.z, fmaf(R[1], v.y, R[0] * v.x)), fmaf(R[5], v.z, fmaf(R[4], v.y, R[3] * v.x)),
-              fmaf(R[8], v.z, fmaf(R[7], v.y, R[6] * v.x)));
+    return f3(R[0] * v.x + R[1] * v.y + R[2] * v.z, R[3] * v.x + R[4] * v.y + R[5] * v.z, R[6] * v.x + R[7] * v.y + R[8] * v.z);
 }
 __device__ __forceinline__ float icp_dot3(float3 a, float3 b) {
 #pragma clang fp contract(off)
-    return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x));
+    return a.x * b.x + a.y * b.y + a.z * b.z;
 }
 __device__ __forceinline__ float3 icp_cross3(float3 a, float3 b) {
 #pragma clang fp contract(off)
-    return f3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+    return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 
 template <class Args>

@@ -1167,6 +1167,27 @@ void mfo_predict_indices(const mfo_cam* c, const float* pose16, const float* sur
  * {-1,-0.5,0,+0.5} map to texels {x-1, x, x, x+1}. */
 static const int kWinPix[4] = {-1, 0, 0, 1};
 
+/* ANALYSIS SWITCH (never on in the parity tests): a literal fp32 reading of the window loops of data.vert:139-141 and
+ * copy_unstable.vert:85-86, `for (i = c - 2s; i < c + 2s; i += s)` with an fp32 induction variable.  In exact arithmetic the loop
+ * makes 4 steps; in fp32 it makes 4 or 5 depending on the rounding of c.  With the switch on, the taps are the
+ * values the fp32 loop visits and a tap's texel is floor(i * size) -- one plausible GPU behaviour, used only to measure how much
+ * the ambiguity matters (tools/window_ambiguity.py). */
+static int g_window_literal = 0;
+void mfo_set_window_literal(int on) { g_window_literal = on; }
+/* taps of one axis: centre coordinate c (normalised), size = cols or rows; returns the number of taps (<= 8) */
+static int window_taps_literal(float c, float size, int* texels) {
+    const float step = (1.0f / (size * 1.0f)) * 0.5f;          /* indexXStep, scale = FACTOR = 1 */
+    const float half = (1.0f * step) * 2.0f;                   /* scale * indexXStep * windowMultiplier */
+    const float end = c + half;
+    int n = 0;
+    for (float i = c - half; i < end && n < 8; i += step) {
+        int t = (int)floorf(i * size);
+        t = t < 0 ? 0 : (t > (int)size - 1 ? (int)size - 1 : t);
+        texels[n++] = t;
+    }
+    return n;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * a14 part 1: data association (data.vert; Model.cpp:466-581)
  * Candidate enumeration: quarter-rate pixels (x%2 == t%2 && y%2 == t%2) in column-major order:
@@ -1219,9 +1240,15 @@ void mfo_fuse_data(const mfo_cam* c, const float* pose16, const uint8_t* rgb, co
             const f3 ray = f3_make(xl, yl, 1);
             float bestDist = 1000;
             int best = 0, operation = 0;
-            for (int a = 0; a < 4; ++a) {
-                for (int b = 0; b < 4; ++b) {
-                    const int tx = iclamp(px + kWinPix[a], 0, W - 1), ty = iclamp(py + kWinPix[b], 0, H - 1);
+            int wx[8], wy[8], nwx = 4, nwy = 4;
+            for (int a = 0; a < 4; ++a) { wx[a] = iclamp(px + kWinPix[a], 0, W - 1); wy[a] = iclamp(py + kWinPix[a], 0, H - 1); }
+            if (g_window_literal) {   /* texcoord as FeedbackBuffer.cpp:44-50 / Model.cpp build the uv buffer */
+                nwx = window_taps_literal((float)((double)((float)px / (float)W) + 1.0 / (2.0 * (double)(float)W)), (float)W, wx);
+                nwy = window_taps_literal((float)((double)((float)py / (float)H) + 1.0 / (2.0 * (double)(float)H)), (float)H, wy);
+            }
+            for (int a = 0; a < nwx; ++a) {
+                for (int b = 0; b < nwy; ++b) {
+                    const int tx = wx[a], ty = wy[b];
                     const int tp = ty * W + tx;
                     const int current = index[tp];
                     if (current > 0) {
@@ -1304,10 +1331,12 @@ static int clean_one(const mfo_cam* c, const float* Ri, const float* ti, const f
     int count = 0, zCount = 0;
     if ((float)time - in[7] < (float)timeDelta && lp.z > 0 && x > 0 && y > 0 && x < (float)W && y < (float)H) {
         static const float off[4] = {-1.0f, -0.5f, 0.0f, 0.5f};
-        for (int a = 0; a < 4; ++a) {
-            for (int b = 0; b < 4; ++b) {
-                const int tx = iclamp((int)floorf(x + off[a]), 0, W - 1);
-                const int ty = iclamp((int)floorf(y + off[b]), 0, H - 1);
+        int wx[8], wy[8], nwx = 4, nwy = 4;
+        for (int a = 0; a < 4; ++a) { wx[a] = iclamp((int)floorf(x + off[a]), 0, W - 1); wy[a] = iclamp((int)floorf(y + off[a]), 0, H - 1); }
+        if (g_window_literal) { nwx = window_taps_literal(x / (float)W, (float)W, wx); nwy = window_taps_literal(y / (float)H, (float)H, wy); }
+        for (int a = 0; a < nwx; ++a) {
+            for (int b = 0; b < nwy; ++b) {
+                const int tx = wx[a], ty = wy[b];
                 const int tp = ty * W + tx;
                 if (index[tp] > 0) {
                     const float* vc = vertConf + tp * 4;

@@ -65,6 +65,8 @@ void mfo_icp_step(const float* Rcurr, const float* tcurr,
                   const float* vmap_g_prev, const float* nmap_g_prev,
                   float distThres, float angleThres, int W, int H,
                   float* A, float* b, float* residual);
+/* ANALYSIS ONLY (tools/window_ambiguity.py): literal fp32 reading of the association / clean window loops; see mf_oracle.c */
+void mfo_set_window_literal(int on);
 /* Eigen LDLT stand-in (RGBDOdometry.cpp:447-459): symmetric solve in double, n = 3 or 6.
  * Returns 0 on success. */
 int mfo_ldlt_solve(const double* A, const double* b, double* x, int n);

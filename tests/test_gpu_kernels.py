@@ -159,10 +159,9 @@ def test_icp_step(hip, oracle, frames):
         scale = np.abs(A).max()
         assert np.abs(gA - A).max() <= 1e-4 * scale
         assert np.abs(gb - b).max() <= 1e-4 * max(np.abs(b).max(), 1e-3 * scale)
-        # sum r^2: every r = n . (s - d) is a millimetre-sized difference of metre-sized products, so fused vs separately rounded
-        # multiply-adds (the device contracts, the oracle rounds every operation) move each r by up to ~1e-4 relative; the sum only
-        # feeds the lastICPError statistic (RGBDOdometry.cpp:476), never the solve
-        assert abs(g[27] - res[0]) <= 3e-4 * max(res[0], 1e-9)
+        # sum r^2: the per-pixel residuals are bit-identical to the oracle's (same operations, each rounded on its own); what is
+        # left is fp32 block sums against the oracle's double accumulation
+        assert abs(g[27] - res[0]) <= 2e-5 * max(res[0], 1e-9)
         dF0, dF1 = oracle.pyrdown_f(dF0), oracle.pyrdown_f(dF1)
 
 

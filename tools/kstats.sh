@@ -1,9 +1,9 @@
 #!/bin/bash
-# per-kernel average durations of a short bench run (rocprofv3 --kernel-trace --stats); prints name, calls, avg us and copies
+# per-kernel average durations of a short bench run (timeout 300 rocprofv3 --kernel-trace --stats); prints name, calls, avg us and copies
 # the stats csv to gpurun_out/<tag>_kernel_stats.csv.  usage: tools/kstats.sh <tag> [bench.py args]
 REPO=$(pwd); TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/prof_k
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k -o k -- python $REPO/bench.py --steps 100 --warmup 60 --min-seconds 0 --frames 60 --no-cpu-baseline --no-host-input --no-roofline "$@" > /tmp/prof_k.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k -o k -- python $REPO/bench.py --steps 100 --warmup 60 --min-seconds 0 --frames 60 --gen-workers 1 --no-cpu-baseline --no-host-input --no-roofline "$@" > /tmp/prof_k.log 2>&1
 mkdir -p $REPO/gpurun_out
 F=$(find /tmp/prof_k -name '*kernel_stats.csv' | head -1)
 cp "$F" $REPO/gpurun_out/${TAG}_kernel_stats.csv

@@ -19,9 +19,11 @@ WIDE = ("k_fuse_update", "k_clean_compact", "k_index_scatter", "k_splat_bin", "k
 
 def load(path):
     out = {}
-    for r in csv.DictReader(open(path)):
-        name = r["kernel"].replace("void ", "").replace("mf::", "")
-        out.setdefault(name, []).append((int(r["launches"]), float(r["mean"])))
+    for line in list(open(path))[1:]:
+        # kernel names may contain commas (template arguments): the four numeric / counter columns are taken from the right
+        name, _counter, launches, mean, _total = line.rstrip("\n").rsplit(",", 4)
+        name = name.replace("void ", "").replace("mf::", "")
+        out.setdefault(name, []).append((int(launches), float(mean)))
     return out
 
 
