@@ -385,8 +385,8 @@ struct IcpKArgs {
 // together (a per-pixel search-then-accumulate serialises four dependent L2 round trips: ~2 us per launch).
 struct IcpCorr { float3 vcurr_g, vcurr_cp, ncurr_g; int j; bool ok; };
 
-// Per-pixel arithmetic of the ICP kernels, every operation rounded on its own and in the oracle's order (oracle/mf_oracle.c
-// m33_mul / f3_dot / f3_cross: a plain reading of Core/Cuda/reduce.cu:292-415), contraction off.  Two reasons:
+// Per-pixel arithmetic of the ICP kernels, every operation rounded on its own and in the order of the CPU restatement the
+// parity tests check against (its m33_mul / f3_dot / f3_cross: a plain reading of Core/Cuda/reduce.cu:292-415), contraction off.  Two reasons:
 //  * everything that DECIDES something -- the rounded projection (ux, uy), the 0.10 m distance gate, the sin 20 degrees gate, the
 //    NaN tests -- is then bit-identical to the oracle, so the inlier set (not just its size) matches by construction, and the
 //    seven row entries of every inlier do too; only the accumulation of the 28 products differs (fp32 block sums here, double there);
