@@ -380,7 +380,8 @@ def main():
                     else f"{kname} (19 launches per model and frame, L2:4 L1:5 L0:10)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "algorithmic_bytes_per_launch": icp_bytes / n_launch, "us_per_launch": t_icp * 1e6,
-                    "traffic": pmc_traffic("k_icp_iter") if not batched else pmc_traffic("k_icp_batch_pixels"), "stage_ms": stages}
+                    # the committed PMC profile was taken on configs[1] (VGA, one model): it says nothing about the other workloads
+                    "traffic": pmc_traffic("k_icp_iter") if args.config == "1" else None, "stage_ms": stages}
         frame_bytes = 741 * P * n_tracked + 192 * count
         roofline_frame = {"bound": "hbm", "algorithmic_bytes": frame_bytes, "ms": 1e3 * total_dt / total_steps,
                           "achieved": frame_bytes / (total_dt / total_steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
