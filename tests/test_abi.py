@@ -93,3 +93,17 @@ def test_cpp_facade_keeps_the_reference_signatures():
                 "addNewModelListener(const ModelListener&", "addInactiveModelListener(const ModelListener&", "setTrackableClassIds(const std::set<int>&",
                 "makeNonStatic()", "ModelList& getModels()", "bool processFrame(FrameDataPointer frame, const Matrix4f* inPose = nullptr, const float weightMultiplier = 1.f,"):
         assert sig in h, sig
+
+
+def test_cpp_facade_host_semantics_without_gpu(tmp_path):
+    """Frame queue (MaskFusion.cpp:37,206-209), model list as std::list<std::shared_ptr<Model>> with stable identities, new / inactive
+    model listeners (MaskFusion.h:303-306), Resolution / Intrinsics preconditions, refusal of what is not built: the facade's host
+    logic against a scripted stand-in for the C ABI (tests/cpp/stub_abi.cpp) -- no GPU, no product library involved."""
+    import subprocess
+    exe = os.path.join(str(tmp_path), "facade_semantics")
+    cmd = ["g++", "-std=c++14", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "facade_semantics.cpp"), os.path.join(ROOT, "tests", "cpp", "stub_abi.cpp"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "facade semantics ok" in out.stdout, out.stdout + out.stderr
