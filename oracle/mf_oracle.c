@@ -103,6 +103,14 @@ static void pose_inverse_Rt(const float* R, const float* t, float* Ri, float* ti
     ti[0] = -v.x; ti[1] = -v.y; ti[2] = -v.z;
 }
 
+/* the t_inv uniform every projection pass is handed (column-major 4x4 in and out) */
+void mfo_pose_inverse16(const float* pose16, float* out16) {
+    float R[9], t[3], Ri[9], ti[3];
+    pose16_to_Rt(pose16, R, t);
+    pose_inverse_Rt(R, t, Ri, ti);
+    Rt_to_pose16(Ri, ti, out16);
+}
+
 /* ------------------------------------------------------------------------------------------------
  * a2: bilateral filter (Core/Shaders/depth_bilateral_metric.frag:30-76)
  * ---------------------------------------------------------------------------------------------- */
@@ -1170,7 +1178,8 @@ static const int kWinPix[4] = {-1, 0, 0, 1};
 /* ANALYSIS SWITCH (never on in the parity tests): a literal fp32 reading of the window loops of data.vert:139-141 and
  * copy_unstable.vert:85-86, `for (i = c - 2s; i < c + 2s; i += s)` with an fp32 induction variable.  In exact arithmetic the loop
  * makes 4 steps; in fp32 it makes 4 or 5 depending on the rounding of c.  With the switch on, the taps are the
- * values the fp32 loop visits and a tap's texel is floor(i * size) -- one plausible GPU behaviour, used only to measure how much
+ * values the fp32 loop visits and a tap's texel is floor(snap_1/256(i * size)) -- the texel rule of oracle/glsl_shim/mfgl.h, under which
+ * the reference's own shader text (oracle/_ref/libmf_glsl.so) makes exactly these decisions (tests/test_glsl_pin.py), used only to measure how much
  * the ambiguity matters (tools/window_ambiguity.py). */
 static int g_window_literal = 0;
 void mfo_set_window_literal(int on) { g_window_literal = on; }
@@ -1181,7 +1190,7 @@ static int window_taps_literal(float c, float size, int* texels) {
     const float end = c + half;
     int n = 0;
     for (float i = c - half; i < end && n < 8; i += step) {
-        int t = (int)floorf(i * size);
+        int t = (int)floorf(rintf(i * size * 256.0f) * (1.0f / 256.0f));   /* texel of a normalised coordinate: 1/256 fixed-point snap, then floor */
         t = t < 0 ? 0 : (t > (int)size - 1 ? (int)size - 1 : t);
         texels[n++] = t;
     }

@@ -6,15 +6,21 @@
  * leg use it, and only as the checker / the timed CPU baseline.
  *
  * PARITY PIN: the reference (martinruenz/maskfusion) ships no tests, golden vectors or fixtures for this path and its
- * build (CUDA + OpenGL 4.3 + Pangolin + OpenCV + Eigen) cannot run here.  Two halves:
+ * build (CUDA + OpenGL 4.3 + Pangolin + OpenCV + Eigen) cannot run here.  Three parts:
  *   - everything restated from Core/Cuda/{reduce,cudafuncs,segmentation}.cu (rows a3-a5, a7-a10, a12 and the device half
  *     of a20 in SURVEY.md section 8) IS pinned: oracle/build_ref.py compiles those translation units for the CPU
  *     (oracle/_ref/libmf_ref.so), tests/golden/ref_vectors.npz holds their outputs on seeded inputs, and
  *     tests/test_ref_pin.py requires this file to reproduce them (bit-exact for integer / per-pixel float results,
  *     1e-5 for reduced sums whose summation order is a launch-shape detail);
- *   - everything restated from GLSL shaders, the OpenGL rasteriser, Eigen and OpenCV (a2, a6, a11, a13-a19, a21 and the
- *     host half of a20) is PARITY UNPINNED: it follows the cited source line by line and is pinned only by analytic
- *     known-answer tests (tests/test_oracle_kat.py, tests/test_oracle_rgbd_kat.py).
+ *   - everything restated from GLSL shaders (a2, a13-a19, a21) IS pinned to the shaders' own text: oracle/build_glsl.py compiles
+ *     Core/Shaders/*.vert / *.frag as C++ (oracle/_ref/libmf_glsl.so, mechanical edits only), tests/golden/glsl_vectors.npz holds
+ *     what they compute on seeded inputs and tests/test_glsl_pin.py requires this file to reproduce it -- bit-exact for every pass
+ *     (the clean pass in the literal window mode, see mfo_set_window_literal).  What OpenGL does AROUND a shader (texel selection,
+ *     point / sprite coverage, depth test) is a documented rule set, not reference-executed;
+ *   - the host-side arithmetic inside absent third-party libraries -- Eigen (LDLT, JacobiSVD, Quaternion: a6, a11, a15) and OpenCV
+ *     (connected components, morphology: host half of a20) -- is PARITY UNPINNED by reference-executed code: restated from the
+ *     published algorithms and checked by analytic known-answer tests (tests/test_oracle_kat.py, tests/test_oracle_rgbd_kat.py)
+ *     and against numpy / SciPy.
  * Citations are relative to /root/reference/.
  *
  * Conventions
@@ -65,6 +71,8 @@ void mfo_icp_step(const float* Rcurr, const float* tcurr,
                   const float* vmap_g_prev, const float* nmap_g_prev,
                   float distThres, float angleThres, int W, int H,
                   float* A, float* b, float* residual);
+/* pose.inverse() as every projection pass consumes it (t_inv uniform); column-major 4x4 */
+void mfo_pose_inverse16(const float* pose16, float* out16);
 /* ANALYSIS ONLY (tools/window_ambiguity.py): literal fp32 reading of the association / clean window loops; see mf_oracle.c */
 void mfo_set_window_literal(int on);
 /* Eigen LDLT stand-in (RGBDOdometry.cpp:447-459): symmetric solve in double, n = 3 or 6.
