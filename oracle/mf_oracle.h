@@ -13,7 +13,7 @@
  *     tests/test_ref_pin.py requires this file to reproduce them (bit-exact for integer / per-pixel float results,
  *     1e-5 for reduced sums whose summation order is a launch-shape detail);
  *   - everything restated from GLSL shaders (a2, a13-a19, a21) IS pinned to the shaders' own text: oracle/build_glsl.py compiles
- *     Core/Shaders/*.vert / *.frag as C++ (oracle/_ref/libmf_glsl.so, mechanical edits only), tests/golden/glsl_vectors.npz holds
+ *     the .vert and .frag files of Core/Shaders as C++ (oracle/_ref/libmf_glsl.so, mechanical edits only), tests/golden/glsl_vectors.npz holds
  *     what they compute on seeded inputs and tests/test_glsl_pin.py requires this file to reproduce it -- bit-exact for every pass
  *     (the clean pass in the literal window mode, see mfo_set_window_literal).  What OpenGL does AROUND a shader (texel selection,
  *     point / sprite coverage, depth test) is a documented rule set, not reference-executed;
