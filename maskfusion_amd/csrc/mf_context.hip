@@ -122,6 +122,7 @@ struct mf_ctx {
                                        // ahead under the latency-bound Gauss-Newton loop of the previous frame
     hipEvent_t ev_pre_done[2] = {nullptr, nullptr};    // preprocessing of frame k finished      (pre -> main)
     hipEvent_t ev_main_done[2] = {nullptr, nullptr};   // frame k finished tracking (so k-1 is complete)  (main -> pre)
+    bool clean_literal = true;                         // Model::clean walks its window with the shader text's fp32 trip count ("cleanLiteralWindow")
     bool global_tiles = true;                          // A/B + test knob ("globalTiles"): 0 = every model through k_global_scatter
     bool early_bg_fusion = true;                       // A/B knob ("earlyBackgroundFusion"): 0 = the host visit drains the stream
     hipEvent_t ev_labels = nullptr;                    // the label stage of this frame has written its result words
@@ -613,7 +614,7 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
     }
     launch_clean(m.surf[dst], m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.time_delta, m.confThr, g.outlier_coefficient, m.id,
                  c->d_index, c->d_ivc, c->d_ict, secondIndexPass ? c->d_iclean : nullptr, depthF, mask, c->d_cand_op, c->d_cand_rec, c->d_flags, c->d_newconf,
-                 c->d_block_counts, m.h_count, secondIndexPass, s);
+                 c->d_block_counts, m.h_count, secondIndexPass, c->clean_literal, s);
     // two swaps (fuse, clean) leave the live buffer where it started
 }
 
@@ -1162,7 +1163,7 @@ extern "C" int mf_model_clean(mf_ctx* c, int32_t model, int32_t time, int32_t ti
     const bool packed = c->model_api_packed != 0;
     launch_clean(m->surf[src], m->surf[dst], m->d_frame, m->d_pose, c->W, c->H, c->K, time_delta, m->confThr, c->cfg.outlier_coefficient, m->id,
                  c->d_index, c->d_ivc, c->d_ict, packed ? c->d_iclean : nullptr, c->d_depthF[k % 3], current_mask(c), c->d_cand_op, c->d_cand_rec,
-                 c->d_flags, c->d_newconf, c->d_block_counts, m->h_count, packed, c->stream);
+                 c->d_flags, c->d_newconf, c->d_block_counts, m->h_count, packed, c->clean_literal, c->stream);
     m->cur = dst;
     return check_launch(c);
 }
@@ -1656,6 +1657,7 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     }
     if (!strcmp(key, "batchTracking")) { c->batch_tracking = value != 0; return MF_OK; }
     if (!strcmp(key, "globalTiles")) { c->global_tiles = value != 0; return MF_OK; }
+    if (!strcmp(key, "cleanLiteralWindow")) { c->clean_literal = value != 0; return MF_OK; }   // 0: the exact-arithmetic 4 x 4 window
     if (!strcmp(key, "earlyBackgroundFusion")) { c->early_bg_fusion = value != 0; return MF_OK; }
     if (!strcmp(key, "modelApiPackedIndex")) { c->model_api_packed = value != 0; return MF_OK; }   // 0: scatter + resolve form (specification)
     if (!strcmp(key, "overlapPreprocessing")) {

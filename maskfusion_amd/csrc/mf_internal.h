@@ -197,7 +197,8 @@ void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose
                   int timeDelta, float confThreshold, float outlierCoeff, int maskID, const int* index,
                   const float4* vc, const float4* ct, const float4* packed /*or null*/, const float* depthF, const uint8_t* mask,
                   const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags, float* newconf, int* block_counts,
-                  int* host_count_mirror, bool transposed /*layout of index/vc/ct*/, hipStream_t s);
+                  int* host_count_mirror, bool transposed /*layout of index/vc/ct*/, bool literalWindow /*fp32 trip count of the shader*/,
+                  hipStream_t s);
 // generic ordered compaction of [n_dev] records (3 x float4 each, record-major) -> surfels, sets frame->count
 void launch_compact_records(const float4* rec, const uint8_t* flags, int n, Surfels dst, FrameDev* frame,
                             int* block_counts, int* host_count_mirror, hipStream_t s);

@@ -399,12 +399,38 @@ void launch_fuse_update(Surfels src, Surfels dst, const FrameDev* frame, int* up
 struct CleanArgs {
     Surfels src, dst; FrameDev* frame; const PoseDev* pose; int W, H; Intr k;
     int timeDelta; float confThreshold; float outlierCoeff; int maskID; int transposed;
+    int literal;   // 1: the window is walked with copy_unstable.vert's own fp32 induction variable (4 or 5 steps per axis), 0: 4 x 4
     const int* index; const float4* vc; const float4* ct;   // separate images (only when the packed map is absent)
     const float4* packed;                                    // {vertConf | initTime, lastTime, index, 0} per texel
     const float* depthF; const uint8_t* mask;
     const uint8_t* cand_op; const float4* cand_rec;
     uint8_t* flags; float* newconf; int* block_counts; int* host_count;
 };
+
+// The window of copy_unstable.vert:85-86 along one axis, exactly as the shader text walks it: `for (i = c - 2s; i < c + 2s; i += s)` on an
+// fp32 induction variable makes 4 steps in exact arithmetic and 4 OR 5 in fp32, depending on the rounding of the centre c (27 % of
+// the x positions at 640 columns make 5); every step is a tap that COUNTS towards `count > 8` / `zCount > 4`.  A tap's texel is the
+// floor of its coordinate snapped to 1/256 texel -- the rule under which the reference's own shader, compiled from its source
+// (oracle/_ref/libmf_glsl.so), was executed and the CPU restatement's literal mode was checked against it bit for bit.  The taps
+// are monotone and span two pixels: at most three distinct texels u[] with multiplicities m[] (an unused slot has m = 0).
+__device__ __forceinline__ void window_slots_literal(float c, int size, int (&u)[3], int (&m)[3]) {
+    const float fs = (float)size;
+    const float step = (1.0f / (fs * 1.0f)) * 0.5f;     // indexXStep = stepX * 0.5 / scale, scale = FACTOR = 1
+    const float half = (1.0f * step) * 2.0f;            // scale * indexXStep * windowMultiplier
+    const float end = c + half;
+    u[0] = u[1] = u[2] = 0; m[0] = m[1] = m[2] = 0;
+    int s = -1, last = -1;                               // texels are >= 0 after the clamp
+    float i = c - half;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        if (i < end) {
+            const int t = clampi((int)floorf(rintf(i * fs * 256.0f) * (1.0f / 256.0f)), 0, size - 1);
+            if (t != last) { s = min(s + 1, 2); u[s] = t; last = t; }
+            m[s] += 1;
+        }
+        i += step;
+    }
+}
 
 __device__ __forceinline__ bool clean_test(const CleanArgs& a, float4 pc, float4 ct, float4 nr, float time, const float* Ri,
                                            float3 ti, float& newconf) {
@@ -425,10 +451,14 @@ __device__ __forceinline__ bool clean_test(const CleanArgs& a, float4 pc, float4
         tys[0] = clampi((int)floorf(y - 1.0f), 0, H - 1); tys[1] = clampi((int)floorf(y - 0.5f), 0, H - 1);
         tys[2] = clampi((int)floorf(y), 0, H - 1);        tys[3] = clampi((int)floorf(y + 0.5f), 0, H - 1);
         // the four fetches are monotone: t0 <= t1 <= t2 <= t3 and t1 is t0 or t2 -> three static slots {t0, t2, t3}
-        const int ux[3] = {txs[0], txs[2], txs[3]};
-        const int mx[3] = {1 + (txs[1] == txs[0]), 1 + (txs[1] != txs[0]) + (txs[3] == txs[2]), (txs[3] != txs[2]) ? 1 : 0};
-        const int uy[3] = {tys[0], tys[2], tys[3]};
-        const int my[3] = {1 + (tys[1] == tys[0]), 1 + (tys[1] != tys[0]) + (tys[3] == tys[2]), (tys[3] != tys[2]) ? 1 : 0};
+        int ux[3] = {txs[0], txs[2], txs[3]};
+        int mx[3] = {1 + (txs[1] == txs[0]), 1 + (txs[1] != txs[0]) + (txs[3] == txs[2]), (txs[3] != txs[2]) ? 1 : 0};
+        int uy[3] = {tys[0], tys[2], tys[3]};
+        int my[3] = {1 + (tys[1] == tys[0]), 1 + (tys[1] != tys[0]) + (tys[3] == tys[2]), (tys[3] != tys[2]) ? 1 : 0};
+        if (a.literal) {   // the shader text's own trip count (see window_slots_literal)
+            window_slots_literal(x / (float)W, W, ux, mx);
+            window_slots_literal(y / (float)H, H, uy, my);
+        }
 #pragma unroll
         for (int ia = 0; ia < 3; ++ia) {
 #pragma unroll
@@ -701,9 +731,10 @@ void launch_frame_advance(FrameDev* frame, int W, int H, FrameDev* host_mirror, 
 void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, int timeDelta,
                   float confThreshold, float outlierCoeff, int maskID, const int* index, const float4* vc, const float4* ct,
                   const float4* packed, const float* depthF, const uint8_t* mask, const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags,
-                  float* newconf, int* block_counts, int* host_count_mirror, bool transposed, hipStream_t s) {
+                  float* newconf, int* block_counts, int* host_count_mirror, bool transposed, bool literalWindow, hipStream_t s) {
     CleanArgs a;
     a.transposed = transposed ? 1 : 0;
+    a.literal = literalWindow ? 1 : 0;
     a.src = src; a.dst = dst; a.frame = frame; a.pose = pose; a.W = W; a.H = H; a.k = k; a.timeDelta = timeDelta;
     a.confThreshold = confThreshold; a.outlierCoeff = outlierCoeff; a.maskID = maskID; a.index = index; a.vc = vc; a.ct = ct;
     a.packed = packed;

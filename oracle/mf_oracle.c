@@ -1183,6 +1183,11 @@ static const int kWinPix[4] = {-1, 0, 0, 1};
  * the ambiguity matters (tools/window_ambiguity.py). */
 static int g_window_literal = 0;
 void mfo_set_window_literal(int on) { g_window_literal = on; }
+/* The clean pass (copy_unstable.vert) DEFAULTS to the literal reading: there every tap counts, the reference's shader text compiled
+ * from its source makes exactly these decisions (tests/test_glsl_pin.py), and the device kernel implements the same
+ * (window_slots_literal in mf_surfel.hip).  mfo_set_clean_literal(0) selects the exact-arithmetic 4 x 4 window (round-1 behaviour). */
+static int g_clean_literal = 1;
+void mfo_set_clean_literal(int on) { g_clean_literal = on; }
 /* taps of one axis: centre coordinate c (normalised), size = cols or rows; returns the number of taps (<= 8) */
 static int window_taps_literal(float c, float size, int* texels) {
     const float step = (1.0f / (size * 1.0f)) * 0.5f;          /* indexXStep, scale = FACTOR = 1 */
@@ -1342,7 +1347,7 @@ static int clean_one(const mfo_cam* c, const float* Ri, const float* ti, const f
         static const float off[4] = {-1.0f, -0.5f, 0.0f, 0.5f};
         int wx[8], wy[8], nwx = 4, nwy = 4;
         for (int a = 0; a < 4; ++a) { wx[a] = iclamp((int)floorf(x + off[a]), 0, W - 1); wy[a] = iclamp((int)floorf(y + off[a]), 0, H - 1); }
-        if (g_window_literal) { nwx = window_taps_literal(x / (float)W, (float)W, wx); nwy = window_taps_literal(y / (float)H, (float)H, wy); }
+        if (g_window_literal || g_clean_literal) { nwx = window_taps_literal(x / (float)W, (float)W, wx); nwy = window_taps_literal(y / (float)H, (float)H, wy); }
         for (int a = 0; a < nwx; ++a) {
             for (int b = 0; b < nwy; ++b) {
                 const int tx = wx[a], ty = wy[b];

@@ -75,6 +75,8 @@ void mfo_icp_step(const float* Rcurr, const float* tcurr,
 void mfo_pose_inverse16(const float* pose16, float* out16);
 /* ANALYSIS ONLY (tools/window_ambiguity.py): literal fp32 reading of the association / clean window loops; see mf_oracle.c */
 void mfo_set_window_literal(int on);
+/* clean pass only, default ON: the window of copy_unstable.vert with the shader text's fp32 trip count (4 or 5 taps per axis) */
+void mfo_set_clean_literal(int on);
 /* Eigen LDLT stand-in (RGBDOdometry.cpp:447-459): symmetric solve in double, n = 3 or 6.
  * Returns 0 on success. */
 int mfo_ldlt_solve(const double* A, const double* b, double* x, int n);

@@ -147,7 +147,7 @@ def test_pipeline_1280x960(hip, oracle):
         mf.processFrame(fr[k][0], fr[k][1])
         assert np.abs(o.pose - mf.getCurrPose()).max() < 1e-4, k
         assert abs(o.count - mf.getBackgroundModel().lastCount()) <= max(20, 0.005 * o.count), k
-    assert o.count > 1_000_000
+    assert o.count > 900_000
     o.close(); mf.close()
 
 
@@ -208,7 +208,7 @@ def test_fused_cloud_matches_oracle_with_given_poses(hip, oracle, res, noise):
             assert np.array_equal(ok, np.isfinite(a[:, 8:]).all(1))
             assert np.abs(a[ok, 8:] - b[ok, 8:]).max() <= 1e-6, k
     print("counts (hip, oracle)", counts[-3:])
-    assert counts[-1][1] > (300_000 if W == 640 else 1_000_000)
+    assert counts[-1][1] > (250_000 if W == 640 else 900_000)     # a populated map (the literal clean window trims ~2 % over 25 frames)
 
 
 @pytest.mark.parametrize("noise", [False, True], ids=["clean", "noisy"])

@@ -1,8 +1,8 @@
 """How much does the fp32 trip count of the association / clean window loops matter?  (CPU only, oracle only.)
 
 data.vert:139-141 and copy_unstable.vert:85-86 walk their 4x4 half-pixel window with an fp32 induction variable; in exact
-arithmetic that is 4 steps per axis, in fp32 it is 4 or 5 depending on the rounding of the centre coordinate.  The parity tests
-(and the device) use the exact-arithmetic reading.  This tool fuses the same synthetic stream with the camera poses GIVEN (so only
+arithmetic that is 4 steps per axis, in fp32 it is 4 or 5 depending on the rounding of the centre coordinate.  Round 1 used the
+exact-arithmetic reading on both sides; since round 2 the clean pass (where every tap counts) uses the literal one, oracle and device.  This tool fuses the same synthetic stream with the camera poses GIVEN (so only
 the surfel life cycle differs) under both readings and reports what changes."""
 import os
 import sys
@@ -21,6 +21,7 @@ L = mfo.lib()
 out = {}
 for literal in (0, 1):
     L.mfo_set_window_literal(literal)
+    L.mfo_set_clean_literal(literal)
     o = mfo.Oracle(W, H, F, F, W / 2.0, H / 2.0, icpWeight=100.0, capacity=1 << 20, so3=0, confGlobal=2.0)
     counts = []
     for k, (rgb, depth, _) in enumerate(frames):
@@ -30,6 +31,7 @@ for literal in (0, 1):
     out[literal] = dict(counts=counts, stable=int((s[:, 3] > 2.0).sum()), conf=float(s[:, 3].mean()))
     o.close()
 L.mfo_set_window_literal(0)
+L.mfo_set_clean_literal(1)
 a, b = out[0], out[1]
 print("frames", N)
 print("exact-arithmetic window (4x4 taps):     surfels", a["counts"][-1], "stable (conf > 2)", a["stable"], "mean confidence %.3f" % a["conf"])
