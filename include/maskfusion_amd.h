@@ -147,7 +147,12 @@ int mf_get_last_fillin(mf_ctx* ctx, int32_t* used);
  * "maxDepthProcessed", "enableMultipleModels", "trackAllModels", "modelSpawnOffset",
  * "newModelMinRelativeSize", "newModelMaxRelativeSize" (SegmentationPerformer.h:36-37) and the MfSegmentation tunables
  * (MaskFusion.h:234-263 / MfSegmentation.h:42-62): "mfThreshold", "mfWeightDistance", "mfWeightConvexity",
- * "mfMorphEdgeIterations", "mfMorphEdgeRadius", "mfMorphMaskIterations", "mfMorphMaskRadius". */
+ * "mfMorphEdgeIterations", "mfMorphEdgeRadius", "mfMorphMaskIterations", "mfMorphMaskRadius".
+ * Implementation switches (defaults are the product; the alternatives exist for A/B measurements and as executable specifications):
+ * "splatTiles" (1), "globalTiles" (1: GlobalProjection of the background through tile lists), "gpuLabels" (1: label stage on the
+ * device), "batchTracking" (1: one Gauss-Newton launch serves every tracked model), "earlyBackgroundFusion" (1), "overlapPreprocessing"
+ * (0), "cleanLiteralWindow" (1: Model::clean walks its window with copy_unstable.vert's own fp32 trip count, 4 or 5 taps per axis;
+ * 0: 4 x 4), "timings", "icpProfile". */
 int mf_set_param(mf_ctx* ctx, const char* key, double value);
 int mf_get_param(mf_ctx* ctx, const char* key, double* value);
 
