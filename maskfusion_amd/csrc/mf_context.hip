@@ -1530,17 +1530,18 @@ extern "C" int mf_download_segmentation(mf_ctx* c, uint8_t* out) {
 // cv::imwrite(exportDir + "Segmentation<tick>.png").  An 8-bit greyscale PNG with stored (uncompressed) deflate blocks: any
 // reader decodes it to the same pixels as OpenCV's file.
 static uint32_t png_crc(uint32_t crc, const uint8_t* p, size_t n) {
-    static uint32_t table[256];
-    static bool init = false;
-    if (!init) {
-        for (uint32_t i = 0; i < 256; ++i) {
-            uint32_t v = i;
-            for (int k = 0; k < 8; ++k) v = (v & 1) ? 0xEDB88320u ^ (v >> 1) : v >> 1;
-            table[i] = v;
+    struct Table {
+        uint32_t t[256];
+        Table() {
+            for (uint32_t i = 0; i < 256; ++i) {
+                uint32_t v = i;
+                for (int k = 0; k < 8; ++k) v = (v & 1) ? 0xEDB88320u ^ (v >> 1) : v >> 1;
+                t[i] = v;
+            }
         }
-        init = true;
-    }
-    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 255] ^ (crc >> 8);
+    };
+    static const Table table;   // initialised once, thread-safely (contexts of different threads may export at the same time)
+    for (size_t i = 0; i < n; ++i) crc = table.t[(crc ^ p[i]) & 255] ^ (crc >> 8);
     return crc;
 }
 static void png_chunk(std::vector<uint8_t>& f, const char* tag, const std::vector<uint8_t>& body) {
