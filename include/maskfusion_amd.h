@@ -139,6 +139,8 @@ int mf_download_segmentation(mf_ctx* ctx, uint8_t* out);
 /* The exportSegmentation branch of processFrame (Core/MaskFusion.cpp:299-303): the label image of the last frame with 255 (ignored)
  * zeroed, as an 8-bit greyscale PNG at `path` (upstream: exportDir + "Segmentation<tick>.png") */
 int mf_export_segmentation_png(mf_ctx* ctx, const char* path);
+/* The cv::imwrite(<name>.png, CV_8UC1) of that branch on its own: H*W bytes -> 8-bit greyscale PNG.  HOST pointer, no GPU involved. */
+int mf_write_png_gray8(const char* path, const uint8_t* img, int32_t width, int32_t height);
 /* whether the last tracking step used the fill-in maps (MaskFusion::requiresFillIn, MaskFusion.cpp:630-648) */
 int mf_get_last_fillin(mf_ctx* ctx, int32_t* used);
 

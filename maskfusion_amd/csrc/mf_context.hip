@@ -1552,17 +1552,14 @@ static void png_chunk(std::vector<uint8_t>& f, const char* tag, const std::vecto
     f.insert(f.end(), body.begin(), body.end());
     be32(png_crc(0xFFFFFFFFu, f.data() + at, f.size() - at) ^ 0xFFFFFFFFu);
 }
-extern "C" int mf_export_segmentation_png(mf_ctx* c, const char* path) {
-    if (!c || !path) return MF_EINVAL;
-    std::vector<uint8_t> img((size_t)c->P);
-    int rc = mf_download_segmentation(c, img.data());
-    if (rc != MF_OK) return rc;
-    const int W = c->W, H = c->H;
+// cv::imwrite(path, CV_8UC1 image) stand-in: 8-bit greyscale PNG, stored deflate blocks.  HOST pointers, no GPU involved.
+extern "C" int mf_write_png_gray8(const char* path, const uint8_t* img, int32_t W, int32_t H) {
+    if (!path || !img || W <= 0 || H <= 0) return MF_EINVAL;
     std::vector<uint8_t> raw;   // filter byte 0 + row
     raw.reserve((size_t)(W + 1) * H);
     for (int y = 0; y < H; ++y) {
         raw.push_back(0);
-        for (int x = 0; x < W; ++x) { const uint8_t v = img[(size_t)y * W + x]; raw.push_back(v > 254 ? 0 : v); }
+        raw.insert(raw.end(), img + (size_t)y * W, img + (size_t)(y + 1) * W);
     }
     std::vector<uint8_t> z = {0x78, 0x01};
     uint32_t a = 1, b = 0;
@@ -1584,11 +1581,20 @@ extern "C" int mf_export_segmentation_png(mf_ctx* c, const char* path) {
     png_chunk(f, "IDAT", z);
     png_chunk(f, "IEND", {});
     FILE* fp = fopen(path, "wb");
-    if (!fp) { c->err = std::string("cannot write ") + path; return MF_EINVAL; }
+    if (!fp) return MF_EINVAL;
     const bool ok = fwrite(f.data(), 1, f.size(), fp) == f.size();
     fclose(fp);
-    if (!ok) { c->err = std::string("short write to ") + path; return MF_EINVAL; }
-    return MF_OK;
+    return ok ? MF_OK : MF_EINVAL;
+}
+extern "C" int mf_export_segmentation_png(mf_ctx* c, const char* path) {
+    if (!c || !path) return MF_EINVAL;
+    std::vector<uint8_t> img((size_t)c->P);
+    int rc = mf_download_segmentation(c, img.data());
+    if (rc != MF_OK) return rc;
+    for (auto& v : img) v = v > 254 ? 0 : v;   // cv::threshold(..., 254, 255, THRESH_TOZERO_INV): 255 (ignored) -> 0
+    rc = mf_write_png_gray8(path, img.data(), c->W, c->H);
+    if (rc != MF_OK) c->err = std::string("cannot write ") + path;
+    return rc;
 }
 
 extern "C" int mf_download_map(mf_ctx* c, int32_t model, float* out, uint32_t max_count, uint32_t* count) {

@@ -73,6 +73,7 @@ SYMBOLS = {
     "mf_model_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "mf_download_segmentation": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mf_export_segmentation_png": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "mf_write_png_gray8": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]),
     "mf_segmentation_labels": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

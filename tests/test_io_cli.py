@@ -155,3 +155,18 @@ def test_trackable_classes_from_config_toml(tmp_path):
     cfg.write_text('[MaskRCNN]\nclass_names = ["BG", "person", "bicycle", "teddy bear", "bottle"]\ntrackable_classes = ["teddy bear", "bottle"]\n')
     assert cli.trackable_class_ids(str(cfg)) == [3, 4]
     assert cli.trackable_class_ids(str(tmp_path / "missing.toml")) is None
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (7, 5), (300, 333)])
+def test_png_writer_round_trip(tmp_path, shape):
+    """mf_write_png_gray8 (what exportSegmentation writes, Core/MaskFusion.cpp:299-303): any PNG reader gets the same pixels back; rows
+    longer than one stored-deflate block (65 535 B) and odd sizes included.  Host code: runs without a GPU."""
+    from PIL import Image
+    from maskfusion_amd.lib import load
+    rng = np.random.default_rng(shape[0])
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    path = str(tmp_path / "seg.png")
+    assert load().mf_write_png_gray8(path.encode(), img.ctypes.data, shape[1], shape[0]) == 0
+    back = np.asarray(Image.open(path))
+    assert back.dtype == np.uint8 and np.array_equal(back, img)
+    assert load().mf_write_png_gray8(str(tmp_path / "no" / "dir.png").encode(), img.ctypes.data, shape[1], shape[0]) != 0
