@@ -1,0 +1,124 @@
+"""-m gpu: every surfel pass of Model on the device against the REFERENCE'S OWN SHADERS (oracle/_ref/libmf_glsl.so: Core/Shaders/*.vert /
+*.frag compiled as C++ by oracle/build_glsl.py; the prebuilt library travels to the GPU box), through the Model-level C ABI -- the
+direct form of what tests/test_gpu_surfel_passes.py (device == oracle) and tests/test_glsl_pin.py (oracle == shader text) establish
+together.  Same construction as test_gpu_surfel_passes.py: the oracle builds a 9-frame map, the device gets that map and pose, then
+each pass runs once on the device and once through the compiled shaders ON THE SAME INPUTS (the shader side is fed the device's own
+intermediate buffers, so every pass is compared in isolation).
+
+  pass                      compared                                                   gate
+  index_map.vert/.frag      index image                                                <= 1e-4 of the pixels differ (points within ~1e-5 px of
+                                                                                       a pixel border: the rasteriser's business)
+  data.vert                 operation per quarter-rate pixel, colour / time stamps      exact;  positions 1e-6, normals 1e-4 (uv-buffer rounding, F2)
+  update.vert               every updated surfel                                       1e-6
+  copy_unstable.vert        surviving count, every survivor                            exact count, 1e-6
+  splat.vert + combo_splat  winning fragment per pixel                                 <= 1e-4 of the pixels differ, the others 1e-6
+
+Written after this round's GPU budget was spent: not yet run on hardware, hence xfail(strict=False) -- it cannot break the suite, and
+an XPASS at the round-end run is the evidence.  (Both halves of the transitive argument ARE green: device == oracle on the GPU,
+oracle == shader text on the CPU at this very resolution.)"""
+import numpy as np
+import pytest
+
+from gpu_util import scene_frames
+
+pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="added after the round's GPU budget was spent; first hardware run pending")]
+
+N_WARM, CONF, TIME_DELTA, DEPTH_CUT, MAXD, OUTLIER = 9, 1.0, 200, 3.0, 20.0, 0.9
+W, H = 640, 480
+
+
+def _maxerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    fin = np.isfinite(a) & np.isfinite(b)
+    return float(np.abs(a[fin] - b[fin]).max()) if fin.any() else 0.0
+
+
+def test_device_passes_against_compiled_shaders(hip, oracle):
+    from maskfusion_amd import MaskFusion
+    from oracle import mfglsl
+    if not mfglsl.available():
+        pytest.skip("oracle/_ref/libmf_glsl.so is not here (built by __graft_entry__.build() where /root/reference exists)")
+    st, frames = scene_frames(N_WARM + 1, W=W, H=H, noise=True)
+    K = (st.fx, st.fy, st.cx, st.cy)
+    cap = 1 << 20
+    o = oracle.Oracle(W, H, *K, icpWeight=100.0, capacity=cap, so3=0, confGlobal=CONF, timeDelta=TIME_DELTA, depthCutoff=DEPTH_CUT, outlierCoeff=OUTLIER)
+    poses = []
+    for k in range(N_WARM):
+        o.process_frame(frames[k][0], frames[k][1])
+        poses.append(o.pose)
+    S, n, t = o.surfels()[:o.count].copy(), o.count, o.tick
+    o.close()
+    T = np.asarray(poses[-1], np.float32)
+    mf = MaskFusion(W, H, *K, icpThresh=100.0, so3=False, numGSurfels=cap, enableMultipleModels=False, initConfidenceGlobal=CONF,
+                    timeDelta=TIME_DELTA, depthCut=DEPTH_CUT, outlierCoefficient=OUTLIER)
+    try:
+        bg = mf.getBackgroundModel()
+        bg.uploadMap(S)
+        bg.overridePose(poses[-1]); bg.overridePose(poses[-1])       # pose == lastPose: fusion weight = the multiplier
+        mf.setTick(t)
+        rgb, depth, _ = frames[N_WARM]
+        mask = np.zeros((H, W), np.uint8)
+        mf.stageFrame(rgb, depth)
+        dF = mf.debugRead("depthF")                                    # the device's filtered depth feeds both sides
+        P = W * H
+
+        # ---- index map ----
+        bg.predictIndices(t, MAXD, TIME_DELTA)
+        g_idx, g_vc, g_nr, g_ct = mf.debugRead("index"), mf.debugRead("index_vc"), mf.debugRead("index_nr"), mf.debugRead("index_ct")
+        s_idx, s_vc, s_ct, s_nr = mfglsl.predict_indices(T, S, t, MAXD, TIME_DELTA, W, H, K)
+        moved = int((g_idx != s_idx).sum())
+        print("index map: filled", int((s_idx > 0).sum()), "pixels whose winner differs", moved)
+        assert moved <= 1e-4 * P
+        same = g_idx == s_idx
+        assert _maxerr(g_vc[same], s_vc[same]) <= 1e-6 and _maxerr(g_nr[same], s_nr[same]) <= 1e-6
+        assert np.array_equal(g_ct[same], s_ct[same])
+
+        # ---- data association: the shader side reads the DEVICE's index map ----
+        bg.fuse(t, DEPTH_CUT, 1.0)
+        par = t & 1
+        nxc, nyc = (W - par + 1) // 2, (H - par + 1) // 2
+        nc = nxc * nyc
+        g_op, g_rec = mf.debugRead("cand_op", count=nc), mf.debugRead("cand_rec", count=nc)
+        s_op, s_best, s_rec = mfglsl.fuse_data(T, rgb, depth, dF, mask, 0, t, 1.0, DEPTH_CUT, K, g_idx, g_vc, g_ct, g_nr)
+        xi, yi = np.meshgrid(np.arange(nxc), np.arange(nyc), indexing="ij")
+        kp = ((2 * xi + par) * H + (2 * yi + par)).reshape(-1)        # uv-buffer position of candidate c = xi * nyc + yi
+        flips = int((g_op != s_op[kp]).sum())
+        print("candidates", nc, "ops", np.bincount(g_op, minlength=3).tolist(), "op flips vs the shader", flips)
+        assert flips == 0 and not np.delete(s_op, kp).any()
+        live = g_op > 0
+        assert np.array_equal(g_rec[live][:, 4:8], s_rec[kp][live][:, 4:8])
+        assert _maxerr(g_rec[live][:, :4], s_rec[kp][live][:, :4]) <= 1e-6
+        assert _maxerr(g_rec[live][:, 8:], s_rec[kp][live][:, 8:]) <= 1e-4
+
+        # ---- update: the shader side gets the device's records and the SHADER's surfel choice (identical decisions were asserted) ----
+        g_S2 = bg.downloadMap()
+        op_p, best_p, rec_p = np.zeros(P, np.uint8), np.zeros(P, np.int32), np.zeros((P, 12), np.float32)
+        op_p[kp], best_p[kp], rec_p[kp] = g_op, s_best[kp], g_rec
+        s_S2 = mfglsl.fuse_update(S, t, op_p, best_p, rec_p)
+        assert len(g_S2) == n
+        assert np.array_equal(g_S2[:, 5:8], s_S2[:, 5:8])
+        assert _maxerr(g_S2[:, :4], s_S2[:, :4]) <= 1e-6 and _maxerr(g_S2[:, 8:], s_S2[:, 8:]) <= 1e-6
+        dcol = np.abs(g_S2[:, 4].astype(np.int64) - s_S2[:, 4].astype(np.int64))
+        assert ((dcol != 0).sum()) <= 1e-4 * n                          # re-encoded rounded mean colour: a .5 tie per 10 000 at most
+
+        # ---- second index pass + clean: both sides on the device's updated buffer and the device's index images ----
+        bg.predictIndices(t, MAXD, TIME_DELTA)
+        i2, vc2, nr2, ct2 = mf.debugRead("index"), mf.debugRead("index_vc"), mf.debugRead("index_nr"), mf.debugRead("index_ct")
+        bg.clean(t, TIME_DELTA, MAXD)
+        g_S3 = bg.downloadMap()
+        s_S3, _ = mfglsl.clean(T, g_S2, op_p, rec_p, t, TIME_DELTA, CONF, MAXD, OUTLIER, 0, K, i2, vc2, ct2, nr2, dF, mask)
+        print("clean: in", n, "+", int((g_op == 2).sum()), "new -> out shader", len(s_S3), "device", len(g_S3))
+        assert len(g_S3) == len(s_S3)
+        assert np.array_equal(g_S3[:, 4:8], s_S3[:, 4:8])
+        assert _maxerr(g_S3[:, :4], s_S3[:, :4]) <= 1e-6
+
+        # ---- splat prediction of the cleaned map ----
+        bg.combinedPredict(MAXD, t, t, TIME_DELTA)
+        g_pv, g_pn, g_img, g_pt = bg.debugRead("pred_vertex"), bg.debugRead("pred_normal"), bg.debugRead("pred_image"), bg.debugRead("pred_time")
+        s_img, s_pv, s_pn, s_pt = mfglsl.combined_predict(T, g_S3, MAXD, CONF, t, t, TIME_DELTA, W, H, K)
+        off = (g_pt != s_pt) | (g_img != s_img).any(-1) | ((g_pv[..., 2] > 0) != (s_pv[..., 2] > 0))
+        print("splat: coverage", float((s_pv[..., 2] > 0).mean()), "pixels whose fragment differs", int(off.sum()))
+        assert (s_pv[..., 2] > 0).mean() > 0.2 and off.sum() <= 1e-4 * P
+        assert _maxerr(g_pv[~off], s_pv[~off]) <= 1e-5 and _maxerr(g_pn[~off], s_pn[~off]) <= 1e-5
+    finally:
+        mf.close()
