@@ -2027,6 +2027,15 @@ static void morph_gray(const uint8_t* in, uint8_t* out, int W, int H, int r, int
         }
 }
 
+/* cv::morphologyEx(img, img, MORPH_CLOSE, ellipse(2r+1), Point(-1,-1), iterations) stand-in on its own (used by the compiled slice of
+ * MfSegmentation.cpp, oracle/build_seg.py): n dilations, then n erosions */
+void mfo_morph_close_ellipse(uint8_t* img, int W, int H, int radius, int iterations) {
+    uint8_t* tmp = (uint8_t*)malloc((size_t)W * H);
+    for (int it = 0; it < iterations; ++it) { morph_gray(img, tmp, W, H, radius, 1); memcpy(img, tmp, (size_t)W * H); }
+    for (int it = 0; it < iterations; ++it) { morph_gray(img, tmp, W, H, radius, 0); memcpy(img, tmp, (size_t)W * H); }
+    free(tmp);
+}
+
 /* mask values without a class id count as "no mask" (0): upstream reads classIDs[mask] unchecked (MfSegmentation.cpp:226,311),
  * which is undefined for such inputs; the product and this restatement define it the same way */
 static inline int mask_id(int value, int nMasks) { return value < nMasks ? value : 0; }

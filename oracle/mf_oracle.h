@@ -6,7 +6,7 @@
  * leg use it, and only as the checker / the timed CPU baseline.
  *
  * PARITY PIN: the reference (martinruenz/maskfusion) ships no tests, golden vectors or fixtures for this path and its
- * build (CUDA + OpenGL 4.3 + Pangolin + OpenCV + Eigen) cannot run here.  Three parts:
+ * build (CUDA + OpenGL 4.3 + Pangolin + OpenCV + Eigen) cannot run here.  Four parts:
  *   - everything restated from Core/Cuda/{reduce,cudafuncs,segmentation}.cu (rows a3-a5, a7-a10, a12 and the device half
  *     of a20 in SURVEY.md section 8) IS pinned: oracle/build_ref.py compiles those translation units for the CPU
  *     (oracle/_ref/libmf_ref.so), tests/golden/ref_vectors.npz holds their outputs on seeded inputs, and
@@ -17,8 +17,10 @@
  *     what they compute on seeded inputs and tests/test_glsl_pin.py requires this file to reproduce it -- bit-exact for every pass
  *     (the clean pass in the literal window mode, see mfo_set_window_literal).  What OpenGL does AROUND a shader (texel selection,
  *     point / sprite coverage, depth test) is a documented rule set, not reference-executed;
- *   - the host-side arithmetic inside absent third-party libraries -- Eigen (LDLT, JacobiSVD, Quaternion: a6, a11, a15) and OpenCV
- *     (connected components, morphology: host half of a20) -- is PARITY UNPINNED by reference-executed code: restated from the
+ *   - the label-propagation logic of the host half of a20 IS pinned to MfSegmentation.cpp:219-523 compiled from the reference's text
+ *     (oracle/build_seg.py, tests/test_seg_pin.py: every pixel identical);
+ *   - the host-side arithmetic inside absent third-party libraries -- Eigen (LDLT, JacobiSVD, Quaternion: a6, a11, a15) and the
+ *     OpenCV primitives under a20 (connected components, morphology) -- is PARITY UNPINNED by reference-executed code: restated from the
  *     published algorithms and checked by analytic known-answer tests (tests/test_oracle_kat.py, tests/test_oracle_rgbd_kat.py)
  *     and against numpy / SciPy.
  * Citations are relative to /root/reference/.
@@ -71,6 +73,8 @@ void mfo_icp_step(const float* Rcurr, const float* tcurr,
                   const float* vmap_g_prev, const float* nmap_g_prev,
                   float distThres, float angleThres, int W, int H,
                   float* A, float* b, float* residual);
+/* cv::morphologyEx(MORPH_CLOSE, ellipse) stand-in, in place (for oracle/build_seg.py's compiled slice of MfSegmentation.cpp) */
+void mfo_morph_close_ellipse(uint8_t* img, int W, int H, int radius, int iterations);
 /* pose.inverse() as every projection pass consumes it (t_inv uniform); column-major 4x4 */
 void mfo_pose_inverse16(const float* pose16, float* out16);
 /* ANALYSIS ONLY (tools/window_ambiguity.py): literal fp32 reading of the association / clean window loops; see mf_oracle.c */
