@@ -6,7 +6,7 @@
  * leg use it, and only as the checker / the timed CPU baseline.
  *
  * PARITY PIN: the reference (martinruenz/maskfusion) ships no tests, golden vectors or fixtures for this path and its
- * build (CUDA + OpenGL 4.3 + Pangolin + OpenCV + Eigen) cannot run here.  Four parts:
+ * build (CUDA + OpenGL 4.3 + Pangolin + OpenCV + Eigen) cannot run here.  Five parts:
  *   - everything restated from Core/Cuda/{reduce,cudafuncs,segmentation}.cu (rows a3-a5, a7-a10, a12 and the device half
  *     of a20 in SURVEY.md section 8) IS pinned: oracle/build_ref.py compiles those translation units for the CPU
  *     (oracle/_ref/libmf_ref.so), tests/golden/ref_vectors.npz holds their outputs on seeded inputs, and
@@ -19,6 +19,10 @@
  *     point / sprite coverage, depth test) is a documented rule set, not reference-executed;
  *   - the label-propagation logic of the host half of a20 IS pinned to MfSegmentation.cpp:219-523 compiled from the reference's text
  *     (oracle/build_seg.py, tests/test_seg_pin.py: every pixel identical);
+ *   - the host loop of the tracker (a6, a11: SO(3) pre-alignment, three-level ICP + photometric Gauss-Newton, joint solve, SE(3)
+ *     update, 0.3 m rule) IS pinned to RGBDOdometry.cpp:227-497 + OdometryProvider.h compiled from the reference's text over the
+ *     CPU-compiled device functions (oracle/build_track.py, tests/test_track_pin.py: poses within 1e-6 in every branch, inlier
+ *     counts equal); Eigen underneath is a fixed-size stand-in (oracle/eigen_shim);
  *   - the host-side arithmetic inside absent third-party libraries -- Eigen (LDLT, JacobiSVD, Quaternion: a6, a11, a15) and the
  *     OpenCV primitives under a20 (connected components, morphology) -- is PARITY UNPINNED by reference-executed code: restated from the
  *     published algorithms and checked by analytic known-answer tests (tests/test_oracle_kat.py, tests/test_oracle_rgbd_kat.py)
