@@ -1147,7 +1147,7 @@ __global__ __launch_bounds__(256) void k_rgbd_finalize(const float* __restrict__
     PoseDev p = *pose;
     p.rejected = 0;
     const float dx = st.tcurr[0] - st.tprev[0], dy = st.tcurr[1] - st.tprev[1], dz = st.tcurr[2] - st.tprev[2];
-    if (rgbOn && sqrtf(dx * dx + dy * dy + dz * dz) > 0.3f) {   // RGBDOdometry.cpp:477-481
+    if (rgbOn && (double)sqrtf(dx * dx + dy * dy + dz * dz) > 0.3) {   // RGBDOdometry.cpp:477-481
         for (int k = 0; k < 9; ++k) st.Rcurr[k] = st.Rprev[k];
         for (int k = 0; k < 3; ++k) { st.tcurr[k] = st.tprev[k]; st.trt[k] = 0.f; }
         p.rejected = 1;

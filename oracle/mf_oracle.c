@@ -939,7 +939,7 @@ void mfo_track_rgbd(const float* const curr_v[3], const float* const curr_n[3], 
     }
     if (rgb) {
         const float dx = tcurr[0] - tprev[0], dy = tcurr[1] - tprev[1], dz = tcurr[2] - tprev[2];
-        if (sqrtf(dx * dx + dy * dy + dz * dz) > 0.3f) {  /* RGBDOdometry.cpp:477-481 */
+        if ((double)sqrtf(dx * dx + dy * dy + dz * dz) > 0.3) {  /* RGBDOdometry.cpp:477-481 */
             memcpy(Rcurr, Rprev, sizeof(Rprev)); memcpy(tcurr, tprev, sizeof(tprev));
             const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
             memcpy(trR, I, sizeof(I)); trt[0] = trt[1] = trt[2] = 0;

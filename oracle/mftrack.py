@@ -28,7 +28,7 @@ def lib():
         _lib = C.CDLL(path)
         pp = C.POINTER(C.c_void_p)
         _lib.mftrack_run.argtypes = [pp] * 8 + [C.c_void_p, C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_int] * 4 + [C.c_float] * 3 + \
-            [f32p, f32p, f32p, f32p, f64p, f64p]
+            [f32p, f32p, f32p, f32p, f64p, f64p, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")]
         _lib.mftrack_run.restype = C.c_int
     return _lib
 
@@ -49,7 +49,7 @@ def track(curr_v, curr_n, prev_v, prev_n, W, H, fx, fy, cx, cy, R, t, *, last_de
           next_image=None, last_next2=None, pyramid=True, fast_odom=False, so3=False, rgb_only=False, icp_weight=100.0,
           dist_thresh=0.10, angle_thresh=float(np.sin(np.deg2rad(20.0)))):
     """One call of the reference's getIncrementalTransformation.  Pyramids are 3-element lists (level 0..2), maps planar (3, h, w).
-    Returns (R 3x3, t, inc 4x4, stats dict, lastA 6x6, lastb 6)."""
+    Returns (R 3x3, t, inc 4x4, stats dict (the six last* members + launch counts), lastA 6x6, lastb 6)."""
     keep = []
     ln2 = None
     if last_next2 is not None:
@@ -61,10 +61,13 @@ def track(curr_v, curr_n, prev_v, prev_n, W, H, fx, fy, cx, cy, R, t, *, last_de
     st = np.zeros(6, np.float32)
     A = np.zeros(36, np.float64)
     b = np.zeros(6, np.float64)
+    ticks = np.zeros(4, np.int32)
     lib().mftrack_run(_pyr3(curr_v, np.float32, keep), _pyr3(curr_n, np.float32, keep), _pyr3(prev_v, np.float32, keep),
                       _pyr3(prev_n, np.float32, keep), _pyr3(last_depth, np.float32, keep), _pyr3(next_depth, np.float32, keep),
                       _pyr3(last_image, np.uint8, keep), _pyr3(next_image, np.uint8, keep), ln2.ctypes.data if ln2 is not None else None,
                       W, H, fx, fy, cx, cy, int(pyramid), int(fast_odom), int(so3), int(rgb_only), icp_weight, dist_thresh, angle_thresh,
-                      Rf, tf, inc, st, A, b)
+                      Rf, tf, inc, st, A, b, ticks)
     names = ["lastICPError", "lastICPCount", "lastRGBError", "lastRGBCount", "lastSO3Error", "lastSO3Count"]
-    return Rf.reshape(3, 3), tf, inc.reshape(4, 4).T.copy(), dict(zip(names, map(float, st))), A.reshape(6, 6), b
+    stats = dict(zip(names, map(float, st)))
+    stats.update(zip(["so3Steps", "rgbResiduals", "icpSteps", "rgbSteps"], map(int, ticks)))       # launches of each device function
+    return Rf.reshape(3, 3), tf, inc.reshape(4, 4).T.copy(), stats, A.reshape(6, 6), b

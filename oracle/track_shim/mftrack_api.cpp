@@ -19,7 +19,14 @@
 #include <limits>
 #include <vector>
 
-#define TICK(name)
+// TICK / TOCK (Stopwatch.h) become call counters: how many times the loop launched each device function is how many iterations
+// each of its exits allowed -- compared with the oracle's so3Iterations / iterationsRun
+static int g_ticks[4];
+static inline void mftrack_tick(const char* name) {
+    static const char* const names[4] = {"so3Step", "computeRgbResidual", "icpStep", "rgbStep"};
+    for (int i = 0; i < 4; i++) if (!strcmp(name, names[i])) g_ticks[i]++;
+}
+#define TICK(name) mftrack_tick(name)
 #define TOCK(name)
 
 struct GPUConfig {
@@ -99,12 +106,14 @@ extern "C" {
 //   lastNext2: level-2 intensity of the previous frame (may be NULL without so3).
 //   Masks: all pixels carry the tracked model's id (maskID 0 everywhere), the single-model case.
 //   R row-major 3x3 and t: pose in / out.  inc16: the returned increment, column-major.  stats6: lastICPError, lastICPCount,
-//   lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count.  lastA36 row-major, lastb6: the final normal equations.
+//   lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count.  lastA36 row-major, lastb6: the final normal equations.  ticks4: launches of
+//   so3Step, computeRgbResidual, icpStep, rgbStep.
 int mftrack_run(const float* const* curr_v, const float* const* curr_n, const float* const* prev_v, const float* const* prev_n,
                 const float* const* lastDepth, const float* const* nextDepth, const uint8_t* const* lastImage, const uint8_t* const* nextImage,
                 const uint8_t* lastNext2, int W, int H, float fx, float fy, float cx, float cy, int pyramid, int fastOdom, int so3,
                 int rgbOnly, float icpWeight, float distThresh, float angleThresh, float* R, float* t, float* inc16, float* stats6,
-                double* lastA36, double* lastb6) {
+                double* lastA36, double* lastb6, int* ticks4) {
+    memset(g_ticks, 0, sizeof(g_ticks));
     RGBDOdometry odo(W, H, cx, cy, fx, fy, 0, distThresh, angleThresh);
     std::vector<DeviceArray2D<float>> vcur(3), ncur(3);
     std::vector<DeviceArray2D<unsigned char>> pmask(3);
@@ -145,6 +154,7 @@ int mftrack_run(const float* const* curr_v, const float* const* curr_n, const fl
     memcpy(stats6, st, sizeof(st));
     memcpy(lastA36, odo.lastA.data(), sizeof(double) * 36);
     memcpy(lastb6, odo.lastb.data(), sizeof(double) * 6);
+    memcpy(ticks4, g_ticks, sizeof(g_ticks));
     return 0;
 }
 

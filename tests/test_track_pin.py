@@ -77,6 +77,9 @@ def _agree(ref, orc, tol, stats=("ICP",)):
         assert sr[f"last{s}Count"] == getattr(so, f"last{s}Count"), s
         e_r, e_o = sr[f"last{s}Error"], getattr(so, f"last{s}Error")
         assert abs(e_r - e_o) <= 1e-4 * max(abs(e_r), 1e-12) + 1e-9, (s, e_r, e_o)
+    # how often each exit let the loop go round: launches of so3Step / completed Gauss-Newton iterations (TICK counters of the harness)
+    assert sr["so3Steps"] == so.so3Iterations
+    assert max(sr["icpSteps"], sr["rgbSteps"]) == so.iterationsRun
 
 
 def test_icp_branch(pair):
