@@ -137,6 +137,9 @@ struct mf_ctx {
     bool map_ready = false;            // the background map exists (first frame processed, Model::initialise or an uploaded map)
     bool tracked_once = false;         // a tracking step has run (its stage timings are meaningful)
     bool timings_on = false, icp_prof_on = false;
+    bool persistent_icp = false;                       // experimental: the geometric loop as one launch with device-wide barriers ("persistentIcp")
+    unsigned* d_grid_barrier = nullptr;                // [0] arrival counter (monotonic), [1] sticky time-out flag
+    unsigned grid_barrier_base = 0;                    // host copy of what the counter will be when the next launch starts
 
     // frame-level
     uint8_t* d_rgb = nullptr; float* d_depth = nullptr; uint8_t* d_mask_in = nullptr; uint8_t* d_zero_mask = nullptr;
@@ -282,7 +285,7 @@ static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int 
         A(dev_alloc(c, m->allocs, &m->d_nmap_g[i], lp * 3));
     }
     {
-        const size_t nbmax = (size_t)std::max(icp_grid_blocks(c->W, c->H), icp_batch_max_blocks(c->W, c->H));
+        const size_t nbmax = (size_t)std::max(std::max(icp_grid_blocks(c->W, c->H), icp_batch_max_blocks(c->W, c->H)), 240);   // 240: k_icp_persist's grid
         for (int b = 0; b < 2; ++b) A(dev_alloc(c, m->allocs, &m->d_partials[b], nbmax * kIcpSlots));
     }
     A(dev_alloc(c, m->allocs, &m->d_gn, 2));
@@ -400,6 +403,7 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     A(dev_alloc(c, c->allocs, &c->d_block_counts, (size_t)kCompactBlocks));
     A(dev_alloc(c, c->allocs, &c->d_icp_log, (size_t)20 * 32));
     A(dev_alloc(c, c->allocs, &c->d_icp_prof, (size_t)20 * 8));
+    A(dev_alloc(c, c->allocs, &c->d_grid_barrier, (size_t)2));
     A(dev_alloc(c, c->allocs, &c->d_edge, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_bin, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_tmp_u8, (size_t)P));
@@ -498,6 +502,30 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
     const float sobelScale = 1.0f / 8.0f;                                                // 1 / 2^sobelSize, :31-32
     const bool timed = c->timings_on && &m == c->models[0].get();
     if (timed) { (void)hipEventRecord(c->ev_icp[0], s); c->tracked_once = true; }
+    if (!rgb && c->persistent_icp && !c->icp_prof_on && icp_persistent_fits(W, H)) {
+        // experimental: all iterations of all levels in one launch (mf_odometry.hip, k_icp_persist)
+        IcpPersistLaunch pl;
+        int n_it = 0;
+        for (int i = 0; i < 3; ++i) {
+            const int lvl = 2 - i;
+            const float div = (float)(1 << lvl);
+            IcpLaunch& l = pl.level[i];
+            l.vmap_curr = cur_vmap[lvl]; l.nmap_curr = cur_nmap[lvl];
+            l.vmap_prev = m.d_vmap_g[lvl]; l.nmap_prev = m.d_nmap_g[lvl];
+            l.W = W >> lvl; l.H = H >> lvl; l.k = Intr{g.fx / div, g.fy / div, g.cx / div, g.cy / div};
+            l.distThres = 0.10f; l.angleThres = sinf(20.f * 3.14159254f / 180.f);
+            pl.iters[i] = iters[lvl];
+            n_it += iters[lvl];
+        }
+        pl.partials[0] = m.d_partials[0]; pl.partials[1] = m.d_partials[1];
+        pl.pose = m.d_pose; pl.host_mirror = m.h_pose; pl.so3_in = so3_seed;
+        pl.log_out = (m.id == 0 && n_it > 0) ? c->d_icp_log : nullptr;
+        pl.jump_limit = jump_limit;
+        pl.barrier = c->d_grid_barrier; pl.base = c->grid_barrier_base;
+        c->grid_barrier_base += launch_icp_persistent(pl, s);
+        if (timed) (void)hipEventRecord(c->ev_icp[1], s);
+        return;
+    }
     int k = 0, nb_prev = 0, prev_level = -1;
     for (int lvl = 2; lvl >= 0; --lvl) {
         const float div = (float)(1 << lvl);
@@ -921,6 +949,11 @@ extern "C" int mf_set_mask_class_ids(mf_ctx* c, const int32_t* class_ids, int32_
 extern "C" int mf_sync(mf_ctx* c) {
     if (!c) return MF_EINVAL;
     MF_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->persistent_icp) {   // experimental persistent Gauss-Newton launch: did a device-wide barrier time out?
+        unsigned flag = 0;
+        MF_HIP(c, hipMemcpy(&flag, c->d_grid_barrier + 1, sizeof(flag), hipMemcpyDeviceToHost));
+        if (flag) { c->err = "persistentIcp: a device-wide barrier timed out (workgroups not co-resident); tracking of that frame was abandoned"; return MF_ESTATE; }
+    }
     if (c->timings_on) {
         // event i marks the START of stage i; stage i lasts until event i+1 (labels: see the header)
         float t[MF_N_TIMINGS] = {};
@@ -1663,6 +1696,7 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
         return MF_OK;
     }
     if (!strcmp(key, "batchTracking")) { c->batch_tracking = value != 0; return MF_OK; }
+    if (!strcmp(key, "persistentIcp")) { c->persistent_icp = value != 0; return MF_OK; }   // experimental, see k_icp_persist
     if (!strcmp(key, "globalTiles")) { c->global_tiles = value != 0; return MF_OK; }
     if (!strcmp(key, "cleanLiteralWindow")) { c->clean_literal = value != 0; return MF_OK; }   // 0: the exact-arithmetic 4 x 4 window
     if (!strcmp(key, "earlyBackgroundFusion")) { c->early_bg_fusion = value != 0; return MF_OK; }

@@ -111,6 +111,20 @@ struct IcpLaunch {
 };
 int icp_grid_blocks(int W, int H);
 void launch_icp_iteration(const IcpLaunch& a, hipStream_t s);
+// ---- experimental: the whole geometric loop as one persistent launch with device-wide barriers (mf_odometry.hip, k_icp_persist)
+struct IcpPersistLaunch {
+    IcpLaunch level[3];                          // coarsest first; only the map pointers, W, H, k and the two thresholds are read
+    int iters[3];
+    float* partials[2];                          // each >= 240 * 32 floats
+    PoseDev* pose; PoseDev* host_mirror;
+    const So3Result* so3_in;
+    float* log_out;                              // optional [n_it][32]
+    float jump_limit;
+    unsigned* barrier;                           // device: [0] monotonic arrival counter, [1] sticky time-out flag
+    unsigned base;                               // counter value before this launch
+};
+bool icp_persistent_fits(int W, int H);          // one workgroup round of <= 3 pixels per thread covers level 0
+unsigned launch_icp_persistent(const IcpPersistLaunch& l, hipStream_t s);   // returns what the launch adds to the arrival counter
 // ---- the same loop for SEVERAL models at once (MaskFusion.cpp:247-276 tracks them one after the other): one launch serves
 // iteration k of every tracked model.  Split in two kernels per iteration -- "solve" (one workgroup per model: reduce the
 // previous iteration's partials, LDL^T, pose) and "pixels" (grid.y = model, no prologue, any number of workgroup rounds) --

@@ -675,6 +675,173 @@ void launch_icp_finalize(const float* partials_in, int nblocks_in, const GNState
 // ------------------------------------------------------------------------------------------------
 // Batched Gauss-Newton loop: iteration k of ALL tracked models per launch (see mf_internal.h).
 // ------------------------------------------------------------------------------------------------
+// EXPERIMENTAL (mf_set_param("persistentIcp", 1); default off; written at the end of round 2 without GPU time left -- it compiles,
+// it has not run): the same geometric Gauss-Newton loop as ONE persistent launch.  All iterations of all three levels run inside a
+// single <<<240, 512>>> launch; between iterations the workgroups meet at a device-wide barrier instead of at a kernel boundary.
+// tools/micro/grid_barrier.hip measures whether such a barrier beats the 3.44 us dependent-launch exchange; if it does, this kernel
+// removes that difference from each of the 19 iterations.  Everything else is k_icp_iter's: the same pixel functions, the same
+// fixed-order fp64 reduction of the per-workgroup partials and the same one-thread solve, done redundantly and bit-identically by
+// every workgroup (the Gauss-Newton state therefore never leaves LDS), the same finalize.  Differences: every workgroup takes a slice
+// of every level (chunk = P / 240 rounded up to 64 pixels, so the coarse levels run on all CUs with one or two wavefronts each), and
+// 240 partials are reduced per iteration at every level.
+// Safety: the barrier needs all workgroups co-resident (240 <= 256 CUs, one workgroup per CU fits: ~40 KB LDS); every spin is bounded
+// (~50 ms) and sets a sticky error word that mf_sync reports, so a launch can fail but cannot hang the GPU.
+// ------------------------------------------------------------------------------------------------
+struct IcpPersistLevel {
+    const float* vc; const float* nc; const float* vp; const float* np;
+    int W, H; Intr k;
+    float distThres, angleThres;
+    int iters;
+};
+struct IcpPersistArgs {
+    IcpPersistLevel lv[3];            // in execution order: coarsest level first
+    float* partials[2];               // ping-pong [gridDim.x][kIcpSlots]
+    PoseDev* pose; PoseDev* host_mirror;
+    const So3Result* so3_in;
+    float* log_out;                   // optional [n_it][32]: the reduced system of every iteration
+    float jump_limit;
+    unsigned* barrier;                // [0]: arrival counter, monotonic across launches; [1]: sticky time-out flag
+    unsigned base;                    // value of the counter when this launch starts
+};
+
+// Device-wide barrier: release (all threads) -> workgroup barrier -> one arrival per workgroup -> bounded spin -> workgroup barrier ->
+// acquire (all threads).  Returns false in every thread of the workgroup when any workgroup of the launch timed out.
+__device__ __forceinline__ bool icp_grid_barrier(unsigned* bar, unsigned target, int* s_ok) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long t0 = wall_clock64();   // 100 MHz
+        while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            if (wall_clock64() - t0 > 5000000ll) { __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        *s_ok = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return *s_ok != 0;
+}
+
+// The solve and the finalize as real function calls: inlined into the iteration loop their ~90-word Gauss-Newton state pushed the
+// kernel to 256 VGPRs with spills (k_icp_iter: 115); one call per iteration costs a few hundred cycles of one thread.
+__device__ __noinline__ void icp_persist_solve(const double* s_sys, GNState* s_st) {
+    GNState st;
+    gn_solve_update_serial(s_sys, *s_st, st);
+    *s_st = st;
+}
+__device__ __noinline__ void icp_persist_finalize(const float* partials_in, int nb_in, const GNState* st_in, PoseDev* pose, PoseDev* host_mirror,
+                                                  float* log_out, float jump_limit, const So3Result* so3, double* s_seg, double* s_sys) {
+    icp_finalize_body(partials_in, nb_in, st_in, pose, host_mirror, log_out, jump_limit, so3, s_seg, s_sys);
+}
+
+__global__ __launch_bounds__(kIcpThreads) void k_icp_persist(const IcpPersistArgs a) {
+    constexpr int kT = kIcpThreads;
+    __shared__ double s_seg[32 * 32];
+    __shared__ double s_sys[32];
+    __shared__ float s_pose[24];  // Rcurr[9] tcurr[3] Rprev_inv[9] tprev[3]
+    __shared__ float s_red[29 * (kT / 2)];
+    __shared__ GNState s_st;
+    __shared__ int s_ok;
+
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        seed_state(*a.pose, s_st);   // RGBDOdometry.cpp:239-243,332-336
+        if (a.so3_in)
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) s_st.resultRt[r * 4 + c] = a.so3_in->R[r * 3 + c];
+        s_ok = 1;
+    }
+    __syncthreads();
+
+    int it = 0, nb_prev = 0;
+#pragma unroll 1
+    for (int li = 0; li < 3; ++li) {
+        const IcpPersistLevel L = a.lv[li];
+        const int P = L.W * L.H;
+        const int chunk = icp_chunk(P, gridDim.x);   // <= kIcpPx * kT (checked by the host)
+        const int beg = blockIdx.x * chunk, end = min(P, beg + chunk);
+#pragma unroll 1
+        for (int j = 0; j < L.iters; ++j, ++it) {
+            // (1) pose-independent streamed loads
+            int idx[kIcpPx]; bool act[kIcpPx];
+            float vx[kIcpPx], vy[kIcpPx], vz[kIcpPx], nx[kIcpPx], ny[kIcpPx], nz[kIcpPx];
+#pragma unroll
+            for (int q = 0; q < kIcpPx; ++q) {
+                idx[q] = beg + q * kT + tid;
+                act[q] = idx[q] < end;
+                const int i = min(idx[q], P - 1);
+                vx[q] = L.vc[i]; vy[q] = L.vc[P + i]; vz[q] = L.vc[2 * P + i];
+                nx[q] = L.nc[i]; ny[q] = L.nc[P + i]; nz[q] = L.nc[2 * P + i];
+            }
+            // (2) finish the previous iteration: reduce -> solve -> pose, identically in every workgroup; the state stays in LDS
+            if (nb_prev > 0) {
+                reduce_partials(a.partials[(it + 1) & 1], nb_prev, s_seg, s_sys);
+                if (tid == 0) icp_persist_solve(s_sys, &s_st);
+                if (blockIdx.x == 0 && a.log_out && tid >= 64 && tid < 96) a.log_out[(it - 1) * 32 + (tid - 64)] = (float)s_sys[tid - 64];
+            }
+            if (tid == 0) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { s_pose[k] = s_st.Rcurr[k]; s_pose[12 + k] = s_st.Rprev_inv[k]; }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { s_pose[9 + k] = s_st.tcurr[k]; s_pose[21 + k] = s_st.tprev[k]; }
+            }
+            __syncthreads();
+            float Rc[9], Rpi[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { Rc[k] = s_pose[k]; Rpi[k] = s_pose[12 + k]; }
+            const float3 tc = f3(s_pose[9], s_pose[10], s_pose[11]);
+            const float3 tp = f3(s_pose[21], s_pose[22], s_pose[23]);
+            // (3) normal equations of this thread's pixels
+            float acc[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) acc[k] = 0.f;
+            IcpCorr cor[kIcpPx];
+            float3 pv[kIcpPx], pn[kIcpPx];
+#pragma unroll
+            for (int q = 0; q < kIcpPx; ++q) {
+                cor[q] = icp_project(vx[q], vy[q], vz[q], nx[q], ny[q], nz[q], Rc, tc, Rpi, tp, L);
+                cor[q].ok = cor[q].ok && act[q];
+                cor[q].j = cor[q].ok ? cor[q].j : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < kIcpPx; ++q) {
+                const int jj = cor[q].j;
+                pv[q] = f3(L.vp[jj], L.vp[P + jj], L.vp[2 * P + jj]);
+                pn[q] = f3(L.np[jj], L.np[P + jj], L.np[2 * P + jj]);
+            }
+#pragma unroll
+            for (int q = 0; q < kIcpPx; ++q) icp_accumulate(cor[q], pv[q], pn[q], Rpi, tp, L, acc);
+            // (4) one 128 B partial per workgroup, then the device-wide barrier that stands where the kernel boundary stood
+            block_sum29_lds<kT>(acc, s_red, a.partials[it & 1] + blockIdx.x * kIcpSlots);
+            if (!icp_grid_barrier(a.barrier, a.base + (unsigned)(it + 1) * gridDim.x, &s_ok)) return;
+            nb_prev = (int)gridDim.x;
+        }
+    }
+    // last reduce + solve, Model::pose / lastPose / statistics, the object-model jump rule: workgroup 0
+    if (blockIdx.x == 0)
+        icp_persist_finalize(nb_prev ? a.partials[(it + 1) & 1] : nullptr, nb_prev, &s_st, a.pose, a.host_mirror,
+                             (a.log_out && it > 0) ? a.log_out + (it - 1) * 32 : nullptr, a.jump_limit, a.so3_in, s_seg, s_sys);
+}
+
+bool icp_persistent_fits(int W, int H) { return icp_chunk(W * H, kIcpMaxBlocks) <= kIcpPx * kIcpThreads; }
+
+unsigned launch_icp_persistent(const IcpPersistLaunch& l, hipStream_t s) {
+    IcpPersistArgs a;
+    int n_it = 0;
+    for (int i = 0; i < 3; ++i) {
+        const IcpLaunch& q = l.level[i];
+        a.lv[i] = IcpPersistLevel{q.vmap_curr, q.nmap_curr, q.vmap_prev, q.nmap_prev, q.W, q.H, q.k, q.distThres, q.angleThres, l.iters[i]};
+        n_it += l.iters[i];
+    }
+    a.partials[0] = l.partials[0]; a.partials[1] = l.partials[1];
+    a.pose = l.pose; a.host_mirror = l.host_mirror; a.so3_in = l.so3_in; a.log_out = l.log_out; a.jump_limit = l.jump_limit;
+    a.barrier = l.barrier; a.base = l.base;
+    hipLaunchKernelGGL(k_icp_persist, dim3(kIcpMaxBlocks), dim3(kIcpThreads), 0, s, a);
+    return (unsigned)n_it * (unsigned)kIcpMaxBlocks;
+}
+
+// ------------------------------------------------------------------------------------------------
 struct IcpSolveArgs { TrackBatch b; int it; int nb_in; const So3Result* so3; };
 
 __global__ __launch_bounds__(256) void k_icp_batch_solve(const IcpSolveArgs a) {
