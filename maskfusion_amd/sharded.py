@@ -216,7 +216,7 @@ class LocalGroup:
             for s in self.shards[1:]:
                 merged = torch.minimum(merged, mfd.keys_to_wire(s.keys))
             merged = _wire_to_keys(merged)
-            torch.cuda.synchronize()
+            _device_sync(self.shards[0].device)
             alive = _alive_from_states([s.state for s in self.shards], [s.local_ids() for s in self.shards])
             for s in self.shards[1:]:
                 alive.pop(0, None)       # the background stand-ins of the object ranks say nothing about the background
@@ -226,11 +226,18 @@ class LocalGroup:
             bg_pose = np.ascontiguousarray(s0.mf.getCurrPose().astype(np.float32).T.reshape(16))
             for s in self.shards[1:]:
                 s.labels.copy_(s0.labels)
-            torch.cuda.synchronize()
+            _device_sync(s0.device)
         for s in self.shards:
             s.phase_fuse(ctl, bg_pose, self.cfg, weight_multiplier, timestamp, first)
         self.frame += 1
         return ctl
+
+
+def _device_sync(device: torch.device):
+    """the collectives above run on torch's stream, the library on its own: drain the device between them (no-op for the CPU tensors
+    of the gloo tests, which drive this file with a stand-in context)"""
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
 
 
 def _wire_to_keys(wire: torch.Tensor) -> torch.Tensor:
@@ -293,7 +300,7 @@ class ShardedMaskFusion:
                 dist.gather(send, recv, dst=0)
             else:
                 recv = [send]
-            torch.cuda.synchronize()
+            _device_sync(self.device)
             if self.rank == 0:
                 alive = {}
                 for r, blk in enumerate(recv):
@@ -304,7 +311,7 @@ class ShardedMaskFusion:
                             alive[int(mid)] = int(st[i, 15] != 0)
                 alive[0] = 1
                 keys = _wire_to_keys(wire)
-                torch.cuda.synchronize()
+                _device_sync(self.device)
                 ctl = s.phase_segment(mask, class_ids, keys, alive, self.cfg)
                 s.mf.sync()
                 bg_pose = np.ascontiguousarray(s.mf.getCurrPose().astype(np.float32).T.reshape(16))
@@ -315,7 +322,7 @@ class ShardedMaskFusion:
             if self.world > 1:
                 mfd.broadcast_labels(s.labels, s.bg_pose, 0)
                 dist.broadcast(self.ctl, 0)
-            torch.cuda.synchronize()
+            _device_sync(self.device)
             c = self.ctl.cpu().numpy()
             ctl = Control(int(c[0]), int(c[1]), int(c[2]), int(c[3]), [int(x) for x in c[8:8 + int(c[7])]])
             bg_pose = s.bg_pose.cpu().numpy()
