@@ -1,18 +1,27 @@
 """Helpers shared by the -m gpu parity tests: torch is used only to hold device memory."""
+import os
+
 import numpy as np
 import torch
 
+# MF_EMU=1: the tests drive tests/_build/libmaskfusion_emu.so (the product's kernels executed on the CPU, tests/hipcpu) instead of the GPU
+# library -- a logic check for machines without a GPU, selected explicitly and never by default.  "Device" memory is host memory then.
+EMU = os.environ.get("MF_EMU") == "1"
+DEVICE = "cpu" if EMU else "cuda"
+
 
 def dev(a: np.ndarray) -> torch.Tensor:
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.clone() if EMU else t.cuda()
 
 
 def empty(shape, dtype=torch.float32) -> torch.Tensor:
-    return torch.empty(shape, dtype=dtype, device="cuda")
+    return torch.empty(shape, dtype=dtype, device=DEVICE)
 
 
 def host(t: torch.Tensor) -> np.ndarray:
-    torch.cuda.synchronize()
+    if not EMU:
+        torch.cuda.synchronize()
     return t.cpu().numpy()
 
 

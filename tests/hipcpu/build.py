@@ -1,0 +1,69 @@
+"""Builds tests/_build/libmaskfusion_emu.so: the product's own sources (maskfusion_amd/csrc/*.hip) compiled with g++ against
+tests/hipcpu/hipcpu.h and run on the CPU by tests/hipcpu/hipcpu_runtime.cpp.  TEST TOOLING: lets the kernel-logic tests run where there
+is no GPU.  The product never loads this library, and nothing here is a fallback: maskfusion_amd.lib.load() knows only the HIP build.
+
+The sources are compiled as they are, except for three mechanical edits applied in memory (the files on disk are untouched):
+  * `asm volatile("s_waitcnt ...")` statements (profiling stamps) are dropped -- AMD mnemonics do not assemble on the host;
+  * `extern __shared__ T name[];` becomes `T* name = (T*)hipcpu::dyn_shared();`;
+  * `#pragma unroll` / `#pragma clang ...` are dropped (g++ warns about them; they do not change meaning).
+"""
+from __future__ import annotations
+
+import os
+import re
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "maskfusion_amd", "csrc")
+OUT = os.path.join(os.path.dirname(HERE), "_build")
+LIB = os.path.join(OUT, "libmaskfusion_emu.so")
+sys.path.insert(0, ROOT)
+from maskfusion_amd.build import SOURCES, HEADERS  # noqa: E402
+
+CXX = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-w", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "include"),
+       "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-I", HERE, "-include", os.path.join(HERE, "hipcpu.h")]
+
+
+def rewrite(text: str) -> str:
+    text = re.sub(r"asm\s+volatile\s*\([^;]*\);", "", text)
+    text = re.sub(r"extern\s+__shared__\s+([\w:]+)\s+(\w+)\s*\[\s*\]\s*;", r"\1* \2 = (\1*)hipcpu::dyn_shared();", text)
+    text = re.sub(r"^\s*#pragma\s+(unroll|clang)[^\n]*$", "", text, flags=re.M)
+    return text
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(HERE, f) for f in os.listdir(HERE)]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, only=None) -> str:
+    if not (force or _stale()) and only is None:
+        return LIB
+    os.makedirs(OUT, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(OUT, "emu_" + src.replace(".hip", ".o"))
+        objs.append(obj)
+        if only is not None and src not in only:
+            continue
+        text = rewrite(open(os.path.join(CSRC, src)).read())
+        r = subprocess.run([*CXX, "-x", "c++", "-c", "-", "-o", obj], input=text.encode(), capture_output=True)
+        if r.returncode != 0:
+            sys.stderr.write(f"--- {src}\n" + r.stderr.decode()[:6000])
+            raise SystemExit(1)
+    if only is not None:
+        return ""
+    rt = os.path.join(OUT, "emu_runtime.o")
+    subprocess.check_call([*CXX, "-c", os.path.join(HERE, "hipcpu_runtime.cpp"), "-o", rt])
+    subprocess.check_call(["g++", "-shared", "-o", LIB, *objs, rt])
+    return LIB
+
+
+if __name__ == "__main__":
+    only = [a for a in sys.argv[1:] if a.endswith(".hip")] or None
+    print(build(force=True, only=only))

@@ -1,0 +1,34 @@
+"""Loads tests/_build/libmaskfusion_emu.so (the product's kernels compiled for and executed on the CPU, tests/hipcpu/build.py) behind the
+same ctypes table as the real library.  TEST TOOLING: `activate()` swaps it into maskfusion_amd.lib for the current PROCESS so that the
+Python mirror (maskfusion_amd.api) drives it; only tests call this, explicitly.  "Device pointers" are host pointers here."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import build as _build  # noqa: E402
+
+_emu = None
+
+
+def load():
+    global _emu
+    if _emu is None:
+        from maskfusion_amd import lib as mflib
+        L = C.CDLL(_build.build())
+        for name, (res, args) in mflib.SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _emu = L
+    return _emu
+
+
+def activate():
+    """maskfusion_amd.lib.load() returns the emulated library from now on (this process only)"""
+    from maskfusion_amd import lib as mflib
+    mflib._lib = load()
+    return mflib._lib

@@ -1,0 +1,217 @@
+// hipcpu_runtime.cpp -- the execution model and the runtime API behind tests/hipcpu/hipcpu.h.  TEST TOOLING (see hipcpu.h).
+#include "hipcpu.h"
+
+#include <map>
+#include <vector>
+
+uint3 threadIdx, blockIdx;
+dim3 blockDim, gridDim;
+
+#if !defined(__x86_64__)
+#error "hipcpu's fiber switch is written for x86-64"
+#endif
+extern "C" void hipcpu_switch(void** save_sp, void* load_sp);
+asm(".text\n"
+    ".hidden hipcpu_switch\n"
+    ".globl hipcpu_switch\n"
+    ".type hipcpu_switch,@function\n"
+    "hipcpu_switch:\n"
+    "    pushq %rbp\n    pushq %rbx\n    pushq %r12\n    pushq %r13\n    pushq %r14\n    pushq %r15\n"
+    "    movq %rsp, (%rdi)\n"
+    "    movq %rsi, %rsp\n"
+    "    popq %r15\n    popq %r14\n    popq %r13\n    popq %r12\n    popq %rbx\n    popq %rbp\n"
+    "    ret\n"
+    ".size hipcpu_switch,.-hipcpu_switch\n");
+
+namespace {
+
+constexpr size_t kStack = 256 * 1024;
+
+struct Fiber {
+    void* sp;
+    uint3 tid;
+    int lin;
+    int parity;
+    int xgen, xparity;           // generation / buffer half of this thread's latest wave exchange
+    bool done;
+};
+
+struct Block {
+    std::vector<Fiber> f;
+    char* stacks = nullptr;
+    std::vector<uint64_t> slots;                 // [2][n]
+    std::vector<int> slot_gen;                   // [2][n]: wave-exchange generation in which the slot was written
+    std::vector<int> wave_arrived, wave_gen, wave_live;
+    int n = 0, live = 0, arrived = 0, gen = 0;
+    void* sched = nullptr;
+    Fiber* cur = nullptr;
+    const std::function<void()>* body = nullptr;
+    std::vector<char> dyn;
+};
+
+Block* g_blk = nullptr;
+unsigned long long g_clock = 0;
+
+inline Fiber* next_live(Block* b, Fiber* me) {
+    int i = me->lin;
+    do { i = (i + 1 == b->n) ? 0 : i + 1; } while (b->f[i].done && i != me->lin);
+    return &b->f[i];
+}
+inline void resume(Block* b, Fiber* from, Fiber* to) {
+    b->cur = to;
+    threadIdx = to->tid;
+    hipcpu_switch(&from->sp, to->sp);
+}
+void fiber_entry() {
+    Block* b = g_blk;
+    Fiber* me = b->cur;
+    (*b->body)();
+    me->done = true;
+    b->live--;
+    b->wave_live[me->lin / 64]--;
+    if (b->live > 0) resume(b, me, next_live(b, me));
+    else hipcpu_switch(&me->sp, b->sched);
+    abort();
+}
+void make_fiber(Fiber* f, char* stack, size_t size) {
+    uintptr_t top = ((uintptr_t)stack + size) & ~(uintptr_t)15;
+    void** sp = (void**)(top - 64);
+    for (int i = 0; i < 8; i++) sp[i] = nullptr;
+    sp[6] = (void*)fiber_entry;
+    f->sp = sp;
+}
+void wave_barrier() {
+    Block* b = g_blk;
+    const int w = b->cur->lin / 64;
+    const int my = b->wave_gen[w];
+    b->wave_arrived[w]++;
+    while (b->wave_gen[w] == my) {
+        if (b->wave_arrived[w] >= b->wave_live[w]) { b->wave_arrived[w] = 0; b->wave_gen[w]++; break; }
+        hipcpu::yield();
+    }
+}
+
+}  // namespace
+
+namespace hipcpu {
+
+void yield() {
+    Block* b = g_blk;
+    Fiber* me = b->cur;
+    Fiber* nx = next_live(b, me);
+    g_clock += 16;
+    if (nx != me) resume(b, me, nx);
+}
+void syncthreads() {
+    Block* b = g_blk;
+    const int my = b->gen;
+    b->arrived++;
+    while (b->gen == my) {
+        if (b->arrived >= b->live) { b->arrived = 0; b->gen++; break; }
+        yield();
+    }
+}
+int lane() { return g_blk->cur->lin & 63; }
+// did lane l of the calling thread's wavefront take part in the calling thread's latest exchange?  (Not "is it alive now": a lane may
+// return from the kernel right after the exchange, before a slower lane has read its slot.)
+bool lane_alive(int l) {
+    Block* b = g_blk;
+    Fiber* me = b->cur;
+    const int i = (me->lin & ~63) + l;
+    return l >= 0 && l < 64 && i < b->n && b->slot_gen[(size_t)me->xparity * b->n + i] == me->xgen;
+}
+const uint64_t* wave_publish(uint64_t v) {
+    Block* b = g_blk;
+    Fiber* me = b->cur;
+    uint64_t* s = b->slots.data() + (size_t)me->parity * b->n;
+    me->xparity = me->parity;
+    me->xgen = b->wave_gen[me->lin / 64] + 1;      // exchanges of a wavefront are numbered from 1 (slot_gen starts at 0 = never)
+    b->slot_gen[(size_t)me->parity * b->n + me->lin] = me->xgen;
+    me->parity ^= 1;
+    s[me->lin] = v;
+    wave_barrier();   // one barrier is enough: this half is only written again two exchanges later (see oracle/ref_shim/mfref_runtime.cpp)
+    return s + (me->lin & ~63);
+}
+void* dyn_shared() { return g_blk->dyn.data(); }
+unsigned long long clock() { return g_clock += 4; }
+
+void launch(dim3 grid, dim3 block, size_t dyn_shared_bytes, const std::function<void()>& body) {
+    const int n = (int)(block.x * block.y * block.z);
+    if (n <= 0 || grid.x * grid.y * grid.z == 0) return;
+    Block blk;
+    blk.n = n;
+    blk.f.resize(n);
+    static char* pool = nullptr;
+    static size_t pool_size = 0;
+    if (pool_size < (size_t)n * kStack) {
+        free(pool);
+        pool_size = (size_t)n * kStack;
+        pool = (char*)malloc(pool_size);
+        if (!pool) { fprintf(stderr, "hipcpu: out of memory for fiber stacks\n"); abort(); }
+    }
+    blk.stacks = pool;
+    blk.slots.assign(2 * (size_t)n + 64, 0);
+    blk.slot_gen.assign(2 * (size_t)n + 64, 0);
+    blk.dyn.assign(dyn_shared_bytes + 16, 0);
+    const int nw = (n + 63) / 64;
+    blk.body = &body;
+    Block* prev = g_blk;
+    const dim3 prevGrid = gridDim, prevBlock = blockDim;
+    g_blk = &blk;
+    gridDim = grid;
+    blockDim = block;
+    // the slot array is indexed [parity][lin] with n rounded up to whole wavefronts
+    blk.n = n;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                blk.live = n; blk.arrived = 0; blk.gen = 0;
+                blk.wave_arrived.assign(nw, 0); blk.wave_gen.assign(nw, 0); blk.wave_live.assign(nw, 0);
+                std::fill(blk.slot_gen.begin(), blk.slot_gen.end(), 0);
+                for (int i = 0; i < n; ++i) {
+                    Fiber& f = blk.f[i];
+                    f.lin = i;
+                    f.tid = uint3{(unsigned)i % block.x, ((unsigned)i / block.x) % block.y, (unsigned)i / (block.x * block.y)};
+                    f.done = false;
+                    f.parity = 0; f.xgen = -1; f.xparity = 0;
+                    blk.wave_live[i / 64]++;
+                    make_fiber(&f, blk.stacks + (size_t)i * kStack, kStack - (size_t)((i * 37) % 256) * 64);
+                }
+                blockIdx = uint3{bx, by, bz};
+                blk.cur = &blk.f[0];
+                threadIdx = blk.f[0].tid;
+                hipcpu_switch(&blk.sched, blk.f[0].sp);
+                if (blk.live != 0) { fprintf(stderr, "hipcpu: workgroup returned with live threads\n"); abort(); }
+            }
+    g_blk = prev;
+    gridDim = prevGrid; blockDim = prevBlock;
+}
+
+}  // namespace hipcpu
+
+// ---- runtime API: one address space, everything completes before it returns ------------------------------------------------------
+static int g_dummy_handles = 0;
+hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); if (*p) memset(*p, 0xCD, n); return *p ? hipSuccess : hipErrorOutOfMemory; }   // device memory is not zero
+hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+hipError_t hipStreamCreate(hipStream_t* s) { *s = (hipStream_t)(uintptr_t)(0x1000 + ++g_dummy_handles); return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
+hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)(uintptr_t)(0x2000 + ++g_dummy_handles); return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipGetLastError() { return hipSuccess; }
+const char* hipGetErrorString(hipError_t) { return "hipcpu"; }

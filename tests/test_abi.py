@@ -50,11 +50,11 @@ def test_product_never_imports_oracle():
                 assert "mf_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
 
 
-def build_facade_exe(out_dir):
+def build_facade_exe(out_dir, lib=None):
     """g++ -std=c++14 tests/cpp/facade_main.cpp against include/ and the shared library -- what INTEGRATION.md asks a MaskFusion
-    maintainer to do.  Returns the executable's path."""
+    maintainer to do.  Returns the executable's path.  lib: another build of the same C ABI (the CPU-executed test build of MF_EMU=1)."""
     import subprocess
-    lib = os.path.join(ROOT, "maskfusion_amd", "libmaskfusion_amd.so")
+    lib = lib or os.path.join(ROOT, "maskfusion_amd", "libmaskfusion_amd.so")
     if not os.path.exists(lib):
         from maskfusion_amd import build
         build.build()

@@ -45,7 +45,7 @@ def test_cpp_facade_matches_python_mirror(hip, tmp_path, multi):
             f.write(np.ascontiguousarray(depth, np.float32).tobytes())
             f.write(np.ascontiguousarray(mask if mask is not None else np.zeros((st.H, st.W)), np.uint8).tobytes())
     outdir = str(tmp_path) + os.sep
-    exe = build_facade_exe(tmp_path)
+    exe = build_facade_exe(tmp_path, lib=hip._name if os.environ.get("MF_EMU") == "1" else None)
     r = subprocess.run([exe, "640", "480", "528", "528", "320", "240", str(n), str(blob), outdir, "1" if multi else "0"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])

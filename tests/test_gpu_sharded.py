@@ -3,6 +3,8 @@ the label stage on context 0, every object model on context 1, the couplings thr
 mf_perform_segmentation, mf_export/import_segmentation_dev and the background pose) against the single-context multi-model run
 (model-by-model tracking): label images, poses, model ids and surfel clouds must be BIT-IDENTICAL -- sharding moves models, it
 does not change a single operation (GlobalProjection.cpp:43-114, MaskFusion.cpp:289-297, Model.h:263-264)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -40,7 +42,7 @@ def test_two_contexts_equal_one_context(hip, track_all):
                         counts=[m.lastCount() for m in ms], seg=one.downloadSegmentation(), clouds=[m.downloadMap() for m in ms] if k == N_FRAMES - 1 else None))
     one.close()
     # ---- sharded: context 0 = background + label stage, context 1 = all object models ----
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cpu") if os.environ.get("MF_EMU") == "1" else torch.device("cuda", 0)
     ctxs = [_make(track_all), _make(track_all)]
     shards = [sharded.Shard(r, 2, ctxs[r], dev) for r in range(2)]
     grp = sharded.LocalGroup(shards, sharded.default_cfg(trackAllModels=track_all, modelSpawnOffset=3))
