@@ -19,10 +19,11 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "maskfusion_amd", "csrc")
 OUT = os.path.join(os.path.dirname(HERE), "_build")
 LIB = os.path.join(OUT, "libmaskfusion_emu.so")
+LIB_COOP = os.path.join(OUT, "libmaskfusion_emu_coop.so")     # -DHIPCPU_COOP: cooperative launches possible, slower (see hipcpu.h)
 sys.path.insert(0, ROOT)
 from maskfusion_amd.build import SOURCES, HEADERS  # noqa: E402
 
-CXX = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-w", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "include"),
+CXX = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-pthread", "-w", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "include"),
        "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-I", HERE, "-include", os.path.join(HERE, "hipcpu.h")]
 
 
@@ -33,37 +34,39 @@ def rewrite(text: str) -> str:
     return text
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
+def _stale(lib) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(HERE, f) for f in os.listdir(HERE)]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, only=None) -> str:
-    if not (force or _stale()) and only is None:
-        return LIB
+def build(force: bool = False, only=None, coop: bool = False) -> str:
+    lib = LIB_COOP if coop else LIB
+    cxx = CXX + (["-DHIPCPU_COOP"] if coop else [])
+    if not (force or _stale(lib)) and only is None:
+        return lib
     os.makedirs(OUT, exist_ok=True)
     objs = []
     for src in SOURCES:
-        obj = os.path.join(OUT, "emu_" + src.replace(".hip", ".o"))
+        obj = os.path.join(OUT, ("emuc_" if coop else "emu_") + src.replace(".hip", ".o"))
         objs.append(obj)
         if only is not None and src not in only:
             continue
         text = rewrite(open(os.path.join(CSRC, src)).read())
-        r = subprocess.run([*CXX, "-x", "c++", "-c", "-", "-o", obj], input=text.encode(), capture_output=True)
+        r = subprocess.run([*cxx, "-x", "c++", "-c", "-", "-o", obj], input=text.encode(), capture_output=True)
         if r.returncode != 0:
             sys.stderr.write(f"--- {src}\n" + r.stderr.decode()[:6000])
             raise SystemExit(1)
     if only is not None:
         return ""
-    rt = os.path.join(OUT, "emu_runtime.o")
-    subprocess.check_call([*CXX, "-c", os.path.join(HERE, "hipcpu_runtime.cpp"), "-o", rt])
-    subprocess.check_call(["g++", "-shared", "-o", LIB, *objs, rt])
-    return LIB
+    rt = os.path.join(OUT, "emuc_runtime.o" if coop else "emu_runtime.o")
+    subprocess.check_call([*cxx, "-c", os.path.join(HERE, "hipcpu_runtime.cpp"), "-o", rt])
+    subprocess.check_call(["g++", "-shared", "-pthread", "-o", lib, *objs, rt])
+    return lib
 
 
 if __name__ == "__main__":
     only = [a for a in sys.argv[1:] if a.endswith(".hip")] or None
-    print(build(force=True, only=only))
+    print(build(force=True, only=only, coop="--coop" in sys.argv))

@@ -15,10 +15,11 @@ _emu = None
 
 
 def load():
+    """MF_EMU_COOP=1 selects the build that can run all workgroups of a launch at once (kernels named in HIPCPU_COOPERATIVE)"""
     global _emu
     if _emu is None:
         from maskfusion_amd import lib as mflib
-        L = C.CDLL(_build.build())
+        L = C.CDLL(_build.build(coop=os.environ.get("MF_EMU_COOP") == "1"))
         for name, (res, args) in mflib.SYMBOLS.items():
             fn = getattr(L, name)
             fn.restype = res

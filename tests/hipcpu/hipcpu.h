@@ -22,18 +22,29 @@
 #include <hip/hip_runtime.h>   // a host compiler's view: vector types, dim3, the runtime API prototypes (defined in hipcpu_runtime.cpp)
 
 #undef __shared__
-#define __shared__ static      // one copy per kernel: workgroups run one after the other
+// Two builds (tests/hipcpu/build.py): the default one runs the workgroups of a launch one after the other on the calling thread -- LDS
+// is one static copy per kernel; the HIPCPU_COOP build can also run ALL workgroups of a launch at once, one OS thread each (what a
+// kernel with a device-wide barrier needs), so LDS and the built-in indices are thread_local there (about 2.5x slower overall).
+#ifdef HIPCPU_COOP
+#define HIPCPU_TLS thread_local
+#else
+#define HIPCPU_TLS
+#endif
+#define __shared__ alignas(64) static HIPCPU_TLS   // LDS allocations are at least 16-byte aligned on the device (float4 accesses)
 #undef __launch_bounds__
 #define __launch_bounds__(...)
 #undef __noinline__
 #define __noinline__ __attribute__((noinline))
 
-extern uint3 threadIdx, blockIdx;
-extern dim3 blockDim, gridDim;
+extern HIPCPU_TLS uint3 threadIdx, blockIdx;
+extern HIPCPU_TLS dim3 blockDim, gridDim;
 static const int warpSize = 64;
 
 namespace hipcpu {
-void launch(dim3 grid, dim3 block, size_t dyn_shared, const std::function<void()>& body);
+// name: the kernel as written at the launch site.  Kernels listed in the environment variable HIPCPU_COOPERATIVE (comma separated
+// prefixes) are launched with ALL workgroups resident at once, one OS thread per workgroup -- what a kernel with a device-wide barrier
+// needs (HIPCPU_COOP build only); every other launch runs its workgroups one after the other on the calling thread.
+void launch(const char* name, dim3 grid, dim3 block, size_t dyn_shared, const std::function<void()>& body);
 void syncthreads();
 void yield();
 int lane();                                        // linear thread id % 64
@@ -47,16 +58,17 @@ template <class T> inline T from_bits(uint64_t b) { T v; memcpy(&v, &b, sizeof(T
 
 #undef hipLaunchKernelGGL
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    hipcpu::launch(dim3(grid), dim3(block), (size_t)(shmem), [&]() { kernel(__VA_ARGS__); })
+    hipcpu::launch(#kernel, dim3(grid), dim3(block), (size_t)(shmem), [&]() { kernel(__VA_ARGS__); })
 
 // ---- synchronisation, wave exchanges ----------------------------------------------------------------------------------------
 static inline void __syncthreads() { hipcpu::syncthreads(); }
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
-#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define __builtin_amdgcn_s_sleep(n) hipcpu::yield()
 static inline unsigned long long __builtin_amdgcn_s_memtime() { return hipcpu::clock(); }
-static inline long long wall_clock64() { return (long long)hipcpu::clock(); }
+long long hipcpu_wall_clock();   // real time at 1 MHz: the device counter runs at 100 MHz, so a time-out written for the GPU is 100x longer here
+static inline long long wall_clock64() { return hipcpu_wall_clock(); }
 
 static inline unsigned long long __ballot(int pred) {
     const uint64_t* s = hipcpu::wave_publish(pred ? 1u : 0u);
@@ -145,8 +157,8 @@ template <class T, class U> static inline T atomicExch(T* p, U v) { const T o = 
 template <class T, class U> static inline T atomicCAS(T* p, U cmp, U v) { const T o = *p; if (o == (T)cmp) *p = (T)v; return o; }
 #define __HIP_MEMORY_SCOPE_AGENT 3
 #define __HIP_MEMORY_SCOPE_WORKGROUP 2
-#define __hip_atomic_fetch_add(p, v, order, scope) atomicAdd((p), (v))
-#define __hip_atomic_load(p, order, scope) (*(p))
-#define __hip_atomic_store(p, v, order, scope) (void)(*(p) = (v))
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)     // real atomics: cooperative launches
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_SEQ_CST)
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
 
 #endif  // HIPCPU_H_

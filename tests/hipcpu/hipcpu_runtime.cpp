@@ -1,11 +1,18 @@
 // hipcpu_runtime.cpp -- the execution model and the runtime API behind tests/hipcpu/hipcpu.h.  TEST TOOLING (see hipcpu.h).
 #include "hipcpu.h"
 
-#include <map>
+#include <execinfo.h>
+#include <sched.h>
+#include <signal.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <string>
+#include <thread>
 #include <vector>
 
-uint3 threadIdx, blockIdx;
-dim3 blockDim, gridDim;
+HIPCPU_TLS uint3 threadIdx, blockIdx;
+HIPCPU_TLS dim3 blockDim, gridDim;
 
 #if !defined(__x86_64__)
 #error "hipcpu's fiber switch is written for x86-64"
@@ -25,7 +32,7 @@ asm(".text\n"
 
 namespace {
 
-constexpr size_t kStack = 256 * 1024;
+constexpr size_t kStack = 256 * 1024, kStackCoop = 64 * 1024;
 
 struct Fiber {
     void* sp;
@@ -49,8 +56,10 @@ struct Block {
     std::vector<char> dyn;
 };
 
-Block* g_blk = nullptr;
-unsigned long long g_clock = 0;
+HIPCPU_TLS Block* g_blk = nullptr;
+HIPCPU_TLS unsigned long long g_clock = 0;
+HIPCPU_TLS bool g_coop = false;   // this OS thread runs one workgroup of a cooperative launch
+HIPCPU_TLS unsigned g_yields = 0;
 
 inline Fiber* next_live(Block* b, Fiber* me) {
     int i = me->lin;
@@ -100,6 +109,7 @@ void yield() {
     Fiber* me = b->cur;
     Fiber* nx = next_live(b, me);
     g_clock += 16;
+    if (g_coop && (++g_yields % (unsigned)b->n) == 0) sched_yield();   // a spinning workgroup lets the other workgroups' threads run
     if (nx != me) resume(b, me, nx);
 }
 void syncthreads() {
@@ -135,14 +145,102 @@ const uint64_t* wave_publish(uint64_t v) {
 void* dyn_shared() { return g_blk->dyn.data(); }
 unsigned long long clock() { return g_clock += 4; }
 
-void launch(dim3 grid, dim3 block, size_t dyn_shared_bytes, const std::function<void()>& body) {
-    const int n = (int)(block.x * block.y * block.z);
-    if (n <= 0 || grid.x * grid.y * grid.z == 0) return;
-    Block blk;
+// one workgroup on the calling OS thread
+static void run_block(Block& blk, dim3 grid, dim3 block, unsigned bx, unsigned by, unsigned bz, size_t stack) {
+    const int n = blk.n, nw = (n + 63) / 64;
+    g_blk = &blk;
+    gridDim = grid;
+    blockDim = block;
+    blk.live = n; blk.arrived = 0; blk.gen = 0;
+    blk.wave_arrived.assign(nw, 0); blk.wave_gen.assign(nw, 0); blk.wave_live.assign(nw, 0);
+    std::fill(blk.slot_gen.begin(), blk.slot_gen.end(), 0);
+    for (int i = 0; i < n; ++i) {
+        Fiber& f = blk.f[i];
+        f.lin = i;
+        f.tid = uint3{(unsigned)i % block.x, ((unsigned)i / block.x) % block.y, (unsigned)i / (block.x * block.y)};
+        f.done = false;
+        f.parity = 0; f.xgen = -1; f.xparity = 0;
+        blk.wave_live[i / 64]++;
+        make_fiber(&f, blk.stacks + (size_t)i * stack, stack - (size_t)((i * 37) % 64) * 64);
+    }
+    blockIdx = uint3{bx, by, bz};
+    blk.cur = &blk.f[0];
+    threadIdx = blk.f[0].tid;
+    hipcpu_switch(&blk.sched, blk.f[0].sp);
+    if (blk.live != 0) { fprintf(stderr, "hipcpu: workgroup returned with live threads\n"); abort(); }
+}
+
+static void init_block(Block& blk, int n, size_t dyn_shared_bytes, const std::function<void()>& body) {
     blk.n = n;
     blk.f.resize(n);
-    static char* pool = nullptr;
-    static size_t pool_size = 0;
+    blk.slots.assign(2 * (size_t)n + 64, 0);
+    blk.slot_gen.assign(2 * (size_t)n + 64, 0);
+    blk.dyn.assign(dyn_shared_bytes + 16, 0);
+    blk.body = &body;
+}
+
+// HIPCPU_BACKTRACE=1: print the native stack when a kernel faults (the Python fault handler only knows Python frames)
+static void segv_handler(int sig) {
+    void* frames[64];
+    const int n = backtrace(frames, 64);
+    const char msg[] = "hipcpu: fault in emulated device code; native stack:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    _exit(139);
+}
+static void install_backtrace_once() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    if (getenv("HIPCPU_BACKTRACE")) { signal(SIGSEGV, segv_handler); signal(SIGBUS, segv_handler); }
+}
+
+static bool is_cooperative(const char* name) {
+    const char* env = getenv("HIPCPU_COOPERATIVE");
+    if (!env || !*env) return false;
+    std::string list(env), kn(name);
+    size_t at = 0;
+    while (at <= list.size()) {
+        size_t comma = list.find(',', at);
+        if (comma == std::string::npos) comma = list.size();
+        const std::string item = list.substr(at, comma - at);
+        if (!item.empty() && kn.compare(0, item.size(), item) == 0) return true;
+        at = comma + 1;
+    }
+    return false;
+}
+
+void launch(const char* name, dim3 grid, dim3 block, size_t dyn_shared_bytes, const std::function<void()>& body) {
+    const int n = (int)(block.x * block.y * block.z);
+    const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+    if (n <= 0 || nblocks == 0) return;
+    install_backtrace_once();
+    if (is_cooperative(name)) {
+#ifndef HIPCPU_COOP
+        fprintf(stderr, "hipcpu: HIPCPU_COOPERATIVE names %s but this is not the HIPCPU_COOP build\n", name);
+        abort();
+#endif
+        // every workgroup resident at once: one OS thread per workgroup, each with its own fibers, LDS (thread_local) and stacks
+        std::vector<std::thread> th;
+        for (unsigned bz = 0; bz < grid.z; ++bz)
+            for (unsigned by = 0; by < grid.y; ++by)
+                for (unsigned bx = 0; bx < grid.x; ++bx)
+                    th.emplace_back([=, &body]() {
+                        Block blk;
+                        init_block(blk, n, dyn_shared_bytes, body);
+                        blk.stacks = (char*)malloc((size_t)n * kStackCoop);
+                        if (!blk.stacks) { fprintf(stderr, "hipcpu: out of memory for fiber stacks\n"); abort(); }
+                        g_coop = true;
+                        run_block(blk, grid, block, bx, by, bz, kStackCoop);
+                        free(blk.stacks);
+                    });
+        for (auto& t : th) t.join();
+        return;
+    }
+    Block blk;
+    init_block(blk, n, dyn_shared_bytes, body);
+    static HIPCPU_TLS char* pool = nullptr;
+    static HIPCPU_TLS size_t pool_size = 0;
     if (pool_size < (size_t)n * kStack) {
         free(pool);
         pool_size = (size_t)n * kStack;
@@ -150,44 +248,22 @@ void launch(dim3 grid, dim3 block, size_t dyn_shared_bytes, const std::function<
         if (!pool) { fprintf(stderr, "hipcpu: out of memory for fiber stacks\n"); abort(); }
     }
     blk.stacks = pool;
-    blk.slots.assign(2 * (size_t)n + 64, 0);
-    blk.slot_gen.assign(2 * (size_t)n + 64, 0);
-    blk.dyn.assign(dyn_shared_bytes + 16, 0);
-    const int nw = (n + 63) / 64;
-    blk.body = &body;
     Block* prev = g_blk;
     const dim3 prevGrid = gridDim, prevBlock = blockDim;
-    g_blk = &blk;
-    gridDim = grid;
-    blockDim = block;
-    // the slot array is indexed [parity][lin] with n rounded up to whole wavefronts
-    blk.n = n;
     for (unsigned bz = 0; bz < grid.z; ++bz)
         for (unsigned by = 0; by < grid.y; ++by)
-            for (unsigned bx = 0; bx < grid.x; ++bx) {
-                blk.live = n; blk.arrived = 0; blk.gen = 0;
-                blk.wave_arrived.assign(nw, 0); blk.wave_gen.assign(nw, 0); blk.wave_live.assign(nw, 0);
-                std::fill(blk.slot_gen.begin(), blk.slot_gen.end(), 0);
-                for (int i = 0; i < n; ++i) {
-                    Fiber& f = blk.f[i];
-                    f.lin = i;
-                    f.tid = uint3{(unsigned)i % block.x, ((unsigned)i / block.x) % block.y, (unsigned)i / (block.x * block.y)};
-                    f.done = false;
-                    f.parity = 0; f.xgen = -1; f.xparity = 0;
-                    blk.wave_live[i / 64]++;
-                    make_fiber(&f, blk.stacks + (size_t)i * kStack, kStack - (size_t)((i * 37) % 256) * 64);
-                }
-                blockIdx = uint3{bx, by, bz};
-                blk.cur = &blk.f[0];
-                threadIdx = blk.f[0].tid;
-                hipcpu_switch(&blk.sched, blk.f[0].sp);
-                if (blk.live != 0) { fprintf(stderr, "hipcpu: workgroup returned with live threads\n"); abort(); }
-            }
+            for (unsigned bx = 0; bx < grid.x; ++bx) run_block(blk, grid, block, bx, by, bz, kStack);
     g_blk = prev;
     gridDim = prevGrid; blockDim = prevBlock;
 }
 
 }  // namespace hipcpu
+
+long long hipcpu_wall_clock() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (long long)ts.tv_sec * 1000000ll + ts.tv_nsec / 1000;
+}
 
 // ---- runtime API: one address space, everything completes before it returns ------------------------------------------------------
 static int g_dummy_handles = 0;
