@@ -1,0 +1,56 @@
+"""Run by tests/test_emu_smoke.py in a subprocess: a few frames of a small synthetic stream through the product's kernels EXECUTED ON
+THE CPU (tests/hipcpu), next to the oracle.  Prints one JSON line.  TEST TOOLING."""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import numpy as np  # noqa: E402
+
+import emu  # noqa: E402
+
+emu.activate()
+from maskfusion_amd import MaskFusion, synth  # noqa: E402
+from oracle import mfo, mfo_mm  # noqa: E402
+
+
+def single_model(n=4, W=160, H=120):
+    f = 528.0 * W / 640.0
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
+    o = mfo.Oracle(W, H, f, f, W / 2.0, H / 2.0, capacity=1 << 17, icpWeight=100.0, so3=0)
+    mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=False, numGSurfels=1 << 17)
+    out = []
+    for k in range(n):
+        rgb, d, _ = st.frame(k)
+        mf.processFrame(rgb, d, timestamp=k)
+        o.process_frame(rgb, d)
+        out.append(dict(count=int(mf.getBackgroundModel().lastCount()), ocount=int(o.count), pose_diff=float(np.abs(mf.getCurrPose() - o.pose).max()),
+                        inliers=float(mf.trackStats(0)["lastICPCount"])))
+    mf.close(); o.close()
+    return out
+
+
+def rgbd_so3(n=3, W=160, H=120):
+    """the GUI configuration: photometric term at weight 20 + SO(3) pre-alignment (two launches per iteration, the RGB-D kernels)"""
+    f = 528.0 * W / 640.0
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
+    o = mfo.Oracle(W, H, f, f, W / 2.0, H / 2.0, capacity=1 << 17, icpWeight=20.0, so3=1)
+    mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=20.0, so3=True, enableMultipleModels=False, numGSurfels=1 << 17)
+    out = []
+    for k in range(n):
+        rgb, d, _ = st.frame(k)
+        mf.processFrame(rgb, d, timestamp=k)
+        o.process_frame(rgb, d)
+        s = mf.trackStats(0)
+        out.append(dict(count=int(mf.getBackgroundModel().lastCount()), ocount=int(o.count), pose_diff=float(np.abs(mf.getCurrPose() - o.pose).max()),
+                        rgb_count=float(s["lastRGBCount"]), so3_iterations=float(s["so3Iterations"])))
+    mf.close(); o.close()
+    return out
+
+
+if __name__ == "__main__":
+    print(json.dumps(dict(single=single_model(), rgbd=rgbd_so3())))
