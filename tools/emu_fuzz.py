@@ -1,0 +1,129 @@
+"""Differential fuzzing of the kernel logic without a GPU: random small scenes, image sizes, holes, empty frames and parameter sets through
+the product's kernels EXECUTED ON THE CPU (tests/hipcpu) next to the oracle.  Development tooling; prints every disagreement.
+    python tools/emu_fuzz.py [n_cases] [seed0]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "hipcpu"))
+import numpy as np  # noqa: E402
+
+import emu  # noqa: E402
+
+emu.activate()
+from maskfusion_amd import MaskFusion, synth  # noqa: E402
+from oracle import mfo, mfo_rgbd  # noqa: E402
+
+
+def one(seed):
+    rng = np.random.default_rng(seed)
+    W = int(rng.choice([64, 80, 96, 128, 160, 176, 208, 240, 320]))
+    H = int(rng.choice([48, 64, 80, 96, 120, 144, 160, 240]))
+    f = float(rng.uniform(0.6, 1.2) * W)
+    cx, cy = W / 2.0 + float(rng.uniform(-6, 6)), H / 2.0 + float(rng.uniform(-6, 6))
+    icpw = float(rng.choice([100.0, 100.0, 20.0, 10.0]))
+    so3 = bool(rng.integers(0, 2)) if icpw < 100 else False
+    fast = bool(rng.integers(0, 2))
+    noise = bool(rng.integers(0, 2))
+    n = int(rng.integers(3, 7))
+    given = bool(rng.integers(0, 2))        # poses supplied (inPose = ground truth): the surfel passes alone, no tracking in between
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=cx, cy=cy, noise=noise, seed=int(seed))
+    cap = 1 << 17
+    o = mfo.Oracle(W, H, f, f, cx, cy, capacity=cap, icpWeight=icpw, so3=int(so3), fastOdom=int(fast))
+    mf = MaskFusion(W, H, f, f, cx, cy, icpThresh=icpw, so3=so3, fastOdom=fast, enableMultipleModels=False, numGSurfels=cap)
+    desc = f"seed {seed}: {W}x{H} f={f:.1f} icpW={icpw} so3={so3} fast={fast} noise={noise} n={n} given={given}"
+    bad = []
+    for k in range(n):
+        rgb, d, _ = st.frame(k)
+        d = d.copy()
+        mode = rng.integers(0, 10) if k > 0 else 9       # frame 0 (the first model) stays intact: a map seeded from a frame with 30 % salt holes tracks chaotically on both sides
+        if mode == 0 and k > 0:
+            d[:] = 0                                            # an empty depth frame
+        elif mode == 1:
+            y0, x0 = int(rng.integers(0, H // 2)), int(rng.integers(0, W // 2))
+            d[y0:y0 + H // 3, x0:x0 + W // 3] = 0              # a large hole
+        elif mode == 2:
+            d[rng.random((H, W)) < 0.3] = 0                     # salt holes
+        elif mode == 3:
+            d[:, : W // 2] = 25.0                               # beyond maxDepthProcessed
+        if given and k > 0:
+            P = st.gt_pose(k).astype(np.float32)
+            mf.processFrame(rgb, d, timestamp=k, inPose=P)
+            o.process_frame(rgb, d, in_pose=P)
+        else:
+            mf.processFrame(rgb, d, timestamp=k)
+            o.process_frame(rgb, d)
+        cg, co = int(mf.getBackgroundModel().lastCount()), int(o.count)
+        pd = float(np.abs(mf.getCurrPose() - o.pose).max())
+        so = mfo_rgbd.track_stats(o)
+        if k > 0 and not given and not (so.lastICPCount > 0.2 * W * H and so.lastICPError < 1e-3 and np.abs(o.pose - st.gt_pose(k)).max() < 0.02):
+            break        # tracking has failed on the oracle's side (singular systems, garbage poses on both sides): nothing to compare from here on
+        # each side filters the depth itself (exp2 vs expf): on noise-free streams exact depth ties flip a few surfels
+        tol_c = (0 if (noise and given) else max(4, co // 100)) if icpw >= 100 else max(5, co // 100)
+        if abs(cg - co) > tol_c or not (pd < (1e-6 if given else 3e-4)):
+            bad.append((k, int(mode), cg, co, pd))
+    mf.close(); o.close()
+    return desc, bad
+
+
+def one_mm(seed):
+    """multi-model frames: global projection, geometric edges, label stage, spawn, masked fusion / clean (standing objects)"""
+    from oracle import mfo_mm
+    rng = np.random.default_rng(seed)
+    W, H = [(320, 240), (240, 160), (256, 192), (400, 240)][int(rng.integers(0, 4))]
+    f = 528.0 * W / 640.0 * float(rng.uniform(0.9, 1.1))
+    n_obj = int(rng.integers(1, 4))
+    spawn = int(rng.integers(1, 5))
+    n = int(rng.integers(spawn + 3, spawn + 8))
+    seg = dict(threshold=0.3, weightDistance=150.0, weightConvexity=2.8, morphEdgeIterations=int(rng.integers(0, 2)), morphMaskIterations=int(rng.integers(0, 2)),
+               minRelSizeNew=0.004)
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, n_objects=n_obj, noise=True, object_motion=0.0, seed=int(seed))
+    cls = [0] + [41 + i for i in range(n_obj)]
+    o = mfo_mm.OracleMM(W, H, f, f, W / 2.0, H / 2.0, icpWeight=100.0, so3=0, capacity=1 << 18, capacityObject=1 << 16, modelSpawnOffset=spawn,
+                        trackAllModels=0, seg=seg)
+    m = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, numGSurfels=1 << 18, numOSurfels=1 << 16, enableMultipleModels=True,
+                   modelSpawnOffset=spawn, trackAllModels=False)
+    for k, v in (("mfThreshold", seg["threshold"]), ("mfWeightDistance", seg["weightDistance"]), ("mfWeightConvexity", seg["weightConvexity"]),
+                 ("mfMorphEdgeIterations", seg["morphEdgeIterations"]), ("mfMorphMaskIterations", seg["morphMaskIterations"]),
+                 ("newModelMinRelativeSize", seg["minRelSizeNew"])):
+        m.setParam(k, v)
+    desc = f"seed {seed}: MM {W}x{H} objects={n_obj} spawnOffset={spawn} n={n} morph={seg['morphEdgeIterations']}/{seg['morphMaskIterations']}"
+    bad = []
+    for k in range(n):
+        rgb, d, mask = st.frame(k)
+        o.process_frame(rgb, d, mask, cls)
+        m.processFrame(rgb, d, mask=mask, classIDs=cls, timestamp=k)
+        gm = m.getModels()
+        oi, gi = [o.model_id(i) for i in range(o.n_models)], [x.getID() for x in gm]
+        if oi != gi:
+            bad.append((k, "ids", oi, gi))
+            break
+        segd = float((o.segmentation() != m.downloadSegmentation()).mean())
+        pd = max(float(np.abs(o.model_pose(i) - gm[i].getPose()).max()) for i in range(len(gm)))
+        # counts: each side filters the depth itself, a handful of surfels on threshold differ (tests/test_gpu_multimodel.py uses the same gate)
+        cd = max((abs(o.model_count(i) - gm[i].lastCount()) - 20) / max(1.0, o.model_count(i)) for i in range(len(gm)))
+        if segd > 5e-3 or pd > 3e-4 or cd > 0.01:
+            bad.append((k, "seg/pose/count", segd, pd, cd))
+    o.close(); m.close()
+    return desc, bad
+
+
+if __name__ == "__main__":
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    mm = "mm" in sys.argv
+    t0 = time.time()
+    nbad = 0
+    for s in range(seed0, seed0 + n_cases):
+        try:
+            desc, bad = (one_mm if mm else one)(s)
+        except Exception as e:                                  # noqa: BLE001
+            desc, bad = f"seed {s}", [("exception", repr(e))]
+        if bad:
+            nbad += 1
+            print("DISAGREE", desc, bad, flush=True)
+        else:
+            print("ok      ", desc, flush=True)
+    print(f"{n_cases} cases, {nbad} with disagreements, {time.time() - t0:.0f} s")
