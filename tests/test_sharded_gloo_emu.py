@@ -1,0 +1,115 @@
+"""The SPMD form of the model-sharded scene end to end on the CPU: two ranks under `gloo`, each with its own context of the product's
+kernels EXECUTED ON THE CPU (tests/hipcpu), frames broadcast from rank 0, projection keys all-reduced (MIN), states gathered, labels and
+the control record broadcast -- against ONE context holding every model.  Label images, poses, ids, counts and the final surfel clouds
+must be bit-identical: sharding moves models, it does not change an operation (the GPU twin is tests/test_gpu_sharded.py,
+the orchestration-only twin tests/test_sharded_gloo.py).  Everything runs in subprocesses: the emulated library is test tooling and
+never enters this process."""
+import os
+import pickle
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, F, N_FRAMES = 240, 160, 198.0, 9
+SEG = dict(mfThreshold=0.3, mfWeightDistance=150.0, mfWeightConvexity=2.8, mfMorphEdgeIterations=0, mfMorphMaskIterations=0,
+           newModelMinRelativeSize=0.004)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _activate():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hipcpu"))
+    import emu
+    emu.activate()
+
+
+def _make(track_all):
+    from maskfusion_amd import MaskFusion
+    m = MaskFusion(W, H, F, F, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, numGSurfels=1 << 17, numOSurfels=1 << 15, enableMultipleModels=True,
+                   modelSpawnOffset=2, trackAllModels=track_all)
+    for k, v in SEG.items():
+        m.setParam(k, v)
+    m.setParam("batchTracking", 0)
+    return m
+
+
+def _frames(track_all):
+    from maskfusion_amd import synth
+    st = synth.Stream(W=W, H=H, fx=F, fy=F, cx=W / 2.0, cy=H / 2.0, n_objects=2, noise=True, object_motion=1.0 if track_all else 0.0)
+    return [st.frame(k) for k in range(N_FRAMES)]
+
+
+def _one_context(_rank, out_dir, track_all):
+    _activate()
+    frames, one, rec = _frames(track_all), _make(track_all), []
+    for k, (rgb, depth, mask) in enumerate(frames):
+        one.processFrame(rgb, depth, mask=mask, classIDs=[0, 41, 42], timestamp=k)
+        ms = one.getModels()
+        rec.append(dict(ids=[m.getID() for m in ms], poses=[m.getPose() for m in ms], counts=[m.lastCount() for m in ms], seg=one.downloadSegmentation(),
+                        clouds=[m.downloadMap() for m in ms] if k == N_FRAMES - 1 else None))
+    one.close()
+    pickle.dump(rec, open(os.path.join(out_dir, "one.pkl"), "wb"))
+
+
+def _spmd(rank, world, port, out_dir, track_all):
+    _activate()
+    import torch
+    import torch.distributed as dist
+    from maskfusion_amd import sharded
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mf = _make(track_all)
+    sm = sharded.ShardedMaskFusion(mf, torch.device("cpu"), sharded.default_cfg(trackAllModels=track_all, modelSpawnOffset=2))
+    frames = _frames(track_all) if rank == 0 else None
+    rec = []
+    for k in range(N_FRAMES):
+        if rank == 0:
+            rgb, depth, mask = frames[k]
+            sm.process_frame(rgb, depth, mask, [0, 41, 42], 1.0, k)
+        else:
+            sm.process_frame(timestamp=k)
+        ms = mf.getModels()
+        own = [(i, m) for i, m in enumerate(ms) if not (rank > 0 and i == 0)]        # rank > 0: model 0 is the background stand-in
+        rec.append(dict(ids=[m.getID() for _, m in own], poses=[m.getPose() for _, m in own], counts=[m.lastCount() for _, m in own],
+                        seg=mf.downloadSegmentation(), clouds=[m.downloadMap() for _, m in own] if k == N_FRAMES - 1 else None))
+    mf.close()
+    pickle.dump(rec, open(os.path.join(out_dir, f"rank{rank}.pkl"), "wb"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("track_all", [False, True], ids=["static-objects", "tracked-objects"])
+def test_two_ranks_equal_one_context(tmp_path, track_all):
+    mp.spawn(_one_context, args=(str(tmp_path), track_all), nprocs=1, join=True)
+    mp.spawn(_spmd, args=(2, _free_port(), str(tmp_path), track_all), nprocs=2, join=True)
+    one = pickle.load(open(tmp_path / "one.pkl", "rb"))
+    ranks = [pickle.load(open(tmp_path / f"rank{r}.pkl", "rb")) for r in range(2)]
+    most = 0
+    for k in range(N_FRAMES):
+        want = one[k]
+        got = {}
+        for r in range(2):
+            for j, mid in enumerate(ranks[r][k]["ids"]):
+                got[mid] = (ranks[r][k]["poses"][j], ranks[r][k]["counts"][j], ranks[r][k]["clouds"][j] if ranks[r][k]["clouds"] else None, r)
+        assert sorted(got) == sorted(want["ids"]), k
+        most = max(most, len(ranks[1][k]["ids"]))
+        assert np.array_equal(ranks[0][k]["seg"], want["seg"]), k
+        if k > 0:
+            assert np.array_equal(ranks[1][k]["seg"], want["seg"]), k                  # the label image reached the object rank
+        for i, mid in enumerate(want["ids"]):
+            pose, count, cloud, r = got[mid]
+            assert r == (0 if mid == 0 else 1), (k, mid)                                # objects live on rank 1, the background on rank 0
+            assert np.array_equal(pose, want["poses"][i]), (k, mid, np.abs(pose - want["poses"][i]).max())
+            assert count == want["counts"][i], (k, mid)
+            if want["clouds"] is not None:
+                assert np.array_equal(cloud, want["clouds"][i], equal_nan=True), (k, mid)
+    # standing boxes: both objects spawn; moving boxes are dropped by the jump rule and re-spawned along the way (identically on both sides)
+    assert max(len(r["ids"]) for r in one) >= (2 if track_all else 3) and most >= (1 if track_all else 2), "the scenario must spawn object models, on rank 1"
