@@ -7,6 +7,9 @@
 //   barrier   : thread 0 of every workgroup arrives on a device-scope counter and spins until all 240 have        -> barrier only
 //   exchange  : every workgroup first writes its own 128 B partial, then the barrier, then reads all 240 x 128 B  -> the ICP exchange
 //   exchange+gather : + a dependent image gather after the exchange (as the model-map gather after the solve)
+//   xcd-local : the same exchange among the 30 workgroups with blockIdx % 8 == 0 only (workgroups are dealt round-robin to the 8 XCDs, so
+//               these share one L2): is a barrier that never leaves an XCD cheaper?  (The coarse pyramid levels -- 19 200 and 76 800
+//               pixels -- could run their 9 iterations on one XCD's 32 CUs.)
 // Release / acquire at agent scope around the counter (the L2s of the 8 XCDs are not coherent with each other for plain accesses).
 // Every spin is bounded: if a barrier does not complete within ~50 ms the kernel sets an error flag and returns -- it cannot hang.
 // Build: hipcc --offload-arch=gfx950 -O3 grid_barrier.hip -o grid_barrier        Run: timeout 60 ./grid_barrier
@@ -29,11 +32,33 @@ __device__ __forceinline__ bool grid_barrier(unsigned* counter, unsigned target,
     return __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
 }
 
-// mode 0: barrier only; 1: + exchange; 2: + dependent gather
+// mode 0: barrier only; 1: + exchange; 2: + dependent gather; 3: exchange among the workgroups of XCD 0 only
 __global__ __launch_bounds__(kThreads) void k_persistent(float* __restrict__ bufA, float* __restrict__ bufB, const float* __restrict__ img,
                                                          unsigned* counter, unsigned* err, int rounds, int mode, float* sink) {
     __shared__ float s[kThreads];
     float v = (float)blockIdx.x;
+    if (mode == 3) {
+        if (blockIdx.x % 8 != 0) return;
+        const unsigned members = (kBlocks + 7) / 8;
+        for (int r = 0; r < rounds; ++r) {
+            float* out = (r & 1) ? bufB : bufA;
+            if (threadIdx.x < 32) out[blockIdx.x * 32 + threadIdx.x] = v * 1e-9f + (float)threadIdx.x;
+            if (!grid_barrier(counter, (unsigned)(r + 1) * members, err)) return;
+            const float4* p4 = reinterpret_cast<const float4*>(out);
+            float acc = 0.f;
+            for (int f = threadIdx.x; f < (int)members * 8; f += kThreads) {
+                const float4 q = p4[(f / 8) * 64 + (f % 8)];      // partial of workgroup 8 * (f / 8)
+                acc += q.x + q.y + q.z + q.w;
+            }
+            s[threadIdx.x] = acc;
+            __syncthreads();
+            for (int o = kThreads / 2; o > 0; o >>= 1) { if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o]; __syncthreads(); }
+            v = s[0];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) sink[blockIdx.x] = v;
+        return;
+    }
     for (int r = 0; r < rounds; ++r) {
         float* out = (r & 1) ? bufB : bufA;
         if (mode >= 1 && threadIdx.x < 32) out[blockIdx.x * 32 + threadIdx.x] = v * 1e-9f + (float)threadIdx.x;
@@ -65,9 +90,9 @@ int main() {
     hipMalloc(&counter, 4); hipMalloc(&err, 4);
     hipMemset(a, 0, kBlocks * 32 * 4); hipMemset(b, 0, kBlocks * 32 * 4); hipMemset(img, 0, 307200 * 4);
     const int rounds = 200;
-    const char* names[3] = {"barrier", "exchange", "exchange+gather"};
+    const char* names[4] = {"barrier", "exchange", "exchange+gather", "xcd-local"};
     printf("us per round inside one persistent launch of <<<%d, %d>>> (%d rounds):\n", kBlocks, kThreads, rounds);
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
         float best = 1e30f;
         unsigned herr = 0;
         for (int rep = 0; rep < 5 && !herr; ++rep) {
