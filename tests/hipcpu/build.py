@@ -20,6 +20,9 @@ CSRC = os.path.join(ROOT, "maskfusion_amd", "csrc")
 OUT = os.path.join(os.path.dirname(HERE), "_build")
 LIB = os.path.join(OUT, "libmaskfusion_emu.so")
 LIB_COOP = os.path.join(OUT, "libmaskfusion_emu_coop.so")     # -DHIPCPU_COOP: cooperative launches possible, slower (see hipcpu.h)
+LIB_ASAN = os.path.join(OUT, "libmaskfusion_emu_asan.so")     # -fsanitize=address: out-of-bounds / use-after-free accesses of "device" memory
+                                                              # (every hipMalloc is a malloc) abort with a report -- run under
+                                                              # LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0
 sys.path.insert(0, ROOT)
 from maskfusion_amd.build import SOURCES, HEADERS  # noqa: E402
 
@@ -42,15 +45,21 @@ def _stale(lib) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, only=None, coop: bool = False) -> str:
-    lib = LIB_COOP if coop else LIB
-    cxx = CXX + (["-DHIPCPU_COOP"] if coop else [])
+LIB_UBSAN = os.path.join(OUT, "libmaskfusion_emu_ubsan.so")   # -fsanitize=undefined: LDS / local array indices out of bounds, misaligned vector accesses,
+                                                              # shifts, signed overflow ... reported on stderr (UBSAN_OPTIONS=print_stacktrace=1)
+
+
+def build(force: bool = False, only=None, coop: bool = False, asan: bool = False, ubsan: bool = False) -> str:
+    lib = LIB_UBSAN if ubsan else LIB_ASAN if asan else (LIB_COOP if coop else LIB)
+    cxx = CXX + (["-DHIPCPU_COOP"] if coop else []) + (["-fsanitize=address", "-fno-omit-frame-pointer", "-g1"] if asan else [])
+    if ubsan:
+        cxx = CXX + ["-fsanitize=undefined", "-fno-sanitize=float-cast-overflow", "-fno-omit-frame-pointer", "-g1"]
     if not (force or _stale(lib)) and only is None:
         return lib
     os.makedirs(OUT, exist_ok=True)
     objs = []
     for src in SOURCES:
-        obj = os.path.join(OUT, ("emuc_" if coop else "emu_") + src.replace(".hip", ".o"))
+        obj = os.path.join(OUT, ("emuu_" if ubsan else "emua_" if asan else "emuc_" if coop else "emu_") + src.replace(".hip", ".o"))
         objs.append(obj)
         if only is not None and src not in only:
             continue
@@ -61,12 +70,12 @@ def build(force: bool = False, only=None, coop: bool = False) -> str:
             raise SystemExit(1)
     if only is not None:
         return ""
-    rt = os.path.join(OUT, "emuc_runtime.o" if coop else "emu_runtime.o")
+    rt = os.path.join(OUT, "emuu_runtime.o" if ubsan else "emua_runtime.o" if asan else "emuc_runtime.o" if coop else "emu_runtime.o")
     subprocess.check_call([*cxx, "-c", os.path.join(HERE, "hipcpu_runtime.cpp"), "-o", rt])
-    subprocess.check_call(["g++", "-shared", "-pthread", "-o", lib, *objs, rt])
+    subprocess.check_call(["g++", "-shared", "-pthread", *(["-fsanitize=address"] if asan else ["-fsanitize=undefined"] if ubsan else []), "-o", lib, *objs, rt])
     return lib
 
 
 if __name__ == "__main__":
     only = [a for a in sys.argv[1:] if a.endswith(".hip")] or None
-    print(build(force=True, only=only, coop="--coop" in sys.argv))
+    print(build(force=True, only=only, coop="--coop" in sys.argv, asan="--asan" in sys.argv, ubsan="--ubsan" in sys.argv))

@@ -15,11 +15,13 @@ _emu = None
 
 
 def load():
-    """MF_EMU_COOP=1 selects the build that can run all workgroups of a launch at once (kernels named in HIPCPU_COOPERATIVE)"""
+    """MF_EMU_COOP=1 selects the build that can run all workgroups of a launch at once (kernels named in HIPCPU_COOPERATIVE);
+    MF_EMU_ASAN=1 the AddressSanitizer build (start Python under LD_PRELOAD=libasan.so, see tests/hipcpu/build.py)"""
     global _emu
     if _emu is None:
         from maskfusion_amd import lib as mflib
-        L = C.CDLL(_build.build(coop=os.environ.get("MF_EMU_COOP") == "1"))
+        L = C.CDLL(_build.build(coop=os.environ.get("MF_EMU_COOP") == "1", asan=os.environ.get("MF_EMU_ASAN") == "1",
+                                 ubsan=os.environ.get("MF_EMU_UBSAN") == "1"))
         for name, (res, args) in mflib.SYMBOLS.items():
             fn = getattr(L, name)
             fn.restype = res
