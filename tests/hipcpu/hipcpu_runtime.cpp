@@ -61,9 +61,17 @@ HIPCPU_TLS unsigned long long g_clock = 0;
 HIPCPU_TLS bool g_coop = false;   // this OS thread runs one workgroup of a cooperative launch
 HIPCPU_TLS unsigned g_yields = 0;
 
+// HIPCPU_SCHEDULE=reverse: threads of a workgroup are resumed in descending order and workgroups run last to first.  Kernels without
+// data races (and without order-dependent float atomics) must produce the same bits under both schedules: a cheap race detector.
+static int g_reverse = -1;
+inline bool reverse_schedule() {
+    if (g_reverse < 0) { const char* e = getenv("HIPCPU_SCHEDULE"); g_reverse = (e && !strcmp(e, "reverse")) ? 1 : 0; }
+    return g_reverse == 1;
+}
 inline Fiber* next_live(Block* b, Fiber* me) {
     int i = me->lin;
-    do { i = (i + 1 == b->n) ? 0 : i + 1; } while (b->f[i].done && i != me->lin);
+    if (reverse_schedule()) { do { i = (i == 0) ? b->n - 1 : i - 1; } while (b->f[i].done && i != me->lin); }
+    else { do { i = (i + 1 == b->n) ? 0 : i + 1; } while (b->f[i].done && i != me->lin); }
     return &b->f[i];
 }
 inline void resume(Block* b, Fiber* from, Fiber* to) {
@@ -164,9 +172,10 @@ static void run_block(Block& blk, dim3 grid, dim3 block, unsigned bx, unsigned b
         make_fiber(&f, blk.stacks + (size_t)i * stack, stack - (size_t)((i * 37) % 64) * 64);
     }
     blockIdx = uint3{bx, by, bz};
-    blk.cur = &blk.f[0];
-    threadIdx = blk.f[0].tid;
-    hipcpu_switch(&blk.sched, blk.f[0].sp);
+    Fiber* first = &blk.f[reverse_schedule() ? n - 1 : 0];
+    blk.cur = first;
+    threadIdx = first->tid;
+    hipcpu_switch(&blk.sched, first->sp);
     if (blk.live != 0) { fprintf(stderr, "hipcpu: workgroup returned with live threads\n"); abort(); }
 }
 
@@ -250,9 +259,11 @@ void launch(const char* name, dim3 grid, dim3 block, size_t dyn_shared_bytes, co
     blk.stacks = pool;
     Block* prev = g_blk;
     const dim3 prevGrid = gridDim, prevBlock = blockDim;
+    const bool rev = reverse_schedule();
     for (unsigned bz = 0; bz < grid.z; ++bz)
         for (unsigned by = 0; by < grid.y; ++by)
-            for (unsigned bx = 0; bx < grid.x; ++bx) run_block(blk, grid, block, bx, by, bz, kStack);
+            for (unsigned bx = 0; bx < grid.x; ++bx)
+                run_block(blk, grid, block, rev ? grid.x - 1 - bx : bx, rev ? grid.y - 1 - by : by, rev ? grid.z - 1 - bz : bz, kStack);
     g_blk = prev;
     gridDim = prevGrid; blockDim = prevBlock;
 }
