@@ -54,12 +54,15 @@ def build(force: bool = False, only=None, coop: bool = False, asan: bool = False
     cxx = CXX + (["-DHIPCPU_COOP"] if coop else []) + (["-fsanitize=address", "-fno-omit-frame-pointer", "-g1"] if asan else [])
     if ubsan:
         cxx = CXX + ["-fsanitize=undefined", "-fno-sanitize=float-cast-overflow", "-fno-omit-frame-pointer", "-g1"]
+    tag = "emuu_" if ubsan else "emua_" if asan else "emuc_" if coop else "emu_"
+    if coop and asan:                       # all workgroups resident AND AddressSanitizer: for kernels with device-wide barriers
+        lib, tag = os.path.join(OUT, "libmaskfusion_emu_coop_asan.so"), "emuca_"
     if not (force or _stale(lib)) and only is None:
         return lib
     os.makedirs(OUT, exist_ok=True)
     objs = []
     for src in SOURCES:
-        obj = os.path.join(OUT, ("emuu_" if ubsan else "emua_" if asan else "emuc_" if coop else "emu_") + src.replace(".hip", ".o"))
+        obj = os.path.join(OUT, tag + src.replace(".hip", ".o"))
         objs.append(obj)
         if only is not None and src not in only:
             continue
@@ -70,7 +73,7 @@ def build(force: bool = False, only=None, coop: bool = False, asan: bool = False
             raise SystemExit(1)
     if only is not None:
         return ""
-    rt = os.path.join(OUT, "emuu_runtime.o" if ubsan else "emua_runtime.o" if asan else "emuc_runtime.o" if coop else "emu_runtime.o")
+    rt = os.path.join(OUT, tag + "runtime.o")
     subprocess.check_call([*cxx, "-c", os.path.join(HERE, "hipcpu_runtime.cpp"), "-o", rt])
     subprocess.check_call(["g++", "-shared", "-pthread", *(["-fsanitize=address"] if asan else ["-fsanitize=undefined"] if ubsan else []), "-o", lib, *objs, rt])
     return lib

@@ -270,10 +270,14 @@ void launch(const char* name, dim3 grid, dim3 block, size_t dyn_shared_bytes, co
 
 }  // namespace hipcpu
 
+// real time in microseconds, divided by HIPCPU_CLOCK_DIV (default 1): device code written against a 100 MHz counter sees time pass 100x
+// (or 100 x DIV) more slowly, so a time-out meant for the GPU leaves room for 240 OS threads on a few cores (and for a sanitizer)
 long long hipcpu_wall_clock() {
+    static long long div = 0;
+    if (div == 0) { const char* e = getenv("HIPCPU_CLOCK_DIV"); div = (e && atoll(e) > 0) ? atoll(e) : 1; }
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
-    return (long long)ts.tv_sec * 1000000ll + ts.tv_nsec / 1000;
+    return ((long long)ts.tv_sec * 1000000ll + ts.tv_nsec / 1000) / div;
 }
 
 // ---- runtime API: one address space, everything completes before it returns ------------------------------------------------------
