@@ -154,7 +154,9 @@ int mf_get_last_fillin(mf_ctx* ctx, int32_t* used);
  * "splatTiles" (1), "globalTiles" (1: GlobalProjection of the background through tile lists), "gpuLabels" (1: label stage on the
  * device), "batchTracking" (1: one Gauss-Newton launch serves every tracked model), "earlyBackgroundFusion" (1), "overlapPreprocessing"
  * (0), "cleanLiteralWindow" (1: Model::clean walks its window with copy_unstable.vert's own fp32 trip count, 4 or 5 taps per axis;
- * 0: 4 x 4), "timings", "icpProfile".  Experimental, default 0, not yet validated on hardware: "persistentIcp" (the geometric Gauss-Newton
+ * 0: 4 x 4), "timings", "icpProfile", "gnLoopGraph" (0; 1: the launches of the geometric Gauss-Newton loop of a tracking step are captured
+ * once per frame parity with hipStreamBeginCapture / EndCapture and replayed as one hipGraphLaunch -- same kernels, same arguments, same
+ * bits; if the runtime refuses the capture the eager launches are used and mf_get_param reads 0 again).  Experimental, default 0, not yet validated on hardware: "persistentIcp" (the geometric Gauss-Newton
  * loop of a single-model tracking step as ONE persistent launch with device-wide barriers between the iterations instead of 19 dependent
  * launches; a barrier that times out makes mf_sync return MF_ESTATE, it cannot hang). */
 int mf_set_param(mf_ctx* ctx, const char* key, double value);

@@ -39,8 +39,12 @@ struct ModelState {
     std::vector<int64_t> log_ts;           // timestamps of the entries (host side of PoseLogItem)
     PoseDev* h_pose = nullptr; FrameDev* h_frame = nullptr; int* h_count = nullptr;
     TrackModelDev track_host;              // host copy of *d_track (pose_host is filled in once h_pose exists)
+    // "gnLoopGraph": the launches of the geometric Gauss-Newton loop captured once per frame parity and replayed as one hipGraph
+    hipGraphExec_t gn_graph[2] = {nullptr, nullptr};
+    unsigned gn_graph_key[2] = {0, 0};     // iteration schedule the graph was captured for
     std::vector<void*> allocs;
     ~ModelState() {
+        for (int i = 0; i < 2; ++i) if (gn_graph[i]) (void)hipGraphExecDestroy(gn_graph[i]);
         for (void* p : allocs) (void)hipFree(p);
         if (h_pose) (void)hipHostFree(h_pose);
         if (h_frame) (void)hipHostFree(h_frame);
@@ -137,6 +141,7 @@ struct mf_ctx {
     bool map_ready = false;            // the background map exists (first frame processed, Model::initialise or an uploaded map)
     bool tracked_once = false;         // a tracking step has run (its stage timings are meaningful)
     bool timings_on = false, icp_prof_on = false;
+    bool gn_loop_graph = false;                        // the launch-per-iteration loop replayed as a captured hipGraph ("gnLoopGraph")
     bool persistent_icp = false;                       // experimental: the geometric loop as one launch with device-wide barriers ("persistentIcp")
     unsigned* d_grid_barrier = nullptr;                // [0] arrival counter (monotonic), [1] sticky time-out flag
     unsigned grid_barrier_base = 0;                    // host copy of what the counter will be when the next launch starts
@@ -527,6 +532,8 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
         return;
     }
     int k = 0, nb_prev = 0, prev_level = -1;
+    // every launch of the loop and its finalize; called once eagerly, or once under stream capture (gnLoopGraph)
+    auto issue_loop = [&](bool with_marks) {
     for (int lvl = 2; lvl >= 0; --lvl) {
         const float div = (float)(1 << lvl);
         for (int j = 0; j < iters[lvl]; ++j) {
@@ -570,7 +577,7 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
             ++k;
         }
     }
-    if (timed) (void)hipEventRecord(c->ev_icp[1], s);
+    if (with_marks && timed) (void)hipEventRecord(c->ev_icp[1], s);
     float* log_out = (k > 0 && m.id == 0) ? c->d_icp_log + 32 * (k - 1) : nullptr;
     if (!rgb)
         launch_icp_finalize(nb_prev ? m.d_partials[(k + 1) & 1] : nullptr, nb_prev, &m.d_gn[k & 1], m.d_pose, m.h_pose, log_out,
@@ -579,6 +586,33 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
         launch_rgbd_finalize(nb_prev ? m.d_partials[(k + 1) & 1] : nullptr, nb_prev ? c->d_rgb_partials[(k + 1) & 1] : nullptr,
                              nb_prev ? c->d_cnt[(k + 1) & 1] : nullptr, nb_prev, g.icp_weight, icp ? 1 : 0, g.rgb_only ? 1 : 0, 1,
                              prev_level, &m.d_gn[k & 1], so3_seed, m.d_pose, m.h_pose, log_out, jump_limit, s);
+    };
+    // "gnLoopGraph": the loop is a chain of launch-bound launches whose arguments depend only on the frame parity -> capture it once per
+    // parity, replay it with one hipGraphLaunch.  Geometric term without SO(3) seed and without profiling stamps only; any failure of the
+    // capture API falls back to the eager launches below (and switches the option off), it is never an error.
+    if (c->gn_loop_graph && !rgb && !so3_seed && !c->icp_prof_on) {
+        const unsigned key = 1u + (unsigned)iters[0] + 16u * (unsigned)iters[1] + 256u * (unsigned)iters[2] + 4096u * (unsigned)(jump_limit > 0.f);
+        if (!m.gn_graph[set] || m.gn_graph_key[set] != key) {
+            if (m.gn_graph[set]) { (void)hipGraphExecDestroy(m.gn_graph[set]); m.gn_graph[set] = nullptr; }
+            hipGraph_t graph = nullptr;
+            bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                issue_loop(false);
+                ok = hipStreamEndCapture(s, &graph) == hipSuccess && graph != nullptr;
+            }
+            if (ok) ok = hipGraphInstantiate(&m.gn_graph[set], graph, nullptr, nullptr, 0) == hipSuccess;
+            if (graph) (void)hipGraphDestroy(graph);
+            if (!ok) { (void)hipGetLastError(); m.gn_graph[set] = nullptr; c->gn_loop_graph = false; }
+            m.gn_graph_key[set] = key;
+            k = 0; nb_prev = 0; prev_level = -1;
+        }
+        if (m.gn_graph[set] && hipGraphLaunch(m.gn_graph[set], s) == hipSuccess) {
+            if (timed) (void)hipEventRecord(c->ev_icp[1], s);
+            return;
+        }
+        c->gn_loop_graph = false;
+    }
+    issue_loop(true);
 }
 
 // The same for several models at once (geometric term only; MaskFusion.cpp:247-276 tracks the models one after the other, their
@@ -1697,6 +1731,7 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     }
     if (!strcmp(key, "batchTracking")) { c->batch_tracking = value != 0; return MF_OK; }
     if (!strcmp(key, "persistentIcp")) { c->persistent_icp = value != 0; return MF_OK; }   // experimental, see k_icp_persist
+    if (!strcmp(key, "gnLoopGraph")) { c->gn_loop_graph = value != 0; return MF_OK; }      // the Gauss-Newton launches as a replayed hipGraph
     if (!strcmp(key, "globalTiles")) { c->global_tiles = value != 0; return MF_OK; }
     if (!strcmp(key, "cleanLiteralWindow")) { c->clean_literal = value != 0; return MF_OK; }   // 0: the exact-arithmetic 4 x 4 window
     if (!strcmp(key, "earlyBackgroundFusion")) { c->early_bg_fusion = value != 0; return MF_OK; }
@@ -1729,6 +1764,8 @@ extern "C" int mf_get_param(mf_ctx* c, const char* key, double* value) {
     if (!c || !key || !value) return MF_EINVAL;
     if (!strcmp(key, "confidenceThreshold")) { *value = c->models[0]->confThr; return MF_OK; }
     if (!strcmp(key, "splatTileEntries")) { *value = c->tile_entries_cap; return MF_OK; }
+    if (!strcmp(key, "gnLoopGraph")) { *value = c->gn_loop_graph ? 1 : 0; return MF_OK; }   // 0 again after a capture that the runtime refused
+    if (!strcmp(key, "persistentIcp")) { *value = c->persistent_icp ? 1 : 0; return MF_OK; }
     for (const ParamRef& p : kParams)
         if (!strcmp(key, p.key)) {
             const char* base = reinterpret_cast<const char*>(&c->cfg);

@@ -56,9 +56,16 @@ template <class T> inline uint64_t to_bits(T v) { static_assert(sizeof(T) <= 8, 
 template <class T> inline T from_bits(uint64_t b) { T v; memcpy(&v, &b, sizeof(T)); return v; }
 }  // namespace hipcpu
 
+// kernel arguments are copied when the launch is issued (as on the device): a launch recorded by a stream capture is replayed later
+namespace hipcpu {
+template <class F, class... A>
+inline void launch_args(const char* name, dim3 grid, dim3 block, size_t dyn_shared, F f, A... a) {
+    launch(name, grid, block, dyn_shared, [=]() { f(a...); });
+}
+}  // namespace hipcpu
 #undef hipLaunchKernelGGL
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    hipcpu::launch(#kernel, dim3(grid), dim3(block), (size_t)(shmem), [&]() { kernel(__VA_ARGS__); })
+    hipcpu::launch_args(#kernel, dim3(grid), dim3(block), (size_t)(shmem), [](auto... hipcpu_a) { kernel(hipcpu_a...); }, ##__VA_ARGS__)
 
 // ---- synchronisation, wave exchanges ----------------------------------------------------------------------------------------
 static inline void __syncthreads() { hipcpu::syncthreads(); }

@@ -219,7 +219,20 @@ static bool is_cooperative(const char* name) {
     return false;
 }
 
+// stream capture (hipGraph): while a capture is open, launches and asynchronous copies are recorded instead of executed; hipGraphLaunch
+// replays them.  One capture at a time (the runtime is single-threaded outside cooperative launches).
+struct Graph { std::vector<std::function<void()>> ops; };
+static Graph* g_capture = nullptr;
+
 void launch(const char* name, dim3 grid, dim3 block, size_t dyn_shared_bytes, const std::function<void()>& body) {
+    if (g_capture) {
+        const std::string kn(name);
+        const std::function<void()> copy = body;
+        Graph* keep = g_capture;
+        (void)keep;
+        g_capture->ops.push_back([=]() { launch(kn.c_str(), grid, block, dyn_shared_bytes, copy); });
+        return;
+    }
     const int n = (int)(block.x * block.y * block.z);
     const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
     if (n <= 0 || nblocks == 0) return;
@@ -287,9 +300,38 @@ hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
-hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
+    if (hipcpu::g_capture) { hipcpu::g_capture->ops.push_back([=]() { memmove(d, s, n); }); return hipSuccess; }
+    memmove(d, s, n);
+    return hipSuccess;
+}
 hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
-hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
+    if (hipcpu::g_capture) { hipcpu::g_capture->ops.push_back([=]() { memset(d, v, n); }); return hipSuccess; }
+    memset(d, v, n);
+    return hipSuccess;
+}
+hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) {
+    if (hipcpu::g_capture) return hipErrorIllegalState;
+    hipcpu::g_capture = new hipcpu::Graph;
+    return hipSuccess;
+}
+hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) {
+    if (!hipcpu::g_capture) return hipErrorIllegalState;
+    *g = reinterpret_cast<hipGraph_t>(hipcpu::g_capture);
+    hipcpu::g_capture = nullptr;
+    return hipSuccess;
+}
+hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, hipGraphNode_t*, char*, size_t) {
+    *e = reinterpret_cast<hipGraphExec_t>(new hipcpu::Graph(*reinterpret_cast<hipcpu::Graph*>(g)));
+    return hipSuccess;
+}
+hipError_t hipGraphDestroy(hipGraph_t g) { delete reinterpret_cast<hipcpu::Graph*>(g); return hipSuccess; }
+hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete reinterpret_cast<hipcpu::Graph*>(e); return hipSuccess; }
+hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) {
+    for (auto& op : reinterpret_cast<hipcpu::Graph*>(e)->ops) op();
+    return hipSuccess;
+}
 hipError_t hipStreamCreate(hipStream_t* s) { *s = (hipStream_t)(uintptr_t)(0x1000 + ++g_dummy_handles); return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
 hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
