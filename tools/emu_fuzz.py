@@ -19,8 +19,12 @@ from oracle import mfo, mfo_rgbd  # noqa: E402
 
 def one(seed):
     rng = np.random.default_rng(seed)
-    W = int(rng.choice([64, 80, 96, 128, 160, 176, 208, 240, 320]))
-    H = int(rng.choice([48, 64, 80, 96, 120, 144, 160, 240]))
+    if os.environ.get("FUZZ_ODD_SIZES") == "1":     # multiples of 8 that are not multiples of 16: partial 16 x 16 tiles, odd pyramid levels
+        W = int(rng.choice([72, 88, 104, 120, 136, 200, 264, 328]))
+        H = int(rng.choice([56, 72, 88, 104, 120, 136, 152, 232]))
+    else:
+        W = int(rng.choice([64, 80, 96, 128, 160, 176, 208, 240, 320]))
+        H = int(rng.choice([48, 64, 80, 96, 120, 144, 160, 240]))
     f = float(rng.uniform(0.6, 1.2) * W)
     cx, cy = W / 2.0 + float(rng.uniform(-6, 6)), H / 2.0 + float(rng.uniform(-6, 6))
     icpw = float(rng.choice([100.0, 100.0, 20.0, 10.0]))
@@ -72,7 +76,8 @@ def one_mm(seed):
     """multi-model frames: global projection, geometric edges, label stage, spawn, masked fusion / clean (standing objects)"""
     from oracle import mfo_mm
     rng = np.random.default_rng(seed)
-    W, H = [(320, 240), (240, 160), (256, 192), (400, 240)][int(rng.integers(0, 4))]
+    sizes = [(264, 200), (328, 232), (200, 152), (296, 216)] if os.environ.get("FUZZ_ODD_SIZES") == "1" else [(320, 240), (240, 160), (256, 192), (400, 240)]
+    W, H = sizes[int(rng.integers(0, 4))]
     f = 528.0 * W / 640.0 * float(rng.uniform(0.9, 1.1))
     n_obj = int(rng.integers(1, 4))
     spawn = int(rng.integers(1, 5))
