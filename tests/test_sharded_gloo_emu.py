@@ -113,3 +113,49 @@ def test_two_ranks_equal_one_context(tmp_path, track_all):
                 assert np.array_equal(cloud, want["clouds"][i], equal_nan=True), (k, mid)
     # standing boxes: both objects spawn; moving boxes are dropped by the jump rule and re-spawned along the way (identically on both sides)
     assert max(len(r["ids"]) for r in one) >= (2 if track_all else 3) and most >= (1 if track_all else 2), "the scenario must spawn object models, on rank 1"
+
+
+# ---- the loop bench.py --gpus N times (weak scaling: one context per rank, frames broadcast from rank 0, per-model state gathered) ----
+def _weak_worker(rank, world, port, out_dir):
+    _activate()
+    import torch
+    import torch.distributed as dist
+    from maskfusion_amd import MaskFusion, dist as mfd, synth
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    st = synth.Stream(W=W, H=H, fx=F, fy=F, cx=W / 2.0, cy=H / 2.0, noise=True)
+    frames = [st.frame(k) for k in range(6)] if rank == 0 else None
+    mf = MaskFusion(W, H, F, F, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=False, numGSurfels=1 << 17)
+    keep = []
+
+    def get_frame(i):
+        return torch.from_numpy(frames[i][0]), torch.from_numpy(frames[i][1])
+
+    def model_step(rgb, depth, stats):                      # bench.py's model_step, device pointers = host pointers here
+        keep.append((rgb, depth))
+        mf.processFrameDevice(rgb.data_ptr(), depth.data_ptr())
+        mf.modelStateDevice(0, stats.data_ptr())
+
+    dev = torch.device("cpu")
+    gathered = mfd.run_steps(get_frame, model_step, 6, H, W, dev)
+    mf.sync()
+    rec = dict(pose=mf.getCurrPose(), count=mf.getBackgroundModel().lastCount(), gathered=[g.numpy().copy() for g in gathered] if gathered is not None and rank == 0 else None)
+    mf.close()
+    pickle.dump(rec, open(os.path.join(out_dir, f"weak{world}_{rank}.pkl"), "wb"))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_weak_scaling_loop_two_ranks(tmp_path):
+    """dist.run_steps with the real ABI calls of bench.py (mf_process_frame_dev + mf_model_state_dev) under gloo, world 2: both ranks track
+    the broadcast frames to the same bits as a single process, and rank 0 receives both state records"""
+    mp.spawn(_weak_worker, args=(1, 0, str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_weak_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    one = pickle.load(open(tmp_path / "weak1_0.pkl", "rb"))
+    r0, r1 = (pickle.load(open(tmp_path / f"weak2_{r}.pkl", "rb")) for r in range(2))
+    for r in (r0, r1):
+        assert np.array_equal(r["pose"], one["pose"]) and r["count"] == one["count"]
+    g = r0["gathered"]
+    assert len(g) == 2 and np.array_equal(g[0], g[1]) and np.array_equal(g[0], one["gathered"][0])
+    assert g[0][15] == 1.0 and g[0][14] == one["count"] and np.allclose(g[0][9:12], one["pose"][:3, 3], atol=1e-7)
