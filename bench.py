@@ -237,6 +237,9 @@ def main():
     ap.add_argument("--so3", action="store_true", help="SO(3) photometric pre-alignment (reference default: on)")
     ap.add_argument("--no-batch", action="store_true", help="config 2s: track the models one after the other (A/B of the batched loop)")
     ap.add_argument("--gen-workers", type=int, default=0, help="processes that ray-cast the synthetic frames (0: auto; 1: no fork, for profiler runs)")
+    ap.add_argument("--param", action="append", default=[], metavar="KEY=VALUE",
+                    help="mf_set_param(KEY, VALUE) on the context before the run (A/B of implementation switches, e.g. persistentIcp=1); "
+                         "recorded in config.params")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host-input", action="store_true")
@@ -290,6 +293,11 @@ def main():
     else:
         mf = MaskFusion(W, H, F, F, CX, CY, icpThresh=args.icp_weight, so3=args.so3, device=local_rank, enableMultipleModels=False,
                         numGSurfels=cfg["surfels"])
+    extra_params = {}
+    for kv in args.param:                                   # A/B of implementation switches: the same workload, one switch flipped
+        key, _, val = kv.partition("=")
+        mf.setParam(key, float(val))
+        extra_params[key] = float(val)
     # Every rank owns one context.  Rank 0 owns the input stream and publishes frame k to all ranks (RCCL broadcast over xGMI
     # when N > 1) on the library's INPUT stream into a ring of 3 buffers; each rank then enqueues processFrame, whose main
     # stream is torch's current stream for the gather of the per-model state record.  Collectives and kernels are ordered
@@ -419,7 +427,8 @@ def main():
             "ms_per_step": 1e3 * total_dt / total_steps, "timed_seconds": total_dt, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["workload"] + variant, "frames_in_hbm": n_frames, "models": n_models, "surfels": count,
-                       "pose_drift_vs_gt_m": drift, "parallelism": f"context-per-gpu x{world}"},
+                       "pose_drift_vs_gt_m": drift, "parallelism": f"context-per-gpu x{world}",
+                       **({"params": extra_params} if extra_params else {})},
             "roofline": roofline, "roofline_frame": roofline_frame, "host_input": host_input, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
