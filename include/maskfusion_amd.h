@@ -156,7 +156,10 @@ int mf_get_last_fillin(mf_ctx* ctx, int32_t* used);
  * (0), "cleanLiteralWindow" (1: Model::clean walks its window with copy_unstable.vert's own fp32 trip count, 4 or 5 taps per axis;
  * 0: 4 x 4), "timings", "icpProfile", "gnLoopGraph" (0; 1: the launches of the geometric Gauss-Newton loop of a tracking step are captured
  * once per frame parity with hipStreamBeginCapture / EndCapture and replayed as one hipGraphLaunch -- same kernels, same arguments, same
- * bits; if the runtime refuses the capture the eager launches are used and mf_get_param reads 0 again).  Experimental, default 0, not yet validated on hardware: "persistentIcp" (the geometric Gauss-Newton
+ * bits; if the runtime refuses the capture the eager launches are used and mf_get_param reads 0 again), "objectSmallGrids" (0; 1: the grid-stride
+ * surfel kernels of an object model run on a grid sized from its last known surfel count instead of 2048 workgroups), "objectScatterSplat" (0;
+ * 1: object models are predicted with the scatter form of the splat instead of tile lists) -- both leave every result bit-identical and
+ * exist for an A/B of the launch-bound multi-model frames.  Experimental, default 0, not yet validated on hardware: "persistentIcp" (the geometric Gauss-Newton
  * loop of a single-model tracking step as ONE persistent launch with device-wide barriers between the iterations instead of 19 dependent
  * launches; a barrier that times out makes mf_sync return MF_ESTATE, it cannot hang). */
 int mf_set_param(mf_ctx* ctx, const char* key, double value);

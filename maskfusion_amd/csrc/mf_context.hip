@@ -141,6 +141,9 @@ struct mf_ctx {
     bool map_ready = false;            // the background map exists (first frame processed, Model::initialise or an uploaded map)
     bool tracked_once = false;         // a tracking step has run (its stage timings are meaningful)
     bool timings_on = false, icp_prof_on = false;
+    // A/B switches for object models (a few thousand surfels each; their per-frame cost is launch overhead), both 0 until measured:
+    bool object_small_grids = false;                   // "objectSmallGrids": the grid-stride surfel kernels with a grid sized from the model's last known count
+    bool object_scatter_splat = false;                 // "objectScatterSplat": object models are predicted with the scatter form instead of tile lists
     bool gn_loop_graph = false;                        // the launch-per-iteration loop replayed as a captured hipGraph ("gnLoopGraph")
     bool persistent_icp = false;                       // experimental: the geometric loop as one launch with device-wide barriers ("persistentIcp")
     unsigned* d_grid_barrier = nullptr;                // [0] arrival counter (monotonic), [1] sticky time-out flag
@@ -652,6 +655,16 @@ static void enqueue_track_batch(mf_ctx* c, const std::vector<ModelState*>& ms, c
     launch_icp_batch_finalize(b, it, nb_prev, so3_seed, s);
 }
 
+// workgroups for the grid-stride surfel kernels of model m: all of them for the background, and for an object model -- with
+// "objectSmallGrids" -- twice what its last known surfel count needs (the count lives on the device; *h_count is its pinned mirror as of the
+// last clean pass: a stale value only costs a few more trips round the grid-stride loop, never a result)
+static int surfel_blocks(const mf_ctx* c, const ModelState& m) {
+    if (!c->object_small_grids || m.id == 0) return kSurfelGridBlocks;
+    const long n = 2L * (long)*m.h_count + 4096;
+    const long b = (n + 255) / 256;
+    return (int)(b < 32 ? 32 : (b > kSurfelGridBlocks ? kSurfelGridBlocks : b));
+}
+
 // predictIndices -> fuse -> [predictIndices] -> clean for one model (Core/MaskFusion.cpp:541-563 / :344-353)
 static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, const float* d_depth, const float* depthF,
                                const uint8_t* mask, float fuseDepthCutoff, float weightMultiplier, bool secondIndexPass, bool marks) {
@@ -659,7 +672,8 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
     const int W = c->W, H = c->H;
     hipStream_t s = c->stream;
     const int src = m.cur, dst = 1 - m.cur;
-    launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, false, s);
+    const int blocks = surfel_blocks(c, m);
+    launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, false, s, blocks);
     launch_index_resolve(m.surf[src], m.d_pose, c->d_keys, W, H, c->d_index, c->d_ivc, c->d_inr, secondIndexPass ? nullptr : c->d_ict,
                          nullptr, s);
     if (marks) mark(c, 4);
@@ -669,7 +683,7 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
     if (marks) mark(c, 5);
     // the scatter half of the second predictIndices (:556) rides on the update pass
     launch_fuse_update(m.surf[src], m.surf[dst], m.d_frame, c->d_upd_first, c->d_cand_rec, m.d_pose, W, H, c->K, g.max_depth_processed,
-                       g.time_delta, secondIndexPass ? c->d_keys : nullptr, true, s);
+                       g.time_delta, secondIndexPass ? c->d_keys : nullptr, true, s, blocks);
     if (marks) mark(c, 6);
     if (secondIndexPass) {
         launch_index_resolve(m.surf[dst], m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, s);
@@ -683,7 +697,7 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
 // MaskFusion::predict for one model: combinedPredict(maxDepthProcessed, tick, tick, timeDelta) -- the fill-in half
 // (performFillIn) is evaluated lazily by the next tracking step from the retained filtered depth.
 static void enqueue_predict(mf_ctx* c, ModelState& m) {
-    if (c->splat_tiles) {
+    if (c->splat_tiles && !(c->object_scatter_splat && m.id != 0)) {
         const bool gray = photometric_on(c);
         if (launch_splat_tiled(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, c->cfg.max_depth_processed, m.confThr,
                                c->cfg.time_delta, c->d_tile_count, c->d_tile_entries, c->tile_entries_cap, c->d_splat_rec0, c->d_splat_rec1,
@@ -692,7 +706,7 @@ static void enqueue_predict(mf_ctx* c, ModelState& m) {
             return;
     }
     launch_splat_scatter(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, c->cfg.max_depth_processed, m.confThr,
-                         c->cfg.time_delta, c->d_keys, c->stream);
+                         c->cfg.time_delta, c->d_keys, c->stream, surfel_blocks(c, m));
     const bool gray = photometric_on(c) ;
     launch_splat_resolve(m.surf[m.cur], m.d_pose, c->d_keys, c->W, c->H, c->K, m.d_predV, m.d_predN, m.d_predImage, m.d_predTime,
                          m.d_frame, c->cur_rgb, gray ? m.d_predGray : nullptr, gray ? m.d_fillGray : nullptr, c->stream);
@@ -767,7 +781,7 @@ static void enqueue_global_projection(mf_ctx* c, ModelState& m, int order) {
                             c->d_tile_entries, c->tile_entries_cap, c->d_splat_rec0, c->d_splat_rec1, c->d_splat_bbox, c->d_keys, c->stream) == 0)
         return;
     launch_global_scatter(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, g.depth_cutoff, 12.0f, g.time_delta, order, m.id, c->d_keys,
-                          c->stream);
+                          c->stream, surfel_blocks(c, m));
 }
 
 // spawnObjectModel (Core/MaskFusion.cpp:671-684): pose = I, makeStatic(globalPose); moveNewModelToList
@@ -1732,6 +1746,8 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!strcmp(key, "batchTracking")) { c->batch_tracking = value != 0; return MF_OK; }
     if (!strcmp(key, "persistentIcp")) { c->persistent_icp = value != 0; return MF_OK; }   // experimental, see k_icp_persist
     if (!strcmp(key, "gnLoopGraph")) { c->gn_loop_graph = value != 0; return MF_OK; }      // the Gauss-Newton launches as a replayed hipGraph
+    if (!strcmp(key, "objectSmallGrids")) { c->object_small_grids = value != 0; return MF_OK; }
+    if (!strcmp(key, "objectScatterSplat")) { c->object_scatter_splat = value != 0; return MF_OK; }
     if (!strcmp(key, "globalTiles")) { c->global_tiles = value != 0; return MF_OK; }
     if (!strcmp(key, "cleanLiteralWindow")) { c->clean_literal = value != 0; return MF_OK; }   // 0: the exact-arithmetic 4 x 4 window
     if (!strcmp(key, "earlyBackgroundFusion")) { c->early_bg_fusion = value != 0; return MF_OK; }

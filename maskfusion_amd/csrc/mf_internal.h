@@ -194,8 +194,12 @@ void launch_rgbd_finalize(const float* icp_partials, const float* rgb_partials, 
 // ---------------- surfels ----------------
 void launch_init_surfels(const uint8_t* rgb, const float* depthRaw, const float* depthF, int W, int H, Intr k,
                          float maxDepth, const FrameDev* frame, float4* rec /*[P][3]*/, uint8_t* flags, hipStream_t s);
+// Grid of the four grid-stride surfel kernels below: 2048 workgroups by default; a model that is known to be small (an object model
+// of a few thousand surfels) may be launched with fewer -- the loops are grid-stride, the result does not depend on the grid.
+constexpr int kSurfelGridBlocks = 2048;
 void launch_index_scatter(Surfels src, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k,
-                          float maxDepth, int timeDelta, unsigned long long* keys, bool transposed, hipStream_t s);
+                          float maxDepth, int timeDelta, unsigned long long* keys, bool transposed, hipStream_t s,
+                          int blocks = kSurfelGridBlocks);
 // packed == nullptr: index / vertConf / normRad (+ colorTime if ct != nullptr) images; else one 32 B record per texel
 void launch_index_resolve(Surfels src, const PoseDev* pose, unsigned long long* keys, int W, int H, int* index,
                           float4* vc, float4* nr, float4* ct /*or null*/, float4* packed /*or null*/, hipStream_t s);
@@ -206,7 +210,7 @@ void launch_fuse_data(const uint8_t* rgb, const float* depthRaw, const float* de
 // keys_or_null != nullptr: also scatters the updated surfels into the index-map keys (the pass that feeds clean)
 void launch_fuse_update(Surfels src, Surfels dst, const FrameDev* frame, int* upd_first, const float4* cand_rec, const PoseDev* pose,
                         int W, int H, Intr k, float maxDepth, int timeDelta, unsigned long long* keys_or_null, bool transposed,
-                        hipStream_t s);
+                        hipStream_t s, int blocks = kSurfelGridBlocks);
 void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k,
                   int timeDelta, float confThreshold, float outlierCoeff, int maskID, const int* index,
                   const float4* vc, const float4* ct, const float4* packed /*or null*/, const float* depthF, const uint8_t* mask,
@@ -218,7 +222,7 @@ void launch_compact_records(const float4* rec, const uint8_t* flags, int n, Surf
                             int* block_counts, int* host_count_mirror, hipStream_t s);
 void launch_splat_scatter(Surfels src, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k,
                           float maxDepth, float confThreshold, int timeDelta, unsigned long long* keys,
-                          hipStream_t s);
+                          hipStream_t s, int blocks = kSurfelGridBlocks);
 void launch_splat_resolve(Surfels src, const PoseDev* pose, unsigned long long* keys, int W, int H, Intr k,
                           float4* predV, float4* predN, uchar4* predImage, uint16_t* predTime, FrameDev* frame,
                           const uint8_t* rgb /*or null*/, uint8_t* predGray /*or null*/, uint8_t* fillGray /*or null*/,
@@ -238,7 +242,8 @@ void launch_edge_map(const float* vmap, const float* nmap, float* out, int W, in
 void launch_edge_binary(const float* edge, uint8_t* out, uint8_t* tmp, int W, int H, float threshold, int radius,
                         int iterations, hipStream_t s);
 void launch_global_scatter(Surfels src, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth,
-                           float confThreshold, int timeDelta, int order, int id, unsigned long long* keys, hipStream_t s);
+                           float confThreshold, int timeDelta, int order, int id, unsigned long long* keys, hipStream_t s,
+                           int blocks = kSurfelGridBlocks);
 void launch_global_resolve(unsigned long long* keys, uint8_t* ids, int P, hipStream_t s);
 int gn_solve_standalone(const double* sys29, const double* resultRt16, const float* Rprev9, const float* tprev3, double* x_serial, double* x_wave,
                         double* resultRt_out, float* Rcurr9, float* tcurr3, float* stats2, hipStream_t s);

@@ -152,9 +152,9 @@ __global__ __launch_bounds__(256) void k_global_scatter(Surfels src, const Frame
 }
 
 void launch_global_scatter(Surfels src, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth,
-                           float confThreshold, int timeDelta, int order, int id, unsigned long long* keys, hipStream_t s) {
+                           float confThreshold, int timeDelta, int order, int id, unsigned long long* keys, hipStream_t s, int blocks) {
     const unsigned payload = ((unsigned)order << 8) | ((unsigned)id & 255u);
-    hipLaunchKernelGGL(k_global_scatter, dim3(2048), dim3(256), 0, s, src, frame, pose, W, H, k, maxDepth, confThreshold, timeDelta,
+    hipLaunchKernelGGL(k_global_scatter, dim3(blocks), dim3(256), 0, s, src, frame, pose, W, H, k, maxDepth, confThreshold, timeDelta,
                        payload, keys);
 }
 

@@ -183,8 +183,8 @@ __global__ __launch_bounds__(256) void k_index_scatter(Surfels src, const FrameD
 }
 
 void launch_index_scatter(Surfels src, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth,
-                          int timeDelta, unsigned long long* keys, bool transposed, hipStream_t s) {
-    hipLaunchKernelGGL(k_index_scatter, dim3(2048), dim3(256), 0, s, src, frame, pose, W, H, k, maxDepth, timeDelta, keys,
+                          int timeDelta, unsigned long long* keys, bool transposed, hipStream_t s, int blocks) {
+    hipLaunchKernelGGL(k_index_scatter, dim3(blocks), dim3(256), 0, s, src, frame, pose, W, H, k, maxDepth, timeDelta, keys,
                        transposed ? 1 : 0);
 }
 
@@ -387,9 +387,9 @@ __global__ __launch_bounds__(256) void k_fuse_update(Surfels src, Surfels dst, c
 
 void launch_fuse_update(Surfels src, Surfels dst, const FrameDev* frame, int* upd_first, const float4* cand_rec, const PoseDev* pose,
                         int W, int H, Intr k, float maxDepth, int timeDelta, unsigned long long* keys_or_null, bool transposed,
-                        hipStream_t s) {
+                        hipStream_t s, int blocks) {
     IndexScatterArgs ix{pose, W, H, k, maxDepth, timeDelta, keys_or_null, transposed ? 1 : 0};
-    hipLaunchKernelGGL(k_fuse_update, dim3(2048), dim3(256), 0, s, src, dst, frame, upd_first, cand_rec, ix);
+    hipLaunchKernelGGL(k_fuse_update, dim3(blocks), dim3(256), 0, s, src, dst, frame, upd_first, cand_rec, ix);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -650,8 +650,8 @@ __global__ __launch_bounds__(256) void k_splat_scatter(Surfels src, const FrameD
 }
 
 void launch_splat_scatter(Surfels src, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth,
-                          float confThreshold, int timeDelta, unsigned long long* keys, hipStream_t s) {
-    hipLaunchKernelGGL(k_splat_scatter, dim3(2048), dim3(256), 0, s, src, frame, pose, W, H, k, maxDepth, confThreshold,
+                          float confThreshold, int timeDelta, unsigned long long* keys, hipStream_t s, int blocks) {
+    hipLaunchKernelGGL(k_splat_scatter, dim3(blocks), dim3(256), 0, s, src, frame, pose, W, H, k, maxDepth, confThreshold,
                        timeDelta, keys);
 }
 

@@ -206,3 +206,42 @@ def test_tiled_global_projection_equals_scatter_form(hip):
         assert np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3] and np.array_equal(a[4], b[4]), k + 1
         nonzero = max(nonzero, int((a[0] != 0).sum()))
     assert len(runs[0][-1][2]) >= 2 and nonzero > 500, "objects must spawn and project"
+
+
+def test_object_model_launch_switches_change_nothing(hip):
+    """"objectSmallGrids" (the grid-stride surfel kernels of an object model on a grid sized from its last known count) and
+    "objectScatterSplat" (object models predicted with the scatter form instead of tile lists) are A/B switches for the launch-bound
+    multi-model frames: label images, poses, clouds and predictions must stay bit-identical"""
+    from maskfusion_amd import MaskFusion, synth
+
+    def run(**params):
+        W, H, f = 320, 240, 264.0
+        st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, n_objects=2, noise=True, object_motion=0.0)
+        mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, numGSurfels=1 << 18, numOSurfels=1 << 16, enableMultipleModels=True,
+                        modelSpawnOffset=2, trackAllModels=True)
+        for k, v in dict(mfThreshold=SEG["threshold"], mfWeightDistance=SEG["weightDistance"], mfWeightConvexity=SEG["weightConvexity"],
+                         mfMorphEdgeIterations=0, mfMorphMaskIterations=0, newModelMinRelativeSize=SEG["minRelSizeNew"], **params).items():
+            mf.setParam(k, v)
+        segs = []
+        for k in range(9):
+            rgb, d, mask = st.frame(k)
+            mf.processFrame(rgb, d, mask=mask, classIDs=[0, 41, 42], timestamp=k)
+            segs.append(mf.downloadSegmentation())
+        ms = mf.getModels()
+        out = dict(ids=[m.getID() for m in ms], poses=[m.getPose() for m in ms], clouds=[m.downloadMap() for m in ms], segs=segs,
+                   preds=[m.debugRead("pred_vertex") for m in ms])
+        mf.close()
+        return out
+
+    def same(a, b):
+        if isinstance(a, dict):
+            return all(same(a[k], b[k]) for k in a)
+        if isinstance(a, list):
+            return len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+        return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+    base = run()
+    assert len(base["ids"]) >= 2, "the scenario must hold an object model"
+    assert same(base, run(objectSmallGrids=1))
+    assert same(base, run(objectScatterSplat=1))
+    assert same(base, run(objectSmallGrids=1, objectScatterSplat=1))
