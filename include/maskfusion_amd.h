@@ -159,7 +159,9 @@ int mf_get_last_fillin(mf_ctx* ctx, int32_t* used);
  * bits; if the runtime refuses the capture the eager launches are used and mf_get_param reads 0 again), "objectSmallGrids" (0; 1: the grid-stride
  * surfel kernels of an object model run on a grid sized from its last known surfel count instead of 2048 workgroups), "objectScatterSplat" (0;
  * 1: object models are predicted with the scatter form of the splat instead of tile lists) -- both leave every result bit-identical and
- * exist for an A/B of the launch-bound multi-model frames.  Experimental, default 0, not yet validated on hardware: "persistentIcp" (the geometric Gauss-Newton
+ * exist for an A/B of the launch-bound multi-model frames; "literalFusionWeight" (0; 1: Model::computeFusionWeight's log map takes cos(theta) from the
+ * float trace of a float matrix as the reference's text does -- its rotation term is then quantised in steps of ~4.9e-4 rad; 0: the same
+ * formula evaluated accurately in double.  See DESIGN.md, finding F5).  Experimental, default 0, not yet validated on hardware: "persistentIcp" (the geometric Gauss-Newton
  * loop of a single-model tracking step as ONE persistent launch with device-wide barriers between the iterations instead of 19 dependent
  * launches; a barrier that times out makes mf_sync return MF_ESTATE, it cannot hang). */
 int mf_set_param(mf_ctx* ctx, const char* key, double value);

@@ -144,6 +144,7 @@ struct mf_ctx {
     // A/B switches for object models (a few thousand surfels each; their per-frame cost is launch overhead), both 0 until measured:
     bool object_small_grids = false;                   // "objectSmallGrids": the grid-stride surfel kernels with a grid sized from the model's last known count
     bool object_scatter_splat = false;                 // "objectScatterSplat": object models are predicted with the scatter form instead of tile lists
+    bool weight_literal = false;                       // "literalFusionWeight": Model::rodrigues2 with the reference's float trace (finding F5)
     bool gn_loop_graph = false;                        // the launch-per-iteration loop replayed as a captured hipGraph ("gnLoopGraph")
     bool persistent_icp = false;                       // experimental: the geometric loop as one launch with device-wide barriers ("persistentIcp")
     unsigned* d_grid_barrier = nullptr;                // [0] arrival counter (monotonic), [1] sticky time-out flag
@@ -245,10 +246,16 @@ extern "C" int mf_default_config(mf_config* cfg, int32_t width, int32_t height, 
     return MF_OK;
 }
 
-static __global__ void k_pose_identity(PoseDev* p) {
+static __global__ void k_set_weight_literal(PoseDev* p, int literal, PoseDev* host_mirror) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    p->weightLiteral = literal;
+    if (host_mirror) host_mirror->weightLiteral = literal;
+}
+static __global__ void k_pose_identity(PoseDev* p, int weight_literal) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     PoseDev q;
     memset(&q, 0, sizeof(q));
+    q.weightLiteral = weight_literal;
     for (int k = 0; k < 9; ++k) q.R[k] = q.Ri[k] = q.lastR[k] = q.initR[k] = (k % 4 == 0) ? 1.f : 0.f;
     q.fusionWeight = 1.f;
     q.alive = 1;
@@ -310,7 +317,7 @@ static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int 
         t.allow_fill = allowFillIn ? 1 : 0;
         m->track_host = t;
     }
-    hipLaunchKernelGGL(k_pose_identity, dim3(1), dim3(64), 0, c->stream, m->d_pose);
+    hipLaunchKernelGGL(k_pose_identity, dim3(1), dim3(64), 0, c->stream, m->d_pose, c->weight_literal ? 1 : 0);
     hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(64), 0, c->stream, m->d_frame, c->host_tick);
     if (hipHostMalloc((void**)&m->h_pose, sizeof(PoseDev)) != hipSuccess || hipHostMalloc((void**)&m->h_frame, sizeof(FrameDev)) != hipSuccess ||
         hipHostMalloc((void**)&m->h_count, sizeof(int)) != hipSuccess)
@@ -318,6 +325,8 @@ static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int 
     memset(m->h_pose, 0, sizeof(PoseDev));
     for (int k = 0; k < 9; ++k) m->h_pose->R[k] = m->h_pose->Ri[k] = (k % 4 == 0) ? 1.f : 0.f;
     m->h_pose->alive = 1;
+    m->h_pose->fusionWeight = 1.f;                         // pose == lastPose: computeFusionWeight(1) = 1 before the first tracking step
+    m->h_pose->weightLiteral = c->weight_literal ? 1 : 0;
     memset(m->h_frame, 0, sizeof(FrameDev));
     m->h_frame->tick = c->host_tick;
     *m->h_count = 0;
@@ -796,7 +805,7 @@ static int spawn_object(mf_ctx* c, int id, int classID) {
         nm->id = id;
         nm->confThr = g.conf_object;
         nm->age = 0; nm->isStatic = true; nm->log_ts.clear(); nm->cur = 0;
-        hipLaunchKernelGGL(k_pose_identity, dim3(1), dim3(64), 0, s, nm->d_pose);
+        hipLaunchKernelGGL(k_pose_identity, dim3(1), dim3(64), 0, s, nm->d_pose, c->weight_literal ? 1 : 0);
         hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(64), 0, s, nm->d_frame, c->host_tick);
         nm->h_frame->tick = c->host_tick;
     } else {
@@ -1746,6 +1755,12 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!strcmp(key, "batchTracking")) { c->batch_tracking = value != 0; return MF_OK; }
     if (!strcmp(key, "persistentIcp")) { c->persistent_icp = value != 0; return MF_OK; }   // experimental, see k_icp_persist
     if (!strcmp(key, "gnLoopGraph")) { c->gn_loop_graph = value != 0; return MF_OK; }      // the Gauss-Newton launches as a replayed hipGraph
+    if (!strcmp(key, "literalFusionWeight")) {
+        c->weight_literal = value != 0;
+        for (auto& m : c->models) hipLaunchKernelGGL(k_set_weight_literal, dim3(1), dim3(64), 0, c->stream, m->d_pose, c->weight_literal ? 1 : 0, m->h_pose);
+        for (auto& m : c->pool) hipLaunchKernelGGL(k_set_weight_literal, dim3(1), dim3(64), 0, c->stream, m->d_pose, c->weight_literal ? 1 : 0, m->h_pose);
+        return check_launch(c);
+    }
     if (!strcmp(key, "objectSmallGrids")) { c->object_small_grids = value != 0; return MF_OK; }
     if (!strcmp(key, "objectScatterSplat")) { c->object_scatter_splat = value != 0; return MF_OK; }
     if (!strcmp(key, "globalTiles")) { c->global_tiles = value != 0; return MF_OK; }

@@ -225,6 +225,51 @@ __device__ inline void rodrigues2_d(const float* Rin, double* r) {
     r[0] = rx; r[1] = ry; r[2] = rz;
 }
 
+// Model::rodrigues2 as the reference's text evaluates it (finding F5): U V^T, its off-diagonal differences and its TRACE are float there
+// (Eigen::Matrix3f), so cos(theta) = (trace - 1) / 2 is quantised in steps of 1.2e-7 and theta = acos(c) in steps of ~4.9e-4 rad near 0:
+// a rotation below that reads as zero, one above it as a multiple of the step.  The polar factor is computed in double (IEEE divisions,
+// no contraction: the same bits as the CPU restatement) and rounded to float where the reference's SVD product is float.
+__device__ inline void rodrigues2_literal_d(const float* Rin, double* r) {
+#pragma clang fp contract(off)
+    double R[9], Rn[9];
+    for (int k = 0; k < 9; ++k) R[k] = Rin[k];
+    for (int it = 0; it < 4; ++it) {
+        const double c00 = R[4] * R[8] - R[5] * R[7], c01 = R[5] * R[6] - R[3] * R[8], c02 = R[3] * R[7] - R[4] * R[6];
+        const double det = R[0] * c00 + R[1] * c01 + R[2] * c02;
+        const double cof[9] = {c00, c01, c02,
+                               R[2] * R[7] - R[1] * R[8], R[0] * R[8] - R[2] * R[6], R[1] * R[6] - R[0] * R[7],
+                               R[1] * R[5] - R[2] * R[4], R[2] * R[3] - R[0] * R[5], R[0] * R[4] - R[1] * R[3]};
+        for (int k = 0; k < 9; ++k) Rn[k] = 0.5 * (R[k] + cof[k] / det);
+        for (int k = 0; k < 9; ++k) R[k] = Rn[k];
+    }
+    float Rf[9];
+    for (int k = 0; k < 9; ++k) Rf[k] = (float)R[k];
+    double rx = (double)(Rf[7] - Rf[5]), ry = (double)(Rf[2] - Rf[6]), rz = (double)(Rf[3] - Rf[1]);
+    const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    const float tr = (Rf[0] + Rf[4]) + Rf[8];
+    double cth = (double)(tr - 1.0f) * 0.5;
+    cth = cth > 1. ? 1. : cth < -1. ? -1. : cth;
+    double theta = acos(cth);
+    if (s < 1e-5) {
+        if (cth > 0) rx = ry = rz = 0;
+        else {
+            double tt = ((double)Rf[0] + 1) * 0.5;
+            rx = sqrt(fmax(tt, 0.0));
+            tt = ((double)Rf[4] + 1) * 0.5;
+            ry = sqrt(fmax(tt, 0.0)) * (Rf[1] < 0 ? -1.0 : 1.0);
+            tt = ((double)Rf[8] + 1) * 0.5;
+            rz = sqrt(fmax(tt, 0.0)) * (Rf[2] < 0 ? -1.0 : 1.0);
+            if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (Rf[5] > 0) != (ry * rz > 0)) rz = -rz;
+            theta /= sqrt(rx * rx + ry * ry + rz * rz);
+            rx *= theta; ry *= theta; rz *= theta;
+        }
+    } else {
+        const double vth = 1 / (2 * s) * theta;
+        rx *= vth; ry *= vth; rz *= vth;
+    }
+    r[0] = rx; r[1] = ry; r[2] = rz;
+}
+
 // Derived members of PoseDev from (R,t) and (lastR,lastT): inverse and Model::computeFusionWeight(1.0)
 // (Core/Model/Model.cpp:449-464).
 __device__ inline void pose_derive(PoseDev& p) {
@@ -239,7 +284,8 @@ __device__ inline void pose_derive(PoseDev& p) {
     float3 td = mul33(p.Ri, f3(p.lastT[0], p.lastT[1], p.lastT[2]));
     td = f3(td.x + p.ti[0], td.y + p.ti[1], td.z + p.ti[2]);
     double rv[3];
-    rodrigues2_d(Rd, rv);
+    if (p.weightLiteral) rodrigues2_literal_d(Rd, rv);
+    else rodrigues2_d(Rd, rv);
     const float rn = (float)sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
     float weighting = fmaxf(norm3(td), rn);
     const float largest = 0.01f, minWeight = 0.5f;

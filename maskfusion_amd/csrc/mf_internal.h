@@ -30,6 +30,7 @@ struct PoseDev {
     int rejected;              // 1 if the last tracking step was reverted by the 0.3 m rule (RGBDOdometry.cpp:477-481)
     float lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count;
     int so3Iterations;
+    int weightLiteral;         // 1: computeFusionWeight's log map with the reference's float trace ("literalFusionWeight", DESIGN.md finding F5)
 };
 
 // Result of the SO(3) pre-alignment kernel (RGBDOdometry.cpp:264-324); seeds resultRt of the Gauss-Newton loop.

@@ -180,6 +180,7 @@ __global__ void k_spawn_pose(PoseDev* obj, const PoseDev* bg, FrameDev* objFrame
     for (int k = 0; k < 9; ++k) q.R[k] = q.Ri[k] = q.lastR[k] = (k % 4 == 0) ? 1.f : 0.f;
     q.fusionWeight = 1.f;
     q.alive = 1;
+    q.weightLiteral = bg->weightLiteral;   // a context-wide switch: the new model inherits it from the background
     m33_inverse_f(bg->R, q.initR);
     const float3 v = mul33(q.initR, f3(bg->t[0], bg->t[1], bg->t[2]));
     q.initT[0] = -v.x; q.initT[1] = -v.y; q.initT[2] = -v.z;

@@ -1581,6 +1581,12 @@ int mfo_requires_fill_in(const uint8_t* predImage, int W, int H, float ratio) {
 
 /* Model.cpp:449-464; rodrigues2 :891-932 (the SVD re-orthonormalisation U V^T is replaced by Newton polar
  * iterations, identical to rounding for the near-rotations that occur). */
+/* Literal mode (finding F5): U V^T, its off-diagonal differences and its trace are FLOAT in the reference (Eigen::Matrix3f,
+ * Model.cpp:892-901), so cos(theta) is quantised in steps of 1.2e-7 and theta = acos(c) in steps of ~4.9e-4 rad near 0.  Off by default
+ * until the device's matching mode ("literalFusionWeight") has been seen on hardware; tests/test_weight_pin.py compares this mode with the
+ * reference's compiled text. */
+static int g_weight_literal = 0;
+void mfo_set_weight_literal(int on) { g_weight_literal = on; }
 static void rodrigues2(const float* Rin, double* r) {
     double R[9], Rn[9];
     for (int k = 0; k < 9; ++k) R[k] = Rin[k];
@@ -1594,8 +1600,15 @@ static void rodrigues2(const float* Rin, double* r) {
         memcpy(R, Rn, sizeof(R));
     }
     double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
-    const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
     double cth = (R[0] + R[4] + R[8] - 1) * 0.5;
+    if (g_weight_literal) {
+        float Rf[9];
+        for (int k = 0; k < 9; ++k) { Rf[k] = (float)R[k]; R[k] = (double)Rf[k]; }     /* the branches below read the float matrix too */
+        rx = (double)(Rf[7] - Rf[5]); ry = (double)(Rf[2] - Rf[6]); rz = (double)(Rf[3] - Rf[1]);
+        const float tr = (Rf[0] + Rf[4]) + Rf[8];
+        cth = (double)(tr - 1.0f) * 0.5;
+    }
+    const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
     cth = cth > 1. ? 1. : cth < -1. ? -1. : cth;
     double theta = acos(cth);
     if (s < 1e-5) {

@@ -221,7 +221,8 @@ void mfo_fill_in(const mfo_cam* cam, const uint8_t* predImage, const float* pred
 /* MaskFusion.cpp:630-648 (nearest sample of the predicted colour image at 20x down-sampling) */
 int mfo_requires_fill_in(const uint8_t* predImage, int W, int H, float ratio);
 
-/* Model.cpp:449-464 + rodrigues2 :891-932 */
+/* Model.cpp:449-464 + rodrigues2 :891-932.  mfo_set_weight_literal(1): the log map with the reference's float trace (finding F5) */
+void mfo_set_weight_literal(int on);
 float mfo_fusion_weight(const float* pose16, const float* lastPose16, float weightMultiplier);
 
 /* ---------------- single-model pipeline (a1) ---------------- */

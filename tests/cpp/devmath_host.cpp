@@ -85,9 +85,10 @@ void dm_gn_solve_update(const double* sys29, const double* resultRt16, const flo
     stats2[0] = out.lastICPError; stats2[1] = out.lastICPCount;
 }
 // pose_derive: Model::pose -> its inverse, and Model::computeFusionWeight(1) from pose / lastPose (row-major R, t)
-void dm_pose_derive(const float* R9, const float* t3, const float* lastR9, const float* lastT3, float* Ri9, float* ti3, float* fusionWeight) {
+void dm_pose_derive(const float* R9, const float* t3, const float* lastR9, const float* lastT3, float* Ri9, float* ti3, float* fusionWeight, int literal) {
     mf::PoseDev p;
     memset(&p, 0, sizeof(p));
+    p.weightLiteral = literal;      // "literalFusionWeight": Model::rodrigues2 with the reference's float trace
     for (int k = 0; k < 9; ++k) { p.R[k] = R9[k]; p.lastR[k] = lastR9[k]; }
     for (int k = 0; k < 3; ++k) { p.t[k] = t3[k]; p.lastT[k] = lastT3[k]; }
     mf::pose_derive(p);

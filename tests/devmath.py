@@ -76,6 +76,6 @@ def lib():
         L.dm_quat_from_rot.argtypes = [f32p, f32p]
         L.dm_window_slots_literal.argtypes = [C.c_float, C.c_int, i32p, i32p]
         L.dm_gn_solve_update.argtypes = [f64p, f64p, f32p, f32p, f64p, f64p, f32p, f32p, f32p, f32p, f32p]
-        L.dm_pose_derive.argtypes = [f32p, f32p, f32p, f32p, f32p, f32p, f32p]
+        L.dm_pose_derive.argtypes = [f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int]
         _lib = L
     return _lib
