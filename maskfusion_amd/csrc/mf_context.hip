@@ -144,7 +144,10 @@ struct mf_ctx {
     // A/B switches for object models (a few thousand surfels each; their per-frame cost is launch overhead), both 0 until measured:
     bool object_small_grids = false;                   // "objectSmallGrids": the grid-stride surfel kernels with a grid sized from the model's last known count
     bool object_scatter_splat = false;                 // "objectScatterSplat": object models are predicted with the scatter form instead of tile lists
-    bool weight_literal = false;                       // "literalFusionWeight": Model::rodrigues2 with the reference's float trace (finding F5)
+#ifndef MF_DEFAULT_LITERAL_FUSION_WEIGHT
+#define MF_DEFAULT_LITERAL_FUSION_WEIGHT 0             // the rehearsal of flipping this default compiles the test build with -D...=1 (tests/conftest.py)
+#endif
+    bool weight_literal = MF_DEFAULT_LITERAL_FUSION_WEIGHT != 0;   // "literalFusionWeight": Model::rodrigues2 with the reference's float trace (finding F5)
     bool gn_loop_graph = false;                        // the launch-per-iteration loop replayed as a captured hipGraph ("gnLoopGraph")
     bool persistent_icp = false;                       // experimental: the geometric loop as one launch with device-wide barriers ("persistentIcp")
     unsigned* d_grid_barrier = nullptr;                // [0] arrival counter (monotonic), [1] sticky time-out flag

@@ -19,6 +19,16 @@ def oracle():
     return mfo
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _literal_weight_rehearsal():
+    """MF_LITERAL_WEIGHT=1 (with MF_EMU=1): rehearse the default flip of finding F5 -- the oracle in its literal fusion-weight mode and the
+    CPU-executed test build compiled with literalFusionWeight on by default"""
+    if os.environ.get("MF_LITERAL_WEIGHT") == "1":
+        from oracle import mfo
+        mfo.lib().mfo_set_weight_literal(1)
+    yield
+
+
 @pytest.fixture(scope="session")
 def hip():
     """The HIP extension + a CUDA(=HIP) torch device; GPU tests fail loudly if either is missing."""
