@@ -29,7 +29,7 @@ def single_model(n=4, W=160, H=120):
         mf.processFrame(rgb, d, timestamp=k)
         o.process_frame(rgb, d)
         out.append(dict(count=int(mf.getBackgroundModel().lastCount()), ocount=int(o.count), pose_diff=float(np.abs(mf.getCurrPose() - o.pose).max()),
-                        inliers=float(mf.trackStats(0)["lastICPCount"])))
+                        inliers=float(mf.trackStats(0)["lastICPCount"]), pose=mf.getCurrPose().reshape(-1).tolist()))
     mf.close(); o.close()
     return out
 
