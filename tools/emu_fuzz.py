@@ -52,13 +52,14 @@ def one(seed):
             d[rng.random((H, W)) < 0.3] = 0                     # salt holes
         elif mode == 3:
             d[:, : W // 2] = 25.0                               # beyond maxDepthProcessed
+        share = os.environ.get("FUZZ_SHARE_FILTER") == "1"     # the oracle takes the product's filtered depth: isolates everything but the filter
         if given and k > 0:
             P = st.gt_pose(k).astype(np.float32)
             mf.processFrame(rgb, d, timestamp=k, inPose=P)
-            o.process_frame(rgb, d, in_pose=P)
+            o.process_frame(rgb, d, in_pose=P, depth_filtered=mf.debugRead("depthF") if share else None)
         else:
             mf.processFrame(rgb, d, timestamp=k)
-            o.process_frame(rgb, d)
+            o.process_frame(rgb, d, depth_filtered=mf.debugRead("depthF") if share else None)
         cg, co = int(mf.getBackgroundModel().lastCount()), int(o.count)
         pd = float(np.abs(mf.getCurrPose() - o.pose).max())
         so = mfo_rgbd.track_stats(o)
