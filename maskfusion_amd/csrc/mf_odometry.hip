@@ -650,7 +650,7 @@ __device__ __forceinline__ void icp_finalize_body(const float* __restrict__ part
         if (so3) { p.lastSO3Error = so3->error; p.lastSO3Count = so3->count; p.so3Iterations = so3->iterations; }
         else { p.lastSO3Error = 0.f; p.lastSO3Count = 0.f; p.so3Iterations = 0; }
         for (int k = 0; k < 3; ++k) p.incT[k] = st.trt[k];
-        if (jump_limit > 0.f && norm3(f3(st.trt[0], st.trt[1], st.trt[2])) > jump_limit) p.alive = 0;
+        if (jump_limit > 0.f && norm3(f3(st.trt[0], st.trt[1], st.trt[2])) >= jump_limit) p.alive = 0;   // `float d > 0.2` is a DOUBLE comparison upstream (MaskFusion.cpp:268): true from 0.2f on
         pose_derive(p);
         *pose = p;
         if (host_mirror) *host_mirror = p;
@@ -1326,7 +1326,7 @@ __global__ __launch_bounds__(256) void k_rgbd_finalize(const float* __restrict__
     if (so3) { p.lastSO3Error = so3->error; p.lastSO3Count = so3->count; p.so3Iterations = so3->iterations; }
     else { p.lastSO3Error = 0.f; p.lastSO3Count = 0.f; p.so3Iterations = 0; }
     for (int k = 0; k < 3; ++k) p.incT[k] = st.trt[k];
-    if (jump_limit > 0.f && norm3(f3(st.trt[0], st.trt[1], st.trt[2])) > jump_limit) p.alive = 0;
+    if (jump_limit > 0.f && norm3(f3(st.trt[0], st.trt[1], st.trt[2])) >= jump_limit) p.alive = 0;   // `float d > 0.2` is a DOUBLE comparison upstream (MaskFusion.cpp:268): true from 0.2f on
     pose_derive(p);
     *pose = p;
     if (host_mirror) *host_mirror = p;

@@ -2381,7 +2381,7 @@ int mfo_mm_process_frame(mfo_mm* x, const uint8_t* rgb, const float* depth, cons
             mm_model* m = &x->models[i];
             if (!m->isStatic || cfg->trackAllModels) {
                 const float d = mm_track(x, m, 0);
-                if (d > 0.2f) { /* inactivateModel, :268-272 */
+                if (d >= 0.2f) { /* inactivateModel, :268-272: `float d > 0.2` compares in double -- 0.2f is the smallest float above 0.2 */
                     mm_model_free(m);
                     memmove(&x->models[i], &x->models[i + 1], sizeof(mm_model) * (size_t)(x->nModels - i - 1));
                     x->nModels--; i--;
