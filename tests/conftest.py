@@ -26,6 +26,15 @@ def _literal_weight_rehearsal():
     if os.environ.get("MF_LITERAL_WEIGHT") == "1":
         from oracle import mfo
         mfo.lib().mfo_set_weight_literal(1)
+        # ... and every context the tests create through the Python mirror switches its literal mode on (this is what makes the rehearsal
+        # work on the GPU as well, where the library's compiled-in default is not touched)
+        from maskfusion_amd import api
+        plain_init = api.MaskFusion.__init__
+
+        def init_with_literal_weight(self, *a, **kw):
+            plain_init(self, *a, **kw)
+            self.setParam("literalFusionWeight", 1)
+        api.MaskFusion.__init__ = init_with_literal_weight
     yield
 
 

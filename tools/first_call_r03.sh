@@ -14,6 +14,8 @@ timeout 600 python -m pytest tests -m gpu -q -x > gpurun_out/r03a_pytest.log 2>&
 (timeout 60 tools/micro/launch_floor; timeout 60 tools/micro/grid_barrier) > gpurun_out/r03a_micro.txt 2>&1; cat gpurun_out/r03a_micro.txt
 MF_TEST_PERSISTENT=1 timeout 300 python -m pytest tests/test_gpu_persistent_icp.py -x -q -s > gpurun_out/r03a_persist.log 2>&1; grep -E "iterations|passed|failed|rror" gpurun_out/r03a_persist.log | head
 timeout 300 python -m pytest tests/test_gpu_gn_graph.py -q -rxX > gpurun_out/r03a_graph.log 2>&1; tail -4 gpurun_out/r03a_graph.log
+# finding F5: the whole suite with the literal fusion weight on both sides (oracle + every context); green => flip both defaults
+MF_LITERAL_WEIGHT=1 timeout 600 python -m pytest tests -m gpu -q > gpurun_out/r03a_pytest_literal_weight.log 2>&1; tail -2 gpurun_out/r03a_pytest_literal_weight.log
 timeout 200 python bench.py > gpurun_out/r03a_bench.json 2> gpurun_out/r03a_bench.err; cut -c1-260 gpurun_out/r03a_bench.json
 timeout 120 python bench.py --no-cpu-baseline --param persistentIcp=1 > gpurun_out/r03a_bench_persist.json 2>> gpurun_out/r03a_bench.err; cut -c1-200 gpurun_out/r03a_bench_persist.json
 timeout 120 python bench.py --no-cpu-baseline --param gnLoopGraph=1 > gpurun_out/r03a_bench_graph.json 2>> gpurun_out/r03a_bench.err; cut -c1-200 gpurun_out/r03a_bench_graph.json
