@@ -92,10 +92,11 @@ def pingpong(n_frames, steps):
     return idx
 
 
-def cpu_baseline(cfg, frames, max_seconds=20.0):
+def cpu_baseline(cfg, frames, max_seconds=25.0):
     """Oracle (port) frames/s on the host cores, bounded sample, from a separate -O3 -march=native build (oracle/mfo.py:
-    build_fast; the parity build keeps -O2 -ffp-contract=off).  The OpenMP thread count is swept up to every hardware thread on
-    2-frame probes first: the oracle's parallel regions are short per-kernel loops, more threads are not always faster."""
+    build_fast; the parity build keeps -O2 -ffp-contract=off).  After 10 warm-up frames (the map has its working size, the pages are
+    touched) the OpenMP thread count is swept on 10 frames per candidate -- the oracle's parallel regions are short per-kernel loops, more
+    threads are not always faster -- and the reported value is the SUSTAINED rate of a further run at the chosen count."""
     import ctypes
     from oracle import mfo
     W, H, F = cfg["W"], cfg["H"], cfg["f"]
@@ -107,36 +108,42 @@ def cpu_baseline(cfg, frames, max_seconds=20.0):
         gomp = None
     o = mfo.Oracle(W, H, F, F, W / 2.0, H / 2.0, icpWeight=100.0, capacity=(1 << 20) * (W * H // 307200), so3=0)
     o.process_frame(frames[0][0], frames[0][1])  # init frame, untimed
-    order = pingpong(len(frames), 1000)[1:]
+    order = pingpong(len(frames), 4000)[1:]
     pos = 0
+
+    def run(n, limit):
+        nonlocal pos
+        t0 = time.time()
+        done = 0
+        while done < n and time.time() - t0 < limit:
+            k = order[pos]; pos += 1
+            o.process_frame(frames[k][0], frames[k][1])
+            done += 1
+        return done, time.time() - t0
+
+    t_all = time.time()
     threads = ncpu
     sweep = {}
     if gomp is not None and ncpu > 4:
+        gomp.omp_set_num_threads(min(ncpu, 32))
+        run(10, 5.0)                                                   # warm-up
         best = None
         for cand in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)} | {ncpu}):
             gomp.omp_set_num_threads(cand)
-            t0 = time.time()
-            for _ in range(2):
-                k = order[pos]; pos += 1
-                o.process_frame(frames[k][0], frames[k][1])
-            dt = time.time() - t0
-            sweep[cand] = round(2.0 / dt, 2)
-            if best is None or dt < best[0]:
-                best = (dt, cand)
+            n, dt = run(10, 3.0)
+            sweep[cand] = round(n / dt, 2)
+            if best is None or n / dt > best[0]:
+                best = (n / dt, cand)
         threads = best[1]
         gomp.omp_set_num_threads(threads)
-    t0 = time.time()
-    n = 0
-    while n < 60 and time.time() - t0 < max_seconds:
-        k = order[pos]; pos += 1
-        o.process_frame(frames[k][0], frames[k][1])
-        n += 1
-    dt = time.time() - t0
+    else:
+        run(10, 5.0)
+    n, dt = run(60, max(3.0, max_seconds - (time.time() - t_all)))
     o.close()
     return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{n} frames of the same {W}x{H} synthetic stream after 1 init frame; OpenMP oracle, "
+            "sample": f"{n} frames of the same {W}x{H} synthetic stream, sustained, after 1 init frame + 10 warm-up frames + the sweep; OpenMP oracle, "
                       f"{'-O3 -march=native build' if fast else 'parity build (-O2, no -march)'}, {threads} of {ncpu} hardware threads "
-                      f"(sweep frames/s by thread count: {sweep})"}
+                      f"(sweep, 10 frames each, frames/s by thread count: {sweep})"}
 
 
 def pmc_traffic(kernel):
@@ -151,14 +158,25 @@ def pmc_traffic(kernel):
         return None
 
 
-def run_sharded(args, cfg, rank, local_rank, world, st, frames):
-    """--config 3: the model-sharded scene.  Every rank calls process_frame for every frame (SPMD); rank 0 holds the inputs."""
+def ranks_seen(world, local_rank):
+    """who took part: the process group's size AND an all-gathered list of the devices the ranks actually sit on"""
     import torch
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    props = torch.cuda.get_device_properties(local_rank)
+    me = {"rank": int(os.environ.get("RANK", "0")), "local_rank": local_rank, "device": torch.cuda.current_device(), "name": props.name,
+          "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", ""))}
+    if world > 1 and dist.is_initialized():
+        seen = [None] * world
+        dist.all_gather_object(seen, me)
+        return {"world_size": dist.get_world_size(), "devices": seen}
+    return {"world_size": 1, "devices": [me]}
+
+
+def sharded_scene(args, cfg, rank, local_rank, world, st, frames, steps, min_seconds):
+    """The model-sharded scene (configs[3]; maskfusion_amd/sharded.py) on the already initialised process group: every rank calls
+    process_frame for every frame (SPMD); rank 0 holds the inputs.  Returns the result record on rank 0 (None elsewhere)."""
+    import torch
+    import torch.distributed as dist
     dev = torch.device("cuda", local_rank)
     from maskfusion_amd import MaskFusion, sharded
     from maskfusion_amd import dist as mfd
@@ -191,27 +209,29 @@ def run_sharded(args, cfg, rank, local_rank, world, st, frames):
             dist.barrier()
 
     run(args.warmup)
-    total_steps, total_dt = 0, 0.0
+    total_steps, total_dt, reps = 0, 0.0, 0
     while True:
+        reps += 1
         barrier()
         t0 = time.perf_counter()
-        run(args.steps)
+        run(steps)
         barrier()
         dt = mfd.max_over_ranks(time.perf_counter() - t0, dev)
-        total_steps += args.steps
+        total_steps += steps
         total_dt += dt
-        if total_dt >= args.min_seconds or total_steps >= 200 * args.steps:
+        if total_dt >= min_seconds or reps >= args.max_reps:
             break
     local = [(m.getID(), m.lastCount()) for i, m in enumerate(mf.getModels()) if rank == 0 or i > 0]
     counts = torch.zeros(world, 2, dtype=torch.float32, device=dev)
     counts[rank, 0], counts[rank, 1] = len(local), sum(c for _, c in local)
     if world > 1:
         dist.all_reduce(counts)
+    out = None
     if rank == 0:
         drift = float(np.linalg.norm(mf.getCurrPose()[:3, 3] - st.gt_pose(order[(cursor[0] - 1) % len(order)])[:3, 3]))
         per_rank = counts.cpu().numpy()
         out = {"metric": f"frames/sec ({W}x{H} RGB-D, one scene: background + {int(per_rank[:, 0].sum()) - 1} object models sharded by model over {world} GPU(s))",
-               "value": total_steps / total_dt, "unit": "frames/s", "n_gpus": world, "steps": total_steps, "steps_requested": args.steps,
+               "value": total_steps / total_dt, "unit": "frames/s", "n_gpus": world, "steps": total_steps, "steps_requested": steps,
                "warmup": args.warmup, "ms_per_step": 1e3 * total_dt / total_steps, "timed_seconds": total_dt, "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": cfg["workload"], "frames_in_hbm": 0, "models": int(per_rank[:, 0].sum()), "surfels": int(per_rank[:, 1].sum()),
@@ -219,6 +239,56 @@ def run_sharded(args, cfg, rank, local_rank, world, st, frames):
                           "parallelism": f"model-sharded x{world} (RCCL: frame broadcast, key all-reduce(MIN), state gather, label broadcast)",
                           "note": "host-pointer frames (the reference's FrameData boundary): H2D + broadcast per frame are inside the timed region"},
                "roofline": None, "roofline_frame": None, "host_input": None, "cpu_baseline": None}
+    mf.close()
+    return out
+
+
+def single_context_scene(args, cfg, local_rank, st, frames, steps, min_seconds):
+    """the same scene with EVERY model in one context on one GPU, through the same host-pointer boundary: the 1-GPU figure the sharded
+    scene's speed-up is quoted against"""
+    from maskfusion_amd import MaskFusion
+    W, H, F = cfg["W"], cfg["H"], cfg["f"]
+    mf = MaskFusion(W, H, F, F, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, device=local_rank, enableMultipleModels=True,
+                    numGSurfels=cfg["surfels"], numOSurfels=1 << 20, trackAllModels=True, modelSpawnOffset=2, initConfidenceGlobal=10.0,
+                    initConfidenceObject=0.01)
+    for k, v in (("mfThreshold", 0.3), ("mfWeightDistance", 150.0), ("mfWeightConvexity", 2.8), ("mfMorphEdgeIterations", 0),
+                 ("mfMorphMaskIterations", 0), ("newModelMinRelativeSize", 0.004)):
+        mf.setParam(k, v)
+    mf.preallocateModels(cfg["n_objects"])
+    cls = [0] + [41 + i for i in range(cfg["n_objects"])]
+    order = pingpong(len(frames), 1 << 16)
+    pos = 0
+    for _ in range(args.warmup):
+        k = order[pos]; pos += 1
+        mf.processFrame(frames[k][0], frames[k][1], mask=frames[k][2], classIDs=cls)
+    total_steps, total_dt = 0, 0.0
+    while total_dt < min_seconds:
+        mf.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            k = order[pos]; pos += 1
+            mf.processFrame(frames[k][0], frames[k][1], mask=frames[k][2], classIDs=cls)
+        mf.sync()
+        total_dt += time.perf_counter() - t0
+        total_steps += steps
+    n_models = len(mf.getModels())
+    mf.close()
+    return {"value": total_steps / total_dt, "unit": "frames/s", "ms_per_step": 1e3 * total_dt / total_steps, "models": n_models,
+            "note": "one context holding every model on rank 0's GPU, mf_process_frame with host pointers (the boundary the sharded form uses)"}
+
+
+def run_sharded(args, cfg, rank, local_rank, world, st, frames):
+    """--config 3: the model-sharded scene as the bench's own line."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    seen = ranks_seen(world, local_rank)
+    out = sharded_scene(args, cfg, rank, local_rank, world, st, frames, args.steps, args.min_seconds)
+    if rank == 0:
+        out["ranks_seen"] = seen
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -232,6 +302,7 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="distinct synthetic frames kept in HBM (0: the config's default; ping-ponged)")
     ap.add_argument("--config", default="1", choices=tuple(CONFIGS), help="workload (1 = the metric's)")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="the timed region is repeated until it has lasted this long")
+    ap.add_argument("--max-reps", type=int, default=100000, help="runaway guard on the repetitions of the timed region")
     ap.add_argument("--icp-weight", type=float, default=100.0, help="icpWeight (>= 100: geometric term only, the metric's setting; "
                     "the reference GUI default is 20: photometric term on, two launches per Gauss-Newton iteration)")
     ap.add_argument("--so3", action="store_true", help="SO(3) photometric pre-alignment (reference default: on)")
@@ -243,6 +314,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host-input", action="store_true")
+    ap.add_argument("--force-sharded-scene", action="store_true", help="run that part at N = 1 as well (rehearsal of the N > 1 code path on one GPU)")
+    ap.add_argument("--no-sharded-scene", action="store_true", help="N > 1: skip the model-sharded 8-object scene that is timed beside the weak-scaling line")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     W, H, F = cfg["W"], cfg["H"], cfg["f"]
@@ -255,6 +328,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # the stream is ray-cast before CUDA exists in this process (the generator forks); only rank 0 owns frames
     st, frames = gen_frames(cfg, n_frames, args.gen_workers) if rank == 0 else (None, None)
+    # N > 1 on the metric's config: the north star's multi-GPU scene (configs[3], 8 objects sharded by model) is timed in the same run,
+    # beside the weak-scaling line whose per-N values the driver compares
+    with_scene = (world > 1 or args.force_sharded_scene) and args.config == "1" and not args.no_sharded_scene
+    st3, frames3 = gen_frames(CONFIGS["3"], CONFIGS["3"]["frames"], args.gen_workers) if (with_scene and rank == 0) else (None, None)
     if args.config == "3":
         if args.steps == 600:
             args.steps = 120
@@ -336,8 +413,9 @@ def main():
     barrier()
     # timed region: `steps` steps between barriers, repeated (each repetition bracketed the same way) until min_seconds have passed;
     # every rank runs the same number of repetitions (the decision is taken on the max-over-ranks time)
-    total_steps, total_dt = 0, 0.0
+    total_steps, total_dt, reps = 0, 0.0, 0
     while True:
+        reps += 1
         barrier()
         t0 = time.perf_counter()
         run(args.steps)
@@ -345,7 +423,7 @@ def main():
         dt = mfd.max_over_ranks(time.perf_counter() - t0, dev)
         total_steps += args.steps
         total_dt += dt
-        if total_dt >= args.min_seconds or total_steps >= 200 * args.steps:
+        if total_dt >= args.min_seconds or reps >= args.max_reps:   # (max_reps: a runaway guard only -- 100 000 by default)
             break
     fps = world * total_steps / total_dt
 
@@ -384,12 +462,27 @@ def main():
         achieved = icp_bytes / n_launch / t_icp / 1e9
         batched = multi and not args.no_batch
         kname = "k_icp_batch_solve + k_icp_batch_pixels" if batched else "k_icp_iter"
+        levels = None
+        if not batched and stages.get("icpFine", 0.0) > 0.0:
+            # the same interval split at the level-0 boundary (a third event on the library's stream): one entry per rocprofv3 kernel name,
+            # so that each can be checked against ONE row of profiles/*kernel_stats.csv (level 0 runs the 512-thread instantiation at
+            # VGA and above, the coarse levels the 256-thread one whenever a level has fewer than 240 chunks of 512 pixels)
+            n_fine, n_coarse = 10, 9
+            b_fine = 48.0 * P
+            b_coarse = (5 * 48.0 * P / 4 + 4 * 48.0 * P / 16) / n_coarse
+            us_f, us_c = stages["icpFine"] * 1e3 / n_fine, stages["icpCoarse"] * 1e3 / n_coarse
+            levels = {"L0": {"kernel": "void mf::k_icp_iter<512>(mf::IcpKArgs)", "launches_per_frame": n_fine, "us": us_f, "bytes": b_fine,
+                             "frac": b_fine / (us_f * 1e-6) / 1e9 / HBM_PEAK_GBS},
+                      "coarse": {"kernel": "void mf::k_icp_iter<256>(mf::IcpKArgs)" if P <= 240 * 512 * 4 else "void mf::k_icp_iter<512>(mf::IcpKArgs) (level 1) / <256> (level 2)",
+                                 "launches_per_frame": n_coarse, "us": us_c,
+                                 "bytes": b_coarse, "frac": b_coarse / (us_c * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                 "note": "5 launches at level 1 (12 P bytes each) + 4 at level 2 (3 P): the average launch"}}
         roofline = {"bound": "hbm", "kernel": f"{kname} (19 iterations/frame, L2:4 L1:5 L0:10; {n_tracked} model(s) per launch)" if batched
                     else f"{kname} (19 launches per model and frame, L2:4 L1:5 L0:10)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "algorithmic_bytes_per_launch": icp_bytes / n_launch, "us_per_launch": t_icp * 1e6,
                     # the committed PMC profile was taken on configs[1] (VGA, one model): it says nothing about the other workloads
-                    "traffic": pmc_traffic("k_icp_iter") if args.config == "1" else None, "stage_ms": stages}
+                    "traffic": pmc_traffic("k_icp_iter") if args.config == "1" else None, "levels": levels, "stage_ms": stages}
         frame_bytes = 741 * P * n_tracked + 192 * count
         roofline_frame = {"bound": "hbm", "algorithmic_bytes": frame_bytes, "ms": 1e3 * total_dt / total_steps,
                           "achieved": frame_bytes / (total_dt / total_steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -418,6 +511,23 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not multi:   # rank 0 at N = 1 only (the other ranks would sit in a collective)
         cpu = cpu_baseline(cfg, frames)
 
+    seen = ranks_seen(world, local_rank)
+    scene = None
+    if with_scene:
+        mf.close()   # the weak-scaling contexts are done: the scene gets the GPUs to itself
+        scene = sharded_scene(args, CONFIGS["3"], rank, local_rank, world, st3, frames3, steps=120, min_seconds=min(args.min_seconds, 2.0))
+        if rank == 0:
+            try:
+                ref = single_context_scene(args, CONFIGS["3"], local_rank, st3, frames3, steps=60, min_seconds=min(args.min_seconds, 1.0))
+            except Exception as e:   # the reference figure must not cost the other ranks (waiting at the barrier below) their run
+                ref = {"value": float("nan"), "error": repr(e)}
+            scene = {"frames_per_s": scene["value"], "ms_per_frame": scene["ms_per_step"], "n_gpus": world, "scaling": "strong",
+                     "models": scene["config"]["models"], "models_per_rank": scene["config"]["models_per_rank"],
+                     "pose_drift_vs_gt_m": scene["config"]["pose_drift_vs_gt_m"], "workload": CONFIGS["3"]["workload"],
+                     "one_gpu_one_context": ref, "speedup_vs_one_gpu": scene["value"] / ref["value"],
+                     "note": "north star: >= 6x at 8 GPUs on this scene; both figures through host-pointer frames"}
+        if world > 1:
+            dist.barrier()
     if rank == 0:
         variant = "" if args.icp_weight >= 100.0 and not args.so3 else f" [variant: icpWeight={args.icp_weight:g}, so3={int(args.so3)}]"
         out = {
@@ -430,6 +540,7 @@ def main():
                        "pose_drift_vs_gt_m": drift, "parallelism": f"context-per-gpu x{world}",
                        **({"params": extra_params} if extra_params else {})},
             "roofline": roofline, "roofline_frame": roofline_frame, "host_input": host_input, "cpu_baseline": cpu,
+            "ranks_seen": seen, "sharded_scene": scene,
         }
         print(json.dumps(out))
     if world > 1:

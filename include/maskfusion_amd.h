@@ -172,8 +172,10 @@ int mf_get_param(mf_ctx* ctx, const char* key, double* value);
  * labels: 0 Preprocess, 1 odomInit (model-side pyramids of the background model), 2 odom (all tracking), 3 indexMap,
  *         4 Fuse::Data, 5 Fuse::Update, 6 Fuse::Copy, 7 IndexMap::ACTIVE, 8 Run,
  *         9 icpIterations: first to last Gauss-Newton iteration launch of the background model (what bench.py divides by
- *           the iteration count for its roofline line) */
-#define MF_N_TIMINGS 10
+ *           the iteration count for its roofline line);
+ *         10 icpCoarse / 11 icpFine: the same interval split right before the first level-0 iteration (launch-per-iteration loop of a
+ *           single model; 0 for the batched / captured forms) */
+#define MF_N_TIMINGS 12
 int mf_get_timings(mf_ctx* ctx, float* ms /* [MF_N_TIMINGS] */);
 /* The context's HIP stream (hipStream_t), for callers that time with their own events. */
 void* mf_get_stream(mf_ctx* ctx);

@@ -69,8 +69,12 @@ class Model:
         self._o._chk(self._o._L.mf_model_fusion_weight(self._o._h, self._i, weightMultiplier, C.byref(out)))
         return out.value
 
-    def performTracking(self, frameToFrameRGB=False, rgbOnly=False, icpWeight=10.0, pyramid=True, fastOdom=False, so3=True,
+    def performTracking(self, frameToFrameRGB=False, rgbOnly=False, icpWeight=None, pyramid=True, fastOdom=False, so3=True,
                         maxDepthProcessed=20.0, logTimestamp=0, tryFillIn=False):
+        # icpWeight=None: the weight the context was created with (the images a photometric term needs only exist if the context has one:
+        # mf_model_perform_tracking returns MF_ESTATE otherwise instead of tracking against images that were never computed)
+        if icpWeight is None:
+            icpWeight = self._o.getParam("icpWeight")
         self._o._chk(self._o._L.mf_model_perform_tracking(self._o._h, self._i, int(frameToFrameRGB), int(rgbOnly), icpWeight,
                                                           int(pyramid), int(fastOdom), int(so3), maxDepthProcessed, logTimestamp,
                                                           int(tryFillIn)))

@@ -81,9 +81,16 @@ def trackable_class_ids(path="config.toml"):
     """MainController.cpp:273-287: ids of [MaskRCNN].trackable_classes within class_names; None when there is no config.toml"""
     if not os.path.exists(path):
         return None
-    import tomli
+    try:
+        import tomllib as toml_reader          # Python >= 3.11
+    except ImportError:
+        try:
+            import tomli as toml_reader        # its backport
+        except ImportError as e:
+            raise RuntimeError(f"{path} exists (upstream reads its [MaskRCNN] table, MainController.cpp:273-287) but neither tomllib "
+                               "(Python >= 3.11) nor tomli is installed; remove the file or install tomli") from e
     with open(path, "rb") as f:
-        cfg = tomli.load(f)["MaskRCNN"]
+        cfg = toml_reader.load(f)["MaskRCNN"]
     names = list(cfg["class_names"])
     return sorted({names.index(c) if c in names else len(names) for c in cfg["trackable_classes"]})
 

@@ -32,6 +32,7 @@ struct ModelState {
     PoseDev* d_pose = nullptr; FrameDev* d_frame = nullptr;
     float4* d_predV = nullptr; float4* d_predN = nullptr; uchar4* d_predImage = nullptr; uint16_t* d_predTime = nullptr;
     uint8_t* d_predGray = nullptr; uint8_t* d_fillGray = nullptr;  // intensity of the RGB projection / of the fill-in image
+    bool pred_gray_valid = false;          // the last prediction of this model wrote d_predGray (/ d_fillGray): it ran with a photometric term configured
     // RGBDOdometry of the model (Model::frameToModel): model-side pyramid, Gauss-Newton state, per-workgroup partial sums
     float* d_vmap_g[3] = {}; float* d_nmap_g[3] = {}; GNState* d_gn = nullptr; float* d_partials[2] = {nullptr, nullptr};
     TrackModelDev* d_track = nullptr;      // the block the batched tracker kernels find all of that through
@@ -145,7 +146,7 @@ struct mf_ctx {
     bool object_small_grids = false;                   // "objectSmallGrids": the grid-stride surfel kernels with a grid sized from the model's last known count
     bool object_scatter_splat = false;                 // "objectScatterSplat": object models are predicted with the scatter form instead of tile lists
 #ifndef MF_DEFAULT_LITERAL_FUSION_WEIGHT
-#define MF_DEFAULT_LITERAL_FUSION_WEIGHT 0             // the rehearsal of flipping this default compiles the test build with -D...=1 (tests/conftest.py)
+#define MF_DEFAULT_LITERAL_FUSION_WEIGHT 1             // default since round 3 (finding F5: the reference's own arithmetic); 0 = the accurate double log map
 #endif
     bool weight_literal = MF_DEFAULT_LITERAL_FUSION_WEIGHT != 0;   // "literalFusionWeight": Model::rodrigues2 with the reference's float trace (finding F5)
     bool gn_loop_graph = false;                        // the launch-per-iteration loop replayed as a captured hipGraph ("gnLoopGraph")
@@ -162,6 +163,7 @@ struct mf_ctx {
     // photometric term + SO(3) (a5, a8-a10, a12)
     uint8_t* d_gray[2][3] = {};            // intensity pyramid of the frame, by frame parity ([prev] = lastNextImage)
     long gray_frame[2] = {-1, -1};         // frame_no each set was computed for
+    long deriv_frame = -1;                 // frame_no the derivative images / gate images (d_dIdx, d_dIdy, d_rgb_gate) were computed for
     int16_t* d_dIdx[3] = {}; int16_t* d_dIdy[3] = {}; uint8_t* d_rgb_gate[3] = {};
     float* d_lastDepth[3] = {}; uint8_t* d_lastImage[3] = {};   // per-model scratch: populateRGBDData(last)
     RgbCorr* d_corres = nullptr; float* d_rgb_partials[2] = {nullptr, nullptr}; int2* d_cnt[2] = {nullptr, nullptr};
@@ -198,6 +200,8 @@ struct mf_ctx {
 
     hipEvent_t ev[MF_N_TIMINGS + 1] = {};
     hipEvent_t ev_icp[2] = {nullptr, nullptr};   // first / after-last Gauss-Newton launch of the background model
+    hipEvent_t ev_icp_mid = nullptr;             // ... and right before its first level-0 iteration (coarse levels | level 0)
+    bool icp_mid_recorded = false;
     float last_ms[MF_N_TIMINGS] = {};
     std::vector<void*> allocs;
     std::vector<void*> host_allocs;
@@ -268,6 +272,7 @@ static __global__ void k_frame_init(FrameDev* f, int tick) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     f->tick = tick; f->count = 0; f->countNext = 0; f->cover = 0; f->useFillIn = 0;
     f->pad[0] = f->pad[1] = f->pad[2] = 0;
+    f->done_cover = 0ull;
 }
 
 static int surfel_capacity(int num) {  // Model::TEXTURE_DIMENSION_*^2 (Core/Model/Model.cpp:101-105)
@@ -446,6 +451,7 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
         if (hipEventCreate(&c->ev[i]) != hipSuccess) return fail(MF_EHIP);
     for (int i = 0; i < 2; ++i)
         if (hipEventCreate(&c->ev_icp[i]) != hipSuccess) return fail(MF_EHIP);
+    if (hipEventCreate(&c->ev_icp_mid) != hipSuccess) return fail(MF_EHIP);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(MF_EHIP);
     *out = c;
     return MF_OK;
@@ -462,6 +468,7 @@ extern "C" void mf_destroy(mf_ctx* c) {
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 2; ++i)
         if (c->ev_icp[i]) (void)hipEventDestroy(c->ev_icp[i]);
+    if (c->ev_icp_mid) (void)hipEventDestroy(c->ev_icp_mid);
     for (int i = 0; i < 2; ++i) {
         if (c->ev_pre_done[i]) (void)hipEventDestroy(c->ev_pre_done[i]);
         if (c->ev_main_done[i]) (void)hipEventDestroy(c->ev_main_done[i]);
@@ -521,7 +528,7 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
     const int iters[3] = {g.fast_odom ? 3 : 10, g.pyramid ? 5 : 0, g.pyramid ? 4 : 0};  // RGBDOdometry.cpp:327-329
     const float sobelScale = 1.0f / 8.0f;                                                // 1 / 2^sobelSize, :31-32
     const bool timed = c->timings_on && &m == c->models[0].get();
-    if (timed) { (void)hipEventRecord(c->ev_icp[0], s); c->tracked_once = true; }
+    if (timed) { (void)hipEventRecord(c->ev_icp[0], s); c->tracked_once = true; c->icp_mid_recorded = false; }
     if (!rgb && c->persistent_icp && !c->icp_prof_on && icp_persistent_fits(W, H)) {
         // experimental: all iterations of all levels in one launch (mf_odometry.hip, k_icp_persist)
         IcpPersistLaunch pl;
@@ -551,6 +558,7 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
     auto issue_loop = [&](bool with_marks) {
     for (int lvl = 2; lvl >= 0; --lvl) {
         const float div = (float)(1 << lvl);
+        if (lvl == 0 && with_marks && timed) { (void)hipEventRecord(c->ev_icp_mid, s); c->icp_mid_recorded = true; }   // coarse levels | level 0 (bench.py: roofline.levels)
         for (int j = 0; j < iters[lvl]; ++j) {
             IcpLaunch l;
             l.vmap_curr = cur_vmap[lvl]; l.nmap_curr = cur_nmap[lvl];
@@ -650,7 +658,7 @@ static void enqueue_track_batch(mf_ctx* c, const std::vector<ModelState*>& ms, c
     const So3Result* so3_seed = so3 ? c->d_so3 : nullptr;
     const int iters[3] = {g.fast_odom ? 3 : 10, g.pyramid ? 5 : 0, g.pyramid ? 4 : 0};
     const bool timed = c->timings_on && ms[0] == c->models[0].get();
-    if (timed) { (void)hipEventRecord(c->ev_icp[0], s); c->tracked_once = true; }
+    if (timed) { (void)hipEventRecord(c->ev_icp[0], s); c->tracked_once = true; c->icp_mid_recorded = false; }
     int it = 0, nb_prev = 0;
     for (int lvl = 2; lvl >= 0; --lvl) {
         const float div = (float)(1 << lvl);
@@ -708,13 +716,16 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
 
 // MaskFusion::predict for one model: combinedPredict(maxDepthProcessed, tick, tick, timeDelta) -- the fill-in half
 // (performFillIn) is evaluated lazily by the next tracking step from the retained filtered depth.
-static void enqueue_predict(mf_ctx* c, ModelState& m) {
+// advance: the end-of-frame bookkeeping of this model (processFrame's tail); the tiled prediction runs it as its epilogue, the scatter
+// form is followed by k_frame_advance.
+static void enqueue_predict(mf_ctx* c, ModelState& m, const FrameAdvance* advance = nullptr) {
+    m.pred_gray_valid = photometric_on(c);
     if (c->splat_tiles && !(c->object_scatter_splat && m.id != 0)) {
         const bool gray = photometric_on(c);
         if (launch_splat_tiled(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, c->cfg.max_depth_processed, m.confThr,
                                c->cfg.time_delta, c->d_tile_count, c->d_tile_entries, c->tile_entries_cap, c->d_splat_rec0, c->d_splat_rec1,
                                c->d_splat_bbox, m.d_predV, m.d_predN, m.d_predImage, m.d_predTime, c->cur_rgb,
-                               gray ? m.d_predGray : nullptr, gray ? m.d_fillGray : nullptr, c->stream) == 0)
+                               gray ? m.d_predGray : nullptr, gray ? m.d_fillGray : nullptr, c->stream, advance) == 0)
             return;
     }
     launch_splat_scatter(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, c->cfg.max_depth_processed, m.confThr,
@@ -722,6 +733,7 @@ static void enqueue_predict(mf_ctx* c, ModelState& m) {
     const bool gray = photometric_on(c) ;
     launch_splat_resolve(m.surf[m.cur], m.d_pose, c->d_keys, c->W, c->H, c->K, m.d_predV, m.d_predN, m.d_predImage, m.d_predTime,
                          m.d_frame, c->cur_rgb, gray ? m.d_predGray : nullptr, gray ? m.d_fillGray : nullptr, c->stream);
+    if (advance) launch_frame_advance(m.d_frame, c->W, c->H, advance->host_mirror, m.d_pose, advance->bg_pose, advance->log_slot, c->stream);
 }
 
 static int check_launch(mf_ctx* c) {
@@ -769,9 +781,11 @@ static int enqueue_preprocess(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
         launch_intensity(d_rgb, 3, c->d_gray[set][0], P, sp);
         for (int i = 0; i + 1 < 3; ++i) launch_pyrdown_u8(c->d_gray[set][i], c->d_gray[set][i + 1], W >> i, H >> i, sp);
         c->gray_frame[set] = k;
-        if (photometric_on(c))
+        if (photometric_on(c)) {
             for (int i = 0; i < 3; ++i)
                 launch_derivative(c->d_gray[set][i], c->d_dIdx[i], c->d_dIdy[i], W >> i, H >> i, rgb_min_scale(i), c->d_rgb_gate[i], sp);
+            c->deriv_frame = k;
+        }
     }
     mark(c, 1, sp);
     if (c->overlap) {
@@ -968,13 +982,13 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
         mark(c, 7);
     }
     for (auto& m : c->models) {  // predict(), :569 ; tick++, :573
-        enqueue_predict(c, *m);
         float* slot = nullptr;
         if (m->d_poselog) {  // MaskFusion.cpp:580-596
             slot = m->d_poselog + (m->log_ts.size() % (size_t)g.pose_log_capacity) * 8;
             m->log_ts.push_back(timestamp);
         }
-        launch_frame_advance(m->d_frame, W, H, m->h_frame, m->d_pose, m.get() == c->models[0].get() ? nullptr : bg.d_pose, slot, s);
+        const FrameAdvance adv{m->h_frame, m.get() == c->models[0].get() ? nullptr : bg.d_pose, slot};
+        enqueue_predict(c, *m, &adv);   // ... with tick++ / the fill-in decision / the pose log entry as its epilogue
         m->age++;  // incrementAge, :600
     }
     mark(c, 8);
@@ -1012,7 +1026,16 @@ extern "C" int mf_sync(mf_ctx* c) {
     if (c->persistent_icp) {   // experimental persistent Gauss-Newton launch: did a device-wide barrier time out?
         unsigned flag = 0;
         MF_HIP(c, hipMemcpy(&flag, c->d_grid_barrier + 1, sizeof(flag), hipMemcpyDeviceToHost));
-        if (flag) { c->err = "persistentIcp: a device-wide barrier timed out (workgroups not co-resident); tracking of that frame was abandoned"; return MF_ESTATE; }
+        if (flag) {
+            // recover: the counter and the host's idea of it are out of step after an abandoned launch and the flag is sticky -- clear both and
+            // go back to the launch-per-iteration loop for the rest of the context's life (as gnLoopGraph does when a capture fails)
+            MF_HIP(c, hipMemset(c->d_grid_barrier, 0, 2 * sizeof(unsigned)));
+            c->grid_barrier_base = 0;
+            c->persistent_icp = false;
+            c->err = "persistentIcp: a device-wide barrier timed out (workgroups not co-resident); tracking of that frame was abandoned, "
+                     "persistentIcp has been switched off for this context";
+            return MF_ESTATE;
+        }
     }
     if (c->timings_on) {
         // event i marks the START of stage i; stage i lasts until event i+1 (labels: see the header)
@@ -1027,6 +1050,9 @@ extern "C" int mf_sync(mf_ctx* c) {
         t[1] = 0.f;
         if (c->tracked_once && hipEventElapsedTime(&init, c->ev[2], c->ev_icp[0]) == hipSuccess) t[1] = init;
         if (c->tracked_once && hipEventElapsedTime(&iters, c->ev_icp[0], c->ev_icp[1]) == hipSuccess) t[9] = iters;
+        float coarse = 0.f, fine = 0.f;   // launch-per-iteration loop of a single model only (the batched / persistent / graph forms record no mid event)
+        if (c->tracked_once && c->icp_mid_recorded && hipEventElapsedTime(&coarse, c->ev_icp[0], c->ev_icp_mid) == hipSuccess &&
+            hipEventElapsedTime(&fine, c->ev_icp_mid, c->ev_icp[1]) == hipSuccess) { t[10] = coarse; t[11] = fine; }
         memcpy(c->last_ms, t, sizeof(t));
     }
     return MF_OK;
@@ -1198,10 +1224,22 @@ extern "C" int mf_model_perform_tracking(mf_ctx* c, int32_t model, int32_t frame
     (void)log_timestamp;   // only forwarded to a debug print upstream
     if (!m || c->frame_no == 0) return MF_EINVAL;
     if (frame_to_frame_rgb) { c->err = "frameToFrameRGB is not supported (never enabled upstream)"; return MF_EINVAL; }
+    const long k = staged_frame(c);
+    // The intensity pyramid, the derivative images and the gate images of the staged frame were built by mf_stage_frame under the CONTEXT's
+    // configuration, and the intensity of the last prediction by that prediction: a per-call photometric term on a context that never
+    // computed them would track against stale or empty images.  Refuse loudly instead (the context must be created with icpWeight < 100
+    // or rgbOnly for a photometric term; SO(3) is guarded inside enqueue_track and simply not run without its two pyramids).
+    if (rgb_only != 0 || icp_weight < 100.f) {
+        const int set = (int)(k & 1);
+        if (c->gray_frame[set] != k || c->deriv_frame != k || !m->pred_gray_valid) {
+            c->err = "performTracking: a photometric term was requested (rgbOnly or icpWeight < 100) but the staged frame / the last prediction carry no "
+                     "intensity and derivative images -- the context was configured without one (icpWeight >= 100, rgbOnly = false) when they were built";
+            return MF_ESTATE;
+        }
+    }
     const mf_config keep = c->cfg;
     c->cfg.rgb_only = rgb_only; c->cfg.icp_weight = icp_weight; c->cfg.pyramid = pyramid; c->cfg.fast_odom = fast_odom; c->cfg.so3 = so3;
     c->cfg.max_depth_processed = max_depth_processed;
-    const long k = staged_frame(c);
     // tryFillIn = MaskFusion::requiresFillIn(model) (:630-648): the decision itself is taken on the device from the coverage of the
     // last prediction; here it only gates whether the fill-in source (the previous frame's filtered depth) is offered at all
     // object models carry the 0.2 m jump rule of the caller (MaskFusion.cpp:268-272): pose->alive = 0 marks "remove this model"

@@ -239,7 +239,8 @@ __device__ inline void rodrigues2_literal_d(const float* Rin, double* r) {
         const double cof[9] = {c00, c01, c02,
                                R[2] * R[7] - R[1] * R[8], R[0] * R[8] - R[2] * R[6], R[1] * R[6] - R[0] * R[7],
                                R[1] * R[5] - R[2] * R[4], R[2] * R[3] - R[0] * R[5], R[0] * R[4] - R[1] * R[3]};
-        for (int k = 0; k < 9; ++k) Rn[k] = 0.5 * (R[k] + cof[k] / det);
+        const double idet = 1.0 / det;   // ONE IEEE division per iteration (nine cost ~3 us of the single-thread finalize chain); the CPU restatement evaluates the same expression
+        for (int k = 0; k < 9; ++k) Rn[k] = 0.5 * (R[k] + cof[k] * idet);
         for (int k = 0; k < 9; ++k) R[k] = Rn[k];
     }
     float Rf[9];

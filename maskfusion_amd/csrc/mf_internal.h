@@ -61,6 +61,7 @@ struct FrameDev {
     int cover;                 // predicted-colour coverage count (requiresFillIn)
     int useFillIn;             // decision taken for the current tracking step
     int pad[3];
+    unsigned long long done_cover;   // k_splat_tile: (workgroups finished << 32) | coverage count of this launch; zero between launches
 };
 
 struct Surfels {               // SoA of float4, 48 B per surfel in three coalesced streams
@@ -232,10 +233,14 @@ void launch_splat_resolve(Surfels src, const PoseDev* pose, unsigned long long* 
 // tile_count must be zero on the first call (it is left zero).  Returns -1 if the image has too many tiles for the LDS
 // histograms (use the scatter form then).
 size_t splat_tiles_scratch_ints(int W, int H);
+// The end-of-frame bookkeeping (k_frame_advance: pose log entry, fill-in decision for the next tracking step, tick++, host mirror) as
+// the epilogue of the tiled prediction: its last workgroup to finish runs it, one launch less per model and frame.
+struct FrameAdvance { FrameDev* host_mirror; const PoseDev* bg_pose; float* log_slot; };
 int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
                        int timeDelta, int* tile_count, int* entries /*[tiles][entries_cap / tiles]*/, int entries_cap,
                        float4* rec0 /*[src.cap]*/, float4* rec1 /*[src.cap]*/, void* bbox /*[src.cap] x 8 B*/, float4* predV, float4* predN,
-                       uchar4* predImage, uint16_t* predTime, const uint8_t* rgb, uint8_t* predGray, uint8_t* fillGray, hipStream_t s);
+                       uchar4* predImage, uint16_t* predTime, const uint8_t* rgb, uint8_t* predGray, uint8_t* fillGray, hipStream_t s,
+                       const FrameAdvance* advance = nullptr);
 void launch_fill_keys(unsigned long long* keys, int n, hipStream_t s);
 void launch_fill_int(int* p, int v, int n, hipStream_t s);
 // ---------------- multi-model coupling (mf_segment.hip) ----------------

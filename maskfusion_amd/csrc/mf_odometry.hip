@@ -197,6 +197,72 @@ __device__ __forceinline__ bool gn_solve_update_wg(const double* s_sys, const GN
     return true;
 }
 
+// The same update with the state resident in LDS and the work after the solve spread over twelve lanes (round 3).  One thread used to run
+// unpack -> LDL^T -> exp -> 3x4 fp64 composition -> float conversions -> 3x3 products -> ~110 scalar stores: ~460 instructions on the one
+// chain every workgroup of every iteration launch waits for (3.2 k cycles = 1.5 us).  Now lanes 0..11 of wavefront 0 each solve the
+// system redundantly in registers (so x needs no broadcast: the LDL^T is ~120 instructions whichever way it is cut) and then compute ONE
+// entry of the 3x4 block of resultRt / of Rcurr / tcurr each, exchanging through 16 floats of LDS: ~230 instructions on the chain.
+// Called by ALL threads of the workgroup (it contains barriers; the other wavefronts only wait at them, as they did before).
+// s_st is updated in place: resultRt, Rcurr, tcurr, trR, trt, lastICPError / Count, valid; everything else keeps its value.  s_pose
+// receives Rcurr[9] tcurr[3] (slots 0..11; slots 12..23 = Rprev_inv, tprev are pose-independent and written by the caller once).
+__device__ __forceinline__ void gn_finish_wg(const double* s_sys, GNState* s_st, float* s_pose, float* s_T /*[16]*/) {
+    const int l = threadIdx.x;
+    const int r = (l >> 2) & 3, c = l & 3;   // lanes 0..11: entry (r, c) of the 3x4 block
+    double nr = 0.0;
+    if (l < 12) {
+        double A[6][6], b[6], x[6];
+        int shift = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 7; ++j) {
+                const double value = s_sys[shift++];
+                if (j == 6) b[i] = value;
+                else { A[i][j] = value; A[j][i] = value; }
+            }
+        ldlt6_solve(A, b, x);
+        double Rw[3][3];
+        rodrigues_d(x[3], x[4], x[5], Rw);
+        const double w0 = r == 0 ? Rw[0][0] : (r == 1 ? Rw[1][0] : Rw[2][0]);
+        const double w1 = r == 0 ? Rw[0][1] : (r == 1 ? Rw[1][1] : Rw[2][1]);
+        const double w2 = r == 0 ? Rw[0][2] : (r == 1 ? Rw[1][2] : Rw[2][2]);
+        const double xr = r == 0 ? x[0] : (r == 1 ? x[1] : x[2]);
+        const double* Rt = s_st->resultRt;
+        nr = w0 * Rt[0 * 4 + c] + w1 * Rt[1 * 4 + c] + w2 * Rt[2 * 4 + c] + xr * Rt[3 * 4 + c];   // resultRt <- [exp(w) | t] * resultRt
+    }
+    __syncthreads();   // every lane has read the old resultRt
+    if (l < 12) {
+        s_st->resultRt[r * 4 + c] = nr;
+        s_T[l] = (float)nr;             // Isometry3f transform: trR = T[r][0..2], trt = T[r][3]
+        if (l == 0) {
+            const float res = (float)s_sys[27], inl = (float)s_sys[28];
+            s_st->lastICPError = sqrtf(res) / inl;
+            s_st->lastICPCount = inl;
+            s_st->valid = 1;
+        }
+    }
+    __syncthreads();
+    // currentT = [Rprev|tprev] * transform.inverse():  iR = trR^T, it = -iR trt, Rcurr = Rprev iR, tcurr = Rprev it + tprev
+    if (l < 9) {
+        const int rr = l / 3, cc = l - 3 * rr;
+        const float v = s_st->Rprev[rr * 3 + 0] * s_T[cc * 4 + 0] + s_st->Rprev[rr * 3 + 1] * s_T[cc * 4 + 1] + s_st->Rprev[rr * 3 + 2] * s_T[cc * 4 + 2];
+        s_st->Rcurr[l] = v;
+        s_pose[l] = v;
+        s_st->trR[l] = s_T[rr * 4 + cc];
+    } else if (l < 12) {
+        const int q = l - 9;
+        s_T[12 + q] = -(s_T[0 * 4 + q] * s_T[0 * 4 + 3] + s_T[1 * 4 + q] * s_T[1 * 4 + 3] + s_T[2 * 4 + q] * s_T[2 * 4 + 3]);
+        s_st->trt[q] = s_T[q * 4 + 3];
+    }
+    __syncthreads();
+    if (l >= 9 && l < 12) {
+        const int q = l - 9;
+        const float v = (s_st->Rprev[q * 3 + 0] * s_T[12] + s_st->Rprev[q * 3 + 1] * s_T[13] + s_st->Rprev[q * 3 + 2] * s_T[14]) + s_st->tprev[q];
+        s_st->tcurr[q] = v;
+        s_pose[9 + q] = v;
+    }
+}
+
 // Fixed-order reduction of `nb` per-workgroup partials ([nb][32] floats) by a 256-thread workgroup -> sys[32] doubles
 // in LDS.  The array is read as float4s with up to 10 independent 16 B loads in flight per lane (a one-load-at-a-time
 // loop cost ~70 cycles per partial: 10 us at 300 workgroups; the partials live in other XCDs' L2s, so every batch is
@@ -368,10 +434,22 @@ __device__ __forceinline__ void block_sum29_lds(const float (&acc)[32], float* s
 // ------------------------------------------------------------------------------------------------
 // The ICP iteration kernel.
 // ------------------------------------------------------------------------------------------------
+// Boundary floats of the two gates on the squared quantities (see icp_accumulate): d2 = max{y : sqrtf(y) <= distThres},
+// s2 = min{y : sqrtf(y) >= angleThres}.  Host libm's sqrtf is correctly rounded, like the device's.
+static void icp_gates(float distThres, float angleThres, float& dist2Max, float& sine2Min) {
+    float d2 = distThres * distThres;
+    while (sqrtf(d2) > distThres) d2 = nextafterf(d2, 0.f);
+    while (sqrtf(nextafterf(d2, INFINITY)) <= distThres) d2 = nextafterf(d2, INFINITY);
+    float s2 = angleThres * angleThres;
+    while (sqrtf(s2) < angleThres) s2 = nextafterf(s2, INFINITY);
+    while (s2 > 0.f && sqrtf(nextafterf(s2, 0.f)) >= angleThres) s2 = nextafterf(s2, 0.f);
+    dist2Max = d2; sine2Min = s2;
+}
+
 struct IcpKArgs {
     const float* vc; const float* nc; const float* vp; const float* np;
     int W, H; Intr k;
-    float distThres, angleThres;
+    float dist2Max, sine2Min;      // the 0.10 m / sin 20 deg gates of reduce.cu:326-341 on the SQUARED quantities (icp_gates)
     const float* partials_in; int nb_in;
     float* partials_out;
     const GNState* st_in; GNState* st_out;
@@ -430,11 +508,14 @@ __device__ __forceinline__ void icp_accumulate(const IcpCorr& c, float3 vprev_g,
                                                const Args& a, float* acc) {
 #pragma clang fp contract(off)
     // search(), second half + getProducts(): Core/Cuda/reduce.cu:326-415
+    // dist = |vprev_g - vcurr_g| <= distThres and sine = |ncurr_g x nprev_g| < angleThres, decided on the squares: sqrtf is monotonic and
+    // correctly rounded, so sqrtf(x) <= T  <=>  x <= max{y : sqrtf(y) <= T}, and sqrtf(x) < T  <=>  x < min{y : sqrtf(y) >= T}; the host finds
+    // the two boundary floats once (icp_gates) and the kernel saves two IEEE square roots (~30 instructions) per pixel -- same inlier set, bit for bit.
     const float3 dv = f3(vprev_g.x - c.vcurr_g.x, vprev_g.y - c.vcurr_g.y, vprev_g.z - c.vcurr_g.z);
-    const float dist = sqrtf(icp_dot3(dv, dv));
+    const float dist2 = icp_dot3(dv, dv);
     const float3 cr = icp_cross3(c.ncurr_g, nprev_g);
-    const float sine = sqrtf(icp_dot3(cr, cr));
-    const bool found = c.ok && sine < a.angleThres && dist <= a.distThres && !isnan(nprev_g.x);
+    const float sine2 = icp_dot3(cr, cr);
+    const bool found = c.ok && sine2 < a.sine2Min && dist2 <= a.dist2Max && !isnan(nprev_g.x);
     if (!found) return;
     const float3 s_cp = c.vcurr_cp;
     const float3 d_cp = icp_mul33(Rpi, f3(vprev_g.x - tp.x, vprev_g.y - tp.y, vprev_g.z - tp.z));
@@ -482,8 +563,8 @@ __global__ __launch_bounds__(kT) void k_icp_iter(const IcpKArgs a) {
     __shared__ double s_sys[32];
     __shared__ float s_pose[24];  // Rcurr[9] tcurr[3] Rprev_inv[9] tprev[3]
     __shared__ float s_red[29 * (kT / 2)];
-    __shared__ GNState s_st;
-    __shared__ GNState s_st_new;  // workgroup 0: the updated state on its way to global memory
+    __shared__ GNState s_st;      // the Gauss-Newton state: loaded (or seeded), updated in place by gn_finish_wg, stored by workgroup 0
+    __shared__ float s_T[16];
 
     const int tid = threadIdx.x;
     // stage the Gauss-Newton state through LDS with one coalesced load (thread 0 would otherwise chase ~80 dependent
@@ -523,37 +604,24 @@ __global__ __launch_bounds__(kT) void k_icp_iter(const IcpKArgs a) {
     // (2) prologue: finish the previous iteration (reduce -> solve -> pose), identically in every workgroup
     if (prof) stamp[1] = __builtin_amdgcn_s_memtime();
     if (a.nb_in > 0) {
-        reduce_partials(a.partials_in, a.nb_in, s_seg, s_sys);
+        reduce_partials(a.partials_in, a.nb_in, s_seg, s_sys);   // (its barriers also publish s_st)
         if (prof) stamp[2] = __builtin_amdgcn_s_memtime();
-        GNState st;
-        if (gn_solve_update_wg(s_sys, s_st, st)) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) { s_pose[k] = st.Rcurr[k]; s_pose[12 + k] = st.Rprev_inv[k]; }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { s_pose[9 + k] = st.tcurr[k]; s_pose[21 + k] = st.tprev[k]; }
-            // workgroup 0 publishes the state (84 words) and the iteration log (32 floats): through LDS, stored after the barrier
-            // by 84 + 32 lanes in one instruction each.  (Thread 0 used to issue those ~115 scalar stores itself, BEFORE the barrier
-            // every other thread of the slowest workgroup of the launch was waiting at: ~1.2 k cycles of every launch.)
-            if (blockIdx.x == 0) s_st_new = st;
-        }
+        gn_finish_wg(s_sys, &s_st, s_pose, s_T);                 // solve, exp, pose composition: state in place, Rcurr / tcurr -> s_pose[0..11]
     } else {
-      __syncthreads();
-      if (tid == 0) {
-        const GNState& st = s_st;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) { s_pose[k] = st.Rcurr[k]; s_pose[12 + k] = st.Rprev_inv[k]; }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { s_pose[9 + k] = st.tcurr[k]; s_pose[21 + k] = st.tprev[k]; }
-      }
+        __syncthreads();
+    }
+    if (tid < 12) {   // the pose-independent half of s_pose, and on the first launch of a tracking step the seeded Rcurr / tcurr
+        s_pose[12 + tid] = tid < 9 ? s_st.Rprev_inv[tid] : s_st.tprev[tid - 9];
+        if (a.nb_in == 0) s_pose[tid] = tid < 9 ? s_st.Rcurr[tid] : s_st.tcurr[tid - 9];
     }
     if (prof) { if (a.nb_in == 0) stamp[2] = stamp[1]; stamp[3] = __builtin_amdgcn_s_memtime(); }
     __syncthreads();
     if (prof) stamp[4] = __builtin_amdgcn_s_memtime();
     if (blockIdx.x == 0) {
+        // workgroup 0 publishes the state (84 words) and the iteration log (32 floats): one store instruction each, after the barrier
         constexpr int kWords = (int)(sizeof(GNState) / 4);
         static_assert(kWords + 32 <= kT, "state + log lanes");
-        const GNState* src = a.nb_in > 0 ? &s_st_new : &s_st;
-        if (tid < kWords) reinterpret_cast<uint32_t*>(a.st_out)[tid] = reinterpret_cast<const uint32_t*>(src)[tid];
+        if (tid < kWords) reinterpret_cast<uint32_t*>(a.st_out)[tid] = reinterpret_cast<const uint32_t*>(&s_st)[tid];
         else if (tid < kWords + 32 && a.log_out && a.nb_in > 0) a.log_out[tid - kWords] = (float)s_sys[tid - kWords];
     }
 
@@ -613,7 +681,7 @@ int icp_grid_blocks(int W, int H) {
 void launch_icp_iteration(const IcpLaunch& l, hipStream_t s) {
     IcpKArgs a;
     a.vc = l.vmap_curr; a.nc = l.nmap_curr; a.vp = l.vmap_prev; a.np = l.nmap_prev;
-    a.W = l.W; a.H = l.H; a.k = l.k; a.distThres = l.distThres; a.angleThres = l.angleThres;
+    a.W = l.W; a.H = l.H; a.k = l.k; icp_gates(l.distThres, l.angleThres, a.dist2Max, a.sine2Min);
     a.partials_in = l.partials_in; a.nb_in = l.nblocks_in; a.partials_out = l.partials_out;
     a.st_in = l.state_in; a.st_out = l.state_out; a.log_out = l.log_out; a.prof_out = l.prof_out; a.pose_in = l.pose_in;
     a.so3_in = l.so3_in;
@@ -626,21 +694,21 @@ void launch_icp_iteration(const IcpLaunch& l, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // last reduce + solve of a tracking step, then Model::pose / lastPose / statistics (RGBDOdometry.cpp:476-496, Model.cpp:437-446)
 // and the object-model jump rule.  Called by all 256 threads of a workgroup.
-__device__ __forceinline__ void icp_finalize_body(const float* __restrict__ partials_in, int nb_in, const GNState* __restrict__ st_in,
+// s_st: LDS copy of the state (st_in may already point at it: the persistent kernel keeps its state there); s_scr: 40 floats of LDS.
+__device__ __forceinline__ void icp_finalize_body(const float* __restrict__ partials_in, int nb_in, const GNState* st_in,
                                                   PoseDev* __restrict__ pose, PoseDev* __restrict__ host_mirror, float* __restrict__ log_out,
-                                                  float jump_limit, const So3Result* __restrict__ so3, double* s_seg, double* s_sys) {
-    GNState st;
-    bool mine = false;
+                                                  float jump_limit, const So3Result* __restrict__ so3, double* s_seg, double* s_sys,
+                                                  GNState* s_st, float* s_scr) {
+    if (st_in != s_st && threadIdx.x < (int)(sizeof(GNState) / 4))
+        reinterpret_cast<uint32_t*>(s_st)[threadIdx.x] = reinterpret_cast<const uint32_t*>(st_in)[threadIdx.x];
     if (nb_in > 0) {
-        reduce_partials(partials_in, nb_in, s_seg, s_sys);
-        mine = gn_solve_update_wg(s_sys, *st_in, st);
-        if (mine && log_out)
-            for (int k = 0; k < 32; ++k) log_out[k] = (float)s_sys[k];
-    } else if (threadIdx.x == 0) {
-        st = *st_in;
-        mine = true;
+        reduce_partials(partials_in, nb_in, s_seg, s_sys);     // (its barriers also publish s_st)
+        gn_finish_wg(s_sys, s_st, s_scr, s_scr + 24);
+        if (log_out && threadIdx.x >= 64 && threadIdx.x < 96) log_out[threadIdx.x - 64] = (float)s_sys[threadIdx.x - 64];
     }
-    if (mine) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const GNState& st = *s_st;
         PoseDev p = *pose;
         for (int k = 0; k < 9; ++k) { p.lastR[k] = st.Rprev[k]; p.R[k] = st.Rcurr[k]; }
         for (int k = 0; k < 3; ++k) { p.lastT[k] = st.tprev[k]; p.t[k] = st.tcurr[k]; }
@@ -663,7 +731,9 @@ __global__ __launch_bounds__(256) void k_icp_finalize(const float* __restrict__ 
                                                        float jump_limit, const So3Result* __restrict__ so3) {
     __shared__ double s_seg[32 * 32];
     __shared__ double s_sys[32];
-    icp_finalize_body(partials_in, nb_in, st_in, pose, host_mirror, log_out, jump_limit, so3, s_seg, s_sys);
+    __shared__ GNState s_st;
+    __shared__ float s_scr[40];
+    icp_finalize_body(partials_in, nb_in, st_in, pose, host_mirror, log_out, jump_limit, so3, s_seg, s_sys, &s_st, s_scr);
 }
 
 void launch_icp_finalize(const float* partials_in, int nblocks_in, const GNState* state_in, PoseDev* pose,
@@ -690,7 +760,7 @@ void launch_icp_finalize(const float* partials_in, int nblocks_in, const GNState
 struct IcpPersistLevel {
     const float* vc; const float* nc; const float* vp; const float* np;
     int W, H; Intr k;
-    float distThres, angleThres;
+    float dist2Max, sine2Min;
     int iters;
 };
 struct IcpPersistArgs {
@@ -725,14 +795,9 @@ __device__ __forceinline__ bool icp_grid_barrier(unsigned* bar, unsigned target,
 
 // The solve and the finalize as real function calls: inlined into the iteration loop their ~90-word Gauss-Newton state pushed the
 // kernel to 256 VGPRs with spills (k_icp_iter: 115); one call per iteration costs a few hundred cycles of one thread.
-__device__ __noinline__ void icp_persist_solve(const double* s_sys, GNState* s_st) {
-    GNState st;
-    gn_solve_update_serial(s_sys, *s_st, st);
-    *s_st = st;
-}
-__device__ __noinline__ void icp_persist_finalize(const float* partials_in, int nb_in, const GNState* st_in, PoseDev* pose, PoseDev* host_mirror,
-                                                  float* log_out, float jump_limit, const So3Result* so3, double* s_seg, double* s_sys) {
-    icp_finalize_body(partials_in, nb_in, st_in, pose, host_mirror, log_out, jump_limit, so3, s_seg, s_sys);
+__device__ __noinline__ void icp_persist_finalize(const float* partials_in, int nb_in, GNState* s_st, PoseDev* pose, PoseDev* host_mirror,
+                                                  float* log_out, float jump_limit, const So3Result* so3, double* s_seg, double* s_sys, float* s_scr) {
+    icp_finalize_body(partials_in, nb_in, s_st, pose, host_mirror, log_out, jump_limit, so3, s_seg, s_sys, s_st, s_scr);
 }
 
 __global__ __launch_bounds__(kIcpThreads) void k_icp_persist(const IcpPersistArgs a) {
@@ -742,6 +807,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp_persist(const IcpPersistArg
     __shared__ float s_pose[24];  // Rcurr[9] tcurr[3] Rprev_inv[9] tprev[3]
     __shared__ float s_red[29 * (kT / 2)];
     __shared__ GNState s_st;
+    __shared__ float s_scr[40];
     __shared__ int s_ok;
 
     const int tid = threadIdx.x;
@@ -777,14 +843,12 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp_persist(const IcpPersistArg
             // (2) finish the previous iteration: reduce -> solve -> pose, identically in every workgroup; the state stays in LDS
             if (nb_prev > 0) {
                 reduce_partials(a.partials[(it + 1) & 1], nb_prev, s_seg, s_sys);
-                if (tid == 0) icp_persist_solve(s_sys, &s_st);
+                gn_finish_wg(s_sys, &s_st, s_pose, s_scr + 24);
                 if (blockIdx.x == 0 && a.log_out && tid >= 64 && tid < 96) a.log_out[(it - 1) * 32 + (tid - 64)] = (float)s_sys[tid - 64];
             }
-            if (tid == 0) {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) { s_pose[k] = s_st.Rcurr[k]; s_pose[12 + k] = s_st.Rprev_inv[k]; }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { s_pose[9 + k] = s_st.tcurr[k]; s_pose[21 + k] = s_st.tprev[k]; }
+            if (tid < 12) {
+                s_pose[12 + tid] = tid < 9 ? s_st.Rprev_inv[tid] : s_st.tprev[tid - 9];
+                if (nb_prev == 0) s_pose[tid] = tid < 9 ? s_st.Rcurr[tid] : s_st.tcurr[tid - 9];
             }
             __syncthreads();
             float Rc[9], Rpi[9];
@@ -821,7 +885,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp_persist(const IcpPersistArg
     // last reduce + solve, Model::pose / lastPose / statistics, the object-model jump rule: workgroup 0
     if (blockIdx.x == 0)
         icp_persist_finalize(nb_prev ? a.partials[(it + 1) & 1] : nullptr, nb_prev, &s_st, a.pose, a.host_mirror,
-                             (a.log_out && it > 0) ? a.log_out + (it - 1) * 32 : nullptr, a.jump_limit, a.so3_in, s_seg, s_sys);
+                             (a.log_out && it > 0) ? a.log_out + (it - 1) * 32 : nullptr, a.jump_limit, a.so3_in, s_seg, s_sys, s_scr);
 }
 
 bool icp_persistent_fits(int W, int H) { return icp_chunk(W * H, kIcpMaxBlocks) <= kIcpPx * kIcpThreads; }
@@ -831,7 +895,9 @@ unsigned launch_icp_persistent(const IcpPersistLaunch& l, hipStream_t s) {
     int n_it = 0;
     for (int i = 0; i < 3; ++i) {
         const IcpLaunch& q = l.level[i];
-        a.lv[i] = IcpPersistLevel{q.vmap_curr, q.nmap_curr, q.vmap_prev, q.nmap_prev, q.W, q.H, q.k, q.distThres, q.angleThres, l.iters[i]};
+        float d2, s2;
+        icp_gates(q.distThres, q.angleThres, d2, s2);
+        a.lv[i] = IcpPersistLevel{q.vmap_curr, q.nmap_curr, q.vmap_prev, q.nmap_prev, q.W, q.H, q.k, d2, s2, l.iters[i]};
         n_it += l.iters[i];
     }
     a.partials[0] = l.partials[0]; a.partials[1] = l.partials[1];
@@ -848,6 +914,7 @@ __global__ __launch_bounds__(256) void k_icp_batch_solve(const IcpSolveArgs a) {
     __shared__ double s_seg[32 * 32];
     __shared__ double s_sys[32];
     __shared__ GNState s_st;
+    __shared__ float s_scr[40];
     const TrackModelDev* __restrict__ md = a.b.m[blockIdx.x];
     const int tid = threadIdx.x;
     if (a.it == 0) {   // RGBDOdometry.cpp:239-243,332-344: Rprev = Rcurr = pose, resultRt = I (or the SO(3) rotation)
@@ -864,8 +931,7 @@ __global__ __launch_bounds__(256) void k_icp_batch_solve(const IcpSolveArgs a) {
     const int prev = (a.it - 1) & 1;
     if (tid < (int)(sizeof(GNState) / 4)) reinterpret_cast<uint32_t*>(&s_st)[tid] = reinterpret_cast<const uint32_t*>(md->st + prev)[tid];
     reduce_partials(md->partials[prev], a.nb_in, s_seg, s_sys);   // (its barriers also publish s_st)
-    GNState out;
-    if (gn_solve_update_wg(s_sys, s_st, out)) s_st = out;   // (thread 0 is the only reader of s_st)
+    gn_finish_wg(s_sys, &s_st, s_scr, s_scr + 24);                 // the same function as k_icp_iter: bit-identical states
     __syncthreads();
     // state (84 words) and log (32 floats) leave through one store instruction each instead of ~115 scalar stores of thread 0
     constexpr int kWords = (int)(sizeof(GNState) / 4);
@@ -877,7 +943,7 @@ struct IcpPxArgs {
     TrackBatch b;
     const float* vc; const float* nc;
     int W, H; Intr k;
-    float distThres, angleThres;
+    float dist2Max, sine2Min;
     int level, parity, chunk;
 };
 constexpr int kBatchThreads = 256;
@@ -935,10 +1001,12 @@ struct IcpFinArgs { TrackBatch b; int n_it; int nb_in; const So3Result* so3; };
 __global__ __launch_bounds__(256) void k_icp_batch_finalize(const IcpFinArgs a) {
     __shared__ double s_seg[32 * 32];
     __shared__ double s_sys[32];
+    __shared__ GNState s_st;
+    __shared__ float s_scr[40];
     const TrackModelDev* __restrict__ md = a.b.m[blockIdx.x];
     const int last = (a.n_it - 1) & 1;
     icp_finalize_body(a.n_it > 0 ? md->partials[last] : nullptr, a.n_it > 0 ? a.nb_in : 0, md->st + (a.n_it > 0 ? last : 0), md->pose, md->pose_host,
-                      (md->log && a.n_it > 0) ? md->log + 32 * (a.n_it - 1) : nullptr, md->jump_limit, a.so3, s_seg, s_sys);
+                      (md->log && a.n_it > 0) ? md->log + 32 * (a.n_it - 1) : nullptr, md->jump_limit, a.so3, s_seg, s_sys, &s_st, s_scr);
 }
 
 // Workgroups per model of the pixel pass: enough of them over all models to fill the GPU a few times over (there is no
@@ -962,7 +1030,7 @@ void launch_icp_batch_solve(const TrackBatch& b, int it, int nb_in, const So3Res
 void launch_icp_batch_pixels(const TrackBatch& b, int it, int level, const float* vmap_curr, const float* nmap_curr, int W, int H, Intr k,
                              float distThres, float angleThres, hipStream_t s) {
     IcpPxArgs a;
-    a.b = b; a.vc = vmap_curr; a.nc = nmap_curr; a.W = W; a.H = H; a.k = k; a.distThres = distThres; a.angleThres = angleThres;
+    a.b = b; a.vc = vmap_curr; a.nc = nmap_curr; a.W = W; a.H = H; a.k = k; icp_gates(distThres, angleThres, a.dist2Max, a.sine2Min);
     a.level = level; a.parity = it & 1; a.chunk = icp_batch_chunk(W * H, b.n);
     hipLaunchKernelGGL(k_icp_batch_pixels, dim3(icp_batch_blocks(W, H, b.n), b.n), dim3(kBatchThreads), 0, s, a);
 }
@@ -977,17 +1045,26 @@ struct GnSolveOut { double x_serial[6], x_wave[6], resultRt[16]; float Rcurr[9],
 __global__ __launch_bounds__(64) void k_gn_solve_test(const double* __restrict__ sys29, const double* __restrict__ resultRt,
                                                       const float* __restrict__ Rprev, const float* __restrict__ tprev, GnSolveOut* out) {
     __shared__ double s_sys[32];
+    __shared__ GNState s_st;
+    __shared__ float s_pose[24];
+    __shared__ float s_T[16];
     if (threadIdx.x < 32) s_sys[threadIdx.x] = threadIdx.x < 29 ? sys29[threadIdx.x] : 0.0;
+    if (threadIdx.x == 0) {
+        GNState& in = s_st;
+        for (int k = 0; k < 16; ++k) in.resultRt[k] = resultRt[k];
+        for (int k = 0; k < 9; ++k) { in.Rprev[k] = Rprev[k]; in.Rcurr[k] = Rprev[k]; in.trR[k] = 0.f; }
+        for (int k = 0; k < 3; ++k) { in.tprev[k] = tprev[k]; in.tcurr[k] = tprev[k]; in.trt[k] = 0.f; }
+        m33_inverse_f(in.Rprev, in.Rprev_inv);
+        in.lastICPError = in.lastICPCount = 0.f; in.valid = 0; in.levelDone = -1; in.lastRGBError = 0.f; in.lastRGBCount = 0.f;
+    }
     __syncthreads();
     double xw[6];
     solve6_wave(s_sys, xw);
+    // what k_icp_iter / k_icp_batch_solve / k_icp_finalize call: twelve lanes, state in LDS (the serial form -- gn_solve_update_serial --
+    // stays as the executable specification: tests/test_devmath_host.py compiles it for the host)
+    gn_finish_wg(s_sys, &s_st, s_pose, s_T);
+    __syncthreads();
     if (threadIdx.x != 0) return;
-    GNState in, st;
-    for (int k = 0; k < 16; ++k) in.resultRt[k] = resultRt[k];
-    for (int k = 0; k < 9; ++k) { in.Rprev[k] = Rprev[k]; in.Rcurr[k] = Rprev[k]; in.trR[k] = 0.f; }
-    for (int k = 0; k < 3; ++k) { in.tprev[k] = tprev[k]; in.tcurr[k] = tprev[k]; in.trt[k] = 0.f; }
-    m33_inverse_f(in.Rprev, in.Rprev_inv);
-    in.lastICPError = in.lastICPCount = 0.f; in.valid = 0; in.levelDone = -1; in.lastRGBError = 0.f; in.lastRGBCount = 0.f;
     double A[6][6], b[6], x[6];
     int shift = 0;
     for (int i = 0; i < 6; ++i)
@@ -997,7 +1074,7 @@ __global__ __launch_bounds__(64) void k_gn_solve_test(const double* __restrict__
             else { A[i][j] = value; A[j][i] = value; }
         }
     ldlt6_solve(A, b, x);
-    gn_solve_update_serial(s_sys, in, st);     // what k_icp_iter / k_icp_batch_solve / k_icp_finalize call
+    const GNState& st = s_st;
     for (int k = 0; k < 6; ++k) { out->x_serial[k] = x[k]; out->x_wave[k] = xw[k]; }
     for (int k = 0; k < 16; ++k) out->resultRt[k] = st.resultRt[k];
     for (int k = 0; k < 9; ++k) { out->Rcurr[k] = st.Rcurr[k]; out->trR[k] = st.trR[k]; }
@@ -1336,7 +1413,7 @@ void launch_rgbd_iteration(const RgbdLaunch& l, hipStream_t s) {
     RgbdKArgs a;
     const IcpLaunch& il = l.icp;
     a.icp.vc = il.vmap_curr; a.icp.nc = il.nmap_curr; a.icp.vp = il.vmap_prev; a.icp.np = il.nmap_prev;
-    a.icp.W = il.W; a.icp.H = il.H; a.icp.k = il.k; a.icp.distThres = il.distThres; a.icp.angleThres = il.angleThres;
+    a.icp.W = il.W; a.icp.H = il.H; a.icp.k = il.k; icp_gates(il.distThres, il.angleThres, a.icp.dist2Max, a.icp.sine2Min);
     a.icp.partials_in = il.partials_in; a.icp.nb_in = il.nblocks_in; a.icp.partials_out = il.partials_out;
     a.icp.st_in = il.state_in; a.icp.st_out = il.state_out; a.icp.log_out = il.log_out; a.icp.prof_out = nullptr; a.icp.pose_in = il.pose_in; a.icp.so3_in = nullptr;
     a.L = l.L; a.corres = l.corres; a.rgb_partials_in = l.rgb_partials_in; a.cnt_in = l.cnt_in; a.cnt_out = l.cnt_out;

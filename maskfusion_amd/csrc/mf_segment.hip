@@ -185,7 +185,7 @@ __global__ void k_spawn_pose(PoseDev* obj, const PoseDev* bg, FrameDev* objFrame
     const float3 v = mul33(q.initR, f3(bg->t[0], bg->t[1], bg->t[2]));
     q.initT[0] = -v.x; q.initT[1] = -v.y; q.initT[2] = -v.z;
     *obj = q;
-    objFrame->tick = bgFrame->tick; objFrame->count = 0; objFrame->countNext = 0; objFrame->cover = 0; objFrame->useFillIn = 0;
+    objFrame->tick = bgFrame->tick; objFrame->count = 0; objFrame->countNext = 0; objFrame->cover = 0; objFrame->useFillIn = 0; objFrame->done_cover = 0ull;
     objFrame->pad[0] = objFrame->pad[1] = objFrame->pad[2] = 0;
     if (host_mirror) *host_mirror = q;
 }

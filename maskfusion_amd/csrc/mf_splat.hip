@@ -137,6 +137,7 @@ struct TileArgs {
     const float4* rec0; const float4* rec1; const short4* bbox;
     float4* predV; float4* predN; uchar4* predImage; uint16_t* predTime;
     const uint8_t* rgb; uint8_t* predGray; uint8_t* fillGray;
+    int advance; FrameAdvance adv;   // advance != 0: the last workgroup also runs the end-of-frame bookkeeping (k_frame_advance)
 };
 
 // The z-test of one 16x16 tile in LDS, shared by the prediction (payload = surfel index) and the global projection (payload =
@@ -195,44 +196,73 @@ __global__ __launch_bounds__(256) void k_splat_tile(const TileArgs a) {
     __shared__ unsigned long long s_key[kTile * kTile];
     __shared__ float4 s_ray[kTile * kTile];
     __shared__ int s_range[1];
+    __shared__ int s_cover;
     const int tile = blockIdx.x;
     const int tx0 = (tile % a.tilesX) * kTile, ty0 = (tile / a.tilesX) * kTile;
     const Intr k = a.k;
+    if (threadIdx.x == 0) s_cover = 0;   // (ordered before its use by the barriers inside tile_ztest)
     tile_ztest<true>(tile, a.tilesX, k, a.tile_count, a.entries, a.tile_cap, a.frame, a.rec0, a.rec1, a.bbox, 0u, s_key, s_ray, s_range);
     const int px = tx0 + (threadIdx.x & (kTile - 1)), py = ty0 + (threadIdx.x >> 4);
-    if (px >= a.W || py >= a.H) return;
-    const int p = py * a.W + px;
-    const unsigned long long key = s_key[threadIdx.x];
-    if (key == kEmptyKey) {
+    int covered = 0;   // this pixel is one of the 20x down-sampled samples of MaskFusion::requiresFillIn and carries a colour
+    if (px < a.W && py < a.H) {
+      const int p = py * a.W + px;
+      const unsigned long long key = s_key[threadIdx.x];
+      if (key == kEmptyKey) {
         a.predV[p] = a.predN[p] = make_float4(0, 0, 0, 0);
         a.predImage[p] = make_uchar4(0, 0, 0, 0);
         a.predTime[p] = 0;
         if (a.predGray) a.predGray[p] = 0;
         if (a.fillGray && a.rgb) a.fillGray[p] = intensity_of((float)a.rgb[p * 3], (float)a.rgb[p * 3 + 1], (float)a.rgb[p * 3 + 2]);
-        return;
+      } else {
+        const int i = (int)(unsigned)(key & 0xFFFFFFFFull);
+        const float z = __uint_as_float((unsigned)(key >> 32));
+        const float4 pc = a.src.pc[i], c4 = a.src.ct[i], n4 = a.src.nr[i];
+        const float3 n = normalize_gl(mul33(a.pose->Ri, f3(n4.x, n4.y, n4.z)));
+        const float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;
+        a.predV[p] = make_float4((fcx - k.cx) * z * (1.f / k.fx), (fcy - k.cy) * z * (1.f / k.fy), z, pc.w);  // combo_splat.frag:56
+        a.predN[p] = make_float4(n.x, n.y, n.z, n4.w);
+        const int ci = (int)c4.x;
+        const uchar4 col = make_uchar4((ci >> 16) & 0xFF, (ci >> 8) & 0xFF, ci & 0xFF, 255);
+        a.predImage[p] = col;
+        a.predTime[p] = (uint16_t)(unsigned)c4.z;
+        if (a.predGray || a.fillGray) {
+            const uint8_t gv = intensity_of((float)col.x, (float)col.y, (float)col.z);
+            if (a.predGray) a.predGray[p] = gv;
+            if (a.fillGray) {
+                const bool empty = col.x == 0 && col.y == 0 && col.z == 0;
+                a.fillGray[p] = (empty && a.rgb) ? intensity_of((float)a.rgb[p * 3], (float)a.rgb[p * 3 + 1], (float)a.rgb[p * 3 + 2]) : gv;
+            }
+        }
+        // MaskFusion::requiresFillIn (MaskFusion.cpp:630-648): nearest sample of the 20x down-sampled colour prediction
+        covered = ((px % 20) == 10 && (py % 20) == 10 && px / 20 < a.W / 20 && py / 20 < a.H / 20 && col.x > 0 && col.y > 0 && col.z > 0) ? 1 : 0;
+      }
     }
-    const int i = (int)(unsigned)(key & 0xFFFFFFFFull);
-    const float z = __uint_as_float((unsigned)(key >> 32));
-    const float4 pc = a.src.pc[i], c4 = a.src.ct[i], n4 = a.src.nr[i];
-    const float3 n = normalize_gl(mul33(a.pose->Ri, f3(n4.x, n4.y, n4.z)));
-    const float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;
-    a.predV[p] = make_float4((fcx - k.cx) * z * (1.f / k.fx), (fcy - k.cy) * z * (1.f / k.fy), z, pc.w);  // combo_splat.frag:56
-    a.predN[p] = make_float4(n.x, n.y, n.z, n4.w);
-    const int ci = (int)c4.x;
-    const uchar4 col = make_uchar4((ci >> 16) & 0xFF, (ci >> 8) & 0xFF, ci & 0xFF, 255);
-    a.predImage[p] = col;
-    a.predTime[p] = (uint16_t)(unsigned)c4.z;
-    if (a.predGray || a.fillGray) {
-        const uint8_t gv = intensity_of((float)col.x, (float)col.y, (float)col.z);
-        if (a.predGray) a.predGray[p] = gv;
-        if (a.fillGray) {
-            const bool empty = col.x == 0 && col.y == 0 && col.z == 0;
-            a.fillGray[p] = (empty && a.rgb) ? intensity_of((float)a.rgb[p * 3], (float)a.rgb[p * 3 + 1], (float)a.rgb[p * 3 + 2]) : gv;
+    // One 64-bit atomic per workgroup carries both its coverage count and its "finished" ticket (the count travels IN the atomic, so
+    // the workgroup that draws the last ticket holds the launch's total without any ordering between workgroups).  That workgroup
+    // hands the total on: to frame->cover for a stand-alone prediction, or straight into the end-of-frame bookkeeping that used to be
+    // its own single-thread launch (k_frame_advance, ~4.7 us per model and frame).  Nothing else in this launch reads what it writes.
+    if (covered) atomicAdd(&s_cover, 1);   // at most two such pixels per 16x16 tile
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int wg_cover = s_cover;
+        const unsigned long long old = atomicAdd(&a.frame->done_cover, (1ull << 32) | (unsigned long long)(unsigned)wg_cover);
+        if ((unsigned)(old >> 32) == gridDim.x - 1u) {
+            const int cover = (int)(unsigned)(old & 0xFFFFFFFFull) + wg_cover;
+            FrameDev* f = a.frame;
+            f->done_cover = 0ull;
+            if (a.advance) {
+                if (a.adv.log_slot) pose_log_entry(a.pose, a.adv.bg_pose, a.adv.log_slot);
+                const int rw = a.W / 20, rh = a.H / 20;
+                f->pad[0] = f->useFillIn;   // decision the tracking step of THIS frame ran with (mf_get_last_fillin)
+                f->useFillIn = ((float)(f->cover + cover) / (float)(rw * rh) < 0.75f) ? 1 : 0;
+                f->cover = 0;
+                f->tick += 1;
+                if (a.adv.host_mirror) *a.adv.host_mirror = *f;
+            } else {
+                f->cover += cover;
+            }
         }
     }
-    // MaskFusion::requiresFillIn (MaskFusion.cpp:630-648): nearest sample of the 20x down-sampled colour prediction
-    if ((px % 20) == 10 && (py % 20) == 10 && px / 20 < a.W / 20 && py / 20 < a.H / 20 && col.x > 0 && col.y > 0 && col.z > 0)
-        atomicAdd(&a.frame->cover, 1);
 }
 
 // GlobalProjection (Core/Model/GlobalProjection.cpp:43-114, splat_models.vert / combo_splat_models.frag) of ONE model through the
@@ -270,7 +300,9 @@ int launch_global_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W
     b.timeDelta = timeDelta; b.tilesX = tilesX; b.tilesY = tilesY; b.tile_count = tile_count;
     b.entries = entries; b.tile_cap = entries_cap / nt; b.frame_rw = frame;
     b.rec0 = rec0; b.rec1 = rec1; b.bbox = reinterpret_cast<short4*>(bbox);
-    const int nblocks = min(256, (src.cap + 2 * kBinThreads - 1) / (2 * kBinThreads));
+    // two 1024-thread workgroups fit on a CU (60 VGPRs): 512 workgroups are ONE round of chunks up to a million surfels (with 256 a
+    // 0.6 M-surfel map was 293 chunks = two rounds, the second one on 37 CUs)
+    const int nblocks = min(512, (src.cap + 2 * kBinThreads - 1) / (2 * kBinThreads));
     hipLaunchKernelGGL(k_splat_bin, dim3(nblocks), dim3(kBinThreads), (size_t)2 * nt * sizeof(int), s, b);
     GlobalTileArgs t;
     t.frame = frame; t.W = W; t.H = H; t.k = k; t.tilesX = tilesX; t.tile_count = tile_count; t.entries = entries; t.tile_cap = b.tile_cap;
@@ -284,7 +316,8 @@ size_t splat_tiles_scratch_ints(int W, int H) { return (size_t)((W + kTile - 1) 
 
 int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
                        int timeDelta, int* tile_count, int* entries, int entries_cap, float4* rec0, float4* rec1, void* bbox, float4* predV,
-                       float4* predN, uchar4* predImage, uint16_t* predTime, const uint8_t* rgb, uint8_t* predGray, uint8_t* fillGray, hipStream_t s) {
+                       float4* predN, uchar4* predImage, uint16_t* predTime, const uint8_t* rgb, uint8_t* predGray, uint8_t* fillGray, hipStream_t s,
+                       const FrameAdvance* advance) {
     const int tilesX = (W + kTile - 1) / kTile, tilesY = (H + kTile - 1) / kTile, nt = tilesX * tilesY;
     if (nt > kMaxTiles) return -1;
     BinArgs b;
@@ -292,7 +325,9 @@ int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W,
     b.timeDelta = timeDelta; b.tilesX = tilesX; b.tilesY = tilesY; b.tile_count = tile_count;
     b.entries = entries; b.tile_cap = entries_cap / nt; b.frame_rw = frame;
     b.rec0 = rec0; b.rec1 = rec1; b.bbox = reinterpret_cast<short4*>(bbox);
-    const int nblocks = min(256, (src.cap + 2 * kBinThreads - 1) / (2 * kBinThreads));
+    // two 1024-thread workgroups fit on a CU (60 VGPRs): 512 workgroups are ONE round of chunks up to a million surfels (with 256 a
+    // 0.6 M-surfel map was 293 chunks = two rounds, the second one on 37 CUs)
+    const int nblocks = min(512, (src.cap + 2 * kBinThreads - 1) / (2 * kBinThreads));
     hipLaunchKernelGGL(k_splat_bin, dim3(nblocks), dim3(kBinThreads), (size_t)2 * nt * sizeof(int), s, b);
     TileArgs t;
     t.src = src; t.frame = frame; t.pose = pose; t.W = W; t.H = H; t.k = k; t.maxDepth = maxDepth; t.confThreshold = confThreshold;
@@ -300,6 +335,8 @@ int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W,
     t.entries = entries; t.tile_cap = b.tile_cap; t.rec0 = rec0; t.rec1 = rec1; t.bbox = reinterpret_cast<const short4*>(bbox);
     t.predV = predV; t.predN = predN; t.predImage = predImage; t.predTime = predTime; t.rgb = rgb; t.predGray = predGray;
     t.fillGray = fillGray;
+    t.advance = advance ? 1 : 0;
+    t.adv = advance ? *advance : FrameAdvance{nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(k_splat_tile, dim3(nt), dim3(256), 0, s, t);
     return 0;
 }

@@ -1582,10 +1582,10 @@ int mfo_requires_fill_in(const uint8_t* predImage, int W, int H, float ratio) {
 /* Model.cpp:449-464; rodrigues2 :891-932 (the SVD re-orthonormalisation U V^T is replaced by Newton polar
  * iterations, identical to rounding for the near-rotations that occur). */
 /* Literal mode (finding F5): U V^T, its off-diagonal differences and its trace are FLOAT in the reference (Eigen::Matrix3f,
- * Model.cpp:892-901), so cos(theta) is quantised in steps of 1.2e-7 and theta = acos(c) in steps of ~4.9e-4 rad near 0.  Off by default
- * until the device's matching mode ("literalFusionWeight") has been seen on hardware; tests/test_weight_pin.py compares this mode with the
- * reference's compiled text. */
-static int g_weight_literal = 0;
+ * Model.cpp:892-901), so cos(theta) is quantised in steps of 1.2e-7 and theta = acos(c) in steps of ~4.9e-4 rad near 0.  ON by default
+ * since round 3 (the device's matching mode "literalFusionWeight" is its default too); mfo_set_weight_literal(0) selects the accurate
+ * double log map of rounds 1-2.  tests/test_weight_pin.py compares both modes with the reference's compiled text. */
+static int g_weight_literal = 1;
 void mfo_set_weight_literal(int on) { g_weight_literal = on; }
 static void rodrigues2(const float* Rin, double* r) {
     double R[9], Rn[9];
@@ -1596,7 +1596,8 @@ static void rodrigues2(const float* Rin, double* r) {
         double cof[9] = {c00, c01, c02,
                          R[2] * R[7] - R[1] * R[8], R[0] * R[8] - R[2] * R[6], R[1] * R[6] - R[0] * R[7],
                          R[1] * R[5] - R[2] * R[4], R[2] * R[3] - R[0] * R[5], R[0] * R[4] - R[1] * R[3]};
-        for (int k = 0; k < 9; ++k) Rn[k] = 0.5 * (R[k] + cof[k] / det); /* cof/det = R^-T */
+        const double idet = 1.0 / det;   /* one division per iteration (the device evaluates the same expression: bit-identical) */
+        for (int k = 0; k < 9; ++k) Rn[k] = 0.5 * (R[k] + cof[k] * idet); /* cof/det = R^-T */
         memcpy(R, Rn, sizeof(R));
     }
     double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
@@ -2215,7 +2216,9 @@ struct mfo_mm {
     uint8_t* cand_op; int32_t* cand_best; float* cand_rec; int n_cand;
     rgbd_scratch rs;
     float* edge; uint8_t* binEdge; uint8_t* ucharBuf; uint8_t* projIDs; uint8_t* ignoreMap; uint8_t* fullSeg;
+    const float* depthF_override;   /* test isolation, as mfo_override_filtered_depth: consumed by the next mfo_mm_process_frame */
 };
+void mfo_mm_override_filtered_depth(mfo_mm* x, const float* depthF) { x->depthF_override = depthF; }
 
 void mfo_mm_default_config(mfo_mm_config* c, int W, int H, float fx, float fy, float cx, float cy) {
     memset(c, 0, sizeof(*c));
@@ -2361,7 +2364,8 @@ int mfo_mm_process_frame(mfo_mm* x, const uint8_t* rgb, const float* depth, cons
     const int W = g->W, H = g->H, P = W * H;
     memcpy(x->rgb, rgb, (size_t)P * 3);
     memcpy(x->depth, depth, sizeof(float) * P);
-    mfo_bilateral(x->depth, x->depthF, W, H);
+    if (x->depthF_override) { memcpy(x->depthF, x->depthF_override, sizeof(float) * P); x->depthF_override = NULL; }
+    else mfo_bilateral(x->depth, x->depthF, W, H);
     mm_model* bg = &x->models[0];
     if (x->tick == 1) {
         bg->cur = 0;

@@ -334,6 +334,8 @@ typedef struct {
 void    mfo_mm_default_config(mfo_mm_config* c, int W, int H, float fx, float fy, float cx, float cy);
 mfo_mm* mfo_mm_create(const mfo_mm_config* c);
 void    mfo_mm_destroy(mfo_mm* x);
+/* test isolation (see mfo_override_filtered_depth): the NEXT mfo_mm_process_frame takes this image as the bilateral filter's output */
+void    mfo_mm_override_filtered_depth(mfo_mm* x, const float* depthF);
 int     mfo_mm_process_frame(mfo_mm* x, const uint8_t* rgb, const float* depth, const uint8_t* mask,
                              const int32_t* classIDs, int nMasks, float weightMultiplier);
 int     mfo_mm_num_models(const mfo_mm* x);

@@ -51,6 +51,7 @@ def mm_lib():
     L.mfo_mm_create.restype = C.c_void_p
     L.mfo_mm_destroy.argtypes = [C.c_void_p]
     L.mfo_mm_process_frame.argtypes = [C.c_void_p, u8p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_float]
+    L.mfo_mm_override_filtered_depth.argtypes = [C.c_void_p, f32p]
     L.mfo_mm_num_models.argtypes = [C.c_void_p]
     L.mfo_mm_num_models.restype = C.c_int
     for n in ("mfo_mm_model_id", "mfo_mm_model_count"):
@@ -166,7 +167,12 @@ class OracleMM:
     def __del__(self):
         self.close()
 
-    def process_frame(self, rgb, depth, mask=None, class_ids=(), weight_multiplier=1.0):
+    def process_frame(self, rgb, depth, mask=None, class_ids=(), weight_multiplier=1.0, depth_filtered=None):
+        """depth_filtered: test isolation -- taken as the bilateral filter's output instead of running the filter (so that a pipeline-level
+        comparison is not perturbed by the last bits of two exp() implementations; the filter is compared on its own)"""
+        if depth_filtered is not None:
+            self._dF = np.ascontiguousarray(depth_filtered, np.float32)
+            mm_lib().mfo_mm_override_filtered_depth(self.h, self._dF)
         m = np.ascontiguousarray(mask, np.uint8) if mask is not None else None
         cid = np.ascontiguousarray(class_ids, np.int32) if len(class_ids) else None
         self._keep = (m, cid)

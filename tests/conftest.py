@@ -19,25 +19,6 @@ def oracle():
     return mfo
 
 
-@pytest.fixture(scope="session", autouse=True)
-def _literal_weight_rehearsal():
-    """MF_LITERAL_WEIGHT=1 (with MF_EMU=1): rehearse the default flip of finding F5 -- the oracle in its literal fusion-weight mode and the
-    CPU-executed test build compiled with literalFusionWeight on by default"""
-    if os.environ.get("MF_LITERAL_WEIGHT") == "1":
-        from oracle import mfo
-        mfo.lib().mfo_set_weight_literal(1)
-        # ... and every context the tests create through the Python mirror switches its literal mode on (this is what makes the rehearsal
-        # work on the GPU as well, where the library's compiled-in default is not touched)
-        from maskfusion_amd import api
-        plain_init = api.MaskFusion.__init__
-
-        def init_with_literal_weight(self, *a, **kw):
-            plain_init(self, *a, **kw)
-            self.setParam("literalFusionWeight", 1)
-        api.MaskFusion.__init__ = init_with_literal_weight
-    yield
-
-
 @pytest.fixture(scope="session")
 def hip():
     """The HIP extension + a CUDA(=HIP) torch device; GPU tests fail loudly if either is missing."""

@@ -55,9 +55,6 @@ def build(force: bool = False, only=None, coop: bool = False, asan: bool = False
     if ubsan:
         cxx = CXX + ["-fsanitize=undefined", "-fno-sanitize=float-cast-overflow", "-fno-omit-frame-pointer", "-g1"]
     tag = "emuu_" if ubsan else "emua_" if asan else "emuc_" if coop else "emu_"
-    if os.environ.get("MF_LITERAL_WEIGHT") == "1":      # rehearsal of the default flip of finding F5: literalFusionWeight on by default
-        cxx = cxx + ["-DMF_DEFAULT_LITERAL_FUSION_WEIGHT=1"]
-        lib, tag = lib.replace(".so", "_litw.so"), tag + "lw_"
     if coop and asan:                       # all workgroups resident AND AddressSanitizer: for kernels with device-wide barriers
         lib, tag = os.path.join(OUT, "libmaskfusion_emu_coop_asan.so"), "emuca_"
     if not (force or _stale(lib)) and only is None:

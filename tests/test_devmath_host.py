@@ -212,18 +212,18 @@ def test_pose_inverse_and_fusion_weight(dm):
         assert np.abs(Ri.reshape(3, 3) - Tinv[:3, :3]).max() < 1e-6 and np.abs(ti - Tinv[:3, 3]).max() < 5e-6
         T1f = np.eye(4, dtype=np.float32); T1f[:3, :3] = R1; T1f[:3, 3] = t1
         T0f = np.eye(4, dtype=np.float32); T0f[:3, :3] = R0; T0f[:3, 3] = t0
-        wo = mfo.fusion_weight(T1f, T0f, 1.0)
+        mfo.lib().mfo_set_weight_literal(0)                      # the accurate double log map (the switch's "off" position since round 3)
+        try:
+            wo = mfo.fusion_weight(T1f, T0f, 1.0)
+        finally:
+            mfo.lib().mfo_set_weight_literal(1)
         assert float(w[0]) == wo, (k, float(w[0]), wo)          # the same operations in the same order: identical
         assert 0.5 <= float(w[0]) <= 1.0
         # "literalFusionWeight" (finding F5: the reference's float trace quantises the rotation): the device's literal mode and the
         # oracle's literal mode are the same operations too
         wl = np.zeros(1, np.float32)
         dm.dm_pose_derive(R1.reshape(9), t1, R0.reshape(9), t0, Ri, ti, wl, 1)
-        mfo.lib().mfo_set_weight_literal(1)
-        try:
-            wol = mfo.fusion_weight(T1f, T0f, 1.0)
-        finally:
-            mfo.lib().mfo_set_weight_literal(0)
+        wol = mfo.fusion_weight(T1f, T0f, 1.0)                   # the oracle's default IS the literal mode
         assert float(wl[0]) == wol, (k, float(wl[0]), wol)
 
 

@@ -1,0 +1,199 @@
+"""Round-3 parity gates on the workloads bench.py actually times ("Next round" item 1):
+
+  * test_long_horizon_ate            600 frames of the noisy S1 stream (configs[1]'s own stream), HIP vs oracle on identical inputs:
+                                     ATE RMSE < 1 mm (north star), per-frame deltas printed every 50 frames, first frame above 1 mm reported.
+  * test_s2_eight_objects_*          the 8-object S2 scene (configs[3]) against OracleMM for 40 frames at modelSpawnOffset = 2: ids per
+                                     frame, model count, label image, background pose -- standing objects (strict, every frame) and
+                                     moving + tracked objects (what bench.py --config 2s / 3 run).
+  * test_config4_four_objects        one 4-object 1280x960 case (configs[4]).
+
+MF_PARITY_FRAMES=<n> shortens the 600-frame run (rehearsals against the CPU-executed kernels, MF_EMU=1)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1500)]
+
+SEG = dict(threshold=0.3, weightDistance=150.0, weightConvexity=2.8, morphEdgeIterations=0, morphMaskIterations=0, minRelSizeNew=0.004)
+
+
+def _render_job(job):
+    kw, k = job
+    from maskfusion_amd import synth
+    return synth.Stream(**kw).frame(k)
+
+
+def render(kw, n):
+    """n frames of synth.Stream(**kw), ray-cast on the host cores (spawned workers: this process may already hold a HIP context)."""
+    from maskfusion_amd import synth
+    workers = max(1, min(32, (os.cpu_count() or 1) - 1, n // 8))
+    if workers <= 1:
+        st = synth.Stream(**kw)
+        return [st.frame(k) for k in range(n)]
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(workers) as pool:
+        return pool.map(_render_job, [(kw, k) for k in range(n)], chunksize=max(1, n // (4 * workers)))
+
+
+def _last_step(log_row):
+    """the Gauss-Newton step the LAST iteration of a frame applied, from the device's log of that iteration's reduced system (27 packed
+    upper-triangle products of the 7-vector row in reduce.cu:378-411 order, then residual and inlier count)"""
+    A, b = np.zeros((6, 6)), np.zeros(6)
+    k = 0
+    for i in range(6):
+        for j in range(i, 7):
+            if j == 6:
+                b[i] = log_row[k]
+            else:
+                A[i, j] = A[j, i] = log_row[k]
+            k += 1
+    x = np.linalg.solve(A, b)
+    return float(np.linalg.norm(x[:3])), float(np.linalg.norm(x[3:]))
+
+
+def test_long_horizon_ate(hip, oracle):
+    """The bench's own workload (600 frames of S1, Kinect-like noise, one background model, geometric ICP) through both sides.
+
+    What can be expected (seen first on the CPU-executed kernels, 60 frames): while the reference's fixed 4/5/10 iteration schedule
+    CONVERGES (last step of a frame below ~1e-5 m / rad; inlier count stationary over its last iterations) the two trajectories agree to
+    micrometres.  From the first frame on which it does NOT converge (frame 15 of this stream: the inlier count is still climbing by
+    40-180 per iteration at the tenth level-0 iteration and the last step is ~1e-4 m) the truncated iteration is no longer a fixed
+    point, the 1e-7 differences of two summation orders are amplified by what is left of the descent, and the trajectories separate by
+    1-2 mm -- and come back together: both are tied to the same frames, each is ~13 mm from the ground truth.  So the gates are:
+      * per frame 1e-4 m while every frame so far has converged;
+      * north star: the ATE RMSE against the ground truth differs by < 1 mm between the two;
+      * the two trajectories are closer to each other than half of what either is from the ground truth (and < 1 mm when that is more).
+    The first unconverged frame and the largest separation are printed (DESIGN.md quotes them)."""
+    from maskfusion_amd import MaskFusion, synth
+    n = int(os.environ.get("MF_PARITY_FRAMES", "600"))
+    kw = dict(W=640, H=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, noise=True)
+    st = synth.Stream(**kw)
+    frames = render(kw, n)
+    cap = 1 << 21
+    o = oracle.Oracle(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpWeight=100.0, capacity=cap, so3=0)
+    m = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=100.0, so3=False, numGSurfels=cap, enableMultipleModels=False)
+    gp, op, gc, oc, last = [], [], [], [], [(0.0, 0.0)]
+    for k, (rgb, depth, _) in enumerate(frames):
+        o.process_frame(rgb, depth)
+        m.processFrame(rgb, depth, timestamp=k)
+        gp.append(m.getCurrPose()); op.append(o.pose)
+        gc.append(m.getBackgroundModel().lastCount()); oc.append(o.count)
+        if k > 0:
+            last.append(_last_step(m.debugRead("icp_log")[18]))
+    o.close(); m.close()
+    gp, op, last = np.array(gp), np.array(op), np.array(last)
+    gt = np.array([st.gt_pose(k) for k in range(n)])
+    d = np.linalg.norm(gp[:, :3, 3] - op[:, :3, 3], axis=1)
+    dR = np.abs(gp[:, :3, :3] - op[:, :3, :3]).max(axis=(1, 2))
+    for k in range(0, n, 50):
+        print(f"frame {k:4d}: |t_hip - t_oracle| {d[k] * 1e3:.4f} mm, max |dR| {dR[k]:.2e}, last step {last[k][0]:.1e} m {last[k][1]:.1e} rad, "
+              f"surfels hip/oracle {gc[k]}/{oc[k]}")
+    unconverged = (last[:, 0] > 2e-5) | (last[:, 1] > 2e-5)
+    first_unc = int(np.argmax(unconverged)) if unconverged.any() else n
+    above = np.nonzero(d > 1e-3)[0]
+    ate = synth.ate_rmse(gp, op)
+    ate_g, ate_o = synth.ate_rmse(gp, gt), synth.ate_rmse(op, gt)
+    print(f"{n} frames: ATE RMSE hip vs oracle {ate * 1e3:.4f} mm (max per-frame {d.max() * 1e3:.4f} mm at frame {int(d.argmax())}); "
+          f"vs GT: hip {ate_g * 1e3:.3f} mm, oracle {ate_o * 1e3:.3f} mm; first frame above 1 mm: {int(above[0]) if len(above) else None}; "
+          f"first frame whose Gauss-Newton loop did not converge (last step > 2e-5): {first_unc}, {int(unconverged.sum())} of {n} frames did not; "
+          f"max |t_hip - t_oracle| before it: {d[:first_unc].max() * 1e3:.4f} mm; final surfels hip/oracle {gc[-1]}/{oc[-1]}")
+    assert first_unc >= min(n, 10), "the stream must start with converging frames"
+    assert d[:first_unc].max() < 1e-4          # float noise while the iteration is a fixed point
+    assert abs(ate_g - ate_o) < 1e-3           # north star: ATE RMSE (vs the ground truth) delta < 1 mm
+    assert ate < max(1e-3, 0.5 * min(ate_g, ate_o))
+    rel = np.abs(np.array(gc, float) - np.array(oc, float)) / np.maximum(np.array(oc, float), 1.0)
+    print("surfel count relative difference: max %.4f at frame %d" % (rel.max(), int(rel.argmax())))
+    assert rel.max() < 1e-2
+
+
+def _pair(oracle, kw, n_frames, track_all, cap_g=1 << 20, cap_o=1 << 18, spawn_offset=2, share_filter=True):
+    """share_filter: the oracle takes the product's filtered depth (the bilateral filter is compared on its own, test_gpu_kernels.py: a few
+    ulp between v_exp_f32 and expf).  Without it the last bits of the filter move ~0.3-0.6 % of the label pixels of this 8-object scene from
+    the very first segmentation on -- geometric-edge values within rounding of the 0.3 threshold, each flip re-cutting a thin component --
+    which says nothing about the label stage; with it every later stage is compared on identical inputs."""
+    n_frames = int(os.environ.get("MF_PARITY_MM_FRAMES", n_frames))
+    from maskfusion_amd import MaskFusion, synth
+    from oracle import mfo_mm
+    st = synth.Stream(**kw)
+    frames = render(kw, n_frames)
+    cls = [0] + [41 + i for i in range(kw["n_objects"])]
+    # confO = 0.01, confG = 10 (what bench.py --config 2s / 3 use)
+    o = mfo_mm.OracleMM(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpWeight=100.0, so3=0, capacity=cap_g, capacityObject=cap_o,
+                        modelSpawnOffset=spawn_offset, trackAllModels=int(track_all), seg=SEG, confGlobal=10.0, confObject=0.01)
+    m = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=100.0, so3=False, numGSurfels=cap_g, numOSurfels=cap_o,
+                   enableMultipleModels=True, modelSpawnOffset=spawn_offset, trackAllModels=track_all, initConfidenceGlobal=10.0,
+                   initConfidenceObject=0.01)
+    for k, v in (("mfThreshold", SEG["threshold"]), ("mfWeightDistance", SEG["weightDistance"]), ("mfWeightConvexity", SEG["weightConvexity"]),
+                 ("mfMorphEdgeIterations", 0), ("mfMorphMaskIterations", 0), ("newModelMinRelativeSize", SEG["minRelSizeNew"])):
+        m.setParam(k, v)
+    rec = []
+    for k, (rgb, depth, mask) in enumerate(frames):
+        m.processFrame(rgb, depth, mask=mask, classIDs=cls, timestamp=k)
+        o.process_frame(rgb, depth, mask, cls, depth_filtered=m.debugRead("depthF") if share_filter else None)
+        gm = m.getModels()
+        rec.append(dict(o_ids=[o.model_id(i) for i in range(o.n_models)], g_ids=[x.getID() for x in gm],
+                        o_cnt=[o.model_count(i) for i in range(o.n_models)], g_cnt=[x.lastCount() for x in gm],
+                        seg_diff=float((o.segmentation() != m.downloadSegmentation()).mean()),
+                        o_pose=[o.model_pose(i) for i in range(o.n_models)], g_pose=[x.getPose() for x in gm]))
+    o.close(); m.close()
+    return rec
+
+
+def _report(rec):
+    for k, r in enumerate(rec):
+        dp = [float(np.abs(a - b).max()) for a, b in zip(r["o_pose"], r["g_pose"])]
+        print(k, "ids oracle/hip", r["o_ids"], r["g_ids"], "label diff %.5f" % r["seg_diff"], "pose diff", [round(x, 6) for x in dp],
+              "counts", r["o_cnt"], r["g_cnt"])
+
+
+def test_s2_eight_objects_standing(hip, oracle):
+    """8 instance-masked boxes standing still, object models follow the camera (the shipped default: static objects): the whole
+    multi-model state machine at the scale of configs[3] -- compared strictly on every one of the 40 frames."""
+    kw = dict(W=640, H=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, n_objects=8, noise=True, object_motion=0.0)
+    rec = _pair(oracle, kw, 40, False)
+    _report(rec)
+    for k, r in enumerate(rec):
+        assert r["o_ids"] == r["g_ids"], f"frame {k}"                                  # same models, same ids, same order
+        assert r["seg_diff"] < 2e-3, f"frame {k}"
+        for i in range(len(r["o_pose"])):
+            assert np.abs(r["o_pose"][i] - r["g_pose"][i]).max() < 2e-4, (k, i)
+        for a, b in zip(r["o_cnt"], r["g_cnt"]):
+            assert abs(a - b) <= max(20, 0.01 * a), (k, a, b)
+    assert len(rec[-1]["o_ids"]) >= 7, "the scenario must spawn the object models"
+
+
+def test_s2_eight_objects_tracked(hip, oracle):
+    """The scene bench.py --config 2s / --config 3 time: 8 moving boxes, trackAllModels.  Model list (ids, count) and label image on every
+    frame, background pose 2e-4; object poses are printed and bounded (each object's ICP runs on ~2-3 k surfels of a few planar faces:
+    the per-frame gate of the standing case does not apply to it, see test_gpu_multimodel.py::test_tracked_objects_short_horizon)."""
+    kw = dict(W=640, H=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, n_objects=8, noise=True, object_motion=1.0)
+    rec = _pair(oracle, kw, 40, True)
+    _report(rec)
+    same_ids = [r["o_ids"] == r["g_ids"] for r in rec]
+    first_split = same_ids.index(False) if False in same_ids else None
+    print("model lists identical on", sum(same_ids), "of", len(rec), "frames; first difference at frame", first_split,
+          "; final model count oracle/hip", len(rec[-1]["o_ids"]), len(rec[-1]["g_ids"]))
+    for k, r in enumerate(rec):
+        assert np.abs(r["o_pose"][0] - r["g_pose"][0]).max() < 2e-4, f"background pose, frame {k}"
+        assert r["g_ids"][0] == 0 and len(set(r["g_ids"])) == len(r["g_ids"])
+        assert r["o_ids"] == r["g_ids"], f"frame {k}"
+        assert r["seg_diff"] < 2e-3, f"frame {k}"
+        for i in range(1, len(r["o_pose"])):
+            assert np.abs(r["o_pose"][i] - r["g_pose"][i]).max() < 4e-2, (k, i)
+    assert len(rec[-1]["g_ids"]) >= 7
+
+
+def test_config4_four_objects_1280x960(hip, oracle):
+    """configs[4]'s shape: 1280x960, 4 objects (standing, so that every frame is comparable), 10 frames."""
+    kw = dict(W=1280, H=960, fx=1056.0, fy=1056.0, cx=640.0, cy=480.0, n_objects=4, noise=True, object_motion=0.0)
+    rec = _pair(oracle, kw, 10, False, cap_g=1 << 22, cap_o=1 << 20)
+    _report(rec)
+    for k, r in enumerate(rec):
+        assert r["o_ids"] == r["g_ids"], f"frame {k}"
+        assert r["seg_diff"] < 2e-3, f"frame {k}"
+        for i in range(len(r["o_pose"])):
+            assert np.abs(r["o_pose"][i] - r["g_pose"][i]).max() < 2e-4, (k, i)
+        for a, b in zip(r["o_cnt"], r["g_cnt"]):
+            assert abs(a - b) <= max(40, 0.01 * a), (k, a, b)
+    assert len(rec[-1]["o_ids"]) >= 4

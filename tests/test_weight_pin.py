@@ -11,8 +11,8 @@ one quantum (0.049 of the weight range) in the reference itself.  What can be pi
   * the oracle's LITERAL mode (mfo_set_weight_literal(1): float matrix, float trace), which the device's "literalFusionWeight" switch
     reproduces bit for bit (tests/test_devmath_host.py), lands on the same quantum as the compiled reference text most of the time and never
     further than one and a half quanta away;
-  * the default (accurate log map in double) is equally close in the worst case and systematically off below the first quantum: that is
-    the documented deviation, kept as the default until the literal mode has been seen on hardware."""
+  * the accurate log map in double (rounds 1-2's default, now `mfo_set_weight_literal(0)` / `literalFusionWeight = 0`) is equally close in
+    the worst case and systematically off below the first quantum.  Since round 3 the LITERAL mode is the default of oracle and device."""
 import numpy as np
 import pytest
 from scipy.spatial.transform import Rotation as Rot
@@ -65,12 +65,12 @@ def test_slow_rotations_within_the_reference_own_quantum():
     for k in range(2000):
         T1, T0, ang, tr = _sample(rng)
         ref = mfweight.fusion_weight(T1, T0, 1.0)
-        L.mfo_set_weight_literal(1)
+        lit = mfo.fusion_weight(T1, T0, 1.0)                                       # literal mode: the default of oracle and device
+        L.mfo_set_weight_literal(0)
         try:
-            lit = mfo.fusion_weight(T1, T0, 1.0)
+            acc = mfo.fusion_weight(T1, T0, 1.0)
         finally:
-            L.mfo_set_weight_literal(0)
-        acc = mfo.fusion_weight(T1, T0, 1.0)
+            L.mfo_set_weight_literal(1)
         d_lit.append(abs(ref - lit)); d_acc.append(abs(ref - acc))
     d_lit, d_acc = np.array(d_lit), np.array(d_acc)
     print("literal mode: same quantum in %.0f %%, mean |dw| %.4f, max %.3f;  accurate mode: within 1e-3 in %.0f %%, mean %.4f, max %.3f"
