@@ -265,7 +265,6 @@ public:
           exportSegmentation_(exportSegmentationResults),
           // MaskFusion.cpp:37
           queueLength_((usePrecomputedMasksOnly || segmentationMethod != Segmentation::Method::MASK_FUSION) ? 0 : frameQueueSize) {
-        if (frameToFrameRGB) throw std::invalid_argument("maskfusion_amd: frameToFrameRGB is never enabled upstream and is not built");
         if (segmentationMethod == Segmentation::Method::CO_FUSION)
             throw std::invalid_argument("maskfusion_amd: the Co-Fusion segmentation method is out of scope (DESIGN.md section 1)");
         const Resolution& res = Resolution::getInstance();
@@ -287,6 +286,7 @@ public:
         width_ = cfg.width, height_ = cfg.height;
         const int rc = mf_create(&cfg, &ctx_);
         if (rc != MF_OK) throw std::runtime_error("maskfusion_amd: mf_create failed with code " + std::to_string(rc));
+        if (frameToFrameRGB) mf_set_param(ctx_, "frameToFrameRGB", 1.0);   // MaskFusion.cpp:66
         refreshModels();
     }
     virtual ~MaskFusion() { mf_destroy(ctx_); }
@@ -357,9 +357,7 @@ public:
     void setPyramid(const bool& v) { set("pyramid", v); }
     void setFastOdom(const bool& v) { set("fastOdom", v); }
     void setSo3(const bool& v) { set("so3", v); }
-    void setFrameToFrameRGB(const bool& v) {
-        if (v) throw std::invalid_argument("maskfusion_amd: frameToFrameRGB is never enabled upstream and is not built");
-    }
+    void setFrameToFrameRGB(const bool& v) { set("frameToFrameRGB", v); }   // Core/MaskFusion.cpp:910 ("-ftf", GUI/MainController.cpp:252,539)
     void setConfidenceThreshold(const float& v) { set("confidenceThreshold", v); }
     void setFernThresh(const float&) {}  // ferns: dead code upstream
     void setDepthCutoff(const float& v) { set("depthCutoff", v); }

@@ -120,6 +120,11 @@ int mf_save_ply(mf_ctx* ctx, const char* export_dir);
 /* {lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count, so3 iterations, rejected by the
  * 0.3 m rule} of the last tracking step of model i (RGBDOdometry.h:68-75, RGBDOdometry.cpp:477-481) */
 int mf_get_track_stats(mf_ctx* ctx, int32_t model, float* out8);
+/* No upstream twin.  The device solves the 6x6 Gauss-Newton system (RGBDOdometry.cpp:447-459 hands it to Eigen::LDLT, diagonal pivoting, on
+ * float-rounded sums) with an unpivoted LDL^T on fp64 sums: identical to rounding for a well-posed system, NOT for a rank-deficient one
+ * (DESIGN.md finding F4).  *ill_iterations = how many iterations of the model's last geometric tracking step were outside that domain:
+ * fewer than 6 inliers, or smallest pivot < 1e-8 x largest diagonal entry (=> cond(A) > 1e8).  0 means the step is the reference's to rounding. */
+int mf_get_gn_condition(mf_ctx* ctx, int32_t model, int32_t* ill_iterations);
 /* RGBDOdometry::lastICPError / lastICPCount (Core/Utils/RGBDOdometry.h) of `model` */
 int mf_get_icp_stats(mf_ctx* ctx, int32_t model, float* last_error, float* last_count);
 /* Model::downloadMap (Core/Model/Model.h:206, Model.cpp:943-974): out has room for max_count*12 floats */
@@ -156,14 +161,15 @@ int mf_get_last_fillin(mf_ctx* ctx, int32_t* used);
  * (0), "cleanLiteralWindow" (1: Model::clean walks its window with copy_unstable.vert's own fp32 trip count, 4 or 5 taps per axis;
  * 0: 4 x 4), "timings", "icpProfile", "gnLoopGraph" (0; 1: the launches of the geometric Gauss-Newton loop of a tracking step are captured
  * once per frame parity with hipStreamBeginCapture / EndCapture and replayed as one hipGraphLaunch -- same kernels, same arguments, same
- * bits; if the runtime refuses the capture the eager launches are used and mf_get_param reads 0 again), "objectSmallGrids" (0; 1: the grid-stride
- * surfel kernels of an object model run on a grid sized from its last known surfel count instead of 2048 workgroups), "objectScatterSplat" (0;
- * 1: object models are predicted with the scatter form of the splat instead of tile lists) -- both leave every result bit-identical and
- * exist for an A/B of the launch-bound multi-model frames; "literalFusionWeight" (0; 1: Model::computeFusionWeight's log map takes cos(theta) from the
- * float trace of a float matrix as the reference's text does -- its rotation term is then quantised in steps of ~4.9e-4 rad; 0: the same
- * formula evaluated accurately in double.  See DESIGN.md, finding F5).  Experimental, default 0, not yet validated on hardware: "persistentIcp" (the geometric Gauss-Newton
- * loop of a single-model tracking step as ONE persistent launch with device-wide barriers between the iterations instead of 19 dependent
- * launches; a barrier that times out makes mf_sync return MF_ESTATE, it cannot hang). */
+ * bits; if the runtime refuses the capture the eager launches are used and mf_get_param reads 0 again), "objectSmallGrids" (1; 1: the grid-stride
+ * surfel kernels of an object model run on a grid sized from its last known surfel count instead of 2048 workgroups), "objectScatterSplat" (1;
+ * 1: object models are predicted with the scatter form of the splat instead of tile lists) -- both leave every result bit-identical; measured on
+ * MI355X on the 12-model S2 scene: 394 -> 407 frames/s with both (profiles/r03a_bench_2s_object_switches.txt), on since round 3;
+ * "literalFusionWeight" (1: Model::computeFusionWeight's log map takes cos(theta) from the float trace of a float matrix as the reference's
+ * text does -- its rotation term is then quantised in steps of ~4.9e-4 rad; 0: the same formula evaluated accurately in double.  See
+ * DESIGN.md, finding F5; default 1 since round 3), "frameToFrameRGB" (0; MaskFusion::setFrameToFrameRGB, "-ftf": the photometric term tracks
+ * against the previous RAW frame, Model.cpp:399-400,981), "objectBoundingBoxLimit" (1: Model::fuse limits an object model's depth by its
+ * bounding box + 5 % as upstream does whenever its GUI draws the models, Model.cpp:480-501; 0: bb_max_z = FLT_MAX, a headless upstream). */
 int mf_set_param(mf_ctx* ctx, const char* key, double value);
 int mf_get_param(mf_ctx* ctx, const char* key, double* value);
 
@@ -224,8 +230,11 @@ int mf_model_initialise(mf_ctx* ctx, int32_t model);
 int mf_model_override_pose(mf_ctx* ctx, int32_t model, const float* pose16);
 /* Model::computeFusionWeight(weightMultiplier) (Core/Model/Model.cpp:449-464) of the model's pose / lastPose.  Synchronous. */
 int mf_model_fusion_weight(mf_ctx* ctx, int32_t model, float weight_multiplier, float* out);
-/* Model::performTracking (Core/Model/Model.h:135-136, Model.cpp:427-447); frame_to_frame_rgb must be 0 (never enabled
- * upstream, Core/MaskFusion.cpp:248); the rgb texture is the staged frame's */
+/* Model::performTracking (Core/Model/Model.h:135-136, Model.cpp:427-447); the rgb texture is the staged frame's.  frame_to_frame_rgb
+ * ("-ftf", GUI/MainController.cpp:252,539): initRGBModel takes the fill-in image -- the previous RAW frame when the last prediction ran
+ * with mf_set_param("frameToFrameRGB", 1) (Model.cpp:981) -- instead of the model's RGB projection (Model.cpp:399-400); models that
+ * allow no fill-in (objects) are unaffected, as upstream.  MF_ESTATE when a photometric term is requested on a context that built no
+ * intensity / derivative images (icpWeight >= 100 and no rgbOnly). */
 int mf_model_perform_tracking(mf_ctx* ctx, int32_t model, int32_t frame_to_frame_rgb, int32_t rgb_only, float icp_weight,
                               int32_t pyramid, int32_t fast_odom, int32_t so3, float max_depth_processed, int64_t log_timestamp,
                               int32_t try_fill_in);

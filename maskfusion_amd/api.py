@@ -282,6 +282,7 @@ class MaskFusion:
     def setOutlierCoefficient(self, v): self.setParam("outlierCoefficient", v)
     def setFastOdom(self, v): self.setParam("fastOdom", int(v))
     def setSo3(self, v): self.setParam("so3", int(v))
+    def setFrameToFrameRGB(self, v): self.setParam("frameToFrameRGB", int(v))   # Core/MaskFusion.cpp:910
     def setRgbOnly(self, v): self.setParam("rgbOnly", int(v))
 
     def trackStats(self, model: int = 0) -> dict:
@@ -291,6 +292,12 @@ class MaskFusion:
         keys = ("lastICPError", "lastICPCount", "lastRGBError", "lastRGBCount", "lastSO3Error", "lastSO3Count", "so3Iterations",
                 "rejected")
         return dict(zip(keys, out.tolist()))
+    def gnIllIterations(self, model: int = 0) -> int:
+        """Gauss-Newton iterations of the last geometric tracking step whose system was outside the solver's stated domain (finding F4)"""
+        n = C.c_int32(0)
+        self._chk(self._L.mf_get_gn_condition(self._h, model, C.byref(n)))
+        return n.value
+
     def setPyramid(self, v): self.setParam("pyramid", int(v))
     def setEnableMultipleModels(self, v): self.setParam("enableMultipleModels", int(v))
 

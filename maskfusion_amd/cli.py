@@ -57,8 +57,6 @@ def settings(flags):
     cal = flags.get("-cal")
     if flags.get("-method", "") == "cofusion":
         raise SystemExit("-method cofusion: the Co-Fusion CRF segmentation is out of scope of this build (DESIGN.md section 1)")
-    if "-ftf" in flags:
-        raise SystemExit("-ftf: frame-to-frame RGB tracking is not built (never enabled upstream, Core/MaskFusion.cpp:248)")
     return dict(W=W, H=H, fx=fx, fy=fy, cx=cx, cy=cy, cal=cal,
                 trackAllModels=False,                                   # GUI/Tools/GUI.h:344 "oi.Track all models" = false
                 mf=dict(mfThreshold=0.3, mfWeightDistance=150.0, mfWeightConvexity=2.8, mfMorphEdgeIterations=0, mfMorphEdgeRadius=1,
@@ -74,7 +72,8 @@ def settings(flags):
                 multi="-static" not in flags, modelSpawnOffset=int(float(flags.get("-offset", 22))),
                 timeDelta=(2 ** 31 - 1) // 2,   # openLoop = true (MainController.cpp:246)
                 start=int(flags.get("-s", 1)), end=int(flags.get("-e", 65535)), rgbOnly="-rgbonly" in flags,
-                flipColors="-f" in flags, device=int(flags.get("-gpu", 0)))
+                flipColors="-f" in flags, device=int(flags.get("-gpu", 0)),
+                frameToFrameRGB="-ftf" in flags)                       # MainController.cpp:252 -> MaskFusion::frameToFrameRGB
 
 
 def trackable_class_ids(path="config.toml"):
@@ -131,6 +130,8 @@ def main(argv=None):
                     modelSpawnOffset=st["modelSpawnOffset"], rgbOnly=st["rgbOnly"], trackAllModels=st["trackAllModels"])
     for key, value in st["mf"].items():
         mf.setParam(key, value)
+    if st["frameToFrameRGB"]:
+        mf.setFrameToFrameRGB(True)
     ids = trackable_class_ids()
     if ids is not None:
         mf.setTrackableClassIds(ids)

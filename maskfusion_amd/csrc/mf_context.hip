@@ -142,17 +142,17 @@ struct mf_ctx {
     bool map_ready = false;            // the background map exists (first frame processed, Model::initialise or an uploaded map)
     bool tracked_once = false;         // a tracking step has run (its stage timings are meaningful)
     bool timings_on = false, icp_prof_on = false;
-    // A/B switches for object models (a few thousand surfels each; their per-frame cost is launch overhead), both 0 until measured:
-    bool object_small_grids = false;                   // "objectSmallGrids": the grid-stride surfel kernels with a grid sized from the model's last known count
-    bool object_scatter_splat = false;                 // "objectScatterSplat": object models are predicted with the scatter form instead of tile lists
+    // A/B switches for object models (a few thousand surfels each; their per-frame cost is launch overhead).  Measured on MI355X, 12-model S2
+    // scene (profiles/r03a_bench_2s_object_switches.txt): 394 frames/s without, 395 / 399 with one, 407 with both -> on since round 3:
+    bool object_small_grids = true;                    // "objectSmallGrids": the grid-stride surfel kernels with a grid sized from the model's last known count
+    bool object_scatter_splat = true;                  // "objectScatterSplat": object models are predicted with the scatter form instead of tile lists
 #ifndef MF_DEFAULT_LITERAL_FUSION_WEIGHT
 #define MF_DEFAULT_LITERAL_FUSION_WEIGHT 1             // default since round 3 (finding F5: the reference's own arithmetic); 0 = the accurate double log map
 #endif
     bool weight_literal = MF_DEFAULT_LITERAL_FUSION_WEIGHT != 0;   // "literalFusionWeight": Model::rodrigues2 with the reference's float trace (finding F5)
+    bool bbox_limit = true;                            // "objectBoundingBoxLimit": Model::fuse limits an object's depth by lastBoundingBox (Model.cpp:480-501; upstream: whenever its GUI draws the models)
+    bool ftf_rgb = false;                              // MaskFusion::frameToFrameRGB ("-ftf"; Model.cpp:399-400,981): the photometric term tracks against the previous RAW frame
     bool gn_loop_graph = false;                        // the launch-per-iteration loop replayed as a captured hipGraph ("gnLoopGraph")
-    bool persistent_icp = false;                       // experimental: the geometric loop as one launch with device-wide barriers ("persistentIcp")
-    unsigned* d_grid_barrier = nullptr;                // [0] arrival counter (monotonic), [1] sticky time-out flag
-    unsigned grid_barrier_base = 0;                    // host copy of what the counter will be when the next launch starts
 
     // frame-level
     uint8_t* d_rgb = nullptr; float* d_depth = nullptr; uint8_t* d_mask_in = nullptr; uint8_t* d_zero_mask = nullptr;
@@ -273,6 +273,7 @@ static __global__ void k_frame_init(FrameDev* f, int tick) {
     f->tick = tick; f->count = 0; f->countNext = 0; f->cover = 0; f->useFillIn = 0;
     f->pad[0] = f->pad[1] = f->pad[2] = 0;
     f->done_cover = 0ull;
+    MF_FRAME_BBOX_RESET(f);
 }
 
 static int surfel_capacity(int num) {  // Model::TEXTURE_DIMENSION_*^2 (Core/Model/Model.cpp:101-105)
@@ -308,7 +309,7 @@ static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int 
         A(dev_alloc(c, m->allocs, &m->d_nmap_g[i], lp * 3));
     }
     {
-        const size_t nbmax = (size_t)std::max(std::max(icp_grid_blocks(c->W, c->H), icp_batch_max_blocks(c->W, c->H)), 240);   // 240: k_icp_persist's grid
+        const size_t nbmax = (size_t)std::max(icp_grid_blocks(c->W, c->H), icp_batch_max_blocks(c->W, c->H));
         for (int b = 0; b < 2; ++b) A(dev_alloc(c, m->allocs, &m->d_partials[b], nbmax * kIcpSlots));
     }
     A(dev_alloc(c, m->allocs, &m->d_gn, 2));
@@ -428,7 +429,6 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     A(dev_alloc(c, c->allocs, &c->d_block_counts, (size_t)kCompactBlocks));
     A(dev_alloc(c, c->allocs, &c->d_icp_log, (size_t)20 * 32));
     A(dev_alloc(c, c->allocs, &c->d_icp_prof, (size_t)20 * 8));
-    A(dev_alloc(c, c->allocs, &c->d_grid_barrier, (size_t)2));
     A(dev_alloc(c, c->allocs, &c->d_edge, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_bin, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_tmp_u8, (size_t)P));
@@ -519,7 +519,7 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
     if (rgb) {
         // initRGBModel + initRGB (Model.cpp:395-406; Q1: both depth pyramids come from the vertex map initICPModel was given)
         launch_rgbd_last_l0(m.d_predV, m.allowFillIn ? fillDepth : nullptr, m.d_predGray, m.d_fillGray, m.d_frame, c->d_lastDepth[0],
-                            c->d_lastImage[0], W * H, s);
+                            c->d_lastImage[0], W * H, s, (c->ftf_rgb && m.allowFillIn) ? 1 : 0);
         for (int i = 0; i + 1 < 3; ++i) {
             launch_pyrdown_f(c->d_lastDepth[i], c->d_lastDepth[i + 1], W >> i, H >> i, s);
             launch_pyrdown_u8(c->d_lastImage[i], c->d_lastImage[i + 1], W >> i, H >> i, s);
@@ -529,30 +529,6 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
     const float sobelScale = 1.0f / 8.0f;                                                // 1 / 2^sobelSize, :31-32
     const bool timed = c->timings_on && &m == c->models[0].get();
     if (timed) { (void)hipEventRecord(c->ev_icp[0], s); c->tracked_once = true; c->icp_mid_recorded = false; }
-    if (!rgb && c->persistent_icp && !c->icp_prof_on && icp_persistent_fits(W, H)) {
-        // experimental: all iterations of all levels in one launch (mf_odometry.hip, k_icp_persist)
-        IcpPersistLaunch pl;
-        int n_it = 0;
-        for (int i = 0; i < 3; ++i) {
-            const int lvl = 2 - i;
-            const float div = (float)(1 << lvl);
-            IcpLaunch& l = pl.level[i];
-            l.vmap_curr = cur_vmap[lvl]; l.nmap_curr = cur_nmap[lvl];
-            l.vmap_prev = m.d_vmap_g[lvl]; l.nmap_prev = m.d_nmap_g[lvl];
-            l.W = W >> lvl; l.H = H >> lvl; l.k = Intr{g.fx / div, g.fy / div, g.cx / div, g.cy / div};
-            l.distThres = 0.10f; l.angleThres = sinf(20.f * 3.14159254f / 180.f);
-            pl.iters[i] = iters[lvl];
-            n_it += iters[lvl];
-        }
-        pl.partials[0] = m.d_partials[0]; pl.partials[1] = m.d_partials[1];
-        pl.pose = m.d_pose; pl.host_mirror = m.h_pose; pl.so3_in = so3_seed;
-        pl.log_out = (m.id == 0 && n_it > 0) ? c->d_icp_log : nullptr;
-        pl.jump_limit = jump_limit;
-        pl.barrier = c->d_grid_barrier; pl.base = c->grid_barrier_base;
-        c->grid_barrier_base += launch_icp_persistent(pl, s);
-        if (timed) (void)hipEventRecord(c->ev_icp[1], s);
-        return;
-    }
     int k = 0, nb_prev = 0, prev_level = -1;
     // every launch of the loop and its finalize; called once eagerly, or once under stream capture (gnLoopGraph)
     auto issue_loop = [&](bool with_marks) {
@@ -697,9 +673,9 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
     launch_index_resolve(m.surf[src], m.d_pose, c->d_keys, W, H, c->d_index, c->d_ivc, c->d_inr, secondIndexPass ? nullptr : c->d_ict,
                          nullptr, s);
     if (marks) mark(c, 4);
-    // Model::fuse maxDepth uniform: min(depthCutoff, model.maxDepth, bb_max_z = FLT_MAX without the GUI) (Model.cpp:527)
+    // Model::fuse maxDepth uniform: min(depthCutoff, model.maxDepth, bb_max_z) (Model.cpp:527); bb_max_z from the model's bounding box on the device
     launch_fuse_data(d_rgb, d_depth, depthF, mask, m.id, m.d_frame, m.d_pose, weightMultiplier, fminf(fuseDepthCutoff, m.maxDepth), W, H,
-                     c->K, c->d_index, c->d_ivc, c->d_inr, c->d_cand_op, c->d_cand_rec, c->d_upd_first, s);
+                     c->K, c->d_index, c->d_ivc, c->d_inr, c->d_cand_op, c->d_cand_rec, c->d_upd_first, s, c->bbox_limit ? 1 : 0);
     if (marks) mark(c, 5);
     // the scatter half of the second predictIndices (:556) rides on the update pass
     launch_fuse_update(m.surf[src], m.surf[dst], m.d_frame, c->d_upd_first, c->d_cand_rec, m.d_pose, W, H, c->K, g.max_depth_processed,
@@ -725,14 +701,14 @@ static void enqueue_predict(mf_ctx* c, ModelState& m, const FrameAdvance* advanc
         if (launch_splat_tiled(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, c->cfg.max_depth_processed, m.confThr,
                                c->cfg.time_delta, c->d_tile_count, c->d_tile_entries, c->tile_entries_cap, c->d_splat_rec0, c->d_splat_rec1,
                                c->d_splat_bbox, m.d_predV, m.d_predN, m.d_predImage, m.d_predTime, c->cur_rgb,
-                               gray ? m.d_predGray : nullptr, gray ? m.d_fillGray : nullptr, c->stream, advance) == 0)
+                               gray ? m.d_predGray : nullptr, gray ? m.d_fillGray : nullptr, c->stream, advance, c->ftf_rgb ? 1 : 0) == 0)
             return;
     }
     launch_splat_scatter(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, c->cfg.max_depth_processed, m.confThr,
                          c->cfg.time_delta, c->d_keys, c->stream, surfel_blocks(c, m));
     const bool gray = photometric_on(c) ;
     launch_splat_resolve(m.surf[m.cur], m.d_pose, c->d_keys, c->W, c->H, c->K, m.d_predV, m.d_predN, m.d_predImage, m.d_predTime,
-                         m.d_frame, c->cur_rgb, gray ? m.d_predGray : nullptr, gray ? m.d_fillGray : nullptr, c->stream);
+                         m.d_frame, c->cur_rgb, gray ? m.d_predGray : nullptr, gray ? m.d_fillGray : nullptr, c->stream, c->ftf_rgb ? 1 : 0);
     if (advance) launch_frame_advance(m.d_frame, c->W, c->H, advance->host_mirror, m.d_pose, advance->bg_pose, advance->log_slot, c->stream);
 }
 
@@ -1023,20 +999,6 @@ extern "C" int mf_set_mask_class_ids(mf_ctx* c, const int32_t* class_ids, int32_
 extern "C" int mf_sync(mf_ctx* c) {
     if (!c) return MF_EINVAL;
     MF_HIP(c, hipStreamSynchronize(c->stream));
-    if (c->persistent_icp) {   // experimental persistent Gauss-Newton launch: did a device-wide barrier time out?
-        unsigned flag = 0;
-        MF_HIP(c, hipMemcpy(&flag, c->d_grid_barrier + 1, sizeof(flag), hipMemcpyDeviceToHost));
-        if (flag) {
-            // recover: the counter and the host's idea of it are out of step after an abandoned launch and the flag is sticky -- clear both and
-            // go back to the launch-per-iteration loop for the rest of the context's life (as gnLoopGraph does when a capture fails)
-            MF_HIP(c, hipMemset(c->d_grid_barrier, 0, 2 * sizeof(unsigned)));
-            c->grid_barrier_base = 0;
-            c->persistent_icp = false;
-            c->err = "persistentIcp: a device-wide barrier timed out (workgroups not co-resident); tracking of that frame was abandoned, "
-                     "persistentIcp has been switched off for this context";
-            return MF_ESTATE;
-        }
-    }
     if (c->timings_on) {
         // event i marks the START of stage i; stage i lasts until event i+1 (labels: see the header)
         float t[MF_N_TIMINGS] = {};
@@ -1050,7 +1012,7 @@ extern "C" int mf_sync(mf_ctx* c) {
         t[1] = 0.f;
         if (c->tracked_once && hipEventElapsedTime(&init, c->ev[2], c->ev_icp[0]) == hipSuccess) t[1] = init;
         if (c->tracked_once && hipEventElapsedTime(&iters, c->ev_icp[0], c->ev_icp[1]) == hipSuccess) t[9] = iters;
-        float coarse = 0.f, fine = 0.f;   // launch-per-iteration loop of a single model only (the batched / persistent / graph forms record no mid event)
+        float coarse = 0.f, fine = 0.f;   // launch-per-iteration loop of a single model only (the batched / graph forms record no mid event)
         if (c->tracked_once && c->icp_mid_recorded && hipEventElapsedTime(&coarse, c->ev_icp[0], c->ev_icp_mid) == hipSuccess &&
             hipEventElapsedTime(&fine, c->ev_icp_mid, c->ev_icp[1]) == hipSuccess) { t[10] = coarse; t[11] = fine; }
         memcpy(c->last_ms, t, sizeof(t));
@@ -1223,7 +1185,6 @@ extern "C" int mf_model_perform_tracking(mf_ctx* c, int32_t model, int32_t frame
     ModelState* m = model_at(c, model);
     (void)log_timestamp;   // only forwarded to a debug print upstream
     if (!m || c->frame_no == 0) return MF_EINVAL;
-    if (frame_to_frame_rgb) { c->err = "frameToFrameRGB is not supported (never enabled upstream)"; return MF_EINVAL; }
     const long k = staged_frame(c);
     // The intensity pyramid, the derivative images and the gate images of the staged frame were built by mf_stage_frame under the CONTEXT's
     // configuration, and the intensity of the last prediction by that prediction: a per-call photometric term on a context that never
@@ -1238,6 +1199,8 @@ extern "C" int mf_model_perform_tracking(mf_ctx* c, int32_t model, int32_t frame
         }
     }
     const mf_config keep = c->cfg;
+    const bool keep_ftf = c->ftf_rgb;
+    c->ftf_rgb = frame_to_frame_rgb != 0;   // which image initRGBModel takes (Model.cpp:399-400); the fill-in image itself was built by the last prediction
     c->cfg.rgb_only = rgb_only; c->cfg.icp_weight = icp_weight; c->cfg.pyramid = pyramid; c->cfg.fast_odom = fast_odom; c->cfg.so3 = so3;
     c->cfg.max_depth_processed = max_depth_processed;
     // tryFillIn = MaskFusion::requiresFillIn(model) (:630-648): the decision itself is taken on the device from the coverage of the
@@ -1245,6 +1208,7 @@ extern "C" int mf_model_perform_tracking(mf_ctx* c, int32_t model, int32_t frame
     // object models carry the 0.2 m jump rule of the caller (MaskFusion.cpp:268-272): pose->alive = 0 marks "remove this model"
     enqueue_track(c, *m, (try_fill_in && m->allowFillIn) ? c->d_depthF[(k + 2) % 3] : nullptr, model == 0 ? 0.f : 0.2f, k);
     c->cfg = keep;
+    c->ftf_rgb = keep_ftf;
     return check_launch(c);
 }
 
@@ -1275,7 +1239,7 @@ extern "C" int mf_model_fuse(mf_ctx* c, int32_t model, int32_t time, float depth
     const int src = m->cur, dst = 1 - m->cur;
     launch_fuse_data(c->cur_rgb, c->cur_depth, c->d_depthF[k % 3], current_mask(c), m->id, m->d_frame, m->d_pose, weight_multiplier,
                      fminf(depth_cutoff, m->maxDepth), c->W, c->H, c->K, c->d_index, c->d_ivc, c->d_inr, c->d_cand_op, c->d_cand_rec,
-                     c->d_upd_first, s);
+                     c->d_upd_first, s, c->bbox_limit ? 1 : 0);
     launch_fuse_update(m->surf[src], m->surf[dst], m->d_frame, c->d_upd_first, c->d_cand_rec, m->d_pose, c->W, c->H, c->K,
                        c->cfg.max_depth_processed, c->cfg.time_delta, nullptr, false, s);
     m->cur = dst;
@@ -1641,6 +1605,16 @@ extern "C" int mf_get_track_stats(mf_ctx* c, int32_t model, float* out8) {
     out8[4] = p.lastSO3Error; out8[5] = p.lastSO3Count; out8[6] = (float)p.so3Iterations; out8[7] = (float)p.rejected;
     return MF_OK;
 }
+// how many Gauss-Newton iterations of the model's last geometric tracking step solved a system outside the solver's stated domain (fewer
+// than 6 inliers, or a pivot below 1e-8 of the largest diagonal entry, i.e. cond(A) > 1e8): DESIGN.md finding F4
+extern "C" int mf_get_gn_condition(mf_ctx* c, int32_t model, int32_t* ill_iterations) {
+    ModelState* m = model_at(c, model);
+    if (!m || !ill_iterations) return MF_EINVAL;
+    int rc = mf_sync(c);
+    if (rc != MF_OK) return rc;
+    *ill_iterations = m->h_pose->illIterations;
+    return MF_OK;
+}
 extern "C" int mf_get_last_fillin(mf_ctx* c, int32_t* used) {
     if (!c || !used) return MF_EINVAL;
     int rc = mf_sync(c);
@@ -1794,8 +1768,9 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
         return MF_OK;
     }
     if (!strcmp(key, "batchTracking")) { c->batch_tracking = value != 0; return MF_OK; }
-    if (!strcmp(key, "persistentIcp")) { c->persistent_icp = value != 0; return MF_OK; }   // experimental, see k_icp_persist
     if (!strcmp(key, "gnLoopGraph")) { c->gn_loop_graph = value != 0; return MF_OK; }      // the Gauss-Newton launches as a replayed hipGraph
+    if (!strcmp(key, "frameToFrameRGB")) { c->ftf_rgb = value != 0; return MF_OK; }         // MaskFusion::setFrameToFrameRGB (Core/MaskFusion.cpp:910)
+    if (!strcmp(key, "objectBoundingBoxLimit")) { c->bbox_limit = value != 0; return MF_OK; }   // 0: a headless upstream that never renders (bb_max_z = FLT_MAX)
     if (!strcmp(key, "literalFusionWeight")) {
         c->weight_literal = value != 0;
         for (auto& m : c->models) hipLaunchKernelGGL(k_set_weight_literal, dim3(1), dim3(64), 0, c->stream, m->d_pose, c->weight_literal ? 1 : 0, m->h_pose);
@@ -1837,7 +1812,8 @@ extern "C" int mf_get_param(mf_ctx* c, const char* key, double* value) {
     if (!strcmp(key, "confidenceThreshold")) { *value = c->models[0]->confThr; return MF_OK; }
     if (!strcmp(key, "splatTileEntries")) { *value = c->tile_entries_cap; return MF_OK; }
     if (!strcmp(key, "gnLoopGraph")) { *value = c->gn_loop_graph ? 1 : 0; return MF_OK; }   // 0 again after a capture that the runtime refused
-    if (!strcmp(key, "persistentIcp")) { *value = c->persistent_icp ? 1 : 0; return MF_OK; }
+    if (!strcmp(key, "frameToFrameRGB")) { *value = c->ftf_rgb ? 1 : 0; return MF_OK; }
+    if (!strcmp(key, "objectBoundingBoxLimit")) { *value = c->bbox_limit ? 1 : 0; return MF_OK; }
     for (const ParamRef& p : kParams)
         if (!strcmp(key, p.key)) {
             const char* base = reinterpret_cast<const char*>(&c->cfg);

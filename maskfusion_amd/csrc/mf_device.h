@@ -23,8 +23,12 @@ __device__ __forceinline__ float3 cross3_exact(float3 a, float3 b) {
 }
 __device__ __forceinline__ float dot3(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ float norm3(float3 a) { return sqrtf(dot3(a, a)); }
-// CUDA-side normalized(): a * rsqrt(dot) (Core/Cuda/operators.cuh:80-84)
-__device__ __forceinline__ float3 normalized_rsqrt(float3 a) { return a * rsqrtf(dot3(a, a)); }
+// CUDA-side normalized(): a * rsqrt(dot) (Core/Cuda/operators.cuh:80-84).  The reference's rsqrtf is an approximate instruction (2 ulp)
+// no CPU build reproduces, and v_rsq_f32 is a different approximation (1 ulp); the CPU restatement evaluates 1 / sqrt with two correctly
+// rounded operations, and so does the device since round 3: the normal maps -- and with them the geometric edge map, whose 0.3 threshold
+// decides label pixels -- are then bit-identical to the restatement's on the same depth (the 8-object scene showed ~0.3 % of the label
+// pixels flipping on 1-ulp normals).  ~20 instructions per normal in three once-per-frame kernels.
+__device__ __forceinline__ float3 normalized_rsqrt(float3 a) { return a * (1.0f / sqrtf(dot3(a, a))); }
 // GLSL normalize(): a / length(a)
 __device__ __forceinline__ float3 normalize_gl(float3 a) {
     const float l = sqrtf(dot3(a, a));

@@ -31,6 +31,7 @@ struct PoseDev {
     float lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count;
     int so3Iterations;
     int weightLiteral;         // 1: computeFusionWeight's log map with the reference's float trace ("literalFusionWeight", DESIGN.md finding F5)
+    int illIterations;         // Gauss-Newton iterations of the last geometric tracking step whose system was outside the solver's stated domain (GNState::ill)
 };
 
 // Result of the SO(3) pre-alignment kernel (RGBDOdometry.cpp:264-324); seeds resultRt of the Gauss-Newton loop.
@@ -50,6 +51,9 @@ struct GNState {
     int valid;
     int levelDone;             // pyramid level whose loop was left early (rgbOnly rule, RGBDOdometry.cpp:392-394); -1: none
     float lastRGBError, lastRGBCount;
+    int ill;                   // iterations so far whose 6x6 system had fewer than 6 inliers or a pivot below 1e-8 of the largest diagonal entry
+                               // (=> cond(A) > 1e8): there the unpivoted fp64 LDL^T here and the reference's pivoted Eigen::LDLT on float-rounded
+                               // sums may return different steps (DESIGN.md finding F4); everywhere else they agree to rounding
 };
 
 // Scalars that live on the device so that no kernel launch needs a host round trip.
@@ -61,8 +65,19 @@ struct FrameDev {
     int cover;                 // predicted-colour coverage count (requiresFillIn)
     int useFillIn;             // decision taken for the current tracking step
     int pad[3];
+    // Model::lastBoundingBox in millimetres (Model.cpp:315-345; {min xyz, max xyz}, empty = min > max) as of the end of the last frame, and
+    // the one being accumulated by this frame's clean pass (object models only; the frame advance moves it over)
+    int bbox[6], bbox_acc[6];
     unsigned long long done_cover;   // k_splat_tile: (workgroups finished << 32) | coverage count of this launch; zero between launches
 };
+
+constexpr int kBBoxEmptyMin = 100000, kBBoxEmptyMax = -100000;   // Model.cpp:315: {1e5, 1e5, 1e5, -1e5, -1e5, -1e5}
+// (device + host) reset of the two boxes of a FrameDev
+#define MF_FRAME_BBOX_RESET(f) do { for (int q_ = 0; q_ < 3; ++q_) { (f)->bbox[q_] = (f)->bbox_acc[q_] = mf::kBBoxEmptyMin; \
+                                                                     (f)->bbox[3 + q_] = (f)->bbox_acc[3 + q_] = mf::kBBoxEmptyMax; } } while (0)
+// end of a frame (the GUI's renderPointCloud runs after processFrame, GUI/MainController.cpp:704-717): the accumulated box becomes lastBoundingBox
+#define MF_FRAME_BBOX_ADVANCE(f) do { for (int q_ = 0; q_ < 6; ++q_) { (f)->bbox[q_] = (f)->bbox_acc[q_]; \
+                                                                       (f)->bbox_acc[q_] = q_ < 3 ? mf::kBBoxEmptyMin : mf::kBBoxEmptyMax; } } while (0)
 
 struct Surfels {               // SoA of float4, 48 B per surfel in three coalesced streams
     float4* pc;                // position + confidence
@@ -113,20 +128,6 @@ struct IcpLaunch {
 };
 int icp_grid_blocks(int W, int H);
 void launch_icp_iteration(const IcpLaunch& a, hipStream_t s);
-// ---- experimental: the whole geometric loop as one persistent launch with device-wide barriers (mf_odometry.hip, k_icp_persist)
-struct IcpPersistLaunch {
-    IcpLaunch level[3];                          // coarsest first; only the map pointers, W, H, k and the two thresholds are read
-    int iters[3];
-    float* partials[2];                          // each >= 240 * 32 floats
-    PoseDev* pose; PoseDev* host_mirror;
-    const So3Result* so3_in;
-    float* log_out;                              // optional [n_it][32]
-    float jump_limit;
-    unsigned* barrier;                           // device: [0] monotonic arrival counter, [1] sticky time-out flag
-    unsigned base;                               // counter value before this launch
-};
-bool icp_persistent_fits(int W, int H);          // one workgroup round of <= 3 pixels per thread covers level 0
-unsigned launch_icp_persistent(const IcpPersistLaunch& l, hipStream_t s);   // returns what the launch adds to the arrival counter
 // ---- the same loop for SEVERAL models at once (MaskFusion.cpp:247-276 tracks them one after the other): one launch serves
 // iteration k of every tracked model.  Split in two kernels per iteration -- "solve" (one workgroup per model: reduce the
 // previous iteration's partials, LDL^T, pose) and "pixels" (grid.y = model, no prologue, any number of workgroup rounds) --
@@ -169,8 +170,9 @@ void launch_intensity(const uint8_t* img, int channels, uint8_t* dst, int n, hip
 void launch_pyrdown_u8(const uint8_t* src, uint8_t* dst, int sw, int sh, hipStream_t s);
 void launch_derivative(const uint8_t* src, int16_t* dx, int16_t* dy, int W, int H, float minScale, uint8_t* gate /*or null*/, hipStream_t s);
 // level 0 of a model's "last" depth / intensity pyramids (populateRGBDData of initRGBModel; Q1: initRGB re-uses the depth)
+// frameToFrameRGB != 0 (and a fill-in image given): initRGBModel takes the fill-in image whatever the fill-in decision (Model.cpp:399-400)
 void launch_rgbd_last_l0(const float4* predV, const float* fillDepth, const uint8_t* predGray, const uint8_t* fillGray,
-                         const FrameDev* frame, float* depth0, uint8_t* image0, int n, hipStream_t s);
+                         const FrameDev* frame, float* depth0, uint8_t* image0, int n, hipStream_t s, int frameToFrameRGB = 0);
 // scratch: so3_scratch_bytes(W2, H2) of device memory; returns -1 if the image needs more workgroups than the staging allows
 size_t so3_scratch_bytes(int W2, int H2);
 int launch_so3_prealign(const uint8_t* lastImage2, const uint8_t* nextImage2, int W2, int H2, Intr k2, So3Result* out, void* scratch,
@@ -208,7 +210,7 @@ void launch_index_resolve(Surfels src, const PoseDev* pose, unsigned long long* 
 void launch_fuse_data(const uint8_t* rgb, const float* depthRaw, const float* depthF, const uint8_t* mask,
                       int maskID, const FrameDev* frame, const PoseDev* pose, float weightMultiplier, float maxDepth,
                       int W, int H, Intr k, const int* index, const float4* vc, const float4* nr, uint8_t* cand_op,
-                      float4* cand_rec, int* upd_first, hipStream_t s);
+                      float4* cand_rec, int* upd_first, hipStream_t s, int bboxLimit = 1);
 // keys_or_null != nullptr: also scatters the updated surfels into the index-map keys (the pass that feeds clean)
 void launch_fuse_update(Surfels src, Surfels dst, const FrameDev* frame, int* upd_first, const float4* cand_rec, const PoseDev* pose,
                         int W, int H, Intr k, float maxDepth, int timeDelta, unsigned long long* keys_or_null, bool transposed,
@@ -228,7 +230,7 @@ void launch_splat_scatter(Surfels src, const FrameDev* frame, const PoseDev* pos
 void launch_splat_resolve(Surfels src, const PoseDev* pose, unsigned long long* keys, int W, int H, Intr k,
                           float4* predV, float4* predN, uchar4* predImage, uint16_t* predTime, FrameDev* frame,
                           const uint8_t* rgb /*or null*/, uint8_t* predGray /*or null*/, uint8_t* fillGray /*or null*/,
-                          hipStream_t s);
+                          hipStream_t s, int fillPassthrough = 0 /* fill_rgb.frag's `passthrough` (frameToFrameRGB) */);
 // Tiled form of scatter + resolve (mf_splat.hip): bins surfels to 16x16 tiles, z-test in LDS, writes the maps directly.
 // tile_count must be zero on the first call (it is left zero).  Returns -1 if the image has too many tiles for the LDS
 // histograms (use the scatter form then).
@@ -240,7 +242,7 @@ int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W,
                        int timeDelta, int* tile_count, int* entries /*[tiles][entries_cap / tiles]*/, int entries_cap,
                        float4* rec0 /*[src.cap]*/, float4* rec1 /*[src.cap]*/, void* bbox /*[src.cap] x 8 B*/, float4* predV, float4* predN,
                        uchar4* predImage, uint16_t* predTime, const uint8_t* rgb, uint8_t* predGray, uint8_t* fillGray, hipStream_t s,
-                       const FrameAdvance* advance = nullptr);
+                       const FrameAdvance* advance = nullptr, int fillPassthrough = 0);
 void launch_fill_keys(unsigned long long* keys, int n, hipStream_t s);
 void launch_fill_int(int* p, int v, int n, hipStream_t s);
 // ---------------- multi-model coupling (mf_segment.hip) ----------------

@@ -30,8 +30,8 @@ namespace mf {
 // Eigen::LDLT (RGBDOdometry.cpp:451-459); Eigen pivots on the diagonal, which for these symmetric positive definite
 // systems changes the result only by rounding.  A non-positive / vanishing pivot zeroes that component (Eigen's
 // behaviour for singular systems) instead of dividing by it.
-__device__ __forceinline__ void ldlt6_solve(double (&A)[6][6], const double (&b)[6], double (&x)[6]) {
-    double maxdiag = 0.0;
+__device__ __forceinline__ void ldlt6_solve(double (&A)[6][6], const double (&b)[6], double (&x)[6], double* min_pivot_ratio = nullptr) {
+    double maxdiag = 0.0, minpiv = 1.7976931348623157e308;
 #pragma unroll
     for (int i = 0; i < 6; ++i) maxdiag = fmax(maxdiag, fabs(A[i][i]));
     const double tol = maxdiag * 1e-14;
@@ -40,6 +40,7 @@ __device__ __forceinline__ void ldlt6_solve(double (&A)[6][6], const double (&b)
     for (int k = 0; k < 6; ++k) {
         const double d = A[k][k];
         const bool ok = d > tol;
+        minpiv = fmin(minpiv, ok ? d : 0.0);
         dinv[k] = ok ? rcp_d(d) : 0.0;   // v_rcp_f64 + Newton: an IEEE division is a ~40-instruction dependent chain per pivot
         // the lower triangle (i >= j) is the working copy; col = column k of the current Schur complement
         double col[6];
@@ -70,6 +71,8 @@ __device__ __forceinline__ void ldlt6_solve(double (&A)[6][6], const double (&b)
         for (int j = i + 1; j < 6; ++j) s -= A[j][i] * x[j];
         x[i] = s;
     }
+    // smallest pivot over largest diagonal entry: >= 1 / cond(A) for a positive definite A (0 when a pivot vanished or A = 0)
+    if (min_pivot_ratio) *min_pivot_ratio = maxdiag > 0.0 ? minpiv / maxdiag : 0.0;
 }
 
 // Wave-parallel 6x6 solve: Gauss-Jordan on the augmented [A|b] with one lane per element (lanes 0..41 of one
@@ -163,7 +166,7 @@ __device__ __forceinline__ void gn_update_from_x(const double (&x)[6], float res
 #pragma unroll
     for (int k = 0; k < 3; ++k) { out.tprev[k] = in.tprev[k]; out.trt[k] = trt[k]; }
     out.valid = 1;
-    out.levelDone = in.levelDone; out.lastRGBError = in.lastRGBError; out.lastRGBCount = in.lastRGBCount;
+    out.levelDone = in.levelDone; out.lastRGBError = in.lastRGBError; out.lastRGBCount = in.lastRGBCount; out.ill = in.ill;
 }
 
 // Serial form (one thread): unpack -> LDL^T -> update.  mf_k_gn_solve (tests/test_gpu_kernels.py) runs it next to the wave solver
@@ -209,8 +212,9 @@ __device__ __forceinline__ void gn_finish_wg(const double* s_sys, GNState* s_st,
     const int l = threadIdx.x;
     const int r = (l >> 2) & 3, c = l & 3;   // lanes 0..11: entry (r, c) of the 3x4 block
     double nr = 0.0;
+    int ill = 0;
     if (l < 12) {
-        double A[6][6], b[6], x[6];
+        double A[6][6], b[6], x[6], ratio;
         int shift = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i)
@@ -220,7 +224,8 @@ __device__ __forceinline__ void gn_finish_wg(const double* s_sys, GNState* s_st,
                 if (j == 6) b[i] = value;
                 else { A[i][j] = value; A[j][i] = value; }
             }
-        ldlt6_solve(A, b, x);
+        ldlt6_solve(A, b, x, &ratio);
+        ill = (s_sys[28] < 6.0 || !(ratio >= 1e-8)) ? 1 : 0;   // outside the stated domain of this solver (finding F4): counted, see GNState::ill
         double Rw[3][3];
         rodrigues_d(x[3], x[4], x[5], Rw);
         const double w0 = r == 0 ? Rw[0][0] : (r == 1 ? Rw[1][0] : Rw[2][0]);
@@ -239,6 +244,7 @@ __device__ __forceinline__ void gn_finish_wg(const double* s_sys, GNState* s_st,
             s_st->lastICPError = sqrtf(res) / inl;
             s_st->lastICPCount = inl;
             s_st->valid = 1;
+            s_st->ill += ill;
         }
     }
     __syncthreads();
@@ -537,7 +543,7 @@ __device__ __forceinline__ void seed_state(const PoseDev& pose, GNState& s) {
     for (int k = 0; k < 3; ++k) { s.tprev[k] = pose.t[k]; s.tcurr[k] = pose.t[k]; s.trt[k] = 0.f; }
     m33_inverse_f(s.Rprev, s.Rprev_inv);  // RGBDOdometry.cpp:332
     s.lastICPError = 0.f; s.lastICPCount = 0.f; s.valid = 0;
-    s.levelDone = -1; s.lastRGBError = 3.4028234664e38f; s.lastRGBCount = 0.f;
+    s.levelDone = -1; s.lastRGBError = 3.4028234664e38f; s.lastRGBCount = 0.f; s.ill = 0;
 }
 
 // Workgroup shape.  Per launch a CU spends its time in three VALU-throughput-bound stretches (one VALU instruction per 4
@@ -694,7 +700,7 @@ void launch_icp_iteration(const IcpLaunch& l, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // last reduce + solve of a tracking step, then Model::pose / lastPose / statistics (RGBDOdometry.cpp:476-496, Model.cpp:437-446)
 // and the object-model jump rule.  Called by all 256 threads of a workgroup.
-// s_st: LDS copy of the state (st_in may already point at it: the persistent kernel keeps its state there); s_scr: 40 floats of LDS.
+// s_st: LDS copy of the state (st_in may already point at it); s_scr: 40 floats of LDS.
 __device__ __forceinline__ void icp_finalize_body(const float* __restrict__ partials_in, int nb_in, const GNState* st_in,
                                                   PoseDev* __restrict__ pose, PoseDev* __restrict__ host_mirror, float* __restrict__ log_out,
                                                   float jump_limit, const So3Result* __restrict__ so3, double* s_seg, double* s_sys,
@@ -718,6 +724,7 @@ __device__ __forceinline__ void icp_finalize_body(const float* __restrict__ part
         if (so3) { p.lastSO3Error = so3->error; p.lastSO3Count = so3->count; p.so3Iterations = so3->iterations; }
         else { p.lastSO3Error = 0.f; p.lastSO3Count = 0.f; p.so3Iterations = 0; }
         for (int k = 0; k < 3; ++k) p.incT[k] = st.trt[k];
+        p.illIterations = st.ill;
         if (jump_limit > 0.f && norm3(f3(st.trt[0], st.trt[1], st.trt[2])) >= jump_limit) p.alive = 0;   // `float d > 0.2` is a DOUBLE comparison upstream (MaskFusion.cpp:268): true from 0.2f on
         pose_derive(p);
         *pose = p;
@@ -744,169 +751,6 @@ void launch_icp_finalize(const float* partials_in, int nblocks_in, const GNState
 
 // ------------------------------------------------------------------------------------------------
 // Batched Gauss-Newton loop: iteration k of ALL tracked models per launch (see mf_internal.h).
-// ------------------------------------------------------------------------------------------------
-// EXPERIMENTAL (mf_set_param("persistentIcp", 1); default off; written at the end of round 2 without GPU time left -- it compiles,
-// it has not run): the same geometric Gauss-Newton loop as ONE persistent launch.  All iterations of all three levels run inside a
-// single <<<240, 512>>> launch; between iterations the workgroups meet at a device-wide barrier instead of at a kernel boundary.
-// tools/micro/grid_barrier.hip measures whether such a barrier beats the 3.44 us dependent-launch exchange; if it does, this kernel
-// removes that difference from each of the 19 iterations.  Everything else is k_icp_iter's: the same pixel functions, the same
-// fixed-order fp64 reduction of the per-workgroup partials and the same one-thread solve, done redundantly and bit-identically by
-// every workgroup (the Gauss-Newton state therefore never leaves LDS), the same finalize.  Differences: every workgroup takes a slice
-// of every level (chunk = P / 240 rounded up to 64 pixels, so the coarse levels run on all CUs with one or two wavefronts each), and
-// 240 partials are reduced per iteration at every level.
-// Safety: the barrier needs all workgroups co-resident (240 <= 256 CUs, one workgroup per CU fits: ~40 KB LDS); every spin is bounded
-// (~50 ms) and sets a sticky error word that mf_sync reports, so a launch can fail but cannot hang the GPU.
-// ------------------------------------------------------------------------------------------------
-struct IcpPersistLevel {
-    const float* vc; const float* nc; const float* vp; const float* np;
-    int W, H; Intr k;
-    float dist2Max, sine2Min;
-    int iters;
-};
-struct IcpPersistArgs {
-    IcpPersistLevel lv[3];            // in execution order: coarsest level first
-    float* partials[2];               // ping-pong [gridDim.x][kIcpSlots]
-    PoseDev* pose; PoseDev* host_mirror;
-    const So3Result* so3_in;
-    float* log_out;                   // optional [n_it][32]: the reduced system of every iteration
-    float jump_limit;
-    unsigned* barrier;                // [0]: arrival counter, monotonic across launches; [1]: sticky time-out flag
-    unsigned base;                    // value of the counter when this launch starts
-};
-
-// Device-wide barrier: release (all threads) -> workgroup barrier -> one arrival per workgroup -> bounded spin -> workgroup barrier ->
-// acquire (all threads).  Returns false in every thread of the workgroup when any workgroup of the launch timed out.
-__device__ __forceinline__ bool icp_grid_barrier(unsigned* bar, unsigned target, int* s_ok) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const long long t0 = wall_clock64();   // 100 MHz
-        while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-            if (wall_clock64() - t0 > 5000000ll) { __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        *s_ok = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    return *s_ok != 0;
-}
-
-// The solve and the finalize as real function calls: inlined into the iteration loop their ~90-word Gauss-Newton state pushed the
-// kernel to 256 VGPRs with spills (k_icp_iter: 115); one call per iteration costs a few hundred cycles of one thread.
-__device__ __noinline__ void icp_persist_finalize(const float* partials_in, int nb_in, GNState* s_st, PoseDev* pose, PoseDev* host_mirror,
-                                                  float* log_out, float jump_limit, const So3Result* so3, double* s_seg, double* s_sys, float* s_scr) {
-    icp_finalize_body(partials_in, nb_in, s_st, pose, host_mirror, log_out, jump_limit, so3, s_seg, s_sys, s_st, s_scr);
-}
-
-__global__ __launch_bounds__(kIcpThreads) void k_icp_persist(const IcpPersistArgs a) {
-    constexpr int kT = kIcpThreads;
-    __shared__ double s_seg[32 * 32];
-    __shared__ double s_sys[32];
-    __shared__ float s_pose[24];  // Rcurr[9] tcurr[3] Rprev_inv[9] tprev[3]
-    __shared__ float s_red[29 * (kT / 2)];
-    __shared__ GNState s_st;
-    __shared__ float s_scr[40];
-    __shared__ int s_ok;
-
-    const int tid = threadIdx.x;
-    if (tid == 0) {
-        seed_state(*a.pose, s_st);   // RGBDOdometry.cpp:239-243,332-336
-        if (a.so3_in)
-            for (int r = 0; r < 3; ++r)
-                for (int c = 0; c < 3; ++c) s_st.resultRt[r * 4 + c] = a.so3_in->R[r * 3 + c];
-        s_ok = 1;
-    }
-    __syncthreads();
-
-    int it = 0, nb_prev = 0;
-#pragma unroll 1
-    for (int li = 0; li < 3; ++li) {
-        const IcpPersistLevel L = a.lv[li];
-        const int P = L.W * L.H;
-        const int chunk = icp_chunk(P, gridDim.x);   // <= kIcpPx * kT (checked by the host)
-        const int beg = blockIdx.x * chunk, end = min(P, beg + chunk);
-#pragma unroll 1
-        for (int j = 0; j < L.iters; ++j, ++it) {
-            // (1) pose-independent streamed loads
-            int idx[kIcpPx]; bool act[kIcpPx];
-            float vx[kIcpPx], vy[kIcpPx], vz[kIcpPx], nx[kIcpPx], ny[kIcpPx], nz[kIcpPx];
-#pragma unroll
-            for (int q = 0; q < kIcpPx; ++q) {
-                idx[q] = beg + q * kT + tid;
-                act[q] = idx[q] < end;
-                const int i = min(idx[q], P - 1);
-                vx[q] = L.vc[i]; vy[q] = L.vc[P + i]; vz[q] = L.vc[2 * P + i];
-                nx[q] = L.nc[i]; ny[q] = L.nc[P + i]; nz[q] = L.nc[2 * P + i];
-            }
-            // (2) finish the previous iteration: reduce -> solve -> pose, identically in every workgroup; the state stays in LDS
-            if (nb_prev > 0) {
-                reduce_partials(a.partials[(it + 1) & 1], nb_prev, s_seg, s_sys);
-                gn_finish_wg(s_sys, &s_st, s_pose, s_scr + 24);
-                if (blockIdx.x == 0 && a.log_out && tid >= 64 && tid < 96) a.log_out[(it - 1) * 32 + (tid - 64)] = (float)s_sys[tid - 64];
-            }
-            if (tid < 12) {
-                s_pose[12 + tid] = tid < 9 ? s_st.Rprev_inv[tid] : s_st.tprev[tid - 9];
-                if (nb_prev == 0) s_pose[tid] = tid < 9 ? s_st.Rcurr[tid] : s_st.tcurr[tid - 9];
-            }
-            __syncthreads();
-            float Rc[9], Rpi[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) { Rc[k] = s_pose[k]; Rpi[k] = s_pose[12 + k]; }
-            const float3 tc = f3(s_pose[9], s_pose[10], s_pose[11]);
-            const float3 tp = f3(s_pose[21], s_pose[22], s_pose[23]);
-            // (3) normal equations of this thread's pixels
-            float acc[32];
-#pragma unroll
-            for (int k = 0; k < 32; ++k) acc[k] = 0.f;
-            IcpCorr cor[kIcpPx];
-            float3 pv[kIcpPx], pn[kIcpPx];
-#pragma unroll
-            for (int q = 0; q < kIcpPx; ++q) {
-                cor[q] = icp_project(vx[q], vy[q], vz[q], nx[q], ny[q], nz[q], Rc, tc, Rpi, tp, L);
-                cor[q].ok = cor[q].ok && act[q];
-                cor[q].j = cor[q].ok ? cor[q].j : 0;
-            }
-#pragma unroll
-            for (int q = 0; q < kIcpPx; ++q) {
-                const int jj = cor[q].j;
-                pv[q] = f3(L.vp[jj], L.vp[P + jj], L.vp[2 * P + jj]);
-                pn[q] = f3(L.np[jj], L.np[P + jj], L.np[2 * P + jj]);
-            }
-#pragma unroll
-            for (int q = 0; q < kIcpPx; ++q) icp_accumulate(cor[q], pv[q], pn[q], Rpi, tp, L, acc);
-            // (4) one 128 B partial per workgroup, then the device-wide barrier that stands where the kernel boundary stood
-            block_sum29_lds<kT>(acc, s_red, a.partials[it & 1] + blockIdx.x * kIcpSlots);
-            if (!icp_grid_barrier(a.barrier, a.base + (unsigned)(it + 1) * gridDim.x, &s_ok)) return;
-            nb_prev = (int)gridDim.x;
-        }
-    }
-    // last reduce + solve, Model::pose / lastPose / statistics, the object-model jump rule: workgroup 0
-    if (blockIdx.x == 0)
-        icp_persist_finalize(nb_prev ? a.partials[(it + 1) & 1] : nullptr, nb_prev, &s_st, a.pose, a.host_mirror,
-                             (a.log_out && it > 0) ? a.log_out + (it - 1) * 32 : nullptr, a.jump_limit, a.so3_in, s_seg, s_sys, s_scr);
-}
-
-bool icp_persistent_fits(int W, int H) { return icp_chunk(W * H, kIcpMaxBlocks) <= kIcpPx * kIcpThreads; }
-
-unsigned launch_icp_persistent(const IcpPersistLaunch& l, hipStream_t s) {
-    IcpPersistArgs a;
-    int n_it = 0;
-    for (int i = 0; i < 3; ++i) {
-        const IcpLaunch& q = l.level[i];
-        float d2, s2;
-        icp_gates(q.distThres, q.angleThres, d2, s2);
-        a.lv[i] = IcpPersistLevel{q.vmap_curr, q.nmap_curr, q.vmap_prev, q.nmap_prev, q.W, q.H, q.k, d2, s2, l.iters[i]};
-        n_it += l.iters[i];
-    }
-    a.partials[0] = l.partials[0]; a.partials[1] = l.partials[1];
-    a.pose = l.pose; a.host_mirror = l.host_mirror; a.so3_in = l.so3_in; a.log_out = l.log_out; a.jump_limit = l.jump_limit;
-    a.barrier = l.barrier; a.base = l.base;
-    hipLaunchKernelGGL(k_icp_persist, dim3(kIcpMaxBlocks), dim3(kIcpThreads), 0, s, a);
-    return (unsigned)n_it * (unsigned)kIcpMaxBlocks;
-}
-
 // ------------------------------------------------------------------------------------------------
 struct IcpSolveArgs { TrackBatch b; int it; int nb_in; const So3Result* so3; };
 
@@ -1055,7 +899,7 @@ __global__ __launch_bounds__(64) void k_gn_solve_test(const double* __restrict__
         for (int k = 0; k < 9; ++k) { in.Rprev[k] = Rprev[k]; in.Rcurr[k] = Rprev[k]; in.trR[k] = 0.f; }
         for (int k = 0; k < 3; ++k) { in.tprev[k] = tprev[k]; in.tcurr[k] = tprev[k]; in.trt[k] = 0.f; }
         m33_inverse_f(in.Rprev, in.Rprev_inv);
-        in.lastICPError = in.lastICPCount = 0.f; in.valid = 0; in.levelDone = -1; in.lastRGBError = 0.f; in.lastRGBCount = 0.f;
+        in.lastICPError = in.lastICPCount = 0.f; in.valid = 0; in.levelDone = -1; in.lastRGBError = 0.f; in.lastRGBCount = 0.f; in.ill = 0;
     }
     __syncthreads();
     double xw[6];
@@ -1121,7 +965,7 @@ __global__ void k_state_from_args(GNState* st, const float* Rc, const float* tc,
     for (int k = 0; k < 16; ++k) s.resultRt[k] = (k % 5 == 0) ? 1.0 : 0.0;
     for (int k = 0; k < 9; ++k) { s.Rcurr[k] = Rc[k]; s.Rprev_inv[k] = Rpi[k]; s.Rprev[k] = 0.f; s.trR[k] = 0.f; }
     for (int k = 0; k < 3; ++k) { s.tcurr[k] = tc[k]; s.tprev[k] = tp[k]; s.trt[k] = 0.f; }
-    s.lastICPError = s.lastICPCount = 0.f; s.valid = 0; s.levelDone = -1; s.lastRGBError = 3.4028234664e38f; s.lastRGBCount = 0.f;
+    s.lastICPError = s.lastICPCount = 0.f; s.valid = 0; s.levelDone = -1; s.lastRGBError = 3.4028234664e38f; s.lastRGBCount = 0.f; s.ill = 0;
     *st = s;
 }
 
@@ -1403,6 +1247,7 @@ __global__ __launch_bounds__(256) void k_rgbd_finalize(const float* __restrict__
     if (so3) { p.lastSO3Error = so3->error; p.lastSO3Count = so3->count; p.so3Iterations = so3->iterations; }
     else { p.lastSO3Error = 0.f; p.lastSO3Count = 0.f; p.so3Iterations = 0; }
     for (int k = 0; k < 3; ++k) p.incT[k] = st.trt[k];
+    p.illIterations = st.ill;   // (the photometric loop does not count: its combined system goes through the wave Gauss-Jordan)
     if (jump_limit > 0.f && norm3(f3(st.trt[0], st.trt[1], st.trt[2])) >= jump_limit) p.alive = 0;   // `float d > 0.2` is a DOUBLE comparison upstream (MaskFusion.cpp:268): true from 0.2f on
     pose_derive(p);
     *pose = p;

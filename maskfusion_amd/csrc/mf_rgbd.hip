@@ -32,19 +32,19 @@ void launch_intensity(const uint8_t* img, int channels, uint8_t* dst, int n, hip
 __global__ __launch_bounds__(256) void k_rgbd_last_l0(const float4* __restrict__ predV, const float* __restrict__ fillDepth,
                                                       const uint8_t* __restrict__ predGray, const uint8_t* __restrict__ fillGray,
                                                       const FrameDev* __restrict__ frame, float cutOff, float* __restrict__ depth0,
-                                                      uint8_t* __restrict__ image0, int n) {
+                                                      uint8_t* __restrict__ image0, int n, int frameToFrameRGB) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const bool useFill = fillDepth != nullptr && frame->useFillIn != 0;
     float z = predV[i].z;
     if (useFill && z == 0) z = fillDepth[i];                       // fill_vertex.frag:37-53
     depth0[i] = (z > cutOff || z <= 0) ? qnan() : z;               // verticesToDepthKernel
-    image0[i] = useFill ? fillGray[i] : predGray[i];
+    image0[i] = (useFill || (frameToFrameRGB != 0 && fillGray != nullptr)) ? fillGray[i] : predGray[i];   // Model.cpp:395-401
 }
 void launch_rgbd_last_l0(const float4* predV, const float* fillDepth, const uint8_t* predGray, const uint8_t* fillGray,
-                         const FrameDev* frame, float* depth0, uint8_t* image0, int n, hipStream_t s) {
+                         const FrameDev* frame, float* depth0, uint8_t* image0, int n, hipStream_t s, int frameToFrameRGB) {
     hipLaunchKernelGGL(k_rgbd_last_l0, dim3((n + 255) / 256), dim3(256), 0, s, predV, fillDepth, predGray, fillGray, frame, 6.0f,
-                       depth0, image0, n);  // maxDepthRGB = 6, RGBDOdometry.cpp:34
+                       depth0, image0, n, frameToFrameRGB);  // maxDepthRGB = 6, RGBDOdometry.cpp:34
 }
 
 // ---------------- pyrDownUcharGauss (cudafuncs.cu:534-588; border quirk Q9, zero texels skipped) ----------------

@@ -186,6 +186,7 @@ __global__ void k_spawn_pose(PoseDev* obj, const PoseDev* bg, FrameDev* objFrame
     q.initT[0] = -v.x; q.initT[1] = -v.y; q.initT[2] = -v.z;
     *obj = q;
     objFrame->tick = bgFrame->tick; objFrame->count = 0; objFrame->countNext = 0; objFrame->cover = 0; objFrame->useFillIn = 0; objFrame->done_cover = 0ull;
+    MF_FRAME_BBOX_RESET(objFrame);
     objFrame->pad[0] = objFrame->pad[1] = objFrame->pad[2] = 0;
     if (host_mirror) *host_mirror = q;
 }

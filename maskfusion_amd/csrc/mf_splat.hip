@@ -137,6 +137,7 @@ struct TileArgs {
     const float4* rec0; const float4* rec1; const short4* bbox;
     float4* predV; float4* predN; uchar4* predImage; uint16_t* predTime;
     const uint8_t* rgb; uint8_t* predGray; uint8_t* fillGray;
+    int fillPassthrough;             // fill_rgb.frag's `passthrough` (frameToFrameRGB, Model.cpp:981): the fill-in image is the raw frame everywhere
     int advance; FrameAdvance adv;   // advance != 0: the last workgroup also runs the end-of-frame bookkeeping (k_frame_advance)
 };
 
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256) void k_splat_tile(const TileArgs a) {
             const uint8_t gv = intensity_of((float)col.x, (float)col.y, (float)col.z);
             if (a.predGray) a.predGray[p] = gv;
             if (a.fillGray) {
-                const bool empty = col.x == 0 && col.y == 0 && col.z == 0;
+                const bool empty = (col.x == 0 && col.y == 0 && col.z == 0) || a.fillPassthrough != 0;
                 a.fillGray[p] = (empty && a.rgb) ? intensity_of((float)a.rgb[p * 3], (float)a.rgb[p * 3 + 1], (float)a.rgb[p * 3 + 2]) : gv;
             }
         }
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(256) void k_splat_tile(const TileArgs a) {
                 f->useFillIn = ((float)(f->cover + cover) / (float)(rw * rh) < 0.75f) ? 1 : 0;
                 f->cover = 0;
                 f->tick += 1;
+                MF_FRAME_BBOX_ADVANCE(f);
                 if (a.adv.host_mirror) *a.adv.host_mirror = *f;
             } else {
                 f->cover += cover;
@@ -317,7 +319,7 @@ size_t splat_tiles_scratch_ints(int W, int H) { return (size_t)((W + kTile - 1) 
 int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
                        int timeDelta, int* tile_count, int* entries, int entries_cap, float4* rec0, float4* rec1, void* bbox, float4* predV,
                        float4* predN, uchar4* predImage, uint16_t* predTime, const uint8_t* rgb, uint8_t* predGray, uint8_t* fillGray, hipStream_t s,
-                       const FrameAdvance* advance) {
+                       const FrameAdvance* advance, int fillPassthrough) {
     const int tilesX = (W + kTile - 1) / kTile, tilesY = (H + kTile - 1) / kTile, nt = tilesX * tilesY;
     if (nt > kMaxTiles) return -1;
     BinArgs b;
@@ -335,6 +337,7 @@ int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W,
     t.entries = entries; t.tile_cap = b.tile_cap; t.rec0 = rec0; t.rec1 = rec1; t.bbox = reinterpret_cast<const short4*>(bbox);
     t.predV = predV; t.predN = predN; t.predImage = predImage; t.predTime = predTime; t.rgb = rgb; t.predGray = predGray;
     t.fillGray = fillGray;
+    t.fillPassthrough = fillPassthrough;
     t.advance = advance ? 1 : 0;
     t.adv = advance ? *advance : FrameAdvance{nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(k_splat_tile, dim3(nt), dim3(256), 0, s, t);

@@ -238,6 +238,7 @@ void launch_index_resolve(Surfels src, const PoseDev* pose, unsigned long long* 
 struct FuseDataArgs {
     const uint8_t* rgb; const float* depthRaw; const float* depthF; const uint8_t* mask; int maskID;
     const FrameDev* frame; const PoseDev* pose; float weightMultiplier; float maxDepth;
+    int bboxLimit;                 // 1: object models limit their fusion depth by lastBoundingBox (upstream with its GUI; "objectBoundingBoxLimit")
     int W, H; Intr k;
     const int* index; const float4* vc; const float4* nr;
     uint8_t* cand_op; float4* cand_rec; int* upd_first;
@@ -260,7 +261,22 @@ __global__ __launch_bounds__(256) void k_fuse_data(const FuseDataArgs a) {
     bool valid = a.mask[py * W + px] == a.maskID;
     valid = valid && !(texf(a.depthRaw, W, H, px - 1, py) == 0 || texf(a.depthRaw, W, H, px, py - 1) == 0 ||
                        texf(a.depthRaw, W, H, px + 1, py) == 0 || texf(a.depthRaw, W, H, px, py + 1) == 0);
-    valid = valid && (vLocal.z > 0 && vLocal.z <= a.maxDepth);
+    // Model::fuse's maxDepth uniform = min(depthCutoff, model.maxDepth, bb_max_z) (Model.cpp:480-501,527): an OBJECT model whose
+    // bounding box exists (the GUI drew it after the previous frame) does not grow in depth beyond the box + 5 %.  The box's two corners are
+    // taken to the camera frame with pose^-1 and only their z is used.
+    float maxDepth = a.maxDepth;
+    if (a.maskID != 0 && a.bboxLimit) {
+        const FrameDev* f = a.frame;
+        if (f->bbox[0] <= f->bbox[3] && f->bbox[1] <= f->bbox[4] && f->bbox[2] <= f->bbox[5]) {   // !lastBoundingBox.isEmpty()
+            const float* Ri = a.pose->Ri; const float* ti = a.pose->ti;
+            const float bbscale = 0.001f;
+            const float zmin = ((Ri[6] * (bbscale * (float)f->bbox[0]) + Ri[7] * (bbscale * (float)f->bbox[1])) + Ri[8] * (bbscale * (float)f->bbox[2])) + ti[2];
+            const float zmax = ((Ri[6] * (bbscale * (float)f->bbox[3]) + Ri[7] * (bbscale * (float)f->bbox[4])) + Ri[8] * (bbscale * (float)f->bbox[5])) + ti[2];
+            const float lo = zmin < zmax ? zmin : zmax, hi = zmin < zmax ? zmax : zmin;
+            maxDepth = fminf(maxDepth, hi + 0.05f * fabsf(hi - lo));
+        }
+    }
+    valid = valid && (vLocal.z > 0 && vLocal.z <= maxDepth);
     if (valid) {
         float R[9];
 #pragma unroll
@@ -321,8 +337,8 @@ __global__ __launch_bounds__(256) void k_fuse_data(const FuseDataArgs a) {
 void launch_fuse_data(const uint8_t* rgb, const float* depthRaw, const float* depthF, const uint8_t* mask, int maskID,
                       const FrameDev* frame, const PoseDev* pose, float weightMultiplier, float maxDepth, int W, int H, Intr k,
                       const int* index, const float4* vc, const float4* nr, uint8_t* cand_op, float4* cand_rec, int* upd_first,
-                      hipStream_t s) {
-    FuseDataArgs a{rgb, depthRaw, depthF, mask, maskID, frame, pose, weightMultiplier, maxDepth, W, H, k,
+                      hipStream_t s, int bboxLimit) {
+    FuseDataArgs a{rgb, depthRaw, depthF, mask, maskID, frame, pose, weightMultiplier, maxDepth, bboxLimit, W, H, k,
                    index, vc, nr, cand_op, cand_rec, upd_first};
     dim3 grid(((W + 1) / 2 + 63) / 64, ((H + 1) / 2 + 3) / 4);
     hipLaunchKernelGGL(k_fuse_data, grid, dim3(256), 0, s, a);
@@ -544,6 +560,13 @@ __global__ __launch_bounds__(256) void k_clean_flags(const CleanArgs a) {
 
 __global__ __launch_bounds__(256) void k_clean_compact(const CleanArgs a) {
     __shared__ int s_w[4];
+    __shared__ int s_bb[6];
+    // Model::lastBoundingBox of an OBJECT model (Model.cpp:315-345 + draw_global_surface.vert:55-78: the box of the surfels the GUI draws --
+    // confidence above the model's threshold -- in millimetres, truncated): accumulated here, where the frame's final records pass through
+    // registers anyway; Model::fuse of the NEXT frame limits its depth with it (Model.cpp:480-501).  The background (id 0) never uses one.
+    const bool bbox_on = a.maskID != 0;
+    int bmin[3] = {kBBoxEmptyMin, kBBoxEmptyMin, kBBoxEmptyMin}, bmax[3] = {kBBoxEmptyMax, kBBoxEmptyMax, kBBoxEmptyMax};
+    if (bbox_on && threadIdx.x < 6) s_bb[threadIdx.x] = threadIdx.x < 3 ? kBBoxEmptyMin : kBBoxEmptyMax;
     const int count = a.frame->countNext;
     const int total = count + cand_count(a.W, a.H, a.frame->tick);
     const float time = (float)a.frame->tick;
@@ -577,10 +600,29 @@ __global__ __launch_bounds__(256) void k_clean_compact(const CleanArgs a) {
             const int o = off + lane_rank(m);
             pc.w = nc;
             if (ct.w == -2.f) ct.w = time;  // copy_unstable.vert:131
-            if (o < a.dst.cap) { a.dst.pc[o] = pc; a.dst.ct[o] = ct; a.dst.nr[o] = nr; }
+            if (o < a.dst.cap) {
+                a.dst.pc[o] = pc; a.dst.ct[o] = ct; a.dst.nr[o] = nr;
+                if (bbox_on && pc.w > a.confThreshold) {   // draw_global_surface.vert:55 (unstable == 0), :69-78
+                    const int x = (int)(1000.f * pc.x), y = (int)(1000.f * pc.y), z = (int)(1000.f * pc.z);
+                    bmin[0] = min(bmin[0], x); bmin[1] = min(bmin[1], y); bmin[2] = min(bmin[2], z);
+                    bmax[0] = max(bmax[0], x); bmax[1] = max(bmax[1], y); bmax[2] = max(bmax[2], z);
+                }
+            }
         }
         base += tot;
         __syncthreads();
+    }
+    if (bbox_on) {   // (the loop's barriers order the initialisation of s_bb before these; a workgroup without elements skips both)
+        if (beg < end) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (bmin[q] != kBBoxEmptyMin) atomicMin(&s_bb[q], bmin[q]);
+                if (bmax[q] != kBBoxEmptyMax) atomicMax(&s_bb[3 + q], bmax[q]);
+            }
+            __syncthreads();
+            if (threadIdx.x < 3 && s_bb[threadIdx.x] != kBBoxEmptyMin) atomicMin(&a.frame->bbox_acc[threadIdx.x], s_bb[threadIdx.x]);
+            else if (threadIdx.x >= 3 && threadIdx.x < 6 && s_bb[threadIdx.x] != kBBoxEmptyMax) atomicMax(&a.frame->bbox_acc[threadIdx.x], s_bb[threadIdx.x]);
+        }
     }
     if (blockIdx.x != gridDim.x - 1) return;
     if (beg >= end) base = block_base(a.block_counts, s_w);   // the last workgroup owns no elements: all threads take part
@@ -660,7 +702,7 @@ __global__ __launch_bounds__(256) void k_splat_resolve(Surfels src, const PoseDe
                                                        float4* __restrict__ predV, float4* __restrict__ predN,
                                                        uchar4* __restrict__ predImage, uint16_t* __restrict__ predTime,
                                                        FrameDev* __restrict__ frame, const uint8_t* __restrict__ rgb,
-                                                       uint8_t* __restrict__ predGray, uint8_t* __restrict__ fillGray) {
+                                                       uint8_t* __restrict__ predGray, uint8_t* __restrict__ fillGray, int fillPassthrough) {
     const int px = blockIdx.x * 64 + (threadIdx.x & 63);
     const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (px >= W || py >= H) return;
@@ -692,7 +734,8 @@ __global__ __launch_bounds__(256) void k_splat_resolve(Surfels src, const PoseDe
         const uint8_t gv = intensity_of((float)col.x, (float)col.y, (float)col.z);
         if (predGray) predGray[p] = gv;
         if (fillGray) {
-            const bool empty = col.x == 0 && col.y == 0 && col.z == 0;
+            // fill_rgb.frag:31-34: the raw frame where the projection is empty -- or everywhere with `passthrough` (frameToFrameRGB, Model.cpp:981)
+            const bool empty = (col.x == 0 && col.y == 0 && col.z == 0) || fillPassthrough != 0;
             fillGray[p] = (empty && rgb) ? intensity_of((float)rgb[p * 3], (float)rgb[p * 3 + 1], (float)rgb[p * 3 + 2]) : gv;
         }
     }
@@ -703,10 +746,10 @@ __global__ __launch_bounds__(256) void k_splat_resolve(Surfels src, const PoseDe
 
 void launch_splat_resolve(Surfels src, const PoseDev* pose, unsigned long long* keys, int W, int H, Intr k, float4* predV,
                           float4* predN, uchar4* predImage, uint16_t* predTime, FrameDev* frame, const uint8_t* rgb,
-                          uint8_t* predGray, uint8_t* fillGray, hipStream_t s) {
+                          uint8_t* predGray, uint8_t* fillGray, hipStream_t s, int fillPassthrough) {
     dim3 grid((W + 63) / 64, (H + 3) / 4);
     hipLaunchKernelGGL(k_splat_resolve, grid, dim3(256), 0, s, src, pose, keys, W, H, k, predV, predN, predImage, predTime, frame, rgb,
-                       predGray, fillGray);
+                       predGray, fillGray, fillPassthrough);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -721,6 +764,7 @@ __global__ void k_frame_advance(FrameDev* frame, int W, int H, FrameDev* host_mi
     frame->useFillIn = ((float)frame->cover / (float)(rw * rh) < 0.75f) ? 1 : 0;
     frame->cover = 0;
     frame->tick += 1;
+    MF_FRAME_BBOX_ADVANCE(frame);
     if (host_mirror) *host_mirror = *frame;
 }
 void launch_frame_advance(FrameDev* frame, int W, int H, FrameDev* host_mirror, const PoseDev* pose, const PoseDev* bg_pose,

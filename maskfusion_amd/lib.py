@@ -56,6 +56,7 @@ SYMBOLS = {
     "mf_model_state_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "mf_get_icp_stats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mf_get_track_stats": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "mf_get_gn_condition": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "mf_get_pose_log": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "mf_export_poses": (C.c_int, [C.c_void_p, C.c_char_p]),
     "mf_save_ply": (C.c_int, [C.c_void_p, C.c_char_p]),

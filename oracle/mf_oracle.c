@@ -462,10 +462,36 @@ void mfo_update_se3(double* resultRt, const double* x6) {
 
 /* Core/Utils/RGBDOdometry.cpp:227-497, icp && !rgb branch (so3 pre-alignment handled by the caller when the
  * photometric data exists; here resultRt starts at identity). */
+/* Stated domain of the Gauss-Newton solve (DESIGN.md finding F4): an iteration is "ill" when its system has fewer than 6 inliers or a pivot of
+ * the UNPIVOTED LDL^T below 1e-8 of the largest diagonal entry (=> cond(A) > 1e8).  There this restatement (Eigen-style pivoted LDLT on the
+ * float-rounded sums, as the reference) and the device (unpivoted LDL^T on fp64 sums) may step differently; both count such iterations. */
+static int g_track_ill = 0;
+int mfo_last_track_ill(void) { return g_track_ill; }
+static int gn_system_ill(const double* A36, float inliers) {
+    double M[6][6], maxdiag = 0.0, minpiv = 1.7976931348623157e308;
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) M[i][j] = A36[i * 6 + j];
+    for (int i = 0; i < 6; ++i) maxdiag = fmax(maxdiag, fabs(M[i][i]));
+    const double tol = maxdiag * 1e-14;
+    for (int k = 0; k < 6; ++k) {
+        const double d = M[k][k];
+        const int ok = d > tol;
+        minpiv = fmin(minpiv, ok ? d : 0.0);
+        const double dinv = ok ? 1.0 / d : 0.0;
+        for (int i = k + 1; i < 6; ++i) {
+            const double l = M[i][k] * dinv;
+            for (int j = k + 1; j <= i; ++j) M[i][j] -= l * M[j][k];
+        }
+    }
+    const double ratio = maxdiag > 0.0 ? minpiv / maxdiag : 0.0;
+    return (inliers < 6.f || !(ratio >= 1e-8)) ? 1 : 0;
+}
+
 void mfo_track_icp(const float* const curr_v[3], const float* const curr_n[3], const float* const prev_v[3],
                    const float* const prev_n[3], int W, int H, float fx, float fy, float cx, float cy,
                    const mfo_track_opts* o, float* R, float* t, float* out_inc16, float* lastICPError,
                    float* lastICPCount, mfo_track_log* log) {
+    g_track_ill = 0;
     float Rprev[9], tprev[3], Rcurr[9], tcurr[3], Rprev_inv[9];
     memcpy(Rprev, R, sizeof(Rprev)); memcpy(tprev, t, sizeof(tprev));
     memcpy(Rcurr, R, sizeof(Rcurr)); memcpy(tcurr, t, sizeof(tcurr));
@@ -492,6 +518,7 @@ void mfo_track_icp(const float* const curr_v[3], const float* const curr_n[3], c
             double dA[36], db[6], x[6];
             for (int k = 0; k < 36; ++k) dA[k] = A[k];
             for (int k = 0; k < 6; ++k) db[k] = b[k];
+            g_track_ill += gn_system_ill(dA, residual[1]);
             mfo_ldlt_solve(dA, db, x, 6);
             mfo_update_se3(resultRt, x);
             for (int r = 0; r < 3; ++r) {
@@ -833,6 +860,7 @@ void mfo_track_rgbd(const float* const curr_v[3], const float* const curr_n[3], 
     memcpy(Rprev, R, sizeof(Rprev)); memcpy(tprev, t, sizeof(tprev));
     memcpy(Rcurr, R, sizeof(Rcurr)); memcpy(tcurr, t, sizeof(tcurr));
     memset(st, 0, sizeof(*st));
+    g_track_ill = 0;
     const float sobelScale = (float)(1.0 / 8.0);      /* 1 / 2^sobelSize, RGBDOdometry.cpp:31-32 */
     const float maxDepthDeltaRGB = 0.07f;              /* :33 */
     const float minGrad[3] = {5.f, 3.f, 1.f};          /* :102-105 */
@@ -914,6 +942,7 @@ void mfo_track_rgbd(const float* const curr_v[3], const float* const curr_n[3], 
             } else if (icp) {
                 for (int k = 0; k < 36; ++k) dA[k] = A_icp[k];
                 for (int k = 0; k < 6; ++k) db[k] = b_icp[k];
+                g_track_ill += gn_system_ill(dA, residual[1]);   /* the geometric loop's stated domain (finding F4) */
             } else {
                 for (int k = 0; k < 36; ++k) dA[k] = A_rgbd[k];
                 for (int k = 0; k < 6; ++k) db[k] = b_rgbd[k];
@@ -1545,14 +1574,14 @@ void mfo_fill_in(const mfo_cam* c, const uint8_t* predImage, const float* predVe
     for (int y = 0; y < H; ++y) {
         for (int x = 0; x < W; ++x) {
             const int p = y * W + x;
-            if (predVertex[p * 4 + 2] == 0 || passthrough) {
+            if (predVertex[p * 4 + 2] == 0 || (passthrough & 1)) {   /* bit 0: `lost` (all three passes); bit 1: frameToFrameRGB (image pass only, Model.cpp:979-981) */
                 const float z = rawDepth[p];
                 fillVertex[p * 4 + 0] = ((float)x - c->cx) * z * (1.0f / c->fx);
                 fillVertex[p * 4 + 1] = ((float)y - c->cy) * z * (1.0f / c->fy);
                 fillVertex[p * 4 + 2] = z;
                 fillVertex[p * 4 + 3] = 1.f;
             } else memcpy(fillVertex + p * 4, predVertex + p * 4, 4 * sizeof(float));
-            if (predNormal[p * 4 + 2] == 0 || passthrough) {
+            if (predNormal[p * 4 + 2] == 0 || (passthrough & 1)) {
                 const f3 vp = get_vertex_f(rawDepth, W, H, x, y, (float)x, (float)y, c);
                 const f3 n = get_normal_forward(rawDepth, c, x, y, vp);
                 fillNormal[p * 4 + 0] = n.x; fillNormal[p * 4 + 1] = n.y; fillNormal[p * 4 + 2] = n.z;
@@ -1681,7 +1710,9 @@ struct mfo_ctx {
     double tms[8];
     rgbd_scratch rs; uint8_t* lastNext[3]; mfo_track_stats stats;
     const float* depthF_override;   /* test isolation: see mfo_override_filtered_depth */
+    int frameToFrameRGB;            /* MaskFusion::frameToFrameRGB ("-ftf"): Model.cpp:399-400 (initRGBModel source), :981 (fill_rgb passthrough) */
 };
+void mfo_set_frame_to_frame_rgb(mfo_ctx* x, int on) { x->frameToFrameRGB = on; }
 
 void mfo_default_config(mfo_config* c, int W, int H, float fx, float fy, float cx, float cy) {
     memset(c, 0, sizeof(*c));
@@ -1749,8 +1780,9 @@ static void oracle_predict(mfo_ctx* x) {
     const mfo_config* g = &x->cfg;
     mfo_combined_predict(&x->cam, x->pose, x->surf[x->cur], x->count, g->maxDepthProcessed, g->confGlobal, x->tick,
                          x->tick, g->timeDelta, x->predImage, x->predVertex, x->predNormal, x->predTime);
-    /* performFillIn(textureRGB, textureDepthMetricFiltered, frameToFrameRGB=false, lost=false) */
-    mfo_fill_in(&x->cam, x->predImage, x->predVertex, x->predNormal, x->rgb, x->depthF, 0, x->fillImage,
+    /* performFillIn(textureRGB, textureDepthMetricFiltered, frameToFrameRGB, lost=false): FillIn::image gets passthrough = lost ||
+     * frameToFrameRGB (Model.cpp:981), FillIn::vertex / normal get `lost` only */
+    mfo_fill_in(&x->cam, x->predImage, x->predVertex, x->predNormal, x->rgb, x->depthF, x->frameToFrameRGB ? 2 : 0, x->fillImage,
                 x->fillVertex, x->fillNormal);
 }
 
@@ -1858,8 +1890,9 @@ int mfo_process_frame_ex(mfo_ctx* x, const uint8_t* rgb, const float* depth, flo
         const float* cn[3] = {x->nmap[0], x->nmap[1], x->nmap[2]};
         const float* pv[3] = {x->vmap_g[0], x->vmap_g[1], x->vmap_g[2]};
         const float* pn[3] = {x->nmap_g[0], x->nmap_g[1], x->nmap_g[2]};
-        /* frameToFrameRGB = false: initRGBModel(doFillIn ? fill-in image : RGB projection), Model.cpp:395-401 */
-        track_model(g, &x->rs, cv, cn, pv, pn, doFillIn ? x->fillVertex : x->predVertex, doFillIn ? x->fillImage : x->predImage,
+        /* initRGBModel(doFillIn || (frameToFrameRGB && allowsFillIn()) ? fill-in image : RGB projection), Model.cpp:395-401 */
+        track_model(g, &x->rs, cv, cn, pv, pn, doFillIn ? x->fillVertex : x->predVertex,
+                    (doFillIn || x->frameToFrameRGB) ? x->fillImage : x->predImage,
                     x->rgb, x->lastNext, R, t, NULL, &x->stats);
         x->lastICPError = x->stats.lastICPError; x->lastICPCount = x->stats.lastICPCount;
         Rt_to_pose16(R, t, x->pose);
@@ -2201,7 +2234,23 @@ typedef struct {
     uint8_t* predImage; float* predVertex; float* predNormal; uint16_t* predTime;
     float lastICPError, lastICPCount;
     uint8_t* lastNext[3];
+    int bbox[6];   /* Model::lastBoundingBox in mm, {min xyz, max xyz}; Model.cpp:315 initial value = empty */
 } mm_model;
+static void mm_bbox_reset(mm_model* m) { for (int k = 0; k < 3; ++k) { m->bbox[k] = 100000; m->bbox[3 + k] = -100000; } }
+/* Model::renderPointCloud (Model.cpp:287-346) + draw_global_surface.vert:55-78, as the GUI runs it after every frame with its defaults
+ * (drawUnstable = false): the box of the surfels whose confidence exceeds the model's threshold, model coordinates, int(1000 * x) */
+static void mm_bbox_update(mm_model* m) {
+    mm_bbox_reset(m);
+    const float* s = m->surf[m->cur];
+    for (int i = 0; i < m->count; ++i) {
+        if (!(s[(size_t)i * 12 + 3] > m->confThr)) continue;
+        for (int k = 0; k < 3; ++k) {
+            const int v = (int)(1000.f * s[(size_t)i * 12 + k]);
+            if (v < m->bbox[k]) m->bbox[k] = v;
+            if (v > m->bbox[3 + k]) m->bbox[3 + k] = v;
+        }
+    }
+}
 
 struct mfo_mm {
     mfo_mm_config cfg;
@@ -2217,7 +2266,11 @@ struct mfo_mm {
     rgbd_scratch rs;
     float* edge; uint8_t* binEdge; uint8_t* ucharBuf; uint8_t* projIDs; uint8_t* ignoreMap; uint8_t* fullSeg;
     const float* depthF_override;   /* test isolation, as mfo_override_filtered_depth: consumed by the next mfo_mm_process_frame */
+    int frameToFrameRGB;            /* as mfo_ctx */
+    int bboxLimit;                  /* object models limit their fusion depth by lastBoundingBox (upstream with its GUI; default 1) */
 };
+void mfo_mm_set_frame_to_frame_rgb(mfo_mm* x, int on) { x->frameToFrameRGB = on; }
+void mfo_mm_set_bbox_limit(mfo_mm* x, int on) { x->bboxLimit = on; }
 void mfo_mm_override_filtered_depth(mfo_mm* x, const float* depthF) { x->depthF_override = depthF; }
 
 void mfo_mm_default_config(mfo_mm_config* c, int W, int H, float fx, float fy, float cx, float cy) {
@@ -2250,6 +2303,7 @@ static void mm_model_init(mfo_mm* x, mm_model* m, int id, float confThr, int cap
     memset(m, 0, sizeof(*m));
     m->id = id; m->classID = -1; m->isStatic = 1; m->confThr = confThr; m->maxDepth = 3.402823466e38f; m->cap = cap;
     mat4_identity(m->pose); mat4_identity(m->lastPose); mat4_identity(m->initialC2Winv);
+    mm_bbox_reset(m);
     m->surf[0] = (float*)calloc((size_t)cap * 12, sizeof(float));
     m->surf[1] = (float*)calloc((size_t)cap * 12, sizeof(float));
     m->predImage = (uint8_t*)calloc((size_t)P * 4, 1);
@@ -2270,6 +2324,7 @@ mfo_mm* mfo_mm_create(const mfo_mm_config* cfg) {
     x->cam.W = g->W; x->cam.H = g->H; x->cam.fx = g->fx; x->cam.fy = g->fy; x->cam.cx = g->cx; x->cam.cy = g->cy;
     const int W = g->W, H = g->H, P = W * H;
     x->tick = 1; x->nextID = 0; x->spawnOffset = 0;
+    x->bboxLimit = 1;
     x->models = (mm_model*)calloc(cfg->maxModels, sizeof(mm_model));
     mm_model_init(x, &x->models[0], x->nextID++, g->confGlobal, g->capacity); /* getNextModelID(true), :80 */
     x->nModels = 1;
@@ -2329,7 +2384,9 @@ static float mm_track(mfo_mm* x, mm_model* m, int allowFillIn) {
     const float* pv[3] = {x->vmap_g[0], x->vmap_g[1], x->vmap_g[2]};
     const float* pn[3] = {x->nmap_g[0], x->nmap_g[1], x->nmap_g[2]};
     mfo_track_stats st;
-    track_model(g, &x->rs, cv, cn, pv, pn, doFillIn ? x->fillVertex : m->predVertex, doFillIn ? x->fillImage : m->predImage,
+    /* only the background model allows fill-in (Model.cpp:400: frameToFrameRGB && allowsFillIn()) */
+    track_model(g, &x->rs, cv, cn, pv, pn, doFillIn ? x->fillVertex : m->predVertex,
+                (doFillIn || (x->frameToFrameRGB && m == &x->models[0])) ? x->fillImage : m->predImage,
                 x->rgb, m->lastNext, R, t, inc, &st);
     m->lastICPError = st.lastICPError; m->lastICPCount = st.lastICPCount;
     Rt_to_pose16(R, t, m->pose);
@@ -2347,7 +2404,18 @@ static void mm_fuse_clean(mfo_mm* x, mm_model* m, float fuseDepthCutoff, float w
     const int src = m->cur, dst = 1 - m->cur;
     mm_predict_indices(x, m, m->surf[src]);
     const float weighting = mfo_fusion_weight(m->pose, m->lastPose, weightMultiplier);
-    const float md = fminf(fuseDepthCutoff, m->maxDepth); /* Model.cpp:527 (bb_max_z = FLT_MAX headless) */
+    float md = fminf(fuseDepthCutoff, m->maxDepth); /* Model.cpp:527 */
+    if (m->id != 0 && x->bboxLimit && m->bbox[0] <= m->bbox[3] && m->bbox[1] <= m->bbox[4] && m->bbox[2] <= m->bbox[5]) {
+        /* Model.cpp:480-501: the two corners of lastBoundingBox in the camera frame (pose^-1), z only, + 5 % */
+        float R[9], t[3], Ri[9], ti[3];
+        pose16_to_Rt(m->pose, R, t);
+        pose_inverse_Rt(R, t, Ri, ti);
+        const float bbscale = 0.001f;
+        const float zmin = ((Ri[6] * (bbscale * (float)m->bbox[0]) + Ri[7] * (bbscale * (float)m->bbox[1])) + Ri[8] * (bbscale * (float)m->bbox[2])) + ti[2];
+        const float zmax = ((Ri[6] * (bbscale * (float)m->bbox[3]) + Ri[7] * (bbscale * (float)m->bbox[4])) + Ri[8] * (bbscale * (float)m->bbox[5])) + ti[2];
+        const float lo = zmin < zmax ? zmin : zmax, hi = zmin < zmax ? zmax : zmin;
+        md = fminf(md, hi + 0.05f * fabsf(hi - lo));
+    }
     mfo_fuse_data(&x->cam, m->pose, x->rgb, x->depth, x->depthF, x->mask, m->id, x->tick, weighting, md, x->index, x->ivc,
                   x->inr, x->cand_op, x->cand_best, x->cand_rec, &x->n_cand);
     mfo_fuse_update(m->surf[src], m->surf[dst], m->count, x->tick, x->cand_op, x->cand_best, x->cand_rec, x->n_cand);
@@ -2454,9 +2522,11 @@ int mfo_mm_process_frame(mfo_mm* x, const uint8_t* rgb, const float* depth, cons
         mfo_combined_predict(&x->cam, m->pose, m->surf[m->cur], m->count, g->maxDepthProcessed, m->confThr, x->tick, x->tick,
                              g->timeDelta, m->predImage, m->predVertex, m->predNormal, m->predTime);
         if (i == 0)
-            mfo_fill_in(&x->cam, m->predImage, m->predVertex, m->predNormal, x->rgb, x->depthF, 0, x->fillImage,
+            mfo_fill_in(&x->cam, m->predImage, m->predVertex, m->predNormal, x->rgb, x->depthF, x->frameToFrameRGB ? 2 : 0, x->fillImage,
                         x->fillVertex, x->fillNormal);
     }
+    /* the GUI's render pass after processFrame (GUI/MainController.cpp:704-717): lastBoundingBox of every object model */
+    for (int i = 1; i < x->nModels; ++i) mm_bbox_update(&x->models[i]);
     x->tick++;
     for (int i = 0; i < x->nModels; ++i) x->models[i].age++;
     return 0;

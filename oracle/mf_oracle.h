@@ -251,12 +251,16 @@ int      mfo_process_frame_ex(mfo_ctx* ctx, const uint8_t* rgb, const float* dep
                               const float* inPose16 /*column-major or NULL*/, int bootstrap);
 /* test isolation: the next mfo_process_frame uses depthF (W*H) as the bilateral filter's output */
 void     mfo_override_filtered_depth(mfo_ctx* ctx, const float* depthF);
+/* MaskFusion::setFrameToFrameRGB ("-ftf"; Model.cpp:399-400,981) */
+void     mfo_set_frame_to_frame_rgb(mfo_ctx* ctx, int on);
 void     mfo_get_pose(const mfo_ctx* ctx, float* pose16);
 int      mfo_get_count(const mfo_ctx* ctx);
 int      mfo_get_tick(const mfo_ctx* ctx);
 const float* mfo_get_surfels(const mfo_ctx* ctx);
 void     mfo_get_icp_stats(const mfo_ctx* ctx, float* err, float* count);
 void     mfo_get_track_stats(const mfo_ctx* ctx, mfo_track_stats* out);
+/* iterations of the LAST mfo_track_icp call whose system was outside the solver's stated domain (< 6 inliers or cond(A) > 1e8: finding F4) */
+int      mfo_last_track_ill(void);
 /* per-stage wall-clock (ms) accumulated since create: order = preprocess, odomInit, odom, indexMap, fuseData,
  * fuseUpdate, clean, predict */
 void     mfo_get_timings(const mfo_ctx* ctx, double* ms8);
@@ -336,6 +340,9 @@ mfo_mm* mfo_mm_create(const mfo_mm_config* c);
 void    mfo_mm_destroy(mfo_mm* x);
 /* test isolation (see mfo_override_filtered_depth): the NEXT mfo_mm_process_frame takes this image as the bilateral filter's output */
 void    mfo_mm_override_filtered_depth(mfo_mm* x, const float* depthF);
+void    mfo_mm_set_frame_to_frame_rgb(mfo_mm* x, int on);
+/* Model::fuse's bb_max_z (Model.cpp:480-501) from the box the GUI's render pass leaves (Model.cpp:287-346); default on */
+void    mfo_mm_set_bbox_limit(mfo_mm* x, int on);
 int     mfo_mm_process_frame(mfo_mm* x, const uint8_t* rgb, const float* depth, const uint8_t* mask,
                              const int32_t* classIDs, int nMasks, float weightMultiplier);
 int     mfo_mm_num_models(const mfo_mm* x);

@@ -137,6 +137,9 @@ def lib():
     L.mfo_process_frame_ex.argtypes = [C.c_void_p, u8p, f32p, C.c_float, f32p, C.c_int]
     L.mfo_process_frame_ex.restype = C.c_int
     L.mfo_override_filtered_depth.argtypes = [C.c_void_p, f32p]
+    L.mfo_last_track_ill.argtypes = []
+    L.mfo_set_frame_to_frame_rgb.argtypes = [C.c_void_p, C.c_int]
+    L.mfo_last_track_ill.restype = C.c_int
     L.mfo_get_pose.argtypes = [C.c_void_p, f32p]
     L.mfo_get_count.argtypes = [C.c_void_p]
     L.mfo_get_count.restype = C.c_int

@@ -52,6 +52,8 @@ def mm_lib():
     L.mfo_mm_destroy.argtypes = [C.c_void_p]
     L.mfo_mm_process_frame.argtypes = [C.c_void_p, u8p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_float]
     L.mfo_mm_override_filtered_depth.argtypes = [C.c_void_p, f32p]
+    L.mfo_mm_set_frame_to_frame_rgb.argtypes = [C.c_void_p, C.c_int]
+    L.mfo_mm_set_bbox_limit.argtypes = [C.c_void_p, C.c_int]
     L.mfo_mm_num_models.argtypes = [C.c_void_p]
     L.mfo_mm_num_models.restype = C.c_int
     for n in ("mfo_mm_model_id", "mfo_mm_model_count"):

@@ -8,6 +8,7 @@
 
 using namespace maskfusion;
 extern "C" int stub_processed(long long* out, int max);
+extern "C" double stub_param(const char* key);
 
 #define CHECK(cond) do { if (!(cond)) { std::printf("FAILED line %d: %s\n", __LINE__, #cond); return 1; } } while (0)
 
@@ -66,9 +67,12 @@ int main() {
         CHECK(stub_processed(seen, 4) == 1 && seen[0] == 1);
     }
     // what is not built says so instead of silently doing something else
-    threw = false;
-    try { MaskFusion mf(200, 35000, 5e-05f, 1e-05f, true, false, false, 115, 4, 2, 3, 10, false, 0.3095f, true, /*frameToFrameRGB*/ true); } catch (const std::invalid_argument&) { threw = true; }
-    CHECK(threw);
+    {   // frameToFrameRGB ("-ftf", GUI/MainController.cpp:252,539) is built since round 3: the constructor argument and the setter reach the core
+        MaskFusion mf(200, 35000, 5e-05f, 1e-05f, true, false, false, 115, 4, 2, 3, 10, false, 0.3095f, true, /*frameToFrameRGB*/ true);
+        CHECK(stub_param("frameToFrameRGB") == 1.0);
+        mf.setFrameToFrameRGB(false);
+        CHECK(stub_param("frameToFrameRGB") == 0.0);
+    }
     threw = false;
     try { MaskFusion mf(200, 35000, 5e-05f, 1e-05f, true, false, false, 115, 4, 2, 3, 10, false, 0.3095f, true, false, 20, Model::MatchingType::Drost, Segmentation::Method::CO_FUSION); } catch (const std::invalid_argument&) { threw = true; }
     CHECK(threw);

@@ -62,10 +62,13 @@ int mf_get_param(mf_ctx* c, const char* key, double* v) {
     *v = !std::strcmp(key, "enableMultipleModels") ? c->cfg.enable_multiple_models : !std::strcmp(key, "timeDelta") ? c->cfg.time_delta : 0.0;
     return MF_OK;
 }
+static double g_ftf = -1.0;   // last value mf_set_param("frameToFrameRGB", .) received (-1: never set)
 int mf_set_param(mf_ctx* c, const char* key, double v) {
     if (!std::strcmp(key, "enableMultipleModels")) c->cfg.enable_multiple_models = (int)v;
+    if (!std::strcmp(key, "frameToFrameRGB")) g_ftf = v;
     return MF_OK;
 }
+double stub_param(const char* key) { return !std::strcmp(key, "frameToFrameRGB") ? g_ftf : -1.0; }
 int mf_export_segmentation_png(mf_ctx*, const char*) { return MF_OK; }
 // what the test reads back
 int stub_processed(long long* out, int max) {

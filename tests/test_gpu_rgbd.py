@@ -179,3 +179,35 @@ def test_pipeline_rgb_only_runs(hip, oracle):
     assert np.linalg.norm(po[:3, 3] - ph[:3, 3]) < 2e-3
     assert abs(sh["lastRGBCount"] - so.lastRGBCount) <= 0.02 * so.lastRGBCount + 5
     assert sh["lastICPCount"] == 0.0
+
+
+def test_frame_to_frame_rgb(hip, oracle):
+    """MaskFusion::frameToFrameRGB ("-ftf", GUI/MainController.cpp:252,539): the photometric term tracks against the previous RAW frame --
+    initRGBModel takes the fill-in image (Model.cpp:399-400), which performFillIn builds with `passthrough` (Model.cpp:981, fill_rgb.frag).
+    Same poses / statistics as the oracle with the switch on, and a different trajectory from the one without it (the switch does something)."""
+    from maskfusion_amd import MaskFusion
+    from gpu_util import scene_frames
+    st, frames = scene_frames(8, noise=True)
+    cap = 1 << 20
+    runs = {}
+    for ftf in (1, 0):
+        o = oracle.Oracle(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpWeight=10.0, capacity=cap, so3=1)
+        oracle.lib().mfo_set_frame_to_frame_rgb(o.h, ftf)
+        m = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=10.0, so3=True, numGSurfels=cap, enableMultipleModels=False)
+        m.setFrameToFrameRGB(bool(ftf))
+        assert m.getParam("frameToFrameRGB") == ftf
+        poses = []
+        for k, (rgb, depth, _) in enumerate(frames):
+            o.process_frame(rgb, depth)
+            m.processFrame(rgb, depth, timestamp=k)
+            gp, op = m.getCurrPose(), o.pose
+            d = float(np.abs(gp - op).max())
+            ts = m.trackStats(0)
+            print("ftf", ftf, "frame", k, "max |pose diff|", d, "rgb count", ts["lastRGBCount"])
+            assert d < 1e-4, (ftf, k)
+            poses.append(gp)
+        runs[ftf] = np.array(poses)
+        o.close(); m.close()
+    sep = float(np.abs(runs[1] - runs[0]).max())
+    print("trajectory with / without frameToFrameRGB differs by", sep)
+    assert sep > 1e-6

@@ -10,7 +10,6 @@ python -c "import __graft_entry__ as g; g.build()"
 python -m pytest tests -q -m "not gpu"
 [ "$MODE" = quick ] && exit 0
 MF_EMU=1 python -m pytest tests -m gpu -q -p no:cacheprovider
-MF_EMU=1 MF_EMU_COOP=1 HIPCPU_COOPERATIVE=k_icp_persist MF_TEST_PERSISTENT=1 python -m pytest tests/test_gpu_persistent_icp.py -q -p no:cacheprovider
 [ "$MODE" = full ] && exit 0
 ASAN=$(gcc -print-file-name=libasan.so)
 LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 MF_EMU=1 MF_EMU_ASAN=1 python -m pytest tests -m gpu -q -p no:cacheprovider
