@@ -21,7 +21,7 @@ SURVEY.md 8e) and tracks / fuses it against the frame rank 0 broadcasts over RCC
 The JSON line also carries
   roofline       -- the dominant kernel (the ICP Gauss-Newton iteration): algorithmic bytes per launch / average launch duration
                     measured here with HIP events on the library's stream, against the 8 TB/s HBM peak; `traffic` = HBM bytes
-                    per launch from the committed PMC profile (profiles/r02_pmc.json) when it was taken on this kernel;
+                    per launch from the newest committed PMC profile (profiles/r*_pmc.json) when it was taken on this kernel;
   roofline_frame -- the same for the whole frame: (741 P + 192 N) algorithmic bytes (SURVEY.md 8d) / frame time;
   host_input     -- frames/s through mf_process_frame (host pointers: 2.15 MB of H2D per frame + one sync), beside `value`;
   cpu_baseline   -- the oracle (CPU restatement, oracle/; a -O3 -march=native timing build) on this box's host cores.
@@ -66,18 +66,30 @@ def _render(args):
     return st.frame(k)
 
 
-def gen_frames(cfg, n, workers=0):
+def gen_frames(cfg, n, workers=0, cache=None):
     """n frames of the synthetic stream, ray-cast in parallel on the host cores (must run before CUDA is initialised: fork).
-    workers = 1: no fork at all (under rocprofv3 --pmc the tool has initialised HSA before Python starts; forked workers hang at exit)."""
+    workers = 1: no fork at all (under rocprofv3 --pmc the tool has initialised HSA before Python starts; forked workers hang at exit).
+    cache: directory the rendered frames are kept in / taken from (profiler passes over the full 600-frame stream re-use the frames of the
+    timing run instead of ray-casting them again without fork)."""
     from maskfusion_amd import synth
     st = synth.Stream(W=cfg["W"], H=cfg["H"], fx=cfg["f"], fy=cfg["f"], cx=cfg["W"] / 2.0, cy=cfg["H"] / 2.0, noise=True,
                       n_objects=cfg["n_objects"], seed=1234)
+    tag = None
+    if cache:
+        tag = os.path.join(cache, f"frames_{cfg['W']}x{cfg['H']}_o{cfg['n_objects']}_n{n}")
+        if os.path.exists(tag + "_rgb.npy"):
+            rgb, depth, mask = (np.load(tag + s + ".npy", mmap_mode="r") for s in ("_rgb", "_depth", "_mask"))
+            return st, [(np.ascontiguousarray(rgb[k]), np.ascontiguousarray(depth[k]), np.ascontiguousarray(mask[k])) for k in range(n)]
     workers = workers or max(1, min(48, (os.cpu_count() or 1) - 2, n))
     if workers > 1:
         with mp.get_context("fork").Pool(workers) as pool:
             frames = pool.map(_render, [(cfg, k) for k in range(n)], chunksize=max(1, n // (4 * workers)))
     else:
         frames = [st.frame(k) for k in range(n)]
+    if tag:
+        os.makedirs(cache, exist_ok=True)
+        for s, j in (("_rgb", 0), ("_depth", 1), ("_mask", 2)):
+            np.save(tag + s + ".npy", np.stack([f[j] for f in frames]))
     return st, frames
 
 
@@ -147,15 +159,18 @@ def cpu_baseline(cfg, frames, max_seconds=25.0):
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC summary (separate rocprofv3 --pmc passes, gfx950 corrections applied
-    when the file was written; see profiles/README.md).  None when there is no such record."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
-    try:
-        rec = json.load(open(path))["kernels"][kernel]
-        return {"bytes_per_launch": rec["fetch_bytes"] + rec["write_bytes"], "fetch_bytes": rec["fetch_bytes"], "write_bytes": rec["write_bytes"],
-                "source": f"profiles/r02_pmc.json ({rec.get('note', '')})"}
-    except Exception:
-        return None
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/r*_pmc.json: separate rocprofv3 --pmc passes,
+    gfx950 corrections applied when the file was written; see profiles/README.md).  None when there is no such record."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+        try:
+            doc = json.load(open(path))
+            rec = doc["kernels"][kernel]
+            return {"bytes_per_launch": rec["fetch_bytes"] + rec["write_bytes"], "fetch_bytes": rec["fetch_bytes"], "write_bytes": rec["write_bytes"],
+                    "source": f"profiles/{os.path.basename(path)} (tree {doc.get('tree', '?')}; {rec.get('note', '')})"}
+        except Exception:
+            continue
+    return None
 
 
 def ranks_seen(world, local_rank):
@@ -307,6 +322,7 @@ def main():
                     "the reference GUI default is 20: photometric term on, two launches per Gauss-Newton iteration)")
     ap.add_argument("--so3", action="store_true", help="SO(3) photometric pre-alignment (reference default: on)")
     ap.add_argument("--no-batch", action="store_true", help="config 2s: track the models one after the other (A/B of the batched loop)")
+    ap.add_argument("--frame-cache", default="", help="directory to keep / find the rendered frames in (profiler passes)")
     ap.add_argument("--gen-workers", type=int, default=0, help="processes that ray-cast the synthetic frames (0: auto; 1: no fork, for profiler runs)")
     ap.add_argument("--param", action="append", default=[], metavar="KEY=VALUE",
                     help="mf_set_param(KEY, VALUE) on the context before the run (A/B of implementation switches, e.g. persistentIcp=1); "
@@ -327,7 +343,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # the stream is ray-cast before CUDA exists in this process (the generator forks); only rank 0 owns frames
-    st, frames = gen_frames(cfg, n_frames, args.gen_workers) if rank == 0 else (None, None)
+    st, frames = gen_frames(cfg, n_frames, args.gen_workers, args.frame_cache or None) if rank == 0 else (None, None)
     # N > 1 on the metric's config: the north star's multi-GPU scene (configs[3], 8 objects sharded by model) is timed in the same run,
     # beside the weak-scaling line whose per-N values the driver compares
     with_scene = (world > 1 or args.force_sharded_scene) and args.config == "1" and not args.no_sharded_scene

@@ -221,6 +221,10 @@ int mf_debug_read(mf_ctx* ctx, const char* what, void* out, uint64_t out_bytes);
  * (RGBDOdometry::initRGB).  mask = model id per pixel as textureMask holds it for fuse / clean (Core/MaskFusion.cpp:297);
  * NULL = leave textureMask as it is (all background in a fresh context).  Host pointers; synchronous. */
 int mf_stage_frame(mf_ctx* ctx, const uint8_t* rgb, const float* depth, const uint8_t* mask);
+/* The same for a frame that is already in device memory (no upstream twin: upstream's FrameData lives on the host, MaskFusion.cpp:212-216
+ * uploads it).  Asynchronous: producers of the buffers are ordered on mf_get_stream(ctx) by the caller (e.g. an RCCL broadcast enqueued
+ * there), and d_rgb / d_depth stay valid and unmodified until the model-level calls of this frame have completed on that stream. */
+int mf_stage_frame_dev(mf_ctx* ctx, const uint8_t* d_rgb, const float* d_depth, const uint8_t* d_mask);
 /* The tail of processFrame (Core/MaskFusion.cpp:569-602) for a frame driven through the calls below: tick++, the
  * requiresFillIn decision for the next tracking step, the pose-log entry with `timestamp`, age++ */
 int mf_end_frame(mf_ctx* ctx, int64_t timestamp);

@@ -202,6 +202,10 @@ class MaskFusion:
         m = np.ascontiguousarray(mask, np.uint8) if mask is not None else None
         self._chk(self._L.mf_stage_frame(self._h, rgb.ctypes.data, depth.ctypes.data, m.ctypes.data if m is not None else None))
 
+    def stageFrameDevice(self, d_rgb: int, d_depth: int, d_mask: int = 0):
+        """stageFrame for buffers already in device memory (pointers as integers), asynchronous: see mf_stage_frame_dev"""
+        self._chk(self._L.mf_stage_frame_dev(self._h, d_rgb, d_depth, d_mask or None))
+
     def endFrame(self, timestamp: int = 0):
         self._chk(self._L.mf_end_frame(self._h, timestamp))
 

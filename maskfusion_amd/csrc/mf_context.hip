@@ -169,8 +169,7 @@ struct mf_ctx {
     RgbCorr* d_corres = nullptr; float* d_rgb_partials[2] = {nullptr, nullptr}; int2* d_cnt[2] = {nullptr, nullptr};
     So3Result* d_so3 = nullptr; char* d_so3_scratch = nullptr;
     // tiled splat prediction (mf_splat.hip)
-    int* d_tile_count = nullptr; int* d_tile_entries = nullptr; int tile_entries_cap = 0; int tile_entries_alloc = 0; int splat_tiles = 1;
-    float4* d_splat_rec0 = nullptr; float4* d_splat_rec1 = nullptr; uint2* d_splat_bbox = nullptr;   // per-surfel sprite set-up
+    int* d_tile_count = nullptr; float4* d_tile_entries = nullptr; int tile_entries_cap = 0; int tile_entries_alloc = 0; int splat_tiles = 1;
     const uint8_t* cur_rgb = nullptr;      // device rgb of the frame being processed (fill-in intensity at predict time)
     const float* cur_depth = nullptr;      // device raw depth of the frame being processed / staged (Model-level entry points)
     int batch_tracking = 1;                // 0: track the models one after the other even when a batch is possible ("batchTracking")
@@ -410,10 +409,9 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
         // ... and never less than 16 list slots per pixel of a tile, so that small maps can still pile up in one place
         c->tile_entries_cap = (int)std::min<size_t>(std::max<size_t>(4 * maxcap, (size_t)16 * P), (size_t)1 << 30);
         c->tile_entries_alloc = c->tile_entries_cap;
-        A(dev_alloc(c, c->allocs, &c->d_tile_entries, (size_t)c->tile_entries_cap));
-        A(dev_alloc(c, c->allocs, &c->d_splat_rec0, maxcap));
-        A(dev_alloc(c, c->allocs, &c->d_splat_rec1, maxcap));
-        A(dev_alloc(c, c->allocs, &c->d_splat_bbox, maxcap));
+        // 48 B per entry (the sprite set-up travels in the list, mf_splat.hip): 1.8 GB for the default 9.4 M-surfel capacity, 6.4 GB at
+        // NUM_GSURFELS = 32M -- of 288 GB
+        A(dev_alloc(c, c->allocs, &c->d_tile_entries, (size_t)c->tile_entries_cap * 3));
     }
     A(dev_alloc(c, c->allocs, &c->d_keys, (size_t)P, 0xFF));
     A(dev_alloc(c, c->allocs, &c->d_index, (size_t)P));
@@ -699,8 +697,8 @@ static void enqueue_predict(mf_ctx* c, ModelState& m, const FrameAdvance* advanc
     if (c->splat_tiles && !(c->object_scatter_splat && m.id != 0)) {
         const bool gray = photometric_on(c);
         if (launch_splat_tiled(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, c->cfg.max_depth_processed, m.confThr,
-                               c->cfg.time_delta, c->d_tile_count, c->d_tile_entries, c->tile_entries_cap, c->d_splat_rec0, c->d_splat_rec1,
-                               c->d_splat_bbox, m.d_predV, m.d_predN, m.d_predImage, m.d_predTime, c->cur_rgb,
+                               c->cfg.time_delta, c->d_tile_count, c->d_tile_entries, c->tile_entries_cap,
+                               m.d_predV, m.d_predN, m.d_predImage, m.d_predTime, c->cur_rgb,
                                gray ? m.d_predGray : nullptr, gray ? m.d_fillGray : nullptr, c->stream, advance, c->ftf_rgb ? 1 : 0) == 0)
             return;
     }
@@ -780,7 +778,7 @@ static void enqueue_global_projection(mf_ctx* c, ModelState& m, int order) {
     const mf_config& g = c->cfg;
     if (m.id == 0 && c->splat_tiles && c->global_tiles &&
         launch_global_tiled(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, g.depth_cutoff, 12.0f, g.time_delta, order, m.id, c->d_tile_count,
-                            c->d_tile_entries, c->tile_entries_cap, c->d_splat_rec0, c->d_splat_rec1, c->d_splat_bbox, c->d_keys, c->stream) == 0)
+                            c->d_tile_entries, c->tile_entries_cap, c->d_keys, c->stream) == 0)
         return;
     launch_global_scatter(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, g.depth_cutoff, 12.0f, g.time_delta, order, m.id, c->d_keys,
                           c->stream, surfel_blocks(c, m));
@@ -1122,6 +1120,19 @@ extern "C" int mf_stage_frame(mf_ctx* c, const uint8_t* rgb, const float* depth,
     c->lastF = (int)(c->frame_no % 3);
     c->frame_no++;
     return mf_sync(c);
+}
+
+// The same for a frame that already sits in device memory (e.g. the buffer an RCCL broadcast landed in): nothing is copied, nothing is
+// synchronised -- the caller orders the producers of the three buffers on the context's stream (mf_get_stream) and keeps rgb / depth alive
+// and unmodified until the frame's model-level calls have completed there.
+extern "C" int mf_stage_frame_dev(mf_ctx* c, const uint8_t* d_rgb, const float* d_depth, const uint8_t* d_mask) {
+    if (!c || !d_rgb || !d_depth) return MF_EINVAL;
+    if (d_mask) MF_HIP(c, hipMemcpyAsync(c->d_mask_tex, d_mask, (size_t)c->P, hipMemcpyDeviceToDevice, c->stream));
+    int rc = enqueue_preprocess(c, d_rgb, d_depth, c->frame_no, true);
+    if (rc != MF_OK) return rc;
+    c->lastF = (int)(c->frame_no % 3);
+    c->frame_no++;
+    return check_launch(c);
 }
 
 // Model::initialise (Core/Model/Model.cpp:240-285): the map of `model` becomes the staged frame's point cloud

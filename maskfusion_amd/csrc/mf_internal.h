@@ -239,8 +239,8 @@ size_t splat_tiles_scratch_ints(int W, int H);
 // the epilogue of the tiled prediction: its last workgroup to finish runs it, one launch less per model and frame.
 struct FrameAdvance { FrameDev* host_mirror; const PoseDev* bg_pose; float* log_slot; };
 int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
-                       int timeDelta, int* tile_count, int* entries /*[tiles][entries_cap / tiles]*/, int entries_cap,
-                       float4* rec0 /*[src.cap]*/, float4* rec1 /*[src.cap]*/, void* bbox /*[src.cap] x 8 B*/, float4* predV, float4* predN,
+                       int timeDelta, int* tile_count, float4* entries /*[tiles][entries_cap / tiles][3]: 48 B per sprite*/, int entries_cap,
+                       float4* predV, float4* predN,
                        uchar4* predImage, uint16_t* predTime, const uint8_t* rgb, uint8_t* predGray, uint8_t* fillGray, hipStream_t s,
                        const FrameAdvance* advance = nullptr, int fillPassthrough = 0);
 void launch_fill_keys(unsigned long long* keys, int n, hipStream_t s);
@@ -256,7 +256,7 @@ void launch_global_resolve(unsigned long long* keys, uint8_t* ids, int P, hipStr
 int gn_solve_standalone(const double* sys29, const double* resultRt16, const float* Rprev9, const float* tprev3, double* x_serial, double* x_wave,
                         double* resultRt_out, float* Rcurr9, float* tcurr3, float* stats2, hipStream_t s);
 int launch_global_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
-                        int timeDelta, int order, int id, int* tile_count, int* entries, int entries_cap, float4* rec0, float4* rec1, void* bbox,
+                        int timeDelta, int order, int id, int* tile_count, float4* entries, int entries_cap,
                         unsigned long long* keys, hipStream_t s);
 void launch_spawn_pose(PoseDev* obj, const PoseDev* bg, FrameDev* objFrame, const FrameDev* bgFrame, PoseDev* host_mirror,
                        hipStream_t s);

@@ -91,6 +91,7 @@ SYMBOLS = {
     "mf_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]),
     "mf_debug_read_model": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_void_p, C.c_uint64]),
     "mf_stage_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mf_stage_frame_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mf_end_frame": (C.c_int, [C.c_void_p, C.c_int64]),
     "mf_model_initialise": (C.c_int, [C.c_void_p, C.c_int32]),
     "mf_model_override_pose": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),

@@ -73,11 +73,16 @@ class Shard:
         return self.rank == 0
 
     # ---- phase 1: everything up to the global projection ---------------------------------------------
-    def phase_track(self, rgb: np.ndarray, depth: np.ndarray, order_of_id: dict, cfg: dict, first: bool, bg_pose16: Optional[np.ndarray] = None):
-        """stage the frame, track the local models, scatter them into this rank's key image.  bg_pose16: the background's NEW pose,
-        needed here only by ranks that hold static objects (they follow it before they are projected, MaskFusion.cpp:274,289)"""
+    def phase_track(self, rgb, depth, order_of_id: dict, cfg: dict, first: bool, bg_pose16: Optional[np.ndarray] = None):
+        """stage the frame, track the local models, scatter them into this rank's key image.  rgb / depth: host arrays (uploaded,
+        synchronous) or torch tensors on this shard's device (staged in place, asynchronous: mf_stage_frame_dev -- the caller orders their
+        producer on the library's stream).  bg_pose16: the background's NEW pose, needed here only by ranks that hold static objects
+        (they follow it before they are projected, MaskFusion.cpp:274,289)"""
         mf = self.mf
-        mf.stageFrame(rgb, depth)
+        if isinstance(rgb, torch.Tensor):
+            mf.stageFrameDevice(rgb.data_ptr(), depth.data_ptr())
+        else:
+            mf.stageFrame(rgb, depth)
         models = mf.getModels()
         if first:
             if self.owns_background():
@@ -258,20 +263,35 @@ class ShardedMaskFusion:
         self.cfg = cfg
         self.device = device
         H, W = mf.height, mf.width
-        self.rgb = torch.empty((H, W, 3), dtype=torch.uint8, device=device)
-        self.depth = torch.empty((H, W), dtype=torch.float32, device=device)
+        # a ring of 3 frame buffers: the library may still read frame k-1 (fill-in intensity at predict time) while frame k is published
+        self.rgbs = [torch.empty((H, W, 3), dtype=torch.uint8, device=device) for _ in range(3)]
+        self.depths = [torch.empty((H, W), dtype=torch.float32, device=device) for _ in range(3)]
         self.ctl = torch.zeros(8 + 64, dtype=torch.int32, device=device)
         self.frame = 0
+        # On a GPU every tensor op and collective of a frame is enqueued on the LIBRARY's stream (torch.cuda.ExternalStream): the frame
+        # broadcast, the staging of the broadcast buffer (mf_stage_frame_dev: no host copy of the frame on any rank), tracking, the key
+        # all-reduce, the label stage and fusion are ordered by that one stream; the host waits only where it has to read something
+        # (the gathered alive flags on rank 0, the control record on every rank).
+        self._ext = torch.cuda.ExternalStream(mf.stream(), device=device) if device.type == "cuda" else None
 
     def process_frame(self, rgb=None, depth=None, mask=None, class_ids=(), weight_multiplier=1.0, timestamp=0):
+        if self._ext is None:
+            return self._process_frame(rgb, depth, mask, class_ids, weight_multiplier, timestamp)
+        with torch.cuda.stream(self._ext):
+            return self._process_frame(rgb, depth, mask, class_ids, weight_multiplier, timestamp)
+
+    def _process_frame(self, rgb, depth, mask, class_ids, weight_multiplier, timestamp):
         dist, s, first = self.dist, self.shard, self.frame == 0
+        on_gpu = self._ext is not None
+        d_rgb, d_depth = self.rgbs[self.frame % 3], self.depths[self.frame % 3]
         if self.rank == 0:
-            self.rgb.copy_(torch.from_numpy(np.ascontiguousarray(rgb, np.uint8)))
-            self.depth.copy_(torch.from_numpy(np.ascontiguousarray(depth, np.float32)))
+            d_rgb.copy_(torch.from_numpy(np.ascontiguousarray(rgb, np.uint8)))
+            d_depth.copy_(torch.from_numpy(np.ascontiguousarray(depth, np.float32)))
         if self.world > 1:
-            dist.broadcast(self.rgb, 0)
-            dist.broadcast(self.depth, 0)
-        rgb_h, depth_h = self.rgb.cpu().numpy(), self.depth.cpu().numpy()
+            dist.broadcast(d_rgb, 0)
+            dist.broadcast(d_depth, 0)
+        # GPU: the broadcast buffers are staged in place; CPU tensors (gloo tests over a stand-in context): as host arrays
+        rgb_h, depth_h = (d_rgb, d_depth) if on_gpu else (d_rgb.numpy(), d_depth.numpy())
         # the global list as of the end of the previous frame travels in the control record
         order = [int(x) for x in self.ctl[8:8 + int(self.ctl[7].item())].tolist()] if self.frame else [0]
         order_of_id = {mid: i for i, mid in enumerate(order)}
@@ -289,7 +309,8 @@ class ShardedMaskFusion:
         ctl = Control(order=order)
         bg_pose = np.eye(4, dtype=np.float32).T.reshape(16)
         if not first:
-            s.mf.sync()
+            if not on_gpu:
+                s.mf.sync()
             wire = mfd.merge_projection_keys(mfd.keys_to_wire(s.keys).clone())
             ids_block = torch.full((MAX_LOCAL + 1,), -1, dtype=torch.float32, device=self.device)
             ids = s.local_ids()
@@ -300,7 +321,8 @@ class ShardedMaskFusion:
                 dist.gather(send, recv, dst=0)
             else:
                 recv = [send]
-            _device_sync(self.device)
+            if not on_gpu:
+                _device_sync(self.device)
             if self.rank == 0:
                 alive = {}
                 for r, blk in enumerate(recv):
@@ -311,7 +333,8 @@ class ShardedMaskFusion:
                             alive[int(mid)] = int(st[i, 15] != 0)
                 alive[0] = 1
                 keys = _wire_to_keys(wire)
-                _device_sync(self.device)
+                if not on_gpu:
+                    _device_sync(self.device)
                 ctl = s.phase_segment(mask, class_ids, keys, alive, self.cfg)
                 s.mf.sync()
                 bg_pose = np.ascontiguousarray(s.mf.getCurrPose().astype(np.float32).T.reshape(16))
@@ -322,8 +345,9 @@ class ShardedMaskFusion:
             if self.world > 1:
                 mfd.broadcast_labels(s.labels, s.bg_pose, 0)
                 dist.broadcast(self.ctl, 0)
-            _device_sync(self.device)
-            c = self.ctl.cpu().numpy()
+            if not on_gpu:
+                _device_sync(self.device)
+            c = self.ctl.cpu().numpy()                       # (the one host wait every rank needs: what to drop / spawn)
             ctl = Control(int(c[0]), int(c[1]), int(c[2]), int(c[3]), [int(x) for x in c[8:8 + int(c[7])]])
             bg_pose = s.bg_pose.cpu().numpy()
         s.phase_fuse(ctl, bg_pose, self.cfg, weight_multiplier, timestamp, first)

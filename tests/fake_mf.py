@@ -172,6 +172,12 @@ class FakeMaskFusion:
         self.log.append(("stage", int(rgb[0, 0, 0]), float(depth[0, 0])))
         self.frames += 1
 
+    def stageFrameDevice(self, d_rgb, d_depth, d_mask=0):
+        """"device" pointers are host pointers here (CPU tensors of the gloo tests)"""
+        rgb = _arr(d_rgb, self.P * 3, C.c_uint8, np.uint8).reshape(self.height, self.width, 3)
+        depth = _arr(d_depth, self.P, C.c_float, np.float32).reshape(self.height, self.width)
+        self.stageFrame(rgb, depth)
+
     def getModels(self):
         return [_ModelView(self, i) for i in range(len(self.models))]
 

@@ -191,9 +191,12 @@ def test_frame_to_frame_rgb(hip, oracle):
     cap = 1 << 20
     runs = {}
     for ftf in (1, 0):
-        o = oracle.Oracle(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpWeight=10.0, capacity=cap, so3=1)
+        # confidence threshold 1: the prediction covers the image from the third frame on, so that tracking does NOT take the fill-in
+        # branch anyway (with the default 4 the first ~10 frames all do, and the switch has nothing left to change)
+        o = oracle.Oracle(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpWeight=10.0, capacity=cap, so3=1, confGlobal=1.0)
         oracle.lib().mfo_set_frame_to_frame_rgb(o.h, ftf)
-        m = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=10.0, so3=True, numGSurfels=cap, enableMultipleModels=False)
+        m = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=10.0, so3=True, numGSurfels=cap, enableMultipleModels=False,
+                       initConfidenceGlobal=1.0)
         m.setFrameToFrameRGB(bool(ftf))
         assert m.getParam("frameToFrameRGB") == ftf
         poses = []
@@ -203,8 +206,8 @@ def test_frame_to_frame_rgb(hip, oracle):
             gp, op = m.getCurrPose(), o.pose
             d = float(np.abs(gp - op).max())
             ts = m.trackStats(0)
-            print("ftf", ftf, "frame", k, "max |pose diff|", d, "rgb count", ts["lastRGBCount"])
-            assert d < 1e-4, (ftf, k)
+            print("ftf", ftf, "frame", k, "max |pose diff|", d, "rgb count", ts["lastRGBCount"], "fill-in", int(m.getLastFillIn()))
+            assert d < 3e-4, (ftf, k)   # (threshold 1 fuses barely-seen surfels: the photometric term on them is less well conditioned than at the default 4)
             poses.append(gp)
         runs[ftf] = np.array(poses)
         o.close(); m.close()
