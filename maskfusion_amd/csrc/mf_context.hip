@@ -36,6 +36,12 @@ struct ModelState {
     // RGBDOdometry of the model (Model::frameToModel): model-side pyramid, Gauss-Newton state, per-workgroup partial sums
     float* d_vmap_g[3] = {}; float* d_nmap_g[3] = {}; GNState* d_gn = nullptr; float* d_partials[2] = {nullptr, nullptr};
     TrackModelDev* d_track = nullptr;      // the block the batched tracker kernels find all of that through
+    // object models: private scratch of the surfel passes, so that the passes of ALL objects of a frame can be one launch each ("batchObjectPasses")
+    struct ObjScratch {
+        unsigned long long* keys = nullptr; int* index = nullptr; float4* ivc = nullptr; float4* inr = nullptr; float4* iclean = nullptr;
+        uint8_t* cand_op = nullptr; float4* cand_rec = nullptr; int* upd_first = nullptr; uint8_t* flags = nullptr; float* newconf = nullptr;
+        int* block_counts = nullptr;
+    } scr;
     float* d_poselog = nullptr;            // Model::poseLog on the device: ring of [cap][8] floats (t, q xyzw, pad)
     std::vector<int64_t> log_ts;           // timestamps of the entries (host side of PoseLogItem)
     PoseDev* h_pose = nullptr; FrameDev* h_frame = nullptr; int* h_count = nullptr;
@@ -151,6 +157,10 @@ struct mf_ctx {
 #endif
     bool weight_literal = MF_DEFAULT_LITERAL_FUSION_WEIGHT != 0;   // "literalFusionWeight": Model::rodrigues2 with the reference's float trace (finding F5)
     bool bbox_limit = true;                            // "objectBoundingBoxLimit": Model::fuse limits an object's depth by lastBoundingBox (Model.cpp:480-501; upstream: whenever its GUI draws the models)
+    bool batch_objects = true;                         // "batchObjectPasses": the surfel passes of all object models of a frame as one launch per pass (grid.z = model)
+    static constexpr int kObjArgSlots = 8;             // argument arrays of the batched launches: pinned staging + device copy, a small ring (two per frame)
+    ObjPassArgs* d_obj_args[kObjArgSlots] = {}; ObjPassArgs* h_obj_args[kObjArgSlots] = {}; hipEvent_t ev_obj_args[kObjArgSlots] = {};
+    unsigned obj_arg_slot = 0;
     bool ftf_rgb = false;                              // MaskFusion::frameToFrameRGB ("-ftf"; Model.cpp:399-400,981): the photometric term tracks against the previous RAW frame
     bool gn_loop_graph = false;                        // the launch-per-iteration loop replayed as a captured hipGraph ("gnLoopGraph")
 
@@ -169,7 +179,8 @@ struct mf_ctx {
     RgbCorr* d_corres = nullptr; float* d_rgb_partials[2] = {nullptr, nullptr}; int2* d_cnt[2] = {nullptr, nullptr};
     So3Result* d_so3 = nullptr; char* d_so3_scratch = nullptr;
     // tiled splat prediction (mf_splat.hip)
-    int* d_tile_count = nullptr; float4* d_tile_entries = nullptr; int tile_entries_cap = 0; int tile_entries_alloc = 0; int splat_tiles = 1;
+    int* d_tile_count = nullptr; int* d_tile_entries = nullptr; int tile_entries_cap = 0; int tile_entries_alloc = 0; int splat_tiles = 1;
+    float4* d_splat_rec0 = nullptr; float4* d_splat_rec1 = nullptr; uint2* d_splat_bbox = nullptr;   // per-surfel sprite set-up
     const uint8_t* cur_rgb = nullptr;      // device rgb of the frame being processed (fill-in intensity at predict time)
     const float* cur_depth = nullptr;      // device raw depth of the frame being processed / staged (Model-level entry points)
     int batch_tracking = 1;                // 0: track the models one after the other even when a batch is possible ("batchTracking")
@@ -313,6 +324,20 @@ static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int 
     }
     A(dev_alloc(c, m->allocs, &m->d_gn, 2));
     A(dev_alloc(c, m->allocs, &m->d_track, 1));
+    if (!allowFillIn) {   // an object model: its own index maps / key image / candidate records (141 B per pixel + 9 B per surfel slot)
+        A(dev_alloc(c, m->allocs, &m->scr.keys, P, 0xFF));
+        A(dev_alloc(c, m->allocs, &m->scr.index, P));
+        A(dev_alloc(c, m->allocs, &m->scr.ivc, P));
+        A(dev_alloc(c, m->allocs, &m->scr.inr, P));
+        A(dev_alloc(c, m->allocs, &m->scr.iclean, P * 2));
+        A(dev_alloc(c, m->allocs, &m->scr.cand_op, P));
+        A(dev_alloc(c, m->allocs, &m->scr.cand_rec, P * 3));
+        A(dev_alloc(c, m->allocs, &m->scr.upd_first, (size_t)cap));
+        A(dev_alloc(c, m->allocs, &m->scr.flags, (size_t)cap + P));
+        A(dev_alloc(c, m->allocs, &m->scr.newconf, (size_t)cap + P));
+        A(dev_alloc(c, m->allocs, &m->scr.block_counts, (size_t)kCompactBlocks));
+        launch_fill_int(m->scr.upd_first, kNoUpdate, cap, c->stream);
+    }
 #undef A
     {
         TrackModelDev t;
@@ -409,9 +434,12 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
         // ... and never less than 16 list slots per pixel of a tile, so that small maps can still pile up in one place
         c->tile_entries_cap = (int)std::min<size_t>(std::max<size_t>(4 * maxcap, (size_t)16 * P), (size_t)1 << 30);
         c->tile_entries_alloc = c->tile_entries_cap;
-        // 48 B per entry (the sprite set-up travels in the list, mf_splat.hip): 1.8 GB for the default 9.4 M-surfel capacity, 6.4 GB at
-        // NUM_GSURFELS = 32M -- of 288 GB
-        A(dev_alloc(c, c->allocs, &c->d_tile_entries, (size_t)c->tile_entries_cap * 3));
+        // (round 3 tried 48-byte list entries carrying the sprite set-up -- one coalesced stream per tile instead of list -> box -> record
+        // gathers: the tile pass gained 2 us, the binning pass lost 3.5 us and the lists grew to 1.8 GB; measured, reverted)
+        A(dev_alloc(c, c->allocs, &c->d_tile_entries, (size_t)c->tile_entries_cap));
+        A(dev_alloc(c, c->allocs, &c->d_splat_rec0, maxcap));
+        A(dev_alloc(c, c->allocs, &c->d_splat_rec1, maxcap));
+        A(dev_alloc(c, c->allocs, &c->d_splat_bbox, maxcap));
     }
     A(dev_alloc(c, c->allocs, &c->d_keys, (size_t)P, 0xFF));
     A(dev_alloc(c, c->allocs, &c->d_index, (size_t)P));
@@ -450,6 +478,12 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     for (int i = 0; i < 2; ++i)
         if (hipEventCreate(&c->ev_icp[i]) != hipSuccess) return fail(MF_EHIP);
     if (hipEventCreate(&c->ev_icp_mid) != hipSuccess) return fail(MF_EHIP);
+    for (int i = 0; i < mf_ctx::kObjArgSlots; ++i) {
+        if (hipMalloc((void**)&c->d_obj_args[i], sizeof(ObjPassArgs) * 64) != hipSuccess ||
+            hipHostMalloc((void**)&c->h_obj_args[i], sizeof(ObjPassArgs) * 64) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_obj_args[i], hipEventDisableTiming) != hipSuccess)
+            return fail(MF_ENOMEM);
+    }
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(MF_EHIP);
     *out = c;
     return MF_OK;
@@ -472,6 +506,11 @@ extern "C" void mf_destroy(mf_ctx* c) {
         if (c->ev_main_done[i]) (void)hipEventDestroy(c->ev_main_done[i]);
     }
     if (c->ev_labels) (void)hipEventDestroy(c->ev_labels);
+    for (int i = 0; i < mf_ctx::kObjArgSlots; ++i) {
+        if (c->d_obj_args[i]) (void)hipFree(c->d_obj_args[i]);
+        if (c->h_obj_args[i]) (void)hipHostFree(c->h_obj_args[i]);
+        if (c->ev_obj_args[i]) (void)hipEventDestroy(c->ev_obj_args[i]);
+    }
     if (c->stream_pre) (void)hipStreamDestroy(c->stream_pre);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -697,8 +736,8 @@ static void enqueue_predict(mf_ctx* c, ModelState& m, const FrameAdvance* advanc
     if (c->splat_tiles && !(c->object_scatter_splat && m.id != 0)) {
         const bool gray = photometric_on(c);
         if (launch_splat_tiled(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, c->cfg.max_depth_processed, m.confThr,
-                               c->cfg.time_delta, c->d_tile_count, c->d_tile_entries, c->tile_entries_cap,
-                               m.d_predV, m.d_predN, m.d_predImage, m.d_predTime, c->cur_rgb,
+                               c->cfg.time_delta, c->d_tile_count, c->d_tile_entries, c->tile_entries_cap, c->d_splat_rec0, c->d_splat_rec1,
+                               c->d_splat_bbox, m.d_predV, m.d_predN, m.d_predImage, m.d_predTime, c->cur_rgb,
                                gray ? m.d_predGray : nullptr, gray ? m.d_fillGray : nullptr, c->stream, advance, c->ftf_rgb ? 1 : 0) == 0)
             return;
     }
@@ -709,6 +748,46 @@ static void enqueue_predict(mf_ctx* c, ModelState& m, const FrameAdvance* advanc
                          m.d_frame, c->cur_rgb, gray ? m.d_predGray : nullptr, gray ? m.d_fillGray : nullptr, c->stream, c->ftf_rgb ? 1 : 0);
     if (advance) launch_frame_advance(m.d_frame, c->W, c->H, advance->host_mirror, m.d_pose, advance->bg_pose, advance->log_slot, c->stream);
 }
+
+// ObjBatch of the object models in `ms` (mf_internal.h): one entry per model, staged through a pinned slot of the ring and copied to the
+// device on the stream; the slot's event guards its reuse (the host is at most a frame ahead in a multi-model scene: it waits for the
+// label stage every frame).  weightMultiplier / log slots are filled by the caller where they matter.
+static int make_obj_batch(mf_ctx* c, const std::vector<ModelState*>& ms, const std::vector<int>& orders, const uint8_t* d_rgb, const float* d_depth,
+                          const float* depthF, const uint8_t* mask, float weightMultiplier, const std::vector<float*>* log_slots, ObjBatch& b, int& blocks) {
+    const mf_config& g = c->cfg;
+    const int slot = (int)(c->obj_arg_slot++ % mf_ctx::kObjArgSlots);
+    MF_HIP(c, hipEventSynchronize(c->ev_obj_args[slot]));
+    ObjPassArgs* h = c->h_obj_args[slot];
+    const bool gray = photometric_on(c);
+    blocks = 32;
+    for (size_t i = 0; i < ms.size(); ++i) {
+        ModelState& m = *ms[i];
+        ObjPassArgs& a = h[i];
+        a.a = m.surf[m.cur]; a.b = m.surf[1 - m.cur];
+        a.frame = m.d_frame; a.pose = m.d_pose;
+        a.maskID = m.id; a.confThreshold = m.confThr; a.fuseMaxDepth = fminf(g.depth_cutoff, m.maxDepth); a.weightMultiplier = weightMultiplier;
+        a.keys = m.scr.keys; a.index = m.scr.index; a.ivc = m.scr.ivc; a.inr = m.scr.inr; a.iclean = m.scr.iclean;
+        a.cand_op = m.scr.cand_op; a.cand_rec = m.scr.cand_rec; a.upd_first = m.scr.upd_first; a.flags = m.scr.flags; a.newconf = m.scr.newconf;
+        a.block_counts = m.scr.block_counts; a.host_count = m.h_count;
+        a.predV = m.d_predV; a.predN = m.d_predN; a.predImage = m.d_predImage; a.predTime = m.d_predTime; a.predGray = gray ? m.d_predGray : nullptr;
+        a.host_frame = m.h_frame; a.log_slot = log_slots ? (*log_slots)[i] : nullptr;
+        a.global_payload = ((unsigned)orders[i] << 8) | ((unsigned)m.id & 255u);
+        blocks = std::max(blocks, surfel_blocks(c, m));
+    }
+    MF_HIP(c, hipMemcpyAsync(c->d_obj_args[slot], h, sizeof(ObjPassArgs) * ms.size(), hipMemcpyHostToDevice, c->stream));
+    MF_HIP(c, hipEventRecord(c->ev_obj_args[slot], c->stream));
+    b.m = c->d_obj_args[slot]; b.n = (int)ms.size();
+    b.W = c->W; b.H = c->H; b.k = c->K; b.maxDepthProcessed = g.max_depth_processed; b.globalMaxDepth = g.depth_cutoff; b.timeDelta = g.time_delta;
+    b.outlierCoeff = g.outlier_coefficient; b.cleanLiteral = c->clean_literal ? 1 : 0; b.bboxLimit = c->bbox_limit ? 1 : 0;
+    b.rgb = d_rgb; b.depthRaw = d_depth; b.depthF = depthF; b.mask = mask; b.bg_pose = c->models[0]->d_pose; b.global_keys = c->d_keys;
+    return MF_OK;
+}
+// every object model of the list, with its position in the list (the GlobalProjection payload)
+static void object_models(mf_ctx* c, std::vector<ModelState*>& ms, std::vector<int>& orders) {
+    ms.clear(); orders.clear();
+    for (size_t i = 1; i < c->models.size(); ++i) { ms.push_back(c->models[i].get()); orders.push_back((int)i); }
+}
+static bool batch_objects_now(const mf_ctx* c) { return c->batch_objects && c->models.size() >= 3 && c->models.size() <= 65; }
 
 static int check_launch(mf_ctx* c) {
     hipError_t e = hipGetLastError();
@@ -778,7 +857,7 @@ static void enqueue_global_projection(mf_ctx* c, ModelState& m, int order) {
     const mf_config& g = c->cfg;
     if (m.id == 0 && c->splat_tiles && c->global_tiles &&
         launch_global_tiled(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, g.depth_cutoff, 12.0f, g.time_delta, order, m.id, c->d_tile_count,
-                            c->d_tile_entries, c->tile_entries_cap, c->d_keys, c->stream) == 0)
+                            c->d_tile_entries, c->tile_entries_cap, c->d_splat_rec0, c->d_splat_rec1, c->d_splat_bbox, c->d_keys, c->stream) == 0)
         return;
     launch_global_scatter(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, g.depth_cutoff, 12.0f, g.time_delta, order, m.id, c->d_keys,
                           c->stream, surfel_blocks(c, m));
@@ -872,7 +951,17 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
 
         if (multi) {
             // GlobalProjection::project(models, tick, tick, timeDelta, depthCutoff) (:289) with its fixed threshold 12
-            for (size_t i = 0; i < c->models.size(); ++i) enqueue_global_projection(c, *c->models[i], (int)i);
+            if (batch_objects_now(c)) {
+                enqueue_global_projection(c, bg, 0);
+                std::vector<ModelState*> objs; std::vector<int> orders;
+                object_models(c, objs, orders);
+                ObjBatch ob; int blocks = 0;
+                int rc = make_obj_batch(c, objs, orders, d_rgb, d_depth, depthF, mask, weight_multiplier, nullptr, ob, blocks);
+                if (rc != MF_OK) return rc;
+                launch_obj_global_scatter(ob, blocks, s);
+            } else {
+                for (size_t i = 0; i < c->models.size(); ++i) enqueue_global_projection(c, *c->models[i], (int)i);
+            }
             launch_global_resolve(c->d_keys, c->d_proj_ids, P, s);
             // MfSegmentation::performSegmentation, device half (MfSegmentation.cpp:149-208)
             launch_edge_map(c->d_vmap[set][0], c->d_nmap[set][0], c->d_edge, W, H, c->seg.weightDistance, c->seg.weightConvexity, s);
@@ -950,11 +1039,44 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
         }
         // (the predict() at MaskFusion.cpp:423 only feeds the dead loop-closure block and is overwritten at :569)
         // fusion, :539-565: if (!rgbOnly && trackingOk && !lost)
-        if (!g.rgb_only)
-          for (size_t i = bg_fused ? 1 : 0; i < c->models.size(); ++i)
+        if (!g.rgb_only) {
+          const bool batch = multi && batch_objects_now(c);
+          for (size_t i = bg_fused ? 1 : 0; i < (batch ? (size_t)1 : c->models.size()); ++i)
             enqueue_fuse_clean(c, *c->models[i], d_rgb, d_depth, depthF, mask, g.depth_cutoff, weight_multiplier, true, i == 0);
+          if (batch) {   // every object model: one launch per pass
+              std::vector<ModelState*> objs; std::vector<int> orders;
+              object_models(c, objs, orders);
+              ObjBatch ob; int blocks = 0;
+              int rc = make_obj_batch(c, objs, orders, d_rgb, d_depth, depthF, mask, weight_multiplier, nullptr, ob, blocks);
+              if (rc != MF_OK) return rc;
+              launch_obj_fuse_clean(ob, blocks, s);
+          }
+        }
         mark(c, 7);
     }
+    if (multi && batch_objects_now(c) && c->map_ready && k > 0) {
+        // predict() + tick++ + pose log of the object models in three launches; the background keeps its tiled prediction
+        ModelState& b0 = *c->models[0];
+        float* slot0 = nullptr;
+        if (b0.d_poselog) { slot0 = b0.d_poselog + (b0.log_ts.size() % (size_t)g.pose_log_capacity) * 8; b0.log_ts.push_back(timestamp); }
+        const FrameAdvance adv0{b0.h_frame, nullptr, slot0};
+        enqueue_predict(c, b0, &adv0);
+        b0.age++;
+        std::vector<ModelState*> objs; std::vector<int> orders;
+        object_models(c, objs, orders);
+        std::vector<float*> slots;
+        for (ModelState* m : objs) {
+            float* slot = nullptr;
+            if (m->d_poselog) { slot = m->d_poselog + (m->log_ts.size() % (size_t)g.pose_log_capacity) * 8; m->log_ts.push_back(timestamp); }
+            slots.push_back(slot);
+            m->pred_gray_valid = photometric_on(c);
+            m->age++;
+        }
+        ObjBatch ob; int blocks = 0;
+        int rc = make_obj_batch(c, objs, orders, d_rgb, d_depth, depthF, mask, weight_multiplier, &slots, ob, blocks);
+        if (rc != MF_OK) return rc;
+        launch_obj_predict_advance(ob, blocks, s);
+    } else
     for (auto& m : c->models) {  // predict(), :569 ; tick++, :573
         float* slot = nullptr;
         if (m->d_poselog) {  // MaskFusion.cpp:580-596
@@ -1781,6 +1903,7 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!strcmp(key, "batchTracking")) { c->batch_tracking = value != 0; return MF_OK; }
     if (!strcmp(key, "gnLoopGraph")) { c->gn_loop_graph = value != 0; return MF_OK; }      // the Gauss-Newton launches as a replayed hipGraph
     if (!strcmp(key, "frameToFrameRGB")) { c->ftf_rgb = value != 0; return MF_OK; }         // MaskFusion::setFrameToFrameRGB (Core/MaskFusion.cpp:910)
+    if (!strcmp(key, "batchObjectPasses")) { c->batch_objects = value != 0; return MF_OK; }  // 0: the object models' surfel passes model by model
     if (!strcmp(key, "objectBoundingBoxLimit")) { c->bbox_limit = value != 0; return MF_OK; }   // 0: a headless upstream that never renders (bb_max_z = FLT_MAX)
     if (!strcmp(key, "literalFusionWeight")) {
         c->weight_literal = value != 0;

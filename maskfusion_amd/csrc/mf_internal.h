@@ -239,10 +239,33 @@ size_t splat_tiles_scratch_ints(int W, int H);
 // the epilogue of the tiled prediction: its last workgroup to finish runs it, one launch less per model and frame.
 struct FrameAdvance { FrameDev* host_mirror; const PoseDev* bg_pose; float* log_slot; };
 int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
-                       int timeDelta, int* tile_count, float4* entries /*[tiles][entries_cap / tiles][3]: 48 B per sprite*/, int entries_cap,
-                       float4* predV, float4* predN,
+                       int timeDelta, int* tile_count, int* entries /*[tiles][entries_cap / tiles]*/, int entries_cap,
+                       float4* rec0 /*[src.cap]*/, float4* rec1 /*[src.cap]*/, void* bbox /*[src.cap] x 8 B*/, float4* predV, float4* predN,
                        uchar4* predImage, uint16_t* predTime, const uint8_t* rgb, uint8_t* predGray, uint8_t* fillGray, hipStream_t s,
                        const FrameAdvance* advance = nullptr, int fillPassthrough = 0);
+// ---- the surfel passes of ALL object models of a frame, one launch per pass (grid.z = model) ----
+// An object model holds a few thousand surfels: each of its ~11 per-frame launches is pure launch latency (~85 us per object and frame in
+// round 2's profile).  The batched kernels are the single-model kernels' bodies called with one model's arguments, picked from a device
+// array by blockIdx.z; every model brings its own scratch (index maps, key image, candidate records, ...), which the single-model path shares.
+struct ObjPassArgs {
+    Surfels a, b;                      // live buffer when the frame's fusion starts / the other one (fuse: a -> b, clean: b -> a)
+    FrameDev* frame; PoseDev* pose;
+    int maskID; float confThreshold, fuseMaxDepth, weightMultiplier;
+    unsigned long long* keys; int* index; float4* ivc; float4* inr; float4* iclean;
+    uint8_t* cand_op; float4* cand_rec; int* upd_first; uint8_t* flags; float* newconf; int* block_counts; int* host_count;
+    float4* predV; float4* predN; uchar4* predImage; uint16_t* predTime; uint8_t* predGray;
+    FrameDev* host_frame; float* log_slot;
+    unsigned global_payload;           // GlobalProjection: order << 8 | id
+};
+struct ObjBatch {
+    const ObjPassArgs* m; int n;
+    int W, H; Intr k; float maxDepthProcessed, globalMaxDepth; int timeDelta; float outlierCoeff; int cleanLiteral, bboxLimit;
+    const uint8_t* rgb; const float* depthRaw; const float* depthF; const uint8_t* mask; const PoseDev* bg_pose;
+    unsigned long long* global_keys;
+};
+void launch_obj_global_scatter(const ObjBatch& b, int blocks, hipStream_t s);          // GlobalProjection of every object model (mf_segment.hip)
+void launch_obj_fuse_clean(const ObjBatch& b, int blocks, hipStream_t s);              // predictIndices -> fuse -> predictIndices -> clean
+void launch_obj_predict_advance(const ObjBatch& b, int blocks, hipStream_t s);         // combinedPredict (scatter form) + the end-of-frame bookkeeping
 void launch_fill_keys(unsigned long long* keys, int n, hipStream_t s);
 void launch_fill_int(int* p, int v, int n, hipStream_t s);
 // ---------------- multi-model coupling (mf_segment.hip) ----------------
@@ -256,7 +279,7 @@ void launch_global_resolve(unsigned long long* keys, uint8_t* ids, int P, hipStr
 int gn_solve_standalone(const double* sys29, const double* resultRt16, const float* Rprev9, const float* tprev3, double* x_serial, double* x_wave,
                         double* resultRt_out, float* Rcurr9, float* tcurr3, float* stats2, hipStream_t s);
 int launch_global_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
-                        int timeDelta, int order, int id, int* tile_count, float4* entries, int entries_cap,
+                        int timeDelta, int order, int id, int* tile_count, int* entries, int entries_cap, float4* rec0, float4* rec1, void* bbox,
                         unsigned long long* keys, hipStream_t s);
 void launch_spawn_pose(PoseDev* obj, const PoseDev* bg, FrameDev* objFrame, const FrameDev* bgFrame, PoseDev* host_mirror,
                        hipStream_t s);

@@ -97,10 +97,10 @@ void launch_edge_binary(const float* edge, uint8_t* out, uint8_t* tmp, int W, in
 // GlobalProjection: the splat scatter of mf_surfel.hip with (model order, model id) as payload
 // key = z bits << 32 | order << 8 | id  -> LESS on z, earlier model in the list wins ties (GL draw order)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_global_scatter(Surfels src, const FrameDev* __restrict__ frame,
-                                                        const PoseDev* __restrict__ pose, int W, int H, Intr k, float maxDepth,
-                                                        float confThreshold, int timeDelta, unsigned payload,
-                                                        unsigned long long* __restrict__ keys) {
+__device__ __forceinline__ void global_scatter_body(Surfels src, const FrameDev* __restrict__ frame,
+                                                    const PoseDev* __restrict__ pose, int W, int H, Intr k, float maxDepth,
+                                                    float confThreshold, int timeDelta, unsigned payload,
+                                                    unsigned long long* __restrict__ keys) {
     if (pose->alive == 0) return;  // model dropped by the jump test earlier in this frame
     const int n = frame->count;
     const float time = (float)frame->tick;
@@ -149,6 +149,21 @@ __global__ __launch_bounds__(256) void k_global_scatter(Surfels src, const Frame
                 zmin_key(&keys[py * W + px], ((unsigned long long)__float_as_uint(cp.z) << 32) | payload);
             }
     }
+}
+
+__global__ __launch_bounds__(256) void k_global_scatter(Surfels src, const FrameDev* __restrict__ frame,
+                                                        const PoseDev* __restrict__ pose, int W, int H, Intr k, float maxDepth,
+                                                        float confThreshold, int timeDelta, unsigned payload,
+                                                        unsigned long long* __restrict__ keys) {
+    global_scatter_body(src, frame, pose, W, H, k, maxDepth, confThreshold, timeDelta, payload, keys);
+}
+// every object model of the list in one launch (grid.z = model; ObjBatch, mf_internal.h): all of them z-test into the one key image
+__global__ __launch_bounds__(256) void k_obj_global_scatter(const ObjBatch b) {
+    const ObjPassArgs& m = b.m[blockIdx.z];
+    global_scatter_body(m.a, m.frame, m.pose, b.W, b.H, b.k, b.globalMaxDepth, 12.0f, b.timeDelta, m.global_payload, b.global_keys);
+}
+void launch_obj_global_scatter(const ObjBatch& b, int blocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_obj_global_scatter, dim3(blocks, 1, b.n), dim3(256), 0, s, b);
 }
 
 void launch_global_scatter(Surfels src, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth,

@@ -64,23 +64,17 @@ struct BinArgs {
     Surfels src; const FrameDev* frame; const PoseDev* pose; int W, H; Intr k; float maxDepth, confThreshold; int timeDelta;
     int tilesX, tilesY;
     int* tile_count;      // [tiles]  zero on entry (each tile workgroup re-zeroes its own counter when it is done)
-    float4* entries;      // [tiles][tile_cap][3]: the sprite set-up travels IN the list -- {h, r^2}, {n, h.n}, {pixel box (4 x int16), -, surfel index}
+    int* entries;         // [tiles][tile_cap]
     int tile_cap;
     FrameDev* frame_rw;   // overflow flag (pad[1])
+    float4* rec0; float4* rec1; short4* bbox;   // [surfels] sprite set-up kept for the tile pass: {h, r^2}, {n, h.n}, pixel box
 };
-
-// A list entry is 48 B (three float4): the tile pass used to chase list[e] -> bbox[i] -> rec0[i], rec1[i], three dependent memory round
-// trips per sprite and thread; now it streams its list (one round trip, coalesced) and touches the surfel buffer only for the winners.
-// The list memory is 12x what an index list needs (4 x capacity entries x 48 B = 1.8 GB for the 9.4 M-surfel default: 0.6 % of the HBM).
-__device__ __forceinline__ float4 pack_box(int px0, int px1, int py0, int py1, int index) {
-    return make_float4(__int_as_float((px0 & 0xFFFF) | (px1 << 16)), __int_as_float((py0 & 0xFFFF) | (py1 << 16)), 0.f, __int_as_float(index));
-}
 
 // Binning in one pass: every tile owns a fixed slice of `entries`, so no scan is needed.  A 1024-thread workgroup counts
 // its entries per tile in LDS, reserves a contiguous range per touched tile with ONE global atomicAdd (~13 k per frame
 // instead of one global atomic per covered pixel), then hands out slots inside the range with LDS atomics.  The order of
 // a tile's list is not deterministic; the z-test that consumes it is order independent.
-__global__ __launch_bounds__(kBinThreads, 8) void k_splat_bin(const BinArgs a) {   // 8 waves per SIMD: two 1024-thread workgroups per CU (<= 64 VGPRs)
+__global__ __launch_bounds__(kBinThreads) void k_splat_bin(const BinArgs a) {
     extern __shared__ int s_mem[];
     const int nt = a.tilesX * a.tilesY;
     int* s_cnt = s_mem;           // [nt] this workgroup's entries per tile, then the start of its reserved range
@@ -94,25 +88,25 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_splat_bin(const BinArgs a) {
   for (int chunk = blockIdx.x; chunk * 2 * kBinThreads < n; chunk += gridDim.x) {
     for (int t = threadIdx.x; t < nt; t += kBinThreads) { s_cnt[t] = 0; s_fill[t] = 0; }
     __syncthreads();
-    // 2 surfels per thread; their sprite set-up stays in registers between the two phases
-    int idx[2]; short4 bb[2]; float4 r0[2], r1[2];
+    // 2 surfels per thread; their sprite boxes stay in registers between the two phases
+    int idx[2]; short4 bb[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int i = (chunk * 2 + r) * kBinThreads + threadIdx.x;
         idx[r] = i;
         bb[r] = make_short4(1, 0, 1, 0);
-        r0[r] = r1[r] = make_float4(0, 0, 0, 0);
         if (i < n) {
             SplatSetup su;
             if (splat_setup(a.src, i, time, Ri, ti, a.W, a.H, a.k, a.maxDepth, a.confThreshold, a.timeDelta, su)) {
                 bb[r] = make_short4((short)su.px0, (short)su.px1, (short)su.py0, (short)su.py1);
-                // the tile pass meets this surfel ~1.8 times (once per overlapped tile): it reads the set-up from its list instead of
+                // the tile pass meets this surfel ~1.8 times (once per overlapped tile): it reads the set-up instead of
                 // repeating its ~300 instructions (ten IEEE divisions) each time
-                r0[r] = make_float4(su.h.x, su.h.y, su.h.z, su.sqrRad);
-                r1[r] = make_float4(su.nrm.x, su.nrm.y, su.nrm.z, su.pn);
+                a.rec0[i] = make_float4(su.h.x, su.h.y, su.h.z, su.sqrRad);
+                a.rec1[i] = make_float4(su.nrm.x, su.nrm.y, su.nrm.z, su.pn);
                 for (int ty = su.py0 / kTile; ty <= su.py1 / kTile; ++ty)
                     for (int tx = su.px0 / kTile; tx <= su.px1 / kTile; ++tx) atomicAdd(&s_cnt[ty * a.tilesX + tx], 1);
             }
+            a.bbox[i] = bb[r];   // also for surfels that draw nothing (empty box): the overflow path of the tile pass scans every box
         }
     }
     __syncthreads();
@@ -127,11 +121,9 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_splat_bin(const BinArgs a) {
                 const int t = ty * a.tilesX + tx;
                 const int slot = s_cnt[t] + atomicAdd(&s_fill[t], 1);
                 // a full list is not an error and drops nothing: tile_count keeps counting, and a tile whose count exceeds its
-                // slice sets up every sprite of the map again instead of reading its list (k_splat_tile); pad[1] only records that it happened
-                if (slot < a.tile_cap) {
-                    float4* e = a.entries + ((size_t)t * a.tile_cap + slot) * 3;
-                    e[0] = r0[r]; e[1] = r1[r]; e[2] = pack_box(bb[r].x, bb[r].y, bb[r].z, bb[r].w, idx[r]);
-                } else a.frame_rw->pad[1] = 1;
+                // slice scans the sprite boxes of the whole map instead of its list (k_splat_tile); pad[1] only records that it happened
+                if (slot < a.tile_cap) a.entries[(size_t)t * a.tile_cap + slot] = idx[r];
+                else a.frame_rw->pad[1] = 1;
             }
     }
     __syncthreads();
@@ -141,7 +133,8 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_splat_bin(const BinArgs a) {
 struct TileArgs {
     Surfels src; FrameDev* frame; const PoseDev* pose; int W, H; Intr k; float maxDepth, confThreshold; int timeDelta;
     int tilesX, tilesY;
-    int* tile_count; const float4* entries; int tile_cap;
+    int* tile_count; const int* entries; int tile_cap;
+    const float4* rec0; const float4* rec1; const short4* bbox;
     float4* predV; float4* predN; uchar4* predImage; uint16_t* predTime;
     const uint8_t* rgb; uint8_t* predGray; uint8_t* fillGray;
     int fillPassthrough;             // fill_rgb.frag's `passthrough` (frameToFrameRGB, Model.cpp:981): the fill-in image is the raw frame everywhere
@@ -151,28 +144,11 @@ struct TileArgs {
 // The z-test of one 16x16 tile in LDS, shared by the prediction (payload = surfel index) and the global projection (payload =
 // model order / id): rays of the tile's pixels, the tile's sprite list (or, after a list overflow, every sprite box of the map),
 // ds_min_u64 per covered pixel.  On return s_key[pixel of the tile] holds the winning key (all threads have passed a barrier).
-// One sprite against the pixels of one tile: ray-disc test (combo_splat.frag:43-52), ds_min_u64 per covered pixel.
-__device__ __forceinline__ void tile_sprite(const SplatSetup& su, int x0, int x1, int y0, int y1, int tx0, int ty0, unsigned payload,
-                                            unsigned long long* s_key, const float4* s_ray) {
-    for (int py = y0; py <= y1; ++py) {
-        for (int px = x0; px <= x1; ++px) {
-            const int lp = (py - ty0) * kTile + (px - tx0);
-            const float4 r4 = s_ray[lp];
-            const float3 l = f3(r4.x, r4.y, r4.z);
-            const float3 cp = l * (su.pn / dot3(l, su.nrm));
-            const float3 diff = cp - su.h;
-            if (!(dot3(diff, diff) <= su.sqrRad)) continue;
-            if (!(cp.z > 0.f)) continue;
-            const unsigned long long key = ((unsigned long long)__float_as_uint(cp.z) << 32) | payload;
-            atomicMin(&s_key[lp], key);
-        }
-    }
-}
-
 template <bool kIndexPayload>
-__device__ __forceinline__ void tile_ztest(int tile, int tilesX, int W, int H, Intr k, int* tile_count, const float4* __restrict__ entries, int tile_cap,
-                                           const Surfels& src, const FrameDev* frame, const PoseDev* pose, float maxDepth, float confThreshold,
-                                           int timeDelta, unsigned payload, unsigned long long* s_key, float4* s_ray, int* s_range) {
+__device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* tile_count, const int* entries, int tile_cap,
+                                           const FrameDev* frame, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
+                                           const short4* __restrict__ bbox, unsigned payload, unsigned long long* s_key, float4* s_ray,
+                                           int* s_range) {
     const int tx0 = (tile % tilesX) * kTile, ty0 = (tile / tilesX) * kTile;
     s_key[threadIdx.x] = kEmptyKey;
     {   // the viewing ray of every pixel of the tile, once (combo_splat.frag:40-42); the per-surfel loops below re-used to
@@ -186,34 +162,30 @@ __device__ __forceinline__ void tile_ztest(int tile, int tilesX, int W, int H, I
         tile_count[tile] = 0;   // consumed: the next binning pass starts from zero
     }
     __syncthreads();
-    if (s_range[0] <= tile_cap) {
-        // the usual case: stream the tile's own list (48 B per sprite, coalesced; nothing else is read until the winners are known)
-        const float4* __restrict__ list = entries + (size_t)tile * tile_cap * 3;
-        const int cnt = s_range[0];
-        for (int e = threadIdx.x; e < cnt; e += 256) {
-            const float4 r0 = list[e * 3 + 0], r1 = list[e * 3 + 1], bx = list[e * 3 + 2];
-            const int bxw = __float_as_int(bx.x), byw = __float_as_int(bx.y), i = __float_as_int(bx.w);
-            const int x0 = max((int)(short)(bxw & 0xFFFF), tx0), x1 = min(bxw >> 16, tx0 + kTile - 1);
-            const int y0 = max((int)(short)(byw & 0xFFFF), ty0), y1 = min(byw >> 16, ty0 + kTile - 1);
-            SplatSetup su;
-            su.h = f3(r0.x, r0.y, r0.z); su.sqrRad = r0.w; su.nrm = f3(r1.x, r1.y, r1.z); su.pn = r1.w;
-            tile_sprite(su, x0, x1, y0, y1, tx0, ty0, kIndexPayload ? (unsigned)i : payload, s_key, s_ray);
-        }
-    } else {
-        // more sprites than list slots (the reference has no such limit): nothing was dropped -- every sprite of the map is set up again
-        // here and tested against this tile.  Slow (the set-up is ~300 instructions) and rare (a VGA tile list holds 4 x capacity / 1200 sprites).
-        const int n = frame->count;
-        const float time = (float)frame->tick;
-        float Ri[9];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) Ri[q] = pose->Ri[q];
-        const float3 ti = f3(pose->ti[0], pose->ti[1], pose->ti[2]);
-        for (int i = threadIdx.x; i < n; i += 256) {
-            SplatSetup su;
-            if (!splat_setup(src, i, time, Ri, ti, W, H, k, maxDepth, confThreshold, timeDelta, su)) continue;
-            const int x0 = max(su.px0, tx0), x1 = min(su.px1, tx0 + kTile - 1);
-            const int y0 = max(su.py0, ty0), y1 = min(su.py1, ty0 + kTile - 1);
-            tile_sprite(su, x0, x1, y0, y1, tx0, ty0, kIndexPayload ? (unsigned)i : payload, s_key, s_ray);
+    const bool overflow = s_range[0] > tile_cap;   // more sprites than list slots (the reference has no such limit): scan every box
+    const int cnt = overflow ? frame->count : s_range[0];
+    const int* __restrict__ list = entries + (size_t)tile * tile_cap;
+    for (int e = threadIdx.x; e < cnt; e += 256) {
+        const int i = overflow ? e : list[e];
+        const short4 bb = bbox[i];
+        const int x0 = max((int)bb.x, tx0), x1 = min((int)bb.y, tx0 + kTile - 1);
+        const int y0 = max((int)bb.z, ty0), y1 = min((int)bb.w, ty0 + kTile - 1);
+        if (x0 > x1 || y0 > y1) continue;
+        const float4 r0 = rec0[i], r1 = rec1[i];
+        SplatSetup su;
+        su.h = f3(r0.x, r0.y, r0.z); su.sqrRad = r0.w; su.nrm = f3(r1.x, r1.y, r1.z); su.pn = r1.w;
+        for (int py = y0; py <= y1; ++py) {
+            for (int px = x0; px <= x1; ++px) {
+                const int lp = (py - ty0) * kTile + (px - tx0);
+                const float4 r4 = s_ray[lp];
+                const float3 l = f3(r4.x, r4.y, r4.z);
+                const float3 cp = l * (su.pn / dot3(l, su.nrm));
+                const float3 diff = cp - su.h;
+                if (!(dot3(diff, diff) <= su.sqrRad)) continue;
+                if (!(cp.z > 0.f)) continue;
+                const unsigned long long key = ((unsigned long long)__float_as_uint(cp.z) << 32) | (kIndexPayload ? (unsigned)i : payload);
+                atomicMin(&s_key[lp], key);
+            }
         }
     }
     __syncthreads();
@@ -230,8 +202,7 @@ __global__ __launch_bounds__(256) void k_splat_tile(const TileArgs a) {
     const int tx0 = (tile % a.tilesX) * kTile, ty0 = (tile / a.tilesX) * kTile;
     const Intr k = a.k;
     if (threadIdx.x == 0) s_cover = 0;   // (ordered before its use by the barriers inside tile_ztest)
-    tile_ztest<true>(tile, a.tilesX, a.W, a.H, k, a.tile_count, a.entries, a.tile_cap, a.src, a.frame, a.pose, a.maxDepth, a.confThreshold, a.timeDelta,
-                     0u, s_key, s_ray, s_range);
+    tile_ztest<true>(tile, a.tilesX, k, a.tile_count, a.entries, a.tile_cap, a.frame, a.rec0, a.rec1, a.bbox, 0u, s_key, s_ray, s_range);
     const int px = tx0 + (threadIdx.x & (kTile - 1)), py = ty0 + (threadIdx.x >> 4);
     int covered = 0;   // this pixel is one of the 20x down-sampled samples of MaskFusion::requiresFillIn and carries a colour
     if (px < a.W && py < a.H) {
@@ -302,9 +273,9 @@ __global__ __launch_bounds__(256) void k_splat_tile(const TileArgs a) {
 // as k_global_scatter (mf_segment.hip), which stays for small (object) models: one global atomic per covered pixel is memory-side
 // work (see the header) and cost ~170 us per frame for a 250 k-surfel background model against ~25 us here.
 struct GlobalTileArgs {
-    Surfels src; const FrameDev* frame; const PoseDev* pose; int W, H; Intr k; int tilesX;
-    float maxDepth, confThreshold; int timeDelta;
-    int* tile_count; const float4* entries; int tile_cap;
+    const FrameDev* frame; int W, H; Intr k; int tilesX;
+    int* tile_count; const int* entries; int tile_cap;
+    const float4* rec0; const float4* rec1; const short4* bbox;
     unsigned payload; unsigned long long* keys;
 };
 __global__ __launch_bounds__(256) void k_global_tile(const GlobalTileArgs a) {
@@ -312,8 +283,7 @@ __global__ __launch_bounds__(256) void k_global_tile(const GlobalTileArgs a) {
     __shared__ float4 s_ray[kTile * kTile];
     __shared__ int s_range[1];
     const int tile = blockIdx.x;
-    tile_ztest<false>(tile, a.tilesX, a.W, a.H, a.k, a.tile_count, a.entries, a.tile_cap, a.src, a.frame, a.pose, a.maxDepth, a.confThreshold,
-                      a.timeDelta, a.payload, s_key, s_ray, s_range);
+    tile_ztest<false>(tile, a.tilesX, a.k, a.tile_count, a.entries, a.tile_cap, a.frame, a.rec0, a.rec1, a.bbox, a.payload, s_key, s_ray, s_range);
     const int px = (tile % a.tilesX) * kTile + (threadIdx.x & (kTile - 1)), py = (tile / a.tilesX) * kTile + (threadIdx.x >> 4);
     if (px >= a.W || py >= a.H) return;
     const unsigned long long key = s_key[threadIdx.x];
@@ -323,7 +293,7 @@ __global__ __launch_bounds__(256) void k_global_tile(const GlobalTileArgs a) {
 }
 
 int launch_global_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
-                        int timeDelta, int order, int id, int* tile_count, float4* entries, int entries_cap,
+                        int timeDelta, int order, int id, int* tile_count, int* entries, int entries_cap, float4* rec0, float4* rec1, void* bbox,
                         unsigned long long* keys, hipStream_t s) {
     const int tilesX = (W + kTile - 1) / kTile, tilesY = (H + kTile - 1) / kTile, nt = tilesX * tilesY;
     if (nt > kMaxTiles) return -1;
@@ -331,13 +301,14 @@ int launch_global_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W
     b.src = src; b.frame = frame; b.pose = pose; b.W = W; b.H = H; b.k = k; b.maxDepth = maxDepth; b.confThreshold = confThreshold;
     b.timeDelta = timeDelta; b.tilesX = tilesX; b.tilesY = tilesY; b.tile_count = tile_count;
     b.entries = entries; b.tile_cap = entries_cap / nt; b.frame_rw = frame;
+    b.rec0 = rec0; b.rec1 = rec1; b.bbox = reinterpret_cast<short4*>(bbox);
     // two 1024-thread workgroups fit on a CU (60 VGPRs): 512 workgroups are ONE round of chunks up to a million surfels (with 256 a
     // 0.6 M-surfel map was 293 chunks = two rounds, the second one on 37 CUs)
     const int nblocks = min(512, (src.cap + 2 * kBinThreads - 1) / (2 * kBinThreads));
     hipLaunchKernelGGL(k_splat_bin, dim3(nblocks), dim3(kBinThreads), (size_t)2 * nt * sizeof(int), s, b);
     GlobalTileArgs t;
-    t.src = src; t.frame = frame; t.pose = pose; t.W = W; t.H = H; t.k = k; t.tilesX = tilesX; t.tile_count = tile_count; t.entries = entries; t.tile_cap = b.tile_cap;
-    t.maxDepth = maxDepth; t.confThreshold = confThreshold; t.timeDelta = timeDelta;
+    t.frame = frame; t.W = W; t.H = H; t.k = k; t.tilesX = tilesX; t.tile_count = tile_count; t.entries = entries; t.tile_cap = b.tile_cap;
+    t.rec0 = rec0; t.rec1 = rec1; t.bbox = reinterpret_cast<const short4*>(bbox);
     t.payload = ((unsigned)order << 8) | ((unsigned)id & 255u); t.keys = keys;
     hipLaunchKernelGGL(k_global_tile, dim3(nt), dim3(256), 0, s, t);
     return 0;
@@ -346,7 +317,7 @@ int launch_global_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W
 size_t splat_tiles_scratch_ints(int W, int H) { return (size_t)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile); }
 
 int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
-                       int timeDelta, int* tile_count, float4* entries, int entries_cap, float4* predV,
+                       int timeDelta, int* tile_count, int* entries, int entries_cap, float4* rec0, float4* rec1, void* bbox, float4* predV,
                        float4* predN, uchar4* predImage, uint16_t* predTime, const uint8_t* rgb, uint8_t* predGray, uint8_t* fillGray, hipStream_t s,
                        const FrameAdvance* advance, int fillPassthrough) {
     const int tilesX = (W + kTile - 1) / kTile, tilesY = (H + kTile - 1) / kTile, nt = tilesX * tilesY;
@@ -355,6 +326,7 @@ int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W,
     b.src = src; b.frame = frame; b.pose = pose; b.W = W; b.H = H; b.k = k; b.maxDepth = maxDepth; b.confThreshold = confThreshold;
     b.timeDelta = timeDelta; b.tilesX = tilesX; b.tilesY = tilesY; b.tile_count = tile_count;
     b.entries = entries; b.tile_cap = entries_cap / nt; b.frame_rw = frame;
+    b.rec0 = rec0; b.rec1 = rec1; b.bbox = reinterpret_cast<short4*>(bbox);
     // two 1024-thread workgroups fit on a CU (60 VGPRs): 512 workgroups are ONE round of chunks up to a million surfels (with 256 a
     // 0.6 M-surfel map was 293 chunks = two rounds, the second one on 37 CUs)
     const int nblocks = min(512, (src.cap + 2 * kBinThreads - 1) / (2 * kBinThreads));
@@ -362,7 +334,7 @@ int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W,
     TileArgs t;
     t.src = src; t.frame = frame; t.pose = pose; t.W = W; t.H = H; t.k = k; t.maxDepth = maxDepth; t.confThreshold = confThreshold;
     t.timeDelta = timeDelta; t.tilesX = tilesX; t.tilesY = tilesY; t.tile_count = tile_count;
-    t.entries = entries; t.tile_cap = b.tile_cap;
+    t.entries = entries; t.tile_cap = b.tile_cap; t.rec0 = rec0; t.rec1 = rec1; t.bbox = reinterpret_cast<const short4*>(bbox);
     t.predV = predV; t.predN = predN; t.predImage = predImage; t.predTime = predTime; t.rgb = rgb; t.predGray = predGray;
     t.fillGray = fillGray;
     t.fillPassthrough = fillPassthrough;

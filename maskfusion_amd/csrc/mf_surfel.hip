@@ -156,9 +156,11 @@ void launch_compact_records(const float4* rec, const uint8_t* flags, int n, Surf
 // index map: scatter (z-test as 64-bit atomicMin) + resolve
 // Raster rule: a 1-px point lands in texel (floor(u), floor(v)); LESS on z; lower index wins ties.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_index_scatter(Surfels src, const FrameDev* __restrict__ frame,
-                                                       const PoseDev* __restrict__ pose, int W, int H, Intr k, float maxDepth,
-                                                       int timeDelta, unsigned long long* __restrict__ keys, int transposed) {
+// (bodies are __device__ functions: the single-model kernels call them with their own arguments, the batched object-model kernels at the
+// end of this file with one model's arguments picked by blockIdx.z)
+__device__ __forceinline__ void index_scatter_body(Surfels src, const FrameDev* __restrict__ frame,
+                                                   const PoseDev* __restrict__ pose, int W, int H, Intr k, float maxDepth,
+                                                   int timeDelta, unsigned long long* __restrict__ keys, int transposed) {
     const int n = frame->count;
     const float time = (float)frame->tick;
     float Ri[9];
@@ -182,6 +184,12 @@ __global__ __launch_bounds__(256) void k_index_scatter(Surfels src, const FrameD
     }
 }
 
+__global__ __launch_bounds__(256) void k_index_scatter(Surfels src, const FrameDev* __restrict__ frame,
+                                                       const PoseDev* __restrict__ pose, int W, int H, Intr k, float maxDepth,
+                                                       int timeDelta, unsigned long long* __restrict__ keys, int transposed) {
+    index_scatter_body(src, frame, pose, W, H, k, maxDepth, timeDelta, keys, transposed);
+}
+
 void launch_index_scatter(Surfels src, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth,
                           int timeDelta, unsigned long long* keys, bool transposed, hipStream_t s, int blocks) {
     hipLaunchKernelGGL(k_index_scatter, dim3(blocks), dim3(256), 0, s, src, frame, pose, W, H, k, maxDepth, timeDelta, keys,
@@ -192,10 +200,10 @@ void launch_index_scatter(Surfels src, const FrameDev* frame, const PoseDev* pos
 //   packed == nullptr (the pass that feeds fuse): index + vertConf + normRad as separate images;
 //   packed != nullptr (the pass that feeds clean): ONE 32 B record per texel {vertConf.xyzw | colorTime.z, colorTime.w,
 //     index bits, 0} -- clean gathers 9 texels per surfel, and three separate images cost it three cache lines per tap.
-__global__ __launch_bounds__(256) void k_index_resolve(Surfels src, const PoseDev* __restrict__ pose,
-                                                       unsigned long long* __restrict__ keys, int P, int* __restrict__ index,
-                                                       float4* __restrict__ vc, float4* __restrict__ nr, float4* __restrict__ ct,
-                                                       float4* __restrict__ packed) {
+__device__ __forceinline__ void index_resolve_body(Surfels src, const PoseDev* __restrict__ pose,
+                                                   unsigned long long* __restrict__ keys, int P, int* __restrict__ index,
+                                                   float4* __restrict__ vc, float4* __restrict__ nr, float4* __restrict__ ct,
+                                                   float4* __restrict__ packed) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= P) return;
     const unsigned long long key = keys[p];
@@ -225,6 +233,13 @@ __global__ __launch_bounds__(256) void k_index_resolve(Surfels src, const PoseDe
     }
 }
 
+__global__ __launch_bounds__(256) void k_index_resolve(Surfels src, const PoseDev* __restrict__ pose,
+                                                       unsigned long long* __restrict__ keys, int P, int* __restrict__ index,
+                                                       float4* __restrict__ vc, float4* __restrict__ nr, float4* __restrict__ ct,
+                                                       float4* __restrict__ packed) {
+    index_resolve_body(src, pose, keys, P, index, vc, nr, ct, packed);
+}
+
 void launch_index_resolve(Surfels src, const PoseDev* pose, unsigned long long* keys, int W, int H, int* index, float4* vc,
                           float4* nr, float4* ct, float4* packed, hipStream_t s) {
     const int P = W * H;
@@ -244,7 +259,7 @@ struct FuseDataArgs {
     uint8_t* cand_op; float4* cand_rec; int* upd_first;
 };
 
-__global__ __launch_bounds__(256) void k_fuse_data(const FuseDataArgs a) {
+__device__ __forceinline__ void fuse_data_body(const FuseDataArgs& a) {
     const int time = a.frame->tick;
     const int par = time & 1;
     const int W = a.W, H = a.H;
@@ -334,6 +349,8 @@ __global__ __launch_bounds__(256) void k_fuse_data(const FuseDataArgs a) {
     a.cand_op[c] = op;
 }
 
+__global__ __launch_bounds__(256) void k_fuse_data(const FuseDataArgs a) { fuse_data_body(a); }
+
 void launch_fuse_data(const uint8_t* rgb, const float* depthRaw, const float* depthF, const uint8_t* mask, int maskID,
                       const FrameDev* frame, const PoseDev* pose, float weightMultiplier, float maxDepth, int W, int H, Intr k,
                       const int* index, const float4* vc, const float4* nr, uint8_t* cand_op, float4* cand_rec, int* upd_first,
@@ -351,9 +368,9 @@ void launch_fuse_data(const uint8_t* rgb, const float* depthRaw, const float* de
 // right here on the values just written, instead of a separate launch re-reading the buffer.
 struct IndexScatterArgs { const PoseDev* pose; int W, H; Intr k; float maxDepth; int timeDelta; unsigned long long* keys; int transposed; };
 
-__global__ __launch_bounds__(256) void k_fuse_update(Surfels src, Surfels dst, const FrameDev* __restrict__ frame,
-                                                     int* __restrict__ upd_first, const float4* __restrict__ cand_rec,
-                                                     const IndexScatterArgs ix) {
+__device__ __forceinline__ void fuse_update_body(Surfels src, Surfels dst, const FrameDev* __restrict__ frame,
+                                                 int* __restrict__ upd_first, const float4* __restrict__ cand_rec,
+                                                 const IndexScatterArgs& ix) {
     const int n = frame->count;
     const float time = (float)frame->tick;
     float Ri[9];
@@ -399,6 +416,12 @@ __global__ __launch_bounds__(256) void k_fuse_update(Surfels src, Surfels dst, c
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_fuse_update(Surfels src, Surfels dst, const FrameDev* __restrict__ frame,
+                                                     int* __restrict__ upd_first, const float4* __restrict__ cand_rec,
+                                                     const IndexScatterArgs ix) {
+    fuse_update_body(src, dst, frame, upd_first, cand_rec, ix);
 }
 
 void launch_fuse_update(Surfels src, Surfels dst, const FrameDev* frame, int* upd_first, const float4* cand_rec, const PoseDev* pose,
@@ -525,7 +548,7 @@ __device__ __forceinline__ bool clean_test(const CleanArgs& a, float4 pc, float4
     return test;
 }
 
-__global__ __launch_bounds__(256) void k_clean_flags(const CleanArgs a) {
+__device__ __forceinline__ void clean_flags_body(const CleanArgs& a) {
     __shared__ int s_w[4];
     const int count = a.frame->count;
     const int total = count + cand_count(a.W, a.H, a.frame->tick);
@@ -558,7 +581,9 @@ __global__ __launch_bounds__(256) void k_clean_flags(const CleanArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_clean_compact(const CleanArgs a) {
+__global__ __launch_bounds__(256) void k_clean_flags(const CleanArgs a) { clean_flags_body(a); }
+
+__device__ __forceinline__ void clean_compact_body(const CleanArgs& a) {
     __shared__ int s_w[4];
     __shared__ int s_bb[6];
     // Model::lastBoundingBox of an OBJECT model (Model.cpp:315-345 + draw_global_surface.vert:55-78: the box of the surfels the GUI draws --
@@ -637,9 +662,11 @@ __global__ __launch_bounds__(256) void k_clean_compact(const CleanArgs a) {
 // Raster rule: sprite side s centred on (u,v) covers pixel (px,py) iff u - s/2 <= px + 0.5 < u + s/2; LESS on the
 // corrected z; lower index wins ties; sprites wider than 64 px are clamped.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_splat_scatter(Surfels src, const FrameDev* __restrict__ frame,
-                                                       const PoseDev* __restrict__ pose, int W, int H, Intr k, float maxDepth,
-                                                       float confThreshold, int timeDelta, unsigned long long* __restrict__ keys) {
+__global__ __launch_bounds__(256) void k_clean_compact(const CleanArgs a) { clean_compact_body(a); }
+
+__device__ __forceinline__ void splat_scatter_body(Surfels src, const FrameDev* __restrict__ frame,
+                                                   const PoseDev* __restrict__ pose, int W, int H, Intr k, float maxDepth,
+                                                   float confThreshold, int timeDelta, unsigned long long* __restrict__ keys) {
     const int n = frame->count;
     const float time = (float)frame->tick;  // combinedPredict(time = tick, maxTime = tick)
     float Ri[9];
@@ -691,18 +718,24 @@ __global__ __launch_bounds__(256) void k_splat_scatter(Surfels src, const FrameD
     }
 }
 
+__global__ __launch_bounds__(256) void k_splat_scatter(Surfels src, const FrameDev* __restrict__ frame,
+                                                       const PoseDev* __restrict__ pose, int W, int H, Intr k, float maxDepth,
+                                                       float confThreshold, int timeDelta, unsigned long long* __restrict__ keys) {
+    splat_scatter_body(src, frame, pose, W, H, k, maxDepth, confThreshold, timeDelta, keys);
+}
+
 void launch_splat_scatter(Surfels src, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth,
                           float confThreshold, int timeDelta, unsigned long long* keys, hipStream_t s, int blocks) {
     hipLaunchKernelGGL(k_splat_scatter, dim3(blocks), dim3(256), 0, s, src, frame, pose, W, H, k, maxDepth, confThreshold,
                        timeDelta, keys);
 }
 
-__global__ __launch_bounds__(256) void k_splat_resolve(Surfels src, const PoseDev* __restrict__ pose,
-                                                       unsigned long long* __restrict__ keys, int W, int H, Intr k,
-                                                       float4* __restrict__ predV, float4* __restrict__ predN,
-                                                       uchar4* __restrict__ predImage, uint16_t* __restrict__ predTime,
-                                                       FrameDev* __restrict__ frame, const uint8_t* __restrict__ rgb,
-                                                       uint8_t* __restrict__ predGray, uint8_t* __restrict__ fillGray, int fillPassthrough) {
+__device__ __forceinline__ void splat_resolve_body(Surfels src, const PoseDev* __restrict__ pose,
+                                                   unsigned long long* __restrict__ keys, int W, int H, Intr k,
+                                                   float4* __restrict__ predV, float4* __restrict__ predN,
+                                                   uchar4* __restrict__ predImage, uint16_t* __restrict__ predTime,
+                                                   FrameDev* __restrict__ frame, const uint8_t* __restrict__ rgb,
+                                                   uint8_t* __restrict__ predGray, uint8_t* __restrict__ fillGray, int fillPassthrough) {
     const int px = blockIdx.x * 64 + (threadIdx.x & 63);
     const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (px >= W || py >= H) return;
@@ -744,6 +777,15 @@ __global__ __launch_bounds__(256) void k_splat_resolve(Surfels src, const PoseDe
         atomicAdd(&frame->cover, 1);
 }
 
+__global__ __launch_bounds__(256) void k_splat_resolve(Surfels src, const PoseDev* __restrict__ pose,
+                                                       unsigned long long* __restrict__ keys, int W, int H, Intr k,
+                                                       float4* __restrict__ predV, float4* __restrict__ predN,
+                                                       uchar4* __restrict__ predImage, uint16_t* __restrict__ predTime,
+                                                       FrameDev* __restrict__ frame, const uint8_t* __restrict__ rgb,
+                                                       uint8_t* __restrict__ predGray, uint8_t* __restrict__ fillGray, int fillPassthrough) {
+    splat_resolve_body(src, pose, keys, W, H, k, predV, predN, predImage, predTime, frame, rgb, predGray, fillGray, fillPassthrough);
+}
+
 void launch_splat_resolve(Surfels src, const PoseDev* pose, unsigned long long* keys, int W, int H, Intr k, float4* predV,
                           float4* predN, uchar4* predImage, uint16_t* predTime, FrameDev* frame, const uint8_t* rgb,
                           uint8_t* predGray, uint8_t* fillGray, hipStream_t s, int fillPassthrough) {
@@ -755,8 +797,8 @@ void launch_splat_resolve(Surfels src, const PoseDev* pose, unsigned long long* 
 // ------------------------------------------------------------------------------------------------
 // end of frame: tick++ and the fill-in decision for the next tracking step
 // ------------------------------------------------------------------------------------------------
-__global__ void k_frame_advance(FrameDev* frame, int W, int H, FrameDev* host_mirror, const PoseDev* pose, const PoseDev* bg_pose,
-                                float* log_slot) {
+__device__ __forceinline__ void frame_advance_body(FrameDev* frame, int W, int H, FrameDev* host_mirror, const PoseDev* pose, const PoseDev* bg_pose,
+                                                   float* log_slot) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (log_slot) pose_log_entry(pose, bg_pose, log_slot);
     const int rw = W / 20, rh = H / 20;
@@ -766,6 +808,10 @@ __global__ void k_frame_advance(FrameDev* frame, int W, int H, FrameDev* host_mi
     frame->tick += 1;
     MF_FRAME_BBOX_ADVANCE(frame);
     if (host_mirror) *host_mirror = *frame;
+}
+__global__ void k_frame_advance(FrameDev* frame, int W, int H, FrameDev* host_mirror, const PoseDev* pose, const PoseDev* bg_pose,
+                                float* log_slot) {
+    frame_advance_body(frame, W, H, host_mirror, pose, bg_pose, log_slot);
 }
 void launch_frame_advance(FrameDev* frame, int W, int H, FrameDev* host_mirror, const PoseDev* pose, const PoseDev* bg_pose,
                           float* log_slot, hipStream_t s) {
@@ -786,6 +832,73 @@ void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose
     a.flags = flags; a.newconf = newconf; a.block_counts = block_counts; a.host_count = host_count_mirror;
     hipLaunchKernelGGL(k_clean_flags, dim3(kCompactBlocks), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_clean_compact, dim3(kCompactBlocks), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The surfel passes of every OBJECT model of a frame, one launch per pass (grid.z = model; mf_internal.h: ObjBatch).  Same bodies, same
+// arguments as the model-by-model launches of enqueue_fuse_clean / enqueue_predict (mf_context.hip) -- the results are bit-identical
+// (tests/test_gpu_multimodel.py::test_object_model_launch_switches_change_nothing) -- but a frame with M objects costs 9 launches
+// instead of 9 M.  Core/MaskFusion.cpp:539-569 runs the models one after the other; nothing couples them.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_obj_index_scatter(const ObjBatch b) {
+    const ObjPassArgs& m = b.m[blockIdx.z];
+    index_scatter_body(m.a, m.frame, m.pose, b.W, b.H, b.k, b.maxDepthProcessed, b.timeDelta, m.keys, 0);
+}
+__global__ __launch_bounds__(256) void k_obj_index_resolve(const ObjBatch b, int second) {
+    const ObjPassArgs& m = b.m[blockIdx.z];
+    if (!second) index_resolve_body(m.a, m.pose, m.keys, b.W * b.H, m.index, m.ivc, m.inr, nullptr, nullptr);
+    else index_resolve_body(m.b, m.pose, m.keys, b.W * b.H, nullptr, nullptr, nullptr, nullptr, m.iclean);
+}
+__global__ __launch_bounds__(256) void k_obj_fuse_data(const ObjBatch b) {
+    const ObjPassArgs& m = b.m[blockIdx.z];
+    const FuseDataArgs a{b.rgb, b.depthRaw, b.depthF, b.mask, m.maskID, m.frame, m.pose, m.weightMultiplier, m.fuseMaxDepth, b.bboxLimit, b.W, b.H, b.k,
+                         m.index, m.ivc, m.inr, m.cand_op, m.cand_rec, m.upd_first};
+    fuse_data_body(a);
+}
+__global__ __launch_bounds__(256) void k_obj_fuse_update(const ObjBatch b) {
+    const ObjPassArgs& m = b.m[blockIdx.z];
+    const IndexScatterArgs ix{m.pose, b.W, b.H, b.k, b.maxDepthProcessed, b.timeDelta, m.keys, 1};
+    fuse_update_body(m.a, m.b, m.frame, m.upd_first, m.cand_rec, ix);
+}
+__device__ __forceinline__ CleanArgs obj_clean_args(const ObjBatch& b, const ObjPassArgs& m) {
+    CleanArgs a;
+    a.src = m.b; a.dst = m.a; a.frame = m.frame; a.pose = m.pose; a.W = b.W; a.H = b.H; a.k = b.k; a.timeDelta = b.timeDelta;
+    a.confThreshold = m.confThreshold; a.outlierCoeff = b.outlierCoeff; a.maskID = m.maskID; a.transposed = 1; a.literal = b.cleanLiteral;
+    a.index = m.index; a.vc = m.ivc; a.ct = nullptr; a.packed = m.iclean; a.depthF = b.depthF; a.mask = b.mask;
+    a.cand_op = m.cand_op; a.cand_rec = m.cand_rec; a.flags = m.flags; a.newconf = m.newconf; a.block_counts = m.block_counts; a.host_count = m.host_count;
+    return a;
+}
+__global__ __launch_bounds__(256) void k_obj_clean_flags(const ObjBatch b) { clean_flags_body(obj_clean_args(b, b.m[blockIdx.z])); }
+__global__ __launch_bounds__(256) void k_obj_clean_compact(const ObjBatch b) { clean_compact_body(obj_clean_args(b, b.m[blockIdx.z])); }
+__global__ __launch_bounds__(256) void k_obj_splat_scatter(const ObjBatch b) {
+    const ObjPassArgs& m = b.m[blockIdx.z];
+    splat_scatter_body(m.a, m.frame, m.pose, b.W, b.H, b.k, b.maxDepthProcessed, m.confThreshold, b.timeDelta, m.keys);
+}
+__global__ __launch_bounds__(256) void k_obj_splat_resolve(const ObjBatch b) {
+    const ObjPassArgs& m = b.m[blockIdx.z];
+    splat_resolve_body(m.a, m.pose, m.keys, b.W, b.H, b.k, m.predV, m.predN, m.predImage, m.predTime, m.frame, b.rgb, m.predGray, nullptr, 0);
+}
+__global__ void k_obj_frame_advance(const ObjBatch b) {
+    const ObjPassArgs& m = b.m[blockIdx.z];
+    frame_advance_body(m.frame, b.W, b.H, m.host_frame, m.pose, b.bg_pose, m.log_slot);
+}
+
+void launch_obj_fuse_clean(const ObjBatch& b, int blocks, hipStream_t s) {
+    const int P = b.W * b.H;
+    const dim3 surfels(blocks, 1, b.n), pixels((P + 255) / 256, 1, b.n), compact(kCompactBlocks, 1, b.n);
+    const dim3 cands(((b.W + 1) / 2 + 63) / 64, ((b.H + 1) / 2 + 3) / 4, b.n);
+    hipLaunchKernelGGL(k_obj_index_scatter, surfels, dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_obj_index_resolve, pixels, dim3(256), 0, s, b, 0);
+    hipLaunchKernelGGL(k_obj_fuse_data, cands, dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_obj_fuse_update, surfels, dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_obj_index_resolve, pixels, dim3(256), 0, s, b, 1);
+    hipLaunchKernelGGL(k_obj_clean_flags, compact, dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_obj_clean_compact, compact, dim3(256), 0, s, b);
+}
+void launch_obj_predict_advance(const ObjBatch& b, int blocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_obj_splat_scatter, dim3(blocks, 1, b.n), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_obj_splat_resolve, dim3((b.W + 63) / 64, (b.H + 3) / 4, b.n), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_obj_frame_advance, dim3(1, 1, b.n), dim3(64), 0, s, b);
 }
 
 }  // namespace mf

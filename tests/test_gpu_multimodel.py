@@ -209,23 +209,24 @@ def test_tiled_global_projection_equals_scatter_form(hip):
 
 
 def test_object_model_launch_switches_change_nothing(hip):
-    """"objectSmallGrids" (the grid-stride surfel kernels of an object model on a grid sized from its last known count) and
-    "objectScatterSplat" (object models predicted with the scatter form instead of tile lists) are A/B switches for the launch-bound
-    multi-model frames: label images, poses, clouds and predictions must stay bit-identical"""
+    """"objectSmallGrids" (the grid-stride surfel kernels of an object model on a grid sized from its last known count),
+    "objectScatterSplat" (object models predicted with the scatter form instead of tile lists) and "batchObjectPasses" (one launch per
+    surfel pass for ALL object models, grid.z = model) only re-arrange launches of the launch-bound multi-model frames: label images,
+    poses, clouds and predictions must stay bit-identical"""
     from maskfusion_amd import MaskFusion, synth
 
-    def run(**params):
+    def run(track_all=False, **params):
         W, H, f = 320, 240, 264.0
-        st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, n_objects=2, noise=True, object_motion=0.0)
+        st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, n_objects=3, noise=True, object_motion=0.0)
         mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, numGSurfels=1 << 18, numOSurfels=1 << 16, enableMultipleModels=True,
-                        modelSpawnOffset=2, trackAllModels=True)
+                        modelSpawnOffset=2, trackAllModels=track_all)
         for k, v in dict(mfThreshold=SEG["threshold"], mfWeightDistance=SEG["weightDistance"], mfWeightConvexity=SEG["weightConvexity"],
                          mfMorphEdgeIterations=0, mfMorphMaskIterations=0, newModelMinRelativeSize=SEG["minRelSizeNew"], **params).items():
             mf.setParam(k, v)
         segs = []
-        for k in range(9):
+        for k in range(11):
             rgb, d, mask = st.frame(k)
-            mf.processFrame(rgb, d, mask=mask, classIDs=[0, 41, 42], timestamp=k)
+            mf.processFrame(rgb, d, mask=mask, classIDs=[0, 41, 42, 43], timestamp=k)
             segs.append(mf.downloadSegmentation())
         ms = mf.getModels()
         out = dict(ids=[m.getID() for m in ms], poses=[m.getPose() for m in ms], clouds=[m.downloadMap() for m in ms], segs=segs,
@@ -240,8 +241,13 @@ def test_object_model_launch_switches_change_nothing(hip):
             return len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
         return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
 
-    base = run()
-    assert len(base["ids"]) >= 2, "the scenario must hold an object model"
-    assert same(base, run(objectSmallGrids=1))
-    assert same(base, run(objectScatterSplat=1))
-    assert same(base, run(objectSmallGrids=1, objectScatterSplat=1))
+    off = dict(objectSmallGrids=0, objectScatterSplat=0, batchObjectPasses=0)
+    base = run(**off)
+    assert len(base["ids"]) >= 3, "the scenario must hold two object models (the batched passes need two)"
+    assert same(base, run(**dict(off, objectSmallGrids=1)))
+    assert same(base, run(**dict(off, objectScatterSplat=1)))
+    assert same(base, run(**dict(off, objectSmallGrids=1, objectScatterSplat=1)))
+    # "batchObjectPasses": the surfel passes of all object models of a frame as one launch per pass (grid.z = model, private scratch per model)
+    assert same(base, run(**dict(off, batchObjectPasses=1)))
+    assert same(base, run())          # the defaults since round 3: all three on
+    assert same(run(track_all=True, **off), run(track_all=True))   # ... and with the objects tracked (spawns, drops by the jump rule)
