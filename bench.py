@@ -158,6 +158,31 @@ def cpu_baseline(cfg, frames, max_seconds=25.0):
                       f"(sweep, 10 frames each, frames/s by thread count: {sweep})"}
 
 
+def measured_copy_ceiling(dev, mib=1024, reps=10):
+    """HBM bandwidth this box actually delivers to a plain streaming kernel: a device-to-device copy of `mib` MiB (torch's copy kernel),
+    bytes read + bytes written over the HIP-event time of `reps` copies after two warm-up copies."""
+    try:
+        import torch
+        n = mib * (1 << 20) // 4
+        a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+        b = torch.empty_like(a)
+        for _ in range(2):
+            b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(reps):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / reps
+        del a, b
+        return {"GB/s": 2.0 * n * 4 / (ms * 1e-3) / 1e9, "what": f"device-to-device copy of {mib} MiB (read + write bytes), {reps} repetitions"}
+    except Exception as e:   # a measurement aid: never the reason a bench line is missing
+        print(f"[bench] copy ceiling not measured: {e}", file=sys.stderr)
+        return None
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/r*_pmc.json: separate rocprofv3 --pmc passes,
     gfx950 corrections applied when the file was written; see profiles/README.md).  None when there is no such record."""
@@ -493,12 +518,15 @@ def main():
                                  "launches_per_frame": n_coarse, "us": us_c,
                                  "bytes": b_coarse, "frac": b_coarse / (us_c * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                  "note": "5 launches at level 1 (12 P bytes each) + 4 at level 2 (3 P): the average launch"}}
+        ceiling = measured_copy_ceiling(dev)
         roofline = {"bound": "hbm", "kernel": f"{kname} (19 iterations/frame, L2:4 L1:5 L0:10; {n_tracked} model(s) per launch)" if batched
                     else f"{kname} (19 launches per model and frame, L2:4 L1:5 L0:10)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "algorithmic_bytes_per_launch": icp_bytes / n_launch, "us_per_launch": t_icp * 1e6,
                     # the committed PMC profile was taken on configs[1] (VGA, one model): it says nothing about the other workloads
-                    "traffic": pmc_traffic("k_icp_iter") if args.config == "1" else None, "levels": levels, "stage_ms": stages}
+                    "traffic": pmc_traffic("k_icp_iter") if args.config == "1" else None, "levels": levels, "stage_ms": stages,
+                    # the same figure over a ceiling MEASURED on this box (a device-to-device copy: read + write bytes)
+                    "measured_ceiling": dict(ceiling, frac_of_measured=achieved / ceiling["GB/s"]) if ceiling else None}
         frame_bytes = 741 * P * n_tracked + 192 * count
         roofline_frame = {"bound": "hbm", "algorithmic_bytes": frame_bytes, "ms": 1e3 * total_dt / total_steps,
                           "achieved": frame_bytes / (total_dt / total_steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -24,6 +24,7 @@ constexpr int kBR = 6;
 constexpr int kBTileW = 64, kBTileH = 4;
 constexpr int kBLdsW = kBTileW + 2 * kBR;  // 76
 constexpr int kBLdsH = kBTileH + 2 * kBR;  // 16
+constexpr float kBOutside = 1e15f;
 
 // The range/space weight exp(-(s2 * a + c2 * b)) is evaluated as 2^-(s2 * a' + c2 * b') with log2(e) folded into the
 // constants and the hardware v_exp_f32 (1 ulp on 2^t; the argument carries |t| * 2^-24 <= 1e-6 relative for every weight
@@ -36,11 +37,13 @@ __global__ __launch_bounds__(256) void k_bilateral(const float* __restrict__ dep
     __shared__ float tile[kBLdsH * kBLdsW];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int x0 = blockIdx.x * kBTileW, y0 = blockIdx.y * kBTileH;
-    // stage (out-of-image taps get a negative sentinel and are skipped, like the clipped loops of the shader)
+    // stage.  The shader clips its loops at the image border; here an out-of-image tap holds kBOutside = 1e15: its range term is
+    // -8e32, 2^that is exactly 0, and it adds tmp * 0 = +0 to both sums -- the same bits as skipping it, without a compare, an exec
+    // mask and a branch per tap (round 3: the 169 branches also kept every ds_read on its own s_waitcnt).
     for (int i = threadIdx.x; i < kBLdsH * kBLdsW; i += 256) {
         const int ly = i / kBLdsW, lx = i - ly * kBLdsW;
         const int gx = x0 + lx - kBR, gy = y0 + ly - kBR;
-        tile[i] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? depth[gy * W + gx] : -1.0f;
+        tile[i] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? depth[gy * W + gx] : kBOutside;
     }
     __syncthreads();
     const float sigma_space2_inv_half = 0.024691358f * 1.44269504088896340736f;   // x log2(e)
@@ -58,13 +61,11 @@ __global__ __launch_bounds__(256) void k_bilateral(const float* __restrict__ dep
 #pragma unroll
             for (int dx = -kBR; dx <= kBR; ++dx) {
                 const float tmp = row[dx];
-                if (tmp >= 0.f) {
-                    const float space_term = -(((float)(dx * dx) + fy2) * sigma_space2_inv_half);   // compile-time constant
-                    const float color2 = (value - tmp) * (value - tmp);
-                    const float weight = __builtin_amdgcn_exp2f(space_term - color2 * sigma_color2_inv_half);
-                    sum1 += tmp * weight;
-                    sum2 += weight;
-                }
+                const float space_term = -(((float)(dx * dx) + fy2) * sigma_space2_inv_half);   // compile-time constant
+                const float color2 = (value - tmp) * (value - tmp);
+                const float weight = __builtin_amdgcn_exp2f(space_term - color2 * sigma_color2_inv_half);   // exactly 0 for an outside tap
+                sum1 += tmp * weight;
+                sum2 += weight;
             }
         }
         res = sum1 / sum2;
