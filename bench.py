@@ -227,6 +227,8 @@ def sharded_scene(args, cfg, rank, local_rank, world, st, frames, steps, min_sec
     for k, v in (("mfThreshold", 0.3), ("mfWeightDistance", 150.0), ("mfWeightConvexity", 2.8), ("mfMorphEdgeIterations", 0),
                  ("mfMorphMaskIterations", 0), ("newModelMinRelativeSize", 0.004)):
         mf.setParam(k, v)
+    if world == 1 or rank > 0:
+        mf.preallocateModels(cfg["n_objects"] if world == 1 else max(2, (cfg["n_objects"] + world - 2) // (world - 1)))   # as single_context_scene: no hipMalloc at spawn time
     scfg = sharded.default_cfg(trackAllModels=True, modelSpawnOffset=2, depthCutoff=3.0)
     smf = sharded.ShardedMaskFusion(mf, dev, scfg)
     cls = [0] + [41 + i for i in range(cfg["n_objects"])]

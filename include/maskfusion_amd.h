@@ -108,6 +108,10 @@ int mf_get_surfel_count(mf_ctx* ctx, int32_t model, uint32_t* count);
  * {R row-major (9), t (3), lastICPError, lastICPCount, surfel count, alive}: what the multi-GPU gather ships per rank
  * (the reference logs the same per model, Core/MaskFusion.cpp:580-602) without a host round trip. */
 int mf_model_state_dev(mf_ctx* ctx, int32_t model, float* d_out16);
+/* the same for every model of the list in one call: d_out16[16 * i ..] = models[i]; capacity = models the buffer holds */
+int mf_models_state_dev(mf_ctx* ctx, float* d_out16, int32_t capacity);
+/* ids of the model list (MaskFusion::models, Core/MaskFusion.h:329-333) in list order; host state, no synchronisation */
+int mf_get_model_ids(mf_ctx* ctx, int32_t* ids, int32_t capacity, int32_t* n);
 /* Model::getPoseLog (Core/Model/Model.h:257-262) of model i, chronological: ts[e] = the frame's timestamp, p7[e] =
  * {tx ty tz qx qy qz qw} of cam->world (background) or obj->world (objects), Core/MaskFusion.cpp:580-596.
  * ts/p7 may be NULL to query *count only. */
@@ -228,6 +232,19 @@ int mf_stage_frame_dev(mf_ctx* ctx, const uint8_t* d_rgb, const float* d_depth, 
 /* The tail of processFrame (Core/MaskFusion.cpp:569-602) for a frame driven through the calls below: tick++, the
  * requiresFillIn decision for the next tracking step, the pose-log entry with `timestamp`, age++ */
 int mf_end_frame(mf_ctx* ctx, int64_t timestamp);
+/* The three per-model LOOPS of MaskFusion::processFrame over this context's model list, for a caller that sequences a frame itself
+ * (one scene sharded by model over several contexts).  They run what mf_process_frame runs for these loops -- ONE batched
+ * Gauss-Newton loop over all tracked models, ONE launch per surfel pass for all object models -- under the context's configuration.
+ * first_model = 0: the whole list; 1: models[0] is the stand-in of a background owned by another context (pose via
+ * mf_model_override_pose; neither tracked, fused nor drawn, but its tick advances).
+ *   mf_track_models    Core/MaskFusion.cpp:247-276 (trackableClassIds, updateStaticPose for static objects, the 0.2 m jump rule)
+ *   mf_fuse_models     :335-339, :369-374 (setMaxDepth, confidence ramp), :342-353 for models[spawned_model] when spawned_model >= 1
+ *                      (-1: none), then the fusion loop :539-565
+ *   mf_predict_models  :569 predict(), :573 tick++, :580-596 pose log, :600 incrementAge -- the end of such a frame (instead of
+ *                      mf_model_combined_predict per model + mf_end_frame) */
+int mf_track_models(mf_ctx* ctx, int32_t first_model, int32_t track_all_models);
+int mf_fuse_models(mf_ctx* ctx, int32_t first_model, float weight_multiplier, int32_t spawned_model);
+int mf_predict_models(mf_ctx* ctx, int32_t first_model, int64_t timestamp);
 /* Model::initialise (Core/Model/Model.h:126, Model.cpp:240-285) from the staged frame */
 int mf_model_initialise(mf_ctx* ctx, int32_t model);
 /* Model::overridePose (Core/Model/Model.h:235-238): lastPose = pose; pose = pose16 */
@@ -286,6 +303,14 @@ int mf_import_projection_keys_dev(mf_ctx* ctx, const uint64_t* d_keys);
 int mf_perform_segmentation(mf_ctx* ctx, const uint8_t* mask, const int32_t* class_ids, int32_t n_masks, const int32_t* model_ids,
                             const int32_t* model_class_ids, int32_t n_models, int32_t next_model_id, int32_t allow_new,
                             int32_t* has_new_label, int32_t* new_class_id);
+/* The same in two halves (what mf_process_frame does with "earlyBackgroundFusion"): _begin enqueues the label stage and returns; the caller
+ * may then enqueue work that does not depend on the decision -- mf_fuse_background: the background is never spawned or dropped and its
+ * fusion (Core/MaskFusion.cpp:539-565 for models.front()) reads only the label image, complete on the stream -- and _end waits for the
+ * label stage alone.  mf_fuse_models skips a background that mf_fuse_background has already fused for the staged frame. */
+int mf_perform_segmentation_begin(mf_ctx* ctx, const uint8_t* mask, const int32_t* class_ids, int32_t n_masks, const int32_t* model_ids,
+                                  const int32_t* model_class_ids, int32_t n_models, int32_t next_model_id, int32_t allow_new);
+int mf_perform_segmentation_end(mf_ctx* ctx, int32_t* has_new_label, int32_t* new_class_id);
+int mf_fuse_background(mf_ctx* ctx, float weight_multiplier);
 /* SegmentationResult::fullSegmentation as device memory: out of the context that ran the label stage, into the others
  * (textureMask->Upload, Core/MaskFusion.cpp:297) */
 int mf_export_segmentation_dev(mf_ctx* ctx, uint8_t* d_out);

@@ -209,6 +209,31 @@ class MaskFusion:
     def endFrame(self, timestamp: int = 0):
         self._chk(self._L.mf_end_frame(self._h, timestamp))
 
+    # the per-model loops of processFrame over this context's list (mf_track_models / mf_fuse_models / mf_predict_models): one batched
+    # Gauss-Newton loop, one launch per surfel pass for all object models.  firstModel = 1: models[0] is a background stand-in.
+    def trackModels(self, firstModel: int = 0, trackAllModels: bool = True):
+        """the tracking loop, Core/MaskFusion.cpp:247-276"""
+        self._chk(self._L.mf_track_models(self._h, firstModel, int(bool(trackAllModels))))
+
+    def fuseModels(self, firstModel: int = 0, weightMultiplier: float = 1.0, spawnedModel: int = -1):
+        """:335-374 object parameters and the spawn-frame pass of models[spawnedModel], then the fusion loop :539-565"""
+        self._chk(self._L.mf_fuse_models(self._h, firstModel, float(weightMultiplier), spawnedModel))
+
+    def predictModels(self, firstModel: int = 0, timestamp: int = 0):
+        """predict() :569 + tick++ / pose log / age++ (the end of a frame sequenced by the caller; replaces endFrame)"""
+        self._chk(self._L.mf_predict_models(self._h, firstModel, timestamp))
+
+    def modelIDs(self):
+        """ids of the model list in list order (host state: does not wait for the device, unlike Model.getID)"""
+        ids = (C.c_int32 * 256)()
+        n = C.c_int32(0)
+        self._chk(self._L.mf_get_model_ids(self._h, ids, 256, C.byref(n)))
+        return [int(ids[i]) for i in range(n.value)]
+
+    def modelsStateDevice(self, d_out16: int, capacity: int):
+        """modelStateDevice for the whole list: 16 floats per model into one device buffer"""
+        self._chk(self._L.mf_models_state_dev(self._h, d_out16, capacity))
+
     def setTrackableClassIds(self, ids):
         a = np.ascontiguousarray(list(ids), np.int32)
         self._chk(self._L.mf_set_trackable_class_ids(self._h, a.ctypes.data if len(a) else None, len(a)))

@@ -138,6 +138,8 @@ struct mf_ctx {
     bool early_bg_fusion = true;                       // A/B knob ("earlyBackgroundFusion"): 0 = the host visit drains the stream
     hipEvent_t ev_labels = nullptr;                    // the label stage of this frame has written its result words
     long frame_no = 0;
+    long bg_fused_frame = -1;          // mf_fuse_background has fused the background of this staged frame (mf_fuse_models then skips it)
+    bool labels_pending = false;       // between mf_perform_segmentation_begin and _end
     int lastF = 0;
     int overlap = 0;                   // 1: preprocessing on stream_pre, one frame ahead ("overlapPreprocessing").  Measured on
                                        // MI355X (tools/host_rate.py, same box A/B): 473-483 us/frame either way -- the filter's
@@ -888,6 +890,94 @@ static int spawn_object(mf_ctx* c, int id, int classID) {
     return MF_OK;
 }
 
+// The tracking loop of processFrame (Core/MaskFusion.cpp:247-276) over models[first..]: every model that is tracked this frame goes
+// into one batch (geometric term) or is tracked on its own (photometric term: its scratch images are shared); static objects then follow
+// the background's NEW pose (models[0]'s pose: on a context that holds only objects the caller has overridden it with the owner's).
+static void enqueue_tracking_loop(mf_ctx* c, size_t first, bool track_all, const float* depthF_prev, long k) {
+    ModelState& bg = *c->models[0];
+    std::vector<ModelState*> tracked, follow;
+    if (first == 0) tracked.push_back(&bg);
+    for (size_t i = 1; i < c->models.size(); ++i) {
+        ModelState& m = *c->models[i];
+        // trackable = trackableClassIds.empty() || trackableClassIds.count(classID), :261
+        bool trackable = c->trackable.empty();
+        for (int id : c->trackable) trackable |= (id == m.classID);
+        if ((!m.isStatic || track_all) && trackable) tracked.push_back(&m);   // jump rule of :268-272 in the finalize step
+        else follow.push_back(&m);
+    }
+    if (!photometric_on(c) && tracked.size() >= 2 && (int)tracked.size() <= kMaxTrackBatch && c->batch_tracking) {
+        enqueue_track_batch(c, tracked, depthF_prev, k);
+    } else {
+        for (ModelState* m : tracked) enqueue_track(c, *m, m == &bg ? depthF_prev : nullptr, m == &bg ? 0.f : 0.2f, k);
+    }
+    for (ModelState* m : follow) launch_static_pose(m->d_pose, bg.d_pose, m->h_pose, c->stream);   // updateStaticPose, :274
+}
+
+// The fusion loop of processFrame (Core/MaskFusion.cpp:539-565) over models[first..]: predictIndices -> fuse -> predictIndices -> clean;
+// the object models go through one launch per pass when there are at least two of them ("batchObjectPasses").
+static int enqueue_fusion_loop(mf_ctx* c, size_t first, bool multi, const uint8_t* d_rgb, const float* d_depth, const float* depthF,
+                               const uint8_t* mask, float weight_multiplier) {
+    const mf_config& g = c->cfg;
+    const bool batch = multi && batch_objects_now(c);
+    for (size_t i = first; i < (batch ? (size_t)1 : c->models.size()); ++i)
+        enqueue_fuse_clean(c, *c->models[i], d_rgb, d_depth, depthF, mask, g.depth_cutoff, weight_multiplier, true, i == 0);
+    if (batch) {   // every object model: one launch per pass
+        std::vector<ModelState*> objs; std::vector<int> orders;
+        object_models(c, objs, orders);
+        ObjBatch ob; int blocks = 0;
+        int rc = make_obj_batch(c, objs, orders, d_rgb, d_depth, depthF, mask, weight_multiplier, nullptr, ob, blocks);
+        if (rc != MF_OK) return rc;
+        launch_obj_fuse_clean(ob, blocks, c->stream);
+    }
+    return MF_OK;
+}
+
+// predict() (Core/MaskFusion.cpp:569) + tick++ (:573) + the pose log entry (:580-596) + incrementAge (:600) over models[first..].
+// first == 1: models[0] is the stand-in of a background that lives in another context -- it is not drawn, but its frame state advances.
+static int enqueue_predict_loop(mf_ctx* c, size_t first, bool may_batch, int64_t timestamp, const uint8_t* d_rgb, const float* d_depth,
+                                const float* depthF, const uint8_t* mask, float weight_multiplier) {
+    const mf_config& g = c->cfg;
+    ModelState& bg = *c->models[0];
+    auto log_slot = [&](ModelState& m) -> float* {   // MaskFusion.cpp:580-596
+        if (!m.d_poselog) return nullptr;
+        float* slot = m.d_poselog + (m.log_ts.size() % (size_t)g.pose_log_capacity) * 8;
+        m.log_ts.push_back(timestamp);
+        return slot;
+    };
+    if (first > 0) {
+        launch_frame_advance(bg.d_frame, c->W, c->H, bg.h_frame, bg.d_pose, nullptr, log_slot(bg), c->stream);
+        bg.age++;
+    }
+    if (may_batch && batch_objects_now(c)) {
+        // predict() + tick++ + pose log of the object models in three launches; the background keeps its tiled prediction
+        if (first == 0) {
+            const FrameAdvance adv0{bg.h_frame, nullptr, log_slot(bg)};
+            enqueue_predict(c, bg, &adv0);
+            bg.age++;
+        }
+        std::vector<ModelState*> objs; std::vector<int> orders;
+        object_models(c, objs, orders);
+        std::vector<float*> slots;
+        for (ModelState* m : objs) {
+            slots.push_back(log_slot(*m));
+            m->pred_gray_valid = photometric_on(c);
+            m->age++;
+        }
+        ObjBatch ob; int blocks = 0;
+        int rc = make_obj_batch(c, objs, orders, d_rgb, d_depth, depthF, mask, weight_multiplier, &slots, ob, blocks);
+        if (rc != MF_OK) return rc;
+        launch_obj_predict_advance(ob, blocks, c->stream);
+        return MF_OK;
+    }
+    for (size_t i = first; i < c->models.size(); ++i) {
+        ModelState& m = *c->models[i];
+        const FrameAdvance adv{m.h_frame, i == 0 ? nullptr : bg.d_pose, log_slot(m)};
+        enqueue_predict(c, m, &adv);   // ... with tick++ / the fill-in decision / the pose log entry as its epilogue
+        m.age++;  // incrementAge, :600
+    }
+    return MF_OK;
+}
+
 static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_depth, const uint8_t* d_mask_in,
                               const int32_t* class_ids, int n_masks, float weight_multiplier, int64_t timestamp = 0,
                               const float* in_pose16 = nullptr, bool bootstrap = false) {
@@ -930,21 +1020,7 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
         mark(c, 2);
         // tracking, :247-276.  Every model that is tracked this frame goes into one batch (geometric term) or is tracked on its
         // own (photometric term: its scratch images are shared); static objects then follow the background's NEW pose
-        std::vector<ModelState*> tracked{&bg}, follow;
-        for (size_t i = 1; i < c->models.size(); ++i) {
-            ModelState& m = *c->models[i];
-            // trackable = trackableClassIds.empty() || trackableClassIds.count(classID), :261
-            bool trackable = c->trackable.empty();
-            for (int id : c->trackable) trackable |= (id == m.classID);
-            if ((!m.isStatic || g.track_all_models) && trackable) tracked.push_back(&m);   // jump rule of :268-272 in the finalize step
-            else follow.push_back(&m);
-        }
-        if (!photometric_on(c) && tracked.size() >= 2 && (int)tracked.size() <= kMaxTrackBatch && c->batch_tracking) {
-            enqueue_track_batch(c, tracked, depthF_prev, k);
-        } else {
-            for (size_t i = 0; i < tracked.size(); ++i) enqueue_track(c, *tracked[i], i == 0 ? depthF_prev : nullptr, i == 0 ? 0.f : 0.2f, k);
-        }
-        for (ModelState* m : follow) launch_static_pose(m->d_pose, bg.d_pose, m->h_pose, s);   // updateStaticPose, :274
+        enqueue_tracking_loop(c, 0, g.track_all_models != 0, depthF_prev, k);
         if (bootstrap && in_pose16) launch_override_pose(bg.d_pose, in_pose16, 1, bg.h_pose, s);   // :280-283 (after the object loop)
         mark(c, 3);
         if (c->overlap) { MF_HIP(c, hipEventRecord(c->ev_main_done[set], s)); main_done_recorded = true; }
@@ -1040,52 +1116,14 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
         // (the predict() at MaskFusion.cpp:423 only feeds the dead loop-closure block and is overwritten at :569)
         // fusion, :539-565: if (!rgbOnly && trackingOk && !lost)
         if (!g.rgb_only) {
-          const bool batch = multi && batch_objects_now(c);
-          for (size_t i = bg_fused ? 1 : 0; i < (batch ? (size_t)1 : c->models.size()); ++i)
-            enqueue_fuse_clean(c, *c->models[i], d_rgb, d_depth, depthF, mask, g.depth_cutoff, weight_multiplier, true, i == 0);
-          if (batch) {   // every object model: one launch per pass
-              std::vector<ModelState*> objs; std::vector<int> orders;
-              object_models(c, objs, orders);
-              ObjBatch ob; int blocks = 0;
-              int rc = make_obj_batch(c, objs, orders, d_rgb, d_depth, depthF, mask, weight_multiplier, nullptr, ob, blocks);
-              if (rc != MF_OK) return rc;
-              launch_obj_fuse_clean(ob, blocks, s);
-          }
+            int rc = enqueue_fusion_loop(c, bg_fused ? 1 : 0, multi, d_rgb, d_depth, depthF, mask, weight_multiplier);
+            if (rc != MF_OK) return rc;
         }
         mark(c, 7);
     }
-    if (multi && batch_objects_now(c) && c->map_ready && k > 0) {
-        // predict() + tick++ + pose log of the object models in three launches; the background keeps its tiled prediction
-        ModelState& b0 = *c->models[0];
-        float* slot0 = nullptr;
-        if (b0.d_poselog) { slot0 = b0.d_poselog + (b0.log_ts.size() % (size_t)g.pose_log_capacity) * 8; b0.log_ts.push_back(timestamp); }
-        const FrameAdvance adv0{b0.h_frame, nullptr, slot0};
-        enqueue_predict(c, b0, &adv0);
-        b0.age++;
-        std::vector<ModelState*> objs; std::vector<int> orders;
-        object_models(c, objs, orders);
-        std::vector<float*> slots;
-        for (ModelState* m : objs) {
-            float* slot = nullptr;
-            if (m->d_poselog) { slot = m->d_poselog + (m->log_ts.size() % (size_t)g.pose_log_capacity) * 8; m->log_ts.push_back(timestamp); }
-            slots.push_back(slot);
-            m->pred_gray_valid = photometric_on(c);
-            m->age++;
-        }
-        ObjBatch ob; int blocks = 0;
-        int rc = make_obj_batch(c, objs, orders, d_rgb, d_depth, depthF, mask, weight_multiplier, &slots, ob, blocks);
+    {
+        int rc = enqueue_predict_loop(c, 0, multi && c->map_ready && k > 0, timestamp, d_rgb, d_depth, depthF, mask, weight_multiplier);
         if (rc != MF_OK) return rc;
-        launch_obj_predict_advance(ob, blocks, s);
-    } else
-    for (auto& m : c->models) {  // predict(), :569 ; tick++, :573
-        float* slot = nullptr;
-        if (m->d_poselog) {  // MaskFusion.cpp:580-596
-            slot = m->d_poselog + (m->log_ts.size() % (size_t)g.pose_log_capacity) * 8;
-            m->log_ts.push_back(timestamp);
-        }
-        const FrameAdvance adv{m->h_frame, m.get() == c->models[0].get() ? nullptr : bg.d_pose, slot};
-        enqueue_predict(c, *m, &adv);   // ... with tick++ / the fill-in decision / the pose log entry as its epilogue
-        m->age++;  // incrementAge, :600
     }
     mark(c, 8);
     // every branch records the event (the caller-supplied-pose branch and the first frame do it here, at the end of the frame)
@@ -1428,6 +1466,66 @@ extern "C" int mf_end_frame(mf_ctx* c, int64_t timestamp) {
     return check_launch(c);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The three per-model LOOPS of MaskFusion::processFrame as calls over this context's model list, for a caller that sequences a frame
+// itself (maskfusion_amd/sharded.py: one scene, its models spread over several contexts).  They run exactly what mf_process_frame runs for
+// these loops -- the batched Gauss-Newton loop over all tracked models, one launch per surfel pass for all object models -- where the
+// Model-level calls above cost ~21 + ~12 launches per model.  first_model = 0: the whole list; 1: models[0] is the stand-in of a
+// background that lives in another context (its pose is set with mf_model_override_pose; it is neither tracked, fused nor drawn).
+// Configuration (rgbOnly, icpWeight, pyramid, fastOdom, so3, depth limits, timeDelta) is the context's.
+// ------------------------------------------------------------------------------------------------
+// the tracking loop, Core/MaskFusion.cpp:247-276 (trackable classes, static objects follow the background, the 0.2 m jump rule)
+extern "C" int mf_track_models(mf_ctx* c, int32_t first_model, int32_t track_all_models) {
+    if (!c || c->frame_no == 0 || first_model < 0 || first_model > 1 || (first_model == 0 && !c->map_ready)) return MF_EINVAL;
+    const long k = staged_frame(c);
+    if (photometric_on(c)) {   // the same guard as mf_model_perform_tracking
+        const int set = (int)(k & 1);
+        bool ok = c->gray_frame[set] == k && c->deriv_frame == k;
+        for (size_t i = (size_t)first_model; i < c->models.size(); ++i) ok = ok && c->models[i]->pred_gray_valid;
+        if (!ok) { c->err = "mf_track_models: photometric term configured, but the staged frame / a prediction carries no intensity images"; return MF_ESTATE; }
+    }
+    enqueue_tracking_loop(c, (size_t)first_model, track_all_models != 0, c->d_depthF[(k + 2) % 3], k);
+    return check_launch(c);
+}
+// the fusion loop, Core/MaskFusion.cpp:539-565, preceded -- when spawned_model >= 1 -- by the spawn-frame pass of that model
+// (:342-353: predictIndices; fuse(maxDepthProcessed, weight 100); clean) and by the per-frame object parameters (:335-339, :369-374)
+extern "C" int mf_fuse_models(mf_ctx* c, int32_t first_model, float weight_multiplier, int32_t spawned_model) {
+    if (!c || c->frame_no == 0 || first_model < 0 || first_model > 1 || (first_model == 0 && !c->map_ready) || spawned_model == 0 ||
+        spawned_model >= (int32_t)c->models.size())
+        return MF_EINVAL;
+    const mf_config& g = c->cfg;
+    const long k = staged_frame(c);
+    const float* depthF = c->d_depthF[k % 3];
+    const uint8_t* mask = current_mask(c);
+    for (size_t i = 1; i < c->models.size(); ++i) c->models[i]->maxDepth = 30.f + 30.f * 1.2f;
+    if (spawned_model > 0)
+        enqueue_fuse_clean(c, *c->models[spawned_model], c->cur_rgb, c->cur_depth, depthF, mask, g.max_depth_processed, 100.f, false, false);
+    for (size_t i = 1; i < c->models.size(); ++i) c->models[i]->confThr = fminf(4.5f, (float)c->models[i]->age / 25.0f);
+    if (!g.rgb_only) {
+        if (first_model == 0 && c->bg_fused_frame == k) first_model = 1;   // mf_fuse_background has run for this frame
+        int rc = enqueue_fusion_loop(c, (size_t)first_model, g.enable_multiple_models != 0, c->cur_rgb, c->cur_depth, depthF, mask, weight_multiplier);
+        if (rc != MF_OK) return rc;
+    }
+    return check_launch(c);
+}
+// predict() (:569) and the tail of the frame (tick++ :573, pose log :580-596, incrementAge :600) -- the end of a frame driven through
+// mf_stage_frame / mf_track_models / mf_fuse_models (do not call mf_end_frame as well)
+extern "C" int mf_predict_models(mf_ctx* c, int32_t first_model, int64_t timestamp) {
+    if (!c || c->frame_no == 0 || first_model < 0 || first_model > 1 || (first_model == 0 && !c->map_ready)) return MF_EINVAL;
+    const long k = staged_frame(c);
+    int rc = enqueue_predict_loop(c, (size_t)first_model, c->cfg.enable_multiple_models != 0, timestamp, c->cur_rgb, c->cur_depth, c->d_depthF[k % 3],
+                                  current_mask(c), 1.0f);
+    if (rc != MF_OK) return rc;
+    c->host_tick++;
+    return check_launch(c);
+}
+// mf_model_state_dev for every model of the list: d_out16[i * 16 ..] = state of models[i] (one call per frame instead of one per model)
+extern "C" int mf_models_state_dev(mf_ctx* c, float* d_out16, int32_t capacity) {
+    if (!c || !d_out16 || capacity < (int32_t)c->models.size()) return MF_EINVAL;
+    for (size_t i = 0; i < c->models.size(); ++i) launch_model_state(c->models[i]->d_pose, c->models[i]->d_frame, d_out16 + 16 * i, c->stream);
+    return check_launch(c);
+}
+
 // Model::makeNonStatic / makeStatic(globalPose) / isNonstatic (Core/Model/Model.h:263-268): a non-static object model is
 // tracked even when trackAllModels is off; makeStatic re-anchors it to the background's current pose
 extern "C" int mf_make_nonstatic(mf_ctx* c, int32_t model) {
@@ -1471,6 +1569,18 @@ extern "C" int mf_set_trackable_class_ids(mf_ctx* c, const int32_t* ids, int32_t
 extern "C" int mf_export_projection_keys_dev(mf_ctx* c, const int32_t* orders, int32_t n_orders, uint64_t* d_keys_out) {
     if (!c || !d_keys_out || n_orders != (int32_t)c->models.size() || (n_orders > 0 && !orders)) return MF_EINVAL;
     hipStream_t s = c->stream;
+    bool all_objects = batch_objects_now(c) && c->frame_no > 0;
+    for (size_t i = 1; i < c->models.size(); ++i) all_objects = all_objects && orders[i] >= 0;
+    if (all_objects) {   // as in mf_process_frame: the object models' sprites in one launch
+        if (orders[0] >= 0) enqueue_global_projection(c, *c->models[0], orders[0]);
+        std::vector<ModelState*> objs; std::vector<int> ord;
+        for (size_t i = 1; i < c->models.size(); ++i) { objs.push_back(c->models[i].get()); ord.push_back(orders[i]); }
+        const long k = staged_frame(c);
+        ObjBatch ob; int blocks = 0;
+        int rc = make_obj_batch(c, objs, ord, c->cur_rgb, c->cur_depth, c->d_depthF[k % 3], current_mask(c), 1.0f, nullptr, ob, blocks);
+        if (rc != MF_OK) return rc;
+        launch_obj_global_scatter(ob, blocks, s);
+    } else
     for (size_t i = 0; i < c->models.size(); ++i) {
         ModelState& m = *c->models[i];
         if (orders[i] < 0) continue;   // a stand-in (e.g. the background on a rank that only holds objects): not drawn
@@ -1491,10 +1601,10 @@ extern "C" int mf_import_projection_keys_dev(mf_ctx* c, const uint64_t* d_keys) 
 // staged frame: geometric edges of its vertex / normal maps, then the label stage against `mask` (host, may be NULL) and the
 // projected-id image of the last global projection.  model_ids == NULL: this context's own model list; otherwise the GLOBAL list
 // (index 0 = background).  The result becomes textureMask (mf_download_segmentation / mf_export_segmentation_dev).  Synchronous.
-extern "C" int mf_perform_segmentation(mf_ctx* c, const uint8_t* mask, const int32_t* class_ids, int32_t n_masks, const int32_t* model_ids,
-                                       const int32_t* model_class_ids, int32_t n_models, int32_t next_model_id, int32_t allow_new,
-                                       int32_t* has_new_label, int32_t* new_class_id) {
-    if (!c || !has_new_label || !new_class_id || c->frame_no == 0 || (model_ids && (!model_class_ids || n_models < 1))) return MF_EINVAL;
+static int segmentation_enqueue(mf_ctx* c, const uint8_t* mask, const int32_t* class_ids, int32_t n_masks, const int32_t* model_ids,
+                                const int32_t* model_class_ids, int32_t n_models, int32_t next_model_id, int32_t allow_new,
+                                int32_t* has_new_label, int32_t* new_class_id) {
+    if (!c || c->frame_no == 0 || (model_ids && (!model_class_ids || n_models < 1))) return MF_EINVAL;
     if (n_masks < 0 || n_masks > 256 || (n_masks > 0 && (!mask || !class_ids))) return MF_EINVAL;
     hipStream_t s = c->stream;
     const int set = (int)(staged_frame(c) & 1);
@@ -1518,11 +1628,51 @@ extern "C" int mf_perform_segmentation(mf_ctx* c, const uint8_t* mask, const int
     int rc = c->labels->enqueue(c->seg, c->W, c->H, c->d_bin, c->cur_depth, n_masks > 0 ? c->d_mask_in : nullptr, n_masks > 0 ? class_ids : kNoClass,
                                 n_masks, c->d_proj_ids, infos, poses, next_model_id, allow_new != 0, c->d_mask_tex, s);
     if (rc != MF_OK) return rc;
+    if (!has_new_label) {   // mf_perform_segmentation_begin: the decision is read by mf_perform_segmentation_end
+        if (!c->ev_labels) MF_HIP(c, hipEventCreateWithFlags(&c->ev_labels, hipEventDisableTiming));
+        MF_HIP(c, hipEventRecord(c->ev_labels, s));
+        c->labels_pending = true;
+        return MF_OK;
+    }
     MF_HIP(c, hipStreamSynchronize(s));
     if (c->labels->h_result[2]) { c->err = "label stage: vote tables overflowed (too many components x masks)"; return MF_ESTATE; }
     *has_new_label = c->labels->h_result[0] != 0;
     *new_class_id = c->labels->h_result[1];
     return MF_OK;
+}
+// The same in two halves, so that work that does not depend on the decision runs on the GPU while the host waits for it -- what
+// mf_process_frame does with the background's fusion ("earlyBackgroundFusion"): _begin enqueues the label stage and returns; the caller may
+// enqueue mf_fuse_background (the background is never spawned or dropped, its fusion reads only the label image, which is complete on the
+// stream); _end waits for the label stage alone and hands out the decision.
+extern "C" int mf_perform_segmentation_begin(mf_ctx* c, const uint8_t* mask, const int32_t* class_ids, int32_t n_masks, const int32_t* model_ids,
+                                             const int32_t* model_class_ids, int32_t n_models, int32_t next_model_id, int32_t allow_new) {
+    if (!c || c->labels_pending) return MF_EINVAL;
+    return segmentation_enqueue(c, mask, class_ids, n_masks, model_ids, model_class_ids, n_models, next_model_id, allow_new, nullptr, nullptr);
+}
+extern "C" int mf_perform_segmentation_end(mf_ctx* c, int32_t* has_new_label, int32_t* new_class_id) {
+    if (!c || !has_new_label || !new_class_id || !c->labels_pending) return MF_EINVAL;
+    c->labels_pending = false;
+    MF_HIP(c, hipEventSynchronize(c->ev_labels));
+    if (c->labels->h_result[2]) { c->err = "label stage: vote tables overflowed (too many components x masks)"; return MF_ESTATE; }
+    *has_new_label = c->labels->h_result[0] != 0;
+    *new_class_id = c->labels->h_result[1];
+    return MF_OK;
+}
+// the background's share of the fusion loop (Core/MaskFusion.cpp:539-565 for models.front()), ahead of mf_fuse_models, which then skips it
+extern "C" int mf_fuse_background(mf_ctx* c, float weight_multiplier) {
+    if (!c || c->frame_no == 0 || !c->map_ready) return MF_EINVAL;
+    const long k = staged_frame(c);
+    if (c->bg_fused_frame == k) { c->err = "mf_fuse_background: the background of this frame is already fused"; return MF_ESTATE; }
+    if (!c->cfg.rgb_only)
+        enqueue_fuse_clean(c, *c->models[0], c->cur_rgb, c->cur_depth, c->d_depthF[k % 3], current_mask(c), c->cfg.depth_cutoff, weight_multiplier, true, false);
+    c->bg_fused_frame = k;
+    return check_launch(c);
+}
+extern "C" int mf_perform_segmentation(mf_ctx* c, const uint8_t* mask, const int32_t* class_ids, int32_t n_masks, const int32_t* model_ids,
+                                       const int32_t* model_class_ids, int32_t n_models, int32_t next_model_id, int32_t allow_new,
+                                       int32_t* has_new_label, int32_t* new_class_id) {
+    if (!has_new_label || !new_class_id || (c && c->labels_pending)) return MF_EINVAL;
+    return segmentation_enqueue(c, mask, class_ids, n_masks, model_ids, model_class_ids, n_models, next_model_id, allow_new, has_new_label, new_class_id);
 }
 extern "C" int mf_export_segmentation_dev(mf_ctx* c, uint8_t* d_out) {
     if (!c || !d_out) return MF_EINVAL;
@@ -1587,6 +1737,13 @@ extern "C" int mf_num_models(mf_ctx* c, int32_t* n) {
 static ModelState* model_at(mf_ctx* c, int32_t i) {
     if (!c || i < 0 || i >= (int32_t)c->models.size()) return nullptr;
     return c->models[i].get();
+}
+// the ids of the model list in list order -- host state only, no synchronisation (mf_model_info waits for the surfel count)
+extern "C" int mf_get_model_ids(mf_ctx* c, int32_t* ids, int32_t capacity, int32_t* n) {
+    if (!c || !ids || !n || capacity < (int32_t)c->models.size()) return MF_EINVAL;
+    for (size_t i = 0; i < c->models.size(); ++i) ids[i] = c->models[i]->id;
+    *n = (int32_t)c->models.size();
+    return MF_OK;
 }
 extern "C" int mf_get_pose(mf_ctx* c, int32_t model, float* out) {
     ModelState* m = model_at(c, model);

@@ -93,6 +93,11 @@ SYMBOLS = {
     "mf_stage_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mf_stage_frame_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mf_end_frame": (C.c_int, [C.c_void_p, C.c_int64]),
+    "mf_track_models": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "mf_fuse_models": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_int32]),
+    "mf_predict_models": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64]),
+    "mf_models_state_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "mf_get_model_ids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "mf_model_initialise": (C.c_int, [C.c_void_p, C.c_int32]),
     "mf_model_override_pose": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "mf_model_fusion_weight": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.POINTER(C.c_float)]),
@@ -107,6 +112,9 @@ SYMBOLS = {
     "mf_import_projection_keys_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mf_perform_segmentation": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "mf_perform_segmentation_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "mf_perform_segmentation_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "mf_fuse_background": (C.c_int, [C.c_void_p, C.c_float]),
     "mf_export_segmentation_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mf_import_segmentation_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mf_spawn_object_model": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),

@@ -67,7 +67,7 @@ class Shard:
 
     # ---------------------------------------------------------------------------------------------
     def local_ids(self) -> List[int]:
-        return [m.getID() for m in self.mf.getModels()]
+        return self.mf.modelIDs()      # host state: no device wait (Model.getID() would drain the stream once per model)
 
     def owns_background(self) -> bool:
         return self.rank == 0
@@ -83,28 +83,25 @@ class Shard:
             mf.stageFrameDevice(rgb.data_ptr(), depth.data_ptr())
         else:
             mf.stageFrame(rgb, depth)
-        models = mf.getModels()
         if first:
             if self.owns_background():
-                models[0].initialise()
+                mf.getBackgroundModel().initialise()
             return
         if not self.owns_background() and bg_pose16 is not None:
             mf._chk(mf._L.mf_model_override_pose(mf._h, 0, np.ascontiguousarray(bg_pose16, np.float32).ctypes.data))
-        for i, m in enumerate(models):
-            if i == 0 and not self.owns_background():
-                continue                                  # the background stand-in
-            info = m.info()
-            if i == 0 or (not info.is_static) or cfg["trackAllModels"]:
-                m.performTracking(False, cfg["rgbOnly"], cfg["icpWeight"], True, cfg["fastOdom"], cfg["so3"], cfg["maxDepthProcessed"], 0, i == 0)
-            else:
-                mf._chk(mf._L.mf_model_update_static_pose(mf._h, i))     # updateStaticPose(globalPose), :274
-        orders = np.array([order_of_id.get(mid, -1) if (i > 0 or self.owns_background()) else -1 for i, mid in enumerate(self.local_ids())], np.int32)
+        # the tracking loop (MaskFusion.cpp:247-276) over the local list in ONE call: the Gauss-Newton loops of all tracked models run as
+        # one batch, static objects follow the background (updateStaticPose, :274).  rgbOnly / icpWeight / fastOdom / so3 /
+        # maxDepthProcessed are the context's configuration (cfg carries the same values for the calls that still take them).
+        first_local = 0 if self.owns_background() else 1
+        mf.trackModels(first_local, cfg["trackAllModels"])
+        ids = self.local_ids()
+        orders = np.array([order_of_id.get(mid, -1) if (i > 0 or self.owns_background()) else -1 for i, mid in enumerate(ids)], np.int32)
         mf._chk(mf._L.mf_export_projection_keys_dev(mf._h, orders.ctypes.data, len(orders), self.keys.data_ptr()))
-        for i in range(len(models)):
-            mf.modelStateDevice(i, self.state[i].data_ptr())
+        mf.modelsStateDevice(self.state.data_ptr(), MAX_LOCAL + 1)
 
     # ---- phase 2 (rank 0): label stage on the merged projection ---------------------------------------
-    def phase_segment(self, mask: Optional[np.ndarray], class_ids: Sequence[int], merged_keys: torch.Tensor, alive_of_id: dict, cfg: dict) -> Control:
+    def phase_segment(self, mask: Optional[np.ndarray], class_ids: Sequence[int], merged_keys: torch.Tensor, alive_of_id: dict, cfg: dict,
+                      weight_multiplier: float = 1.0) -> Control:
         mf = self.mf
         import ctypes as C
         # inactivateModel for objects the jump rule dropped on their ranks (MaskFusion.cpp:268-272)
@@ -117,9 +114,14 @@ class Shard:
         has_new, new_cls = C.c_int32(0), C.c_int32(-1)
         m = np.ascontiguousarray(mask, np.uint8) if mask is not None and len(class_ids) else None
         cid = np.ascontiguousarray(class_ids, np.int32) if m is not None else None
-        mf._chk(mf._L.mf_perform_segmentation(mf._h, m.ctypes.data if m is not None else None, cid.ctypes.data if cid is not None else None,
-                                              len(class_ids) if m is not None else 0, ids.ctypes.data, cls.ctypes.data, len(ids), self.next_id,
-                                              int(self.spawn_offset >= cfg["modelSpawnOffset"]), C.byref(has_new), C.byref(new_cls)))
+        # label stage enqueued; the background's fusion (it reads the label image on the stream, and the background is never spawned or
+        # dropped) keeps the GPU busy while the host waits for the new-model decision -- as mf_process_frame does
+        mf._chk(mf._L.mf_perform_segmentation_begin(mf._h, m.ctypes.data if m is not None else None, cid.ctypes.data if cid is not None else None,
+                                                    len(class_ids) if m is not None else 0, ids.ctypes.data, cls.ctypes.data, len(ids), self.next_id,
+                                                    int(self.spawn_offset >= cfg["modelSpawnOffset"])))
+        if not cfg["rgbOnly"]:
+            mf._chk(mf._L.mf_fuse_background(mf._h, float(weight_multiplier)))
+        mf._chk(mf._L.mf_perform_segmentation_end(mf._h, C.byref(has_new), C.byref(new_cls)))
         ctl = Control(order=[g.id for g in self.table])
         if has_new.value and len(self.table) < cfg["maxModels"]:
             ctl.has_new, ctl.new_id, ctl.new_class = 1, self.next_id, new_cls.value
@@ -150,30 +152,21 @@ class Shard:
             mf._chk(mf._L.mf_model_override_pose(mf._h, 0, np.ascontiguousarray(bg_pose16, np.float32).ctypes.data))
         # drops decided by the jump rule: the list rank 0 kept
         keep = set(ctl.order)
-        for i in reversed(range(1, len(mf.getModels()))):
-            if mf.getModels()[i].getID() not in keep:
+        ids = self.local_ids()
+        for i in reversed(range(1, len(ids))):
+            if ids[i] not in keep:
                 mf._chk(mf._L.mf_drop_model(mf._h, i))
-        spawned = None
+                del ids[i]
+        spawned = -1
         if ctl.has_new and ctl.owner == self.rank:
             mf._chk(mf._L.mf_spawn_object_model(mf._h, ctl.new_id, ctl.new_class))
-            spawned = len(mf.getModels()) - 1
-        models = mf.getModels()
-        if spawned is not None:      # :342-353: predictIndices; fuse(maxDepthProcessed, weight 100); clean (no second index pass)
-            nm = models[spawned]
-            nm.predictIndices(t, cfg["maxDepthProcessed"], cfg["timeDelta"])
-            nm.fuse(t, cfg["maxDepthProcessed"], 100.0)
-            nm.clean(t, cfg["timeDelta"], cfg["maxDepthProcessed"])
-        mf._chk(mf._L.mf_update_object_params(mf._h))      # :335-339, :369-374 (after the spawn-frame fuse, which runs with initConfidenceObject)
+            spawned = len(ids)
+        # :335-339 / :369-374 object parameters, :342-353 the spawn-frame pass of the new model (fuse with weight 100 under
+        # initConfidenceObject, clean without a second index pass), then the fusion loop :539-565 and predict() :569 + the frame's tail --
+        # the object models go through one launch per surfel pass
         first_local = 0 if self.owns_background() else 1
-        if not cfg["rgbOnly"]:       # :539-565
-            for m in models[first_local:]:
-                m.predictIndices(t, cfg["maxDepthProcessed"], cfg["timeDelta"])
-                m.fuse(t, cfg["depthCutoff"], weight_multiplier)
-                m.predictIndices(t, cfg["maxDepthProcessed"], cfg["timeDelta"])
-                m.clean(t, cfg["timeDelta"], cfg["maxDepthProcessed"])
-        for m in models[first_local:]:   # predict(), :569
-            m.combinedPredict(cfg["maxDepthProcessed"], t, t, cfg["timeDelta"])
-        mf.endFrame(timestamp)
+        mf.fuseModels(first_local, weight_multiplier, spawned)
+        mf.predictModels(first_local, timestamp)
         self.tick += 1
 
 
@@ -226,7 +219,7 @@ class LocalGroup:
             for s in self.shards[1:]:
                 alive.pop(0, None)       # the background stand-ins of the object ranks say nothing about the background
             alive[0] = 1
-            ctl = s0.phase_segment(mask, class_ids, merged, alive, self.cfg)
+            ctl = s0.phase_segment(mask, class_ids, merged, alive, self.cfg, weight_multiplier)
             s0.mf.sync()
             bg_pose = np.ascontiguousarray(s0.mf.getCurrPose().astype(np.float32).T.reshape(16))
             for s in self.shards[1:]:
@@ -268,6 +261,7 @@ class ShardedMaskFusion:
         self.depths = [torch.empty((H, W), dtype=torch.float32, device=device) for _ in range(3)]
         self.ctl = torch.zeros(8 + 64, dtype=torch.int32, device=device)
         self.frame = 0
+        self._order = [0]              # host copy of the global model list (ids in order) as of the end of the last frame
         # On a GPU every tensor op and collective of a frame is enqueued on the LIBRARY's stream (torch.cuda.ExternalStream): the frame
         # broadcast, the staging of the broadcast buffer (mf_stage_frame_dev: no host copy of the frame on any rank), tracking, the key
         # all-reduce, the label stage and fusion are ordered by that one stream; the host waits only where it has to read something
@@ -292,8 +286,9 @@ class ShardedMaskFusion:
             dist.broadcast(d_depth, 0)
         # GPU: the broadcast buffers are staged in place; CPU tensors (gloo tests over a stand-in context): as host arrays
         rgb_h, depth_h = (d_rgb, d_depth) if on_gpu else (d_rgb.numpy(), d_depth.numpy())
-        # the global list as of the end of the previous frame travels in the control record
-        order = [int(x) for x in self.ctl[8:8 + int(self.ctl[7].item())].tolist()] if self.frame else [0]
+        # the global list as of the end of the previous frame travelled in the control record: every rank kept its host copy (reading the
+        # device record here would drain the stream before the frame has even started)
+        order = list(self._order) if self.frame else [0]
         order_of_id = {mid: i for i, mid in enumerate(order)}
         if first or self.cfg["trackAllModels"] or self.world == 1:
             s.phase_track(rgb_h, depth_h, order_of_id, self.cfg, first)
@@ -335,7 +330,7 @@ class ShardedMaskFusion:
                 keys = _wire_to_keys(wire)
                 if not on_gpu:
                     _device_sync(self.device)
-                ctl = s.phase_segment(mask, class_ids, keys, alive, self.cfg)
+                ctl = s.phase_segment(mask, class_ids, keys, alive, self.cfg, weight_multiplier)
                 s.mf.sync()
                 bg_pose = np.ascontiguousarray(s.mf.getCurrPose().astype(np.float32).T.reshape(16))
                 rec = [ctl.has_new, ctl.new_id, ctl.new_class, ctl.owner, 0, 0, 0, len(ctl.order)] + ctl.order
@@ -347,17 +342,13 @@ class ShardedMaskFusion:
                 dist.broadcast(self.ctl, 0)
             if not on_gpu:
                 _device_sync(self.device)
-            c = self.ctl.cpu().numpy()                       # (the one host wait every rank needs: what to drop / spawn)
-            ctl = Control(int(c[0]), int(c[1]), int(c[2]), int(c[3]), [int(x) for x in c[8:8 + int(c[7])]])
-            bg_pose = s.bg_pose.cpu().numpy()
+            if self.rank != 0:
+                # (the one host wait the object ranks need: what to drop / spawn, and the background's pose; rank 0 wrote both itself)
+                c = self.ctl.cpu().numpy()
+                ctl = Control(int(c[0]), int(c[1]), int(c[2]), int(c[3]), [int(x) for x in c[8:8 + int(c[7])]])
+                bg_pose = s.bg_pose.cpu().numpy()
         s.phase_fuse(ctl, bg_pose, self.cfg, weight_multiplier, timestamp, first)
-        if not first and ctl.has_new:
-            # the list that the NEXT frame's projection orders by includes the new model
-            c = self.ctl.cpu().numpy()
-            n = int(c[7])
-            self.ctl[8 + n] = ctl.new_id
-            self.ctl[7] = n + 1
-        elif first:
-            self.ctl[7] = 1
+        # the list that the NEXT frame's projection orders by includes the new model
+        self._order = list(ctl.order) + ([ctl.new_id] if (not first and ctl.has_new) else [])
         self.frame += 1
         return ctl

@@ -129,6 +129,26 @@ class _Lib:
         c.log.append(("segment", n_models, int(next_id), int(allow_new), hn, nc))
         return 0
 
+    def mf_perform_segmentation_begin(self, h, mask_ptr, cid_ptr, n_masks, ids_ptr, cls_ptr, n_models, next_id, allow_new):
+        hn, nc = C.c_int32(0), C.c_int32(-1)
+        self.mf_perform_segmentation(h, mask_ptr, cid_ptr, n_masks, ids_ptr, cls_ptr, n_models, next_id, allow_new, C.byref(hn), C.byref(nc))
+        self._pending = (hn.value, nc.value)
+        return 0
+
+    def mf_perform_segmentation_end(self, h, has_new, new_cls):
+        has_new._obj.value, new_cls._obj.value = self._pending
+        return 0
+
+    def mf_fuse_background(self, h, weight):
+        c = self.c
+        v = _ModelView(c, 0)
+        v.predictIndices(c.tick, c.max_depth_processed, c.time_delta)
+        v.fuse(c.tick, c.depth_cutoff, weight)
+        v.predictIndices(c.tick, c.max_depth_processed, c.time_delta)
+        v.clean(c.tick, c.time_delta, c.max_depth_processed)
+        c.bg_fused_tick = c.tick
+        return 0
+
     def mf_export_segmentation_dev(self, h, ptr):
         _arr(ptr, self.c.P, C.c_uint8, np.uint8)[:] = self.c.labels
         return 0
@@ -161,6 +181,9 @@ class FakeMaskFusion:
         self.proj = np.zeros(self.P, np.uint8)
         self.log = []
         self.frames = 0
+        self.tick = 1
+        self.bg_fused_tick = 0
+        self.max_depth_processed, self.depth_cutoff, self.time_delta = 20.0, 3.0, 200    # the context's configuration (sharded.default_cfg)
         self._L = _Lib(self)
         self._h = 0
 
@@ -200,4 +223,43 @@ class FakeMaskFusion:
     def endFrame(self, timestamp=0):
         for m in self.models:
             m.age += 1
+        self.tick += 1
         self.log.append(("end", int(timestamp), tuple(m.id for m in self.models)))
+
+    # ---- the loop-level calls (mf_track_models / mf_fuse_models / mf_predict_models): the same per-model steps, logged one by one ----
+    def modelIDs(self):
+        return [m.id for m in self.models]
+
+    def modelsStateDevice(self, ptr, capacity):
+        assert capacity >= len(self.models)
+        for i in range(len(self.models)):
+            self.modelStateDevice(i, int(ptr) + 64 * i)
+
+    def trackModels(self, firstModel=0, trackAllModels=True):
+        for i in range(firstModel, len(self.models)):
+            if i == 0 or (not self.models[i].static) or trackAllModels:
+                _ModelView(self, i).performTracking(False, False, 100.0, True, False, False, self.max_depth_processed, 0, i == 0)
+            else:
+                self._L.mf_model_update_static_pose(self._h, i)
+
+    def fuseModels(self, firstModel=0, weightMultiplier=1.0, spawnedModel=-1):
+        t = self.tick
+        if spawnedModel > 0:
+            nm = _ModelView(self, spawnedModel)
+            nm.predictIndices(t, self.max_depth_processed, self.time_delta)
+            nm.fuse(t, self.max_depth_processed, 100.0)
+            nm.clean(t, self.time_delta, self.max_depth_processed)
+        for i in range(firstModel, len(self.models)):
+            if i == 0 and self.bg_fused_tick == t:
+                continue                      # mf_fuse_background has run for this frame
+            m = _ModelView(self, i)
+            m.predictIndices(t, self.max_depth_processed, self.time_delta)
+            m.fuse(t, self.depth_cutoff, weightMultiplier)
+            m.predictIndices(t, self.max_depth_processed, self.time_delta)
+            m.clean(t, self.time_delta, self.max_depth_processed)
+
+    def predictModels(self, firstModel=0, timestamp=0):
+        t = self.tick
+        for i in range(firstModel, len(self.models)):
+            _ModelView(self, i).combinedPredict(self.max_depth_processed, t, t, self.time_delta)
+        self.endFrame(timestamp)
