@@ -157,6 +157,17 @@ __device__ __forceinline__ float3 get_normal_forward(const float* depth, int W, 
 // ---- pose math shared by the odometry and the object-model kernels ----
 // fp64 reciprocal / square root from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~2^-26) plus Newton steps: ~8 instructions
 // instead of the ~40 of an IEEE division; last-ulp differences are irrelevant for a Gauss-Newton step.
+// Image kernels: workgroup b of a launch runs on XCD b % 8 (observed placement: used for speed, never for correctness), and every XCD has
+// its own 4 MiB L2.  A row-major tile order therefore deals neighbouring tiles -- which share their halo rows -- to eight different L2s,
+// and each L2 ends up fetching the whole image from HBM (k_bilateral: 9.5 MB fetched for a 1.2 MB image).  This maps the launch's linear
+// workgroup id to a tile index such that XCD k owns the k-th CONTIGUOUS eighth of the tile list; launch 8 * ceil(tiles / 8) workgroups
+// and skip indices >= tiles.
+__device__ __forceinline__ int xcd_contiguous_tile(int linear_wg, int tiles) {
+    const int per = (tiles + 7) >> 3;
+    return (linear_wg & 7) * per + (linear_wg >> 3);
+}
+__host__ __device__ inline int xcd_padded_grid(int tiles) { return ((tiles + 7) >> 3) << 3; }
+
 __device__ __forceinline__ double rcp_d(double x) {
     double r = __builtin_amdgcn_rcp(x);
     r = r * (2.0 - x * r);

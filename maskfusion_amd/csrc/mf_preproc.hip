@@ -36,7 +36,10 @@ constexpr float kBOutside = 1e15f;
 __global__ __launch_bounds__(256) void k_bilateral(const float* __restrict__ depth, float* __restrict__ out, int W, int H) {
     __shared__ float tile[kBLdsH * kBLdsW];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int x0 = blockIdx.x * kBTileW, y0 = blockIdx.y * kBTileH;
+    const int tiles_x = (W + kBTileW - 1) / kBTileW, tiles = tiles_x * ((H + kBTileH - 1) / kBTileH);
+    const int tile_id = xcd_contiguous_tile(blockIdx.x, tiles);   // each XCD's L2 fetches its own band of the image (+ halo), not all of it
+    if (tile_id >= tiles) return;
+    const int x0 = (tile_id % tiles_x) * kBTileW, y0 = (tile_id / tiles_x) * kBTileH;
     // stage.  The shader clips its loops at the image border; here an out-of-image tap holds kBOutside = 1e15: its range term is
     // -8e32, 2^that is exactly 0, and it adds tmp * 0 = +0 to both sums -- the same bits as skipping it, without a compare, an exec
     // mask and a branch per tap (round 3: the 169 branches also kept every ds_read on its own s_waitcnt).
@@ -74,8 +77,8 @@ __global__ __launch_bounds__(256) void k_bilateral(const float* __restrict__ dep
 }
 
 void launch_bilateral(const float* depth, float* out, int W, int H, hipStream_t s) {
-    dim3 grid((W + kBTileW - 1) / kBTileW, (H + kBTileH - 1) / kBTileH);
-    hipLaunchKernelGGL(k_bilateral, grid, dim3(256), 0, s, depth, out, W, H);
+    const int tiles = ((W + kBTileW - 1) / kBTileW) * ((H + kBTileH - 1) / kBTileH);
+    hipLaunchKernelGGL(k_bilateral, dim3(xcd_padded_grid(tiles)), dim3(256), 0, s, depth, out, W, H);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -209,7 +212,10 @@ __global__ __launch_bounds__(256) void k_frame_pyramid(const FramePyrArgs a) {
     __shared__ float s1[kFpL1 * kFpL1];
     __shared__ float s2[kFpL2 * kFpL2];
     const int W0 = a.W, H0 = a.H, W1 = W0 >> 1, H1 = H0 >> 1, W2 = W0 >> 2, H2 = H0 >> 2;
-    const int X2 = blockIdx.x * kFpT2, Y2 = blockIdx.y * kFpT2;  // tile origin at level 2
+    const int tiles_x = (W2 + kFpT2 - 1) / kFpT2, tiles = tiles_x * ((H2 + kFpT2 - 1) / kFpT2);
+    const int tile = xcd_contiguous_tile(blockIdx.x, tiles);     // XCD k works on the k-th band of tile rows (mf_device.h)
+    if (tile >= tiles) return;
+    const int X2 = (tile % tiles_x) * kFpT2, Y2 = (tile / tiles_x) * kFpT2;  // tile origin at level 2
     const int ox1 = 2 * X2 - 2, oy1 = 2 * Y2 - 2;                // LDS origins (may be negative)
     const int ox0 = 2 * ox1 - 2, oy0 = 2 * oy1 - 2;
     const int tid = threadIdx.x;
@@ -254,8 +260,8 @@ void launch_frame_pyramid(const float* depth, float* const vmap[3], float* const
     FramePyrArgs a;
     a.depth = depth; a.W = W; a.H = H; a.k = k; a.cutoff = cutoff;
     for (int i = 0; i < 3; ++i) { a.vmap[i] = vmap[i]; a.nmap[i] = nmap[i]; }
-    dim3 grid(((W >> 2) + kFpT2 - 1) / kFpT2, ((H >> 2) + kFpT2 - 1) / kFpT2);
-    hipLaunchKernelGGL(k_frame_pyramid, grid, dim3(256), 0, s, a);
+    const int tiles = (((W >> 2) + kFpT2 - 1) / kFpT2) * (((H >> 2) + kFpT2 - 1) / kFpT2);
+    hipLaunchKernelGGL(k_frame_pyramid, dim3(xcd_padded_grid(tiles)), dim3(256), 0, s, a);
 }
 
 }  // namespace mf
