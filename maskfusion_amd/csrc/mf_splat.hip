@@ -60,6 +60,10 @@ __device__ __forceinline__ bool splat_setup(const Surfels& src, int i, float tim
     return true;
 }
 
+// lanes that share one sprite in the tile z-test (1, 2, 4, 8, 16; mf_set_param "spriteLanes"): process-wide, an A/B switch for measurements
+static int g_sprite_lanes = 4;
+void set_sprite_lanes(int n) { g_sprite_lanes = (n == 1 || n == 2 || n == 8 || n == 16) ? n : 4; }
+
 struct BinArgs {
     Surfels src; const FrameDev* frame; const PoseDev* pose; int W, H; Intr k; float maxDepth, confThreshold; int timeDelta;
     int tilesX, tilesY;
@@ -144,7 +148,7 @@ struct TileArgs {
 // The z-test of one 16x16 tile in LDS, shared by the prediction (payload = surfel index) and the global projection (payload =
 // model order / id): rays of the tile's pixels, the tile's sprite list (or, after a list overflow, every sprite box of the map),
 // ds_min_u64 per covered pixel.  On return s_key[pixel of the tile] holds the winning key (all threads have passed a barrier).
-template <bool kIndexPayload>
+template <bool kIndexPayload, int kSpriteLanes>
 __device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* tile_count, const int* entries, int tile_cap,
                                            const FrameDev* frame, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                                            const short4* __restrict__ bbox, unsigned payload, unsigned long long* s_key, float4* s_ray,
@@ -165,7 +169,13 @@ __device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* ti
     const bool overflow = s_range[0] > tile_cap;   // more sprites than list slots (the reference has no such limit): scan every box
     const int cnt = overflow ? frame->count : s_range[0];
     const int* __restrict__ list = entries + (size_t)tile * tile_cap;
-    for (int e = threadIdx.x; e < cnt; e += 256) {
+    // kSpriteLanes neighbouring lanes share one sprite and take every kSpriteLanes-th pixel of its clipped box (with one lane per sprite a
+    // wavefront runs as long as its largest box).  The lanes read the same list entry / records (one request) and the z-test is order
+    // independent, so the keys are the same bits.  Measured on MI355X (profiles/r03h_*): prediction stage 65.5 us with 1 lane,
+    // 62.2 / 62.6 with 2 / 4, 66.3 with 8, 81.4 with 16 -- the boxes are small (4.3 px a side on the bench stream), and the pass is half
+    // VALU (two IEEE divisions' worth per pixel test), half gather latency; 4 is the default.
+    const int sub = threadIdx.x & (kSpriteLanes - 1);
+    for (int e = threadIdx.x / kSpriteLanes; e < cnt; e += 256 / kSpriteLanes) {
         const int i = overflow ? e : list[e];
         const short4 bb = bbox[i];
         const int x0 = max((int)bb.x, tx0), x1 = min((int)bb.y, tx0 + kTile - 1);
@@ -174,18 +184,21 @@ __device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* ti
         const float4 r0 = rec0[i], r1 = rec1[i];
         SplatSetup su;
         su.h = f3(r0.x, r0.y, r0.z); su.sqrRad = r0.w; su.nrm = f3(r1.x, r1.y, r1.z); su.pn = r1.w;
-        for (int py = y0; py <= y1; ++py) {
-            for (int px = x0; px <= x1; ++px) {
-                const int lp = (py - ty0) * kTile + (px - tx0);
-                const float4 r4 = s_ray[lp];
-                const float3 l = f3(r4.x, r4.y, r4.z);
-                const float3 cp = l * (su.pn / dot3(l, su.nrm));
-                const float3 diff = cp - su.h;
-                if (!(dot3(diff, diff) <= su.sqrRad)) continue;
-                if (!(cp.z > 0.f)) continue;
-                const unsigned long long key = ((unsigned long long)__float_as_uint(cp.z) << 32) | (kIndexPayload ? (unsigned)i : payload);
-                atomicMin(&s_key[lp], key);
-            }
+        const int w = x1 - x0 + 1, area = w * (y1 - y0 + 1);
+        int cx = sub, cy = 0;
+        while (cx >= w) { cx -= w; ++cy; }
+        for (int q = sub; q < area; q += kSpriteLanes) {
+            const int lp = (y0 + cy - ty0) * kTile + (x0 + cx - tx0);
+            cx += kSpriteLanes;
+            while (cx >= w) { cx -= w; ++cy; }
+            const float4 r4 = s_ray[lp];
+            const float3 l = f3(r4.x, r4.y, r4.z);
+            const float3 cp = l * (su.pn / dot3(l, su.nrm));
+            const float3 diff = cp - su.h;
+            if (!(dot3(diff, diff) <= su.sqrRad)) continue;
+            if (!(cp.z > 0.f)) continue;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(cp.z) << 32) | (kIndexPayload ? (unsigned)i : payload);
+            atomicMin(&s_key[lp], key);   // (looking at s_key before the atomic -- most sprites lose -- was measured: no gain)
         }
     }
     __syncthreads();
@@ -193,19 +206,24 @@ __device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* ti
 
 // Pass 3: one 256-thread workgroup per 16x16 tile: LDS z-test over the tile's surfel list, then the fragment outputs
 // (combo_splat.frag) of every pixel of the tile.
+template <int kSpriteLanes>
 __global__ __launch_bounds__(256) void k_splat_tile(const TileArgs a) {
     __shared__ unsigned long long s_key[kTile * kTile];
     __shared__ float4 s_ray[kTile * kTile];
     __shared__ int s_range[1];
     __shared__ int s_cover;
-    const int tile = blockIdx.x;
+    // XCD k draws the k-th contiguous eighth of the tile list (mf_device.h): a sprite overlaps 1.8 tiles on average, and neighbouring
+    // tiles now find its records in the same L2.  The grid is padded to a multiple of 8; a padding workgroup draws nothing but still
+    // takes its ticket below.
+    const int tile = xcd_contiguous_tile(blockIdx.x, a.tilesX * a.tilesY);
+    const bool live = tile < a.tilesX * a.tilesY;
     const int tx0 = (tile % a.tilesX) * kTile, ty0 = (tile / a.tilesX) * kTile;
     const Intr k = a.k;
     if (threadIdx.x == 0) s_cover = 0;   // (ordered before its use by the barriers inside tile_ztest)
-    tile_ztest<true>(tile, a.tilesX, k, a.tile_count, a.entries, a.tile_cap, a.frame, a.rec0, a.rec1, a.bbox, 0u, s_key, s_ray, s_range);
+    if (live) tile_ztest<true, kSpriteLanes>(tile, a.tilesX, k, a.tile_count, a.entries, a.tile_cap, a.frame, a.rec0, a.rec1, a.bbox, 0u, s_key, s_ray, s_range);
     const int px = tx0 + (threadIdx.x & (kTile - 1)), py = ty0 + (threadIdx.x >> 4);
     int covered = 0;   // this pixel is one of the 20x down-sampled samples of MaskFusion::requiresFillIn and carries a colour
-    if (px < a.W && py < a.H) {
+    if (live && px < a.W && py < a.H) {
       const int p = py * a.W + px;
       const unsigned long long key = s_key[threadIdx.x];
       if (key == kEmptyKey) {
@@ -273,17 +291,19 @@ __global__ __launch_bounds__(256) void k_splat_tile(const TileArgs a) {
 // as k_global_scatter (mf_segment.hip), which stays for small (object) models: one global atomic per covered pixel is memory-side
 // work (see the header) and cost ~170 us per frame for a 250 k-surfel background model against ~25 us here.
 struct GlobalTileArgs {
-    const FrameDev* frame; int W, H; Intr k; int tilesX;
+    const FrameDev* frame; int W, H; Intr k; int tilesX, tilesY;
     int* tile_count; const int* entries; int tile_cap;
     const float4* rec0; const float4* rec1; const short4* bbox;
     unsigned payload; unsigned long long* keys;
 };
+template <int kSpriteLanes>
 __global__ __launch_bounds__(256) void k_global_tile(const GlobalTileArgs a) {
     __shared__ unsigned long long s_key[kTile * kTile];
     __shared__ float4 s_ray[kTile * kTile];
     __shared__ int s_range[1];
-    const int tile = blockIdx.x;
-    tile_ztest<false>(tile, a.tilesX, a.k, a.tile_count, a.entries, a.tile_cap, a.frame, a.rec0, a.rec1, a.bbox, a.payload, s_key, s_ray, s_range);
+    const int tile = xcd_contiguous_tile(blockIdx.x, a.tilesX * a.tilesY);
+    if (tile >= a.tilesX * a.tilesY) return;
+    tile_ztest<false, kSpriteLanes>(tile, a.tilesX, a.k, a.tile_count, a.entries, a.tile_cap, a.frame, a.rec0, a.rec1, a.bbox, a.payload, s_key, s_ray, s_range);
     const int px = (tile % a.tilesX) * kTile + (threadIdx.x & (kTile - 1)), py = (tile / a.tilesX) * kTile + (threadIdx.x >> 4);
     if (px >= a.W || py >= a.H) return;
     const unsigned long long key = s_key[threadIdx.x];
@@ -307,10 +327,16 @@ int launch_global_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W
     const int nblocks = min(512, (src.cap + 2 * kBinThreads - 1) / (2 * kBinThreads));
     hipLaunchKernelGGL(k_splat_bin, dim3(nblocks), dim3(kBinThreads), (size_t)2 * nt * sizeof(int), s, b);
     GlobalTileArgs t;
-    t.frame = frame; t.W = W; t.H = H; t.k = k; t.tilesX = tilesX; t.tile_count = tile_count; t.entries = entries; t.tile_cap = b.tile_cap;
+    t.frame = frame; t.W = W; t.H = H; t.k = k; t.tilesX = tilesX; t.tilesY = tilesY; t.tile_count = tile_count; t.entries = entries; t.tile_cap = b.tile_cap;
     t.rec0 = rec0; t.rec1 = rec1; t.bbox = reinterpret_cast<const short4*>(bbox);
     t.payload = ((unsigned)order << 8) | ((unsigned)id & 255u); t.keys = keys;
-    hipLaunchKernelGGL(k_global_tile, dim3(nt), dim3(256), 0, s, t);
+    switch (g_sprite_lanes) {
+        case 1: hipLaunchKernelGGL(k_global_tile<1>, dim3(xcd_padded_grid(nt)), dim3(256), 0, s, t); break;
+        case 2: hipLaunchKernelGGL(k_global_tile<2>, dim3(xcd_padded_grid(nt)), dim3(256), 0, s, t); break;
+        case 8: hipLaunchKernelGGL(k_global_tile<8>, dim3(xcd_padded_grid(nt)), dim3(256), 0, s, t); break;
+        case 16: hipLaunchKernelGGL(k_global_tile<16>, dim3(xcd_padded_grid(nt)), dim3(256), 0, s, t); break;
+        default: hipLaunchKernelGGL(k_global_tile<4>, dim3(xcd_padded_grid(nt)), dim3(256), 0, s, t); break;
+    }
     return 0;
 }
 
@@ -340,7 +366,13 @@ int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W,
     t.fillPassthrough = fillPassthrough;
     t.advance = advance ? 1 : 0;
     t.adv = advance ? *advance : FrameAdvance{nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(k_splat_tile, dim3(nt), dim3(256), 0, s, t);
+    switch (g_sprite_lanes) {
+        case 1: hipLaunchKernelGGL(k_splat_tile<1>, dim3(xcd_padded_grid(nt)), dim3(256), 0, s, t); break;
+        case 2: hipLaunchKernelGGL(k_splat_tile<2>, dim3(xcd_padded_grid(nt)), dim3(256), 0, s, t); break;
+        case 8: hipLaunchKernelGGL(k_splat_tile<8>, dim3(xcd_padded_grid(nt)), dim3(256), 0, s, t); break;
+        case 16: hipLaunchKernelGGL(k_splat_tile<16>, dim3(xcd_padded_grid(nt)), dim3(256), 0, s, t); break;
+        default: hipLaunchKernelGGL(k_splat_tile<4>, dim3(xcd_padded_grid(nt)), dim3(256), 0, s, t); break;
+    }
     return 0;
 }
 
