@@ -198,6 +198,7 @@ struct mf_ctx {
     uint8_t* d_cand_op = nullptr; float4* d_cand_rec = nullptr; int* d_upd_first = nullptr;
     uint8_t* d_flags = nullptr; float* d_newconf = nullptr; int* d_block_counts = nullptr;
     float* d_icp_log = nullptr; unsigned long long* d_icp_prof = nullptr;
+    unsigned long long* d_splat_prof = nullptr; bool splat_prof_on = false;   // "splatProfile": [tiles][8] stamps of the background's tile pass
     // multi-model coupling
     float* d_edge = nullptr; uint8_t* d_bin = nullptr; uint8_t* d_tmp_u8 = nullptr; uint8_t* d_proj_ids = nullptr;
     uint8_t* h_bin = nullptr; uint8_t* h_ids = nullptr; float* h_depth = nullptr; uint8_t* h_mask = nullptr; uint8_t* h_full = nullptr;
@@ -497,6 +498,7 @@ extern "C" void mf_destroy(mf_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->models.clear();
     for (void* p : c->allocs) (void)hipFree(p);
+    if (c->d_splat_prof) (void)hipFree(c->d_splat_prof);
     for (void* p : c->host_allocs) (void)hipHostFree(p);
     for (int i = 0; i <= MF_N_TIMINGS; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -740,7 +742,8 @@ static void enqueue_predict(mf_ctx* c, ModelState& m, const FrameAdvance* advanc
         if (launch_splat_tiled(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, c->cfg.max_depth_processed, m.confThr,
                                c->cfg.time_delta, c->d_tile_count, c->d_tile_entries, c->tile_entries_cap, c->d_splat_rec0, c->d_splat_rec1,
                                c->d_splat_bbox, m.d_predV, m.d_predN, m.d_predImage, m.d_predTime, c->cur_rgb,
-                               gray ? m.d_predGray : nullptr, gray ? m.d_fillGray : nullptr, c->stream, advance, c->ftf_rgb ? 1 : 0) == 0)
+                               gray ? m.d_predGray : nullptr, gray ? m.d_fillGray : nullptr, c->stream, advance, c->ftf_rgb ? 1 : 0,
+                               (c->splat_prof_on && m.id == 0) ? c->d_splat_prof : nullptr) == 0)
             return;
     }
     launch_splat_scatter(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, c->cfg.max_depth_processed, m.confThr,
@@ -2049,6 +2052,13 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!c || !key) return MF_EINVAL;
     if (!strcmp(key, "timings")) { c->timings_on = value != 0; return MF_OK; }
     if (!strcmp(key, "icpProfile")) { c->icp_prof_on = value != 0; return MF_OK; }
+    if (!strcmp(key, "splatProfile")) {   // per-tile shader-clock stamps of k_splat_tile (tools/splat_prof.py); debug tap "splat_prof"
+        if (value != 0 && !c->d_splat_prof) {
+            if (hipMalloc(&c->d_splat_prof, splat_tiles_scratch_ints(c->W, c->H) * 8 * sizeof(unsigned long long)) != hipSuccess) return MF_ENOMEM;
+        }
+        c->splat_prof_on = value != 0;
+        return MF_OK;
+    }
     if (!strcmp(key, "gpuLabels")) { c->gpu_labels = value != 0; return MF_OK; }   // 0: host label stage (specification)
     if (!strcmp(key, "splatTiles")) { c->splat_tiles = value != 0; return MF_OK; }
     if (!strcmp(key, "splatTileEntries")) {   // test knob: shrink the tile lists (never beyond what was allocated) to force the overflow path
@@ -2074,6 +2084,7 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!strcmp(key, "cleanLiteralWindow")) { c->clean_literal = value != 0; return MF_OK; }   // 0: the exact-arithmetic 4 x 4 window
     if (!strcmp(key, "earlyBackgroundFusion")) { c->early_bg_fusion = value != 0; return MF_OK; }
     if (!strcmp(key, "modelApiPackedIndex")) { c->model_api_packed = value != 0; return MF_OK; }   // 0: scatter + resolve form (specification)
+    if (!strcmp(key, "tileThreads")) { set_tile_threads((int)value); return MF_OK; }   // A/B: threads per tile workgroup of the tile passes
     if (!strcmp(key, "spriteLanes")) { set_sprite_lanes((int)value); return MF_OK; }   // A/B: lanes per sprite in the tile z-test (default 4)
     if (!strcmp(key, "overlapPreprocessing")) {
         (void)hipStreamSynchronize(c->stream_pre);
@@ -2165,6 +2176,10 @@ static int debug_read_impl(mf_ctx* c, ModelState& mdl, const char* what, void* o
     else if (w == "clean_newconf") { src = c->d_newconf; bytes = ((size_t)c->cap_max + P) * 4; variable = true; }
     else if (w == "icp_log") { src = c->d_icp_log; bytes = 19 * 32 * 4; }
     else if (w == "icp_prof") { src = c->d_icp_prof; bytes = 19 * 8 * 8; }
+    else if (w == "splat_prof") {
+        if (!c->d_splat_prof) { c->err = "splat_prof: switch splatProfile on first"; return MF_ESTATE; }
+        src = c->d_splat_prof; bytes = splat_tiles_scratch_ints(c->W, c->H) * 8 * 8;
+    }
     else if (w == "edge_map") { src = c->d_edge; bytes = P * 4; }
     else if (w == "edge_binary") { src = c->d_bin; bytes = P; }
     else if (w == "projected_ids") { src = c->d_proj_ids; bytes = P; }

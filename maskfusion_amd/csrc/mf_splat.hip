@@ -63,6 +63,13 @@ __device__ __forceinline__ bool splat_setup(const Surfels& src, int i, float tim
 // lanes that share one sprite in the tile z-test (1, 2, 4, 8, 16; mf_set_param "spriteLanes"): process-wide, an A/B switch for measurements
 static int g_sprite_lanes = 4;
 void set_sprite_lanes(int n) { g_sprite_lanes = (n == 1 || n == 2 || n == 8 || n == 16) ? n : 4; }
+// threads per tile workgroup (256, 512, 1024; "tileThreads"): a tile has 256 pixels, the threads beyond them only walk the sprite list.
+// 1200 tiles of 256 threads are 4.7 wavefronts per SIMD on 256 CUs -- too few to hide the list's dependent gathers and the division
+// chain of the pixel test (tools/splat_prof.py: a tile workgroup lives ~32 k cycles, ~4 k of them issuing)
+// Measured (profiles/r03k_*, prediction stage incl. binning): 256 threads 62.6 us, 512 threads 58.0 us, 1024 threads 65.9 us (4 lanes per
+// sprite each) -- 512 is the default.
+static int g_tile_threads = 512;
+void set_tile_threads(int n) { g_tile_threads = (n == 256 || n == 1024) ? n : 512; }
 
 struct BinArgs {
     Surfels src; const FrameDev* frame; const PoseDev* pose; int W, H; Intr k; float maxDepth, confThreshold; int timeDelta;
@@ -143,6 +150,7 @@ struct TileArgs {
     const uint8_t* rgb; uint8_t* predGray; uint8_t* fillGray;
     int fillPassthrough;             // fill_rgb.frag's `passthrough` (frameToFrameRGB, Model.cpp:981): the fill-in image is the raw frame everywhere
     int advance; FrameAdvance adv;   // advance != 0: the last workgroup also runs the end-of-frame bookkeeping (k_frame_advance)
+    unsigned long long* prof;        // optional ("splatProfile"): [tiles][8] shader-clock stamps of thread 0 + the tile's list length
 };
 
 // The z-test of one 16x16 tile in LDS, shared by the prediction (payload = surfel index) and the global projection (payload =
@@ -152,8 +160,9 @@ template <bool kIndexPayload, int kSpriteLanes>
 __device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* tile_count, const int* entries, int tile_cap,
                                            const FrameDev* frame, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                                            const short4* __restrict__ bbox, unsigned payload, unsigned long long* s_key, float4* s_ray,
-                                           int* s_range) {
+                                           int* s_range, unsigned long long* stamp = nullptr) {
     const int tx0 = (tile % tilesX) * kTile, ty0 = (tile / tilesX) * kTile;
+    if (threadIdx.x < kTile * kTile) {
     s_key[threadIdx.x] = kEmptyKey;
     {   // the viewing ray of every pixel of the tile, once (combo_splat.frag:40-42); the per-surfel loops below re-used to
         // spend two thirds of their instructions recomputing it (two divisions + a normalisation per covered pixel)
@@ -161,11 +170,13 @@ __device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* ti
         const float3 l = normalize_gl(f3((fcx - k.cx) / k.fx, (fcy - k.cy) / k.fy, 1.0f));
         s_ray[threadIdx.x] = make_float4(l.x, l.y, l.z, 0.f);
     }
+    }
     if (threadIdx.x == 0) {
         s_range[0] = tile_count[tile];
         tile_count[tile] = 0;   // consumed: the next binning pass starts from zero
     }
     __syncthreads();
+    if (stamp) { stamp[1] = __builtin_amdgcn_s_memtime(); stamp[6] = (unsigned long long)s_range[0]; }
     const bool overflow = s_range[0] > tile_cap;   // more sprites than list slots (the reference has no such limit): scan every box
     const int cnt = overflow ? frame->count : s_range[0];
     const int* __restrict__ list = entries + (size_t)tile * tile_cap;
@@ -174,8 +185,9 @@ __device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* ti
     // independent, so the keys are the same bits.  Measured on MI355X (profiles/r03h_*): prediction stage 65.5 us with 1 lane,
     // 62.2 / 62.6 with 2 / 4, 66.3 with 8, 81.4 with 16 -- the boxes are small (4.3 px a side on the bench stream), and the pass is half
     // VALU (two IEEE divisions' worth per pixel test), half gather latency; 4 is the default.
-    const int sub = threadIdx.x & (kSpriteLanes - 1);
-    for (int e = threadIdx.x / kSpriteLanes; e < cnt; e += 256 / kSpriteLanes) {
+    constexpr int kLX = kSpriteLanes >= 8 ? 4 : (kSpriteLanes >= 2 ? 2 : 1), kLY = kSpriteLanes / kLX;
+    const int sub = threadIdx.x & (kSpriteLanes - 1), sx = sub % kLX, sy = sub / kLX;
+    for (int e = threadIdx.x / kSpriteLanes; e < cnt; e += (int)blockDim.x / kSpriteLanes) {   // blockDim.x = 256, 512 or 1024 ("tileThreads")
         const int i = overflow ? e : list[e];
         const short4 bb = bbox[i];
         const int x0 = max((int)bb.x, tx0), x1 = min((int)bb.y, tx0 + kTile - 1);
@@ -184,30 +196,35 @@ __device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* ti
         const float4 r0 = rec0[i], r1 = rec1[i];
         SplatSetup su;
         su.h = f3(r0.x, r0.y, r0.z); su.sqrRad = r0.w; su.nrm = f3(r1.x, r1.y, r1.z); su.pn = r1.w;
-        const int w = x1 - x0 + 1, area = w * (y1 - y0 + 1);
-        int cx = sub, cy = 0;
-        while (cx >= w) { cx -= w; ++cy; }
-        for (int q = sub; q < area; q += kSpriteLanes) {
-            const int lp = (y0 + cy - ty0) * kTile + (x0 + cx - tx0);
-            cx += kSpriteLanes;
-            while (cx >= w) { cx -= w; ++cy; }
-            const float4 r4 = s_ray[lp];
-            const float3 l = f3(r4.x, r4.y, r4.z);
-            const float3 cp = l * (su.pn / dot3(l, su.nrm));
-            const float3 diff = cp - su.h;
-            if (!(dot3(diff, diff) <= su.sqrRad)) continue;
-            if (!(cp.z > 0.f)) continue;
-            const unsigned long long key = ((unsigned long long)__float_as_uint(cp.z) << 32) | (kIndexPayload ? (unsigned)i : payload);
-            atomicMin(&s_key[lp], key);   // (looking at s_key before the atomic -- most sprites lose -- was measured: no gain)
+        // the kSpriteLanes lanes of a sprite form a kLX x kLY block that strides over the box: two plain nested loops (a flat pixel counter
+        // needed a wrap-around loop per pixel), and the next pixel's ray is on its way from LDS while this one is tested
+        for (int py = y0 + sy; py <= y1; py += kLY) {
+            const int row = (py - ty0) * kTile - tx0;
+            int px = x0 + sx;
+            float4 nxt = s_ray[row + min(px, x1)];
+            for (; px <= x1; px += kLX) {
+                const int lp = row + px;
+                const float4 r4 = nxt;
+                nxt = s_ray[row + min(px + kLX, x1)];
+                const float3 l = f3(r4.x, r4.y, r4.z);
+                const float3 cp = l * (su.pn / dot3(l, su.nrm));
+                const float3 diff = cp - su.h;
+                if (!(dot3(diff, diff) <= su.sqrRad)) continue;
+                if (!(cp.z > 0.f)) continue;
+                const unsigned long long key = ((unsigned long long)__float_as_uint(cp.z) << 32) | (kIndexPayload ? (unsigned)i : payload);
+                atomicMin(&s_key[lp], key);   // (looking at s_key before the atomic -- most sprites lose -- was measured: no gain)
+            }
         }
     }
+    if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();
     __syncthreads();
+    if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
 }
 
-// Pass 3: one 256-thread workgroup per 16x16 tile: LDS z-test over the tile's surfel list, then the fragment outputs
+// Pass 3: one workgroup (512 threads by default, the first 256 own the pixels) per 16x16 tile: LDS z-test over the tile's surfel list, then the fragment outputs
 // (combo_splat.frag) of every pixel of the tile.
 template <int kSpriteLanes>
-__global__ __launch_bounds__(256) void k_splat_tile(const TileArgs a) {
+__global__ __launch_bounds__(1024) void k_splat_tile(const TileArgs a) {
     __shared__ unsigned long long s_key[kTile * kTile];
     __shared__ float4 s_ray[kTile * kTile];
     __shared__ int s_range[1];
@@ -220,10 +237,14 @@ __global__ __launch_bounds__(256) void k_splat_tile(const TileArgs a) {
     const int tx0 = (tile % a.tilesX) * kTile, ty0 = (tile / a.tilesX) * kTile;
     const Intr k = a.k;
     if (threadIdx.x == 0) s_cover = 0;   // (ordered before its use by the barriers inside tile_ztest)
-    if (live) tile_ztest<true, kSpriteLanes>(tile, a.tilesX, k, a.tile_count, a.entries, a.tile_cap, a.frame, a.rec0, a.rec1, a.bbox, 0u, s_key, s_ray, s_range);
+    unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool prof = a.prof != nullptr && live && threadIdx.x == 0;
+    if (prof) stamp[0] = __builtin_amdgcn_s_memtime();
+    if (live) tile_ztest<true, kSpriteLanes>(tile, a.tilesX, k, a.tile_count, a.entries, a.tile_cap, a.frame, a.rec0, a.rec1, a.bbox, 0u, s_key, s_ray, s_range,
+                                            prof ? stamp : nullptr);
     const int px = tx0 + (threadIdx.x & (kTile - 1)), py = ty0 + (threadIdx.x >> 4);
     int covered = 0;   // this pixel is one of the 20x down-sampled samples of MaskFusion::requiresFillIn and carries a colour
-    if (live && px < a.W && py < a.H) {
+    if (live && threadIdx.x < kTile * kTile && px < a.W && py < a.H) {   // (threads beyond the tile's 256 pixels only helped with the list)
       const int p = py * a.W + px;
       const unsigned long long key = s_key[threadIdx.x];
       if (key == kEmptyKey) {
@@ -260,6 +281,12 @@ __global__ __launch_bounds__(256) void k_splat_tile(const TileArgs a) {
     // the workgroup that draws the last ticket holds the launch's total without any ordering between workgroups).  That workgroup
     // hands the total on: to frame->cover for a stand-alone prediction, or straight into the end-of-frame bookkeeping that used to be
     // its own single-thread launch (k_frame_advance, ~4.7 us per model and frame).  Nothing else in this launch reads what it writes.
+    if (prof) {
+        stamp[4] = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp[5] = __builtin_amdgcn_s_memtime();
+        for (int q = 0; q < 8; ++q) a.prof[(size_t)tile * 8 + q] = stamp[q];
+    }
     if (covered) atomicAdd(&s_cover, 1);   // at most two such pixels per 16x16 tile
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -297,7 +324,7 @@ struct GlobalTileArgs {
     unsigned payload; unsigned long long* keys;
 };
 template <int kSpriteLanes>
-__global__ __launch_bounds__(256) void k_global_tile(const GlobalTileArgs a) {
+__global__ __launch_bounds__(1024) void k_global_tile(const GlobalTileArgs a) {
     __shared__ unsigned long long s_key[kTile * kTile];
     __shared__ float4 s_ray[kTile * kTile];
     __shared__ int s_range[1];
@@ -305,7 +332,7 @@ __global__ __launch_bounds__(256) void k_global_tile(const GlobalTileArgs a) {
     if (tile >= a.tilesX * a.tilesY) return;
     tile_ztest<false, kSpriteLanes>(tile, a.tilesX, a.k, a.tile_count, a.entries, a.tile_cap, a.frame, a.rec0, a.rec1, a.bbox, a.payload, s_key, s_ray, s_range);
     const int px = (tile % a.tilesX) * kTile + (threadIdx.x & (kTile - 1)), py = (tile / a.tilesX) * kTile + (threadIdx.x >> 4);
-    if (px >= a.W || py >= a.H) return;
+    if (threadIdx.x >= kTile * kTile || px >= a.W || py >= a.H) return;
     const unsigned long long key = s_key[threadIdx.x];
     if (key == kEmptyKey) return;
     const int p = py * a.W + px;
@@ -331,11 +358,11 @@ int launch_global_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W
     t.rec0 = rec0; t.rec1 = rec1; t.bbox = reinterpret_cast<const short4*>(bbox);
     t.payload = ((unsigned)order << 8) | ((unsigned)id & 255u); t.keys = keys;
     switch (g_sprite_lanes) {
-        case 1: hipLaunchKernelGGL(k_global_tile<1>, dim3(xcd_padded_grid(nt)), dim3(256), 0, s, t); break;
-        case 2: hipLaunchKernelGGL(k_global_tile<2>, dim3(xcd_padded_grid(nt)), dim3(256), 0, s, t); break;
-        case 8: hipLaunchKernelGGL(k_global_tile<8>, dim3(xcd_padded_grid(nt)), dim3(256), 0, s, t); break;
-        case 16: hipLaunchKernelGGL(k_global_tile<16>, dim3(xcd_padded_grid(nt)), dim3(256), 0, s, t); break;
-        default: hipLaunchKernelGGL(k_global_tile<4>, dim3(xcd_padded_grid(nt)), dim3(256), 0, s, t); break;
+        case 1: hipLaunchKernelGGL(k_global_tile<1>, dim3(xcd_padded_grid(nt)), dim3(g_tile_threads), 0, s, t); break;
+        case 2: hipLaunchKernelGGL(k_global_tile<2>, dim3(xcd_padded_grid(nt)), dim3(g_tile_threads), 0, s, t); break;
+        case 8: hipLaunchKernelGGL(k_global_tile<8>, dim3(xcd_padded_grid(nt)), dim3(g_tile_threads), 0, s, t); break;
+        case 16: hipLaunchKernelGGL(k_global_tile<16>, dim3(xcd_padded_grid(nt)), dim3(g_tile_threads), 0, s, t); break;
+        default: hipLaunchKernelGGL(k_global_tile<4>, dim3(xcd_padded_grid(nt)), dim3(g_tile_threads), 0, s, t); break;
     }
     return 0;
 }
@@ -345,7 +372,7 @@ size_t splat_tiles_scratch_ints(int W, int H) { return (size_t)((W + kTile - 1) 
 int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
                        int timeDelta, int* tile_count, int* entries, int entries_cap, float4* rec0, float4* rec1, void* bbox, float4* predV,
                        float4* predN, uchar4* predImage, uint16_t* predTime, const uint8_t* rgb, uint8_t* predGray, uint8_t* fillGray, hipStream_t s,
-                       const FrameAdvance* advance, int fillPassthrough) {
+                       const FrameAdvance* advance, int fillPassthrough, unsigned long long* prof) {
     const int tilesX = (W + kTile - 1) / kTile, tilesY = (H + kTile - 1) / kTile, nt = tilesX * tilesY;
     if (nt > kMaxTiles) return -1;
     BinArgs b;
@@ -364,14 +391,15 @@ int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W,
     t.predV = predV; t.predN = predN; t.predImage = predImage; t.predTime = predTime; t.rgb = rgb; t.predGray = predGray;
     t.fillGray = fillGray;
     t.fillPassthrough = fillPassthrough;
+    t.prof = prof;
     t.advance = advance ? 1 : 0;
     t.adv = advance ? *advance : FrameAdvance{nullptr, nullptr, nullptr};
     switch (g_sprite_lanes) {
-        case 1: hipLaunchKernelGGL(k_splat_tile<1>, dim3(xcd_padded_grid(nt)), dim3(256), 0, s, t); break;
-        case 2: hipLaunchKernelGGL(k_splat_tile<2>, dim3(xcd_padded_grid(nt)), dim3(256), 0, s, t); break;
-        case 8: hipLaunchKernelGGL(k_splat_tile<8>, dim3(xcd_padded_grid(nt)), dim3(256), 0, s, t); break;
-        case 16: hipLaunchKernelGGL(k_splat_tile<16>, dim3(xcd_padded_grid(nt)), dim3(256), 0, s, t); break;
-        default: hipLaunchKernelGGL(k_splat_tile<4>, dim3(xcd_padded_grid(nt)), dim3(256), 0, s, t); break;
+        case 1: hipLaunchKernelGGL(k_splat_tile<1>, dim3(xcd_padded_grid(nt)), dim3(g_tile_threads), 0, s, t); break;
+        case 2: hipLaunchKernelGGL(k_splat_tile<2>, dim3(xcd_padded_grid(nt)), dim3(g_tile_threads), 0, s, t); break;
+        case 8: hipLaunchKernelGGL(k_splat_tile<8>, dim3(xcd_padded_grid(nt)), dim3(g_tile_threads), 0, s, t); break;
+        case 16: hipLaunchKernelGGL(k_splat_tile<16>, dim3(xcd_padded_grid(nt)), dim3(g_tile_threads), 0, s, t); break;
+        default: hipLaunchKernelGGL(k_splat_tile<4>, dim3(xcd_padded_grid(nt)), dim3(g_tile_threads), 0, s, t); break;
     }
     return 0;
 }

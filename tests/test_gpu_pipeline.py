@@ -134,6 +134,41 @@ def test_tiled_splat_equals_scatter_form(hip):
     assert np.array_equal(a["pose"], b["pose"]) and a["count"] == b["count"] and a["stats"] == b["stats"]
 
 
+def test_tile_pass_launch_shapes_change_nothing(hip):
+    """The tile passes' launch shape -- lanes per sprite (1..16) and threads per tile workgroup (256 / 512 / 1024), mf_set_param
+    "spriteLanes" / "tileThreads" -- only changes who tests which pixel: the LDS z-test is order independent, so every shape leaves the
+    prediction, the pose and the map bit-identical to the scatter form's (the executable specification)."""
+    from maskfusion_amd import MaskFusion
+    st, fr = scene_frames(8, noise=True)
+    runs = []
+    shapes = [(None, None, 0), (4, 256, 1), (1, 256, 1), (2, 512, 1), (4, 1024, 1), (8, 1024, 1), (16, 512, 1)]
+    try:
+        for lanes, threads, tiles in shapes:
+            mf = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=10.0, so3=True, enableMultipleModels=False,
+                            numGSurfels=1 << 20, initConfidenceGlobal=2.0)
+            mf.setParam("splatTiles", tiles)
+            if lanes:
+                mf.setParam("spriteLanes", lanes)
+                mf.setParam("tileThreads", threads)
+            for k in range(8):
+                mf.processFrame(fr[k][0], fr[k][1])
+            runs.append(dict(pose=mf.getCurrPose(), count=mf.getBackgroundModel().lastCount(), v=mf.debugRead("pred_vertex"),
+                             n=mf.debugRead("pred_normal"), img=mf.debugRead("pred_image"), t=mf.debugRead("pred_time")))
+            mf.close()
+    finally:
+        from maskfusion_amd import MaskFusion as M     # the two switches are process-wide: back to the defaults
+        mf = M(st.W, st.H, st.fx, st.fy, st.cx, st.cy, enableMultipleModels=False, numGSurfels=1 << 16)
+        mf.setParam("spriteLanes", 4)
+        mf.setParam("tileThreads", 512)
+        mf.close()
+    ref = runs[0]
+    assert (ref["v"][..., 2] > 0).mean() > 0.2
+    for shape, r in zip(shapes[1:], runs[1:]):
+        for key in ("v", "n", "img", "t", "pose"):
+            assert np.array_equal(ref[key], r[key]), (shape, key)
+        assert ref["count"] == r["count"], shape
+
+
 def test_pipeline_1280x960(hip, oracle):
     """BASELINE.json configs[4] resolution: tiles, grids and list capacities scale (4 800 splat tiles, multi-round ICP grid)."""
     from maskfusion_amd import MaskFusion, synth
