@@ -12,8 +12,10 @@
 // partial sums in a fixed order, solves the 6x6 system in fp64 and updates the pose (every workgroup does this
 // redundantly and identically, so no workgroup ever waits on another inside a launch -- visibility comes from
 // the kernel boundary only), then streams the current vertex/normal planes, gathers the model planes, and reduces 29
-// accumulators with a recursive-halving tree (DPP exchanges) + one LDS stage.  No host round trip, no atomics,
+// accumulators through LDS (lane pairs by DPP, column-wise stores, 16-lane butterflies).  No host round trip, no atomics,
 // bit-reproducible run to run.  With the photometric term an iteration is two launches (k_rgbd_iter, k_rgb_step).
+// A launch per iteration is the cheapest device-wide synchronisation this GPU offers: the same loop inside one persistent
+// launch (device-wide barriers) was measured 5.8x slower in round 3 and removed.
 #include <string.h>
 
 #include "mf_internal.h"
@@ -187,17 +189,6 @@ __device__ __forceinline__ void gn_solve_update_serial(const double* sys, const 
         }
     ldlt6_solve(A, b, x);
     gn_update_from_x(x, (float)sys[27], (float)sys[28], in, out);
-}
-
-// Workgroup-level: wavefront 0 solves in parallel, its lane 0 applies the update.  Call with all threads of the
-// workgroup after reduce_partials(); returns true in the thread that holds `out`.
-__device__ __forceinline__ bool gn_solve_update_wg(const double* s_sys, const GNState& in, GNState& out) {
-    if (threadIdx.x != 0) return false;
-    // One thread, everything in registers: ~100 fp64 operations whose six pivots form the only long dependency chain.  The
-    // wave-parallel Gauss-Jordan (solve6_wave, kept for the RGB-D kernels and as a cross-check) spends its time in 18
-    // ds_bpermute round trips: 2.1 k cycles against ~0.9 k here.
-    gn_solve_update_serial(s_sys, in, out);
-    return true;
 }
 
 // The same update with the state resident in LDS and the work after the solve spread over twelve lanes (round 3).  One thread used to run
