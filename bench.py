@@ -22,6 +22,8 @@ The JSON line also carries
   roofline       -- the dominant kernel (the ICP Gauss-Newton iteration): algorithmic bytes per launch / average launch duration
                     measured here with HIP events on the library's stream, against the 8 TB/s HBM peak; `traffic` = HBM bytes
                     per launch from the newest committed PMC profile (profiles/r*_pmc.json) when it was taken on this kernel;
+                    `levels` = the same interval per rocprofv3 kernel name (level 0 / coarse levels); `measured_ceiling` = the same
+                    figure over the bandwidth a device-to-device copy reaches on this box (SURVEY.md 8d);
   roofline_frame -- the same for the whole frame: (741 P + 192 N) algorithmic bytes (SURVEY.md 8d) / frame time;
   host_input     -- frames/s through mf_process_frame (host pointers: 2.15 MB of H2D per frame + one sync), beside `value`;
   cpu_baseline   -- the oracle (CPU restatement, oracle/; a -O3 -march=native timing build) on this box's host cores.
