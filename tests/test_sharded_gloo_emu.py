@@ -115,6 +115,60 @@ def test_two_ranks_equal_one_context(tmp_path, track_all):
     assert max(len(r["ids"]) for r in one) >= (2 if track_all else 3) and most >= (1 if track_all else 2), "the scenario must spawn object models, on rank 1"
 
 
+# ---- N = 1: every model on the one rank (bench.py --config 3 on one GPU).  The loop-level calls then run the SAME batches as
+# mf_process_frame -- one Gauss-Newton loop over the background and all objects, one launch per surfel pass for all objects -- so the
+# sharded form must reproduce the single context bit for bit with batching ON (the two-rank test above switches batchTracking off,
+# because two ranks cannot form the one-context batch).
+def _make_batched(track_all):
+    from maskfusion_amd import MaskFusion
+    m = MaskFusion(W, H, F, F, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, numGSurfels=1 << 17, numOSurfels=1 << 15, enableMultipleModels=True,
+                   modelSpawnOffset=2, trackAllModels=track_all)
+    for k, v in SEG.items():
+        m.setParam(k, v)
+    return m
+
+
+def _one_rank_both(_rank, out_dir, track_all):
+    _activate()
+    import torch
+    from maskfusion_amd import sharded
+    frames = _frames(track_all)
+
+    def record(mf, k):
+        ms = mf.getModels()
+        return dict(ids=[m.getID() for m in ms], poses=[m.getPose() for m in ms], counts=[m.lastCount() for m in ms], seg=mf.downloadSegmentation(),
+                    clouds=[m.downloadMap() for m in ms] if k == N_FRAMES - 1 else None)
+
+    one, rec_one = _make_batched(track_all), []
+    for k, (rgb, depth, mask) in enumerate(frames):
+        one.processFrame(rgb, depth, mask=mask, classIDs=[0, 41, 42], timestamp=k)
+        rec_one.append(record(one, k))
+    one.close()
+    mf, rec_sh = _make_batched(track_all), []
+    sm = sharded.ShardedMaskFusion(mf, torch.device("cpu"), sharded.default_cfg(trackAllModels=track_all, modelSpawnOffset=2))
+    for k, (rgb, depth, mask) in enumerate(frames):
+        sm.process_frame(rgb, depth, mask, [0, 41, 42], 1.0, k)
+        rec_sh.append(record(mf, k))
+    mf.close()
+    pickle.dump((rec_one, rec_sh), open(os.path.join(out_dir, "one_rank.pkl"), "wb"))
+
+
+@pytest.mark.parametrize("track_all", [False, True], ids=["static-objects", "tracked-objects"])
+def test_one_rank_sharded_form_equals_one_context(tmp_path, track_all):
+    mp.spawn(_one_rank_both, args=(str(tmp_path), track_all), nprocs=1, join=True)
+    rec_one, rec_sh = pickle.load(open(tmp_path / "one_rank.pkl", "rb"))
+    for k, (a, b) in enumerate(zip(rec_one, rec_sh)):
+        assert a["ids"] == b["ids"], k
+        assert np.array_equal(a["seg"], b["seg"]), k
+        assert a["counts"] == b["counts"], k
+        for i in range(len(a["ids"])):
+            assert np.array_equal(a["poses"][i], b["poses"][i]), (k, a["ids"][i])
+        if a["clouds"] is not None:
+            for i in range(len(a["ids"])):
+                assert np.array_equal(a["clouds"][i], b["clouds"][i], equal_nan=True), (k, a["ids"][i])
+    assert max(len(r["ids"]) for r in rec_one) >= (2 if track_all else 3)
+
+
 # ---- the loop bench.py --gpus N times (weak scaling: one context per rank, frames broadcast from rank 0, per-model state gathered) ----
 def _weak_worker(rank, world, port, out_dir):
     _activate()
