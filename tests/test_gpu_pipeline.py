@@ -328,3 +328,29 @@ def test_erased_frames_match_oracle(hip, oracle):
             else:
                 assert ig == io, (k, ig, io)
     o.close(); m.close()
+
+
+def test_full_map_clamps_like_the_oracle(hip, oracle):
+    """Maximum size (SURVEY.md 8c edge cases): a surfel buffer that fills up.  Upstream's transform feedback discards the primitives that do
+    not fit (Model.cpp:649-772 writes into a buffer of MAX_VERTICES); here the ordered compaction of the clean pass stops at the capacity,
+    on both sides: the count sticks at the capacity, the map stays usable and tracking goes on."""
+    from maskfusion_amd import MaskFusion
+    st, frames = scene_frames(10, noise=True)
+    cap = 512 * 512                  # Model::TEXTURE_DIMENSION^2 (Model.cpp:101-105); the first frame alone yields 301 k surfels: full from frame 0 on
+    o = oracle.Oracle(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpWeight=100.0, capacity=cap, so3=0)
+    m = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=100.0, so3=False, numGSurfels=cap, enableMultipleModels=False)
+    full = 0
+    for k, (rgb, depth, _) in enumerate(frames):
+        o.process_frame(rgb, depth)
+        m.processFrame(rgb, depth, timestamp=k)
+        gc, oc = m.getBackgroundModel().lastCount(), o.count
+        d = np.abs(m.getCurrPose() - o.pose).max()
+        print(k, "counts", gc, oc, "pose diff", d)
+        assert gc <= cap and oc <= cap
+        assert abs(gc - oc) <= max(8, 0.005 * oc), (k, gc, oc)
+        assert d < 2e-4, (k, d)
+        full += int(gc == cap and oc == cap)
+    assert full >= 8, "the scenario must fill the buffer"
+    cloud = m.getBackgroundModel().downloadMap()
+    assert len(cloud) == cap and np.isfinite(cloud[:, :3]).all()
+    o.close(); m.close()
