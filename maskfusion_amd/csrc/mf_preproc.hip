@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_bilateral(const float* __restrict__ dep
     if (gx >= W || gy >= H) return;
     const float value = tile[(ty + kBR) * kBLdsW + tx + kBR];
     float res = 0.f;
-    if (value > 0.03f) {
+    if (!(value <= 0.03f)) {   // the shader's gate as written (`if (value <= 0.03f) 0 else filter`, :34): a NaN centre is filtered, to NaN
         float sum1 = 0.f, sum2 = 0.f;
 #pragma unroll
         for (int dy = -kBR; dy <= kBR; ++dy) {

@@ -52,5 +52,32 @@ def rgbd_so3(n=3, W=160, H=120):
     return out
 
 
+def bad_depth_pixels(n=4, W=160, H=120):
+    """sensor garbage in the depth image -- NaN, +inf and negative patches: the filter includes every in-image tap like the shader does
+    (depth_bilateral_metric.frag:30-76: a NaN tap poisons its 13x13 neighbourhood, which then fails the `z > 0` tests downstream), so the
+    frame loses those regions and nothing else, on both sides"""
+    f = 528.0 * W / 640.0
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
+    o = mfo.Oracle(W, H, f, f, W / 2.0, H / 2.0, capacity=1 << 17, icpWeight=100.0, so3=0)
+    mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=False, numGSurfels=1 << 17)
+    out = []
+    for k in range(n):
+        rgb, d, _ = st.frame(k)
+        d = d.copy()
+        d[10:14, 20:30] = np.nan
+        d[60:63, 100:104] = np.inf
+        d[90:94, 40:48] = -1.0
+        mf.processFrame(rgb, d, timestamp=k)
+        o.process_frame(rgb, d)
+        gF, oF = mf.debugRead("depthF"), o.dbg("depthF")
+        pose = mf.getCurrPose()
+        out.append(dict(count=int(mf.getBackgroundModel().lastCount()), ocount=int(o.count), pose_finite=bool(np.isfinite(pose).all()),
+                        pose_diff=float(np.abs(pose - o.pose).max()), nan_pattern_equal=bool(np.array_equal(np.isnan(gF), np.isnan(oF))),
+                        nan_pixels=int(np.isnan(gF).sum()),
+                        filtered_diff=float(np.nanmax(np.abs(gF - oF)))))
+    mf.close(); o.close()
+    return out
+
+
 if __name__ == "__main__":
-    print(json.dumps(dict(single=single_model(), rgbd=rgbd_so3())))
+    print(json.dumps(dict(single=single_model(), rgbd=rgbd_so3(), bad_depth=bad_depth_pixels())))
