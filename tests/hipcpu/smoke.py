@@ -79,5 +79,27 @@ def bad_depth_pixels(n=4, W=160, H=120):
     return out
 
 
+def schedule_switches(n=5, W=160, H=120):
+    """the iteration schedule {fastOdom ? 3 : 10, pyramid ? 5 : 0, pyramid ? 4 : 0} (RGBDOdometry.cpp:327-329; -fo / pyramid off) in its four
+    combinations, the last one with the photometric term and SO(3): device loop against the oracle's"""
+    f = 528.0 * W / 640.0
+    out = {}
+    for name, fast, pyr, icp, so3 in (("fast", 1, 1, 100.0, 0), ("nopyramid", 0, 0, 100.0, 0), ("fast_nopyramid", 1, 0, 100.0, 0), ("fast_rgbd_so3", 1, 1, 20.0, 1)):
+        st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
+        o = mfo.Oracle(W, H, f, f, W / 2.0, H / 2.0, capacity=1 << 17, icpWeight=icp, so3=so3, fastOdom=fast, pyramid=pyr)
+        mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=icp, so3=bool(so3), fastOdom=bool(fast), enableMultipleModels=False, numGSurfels=1 << 17)
+        if not pyr:
+            mf.setPyramid(0)
+        rows = []
+        for k in range(n):
+            rgb, d, _ = st.frame(k)
+            mf.processFrame(rgb, d, timestamp=k)
+            o.process_frame(rgb, d)
+            rows.append(dict(count=int(mf.getBackgroundModel().lastCount()), ocount=int(o.count), pose_diff=float(np.abs(mf.getCurrPose() - o.pose).max())))
+        mf.close(); o.close()
+        out[name] = rows
+    return out
+
+
 if __name__ == "__main__":
-    print(json.dumps(dict(single=single_model(), rgbd=rgbd_so3(), bad_depth=bad_depth_pixels())))
+    print(json.dumps(dict(single=single_model(), rgbd=rgbd_so3(), bad_depth=bad_depth_pixels(), schedule=schedule_switches())))
