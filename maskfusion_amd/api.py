@@ -138,7 +138,9 @@ class MaskFusion:
         h = C.c_void_p()
         rc = self._L.mf_create(C.byref(cfg), C.byref(h))
         if rc != 0:
-            raise MFError(f"mf_create failed with code {rc} (needs a gfx950 GPU; there is no CPU path)")
+            why = {-1: "invalid configuration: width and height must be positive multiples of 8 (three pyramid levels), surfel capacities > 0",
+                   -2: "needs a gfx950 GPU; there is no CPU path", -4: "out of device memory"}.get(rc, "see the HIP runtime's message on stderr")
+            raise MFError(f"mf_create failed with code {rc} ({why})")
         self._h = h
 
     # -- lifetime -----------------------------------------------------------------------------
