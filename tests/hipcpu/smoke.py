@@ -101,5 +101,38 @@ def schedule_switches(n=5, W=160, H=120):
     return out
 
 
+def multimodel_bad_depth(n=7, W=240, H=160):
+    """the multi-model frame (global projection, label stage, spawn, per-model fusion) on the same kind of sensor garbage, some of it inside
+    an object's mask; the oracle gets the device's filtered depth (the two filters differ by a few ulp of exp, which is the ONLY source of
+    the 1 % count differences of freshly spawned objects): ids, surfel counts and label images must then be identical"""
+    f = 198.0
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, n_objects=2, noise=True, object_motion=0.0)
+    seg_o = dict(threshold=0.3, weightDistance=150.0, weightConvexity=2.8, morphEdgeIterations=0, morphMaskIterations=0, minRelSizeNew=0.004)
+    seg_d = dict(mfThreshold=0.3, mfWeightDistance=150.0, mfWeightConvexity=2.8, mfMorphEdgeIterations=0, mfMorphMaskIterations=0, newModelMinRelativeSize=0.004)
+    o = mfo_mm.OracleMM(W, H, f, f, W / 2.0, H / 2.0, icpWeight=100.0, so3=0, capacity=1 << 17, capacityObject=1 << 15, modelSpawnOffset=2, trackAllModels=0, seg=seg_o)
+    mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, numGSurfels=1 << 17, numOSurfels=1 << 15, enableMultipleModels=True,
+                    modelSpawnOffset=2, trackAllModels=False)
+    for k, v in seg_d.items():
+        mf.setParam(k, v)
+    out = []
+    for k in range(n):
+        rgb, d, m = st.frame(k)
+        d = d.copy()
+        d[10:14, 20:30] = np.nan
+        d[100:103, 150:154] = np.inf
+        d[120:124, 40:48] = -1.0
+        ys, xs = np.where(m == 1)
+        if len(ys) > 20:
+            d[ys[:6], xs[:6]] = np.nan
+        mf.processFrame(rgb, d, mask=m, classIDs=[0, 41, 42], timestamp=k)
+        o.process_frame(rgb, d, m, [0, 41, 42], depth_filtered=mf.debugRead("depthF"))
+        ms = mf.getModels()
+        out.append(dict(ids=[x.getID() for x in ms], oids=[o.model_id(i) for i in range(o.n_models)], counts=[x.lastCount() for x in ms],
+                        ocounts=[o.model_count(i) for i in range(o.n_models)], label_diff=int((mf.downloadSegmentation() != o.segmentation()).sum()),
+                        pose_diff=max(float(np.abs(ms[i].getPose() - o.model_pose(i)).max()) for i in range(min(len(ms), o.n_models)))))
+    mf.close(); o.close()
+    return out
+
+
 if __name__ == "__main__":
-    print(json.dumps(dict(single=single_model(), rgbd=rgbd_so3(), bad_depth=bad_depth_pixels(), schedule=schedule_switches())))
+    print(json.dumps(dict(single=single_model(), rgbd=rgbd_so3(), bad_depth=bad_depth_pixels(), schedule=schedule_switches(), mm_bad_depth=multimodel_bad_depth())))
