@@ -134,5 +134,29 @@ def multimodel_bad_depth(n=7, W=240, H=160):
     return out
 
 
+def weight_multiplier_cases(n=6, W=160, H=120):
+    """processFrame's third argument (MaskFusion.cpp:200; Model::fuse weighting = computeFusionWeight(weightMultiplier), Model.cpp:449-464)
+    at 0.3 and 3.0, poses given and filtered depth shared: every surfel in the same slot with the same confidence"""
+    f = 528.0 * W / 640.0
+    out = {}
+    for wm in (0.3, 3.0):
+        st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
+        o = mfo.Oracle(W, H, f, f, W / 2.0, H / 2.0, capacity=1 << 17, icpWeight=100.0, so3=0, confGlobal=2.0)
+        mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=False, numGSurfels=1 << 17, initConfidenceGlobal=2.0)
+        rows = []
+        for k in range(n):
+            rgb, d, _ = st.frame(k)
+            T = st.gt_pose(k).astype(np.float32)
+            mf.processFrame(rgb, d, timestamp=k, weightMultiplier=wm, inPose=T if k else None)
+            o.process_frame(rgb, d, weight_multiplier=wm, in_pose=T if k else None, depth_filtered=mf.debugRead("depthF"))
+            g, oc = mf.getBackgroundModel().downloadMap(), o.surfels()
+            same = len(g) == len(oc)
+            rows.append(dict(count=len(g), ocount=len(oc), max_diff=float(np.abs(g[:, :4] - oc[:, :4]).max()) if same else -1.0,
+                             stamps_equal=bool(same and np.array_equal(g[:, 4:8], oc[:, 4:8])), conf_mean=float(g[:, 3].mean())))
+        mf.close(); o.close()
+        out[str(wm)] = rows
+    return out
+
+
 if __name__ == "__main__":
-    print(json.dumps(dict(single=single_model(), rgbd=rgbd_so3(), bad_depth=bad_depth_pixels(), schedule=schedule_switches(), mm_bad_depth=multimodel_bad_depth())))
+    print(json.dumps(dict(single=single_model(), rgbd=rgbd_so3(), bad_depth=bad_depth_pixels(), schedule=schedule_switches(), mm_bad_depth=multimodel_bad_depth(), weight=weight_multiplier_cases())))
