@@ -158,5 +158,38 @@ def weight_multiplier_cases(n=6, W=160, H=120):
     return out
 
 
+def device_resident_masks(n=8, W=240, H=160):
+    """mf_process_frame_dev + mf_set_mask_class_ids (frames and masks already in device memory: what bench.py --config 2s times) against
+    mf_process_frame with host pointers and FrameData::classIDs: the same multi-model run, bit for bit (tracked objects, spawns and drops)"""
+    f = 198.0
+    seg_d = dict(mfThreshold=0.3, mfWeightDistance=150.0, mfWeightConvexity=2.8, mfMorphEdgeIterations=0, mfMorphMaskIterations=0, newModelMinRelativeSize=0.004)
+
+    def make():
+        mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, numGSurfels=1 << 17, numOSurfels=1 << 15, enableMultipleModels=True,
+                        modelSpawnOffset=2, trackAllModels=True)
+        for k, v in seg_d.items():
+            mf.setParam(k, v)
+        return mf
+
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, n_objects=2, noise=True, object_motion=1.0)
+    a, b = make(), make()
+    b.setMaskClassIDs([0, 41, 42])
+    keep, out = [], []
+    for k in range(n):
+        rgb, d, m = st.frame(k)
+        a.processFrame(rgb, d, mask=m, classIDs=[0, 41, 42], timestamp=k)
+        bufs = (np.ascontiguousarray(rgb), np.ascontiguousarray(d, np.float32), np.ascontiguousarray(m, np.uint8))
+        keep.append(bufs)                      # ("device" pointers are host pointers under the CPU-executed kernels)
+        b.processFrameDevice(bufs[0].ctypes.data, bufs[1].ctypes.data, bufs[2].ctypes.data, timestamp=k)
+        b.sync()
+        ma, mb = a.getModels(), b.getModels()
+        out.append(dict(ids=[x.getID() for x in ma], ids_dev=[x.getID() for x in mb], classes=[x.getClassID() for x in ma], classes_dev=[x.getClassID() for x in mb],
+                        counts_equal=[x.lastCount() for x in ma] == [x.lastCount() for x in mb],
+                        poses_equal=bool(len(ma) == len(mb) and all(np.array_equal(x.getPose(), y.getPose()) for x, y in zip(ma, mb))),
+                        label_diff=int((a.downloadSegmentation() != b.downloadSegmentation()).sum())))
+    a.close(); b.close()
+    return out
+
+
 if __name__ == "__main__":
-    print(json.dumps(dict(single=single_model(), rgbd=rgbd_so3(), bad_depth=bad_depth_pixels(), schedule=schedule_switches(), mm_bad_depth=multimodel_bad_depth(), weight=weight_multiplier_cases())))
+    print(json.dumps(dict(single=single_model(), rgbd=rgbd_so3(), bad_depth=bad_depth_pixels(), schedule=schedule_switches(), mm_bad_depth=multimodel_bad_depth(), weight=weight_multiplier_cases(), dev_masks=device_resident_masks())))
