@@ -191,5 +191,38 @@ def device_resident_masks(n=8, W=240, H=160):
     return out
 
 
+def static_switches(n=9, W=240, H=160):
+    """Model::makeNonStatic / makeStatic / isNonstatic / updateStaticPose (Core/Model/Model.h:263-268; MaskFusion.cpp:263-276) with
+    trackAllModels off: a static object follows the background -- pose_obj * pose_bg^-1 stays what makeStatic recorded -- a non-static one is
+    tracked (and may fall to the 0.2 m jump rule, which replaces it by a fresh, static model)"""
+    f = 198.0
+    seg_d = dict(mfThreshold=0.3, mfWeightDistance=150.0, mfWeightConvexity=2.8, mfMorphEdgeIterations=0, mfMorphMaskIterations=0, newModelMinRelativeSize=0.004)
+    mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, numGSurfels=1 << 17, numOSurfels=1 << 15, enableMultipleModels=True,
+                    modelSpawnOffset=2, trackAllModels=False)
+    for k, v in seg_d.items():
+        mf.setParam(k, v)
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, n_objects=1, noise=True, object_motion=0.0)
+    rel, out = [], dict(flag_after_nonstatic=None, flag_after_static=None, tracked_or_replaced=None)
+    for k in range(n):
+        rgb, d, m = st.frame(k)
+        ms = mf.getModels()
+        id_before = ms[1].getID() if len(ms) > 1 else None
+        if k == 5 and len(ms) > 1:
+            ms[1].makeNonStatic()
+            out["flag_after_nonstatic"] = bool(ms[1].isNonstatic())
+        if k == 6 and len(ms) > 1:
+            ms[1].makeStatic()
+            out["flag_after_static"] = bool(ms[1].isNonstatic())
+        mf.processFrame(rgb, d, mask=m, classIDs=[0, 41], timestamp=k)
+        ms = mf.getModels()
+        if k == 5 and len(ms) > 1:
+            out["tracked_or_replaced"] = bool(ms[1].getID() != id_before or ms[1].isNonstatic())
+        if len(ms) > 1:
+            rel.append((k, ms[1].getID(), (ms[1].getPose() @ np.linalg.inv(ms[0].getPose())).reshape(-1).tolist()))
+    mf.close()
+    out["relative"] = rel
+    return out
+
+
 if __name__ == "__main__":
-    print(json.dumps(dict(single=single_model(), rgbd=rgbd_so3(), bad_depth=bad_depth_pixels(), schedule=schedule_switches(), mm_bad_depth=multimodel_bad_depth(), weight=weight_multiplier_cases(), dev_masks=device_resident_masks())))
+    print(json.dumps(dict(single=single_model(), rgbd=rgbd_so3(), bad_depth=bad_depth_pixels(), schedule=schedule_switches(), mm_bad_depth=multimodel_bad_depth(), weight=weight_multiplier_cases(), dev_masks=device_resident_masks(), static=static_switches())))
