@@ -338,6 +338,86 @@ def run_sharded(args, cfg, rank, local_rank, world, st, frames):
         dist.destroy_process_group()
 
 
+def rocprof_rows(names):
+    """per-kernel rows {name: {"us": average duration, "calls": n, "source": file}} from the newest committed rocprofv3 --kernel-trace --stats
+    summary under profiles/ that holds them (the cross-check the roofline entries name; None when there is none)"""
+    import csv
+    import glob
+    out = {}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*kernel_stats.csv")), reverse=True):
+        try:
+            rows = list(csv.DictReader(open(path)))
+        except Exception:
+            continue
+        for r in rows:
+            nm = r.get("Name", "")
+            for want in names:
+                if want in nm and want not in out:
+                    try:
+                        out[want] = {"us": float(r["AverageNs"]) / 1e3, "calls": int(r["Calls"]), "kernel": nm, "source": "profiles/" + os.path.basename(path)}
+                    except Exception:
+                        pass
+        if len(out) == len(names):
+            break
+    return out or None
+
+
+def reference_default_variant(cfg, local_rank, d_rgb, d_depth, order, seconds=1.5):
+    """The configuration the reference ships with (GUI/Tools/GUI.h:189,195: icpWeight 20 -> photometric term on, SO(3) pre-alignment on) on
+    the same resident stream: SURVEY.md 8a rows a8-a10.  A Gauss-Newton iteration is two launches there (k_rgbd_iter: ICP normal equations +
+    photometric correspondences; k_rgb_step: photometric normal equations), preceded by <= 10 SO(3) iterations on the 160x120 level.
+    Reported beside `value` (a `variants` entry), never as `value`."""
+    from maskfusion_amd import MaskFusion
+    W, H, F = cfg["W"], cfg["H"], cfg["f"]
+    P = W * H
+    mf = MaskFusion(W, H, F, F, W / 2.0, H / 2.0, icpThresh=20.0, so3=True, device=local_rank, enableMultipleModels=False, numGSurfels=cfg["surfels"])
+    pos = 0
+    for _ in range(60):
+        k = order[pos]; pos += 1
+        mf.processFrameDevice(d_rgb[k].data_ptr(), d_depth[k].data_ptr())
+    mf.sync()
+    steps, dt = 0, 0.0
+    while dt < seconds:
+        t0 = time.perf_counter()
+        for _ in range(200):
+            k = order[pos % len(order)]; pos += 1
+            mf.processFrameDevice(d_rgb[k].data_ptr(), d_depth[k].data_ptr())
+        mf.sync()
+        dt += time.perf_counter() - t0
+        steps += 200
+    mf.enableTimings(True)
+    acc, n = {}, 60
+    so3_its = 0.0
+    for _ in range(n):
+        k = order[pos % len(order)]; pos += 1
+        mf.processFrameDevice(d_rgb[k].data_ptr(), d_depth[k].data_ptr())
+        for kx, v in mf.timings().items():
+            acc[kx] = acc.get(kx, 0.0) + v
+        so3_its += mf.trackStats(0)["so3Iterations"]
+    mf.enableTimings(False)
+    stages = {kx: v / n for kx, v in acc.items()}
+    count = mf.getBackgroundModel().lastCount()
+    mf.close()
+    # SURVEY.md 8d contract bytes per pixel and iteration: ICP 48 B, computeRgbResidual 30 B, rgbStep 32 B; (10 + 5/4 + 4/16) P pixel-iterations
+    px_it = (10 + 5 / 4.0 + 4 / 16.0) * P
+    loop_bytes = px_it * (48 + 30 + 32)
+    t_loop = stages["icpIterations"] * 1e-3
+    kern = rocprof_rows(["k_rgbd_iter", "k_rgb_step", "k_so3_iter"])
+    levels = None
+    if kern:
+        per_launch = {"k_rgbd_iter": px_it * 78 / 19, "k_rgb_step": px_it * 32 / 19, "k_so3_iter": 2.0 * (P / 16)}
+        levels = {nm: dict(r, bytes=per_launch[nm], frac=per_launch[nm] / (r["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS) for nm, r in kern.items()}
+    return {"workload": "configs[1]'s stream with the reference's GUI defaults: icpWeight=20 (photometric term on), SO(3) pre-alignment on",
+            "value": steps / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "surfels": count,
+            "so3_iterations_per_frame": so3_its / n,
+            "roofline": {"bound": "hbm", "kernel": "k_rgbd_iter + k_rgb_step (19 iterations x 2 launches per frame)",
+                         "algorithmic_bytes_per_iteration": loop_bytes / 19, "us_per_iteration": t_loop * 1e6 / 19,
+                         "achieved": loop_bytes / t_loop / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": loop_bytes / t_loop / 1e9 / HBM_PEAK_GBS,
+                         "note": "HIP events on the library's stream around the 38 launches of the loop; contract bytes 48 + 30 + 32 B per pixel "
+                                 "and iteration (SURVEY.md 8d); `levels`: per kernel from the committed rocprofv3 summary named in each entry",
+                         "levels": levels, "stage_ms": stages}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -359,6 +439,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host-input", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the reference-default (icpWeight 20 + SO(3)) side measurement of config 1")
     ap.add_argument("--force-sharded-scene", action="store_true", help="run that part at N = 1 as well (rehearsal of the N > 1 code path on one GPU)")
     ap.add_argument("--no-sharded-scene", action="store_true", help="N > 1: skip the model-sharded 8-object scene that is timed beside the weak-scaling line")
     args = ap.parse_args()
@@ -559,6 +640,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not multi:   # rank 0 at N = 1 only (the other ranks would sit in a collective)
         cpu = cpu_baseline(cfg, frames)
 
+    variants = None
+    if rank == 0 and world == 1 and args.config == "1" and not args.no_variants and args.icp_weight >= 100.0 and not args.so3:
+        try:
+            variants = {"reference_default": reference_default_variant(cfg, local_rank, d_rgb, d_depth, order)}
+        except Exception as e:   # a side measurement: never the reason the bench line is missing
+            print(f"[bench] reference-default variant not measured: {e!r}", file=sys.stderr)
+
     seen = ranks_seen(world, local_rank)
     scene = None
     if with_scene:
@@ -587,7 +675,7 @@ def main():
             "config": {"workload": cfg["workload"] + variant, "frames_in_hbm": n_frames, "models": n_models, "surfels": count,
                        "pose_drift_vs_gt_m": drift, "parallelism": f"context-per-gpu x{world}",
                        **({"params": extra_params} if extra_params else {})},
-            "roofline": roofline, "roofline_frame": roofline_frame, "host_input": host_input, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_frame": roofline_frame, "host_input": host_input, "cpu_baseline": cpu, "variants": variants,
             "ranks_seen": seen, "sharded_scene": scene,
         }
         print(json.dumps(out))

@@ -184,8 +184,15 @@ int mf_get_param(mf_ctx* ctx, const char* key, double* value);
  *         9 icpIterations: first to last Gauss-Newton iteration launch of the background model (what bench.py divides by
  *           the iteration count for its roofline line);
  *         10 icpCoarse / 11 icpFine: the same interval split right before the first level-0 iteration (launch-per-iteration loop of a
- *           single model; 0 for the batched / captured forms) */
-#define MF_N_TIMINGS 12
+ *           single model; 0 for the batched / captured forms);
+ *         multi-model frames only (0 otherwise) -- what lies between the end of tracking and Fuse::Copy's end (labels 3..6 cover the
+ *         BACKGROUND's passes there; Core/MaskFusion.cpp:287-375,539-565):
+ *         12 mmGlobalProjection (GlobalProjection::project of every model + id resolve), 13 mmEdgeLabels (geometric edge map, binary
+ *         edges, the device label stage), 14 mmBackgroundFuseClean (the background's predictIndices / fuse / clean, enqueued ahead of
+ *         the host's look at the label stage's decision), 15 mmHostStall (GPU idle between the end of that and the first object pass:
+ *         the host had not enqueued it yet), 16 mmObjectFuseClean (spawn pass + every object model's predictIndices / fuse / clean),
+ *         17 mmHostWaitMs (HOST wall-clock milliseconds spent in the event wait behind the label stage) */
+#define MF_N_TIMINGS 18
 int mf_get_timings(mf_ctx* ctx, float* ms /* [MF_N_TIMINGS] */);
 /* The context's HIP stream (hipStream_t), for callers that time with their own events. */
 void* mf_get_stream(mf_ctx* ctx);

@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <memory>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -36,6 +37,7 @@ struct ModelState {
     // RGBDOdometry of the model (Model::frameToModel): model-side pyramid, Gauss-Newton state, per-workgroup partial sums
     float* d_vmap_g[3] = {}; float* d_nmap_g[3] = {}; GNState* d_gn = nullptr; float* d_partials[2] = {nullptr, nullptr};
     TrackModelDev* d_track = nullptr;      // the block the batched tracker kernels find all of that through
+    float* d_icp_log = nullptr;            // [20][32] reduced systems of the model's last tracking step, one row per iteration (debug tap "icp_log")
     // object models: private scratch of the surfel passes, so that the passes of ALL objects of a frame can be one launch each ("batchObjectPasses")
     struct ObjScratch {
         unsigned long long* keys = nullptr; int* index = nullptr; float4* ivc = nullptr; float4* inr = nullptr; float4* iclean = nullptr;
@@ -137,6 +139,7 @@ struct mf_ctx {
     bool global_tiles = true;                          // A/B + test knob ("globalTiles"): 0 = every model through k_global_scatter
     bool early_bg_fusion = true;                       // A/B knob ("earlyBackgroundFusion"): 0 = the host visit drains the stream
     hipEvent_t ev_labels = nullptr;                    // the label stage of this frame has written its result words
+    hipEvent_t ev_staged = nullptr;                    // mf_stage_frame_dev: the producers of the staged buffers, ordered on `stream`, have run (main -> pre)
     long frame_no = 0;
     long bg_fused_frame = -1;          // mf_fuse_background has fused the background of this staged frame (mf_fuse_models then skips it)
     bool labels_pending = false;       // between mf_perform_segmentation_begin and _end
@@ -197,7 +200,7 @@ struct mf_ctx {
     float4* d_iclean = nullptr;            // packed column-major index map of the clean pass: 2 x float4 per texel
     uint8_t* d_cand_op = nullptr; float4* d_cand_rec = nullptr; int* d_upd_first = nullptr;
     uint8_t* d_flags = nullptr; float* d_newconf = nullptr; int* d_block_counts = nullptr;
-    float* d_icp_log = nullptr; unsigned long long* d_icp_prof = nullptr;
+    unsigned long long* d_icp_prof = nullptr;
     unsigned long long* d_splat_prof = nullptr; bool splat_prof_on = false;   // "splatProfile": [tiles][8] stamps of the background's tile pass
     // multi-model coupling
     float* d_edge = nullptr; uint8_t* d_bin = nullptr; uint8_t* d_tmp_u8 = nullptr; uint8_t* d_proj_ids = nullptr;
@@ -212,6 +215,8 @@ struct mf_ctx {
     std::vector<std::unique_ptr<ModelState>> models;
 
     hipEvent_t ev[MF_N_TIMINGS + 1] = {};
+    hipEvent_t ev_mm[5] = {};                    // multi-model frame: after global projection | label stage | background fuse+clean | first object pass | (spare)
+    bool mm_marked = false; float mm_host_wait_ms = 0.f;
     hipEvent_t ev_icp[2] = {nullptr, nullptr};   // first / after-last Gauss-Newton launch of the background model
     hipEvent_t ev_icp_mid = nullptr;             // ... and right before its first level-0 iteration (coarse levels | level 0)
     bool icp_mid_recorded = false;
@@ -327,6 +332,7 @@ static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int 
     }
     A(dev_alloc(c, m->allocs, &m->d_gn, 2));
     A(dev_alloc(c, m->allocs, &m->d_track, 1));
+    A(dev_alloc(c, m->allocs, &m->d_icp_log, (size_t)20 * 32));
     if (!allowFillIn) {   // an object model: its own index maps / key image / candidate records (141 B per pixel + 9 B per surfel slot)
         A(dev_alloc(c, m->allocs, &m->scr.keys, P, 0xFF));
         A(dev_alloc(c, m->allocs, &m->scr.index, P));
@@ -348,7 +354,7 @@ static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int 
         t.predV = m->d_predV; t.predN = m->d_predN; t.pose = m->d_pose; t.frame = m->d_frame;
         for (int i = 0; i < 3; ++i) { t.vm[i] = m->d_vmap_g[i]; t.nm[i] = m->d_nmap_g[i]; }
         t.partials[0] = m->d_partials[0]; t.partials[1] = m->d_partials[1]; t.st = m->d_gn;
-        t.log = allowFillIn ? c->d_icp_log : nullptr;             // only the background model (the one with fill-in) is logged
+        t.log = m->d_icp_log;                                      // 128 B per iteration and model
         t.jump_limit = allowFillIn ? 0.f : 0.2f;                   // MaskFusion.cpp:268-272 applies to object models
         t.allow_fill = allowFillIn ? 1 : 0;
         m->track_host = t;
@@ -456,7 +462,6 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     A(dev_alloc(c, c->allocs, &c->d_flags, (size_t)c->cap_max + P));
     A(dev_alloc(c, c->allocs, &c->d_newconf, (size_t)c->cap_max + P));
     A(dev_alloc(c, c->allocs, &c->d_block_counts, (size_t)kCompactBlocks));
-    A(dev_alloc(c, c->allocs, &c->d_icp_log, (size_t)20 * 32));
     A(dev_alloc(c, c->allocs, &c->d_icp_prof, (size_t)20 * 8));
     A(dev_alloc(c, c->allocs, &c->d_edge, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_bin, (size_t)P));
@@ -480,6 +485,8 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
         if (hipEventCreate(&c->ev[i]) != hipSuccess) return fail(MF_EHIP);
     for (int i = 0; i < 2; ++i)
         if (hipEventCreate(&c->ev_icp[i]) != hipSuccess) return fail(MF_EHIP);
+    for (int i = 0; i < 5; ++i)
+        if (hipEventCreate(&c->ev_mm[i]) != hipSuccess) return fail(MF_EHIP);
     if (hipEventCreate(&c->ev_icp_mid) != hipSuccess) return fail(MF_EHIP);
     for (int i = 0; i < mf_ctx::kObjArgSlots; ++i) {
         if (hipMalloc((void**)&c->d_obj_args[i], sizeof(ObjPassArgs) * 64) != hipSuccess ||
@@ -505,11 +512,14 @@ extern "C" void mf_destroy(mf_ctx* c) {
     for (int i = 0; i < 2; ++i)
         if (c->ev_icp[i]) (void)hipEventDestroy(c->ev_icp[i]);
     if (c->ev_icp_mid) (void)hipEventDestroy(c->ev_icp_mid);
+    for (int i = 0; i < 5; ++i)
+        if (c->ev_mm[i]) (void)hipEventDestroy(c->ev_mm[i]);
     for (int i = 0; i < 2; ++i) {
         if (c->ev_pre_done[i]) (void)hipEventDestroy(c->ev_pre_done[i]);
         if (c->ev_main_done[i]) (void)hipEventDestroy(c->ev_main_done[i]);
     }
     if (c->ev_labels) (void)hipEventDestroy(c->ev_labels);
+    if (c->ev_staged) (void)hipEventDestroy(c->ev_staged);
     for (int i = 0; i < mf_ctx::kObjArgSlots; ++i) {
         if (c->d_obj_args[i]) (void)hipFree(c->d_obj_args[i]);
         if (c->h_obj_args[i]) (void)hipHostFree(c->h_obj_args[i]);
@@ -586,7 +596,7 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
             l.nblocks_in = nb_prev;
             l.partials_out = m.d_partials[k & 1];
             l.state_in = &m.d_gn[k & 1]; l.state_out = &m.d_gn[(k + 1) & 1];
-            l.log_out = (k > 0 && m.id == 0) ? c->d_icp_log + 32 * (k - 1) : nullptr;
+            l.log_out = (k > 0) ? m.d_icp_log + 32 * (k - 1) : nullptr;
             l.prof_out = (c->icp_prof_on && m.id == 0 && !rgb) ? c->d_icp_prof + 8 * k : nullptr;
             l.pose_in = (k == 0) ? m.d_pose : nullptr;
             l.so3_in = (k == 0) ? so3_seed : nullptr;
@@ -618,7 +628,7 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
         }
     }
     if (with_marks && timed) (void)hipEventRecord(c->ev_icp[1], s);
-    float* log_out = (k > 0 && m.id == 0) ? c->d_icp_log + 32 * (k - 1) : nullptr;
+    float* log_out = (k > 0) ? m.d_icp_log + 32 * (k - 1) : nullptr;
     if (!rgb)
         launch_icp_finalize(nb_prev ? m.d_partials[(k + 1) & 1] : nullptr, nb_prev, &m.d_gn[k & 1], m.d_pose, m.h_pose, log_out,
                             jump_limit, so3_seed, s);
@@ -997,6 +1007,7 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
     ModelState& bg = *c->models[0];
     bool main_done_recorded = false;
     bool bg_fused = false;
+    c->mm_marked = false;
 
     int prc = enqueue_preprocess(c, d_rgb, d_depth, k, c->map_ready);
     if (prc != MF_OK) return prc;
@@ -1042,6 +1053,7 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
                 for (size_t i = 0; i < c->models.size(); ++i) enqueue_global_projection(c, *c->models[i], (int)i);
             }
             launch_global_resolve(c->d_keys, c->d_proj_ids, P, s);
+            if (c->timings_on) (void)hipEventRecord(c->ev_mm[0], s);
             // MfSegmentation::performSegmentation, device half (MfSegmentation.cpp:149-208)
             launch_edge_map(c->d_vmap[set][0], c->d_nmap[set][0], c->d_edge, W, H, c->seg.weightDistance, c->seg.weightConvexity, s);
             launch_edge_binary(c->d_edge, c->d_bin, c->d_tmp_u8, W, H, c->seg.threshold, c->seg.morphEdgeRadius,
@@ -1070,11 +1082,16 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
                 // surfels; upstream fuses the new model first, MaskFusion.cpp:342-353,539-565.)
                 if (!c->ev_labels) MF_HIP(c, hipEventCreateWithFlags(&c->ev_labels, hipEventDisableTiming));
                 MF_HIP(c, hipEventRecord(c->ev_labels, s));
+                if (c->timings_on) (void)hipEventRecord(c->ev_mm[1], s);
                 if (!g.rgb_only && c->early_bg_fusion) {
                     enqueue_fuse_clean(c, bg, d_rgb, d_depth, depthF, mask, g.depth_cutoff, weight_multiplier, true, true);
                     bg_fused = true;
                 }
+                if (c->timings_on) (void)hipEventRecord(c->ev_mm[2], s);
+                const auto t_wait0 = std::chrono::steady_clock::now();
                 MF_HIP(c, hipEventSynchronize(c->ev_labels));
+                c->mm_host_wait_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_wait0).count();
+                if (c->timings_on) { (void)hipEventRecord(c->ev_mm[3], s); c->mm_marked = true; }
                 if (c->labels->h_result[2]) { c->err = "label stage: vote tables overflowed (too many components x masks)"; return MF_ESTATE; }
                 res.hasNewLabel = c->labels->h_result[0] != 0;
                 res.newClassID = c->labels->h_result[1];
@@ -1176,6 +1193,15 @@ extern "C" int mf_sync(mf_ctx* c) {
         float coarse = 0.f, fine = 0.f;   // launch-per-iteration loop of a single model only (the batched / graph forms record no mid event)
         if (c->tracked_once && c->icp_mid_recorded && hipEventElapsedTime(&coarse, c->ev_icp[0], c->ev_icp_mid) == hipSuccess &&
             hipEventElapsedTime(&fine, c->ev_icp_mid, c->ev_icp[1]) == hipSuccess) { t[10] = coarse; t[11] = fine; }
+        if (c->mm_marked) {   // multi-model frame with the device label stage: what labels 3..7 do not show (see the header)
+            float v = 0.f;
+            if (hipEventElapsedTime(&v, c->ev[3], c->ev_mm[0]) == hipSuccess) t[12] = v;
+            if (hipEventElapsedTime(&v, c->ev_mm[0], c->ev_mm[1]) == hipSuccess) t[13] = v;
+            if (hipEventElapsedTime(&v, c->ev_mm[1], c->ev_mm[2]) == hipSuccess) t[14] = v;
+            if (hipEventElapsedTime(&v, c->ev_mm[2], c->ev_mm[3]) == hipSuccess) t[15] = v;
+            if (hipEventElapsedTime(&v, c->ev_mm[3], c->ev[7]) == hipSuccess) t[16] = v;
+            t[17] = c->mm_host_wait_ms;
+        }
         memcpy(c->last_ms, t, sizeof(t));
     }
     return MF_OK;
@@ -1291,6 +1317,13 @@ extern "C" int mf_stage_frame(mf_ctx* c, const uint8_t* rgb, const float* depth,
 extern "C" int mf_stage_frame_dev(mf_ctx* c, const uint8_t* d_rgb, const float* d_depth, const uint8_t* d_mask) {
     if (!c || !d_rgb || !d_depth) return MF_EINVAL;
     if (d_mask) MF_HIP(c, hipMemcpyAsync(c->d_mask_tex, d_mask, (size_t)c->P, hipMemcpyDeviceToDevice, c->stream));
+    if (c->overlap) {
+        // with overlapPreprocessing the filter / pyramid kernels run on stream_pre, which otherwise only waits for the previous frame's tracking:
+        // the buffers' producers (an RCCL broadcast, a copy) are ordered on `stream` by contract, so the preprocessing stream waits for them here
+        if (!c->ev_staged) MF_HIP(c, hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
+        MF_HIP(c, hipEventRecord(c->ev_staged, c->stream));
+        MF_HIP(c, hipStreamWaitEvent(c->stream_pre, c->ev_staged, 0));
+    }
     int rc = enqueue_preprocess(c, d_rgb, d_depth, c->frame_no, true);
     if (rc != MF_OK) return rc;
     c->lastF = (int)(c->frame_no % 3);
@@ -2174,7 +2207,7 @@ static int debug_read_impl(mf_ctx* c, ModelState& mdl, const char* what, void* o
     else if (w == "cand_rec") { src = c->d_cand_rec; bytes = P * 48; variable = true; }
     else if (w == "clean_flags") { src = c->d_flags; bytes = (size_t)c->cap_max + P; variable = true; }
     else if (w == "clean_newconf") { src = c->d_newconf; bytes = ((size_t)c->cap_max + P) * 4; variable = true; }
-    else if (w == "icp_log") { src = c->d_icp_log; bytes = 19 * 32 * 4; }
+    else if (w == "icp_log") { src = mdl.d_icp_log; bytes = 19 * 32 * 4; }
     else if (w == "icp_prof") { src = c->d_icp_prof; bytes = 19 * 8 * 8; }
     else if (w == "splat_prof") {
         if (!c->d_splat_prof) { c->err = "splat_prof: switch splatProfile on first"; return MF_ESTATE; }

@@ -72,12 +72,18 @@ struct FrameDev {
 };
 
 constexpr int kBBoxEmptyMin = 100000, kBBoxEmptyMax = -100000;   // Model.cpp:315: {1e5, 1e5, 1e5, -1e5, -1e5, -1e5}
+constexpr int kBBoxNotRun = 0x7FFFFFFF;   // bbox_acc[0] between the frame advance and the next clean pass: no clean has accumulated a box since
 // (device + host) reset of the two boxes of a FrameDev
 #define MF_FRAME_BBOX_RESET(f) do { for (int q_ = 0; q_ < 3; ++q_) { (f)->bbox[q_] = (f)->bbox_acc[q_] = mf::kBBoxEmptyMin; \
-                                                                     (f)->bbox[3 + q_] = (f)->bbox_acc[3 + q_] = mf::kBBoxEmptyMax; } } while (0)
-// end of a frame (the GUI's renderPointCloud runs after processFrame, GUI/MainController.cpp:704-717): the accumulated box becomes lastBoundingBox
-#define MF_FRAME_BBOX_ADVANCE(f) do { for (int q_ = 0; q_ < 6; ++q_) { (f)->bbox[q_] = (f)->bbox_acc[q_]; \
-                                                                       (f)->bbox_acc[q_] = q_ < 3 ? mf::kBBoxEmptyMin : mf::kBBoxEmptyMax; } } while (0)
+                                                                     (f)->bbox[3 + q_] = (f)->bbox_acc[3 + q_] = mf::kBBoxEmptyMax; } \
+                                    (f)->bbox_acc[0] = mf::kBBoxNotRun; } while (0)
+// start of a clean pass (its first kernel, before the compaction accumulates): the box of a frame is the box of its LAST clean pass, like the
+// reference's render pass over the final buffer -- on a spawn frame the spawn pass's clean output is not part of it
+#define MF_FRAME_BBOX_BEGIN(f) do { for (int q_ = 0; q_ < 6; ++q_) (f)->bbox_acc[q_] = q_ < 3 ? mf::kBBoxEmptyMin : mf::kBBoxEmptyMax; } while (0)
+// end of a frame (the GUI's renderPointCloud runs after processFrame, GUI/MainController.cpp:704-717): the accumulated box becomes
+// lastBoundingBox; a frame without a clean pass for this model (rgbOnly, model-level calls) leaves the buffer, hence the box, as it was
+#define MF_FRAME_BBOX_ADVANCE(f) do { if ((f)->bbox_acc[0] != mf::kBBoxNotRun) for (int q_ = 0; q_ < 6; ++q_) (f)->bbox[q_] = (f)->bbox_acc[q_]; \
+                                      (f)->bbox_acc[0] = mf::kBBoxNotRun; } while (0)
 
 struct Surfels {               // SoA of float4, 48 B per surfel in three coalesced streams
     float4* pc;                // position + confidence

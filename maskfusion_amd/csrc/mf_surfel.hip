@@ -577,7 +577,10 @@ __device__ __forceinline__ void clean_flags_body(const CleanArgs& a) {
     const int tot = block_sum_i(kept, s_w);
     if (threadIdx.x == 0) {
         a.block_counts[blockIdx.x] = tot;
-        if (blockIdx.x == 0) a.frame->countNext = count;  // snapshot for pass 2 (see FrameDev)
+        if (blockIdx.x == 0) {
+            a.frame->countNext = count;  // snapshot for pass 2 (see FrameDev)
+            if (a.maskID != 0) MF_FRAME_BBOX_BEGIN(a.frame);   // the compaction pass (next launch) accumulates this clean pass's box
+        }
     }
 }
 

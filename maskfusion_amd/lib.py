@@ -8,9 +8,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmaskfusion_amd.so")
 
 MF_OK = 0
-MF_N_TIMINGS = 12
+MF_N_TIMINGS = 18
 TIMING_LABELS = ["Preprocess", "odomInit", "odom", "indexMap", "Fuse::Data", "Fuse::Update", "Fuse::Copy",
-                 "IndexMap::ACTIVE", "Run", "icpIterations", "icpCoarse", "icpFine"]
+                 "IndexMap::ACTIVE", "Run", "icpIterations", "icpCoarse", "icpFine",
+                 "mmGlobalProjection", "mmEdgeLabels", "mmBackgroundFuseClean", "mmHostStall", "mmObjectFuseClean", "mmHostWaitMs"]
 
 
 class MFError(RuntimeError):

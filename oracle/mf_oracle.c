@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <stdio.h>
 
 #define MFO_NAN (__builtin_nanf(""))
 
@@ -467,6 +468,17 @@ void mfo_update_se3(double* resultRt, const double* x6) {
  * float-rounded sums, as the reference) and the device (unpivoted LDL^T on fp64 sums) may step differently; both count such iterations. */
 static int g_track_ill = 0;
 int mfo_last_track_ill(void) { return g_track_ill; }
+/* the reduced geometric systems of the last tracking step, one row per iteration in the device log's layout: 27 packed upper-triangle
+ * products of the 7-vector row (reduce.cu:378-411 order: A[i][i..5], b[i]), then the residual and the inlier count (test tooling) */
+static float g_track_log[20][32]; static int g_track_log_n = 0;
+static void track_log_push(const float* A36, const float* b6, const float* residual2) {
+    if (g_track_log_n >= 20) return;
+    float* row = g_track_log[g_track_log_n++];
+    int k = 0;
+    for (int i = 0; i < 6; ++i) { for (int j = i; j < 6; ++j) row[k++] = A36[i * 6 + j]; row[k++] = b6[i]; }
+    row[27] = residual2[0]; row[28] = residual2[1]; row[29] = row[30] = row[31] = 0.f;
+}
+int mfo_last_track_log(float* out /* [20][32] */) { memcpy(out, g_track_log, sizeof(g_track_log)); return g_track_log_n; }
 static int gn_system_ill(const double* A36, float inliers) {
     double M[6][6], maxdiag = 0.0, minpiv = 1.7976931348623157e308;
     for (int i = 0; i < 6; ++i)
@@ -860,7 +872,7 @@ void mfo_track_rgbd(const float* const curr_v[3], const float* const curr_n[3], 
     memcpy(Rprev, R, sizeof(Rprev)); memcpy(tprev, t, sizeof(tprev));
     memcpy(Rcurr, R, sizeof(Rcurr)); memcpy(tcurr, t, sizeof(tcurr));
     memset(st, 0, sizeof(*st));
-    g_track_ill = 0;
+    g_track_ill = 0; g_track_log_n = 0;
     const float sobelScale = (float)(1.0 / 8.0);      /* 1 / 2^sobelSize, RGBDOdometry.cpp:31-32 */
     const float maxDepthDeltaRGB = 0.07f;              /* :33 */
     const float minGrad[3] = {5.f, 3.f, 1.f};          /* :102-105 */
@@ -930,6 +942,7 @@ void mfo_track_rgbd(const float* const curr_v[3], const float* const curr_n[3], 
                              o->distThresh, o->angleThresh, lw, lh, A_icp, b_icp, residual);
                 st->lastICPError = sqrtf(residual[0]) / residual[1];
                 st->lastICPCount = residual[1];
+                track_log_push(A_icp, b_icp, residual);
             }
             float A_rgbd[36], b_rgbd[6];
             memset(A_rgbd, 0, sizeof(A_rgbd)); memset(b_rgbd, 0, sizeof(b_rgbd));
@@ -2235,6 +2248,9 @@ typedef struct {
     float lastICPError, lastICPCount;
     uint8_t* lastNext[3];
     int bbox[6];   /* Model::lastBoundingBox in mm, {min xyz, max xyz}; Model.cpp:315 initial value = empty */
+    float trackedPose[16]; int trackedThisFrame;   /* what THIS side's tracking step returned from its own state (teacher forcing keeps it readable) */
+    float trackedPoseAlt[16];                      /* ... and what it returns when the start pose is moved by one micrometre (its own sensitivity) */
+    float trackLog[20][32]; int trackLogN;         /* reduced systems of the last tracking step, per iteration (mfo_last_track_log) */
 } mm_model;
 static void mm_bbox_reset(mm_model* m) { for (int k = 0; k < 3; ++k) { m->bbox[k] = 100000; m->bbox[3 + k] = -100000; } }
 /* Model::renderPointCloud (Model.cpp:287-346) + draw_global_surface.vert:55-78, as the GUI runs it after every frame with its defaults
@@ -2268,10 +2284,49 @@ struct mfo_mm {
     const float* depthF_override;   /* test isolation, as mfo_override_filtered_depth: consumed by the next mfo_mm_process_frame */
     int frameToFrameRGB;            /* as mfo_ctx */
     int bboxLimit;                  /* object models limit their fusion depth by lastBoundingBox (upstream with its GUI; default 1) */
+    int32_t trackable[256]; int nTrackable;   /* MaskFusion::trackableClassIds (MaskFusion.cpp:261,940); empty: every class */
+    /* test isolation ("teacher forcing"): poses another implementation obtained for this frame, by model id; consumed by the next frame */
+    int32_t forceIDs[64]; float forcePoses[64][16]; int nForce; int forceOn;
 };
 void mfo_mm_set_frame_to_frame_rgb(mfo_mm* x, int on) { x->frameToFrameRGB = on; }
 void mfo_mm_set_bbox_limit(mfo_mm* x, int on) { x->bboxLimit = on; }
 void mfo_mm_override_filtered_depth(mfo_mm* x, const float* depthF) { x->depthF_override = depthF; }
+/* MaskFusion::setTrackableClassIds (MaskFusion.cpp:940) */
+void mfo_mm_set_trackable_class_ids(mfo_mm* x, const int32_t* ids, int n) {
+    x->nTrackable = n < 0 ? 0 : (n > 256 ? 256 : n);
+    for (int i = 0; i < x->nTrackable; ++i) x->trackable[i] = ids[i];
+}
+/* Model::makeNonStatic / makeStatic(globalPose) (Model.h:264-265): initialC2Winv = pose * globalPose^-1 */
+void mfo_mm_make_nonstatic(mfo_mm* x, int i) { if (i > 0 && i < x->nModels) x->models[i].isStatic = 0; }
+int mfo_mm_is_nonstatic(const mfo_mm* x, int i) { return (i >= 0 && i < x->nModels) ? !x->models[i].isStatic : 0; }
+int mfo_mm_model_class(const mfo_mm* x, int i) { return x->models[i].classID; }
+/* Teacher forcing (test isolation, like mfo_mm_override_filtered_depth): the NEXT mfo_mm_process_frame tracks every model from its own
+ * state as usual -- that result stays readable through mfo_mm_model_tracked_pose -- and then continues with the poses given here (by model
+ * id; ids this side does not hold yet are ignored).  A tracked object model whose id is missing from the list is dropped as if by the 0.2 m
+ * jump rule (MaskFusion.cpp:268-272), one that is listed is kept whatever the length of its own step.  A chaotic quantity (the pose of an
+ * ill-conditioned object) then cannot make the two sides' model lists drift apart, and every pass of every frame is compared on equal input. */
+void mfo_mm_force_tracking(mfo_mm* x, const int32_t* ids, const float* poses16, int n) {
+    x->nForce = n < 0 ? 0 : (n > 64 ? 64 : n);
+    for (int i = 0; i < x->nForce; ++i) { x->forceIDs[i] = ids[i]; memcpy(x->forcePoses[i], poses16 + 16 * i, sizeof(float) * 16); }
+    x->forceOn = 1;
+}
+static const float* mm_forced_pose(const mfo_mm* x, int id) {
+    for (int i = 0; i < x->nForce; ++i) if (x->forceIDs[i] == id) return x->forcePoses[i];
+    return NULL;
+}
+void mfo_mm_model_tracked_pose(const mfo_mm* x, int i, float* p, int* tracked) {
+    memcpy(p, x->models[i].trackedPose, sizeof(float) * 16);
+    *tracked = x->models[i].trackedThisFrame;
+}
+/* Conditioning probe of the same step (teacher-forced frames only): the pose the tracker returns when its START pose is shifted by 1e-6 m
+ * along x.  A well-posed step forgets a micrometre; an object seen as two or three small planar faces does not (its 6x6 system has a
+ * condition number of 1e5..1e7 and the fp32 sums feeding it carry 1e-7 of noise whatever the summation order), and then no two
+ * implementations -- the reference's own float reduction tree included -- can agree more closely than this probe moves. */
+int mfo_mm_model_track_log(const mfo_mm* x, int i, float* out /* [20][32] */) {
+    memcpy(out, x->models[i].trackLog, sizeof(x->models[i].trackLog));
+    return x->models[i].trackLogN;
+}
+void mfo_mm_model_tracked_pose_alt(const mfo_mm* x, int i, float* p) { memcpy(p, x->models[i].trackedPoseAlt, sizeof(float) * 16); }
 
 void mfo_mm_default_config(mfo_mm_config* c, int W, int H, float fx, float fy, float cx, float cy) {
     memset(c, 0, sizeof(*c));
@@ -2296,6 +2351,14 @@ static void mat4_rigid_inverse_cm(const float* p, float* out) {
     pose16_to_Rt(p, R, t);
     pose_inverse_Rt(R, t, Ri, ti);
     Rt_to_pose16(Ri, ti, out);
+}
+
+void mfo_mm_make_static(mfo_mm* x, int i) {
+    if (i <= 0 || i >= x->nModels) return;
+    float ginv[16];
+    mat4_rigid_inverse_cm(x->models[0].pose, ginv);
+    mat4_mul_cm(x->models[i].pose, ginv, x->models[i].initialC2Winv);
+    x->models[i].isStatic = 1;
 }
 
 static void mm_model_init(mfo_mm* x, mm_model* m, int id, float confThr, int cap) {
@@ -2389,8 +2452,38 @@ static float mm_track(mfo_mm* x, mm_model* m, int allowFillIn) {
                 (doFillIn || (x->frameToFrameRGB && m == &x->models[0])) ? x->fillImage : m->predImage,
                 x->rgb, m->lastNext, R, t, inc, &st);
     m->lastICPError = st.lastICPError; m->lastICPCount = st.lastICPCount;
+    m->trackLogN = mfo_last_track_log(&m->trackLog[0][0]);
     Rt_to_pose16(R, t, m->pose);
     return sqrtf(inc[12] * inc[12] + inc[13] * inc[13] + inc[14] * inc[14]);
+}
+
+/* the probe: runs the step from the shifted start, keeps the result in trackedPoseAlt and restores every piece of state the step touches */
+static void mm_track_probe(mfo_mm* x, mm_model* m, int allowFillIn) {
+    const int W = x->cfg.base.W, H = x->cfg.base.H;
+    float pose0[16], last0[16];
+    memcpy(pose0, m->pose, sizeof(pose0)); memcpy(last0, m->lastPose, sizeof(last0));
+    const float e0 = m->lastICPError, c0 = m->lastICPCount;
+    uint8_t* keep[3];
+    for (int i = 0; i < 3; ++i) {
+        const size_t n = (size_t)(W >> i) * (H >> i);
+        keep[i] = (uint8_t*)malloc(n); memcpy(keep[i], m->lastNext[i], n);
+    }
+    m->pose[12] += 1e-6f;
+    mm_track(x, m, allowFillIn);
+    memcpy(m->trackedPoseAlt, m->pose, sizeof(m->pose));
+    if (getenv("MFO_PROBE_DEBUG")) {   /* exploratory: spread of the step over several micrometre shifts */
+        float ref[16]; memcpy(ref, m->pose, sizeof(ref));
+        for (int q = 0; q < 8; ++q) {
+            memcpy(m->pose, pose0, sizeof(pose0));
+            m->pose[12 + q % 3] += (q & 1 ? -1.f : 1.f) * (q < 4 ? 1e-6f : 1e-7f) * (1 + q);
+            mm_track(x, m, allowFillIn);
+            float d = 0; for (int k = 0; k < 16; ++k) d = fmaxf(d, fabsf(m->pose[k] - ref[k]));
+            fprintf(stderr, "probe model %d q %d: |step - step0| %.3e\n", m->id, q, d);
+        }
+    }
+    memcpy(m->pose, pose0, sizeof(pose0)); memcpy(m->lastPose, last0, sizeof(last0));
+    m->lastICPError = e0; m->lastICPCount = c0;
+    for (int i = 0; i < 3; ++i) { memcpy(m->lastNext[i], keep[i], (size_t)(W >> i) * (H >> i)); free(keep[i]); }
 }
 
 static void mm_predict_indices(mfo_mm* x, mm_model* m, const float* surf) {
@@ -2448,12 +2541,24 @@ int mfo_mm_process_frame(mfo_mm* x, const uint8_t* rgb, const float* depth, cons
             mfo_create_nmap(x->vmap[i], x->nmap[i], W >> i, H >> i);
         }
         /* tracking, :247-276 */
+        const int forced = x->forceOn;
+        x->forceOn = 0;
+        for (int i = 0; i < x->nModels; ++i) x->models[i].trackedThisFrame = 0;
+        if (forced) mm_track_probe(x, bg, 1);
         mm_track(x, bg, 1);
+        memcpy(bg->trackedPose, bg->pose, sizeof(bg->pose)); bg->trackedThisFrame = 1;
+        if (forced && mm_forced_pose(x, bg->id)) memcpy(bg->pose, mm_forced_pose(x, bg->id), sizeof(bg->pose));
         for (int i = 1; i < x->nModels; ++i) {
             mm_model* m = &x->models[i];
-            if (!m->isStatic || cfg->trackAllModels) {
+            int trackable = x->nTrackable == 0;   /* trackableClassIds.empty() || trackableClassIds.count(classID), :261 */
+            for (int q = 0; q < x->nTrackable; ++q) trackable |= (x->trackable[q] == m->classID);
+            if ((!m->isStatic || cfg->trackAllModels) && trackable) {
+                if (forced) mm_track_probe(x, m, 0);
                 const float d = mm_track(x, m, 0);
-                if (d >= 0.2f) { /* inactivateModel, :268-272: `float d > 0.2` compares in double -- 0.2f is the smallest float above 0.2 */
+                memcpy(m->trackedPose, m->pose, sizeof(m->pose)); m->trackedThisFrame = 1;
+                const float* fp = forced ? mm_forced_pose(x, m->id) : NULL;
+                if (fp) memcpy(m->pose, fp, sizeof(m->pose));
+                if (forced ? (fp == NULL) : (d >= 0.2f)) { /* inactivateModel, :268-272: `float d > 0.2` compares in double -- 0.2f is the smallest float above 0.2 */
                     mm_model_free(m);
                     memmove(&x->models[i], &x->models[i + 1], sizeof(mm_model) * (size_t)(x->nModels - i - 1));
                     x->nModels--; i--;
@@ -2540,3 +2645,8 @@ const float* mfo_mm_model_surfels(const mfo_mm* x, int i) { return x->models[i].
 const uint8_t* mfo_mm_segmentation(const mfo_mm* x) { return x->fullSeg; }
 const uint8_t* mfo_mm_projected_ids(const mfo_mm* x) { return x->projIDs; }
 const float* mfo_mm_edge_map(const mfo_mm* x) { return x->edge; }
+/* debug taps: model-side pyramid of the model tracked LAST in the last frame (planar [3][h][w]); the current frame's maps */
+const float* mfo_mm_dbg_map(const mfo_mm* x, int which, int level) {
+    switch (which) { case 0: return x->vmap_g[level]; case 1: return x->nmap_g[level]; case 2: return x->vmap[level]; default: return x->nmap[level]; }
+}
+const float* mfo_mm_dbg_pred(const mfo_mm* x, int model, int which) { return which == 0 ? x->models[model].predVertex : x->models[model].predNormal; }

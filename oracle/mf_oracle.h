@@ -261,6 +261,7 @@ void     mfo_get_icp_stats(const mfo_ctx* ctx, float* err, float* count);
 void     mfo_get_track_stats(const mfo_ctx* ctx, mfo_track_stats* out);
 /* iterations of the LAST mfo_track_icp call whose system was outside the solver's stated domain (< 6 inliers or cond(A) > 1e8: finding F4) */
 int      mfo_last_track_ill(void);
+int      mfo_last_track_log(float* out_20x32);   /* reduced geometric systems of the last tracking step, one row per iteration (device log layout) */
 /* per-stage wall-clock (ms) accumulated since create: order = preprocess, odomInit, odom, indexMap, fuseData,
  * fuseUpdate, clean, predict */
 void     mfo_get_timings(const mfo_ctx* ctx, double* ms8);
@@ -343,6 +344,17 @@ void    mfo_mm_override_filtered_depth(mfo_mm* x, const float* depthF);
 void    mfo_mm_set_frame_to_frame_rgb(mfo_mm* x, int on);
 /* Model::fuse's bb_max_z (Model.cpp:480-501) from the box the GUI's render pass leaves (Model.cpp:287-346); default on */
 void    mfo_mm_set_bbox_limit(mfo_mm* x, int on);
+/* MaskFusion::setTrackableClassIds (MaskFusion.cpp:261,940); Model::makeNonStatic / makeStatic / isNonstatic (Model.h:264-268) by list position */
+void    mfo_mm_set_trackable_class_ids(mfo_mm* x, const int32_t* ids, int n);
+void    mfo_mm_make_nonstatic(mfo_mm* x, int i);
+void    mfo_mm_make_static(mfo_mm* x, int i);
+int     mfo_mm_is_nonstatic(const mfo_mm* x, int i);
+int     mfo_mm_model_class(const mfo_mm* x, int i);
+/* teacher forcing (test isolation): see mf_oracle.c */
+void    mfo_mm_force_tracking(mfo_mm* x, const int32_t* ids, const float* poses16, int n);
+void    mfo_mm_model_tracked_pose(const mfo_mm* x, int i, float* pose16, int* tracked);
+int     mfo_mm_model_track_log(const mfo_mm* x, int i, float* out_20x32);
+void    mfo_mm_model_tracked_pose_alt(const mfo_mm* x, int i, float* pose16);   /* the same step from a start pose shifted by 1e-6 m */
 int     mfo_mm_process_frame(mfo_mm* x, const uint8_t* rgb, const float* depth, const uint8_t* mask,
                              const int32_t* classIDs, int nMasks, float weightMultiplier);
 int     mfo_mm_num_models(const mfo_mm* x);
@@ -353,6 +365,8 @@ const float*   mfo_mm_model_surfels(const mfo_mm* x, int i);
 const uint8_t* mfo_mm_segmentation(const mfo_mm* x);   /* last fullSegmentation */
 const uint8_t* mfo_mm_projected_ids(const mfo_mm* x);  /* last GlobalProjection ids */
 const float*   mfo_mm_edge_map(const mfo_mm* x);
+const float*   mfo_mm_dbg_map(const mfo_mm* x, int which /*0 vmap_g 1 nmap_g 2 vmap 3 nmap*/, int level);
+const float*   mfo_mm_dbg_pred(const mfo_mm* x, int model, int which /*0 vertex 1 normal*/);   /* [H][W][4] */
 
 #ifdef __cplusplus
 }

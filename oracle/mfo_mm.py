@@ -54,6 +54,22 @@ def mm_lib():
     L.mfo_mm_override_filtered_depth.argtypes = [C.c_void_p, f32p]
     L.mfo_mm_set_frame_to_frame_rgb.argtypes = [C.c_void_p, C.c_int]
     L.mfo_mm_set_bbox_limit.argtypes = [C.c_void_p, C.c_int]
+    L.mfo_mm_set_trackable_class_ids.argtypes = [C.c_void_p, i32p, C.c_int]
+    L.mfo_mm_make_nonstatic.argtypes = [C.c_void_p, C.c_int]
+    L.mfo_mm_make_static.argtypes = [C.c_void_p, C.c_int]
+    L.mfo_mm_is_nonstatic.argtypes = [C.c_void_p, C.c_int]
+    L.mfo_mm_is_nonstatic.restype = C.c_int
+    L.mfo_mm_model_class.argtypes = [C.c_void_p, C.c_int]
+    L.mfo_mm_model_class.restype = C.c_int
+    L.mfo_mm_force_tracking.argtypes = [C.c_void_p, i32p, f32p, C.c_int]
+    L.mfo_mm_model_tracked_pose.argtypes = [C.c_void_p, C.c_int, f32p, C.POINTER(C.c_int)]
+    L.mfo_mm_dbg_map.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.mfo_mm_dbg_map.restype = C.POINTER(C.c_float)
+    L.mfo_mm_dbg_pred.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.mfo_mm_dbg_pred.restype = C.POINTER(C.c_float)
+    L.mfo_mm_model_track_log.argtypes = [C.c_void_p, C.c_int, f32p]
+    L.mfo_mm_model_track_log.restype = C.c_int
+    L.mfo_mm_model_tracked_pose_alt.argtypes = [C.c_void_p, C.c_int, f32p]
     L.mfo_mm_num_models.argtypes = [C.c_void_p]
     L.mfo_mm_num_models.restype = C.c_int
     for n in ("mfo_mm_model_id", "mfo_mm_model_count"):
@@ -183,6 +199,59 @@ class OracleMM:
                                              m.ctypes.data if m is not None else None,
                                              cid.ctypes.data if cid is not None else None, len(class_ids),
                                              weight_multiplier)
+
+    def set_trackable_class_ids(self, ids):
+        a = np.ascontiguousarray(list(ids) if len(ids) else [0], np.int32)
+        mm_lib().mfo_mm_set_trackable_class_ids(self.h, a, len(ids))
+
+    def make_nonstatic(self, i):
+        mm_lib().mfo_mm_make_nonstatic(self.h, i)
+
+    def make_static(self, i):
+        mm_lib().mfo_mm_make_static(self.h, i)
+
+    def is_nonstatic(self, i):
+        return bool(mm_lib().mfo_mm_is_nonstatic(self.h, i))
+
+    def model_class(self, i):
+        return mm_lib().mfo_mm_model_class(self.h, i)
+
+    def force_tracking(self, ids, poses):
+        """teacher forcing: the next frame continues with these poses (4x4 each, by model id) after its own tracking steps, and its
+        drop decisions follow the list (see mf_oracle.c)"""
+        a = np.ascontiguousarray(list(ids), np.int32)
+        p = np.ascontiguousarray(np.stack([pose16(T) for T in poses]), np.float32) if len(ids) else np.zeros((1, 16), np.float32)
+        mm_lib().mfo_mm_force_tracking(self.h, a if len(ids) else np.zeros(1, np.int32), p.reshape(-1), len(ids))
+
+    def model_tracked_pose(self, i):
+        """(pose this side's own tracking step returned in the last frame, whether the model was tracked at all)"""
+        p = np.zeros(16, np.float32)
+        t = C.c_int(0)
+        mm_lib().mfo_mm_model_tracked_pose(self.h, i, p, C.byref(t))
+        return from_pose16(p), bool(t.value)
+
+    def dbg_map(self, what, level):
+        """'vmap_g' / 'nmap_g' (model-side pyramid of the model tracked last) or 'vmap' / 'nmap' (current frame), planar (3, h, w)"""
+        w = ("vmap_g", "nmap_g", "vmap", "nmap").index(what)
+        h_, w_ = self.H >> level, self.W >> level
+        return np.ctypeslib.as_array(mm_lib().mfo_mm_dbg_map(self.h, w, level), shape=(3, h_, w_)).copy()
+
+    def dbg_pred(self, model, what):
+        return np.ctypeslib.as_array(mm_lib().mfo_mm_dbg_pred(self.h, model, ("vertex", "normal").index(what)), shape=(self.H, self.W, 4)).copy()
+
+    def model_track_log(self, i):
+        """reduced geometric systems of model i's last tracking step: (iterations, 32) in the device log's layout"""
+        out = np.zeros((20, 32), np.float32)
+        n = mm_lib().mfo_mm_model_track_log(self.h, i, out.reshape(-1))
+        return out[:n]
+
+    def model_step_sensitivity(self, i):
+        """max |entry| by which this side's own tracking step of the last (teacher-forced) frame moves when its start pose is shifted by
+        one micrometre: the conditioning of that step, measured"""
+        p = np.zeros(16, np.float32)
+        mm_lib().mfo_mm_model_tracked_pose_alt(self.h, i, p)
+        own, _ = self.model_tracked_pose(i)
+        return float(np.abs(from_pose16(p) - own).max())
 
     @property
     def n_models(self):
