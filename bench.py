@@ -632,9 +632,12 @@ def main():
                 mf.processFrame(frames[k][0], frames[k][1], mask=frames[k][2], classIDs=cls)
             else:
                 mf.processFrame(frames[k][0], frames[k][1])
+        mf.sync()
         dt_h = time.perf_counter() - t0
         host_input = {"value": n / dt_h, "unit": "frames/s", "ms_per_step": 1e3 * dt_h / n,
-                      "note": f"mf_process_frame with host pointers: {(7 + (1 if multi else 0)) * P / 1e6:.2f} MB H2D per frame + one synchronisation per frame"}
+                      "note": f"mf_process_frame with host pointers (pageable numpy arrays): {(7 + (1 if multi else 0)) * P / 1e6:.2f} MB per frame copied into a "
+                              "pinned double buffer and uploaded asynchronously under the previous frame's kernels; no synchronisation per frame "
+                              "(rounds 1-3: one hipStreamSynchronize per frame)"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not multi:   # rank 0 at N = 1 only (the other ranks would sit in a collective)

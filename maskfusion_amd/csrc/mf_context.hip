@@ -171,6 +171,17 @@ struct mf_ctx {
 
     // frame-level
     uint8_t* d_rgb = nullptr; float* d_depth = nullptr; uint8_t* d_mask_in = nullptr; uint8_t* d_zero_mask = nullptr;
+    // mf_process_frame (host pointers, the reference's FrameData boundary) without a synchronisation per frame ("hostInputAsync", default on):
+    // the caller's buffers are copied into a pinned staging slot (so they may be reused at once), the slot goes to the device on its own
+    // stream under the previous frame's kernels, and the call returns when the frame is enqueued; every getter synchronises, as they do
+    // behind mf_process_frame_dev.  Two slots each: frame k+2 reuses what frame k used.
+    bool host_async = true;
+    hipStream_t stream_in = nullptr;
+    uint8_t* h_in[2] = {nullptr, nullptr};                 // pinned: rgb (3P) | depth (4P) | mask (P)
+    uint8_t* d_in_rgb[2] = {}; float* d_in_depth[2] = {}; uint8_t* d_in_mask[2] = {};   // slot 0 = d_rgb / d_depth / d_mask_in
+    hipEvent_t ev_in_copied[2] = {nullptr, nullptr};       // the slot's H2D copies have completed   (in -> main / pre, and the host before it refills the slot)
+    hipEvent_t ev_in_consumed[2] = {nullptr, nullptr};     // the frame that read the slot has been processed   (main -> in)
+    unsigned in_slot = 0;
     uint8_t* d_mask_tex = nullptr;  // textureMask: the last full segmentation (Core/MaskFusion.cpp:297)
     float* d_depthF[3] = {nullptr, nullptr, nullptr};  // ring: frame k filters into [k % 3], fill-in reads [(k - 1) % 3]
     float* d_vmap[2][3] = {}; float* d_nmap[2][3] = {};
@@ -192,8 +203,12 @@ struct mf_ctx {
     int model_api_packed = 0;              // mf_model_predict_indices also builds the packed column-major map clean() uses in-frame
     std::vector<int32_t> mask_classes;     // FrameData::classIDs for mf_process_frame_dev (mf_set_mask_class_ids)
     std::vector<int> trackable;            // MaskFusion::trackableClassIds (empty: every class is trackable)
-    struct RetiredLog { int id; std::vector<int64_t> ts; std::vector<float> p; };
-    std::vector<RetiredLog> retired;       // pose logs of dropped models (MaskFusion::inactiveModels, exportPoses)
+    // pose logs of dropped models (MaskFusion::inactiveModels, exportPoses).  A drop must not stall the frame it happens in (a scene of tracked
+    // objects drops and re-spawns one every few frames): the entries are copied device-to-device, in stream order, into an arena allocated
+    // once (`arena_off` / `n` say where) and only read back when somebody exports them; `p` is filled then (or at once when the arena is full)
+    struct RetiredLog { int id; std::vector<int64_t> ts; std::vector<float> p; size_t arena_off = 0, n = 0; bool in_arena = false; };
+    std::vector<RetiredLog> retired;
+    float* d_retired = nullptr; size_t retired_cap = 0, retired_used = 0;   // [retired_cap][8] floats
     std::vector<std::unique_ptr<ModelState>> pool;   // MaskFusion::preallocatedModels (buffers allocated ahead of the spawn)
     unsigned long long* d_keys = nullptr;
     int* d_index = nullptr; float4* d_ivc = nullptr; float4* d_ict = nullptr; float4* d_inr = nullptr;
@@ -327,7 +342,9 @@ static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int 
         A(dev_alloc(c, m->allocs, &m->d_nmap_g[i], lp * 3));
     }
     {
-        const size_t nbmax = (size_t)std::max(icp_grid_blocks(c->W, c->H), icp_batch_max_blocks(c->W, c->H));
+        int nbm = icp_batch_max_blocks(c->W, c->H);
+        for (int i = 0; i < 3; ++i) nbm = std::max(nbm, std::max(icp_grid_blocks(c->W >> i, c->H >> i), icp_geo_grid_blocks(c->W >> i, c->H >> i)));
+        const size_t nbmax = (size_t)nbm;
         for (int b = 0; b < 2; ++b) A(dev_alloc(c, m->allocs, &m->d_partials[b], nbmax * kIcpSlots));
     }
     A(dev_alloc(c, m->allocs, &m->d_gn, 2));
@@ -408,6 +425,16 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     A(dev_alloc(c, c->allocs, &c->d_rgb, (size_t)P * 3));
     A(dev_alloc(c, c->allocs, &c->d_depth, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_mask_in, (size_t)P));
+    c->d_in_rgb[0] = c->d_rgb; c->d_in_depth[0] = c->d_depth; c->d_in_mask[0] = c->d_mask_in;
+    A(dev_alloc(c, c->allocs, &c->d_in_rgb[1], (size_t)P * 3));
+    A(dev_alloc(c, c->allocs, &c->d_in_depth[1], (size_t)P));
+    A(dev_alloc(c, c->allocs, &c->d_in_mask[1], (size_t)P));
+    for (int i = 0; i < 2; ++i) {
+        A(host_alloc(c, &c->h_in[i], (size_t)P * 8));
+        if (hipEventCreateWithFlags(&c->ev_in_copied[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_in_consumed[i], hipEventDisableTiming) != hipSuccess) return fail(MF_EHIP);
+    }
+    if (hipStreamCreateWithFlags(&c->stream_in, hipStreamNonBlocking) != hipSuccess) return fail(MF_EHIP);
     A(dev_alloc(c, c->allocs, &c->d_zero_mask, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_mask_tex, (size_t)P));
     for (int b = 0; b < 3; ++b) A(dev_alloc(c, c->allocs, &c->d_depthF[b], (size_t)P));
@@ -462,7 +489,7 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     A(dev_alloc(c, c->allocs, &c->d_flags, (size_t)c->cap_max + P));
     A(dev_alloc(c, c->allocs, &c->d_newconf, (size_t)c->cap_max + P));
     A(dev_alloc(c, c->allocs, &c->d_block_counts, (size_t)kCompactBlocks));
-    A(dev_alloc(c, c->allocs, &c->d_icp_prof, (size_t)20 * 8));
+    A(dev_alloc(c, c->allocs, &c->d_icp_prof, (size_t)20 * 16));
     A(dev_alloc(c, c->allocs, &c->d_edge, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_bin, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_tmp_u8, (size_t)P));
@@ -520,6 +547,11 @@ extern "C" void mf_destroy(mf_ctx* c) {
     }
     if (c->ev_labels) (void)hipEventDestroy(c->ev_labels);
     if (c->ev_staged) (void)hipEventDestroy(c->ev_staged);
+    for (int i = 0; i < 2; ++i) {
+        if (c->ev_in_copied[i]) (void)hipEventDestroy(c->ev_in_copied[i]);
+        if (c->ev_in_consumed[i]) (void)hipEventDestroy(c->ev_in_consumed[i]);
+    }
+    if (c->stream_in) { (void)hipStreamSynchronize(c->stream_in); (void)hipStreamDestroy(c->stream_in); }
     for (int i = 0; i < mf_ctx::kObjArgSlots; ++i) {
         if (c->d_obj_args[i]) (void)hipFree(c->d_obj_args[i]);
         if (c->h_obj_args[i]) (void)hipHostFree(c->h_obj_args[i]);
@@ -597,7 +629,7 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
             l.partials_out = m.d_partials[k & 1];
             l.state_in = &m.d_gn[k & 1]; l.state_out = &m.d_gn[(k + 1) & 1];
             l.log_out = (k > 0) ? m.d_icp_log + 32 * (k - 1) : nullptr;
-            l.prof_out = (c->icp_prof_on && m.id == 0 && !rgb) ? c->d_icp_prof + 8 * k : nullptr;
+            l.prof_out = (c->icp_prof_on && m.id == 0 && !rgb) ? c->d_icp_prof + 16 * k : nullptr;
             l.pose_in = (k == 0) ? m.d_pose : nullptr;
             l.so3_in = (k == 0) ? so3_seed : nullptr;
             if (!rgb) {
@@ -622,7 +654,7 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
                 r.so3_in = l.so3_in;
                 launch_rgbd_iteration(r, s);
             }
-            nb_prev = icp_grid_blocks(l.W, l.H);
+            nb_prev = rgb ? icp_grid_blocks(l.W, l.H) : icp_geo_grid_blocks(l.W, l.H);
             prev_level = lvl;
             ++k;
         }
@@ -991,6 +1023,63 @@ static int enqueue_predict_loop(mf_ctx* c, size_t first, bool may_batch, int64_t
     return MF_OK;
 }
 
+// inactivateModel (Core/MaskFusion.cpp:699-713) for models[i], i > 0: the pose log moves to the retired list, the MODEL -- its surfel
+// buffers, maps and scratch, ~100 MB at VGA -- goes back to the preallocation pool instead of being freed (upstream deletes the data; what a
+// later spawn gets is a fresh model either way: spawn_object re-initialises pose, frame state and counters on the stream).  Neither step
+// waits for the GPU: round 3 freed ~30 allocations here and allocated them again (plus a drained stream and a 2 MB read-back for the log) at
+// the next spawn -- 1.5 of the 2.4 ms of a frame of bench.py --config 2s, whose scene drops and re-spawns a tracked box every other frame.
+static int retire_model(mf_ctx* c, size_t i) {
+    std::unique_ptr<ModelState> m = std::move(c->models[i]);
+    c->models.erase(c->models.begin() + (long)i);
+    const size_t cap = (size_t)c->cfg.pose_log_capacity, n_all = m->log_ts.size(), n = n_all < cap ? n_all : cap;
+    if (m->d_poselog && n > 0) {
+        mf_ctx::RetiredLog r;
+        r.id = m->id;
+        r.ts.assign(m->log_ts.end() - (long)n, m->log_ts.end());
+        r.n = n;
+        if (!c->d_retired) {
+            c->retired_cap = 1u << 17;   // 131 072 entries of 32 B: 4 MB, once
+            void* q = nullptr;
+            if (hipMalloc(&q, c->retired_cap * 8 * sizeof(float)) == hipSuccess) { c->d_retired = (float*)q; c->allocs.push_back(q); }
+            else { (void)hipGetLastError(); c->retired_cap = 0; }
+        }
+        if (c->d_retired && c->retired_used + n <= c->retired_cap) {
+            // chronological order: entries n_all - n .. n_all - 1 of a ring of `cap` slots -> at most two contiguous pieces
+            const size_t first = (n_all - n) % cap, run1 = (first + n <= cap) ? n : cap - first;
+            MF_HIP(c, hipMemcpyAsync(c->d_retired + c->retired_used * 8, m->d_poselog + first * 8, run1 * 8 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+            if (run1 < n)
+                MF_HIP(c, hipMemcpyAsync(c->d_retired + (c->retired_used + run1) * 8, m->d_poselog, (n - run1) * 8 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+            r.arena_off = c->retired_used; r.in_arena = true;
+            c->retired_used += n;
+        } else {
+            std::vector<int64_t> ts;
+            int rc = download_pose_log(c, *m, ts, r.p);   // arena full: the synchronising path
+            if (rc != MF_OK) return rc;
+        }
+        c->retired.push_back(std::move(r));
+    }
+    m->id = -1; m->classID = -1; m->age = 0; m->isStatic = true; m->log_ts.clear(); m->cur = 0; m->pred_gray_valid = false; m->maxDepth = FLT_MAX;
+    *m->h_count = 0;
+    c->pool.push_back(std::move(m));
+    return MF_OK;
+}
+// the retired logs' entries on the host (export time: a synchronisation is fine there)
+static int materialise_retired(mf_ctx* c) {
+    bool any = false;
+    for (auto& r : c->retired) any |= r.in_arena;
+    if (!any) return MF_OK;
+    MF_HIP(c, hipStreamSynchronize(c->stream));
+    for (auto& r : c->retired) {
+        if (!r.in_arena) continue;
+        std::vector<float> raw(r.n * 8);
+        MF_HIP(c, hipMemcpy(raw.data(), c->d_retired + r.arena_off * 8, r.n * 8 * sizeof(float), hipMemcpyDeviceToHost));
+        r.p.clear();
+        for (size_t e = 0; e < r.n; ++e) r.p.insert(r.p.end(), raw.data() + e * 8, raw.data() + e * 8 + 7);
+        r.in_arena = false;
+    }
+    return MF_OK;
+}
+
 static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_depth, const uint8_t* d_mask_in,
                               const int32_t* class_ids, int n_masks, float weight_multiplier, int64_t timestamp = 0,
                               const float* in_pose16 = nullptr, bool bootstrap = false) {
@@ -1106,10 +1195,8 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
             // inactivateModel for objects the jump rule dropped (:268-272); data is deleted (no re-detection upstream)
             for (size_t i = 1; i < c->models.size();) {
                 if (c->models[i]->h_pose->alive == 0) {
-                    mf_ctx::RetiredLog r;
-                    r.id = c->models[i]->id;
-                    if (download_pose_log(c, *c->models[i], r.ts, r.p) == MF_OK && !r.ts.empty()) c->retired.push_back(std::move(r));
-                    c->models.erase(c->models.begin() + i);
+                    int rc = retire_model(c, i);
+                    if (rc != MF_OK) return rc;
                 } else ++i;
             }
             if (!c->gpu_labels) {
@@ -1211,7 +1298,29 @@ extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* dept
                                 int32_t n_masks, int64_t timestamp, const float* in_pose16, float weight_multiplier, int32_t bootstrap) {
     if (!c || !rgb || !depth) return MF_EINVAL;
     if (bootstrap && !in_pose16) { c->err = "bootstrap needs in_pose (MaskFusion.cpp:281)"; return MF_EINVAL; }
-    // staged on the input stream (the frame is first read there); the previous frame has completed (this call syncs)
+    if (c->host_async) {
+        // pinned double buffer + asynchronous upload: no hipStreamSynchronize per frame on the boundary a drop-in
+        // user sees (MaskFusion.cpp:212-216 uploads FrameData every frame)
+        const size_t P = (size_t)c->P;
+        const int slot = (int)(c->in_slot++ & 1u);
+        MF_HIP(c, hipEventSynchronize(c->ev_in_copied[slot]));        // the staging slot's previous upload (two frames ago) has left it
+        uint8_t* h = c->h_in[slot];
+        memcpy(h, rgb, P * 3);
+        memcpy(h + P * 3, depth, P * sizeof(float));
+        if (mask) memcpy(h + P * 7, mask, P);
+        MF_HIP(c, hipStreamWaitEvent(c->stream_in, c->ev_in_consumed[slot], 0));   // the frame that read these device buffers is done
+        MF_HIP(c, hipMemcpyAsync(c->d_in_rgb[slot], h, P * 3, hipMemcpyHostToDevice, c->stream_in));
+        MF_HIP(c, hipMemcpyAsync(c->d_in_depth[slot], h + P * 3, P * sizeof(float), hipMemcpyHostToDevice, c->stream_in));
+        if (mask) MF_HIP(c, hipMemcpyAsync(c->d_in_mask[slot], h + P * 7, P, hipMemcpyHostToDevice, c->stream_in));
+        MF_HIP(c, hipEventRecord(c->ev_in_copied[slot], c->stream_in));
+        MF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_in_copied[slot], 0));
+        if (c->overlap) MF_HIP(c, hipStreamWaitEvent(c->stream_pre, c->ev_in_copied[slot], 0));
+        int rc = process_frame_impl(c, c->d_in_rgb[slot], c->d_in_depth[slot], mask ? c->d_in_mask[slot] : nullptr, class_ids, n_masks, weight_multiplier,
+                                    timestamp, in_pose16, bootstrap != 0);
+        (void)hipEventRecord(c->ev_in_consumed[slot], c->stream);     // (also on a failed frame: the slot must become reusable)
+        return rc;
+    }
+    // blocking form: staged on the input stream (the frame is first read there); the previous frame has completed (this call syncs)
     hipStream_t sin = c->overlap ? c->stream_pre : c->stream;
     MF_HIP(c, hipMemcpyAsync(c->d_rgb, rgb, (size_t)c->P * 3, hipMemcpyHostToDevice, sin));
     MF_HIP(c, hipMemcpyAsync(c->d_depth, depth, (size_t)c->P * sizeof(float), hipMemcpyHostToDevice, sin));
@@ -1735,12 +1844,7 @@ extern "C" int mf_spawn_object_model(mf_ctx* c, int32_t id, int32_t class_id) {
 extern "C" int mf_drop_model(mf_ctx* c, int32_t model) {
     ModelState* m = model_at(c, model);
     if (!m || model == 0) return MF_EINVAL;
-    mf_ctx::RetiredLog r;
-    r.id = m->id;
-    if (download_pose_log(c, *m, r.ts, r.p) == MF_OK && !r.ts.empty()) c->retired.push_back(std::move(r));
-    MF_HIP(c, hipStreamSynchronize(c->stream));
-    c->models.erase(c->models.begin() + model);
-    return MF_OK;
+    return retire_model(c, (size_t)model);
 }
 // Model::updateStaticPose(globalPose) (Core/Model/Model.h:263): pose = initialC2Winv * background pose
 extern "C" int mf_model_update_static_pose(mf_ctx* c, int32_t model) {
@@ -1877,6 +1981,10 @@ extern "C" int mf_export_poses(mf_ctx* c, const char* export_dir) {
         if (rc != MF_OK) return rc;
         if (!m->d_poselog) continue;
         rc = write_pose_file(c, dir, m->id, t, p);
+        if (rc != MF_OK) return rc;
+    }
+    {
+        int rc = materialise_retired(c);
         if (rc != MF_OK) return rc;
     }
     for (auto& r : c->retired) {
@@ -2085,6 +2193,10 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!c || !key) return MF_EINVAL;
     if (!strcmp(key, "timings")) { c->timings_on = value != 0; return MF_OK; }
     if (!strcmp(key, "icpProfile")) { c->icp_prof_on = value != 0; return MF_OK; }
+    if (!strcmp(key, "hostInputAsync")) {   // 0: mf_process_frame blocks until the frame is fused (rounds 1-3); 1: returns when it is enqueued
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipStreamSynchronize(c->stream_in) != hipSuccess) return MF_EHIP;
+        c->host_async = value != 0; return MF_OK;
+    }
     if (!strcmp(key, "splatProfile")) {   // per-tile shader-clock stamps of k_splat_tile (tools/splat_prof.py); debug tap "splat_prof"
         if (value != 0 && !c->d_splat_prof) {
             if (hipMalloc(&c->d_splat_prof, splat_tiles_scratch_ints(c->W, c->H) * 8 * sizeof(unsigned long long)) != hipSuccess) return MF_ENOMEM;
@@ -2208,7 +2320,7 @@ static int debug_read_impl(mf_ctx* c, ModelState& mdl, const char* what, void* o
     else if (w == "clean_flags") { src = c->d_flags; bytes = (size_t)c->cap_max + P; variable = true; }
     else if (w == "clean_newconf") { src = c->d_newconf; bytes = ((size_t)c->cap_max + P) * 4; variable = true; }
     else if (w == "icp_log") { src = mdl.d_icp_log; bytes = 19 * 32 * 4; }
-    else if (w == "icp_prof") { src = c->d_icp_prof; bytes = 19 * 8 * 8; }
+    else if (w == "icp_prof") { src = c->d_icp_prof; bytes = 19 * 16 * 8; }
     else if (w == "splat_prof") {
         if (!c->d_splat_prof) { c->err = "splat_prof: switch splatProfile on first"; return MF_ESTATE; }
         src = c->d_splat_prof; bytes = splat_tiles_scratch_ints(c->W, c->H) * 8 * 8;
@@ -2444,7 +2556,7 @@ extern "C" int mf_k_icp_step(const float* Rcurr9, const float* tcurr3, const flo
     if (!Rcurr9 || !tcurr3 || !d_vc || !d_nc || !Rpi9 || !tprev3 || !d_vp || !d_np || !d_out32 || (W * H) % 4) return MF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     float* scratch = nullptr;
-    const size_t nb = (size_t)icp_grid_blocks(W, H);
+    const size_t nb = (size_t)icp_geo_grid_blocks(W, H);
     const size_t bytes = nb * kIcpSlots * sizeof(float) + 2 * sizeof(GNState) + 24 * sizeof(float) + 64;
     if (hipMalloc((void**)&scratch, bytes) != hipSuccess) return MF_ENOMEM;
     char* base = reinterpret_cast<char*>(scratch);

@@ -183,6 +183,8 @@ __device__ __forceinline__ double sqrt_d(double x) {  // x > 0
 }
 
 __device__ inline void m33_inverse_f(const float* m, float* inv) {  // cofactor inverse (Eigen fixed-size stand-in)
+#pragma clang fp contract(off)   // every operation rounded on its own, as the CPU restatement computes it: the inverse pose must not depend on the
+                                 // kernel it was derived in (round 4: see pose_derive)
     const float c00 = m[4] * m[8] - m[5] * m[7];
     const float c01 = m[5] * m[6] - m[3] * m[8];
     const float c02 = m[3] * m[7] - m[4] * m[6];
@@ -197,6 +199,7 @@ __device__ inline void m33_inverse_f(const float* m, float* inv) {  // cofactor 
 // Model::rodrigues2 (Core/Model/Model.cpp:891-932); the SVD re-orthonormalisation U V^T is done by Newton polar
 // iterations (identical to rounding for near-rotations).
 __device__ inline void rodrigues2_d(const float* Rin, double* r) {
+#pragma clang fp contract(off)
     double R[9], Rn[9];
     for (int k = 0; k < 9; ++k) R[k] = Rin[k];
     for (int it = 0; it < 4; ++it) {
@@ -246,6 +249,7 @@ __device__ inline void rodrigues2_d(const float* Rin, double* r) {
 // no contraction: the same bits as the CPU restatement) and rounded to float where the reference's SVD product is float.
 __device__ inline void rodrigues2_literal_d(const float* Rin, double* r) {
 #pragma clang fp contract(off)
+#pragma clang fp contract(off)
     double R[9], Rn[9];
     for (int k = 0; k < 9; ++k) R[k] = Rin[k];
     for (int it = 0; it < 4; ++it) {
@@ -289,21 +293,30 @@ __device__ inline void rodrigues2_literal_d(const float* Rin, double* r) {
 // Derived members of PoseDev from (R,t) and (lastR,lastT): inverse and Model::computeFusionWeight(1.0)
 // (Core/Model/Model.cpp:449-464).
 __device__ inline void pose_derive(PoseDev& p) {
+    // Contraction off, operands in the CPU restatement's order.  This function is inlined into kernels of several files; mf_odometry.hip (the
+    // Gauss-Newton finalize kernels) is compiled with FMA contraction, the surfel / pose-override kernels without.  Left to the compiler, the
+    // inverse pose of a TRACKED frame came out one ulp away from the restatement's (an overridden pose did not), surfels on a pixel border
+    // projected into the neighbouring texel and two of 76 800 association decisions of a teacher-forced frame differed on the MI355X while the
+    // CPU-executed kernels agreed everywhere (round 4, tests/test_gpu_parity_long.py::test_s2_eight_objects_tracked_teacher_forced).
+#pragma clang fp contract(off)
     m33_inverse_f(p.R, p.Ri);
-    const float3 v = mul33(p.Ri, f3(p.t[0], p.t[1], p.t[2]));
-    p.ti[0] = -v.x; p.ti[1] = -v.y; p.ti[2] = -v.z;
+    p.ti[0] = -(p.Ri[0] * p.t[0] + p.Ri[1] * p.t[1] + p.Ri[2] * p.t[2]);
+    p.ti[1] = -(p.Ri[3] * p.t[0] + p.Ri[4] * p.t[1] + p.Ri[5] * p.t[2]);
+    p.ti[2] = -(p.Ri[6] * p.t[0] + p.Ri[7] * p.t[1] + p.Ri[8] * p.t[2]);
     // getLastTransform() = pose^-1 * lastPose
     float Rd[9];
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c)
             Rd[r * 3 + c] = p.Ri[r * 3] * p.lastR[c] + p.Ri[r * 3 + 1] * p.lastR[3 + c] + p.Ri[r * 3 + 2] * p.lastR[6 + c];
-    float3 td = mul33(p.Ri, f3(p.lastT[0], p.lastT[1], p.lastT[2]));
+    float3 td = f3(p.Ri[0] * p.lastT[0] + p.Ri[1] * p.lastT[1] + p.Ri[2] * p.lastT[2], p.Ri[3] * p.lastT[0] + p.Ri[4] * p.lastT[1] + p.Ri[5] * p.lastT[2],
+                   p.Ri[6] * p.lastT[0] + p.Ri[7] * p.lastT[1] + p.Ri[8] * p.lastT[2]);
     td = f3(td.x + p.ti[0], td.y + p.ti[1], td.z + p.ti[2]);
     double rv[3];
     if (p.weightLiteral) rodrigues2_literal_d(Rd, rv);
     else rodrigues2_d(Rd, rv);
     const float rn = (float)sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
-    float weighting = fmaxf(norm3(td), rn);
+    const float tn = sqrtf(td.x * td.x + td.y * td.y + td.z * td.z);
+    float weighting = fmaxf(tn, rn);
     const float largest = 0.01f, minWeight = 0.5f;
     if (weighting > largest) weighting = largest;
     p.fusionWeight = fmaxf(1.0f - (weighting / largest), minWeight);
@@ -320,16 +333,25 @@ __device__ inline void quat_from_rot(const float* m /*row-major*/, float* q /*x 
         t = 0.5f / t;
         q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t;
     } else {
+        // the three cases written out with constant indices (i = largest diagonal entry, j = i + 1, k = j + 1 mod 3): an index computed at run
+        // time puts m[] and q[] into scratch memory -- 48 bytes per lane that every launch of every kernel containing this (the tiled
+        // prediction's epilogue among them) then has to set up
         int i = 0;
         if (m[4] > m[0]) i = 1;
-        if (m[8] > m[i * 3 + i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrtf(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0f);
-        q[i] = 0.5f * t;
-        t = 0.5f / t;
-        q[3] = (m[k * 3 + j] - m[j * 3 + k]) * t;
-        q[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
-        q[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+        if (m[8] > (i == 0 ? m[0] : m[4])) i = 2;
+        if (i == 0) {        // j = 1, k = 2
+            t = sqrtf(m[0] - m[4] - m[8] + 1.0f);
+            q[0] = 0.5f * t; t = 0.5f / t;
+            q[3] = (m[7] - m[5]) * t; q[1] = (m[3] + m[1]) * t; q[2] = (m[6] + m[2]) * t;
+        } else if (i == 1) { // j = 2, k = 0
+            t = sqrtf(m[4] - m[8] - m[0] + 1.0f);
+            q[1] = 0.5f * t; t = 0.5f / t;
+            q[3] = (m[2] - m[6]) * t; q[2] = (m[7] + m[5]) * t; q[0] = (m[1] + m[3]) * t;
+        } else {             // j = 0, k = 1
+            t = sqrtf(m[8] - m[0] - m[4] + 1.0f);
+            q[2] = 0.5f * t; t = 0.5f / t;
+            q[3] = (m[3] - m[1]) * t; q[0] = (m[2] + m[6]) * t; q[1] = (m[5] + m[7]) * t;
+        }
     }
 }
 __device__ inline void pose_log_entry(const PoseDev* pose, const PoseDev* bg /*nullptr for the background itself*/, float* o /*[8]*/) {

@@ -128,11 +128,12 @@ struct IcpLaunch {
     float* partials_out;
     const GNState* state_in; GNState* state_out;
     float* log_out;                              // optional [32] floats of the reduced system solved in this launch
-    unsigned long long* prof_out = nullptr;      // optional [8] shader-clock stamps (workgroup 0)
+    unsigned long long* prof_out = nullptr;      // optional [16] shader-clock stamps (workgroup 0)
     const PoseDev* pose_in = nullptr;            // first launch only: seed the Gauss-Newton state from this pose
     const So3Result* so3_in = nullptr;           // first launch only: SO(3) pre-alignment seeds resultRt's rotation
 };
-int icp_grid_blocks(int W, int H);
+int icp_grid_blocks(int W, int H);       // workgroups of the RGB-D iteration kernels for this level
+int icp_geo_grid_blocks(int W, int H);   // workgroups of the geometric kernel k_icp_iter (more of them at the coarse levels: one pixel slot per thread)
 void launch_icp_iteration(const IcpLaunch& a, hipStream_t s);
 // ---- the same loop for SEVERAL models at once (MaskFusion.cpp:247-276 tracks them one after the other): one launch serves
 // iteration k of every tracked model.  Split in two kernels per iteration -- "solve" (one workgroup per model: reduce the

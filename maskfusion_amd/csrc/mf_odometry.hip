@@ -191,17 +191,38 @@ __device__ __forceinline__ void gn_solve_update_serial(const double* sys, const 
     gn_update_from_x(x, (float)sys[27], (float)sys[28], in, out);
 }
 
-// The same update with the state resident in LDS and the work after the solve spread over twelve lanes (round 3).  One thread used to run
-// unpack -> LDL^T -> exp -> 3x4 fp64 composition -> float conversions -> 3x3 products -> ~110 scalar stores: ~460 instructions on the one
-// chain every workgroup of every iteration launch waits for (3.2 k cycles = 1.5 us).  Now lanes 0..11 of wavefront 0 each solve the
-// system redundantly in registers (so x needs no broadcast: the LDL^T is ~120 instructions whichever way it is cut) and then compute ONE
-// entry of the 3x4 block of resultRt / of Rcurr / tcurr each, exchanging through 16 floats of LDS: ~230 instructions on the chain.
-// Called by ALL threads of the workgroup (it contains barriers; the other wavefronts only wait at them, as they did before).
-// s_st is updated in place: resultRt, Rcurr, tcurr, trR, trt, lastICPError / Count, valid; everything else keeps its value.  s_pose
+// The same update with the state resident in LDS, run by WAVEFRONT 0 ALONE (the other wavefronts of the workgroup return at once and wait
+// at the caller's next barrier, as they always did).  Lanes 0..11 each solve the system redundantly in registers (so x needs no broadcast:
+// the LDL^T is ~120 instructions whichever way it is cut) and compute ONE entry of the 3x4 block of resultRt; the float work after that --
+// transform^-1, Rcurr = Rprev iR, tcurr = Rprev it + tprev -- is exchanged between those lanes with wavefront shuffles.
+// Round 3 exchanged through LDS behind three workgroup barriers: the in-kernel stamps of round 4 (profiles/r04a_icp_prof.txt) priced those
+// three steps at 500 + 650 + 480 of the prologue's ~4 000 cycles, more than the LDL^T (1 000) or exp + composition (1 000).  LDS
+// instructions of ONE wavefront execute in issue order, so reading the old resultRt and then overwriting it needs no barrier either.
+// The float expressions are those of the CPU restatement, operation by operation (contraction off): given the same T the pose is the
+// oracle's bit for bit, in every kernel that calls this.
+// s_st is updated in place: resultRt, Rcurr, tcurr, trR, trt, lastICPError / Count, valid, ill; everything else keeps its value.  s_pose
 // receives Rcurr[9] tcurr[3] (slots 0..11; slots 12..23 = Rprev_inv, tprev are pose-independent and written by the caller once).
-__device__ __forceinline__ void gn_finish_wg(const double* s_sys, GNState* s_st, float* s_pose, float* s_T /*[16]*/) {
+// The caller places a barrier between this call and any other wavefront's use of s_st / s_pose.
+struct GnStamps { unsigned long long t[6]; };   // shader-clock stamps inside the solve (profiling; thread 0 of workgroup 0)
+__device__ __forceinline__ void gn_finish_wg(const double* s_sys, GNState* s_st, float* s_pose, float* s_T /*[16], unused since round 4*/, bool stamps,
+                                             GnStamps& st) {
+    (void)s_T;
+    if (threadIdx.x == 64) {   // wavefront 1 has nothing to do until the caller's barrier: the iteration's statistics (an IEEE square root and a
+                               // division, ~150 cycles) leave wavefront 0's chain
+        const float res = (float)s_sys[27], inl = (float)s_sys[28];
+        s_st->lastICPError = sqrtf(res) / inl;
+        s_st->lastICPCount = inl;
+        s_st->valid = 1;
+    }
+    if (threadIdx.x >= 64) return;
     const int l = threadIdx.x;
     const int r = (l >> 2) & 3, c = l & 3;   // lanes 0..11: entry (r, c) of the 3x4 block
+    // pose-independent operands of the float tail, fetched before the solve (their latency hides under it): row `row` of Rprev, tprev[q]
+    const int rr = l / 3, cc = l - 3 * rr, q = l - 9;
+    const bool isR = l < 9, isT = l >= 9 && l < 12;
+    const int row = isR ? rr : (isT ? q : 0);
+    const float p0 = s_st->Rprev[row * 3 + 0], p1 = s_st->Rprev[row * 3 + 1], p2 = s_st->Rprev[row * 3 + 2];
+    const float tpq = s_st->tprev[isT ? q : 0];
     double nr = 0.0;
     int ill = 0;
     if (l < 12) {
@@ -215,8 +236,10 @@ __device__ __forceinline__ void gn_finish_wg(const double* s_sys, GNState* s_st,
                 if (j == 6) b[i] = value;
                 else { A[i][j] = value; A[j][i] = value; }
             }
+        if (stamps) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st.t[0] = __builtin_amdgcn_s_memtime(); }
         ldlt6_solve(A, b, x, &ratio);
         ill = (s_sys[28] < 6.0 || !(ratio >= 1e-8)) ? 1 : 0;   // outside the stated domain of this solver (finding F4): counted, see GNState::ill
+        if (stamps) st.t[1] = __builtin_amdgcn_s_memtime() + (unsigned long long)(x[0] == 1.2345e300);   // (the stamp waits for the solve)
         double Rw[3][3];
         rodrigues_d(x[3], x[4], x[5], Rw);
         const double w0 = r == 0 ? Rw[0][0] : (r == 1 ? Rw[1][0] : Rw[2][0]);
@@ -225,39 +248,50 @@ __device__ __forceinline__ void gn_finish_wg(const double* s_sys, GNState* s_st,
         const double xr = r == 0 ? x[0] : (r == 1 ? x[1] : x[2]);
         const double* Rt = s_st->resultRt;
         nr = w0 * Rt[0 * 4 + c] + w1 * Rt[1 * 4 + c] + w2 * Rt[2 * 4 + c] + xr * Rt[3 * 4 + c];   // resultRt <- [exp(w) | t] * resultRt
+        if (stamps) st.t[2] = __builtin_amdgcn_s_memtime() + (unsigned long long)(nr == 1.2345e300);
     }
-    __syncthreads();   // every lane has read the old resultRt
+    // Isometry3f transform T = float(resultRt[0..2][0..3]) lives in lanes r * 4 + c; currentT = [Rprev|tprev] * transform.inverse():
+    // iR = trR^T, it = -iR trt, Rcurr = Rprev iR, tcurr = Rprev it + tprev.  The twelve entries are broadcast with v_readlane (a scalar
+    // register each, a few cycles) and every lane selects its operands: no LDS round trip, no ds_bpermute latency on the chain.
+    const float tv = (float)nr;
+    const int tvb = __float_as_int(tv);
+    float T[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) T[j] = __int_as_float(__builtin_amdgcn_readlane(tvb, j));
+    // lanes 0..8: a_k = T[cc][k]; lanes 9..11: a_k = T[k][q]
+    const float a0 = isR ? (cc == 0 ? T[0] : (cc == 1 ? T[4] : T[8])) : (q == 0 ? T[0] : (q == 1 ? T[1] : T[2]));
+    const float a1 = isR ? (cc == 0 ? T[1] : (cc == 1 ? T[5] : T[9])) : (q == 0 ? T[4] : (q == 1 ? T[5] : T[6]));
+    const float a2 = isR ? (cc == 0 ? T[2] : (cc == 1 ? T[6] : T[10])) : (q == 0 ? T[8] : (q == 1 ? T[9] : T[10]));
+    const float t0 = T[3], t1 = T[7], t2 = T[11];                                                   // trt
+    float rcur, itq;
+    {
+#pragma clang fp contract(off)
+        rcur = p0 * a0 + p1 * a1 + p2 * a2;                 // lanes 0..8: Rcurr[rr][cc] = sum_k Rprev[rr][k] iR[k][cc], iR[k][cc] = T[cc][k]
+        itq = -(a0 * t0 + a1 * t1 + a2 * t2);               // lanes 9..11: it[q] = -(iR trt)[q], iR[q][k] = T[k][q]
+    }
+    const int itb = __float_as_int(itq);
+    const float i0 = __int_as_float(__builtin_amdgcn_readlane(itb, 9)), i1 = __int_as_float(__builtin_amdgcn_readlane(itb, 10)),
+                i2 = __int_as_float(__builtin_amdgcn_readlane(itb, 11));
+    float tcur;
+    {
+#pragma clang fp contract(off)
+        tcur = (p0 * i0 + p1 * i1 + p2 * i2) + tpq;         // lanes 9..11: tcurr[q]
+    }
     if (l < 12) {
-        s_st->resultRt[r * 4 + c] = nr;
-        s_T[l] = (float)nr;             // Isometry3f transform: trR = T[r][0..2], trt = T[r][3]
-        if (l == 0) {
-            const float res = (float)s_sys[27], inl = (float)s_sys[28];
-            s_st->lastICPError = sqrtf(res) / inl;
-            s_st->lastICPCount = inl;
-            s_st->valid = 1;
-            s_st->ill += ill;
-        }
+        s_st->resultRt[r * 4 + c] = nr;   // behind the broadcast: every lane of the wavefront has read the old block by now (one wavefront,
+                                          // instructions in order -- and a schedule-independent order for the CPU-executed build)
+        if (c < 3) s_st->trR[r * 3 + c] = tv; else s_st->trt[r] = tv;
     }
-    __syncthreads();
-    // currentT = [Rprev|tprev] * transform.inverse():  iR = trR^T, it = -iR trt, Rcurr = Rprev iR, tcurr = Rprev it + tprev
-    if (l < 9) {
-        const int rr = l / 3, cc = l - 3 * rr;
-        const float v = s_st->Rprev[rr * 3 + 0] * s_T[cc * 4 + 0] + s_st->Rprev[rr * 3 + 1] * s_T[cc * 4 + 1] + s_st->Rprev[rr * 3 + 2] * s_T[cc * 4 + 2];
-        s_st->Rcurr[l] = v;
-        s_pose[l] = v;
-        s_st->trR[l] = s_T[rr * 4 + cc];
-    } else if (l < 12) {
-        const int q = l - 9;
-        s_T[12 + q] = -(s_T[0 * 4 + q] * s_T[0 * 4 + 3] + s_T[1 * 4 + q] * s_T[1 * 4 + 3] + s_T[2 * 4 + q] * s_T[2 * 4 + 3]);
-        s_st->trt[q] = s_T[q * 4 + 3];
+    if (isR) { s_st->Rcurr[l] = rcur; s_pose[l] = rcur; }
+    else if (isT) { s_st->tcurr[q] = tcur; s_pose[9 + q] = tcur; }
+    if (l == 0) {
+        s_st->ill += ill;
+        if (stamps) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st.t[3] = __builtin_amdgcn_s_memtime(); st.t[4] = st.t[3]; st.t[5] = st.t[3]; }
     }
-    __syncthreads();
-    if (l >= 9 && l < 12) {
-        const int q = l - 9;
-        const float v = (s_st->Rprev[q * 3 + 0] * s_T[12] + s_st->Rprev[q * 3 + 1] * s_T[13] + s_st->Rprev[q * 3 + 2] * s_T[14]) + s_st->tprev[q];
-        s_st->tcurr[q] = v;
-        s_pose[9 + q] = v;
-    }
+}
+__device__ __forceinline__ void gn_finish_wg(const double* s_sys, GNState* s_st, float* s_pose, float* s_T /*[16]*/) {
+    GnStamps unused;
+    gn_finish_wg(s_sys, s_st, s_pose, s_T, false, unused);
 }
 
 // Fixed-order reduction of `nb` per-workgroup partials ([nb][32] floats) by a 256-thread workgroup -> sys[32] doubles
@@ -451,7 +485,7 @@ struct IcpKArgs {
     float* partials_out;
     const GNState* st_in; GNState* st_out;
     float* log_out;
-    unsigned long long* prof_out;  // optional: 8 shader-clock stamps of workgroup 0 / thread 0
+    unsigned long long* prof_out;  // optional: 16 shader-clock stamps of workgroup 0 / thread 0 (8 of the launch + 6 inside the solve)
     const PoseDev* pose_in;        // first launch of a tracking step: seed the state from the model pose
     const So3Result* so3_in;       // ... and resultRt's rotation from the SO(3) pre-alignment (RGBDOdometry.cpp:338-344)
 };
@@ -554,8 +588,15 @@ __host__ __device__ inline int icp_chunk(int P, int nblocks) {
 
 // kT: threads per workgroup (512 at level 0; 256 at the coarse levels, where there are fewer 512-pixel chunks than CUs:
 // twice the workgroups, half the wavefronts per CU -> half the per-CU halving-reduction time)
-template <int kT>
+// kPx: pixel slots per thread = ceil(chunk / kT): 3 at level 0 of a VGA frame (1280-pixel chunks), 2 at level 1 (320), 1 at level 2 (256).
+// The pixel phase is VALU-bound (~330 instructions per pixel; a SIMD issues one wave-instruction per 2 cycles), so a slot nobody needs is
+// not free: round 3 ran three slots at every level -- at level 2 two thirds of the phase's instructions worked on masked pixels.  A slot
+// whose 64 pixels all lie beyond the chunk is skipped by the WHOLE wavefront (a scalar branch, no exec-mask bookkeeping): at level 0 the
+// chunk is 2.5 slots, wavefronts 4..7 skip the third one and every SIMD carries 5 slots instead of 6.  Masked or skipped, a slot adds
+// nothing to the sums: results are bit-identical to the three-slot form.
+template <int kT, int kPx>
 __global__ __launch_bounds__(kT) void k_icp_iter(const IcpKArgs a) {
+    constexpr bool kSkipIdleSlots = kT == 256 && kPx > 1;
     __shared__ double s_seg[32 * 32];
     __shared__ double s_sys[32];
     __shared__ float s_pose[24];  // Rcurr[9] tcurr[3] Rprev_inv[9] tprev[3]
@@ -576,26 +617,34 @@ __global__ __launch_bounds__(kT) void k_icp_iter(const IcpKArgs a) {
     }
     const bool prof = a.prof_out != nullptr && blockIdx.x == 0 && tid == 0;
     unsigned long long stamp[8];
+    GnStamps gst;
     if (prof) stamp[0] = __builtin_amdgcn_s_memtime();
     const int P = a.W * a.H;
-    // A workgroup owns a contiguous chunk of <= kIcpPx * kIcpThreads pixels (icp_grid_blocks keeps the grid <= one workgroup
+    // A workgroup owns a contiguous chunk of <= kPx * kT pixels (icp_grid_blocks keeps the grid <= one workgroup
     // per CU so that a launch is ONE round of workgroups: 300 workgroups of 1024 px on 256 CUs ran as two rounds and
-    // doubled the level-0 launch time).  Thread t handles pixels beg + t + q * kT, q < kIcpPx.
+    // doubled the level-0 launch time).  Thread t handles pixels beg + t + q * kT, q < kPx.
     const int chunk = icp_chunk(P, gridDim.x);
     const int beg = blockIdx.x * chunk, end = min(P, beg + chunk);
 
     // (1) issue the pose-independent streamed loads first so their latency overlaps the solve below
-    int idx[kIcpPx]; bool act[kIcpPx];
-    float vx[kIcpPx], vy[kIcpPx], vz[kIcpPx], nx[kIcpPx], ny[kIcpPx], nz[kIcpPx];
+    int idx[kPx]; bool act[kPx], won[kPx];
+    float vx[kPx], vy[kPx], vz[kPx], nx[kPx], ny[kPx], nz[kPx];
 #pragma unroll
-    for (int q = 0; q < kIcpPx; ++q) {
-        // slots past the end of the chunk re-read its last pixel and are masked out of the sums below: no divergent control flow
-        // around the loads / projections / gathers of the three slots (the exec-mask bookkeeping was ~10 % of the pixel phase)
+    for (int q = 0; q < kPx; ++q) {
+        // lanes past the end of the chunk re-read its last pixel and are masked out of the sums below: no divergent control flow
+        // around the loads / projections / gathers (the exec-mask bookkeeping was ~10 % of the pixel phase); a slot that is past
+        // the end for the whole wavefront is skipped with a scalar branch
         idx[q] = beg + q * kT + tid;
         act[q] = idx[q] < end;
-        const int i = min(idx[q], P - 1);
-        vx[q] = a.vc[i]; vy[q] = a.vc[P + i]; vz[q] = a.vc[2 * P + i];
-        nx[q] = a.nc[i]; ny[q] = a.nc[P + i]; nz[q] = a.nc[2 * P + i];
+        // (only where whole wavefronts are known to idle: a scalar branch is a scheduling fence for the loads around it, and at level 0 --
+        // every wavefront carries at least two full slots -- the fenced form measured 0.2 us SLOWER per launch, profiles/r04b_*)
+        won[q] = kSkipIdleSlots ? (__builtin_amdgcn_readfirstlane(beg + q * kT + (tid & ~63)) < end) : true;
+        vx[q] = vy[q] = vz[q] = nx[q] = ny[q] = nz[q] = 0.f;
+        if (won[q]) {
+            const int i = min(idx[q], P - 1);
+            vx[q] = a.vc[i]; vy[q] = a.vc[P + i]; vz[q] = a.vc[2 * P + i];
+            nx[q] = a.nc[i]; ny[q] = a.nc[P + i]; nz[q] = a.nc[2 * P + i];
+        }
     }
 
     // (2) prologue: finish the previous iteration (reduce -> solve -> pose), identically in every workgroup
@@ -603,7 +652,7 @@ __global__ __launch_bounds__(kT) void k_icp_iter(const IcpKArgs a) {
     if (a.nb_in > 0) {
         reduce_partials(a.partials_in, a.nb_in, s_seg, s_sys);   // (its barriers also publish s_st)
         if (prof) stamp[2] = __builtin_amdgcn_s_memtime();
-        gn_finish_wg(s_sys, &s_st, s_pose, s_T);                 // solve, exp, pose composition: state in place, Rcurr / tcurr -> s_pose[0..11]
+        gn_finish_wg(s_sys, &s_st, s_pose, s_T, prof, gst);     // solve, exp, pose composition: state in place, Rcurr / tcurr -> s_pose[0..11]
     } else {
         __syncthreads();
     }
@@ -633,22 +682,25 @@ __global__ __launch_bounds__(kT) void k_icp_iter(const IcpKArgs a) {
 #pragma unroll
     for (int k = 0; k < 32; ++k) acc[k] = 0.f;
     // all projections, then all gathers (independent loads in flight together), then the products
-    IcpCorr cor[kIcpPx];
-    float3 pv[kIcpPx], pn[kIcpPx];
+    IcpCorr cor[kPx];
+    float3 pv[kPx], pn[kPx];
 #pragma unroll
-    for (int q = 0; q < kIcpPx; ++q) {
+    for (int q = 0; q < kPx; ++q) {
+        if (!won[q]) continue;
         cor[q] = icp_project(vx[q], vy[q], vz[q], nx[q], ny[q], nz[q], Rc, tc, Rpi, tp, a);
         cor[q].ok = cor[q].ok && act[q];
         cor[q].j = cor[q].ok ? cor[q].j : 0;
     }
 #pragma unroll
-    for (int q = 0; q < kIcpPx; ++q) {
+    for (int q = 0; q < kPx; ++q) {
+        if (!won[q]) continue;
         const int j = cor[q].j;
         pv[q] = f3(a.vp[j], a.vp[P + j], a.vp[2 * P + j]);
         pn[q] = f3(a.np[j], a.np[P + j], a.np[2 * P + j]);
     }
 #pragma unroll
-    for (int q = 0; q < kIcpPx; ++q) icp_accumulate(cor[q], pv[q], pn[q], Rpi, tp, a, acc);
+    for (int q = 0; q < kPx; ++q)
+        if (won[q]) icp_accumulate(cor[q], pv[q], pn[q], Rpi, tp, a, acc);
 
     // (4) wavefront reduction (halving tree), one LDS stage across the wavefronts, one 128 B partial per workgroup
     if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[5] = __builtin_amdgcn_s_memtime(); }
@@ -657,22 +709,39 @@ __global__ __launch_bounds__(kT) void k_icp_iter(const IcpKArgs a) {
     if (prof) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp[7] = __builtin_amdgcn_s_memtime();
+#pragma unroll
         for (int k = 0; k < 8; ++k) a.prof_out[k] = stamp[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a.prof_out[8 + k] = a.nb_in > 0 ? gst.t[k] : 0ull;
     }
 }
 
 // threads per workgroup of the ICP-only kernel for an image of P pixels
 static int icp_threads_for(int P) { return ((P + kIcpThreads - 1) / kIcpThreads < kIcpMaxBlocks) ? 256 : kIcpThreads; }
 
-int icp_grid_blocks(int W, int H) {
+static int icp_blocks_capped(int W, int H, int cap256) {
     const int P = W * H;
     const int T = icp_threads_for(P);
+    const int cap = T == 256 ? cap256 : kIcpMaxBlocks;
     int nb = (P + T - 1) / T;
-    if (nb > kIcpMaxBlocks) {
-        nb = kIcpMaxBlocks;
+    if (nb > cap) {
+        nb = cap;
         while (icp_chunk(P, nb) > kIcpPx * T) ++nb;  // larger images: more than one round of workgroups
     }
     return nb;
+}
+// grid of the RGB-D kernels (512 threads whatever the level) and the upper bound older callers size their scratch with
+int icp_grid_blocks(int W, int H) { return icp_blocks_capped(W, H, kIcpMaxBlocks); }
+// grid of the geometric kernel k_icp_iter.  A level that runs 256-thread workgroups (fewer than 240 chunks of 512 pixels: levels 1 and 2 of
+// a VGA frame) gets one workgroup per 256 pixels up to 320 of them -- level 1: 300 workgroups, ONE pixel slot per thread, two workgroups on
+// 44 of the 256 CUs (23 KB of LDS and 4 wavefronts each) -- instead of 240 chunks of 320 pixels whose second slot kept one wavefront in
+// four busy and the other three waiting for it (round 4: the pixel phase is VALU-bound, a slot costs what it costs however few lanes use it).
+int icp_geo_grid_blocks(int W, int H) { return icp_blocks_capped(W, H, 320); }
+
+// pixel slots per thread the launch needs: ceil(chunk / threads), 1..kIcpPx
+int icp_pixel_slots(int W, int H) {
+    const int P = W * H, T = icp_threads_for(P);
+    return (icp_chunk(P, icp_geo_grid_blocks(W, H)) + T - 1) / T;
 }
 
 void launch_icp_iteration(const IcpLaunch& l, hipStream_t s) {
@@ -682,8 +751,16 @@ void launch_icp_iteration(const IcpLaunch& l, hipStream_t s) {
     a.partials_in = l.partials_in; a.nb_in = l.nblocks_in; a.partials_out = l.partials_out;
     a.st_in = l.state_in; a.st_out = l.state_out; a.log_out = l.log_out; a.prof_out = l.prof_out; a.pose_in = l.pose_in;
     a.so3_in = l.so3_in;
-    if (icp_threads_for(l.W * l.H) == 256) hipLaunchKernelGGL(k_icp_iter<256>, dim3(icp_grid_blocks(l.W, l.H)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_icp_iter<kIcpThreads>, dim3(icp_grid_blocks(l.W, l.H)), dim3(kIcpThreads), 0, s, a);
+    const dim3 grid(icp_geo_grid_blocks(l.W, l.H));
+    const int px = icp_pixel_slots(l.W, l.H);
+    if (icp_threads_for(l.W * l.H) == 256) {
+        if (px <= 1) hipLaunchKernelGGL((k_icp_iter<256, 1>), grid, dim3(256), 0, s, a);
+        else if (px == 2) hipLaunchKernelGGL((k_icp_iter<256, 2>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_icp_iter<256, kIcpPx>), grid, dim3(256), 0, s, a);
+    } else {
+        if (px <= 2) hipLaunchKernelGGL((k_icp_iter<kIcpThreads, 2>), grid, dim3(kIcpThreads), 0, s, a);
+        else hipLaunchKernelGGL((k_icp_iter<kIcpThreads, kIcpPx>), grid, dim3(kIcpThreads), 0, s, a);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -877,7 +954,7 @@ void launch_icp_batch_finalize(const TrackBatch& b, int n_it, int nb_in, const S
 // stand-alone Gauss-Newton update for the parity tests (mf_k_gn_solve): the production one-thread path (unpack -> LDL^T -> exp ->
 // pose composition) and the wave-parallel Gauss-Jordan of the RGB-D kernels on the same system
 struct GnSolveOut { double x_serial[6], x_wave[6], resultRt[16]; float Rcurr[9], tcurr[3], trR[9], trt[3], lastICPError, lastICPCount; };
-__global__ __launch_bounds__(64) void k_gn_solve_test(const double* __restrict__ sys29, const double* __restrict__ resultRt,
+__global__ __launch_bounds__(128) void k_gn_solve_test(const double* __restrict__ sys29, const double* __restrict__ resultRt,
                                                       const float* __restrict__ Rprev, const float* __restrict__ tprev, GnSolveOut* out) {
     __shared__ double s_sys[32];
     __shared__ GNState s_st;
@@ -931,7 +1008,7 @@ int gn_solve_standalone(const double* sys29, const double* resultRt16, const flo
               hipMemcpyAsync(d_R, Rprev9, 36, hipMemcpyHostToDevice, s) == hipSuccess &&
               hipMemcpyAsync(d_R + 9, tprev3, 12, hipMemcpyHostToDevice, s) == hipSuccess;
     if (ok) {
-        hipLaunchKernelGGL(k_gn_solve_test, dim3(1), dim3(64), 0, s, d_sys, d_rt, d_R, d_R + 9, d_out);
+        hipLaunchKernelGGL(k_gn_solve_test, dim3(1), dim3(128), 0, s, d_sys, d_rt, d_R, d_R + 9, d_out);   // two wavefronts: gn_finish_wg's statistics run in the second
         ok = hipMemcpyAsync(&h, d_out, sizeof(h), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
     }
     (void)hipFree(buf);
@@ -963,14 +1040,14 @@ __global__ void k_state_from_args(GNState* st, const float* Rc, const float* tc,
 void launch_icp_step_standalone(const float* Rcurr, const float* tcurr, const float* vc, const float* nc, const float* Rpi,
                                 const float* tprev, Intr k, const float* vp, const float* np, float distThres,
                                 float angleThres, int W, int H, float* partials, GNState* st, float* out32, hipStream_t s) {
-    // partials: scratch of icp_grid_blocks(W,H) * 32 floats; st: two GNState
+    // partials: scratch of icp_geo_grid_blocks(W,H) * 32 floats; st: two GNState
     hipLaunchKernelGGL(k_state_from_args, dim3(1), dim3(64), 0, s, st, Rcurr, tcurr, Rpi, tprev);
     IcpLaunch l;
     l.vmap_curr = vc; l.nmap_curr = nc; l.vmap_prev = vp; l.nmap_prev = np; l.W = W; l.H = H; l.k = k;
     l.distThres = distThres; l.angleThres = angleThres; l.partials_in = nullptr; l.nblocks_in = 0;
     l.partials_out = partials; l.state_in = st; l.state_out = st + 1; l.log_out = nullptr; l.prof_out = nullptr;
     launch_icp_iteration(l, s);
-    hipLaunchKernelGGL(k_icp_reduce_only, dim3(1), dim3(256), 0, s, partials, icp_grid_blocks(W, H), out32);
+    hipLaunchKernelGGL(k_icp_reduce_only, dim3(1), dim3(256), 0, s, partials, icp_geo_grid_blocks(W, H), out32);
 }
 
 // ------------------------------------------------------------------------------------------------

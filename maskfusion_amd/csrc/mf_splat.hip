@@ -22,6 +22,8 @@ constexpr int kBinThreads = 1024;
 constexpr int kMaxTiles = 8192;          // bounds the LDS histograms (VGA: 1200 tiles, 1280x960: 4800); larger images use the scatter form
 
 struct SplatSetup { float3 h, nrm; float sqrRad, pn; int px0, px1, py0, py1; };
+struct TileStamps { unsigned long long t[8]; };   // "splatProfile": shader-clock stamps of a tile workgroup's thread 0 (by reference + constant
+                                                  // indices: an array handed over as a pointer lives in scratch memory, for every launch)
 
 // splat.vert:40-105 for surfel i; false if it draws nothing.  Verbatim the per-surfel part of k_splat_scatter.
 __device__ __forceinline__ bool splat_setup(const Surfels& src, int i, float time, const float* Ri, float3 ti, int W, int H, Intr k,
@@ -160,7 +162,7 @@ template <bool kIndexPayload, int kSpriteLanes>
 __device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* tile_count, const int* entries, int tile_cap,
                                            const FrameDev* frame, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                                            const short4* __restrict__ bbox, unsigned payload, unsigned long long* s_key, float4* s_ray,
-                                           int* s_range, unsigned long long* stamp = nullptr) {
+                                           int* s_range, bool prof, TileStamps& stamp) {
     const int tx0 = (tile % tilesX) * kTile, ty0 = (tile / tilesX) * kTile;
     if (threadIdx.x < kTile * kTile) {
     s_key[threadIdx.x] = kEmptyKey;
@@ -176,7 +178,7 @@ __device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* ti
         tile_count[tile] = 0;   // consumed: the next binning pass starts from zero
     }
     __syncthreads();
-    if (stamp) { stamp[1] = __builtin_amdgcn_s_memtime(); stamp[6] = (unsigned long long)s_range[0]; }
+    if (prof) { stamp.t[1] = __builtin_amdgcn_s_memtime(); stamp.t[6] = (unsigned long long)s_range[0]; }
     const bool overflow = s_range[0] > tile_cap;   // more sprites than list slots (the reference has no such limit): scan every box
     const int cnt = overflow ? frame->count : s_range[0];
     const int* __restrict__ list = entries + (size_t)tile * tile_cap;
@@ -187,15 +189,32 @@ __device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* ti
     // VALU (two IEEE divisions' worth per pixel test), half gather latency; 4 is the default.
     constexpr int kLX = kSpriteLanes >= 8 ? 4 : (kSpriteLanes >= 2 ? 2 : 1), kLY = kSpriteLanes / kLX;
     const int sub = threadIdx.x & (kSpriteLanes - 1), sx = sub % kLX, sy = sub / kLX;
-    for (int e = threadIdx.x / kSpriteLanes; e < cnt; e += (int)blockDim.x / kSpriteLanes) {   // blockDim.x = 256, 512 or 1024 ("tileThreads")
-        const int i = overflow ? e : list[e];
-        const short4 bb = bbox[i];
+    // Software pipeline over the list (round 4).  An entry costs three DEPENDENT gathers -- list[e] -> bbox[i] -> rec0[i], rec1[i] -- and the
+    // in-kernel stamps of round 3 (tools/splat_prof.py) showed a tile workgroup issuing for ~4 k of its ~32 k cycles: it waits.  Every round
+    // now first issues the loads of LATER rounds -- the list entry two rounds ahead, the box and the two records of the next round's sprite
+    // (every listed sprite overlaps the tile, so its records are always needed) -- and only then tests the sprite whose data arrived during
+    // the previous round: one memory latency per round, overlapped with the pixel tests, instead of three in a row.  Same keys, bit for bit.
+    const int stride = (int)blockDim.x / kSpriteLanes;   // blockDim.x = 256, 512 or 1024 ("tileThreads")
+    const int e0 = threadIdx.x / kSpriteLanes;
+    const short4 kNoBox = make_short4(1, 0, 1, 0);
+    int i0 = e0 < cnt ? (overflow ? e0 : list[e0]) : -1;
+    int i1 = e0 + stride < cnt ? (overflow ? e0 + stride : list[e0 + stride]) : -1;
+    short4 bb0 = i0 >= 0 ? bbox[i0] : kNoBox;
+    float4 r0 = i0 >= 0 ? rec0[i0] : make_float4(0, 0, 0, 0), r1 = i0 >= 0 ? rec1[i0] : make_float4(0, 0, 0, 0);
+    for (int e = e0; e < cnt; e += stride) {
+        const int i = i0;
+        const short4 bb = bb0;
+        const float4 c0 = r0, c1 = r1;
+        // loads of the rounds to come (nothing below depends on them)
+        const int e2 = e + 2 * stride;
+        const int i2 = e2 < cnt ? (overflow ? e2 : list[e2]) : -1;
+        if (i1 >= 0) { bb0 = bbox[i1]; r0 = rec0[i1]; r1 = rec1[i1]; } else bb0 = kNoBox;
+        i0 = i1; i1 = i2;
         const int x0 = max((int)bb.x, tx0), x1 = min((int)bb.y, tx0 + kTile - 1);
         const int y0 = max((int)bb.z, ty0), y1 = min((int)bb.w, ty0 + kTile - 1);
         if (x0 > x1 || y0 > y1) continue;
-        const float4 r0 = rec0[i], r1 = rec1[i];
         SplatSetup su;
-        su.h = f3(r0.x, r0.y, r0.z); su.sqrRad = r0.w; su.nrm = f3(r1.x, r1.y, r1.z); su.pn = r1.w;
+        su.h = f3(c0.x, c0.y, c0.z); su.sqrRad = c0.w; su.nrm = f3(c1.x, c1.y, c1.z); su.pn = c1.w;
         // the kSpriteLanes lanes of a sprite form a kLX x kLY block that strides over the box: two plain nested loops (a flat pixel counter
         // needed a wrap-around loop per pixel), and the next pixel's ray is on its way from LDS while this one is tested
         for (int py = y0 + sy; py <= y1; py += kLY) {
@@ -216,9 +235,9 @@ __device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* ti
             }
         }
     }
-    if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();
+    if (prof) stamp.t[2] = __builtin_amdgcn_s_memtime();
     __syncthreads();
-    if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
+    if (prof) stamp.t[3] = __builtin_amdgcn_s_memtime();
 }
 
 // Pass 3: one workgroup (512 threads by default, the first 256 own the pixels) per 16x16 tile: LDS z-test over the tile's surfel list, then the fragment outputs
@@ -237,11 +256,15 @@ __global__ __launch_bounds__(1024) void k_splat_tile(const TileArgs a) {
     const int tx0 = (tile % a.tilesX) * kTile, ty0 = (tile / a.tilesX) * kTile;
     const Intr k = a.k;
     if (threadIdx.x == 0) s_cover = 0;   // (ordered before its use by the barriers inside tile_ztest)
-    unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    TileStamps stamp;
     const bool prof = a.prof != nullptr && live && threadIdx.x == 0;
-    if (prof) stamp[0] = __builtin_amdgcn_s_memtime();
+    if (prof) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) stamp.t[q] = 0;
+        stamp.t[0] = __builtin_amdgcn_s_memtime();
+    }
     if (live) tile_ztest<true, kSpriteLanes>(tile, a.tilesX, k, a.tile_count, a.entries, a.tile_cap, a.frame, a.rec0, a.rec1, a.bbox, 0u, s_key, s_ray, s_range,
-                                            prof ? stamp : nullptr);
+                                            prof, stamp);
     const int px = tx0 + (threadIdx.x & (kTile - 1)), py = ty0 + (threadIdx.x >> 4);
     int covered = 0;   // this pixel is one of the 20x down-sampled samples of MaskFusion::requiresFillIn and carries a colour
     if (live && threadIdx.x < kTile * kTile && px < a.W && py < a.H) {   // (threads beyond the tile's 256 pixels only helped with the list)
@@ -282,10 +305,11 @@ __global__ __launch_bounds__(1024) void k_splat_tile(const TileArgs a) {
     // hands the total on: to frame->cover for a stand-alone prediction, or straight into the end-of-frame bookkeeping that used to be
     // its own single-thread launch (k_frame_advance, ~4.7 us per model and frame).  Nothing else in this launch reads what it writes.
     if (prof) {
-        stamp[4] = __builtin_amdgcn_s_memtime();
+        stamp.t[4] = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stamp[5] = __builtin_amdgcn_s_memtime();
-        for (int q = 0; q < 8; ++q) a.prof[(size_t)tile * 8 + q] = stamp[q];
+        stamp.t[5] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a.prof[(size_t)tile * 8 + q] = stamp.t[q];
     }
     if (covered) atomicAdd(&s_cover, 1);   // at most two such pixels per 16x16 tile
     __syncthreads();
@@ -330,7 +354,9 @@ __global__ __launch_bounds__(1024) void k_global_tile(const GlobalTileArgs a) {
     __shared__ int s_range[1];
     const int tile = xcd_contiguous_tile(blockIdx.x, a.tilesX * a.tilesY);
     if (tile >= a.tilesX * a.tilesY) return;
-    tile_ztest<false, kSpriteLanes>(tile, a.tilesX, a.k, a.tile_count, a.entries, a.tile_cap, a.frame, a.rec0, a.rec1, a.bbox, a.payload, s_key, s_ray, s_range);
+    TileStamps unused;
+    tile_ztest<false, kSpriteLanes>(tile, a.tilesX, a.k, a.tile_count, a.entries, a.tile_cap, a.frame, a.rec0, a.rec1, a.bbox, a.payload, s_key, s_ray, s_range,
+                                    false, unused);
     const int px = (tile % a.tilesX) * kTile + (threadIdx.x & (kTile - 1)), py = (tile / a.tilesX) * kTile + (threadIdx.x >> 4);
     if (threadIdx.x >= kTile * kTile || px >= a.W || py >= a.H) return;
     const unsigned long long key = s_key[threadIdx.x];

@@ -3,11 +3,17 @@
 MaskFusion's per-model state (surfel map, tracker pyramids, pose) is independent (Core/Model/Model.h:271-323).  What
 MaskFusion::processFrame couples between models crosses the contexts here:
 
-  frame                      rank 0 -> all     broadcast rgb + depth (7 P bytes); every rank filters / builds its own pyramids
-  background pose            rank 0 -> all     broadcast 64 B (static objects follow it, Model.h:263; spawn anchors to it)
-  z-merged model-id image    all   -> all      all-reduce(MIN) of the uint64 projection keys (GlobalProjection.cpp:43-114)
-  per-model state            all   -> rank 0   gather {pose, ICP error, inliers, surfels, alive} (the 0.2 m jump rule, logging)
-  label image + control      rank 0 -> all     broadcast P bytes + {has_new, new id, new class, owner rank} (MaskFusion.cpp:289-297)
+  1 frame                    rank 0 -> all     ONE broadcast of rgb | depth packed in one buffer (7 P bytes); every rank filters / builds
+                                               its own pyramids
+  2 z-merged model-id image  all   -> all      all-reduce(MIN) of the uint64 projection keys (GlobalProjection.cpp:43-114)
+  3 per-model state          all   -> rank 0   gather {pose, ICP error, inliers, surfels, alive} (the 0.2 m jump rule, logging)
+  4 labels + pose + control  rank 0 -> all     ONE broadcast of the label image | the background's state record | {has_new, new id, new class,
+                                               owner rank, global list} packed in one buffer (P + 64 + 288 bytes; MaskFusion.cpp:289-297)
+  (static objects only: the background's NEW pose, 64 B, rank 0 -> all before the projection -- they follow it, Model.h:263)
+
+FOUR collectives per frame with tracked objects (tests/test_sharded_gloo.py counts them); round 3 issued seven (rgb and depth, labels, pose
+and control as separate broadcasts) and rank 0 drained its stream after the label stage to read the pose it was about to publish -- the
+record now goes from the library's device state into the packed buffer on the stream (mf_model_state_dev).
 
 Rank 0 owns the background model, the label stage and the model-id allocator; an object model lives on the rank chosen when it
 is spawned (the rank with the fewest models; rank 0 only when it is alone).  The frame logic is written as three phases per rank
@@ -29,6 +35,15 @@ from . import dist as mfd
 
 STATE_W = mfd.STATS_WIDTH        # R(9) t(3) icpError icpCount surfels alive
 MAX_LOCAL = 32                   # object models per rank in the gathered state block
+CTL_WORDS = 8 + 64               # control record: has_new, new_id, new_class, owner, 0, 0, 0, len(order), order[64]
+
+
+def pose16_from_state(rec: np.ndarray) -> np.ndarray:
+    """column-major 4x4 (what mf_model_override_pose takes) from a state record's R (row-major 9) and t (3)"""
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = np.asarray(rec[:9], np.float32).reshape(3, 3)
+    T[:3, 3] = rec[9:12]
+    return np.ascontiguousarray(T.T.reshape(16))
 
 
 @dataclass
@@ -56,8 +71,13 @@ class Shard:
         self.rank, self.world, self.mf, self.device = rank, world, mf, device
         P = mf.width * mf.height
         self.keys = torch.empty(P, dtype=torch.int64, device=device)
-        self.labels = torch.empty(P, dtype=torch.uint8, device=device)
-        self.bg_pose = torch.zeros(16, dtype=torch.float32, device=device)
+        # what rank 0 publishes after the label stage, in ONE buffer: label image (P) | background state record (16 floats: R row-major,
+        # t, ICP error, inliers, surfels, alive) | control record (CTL_WORDS int32).  labels / bg_state / ctl are views into it.
+        self.post = torch.zeros(P + 64 + 4 * CTL_WORDS, dtype=torch.uint8, device=device)
+        self.labels = self.post[:P]
+        self.bg_state = self.post[P:P + 64].view(torch.float32)
+        self.ctl = self.post[P + 64:].view(torch.int32)
+        self.bg_pose = torch.zeros(16, dtype=torch.float32, device=device)   # static objects: the early pose broadcast
         self.state = torch.zeros((MAX_LOCAL + 1, STATE_W), dtype=torch.float32, device=device)
         # rank 0 only
         self.table: List[GlobalModel] = [GlobalModel(0, -1, 0)]
@@ -256,10 +276,14 @@ class ShardedMaskFusion:
         self.cfg = cfg
         self.device = device
         H, W = mf.height, mf.width
-        # a ring of 3 frame buffers: the library may still read frame k-1 (fill-in intensity at predict time) while frame k is published
-        self.rgbs = [torch.empty((H, W, 3), dtype=torch.uint8, device=device) for _ in range(3)]
-        self.depths = [torch.empty((H, W), dtype=torch.float32, device=device) for _ in range(3)]
-        self.ctl = torch.zeros(8 + 64, dtype=torch.int32, device=device)
+        # a ring of 3 frame buffers: the library may still read frame k-1 (fill-in intensity at predict time) while frame k is published.
+        # rgb (3 P bytes) and depth (4 P bytes) of a frame share ONE buffer, so that the frame is ONE broadcast (north star); 3 P is a multiple
+        # of 4 (width and height are multiples of 8), the float view is aligned.
+        P = H * W
+        self.frames = [torch.empty(7 * P, dtype=torch.uint8, device=device) for _ in range(3)]
+        self.rgbs = [f[:3 * P].view(H, W, 3) for f in self.frames]
+        self.depths = [f[3 * P:].view(torch.float32).view(H, W) for f in self.frames]
+        self.collectives = 0           # issued by this rank so far (the gloo test asserts four per frame)
         self.frame = 0
         self._order = [0]              # host copy of the global model list (ids in order) as of the end of the last frame
         # On a GPU every tensor op and collective of a frame is enqueued on the LIBRARY's stream (torch.cuda.ExternalStream): the frame
@@ -282,8 +306,8 @@ class ShardedMaskFusion:
             d_rgb.copy_(torch.from_numpy(np.ascontiguousarray(rgb, np.uint8)))
             d_depth.copy_(torch.from_numpy(np.ascontiguousarray(depth, np.float32)))
         if self.world > 1:
-            dist.broadcast(d_rgb, 0)
-            dist.broadcast(d_depth, 0)
+            dist.broadcast(self.frames[self.frame % 3], 0)      # collective 1: rgb | depth
+            self.collectives += 1
         # GPU: the broadcast buffers are staged in place; CPU tensors (gloo tests over a stand-in context): as host arrays
         rgb_h, depth_h = (d_rgb, d_depth) if on_gpu else (d_rgb.numpy(), d_depth.numpy())
         # the global list as of the end of the previous frame travelled in the control record: every rank kept its host copy (reading the
@@ -299,6 +323,7 @@ class ShardedMaskFusion:
                 s.mf.sync()
                 s.bg_pose.copy_(torch.from_numpy(np.ascontiguousarray(s.mf.getCurrPose().astype(np.float32).T.reshape(16))))
             dist.broadcast(s.bg_pose, 0)
+            self.collectives += 1
             if self.rank != 0:
                 s.phase_track(rgb_h, depth_h, order_of_id, self.cfg, first, s.bg_pose.cpu().numpy())
         ctl = Control(order=order)
@@ -306,14 +331,16 @@ class ShardedMaskFusion:
         if not first:
             if not on_gpu:
                 s.mf.sync()
-            wire = mfd.merge_projection_keys(mfd.keys_to_wire(s.keys).clone())
+            wire = mfd.merge_projection_keys(mfd.keys_to_wire(s.keys).clone())      # collective 2
+            self.collectives += 1 if self.world > 1 else 0
             ids_block = torch.full((MAX_LOCAL + 1,), -1, dtype=torch.float32, device=self.device)
             ids = s.local_ids()
             ids_block[:len(ids)] = torch.tensor(ids, dtype=torch.float32)
             send = torch.cat([s.state.reshape(-1), ids_block])
             if self.world > 1:
                 recv = [torch.empty_like(send) for _ in range(self.world)] if self.rank == 0 else None
-                dist.gather(send, recv, dst=0)
+                dist.gather(send, recv, dst=0)                                       # collective 3
+                self.collectives += 1
             else:
                 recv = [send]
             if not on_gpu:
@@ -331,22 +358,24 @@ class ShardedMaskFusion:
                 if not on_gpu:
                     _device_sync(self.device)
                 ctl = s.phase_segment(mask, class_ids, keys, alive, self.cfg, weight_multiplier)
-                s.mf.sync()
-                bg_pose = np.ascontiguousarray(s.mf.getCurrPose().astype(np.float32).T.reshape(16))
+                # the background's state record goes from the library's device state into the packed buffer ON THE STREAM (no drained stream
+                # on rank 0: round 3 synchronised here to read the pose it was about to publish); rank 0 itself never needs it on the host
+                s.mf.modelStateDevice(0, s.bg_state.data_ptr())
                 rec = [ctl.has_new, ctl.new_id, ctl.new_class, ctl.owner, 0, 0, 0, len(ctl.order)] + ctl.order
-                self.ctl.zero_()
-                self.ctl[:len(rec)] = torch.tensor(rec, dtype=torch.int32)
-                s.bg_pose.copy_(torch.from_numpy(bg_pose))
+                rec_t = torch.zeros(CTL_WORDS, dtype=torch.int32)
+                rec_t[:len(rec)] = torch.tensor(rec, dtype=torch.int32)
+                s.ctl.copy_(rec_t, non_blocking=True)
             if self.world > 1:
-                mfd.broadcast_labels(s.labels, s.bg_pose, 0)
-                dist.broadcast(self.ctl, 0)
+                dist.broadcast(s.post, 0)                                            # collective 4: labels | background state | control
+                self.collectives += 1
             if not on_gpu:
                 _device_sync(self.device)
             if self.rank != 0:
                 # (the one host wait the object ranks need: what to drop / spawn, and the background's pose; rank 0 wrote both itself)
-                c = self.ctl.cpu().numpy()
+                tail = s.post[s.post.numel() - 64 - 4 * CTL_WORDS:].cpu().numpy()
+                c = tail[64:].view(np.int32)
                 ctl = Control(int(c[0]), int(c[1]), int(c[2]), int(c[3]), [int(x) for x in c[8:8 + int(c[7])]])
-                bg_pose = s.bg_pose.cpu().numpy()
+                bg_pose = pose16_from_state(tail[:64].view(np.float32))
         s.phase_fuse(ctl, bg_pose, self.cfg, weight_multiplier, timestamp, first)
         # the list that the NEXT frame's projection orders by includes the new model
         self._order = list(ctl.order) + ([ctl.new_id] if (not first and ctl.has_new) else [])

@@ -118,6 +118,16 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
     if (row_mask != 0xf || bank_mask != 0xf) { fprintf(stderr, "hipcpu: partial DPP masks not emulated\n"); abort(); }
     return hipcpu::lane_alive(l) ? (int)(uint32_t)s[l] : (bound_ctrl ? 0 : old);
 }
+// v_readfirstlane_b32 / v_readlane_b32: the value of the first active lane / of a given lane, uniform across the wavefront
+static inline int __builtin_amdgcn_readfirstlane(int v) {
+    const uint64_t* s = hipcpu::wave_publish((uint32_t)v);
+    for (int l = 0; l < 64; ++l) if (hipcpu::lane_alive(l)) return (int)(uint32_t)s[l];
+    return v;
+}
+static inline int __builtin_amdgcn_readlane(int v, int lane) {
+    const uint64_t* s = hipcpu::wave_publish((uint32_t)v);
+    return hipcpu::lane_alive(lane & 63) ? (int)(uint32_t)s[lane & 63] : 0;
+}
 static inline int __builtin_amdgcn_mbcnt_lo(unsigned mask, int base) {
     const int me = hipcpu::lane();
     return base + __builtin_popcount(mask & (me >= 32 ? 0xFFFFFFFFu : ((1u << me) - 1u)));

@@ -56,7 +56,7 @@ def _spmd_worker(rank, world, port, out_dir, track_all):
             c = sm.process_frame(timestamp=k)      # only rank 0's inputs are used
         ctls.append((c.has_new, c.new_id, c.new_class, c.owner, tuple(c.order)))
     with open(os.path.join(out_dir, f"spmd{rank}.pkl"), "wb") as f:
-        pickle.dump(dict(log=mf.log, ctls=ctls, ids=[m.id for m in mf.models],
+        pickle.dump(dict(log=mf.log, ctls=ctls, ids=[m.id for m in mf.models], collectives=sm.collectives,
                          table=[(g.id, g.class_id, g.rank) for g in sm.shard.table] if rank == 0 else None), f)
     dist.destroy_process_group()
 
@@ -86,6 +86,11 @@ def test_spmd_world2_equals_in_process_form(tmp_path, track_all):
         assert spmd[r]["log"] == mfs[r].log, r
         assert spmd[r]["ids"] == [m.id for m in mfs[r].models]
     assert spmd[0]["table"] == [(g.id, g.class_id, g.rank) for g in shards[0].table]
+    # the latency budget of a sharded frame, in code: ONE packed frame broadcast, the key all-reduce, the state gather, ONE packed
+    # post-segmentation broadcast (labels | background state | control) = 4 collectives per frame on every rank; the first frame only
+    # publishes the frame; static objects add the early 64-byte pose broadcast (they follow the background's NEW pose, Model.h:263)
+    per_frame = 4 if track_all else 5
+    assert spmd[0]["collectives"] == spmd[1]["collectives"] == 1 + per_frame * (N_FRAMES - 1)
 
 
 @pytest.mark.parametrize("track_all", [True, False], ids=["trackAllModels", "staticObjects"])
