@@ -89,8 +89,13 @@ class KlgLogReader:
             rgb = np.zeros((self.H, self.W, 3), np.uint8)
         elif isz == P * 3:
             rgb = np.frombuffer(ibuf, np.uint8, P * 3).reshape(self.H, self.W, 3).copy()
-        else:  # JPEG (the reference decodes to its native channel order; logs store BGR -> use -f like upstream if needed)
-            rgb = np.asarray(_pil().open(io.BytesIO(ibuf)).convert("RGB"), np.uint8)
+        else:
+            # JPEG: GUI/Tools/JPEGLoader.h decodes with libjpeg's defaults (ISLOW DCT, fancy upsampling, JCS_RGB) and stores every pixel with
+            # its first and third channel SWAPPED (`rgb[2] = t0; rgb[1] = t1; rgb[0] = t2`, :73-79: the loggers of this family compress
+            # OpenCV's BGR images, the swap gives RGB back).  Pillow is the same libjpeg-turbo decoder; the swap is reproduced here.  Pinned
+            # byte for byte against the reference's loader compiled from its text (tests/test_io_pin.py, round 4 -- round 3 returned the
+            # decoder's channel order, i.e. the reverse of what upstream hands to processFrame).
+            rgb = np.asarray(_pil().open(io.BytesIO(ibuf)).convert("RGB"), np.uint8)[..., ::-1]
             if rgb.shape[:2] != (self.H, self.W):
                 raise ValueError("JPEG frame size does not match the configured resolution")
         f = FrameData(timestamp=ts, index=self.currentFrame, rgb=np.ascontiguousarray(rgb), depth=depth)

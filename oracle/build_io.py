@@ -21,7 +21,8 @@ REF = os.environ.get("MF_REFERENCE_DIR", "/root/reference")
 FILES = {k: os.path.join(REF, *v) for k, v in dict(
     klg_cpp=("GUI", "Tools", "KlgLogReader.cpp"), klg_h=("GUI", "Tools", "KlgLogReader.h"), log_h=("GUI", "Tools", "LogReader.h"),
     img_cpp=("GUI", "Tools", "ImageLogReader.cpp"), frame_h=("Core", "FrameData.h"), res_h=("Core", "Utils", "Resolution.h"),
-    macros_h=("Core", "Utils", "Macros.h")).items()}
+    macros_h=("Core", "Utils", "Macros.h"), jpeg_h=("GUI", "Tools", "JPEGLoader.h")).items()}
+JPEG_SO = "libjpeg.so.8"     # libjpeg-turbo's IJG-v8 ABI: what the image ships (no headers: oracle/io_shim/jpeglib.h + jpeg_probe.c)
 
 
 def reference_available() -> bool:
@@ -68,6 +69,7 @@ def translation_unit() -> str:
         "MFIO_KLGLOGREADER_CLASS": _class(_read("klg_h"), "class KlgLogReader : public LogReader {"),
         "MFIO_KLGLOGREADER_CPP": klg[klg.index("KlgLogReader::KlgLogReader("):],
         "MFIO_LOADMASKIDS": _function(_read("img_cpp"), "void ImageLogReader::loadMaskIDs("),
+        "MFIO_JPEGLOADER_H": _strip_includes(_read("jpeg_h")),
     }
     for k, v in parts.items():
         assert api.count("\n" + k + "\n") == 1, k
@@ -90,10 +92,21 @@ def build(force: bool = False) -> str | None:
     if not (force or _stale()):
         return LIB
     os.makedirs(OUT, exist_ok=True)
+    version, size = jpeg_abi()
     # -DNDEBUG: Macros.h's RELEASE flavour of CHECK_THROW (`if (!x) throw`), the way upstream ships
-    subprocess.run(["g++", "-std=c++14", "-O2", "-fPIC", "-shared", "-w", "-DNDEBUG", "-I", SHIM, "-x", "c++", "-", "-o", LIB, "-lz"],
+    subprocess.run(["g++", "-std=c++14", "-O2", "-fPIC", "-shared", "-w", "-DNDEBUG", f"-DMFIO_JPEG_LIB_VERSION={version}",
+                    f"-DMFIO_JPEG_DECOMPRESS_SIZE={size}", "-I", SHIM, "-x", "c++", "-", "-o", LIB, "-lz", "-l:" + JPEG_SO],
                    input=translation_unit().encode(), check=True)
     return LIB
+
+
+def jpeg_abi():
+    """(JPEG_LIB_VERSION, sizeof(struct jpeg_decompress_struct)) as the installed libjpeg reports them (oracle/io_shim/jpeg_probe.c)"""
+    exe = os.path.join(OUT, "jpeg_probe")
+    os.makedirs(OUT, exist_ok=True)
+    subprocess.run(["gcc", "-O1", "-o", exe, os.path.join(SHIM, "jpeg_probe.c"), "-l:" + JPEG_SO], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()
+    return int(out[0]), int(out[1])
 
 
 if __name__ == "__main__":

@@ -23,10 +23,13 @@ MFIO_FRAMEDATA_H
 namespace pangolin {
 inline bool FileExists(const std::string& f) { FILE* p = fopen(f.c_str(), "rb"); if (p) fclose(p); return p != nullptr; }
 }
-// GUI/Tools/JPEGLoader.h needs libjpeg: JPEG-compressed colour frames are outside this harness
-struct JPEGLoader {
-    void readData(unsigned char*, int, unsigned char*) { throw std::runtime_error("mfio: JPEG-compressed .klg frames are not supported by the pin harness"); }
-};
+// GUI/Tools/JPEGLoader.h (the reference's libjpeg calling sequence and its channel swap), compiled from its text against the installed
+// libjpeg.so.8 through oracle/io_shim/jpeglib.h (the image has the library but not its headers)
+extern "C" {
+#include "jpeglib.h"
+}
+
+MFIO_JPEGLOADER_H
 
 MFIO_LOGREADER_CLASS
 

@@ -74,6 +74,35 @@ def main():
             vec[f"klg_ts_{i}_flip{flip}"] = np.int64(ts)
             vec[f"klg_depth_{i}_flip{flip}"] = depth
             vec[f"klg_rgb_{i}_flip{flip}"] = rgb
+    # jpeg.klg: colour stored JPEG-compressed (imageSize != W*H*3 -> JPEGLoader::readData, KlgLogReader.cpp:74-77), what every real .klg of the
+    # ElasticFusion family carries.  Baseline JFIF files without COM / EXIF segments (the reference's source manager leaves skip_input_data
+    # unset), written with Pillow: 4:2:0 at quality 90, 4:4:4 at 75, 4:2:2 at 95, and a last frame that is never delivered.
+    import io as _io
+    from PIL import Image
+    JW, JH = 32, 24
+    yy, xx = np.mgrid[0:JH, 0:JW]
+    base = np.stack([(xx * 8) % 256, (yy * 10) % 256, ((xx + yy) * 5) % 256], -1).astype(np.uint8)
+    base[5:12, 8:20] = [200, 40, 90]
+    jframes = []
+    for k, (q, ss) in enumerate([(90, 2), (75, 0), (95, 1), (50, 2)]):
+        b = _io.BytesIO()
+        Image.fromarray(base if k % 2 == 0 else np.ascontiguousarray(base[::-1])).save(b, format="JPEG", quality=q, subsampling=ss)
+        jframes.append((2000000 + 41 * k, (900 + 7 * k + np.add.outer(np.arange(JH), np.arange(JW))).astype(np.uint16), b.getvalue()))
+    with open(os.path.join(OUT, "jpeg.klg"), "wb") as f:
+        f.write(struct.pack("<i", len(jframes)))
+        for ts, depth, c in jframes:
+            assert len(c) != JW * JH * 3
+            f.write(struct.pack("<qii", ts, depth.nbytes, len(c)))
+            f.write(depth.tobytes())
+            f.write(c)
+    for flip in (0, 1):
+        n, out = mfio.read_klg(os.path.join(OUT, "jpeg.klg"), JW, JH, bool(flip))
+        vec[f"jpeg_num_frames_flip{flip}"] = np.int32(n)
+        vec[f"jpeg_delivered_flip{flip}"] = np.int32(len(out))
+        for i, (ts, depth, rgb) in enumerate(out):
+            vec[f"jpeg_ts_{i}_flip{flip}"] = np.int64(ts)
+            vec[f"jpeg_depth_{i}_flip{flip}"] = depth
+            vec[f"jpeg_rgb_{i}_flip{flip}"] = rgb
     save = reference_save_id_image()
     cases = [([41, 57, 1], [[10, 20, 110, 220], [5, 6, 7, 9], [0, 0, 480, 640]]),   # class ids + one box each (y1 x1 y2 x2, Mask R-CNN order)
              ([3], []),                                                             # ids only

@@ -49,7 +49,11 @@ def test_klg_jpeg_frames(tmp_path):
         for k in range(2):
             f.write(struct.pack("<qii", k, len(d16), len(buf.getvalue()))); f.write(d16); f.write(buf.getvalue())
     fr = KlgLogReader(p, W, H).getNext()
-    assert np.allclose(fr.depth, 1.5) and np.abs(fr.rgb.astype(int) - rgb.astype(int)).mean() < 4
+    # GUI/Tools/JPEGLoader.h swaps the first and third channel of what libjpeg decodes (the loggers compress BGR images): without -f the frame
+    # comes back channel-reversed, with it as encoded (pinned against the compiled loader in tests/test_io_pin.py)
+    assert np.allclose(fr.depth, 1.5) and np.abs(fr.rgb.astype(int) - rgb[..., ::-1].astype(int)).mean() < 4
+    fr = KlgLogReader(p, W, H, flipColors=True).getNext()
+    assert np.abs(fr.rgb.astype(int) - rgb.astype(int)).mean() < 4
 
 
 def test_image_directory(tmp_path):

@@ -38,6 +38,29 @@ def test_klg_frames_are_the_reference_readers(vec, flip):
     r.close()
 
 
+@pytest.mark.parametrize("flip", [0, 1])
+def test_jpeg_klg_frames_are_the_reference_readers(vec, flip):
+    """colour stored JPEG-compressed (KlgLogReader.cpp:74-77 -> GUI/Tools/JPEGLoader.h): the golden frames come from the reference's loader,
+    compiled from its text against the installed libjpeg (oracle/build_io.py, oracle/io_shim/jpeglib.h); readers.py decodes with Pillow and
+    applies the loader's channel swap -- byte for byte, 4:2:0 / 4:4:4 / 4:2:2 sampling"""
+    JW, JH = 32, 24
+    r = readers.KlgLogReader(os.path.join(GOLD, "jpeg.klg"), JW, JH, flipColors=bool(flip))
+    assert r.getNumFrames() == int(vec[f"jpeg_num_frames_flip{flip}"]) == 4
+    frames = list(r)
+    assert len(frames) == int(vec[f"jpeg_delivered_flip{flip}"]) == 3
+    for i, f in enumerate(frames):
+        assert f.timestamp == int(vec[f"jpeg_ts_{i}_flip{flip}"])
+        assert f.depth.tobytes() == vec[f"jpeg_depth_{i}_flip{flip}"].tobytes(), i
+        assert f.rgb.dtype == np.uint8 and f.rgb.shape == (JH, JW, 3)
+        assert np.array_equal(f.rgb, vec[f"jpeg_rgb_{i}_flip{flip}"]), (i, int(np.abs(f.rgb.astype(int) - vec[f"jpeg_rgb_{i}_flip{flip}"].astype(int)).max()))
+    # the decoded frame is a picture of what was encoded, in the channel order upstream hands on: the 200 / 40 / 90 patch of the source image
+    # comes back swapped (90 / 40 / 200) without -f and as encoded with it
+    patch = frames[0].rgb[6:11, 10:18].reshape(-1, 3).mean(0)
+    want = np.array([200, 40, 90] if flip else [90, 40, 200], float)
+    assert np.abs(patch - want).max() < 12
+    r.close()
+
+
 @pytest.mark.parametrize("i", [0, 1, 2])
 def test_mask_descriptor_is_parsed_like_the_reference(vec, i):
     ids, rois = readers.ImageLogReader.loadMaskIDs(os.path.join(GOLD, f"Mask{i:04d}.txt"))
