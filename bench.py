@@ -597,9 +597,11 @@ def main():
             b_fine = 48.0 * P
             b_coarse = (5 * 48.0 * P / 4 + 4 * 48.0 * P / 16) / n_coarse
             us_f, us_c = stages["icpFine"] * 1e3 / n_fine, stages["icpCoarse"] * 1e3 / n_coarse
-            levels = {"L0": {"kernel": "void mf::k_icp_iter<512>(mf::IcpKArgs)", "launches_per_frame": n_fine, "us": us_f, "bytes": b_fine,
+            # kernel names as rocprofv3 prints them (template arguments: threads per workgroup, pixel slots per thread): VGA runs level 0 as
+            # <512, 3> and levels 1 and 2 as <256, 1>; at 1280x960 level 1 is a <512, 3> launch as well
+            levels = {"L0": {"kernel": "void mf::k_icp_iter<512, 3>(mf::IcpKArgs)", "launches_per_frame": n_fine, "us": us_f, "bytes": b_fine,
                              "frac": b_fine / (us_f * 1e-6) / 1e9 / HBM_PEAK_GBS},
-                      "coarse": {"kernel": "void mf::k_icp_iter<256>(mf::IcpKArgs)" if P <= 240 * 512 * 4 else "void mf::k_icp_iter<512>(mf::IcpKArgs) (level 1) / <256> (level 2)",
+                      "coarse": {"kernel": "void mf::k_icp_iter<256, 1>(mf::IcpKArgs)" if P <= 240 * 512 * 4 else "void mf::k_icp_iter<512, 3>(mf::IcpKArgs) (level 1) / <256, 1> (level 2)",
                                  "launches_per_frame": n_coarse, "us": us_c,
                                  "bytes": b_coarse, "frac": b_coarse / (us_c * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                  "note": "5 launches at level 1 (12 P bytes each) + 4 at level 2 (3 P): the average launch"}}

@@ -195,6 +195,7 @@ struct mf_ctx {
     RgbCorr* d_corres = nullptr; float* d_rgb_partials[2] = {nullptr, nullptr}; int2* d_cnt[2] = {nullptr, nullptr};
     So3Result* d_so3 = nullptr; char* d_so3_scratch = nullptr;
     // tiled splat prediction (mf_splat.hip)
+    SplatTuning splat_tune;                // "spriteLanes" / "tileThreads" of THIS context
     int* d_tile_count = nullptr; int* d_tile_entries = nullptr; int tile_entries_cap = 0; int tile_entries_alloc = 0; int splat_tiles = 1;
     float4* d_splat_rec0 = nullptr; float4* d_splat_rec1 = nullptr; uint2* d_splat_bbox = nullptr;   // per-surfel sprite set-up
     const uint8_t* cur_rgb = nullptr;      // device rgb of the frame being processed (fill-in intensity at predict time)
@@ -315,7 +316,32 @@ static int surfel_capacity(int num) {  // Model::TEXTURE_DIMENSION_*^2 (Core/Mod
 }
 
 // Model::Model (Core/Model/Model.cpp:115-223): buffers of one model
-static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int cap, std::unique_ptr<ModelState>& out) {
+// An object model's private scratch of the batched surfel passes: its own index maps / key image / candidate records, 141 B per pixel + 9 B per
+// surfel slot (43 MB at VGA, 173 MB at 1280x960).  Only the batched passes ("batchObjectPasses", >= 2 objects) touch it, so it is allocated when
+// a model first takes part in one -- or ahead of time for preallocated models, whose point is that nothing is allocated at spawn time
+// (every object model used to carry it from its creation on, batched or not).
+static int ensure_obj_scratch(mf_ctx* c, ModelState& m) {
+    if (m.scr.keys) return MF_OK;
+    const size_t P = (size_t)c->P, cap = (size_t)m.cap;
+    int rc;
+#define A(call) do { rc = (call); if (rc != MF_OK) return rc; } while (0)
+    A(dev_alloc(c, m.allocs, &m.scr.keys, P, 0xFF));
+    A(dev_alloc(c, m.allocs, &m.scr.index, P));
+    A(dev_alloc(c, m.allocs, &m.scr.ivc, P));
+    A(dev_alloc(c, m.allocs, &m.scr.inr, P));
+    A(dev_alloc(c, m.allocs, &m.scr.iclean, P * 2));
+    A(dev_alloc(c, m.allocs, &m.scr.cand_op, P));
+    A(dev_alloc(c, m.allocs, &m.scr.cand_rec, P * 3));
+    A(dev_alloc(c, m.allocs, &m.scr.upd_first, cap));
+    A(dev_alloc(c, m.allocs, &m.scr.flags, cap + P));
+    A(dev_alloc(c, m.allocs, &m.scr.newconf, cap + P));
+    A(dev_alloc(c, m.allocs, &m.scr.block_counts, (size_t)kCompactBlocks));
+#undef A
+    launch_fill_int(m.scr.upd_first, kNoUpdate, (int)cap, c->stream);
+    return MF_OK;
+}
+
+static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int cap, std::unique_ptr<ModelState>& out, bool with_scratch = false) {
     std::unique_ptr<ModelState> m(new ModelState());
     m->id = id; m->confThr = confThr; m->allowFillIn = allowFillIn; m->cap = cap;
     const size_t P = (size_t)c->P;
@@ -350,20 +376,7 @@ static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int 
     A(dev_alloc(c, m->allocs, &m->d_gn, 2));
     A(dev_alloc(c, m->allocs, &m->d_track, 1));
     A(dev_alloc(c, m->allocs, &m->d_icp_log, (size_t)20 * 32));
-    if (!allowFillIn) {   // an object model: its own index maps / key image / candidate records (141 B per pixel + 9 B per surfel slot)
-        A(dev_alloc(c, m->allocs, &m->scr.keys, P, 0xFF));
-        A(dev_alloc(c, m->allocs, &m->scr.index, P));
-        A(dev_alloc(c, m->allocs, &m->scr.ivc, P));
-        A(dev_alloc(c, m->allocs, &m->scr.inr, P));
-        A(dev_alloc(c, m->allocs, &m->scr.iclean, P * 2));
-        A(dev_alloc(c, m->allocs, &m->scr.cand_op, P));
-        A(dev_alloc(c, m->allocs, &m->scr.cand_rec, P * 3));
-        A(dev_alloc(c, m->allocs, &m->scr.upd_first, (size_t)cap));
-        A(dev_alloc(c, m->allocs, &m->scr.flags, (size_t)cap + P));
-        A(dev_alloc(c, m->allocs, &m->scr.newconf, (size_t)cap + P));
-        A(dev_alloc(c, m->allocs, &m->scr.block_counts, (size_t)kCompactBlocks));
-        launch_fill_int(m->scr.upd_first, kNoUpdate, cap, c->stream);
-    }
+    if (!allowFillIn && with_scratch) A(ensure_obj_scratch(c, *m));
 #undef A
     {
         TrackModelDev t;
@@ -785,7 +798,7 @@ static void enqueue_predict(mf_ctx* c, ModelState& m, const FrameAdvance* advanc
                                c->cfg.time_delta, c->d_tile_count, c->d_tile_entries, c->tile_entries_cap, c->d_splat_rec0, c->d_splat_rec1,
                                c->d_splat_bbox, m.d_predV, m.d_predN, m.d_predImage, m.d_predTime, c->cur_rgb,
                                gray ? m.d_predGray : nullptr, gray ? m.d_fillGray : nullptr, c->stream, advance, c->ftf_rgb ? 1 : 0,
-                               (c->splat_prof_on && m.id == 0) ? c->d_splat_prof : nullptr) == 0)
+                               (c->splat_prof_on && m.id == 0) ? c->d_splat_prof : nullptr, c->splat_tune) == 0)
             return;
     }
     launch_splat_scatter(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, c->cfg.max_depth_processed, m.confThr,
@@ -810,6 +823,7 @@ static int make_obj_batch(mf_ctx* c, const std::vector<ModelState*>& ms, const s
     for (size_t i = 0; i < ms.size(); ++i) {
         ModelState& m = *ms[i];
         ObjPassArgs& a = h[i];
+        if (!m.scr.keys) { int rc = ensure_obj_scratch(c, m); if (rc != MF_OK) return rc; }   // first batched pass of a model created at spawn time
         a.a = m.surf[m.cur]; a.b = m.surf[1 - m.cur];
         a.frame = m.d_frame; a.pose = m.d_pose;
         a.maskID = m.id; a.confThreshold = m.confThr; a.fuseMaxDepth = fminf(g.depth_cutoff, m.maxDepth); a.weightMultiplier = weightMultiplier;
@@ -904,7 +918,7 @@ static void enqueue_global_projection(mf_ctx* c, ModelState& m, int order) {
     const mf_config& g = c->cfg;
     if (m.id == 0 && c->splat_tiles && c->global_tiles &&
         launch_global_tiled(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, g.depth_cutoff, 12.0f, g.time_delta, order, m.id, c->d_tile_count,
-                            c->d_tile_entries, c->tile_entries_cap, c->d_splat_rec0, c->d_splat_rec1, c->d_splat_bbox, c->d_keys, c->stream) == 0)
+                            c->d_tile_entries, c->tile_entries_cap, c->d_splat_rec0, c->d_splat_rec1, c->d_splat_bbox, c->d_keys, c->stream, c->splat_tune) == 0)
         return;
     launch_global_scatter(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, g.depth_cutoff, 12.0f, g.time_delta, order, m.id, c->d_keys,
                           c->stream, surfel_blocks(c, m));
@@ -1364,7 +1378,7 @@ extern "C" int mf_preallocate_models(mf_ctx* c, uint32_t count) {
     if (!c) return MF_EINVAL;
     for (uint32_t i = 0; i < count; ++i) {
         std::unique_ptr<ModelState> m;
-        int rc = create_model(c, -1, c->cfg.conf_object, false, surfel_capacity(c->cfg.num_osurfels), m);
+        int rc = create_model(c, -1, c->cfg.conf_object, false, surfel_capacity(c->cfg.num_osurfels), m, c->batch_objects);
         if (rc != MF_OK) return rc;
         c->pool.push_back(std::move(m));
     }
@@ -2229,8 +2243,8 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!strcmp(key, "cleanLiteralWindow")) { c->clean_literal = value != 0; return MF_OK; }   // 0: the exact-arithmetic 4 x 4 window
     if (!strcmp(key, "earlyBackgroundFusion")) { c->early_bg_fusion = value != 0; return MF_OK; }
     if (!strcmp(key, "modelApiPackedIndex")) { c->model_api_packed = value != 0; return MF_OK; }   // 0: scatter + resolve form (specification)
-    if (!strcmp(key, "tileThreads")) { set_tile_threads((int)value); return MF_OK; }   // A/B: threads per tile workgroup of the tile passes
-    if (!strcmp(key, "spriteLanes")) { set_sprite_lanes((int)value); return MF_OK; }   // A/B: lanes per sprite in the tile z-test (default 4)
+    if (!strcmp(key, "tileThreads")) { c->splat_tune.tile_threads = (int)value; return MF_OK; }   // A/B: threads per tile workgroup of the tile passes
+    if (!strcmp(key, "spriteLanes")) { c->splat_tune.sprite_lanes = (int)value; return MF_OK; }   // A/B: lanes per sprite in the tile z-test (default 4)
     if (!strcmp(key, "overlapPreprocessing")) {
         (void)hipStreamSynchronize(c->stream_pre);
         (void)hipStreamSynchronize(c->stream);

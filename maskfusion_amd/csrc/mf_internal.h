@@ -242,8 +242,7 @@ void launch_splat_resolve(Surfels src, const PoseDev* pose, unsigned long long* 
 // tile_count must be zero on the first call (it is left zero).  Returns -1 if the image has too many tiles for the LDS
 // histograms (use the scatter form then).
 size_t splat_tiles_scratch_ints(int W, int H);
-void set_sprite_lanes(int n);
-void set_tile_threads(int n);
+struct SplatTuning { int sprite_lanes = 4, tile_threads = 512; };   // A/B knobs of the tile passes ("spriteLanes", "tileThreads"), owned by the context
 // The end-of-frame bookkeeping (k_frame_advance: pose log entry, fill-in decision for the next tracking step, tick++, host mirror) as
 // the epilogue of the tiled prediction: its last workgroup to finish runs it, one launch less per model and frame.
 struct FrameAdvance { FrameDev* host_mirror; const PoseDev* bg_pose; float* log_slot; };
@@ -251,7 +250,8 @@ int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W,
                        int timeDelta, int* tile_count, int* entries /*[tiles][entries_cap / tiles]*/, int entries_cap,
                        float4* rec0 /*[src.cap]*/, float4* rec1 /*[src.cap]*/, void* bbox /*[src.cap] x 8 B*/, float4* predV, float4* predN,
                        uchar4* predImage, uint16_t* predTime, const uint8_t* rgb, uint8_t* predGray, uint8_t* fillGray, hipStream_t s,
-                       const FrameAdvance* advance = nullptr, int fillPassthrough = 0, unsigned long long* prof = nullptr /*[tiles][8] stamps*/);
+                       const FrameAdvance* advance = nullptr, int fillPassthrough = 0, unsigned long long* prof = nullptr /*[tiles][8] stamps*/,
+                       SplatTuning tune = SplatTuning());
 // ---- the surfel passes of ALL object models of a frame, one launch per pass (grid.z = model) ----
 // An object model holds a few thousand surfels: each of its ~11 per-frame launches is pure launch latency (~85 us per object and frame in
 // round 2's profile).  The batched kernels are the single-model kernels' bodies called with one model's arguments, picked from a device
@@ -289,7 +289,7 @@ int gn_solve_standalone(const double* sys29, const double* resultRt16, const flo
                         double* resultRt_out, float* Rcurr9, float* tcurr3, float* stats2, hipStream_t s);
 int launch_global_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
                         int timeDelta, int order, int id, int* tile_count, int* entries, int entries_cap, float4* rec0, float4* rec1, void* bbox,
-                        unsigned long long* keys, hipStream_t s);
+                        unsigned long long* keys, hipStream_t s, SplatTuning tune = SplatTuning());
 void launch_spawn_pose(PoseDev* obj, const PoseDev* bg, FrameDev* objFrame, const FrameDev* bgFrame, PoseDev* host_mirror,
                        hipStream_t s);
 void launch_static_pose(PoseDev* obj, const PoseDev* bg, PoseDev* host_mirror, hipStream_t s);

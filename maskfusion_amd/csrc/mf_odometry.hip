@@ -294,40 +294,65 @@ __device__ __forceinline__ void gn_finish_wg(const double* s_sys, GNState* s_st,
     gn_finish_wg(s_sys, s_st, s_pose, s_T, false, unused);
 }
 
+// value of lane (lane ^ kXor) for a 32-bit pattern, kXor = 1 or 2: quad permutes on the DPP path (no LDS crossbar)
+template <int kXor>
+__device__ __forceinline__ float lane_xor_bits(int bits, int /*lane*/) {
+    static_assert(kXor == 1 || kXor == 2, "quad permutes only");
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, bits, kXor == 1 ? 0xB1 : 0x4E, 0xf, 0xf, false));
+}
+
 // Fixed-order reduction of `nb` per-workgroup partials ([nb][32] floats) by a 256-thread workgroup -> sys[32] doubles
 // in LDS.  The array is read as float4s with up to 10 independent 16 B loads in flight per lane (a one-load-at-a-time
 // loop cost ~70 cycles per partial: 10 us at 300 workgroups; the partials live in other XCDs' L2s, so every batch is
-// a fabric round trip).  Thread t < 256 owns components 4*(t%8)..+3 of workgroups t/8, t/8 + 32, ...; the 32 row sums
-// per component are then added in row order by lanes 0..31.  Order is fixed, so every workgroup (and every run) gets
-// bit-identical sums.
+// a fabric round trip).  Thread t < 256 owns components 4*(t%8)..+3 of workgroups t/8, t/8 + 32, ...
+// Round 4 (in-kernel stamps, profiles/r04c_icp_prof.txt: this phase was 3.1 k of a launch's 13.6 k ticks, of which the memory round trip
+// is ~0.9 k): a thread's own <= 10 values per component are added in fp32 -- they ARE fp32 sums of up to 1 536 products each, the extra
+// rounding is below theirs -- instead of 40 conversions + 40 fp64 additions + 80 selects per thread on a quarter-rate pipe; the 32 row sums
+// per component are then added in fp64 by FOUR lanes per component (8 rows each, in row order) and a quad butterfly on the DPP path
+// instead of one lane walking 32 dependent additions.  The order is fixed, so every workgroup (and every run) gets bit-identical sums.
+__device__ __forceinline__ double quad_sum_d(double v) {   // v + its three quad neighbours, same bits in all four lanes
+    const int lane = threadIdx.x & 63;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    double o = __hiloint2double(__float_as_int(lane_xor_bits<1>(hi, lane)), __float_as_int(lane_xor_bits<1>(lo, lane)));
+    v = (lane & 1) ? o + v : v + o;            // both lanes of a pair add (even lane's value) + (odd lane's value)
+    lo = __double2loint(v); hi = __double2hiint(v);
+    o = __hiloint2double(__float_as_int(lane_xor_bits<2>(hi, lane)), __float_as_int(lane_xor_bits<2>(lo, lane)));
+    return (lane & 2) ? o + v : v + o;
+}
+__device__ __forceinline__ void reduce_rows(const double* s_seg /*[32][32]*/, double* s_sys /*[32]*/, int t /* 0..127 */) {
+    const int comp = t >> 2, part = t & 3;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += s_seg[(part * 8 + k) * 32 + comp];
+    s = quad_sum_d(s);
+    if (part == 0) s_sys[comp] = s;
+}
+__device__ __forceinline__ void partial_sums_f32(const float4* __restrict__ p4, int n4, int t, float (&a)[4]) {
+    a[0] = a[1] = a[2] = a[3] = 0.f;
+    for (int f = t; f < n4; f += 2560) {  // 10 independent 16 B loads in flight per lane
+        float4 v[10];
+#pragma unroll
+        for (int u = 0; u < 10; ++u) v[u] = p4[min(f + 256 * u, n4 - 1)];  // unconditional: all ten issue back to back
+#pragma unroll
+        for (int u = 0; u < 10; ++u) {
+            const bool in = f + 256 * u < n4;
+            a[0] += in ? v[u].x : 0.f; a[1] += in ? v[u].y : 0.f;
+            a[2] += in ? v[u].z : 0.f; a[3] += in ? v[u].w : 0.f;
+        }
+    }
+}
 __device__ __forceinline__ void reduce_partials(const float* __restrict__ partials, int nb, double* s_seg /*[32][32]*/,
                                                 double* s_sys /*[32]*/) {
     // The first 256 threads of the workgroup load; any workgroup size that is a multiple of 256 may call this.
-    const float4* __restrict__ p4 = reinterpret_cast<const float4*>(partials);
-    const int n4 = nb * (kIcpSlots / 4);
     if (threadIdx.x < 256) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        for (int f = threadIdx.x; f < n4; f += 2560) {  // 10 independent 16 B loads in flight per lane
-            float4 v[10];
-#pragma unroll
-            for (int u = 0; u < 10; ++u) v[u] = p4[min(f + 256 * u, n4 - 1)];  // unconditional: all ten issue back to back
-#pragma unroll
-            for (int u = 0; u < 10; ++u) {
-                const bool in = f + 256 * u < n4;
-                a0 += in ? (double)v[u].x : 0.0; a1 += in ? (double)v[u].y : 0.0;
-                a2 += in ? (double)v[u].z : 0.0; a3 += in ? (double)v[u].w : 0.0;
-            }
-        }
+        float a[4];
+        partial_sums_f32(reinterpret_cast<const float4*>(partials), nb * (kIcpSlots / 4), threadIdx.x, a);
         const int row = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
-        s_seg[row * 32 + c4 + 0] = a0; s_seg[row * 32 + c4 + 1] = a1; s_seg[row * 32 + c4 + 2] = a2; s_seg[row * 32 + c4 + 3] = a3;
+        s_seg[row * 32 + c4 + 0] = (double)a[0]; s_seg[row * 32 + c4 + 1] = (double)a[1];
+        s_seg[row * 32 + c4 + 2] = (double)a[2]; s_seg[row * 32 + c4 + 3] = (double)a[3];
     }
     __syncthreads();
-    if (threadIdx.x < 32) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) s += s_seg[k * 32 + threadIdx.x];
-        s_sys[threadIdx.x] = s;
-    }
+    if (threadIdx.x < 128) reduce_rows(s_seg, s_sys, threadIdx.x);
     __syncthreads();
 }
 
@@ -341,23 +366,12 @@ __device__ __forceinline__ void reduce_partials_pair(const float* __restrict__ p
     if (threadIdx.x < 64)
         for (int i = threadIdx.x; i < nb; i += 64) { const int2 v = cnt[i]; c += (unsigned)v.x; g += (unsigned)v.y; }
     if (half < 2) {
-        const float4* __restrict__ p4 = reinterpret_cast<const float4*>(half ? pb : pa);
+        float a[4];
+        partial_sums_f32(reinterpret_cast<const float4*>(half ? pb : pa), nb * (kIcpSlots / 4), t, a);
         double* s_seg = half ? s_segB : s_segA;
-        const int n4 = nb * (kIcpSlots / 4);
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        for (int f = t; f < n4; f += 2560) {
-            float4 v[10];
-#pragma unroll
-            for (int u = 0; u < 10; ++u) v[u] = p4[min(f + 256 * u, n4 - 1)];
-#pragma unroll
-            for (int u = 0; u < 10; ++u) {
-                const bool in = f + 256 * u < n4;
-                a0 += in ? (double)v[u].x : 0.0; a1 += in ? (double)v[u].y : 0.0;
-                a2 += in ? (double)v[u].z : 0.0; a3 += in ? (double)v[u].w : 0.0;
-            }
-        }
         const int row = t >> 3, c4 = (t & 7) * 4;
-        s_seg[row * 32 + c4 + 0] = a0; s_seg[row * 32 + c4 + 1] = a1; s_seg[row * 32 + c4 + 2] = a2; s_seg[row * 32 + c4 + 3] = a3;
+        s_seg[row * 32 + c4 + 0] = (double)a[0]; s_seg[row * 32 + c4 + 1] = (double)a[1];
+        s_seg[row * 32 + c4 + 2] = (double)a[2]; s_seg[row * 32 + c4 + 3] = (double)a[3];
     }
     if (threadIdx.x < 64) {
 #pragma unroll
@@ -365,13 +379,7 @@ __device__ __forceinline__ void reduce_partials_pair(const float* __restrict__ p
         if (threadIdx.x == 0) { s_cnt[0] = (int)c; s_cnt[1] = (int)g; }
     }
     __syncthreads();
-    if (t < 32 && half < 2) {
-        const double* s_seg = half ? s_segB : s_segA;
-        double sum = 0.0;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) sum += s_seg[k * 32 + t];
-        (half ? s_sysB : s_sysA)[t] = sum;
-    }
+    if (t < 128 && half < 2) reduce_rows(half ? s_segB : s_segA, half ? s_sysB : s_sysA, t);
     __syncthreads();
 }
 

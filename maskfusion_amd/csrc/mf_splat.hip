@@ -62,16 +62,15 @@ __device__ __forceinline__ bool splat_setup(const Surfels& src, int i, float tim
     return true;
 }
 
-// lanes that share one sprite in the tile z-test (1, 2, 4, 8, 16; mf_set_param "spriteLanes"): process-wide, an A/B switch for measurements
-static int g_sprite_lanes = 4;
-void set_sprite_lanes(int n) { g_sprite_lanes = (n == 1 || n == 2 || n == 8 || n == 16) ? n : 4; }
+// lanes that share one sprite in the tile z-test (1, 2, 4, 8, 16; mf_set_param "spriteLanes"): an A/B switch for measurements, per context
+// (SplatTuning travels with the launch; rounds 2-3 kept both knobs in process-wide statics that one context's setting changed for all)
+int splat_sprite_lanes(int n) { return (n == 1 || n == 2 || n == 8 || n == 16) ? n : 4; }
 // threads per tile workgroup (256, 512, 1024; "tileThreads"): a tile has 256 pixels, the threads beyond them only walk the sprite list.
 // 1200 tiles of 256 threads are 4.7 wavefronts per SIMD on 256 CUs -- too few to hide the list's dependent gathers and the division
 // chain of the pixel test (tools/splat_prof.py: a tile workgroup lives ~32 k cycles, ~4 k of them issuing)
 // Measured (profiles/r03k_*, prediction stage incl. binning): 256 threads 62.6 us, 512 threads 58.0 us, 1024 threads 65.9 us (4 lanes per
 // sprite each) -- 512 is the default.
-static int g_tile_threads = 512;
-void set_tile_threads(int n) { g_tile_threads = (n == 256 || n == 1024) ? n : 512; }
+int splat_tile_threads(int n) { return (n == 256 || n == 1024) ? n : 512; }
 
 struct BinArgs {
     Surfels src; const FrameDev* frame; const PoseDev* pose; int W, H; Intr k; float maxDepth, confThreshold; int timeDelta;
@@ -367,9 +366,10 @@ __global__ __launch_bounds__(1024) void k_global_tile(const GlobalTileArgs a) {
 
 int launch_global_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
                         int timeDelta, int order, int id, int* tile_count, int* entries, int entries_cap, float4* rec0, float4* rec1, void* bbox,
-                        unsigned long long* keys, hipStream_t s) {
+                        unsigned long long* keys, hipStream_t s, SplatTuning tune) {
     const int tilesX = (W + kTile - 1) / kTile, tilesY = (H + kTile - 1) / kTile, nt = tilesX * tilesY;
     if (nt > kMaxTiles) return -1;
+    const int g_sprite_lanes = splat_sprite_lanes(tune.sprite_lanes), g_tile_threads = splat_tile_threads(tune.tile_threads);
     BinArgs b;
     b.src = src; b.frame = frame; b.pose = pose; b.W = W; b.H = H; b.k = k; b.maxDepth = maxDepth; b.confThreshold = confThreshold;
     b.timeDelta = timeDelta; b.tilesX = tilesX; b.tilesY = tilesY; b.tile_count = tile_count;
@@ -398,9 +398,10 @@ size_t splat_tiles_scratch_ints(int W, int H) { return (size_t)((W + kTile - 1) 
 int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
                        int timeDelta, int* tile_count, int* entries, int entries_cap, float4* rec0, float4* rec1, void* bbox, float4* predV,
                        float4* predN, uchar4* predImage, uint16_t* predTime, const uint8_t* rgb, uint8_t* predGray, uint8_t* fillGray, hipStream_t s,
-                       const FrameAdvance* advance, int fillPassthrough, unsigned long long* prof) {
+                       const FrameAdvance* advance, int fillPassthrough, unsigned long long* prof, SplatTuning tune) {
     const int tilesX = (W + kTile - 1) / kTile, tilesY = (H + kTile - 1) / kTile, nt = tilesX * tilesY;
     if (nt > kMaxTiles) return -1;
+    const int g_sprite_lanes = splat_sprite_lanes(tune.sprite_lanes), g_tile_threads = splat_tile_threads(tune.tile_threads);
     BinArgs b;
     b.src = src; b.frame = frame; b.pose = pose; b.W = W; b.H = H; b.k = k; b.maxDepth = maxDepth; b.confThreshold = confThreshold;
     b.timeDelta = timeDelta; b.tilesX = tilesX; b.tilesY = tilesY; b.tile_count = tile_count;

@@ -118,6 +118,10 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
     if (row_mask != 0xf || bank_mask != 0xf) { fprintf(stderr, "hipcpu: partial DPP masks not emulated\n"); abort(); }
     return hipcpu::lane_alive(l) ? (int)(uint32_t)s[l] : (bound_ctrl ? 0 : old);
 }
+// the halves of a double (CUDA / HIP device intrinsics)
+static inline int __double2loint(double v) { uint64_t b; memcpy(&b, &v, 8); return (int)(uint32_t)(b & 0xFFFFFFFFu); }
+static inline int __double2hiint(double v) { uint64_t b; memcpy(&b, &v, 8); return (int)(uint32_t)(b >> 32); }
+static inline double __hiloint2double(int hi, int lo) { const uint64_t b = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; double v; memcpy(&v, &b, 8); return v; }
 // v_readfirstlane_b32 / v_readlane_b32: the value of the first active lane / of a given lane, uniform across the wavefront
 static inline int __builtin_amdgcn_readfirstlane(int v) {
     const uint64_t* s = hipcpu::wave_publish((uint32_t)v);
