@@ -14,7 +14,10 @@
 #include <string.h>
 #include <memory>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace mf;
@@ -126,6 +129,43 @@ struct LabelsScratch {
 
 }  // namespace
 
+// One helper thread per context that copies a plane of the caller's frame into the pinned staging slot while the calling thread copies the
+// other (mf_process_frame, "hostInputAsync"): the 2.15 MB of a VGA frame cost a single thread ~0.2 ms -- more than enqueueing the frame's 34
+// launches -- and were what kept the host-pointer boundary below the device-resident rate.  Started on first use, joined in mf_destroy.
+struct CopyWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    void* dst = nullptr; const void* src = nullptr; size_t n = 0;
+    bool has_job = false, quit = false;
+    void run() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return has_job || quit; });
+            if (quit) return;
+            void* d = dst; const void* sp = src; const size_t bytes = n;
+            lk.unlock();
+            memcpy(d, sp, bytes);
+            lk.lock();
+            has_job = false;
+            cv.notify_all();
+        }
+    }
+    void post(void* d, const void* sp, size_t bytes) {
+        { std::lock_guard<std::mutex> g(m); dst = d; src = sp; n = bytes; has_job = true; }
+        if (!th.joinable()) th = std::thread([this] { run(); });
+        cv.notify_all();
+    }
+    void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return !has_job; }); }
+    ~CopyWorker() {
+        if (th.joinable()) {
+            { std::lock_guard<std::mutex> g(m); quit = true; }
+            cv.notify_all();
+            th.join();
+        }
+    }
+};
+
 struct mf_ctx {
     mf_config cfg;
     int W, H, P;
@@ -182,6 +222,7 @@ struct mf_ctx {
     hipEvent_t ev_in_copied[2] = {nullptr, nullptr};       // the slot's H2D copies have completed   (in -> main / pre, and the host before it refills the slot)
     hipEvent_t ev_in_consumed[2] = {nullptr, nullptr};     // the frame that read the slot has been processed   (main -> in)
     unsigned in_slot = 0;
+    std::unique_ptr<CopyWorker> copy_worker;
     uint8_t* d_mask_tex = nullptr;  // textureMask: the last full segmentation (Core/MaskFusion.cpp:297)
     float* d_depthF[3] = {nullptr, nullptr, nullptr};  // ring: frame k filters into [k % 3], fill-in reads [(k - 1) % 3]
     float* d_vmap[2][3] = {}; float* d_nmap[2][3] = {};
@@ -1319,9 +1360,11 @@ extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* dept
         const int slot = (int)(c->in_slot++ & 1u);
         MF_HIP(c, hipEventSynchronize(c->ev_in_copied[slot]));        // the staging slot's previous upload (two frames ago) has left it
         uint8_t* h = c->h_in[slot];
-        memcpy(h, rgb, P * 3);
-        memcpy(h + P * 3, depth, P * sizeof(float));
+        if (!c->copy_worker) c->copy_worker.reset(new CopyWorker());
+        c->copy_worker->post(h + P * 3, depth, P * sizeof(float));   // the helper thread takes the depth plane (4 P bytes) ...
+        memcpy(h, rgb, P * 3);                                        // ... this one colour and mask (3 P + P)
         if (mask) memcpy(h + P * 7, mask, P);
+        c->copy_worker->wait();
         MF_HIP(c, hipStreamWaitEvent(c->stream_in, c->ev_in_consumed[slot], 0));   // the frame that read these device buffers is done
         MF_HIP(c, hipMemcpyAsync(c->d_in_rgb[slot], h, P * 3, hipMemcpyHostToDevice, c->stream_in));
         MF_HIP(c, hipMemcpyAsync(c->d_in_depth[slot], h + P * 3, P * sizeof(float), hipMemcpyHostToDevice, c->stream_in));
