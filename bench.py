@@ -634,9 +634,10 @@ def main():
                 mf.processFrame(frames[k][0], frames[k][1], mask=frames[k][2], classIDs=cls)
             else:
                 mf.processFrame(frames[k][0], frames[k][1])
+        dt_calls = time.perf_counter() - t0     # the calls alone: how long the HOST needs per frame (staging copy + uploads + ~34 launches)
         mf.sync()
         dt_h = time.perf_counter() - t0
-        host_input = {"value": n / dt_h, "unit": "frames/s", "ms_per_step": 1e3 * dt_h / n,
+        host_input = {"value": n / dt_h, "unit": "frames/s", "ms_per_step": 1e3 * dt_h / n, "host_ms_per_call": 1e3 * dt_calls / n,
                       "note": f"mf_process_frame with host pointers (pageable numpy arrays): {(7 + (1 if multi else 0)) * P / 1e6:.2f} MB per frame copied into a "
                               "pinned double buffer and uploaded asynchronously under the previous frame's kernels; no synchronisation per frame "
                               "(rounds 1-3: one hipStreamSynchronize per frame)"}

@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <memory>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -137,30 +138,46 @@ struct CopyWorker {
     std::mutex m;
     std::condition_variable cv;
     void* dst = nullptr; const void* src = nullptr; size_t n = 0;
-    bool has_job = false, quit = false;
+    std::atomic<unsigned> posted{0}, done{0};
+    std::atomic<bool> sleeping{false}, quit{false};
+    // The helper spins for a couple of milliseconds after a job before it goes to sleep: a streaming caller posts the next job ~0.3 ms later,
+    // and waking a sleeping thread costs 30-60 us -- as much as the half of the copy it is supposed to take off the caller (first version of
+    // round 4: 2 309 -> 2 310 frames/s).  An idle context sleeps on the condition variable.
     void run() {
-        std::unique_lock<std::mutex> lk(m);
+        unsigned seen = 0;
         for (;;) {
-            cv.wait(lk, [&] { return has_job || quit; });
-            if (quit) return;
-            void* d = dst; const void* sp = src; const size_t bytes = n;
-            lk.unlock();
-            memcpy(d, sp, bytes);
-            lk.lock();
-            has_job = false;
-            cv.notify_all();
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            while (posted.load(std::memory_order_acquire) == seen && !quit.load(std::memory_order_acquire)) {
+                __builtin_ia32_pause();
+                if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+                    std::unique_lock<std::mutex> lk(m);
+                    sleeping.store(true);
+                    cv.wait(lk, [&] { return posted.load(std::memory_order_acquire) != seen || quit.load(std::memory_order_acquire); });
+                    sleeping.store(false);
+                    break;
+                }
+            }
+            if (quit.load(std::memory_order_acquire)) return;
+            memcpy(dst, src, n);
+            ++seen;
+            done.store(seen, std::memory_order_release);
         }
     }
     void post(void* d, const void* sp, size_t bytes) {
-        { std::lock_guard<std::mutex> g(m); dst = d; src = sp; n = bytes; has_job = true; }
+        dst = d; src = sp; n = bytes;
+        posted.fetch_add(1, std::memory_order_release);
         if (!th.joinable()) th = std::thread([this] { run(); });
-        cv.notify_all();
+        if (sleeping.load()) { std::lock_guard<std::mutex> g(m); cv.notify_one(); }
     }
-    void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return !has_job; }); }
+    void wait() {
+        const unsigned p = posted.load(std::memory_order_acquire);
+        while (done.load(std::memory_order_acquire) != p) __builtin_ia32_pause();
+    }
     ~CopyWorker() {
         if (th.joinable()) {
-            { std::lock_guard<std::mutex> g(m); quit = true; }
-            cv.notify_all();
+            quit.store(true, std::memory_order_release);
+            { std::lock_guard<std::mutex> g(m); cv.notify_one(); }
             th.join();
         }
     }
