@@ -674,9 +674,12 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
         // initRGBModel + initRGB (Model.cpp:395-406; Q1: both depth pyramids come from the vertex map initICPModel was given)
         launch_rgbd_last_l0(m.d_predV, m.allowFillIn ? fillDepth : nullptr, m.d_predGray, m.d_fillGray, m.d_frame, c->d_lastDepth[0],
                             c->d_lastImage[0], W * H, s, (c->ftf_rgb && m.allowFillIn) ? 1 : 0);
-        for (int i = 0; i + 1 < 3; ++i) {
-            launch_pyrdown_f(c->d_lastDepth[i], c->d_lastDepth[i + 1], W >> i, H >> i, s);
-            launch_pyrdown_u8(c->d_lastImage[i], c->d_lastImage[i + 1], W >> i, H >> i, s);
+        for (int i = 0; i + 1 < 3; ++i) {   // one level of the depth pyramid and of the intensity pyramid per launch (independent of each other)
+            SmallJobs jobs;
+            jobs.n = 2;
+            jobs.j[0] = SmallJob{1, c->d_lastDepth[i], c->d_lastDepth[i + 1], nullptr, nullptr, W >> i, H >> i, 0.f};
+            jobs.j[1] = SmallJob{0, c->d_lastImage[i], c->d_lastImage[i + 1], nullptr, nullptr, W >> i, H >> i, 0.f};
+            launch_small_jobs(jobs, s);
         }
     }
     const int iters[3] = {g.fast_odom ? 3 : 10, g.pyramid ? 5 : 0, g.pyramid ? 4 : 0};  // RGBDOdometry.cpp:327-329
@@ -954,8 +957,11 @@ static int enqueue_preprocess(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
         for (int i = 0; i + 1 < 3; ++i) launch_pyrdown_u8(c->d_gray[set][i], c->d_gray[set][i + 1], W >> i, H >> i, sp);
         c->gray_frame[set] = k;
         if (photometric_on(c)) {
+            SmallJobs jobs;   // the three levels' derivative / gate images: one launch
+            jobs.n = 3;
             for (int i = 0; i < 3; ++i)
-                launch_derivative(c->d_gray[set][i], c->d_dIdx[i], c->d_dIdy[i], W >> i, H >> i, rgb_min_scale(i), c->d_rgb_gate[i], sp);
+                jobs.j[i] = SmallJob{2, c->d_gray[set][i], c->d_dIdx[i], c->d_dIdy[i], c->d_rgb_gate[i], W >> i, H >> i, rgb_min_scale(i)};
+            launch_small_jobs(jobs, sp);
             c->deriv_frame = k;
         }
     }

@@ -176,6 +176,11 @@ struct RgbLevel {  // one pyramid level of RGBDOdometry's photometric inputs
 void launch_intensity(const uint8_t* img, int channels, uint8_t* dst, int n, hipStream_t s);
 void launch_pyrdown_u8(const uint8_t* src, uint8_t* dst, int sw, int sh, hipStream_t s);
 void launch_derivative(const uint8_t* src, int16_t* dx, int16_t* dy, int W, int H, float minScale, uint8_t* gate /*or null*/, hipStream_t s);
+// up to three independent small image jobs in ONE launch (mf_rgbd.hip): kind 0 pyrDownUcharGauss (W, H = source size), 1 pyrDownGaussF (source size),
+// 2 computeDerivativeImages (+ gate image; W, H = image size)
+struct SmallJob { int kind; const void* src; void* dst; void* dst2; uint8_t* gate; int W, H; float minScale; };
+struct SmallJobs { SmallJob j[3]; int n; };
+void launch_small_jobs(const SmallJobs& a, hipStream_t s);
 // level 0 of a model's "last" depth / intensity pyramids (populateRGBDData of initRGBModel; Q1: initRGB re-uses the depth)
 // frameToFrameRGB != 0 (and a fill-in image given): initRGBModel takes the fill-in image whatever the fill-in decision (Model.cpp:399-400)
 void launch_rgbd_last_l0(const float4* predV, const float* fillDepth, const uint8_t* predGray, const uint8_t* fillGray,

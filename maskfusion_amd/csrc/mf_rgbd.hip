@@ -53,9 +53,9 @@ __device__ __forceinline__ float gauss5w(int r, int c) {
     const int b = (c == 0 || c == 4) ? 1 : ((c == 2) ? 6 : 4);
     return (float)(a * b);
 }
-__global__ __launch_bounds__(256) void k_pyrdown_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int sw, int sh) {
+__device__ __forceinline__ void pyrdown_u8_body(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int sw, int sh, int bx, int by) {
     const int dw = sw / 2, dh = sh / 2;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = bx * 64 + (threadIdx.x & 63), y = by * 4 + (threadIdx.x >> 6);
     if (x >= dw || y >= dh) return;
     const int D = 5;
     const int tx = min(2 * x - D / 2 + D, sw - 1), ty = min(2 * y - D / 2 + D, sh - 1);
@@ -73,15 +73,42 @@ __global__ __launch_bounds__(256) void k_pyrdown_u8(const uint8_t* __restrict__ 
     const float r = sum / (float)count;             // 0 / 0 -> NaN -> 0 (cvt semantics of the reference)
     dst[y * dw + x] = isnan(r) ? (uint8_t)0 : (uint8_t)(int)r;
 }
+__global__ __launch_bounds__(256) void k_pyrdown_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int sw, int sh) {
+    pyrdown_u8_body(src, dst, sw, sh, blockIdx.x, blockIdx.y);
+}
 void launch_pyrdown_u8(const uint8_t* src, uint8_t* dst, int sw, int sh, hipStream_t s) {
     dim3 grid((sw / 2 + 63) / 64, (sh / 2 + 3) / 4);
     hipLaunchKernelGGL(k_pyrdown_u8, grid, dim3(256), 0, s, src, dst, sw, sh);
 }
+// pyrDownGaussF (cudafuncs.cu:510-532) with the per-pixel expressions of k_pyrdown_f (mf_preproc.hip; both files round every operation on
+// its own): the copy that rides in the combined launches below
+__device__ __forceinline__ float gauss5f(int i) { return i == 2 ? 6.f : ((i == 1 || i == 3) ? 4.f : 1.f); }
+__device__ __forceinline__ void pyrdown_f_body(const float* __restrict__ src, float* __restrict__ dst, int sw, int sh, int bx, int by) {
+    const int dw = sw >> 1, dh = sh >> 1;
+    const int x = bx * 64 + (threadIdx.x & 63);
+    const int y = by * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    const int tx = min(2 * x + 3, sw - 1);
+    const int ty = min(2 * y + 3, sh - 1);
+    float sum = 0.f;
+    int count = 0;
+    for (int cy = max(0, 2 * y - 2); cy < ty; ++cy) {
+        for (int cx = max(0, 2 * x - 2); cx < tx; ++cx) {
+            const float v = src[cy * sw + cx];
+            if (!isnan(v)) {
+                const float w = gauss5f(ty - cy - 1) * gauss5f(tx - cx - 1);
+                sum += v * w;
+                count += (int)w;
+            }
+        }
+    }
+    dst[y * dw + x] = sum / (float)count;
+}
 
 // ---------------- computeDerivativeImages ----------------
-__global__ __launch_bounds__(256) void k_derivative(const uint8_t* __restrict__ src, int16_t* __restrict__ dx,
-                                                    int16_t* __restrict__ dy, int W, int H, float minScale, uint8_t* __restrict__ gate) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void derivative_body(const uint8_t* __restrict__ src, int16_t* __restrict__ dx, int16_t* __restrict__ dy, int W, int H,
+                                                float minScale, uint8_t* __restrict__ gate, int bx, int by) {
+    const int x = bx * 64 + (threadIdx.x & 63), y = by * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     const float gx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
     const float gy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
@@ -104,9 +131,35 @@ __global__ __launch_bounds__(256) void k_derivative(const uint8_t* __restrict__ 
     dy[y * W + x] = sy;
     if (gate) gate[y * W + x] = rgb_gate_px(src, sx, sy, minScale, W, H, x, y) ? 1 : 0;
 }
+__global__ __launch_bounds__(256) void k_derivative(const uint8_t* __restrict__ src, int16_t* __restrict__ dx,
+                                                    int16_t* __restrict__ dy, int W, int H, float minScale, uint8_t* __restrict__ gate) {
+    derivative_body(src, dx, dy, W, H, minScale, gate, blockIdx.x, blockIdx.y);
+}
 void launch_derivative(const uint8_t* src, int16_t* dx, int16_t* dy, int W, int H, float minScale, uint8_t* gate, hipStream_t s) {
     dim3 grid((W + 63) / 64, (H + 3) / 4);
     hipLaunchKernelGGL(k_derivative, grid, dim3(256), 0, s, src, dx, dy, W, H, minScale, gate);
+}
+
+// Up to three INDEPENDENT small image jobs in one launch (grid.z = job): the derivative images of the three pyramid levels; one level of a
+// model's "last" depth pyramid together with the same level of its "last" intensity pyramid.  Each of these is a 5-8 us launch on an image
+// of at most 0.3 M pixels -- launch latency, not work -- and the reference-default frame carried nine of them one after the other (72 us of
+// 617, profiles/r04_rgbd_kernel_stats.csv).  The bodies are the single-job kernels' bodies: same bits.
+__global__ __launch_bounds__(256) void k_small_jobs(const SmallJobs a) {
+    const SmallJob& j = a.j[blockIdx.z];
+    switch (j.kind) {
+        case 0: pyrdown_u8_body(static_cast<const uint8_t*>(j.src), static_cast<uint8_t*>(j.dst), j.W, j.H, blockIdx.x, blockIdx.y); break;
+        case 1: pyrdown_f_body(static_cast<const float*>(j.src), static_cast<float*>(j.dst), j.W, j.H, blockIdx.x, blockIdx.y); break;
+        default: derivative_body(static_cast<const uint8_t*>(j.src), static_cast<int16_t*>(j.dst), static_cast<int16_t*>(j.dst2), j.W, j.H, j.minScale,
+                                 j.gate, blockIdx.x, blockIdx.y); break;
+    }
+}
+void launch_small_jobs(const SmallJobs& a, hipStream_t s) {
+    int gx = 1, gy = 1;
+    for (int i = 0; i < a.n; ++i) {
+        const int w = a.j[i].kind == 2 ? a.j[i].W : a.j[i].W / 2, h = a.j[i].kind == 2 ? a.j[i].H : a.j[i].H / 2;   // output size of the job
+        gx = max(gx, (w + 63) / 64); gy = max(gy, (h + 3) / 4);
+    }
+    hipLaunchKernelGGL(k_small_jobs, dim3(gx, gy, a.n), dim3(256), 0, s, a);
 }
 
 // ---------------- SO(3) pre-alignment: all iterations in one workgroup ----------------

@@ -128,3 +128,50 @@ def test_set_tick_skips_frame_numbers(hip):
     assert m[:, 7].max() == 50.0 and m[:, 6].max() == 50.0    # lastTime / initTime of surfels touched / created at tick 50
     assert np.linalg.norm(mf.getCurrPose()[:3, 3] - st.gt_pose(2)[:3, 3]) < 5e-3
     mf.close()
+
+
+@pytest.mark.parametrize("multi", [False, True], ids=["single-model", "multi-model"])
+def test_asynchronous_host_frames_equal_the_blocking_form(hip, multi):
+    """mf_process_frame since round 4: the caller's buffers are copied into a pinned double buffer (a helper thread takes the depth plane),
+    uploaded on their own stream under the previous frame's kernels, and the call returns when the frame is enqueued.  Same frames through
+    `hostInputAsync = 0` (rounds 1-3: upload on the main stream, one synchronisation per frame): poses, counts, label images and clouds
+    bit-identical -- also when the caller overwrites its buffers right after the call returns (they must have been consumed by then)."""
+    from maskfusion_amd import MaskFusion, synth
+    W, H, f = 320, 240, 264.0
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True, n_objects=2 if multi else 0, object_motion=0.0)
+
+    def run(asynchronous):
+        mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=multi, numGSurfels=1 << 18, numOSurfels=1 << 16,
+                        modelSpawnOffset=2, trackAllModels=False)
+        if multi:
+            for k, v in (("mfThreshold", 0.3), ("mfWeightDistance", 150.0), ("mfWeightConvexity", 2.8), ("mfMorphEdgeIterations", 0),
+                         ("mfMorphMaskIterations", 0), ("newModelMinRelativeSize", 0.004)):
+                mf.setParam(k, v)
+        mf.setParam("hostInputAsync", 1 if asynchronous else 0)
+        rgb_buf, d_buf, m_buf = np.zeros((H, W, 3), np.uint8), np.zeros((H, W), np.float32), np.zeros((H, W), np.uint8)
+        poses = []
+        for k in range(10):
+            rgb, d, m = st.frame(k)
+            rgb_buf[...] = rgb; d_buf[...] = d; m_buf[...] = m
+            if multi:
+                mf.processFrame(rgb_buf, d_buf, mask=m_buf, classIDs=[0, 41, 42], timestamp=k)
+            else:
+                mf.processFrame(rgb_buf, d_buf, timestamp=k)
+            rgb_buf[...] = 0; d_buf[...] = np.nan; m_buf[...] = 7       # the caller's buffers are the caller's again
+            if k % 3 == 2:
+                poses.append(mf.getCurrPose())                          # (a getter synchronises; the frames in between stay queued)
+        ms = mf.getModels()
+        out = dict(poses=poses, ids=[x.getID() for x in ms], counts=[x.lastCount() for x in ms], clouds=[x.downloadMap() for x in ms],
+                   labels=mf.downloadSegmentation() if multi else None, final=[x.getPose() for x in ms])
+        mf.close()
+        return out
+
+    a, b = run(True), run(False)
+    assert a["ids"] == b["ids"] and a["counts"] == b["counts"]
+    assert len(a["ids"]) == (3 if multi else 1)
+    for x, y in zip(a["poses"] + a["final"], b["poses"] + b["final"]):
+        assert np.array_equal(x, y)
+    for x, y in zip(a["clouds"], b["clouds"]):
+        assert np.array_equal(x, y, equal_nan=True)
+    if multi:
+        assert np.array_equal(a["labels"], b["labels"])
