@@ -97,6 +97,10 @@ void launch_edge_binary(const float* edge, uint8_t* out, uint8_t* tmp, int W, in
 // GlobalProjection: the splat scatter of mf_surfel.hip with (model order, model id) as payload
 // key = z bits << 32 | order << 8 | id  -> LESS on z, earlier model in the list wins ties (GL draw order)
 // ------------------------------------------------------------------------------------------------
+// kLanes neighbouring lanes share one surfel and split its sprite's pixels between them as a kLX x kLY block (1: the thread-per-surfel form).
+// The object models' launches use 4: a few thousand sprites of 4-10 px a side kept a handful of threads busy for ~36 us each (round 4 trace),
+// the rest of the GPU idle; the keys are the same bits in any split (atomicMin is order independent).
+template <int kLanes>
 __device__ __forceinline__ void global_scatter_body(Surfels src, const FrameDev* __restrict__ frame,
                                                     const PoseDev* __restrict__ pose, int W, int H, Intr k, float maxDepth,
                                                     float confThreshold, int timeDelta, unsigned payload,
@@ -108,7 +112,9 @@ __device__ __forceinline__ void global_scatter_body(Surfels src, const FrameDev*
 #pragma unroll
     for (int q = 0; q < 9; ++q) Ri[q] = pose->Ri[q];
     const float3 ti = f3(pose->ti[0], pose->ti[1], pose->ti[2]);
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    constexpr int kLX = kLanes >= 2 ? 2 : 1, kLY = kLanes / kLX;
+    const int sub = threadIdx.x % kLanes, sx = sub % kLX, sy = sub / kLX;
+    for (int i = (blockIdx.x * 256 + threadIdx.x) / kLanes; i < n; i += gridDim.x * 256 / kLanes) {
         const float4 pc = src.pc[i];
         if (pc.w < confThreshold) continue;
         const float lastTime = src.ct[i].w;
@@ -138,8 +144,8 @@ __device__ __forceinline__ void global_scatter_body(Surfels src, const FrameDev*
         const int py0 = max(0, (int)ceilf(v - half - 0.5f)), py1 = min(H - 1, (int)ceilf(v + half - 0.5f) - 1);
         const float sqrRad = rad * rad;
         const float pn = dot3(h, nrm);
-        for (int py = py0; py <= py1; ++py)
-            for (int px = px0; px <= px1; ++px) {
+        for (int py = py0 + sy; py <= py1; py += kLY)
+            for (int px = px0 + sx; px <= px1; px += kLX) {
                 const float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;
                 const float3 l = normalize_gl(f3((fcx - k.cx) / k.fx, (fcy - k.cy) / k.fy, 1.0f));
                 const float3 cp = l * (pn / dot3(l, nrm));
@@ -155,12 +161,12 @@ __global__ __launch_bounds__(256) void k_global_scatter(Surfels src, const Frame
                                                         const PoseDev* __restrict__ pose, int W, int H, Intr k, float maxDepth,
                                                         float confThreshold, int timeDelta, unsigned payload,
                                                         unsigned long long* __restrict__ keys) {
-    global_scatter_body(src, frame, pose, W, H, k, maxDepth, confThreshold, timeDelta, payload, keys);
+    global_scatter_body<1>(src, frame, pose, W, H, k, maxDepth, confThreshold, timeDelta, payload, keys);
 }
 // every object model of the list in one launch (grid.z = model; ObjBatch, mf_internal.h): all of them z-test into the one key image
 __global__ __launch_bounds__(256) void k_obj_global_scatter(const ObjBatch b) {
     const ObjPassArgs& m = b.m[blockIdx.z];
-    global_scatter_body(m.a, m.frame, m.pose, b.W, b.H, b.k, b.globalMaxDepth, 12.0f, b.timeDelta, m.global_payload, b.global_keys);
+    global_scatter_body<4>(m.a, m.frame, m.pose, b.W, b.H, b.k, b.globalMaxDepth, 12.0f, b.timeDelta, m.global_payload, b.global_keys);
 }
 void launch_obj_global_scatter(const ObjBatch& b, int blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_obj_global_scatter, dim3(blocks, 1, b.n), dim3(256), 0, s, b);
