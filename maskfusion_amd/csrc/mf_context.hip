@@ -225,6 +225,18 @@ struct mf_ctx {
     unsigned obj_arg_slot = 0;
     bool ftf_rgb = false;                              // MaskFusion::frameToFrameRGB ("-ftf"; Model.cpp:399-400,981): the photometric term tracks against the previous RAW frame
     bool gn_loop_graph = false;                        // the launch-per-iteration loop replayed as a captured hipGraph ("gnLoopGraph")
+    // "frameGraph": the WHOLE single-model frame of mf_process_frame (host pointers) as one captured hipGraph per buffer combination -- input
+    // slot x map parity x filtered-depth ring slot = 12 -- replayed with one hipGraphLaunch.  The frame's ~34 launches cost the host more
+    // than the GPU needs to run them (profiles/r04g_bench_async.json: 0.42 ms of host time per call against 0.33 ms of GPU work); the launch-
+    // bound part of the path is exactly what hipGraphs are for.  Only arguments that are constant for a combination are baked in (a key of
+    // the weight multiplier and a configuration epoch re-captures when they change); the pose-log entry, whose slot moves every frame, is
+    // one small launch behind the graph.
+    bool frame_graph = true;
+    bool capturing_frame = false;                      // inside the capture: no pose-log slot, no time stamp (the caller adds them behind the graph)
+    unsigned long long cfg_epoch = 1;                  // bumped by every mf_set_param / lifecycle call: whatever a graph baked in may have changed
+    struct FrameGraph { hipGraphExec_t exec = nullptr; unsigned long long key = 0; };
+    FrameGraph frame_graphs[12];
+    long frame_graph_launches = 0;                     // (debug tap: "frameGraphLaunches")
 
     // frame-level
     uint8_t* d_rgb = nullptr; float* d_depth = nullptr; uint8_t* d_mask_in = nullptr; uint8_t* d_zero_mask = nullptr;
@@ -616,6 +628,7 @@ extern "C" void mf_destroy(mf_ctx* c) {
         if (c->ev_pre_done[i]) (void)hipEventDestroy(c->ev_pre_done[i]);
         if (c->ev_main_done[i]) (void)hipEventDestroy(c->ev_main_done[i]);
     }
+    for (auto& g : c->frame_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (c->ev_labels) (void)hipEventDestroy(c->ev_labels);
     if (c->ev_staged) (void)hipEventDestroy(c->ev_staged);
     for (int i = 0; i < 2; ++i) {
@@ -1062,7 +1075,7 @@ static int enqueue_predict_loop(mf_ctx* c, size_t first, bool may_batch, int64_t
     const mf_config& g = c->cfg;
     ModelState& bg = *c->models[0];
     auto log_slot = [&](ModelState& m) -> float* {   // MaskFusion.cpp:580-596
-        if (!m.d_poselog) return nullptr;
+        if (!m.d_poselog || c->capturing_frame) return nullptr;   // (captured frame: the entry is a launch of its own behind the graph)
         float* slot = m.d_poselog + (m.log_ts.size() % (size_t)g.pose_log_capacity) * 8;
         m.log_ts.push_back(timestamp);
         return slot;
@@ -1372,6 +1385,67 @@ extern "C" int mf_sync(mf_ctx* c) {
     return MF_OK;
 }
 
+// One single-model frame of mf_process_frame through the frame graph (see mf_ctx::frame_graph).  d_rgb / d_depth: input slot `slot`.
+static int process_frame_graphed(mf_ctx* c, int slot, float weight_multiplier, int64_t timestamp) {
+    const mf_config& g = c->cfg;
+    ModelState& bg = *c->models[0];
+    const long k = c->frame_no;
+    const int set = (int)(k & 1), ring = (int)(k % 3);
+    const bool rgbd = photometric_on(c) || g.so3 != 0;
+    const bool so3_active = g.so3 != 0 && c->gray_frame[set ^ 1] == k - 1;   // what enqueue_track will find once this frame's pyramid exists
+    unsigned wm_bits; memcpy(&wm_bits, &weight_multiplier, 4);
+    const unsigned long long key = (c->cfg_epoch << 34) ^ ((unsigned long long)wm_bits << 2) ^ (so3_active ? 2ull : 0ull) ^ 1ull;
+    mf_ctx::FrameGraph& fg = c->frame_graphs[(slot * 2 + set) * 3 + ring];
+    bool launched = false;
+    if (fg.exec && fg.key == key) {
+        if (hipGraphLaunch(fg.exec, c->stream) == hipSuccess) {
+            // the host-side half of process_frame_impl for this branch (everything the enqueue functions do besides launching)
+            c->cur_rgb = c->d_in_rgb[slot]; c->cur_depth = c->d_in_depth[slot];
+            if (rgbd) { c->gray_frame[set] = k; if (photometric_on(c)) c->deriv_frame = k; }
+            bg.pred_gray_valid = photometric_on(c);
+            bg.age++;
+            c->lastF = ring; c->frame_no++; c->host_tick++;
+            launched = true;
+        } else { (void)hipGetLastError(); c->frame_graph = false; }
+    } else {
+        if (fg.exec) { (void)hipGraphExecDestroy(fg.exec); fg.exec = nullptr; }
+        // capture this frame's launches (the enqueue code runs as usual -- host bookkeeping included -- its launches land in the graph)
+        struct { long frame_no; int host_tick, lastF; const uint8_t* cur_rgb; const float* cur_depth; long gray[2], deriv; unsigned age; bool pgv; } snap =
+            {c->frame_no, c->host_tick, c->lastF, c->cur_rgb, c->cur_depth, {c->gray_frame[0], c->gray_frame[1]}, c->deriv_frame, bg.age, bg.pred_gray_valid};
+        hipGraph_t graph = nullptr;
+        bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        int rc = MF_OK;
+        if (ok) {
+            c->capturing_frame = true;
+            rc = process_frame_impl(c, c->d_in_rgb[slot], c->d_in_depth[slot], nullptr, nullptr, 0, weight_multiplier, timestamp);
+            c->capturing_frame = false;
+            ok = hipStreamEndCapture(c->stream, &graph) == hipSuccess && graph != nullptr && rc == MF_OK;
+        }
+        if (ok) ok = hipGraphInstantiate(&fg.exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) (void)hipGraphDestroy(graph);
+        if (ok) ok = hipGraphLaunch(fg.exec, c->stream) == hipSuccess;
+        if (ok) { fg.key = key; launched = true; }
+        else {
+            // the runtime refused: nothing of this frame has run.  Undo the bookkeeping of the captured pass and take the eager path for good.
+            (void)hipGetLastError();
+            if (fg.exec) { (void)hipGraphExecDestroy(fg.exec); fg.exec = nullptr; }
+            c->frame_no = snap.frame_no; c->host_tick = snap.host_tick; c->lastF = snap.lastF; c->cur_rgb = snap.cur_rgb; c->cur_depth = snap.cur_depth;
+            c->gray_frame[0] = snap.gray[0]; c->gray_frame[1] = snap.gray[1]; c->deriv_frame = snap.deriv; bg.age = snap.age; bg.pred_gray_valid = snap.pgv;
+            c->frame_graph = false;
+            if (rc != MF_OK) return rc;
+        }
+    }
+    if (!launched)
+        return process_frame_impl(c, c->d_in_rgb[slot], c->d_in_depth[slot], nullptr, nullptr, 0, weight_multiplier, timestamp);
+    c->frame_graph_launches++;
+    if (bg.d_poselog) {   // MaskFusion.cpp:580-596, behind the graph: the pose is final once tracking has run
+        float* lslot = bg.d_poselog + (bg.log_ts.size() % (size_t)g.pose_log_capacity) * 8;
+        bg.log_ts.push_back(timestamp);
+        launch_pose_log(bg.d_pose, nullptr, lslot, c->stream);
+    }
+    return check_launch(c);
+}
+
 extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* depth, const uint8_t* mask, const int32_t* class_ids,
                                 int32_t n_masks, int64_t timestamp, const float* in_pose16, float weight_multiplier, int32_t bootstrap) {
     if (!c || !rgb || !depth) return MF_EINVAL;
@@ -1395,8 +1469,12 @@ extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* dept
         MF_HIP(c, hipEventRecord(c->ev_in_copied[slot], c->stream_in));
         MF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_in_copied[slot], 0));
         if (c->overlap) MF_HIP(c, hipStreamWaitEvent(c->stream_pre, c->ev_in_copied[slot], 0));
-        int rc = process_frame_impl(c, c->d_in_rgb[slot], c->d_in_depth[slot], mask ? c->d_in_mask[slot] : nullptr, class_ids, n_masks, weight_multiplier,
-                                    timestamp, in_pose16, bootstrap != 0);
+        // the single-model frame without a supplied pose, nothing being timed or profiled: one graph launch instead of ~34 launches
+        const bool graphed = c->frame_graph && c->cfg.enable_multiple_models == 0 && !in_pose16 && c->map_ready && !c->timings_on && !c->icp_prof_on &&
+                             !c->splat_prof_on && !c->overlap && !c->gn_loop_graph;
+        int rc = graphed ? process_frame_graphed(c, slot, weight_multiplier, timestamp)
+                         : process_frame_impl(c, c->d_in_rgb[slot], c->d_in_depth[slot], mask ? c->d_in_mask[slot] : nullptr, class_ids, n_masks,
+                                              weight_multiplier, timestamp, in_pose16, bootstrap != 0);
         (void)hipEventRecord(c->ev_in_consumed[slot], c->stream);     // (also on a failed frame: the slot must become reusable)
         return rc;
     }
@@ -2271,6 +2349,8 @@ static const SegRef kSegParams[] = {
 
 extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!c || !key) return MF_EINVAL;
+    c->cfg_epoch++;   // captured frames bake configuration values into their launches
+    if (!strcmp(key, "frameGraph")) { c->frame_graph = value != 0; return MF_OK; }   // 0: mf_process_frame enqueues its launches one by one
     if (!strcmp(key, "timings")) { c->timings_on = value != 0; return MF_OK; }
     if (!strcmp(key, "icpProfile")) { c->icp_prof_on = value != 0; return MF_OK; }
     if (!strcmp(key, "hostInputAsync")) {   // 0: mf_process_frame blocks until the frame is fused (rounds 1-3); 1: returns when it is enqueued
@@ -2340,6 +2420,8 @@ extern "C" int mf_get_param(mf_ctx* c, const char* key, double* value) {
     if (!strcmp(key, "confidenceThreshold")) { *value = c->models[0]->confThr; return MF_OK; }
     if (!strcmp(key, "splatTileEntries")) { *value = c->tile_entries_cap; return MF_OK; }
     if (!strcmp(key, "gnLoopGraph")) { *value = c->gn_loop_graph ? 1 : 0; return MF_OK; }   // 0 again after a capture that the runtime refused
+    if (!strcmp(key, "frameGraph")) { *value = c->frame_graph ? 1 : 0; return MF_OK; }      // 0 again after a capture that the runtime refused
+    if (!strcmp(key, "frameGraphLaunches")) { *value = (double)c->frame_graph_launches; return MF_OK; }
     if (!strcmp(key, "frameToFrameRGB")) { *value = c->ftf_rgb ? 1 : 0; return MF_OK; }
     if (!strcmp(key, "objectBoundingBoxLimit")) { *value = c->bbox_limit ? 1 : 0; return MF_OK; }
     for (const ParamRef& p : kParams)

@@ -303,6 +303,7 @@ void launch_model_state(const PoseDev* pose, const FrameDev* frame, float* out16
 
 // end-of-frame bookkeeping: tick++, cover -> useFillIn decision for the next frame
 // ... and the pose-log entry of this frame (MaskFusion.cpp:580-596) when log != nullptr
+void launch_pose_log(const PoseDev* pose, const PoseDev* bg_pose /*nullptr: the background itself*/, float* slot, hipStream_t s);
 void launch_frame_advance(FrameDev* frame, int W, int H, FrameDev* host_mirror, const PoseDev* pose, const PoseDev* bg_pose,
                           float* log_slot, hipStream_t s);
 

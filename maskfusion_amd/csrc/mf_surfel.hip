@@ -827,6 +827,14 @@ void launch_frame_advance(FrameDev* frame, int W, int H, FrameDev* host_mirror, 
     hipLaunchKernelGGL(k_frame_advance, dim3(1), dim3(64), 0, s, frame, W, H, host_mirror, pose, bg_pose, log_slot);
 }
 
+// the pose-log entry alone (MaskFusion.cpp:580-596): what the frame advance writes, as a launch of its own behind a captured frame
+__global__ void k_pose_log(const PoseDev* __restrict__ pose, const PoseDev* __restrict__ bg_pose, float* __restrict__ slot) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) pose_log_entry(pose, bg_pose, slot);
+}
+void launch_pose_log(const PoseDev* pose, const PoseDev* bg_pose, float* slot, hipStream_t s) {
+    hipLaunchKernelGGL(k_pose_log, dim3(1), dim3(64), 0, s, pose, bg_pose, slot);
+}
+
 void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, int timeDelta,
                   float confThreshold, float outlierCoeff, int maskID, const int* index, const float4* vc, const float4* ct,
                   const float4* packed, const float* depthF, const uint8_t* mask, const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags,

@@ -175,3 +175,41 @@ def test_asynchronous_host_frames_equal_the_blocking_form(hip, multi):
         assert np.array_equal(x, y, equal_nan=True)
     if multi:
         assert np.array_equal(a["labels"], b["labels"])
+
+
+@pytest.mark.parametrize("variant", ["geometric", "rgbd_so3"])
+def test_frame_graph_equals_eager_launches(hip, variant):
+    """`frameGraph` (default on): the whole single-model frame of mf_process_frame replayed as one captured hipGraph per buffer combination
+    (input slot x map parity x filtered-depth ring slot).  Against `frameGraph = 0` (every launch enqueued on its own): poses on every frame,
+    the final cloud, the pose log and the tracking statistics bit-identical -- through the six captures of the first frames, their replays, a
+    change of the weight multiplier (a new key: re-capture) and a parameter change (configuration epoch)."""
+    from maskfusion_amd import MaskFusion, synth
+    W, H, f = 320, 240, 264.0
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
+    frames = [st.frame(k) for k in range(18)]
+    icp, so3 = (100.0, False) if variant == "geometric" else (20.0, True)
+
+    def run(graph):
+        mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=icp, so3=so3, enableMultipleModels=False, numGSurfels=1 << 18)
+        mf.setParam("frameGraph", 1 if graph else 0)
+        poses = []
+        for k, (rgb, d, _) in enumerate(frames):
+            if k == 13:
+                mf.setParam("confidenceThreshold", 3.0)
+            mf.processFrame(rgb, d, timestamp=1000 + k, weightMultiplier=2.0 if k >= 10 else 1.0)
+            poses.append(mf.getCurrPose())
+        out = dict(poses=poses, cloud=mf.getBackgroundModel().downloadMap(), log=mf.getPoseLog(0), stats=mf.trackStats(0),
+                   launches=mf.getParam("frameGraphLaunches"), on=mf.getParam("frameGraph"))
+        mf.close()
+        return out
+
+    a, b = run(True), run(False)
+    assert a["on"] == 1 and a["launches"] == len(frames) - 1 and b["launches"] == 0     # every frame but the map initialisation went through a graph
+    for k, (x, y) in enumerate(zip(a["poses"], b["poses"])):
+        assert np.array_equal(x, y), k
+    assert np.array_equal(a["cloud"], b["cloud"], equal_nan=True)
+    assert np.array_equal(a["log"][0], b["log"][0]) and np.array_equal(a["log"][1], b["log"][1])
+    assert a["log"][0].tolist() == [1000 + k for k in range(len(frames))]
+    assert a["stats"] == b["stats"]
+    if variant == "rgbd_so3":
+        assert a["stats"]["lastRGBCount"] > 0 and a["stats"]["so3Iterations"] >= 1
