@@ -627,6 +627,12 @@ def main():
         ks = [order[(cursor[0] + i) % len(order)] for i in range(n)]
         cursor[0] += n
         cls = [0] + [41 + i for i in range(cfg["n_objects"])]
+        for k in ks[:12]:     # untimed: the first calls through this entry point capture their frame graphs (six buffer combinations)
+            if multi:
+                mf.processFrame(frames[k][0], frames[k][1], mask=frames[k][2], classIDs=cls)
+            else:
+                mf.processFrame(frames[k][0], frames[k][1])
+        mf.setParam("hostProfileReset", 1)
         mf.sync()
         t0 = time.perf_counter()
         for k in ks:
@@ -638,6 +644,7 @@ def main():
         mf.sync()
         dt_h = time.perf_counter() - t0
         host_input = {"value": n / dt_h, "unit": "frames/s", "ms_per_step": 1e3 * dt_h / n, "host_ms_per_call": 1e3 * dt_calls / n,
+                      "host_us_inside_the_call": {k: mf.getParam(k) for k in ("hostStageUs", "hostUploadUs", "hostEnqueueUs", "hostCallUs")},
                       "note": f"mf_process_frame with host pointers (pageable numpy arrays): {(7 + (1 if multi else 0)) * P / 1e6:.2f} MB per frame copied into a "
                               "pinned double buffer and uploaded asynchronously under the previous frame's kernels; no synchronisation per frame "
                               "(rounds 1-3: one hipStreamSynchronize per frame)"}

@@ -237,6 +237,7 @@ struct mf_ctx {
     struct FrameGraph { hipGraphExec_t exec = nullptr; unsigned long long key = 0; };
     FrameGraph frame_graphs[12];
     long frame_graph_launches = 0;                     // (debug tap: "frameGraphLaunches")
+    double host_us[4] = {0, 0, 0, 0}; long host_calls = 0;   // mf_process_frame's host time: staging copy | upload enqueue | frame enqueue | whole call ("hostStageUs" ...)
 
     // frame-level
     uint8_t* d_rgb = nullptr; float* d_depth = nullptr; uint8_t* d_mask_in = nullptr; uint8_t* d_zero_mask = nullptr;
@@ -1455,6 +1456,7 @@ extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* dept
         // user sees (MaskFusion.cpp:212-216 uploads FrameData every frame)
         const size_t P = (size_t)c->P;
         const int slot = (int)(c->in_slot++ & 1u);
+        const auto t_0 = std::chrono::steady_clock::now();
         MF_HIP(c, hipEventSynchronize(c->ev_in_copied[slot]));        // the staging slot's previous upload (two frames ago) has left it
         uint8_t* h = c->h_in[slot];
         if (!c->copy_worker) c->copy_worker.reset(new CopyWorker());
@@ -1462,6 +1464,7 @@ extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* dept
         memcpy(h, rgb, P * 3);                                        // ... this one colour and mask (3 P + P)
         if (mask) memcpy(h + P * 7, mask, P);
         c->copy_worker->wait();
+        const auto t_1 = std::chrono::steady_clock::now();
         MF_HIP(c, hipStreamWaitEvent(c->stream_in, c->ev_in_consumed[slot], 0));   // the frame that read these device buffers is done
         MF_HIP(c, hipMemcpyAsync(c->d_in_rgb[slot], h, P * 3, hipMemcpyHostToDevice, c->stream_in));
         MF_HIP(c, hipMemcpyAsync(c->d_in_depth[slot], h + P * 3, P * sizeof(float), hipMemcpyHostToDevice, c->stream_in));
@@ -1469,6 +1472,7 @@ extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* dept
         MF_HIP(c, hipEventRecord(c->ev_in_copied[slot], c->stream_in));
         MF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_in_copied[slot], 0));
         if (c->overlap) MF_HIP(c, hipStreamWaitEvent(c->stream_pre, c->ev_in_copied[slot], 0));
+        const auto t_2 = std::chrono::steady_clock::now();
         // the single-model frame without a supplied pose, nothing being timed or profiled: one graph launch instead of ~34 launches
         const bool graphed = c->frame_graph && c->cfg.enable_multiple_models == 0 && !in_pose16 && c->map_ready && !c->timings_on && !c->icp_prof_on &&
                              !c->splat_prof_on && !c->overlap && !c->gn_loop_graph;
@@ -1476,6 +1480,9 @@ extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* dept
                          : process_frame_impl(c, c->d_in_rgb[slot], c->d_in_depth[slot], mask ? c->d_in_mask[slot] : nullptr, class_ids, n_masks,
                                               weight_multiplier, timestamp, in_pose16, bootstrap != 0);
         (void)hipEventRecord(c->ev_in_consumed[slot], c->stream);     // (also on a failed frame: the slot must become reusable)
+        const auto t_3 = std::chrono::steady_clock::now();
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        c->host_us[0] += us(t_0, t_1); c->host_us[1] += us(t_1, t_2); c->host_us[2] += us(t_2, t_3); c->host_us[3] += us(t_0, t_3); c->host_calls++;
         return rc;
     }
     // blocking form: staged on the input stream (the frame is first read there); the previous frame has completed (this call syncs)
@@ -2351,6 +2358,7 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!c || !key) return MF_EINVAL;
     c->cfg_epoch++;   // captured frames bake configuration values into their launches
     if (!strcmp(key, "frameGraph")) { c->frame_graph = value != 0; return MF_OK; }   // 0: mf_process_frame enqueues its launches one by one
+    if (!strcmp(key, "hostProfileReset")) { c->cfg_epoch--; for (double& v : c->host_us) v = 0; c->host_calls = 0; return MF_OK; }
     if (!strcmp(key, "timings")) { c->timings_on = value != 0; return MF_OK; }
     if (!strcmp(key, "icpProfile")) { c->icp_prof_on = value != 0; return MF_OK; }
     if (!strcmp(key, "hostInputAsync")) {   // 0: mf_process_frame blocks until the frame is fused (rounds 1-3); 1: returns when it is enqueued
@@ -2422,6 +2430,11 @@ extern "C" int mf_get_param(mf_ctx* c, const char* key, double* value) {
     if (!strcmp(key, "gnLoopGraph")) { *value = c->gn_loop_graph ? 1 : 0; return MF_OK; }   // 0 again after a capture that the runtime refused
     if (!strcmp(key, "frameGraph")) { *value = c->frame_graph ? 1 : 0; return MF_OK; }      // 0 again after a capture that the runtime refused
     if (!strcmp(key, "frameGraphLaunches")) { *value = (double)c->frame_graph_launches; return MF_OK; }
+    // mean host microseconds per mf_process_frame call since the context was created: staging copy | upload enqueue | frame enqueue | whole call
+    if (!strcmp(key, "hostStageUs")) { *value = c->host_calls ? c->host_us[0] / c->host_calls : 0; return MF_OK; }
+    if (!strcmp(key, "hostUploadUs")) { *value = c->host_calls ? c->host_us[1] / c->host_calls : 0; return MF_OK; }
+    if (!strcmp(key, "hostEnqueueUs")) { *value = c->host_calls ? c->host_us[2] / c->host_calls : 0; return MF_OK; }
+    if (!strcmp(key, "hostCallUs")) { *value = c->host_calls ? c->host_us[3] / c->host_calls : 0; return MF_OK; }
     if (!strcmp(key, "frameToFrameRGB")) { *value = c->ftf_rgb ? 1 : 0; return MF_OK; }
     if (!strcmp(key, "objectBoundingBoxLimit")) { *value = c->bbox_limit ? 1 : 0; return MF_OK; }
     for (const ParamRef& p : kParams)
