@@ -237,7 +237,8 @@ struct mf_ctx {
     struct FrameGraph { hipGraphExec_t exec = nullptr; unsigned long long key = 0; };
     FrameGraph frame_graphs[12];
     long frame_graph_launches = 0;                     // (debug tap: "frameGraphLaunches")
-    double host_us[4] = {0, 0, 0, 0}; long host_calls = 0;   // mf_process_frame's host time: staging copy | upload enqueue | frame enqueue | whole call ("hostStageUs" ...)
+    double host_us[5] = {0, 0, 0, 0, 0}; long host_calls = 0;   // mf_process_frame's host time: wait for the slot + staging copy | upload enqueue | frame enqueue | whole call | the wait alone ("hostStageUs" ... "hostWaitUs")
+    bool upload_on_main = false;                           // "hostUploadOnMain": the upload on the frame's own stream (no overlap with the previous frame; a measurement switch)
 
     // frame-level
     uint8_t* d_rgb = nullptr; float* d_depth = nullptr; uint8_t* d_mask_in = nullptr; uint8_t* d_zero_mask = nullptr;
@@ -247,7 +248,9 @@ struct mf_ctx {
     // behind mf_process_frame_dev.  Two slots each: frame k+2 reuses what frame k used.
     bool host_async = true;
     hipStream_t stream_in = nullptr;
-    uint8_t* h_in[2] = {nullptr, nullptr};                 // pinned: rgb (3P) | depth (4P) | mask (P)
+    uint8_t* h_in[2] = {nullptr, nullptr};                 // pinned: depth (4P) | rgb (3P) | mask (P), each part 256-B aligned: ONE upload per frame
+    uint8_t* d_in_block[2] = {nullptr, nullptr};           // the same layout in HBM; d_in_* below are views into it
+    size_t in_off_rgb = 0, in_off_mask = 0, in_bytes = 0;
     uint8_t* d_in_rgb[2] = {}; float* d_in_depth[2] = {}; uint8_t* d_in_mask[2] = {};   // slot 0 = d_rgb / d_depth / d_mask_in
     hipEvent_t ev_in_copied[2] = {nullptr, nullptr};       // the slot's H2D copies have completed   (in -> main / pre, and the host before it refills the slot)
     hipEvent_t ev_in_consumed[2] = {nullptr, nullptr};     // the frame that read the slot has been processed   (main -> in)
@@ -506,15 +509,20 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     c->cap_max = cap_bg > cap_obj ? cap_bg : cap_obj;
     int rc = MF_OK;
 #define A(call) do { rc = (call); if (rc != MF_OK) return fail(rc); } while (0)
-    A(dev_alloc(c, c->allocs, &c->d_rgb, (size_t)P * 3));
-    A(dev_alloc(c, c->allocs, &c->d_depth, (size_t)P));
-    A(dev_alloc(c, c->allocs, &c->d_mask_in, (size_t)P));
-    c->d_in_rgb[0] = c->d_rgb; c->d_in_depth[0] = c->d_depth; c->d_in_mask[0] = c->d_mask_in;
-    A(dev_alloc(c, c->allocs, &c->d_in_rgb[1], (size_t)P * 3));
-    A(dev_alloc(c, c->allocs, &c->d_in_depth[1], (size_t)P));
-    A(dev_alloc(c, c->allocs, &c->d_in_mask[1], (size_t)P));
+    // one block per input slot, depth | rgb | mask: a host frame arrives with one copy (mf_process_frame)
+    auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    c->in_off_rgb = up256((size_t)P * sizeof(float));
+    c->in_off_mask = up256(c->in_off_rgb + (size_t)P * 3);
+    c->in_bytes = up256(c->in_off_mask + (size_t)P);
     for (int i = 0; i < 2; ++i) {
-        A(host_alloc(c, &c->h_in[i], (size_t)P * 8));
+        A(dev_alloc(c, c->allocs, &c->d_in_block[i], c->in_bytes));
+        c->d_in_depth[i] = reinterpret_cast<float*>(c->d_in_block[i]);
+        c->d_in_rgb[i] = c->d_in_block[i] + c->in_off_rgb;
+        c->d_in_mask[i] = c->d_in_block[i] + c->in_off_mask;
+    }
+    c->d_rgb = c->d_in_rgb[0]; c->d_depth = c->d_in_depth[0]; c->d_mask_in = c->d_in_mask[0];
+    for (int i = 0; i < 2; ++i) {
+        A(host_alloc(c, &c->h_in[i], c->in_bytes));
         if (hipEventCreateWithFlags(&c->ev_in_copied[i], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_in_consumed[i], hipEventDisableTiming) != hipSuccess) return fail(MF_EHIP);
     }
@@ -1458,19 +1466,19 @@ extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* dept
         const int slot = (int)(c->in_slot++ & 1u);
         const auto t_0 = std::chrono::steady_clock::now();
         MF_HIP(c, hipEventSynchronize(c->ev_in_copied[slot]));        // the staging slot's previous upload (two frames ago) has left it
+        const auto t_w = std::chrono::steady_clock::now();
         uint8_t* h = c->h_in[slot];
         if (!c->copy_worker) c->copy_worker.reset(new CopyWorker());
-        c->copy_worker->post(h + P * 3, depth, P * sizeof(float));   // the helper thread takes the depth plane (4 P bytes) ...
-        memcpy(h, rgb, P * 3);                                        // ... this one colour and mask (3 P + P)
-        if (mask) memcpy(h + P * 7, mask, P);
+        c->copy_worker->post(h, depth, P * sizeof(float));            // the helper thread takes the depth plane (4 P bytes) ...
+        memcpy(h + c->in_off_rgb, rgb, P * 3);                        // ... this one colour and mask (3 P + P)
+        if (mask) memcpy(h + c->in_off_mask, mask, P);
         c->copy_worker->wait();
         const auto t_1 = std::chrono::steady_clock::now();
-        MF_HIP(c, hipStreamWaitEvent(c->stream_in, c->ev_in_consumed[slot], 0));   // the frame that read these device buffers is done
-        MF_HIP(c, hipMemcpyAsync(c->d_in_rgb[slot], h, P * 3, hipMemcpyHostToDevice, c->stream_in));
-        MF_HIP(c, hipMemcpyAsync(c->d_in_depth[slot], h + P * 3, P * sizeof(float), hipMemcpyHostToDevice, c->stream_in));
-        if (mask) MF_HIP(c, hipMemcpyAsync(c->d_in_mask[slot], h + P * 7, P, hipMemcpyHostToDevice, c->stream_in));
-        MF_HIP(c, hipEventRecord(c->ev_in_copied[slot], c->stream_in));
-        MF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_in_copied[slot], 0));
+        hipStream_t sup = c->upload_on_main ? c->stream : c->stream_in;
+        if (!c->upload_on_main) MF_HIP(c, hipStreamWaitEvent(sup, c->ev_in_consumed[slot], 0));   // the frame that read this device block is done
+        MF_HIP(c, hipMemcpyAsync(c->d_in_block[slot], h, mask ? c->in_off_mask + P : c->in_off_rgb + P * 3, hipMemcpyHostToDevice, sup));
+        MF_HIP(c, hipEventRecord(c->ev_in_copied[slot], sup));
+        if (!c->upload_on_main) MF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_in_copied[slot], 0));
         if (c->overlap) MF_HIP(c, hipStreamWaitEvent(c->stream_pre, c->ev_in_copied[slot], 0));
         const auto t_2 = std::chrono::steady_clock::now();
         // the single-model frame without a supplied pose, nothing being timed or profiled: one graph launch instead of ~34 launches
@@ -1482,7 +1490,7 @@ extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* dept
         (void)hipEventRecord(c->ev_in_consumed[slot], c->stream);     // (also on a failed frame: the slot must become reusable)
         const auto t_3 = std::chrono::steady_clock::now();
         auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-        c->host_us[0] += us(t_0, t_1); c->host_us[1] += us(t_1, t_2); c->host_us[2] += us(t_2, t_3); c->host_us[3] += us(t_0, t_3); c->host_calls++;
+        c->host_us[0] += us(t_0, t_1); c->host_us[1] += us(t_1, t_2); c->host_us[2] += us(t_2, t_3); c->host_us[3] += us(t_0, t_3); c->host_us[4] += us(t_0, t_w); c->host_calls++;
         return rc;
     }
     // blocking form: staged on the input stream (the frame is first read there); the previous frame has completed (this call syncs)
@@ -2365,6 +2373,10 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
         if (hipStreamSynchronize(c->stream) != hipSuccess || hipStreamSynchronize(c->stream_in) != hipSuccess) return MF_EHIP;
         c->host_async = value != 0; return MF_OK;
     }
+    if (!strcmp(key, "hostUploadOnMain")) {   // 1: the host frame's upload on the frame's own stream, serial with it (what its overlap is worth)
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipStreamSynchronize(c->stream_in) != hipSuccess) return MF_EHIP;
+        c->upload_on_main = value != 0; return MF_OK;
+    }
     if (!strcmp(key, "splatProfile")) {   // per-tile shader-clock stamps of k_splat_tile (tools/splat_prof.py); debug tap "splat_prof"
         if (value != 0 && !c->d_splat_prof) {
             if (hipMalloc(&c->d_splat_prof, splat_tiles_scratch_ints(c->W, c->H) * 8 * sizeof(unsigned long long)) != hipSuccess) return MF_ENOMEM;
@@ -2435,6 +2447,8 @@ extern "C" int mf_get_param(mf_ctx* c, const char* key, double* value) {
     if (!strcmp(key, "hostUploadUs")) { *value = c->host_calls ? c->host_us[1] / c->host_calls : 0; return MF_OK; }
     if (!strcmp(key, "hostEnqueueUs")) { *value = c->host_calls ? c->host_us[2] / c->host_calls : 0; return MF_OK; }
     if (!strcmp(key, "hostCallUs")) { *value = c->host_calls ? c->host_us[3] / c->host_calls : 0; return MF_OK; }
+    if (!strcmp(key, "hostWaitUs")) { *value = c->host_calls ? c->host_us[4] / c->host_calls : 0; return MF_OK; }
+    if (!strcmp(key, "hostUploadOnMain")) { *value = c->upload_on_main ? 1 : 0; return MF_OK; }
     if (!strcmp(key, "frameToFrameRGB")) { *value = c->ftf_rgb ? 1 : 0; return MF_OK; }
     if (!strcmp(key, "objectBoundingBoxLimit")) { *value = c->bbox_limit ? 1 : 0; return MF_OK; }
     for (const ParamRef& p : kParams)
