@@ -439,6 +439,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host-input", action="store_true")
+    ap.add_argument("--host-input-frames", type=int, default=150, help="frames of the host-pointer side measurement (host_input)")
     ap.add_argument("--no-variants", action="store_true", help="skip the reference-default (icpWeight 20 + SO(3)) side measurement of config 1")
     ap.add_argument("--force-sharded-scene", action="store_true", help="run that part at N = 1 as well (rehearsal of the N > 1 code path on one GPU)")
     ap.add_argument("--no-sharded-scene", action="store_true", help="N > 1: skip the model-sharded 8-object scene that is timed beside the weak-scaling line")
@@ -623,7 +624,7 @@ def main():
     host_input = None
     if rank == 0 and world == 1 and not args.no_host_input:
         # the reference's own boundary: FrameData in host memory (MaskFusion.cpp:212-216 uploads it every frame)
-        n = 150
+        n = args.host_input_frames
         ks = [order[(cursor[0] + i) % len(order)] for i in range(n)]
         cursor[0] += n
         cls = [0] + [41 + i for i in range(cfg["n_objects"])]

@@ -238,6 +238,8 @@ struct mf_ctx {
     FrameGraph frame_graphs[12];
     long frame_graph_launches = 0;                     // (debug tap: "frameGraphLaunches")
     double host_us[5] = {0, 0, 0, 0, 0}; long host_calls = 0;   // mf_process_frame's host time: wait for the slot + staging copy | upload enqueue | frame enqueue | whole call | the wait alone ("hostStageUs" ... "hostWaitUs")
+    hipEvent_t ev_tracked = nullptr;                       // the frame's tracking has run (recorded by every frame that tracks)
+    bool upload_after_tracking = false;                    // "hostUploadAfterTracking": frame k+1's upload starts when frame k has tracked (under its surfel passes, not under its launch chain)
     bool upload_on_main = false;                           // "hostUploadOnMain": the upload on the frame's own stream (no overlap with the previous frame; a measurement switch)
 
     // frame-level
@@ -527,6 +529,7 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
             hipEventCreateWithFlags(&c->ev_in_consumed[i], hipEventDisableTiming) != hipSuccess) return fail(MF_EHIP);
     }
     if (hipStreamCreateWithFlags(&c->stream_in, hipStreamNonBlocking) != hipSuccess) return fail(MF_EHIP);
+    if (hipEventCreateWithFlags(&c->ev_tracked, hipEventDisableTiming) != hipSuccess) return fail(MF_EHIP);
     A(dev_alloc(c, c->allocs, &c->d_zero_mask, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_mask_tex, (size_t)P));
     for (int b = 0; b < 3; ++b) A(dev_alloc(c, c->allocs, &c->d_depthF[b], (size_t)P));
@@ -643,6 +646,7 @@ extern "C" void mf_destroy(mf_ctx* c) {
     for (int i = 0; i < 2; ++i) {
         if (c->ev_in_copied[i]) (void)hipEventDestroy(c->ev_in_copied[i]);
         if (c->ev_in_consumed[i]) (void)hipEventDestroy(c->ev_in_consumed[i]);
+        if (i == 0 && c->ev_tracked) (void)hipEventDestroy(c->ev_tracked);
     }
     if (c->stream_in) { (void)hipStreamSynchronize(c->stream_in); (void)hipStreamDestroy(c->stream_in); }
     for (int i = 0; i < mf_ctx::kObjArgSlots; ++i) {
@@ -1226,6 +1230,8 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
         enqueue_tracking_loop(c, 0, g.track_all_models != 0, depthF_prev, k);
         if (bootstrap && in_pose16) launch_override_pose(bg.d_pose, in_pose16, 1, bg.h_pose, s);   // :280-283 (after the object loop)
         mark(c, 3);
+        // the next host frame's upload may be told to start here (mf_process_frame); inside a captured frame the record is an external event node
+        if (c->upload_after_tracking) (void)hipEventRecordWithFlags(c->ev_tracked, s, c->capturing_frame ? hipEventRecordExternal : 0);
         if (c->overlap) { MF_HIP(c, hipEventRecord(c->ev_main_done[set], s)); main_done_recorded = true; }
 
         if (multi) {
@@ -1476,6 +1482,9 @@ extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* dept
         const auto t_1 = std::chrono::steady_clock::now();
         hipStream_t sup = c->upload_on_main ? c->stream : c->stream_in;
         if (!c->upload_on_main) MF_HIP(c, hipStreamWaitEvent(sup, c->ev_in_consumed[slot], 0));   // the frame that read this device block is done
+        // (a scheduling hint on top of that: the previous frame has tracked -- the 49 us of PCIe traffic land under its few long surfel passes
+        // instead of under its chain of ~25 dependent launches, whose packets and arguments cross the same link)
+        if (!c->upload_on_main && c->upload_after_tracking) MF_HIP(c, hipStreamWaitEvent(sup, c->ev_tracked, 0));
         MF_HIP(c, hipMemcpyAsync(c->d_in_block[slot], h, mask ? c->in_off_mask + P : c->in_off_rgb + P * 3, hipMemcpyHostToDevice, sup));
         MF_HIP(c, hipEventRecord(c->ev_in_copied[slot], sup));
         if (!c->upload_on_main) MF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_in_copied[slot], 0));
@@ -2373,6 +2382,7 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
         if (hipStreamSynchronize(c->stream) != hipSuccess || hipStreamSynchronize(c->stream_in) != hipSuccess) return MF_EHIP;
         c->host_async = value != 0; return MF_OK;
     }
+    if (!strcmp(key, "hostUploadAfterTracking")) { c->upload_after_tracking = value != 0; return MF_OK; }
     if (!strcmp(key, "hostUploadOnMain")) {   // 1: the host frame's upload on the frame's own stream, serial with it (what its overlap is worth)
         if (hipStreamSynchronize(c->stream) != hipSuccess || hipStreamSynchronize(c->stream_in) != hipSuccess) return MF_EHIP;
         c->upload_on_main = value != 0; return MF_OK;
@@ -2449,6 +2459,7 @@ extern "C" int mf_get_param(mf_ctx* c, const char* key, double* value) {
     if (!strcmp(key, "hostCallUs")) { *value = c->host_calls ? c->host_us[3] / c->host_calls : 0; return MF_OK; }
     if (!strcmp(key, "hostWaitUs")) { *value = c->host_calls ? c->host_us[4] / c->host_calls : 0; return MF_OK; }
     if (!strcmp(key, "hostUploadOnMain")) { *value = c->upload_on_main ? 1 : 0; return MF_OK; }
+    if (!strcmp(key, "hostUploadAfterTracking")) { *value = c->upload_after_tracking ? 1 : 0; return MF_OK; }
     if (!strcmp(key, "frameToFrameRGB")) { *value = c->ftf_rgb ? 1 : 0; return MF_OK; }
     if (!strcmp(key, "objectBoundingBoxLimit")) { *value = c->bbox_limit ? 1 : 0; return MF_OK; }
     for (const ParamRef& p : kParams)

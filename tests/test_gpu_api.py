@@ -140,10 +140,11 @@ def test_asynchronous_host_frames_equal_the_blocking_form(hip, multi):
     W, H, f = 320, 240, 264.0
     st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True, n_objects=2 if multi else 0, object_motion=0.0)
 
-    def run(asynchronous, upload_on_main=False):
+    def run(asynchronous, upload_on_main=False, after_tracking=False):
         mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=multi, numGSurfels=1 << 18, numOSurfels=1 << 16,
                         modelSpawnOffset=2, trackAllModels=False)
         mf.setParam("hostUploadOnMain", 1 if upload_on_main else 0)      # the measurement switch: the one packed upload serial with its frame
+        mf.setParam("hostUploadAfterTracking", 1 if after_tracking else 0)   # the upload of frame k+1 held back until frame k has tracked
         if multi:
             for k, v in (("mfThreshold", 0.3), ("mfWeightDistance", 150.0), ("mfWeightConvexity", 2.8), ("mfMorphEdgeIterations", 0),
                          ("mfMorphMaskIterations", 0), ("newModelMinRelativeSize", 0.004)):
@@ -168,7 +169,7 @@ def test_asynchronous_host_frames_equal_the_blocking_form(hip, multi):
         return out
 
     b = run(False)
-    for a in (run(True), run(True, upload_on_main=True)):
+    for a in (run(True), run(True, upload_on_main=True), run(True, after_tracking=True)):
         assert a["ids"] == b["ids"] and a["counts"] == b["counts"]
         assert len(a["ids"]) == (3 if multi else 1)
         for x, y in zip(a["poses"] + a["final"], b["poses"] + b["final"]):

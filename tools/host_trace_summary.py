@@ -94,6 +94,27 @@ def main():
                        "running_under_kernels_frac": overlapped / len(ups) if ups else None,
                        "kernels_they_ran_under": dict(under.most_common(8))},
            "copy_directions_seen": dict(collections.Counter(c[2] for c in copies))}
+    # wall-clock of the host section as the timeline sees it, and where in a frame its upload starts / ends
+    first, last = starts[n - n_host], starts[n]
+    out["host_input"]["span_us_per_frame"] = (kern[last][0] - kern[first][0]) / n_host / 1e3
+    rel = []
+    fs = [kern[s][0] for s in starts]
+    import bisect
+    for s, e, _, _ in ups:
+        i = bisect.bisect_right(fs, s) - 1
+        rel.append(((s - fs[i]) / 1e3, (e - fs[i]) / 1e3))
+    if rel:
+        rel.sort()
+        out["uploads"]["start_us_into_the_frame_it_runs_under"] = {"p10": rel[len(rel) // 10][0], "median": rel[len(rel) // 2][0], "p90": rel[9 * len(rel) // 10][0]}
+    if len(sys.argv) > 3:     # merged timeline of six frames in the middle of the host section
+        a, b = starts[n - n_host // 2], starts[n - n_host // 2 + 6]
+        t_a, t_b = kern[a][0], kern[b][0]
+        ev = [(s, e, nme, "q" + str(q)) for s, e, nme, q in kern[a:b]] + [(s, e, "UPLOAD", "copy") for s, e, _, _ in ups if t_a <= s < t_b]
+        ev.sort()
+        with open(sys.argv[3], "w") as f:
+            f.write("start_us,end_us,dur_us,what,where\n")
+            for s, e, nme, q in ev:
+                f.write(f"{(s - t_a) / 1e3:.2f},{(e - t_a) / 1e3:.2f},{(e - s) / 1e3:.2f},{nme},{q}\n")
     json.dump(out, sys.stdout, indent=1)
     print()
 
