@@ -225,13 +225,14 @@ struct mf_ctx {
     unsigned obj_arg_slot = 0;
     bool ftf_rgb = false;                              // MaskFusion::frameToFrameRGB ("-ftf"; Model.cpp:399-400,981): the photometric term tracks against the previous RAW frame
     bool gn_loop_graph = false;                        // the launch-per-iteration loop replayed as a captured hipGraph ("gnLoopGraph")
-    // "frameGraph": the WHOLE single-model frame of mf_process_frame (host pointers) as one captured hipGraph per buffer combination -- input
-    // slot x map parity x filtered-depth ring slot = 12 -- replayed with one hipGraphLaunch.  The frame's ~34 launches cost the host more
-    // than the GPU needs to run them (profiles/r04g_bench_async.json: 0.42 ms of host time per call against 0.33 ms of GPU work); the launch-
-    // bound part of the path is exactly what hipGraphs are for.  Only arguments that are constant for a combination are baked in (a key of
-    // the weight multiplier and a configuration epoch re-captures when they change); the pose-log entry, whose slot moves every frame, is
-    // one small launch behind the graph.
-    bool frame_graph = true;
+    // "frameGraph" (a switch, default off): the WHOLE single-model frame of mf_process_frame (host pointers) as one captured hipGraph per
+    // buffer combination -- input slot x map parity x filtered-depth ring slot = 12 -- replayed with one hipGraphLaunch.  It takes the host's
+    // share of a call from 89 to 15 us (profiles/r04i_*), bit-identical results (tests/test_gpu_api.py), but the GPU needs ~9 us MORE per
+    // frame than for the 34 eager launches (profiles/r04o_host_ab.json: 333 against 324 us per frame; the pose-log entry, whose slot moves
+    // every frame, is a launch of its own behind the graph) and the call is paced by the GPU either way -- so eager launches are the default
+    // and the graph is there for a caller that wants its host thread back.  Only arguments that are constant for a combination are baked in
+    // (a key of the weight multiplier and a configuration epoch re-captures when they change).
+    bool frame_graph = false;
     bool capturing_frame = false;                      // inside the capture: no pose-log slot, no time stamp (the caller adds them behind the graph)
     unsigned long long cfg_epoch = 1;                  // bumped by every mf_set_param / lifecycle call: whatever a graph baked in may have changed
     struct FrameGraph { hipGraphExec_t exec = nullptr; unsigned long long key = 0; };
@@ -240,6 +241,12 @@ struct mf_ctx {
     double host_us[5] = {0, 0, 0, 0, 0}; long host_calls = 0;   // mf_process_frame's host time: wait for the slot + staging copy | upload enqueue | frame enqueue | whole call | the wait alone ("hostStageUs" ... "hostWaitUs")
     hipEvent_t ev_tracked = nullptr;                       // the frame's tracking has run (recorded by every frame that tracks)
     bool upload_after_tracking = false;                    // "hostUploadAfterTracking": frame k+1's upload starts when frame k has tracked (under its surfel passes, not under its launch chain)
+    // "hostLockstep" (default on): the call waits for frame k-2 to have RUN before it enqueues frame k's upload, so the host is at most two
+    // frames ahead and the upload's dependency (the frame that last read the device block) is already satisfied when it is enqueued.  Left
+    // to run three frames ahead, every frame pays ~40 us for cross-queue dependencies that are still open at enqueue time
+    // (profiles/r04o_host_ab.json: 364 -> 333 us per frame with the frame graph, 352 -> 324 us with eager launches; device-resident: 305)
+    bool host_lockstep = true;
+    bool upload_kernel = false;                            // "hostUploadKernel": a copy kernel reading the pinned block over PCIe instead of the DMA engine
     bool upload_on_main = false;                           // "hostUploadOnMain": the upload on the frame's own stream (no overlap with the previous frame; a measurement switch)
 
     // frame-level
@@ -1230,8 +1237,9 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
         enqueue_tracking_loop(c, 0, g.track_all_models != 0, depthF_prev, k);
         if (bootstrap && in_pose16) launch_override_pose(bg.d_pose, in_pose16, 1, bg.h_pose, s);   // :280-283 (after the object loop)
         mark(c, 3);
-        // the next host frame's upload may be told to start here (mf_process_frame); inside a captured frame the record is an external event node
-        if (c->upload_after_tracking) (void)hipEventRecordWithFlags(c->ev_tracked, s, c->capturing_frame ? hipEventRecordExternal : 0);
+        // the next host frame's upload may be told to start here (mf_process_frame).  Eager launches only: an external event record inside the
+        // captured frame (hipEventRecordWithFlags(.., hipEventRecordExternal)) is refused by this runtime with hipErrorInvalidValue (r04n)
+        if (c->upload_after_tracking && !c->capturing_frame) (void)hipEventRecord(c->ev_tracked, s);
         if (c->overlap) { MF_HIP(c, hipEventRecord(c->ev_main_done[set], s)); main_done_recorded = true; }
 
         if (multi) {
@@ -1461,6 +1469,11 @@ static int process_frame_graphed(mf_ctx* c, int slot, float weight_multiplier, i
     return check_launch(c);
 }
 
+// measurement switch "hostUploadKernel": the packed host block fetched by a few workgroups instead of the DMA engine (16 B per lane and step)
+static __global__ void __launch_bounds__(256) k_upload_block(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* depth, const uint8_t* mask, const int32_t* class_ids,
                                 int32_t n_masks, int64_t timestamp, const float* in_pose16, float weight_multiplier, int32_t bootstrap) {
     if (!c || !rgb || !depth) return MF_EINVAL;
@@ -1481,17 +1494,23 @@ extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* dept
         c->copy_worker->wait();
         const auto t_1 = std::chrono::steady_clock::now();
         hipStream_t sup = c->upload_on_main ? c->stream : c->stream_in;
+        if (c->host_lockstep) MF_HIP(c, hipEventSynchronize(c->ev_in_consumed[slot]));   // (frame k-2 has run: at most two frames are queued)
         if (!c->upload_on_main) MF_HIP(c, hipStreamWaitEvent(sup, c->ev_in_consumed[slot], 0));   // the frame that read this device block is done
         // (a scheduling hint on top of that: the previous frame has tracked -- the 49 us of PCIe traffic land under its few long surfel passes
         // instead of under its chain of ~25 dependent launches, whose packets and arguments cross the same link)
         if (!c->upload_on_main && c->upload_after_tracking) MF_HIP(c, hipStreamWaitEvent(sup, c->ev_tracked, 0));
-        MF_HIP(c, hipMemcpyAsync(c->d_in_block[slot], h, mask ? c->in_off_mask + P : c->in_off_rgb + P * 3, hipMemcpyHostToDevice, sup));
+        const size_t up_bytes = mask ? c->in_off_mask + P : c->in_off_rgb + P * 3;
+        if (c->upload_kernel)
+            hipLaunchKernelGGL(k_upload_block, dim3(32), dim3(256), 0, sup, reinterpret_cast<const uint4*>(h), reinterpret_cast<uint4*>(c->d_in_block[slot]),
+                               (up_bytes + 15) / 16);
+        else
+            MF_HIP(c, hipMemcpyAsync(c->d_in_block[slot], h, up_bytes, hipMemcpyHostToDevice, sup));
         MF_HIP(c, hipEventRecord(c->ev_in_copied[slot], sup));
         if (!c->upload_on_main) MF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_in_copied[slot], 0));
         if (c->overlap) MF_HIP(c, hipStreamWaitEvent(c->stream_pre, c->ev_in_copied[slot], 0));
         const auto t_2 = std::chrono::steady_clock::now();
         // the single-model frame without a supplied pose, nothing being timed or profiled: one graph launch instead of ~34 launches
-        const bool graphed = c->frame_graph && c->cfg.enable_multiple_models == 0 && !in_pose16 && c->map_ready && !c->timings_on && !c->icp_prof_on &&
+        const bool graphed = c->frame_graph && !c->upload_after_tracking && c->cfg.enable_multiple_models == 0 && !in_pose16 && c->map_ready && !c->timings_on && !c->icp_prof_on &&
                              !c->splat_prof_on && !c->overlap && !c->gn_loop_graph;
         int rc = graphed ? process_frame_graphed(c, slot, weight_multiplier, timestamp)
                          : process_frame_impl(c, c->d_in_rgb[slot], c->d_in_depth[slot], mask ? c->d_in_mask[slot] : nullptr, class_ids, n_masks,
@@ -2383,6 +2402,11 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
         c->host_async = value != 0; return MF_OK;
     }
     if (!strcmp(key, "hostUploadAfterTracking")) { c->upload_after_tracking = value != 0; return MF_OK; }
+    if (!strcmp(key, "hostLockstep")) { c->host_lockstep = value != 0; return MF_OK; }
+    if (!strcmp(key, "hostUploadKernel")) {
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipStreamSynchronize(c->stream_in) != hipSuccess) return MF_EHIP;
+        c->upload_kernel = value != 0; return MF_OK;
+    }
     if (!strcmp(key, "hostUploadOnMain")) {   // 1: the host frame's upload on the frame's own stream, serial with it (what its overlap is worth)
         if (hipStreamSynchronize(c->stream) != hipSuccess || hipStreamSynchronize(c->stream_in) != hipSuccess) return MF_EHIP;
         c->upload_on_main = value != 0; return MF_OK;

@@ -140,11 +140,13 @@ def test_asynchronous_host_frames_equal_the_blocking_form(hip, multi):
     W, H, f = 320, 240, 264.0
     st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True, n_objects=2 if multi else 0, object_motion=0.0)
 
-    def run(asynchronous, upload_on_main=False, after_tracking=False):
+    def run(asynchronous, upload_on_main=False, after_tracking=False, lockstep=False, upload_kernel=False):
         mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=multi, numGSurfels=1 << 18, numOSurfels=1 << 16,
                         modelSpawnOffset=2, trackAllModels=False)
         mf.setParam("hostUploadOnMain", 1 if upload_on_main else 0)      # the measurement switch: the one packed upload serial with its frame
         mf.setParam("hostUploadAfterTracking", 1 if after_tracking else 0)   # the upload of frame k+1 held back until frame k has tracked
+        mf.setParam("hostLockstep", 1 if lockstep else 0)                # the call waits for frame k-2 before it enqueues frame k's upload
+        mf.setParam("hostUploadKernel", 1 if upload_kernel else 0)       # a copy kernel instead of the DMA engine
         if multi:
             for k, v in (("mfThreshold", 0.3), ("mfWeightDistance", 150.0), ("mfWeightConvexity", 2.8), ("mfMorphEdgeIterations", 0),
                          ("mfMorphMaskIterations", 0), ("newModelMinRelativeSize", 0.004)):
@@ -169,7 +171,7 @@ def test_asynchronous_host_frames_equal_the_blocking_form(hip, multi):
         return out
 
     b = run(False)
-    for a in (run(True), run(True, upload_on_main=True), run(True, after_tracking=True)):
+    for a in (run(True), run(True, upload_on_main=True), run(True, after_tracking=True), run(True, lockstep=True), run(True, upload_kernel=True)):
         assert a["ids"] == b["ids"] and a["counts"] == b["counts"]
         assert len(a["ids"]) == (3 if multi else 1)
         for x, y in zip(a["poses"] + a["final"], b["poses"] + b["final"]):
@@ -182,7 +184,7 @@ def test_asynchronous_host_frames_equal_the_blocking_form(hip, multi):
 
 @pytest.mark.parametrize("variant", ["geometric", "rgbd_so3"])
 def test_frame_graph_equals_eager_launches(hip, variant):
-    """`frameGraph` (default on): the whole single-model frame of mf_process_frame replayed as one captured hipGraph per buffer combination
+    """`frameGraph` (a switch; default off since r04o measured eager launches 9 us per frame faster on the GPU): the whole single-model frame of mf_process_frame replayed as one captured hipGraph per buffer combination
     (input slot x map parity x filtered-depth ring slot).  Against `frameGraph = 0` (every launch enqueued on its own): poses on every frame,
     the final cloud, the pose log and the tracking statistics bit-identical -- through the six captures of the first frames, their replays, a
     change of the weight multiplier (a new key: re-capture) and a parameter change (configuration epoch)."""
