@@ -78,8 +78,9 @@ const char* mf_last_error(const mf_ctx* ctx);
 
 /* MaskFusion::processFrame (Core/MaskFusion.h:69-70, Core/MaskFusion.cpp:200-607).
  * mask/class_ids may be NULL (n_masks = 0); in_pose16 may be NULL.  The caller's buffers are copied into pinned staging memory before
- * the call returns (they may be reused at once); the upload and the frame itself are ENQUEUED -- the call does not wait for the GPU
- * (a multi-model frame waits once, for the label stage's decision).  Every getter below synchronises first, so
+ * the call returns (they may be reused at once); the upload and the frame itself are ENQUEUED -- the call does not wait for THIS frame
+ * (it keeps the host at most two frames ahead: it waits for frame k-2 before enqueueing frame k's upload; a multi-model frame also
+ * waits once for the label stage's decision).  Every getter below synchronises first, so
  * processFrame(...); getCurrPose() reads this frame's pose as upstream; mf_sync() waits explicitly.
  * mf_set_param("hostInputAsync", 0) restores the blocking form of rounds 1-3 ("blocks until the frame is fused"). */
 int mf_process_frame(mf_ctx* ctx, const uint8_t* rgb, const float* depth, const uint8_t* mask,
