@@ -647,7 +647,8 @@ def main():
         host_input = {"value": n / dt_h, "unit": "frames/s", "ms_per_step": 1e3 * dt_h / n, "host_ms_per_call": 1e3 * dt_calls / n,
                       "host_us_inside_the_call": {k: mf.getParam(k) for k in ("hostWaitUs", "hostStageUs", "hostUploadUs", "hostEnqueueUs", "hostCallUs")},
                       "note": f"mf_process_frame with host pointers (pageable numpy arrays): {(7 + (1 if multi else 0)) * P / 1e6:.2f} MB per frame copied into a "
-                              "pinned double buffer and uploaded asynchronously (one packed copy) under the previous frame's kernels; no synchronisation per frame "
+                              "pinned double buffer and uploaded asynchronously (one packed copy) under the previous frame's kernels; no synchronisation per frame, "
+                              "the host kept at most two frames ahead (hostLockstep: its wait is inside hostUploadUs) "
                               "(rounds 1-3: one hipStreamSynchronize per frame)"}
 
     cpu = None

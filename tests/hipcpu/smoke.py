@@ -225,4 +225,7 @@ def static_switches(n=9, W=240, H=160):
 
 
 if __name__ == "__main__":
-    print(json.dumps(dict(single=single_model(), rgbd=rgbd_so3(), bad_depth=bad_depth_pixels(), schedule=schedule_switches(), mm_bad_depth=multimodel_bad_depth(), weight=weight_multiplier_cases(), dev_masks=device_resident_masks(), static=static_switches())))
+    scenarios = dict(single=single_model, rgbd=rgbd_so3, bad_depth=bad_depth_pixels, schedule=schedule_switches, mm_bad_depth=multimodel_bad_depth,
+                     weight=weight_multiplier_cases, dev_masks=device_resident_masks, static=static_switches)
+    wanted = sys.argv[1:] or list(scenarios)      # (tests/test_gpu_emu_agrees.py asks for "single" only; the CPU suite runs all of them)
+    print(json.dumps({k: scenarios[k]() for k in wanted}))

@@ -20,7 +20,7 @@ def test_cpu_executed_kernels_agree_with_the_hardware(hip):
     from maskfusion_amd import MaskFusion, synth
     env = dict(os.environ)
     env.pop("MF_EMU", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipcpu", "smoke.py")], capture_output=True, text=True, timeout=1100, env=env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipcpu", "smoke.py"), "single"], capture_output=True, text=True, timeout=1100, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     emu = json.loads(r.stdout.strip().splitlines()[-1])["single"]
     W, H = 160, 120
