@@ -1,0 +1,42 @@
+"""Measurement tooling that is not exercised by bench.py itself: known-answer checks, CPU only."""
+import csv
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_host_trace_summary_on_a_fabricated_timeline(tmp_path):
+    """tools/host_trace_summary.py (the timeline summary behind DESIGN.md section 5, host-pointer path): a fabricated rocprofv3 trace --
+    240 device-resident frames of three kernels, then 160 host frames whose ICP kernel is 2 us longer, with a 5 us bubble and one 50 us
+    upload per frame starting 20 us into the frame -- must come back with exactly those figures."""
+    kernels = [("void mf::k_bilateral(float const*)", 16000), ("void mf::k_icp_iter<512, 3>(mf::IcpKArgs)", 8000), ("mf::k_clean_flags(mf::CleanArgs)", 24000)]
+    t, krows, crows = 1_000_000, [], []
+    for f in range(400):
+        host = f >= 240
+        if host:
+            crows.append({"Kind": "MEMORY_COPY", "Direction": "MEMORY_COPY_HOST_TO_DEVICE", "Start_Timestamp": t + 20000, "End_Timestamp": t + 70000})
+        for i, (name, dur) in enumerate(kernels):
+            d = dur + (2000 if host and "icp" in name else 0)
+            krows.append({"Kind": "KERNEL_DISPATCH", "Queue_Id": 1, "Kernel_Name": name, "Start_Timestamp": t, "End_Timestamp": t + d})
+            t += d + (5000 if host and i == len(kernels) - 1 else 0)
+    for name, rows in (("x_kernel_trace.csv", krows), ("x_memory_copy_trace.csv", crows)):
+        with open(tmp_path / name, "w", newline="") as fh:
+            w = csv.DictWriter(fh, fieldnames=list(rows[0]))
+            w.writeheader()
+            w.writerows(rows)
+    tl = tmp_path / "timeline.csv"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_trace_summary.py"), str(tmp_path), "150", str(tl)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    dev, host = out["device_resident"], out["host_input"]
+    assert dev["period_us_median"] == 48.0 and dev["gap_to_next_frame_us_median"] == 0.0 and dev["launches_per_frame"] == 3.0
+    assert host["period_us_median"] == 55.0 and host["gap_to_next_frame_us_median"] == 5.0 and abs(host["kernel_busy_us_mean"] - 50.0) < 1e-9
+    assert out["delta_us"]["k_icp_iter<512, 3>"] == 2.0 and out["delta_us"]["k_bilateral"] == 0.0
+    up = out["uploads"]
+    assert abs(up["per_frame"] - 1.0) < 0.01 and up["us_mean"] == 50.0 and up["running_under_kernels_frac"] == 1.0
+    assert up["start_us_into_the_frame_it_runs_under"]["median"] == 20.0
+    lines = tl.read_text().splitlines()
+    assert lines[0] == "start_us,end_us,dur_us,what,where" and sum("UPLOAD" in ln for ln in lines) == 6
