@@ -246,6 +246,11 @@ struct mf_ctx {
     // to run three frames ahead, every frame pays ~40 us for cross-queue dependencies that are still open at enqueue time
     // (profiles/r04o_host_ab.json: 364 -> 333 us per frame with the frame graph, 352 -> 324 us with eager launches; device-resident: 305)
     bool host_lockstep = true;
+    bool copy_helper = true;                               // "hostCopyHelper": 0 = the calling thread stages the whole frame itself
+    // "hostWaitUpload" (default on, needs hostLockstep): the call also waits for its OWN upload (~60 us of the ~300 the host has to spare per
+    // frame) before it enqueues the frame, which then needs no cross-queue wait at all: 322 -> 317 us per frame (profiles/r04q_host_ab.json;
+    // device-resident frames: 305).  The staging helper thread makes no difference any more (322.2 against 322.1): staging is off the critical path.
+    bool host_wait_upload = true;
     bool upload_kernel = false;                            // "hostUploadKernel": a copy kernel reading the pinned block over PCIe instead of the DMA engine
     bool upload_on_main = false;                           // "hostUploadOnMain": the upload on the frame's own stream (no overlap with the previous frame; a measurement switch)
 
@@ -1487,11 +1492,15 @@ extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* dept
         MF_HIP(c, hipEventSynchronize(c->ev_in_copied[slot]));        // the staging slot's previous upload (two frames ago) has left it
         const auto t_w = std::chrono::steady_clock::now();
         uint8_t* h = c->h_in[slot];
-        if (!c->copy_worker) c->copy_worker.reset(new CopyWorker());
-        c->copy_worker->post(h, depth, P * sizeof(float));            // the helper thread takes the depth plane (4 P bytes) ...
+        if (c->copy_helper) {
+            if (!c->copy_worker) c->copy_worker.reset(new CopyWorker());
+            c->copy_worker->post(h, depth, P * sizeof(float));        // the helper thread takes the depth plane (4 P bytes) ...
+        } else {
+            memcpy(h, depth, P * sizeof(float));
+        }
         memcpy(h + c->in_off_rgb, rgb, P * 3);                        // ... this one colour and mask (3 P + P)
         if (mask) memcpy(h + c->in_off_mask, mask, P);
-        c->copy_worker->wait();
+        if (c->copy_helper) c->copy_worker->wait();
         const auto t_1 = std::chrono::steady_clock::now();
         hipStream_t sup = c->upload_on_main ? c->stream : c->stream_in;
         if (c->host_lockstep) MF_HIP(c, hipEventSynchronize(c->ev_in_consumed[slot]));   // (frame k-2 has run: at most two frames are queued)
@@ -1506,7 +1515,10 @@ extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* dept
         else
             MF_HIP(c, hipMemcpyAsync(c->d_in_block[slot], h, up_bytes, hipMemcpyHostToDevice, sup));
         MF_HIP(c, hipEventRecord(c->ev_in_copied[slot], sup));
-        if (!c->upload_on_main) MF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_in_copied[slot], 0));
+        if (!c->upload_on_main) {
+            if (c->host_wait_upload && c->host_lockstep) MF_HIP(c, hipEventSynchronize(c->ev_in_copied[slot]));   // (~60 us of the ~300 the host has to spare per frame)
+            else MF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_in_copied[slot], 0));
+        }
         if (c->overlap) MF_HIP(c, hipStreamWaitEvent(c->stream_pre, c->ev_in_copied[slot], 0));
         const auto t_2 = std::chrono::steady_clock::now();
         // the single-model frame without a supplied pose, nothing being timed or profiled: one graph launch instead of ~34 launches
@@ -2403,6 +2415,8 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     }
     if (!strcmp(key, "hostUploadAfterTracking")) { c->upload_after_tracking = value != 0; return MF_OK; }
     if (!strcmp(key, "hostLockstep")) { c->host_lockstep = value != 0; return MF_OK; }
+    if (!strcmp(key, "hostWaitUpload")) { c->host_wait_upload = value != 0; return MF_OK; }
+    if (!strcmp(key, "hostCopyHelper")) { c->copy_helper = value != 0; return MF_OK; }
     if (!strcmp(key, "hostUploadKernel")) {
         if (hipStreamSynchronize(c->stream) != hipSuccess || hipStreamSynchronize(c->stream_in) != hipSuccess) return MF_EHIP;
         c->upload_kernel = value != 0; return MF_OK;

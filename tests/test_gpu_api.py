@@ -140,13 +140,15 @@ def test_asynchronous_host_frames_equal_the_blocking_form(hip, multi):
     W, H, f = 320, 240, 264.0
     st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True, n_objects=2 if multi else 0, object_motion=0.0)
 
-    def run(asynchronous, upload_on_main=False, after_tracking=False, lockstep=False, upload_kernel=False):
+    def run(asynchronous, upload_on_main=False, after_tracking=False, lockstep=True, upload_kernel=False, wait_upload=True, helper=True):
         mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=multi, numGSurfels=1 << 18, numOSurfels=1 << 16,
                         modelSpawnOffset=2, trackAllModels=False)
         mf.setParam("hostUploadOnMain", 1 if upload_on_main else 0)      # the measurement switch: the one packed upload serial with its frame
         mf.setParam("hostUploadAfterTracking", 1 if after_tracking else 0)   # the upload of frame k+1 held back until frame k has tracked
         mf.setParam("hostLockstep", 1 if lockstep else 0)                # the call waits for frame k-2 before it enqueues frame k's upload
         mf.setParam("hostUploadKernel", 1 if upload_kernel else 0)       # a copy kernel instead of the DMA engine
+        mf.setParam("hostWaitUpload", 1 if wait_upload else 0)           # the call waits for its own upload: no cross-queue wait for the frame
+        mf.setParam("hostCopyHelper", 1 if helper else 0)                # the staging copy shared with a helper thread
         if multi:
             for k, v in (("mfThreshold", 0.3), ("mfWeightDistance", 150.0), ("mfWeightConvexity", 2.8), ("mfMorphEdgeIterations", 0),
                          ("mfMorphMaskIterations", 0), ("newModelMinRelativeSize", 0.004)):
@@ -171,7 +173,8 @@ def test_asynchronous_host_frames_equal_the_blocking_form(hip, multi):
         return out
 
     b = run(False)
-    for a in (run(True), run(True, upload_on_main=True), run(True, after_tracking=True), run(True, lockstep=True), run(True, upload_kernel=True)):
+    for a in (run(True), run(True, upload_on_main=True), run(True, after_tracking=True), run(True, lockstep=False), run(True, upload_kernel=True),
+              run(True, wait_upload=False), run(True, helper=False)):
         assert a["ids"] == b["ids"] and a["counts"] == b["counts"]
         assert len(a["ids"]) == (3 if multi else 1)
         for x, y in zip(a["poses"] + a["final"], b["poses"] + b["final"]):

@@ -55,11 +55,12 @@ def stages(kind, n=120):
 burst("host", 400)        # the map near its natural size
 mf.sync()
 out = {"us_per_frame": [], "stage_us_last_frame_of_a_burst": []}
-modes = [("device", {}), ("host", {}), ("host", {"hostLockstep": 1}), ("host", {"frameGraph": 0, "hostLockstep": 1}), ("host", {"hostUploadKernel": 1}),
-         ("host", {"hostUploadKernel": 1, "hostLockstep": 1}), ("host", {"frameGraph": 0}), ("host", {"hostUploadAfterTracking": 1}),
-         ("host", {"hostUploadOnMain": 1}), ("host", {"hostInputAsync": 0})]
+modes = [("device", {}), ("host", {}), ("host", {"hostWaitUpload": 1}), ("host", {"hostWaitUpload": 1, "frameGraph": 1}), ("host", {"hostCopyHelper": 0}),
+         ("host", {"hostWaitUpload": 1, "hostCopyHelper": 0}), ("host", {"hostLockstep": 0}), ("host", {"hostUploadOnMain": 1}), ("host", {"hostInputAsync": 0})]
 if len(sys.argv) > 2 and sys.argv[2] == "short":
-    modes = modes[:6]
+    modes = modes[:7]
+DEFAULTS = {"hostUploadOnMain": 0, "frameGraph": 0, "hostInputAsync": 1, "hostUploadAfterTracking": 0, "hostLockstep": 1, "hostUploadKernel": 0, "hostWaitUpload": 0,
+            "hostCopyHelper": 1}
 for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
     for kind, params in modes:
         for k, v in params.items():
@@ -68,6 +69,6 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
         if rep == 0 and not params.get("hostInputAsync", 1) == 0 and not (len(sys.argv) > 2 and sys.argv[2] == "short"):
             out["stage_us_last_frame_of_a_burst"].append({"boundary": kind, "params": params, "stages": stages(kind)})
         for k in params:
-            mf.setParam(k, {"hostUploadOnMain": 0, "frameGraph": 1, "hostInputAsync": 1, "hostUploadAfterTracking": 0, "hostLockstep": 0, "hostUploadKernel": 0}[k])
+            mf.setParam(k, DEFAULTS[k])
 out["surfels"] = sum(m.lastCount() for m in mf.getModels())
 print(json.dumps(out))
