@@ -1516,7 +1516,9 @@ extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* dept
             MF_HIP(c, hipMemcpyAsync(c->d_in_block[slot], h, up_bytes, hipMemcpyHostToDevice, sup));
         MF_HIP(c, hipEventRecord(c->ev_in_copied[slot], sup));
         if (!c->upload_on_main) {
-            if (c->host_wait_upload && c->host_lockstep) MF_HIP(c, hipEventSynchronize(c->ev_in_copied[slot]));   // (~60 us of the ~300 the host has to spare per frame)
+            // (single-model frames: ~60 us of the ~300 the host has to spare.  A multi-model call synchronises in mid-frame for the label stage's
+            // decision and has no time to spare: its upload stays a cross-queue wait under the previous frame's tail)
+            if (c->host_wait_upload && c->host_lockstep && c->cfg.enable_multiple_models == 0) MF_HIP(c, hipEventSynchronize(c->ev_in_copied[slot]));
             else MF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_in_copied[slot], 0));
         }
         if (c->overlap) MF_HIP(c, hipStreamWaitEvent(c->stream_pre, c->ev_in_copied[slot], 0));
