@@ -628,7 +628,7 @@ def main():
         ks = [order[(cursor[0] + i) % len(order)] for i in range(n)]
         cursor[0] += n
         cls = [0] + [41 + i for i in range(cfg["n_objects"])]
-        for k in ks[:12]:     # untimed: the first calls through this entry point capture their frame graphs (six buffer combinations)
+        for k in ks[:12]:     # untimed: the entry point's first calls (pinned buffers, helper thread, and the frame graphs if that switch is on)
             if multi:
                 mf.processFrame(frames[k][0], frames[k][1], mask=frames[k][2], classIDs=cls)
             else:

@@ -55,11 +55,11 @@ def stages(kind, n=120):
 burst("host", 400)        # the map near its natural size
 mf.sync()
 out = {"us_per_frame": [], "stage_us_last_frame_of_a_burst": []}
-modes = [("device", {}), ("host", {}), ("host", {"hostWaitUpload": 1}), ("host", {"hostWaitUpload": 1, "frameGraph": 1}), ("host", {"hostCopyHelper": 0}),
-         ("host", {"hostWaitUpload": 1, "hostCopyHelper": 0}), ("host", {"hostLockstep": 0}), ("host", {"hostUploadOnMain": 1}), ("host", {"hostInputAsync": 0})]
+modes = [("device", {}), ("host", {}), ("host", {"hostWaitUpload": 0}), ("host", {"frameGraph": 1}), ("host", {"hostCopyHelper": 0}),
+         ("host", {"hostWaitUpload": 0, "hostCopyHelper": 0}), ("host", {"hostLockstep": 0}), ("host", {"hostUploadOnMain": 1}), ("host", {"hostInputAsync": 0})]
 if len(sys.argv) > 2 and sys.argv[2] == "short":
     modes = modes[:7]
-DEFAULTS = {"hostUploadOnMain": 0, "frameGraph": 0, "hostInputAsync": 1, "hostUploadAfterTracking": 0, "hostLockstep": 1, "hostUploadKernel": 0, "hostWaitUpload": 0,
+DEFAULTS = {"hostUploadOnMain": 0, "frameGraph": 0, "hostInputAsync": 1, "hostUploadAfterTracking": 0, "hostLockstep": 1, "hostUploadKernel": 0, "hostWaitUpload": 1,
             "hostCopyHelper": 1}
 for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
     for kind, params in modes:
