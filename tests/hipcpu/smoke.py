@@ -224,8 +224,41 @@ def static_switches(n=9, W=240, H=160):
     return out
 
 
+def host_paths(n=8, W=160, H=120):
+    """mf_process_frame's host-side variants (round 4: pinned double buffer with ONE packed upload, hostLockstep, hostWaitUpload, the staging
+    helper thread, the captured frame graph, the measurement switches) against the blocking form of rounds 1-3: every variant is the same
+    kernels on the same inputs, so poses, counts and the cloud's bytes must be identical.  (Streams and events are synchronous here: this
+    checks the bookkeeping -- slots, views into the packed block, graph replays --, the overlap itself is tests/test_gpu_api.py on the MI355X.)"""
+    import hashlib
+    f = 528.0 * W / 640.0
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
+    frames = [st.frame(k) for k in range(n)]
+    variants = {"blocking": {"hostInputAsync": 0}, "default": {}, "frame_graph": {"frameGraph": 1}, "three_ahead": {"hostLockstep": 0},
+                "stream_wait": {"hostWaitUpload": 0}, "no_helper": {"hostCopyHelper": 0}, "copy_kernel": {"hostUploadKernel": 1},
+                "serial_upload": {"hostUploadOnMain": 1}, "after_tracking": {"hostUploadAfterTracking": 1}}
+    out = {}
+    for name, params in variants.items():
+        mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=False, numGSurfels=1 << 17)
+        for k, v in params.items():
+            mf.setParam(k, v)
+        rgb_buf, d_buf = np.zeros((H, W, 3), np.uint8), np.zeros((H, W), np.float32)
+        poses = []
+        for k, (rgb, d, _) in enumerate(frames):
+            rgb_buf[...] = rgb; d_buf[...] = d
+            mf.processFrame(rgb_buf, d_buf, timestamp=k)
+            rgb_buf[...] = 0; d_buf[...] = np.nan                       # the caller's buffers are the caller's again
+            if k % 3 == 2:
+                poses.append(mf.getCurrPose().reshape(-1).tolist())
+        poses.append(mf.getCurrPose().reshape(-1).tolist())
+        cloud = np.ascontiguousarray(mf.getBackgroundModel().downloadMap())
+        out[name] = dict(poses=poses, count=int(mf.getBackgroundModel().lastCount()), cloud_sha1=hashlib.sha1(cloud.tobytes()).hexdigest(),
+                         graph_launches=float(mf.getParam("frameGraphLaunches")))
+        mf.close()
+    return out
+
+
 if __name__ == "__main__":
     scenarios = dict(single=single_model, rgbd=rgbd_so3, bad_depth=bad_depth_pixels, schedule=schedule_switches, mm_bad_depth=multimodel_bad_depth,
-                     weight=weight_multiplier_cases, dev_masks=device_resident_masks, static=static_switches)
+                     weight=weight_multiplier_cases, dev_masks=device_resident_masks, static=static_switches, host_paths=host_paths)
     wanted = sys.argv[1:] or list(scenarios)      # (tests/test_gpu_emu_agrees.py asks for "single" only; the CPU suite runs all of them)
     print(json.dumps({k: scenarios[k]() for k in wanted}))
