@@ -54,9 +54,14 @@ CONFIGS = {
     "3": dict(W=640, H=480, f=528.0, surfels=9437184, n_objects=8, frames=120,
               workload="configs[3]: S2 synthetic 640x480 RGB-D stream with 8 rigid moving objects, ONE scene sharded by model over the ranks "
                        "(rank 0: background + label stage; objects on the other ranks), trackAllModels, icpWeight=100"),
-    "4": dict(W=1280, H=960, f=1056.0, surfels=32 * 1024 * 1024, n_objects=0, frames=200,
-              workload="configs[4] (per GPU): synthetic 1280x960 RGB-D stream (S3 scaling of S1), 1 model per GPU, NUM_GSURFELS=32M, "
-                       "icpWeight=100 + surfel fusion, empty masks"),
+    "4": dict(W=1280, H=960, f=1056.0, surfels=32 * 1024 * 1024, osurfels=4 * 1024 * 1024, n_objects=4, frames=40, object_motion=0.0,
+              workload="configs[4] on one GPU (SURVEY.md 8d S3): synthetic 1280x960 RGB-D stream with 4 instance-masked objects, MASKFUSION_NUM_GSURFELS=32M / "
+                       "NUM_OSURFELS=4M, every map pre-filled to >= 80 % of its capacity (26.5 M background surfels, 3.4 M per object model: generated on "
+                       "the scene's surfaces and loaded with Model.uploadMap, maskfusion_amd/stress.py), icpWeight=100, global projection + label stage + "
+                       "per-model fusion; the objects stand and follow the camera (trackAllModels off)"),
+    "4n": dict(W=1280, H=960, f=1056.0, surfels=32 * 1024 * 1024, n_objects=0, frames=200,
+               workload="1280x960 stream, natural map: synthetic 1280x960 RGB-D stream (S3 scaling of S1), 1 background model, NUM_GSURFELS=32M budget "
+                        "(the map grows to its natural size, ~1.4 M surfels), icpWeight=100 + surfel fusion, empty masks"),
 }
 
 
@@ -64,7 +69,7 @@ def _render(args):
     cfg, k = args
     from maskfusion_amd import synth
     st = synth.Stream(W=cfg["W"], H=cfg["H"], fx=cfg["f"], fy=cfg["f"], cx=cfg["W"] / 2.0, cy=cfg["H"] / 2.0, noise=True,
-                      n_objects=cfg["n_objects"], seed=1234)
+                      n_objects=cfg["n_objects"], seed=1234, object_motion=cfg.get("object_motion", 1.0))
     return st.frame(k)
 
 
@@ -75,10 +80,10 @@ def gen_frames(cfg, n, workers=0, cache=None):
     timing run instead of ray-casting them again without fork)."""
     from maskfusion_amd import synth
     st = synth.Stream(W=cfg["W"], H=cfg["H"], fx=cfg["f"], fy=cfg["f"], cx=cfg["W"] / 2.0, cy=cfg["H"] / 2.0, noise=True,
-                      n_objects=cfg["n_objects"], seed=1234)
+                      n_objects=cfg["n_objects"], seed=1234, object_motion=cfg.get("object_motion", 1.0))
     tag = None
     if cache:
-        tag = os.path.join(cache, f"frames_{cfg['W']}x{cfg['H']}_o{cfg['n_objects']}_n{n}")
+        tag = os.path.join(cache, f"frames_{cfg['W']}x{cfg['H']}_o{cfg['n_objects']}_m{cfg.get('object_motion', 1.0):g}_n{n}")
         if os.path.exists(tag + "_rgb.npy"):
             rgb, depth, mask = (np.load(tag + s + ".npy", mmap_mode="r") for s in ("_rgb", "_depth", "_mask"))
             return st, [(np.ascontiguousarray(rgb[k]), np.ascontiguousarray(depth[k]), np.ascontiguousarray(mask[k])) for k in range(n)]
@@ -338,13 +343,13 @@ def run_sharded(args, cfg, rank, local_rank, world, st, frames):
         dist.destroy_process_group()
 
 
-def rocprof_rows(names):
+def rocprof_rows(names, pattern="r*kernel_stats.csv"):
     """per-kernel rows {name: {"us": average duration, "calls": n, "source": file}} from the newest committed rocprofv3 --kernel-trace --stats
     summary under profiles/ that holds them (the cross-check the roofline entries name; None when there is none)"""
     import csv
     import glob
     out = {}
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*kernel_stats.csv")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
         try:
             rows = list(csv.DictReader(open(path)))
         except Exception:
@@ -417,6 +422,145 @@ def reference_default_variant(cfg, local_rank, d_rgb, d_depth, order, seconds=1.
                                  "and iteration (SURVEY.md 8d); `levels`: per kernel from the committed rocprofv3 summary named in each entry",
                          "levels": levels, "stage_ms": stages}}
 
+# ------------------------------------------------------------------------------------------------------------------------------------
+# configs[4] as specified: 1280x960, 32M / 4M surfel budgets pre-filled to >= 80 %, 4 objects -- the workload on which
+# the surfel passes (Core/Model/Model.cpp:466-772: predictIndices, fuse, clean, combinedPredict) are bandwidth-relevant.
+# ------------------------------------------------------------------------------------------------------------------------------------
+C4_LEAD_IN = 10          # frames the lead-in may take (maskfusion_amd/stress.py: the fourth object spawns in frame 8)
+
+
+class RoomMapJob:
+    """The 26.5 M-surfel background map takes ~6 s of numpy: it is generated by a forked child (before CUDA exists in this process) into
+    /dev/shm while the parent goes on, and mapped when the scenario needs it."""
+
+    def __init__(self, n_objects=4):
+        import tempfile
+        self.path = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir(), f"mf_bench_room_{os.getpid()}.npy")
+        self.pid = os.fork()
+        if self.pid == 0:
+            try:
+                from maskfusion_amd import stress, synth
+                st = stress.stream(n_objects)
+                m = synth.dense_room_map(st.scene, int(1.005 * 0.8 * stress.surfel_capacity(stress.NUM_GSURFELS)), last_time=0.0)
+                np.save(self.path, m)
+            finally:
+                os._exit(0)
+
+    def result(self):
+        os.waitpid(self.pid, 0)
+        m = np.load(self.path)
+        os.unlink(self.path)
+        return m
+
+
+# SURVEY.md 8d contract bytes of the surfel half, per surfel (N = live surfels of the model) and per pixel (P), by kernel: one read-modify-write
+# (update + clean) 96 B/surfel and two projections of 48 B/surfel each; image-side outputs 52 P per index map, 38 P for the prediction.
+C4_KERNEL_BYTES = {
+    "k_index_scatter": lambda N, P: 48.0 * N,                    # projection 1 (pre-fusion index map): the surfel stream
+    "k_index_resolve": lambda N, P: 52.0 * P,                    # ... its image-side outputs
+    "k_fuse_update": lambda N, P: 96.0 * N,                      # update: read 48 + write 48 (the second index scatter rides on it)
+    "k_clean_flags": lambda N, P: 48.0 * N,                      # clean, pass 1: the surfel stream (+ its window gathers, image side)
+    "k_clean_compact": lambda N, P: 96.0 * N,                    # clean, pass 2: read 48 + write 48
+    "k_splat_bin": lambda N, P: 48.0 * N,                        # projection 2 (prediction): the surfel stream
+    "k_splat_tile": lambda N, P: 38.0 * P,                       # ... its image-side outputs
+}
+
+
+def config4_scene(local_rank, frames, room_job, seconds=2.0, min_frames=20, stages_frames=10, params=()):
+    """The dense configs[4] scenario on one GPU: lead-in + uploaded maps (maskfusion_amd/stress.py), then frames/s over device-resident frames
+    (ping-ponged), the stage timings of an instrumented pass, and per-kernel roofline rows from the newest committed rocprofv3 summary of this
+    scenario (profiles/r*_c4_kernel_stats.csv), each with its SURVEY.md 8d contract bytes."""
+    import torch
+    from maskfusion_amd import stress
+    dev = torch.device("cuda", local_rank)
+    st = stress.stream(4)
+    mf = stress.make_context(local_rank)
+    for key, val in params:
+        mf.setParam(key, val)
+    cls = [0] + [41 + i for i in range(4)]
+    room = room_job.result() if room_job is not None else None
+    t_setup = time.perf_counter()
+    k0, loaded = stress.lead_in(mf, st, frames, cls, n_objects=4, max_frames=C4_LEAD_IN, room_map=room, log=lambda m: print("[bench c4] " + m, file=sys.stderr))
+    del room
+    mf.sync()
+    t_setup = time.perf_counter() - t_setup
+    rest = frames[k0:]
+    d = [tuple(torch.from_numpy(x).to(dev) for x in f) for f in rest]
+    mf.setMaskClassIDs(cls)
+    order = pingpong(len(d), 1 << 16)
+    pos = 0
+
+    def step():
+        nonlocal pos
+        r, dd, m = d[order[pos % len(order)]]
+        pos += 1
+        mf.processFrameDevice(r.data_ptr(), dd.data_ptr(), m.data_ptr(), timestamp=k0 + pos)
+
+    for _ in range(4):
+        step()
+    mf.sync()
+    steps, dt = 0, 0.0
+    while dt < seconds or steps < min_frames:
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step()
+        mf.sync()
+        dt += time.perf_counter() - t0
+        steps += 10
+    mf.enableTimings(True)
+    acc = {}
+    for _ in range(stages_frames):
+        step()
+        for kx, v in mf.timings().items():
+            acc[kx] = acc.get(kx, 0.0) + v
+    mf.enableTimings(False)
+    stages = {kx: v / stages_frames for kx, v in acc.items()}
+    models = mf.getModels()
+    counts = [m.lastCount() for m in models]
+    ids = [m.getID() for m in models]
+    drift = float(np.linalg.norm(mf.getCurrPose()[:3, 3] - st.gt_pose(k0 + order[(pos - 1) % len(order)])[:3, 3]))
+    caps = [stress.surfel_capacity(stress.NUM_GSURFELS)] + [stress.surfel_capacity(stress.NUM_OSURFELS)] * (len(counts) - 1)
+    mf.close()
+    P = stress.W * stress.H
+    ms = 1e3 * dt / steps
+    N_bg, N_all = counts[0], sum(counts)
+    frame_bytes = 741.0 * P + 192.0 * N_all            # one tracked model (the background) + the surfel half of every model
+    rows = rocprof_rows(list(C4_KERNEL_BYTES), pattern="r*_c4_kernel_stats.csv")
+    levels = None
+    if rows:
+        levels = {}
+        for nm, r in rows.items():
+            b = C4_KERNEL_BYTES[nm](N_bg, P)
+            levels[nm] = dict(r, contract_bytes=b, frac=b / (r["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                              note="background model's launch (N = %d): average duration of ALL launches of this name in the named summary; "
+                                   "the object models' batched passes are the k_obj_* rows of the same file" % N_bg)
+    return {"workload": CONFIGS["4"]["workload"], "value": steps / dt, "unit": "frames/s", "ms_per_step": ms, "steps": steps,
+            "models": len(counts), "model_ids": ids, "surfels": counts, "fill": [c / cap for c, cap in zip(counts, caps)],
+            "pose_drift_vs_gt_m": drift, "setup_seconds": t_setup, "lead_in_frames": k0, "stage_ms": stages,
+            "roofline_frame": {"bound": "hbm", "algorithmic_bytes": frame_bytes, "ms": ms, "achieved": frame_bytes / (ms * 1e-3) / 1e9,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frame_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "note": "(741 P for the tracked background + 192 N over every model's surfels) bytes per frame, SURVEY.md 8d"},
+            "roofline_kernels": levels}
+
+
+def run_config4(args, local_rank, frames, room_job):
+    """--config 4 as the bench's own line"""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    res = config4_scene(local_rank, frames, room_job, seconds=max(args.min_seconds, 2.0), min_frames=max(20, min(args.steps, 200)),
+                        params=[tuple((kv.partition("=")[0], float(kv.partition("=")[2]))) for kv in args.param])
+    out = {"metric": f"frames/sec (1280x960 RGB-D, background + {res['models'] - 1} object models, 32M / 4M surfel budgets filled >= 80 %, ICP + surfel fusion)",
+           "value": res["value"], "unit": "frames/s", "n_gpus": 1, "steps": res["steps"], "steps_requested": args.steps, "warmup": 4,
+           "ms_per_step": res["ms_per_step"], "timed_seconds": res["steps"] * res["ms_per_step"] * 1e-3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": res["workload"], "frames_in_hbm": len(frames) - res["lead_in_frames"], "models": res["models"], "surfels": res["surfels"],
+                      "fill": res["fill"], "pose_drift_vs_gt_m": res["pose_drift_vs_gt_m"], "parallelism": "one context, one GPU",
+                      **({"params": {kv.partition("=")[0]: float(kv.partition("=")[2]) for kv in args.param}} if args.param else {})},
+           "roofline": None, "roofline_frame": res["roofline_frame"], "roofline_kernels": res["roofline_kernels"], "stage_ms": res["stage_ms"],
+           "setup_seconds": res["setup_seconds"], "host_input": None, "cpu_baseline": None, "ranks_seen": ranks_seen(1, local_rank)}
+    print(json.dumps(out))
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -440,7 +584,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host-input", action="store_true")
     ap.add_argument("--host-input-frames", type=int, default=150, help="frames of the host-pointer side measurement (host_input)")
-    ap.add_argument("--no-variants", action="store_true", help="skip the reference-default (icpWeight 20 + SO(3)) side measurement of config 1")
+    ap.add_argument("--no-variants", action="store_true", help="skip the side measurements of config 1: reference defaults (icpWeight 20 + SO(3)) and the dense configs[4] scenario")
     ap.add_argument("--force-sharded-scene", action="store_true", help="run that part at N = 1 as well (rehearsal of the N > 1 code path on one GPU)")
     ap.add_argument("--no-sharded-scene", action="store_true", help="N > 1: skip the model-sharded 8-object scene that is timed beside the weak-scaling line")
     args = ap.parse_args()
@@ -459,6 +603,17 @@ def main():
     # beside the weak-scaling line whose per-N values the driver compares
     with_scene = (world > 1 or args.force_sharded_scene) and args.config == "1" and not args.no_sharded_scene
     st3, frames3 = gen_frames(CONFIGS["3"], CONFIGS["3"]["frames"], args.gen_workers) if (with_scene and rank == 0) else (None, None)
+    # the dense configs[4] scenario rides along as a variant of the default line (and is --config 4's own line): its frames are ray-cast and
+    # its background map generated (a forked child) before CUDA exists in this process
+    with_c4 = rank == 0 and world == 1 and ((args.config == "1" and not args.no_variants and args.icp_weight >= 100.0 and not args.so3) or args.config == "4")
+    frames4 = room_job = None
+    if with_c4:
+        room_job = RoomMapJob(4)
+        frames4 = frames if args.config == "4" else gen_frames(CONFIGS["4"], C4_LEAD_IN + 12, args.gen_workers, args.frame_cache or None)[1]
+    if args.config == "4":
+        if world > 1:
+            raise SystemExit("--config 4 is a one-GPU scenario (configs[4]'s per-GPU share); run it with --gpus 1")
+        return run_config4(args, local_rank, frames4, room_job)
     if args.config == "3":
         if args.steps == 600:
             args.steps = 120
@@ -661,6 +816,13 @@ def main():
             variants = {"reference_default": reference_default_variant(cfg, local_rank, d_rgb, d_depth, order)}
         except Exception as e:   # a side measurement: never the reason the bench line is missing
             print(f"[bench] reference-default variant not measured: {e!r}", file=sys.stderr)
+        if with_c4:
+            try:
+                mf.close()        # the dense scenario holds ~6 GB of maps: it gets the GPU to itself
+                d_rgb = d_depth = None
+                variants = dict(variants or {}, config4_stress=config4_scene(local_rank, frames4, room_job, seconds=1.0, min_frames=20))
+            except Exception as e:
+                print(f"[bench] configs[4] stress variant not measured: {e!r}", file=sys.stderr)
 
     seen = ranks_seen(world, local_rank)
     scene = None

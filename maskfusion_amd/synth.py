@@ -185,6 +185,98 @@ class Stream:
         return rgb, depth, mask
 
 
+def _rect_cells(la, lb, spacing):
+    return max(1, int(round(la / spacing))), max(1, int(round(lb / spacing)))
+
+
+def _rect_records(origin, ea, eb, la, lb, normal, spacing, base, phase, conf, init_time, last_time, radius, dst=None):
+    """surfel records on the rectangle origin + a ea + b eb, a in [0, la], b in [0, lb], one per `spacing` x `spacing` cell (cell centres,
+    a-major order -- spatially coherent like the creation order of a real map), all with the same normal / radius / confidence / stamps"""
+    na, nb = _rect_cells(la, lb, spacing)
+    av = (np.arange(na, dtype=np.float32) + 0.5) * np.float32(la / na)
+    b = ((np.arange(nb, dtype=np.float32) + 0.5) * np.float32(lb / nb))[None, :]
+    out = (np.empty((na * nb, 12), np.float32) if dst is None else dst).reshape(na, nb, 12)   # dst: a (na * nb, 12) slice of the caller's array
+    rows = max(1, 16384 // nb)      # a block of records that stays in cache while its twelve interleaved columns are written
+    for r0 in range(0, na, rows):
+        o = out[r0:r0 + rows]
+        a = av[r0:r0 + rows, None]
+        for k in range(3):
+            o[..., k] = np.float32(origin[k]) + a * np.float32(ea[k]) + b * np.float32(eb[k])
+        x, y, z = o[..., 0], o[..., 1], o[..., 2]
+        # smooth procedural colour (cheaper than Scene._texture: 26 M records are generated per call), packed as surfels carry it
+        r = np.clip(base[0] + 45.0 * np.sin(7.0 * x + 5.0 * y + np.float32(phase)), 1, 255).astype(np.int32)
+        g = np.clip(base[1] + 45.0 * np.sin(6.0 * z - 4.0 * y + np.float32(1.3 * phase)), 1, 255).astype(np.int32)
+        bl = np.clip(base[2] + 30.0 * np.sin(9.0 * (x + z) + np.float32(phase)), 1, 255).astype(np.int32)
+        o[..., 3] = conf
+        o[..., 4] = ((r << 16) + (g << 8) + bl).astype(np.float32)
+        o[..., 5] = 0.0
+        o[..., 6] = init_time
+        o[..., 7] = last_time
+        o[..., 8], o[..., 9], o[..., 10] = normal
+        o[..., 11] = radius
+    return out.reshape(-1, 12)
+
+
+def _box_faces(half):
+    """the six faces of an axis-aligned box [-half, half]^3 as (origin, ea, eb, la, lb, normal); normals point INTO the box, the direction
+    a depth camera's normals have (away from the viewer: geometry.glsl:28-40 on a fronto-parallel wall gives +z)"""
+    faces = []
+    for ax in range(3):
+        a1, a2 = (ax + 1) % 3, (ax + 2) % 3
+        for sgn in (-1.0, 1.0):
+            o = -np.asarray(half, float)
+            o[ax] = sgn * half[ax]
+            ea, eb, n = np.zeros(3), np.zeros(3), np.zeros(3)
+            ea[a1], eb[a2], n[ax] = 1.0, 1.0, -sgn
+            faces.append((o, ea, eb, 2 * half[a1], 2 * half[a2], n))
+    return faces
+
+
+def dense_room_map(scene: "Scene", n_target: int, last_time: float, conf: float = 20.0, init_time: float = 1.0, zfront: float = -1.0):
+    """A pre-filled BACKGROUND map ("pre-filled to >= 80 % capacity by a long orbit"): ~n_target surfels at uniform
+    density on the room's five planes and its static boxes, world coordinates = the background model's frame (camera 0 = identity).
+    Radius = sqrt(2) x spacing, what a surfel created at one surfel per pixel carries (surfels.glsl getRadius); every record is stable
+    (confidence above the threshold) and active (last seen at `last_time`), with equal initTime so that Model::clean's duplicate rule
+    (copy_unstable.vert:100-106 needs an OLDER neighbour) keeps the density.  Returns (n, 12) float32 in Model::downloadMap's layout."""
+    x0, x1, y0, y1, z0, z1 = -2.5, 2.5, -1.5, 1.2, zfront, scene.zback
+    rects = [  # (origin, ea, eb, la, lb, normal pointing out of the room, base colour)
+        ((x0, y0, z1), (1, 0, 0), (0, 1, 0), x1 - x0, y1 - y0, (0, 0, 1), scene.planes[0][2]),
+        ((x0, y0, z0), (0, 0, 1), (0, 1, 0), z1 - z0, y1 - y0, (-1, 0, 0), scene.planes[1][2]),
+        ((x1, y0, z0), (0, 0, 1), (0, 1, 0), z1 - z0, y1 - y0, (1, 0, 0), scene.planes[2][2]),
+        ((x0, y1, z0), (1, 0, 0), (0, 0, 1), x1 - x0, z1 - z0, (0, 1, 0), scene.planes[3][2]),
+        ((x0, y0, z0), (1, 0, 0), (0, 0, 1), x1 - x0, z1 - z0, (0, -1, 0), scene.planes[4][2]),
+    ]
+    for bx in scene.boxes:
+        if bx.instance != 0:
+            continue
+        for (o, ea, eb, la, lb, n) in _box_faces(bx.half):
+            rects.append((o + bx.center, ea, eb, la, lb, n, bx.color))
+    area = sum(r[3] * r[4] for r in rects)
+    spacing = float(np.sqrt(area / n_target))
+    sizes = [int(np.prod(_rect_cells(r[3], r[4], spacing))) for r in rects]
+    out = np.empty((sum(sizes), 12), np.float32)
+    at = 0
+    for k, ((o, ea, eb, la, lb, n, base), sz) in enumerate(zip(rects, sizes)):
+        _rect_records(o, ea, eb, la, lb, n, spacing, base, 0.9 * k, conf, init_time, last_time, np.float32(1.41421356 * spacing), out[at:at + sz])
+        at += sz
+    return out
+
+
+def dense_object_map(box: "Box", n_target: int, T_obj_from_world: np.ndarray, last_time: float, conf: float = 20.0, init_time: float = 1.0):
+    """The same for one (standing) instance-masked box: ~n_target surfels on its six faces, transformed from world coordinates into the
+    OBJECT model's frame with `T_obj_from_world` (= objectPose . backgroundPose^-1)."""
+    faces = _box_faces(box.half)
+    area = sum(f[3] * f[4] for f in faces)
+    spacing = float(np.sqrt(area / n_target))
+    T = np.asarray(T_obj_from_world, np.float64) @ make_pose(np.eye(3), box.center)
+    R, t = T[:3, :3], T[:3, 3]
+    parts = []
+    for k, (o, ea, eb, la, lb, n) in enumerate(faces):
+        parts.append(_rect_records(R @ o + t, R @ ea, R @ eb, la, lb, (R @ n).astype(np.float32), spacing, box.color, 1.7 + 0.37 * k, conf,
+                                   init_time, last_time, np.float32(1.41421356 * spacing)))
+    return np.concatenate(parts)
+
+
 def ate_rmse(est: np.ndarray, gt: np.ndarray) -> float:
     """Translational ATE RMSE between two (N,4,4) trajectories that share frame 0 (no alignment needed)."""
     d = est[:, :3, 3] - gt[:, :3, 3]

@@ -16,6 +16,9 @@
 #include <string.h>
 #include <time.h>
 #include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define MFO_NAN (__builtin_nanf(""))
 
@@ -1179,20 +1182,11 @@ int mfo_init_surfels(const mfo_cam* c, const uint8_t* rgb, const float* depthRaw
  * Raster rule (documented): 1-px point -> texel floor(u), floor(v); z-test LESS on the float z, first
  * (lowest index) surfel wins ties.
  * ---------------------------------------------------------------------------------------------- */
-void mfo_predict_indices(const mfo_cam* c, const float* pose16, const float* surfels, int count, int time,
-                         float maxDepth, int timeDelta, int32_t* index, float* vertConf, float* colorTime,
-                         float* normRad) {
-    const int W = c->W, H = c->H, P = W * H;
-    float R[9], t[3], Ri[9], ti[3];
-    pose16_to_Rt(pose16, R, t);
-    pose_inverse_Rt(R, t, Ri, ti);
-    float* zbuf = (float*)malloc(sizeof(float) * P);
-    for (int i = 0; i < P; ++i) zbuf[i] = INFINITY;
-    memset(index, 0, sizeof(int32_t) * P);
-    memset(vertConf, 0, sizeof(float) * 4 * P);
-    memset(colorTime, 0, sizeof(float) * 4 * P);
-    memset(normRad, 0, sizeof(float) * 4 * P);
-    for (int i = 0; i < count; ++i) {
+/* z-test of surfels [i0, i1) in index order into zbuf / win (win: -1 = none): the serial loop of the pass */
+static void predict_indices_range(const mfo_cam* c, const float* Ri, const float* ti, const float* surfels, int i0, int i1, int time,
+                                  float maxDepth, int timeDelta, float* zbuf, int32_t* win) {
+    const int W = c->W, H = c->H;
+    for (int i = i0; i < i1; ++i) {
         const float* s = surfels + (size_t)i * 12;
         f3 h = m33_mul(Ri, f3_make(s[0], s[1], s[2]));
         h = f3_make(h.x + ti[0], h.y + ti[1], h.z + ti[2]);
@@ -1204,13 +1198,62 @@ void mfo_predict_indices(const mfo_cam* c, const float* pose16, const float* sur
         const int p = py * W + px;
         if (!(h.z < zbuf[p])) continue;
         zbuf[p] = h.z;
+        win[p] = i;
+    }
+}
+/* how many threads the z-buffer passes split a big surfel buffer over (each gets a private z-buffer; see splat_zbuffer) */
+static int zbuffer_threads(int count) {
+    int T = 1;
+#ifdef _OPENMP
+    T = omp_get_max_threads();
+#endif
+    if (T > 16) T = 16;
+    if (count < 400000 || T < 2) return 1;
+    return T;
+}
+void mfo_predict_indices(const mfo_cam* c, const float* pose16, const float* surfels, int count, int time,
+                         float maxDepth, int timeDelta, int32_t* index, float* vertConf, float* colorTime,
+                         float* normRad) {
+    const int W = c->W, H = c->H, P = W * H;
+    (void)H;
+    float R[9], t[3], Ri[9], ti[3];
+    pose16_to_Rt(pose16, R, t);
+    pose_inverse_Rt(R, t, Ri, ti);
+    /* The z-test visits the surfels in index order; LESS keeps the first (lowest-index) surfel among equal depths.  A big buffer is cut into
+     * T contiguous index ranges, each tested into a private z-buffer in index order, and the private buffers are merged in range order with
+     * the same strict LESS: per pixel the winner is the smallest z and, among equal z, the lowest index -- the serial loop's result. */
+    const int T = zbuffer_threads(count);
+    float* zbuf = (float*)malloc(sizeof(float) * (size_t)P * T);
+    int32_t* win = (int32_t*)malloc(sizeof(int32_t) * (size_t)P * T);
+#pragma omp parallel for schedule(static) num_threads(T)
+    for (int k = 0; k < T; ++k) {
+        float* zb = zbuf + (size_t)k * P; int32_t* wn = win + (size_t)k * P;
+        for (int i = 0; i < P; ++i) { zb[i] = INFINITY; wn[i] = -1; }
+        const int i0 = (int)((long long)count * k / T), i1 = (int)((long long)count * (k + 1) / T);
+        predict_indices_range(c, Ri, ti, surfels, i0, i1, time, maxDepth, timeDelta, zb, wn);
+    }
+#pragma omp parallel for schedule(static)
+    for (int p = 0; p < P; ++p) {
+        for (int k = 1; k < T; ++k)
+            if (zbuf[(size_t)k * P + p] < zbuf[p]) { zbuf[p] = zbuf[(size_t)k * P + p]; win[p] = win[(size_t)k * P + p]; }
+        /* the attachments of the winning fragment (index_map.frag); an untouched texel keeps the clear value 0 */
+        const int i = win[p];
+        if (i < 0) {
+            index[p] = 0;
+            memset(vertConf + (size_t)p * 4, 0, 4 * sizeof(float)); memset(colorTime + (size_t)p * 4, 0, 4 * sizeof(float));
+            memset(normRad + (size_t)p * 4, 0, 4 * sizeof(float));
+            continue;
+        }
+        const float* s = surfels + (size_t)i * 12;
+        f3 h = m33_mul(Ri, f3_make(s[0], s[1], s[2]));
+        h = f3_make(h.x + ti[0], h.y + ti[1], h.z + ti[2]);
         index[p] = i;
         vertConf[p * 4 + 0] = h.x; vertConf[p * 4 + 1] = h.y; vertConf[p * 4 + 2] = h.z; vertConf[p * 4 + 3] = s[3];
         memcpy(colorTime + p * 4, s + 4, 4 * sizeof(float));
         const f3 n = f3_glnormalize(m33_mul(Ri, f3_make(s[8], s[9], s[10])));
         normRad[p * 4 + 0] = n.x; normRad[p * 4 + 1] = n.y; normRad[p * 4 + 2] = n.z; normRad[p * 4 + 3] = s[11];
     }
-    free(zbuf);
+    free(zbuf); free(win);
 }
 
 /* Window rule for data.vert:139-141 (documented oracle rule): pixel-centre offsets
@@ -1466,14 +1509,14 @@ int mfo_clean(const mfo_cam* c, const float* pose16, const float* src, int count
 #define MFO_MAX_SPRITE 64.0f
 /* z-buffered splat of one surfel buffer.  zbuf / winner (surfel index, -1 = none) / owner (caller tag per pixel, may be
  * NULL) are in-out so that several models can share one z-buffer (GlobalProjection). */
-static void splat_zbuffer(const mfo_cam* c, const float* pose16, const float* surfels, int count, float maxDepth,
+static void splat_zbuffer_range(const mfo_cam* c, const float* pose16, const float* surfels, int i0, int i1, float maxDepth,
                           float confThreshold, int time, int maxTime, int timeDelta, float* zbuf, int32_t* winner,
                           uint8_t* owner, uint8_t tag) {
     const int W = c->W, H = c->H;
     float R[9], t[3], Ri[9], ti[3];
     pose16_to_Rt(pose16, R, t);
     pose_inverse_Rt(R, t, Ri, ti);
-    for (int i = 0; i < count; ++i) {
+    for (int i = i0; i < i1; ++i) {
         const float* s = surfels + (size_t)i * 12;
         f3 h = m33_mul(Ri, f3_make(s[0], s[1], s[2]));
         h = f3_make(h.x + ti[0], h.y + ti[1], h.z + ti[2]);
@@ -1521,6 +1564,37 @@ static void splat_zbuffer(const mfo_cam* c, const float* pose16, const float* su
             }
         }
     }
+}
+
+/* The whole buffer.  A big one is cut into contiguous index ranges, each splatted in index order into a private z-buffer, and the private
+ * buffers are merged into the caller's in range order with the same strict LESS -- per pixel the smallest z wins and, among equal z, the
+ * earlier surfel (and the earlier model: the caller's buffer holds the models drawn before this one): the serial loop's result. */
+static void splat_zbuffer(const mfo_cam* c, const float* pose16, const float* surfels, int count, float maxDepth,
+                          float confThreshold, int time, int maxTime, int timeDelta, float* zbuf, int32_t* winner,
+                          uint8_t* owner, uint8_t tag) {
+    const int T = zbuffer_threads(count);
+    if (T == 1) {
+        splat_zbuffer_range(c, pose16, surfels, 0, count, maxDepth, confThreshold, time, maxTime, timeDelta, zbuf, winner, owner, tag);
+        return;
+    }
+    const int P = c->W * c->H;
+    float* pz = (float*)malloc(sizeof(float) * (size_t)P * T);
+    int32_t* pw = (int32_t*)malloc(sizeof(int32_t) * (size_t)P * T);
+#pragma omp parallel for schedule(static) num_threads(T)
+    for (int k = 0; k < T; ++k) {
+        float* zb = pz + (size_t)k * P; int32_t* wn = pw + (size_t)k * P;
+        for (int i = 0; i < P; ++i) { zb[i] = INFINITY; wn[i] = -1; }
+        const int i0 = (int)((long long)count * k / T), i1 = (int)((long long)count * (k + 1) / T);
+        splat_zbuffer_range(c, pose16, surfels, i0, i1, maxDepth, confThreshold, time, maxTime, timeDelta, zb, wn, NULL, 0);
+    }
+#pragma omp parallel for schedule(static)
+    for (int p = 0; p < P; ++p)
+        for (int k = 0; k < T; ++k)
+            if (pz[(size_t)k * P + p] < zbuf[p]) {
+                zbuf[p] = pz[(size_t)k * P + p]; winner[p] = pw[(size_t)k * P + p];
+                if (owner) owner[p] = tag;
+            }
+    free(pz); free(pw);
 }
 
 void mfo_combined_predict(const mfo_cam* c, const float* pose16, const float* surfels, int count, float maxDepth,
@@ -2637,6 +2711,16 @@ int mfo_mm_process_frame(mfo_mm* x, const uint8_t* rgb, const float* depth, cons
     return 0;
 }
 
+/* Test tooling, the twin of mf_model_upload_map (include/maskfusion_amd.h): replace the live surfel buffer of model i with `count` records
+ * (12 floats each).  No upstream twin -- a long orbit would fill the map; the configs[4] parity / stress case loads a pre-filled map instead
+ * (SURVEY.md 8d S3).  Returns 0, or -1 when the model does not exist or the records do not fit its capacity. */
+int mfo_mm_upload_map(mfo_mm* x, int i, const float* surfels12, int count) {
+    if (i < 0 || i >= x->nModels || count < 0 || count > x->models[i].cap) return -1;
+    mm_model* m = &x->models[i];
+    memcpy(m->surf[m->cur], surfels12, sizeof(float) * 12 * (size_t)count);
+    m->count = count;
+    return 0;
+}
 int mfo_mm_num_models(const mfo_mm* x) { return x->nModels; }
 int mfo_mm_model_id(const mfo_mm* x, int i) { return x->models[i].id; }
 int mfo_mm_model_count(const mfo_mm* x, int i) { return x->models[i].count; }

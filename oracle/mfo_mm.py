@@ -70,6 +70,8 @@ def mm_lib():
     L.mfo_mm_model_track_log.argtypes = [C.c_void_p, C.c_int, f32p]
     L.mfo_mm_model_track_log.restype = C.c_int
     L.mfo_mm_model_tracked_pose_alt.argtypes = [C.c_void_p, C.c_int, f32p]
+    L.mfo_mm_upload_map.argtypes = [C.c_void_p, C.c_int, f32p, C.c_int]
+    L.mfo_mm_upload_map.restype = C.c_int
     L.mfo_mm_num_models.argtypes = [C.c_void_p]
     L.mfo_mm_num_models.restype = C.c_int
     for n in ("mfo_mm_model_id", "mfo_mm_model_count"):
@@ -252,6 +254,12 @@ class OracleMM:
         mm_lib().mfo_mm_model_tracked_pose_alt(self.h, i, p)
         own, _ = self.model_tracked_pose(i)
         return float(np.abs(from_pose16(p) - own).max())
+
+    def upload_map(self, i, surfels):
+        """replace model i's surfel buffer with `surfels` ((n, 12) float32): the twin of Model.uploadMap on the product's side"""
+        s = np.ascontiguousarray(surfels, np.float32).reshape(-1, 12)
+        if mm_lib().mfo_mm_upload_map(self.h, i, s.reshape(-1), len(s)) != 0:
+            raise ValueError("upload_map: no such model, or more records than its capacity")
 
     @property
     def n_models(self):

@@ -4,7 +4,7 @@ import os
 import numpy as np
 import torch
 
-# MF_EMU=1: the tests drive tests/_build/libmaskfusion_emu.so (the product's kernels executed on the CPU, tests/hipcpu) instead of the GPU
+# MF_EMU=1: the tests drive tests/_emu/libmaskfusion_emu.so (the product's kernels executed on the CPU, tests/hipcpu) instead of the GPU
 # library -- a logic check for machines without a GPU, selected explicitly and never by default.  "Device" memory is host memory then.
 EMU = os.environ.get("MF_EMU") == "1"
 DEVICE = "cpu" if EMU else "cuda"

@@ -18,7 +18,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "maskfusion_amd", "csrc")
 OUT = os.path.join(os.path.dirname(HERE), "_build")
-LIB = os.path.join(OUT, "libmaskfusion_emu.so")
+# the plain build lives in tests/_emu/ -- git-ignored like tests/_build/, but NOT gpurun-ignored: it travels to the GPU box, where
+# tests/test_gpu_emu_agrees.py compares it with the hardware (building it there cost that test 200 s of the driver's GPU-suite limit)
+SHIP = os.path.join(os.path.dirname(HERE), "_emu")
+LIB = os.path.join(SHIP, "libmaskfusion_emu.so")
 LIB_COOP = os.path.join(OUT, "libmaskfusion_emu_coop.so")     # -DHIPCPU_COOP: cooperative launches possible, slower (see hipcpu.h)
 LIB_ASAN = os.path.join(OUT, "libmaskfusion_emu_asan.so")     # -fsanitize=address: out-of-bounds / use-after-free accesses of "device" memory
                                                               # (every hipMalloc is a malloc) abort with a report -- run under
@@ -41,7 +44,7 @@ def _stale(lib) -> bool:
     if not os.path.exists(lib):
         return True
     t = os.path.getmtime(lib)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(HERE, f) for f in os.listdir(HERE)]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(HERE, f) for f in ("hipcpu.h", "hipcpu_runtime.cpp", "build.py")]   # (not the directory listing: __pycache__ changes whenever Python imports from here)
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
@@ -60,6 +63,7 @@ def build(force: bool = False, only=None, coop: bool = False, asan: bool = False
     if not (force or _stale(lib)) and only is None:
         return lib
     os.makedirs(OUT, exist_ok=True)
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
     objs = []
     for src in SOURCES:
         obj = os.path.join(OUT, tag + src.replace(".hip", ".o"))

@@ -1,4 +1,4 @@
-"""Loads tests/_build/libmaskfusion_emu.so (the product's kernels compiled for and executed on the CPU, tests/hipcpu/build.py) behind the
+"""Loads tests/_emu/libmaskfusion_emu.so (the product's kernels compiled for and executed on the CPU, tests/hipcpu/build.py) behind the
 same ctypes table as the real library.  TEST TOOLING: `activate()` swaps it into maskfusion_amd.lib for the current PROCESS so that the
 Python mirror (maskfusion_amd.api) drives it; only tests call this, explicitly.  "Device pointers" are host pointers here."""
 from __future__ import annotations

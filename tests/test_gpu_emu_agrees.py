@@ -1,6 +1,6 @@
 """-m gpu: how faithful is the CPU-executed test build (tests/hipcpu) to the hardware?  The same small stream through
 maskfusion_amd/libmaskfusion_amd.so on the MI355X (this process) and through the same sources compiled with g++ and executed on the CPU
-(a subprocess: tests/hipcpu/smoke.py builds tests/_build/libmaskfusion_emu.so on the box).  Same kernels, same order; what differs is the
+(a subprocess: tests/hipcpu/smoke.py; tests/_emu/libmaskfusion_emu.so travels to the box prebuilt and is rebuilt there only if stale).  Same kernels, same order; what differs is the
 device's own arithmetic (v_exp / v_rcp seeds, contraction), so inlier counts and surfel counts must be equal and poses agree to 2e-5.
 Written when the round's GPU minutes were spent: non-strict xfail until a hardware run has been seen."""
 import json
