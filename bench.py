@@ -54,7 +54,7 @@ CONFIGS = {
     "3": dict(W=640, H=480, f=528.0, surfels=9437184, n_objects=8, frames=120,
               workload="configs[3]: S2 synthetic 640x480 RGB-D stream with 8 rigid moving objects, ONE scene sharded by model over the ranks "
                        "(rank 0: background + label stage; objects on the other ranks), trackAllModels, icpWeight=100"),
-    "4": dict(W=1280, H=960, f=1056.0, surfels=32 * 1024 * 1024, osurfels=4 * 1024 * 1024, n_objects=4, frames=40, object_motion=0.0,
+    "4": dict(W=1280, H=960, f=1056.0, surfels=32 * 1024 * 1024, osurfels=4 * 1024 * 1024, n_objects=4, frames=40, s3=True,
               workload="configs[4] on one GPU (SURVEY.md 8d S3): synthetic 1280x960 RGB-D stream with 4 instance-masked objects, MASKFUSION_NUM_GSURFELS=32M / "
                        "NUM_OSURFELS=4M, every map pre-filled to >= 80 % of its capacity (26.5 M background surfels, 3.4 M per object model: generated on "
                        "the scene's surfaces and loaded with Model.uploadMap, maskfusion_amd/stress.py), icpWeight=100, global projection + label stage + "
@@ -65,12 +65,18 @@ CONFIGS = {
 }
 
 
+def _stream(cfg):
+    from maskfusion_amd import synth
+    if cfg.get("s3"):        # configs[4]'s scene: maskfusion_amd/stress.py
+        from maskfusion_amd import stress
+        return stress.stream(cfg["n_objects"])
+    return synth.Stream(W=cfg["W"], H=cfg["H"], fx=cfg["f"], fy=cfg["f"], cx=cfg["W"] / 2.0, cy=cfg["H"] / 2.0, noise=True,
+                        n_objects=cfg["n_objects"], seed=1234)
+
+
 def _render(args):
     cfg, k = args
-    from maskfusion_amd import synth
-    st = synth.Stream(W=cfg["W"], H=cfg["H"], fx=cfg["f"], fy=cfg["f"], cx=cfg["W"] / 2.0, cy=cfg["H"] / 2.0, noise=True,
-                      n_objects=cfg["n_objects"], seed=1234, object_motion=cfg.get("object_motion", 1.0))
-    return st.frame(k)
+    return _stream(cfg).frame(k)
 
 
 def gen_frames(cfg, n, workers=0, cache=None):
@@ -78,12 +84,10 @@ def gen_frames(cfg, n, workers=0, cache=None):
     workers = 1: no fork at all (under rocprofv3 --pmc the tool has initialised HSA before Python starts; forked workers hang at exit).
     cache: directory the rendered frames are kept in / taken from (profiler passes over the full 600-frame stream re-use the frames of the
     timing run instead of ray-casting them again without fork)."""
-    from maskfusion_amd import synth
-    st = synth.Stream(W=cfg["W"], H=cfg["H"], fx=cfg["f"], fy=cfg["f"], cx=cfg["W"] / 2.0, cy=cfg["H"] / 2.0, noise=True,
-                      n_objects=cfg["n_objects"], seed=1234, object_motion=cfg.get("object_motion", 1.0))
+    st = _stream(cfg)
     tag = None
     if cache:
-        tag = os.path.join(cache, f"frames_{cfg['W']}x{cfg['H']}_o{cfg['n_objects']}_m{cfg.get('object_motion', 1.0):g}_n{n}")
+        tag = os.path.join(cache, f"frames_{cfg['W']}x{cfg['H']}_o{cfg['n_objects']}{'_s3' if cfg.get('s3') else ''}_n{n}")
         if os.path.exists(tag + "_rgb.npy"):
             rgb, depth, mask = (np.load(tag + s + ".npy", mmap_mode="r") for s in ("_rgb", "_depth", "_mask"))
             return st, [(np.ascontiguousarray(rgb[k]), np.ascontiguousarray(depth[k]), np.ascontiguousarray(mask[k])) for k in range(n)]
@@ -433,20 +437,28 @@ class RoomMapJob:
     """The 26.5 M-surfel background map takes ~6 s of numpy: it is generated by a forked child (before CUDA exists in this process) into
     /dev/shm while the parent goes on, and mapped when the scenario needs it."""
 
-    def __init__(self, n_objects=4):
+    def __init__(self, n_objects=4, fork=True):
         import tempfile
+        self.n_objects = n_objects
+        self.pid = None
+        if not fork:       # profiler runs (--gen-workers 1): no forked children under rocprofv3
+            return
         self.path = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir(), f"mf_bench_room_{os.getpid()}.npy")
         self.pid = os.fork()
         if self.pid == 0:
             try:
-                from maskfusion_amd import stress, synth
-                st = stress.stream(n_objects)
-                m = synth.dense_room_map(st.scene, int(1.005 * 0.8 * stress.surfel_capacity(stress.NUM_GSURFELS)), last_time=0.0)
-                np.save(self.path, m)
+                np.save(self.path, self.generate())
             finally:
                 os._exit(0)
 
+    def generate(self):
+        from maskfusion_amd import stress, synth
+        return synth.dense_room_map(stress.stream(self.n_objects).scene, int(1.005 * 0.8 * stress.surfel_capacity(stress.NUM_GSURFELS)), last_time=0.0,
+                                    furniture_above=self.n_objects)
+
     def result(self):
+        if self.pid is None:
+            return self.generate()
         os.waitpid(self.pid, 0)
         m = np.load(self.path)
         os.unlink(self.path)
@@ -608,7 +620,7 @@ def main():
     with_c4 = rank == 0 and world == 1 and ((args.config == "1" and not args.no_variants and args.icp_weight >= 100.0 and not args.so3) or args.config == "4")
     frames4 = room_job = None
     if with_c4:
-        room_job = RoomMapJob(4)
+        room_job = RoomMapJob(4, fork=args.gen_workers != 1)
         frames4 = frames if args.config == "4" else gen_frames(CONFIGS["4"], C4_LEAD_IN + 12, args.gen_workers, args.frame_cache or None)[1]
     if args.config == "4":
         if world > 1:

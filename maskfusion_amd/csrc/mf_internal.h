@@ -222,11 +222,10 @@ void launch_index_resolve(Surfels src, const PoseDev* pose, unsigned long long* 
 void launch_fuse_data(const uint8_t* rgb, const float* depthRaw, const float* depthF, const uint8_t* mask,
                       int maskID, const FrameDev* frame, const PoseDev* pose, float weightMultiplier, float maxDepth,
                       int W, int H, Intr k, const int* index, const float4* vc, const float4* nr, uint8_t* cand_op,
-                      float4* cand_rec, int* upd_first, hipStream_t s, int bboxLimit = 1);
-// keys_or_null != nullptr: also scatters the updated surfels into the index-map keys (the pass that feeds clean)
-void launch_fuse_update(Surfels src, Surfels dst, const FrameDev* frame, int* upd_first, const float4* cand_rec, const PoseDev* pose,
-                        int W, int H, Intr k, float maxDepth, int timeDelta, unsigned long long* keys_or_null, bool transposed,
-                        hipStream_t s, int blocks = kSurfelGridBlocks);
+                      float4* cand_rec, int* upd_first, int* cand_best, hipStream_t s, int bboxLimit = 1);
+// update.vert IN PLACE: one thread per candidate, the winning candidate of a surfel (upd_first) merges into it where it stands
+void launch_fuse_update(Surfels s, const FrameDev* frame, int* upd_first, const uint8_t* cand_op, const int* cand_best, const float4* cand_rec,
+                        int W, int H, hipStream_t st);
 void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k,
                   int timeDelta, float confThreshold, float outlierCoeff, int maskID, const int* index,
                   const float4* vc, const float4* ct, const float4* packed /*or null*/, const float* depthF, const uint8_t* mask,
@@ -262,11 +261,11 @@ int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W,
 // round 2's profile).  The batched kernels are the single-model kernels' bodies called with one model's arguments, picked from a device
 // array by blockIdx.z; every model brings its own scratch (index maps, key image, candidate records, ...), which the single-model path shares.
 struct ObjPassArgs {
-    Surfels a, b;                      // live buffer when the frame's fusion starts / the other one (fuse: a -> b, clean: b -> a)
+    Surfels a, b;                      // live buffer when the frame's fusion starts / the other one (fuse: in place in a; clean: a -> b, then b is live)
     FrameDev* frame; PoseDev* pose;
     int maskID; float confThreshold, fuseMaxDepth, weightMultiplier;
     unsigned long long* keys; int* index; float4* ivc; float4* inr; float4* iclean;
-    uint8_t* cand_op; float4* cand_rec; int* upd_first; uint8_t* flags; float* newconf; int* block_counts; int* host_count;
+    uint8_t* cand_op; float4* cand_rec; int* upd_first; int* cand_best; uint8_t* flags; float* newconf; int* block_counts; int* host_count;
     float4* predV; float4* predN; uchar4* predImage; uint16_t* predTime; uint8_t* predGray;
     FrameDev* host_frame; float* log_slot;
     unsigned global_payload;           // GlobalProjection: order << 8 | id

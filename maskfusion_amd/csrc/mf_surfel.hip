@@ -257,6 +257,7 @@ struct FuseDataArgs {
     int W, H; Intr k;
     const int* index; const float4* vc; const float4* nr;
     uint8_t* cand_op; float4* cand_rec; int* upd_first;
+    int* cand_best;                // surfel a merge candidate was associated with (read by the update pass; untouched for the others)
 };
 
 __device__ __forceinline__ void fuse_data_body(const FuseDataArgs& a) {
@@ -344,7 +345,10 @@ __device__ __forceinline__ void fuse_data_body(const FuseDataArgs& a) {
         a.cand_rec[c * 3 + 0] = make_float4(vGlobal.x, vGlobal.y, vGlobal.z, surfel_confidence(x, y, weighting, k));
         a.cand_rec[c * 3 + 1] = make_float4((float)((pc[0] << 16) + (pc[1] << 8) + pc[2]), 0.f, (float)time, merge ? -1.f : -2.f);
         a.cand_rec[c * 3 + 2] = make_float4(nGlobal.x, nGlobal.y, nGlobal.z, surfel_radius(vF.z, nLocal.z, k));
-        if (merge) atomicMin(&a.upd_first[best], c);  // first writer (lowest column-major index) wins
+        if (merge) {
+            atomicMin(&a.upd_first[best], c);  // first writer (lowest column-major index) wins
+            a.cand_best[c] = best;
+        }
     }
     a.cand_op[c] = op;
 }
@@ -354,81 +358,64 @@ __global__ __launch_bounds__(256) void k_fuse_data(const FuseDataArgs a) { fuse_
 void launch_fuse_data(const uint8_t* rgb, const float* depthRaw, const float* depthF, const uint8_t* mask, int maskID,
                       const FrameDev* frame, const PoseDev* pose, float weightMultiplier, float maxDepth, int W, int H, Intr k,
                       const int* index, const float4* vc, const float4* nr, uint8_t* cand_op, float4* cand_rec, int* upd_first,
-                      hipStream_t s, int bboxLimit) {
+                      int* cand_best, hipStream_t s, int bboxLimit) {
     FuseDataArgs a{rgb, depthRaw, depthF, mask, maskID, frame, pose, weightMultiplier, maxDepth, bboxLimit, W, H, k,
-                   index, vc, nr, cand_op, cand_rec, upd_first};
+                   index, vc, nr, cand_op, cand_rec, upd_first, cand_best};
     dim3 grid(((W + 1) / 2 + 63) / 64, ((H + 1) / 2 + 3) / 4);
     hipLaunchKernelGGL(k_fuse_data, grid, dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
-// surfel update (update.vert): src -> dst, consuming (and resetting) the per-surfel merge slot
+// surfel update (update.vert), IN PLACE.  The reference copies the whole buffer through transform feedback (Model.cpp:583-646) although
+// only the surfels a candidate was merged into change -- at most P / 4 of them, of 26 M in a full map.  Here one thread per candidate
+// updates "its" surfel where it stands (first writer wins: the candidate with the lowest column-major index owns the merge, decided by
+// the atomicMin of the association pass) and re-arms the surfel's merge slot; no surfel reads another, so the values are the ones the
+// copying form wrote (rounds 1-4: an N-sized pass of 100 B per surfel with the second index scatter riding on it).
 // ------------------------------------------------------------------------------------------------
-// idx != nullptr: the index-map scatter of the pass that feeds clean() (predictIndices after fuse, MaskFusion.cpp:556) is done
-// right here on the values just written, instead of a separate launch re-reading the buffer.
-struct IndexScatterArgs { const PoseDev* pose; int W, H; Intr k; float maxDepth; int timeDelta; unsigned long long* keys; int transposed; };
-
-__device__ __forceinline__ void fuse_update_body(Surfels src, Surfels dst, const FrameDev* __restrict__ frame,
-                                                 int* __restrict__ upd_first, const float4* __restrict__ cand_rec,
-                                                 const IndexScatterArgs& ix) {
-    const int n = frame->count;
+__device__ __forceinline__ void fuse_update_body(Surfels s, const FrameDev* __restrict__ frame, int* __restrict__ upd_first,
+                                                 const uint8_t* __restrict__ cand_op, const int* __restrict__ cand_best,
+                                                 const float4* __restrict__ cand_rec, int W, int H) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cand_count(W, H, frame->tick)) return;
+    if (cand_op[c] != 1) return;
+    const int i = cand_best[c];
+    if (i < 0 || i >= frame->count) return;
+    if (upd_first[i] != c) return;          // an earlier candidate owns this surfel's merge
+    upd_first[i] = kNoUpdate;
     const float time = (float)frame->tick;
-    float Ri[9];
-    float3 ti = f3(0, 0, 0);
-    if (ix.keys) {
-#pragma unroll
-        for (int q = 0; q < 9; ++q) Ri[q] = ix.pose->Ri[q];
-        ti = f3(ix.pose->ti[0], ix.pose->ti[1], ix.pose->ti[2]);
-    }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        float4 pc = src.pc[i], ct = src.ct[i], nr = src.nr[i];
-        const int m = upd_first[i];
-        if (m != kNoUpdate) {
-            upd_first[i] = kNoUpdate;
-            const float4 mp = cand_rec[m * 3 + 0], mc = cand_rec[m * 3 + 1], mn = cand_rec[m * 3 + 2];
-            const float c_k = pc.w, a = mp.w;
-            if (mn.w < (1.0f + 0.5f) * nr.w) {
-                pc = make_float4(((c_k * pc.x) + (a * mp.x)) / (c_k + a), ((c_k * pc.y) + (a * mp.y)) / (c_k + a),
-                                 ((c_k * pc.z) + (a * mp.z)) / (c_k + a), c_k + a);
-                const float3 oc = decode_color(ct.x), nc = decode_color(mc.x);
-                ct = make_float4(encode_color(((c_k * oc.x) + (a * nc.x)) / (c_k + a), ((c_k * oc.y) + (a * nc.y)) / (c_k + a),
-                                              ((c_k * oc.z) + (a * nc.z)) / (c_k + a)),
-                                 ct.y, ct.z, time);
-                const float4 av = make_float4(((c_k * nr.x) + (a * mn.x)) / (c_k + a), ((c_k * nr.y) + (a * mn.y)) / (c_k + a),
-                                              ((c_k * nr.z) + (a * mn.z)) / (c_k + a), ((c_k * nr.w) + (a * mn.w)) / (c_k + a));
-                const float3 nn = normalize_gl(f3(av.x, av.y, av.z));
-                nr = make_float4(nn.x, nn.y, nn.z, av.w);
-            } else {
-                pc.w = c_k + a;
-                ct.w = time;
-            }
-        }
-        dst.pc[i] = pc; dst.ct[i] = ct; dst.nr[i] = nr;
-        if (ix.keys) {   // k_index_scatter on the updated surfel (index_map.vert:40-60)
-            const float3 h = mul33(Ri, f3(pc.x, pc.y, pc.z)) + ti;
-            if (!(h.z > ix.maxDepth || h.z <= 0 || time - ct.w > (float)ix.timeDelta)) {
-                const float u = ((ix.k.fx * h.x) / h.z) + ix.k.cx;
-                const float v = ((ix.k.fy * h.y) / h.z) + ix.k.cy;
-                if (u >= 0.f && u < (float)ix.W && v >= 0.f && v < (float)ix.H) {
-                    const int p = ix.transposed ? (int)floorf(u) * ix.H + (int)floorf(v) : (int)floorf(v) * ix.W + (int)floorf(u);
-                    zmin_key(&ix.keys[p], ((unsigned long long)__float_as_uint(h.z) << 32) | (unsigned)i);
-                }
-            }
-        }
+    float4 pc = s.pc[i], ct = s.ct[i], nr = s.nr[i];
+    const float4 mp = cand_rec[c * 3 + 0], mc = cand_rec[c * 3 + 1], mn = cand_rec[c * 3 + 2];
+    const float c_k = pc.w, a = mp.w;
+    if (mn.w < (1.0f + 0.5f) * nr.w) {
+        pc = make_float4(((c_k * pc.x) + (a * mp.x)) / (c_k + a), ((c_k * pc.y) + (a * mp.y)) / (c_k + a),
+                         ((c_k * pc.z) + (a * mp.z)) / (c_k + a), c_k + a);
+        const float3 oc = decode_color(ct.x), nc = decode_color(mc.x);
+        ct = make_float4(encode_color(((c_k * oc.x) + (a * nc.x)) / (c_k + a), ((c_k * oc.y) + (a * nc.y)) / (c_k + a),
+                                      ((c_k * oc.z) + (a * nc.z)) / (c_k + a)),
+                         ct.y, ct.z, time);
+        const float4 av = make_float4(((c_k * nr.x) + (a * mn.x)) / (c_k + a), ((c_k * nr.y) + (a * mn.y)) / (c_k + a),
+                                      ((c_k * nr.z) + (a * mn.z)) / (c_k + a), ((c_k * nr.w) + (a * mn.w)) / (c_k + a));
+        const float3 nn = normalize_gl(f3(av.x, av.y, av.z));
+        nr = make_float4(nn.x, nn.y, nn.z, av.w);
+        s.pc[i] = pc; s.ct[i] = ct; s.nr[i] = nr;
+    } else {
+        pc.w = c_k + a;
+        ct.w = time;
+        s.pc[i] = pc; s.ct[i] = ct;
     }
 }
 
-__global__ __launch_bounds__(256) void k_fuse_update(Surfels src, Surfels dst, const FrameDev* __restrict__ frame,
-                                                     int* __restrict__ upd_first, const float4* __restrict__ cand_rec,
-                                                     const IndexScatterArgs ix) {
-    fuse_update_body(src, dst, frame, upd_first, cand_rec, ix);
+__global__ __launch_bounds__(256) void k_fuse_update(Surfels s, const FrameDev* __restrict__ frame, int* __restrict__ upd_first,
+                                                     const uint8_t* __restrict__ cand_op, const int* __restrict__ cand_best,
+                                                     const float4* __restrict__ cand_rec, int W, int H) {
+    fuse_update_body(s, frame, upd_first, cand_op, cand_best, cand_rec, W, H);
 }
 
-void launch_fuse_update(Surfels src, Surfels dst, const FrameDev* frame, int* upd_first, const float4* cand_rec, const PoseDev* pose,
-                        int W, int H, Intr k, float maxDepth, int timeDelta, unsigned long long* keys_or_null, bool transposed,
-                        hipStream_t s, int blocks) {
-    IndexScatterArgs ix{pose, W, H, k, maxDepth, timeDelta, keys_or_null, transposed ? 1 : 0};
-    hipLaunchKernelGGL(k_fuse_update, dim3(blocks), dim3(256), 0, s, src, dst, frame, upd_first, cand_rec, ix);
+static inline int cand_blocks(int W, int H) { return (((W + 1) / 2) * ((H + 1) / 2) + 255) / 256; }
+
+void launch_fuse_update(Surfels s, const FrameDev* frame, int* upd_first, const uint8_t* cand_op, const int* cand_best, const float4* cand_rec,
+                        int W, int H, hipStream_t st) {
+    hipLaunchKernelGGL(k_fuse_update, dim3(cand_blocks(W, H)), dim3(256), 0, st, s, frame, upd_first, cand_op, cand_best, cand_rec, W, H);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -864,22 +851,25 @@ __global__ __launch_bounds__(256) void k_obj_index_scatter(const ObjBatch b) {
 __global__ __launch_bounds__(256) void k_obj_index_resolve(const ObjBatch b, int second) {
     const ObjPassArgs& m = b.m[blockIdx.z];
     if (!second) index_resolve_body(m.a, m.pose, m.keys, b.W * b.H, m.index, m.ivc, m.inr, nullptr, nullptr);
-    else index_resolve_body(m.b, m.pose, m.keys, b.W * b.H, nullptr, nullptr, nullptr, nullptr, m.iclean);
+    else index_resolve_body(m.a, m.pose, m.keys, b.W * b.H, nullptr, nullptr, nullptr, nullptr, m.iclean);
 }
 __global__ __launch_bounds__(256) void k_obj_fuse_data(const ObjBatch b) {
     const ObjPassArgs& m = b.m[blockIdx.z];
     const FuseDataArgs a{b.rgb, b.depthRaw, b.depthF, b.mask, m.maskID, m.frame, m.pose, m.weightMultiplier, m.fuseMaxDepth, b.bboxLimit, b.W, b.H, b.k,
-                         m.index, m.ivc, m.inr, m.cand_op, m.cand_rec, m.upd_first};
+                         m.index, m.ivc, m.inr, m.cand_op, m.cand_rec, m.upd_first, m.cand_best};
     fuse_data_body(a);
 }
 __global__ __launch_bounds__(256) void k_obj_fuse_update(const ObjBatch b) {
     const ObjPassArgs& m = b.m[blockIdx.z];
-    const IndexScatterArgs ix{m.pose, b.W, b.H, b.k, b.maxDepthProcessed, b.timeDelta, m.keys, 1};
-    fuse_update_body(m.a, m.b, m.frame, m.upd_first, m.cand_rec, ix);
+    fuse_update_body(m.a, m.frame, m.upd_first, m.cand_op, m.cand_best, m.cand_rec, b.W, b.H);
+}
+__global__ __launch_bounds__(256) void k_obj_index_scatter2(const ObjBatch b) {   // predictIndices after fuse (MaskFusion.cpp:556), column-major texels
+    const ObjPassArgs& m = b.m[blockIdx.z];
+    index_scatter_body(m.a, m.frame, m.pose, b.W, b.H, b.k, b.maxDepthProcessed, b.timeDelta, m.keys, 1);
 }
 __device__ __forceinline__ CleanArgs obj_clean_args(const ObjBatch& b, const ObjPassArgs& m) {
     CleanArgs a;
-    a.src = m.b; a.dst = m.a; a.frame = m.frame; a.pose = m.pose; a.W = b.W; a.H = b.H; a.k = b.k; a.timeDelta = b.timeDelta;
+    a.src = m.a; a.dst = m.b; a.frame = m.frame; a.pose = m.pose; a.W = b.W; a.H = b.H; a.k = b.k; a.timeDelta = b.timeDelta;
     a.confThreshold = m.confThreshold; a.outlierCoeff = b.outlierCoeff; a.maskID = m.maskID; a.transposed = 1; a.literal = b.cleanLiteral;
     a.index = m.index; a.vc = m.ivc; a.ct = nullptr; a.packed = m.iclean; a.depthF = b.depthF; a.mask = b.mask;
     a.cand_op = m.cand_op; a.cand_rec = m.cand_rec; a.flags = m.flags; a.newconf = m.newconf; a.block_counts = m.block_counts; a.host_count = m.host_count;
@@ -907,7 +897,8 @@ void launch_obj_fuse_clean(const ObjBatch& b, int blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_obj_index_scatter, surfels, dim3(256), 0, s, b);
     hipLaunchKernelGGL(k_obj_index_resolve, pixels, dim3(256), 0, s, b, 0);
     hipLaunchKernelGGL(k_obj_fuse_data, cands, dim3(256), 0, s, b);
-    hipLaunchKernelGGL(k_obj_fuse_update, surfels, dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_obj_fuse_update, dim3(cand_blocks(b.W, b.H), 1, b.n), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_obj_index_scatter2, surfels, dim3(256), 0, s, b);
     hipLaunchKernelGGL(k_obj_index_resolve, pixels, dim3(256), 0, s, b, 1);
     hipLaunchKernelGGL(k_obj_clean_flags, compact, dim3(256), 0, s, b);
     hipLaunchKernelGGL(k_obj_clean_compact, compact, dim3(256), 0, s, b);

@@ -34,8 +34,16 @@ def surfel_capacity(num: int) -> int:
     return d * d
 
 
+SCENE_BOXES = 6       # object boxes in the scene: with synth.Scene's ring of six, boxes 1..4 are all in view (in its ring of four, box 3 hides)
+
+
+def stream_kwargs(n_objects: int = 4, noise: bool = True) -> dict:
+    return dict(W=W, H=H, fx=F, fy=F, cx=W / 2.0, cy=H / 2.0, n_objects=SCENE_BOXES, noise=noise, object_motion=0.0, seed=1234, masked_objects=n_objects)
+
+
 def stream(n_objects: int = 4, noise: bool = True) -> synth.Stream:
-    return synth.Stream(W=W, H=H, fx=F, fy=F, cx=W / 2.0, cy=H / 2.0, n_objects=n_objects, noise=noise, object_motion=0.0, seed=1234)
+    """S3: the room with six standing boxes of which the first `n_objects` are instance-masked (the others are furniture)"""
+    return synth.Stream(**stream_kwargs(n_objects, noise))
 
 
 def make_context(device: int = 0, num_g: int = NUM_GSURFELS, num_o: int = NUM_OSURFELS, n_objects: int = 4):
@@ -56,7 +64,7 @@ def box_of_model(mf, index: int, st: synth.Stream, taken=()):
     T = models[index].getPose() @ np.linalg.inv(models[0].getPose())
     s = models[index].downloadMap()
     cw = (np.linalg.inv(T) @ np.r_[s[:, :3].astype(np.float64).mean(0), 1.0])[:3]
-    box = min((b for b in st.scene.boxes if b.instance and b.instance not in taken), key=lambda b: float(np.linalg.norm(b.center - cw)))
+    box = min((b for b in st.scene.boxes if 0 < b.instance <= st.masked_objects and b.instance not in taken), key=lambda b: float(np.linalg.norm(b.center - cw)))
     return box, T
 
 
@@ -94,7 +102,7 @@ def lead_in(mf, st: synth.Stream, frames, cls, n_objects: int = 4, fill: float =
         if len(loaded) >= n_objects or k >= max_frames:
             break
     if room_map is None:
-        bg = synth.dense_room_map(st.scene, int(1.005 * fill * cap_g), last_time=float(k))
+        bg = synth.dense_room_map(st.scene, int(1.005 * fill * cap_g), last_time=float(k), furniture_above=st.masked_objects)
     else:
         bg = room_map
         bg[:, 7] = float(k)

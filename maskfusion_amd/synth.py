@@ -170,6 +170,7 @@ class Stream:
     speed: float = 1.0
     max_depth: float = 0.0
     object_motion: float = 1.0   # 0 = the instance-masked boxes stand still
+    masked_objects: int = -1     # >= 0: only instance ids 1..masked_objects carry a mask; the other object boxes are rendered as furniture (mask 0)
 
     def __post_init__(self):
         self.scene = Scene(self.n_objects, self.seed, object_motion=self.object_motion)
@@ -182,6 +183,8 @@ class Stream:
                                              self.max_depth)
         if self.noise:
             depth = add_sensor_noise(depth, 99 + k)
+        if self.masked_objects >= 0:
+            mask = np.where(mask > self.masked_objects, 0, mask).astype(np.uint8)
         return rgb, depth, mask
 
 
@@ -232,12 +235,14 @@ def _box_faces(half):
     return faces
 
 
-def dense_room_map(scene: "Scene", n_target: int, last_time: float, conf: float = 20.0, init_time: float = 1.0, zfront: float = -1.0):
+def dense_room_map(scene: "Scene", n_target: int, last_time: float, conf: float = 20.0, init_time: float = 1.0, zfront: float = -1.0,
+                   furniture_above: int = 1 << 30):
     """A pre-filled BACKGROUND map ("pre-filled to >= 80 % capacity by a long orbit"): ~n_target surfels at uniform
     density on the room's five planes and its static boxes, world coordinates = the background model's frame (camera 0 = identity).
     Radius = sqrt(2) x spacing, what a surfel created at one surfel per pixel carries (surfels.glsl getRadius); every record is stable
     (confidence above the threshold) and active (last seen at `last_time`), with equal initTime so that Model::clean's duplicate rule
-    (copy_unstable.vert:100-106 needs an OLDER neighbour) keeps the density.  Returns (n, 12) float32 in Model::downloadMap's layout."""
+    (copy_unstable.vert:100-106 needs an OLDER neighbour) keeps the density.  Standing object boxes whose instance id is above
+    `furniture_above` carry no mask (Stream.masked_objects) and belong to the room.  Returns (n, 12) float32 in Model::downloadMap's layout."""
     x0, x1, y0, y1, z0, z1 = -2.5, 2.5, -1.5, 1.2, zfront, scene.zback
     rects = [  # (origin, ea, eb, la, lb, normal pointing out of the room, base colour)
         ((x0, y0, z1), (1, 0, 0), (0, 1, 0), x1 - x0, y1 - y0, (0, 0, 1), scene.planes[0][2]),
@@ -247,7 +252,7 @@ def dense_room_map(scene: "Scene", n_target: int, last_time: float, conf: float 
         ((x0, y0, z0), (1, 0, 0), (0, 0, 1), x1 - x0, z1 - z0, (0, -1, 0), scene.planes[4][2]),
     ]
     for bx in scene.boxes:
-        if bx.instance != 0:
+        if bx.instance != 0 and bx.instance <= furniture_above:
             continue
         for (o, ea, eb, la, lb, n) in _box_faces(bx.half):
             rects.append((o + bx.center, ea, eb, la, lb, n, bx.color))

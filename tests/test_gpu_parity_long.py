@@ -391,8 +391,9 @@ def test_config4_dense_maps(hip, oracle):
     n_dense = int(os.environ.get("MF_PARITY_C4_FRAMES", 5))
     num_g, num_o = int(os.environ.get("MF_PARITY_C4_GSURFELS", stress.NUM_GSURFELS)), int(os.environ.get("MF_PARITY_C4_OSURFELS", stress.NUM_OSURFELS))
     st = stress.stream(4)
-    kw = dict(W=st.W, H=st.H, fx=st.fx, fy=st.fy, cx=st.cx, cy=st.cy, n_objects=4, noise=True, object_motion=0.0)
-    frames = render(kw, 10 + n_dense)
+    kw = stress.stream_kwargs(4)
+    max_lead = int(os.environ.get("MF_PARITY_C4_LEADIN", 16))
+    frames = render(kw, max_lead + n_dense)
     cls = [0] + [41 + i for i in range(4)]
     W, H, f = st.W, st.H, st.fx
     o = mfo_mm.OracleMM(W, H, f, f, W / 2.0, H / 2.0, icpWeight=100.0, so3=0, capacity=stress.surfel_capacity(num_g), capacityObject=stress.surfel_capacity(num_o),
@@ -404,7 +405,7 @@ def test_config4_dense_maps(hip, oracle):
         o.force_tracking([x.getID() for x in gm], [x.getPose() for x in gm])
         o.process_frame(rgb, depth, mask, cls, depth_filtered=m.debugRead("depthF"))
 
-    k0, loaded = stress.lead_in(m, st, frames, cls, n_objects=4, on_frame=oracle_frame, on_upload=lambda i, s: o.upload_map(i, s), log=print, max_frames=10)
+    k0, loaded = stress.lead_in(m, st, frames, cls, n_objects=4, on_frame=oracle_frame, on_upload=lambda i, s: o.upload_map(i, s), log=print, max_frames=max_lead)
     assert len(loaded) == 5, loaded                                   # the background and four object models, each on its own box
     assert loaded[0] >= 0.8 * stress.surfel_capacity(num_g) and min(loaded[i] for i in range(1, 5)) >= 0.8 * stress.surfel_capacity(num_o)
     worst_lab = 0.0
