@@ -168,9 +168,7 @@ int mf_get_last_fillin(mf_ctx* ctx, int32_t* used);
  * "splatTiles" (1), "globalTiles" (1: GlobalProjection of the background through tile lists), "gpuLabels" (1: label stage on the
  * device), "batchTracking" (1: one Gauss-Newton launch serves every tracked model), "earlyBackgroundFusion" (1), "overlapPreprocessing"
  * (0), "cleanLiteralWindow" (1: Model::clean walks its window with copy_unstable.vert's own fp32 trip count, 4 or 5 taps per axis;
- * 0: 4 x 4), "timings", "icpProfile", "gnLoopGraph" (0; 1: the launches of the geometric Gauss-Newton loop of a tracking step are captured
- * once per frame parity with hipStreamBeginCapture / EndCapture and replayed as one hipGraphLaunch -- same kernels, same arguments, same
- * bits; if the runtime refuses the capture the eager launches are used and mf_get_param reads 0 again), "objectSmallGrids" (1; 1: the grid-stride
+ * 0: 4 x 4), "timings", "icpProfile", "objectSmallGrids" (1; 1: the grid-stride
  * surfel kernels of an object model run on a grid sized from its last known surfel count instead of 2048 workgroups), "objectScatterSplat" (1;
  * 1: object models are predicted with the scatter form of the splat instead of tile lists) -- both leave every result bit-identical; measured on
  * MI355X on the 12-model S2 scene: 394 -> 407 frames/s with both (profiles/r03a_bench_2s_object_switches.txt), on since round 3;

@@ -13,12 +13,8 @@
 #include <stdio.h>
 #include <string.h>
 #include <memory>
-#include <atomic>
 #include <chrono>
-#include <condition_variable>
-#include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
 
 using namespace mf;
@@ -45,19 +41,15 @@ struct ModelState {
     // object models: private scratch of the surfel passes, so that the passes of ALL objects of a frame can be one launch each ("batchObjectPasses")
     struct ObjScratch {
         unsigned long long* keys = nullptr; int* index = nullptr; float4* ivc = nullptr; float4* inr = nullptr; float4* iclean = nullptr;
-        uint8_t* cand_op = nullptr; float4* cand_rec = nullptr; int* upd_first = nullptr; uint8_t* flags = nullptr; float* newconf = nullptr;
-        int* block_counts = nullptr;
+        uint8_t* cand_op = nullptr; float4* cand_rec = nullptr; int* upd_first = nullptr; int* cand_best = nullptr;
+        unsigned long long* scan_state = nullptr; int* clean_ctl = nullptr;
     } scr;
     float* d_poselog = nullptr;            // Model::poseLog on the device: ring of [cap][8] floats (t, q xyzw, pad)
     std::vector<int64_t> log_ts;           // timestamps of the entries (host side of PoseLogItem)
     PoseDev* h_pose = nullptr; FrameDev* h_frame = nullptr; int* h_count = nullptr;
     TrackModelDev track_host;              // host copy of *d_track (pose_host is filled in once h_pose exists)
-    // "gnLoopGraph": the launches of the geometric Gauss-Newton loop captured once per frame parity and replayed as one hipGraph
-    hipGraphExec_t gn_graph[2] = {nullptr, nullptr};
-    unsigned gn_graph_key[2] = {0, 0};     // iteration schedule the graph was captured for
     std::vector<void*> allocs;
     ~ModelState() {
-        for (int i = 0; i < 2; ++i) if (gn_graph[i]) (void)hipGraphExecDestroy(gn_graph[i]);
         for (void* p : allocs) (void)hipFree(p);
         if (h_pose) (void)hipHostFree(h_pose);
         if (h_frame) (void)hipHostFree(h_frame);
@@ -130,59 +122,6 @@ struct LabelsScratch {
 
 }  // namespace
 
-// One helper thread per context that copies a plane of the caller's frame into the pinned staging slot while the calling thread copies the
-// other (mf_process_frame, "hostInputAsync"): the 2.15 MB of a VGA frame cost a single thread ~0.2 ms -- more than enqueueing the frame's 34
-// launches -- and were what kept the host-pointer boundary below the device-resident rate.  Started on first use, joined in mf_destroy.
-struct CopyWorker {
-    std::thread th;
-    std::mutex m;
-    std::condition_variable cv;
-    void* dst = nullptr; const void* src = nullptr; size_t n = 0;
-    std::atomic<unsigned> posted{0}, done{0};
-    std::atomic<bool> sleeping{false}, quit{false};
-    // The helper spins for a couple of milliseconds after a job before it goes to sleep: a streaming caller posts the next job ~0.3 ms later,
-    // and waking a sleeping thread costs 30-60 us -- as much as the half of the copy it is supposed to take off the caller (first version of
-    // round 4: 2 309 -> 2 310 frames/s).  An idle context sleeps on the condition variable.
-    void run() {
-        unsigned seen = 0;
-        for (;;) {
-            const auto t0 = std::chrono::steady_clock::now();
-            unsigned spins = 0;
-            while (posted.load(std::memory_order_acquire) == seen && !quit.load(std::memory_order_acquire)) {
-                __builtin_ia32_pause();
-                if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
-                    std::unique_lock<std::mutex> lk(m);
-                    sleeping.store(true);
-                    cv.wait(lk, [&] { return posted.load(std::memory_order_acquire) != seen || quit.load(std::memory_order_acquire); });
-                    sleeping.store(false);
-                    break;
-                }
-            }
-            if (quit.load(std::memory_order_acquire)) return;
-            memcpy(dst, src, n);
-            ++seen;
-            done.store(seen, std::memory_order_release);
-        }
-    }
-    void post(void* d, const void* sp, size_t bytes) {
-        dst = d; src = sp; n = bytes;
-        posted.fetch_add(1, std::memory_order_release);
-        if (!th.joinable()) th = std::thread([this] { run(); });
-        if (sleeping.load()) { std::lock_guard<std::mutex> g(m); cv.notify_one(); }
-    }
-    void wait() {
-        const unsigned p = posted.load(std::memory_order_acquire);
-        while (done.load(std::memory_order_acquire) != p) __builtin_ia32_pause();
-    }
-    ~CopyWorker() {
-        if (th.joinable()) {
-            quit.store(true, std::memory_order_release);
-            { std::lock_guard<std::mutex> g(m); cv.notify_one(); }
-            th.join();
-        }
-    }
-};
-
 struct mf_ctx {
     mf_config cfg;
     int W, H, P;
@@ -224,35 +163,16 @@ struct mf_ctx {
     ObjPassArgs* d_obj_args[kObjArgSlots] = {}; ObjPassArgs* h_obj_args[kObjArgSlots] = {}; hipEvent_t ev_obj_args[kObjArgSlots] = {};
     unsigned obj_arg_slot = 0;
     bool ftf_rgb = false;                              // MaskFusion::frameToFrameRGB ("-ftf"; Model.cpp:399-400,981): the photometric term tracks against the previous RAW frame
-    bool gn_loop_graph = false;                        // the launch-per-iteration loop replayed as a captured hipGraph ("gnLoopGraph")
-    // "frameGraph" (a switch, default off): the WHOLE single-model frame of mf_process_frame (host pointers) as one captured hipGraph per
-    // buffer combination -- input slot x map parity x filtered-depth ring slot = 12 -- replayed with one hipGraphLaunch.  It takes the host's
-    // share of a call from 89 to 15 us (profiles/r04i_*), bit-identical results (tests/test_gpu_api.py), but the GPU needs ~9 us MORE per
-    // frame than for the 34 eager launches (profiles/r04o_host_ab.json: 333 against 324 us per frame; the pose-log entry, whose slot moves
-    // every frame, is a launch of its own behind the graph) and the call is paced by the GPU either way -- so eager launches are the default
-    // and the graph is there for a caller that wants its host thread back.  Only arguments that are constant for a combination are baked in
-    // (a key of the weight multiplier and a configuration epoch re-captures when they change).
-    bool frame_graph = false;
-    bool capturing_frame = false;                      // inside the capture: no pose-log slot, no time stamp (the caller adds them behind the graph)
-    unsigned long long cfg_epoch = 1;                  // bumped by every mf_set_param / lifecycle call: whatever a graph baked in may have changed
-    struct FrameGraph { hipGraphExec_t exec = nullptr; unsigned long long key = 0; };
-    FrameGraph frame_graphs[12];
-    long frame_graph_launches = 0;                     // (debug tap: "frameGraphLaunches")
     double host_us[5] = {0, 0, 0, 0, 0}; long host_calls = 0;   // mf_process_frame's host time: wait for the slot + staging copy | upload enqueue | frame enqueue | whole call | the wait alone ("hostStageUs" ... "hostWaitUs")
-    hipEvent_t ev_tracked = nullptr;                       // the frame's tracking has run (recorded by every frame that tracks)
-    bool upload_after_tracking = false;                    // "hostUploadAfterTracking": frame k+1's upload starts when frame k has tracked (under its surfel passes, not under its launch chain)
     // "hostLockstep" (default on): the call waits for frame k-2 to have RUN before it enqueues frame k's upload, so the host is at most two
     // frames ahead and the upload's dependency (the frame that last read the device block) is already satisfied when it is enqueued.  Left
     // to run three frames ahead, every frame pays ~40 us for cross-queue dependencies that are still open at enqueue time
-    // (profiles/r04o_host_ab.json: 364 -> 333 us per frame with the frame graph, 352 -> 324 us with eager launches; device-resident: 305)
+    // (profiles/r04o_host_ab.json: 352 -> 324 us per frame; device-resident: 305)
     bool host_lockstep = true;
-    bool copy_helper = true;                               // "hostCopyHelper": 0 = the calling thread stages the whole frame itself
     // "hostWaitUpload" (default on, needs hostLockstep): the call also waits for its OWN upload (~60 us of the ~300 the host has to spare per
     // frame) before it enqueues the frame, which then needs no cross-queue wait at all: 322 -> 317 us per frame (profiles/r04q_host_ab.json;
-    // device-resident frames: 305).  The staging helper thread makes no difference any more (322.2 against 322.1): staging is off the critical path.
+    // device-resident frames: 305).
     bool host_wait_upload = true;
-    bool upload_kernel = false;                            // "hostUploadKernel": a copy kernel reading the pinned block over PCIe instead of the DMA engine
-    bool upload_on_main = false;                           // "hostUploadOnMain": the upload on the frame's own stream (no overlap with the previous frame; a measurement switch)
 
     // frame-level
     uint8_t* d_rgb = nullptr; float* d_depth = nullptr; uint8_t* d_mask_in = nullptr; uint8_t* d_zero_mask = nullptr;
@@ -269,7 +189,6 @@ struct mf_ctx {
     hipEvent_t ev_in_copied[2] = {nullptr, nullptr};       // the slot's H2D copies have completed   (in -> main / pre, and the host before it refills the slot)
     hipEvent_t ev_in_consumed[2] = {nullptr, nullptr};     // the frame that read the slot has been processed   (main -> in)
     unsigned in_slot = 0;
-    std::unique_ptr<CopyWorker> copy_worker;
     uint8_t* d_mask_tex = nullptr;  // textureMask: the last full segmentation (Core/MaskFusion.cpp:297)
     float* d_depthF[3] = {nullptr, nullptr, nullptr};  // ring: frame k filters into [k % 3], fill-in reads [(k - 1) % 3]
     float* d_vmap[2][3] = {}; float* d_nmap[2][3] = {};
@@ -304,6 +223,8 @@ struct mf_ctx {
     float4* d_iclean = nullptr;            // packed column-major index map of the clean pass: 2 x float4 per texel
     uint8_t* d_cand_op = nullptr; float4* d_cand_rec = nullptr; int* d_upd_first = nullptr;
     uint8_t* d_flags = nullptr; float* d_newconf = nullptr; int* d_block_counts = nullptr;
+    int* d_cand_best = nullptr;            // surfel a merge candidate was associated with (fuse_data -> fuse_update)
+    unsigned long long* d_scan_state = nullptr; int* d_clean_ctl = nullptr; unsigned clean_epoch = 0;   // Model::clean's decoupled look-back (mf_surfel.hip)
     unsigned long long* d_icp_prof = nullptr;
     unsigned long long* d_splat_prof = nullptr; bool splat_prof_on = false;   // "splatProfile": [tiles][8] stamps of the background's tile pass
     // multi-model coupling
@@ -421,9 +342,9 @@ static int ensure_obj_scratch(mf_ctx* c, ModelState& m) {
     A(dev_alloc(c, m.allocs, &m.scr.cand_op, P));
     A(dev_alloc(c, m.allocs, &m.scr.cand_rec, P * 3));
     A(dev_alloc(c, m.allocs, &m.scr.upd_first, cap));
-    A(dev_alloc(c, m.allocs, &m.scr.flags, cap + P));
-    A(dev_alloc(c, m.allocs, &m.scr.newconf, cap + P));
-    A(dev_alloc(c, m.allocs, &m.scr.block_counts, (size_t)kCompactBlocks));
+    A(dev_alloc(c, m.allocs, &m.scr.cand_best, P));
+    A(dev_alloc(c, m.allocs, &m.scr.scan_state, clean_scan_entries((long)cap + (long)P)));
+    A(dev_alloc(c, m.allocs, &m.scr.clean_ctl, 2));
 #undef A
     launch_fill_int(m.scr.upd_first, kNoUpdate, (int)cap, c->stream);
     return MF_OK;
@@ -541,7 +462,6 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
             hipEventCreateWithFlags(&c->ev_in_consumed[i], hipEventDisableTiming) != hipSuccess) return fail(MF_EHIP);
     }
     if (hipStreamCreateWithFlags(&c->stream_in, hipStreamNonBlocking) != hipSuccess) return fail(MF_EHIP);
-    if (hipEventCreateWithFlags(&c->ev_tracked, hipEventDisableTiming) != hipSuccess) return fail(MF_EHIP);
     A(dev_alloc(c, c->allocs, &c->d_zero_mask, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_mask_tex, (size_t)P));
     for (int b = 0; b < 3; ++b) A(dev_alloc(c, c->allocs, &c->d_depthF[b], (size_t)P));
@@ -596,6 +516,9 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     A(dev_alloc(c, c->allocs, &c->d_flags, (size_t)c->cap_max + P));
     A(dev_alloc(c, c->allocs, &c->d_newconf, (size_t)c->cap_max + P));
     A(dev_alloc(c, c->allocs, &c->d_block_counts, (size_t)kCompactBlocks));
+    A(dev_alloc(c, c->allocs, &c->d_cand_best, (size_t)P));
+    A(dev_alloc(c, c->allocs, &c->d_scan_state, clean_scan_entries((long)c->cap_max + (long)P)));
+    A(dev_alloc(c, c->allocs, &c->d_clean_ctl, 2));
     A(dev_alloc(c, c->allocs, &c->d_icp_prof, (size_t)20 * 16));
     A(dev_alloc(c, c->allocs, &c->d_edge, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_bin, (size_t)P));
@@ -652,13 +575,11 @@ extern "C" void mf_destroy(mf_ctx* c) {
         if (c->ev_pre_done[i]) (void)hipEventDestroy(c->ev_pre_done[i]);
         if (c->ev_main_done[i]) (void)hipEventDestroy(c->ev_main_done[i]);
     }
-    for (auto& g : c->frame_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (c->ev_labels) (void)hipEventDestroy(c->ev_labels);
     if (c->ev_staged) (void)hipEventDestroy(c->ev_staged);
     for (int i = 0; i < 2; ++i) {
         if (c->ev_in_copied[i]) (void)hipEventDestroy(c->ev_in_copied[i]);
         if (c->ev_in_consumed[i]) (void)hipEventDestroy(c->ev_in_consumed[i]);
-        if (i == 0 && c->ev_tracked) (void)hipEventDestroy(c->ev_tracked);
     }
     if (c->stream_in) { (void)hipStreamSynchronize(c->stream_in); (void)hipStreamDestroy(c->stream_in); }
     for (int i = 0; i < mf_ctx::kObjArgSlots; ++i) {
@@ -725,7 +646,7 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
     const bool timed = c->timings_on && &m == c->models[0].get();
     if (timed) { (void)hipEventRecord(c->ev_icp[0], s); c->tracked_once = true; c->icp_mid_recorded = false; }
     int k = 0, nb_prev = 0, prev_level = -1;
-    // every launch of the loop and its finalize; called once eagerly, or once under stream capture (gnLoopGraph)
+    // every launch of the loop and its finalize
     auto issue_loop = [&](bool with_marks) {
     for (int lvl = 2; lvl >= 0; --lvl) {
         const float div = (float)(1 << lvl);
@@ -781,31 +702,6 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
                              nb_prev ? c->d_cnt[(k + 1) & 1] : nullptr, nb_prev, g.icp_weight, icp ? 1 : 0, g.rgb_only ? 1 : 0, 1,
                              prev_level, &m.d_gn[k & 1], so3_seed, m.d_pose, m.h_pose, log_out, jump_limit, s);
     };
-    // "gnLoopGraph": the loop is a chain of launch-bound launches whose arguments depend only on the frame parity -> capture it once per
-    // parity, replay it with one hipGraphLaunch.  Geometric term without SO(3) seed and without profiling stamps only; any failure of the
-    // capture API falls back to the eager launches below (and switches the option off), it is never an error.
-    if (c->gn_loop_graph && !rgb && !so3_seed && !c->icp_prof_on) {
-        const unsigned key = 1u + (unsigned)iters[0] + 16u * (unsigned)iters[1] + 256u * (unsigned)iters[2] + 4096u * (unsigned)(jump_limit > 0.f);
-        if (!m.gn_graph[set] || m.gn_graph_key[set] != key) {
-            if (m.gn_graph[set]) { (void)hipGraphExecDestroy(m.gn_graph[set]); m.gn_graph[set] = nullptr; }
-            hipGraph_t graph = nullptr;
-            bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
-            if (ok) {
-                issue_loop(false);
-                ok = hipStreamEndCapture(s, &graph) == hipSuccess && graph != nullptr;
-            }
-            if (ok) ok = hipGraphInstantiate(&m.gn_graph[set], graph, nullptr, nullptr, 0) == hipSuccess;
-            if (graph) (void)hipGraphDestroy(graph);
-            if (!ok) { (void)hipGetLastError(); m.gn_graph[set] = nullptr; c->gn_loop_graph = false; }
-            m.gn_graph_key[set] = key;
-            k = 0; nb_prev = 0; prev_level = -1;
-        }
-        if (m.gn_graph[set] && hipGraphLaunch(m.gn_graph[set], s) == hipSuccess) {
-            if (timed) (void)hipEventRecord(c->ev_icp[1], s);
-            return;
-        }
-        c->gn_loop_graph = false;
-    }
     issue_loop(true);
 }
 
@@ -857,6 +753,17 @@ static int surfel_blocks(const mf_ctx* c, const ModelState& m) {
 }
 
 // predictIndices -> fuse -> [predictIndices] -> clean for one model (Core/MaskFusion.cpp:541-563 / :344-353)
+// workgroups of a clean launch for model m: sized from its last known count (pinned mirror; the chunks are drawn from a ticket counter,
+// so a stale value costs a workgroup a few more rounds, never a result)
+static int clean_blocks(const mf_ctx* c, const ModelState& m) {
+    return clean_grid((long)*m.h_count + (long)c->P / 2);
+}
+static unsigned next_clean_epoch(mf_ctx* c) {
+    c->clean_epoch = (c->clean_epoch + 1u) & 0x3FFFFFFFu;
+    if (c->clean_epoch == 0) c->clean_epoch = 1;
+    return c->clean_epoch;
+}
+
 static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, const float* d_depth, const float* depthF,
                                const uint8_t* mask, float fuseDepthCutoff, float weightMultiplier, bool secondIndexPass, bool marks) {
     const mf_config& g = c->cfg;
@@ -870,19 +777,19 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
     if (marks) mark(c, 4);
     // Model::fuse maxDepth uniform: min(depthCutoff, model.maxDepth, bb_max_z) (Model.cpp:527); bb_max_z from the model's bounding box on the device
     launch_fuse_data(d_rgb, d_depth, depthF, mask, m.id, m.d_frame, m.d_pose, weightMultiplier, fminf(fuseDepthCutoff, m.maxDepth), W, H,
-                     c->K, c->d_index, c->d_ivc, c->d_inr, c->d_cand_op, c->d_cand_rec, c->d_upd_first, s, c->bbox_limit ? 1 : 0);
+                     c->K, c->d_index, c->d_ivc, c->d_inr, c->d_cand_op, c->d_cand_rec, c->d_upd_first, c->d_cand_best, s, c->bbox_limit ? 1 : 0);
     if (marks) mark(c, 5);
-    // the scatter half of the second predictIndices (:556) rides on the update pass
-    launch_fuse_update(m.surf[src], m.surf[dst], m.d_frame, c->d_upd_first, c->d_cand_rec, m.d_pose, W, H, c->K, g.max_depth_processed,
-                       g.time_delta, secondIndexPass ? c->d_keys : nullptr, true, s, blocks);
+    // update.vert in place: only the surfels a candidate merged into are touched (the reference copies the whole buffer, Model.cpp:583-646)
+    launch_fuse_update(m.surf[src], m.d_frame, c->d_upd_first, c->d_cand_op, c->d_cand_best, c->d_cand_rec, W, H, s);
     if (marks) mark(c, 6);
-    if (secondIndexPass) {
-        launch_index_resolve(m.surf[dst], m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, s);
+    if (secondIndexPass) {   // predictIndices on the updated buffer (:556), column-major packed texels for clean's window gathers
+        launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, true, s, blocks);
+        launch_index_resolve(m.surf[src], m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, s);
     }
-    launch_clean(m.surf[dst], m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.time_delta, m.confThr, g.outlier_coefficient, m.id,
-                 c->d_index, c->d_ivc, c->d_ict, secondIndexPass ? c->d_iclean : nullptr, depthF, mask, c->d_cand_op, c->d_cand_rec, c->d_flags, c->d_newconf,
-                 c->d_block_counts, m.h_count, secondIndexPass, c->clean_literal, s);
-    // two swaps (fuse, clean) leave the live buffer where it started
+    launch_clean(m.surf[src], m.surf[dst], m.d_frame, m.d_pose, W, H, c->K, g.time_delta, m.confThr, g.outlier_coefficient, m.id,
+                 c->d_index, c->d_ivc, c->d_ict, secondIndexPass ? c->d_iclean : nullptr, depthF, mask, c->d_cand_op, c->d_cand_rec, nullptr, nullptr,
+                 c->d_scan_state, c->d_clean_ctl, next_clean_epoch(c), clean_blocks(c, m), m.h_count, secondIndexPass, c->clean_literal, s);
+    m.cur = dst;   // one copying pass per frame (clean): the live buffer alternates
 }
 
 // MaskFusion::predict for one model: combinedPredict(maxDepthProcessed, tick, tick, timeDelta) -- the fill-in half
@@ -927,8 +834,8 @@ static int make_obj_batch(mf_ctx* c, const std::vector<ModelState*>& ms, const s
         a.frame = m.d_frame; a.pose = m.d_pose;
         a.maskID = m.id; a.confThreshold = m.confThr; a.fuseMaxDepth = fminf(g.depth_cutoff, m.maxDepth); a.weightMultiplier = weightMultiplier;
         a.keys = m.scr.keys; a.index = m.scr.index; a.ivc = m.scr.ivc; a.inr = m.scr.inr; a.iclean = m.scr.iclean;
-        a.cand_op = m.scr.cand_op; a.cand_rec = m.scr.cand_rec; a.upd_first = m.scr.upd_first; a.flags = m.scr.flags; a.newconf = m.scr.newconf;
-        a.block_counts = m.scr.block_counts; a.host_count = m.h_count;
+        a.cand_op = m.scr.cand_op; a.cand_rec = m.scr.cand_rec; a.upd_first = m.scr.upd_first; a.cand_best = m.scr.cand_best;
+        a.scan_state = m.scr.scan_state; a.clean_ctl = m.scr.clean_ctl; a.host_count = m.h_count;
         a.predV = m.d_predV; a.predN = m.d_predN; a.predImage = m.d_predImage; a.predTime = m.d_predTime; a.predGray = gray ? m.d_predGray : nullptr;
         a.host_frame = m.h_frame; a.log_slot = log_slots ? (*log_slots)[i] : nullptr;
         a.global_payload = ((unsigned)orders[i] << 8) | ((unsigned)m.id & 255u);
@@ -938,7 +845,7 @@ static int make_obj_batch(mf_ctx* c, const std::vector<ModelState*>& ms, const s
     MF_HIP(c, hipEventRecord(c->ev_obj_args[slot], c->stream));
     b.m = c->d_obj_args[slot]; b.n = (int)ms.size();
     b.W = c->W; b.H = c->H; b.k = c->K; b.maxDepthProcessed = g.max_depth_processed; b.globalMaxDepth = g.depth_cutoff; b.timeDelta = g.time_delta;
-    b.outlierCoeff = g.outlier_coefficient; b.cleanLiteral = c->clean_literal ? 1 : 0; b.bboxLimit = c->bbox_limit ? 1 : 0;
+    b.outlierCoeff = g.outlier_coefficient; b.cleanLiteral = c->clean_literal ? 1 : 0; b.bboxLimit = c->bbox_limit ? 1 : 0; b.cleanEpoch = 0;
     b.rgb = d_rgb; b.depthRaw = d_depth; b.depthF = depthF; b.mask = mask; b.bg_pose = c->models[0]->d_pose; b.global_keys = c->d_keys;
     return MF_OK;
 }
@@ -1088,7 +995,11 @@ static int enqueue_fusion_loop(mf_ctx* c, size_t first, bool multi, const uint8_
         ObjBatch ob; int blocks = 0;
         int rc = make_obj_batch(c, objs, orders, d_rgb, d_depth, depthF, mask, weight_multiplier, nullptr, ob, blocks);
         if (rc != MF_OK) return rc;
-        launch_obj_fuse_clean(ob, blocks, c->stream);
+        ob.cleanEpoch = next_clean_epoch(c);
+        int cblocks = 8;
+        for (ModelState* m : objs) cblocks = std::max(cblocks, clean_blocks(c, *m));
+        launch_obj_fuse_clean(ob, blocks, cblocks, c->stream);
+        for (ModelState* m : objs) m->cur = 1 - m->cur;   // fuse in place, clean a -> b: b is the live buffer now
     }
     return MF_OK;
 }
@@ -1100,7 +1011,7 @@ static int enqueue_predict_loop(mf_ctx* c, size_t first, bool may_batch, int64_t
     const mf_config& g = c->cfg;
     ModelState& bg = *c->models[0];
     auto log_slot = [&](ModelState& m) -> float* {   // MaskFusion.cpp:580-596
-        if (!m.d_poselog || c->capturing_frame) return nullptr;   // (captured frame: the entry is a launch of its own behind the graph)
+        if (!m.d_poselog) return nullptr;
         float* slot = m.d_poselog + (m.log_ts.size() % (size_t)g.pose_log_capacity) * 8;
         m.log_ts.push_back(timestamp);
         return slot;
@@ -1242,9 +1153,6 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
         enqueue_tracking_loop(c, 0, g.track_all_models != 0, depthF_prev, k);
         if (bootstrap && in_pose16) launch_override_pose(bg.d_pose, in_pose16, 1, bg.h_pose, s);   // :280-283 (after the object loop)
         mark(c, 3);
-        // the next host frame's upload may be told to start here (mf_process_frame).  Eager launches only: an external event record inside the
-        // captured frame (hipEventRecordWithFlags(.., hipEventRecordExternal)) is refused by this runtime with hipErrorInvalidValue (r04n)
-        if (c->upload_after_tracking && !c->capturing_frame) (void)hipEventRecord(c->ev_tracked, s);
         if (c->overlap) { MF_HIP(c, hipEventRecord(c->ev_main_done[set], s)); main_done_recorded = true; }
 
         if (multi) {
@@ -1413,72 +1321,6 @@ extern "C" int mf_sync(mf_ctx* c) {
     return MF_OK;
 }
 
-// One single-model frame of mf_process_frame through the frame graph (see mf_ctx::frame_graph).  d_rgb / d_depth: input slot `slot`.
-static int process_frame_graphed(mf_ctx* c, int slot, float weight_multiplier, int64_t timestamp) {
-    const mf_config& g = c->cfg;
-    ModelState& bg = *c->models[0];
-    const long k = c->frame_no;
-    const int set = (int)(k & 1), ring = (int)(k % 3);
-    const bool rgbd = photometric_on(c) || g.so3 != 0;
-    const bool so3_active = g.so3 != 0 && c->gray_frame[set ^ 1] == k - 1;   // what enqueue_track will find once this frame's pyramid exists
-    unsigned wm_bits; memcpy(&wm_bits, &weight_multiplier, 4);
-    const unsigned long long key = (c->cfg_epoch << 34) ^ ((unsigned long long)wm_bits << 2) ^ (so3_active ? 2ull : 0ull) ^ 1ull;
-    mf_ctx::FrameGraph& fg = c->frame_graphs[(slot * 2 + set) * 3 + ring];
-    bool launched = false;
-    if (fg.exec && fg.key == key) {
-        if (hipGraphLaunch(fg.exec, c->stream) == hipSuccess) {
-            // the host-side half of process_frame_impl for this branch (everything the enqueue functions do besides launching)
-            c->cur_rgb = c->d_in_rgb[slot]; c->cur_depth = c->d_in_depth[slot];
-            if (rgbd) { c->gray_frame[set] = k; if (photometric_on(c)) c->deriv_frame = k; }
-            bg.pred_gray_valid = photometric_on(c);
-            bg.age++;
-            c->lastF = ring; c->frame_no++; c->host_tick++;
-            launched = true;
-        } else { (void)hipGetLastError(); c->frame_graph = false; }
-    } else {
-        if (fg.exec) { (void)hipGraphExecDestroy(fg.exec); fg.exec = nullptr; }
-        // capture this frame's launches (the enqueue code runs as usual -- host bookkeeping included -- its launches land in the graph)
-        struct { long frame_no; int host_tick, lastF; const uint8_t* cur_rgb; const float* cur_depth; long gray[2], deriv; unsigned age; bool pgv; } snap =
-            {c->frame_no, c->host_tick, c->lastF, c->cur_rgb, c->cur_depth, {c->gray_frame[0], c->gray_frame[1]}, c->deriv_frame, bg.age, bg.pred_gray_valid};
-        hipGraph_t graph = nullptr;
-        bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-        int rc = MF_OK;
-        if (ok) {
-            c->capturing_frame = true;
-            rc = process_frame_impl(c, c->d_in_rgb[slot], c->d_in_depth[slot], nullptr, nullptr, 0, weight_multiplier, timestamp);
-            c->capturing_frame = false;
-            ok = hipStreamEndCapture(c->stream, &graph) == hipSuccess && graph != nullptr && rc == MF_OK;
-        }
-        if (ok) ok = hipGraphInstantiate(&fg.exec, graph, nullptr, nullptr, 0) == hipSuccess;
-        if (graph) (void)hipGraphDestroy(graph);
-        if (ok) ok = hipGraphLaunch(fg.exec, c->stream) == hipSuccess;
-        if (ok) { fg.key = key; launched = true; }
-        else {
-            // the runtime refused: nothing of this frame has run.  Undo the bookkeeping of the captured pass and take the eager path for good.
-            (void)hipGetLastError();
-            if (fg.exec) { (void)hipGraphExecDestroy(fg.exec); fg.exec = nullptr; }
-            c->frame_no = snap.frame_no; c->host_tick = snap.host_tick; c->lastF = snap.lastF; c->cur_rgb = snap.cur_rgb; c->cur_depth = snap.cur_depth;
-            c->gray_frame[0] = snap.gray[0]; c->gray_frame[1] = snap.gray[1]; c->deriv_frame = snap.deriv; bg.age = snap.age; bg.pred_gray_valid = snap.pgv;
-            c->frame_graph = false;
-            if (rc != MF_OK) return rc;
-        }
-    }
-    if (!launched)
-        return process_frame_impl(c, c->d_in_rgb[slot], c->d_in_depth[slot], nullptr, nullptr, 0, weight_multiplier, timestamp);
-    c->frame_graph_launches++;
-    if (bg.d_poselog) {   // MaskFusion.cpp:580-596, behind the graph: the pose is final once tracking has run
-        float* lslot = bg.d_poselog + (bg.log_ts.size() % (size_t)g.pose_log_capacity) * 8;
-        bg.log_ts.push_back(timestamp);
-        launch_pose_log(bg.d_pose, nullptr, lslot, c->stream);
-    }
-    return check_launch(c);
-}
-
-// measurement switch "hostUploadKernel": the packed host block fetched by a few workgroups instead of the DMA engine (16 B per lane and step)
-static __global__ void __launch_bounds__(256) k_upload_block(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
-}
-
 extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* depth, const uint8_t* mask, const int32_t* class_ids,
                                 int32_t n_masks, int64_t timestamp, const float* in_pose16, float weight_multiplier, int32_t bootstrap) {
     if (!c || !rgb || !depth) return MF_EINVAL;
@@ -1492,43 +1334,24 @@ extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* dept
         MF_HIP(c, hipEventSynchronize(c->ev_in_copied[slot]));        // the staging slot's previous upload (two frames ago) has left it
         const auto t_w = std::chrono::steady_clock::now();
         uint8_t* h = c->h_in[slot];
-        if (c->copy_helper) {
-            if (!c->copy_worker) c->copy_worker.reset(new CopyWorker());
-            c->copy_worker->post(h, depth, P * sizeof(float));        // the helper thread takes the depth plane (4 P bytes) ...
-        } else {
-            memcpy(h, depth, P * sizeof(float));
-        }
-        memcpy(h + c->in_off_rgb, rgb, P * 3);                        // ... this one colour and mask (3 P + P)
+        memcpy(h, depth, P * sizeof(float));                           // depth | colour | mask: one packed block, one upload
+        memcpy(h + c->in_off_rgb, rgb, P * 3);
         if (mask) memcpy(h + c->in_off_mask, mask, P);
-        if (c->copy_helper) c->copy_worker->wait();
         const auto t_1 = std::chrono::steady_clock::now();
-        hipStream_t sup = c->upload_on_main ? c->stream : c->stream_in;
+        hipStream_t sup = c->stream_in;
         if (c->host_lockstep) MF_HIP(c, hipEventSynchronize(c->ev_in_consumed[slot]));   // (frame k-2 has run: at most two frames are queued)
-        if (!c->upload_on_main) MF_HIP(c, hipStreamWaitEvent(sup, c->ev_in_consumed[slot], 0));   // the frame that read this device block is done
-        // (a scheduling hint on top of that: the previous frame has tracked -- the 49 us of PCIe traffic land under its few long surfel passes
-        // instead of under its chain of ~25 dependent launches, whose packets and arguments cross the same link)
-        if (!c->upload_on_main && c->upload_after_tracking) MF_HIP(c, hipStreamWaitEvent(sup, c->ev_tracked, 0));
+        MF_HIP(c, hipStreamWaitEvent(sup, c->ev_in_consumed[slot], 0));                  // the frame that read this device block is done
         const size_t up_bytes = mask ? c->in_off_mask + P : c->in_off_rgb + P * 3;
-        if (c->upload_kernel)
-            hipLaunchKernelGGL(k_upload_block, dim3(32), dim3(256), 0, sup, reinterpret_cast<const uint4*>(h), reinterpret_cast<uint4*>(c->d_in_block[slot]),
-                               (up_bytes + 15) / 16);
-        else
-            MF_HIP(c, hipMemcpyAsync(c->d_in_block[slot], h, up_bytes, hipMemcpyHostToDevice, sup));
+        MF_HIP(c, hipMemcpyAsync(c->d_in_block[slot], h, up_bytes, hipMemcpyHostToDevice, sup));
         MF_HIP(c, hipEventRecord(c->ev_in_copied[slot], sup));
-        if (!c->upload_on_main) {
-            // (single-model frames: ~60 us of the ~300 the host has to spare.  A multi-model call synchronises in mid-frame for the label stage's
-            // decision and has no time to spare: its upload stays a cross-queue wait under the previous frame's tail)
-            if (c->host_wait_upload && c->host_lockstep && c->cfg.enable_multiple_models == 0) MF_HIP(c, hipEventSynchronize(c->ev_in_copied[slot]));
-            else MF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_in_copied[slot], 0));
-        }
+        // (single-model frames: ~60 us of the ~300 the host has to spare.  A multi-model call synchronises in mid-frame for the label stage's
+        // decision and has no time to spare: its upload stays a cross-queue wait under the previous frame's tail)
+        if (c->host_wait_upload && c->host_lockstep && c->cfg.enable_multiple_models == 0) MF_HIP(c, hipEventSynchronize(c->ev_in_copied[slot]));
+        else MF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_in_copied[slot], 0));
         if (c->overlap) MF_HIP(c, hipStreamWaitEvent(c->stream_pre, c->ev_in_copied[slot], 0));
         const auto t_2 = std::chrono::steady_clock::now();
-        // the single-model frame without a supplied pose, nothing being timed or profiled: one graph launch instead of ~34 launches
-        const bool graphed = c->frame_graph && !c->upload_after_tracking && c->cfg.enable_multiple_models == 0 && !in_pose16 && c->map_ready && !c->timings_on && !c->icp_prof_on &&
-                             !c->splat_prof_on && !c->overlap && !c->gn_loop_graph;
-        int rc = graphed ? process_frame_graphed(c, slot, weight_multiplier, timestamp)
-                         : process_frame_impl(c, c->d_in_rgb[slot], c->d_in_depth[slot], mask ? c->d_in_mask[slot] : nullptr, class_ids, n_masks,
-                                              weight_multiplier, timestamp, in_pose16, bootstrap != 0);
+        int rc = process_frame_impl(c, c->d_in_rgb[slot], c->d_in_depth[slot], mask ? c->d_in_mask[slot] : nullptr, class_ids, n_masks,
+                                    weight_multiplier, timestamp, in_pose16, bootstrap != 0);
         (void)hipEventRecord(c->ev_in_consumed[slot], c->stream);     // (also on a failed frame: the slot must become reusable)
         const auto t_3 = std::chrono::steady_clock::now();
         auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
@@ -1760,20 +1583,17 @@ extern "C" int mf_model_predict_indices(mf_ctx* c, int32_t model, int32_t time, 
 
 // Model::fuse(time, rgb, mask, depthRaw, depthFiltered, depthCutoff, weightMultiplier) (Core/Model/Model.h:142-143,
 // Model.cpp:466-647) with the staged frame's textures: data association against the index map of the last
-// mf_model_predict_indices of THIS model, then the update pass; the live buffer flips.
+// mf_model_predict_indices of THIS model, then the update pass (in place).
 extern "C" int mf_model_fuse(mf_ctx* c, int32_t model, int32_t time, float depth_cutoff, float weight_multiplier) {
     ModelState* m = model_at(c, model);
     if (!m || c->frame_no == 0) return MF_EINVAL;
     hipStream_t s = c->stream;
     const long k = staged_frame(c);
     set_model_tick(c, *m, time);
-    const int src = m->cur, dst = 1 - m->cur;
     launch_fuse_data(c->cur_rgb, c->cur_depth, c->d_depthF[k % 3], current_mask(c), m->id, m->d_frame, m->d_pose, weight_multiplier,
                      fminf(depth_cutoff, m->maxDepth), c->W, c->H, c->K, c->d_index, c->d_ivc, c->d_inr, c->d_cand_op, c->d_cand_rec,
-                     c->d_upd_first, s, c->bbox_limit ? 1 : 0);
-    launch_fuse_update(m->surf[src], m->surf[dst], m->d_frame, c->d_upd_first, c->d_cand_rec, m->d_pose, c->W, c->H, c->K,
-                       c->cfg.max_depth_processed, c->cfg.time_delta, nullptr, false, s);
-    m->cur = dst;
+                     c->d_upd_first, c->d_cand_best, s, c->bbox_limit ? 1 : 0);
+    launch_fuse_update(m->surf[m->cur], m->d_frame, c->d_upd_first, c->d_cand_op, c->d_cand_best, c->d_cand_rec, c->W, c->H, s);   // in place
     return check_launch(c);
 }
 
@@ -1789,7 +1609,8 @@ extern "C" int mf_model_clean(mf_ctx* c, int32_t model, int32_t time, int32_t ti
     const bool packed = c->model_api_packed != 0;
     launch_clean(m->surf[src], m->surf[dst], m->d_frame, m->d_pose, c->W, c->H, c->K, time_delta, m->confThr, c->cfg.outlier_coefficient, m->id,
                  c->d_index, c->d_ivc, c->d_ict, packed ? c->d_iclean : nullptr, c->d_depthF[k % 3], current_mask(c), c->d_cand_op, c->d_cand_rec,
-                 c->d_flags, c->d_newconf, c->d_block_counts, m->h_count, packed, c->clean_literal, c->stream);
+                 c->d_flags, c->d_newconf, c->d_scan_state, c->d_clean_ctl, next_clean_epoch(c), clean_blocks(c, *m), m->h_count, packed, c->clean_literal,
+                 c->stream);
     m->cur = dst;
     return check_launch(c);
 }
@@ -2406,27 +2227,15 @@ static const SegRef kSegParams[] = {
 
 extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!c || !key) return MF_EINVAL;
-    c->cfg_epoch++;   // captured frames bake configuration values into their launches
-    if (!strcmp(key, "frameGraph")) { c->frame_graph = value != 0; return MF_OK; }   // 0: mf_process_frame enqueues its launches one by one
-    if (!strcmp(key, "hostProfileReset")) { c->cfg_epoch--; for (double& v : c->host_us) v = 0; c->host_calls = 0; return MF_OK; }
+    if (!strcmp(key, "hostProfileReset")) { for (double& v : c->host_us) v = 0; c->host_calls = 0; return MF_OK; }
     if (!strcmp(key, "timings")) { c->timings_on = value != 0; return MF_OK; }
     if (!strcmp(key, "icpProfile")) { c->icp_prof_on = value != 0; return MF_OK; }
     if (!strcmp(key, "hostInputAsync")) {   // 0: mf_process_frame blocks until the frame is fused (rounds 1-3); 1: returns when it is enqueued
         if (hipStreamSynchronize(c->stream) != hipSuccess || hipStreamSynchronize(c->stream_in) != hipSuccess) return MF_EHIP;
         c->host_async = value != 0; return MF_OK;
     }
-    if (!strcmp(key, "hostUploadAfterTracking")) { c->upload_after_tracking = value != 0; return MF_OK; }
     if (!strcmp(key, "hostLockstep")) { c->host_lockstep = value != 0; return MF_OK; }
     if (!strcmp(key, "hostWaitUpload")) { c->host_wait_upload = value != 0; return MF_OK; }
-    if (!strcmp(key, "hostCopyHelper")) { c->copy_helper = value != 0; return MF_OK; }
-    if (!strcmp(key, "hostUploadKernel")) {
-        if (hipStreamSynchronize(c->stream) != hipSuccess || hipStreamSynchronize(c->stream_in) != hipSuccess) return MF_EHIP;
-        c->upload_kernel = value != 0; return MF_OK;
-    }
-    if (!strcmp(key, "hostUploadOnMain")) {   // 1: the host frame's upload on the frame's own stream, serial with it (what its overlap is worth)
-        if (hipStreamSynchronize(c->stream) != hipSuccess || hipStreamSynchronize(c->stream_in) != hipSuccess) return MF_EHIP;
-        c->upload_on_main = value != 0; return MF_OK;
-    }
     if (!strcmp(key, "splatProfile")) {   // per-tile shader-clock stamps of k_splat_tile (tools/splat_prof.py); debug tap "splat_prof"
         if (value != 0 && !c->d_splat_prof) {
             if (hipMalloc(&c->d_splat_prof, splat_tiles_scratch_ints(c->W, c->H) * 8 * sizeof(unsigned long long)) != hipSuccess) return MF_ENOMEM;
@@ -2443,7 +2252,6 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
         return MF_OK;
     }
     if (!strcmp(key, "batchTracking")) { c->batch_tracking = value != 0; return MF_OK; }
-    if (!strcmp(key, "gnLoopGraph")) { c->gn_loop_graph = value != 0; return MF_OK; }      // the Gauss-Newton launches as a replayed hipGraph
     if (!strcmp(key, "frameToFrameRGB")) { c->ftf_rgb = value != 0; return MF_OK; }         // MaskFusion::setFrameToFrameRGB (Core/MaskFusion.cpp:910)
     if (!strcmp(key, "batchObjectPasses")) { c->batch_objects = value != 0; return MF_OK; }  // 0: the object models' surfel passes model by model
     if (!strcmp(key, "objectBoundingBoxLimit")) { c->bbox_limit = value != 0; return MF_OK; }   // 0: a headless upstream that never renders (bb_max_z = FLT_MAX)
@@ -2489,17 +2297,12 @@ extern "C" int mf_get_param(mf_ctx* c, const char* key, double* value) {
     if (!c || !key || !value) return MF_EINVAL;
     if (!strcmp(key, "confidenceThreshold")) { *value = c->models[0]->confThr; return MF_OK; }
     if (!strcmp(key, "splatTileEntries")) { *value = c->tile_entries_cap; return MF_OK; }
-    if (!strcmp(key, "gnLoopGraph")) { *value = c->gn_loop_graph ? 1 : 0; return MF_OK; }   // 0 again after a capture that the runtime refused
-    if (!strcmp(key, "frameGraph")) { *value = c->frame_graph ? 1 : 0; return MF_OK; }      // 0 again after a capture that the runtime refused
-    if (!strcmp(key, "frameGraphLaunches")) { *value = (double)c->frame_graph_launches; return MF_OK; }
     // mean host microseconds per mf_process_frame call since the context was created: staging copy | upload enqueue | frame enqueue | whole call
     if (!strcmp(key, "hostStageUs")) { *value = c->host_calls ? c->host_us[0] / c->host_calls : 0; return MF_OK; }
     if (!strcmp(key, "hostUploadUs")) { *value = c->host_calls ? c->host_us[1] / c->host_calls : 0; return MF_OK; }
     if (!strcmp(key, "hostEnqueueUs")) { *value = c->host_calls ? c->host_us[2] / c->host_calls : 0; return MF_OK; }
     if (!strcmp(key, "hostCallUs")) { *value = c->host_calls ? c->host_us[3] / c->host_calls : 0; return MF_OK; }
     if (!strcmp(key, "hostWaitUs")) { *value = c->host_calls ? c->host_us[4] / c->host_calls : 0; return MF_OK; }
-    if (!strcmp(key, "hostUploadOnMain")) { *value = c->upload_on_main ? 1 : 0; return MF_OK; }
-    if (!strcmp(key, "hostUploadAfterTracking")) { *value = c->upload_after_tracking ? 1 : 0; return MF_OK; }
     if (!strcmp(key, "frameToFrameRGB")) { *value = c->ftf_rgb ? 1 : 0; return MF_OK; }
     if (!strcmp(key, "objectBoundingBoxLimit")) { *value = c->bbox_limit ? 1 : 0; return MF_OK; }
     for (const ParamRef& p : kParams)

@@ -68,18 +68,18 @@ struct FrameDev {
     // Model::lastBoundingBox in millimetres (Model.cpp:315-345; {min xyz, max xyz}, empty = min > max) as of the end of the last frame, and
     // the one being accumulated by this frame's clean pass (object models only; the frame advance moves it over)
     int bbox[6], bbox_acc[6];
+    int bbox_tmp[6];           // ... and what the workgroups of a running clean launch have merged so far (empty between launches)
     unsigned long long done_cover;   // k_splat_tile: (workgroups finished << 32) | coverage count of this launch; zero between launches
 };
 
 constexpr int kBBoxEmptyMin = 100000, kBBoxEmptyMax = -100000;   // Model.cpp:315: {1e5, 1e5, 1e5, -1e5, -1e5, -1e5}
 constexpr int kBBoxNotRun = 0x7FFFFFFF;   // bbox_acc[0] between the frame advance and the next clean pass: no clean has accumulated a box since
 // (device + host) reset of the two boxes of a FrameDev
-#define MF_FRAME_BBOX_RESET(f) do { for (int q_ = 0; q_ < 3; ++q_) { (f)->bbox[q_] = (f)->bbox_acc[q_] = mf::kBBoxEmptyMin; \
-                                                                     (f)->bbox[3 + q_] = (f)->bbox_acc[3 + q_] = mf::kBBoxEmptyMax; } \
+#define MF_FRAME_BBOX_RESET(f) do { for (int q_ = 0; q_ < 3; ++q_) { (f)->bbox[q_] = (f)->bbox_acc[q_] = (f)->bbox_tmp[q_] = mf::kBBoxEmptyMin; \
+                                                                     (f)->bbox[3 + q_] = (f)->bbox_acc[3 + q_] = (f)->bbox_tmp[3 + q_] = mf::kBBoxEmptyMax; } \
                                     (f)->bbox_acc[0] = mf::kBBoxNotRun; } while (0)
-// start of a clean pass (its first kernel, before the compaction accumulates): the box of a frame is the box of its LAST clean pass, like the
-// reference's render pass over the final buffer -- on a spawn frame the spawn pass's clean output is not part of it
-#define MF_FRAME_BBOX_BEGIN(f) do { for (int q_ = 0; q_ < 6; ++q_) (f)->bbox_acc[q_] = q_ < 3 ? mf::kBBoxEmptyMin : mf::kBBoxEmptyMax; } while (0)
+// (the box of a frame is the box of its LAST clean pass, like the reference's render pass over the final buffer -- on a spawn frame the spawn
+// pass's clean output is not part of it: every clean launch REPLACES bbox_acc with what its workgroups merged into bbox_tmp)
 // end of a frame (the GUI's renderPointCloud runs after processFrame, GUI/MainController.cpp:704-717): the accumulated box becomes
 // lastBoundingBox; a frame without a clean pass for this model (rgbOnly, model-level calls) leaves the buffer, hence the box, as it was
 #define MF_FRAME_BBOX_ADVANCE(f) do { if ((f)->bbox_acc[0] != mf::kBBoxNotRun) for (int q_ = 0; q_ < 6; ++q_) (f)->bbox[q_] = (f)->bbox_acc[q_]; \
@@ -226,10 +226,17 @@ void launch_fuse_data(const uint8_t* rgb, const float* depthRaw, const float* de
 // update.vert IN PLACE: one thread per candidate, the winning candidate of a surfel (upd_first) merges into it where it stands
 void launch_fuse_update(Surfels s, const FrameDev* frame, int* upd_first, const uint8_t* cand_op, const int* cand_best, const float4* cand_rec,
                         int W, int H, hipStream_t st);
+// Model::clean in one launch (test + ordered compaction with a decoupled look-back, mf_surfel.hip).  flags / newconf: optional taps (nullptr
+// inside a frame); scan_state: clean_scan_entries(capacity + P) words, never reset (epoch must differ from launch to launch and be > 0);
+// ctl: two ints, zero between launches; blocks: clean_grid(elements expected)
+constexpr int kCleanGridMax = 2048;
+int clean_grid(long elements);
+size_t clean_scan_entries(long max_elements);
 void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k,
                   int timeDelta, float confThreshold, float outlierCoeff, int maskID, const int* index,
                   const float4* vc, const float4* ct, const float4* packed /*or null*/, const float* depthF, const uint8_t* mask,
-                  const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags, float* newconf, int* block_counts,
+                  const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags /*or null*/, float* newconf /*or null*/,
+                  unsigned long long* scan_state, int* ctl, unsigned epoch, int blocks,
                   int* host_count_mirror, bool transposed /*layout of index/vc/ct*/, bool literalWindow /*fp32 trip count of the shader*/,
                   hipStream_t s);
 // generic ordered compaction of [n_dev] records (3 x float4 each, record-major) -> surfels, sets frame->count
@@ -265,7 +272,7 @@ struct ObjPassArgs {
     FrameDev* frame; PoseDev* pose;
     int maskID; float confThreshold, fuseMaxDepth, weightMultiplier;
     unsigned long long* keys; int* index; float4* ivc; float4* inr; float4* iclean;
-    uint8_t* cand_op; float4* cand_rec; int* upd_first; int* cand_best; uint8_t* flags; float* newconf; int* block_counts; int* host_count;
+    uint8_t* cand_op; float4* cand_rec; int* upd_first; int* cand_best; unsigned long long* scan_state; int* clean_ctl; int* host_count;
     float4* predV; float4* predN; uchar4* predImage; uint16_t* predTime; uint8_t* predGray;
     FrameDev* host_frame; float* log_slot;
     unsigned global_payload;           // GlobalProjection: order << 8 | id
@@ -273,11 +280,12 @@ struct ObjPassArgs {
 struct ObjBatch {
     const ObjPassArgs* m; int n;
     int W, H; Intr k; float maxDepthProcessed, globalMaxDepth; int timeDelta; float outlierCoeff; int cleanLiteral, bboxLimit;
+    unsigned cleanEpoch;               // CleanArgs::epoch of this batch's clean launch
     const uint8_t* rgb; const float* depthRaw; const float* depthF; const uint8_t* mask; const PoseDev* bg_pose;
     unsigned long long* global_keys;
 };
 void launch_obj_global_scatter(const ObjBatch& b, int blocks, hipStream_t s);          // GlobalProjection of every object model (mf_segment.hip)
-void launch_obj_fuse_clean(const ObjBatch& b, int blocks, hipStream_t s);              // predictIndices -> fuse -> predictIndices -> clean
+void launch_obj_fuse_clean(const ObjBatch& b, int blocks, int clean_blocks, hipStream_t s);   // predictIndices -> fuse -> predictIndices -> clean
 void launch_obj_predict_advance(const ObjBatch& b, int blocks, hipStream_t s);         // combinedPredict (scatter form) + the end-of-frame bookkeeping
 void launch_fill_keys(unsigned long long* keys, int n, hipStream_t s);
 void launch_fill_int(int* p, int v, int n, hipStream_t s);

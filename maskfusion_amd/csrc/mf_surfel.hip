@@ -430,7 +430,11 @@ struct CleanArgs {
     const float4* packed;                                    // {vertConf | initTime, lastTime, index, 0} per texel
     const float* depthF; const uint8_t* mask;
     const uint8_t* cand_op; const float4* cand_rec;
-    uint8_t* flags; float* newconf; int* block_counts; int* host_count;
+    uint8_t* flags; float* newconf;    // optional taps (Model-level calls, tests): keep flag / new confidence per element; nullptr inside a frame
+    int* host_count;
+    unsigned long long* scan_state;    // [chunks] decoupled look-back: (launch epoch << 34 | status << 32 | survivors)
+    int* ctl;                          // {ticket, finished workgroups}; zero between launches
+    unsigned epoch;                    // distinguishes this launch's entries of scan_state from older ones (never reset)
 };
 
 // The window of copy_unstable.vert:85-86 along one axis, exactly as the shader text walks it: `for (i = c - 2s; i < c + 2s; i += s)` on an
@@ -535,46 +539,60 @@ __device__ __forceinline__ bool clean_test(const CleanArgs& a, float4 pc, float4
     return test;
 }
 
-__device__ __forceinline__ void clean_flags_body(const CleanArgs& a) {
-    __shared__ int s_w[4];
-    const int count = a.frame->count;
-    const int total = count + cand_count(a.W, a.H, a.frame->tick);
-    const float time = (float)a.frame->tick;
-    float Ri[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) Ri[q] = a.pose->Ri[q];
-    const float3 ti = f3(a.pose->ti[0], a.pose->ti[1], a.pose->ti[2]);
-    const int chunk = chunk_size(total);
-    const int beg = blockIdx.x * chunk, end = min(total, beg + chunk);
-    int kept = 0;
-    for (int i = beg + threadIdx.x; i < end; i += 256) {
-        bool keep = false;
-        float nc = 0.f;
-        if (i < count) {
-            keep = clean_test(a, a.src.pc[i], a.src.ct[i], a.src.nr[i], time, Ri, ti, nc);
-        } else {
-            const int c = i - count;
-            if (a.cand_op[c] == 2)
-                keep = clean_test(a, a.cand_rec[c * 3 + 0], a.cand_rec[c * 3 + 1], a.cand_rec[c * 3 + 2], time, Ri, ti, nc);
-        }
-        a.flags[i] = keep ? 1 : 0;
-        a.newconf[i] = nc;
-        kept += keep ? 1 : 0;
-    }
-    const int tot = block_sum_i(kept, s_w);
-    if (threadIdx.x == 0) {
-        a.block_counts[blockIdx.x] = tot;
-        if (blockIdx.x == 0) {
-            a.frame->countNext = count;  // snapshot for pass 2 (see FrameDev)
-            if (a.maskID != 0) MF_FRAME_BBOX_BEGIN(a.frame);   // the compaction pass (next launch) accumulates this clean pass's box
-        }
-    }
+// ------------------------------------------------------------------------------------------------
+// clean (copy_unstable.vert:53-157) in ONE pass: test + ordered compaction with a decoupled look-back.
+// Rounds 1-4 ran two launches (k_clean_flags: test -> keep flags + new confidences + per-workgroup counts; k_clean_compact: prefix of the
+// counts, ordered copy): every surfel was read twice and its flag / confidence took a round trip through HBM -- 154 B per surfel, of
+// which 96 are compulsory (read 48, write 48).  Here a workgroup draws a chunk of kCleanChunk consecutive elements (element i < count:
+// old surfel i; element count + c: candidate c, live only with op == 2) from a ticket counter, tests its elements, publishes the chunk's
+// number of survivors, obtains the number of survivors of all earlier chunks by looking back over the published values (Merrill & Garland's
+// decoupled look-back; the ticket order guarantees that every earlier chunk is owned by a workgroup that is already running, so the wait
+// terminates), and copies its survivors to their final slots -- the order of the output is the order of the input, as transform feedback
+// keeps it.  The records stay in registers between the test and the copy.
+// ------------------------------------------------------------------------------------------------
+constexpr int kCleanPerThread = 4;
+constexpr int kCleanChunk = 256 * kCleanPerThread;
+constexpr unsigned kScanAggregate = 1u, kScanInclusive = 2u;
+
+__device__ __forceinline__ unsigned long long scan_load(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void scan_store(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(256) void k_clean_flags(const CleanArgs a) { clean_flags_body(a); }
+// exclusive prefix of chunk `chunk` (> 0), by wavefront 0: lanes read the states of the 64 chunks before it, nearest first
+__device__ __forceinline__ int scan_look_back(const unsigned long long* __restrict__ state, int chunk, unsigned epoch, int& gave_up) {
+    const int lane = threadIdx.x & 63;
+    int exclusive = 0;
+    int idx = chunk - 1;          // nearest chunk not yet accounted for
+    for (;;) {
+        const int mine = idx - lane;
+        unsigned long long v = 0;
+        unsigned tag = 0;
+        int spins = 0;
+        for (;;) {    // every lane that has a chunk to read waits until that chunk has published something for THIS launch
+            if (mine >= 0) { v = scan_load(&state[mine]); tag = (unsigned)(v >> 32); }
+            const bool ready = mine < 0 || (tag >> 2) == epoch;
+            if (__ballot(!ready) == 0ull) break;
+            if (++spins > (1 << 22)) { gave_up = 1; break; }   // never in a correct run: a bounded wait cannot hang the GPU
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const bool inclusive = mine >= 0 && (tag >> 2) == epoch && (tag & 3u) == kScanInclusive;
+        const unsigned long long incl_mask = __ballot(inclusive);
+        // lanes up to (and including) the nearest chunk that carries an inclusive prefix contribute; without one, all 64 do
+        const int stop = incl_mask ? __builtin_ctzll(incl_mask) : 63;
+        int contrib = (mine >= 0 && lane <= stop) ? (int)(unsigned)(v & 0xFFFFFFFFull) : 0;
+        exclusive += wave_sum_i(contrib);
+        if (incl_mask || idx - 64 < 0 || gave_up) break;
+        idx -= 64;
+    }
+    return exclusive;
+}
 
-__device__ __forceinline__ void clean_compact_body(const CleanArgs& a) {
-    __shared__ int s_w[4];
+__device__ __forceinline__ void clean_body(const CleanArgs& a) {
+    __shared__ int s_chunk, s_base;
+    __shared__ int s_cnt[kCleanPerThread][4];
     __shared__ int s_bb[6];
     // Model::lastBoundingBox of an OBJECT model (Model.cpp:315-345 + draw_global_surface.vert:55-78: the box of the surfels the GUI draws --
     // confidence above the model's threshold -- in millimetres, truncated): accumulated here, where the frame's final records pass through
@@ -582,77 +600,134 @@ __device__ __forceinline__ void clean_compact_body(const CleanArgs& a) {
     const bool bbox_on = a.maskID != 0;
     int bmin[3] = {kBBoxEmptyMin, kBBoxEmptyMin, kBBoxEmptyMin}, bmax[3] = {kBBoxEmptyMax, kBBoxEmptyMax, kBBoxEmptyMax};
     if (bbox_on && threadIdx.x < 6) s_bb[threadIdx.x] = threadIdx.x < 3 ? kBBoxEmptyMin : kBBoxEmptyMax;
-    const int count = a.frame->countNext;
+    // frame->count stays what it is for the whole launch: the new count is installed by the LAST workgroup to finish (below)
+    const int count = a.frame->count;
     const int total = count + cand_count(a.W, a.H, a.frame->tick);
+    const int nchunks = (total + kCleanChunk - 1) / kCleanChunk;
     const float time = (float)a.frame->tick;
-    const int chunk = chunk_size(total);
-    const int beg = blockIdx.x * chunk, end = min(total, beg + chunk);
+    float Ri[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) Ri[q] = a.pose->Ri[q];
+    const float3 ti = f3(a.pose->ti[0], a.pose->ti[1], a.pose->ti[2]);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int base = 0;
-    for (int i0 = beg; i0 < end; i0 += 256) {
-        // every load of the slice is issued before anything depends on one of them (the keep flag, the record, the new
-        // confidence, and -- first slice -- the workgroup's base offset): one memory latency per slice instead of three
-        const int i = i0 + threadIdx.x;
-        const bool in = i < end;
-        uint8_t flag = 0;
-        float nc = 0.f;
-        float4 pc = make_float4(0, 0, 0, 0), ct = pc, nr = pc;
-        if (in) {
-            flag = a.flags[i];
-            nc = a.newconf[i];
-            if (i < count) { pc = a.src.pc[i]; ct = a.src.ct[i]; nr = a.src.nr[i]; }
-            else { const int c = i - count; pc = a.cand_rec[c * 3 + 0]; ct = a.cand_rec[c * 3 + 1]; nr = a.cand_rec[c * 3 + 2]; }
-        }
-        if (i0 == beg) base = block_base(a.block_counts, s_w);
-        const bool keep = in && flag;
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) s_w[wave] = __popcll(m);
+    for (;;) {
+        if (threadIdx.x == 0) s_chunk = atomicAdd(&a.ctl[0], 1);
         __syncthreads();
-        int off = base;
-        for (int w = 0; w < wave; ++w) off += s_w[w];
-        const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-        if (keep) {
-            const int o = off + lane_rank(m);
-            pc.w = nc;
-            if (ct.w == -2.f) ct.w = time;  // copy_unstable.vert:131
-            if (o < a.dst.cap) {
-                a.dst.pc[o] = pc; a.dst.ct[o] = ct; a.dst.nr[o] = nr;
-                if (bbox_on && pc.w > a.confThreshold) {   // draw_global_surface.vert:55 (unstable == 0), :69-78
-                    const int x = (int)(1000.f * pc.x), y = (int)(1000.f * pc.y), z = (int)(1000.f * pc.z);
+        const int chunk = s_chunk;
+        if (chunk >= nchunks) break;
+        // every record of the chunk is requested before anything depends on one of them
+        float4 pc[kCleanPerThread], ct[kCleanPerThread], nr[kCleanPerThread];
+        bool live[kCleanPerThread];
+#pragma unroll
+        for (int j = 0; j < kCleanPerThread; ++j) {
+            const int i = chunk * kCleanChunk + j * 256 + (int)threadIdx.x;
+            live[j] = i < total;
+            pc[j] = ct[j] = nr[j] = make_float4(0, 0, 0, 0);
+            if (i < count) { pc[j] = a.src.pc[i]; ct[j] = a.src.ct[i]; nr[j] = a.src.nr[i]; }
+            else if (live[j]) {
+                const int c = i - count;
+                live[j] = a.cand_op[c] == 2;      // op == 1 records carry w = -1 and are dropped, op == 0 slots hold nothing
+                if (live[j]) { pc[j] = a.cand_rec[c * 3 + 0]; ct[j] = a.cand_rec[c * 3 + 1]; nr[j] = a.cand_rec[c * 3 + 2]; }
+            }
+        }
+        bool keep[kCleanPerThread];
+        int rank[kCleanPerThread];
+#pragma unroll
+        for (int j = 0; j < kCleanPerThread; ++j) {
+            float nc = 0.f;
+            keep[j] = live[j] && clean_test(a, pc[j], ct[j], nr[j], time, Ri, ti, nc);
+            if (a.flags) {
+                const int i = chunk * kCleanChunk + j * 256 + (int)threadIdx.x;
+                if (i < total) { a.flags[i] = keep[j] ? 1 : 0; a.newconf[i] = live[j] ? nc : 0.f; }
+            }
+            pc[j].w = nc;
+            if (ct[j].w == -2.f) ct[j].w = time;  // copy_unstable.vert:131
+            const unsigned long long m = __ballot(keep[j]);
+            rank[j] = lane_rank(m);
+            if (lane == 0) s_cnt[j][wave] = __popcll(m);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            int tot = 0;
+#pragma unroll
+            for (int j = 0; j < kCleanPerThread; ++j) tot += s_cnt[j][0] + s_cnt[j][1] + s_cnt[j][2] + s_cnt[j][3];
+            const unsigned long long tag = (unsigned long long)a.epoch << 34;
+            int excl = 0, gave_up = 0;
+            if (chunk > 0) {
+                if (lane == 0) scan_store(&a.scan_state[chunk], tag | ((unsigned long long)kScanAggregate << 32) | (unsigned)tot);
+                excl = scan_look_back(a.scan_state, chunk, a.epoch, gave_up);
+            }
+            if (lane == 0) {
+                scan_store(&a.scan_state[chunk], tag | ((unsigned long long)kScanInclusive << 32) | (unsigned)(excl + tot));
+                s_base = excl;
+                if (gave_up) a.frame->pad[2] = 1;
+                if (chunk == nchunks - 1) __hip_atomic_store(&a.frame->countNext, min(excl + tot, a.dst.cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        int off = s_base;
+#pragma unroll
+        for (int j = 0; j < kCleanPerThread; ++j) {
+            int o = off + rank[j];
+            for (int w = 0; w < wave; ++w) o += s_cnt[j][w];
+            if (keep[j] && o < a.dst.cap) {
+                a.dst.pc[o] = pc[j]; a.dst.ct[o] = ct[j]; a.dst.nr[o] = nr[j];
+                if (bbox_on && pc[j].w > a.confThreshold) {   // draw_global_surface.vert:55 (unstable == 0), :69-78
+                    const int x = (int)(1000.f * pc[j].x), y = (int)(1000.f * pc[j].y), z = (int)(1000.f * pc[j].z);
                     bmin[0] = min(bmin[0], x); bmin[1] = min(bmin[1], y); bmin[2] = min(bmin[2], z);
                     bmax[0] = max(bmax[0], x); bmax[1] = max(bmax[1], y); bmax[2] = max(bmax[2], z);
                 }
             }
+            off += s_cnt[j][0] + s_cnt[j][1] + s_cnt[j][2] + s_cnt[j][3];
         }
-        base += tot;
-        __syncthreads();
+        __syncthreads();   // s_chunk / s_cnt / s_base are rewritten by the next round
     }
-    if (bbox_on) {   // (the loop's barriers order the initialisation of s_bb before these; a workgroup without elements skips both)
-        if (beg < end) {
+    if (bbox_on) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                if (bmin[q] != kBBoxEmptyMin) atomicMin(&s_bb[q], bmin[q]);
-                if (bmax[q] != kBBoxEmptyMax) atomicMax(&s_bb[3 + q], bmax[q]);
-            }
-            __syncthreads();
-            if (threadIdx.x < 3 && s_bb[threadIdx.x] != kBBoxEmptyMin) atomicMin(&a.frame->bbox_acc[threadIdx.x], s_bb[threadIdx.x]);
-            else if (threadIdx.x >= 3 && threadIdx.x < 6 && s_bb[threadIdx.x] != kBBoxEmptyMax) atomicMax(&a.frame->bbox_acc[threadIdx.x], s_bb[threadIdx.x]);
+        for (int q = 0; q < 3; ++q) {
+            if (bmin[q] != kBBoxEmptyMin) atomicMin(&s_bb[q], bmin[q]);
+            if (bmax[q] != kBBoxEmptyMax) atomicMax(&s_bb[3 + q], bmax[q]);
         }
+        __syncthreads();
+        if (threadIdx.x < 3 && s_bb[threadIdx.x] != kBBoxEmptyMin) atomicMin(&a.frame->bbox_tmp[threadIdx.x], s_bb[threadIdx.x]);
+        else if (threadIdx.x >= 3 && threadIdx.x < 6 && s_bb[threadIdx.x] != kBBoxEmptyMax) atomicMax(&a.frame->bbox_tmp[threadIdx.x], s_bb[threadIdx.x]);
     }
-    if (blockIdx.x != gridDim.x - 1) return;
-    if (beg >= end) base = block_base(a.block_counts, s_w);   // the last workgroup owns no elements: all threads take part
+    // The last workgroup to FINISH installs the launch's results: by then nobody reads frame->count or the ticket any more, and every
+    // workgroup's box contribution is in (its atomics precede its increment, which releases them).
+    __syncthreads();
     if (threadIdx.x == 0) {
-        a.frame->count = min(base, a.dst.cap);
-        if (a.host_count) *a.host_count = min(base, a.dst.cap);
+        const int done = __hip_atomic_fetch_add(&a.ctl[1], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (int)gridDim.x - 1) {
+            const int n = __hip_atomic_load(&a.frame->countNext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.frame->count = n;
+            if (a.host_count) *a.host_count = n;
+            if (bbox_on) {   // the box of a frame is the box of its LAST clean pass (the reference's render pass sees the final buffer)
+                for (int q = 0; q < 6; ++q) {
+                    a.frame->bbox_acc[q] = __hip_atomic_load(&a.frame->bbox_tmp[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&a.frame->bbox_tmp[q], q < 3 ? kBBoxEmptyMin : kBBoxEmptyMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __hip_atomic_store(&a.ctl[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.ctl[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
+
+__global__ __launch_bounds__(256) void k_clean(const CleanArgs a) { clean_body(a); }
+
+// workgroups of a clean launch for `elements` elements (an upper bound or an estimate: the chunks are drawn from a ticket counter, any
+// grid covers any count)
+int clean_grid(long elements) {
+    const long chunks = (elements + kCleanChunk - 1) / kCleanChunk;
+    return (int)(chunks < 8 ? 8 : (chunks > kCleanGridMax ? kCleanGridMax : chunks));
+}
+size_t clean_scan_entries(long max_elements) { return (size_t)((max_elements + kCleanChunk - 1) / kCleanChunk + 1); }
 
 // ------------------------------------------------------------------------------------------------
 // splat prediction: scatter (per-surfel sprite loop, ray-disc test, 64-bit atomicMin) + resolve
 // Raster rule: sprite side s centred on (u,v) covers pixel (px,py) iff u - s/2 <= px + 0.5 < u + s/2; LESS on the
 // corrected z; lower index wins ties; sprites wider than 64 px are clamped.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_clean_compact(const CleanArgs a) { clean_compact_body(a); }
 
 // kLanes neighbouring lanes share one surfel and split its sprite's pixels between them as a kLX x kLY block (1: the thread-per-surfel form).
 // The object models' launches use 4: a few thousand sprites of 4-10 px a side kept a handful of threads busy for ~36 us each (round 4 trace),
@@ -825,7 +900,8 @@ void launch_pose_log(const PoseDev* pose, const PoseDev* bg_pose, float* slot, h
 void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, int timeDelta,
                   float confThreshold, float outlierCoeff, int maskID, const int* index, const float4* vc, const float4* ct,
                   const float4* packed, const float* depthF, const uint8_t* mask, const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags,
-                  float* newconf, int* block_counts, int* host_count_mirror, bool transposed, bool literalWindow, hipStream_t s) {
+                  float* newconf, unsigned long long* scan_state, int* ctl, unsigned epoch, int blocks, int* host_count_mirror, bool transposed,
+                  bool literalWindow, hipStream_t s) {
     CleanArgs a;
     a.transposed = transposed ? 1 : 0;
     a.literal = literalWindow ? 1 : 0;
@@ -833,9 +909,9 @@ void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose
     a.confThreshold = confThreshold; a.outlierCoeff = outlierCoeff; a.maskID = maskID; a.index = index; a.vc = vc; a.ct = ct;
     a.packed = packed;
     a.depthF = depthF; a.mask = mask; a.cand_op = cand_op; a.cand_rec = cand_rec;
-    a.flags = flags; a.newconf = newconf; a.block_counts = block_counts; a.host_count = host_count_mirror;
-    hipLaunchKernelGGL(k_clean_flags, dim3(kCompactBlocks), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_clean_compact, dim3(kCompactBlocks), dim3(256), 0, s, a);
+    a.flags = flags; a.newconf = newconf; a.host_count = host_count_mirror;
+    a.scan_state = scan_state; a.ctl = ctl; a.epoch = epoch;
+    hipLaunchKernelGGL(k_clean, dim3(blocks), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -872,11 +948,11 @@ __device__ __forceinline__ CleanArgs obj_clean_args(const ObjBatch& b, const Obj
     a.src = m.a; a.dst = m.b; a.frame = m.frame; a.pose = m.pose; a.W = b.W; a.H = b.H; a.k = b.k; a.timeDelta = b.timeDelta;
     a.confThreshold = m.confThreshold; a.outlierCoeff = b.outlierCoeff; a.maskID = m.maskID; a.transposed = 1; a.literal = b.cleanLiteral;
     a.index = m.index; a.vc = m.ivc; a.ct = nullptr; a.packed = m.iclean; a.depthF = b.depthF; a.mask = b.mask;
-    a.cand_op = m.cand_op; a.cand_rec = m.cand_rec; a.flags = m.flags; a.newconf = m.newconf; a.block_counts = m.block_counts; a.host_count = m.host_count;
+    a.cand_op = m.cand_op; a.cand_rec = m.cand_rec; a.flags = nullptr; a.newconf = nullptr; a.host_count = m.host_count;
+    a.scan_state = m.scan_state; a.ctl = m.clean_ctl; a.epoch = b.cleanEpoch;
     return a;
 }
-__global__ __launch_bounds__(256) void k_obj_clean_flags(const ObjBatch b) { clean_flags_body(obj_clean_args(b, b.m[blockIdx.z])); }
-__global__ __launch_bounds__(256) void k_obj_clean_compact(const ObjBatch b) { clean_compact_body(obj_clean_args(b, b.m[blockIdx.z])); }
+__global__ __launch_bounds__(256) void k_obj_clean(const ObjBatch b) { clean_body(obj_clean_args(b, b.m[blockIdx.z])); }
 __global__ __launch_bounds__(256) void k_obj_splat_scatter(const ObjBatch b) {
     const ObjPassArgs& m = b.m[blockIdx.z];
     splat_scatter_body<4>(m.a, m.frame, m.pose, b.W, b.H, b.k, b.maxDepthProcessed, m.confThreshold, b.timeDelta, m.keys);
@@ -890,9 +966,9 @@ __global__ void k_obj_frame_advance(const ObjBatch b) {
     frame_advance_body(m.frame, b.W, b.H, m.host_frame, m.pose, b.bg_pose, m.log_slot);
 }
 
-void launch_obj_fuse_clean(const ObjBatch& b, int blocks, hipStream_t s) {
+void launch_obj_fuse_clean(const ObjBatch& b, int blocks, int clean_blocks, hipStream_t s) {
     const int P = b.W * b.H;
-    const dim3 surfels(blocks, 1, b.n), pixels((P + 255) / 256, 1, b.n), compact(kCompactBlocks, 1, b.n);
+    const dim3 surfels(blocks, 1, b.n), pixels((P + 255) / 256, 1, b.n), compact(clean_blocks, 1, b.n);
     const dim3 cands(((b.W + 1) / 2 + 63) / 64, ((b.H + 1) / 2 + 3) / 4, b.n);
     hipLaunchKernelGGL(k_obj_index_scatter, surfels, dim3(256), 0, s, b);
     hipLaunchKernelGGL(k_obj_index_resolve, pixels, dim3(256), 0, s, b, 0);
@@ -900,8 +976,7 @@ void launch_obj_fuse_clean(const ObjBatch& b, int blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_obj_fuse_update, dim3(cand_blocks(b.W, b.H), 1, b.n), dim3(256), 0, s, b);
     hipLaunchKernelGGL(k_obj_index_scatter2, surfels, dim3(256), 0, s, b);
     hipLaunchKernelGGL(k_obj_index_resolve, pixels, dim3(256), 0, s, b, 1);
-    hipLaunchKernelGGL(k_obj_clean_flags, compact, dim3(256), 0, s, b);
-    hipLaunchKernelGGL(k_obj_clean_compact, compact, dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_obj_clean, compact, dim3(256), 0, s, b);
 }
 void launch_obj_predict_advance(const ObjBatch& b, int blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_obj_splat_scatter, dim3(blocks, 1, b.n), dim3(256), 0, s, b);

@@ -225,17 +225,15 @@ def static_switches(n=9, W=240, H=160):
 
 
 def host_paths(n=8, W=160, H=120):
-    """mf_process_frame's host-side variants (round 4: pinned double buffer with ONE packed upload, hostLockstep, hostWaitUpload, the staging
-    helper thread, the captured frame graph, the measurement switches) against the blocking form of rounds 1-3: every variant is the same
-    kernels on the same inputs, so poses, counts and the cloud's bytes must be identical.  (Streams and events are synchronous here: this
-    checks the bookkeeping -- slots, views into the packed block, graph replays --, the overlap itself is tests/test_gpu_api.py on the MI355X.)"""
+    """mf_process_frame's host-side variants (pinned double buffer with ONE packed upload, hostLockstep, hostWaitUpload) against the blocking
+    form of rounds 1-3: every variant is the same kernels on the same inputs, so poses, counts and the cloud's bytes must be identical.
+    (Streams and events are synchronous here: this checks the bookkeeping -- slots, views into the packed block --, the overlap itself is
+    tests/test_gpu_api.py on the MI355X.)"""
     import hashlib
     f = 528.0 * W / 640.0
     st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
     frames = [st.frame(k) for k in range(n)]
-    variants = {"blocking": {"hostInputAsync": 0}, "default": {}, "frame_graph": {"frameGraph": 1}, "three_ahead": {"hostLockstep": 0},
-                "stream_wait": {"hostWaitUpload": 0}, "no_helper": {"hostCopyHelper": 0}, "copy_kernel": {"hostUploadKernel": 1},
-                "serial_upload": {"hostUploadOnMain": 1}, "after_tracking": {"hostUploadAfterTracking": 1}}
+    variants = {"blocking": {"hostInputAsync": 0}, "default": {}, "three_ahead": {"hostLockstep": 0}, "stream_wait": {"hostWaitUpload": 0}}
     out = {}
     for name, params in variants.items():
         mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=False, numGSurfels=1 << 17)
@@ -251,8 +249,7 @@ def host_paths(n=8, W=160, H=120):
                 poses.append(mf.getCurrPose().reshape(-1).tolist())
         poses.append(mf.getCurrPose().reshape(-1).tolist())
         cloud = np.ascontiguousarray(mf.getBackgroundModel().downloadMap())
-        out[name] = dict(poses=poses, count=int(mf.getBackgroundModel().lastCount()), cloud_sha1=hashlib.sha1(cloud.tobytes()).hexdigest(),
-                         graph_launches=float(mf.getParam("frameGraphLaunches")))
+        out[name] = dict(poses=poses, count=int(mf.getBackgroundModel().lastCount()), cloud_sha1=hashlib.sha1(cloud.tobytes()).hexdigest())
         mf.close()
     return out
 

@@ -132,23 +132,19 @@ def test_set_tick_skips_frame_numbers(hip):
 
 @pytest.mark.parametrize("multi", [False, True], ids=["single-model", "multi-model"])
 def test_asynchronous_host_frames_equal_the_blocking_form(hip, multi):
-    """mf_process_frame since round 4: the caller's buffers are copied into a pinned double buffer (a helper thread takes the depth plane),
-    uploaded on their own stream under the previous frame's kernels, and the call returns when the frame is enqueued.  Same frames through
+    """mf_process_frame since round 4: the caller's buffers are copied into a pinned double buffer, uploaded (one packed copy) on their own
+    stream under the previous frame's kernels, and the call returns when the frame is enqueued.  Same frames through
     `hostInputAsync = 0` (rounds 1-3: upload on the main stream, one synchronisation per frame): poses, counts, label images and clouds
     bit-identical -- also when the caller overwrites its buffers right after the call returns (they must have been consumed by then)."""
     from maskfusion_amd import MaskFusion, synth
     W, H, f = 320, 240, 264.0
     st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True, n_objects=2 if multi else 0, object_motion=0.0)
 
-    def run(asynchronous, upload_on_main=False, after_tracking=False, lockstep=True, upload_kernel=False, wait_upload=True, helper=True):
+    def run(asynchronous, lockstep=True, wait_upload=True):
         mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=multi, numGSurfels=1 << 18, numOSurfels=1 << 16,
                         modelSpawnOffset=2, trackAllModels=False)
-        mf.setParam("hostUploadOnMain", 1 if upload_on_main else 0)      # the measurement switch: the one packed upload serial with its frame
-        mf.setParam("hostUploadAfterTracking", 1 if after_tracking else 0)   # the upload of frame k+1 held back until frame k has tracked
         mf.setParam("hostLockstep", 1 if lockstep else 0)                # the call waits for frame k-2 before it enqueues frame k's upload
-        mf.setParam("hostUploadKernel", 1 if upload_kernel else 0)       # a copy kernel instead of the DMA engine
         mf.setParam("hostWaitUpload", 1 if wait_upload else 0)           # the call waits for its own upload: no cross-queue wait for the frame
-        mf.setParam("hostCopyHelper", 1 if helper else 0)                # the staging copy shared with a helper thread
         if multi:
             for k, v in (("mfThreshold", 0.3), ("mfWeightDistance", 150.0), ("mfWeightConvexity", 2.8), ("mfMorphEdgeIterations", 0),
                          ("mfMorphMaskIterations", 0), ("newModelMinRelativeSize", 0.004)):
@@ -173,8 +169,7 @@ def test_asynchronous_host_frames_equal_the_blocking_form(hip, multi):
         return out
 
     b = run(False)
-    for a in (run(True), run(True, upload_on_main=True), run(True, after_tracking=True), run(True, lockstep=False), run(True, upload_kernel=True),
-              run(True, wait_upload=False), run(True, helper=False)):
+    for a in (run(True), run(True, lockstep=False), run(True, wait_upload=False)):
         assert a["ids"] == b["ids"] and a["counts"] == b["counts"]
         assert len(a["ids"]) == (3 if multi else 1)
         for x, y in zip(a["poses"] + a["final"], b["poses"] + b["final"]):
@@ -183,41 +178,3 @@ def test_asynchronous_host_frames_equal_the_blocking_form(hip, multi):
             assert np.array_equal(x, y, equal_nan=True)
         if multi:
             assert np.array_equal(a["labels"], b["labels"])
-
-
-@pytest.mark.parametrize("variant", ["geometric", "rgbd_so3"])
-def test_frame_graph_equals_eager_launches(hip, variant):
-    """`frameGraph` (a switch; default off since r04o measured eager launches 9 us per frame faster on the GPU): the whole single-model frame of mf_process_frame replayed as one captured hipGraph per buffer combination
-    (input slot x map parity x filtered-depth ring slot).  Against `frameGraph = 0` (every launch enqueued on its own): poses on every frame,
-    the final cloud, the pose log and the tracking statistics bit-identical -- through the six captures of the first frames, their replays, a
-    change of the weight multiplier (a new key: re-capture) and a parameter change (configuration epoch)."""
-    from maskfusion_amd import MaskFusion, synth
-    W, H, f = 320, 240, 264.0
-    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
-    frames = [st.frame(k) for k in range(18)]
-    icp, so3 = (100.0, False) if variant == "geometric" else (20.0, True)
-
-    def run(graph):
-        mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=icp, so3=so3, enableMultipleModels=False, numGSurfels=1 << 18)
-        mf.setParam("frameGraph", 1 if graph else 0)
-        poses = []
-        for k, (rgb, d, _) in enumerate(frames):
-            if k == 13:
-                mf.setParam("confidenceThreshold", 3.0)
-            mf.processFrame(rgb, d, timestamp=1000 + k, weightMultiplier=2.0 if k >= 10 else 1.0)
-            poses.append(mf.getCurrPose())
-        out = dict(poses=poses, cloud=mf.getBackgroundModel().downloadMap(), log=mf.getPoseLog(0), stats=mf.trackStats(0),
-                   launches=mf.getParam("frameGraphLaunches"), on=mf.getParam("frameGraph"))
-        mf.close()
-        return out
-
-    a, b = run(True), run(False)
-    assert a["on"] == 1 and a["launches"] == len(frames) - 1 and b["launches"] == 0     # every frame but the map initialisation went through a graph
-    for k, (x, y) in enumerate(zip(a["poses"], b["poses"])):
-        assert np.array_equal(x, y), k
-    assert np.array_equal(a["cloud"], b["cloud"], equal_nan=True)
-    assert np.array_equal(a["log"][0], b["log"][0]) and np.array_equal(a["log"][1], b["log"][1])
-    assert a["log"][0].tolist() == [1000 + k for k in range(len(frames))]
-    assert a["stats"] == b["stats"]
-    if variant == "rgbd_so3":
-        assert a["stats"]["lastRGBCount"] > 0 and a["stats"]["so3Iterations"] >= 1

@@ -21,7 +21,7 @@ from maskfusion_amd import MaskFusion, synth  # noqa: E402
 from maskfusion_amd.lib import MFError  # noqa: E402
 
 SWITCHES = ["splatTiles", "globalTiles", "gpuLabels", "batchTracking", "earlyBackgroundFusion", "overlapPreprocessing", "cleanLiteralWindow",
-            "timings", "gnLoopGraph"]
+            "timings"]
 
 
 def one(seed, tmp):
