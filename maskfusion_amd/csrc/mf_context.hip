@@ -225,6 +225,10 @@ struct mf_ctx {
     uint8_t* d_flags = nullptr; float* d_newconf = nullptr; int* d_block_counts = nullptr;
     int* d_cand_best = nullptr;            // surfel a merge candidate was associated with (fuse_data -> fuse_update)
     unsigned long long* d_scan_state = nullptr; int* d_clean_ctl = nullptr; unsigned clean_epoch = 0;   // Model::clean's decoupled look-back (mf_surfel.hip)
+    // visibility list of the projection passes (Surfels::box, k_cull): the runs of ONE buffer that can be in view under ONE pose; vis_tag says whose
+    int* d_vis_list = nullptr; int* d_vis_count = nullptr; int* d_cull_ctl = nullptr; int vis_max_runs = 0;
+    struct { const void* model = nullptr; long frame = -1; int cur = -1; } vis_tag;
+    bool cull_runs = true;                 // "cullRuns": 0 = every projection pass streams the whole buffer (A/B switch, executable specification)
     unsigned long long* d_icp_prof = nullptr;
     unsigned long long* d_splat_prof = nullptr; bool splat_prof_on = false;   // "splatProfile": [tiles][8] stamps of the background's tile pass
     // multi-model coupling
@@ -313,7 +317,7 @@ static __global__ void k_pose_identity(PoseDev* p, int weight_literal) {
 }
 static __global__ void k_frame_init(FrameDev* f, int tick) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    f->tick = tick; f->count = 0; f->countNext = 0; f->cover = 0; f->useFillIn = 0;
+    f->tick = tick; f->count = 0; f->countNext = 0; f->runs = 0; f->cover = 0; f->useFillIn = 0;
     f->pad[0] = f->pad[1] = f->pad[2] = 0;
     f->done_cover = 0ull;
     MF_FRAME_BBOX_RESET(f);
@@ -360,6 +364,7 @@ static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int 
         A(dev_alloc(c, m->allocs, &m->surf[b].pc, (size_t)cap));
         A(dev_alloc(c, m->allocs, &m->surf[b].ct, (size_t)cap));
         A(dev_alloc(c, m->allocs, &m->surf[b].nr, (size_t)cap));
+        A(dev_alloc(c, m->allocs, &m->surf[b].box, run_table_entries((long)cap + (long)c->P)));
         m->surf[b].cap = cap;
     }
     A(dev_alloc(c, m->allocs, &m->d_pose, 1));
@@ -519,6 +524,10 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     A(dev_alloc(c, c->allocs, &c->d_cand_best, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_scan_state, clean_scan_entries((long)c->cap_max + (long)P)));
     A(dev_alloc(c, c->allocs, &c->d_clean_ctl, 2));
+    c->vis_max_runs = (int)(run_table_entries((long)c->cap_max + (long)P) / 2);
+    A(dev_alloc(c, c->allocs, &c->d_vis_list, (size_t)c->vis_max_runs));
+    A(dev_alloc(c, c->allocs, &c->d_vis_count, 1));
+    A(dev_alloc(c, c->allocs, &c->d_cull_ctl, 2));
     A(dev_alloc(c, c->allocs, &c->d_icp_prof, (size_t)20 * 16));
     A(dev_alloc(c, c->allocs, &c->d_edge, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_bin, (size_t)P));
@@ -753,6 +762,21 @@ static int surfel_blocks(const mf_ctx* c, const ModelState& m) {
 }
 
 // predictIndices -> fuse -> [predictIndices] -> clean for one model (Core/MaskFusion.cpp:541-563 / :344-353)
+// The runs of m's live buffer that can be in view under m's current pose (k_cull), for the projection passes of this frame: culled once per
+// buffer and pose -- GlobalProjection and the two index-map passes of a frame share one list (the in-place update moves no surfel of a run
+// that is not listed: only surfels the first index map drew are merged), the prediction after clean() gets its own (new buffer).
+// Depth range: the widest any consumer uses.  nullptr: culling is off.
+static const VisList* ensure_vis(mf_ctx* c, ModelState& m, VisList& out) {
+    if (!c->cull_runs) return nullptr;
+    out.list = c->d_vis_list; out.count = c->d_vis_count;
+    if (c->vis_tag.model == &m && c->vis_tag.frame == c->frame_no && c->vis_tag.cur == m.cur) return &out;
+    const mf_config& g = c->cfg;
+    launch_cull(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, fmaxf(g.depth_cutoff, g.max_depth_processed), g.time_delta, c->d_vis_list,
+                c->d_vis_count, c->d_cull_ctl, (int)(run_table_entries((long)m.cap + (long)c->P) / 2), c->stream);
+    c->vis_tag.model = &m; c->vis_tag.frame = c->frame_no; c->vis_tag.cur = m.cur;
+    return &out;
+}
+
 // workgroups of a clean launch for model m: sized from its last known count (pinned mirror; the chunks are drawn from a ticket counter,
 // so a stale value costs a workgroup a few more rounds, never a result)
 static int clean_blocks(const mf_ctx* c, const ModelState& m) {
@@ -771,7 +795,9 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
     hipStream_t s = c->stream;
     const int src = m.cur, dst = 1 - m.cur;
     const int blocks = surfel_blocks(c, m);
-    launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, false, s, blocks);
+    VisList vl;
+    const VisList* vis = ensure_vis(c, m, vl);
+    launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, false, s, blocks, vis);
     launch_index_resolve(m.surf[src], m.d_pose, c->d_keys, W, H, c->d_index, c->d_ivc, c->d_inr, secondIndexPass ? nullptr : c->d_ict,
                          nullptr, s);
     if (marks) mark(c, 4);
@@ -783,7 +809,7 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
     launch_fuse_update(m.surf[src], m.d_frame, c->d_upd_first, c->d_cand_op, c->d_cand_best, c->d_cand_rec, W, H, s);
     if (marks) mark(c, 6);
     if (secondIndexPass) {   // predictIndices on the updated buffer (:556), column-major packed texels for clean's window gathers
-        launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, true, s, blocks);
+        launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, true, s, blocks, vis);
         launch_index_resolve(m.surf[src], m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, s);
     }
     launch_clean(m.surf[src], m.surf[dst], m.d_frame, m.d_pose, W, H, c->K, g.time_delta, m.confThr, g.outlier_coefficient, m.id,
@@ -800,11 +826,13 @@ static void enqueue_predict(mf_ctx* c, ModelState& m, const FrameAdvance* advanc
     m.pred_gray_valid = photometric_on(c);
     if (c->splat_tiles && !(c->object_scatter_splat && m.id != 0)) {
         const bool gray = photometric_on(c);
+        VisList vl;
+        const VisList* vis = ensure_vis(c, m, vl);
         if (launch_splat_tiled(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, c->cfg.max_depth_processed, m.confThr,
                                c->cfg.time_delta, c->d_tile_count, c->d_tile_entries, c->tile_entries_cap, c->d_splat_rec0, c->d_splat_rec1,
                                c->d_splat_bbox, m.d_predV, m.d_predN, m.d_predImage, m.d_predTime, c->cur_rgb,
                                gray ? m.d_predGray : nullptr, gray ? m.d_fillGray : nullptr, c->stream, advance, c->ftf_rgb ? 1 : 0,
-                               (c->splat_prof_on && m.id == 0) ? c->d_splat_prof : nullptr, c->splat_tune) == 0)
+                               (c->splat_prof_on && m.id == 0) ? c->d_splat_prof : nullptr, c->splat_tune, vis) == 0)
             return;
     }
     launch_splat_scatter(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, c->cfg.max_depth_processed, m.confThr,
@@ -925,10 +953,14 @@ static int download_pose_log(mf_ctx* c, ModelState& m, std::vector<int64_t>& ts,
 // object models (a few thousand sprites) keep the scatter form, which costs them one short launch.  Both write the same keys.
 static void enqueue_global_projection(mf_ctx* c, ModelState& m, int order) {
     const mf_config& g = c->cfg;
-    if (m.id == 0 && c->splat_tiles && c->global_tiles &&
-        launch_global_tiled(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, g.depth_cutoff, 12.0f, g.time_delta, order, m.id, c->d_tile_count,
-                            c->d_tile_entries, c->tile_entries_cap, c->d_splat_rec0, c->d_splat_rec1, c->d_splat_bbox, c->d_keys, c->stream, c->splat_tune) == 0)
-        return;
+    if (m.id == 0 && c->splat_tiles && c->global_tiles) {
+        VisList vl;
+        const VisList* vis = ensure_vis(c, m, vl);
+        if (launch_global_tiled(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, g.depth_cutoff, 12.0f, g.time_delta, order, m.id, c->d_tile_count,
+                                c->d_tile_entries, c->tile_entries_cap, c->d_splat_rec0, c->d_splat_rec1, c->d_splat_bbox, c->d_keys, c->stream, c->splat_tune,
+                                vis) == 0)
+            return;
+    }
     launch_global_scatter(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, g.depth_cutoff, 12.0f, g.time_delta, order, m.id, c->d_keys,
                           c->stream, surfel_blocks(c, m));
 }
@@ -1135,6 +1167,7 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
         launch_init_surfels(d_rgb, d_depth, depthF, W, H, c->K, g.max_depth_processed, bg.d_frame, c->d_cand_rec, c->d_flags, s);
         bg.cur = 0;
         launch_compact_records(c->d_cand_rec, c->d_flags, P, bg.surf[0], bg.d_frame, c->d_block_counts, bg.h_count, s);
+        launch_run_table(bg.surf[0], bg.d_frame, s);
         mark(c, 7);
     } else if (in_pose16 && !bootstrap) {
         // the caller supplies the camera pose: no tracking, no segmentation, object poses untouched
@@ -1445,6 +1478,7 @@ static const uint8_t* current_mask(const mf_ctx* c) { return c->cfg.enable_multi
 // upload + MaskFusion::filterDepth (:217) + Model::generateCUDATextures (Model.cpp:350-389) + intensity pyramid: everything of
 // processFrame that does not touch a model.  mask: model id per pixel = what textureMask holds for fuse / clean (NULL: left as it is)
 extern "C" int mf_stage_frame(mf_ctx* c, const uint8_t* rgb, const float* depth, const uint8_t* mask) {
+    if (c) c->vis_tag.model = nullptr;   // (a visibility list belongs to one frame and one pose)
     if (!c || !rgb || !depth) return MF_EINVAL;
     hipStream_t sin = c->overlap ? c->stream_pre : c->stream;
     MF_HIP(c, hipStreamSynchronize(c->stream));
@@ -1462,6 +1496,7 @@ extern "C" int mf_stage_frame(mf_ctx* c, const uint8_t* rgb, const float* depth,
 // synchronised -- the caller orders the producers of the three buffers on the context's stream (mf_get_stream) and keeps rgb / depth alive
 // and unmodified until the frame's model-level calls have completed there.
 extern "C" int mf_stage_frame_dev(mf_ctx* c, const uint8_t* d_rgb, const float* d_depth, const uint8_t* d_mask) {
+    if (c) c->vis_tag.model = nullptr;   // (a visibility list belongs to one frame and one pose)
     if (!c || !d_rgb || !d_depth) return MF_EINVAL;
     if (d_mask) MF_HIP(c, hipMemcpyAsync(c->d_mask_tex, d_mask, (size_t)c->P, hipMemcpyDeviceToDevice, c->stream));
     if (c->overlap) {
@@ -1486,6 +1521,8 @@ extern "C" int mf_model_initialise(mf_ctx* c, int32_t model) {
     launch_init_surfels(c->cur_rgb, c->cur_depth, c->d_depthF[k % 3], c->W, c->H, c->K, c->cfg.max_depth_processed, m->d_frame, c->d_cand_rec,
                         c->d_flags, c->stream);
     launch_compact_records(c->d_cand_rec, c->d_flags, c->P, m->surf[m->cur], m->d_frame, c->d_block_counts, m->h_count, c->stream);
+    launch_run_table(m->surf[m->cur], m->d_frame, c->stream);
+    c->vis_tag.model = nullptr;
     if (model == 0) c->map_ready = true;
     return check_launch(c);
 }
@@ -1508,6 +1545,8 @@ extern "C" int mf_model_upload_map(mf_ctx* c, int32_t model, const float* surfel
         MF_HIP(c, hipMemcpy(s.nr, d.data(), count * sizeof(float4), hipMemcpyHostToDevice));
     }
     hipLaunchKernelGGL(k_set_count, dim3(1), dim3(64), 0, c->stream, m->d_frame, (int)count, m->h_count);
+    launch_run_table(m->surf[m->cur], m->d_frame, c->stream);
+    c->vis_tag.model = nullptr;
     if (model == 0) c->map_ready = true;   // the map exists: the next mf_process_frame tracks instead of initialising
     return check_launch(c);
 }
@@ -1517,6 +1556,7 @@ extern "C" int mf_model_override_pose(mf_ctx* c, int32_t model, const float* pos
     ModelState* m = model_at(c, model);
     if (!m || !pose16) return MF_EINVAL;
     launch_override_pose(m->d_pose, pose16, 0, m->h_pose, c->stream);
+    c->vis_tag.model = nullptr;   // a visibility list belongs to ONE pose
     return check_launch(c);
 }
 
@@ -1536,6 +1576,7 @@ extern "C" int mf_model_fusion_weight(mf_ctx* c, int32_t model, float weight_mul
 extern "C" int mf_model_perform_tracking(mf_ctx* c, int32_t model, int32_t frame_to_frame_rgb, int32_t rgb_only, float icp_weight,
                                          int32_t pyramid, int32_t fast_odom, int32_t so3, float max_depth_processed, int64_t log_timestamp,
                                          int32_t try_fill_in) {
+    if (c) c->vis_tag.model = nullptr;   // (a visibility list belongs to one frame and one pose)
     ModelState* m = model_at(c, model);
     (void)log_timestamp;   // only forwarded to a debug print upstream
     if (!m || c->frame_no == 0) return MF_EINVAL;
@@ -1657,6 +1698,7 @@ extern "C" int mf_end_frame(mf_ctx* c, int64_t timestamp) {
 // ------------------------------------------------------------------------------------------------
 // the tracking loop, Core/MaskFusion.cpp:247-276 (trackable classes, static objects follow the background, the 0.2 m jump rule)
 extern "C" int mf_track_models(mf_ctx* c, int32_t first_model, int32_t track_all_models) {
+    if (c) c->vis_tag.model = nullptr;   // (a visibility list belongs to one frame and one pose)
     if (!c || c->frame_no == 0 || first_model < 0 || first_model > 1 || (first_model == 0 && !c->map_ready)) return MF_EINVAL;
     const long k = staged_frame(c);
     if (photometric_on(c)) {   // the same guard as mf_model_perform_tracking
@@ -1728,6 +1770,7 @@ static __global__ void k_make_static(PoseDev* obj, const PoseDev* bg, PoseDev* h
     if (host_mirror) *host_mirror = p;
 }
 extern "C" int mf_make_static(mf_ctx* c, int32_t model) {
+    if (c) c->vis_tag.model = nullptr;   // (a visibility list belongs to one frame and one pose)
     ModelState* m = model_at(c, model);
     if (!m || model == 0) return MF_EINVAL;
     hipLaunchKernelGGL(k_make_static, dim3(1), dim3(64), 0, c->stream, m->d_pose, c->models[0]->d_pose, m->h_pose);
@@ -1884,6 +1927,7 @@ extern "C" int mf_drop_model(mf_ctx* c, int32_t model) {
 }
 // Model::updateStaticPose(globalPose) (Core/Model/Model.h:263): pose = initialC2Winv * background pose
 extern "C" int mf_model_update_static_pose(mf_ctx* c, int32_t model) {
+    if (c) c->vis_tag.model = nullptr;   // (a visibility list belongs to one frame and one pose)
     ModelState* m = model_at(c, model);
     if (!m || model == 0) return MF_EINVAL;
     launch_static_pose(m->d_pose, c->models[0]->d_pose, m->h_pose, c->stream);
@@ -2264,6 +2308,7 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!strcmp(key, "objectSmallGrids")) { c->object_small_grids = value != 0; return MF_OK; }
     if (!strcmp(key, "objectScatterSplat")) { c->object_scatter_splat = value != 0; return MF_OK; }
     if (!strcmp(key, "globalTiles")) { c->global_tiles = value != 0; return MF_OK; }
+    if (!strcmp(key, "cullRuns")) { c->cull_runs = value != 0; c->vis_tag.model = nullptr; return MF_OK; }
     if (!strcmp(key, "cleanLiteralWindow")) { c->clean_literal = value != 0; return MF_OK; }   // 0: the exact-arithmetic 4 x 4 window
     if (!strcmp(key, "earlyBackgroundFusion")) { c->early_bg_fusion = value != 0; return MF_OK; }
     if (!strcmp(key, "modelApiPackedIndex")) { c->model_api_packed = value != 0; return MF_OK; }   // 0: scatter + resolve form (specification)
@@ -2297,6 +2342,15 @@ extern "C" int mf_get_param(mf_ctx* c, const char* key, double* value) {
     if (!c || !key || !value) return MF_EINVAL;
     if (!strcmp(key, "confidenceThreshold")) { *value = c->models[0]->confThr; return MF_OK; }
     if (!strcmp(key, "splatTileEntries")) { *value = c->tile_entries_cap; return MF_OK; }
+    if (!strcmp(key, "cullRuns")) { *value = c->cull_runs ? 1 : 0; return MF_OK; }
+    if (!strcmp(key, "visibleRuns") || !strcmp(key, "backgroundRuns")) {   // test taps: size of the last visibility list / of the background's run table
+        MF_HIP(c, hipStreamSynchronize(c->stream));
+        int v = 0;
+        if (!strcmp(key, "visibleRuns")) MF_HIP(c, hipMemcpy(&v, c->d_vis_count, sizeof(int), hipMemcpyDeviceToHost));
+        else { FrameDev f; MF_HIP(c, hipMemcpy(&f, c->models[0]->d_frame, sizeof(FrameDev), hipMemcpyDeviceToHost)); v = f.runs; }
+        *value = v;
+        return MF_OK;
+    }
     // mean host microseconds per mf_process_frame call since the context was created: staging copy | upload enqueue | frame enqueue | whole call
     if (!strcmp(key, "hostStageUs")) { *value = c->host_calls ? c->host_us[0] / c->host_calls : 0; return MF_OK; }
     if (!strcmp(key, "hostUploadUs")) { *value = c->host_calls ? c->host_us[1] / c->host_calls : 0; return MF_OK; }

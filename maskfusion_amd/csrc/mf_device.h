@@ -53,6 +53,20 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     return v;
 }
 
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// order-preserving map float -> int (and back): integer atomicMin / atomicMax then order floats, negative ones included
+__device__ __forceinline__ int box_enc(float f) { const int b = __float_as_int(f); return b >= 0 ? b : b ^ 0x7FFFFFFF; }
+__device__ __forceinline__ float box_dec(int e) { return __int_as_float(e >= 0 ? e : e ^ 0x7FFFFFFF); }
+
 // rank of this lane among the set lanes of a ballot (wave64)
 __device__ __forceinline__ int lane_rank(unsigned long long mask) {
     const int lo = __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0);
@@ -63,6 +77,14 @@ __device__ __forceinline__ int lane_rank(unsigned long long mask) {
 // scatter passes 5-15 % SLOWER -- the atomics are not what bounds them.)
 __device__ __forceinline__ void zmin_key(unsigned long long* addr, unsigned long long key) {
     atomicMin(addr, key);
+}
+// The same behind a plain read: a fragment that cannot win is dropped without an atomic.  The read may be stale (device-scope atomics are
+// performed memory-side, past the L2 the read hits) -- a stale value is an OLDER, larger key, so a fragment is only ever dropped when it
+// loses against the current one too: same keys, bit for bit.  For the passes of OBJECT models, whose surfels pile up on a few thousand
+// pixels (the 3.4 M-surfel object maps of configs[4]: ~85 fragments per pixel, nearly all of them losers); on a background map at one or two
+// fragments per pixel the extra read costs more than it saves (measured in round 2: +5-15 %).
+__device__ __forceinline__ void zmin_key_pretested(unsigned long long* addr, unsigned long long key) {
+    if (key < __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(addr, key);   // (agent scope: past the per-CU L1, which would keep serving the launch's first value)
 }
 
 // ---- exp() and acos() of the surfel shaders (surfels.glsl:44, data.vert:167): GLSL leaves their last bits to the GPU vendor.

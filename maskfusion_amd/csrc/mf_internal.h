@@ -62,6 +62,7 @@ struct FrameDev {
     int count;                 // Model::count (live surfels)
     int countNext;             // snapshot of `count` taken by clean pass 1 and read by pass 2, whose last workgroup then
                                // rewrites `count` (no workgroup of pass 2 reads `count`, so no intra-launch ordering is assumed)
+    int runs;                  // entries of the live buffer's run table (Surfels::box)
     int cover;                 // predicted-colour coverage count (requiresFillIn)
     int useFillIn;             // decision taken for the current tracking step
     int pad[3];
@@ -90,7 +91,19 @@ struct Surfels {               // SoA of float4, 48 B per surfel in three coales
     float4* ct;                // colour, unused, initTime, lastTime
     float4* nr;                // normal + radius
     int cap;                   // capacity in surfels (writes beyond it are dropped, like a full transform-feedback buffer)
+    // Run table: the buffer as consecutive RUNS of at most kRun surfels (run r = the survivors of the r-th chunk of the clean pass that wrote the
+    // buffer, or -- after Model::initialise / an uploaded map -- slots [r kRun, (r + 1) kRun)), two int4 per run:
+    //   {enc(min x), enc(min y), enc(min z), enc(newest lastTime)}, {enc(max x), enc(max y), enc(max z), first slot of the run}
+    // (enc: order-preserving float -> int, mf_device.h box_enc; entry [frame->runs] carries the buffer's count as the end of the last run).
+    // Surfels are stored in creation order, i.e. in spatially coherent runs; a full map is mostly out of view (the 26.5 M-surfel map of
+    // configs[4]: 86 %), and the projection passes (index map x 2, prediction, GlobalProjection) only visit the runs whose box meets the viewing
+    // frustum and that hold a surfel seen within timeDelta (k_cull) -- the reference streams the whole buffer through every pass
+    // (ModelProjection.cpp:100-152,187-268).  Every frame's clean pass rewrites the buffer and with it the table.
+    int4* box;
 };
+constexpr int kRun = 512;
+struct VisList { const int* list; const int* count; };   // device memory: run indices (any order) and how many (launch_cull)
+constexpr int kBoxEmptyMin = 0x7FFFFFFF, kBoxEmptyMax = (int)0x80000000;
 
 // Persistent per-model block of the tracker (device memory, written once when the model is created): what the batched
 // Gauss-Newton kernels need to find a model's maps, state and partial sums from blockIdx alone.
@@ -213,9 +226,17 @@ void launch_init_surfels(const uint8_t* rgb, const float* depthRaw, const float*
 // Grid of the four grid-stride surfel kernels below: 2048 workgroups by default; a model that is known to be small (an object model
 // of a few thousand surfels) may be launched with fewer -- the loops are grid-stride, the result does not depend on the grid.
 constexpr int kSurfelGridBlocks = 2048;
+// vis: nullptr = every surfel; else the runs launch_cull found possibly visible
 void launch_index_scatter(Surfels src, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k,
                           float maxDepth, int timeDelta, unsigned long long* keys, bool transposed, hipStream_t s,
-                          int blocks = kSurfelGridBlocks);
+                          int blocks = kSurfelGridBlocks, const VisList* vis = nullptr);
+// run table of s from scratch: fixed runs of kRun slots (after Model::initialise / an uploaded map; the clean pass writes it afterwards)
+void launch_run_table(Surfels s, FrameDev* frame, hipStream_t st);
+size_t run_table_entries(long capacity_plus_candidates);   // int4 entries of a run table (2 per run + the end marker)
+// the runs of s whose box meets the viewing frustum (image bounds + 2 px, -1 cm .. maxDepth + 1 cm) and that hold a surfel seen within
+// timeDelta: their indices -> list (any order), their number -> count[0]; ctl: 2 ints, zero between launches
+void launch_cull(Surfels s, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, int timeDelta, int* list, int* count,
+                 int* ctl, int max_runs, hipStream_t st);
 // packed == nullptr: index / vertConf / normRad (+ colorTime if ct != nullptr) images; else one 32 B record per texel
 void launch_index_resolve(Surfels src, const PoseDev* pose, unsigned long long* keys, int W, int H, int* index,
                           float4* vc, float4* nr, float4* ct /*or null*/, float4* packed /*or null*/, hipStream_t s);
@@ -262,7 +283,7 @@ int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W,
                        float4* rec0 /*[src.cap]*/, float4* rec1 /*[src.cap]*/, void* bbox /*[src.cap] x 8 B*/, float4* predV, float4* predN,
                        uchar4* predImage, uint16_t* predTime, const uint8_t* rgb, uint8_t* predGray, uint8_t* fillGray, hipStream_t s,
                        const FrameAdvance* advance = nullptr, int fillPassthrough = 0, unsigned long long* prof = nullptr /*[tiles][8] stamps*/,
-                       SplatTuning tune = SplatTuning());
+                       SplatTuning tune = SplatTuning(), const VisList* vis = nullptr);
 // ---- the surfel passes of ALL object models of a frame, one launch per pass (grid.z = model) ----
 // An object model holds a few thousand surfels: each of its ~11 per-frame launches is pure launch latency (~85 us per object and frame in
 // round 2's profile).  The batched kernels are the single-model kernels' bodies called with one model's arguments, picked from a device
@@ -301,7 +322,7 @@ int gn_solve_standalone(const double* sys29, const double* resultRt16, const flo
                         double* resultRt_out, float* Rcurr9, float* tcurr3, float* stats2, hipStream_t s);
 int launch_global_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
                         int timeDelta, int order, int id, int* tile_count, int* entries, int entries_cap, float4* rec0, float4* rec1, void* bbox,
-                        unsigned long long* keys, hipStream_t s, SplatTuning tune = SplatTuning());
+                        unsigned long long* keys, hipStream_t s, SplatTuning tune = SplatTuning(), const VisList* vis = nullptr);
 void launch_spawn_pose(PoseDev* obj, const PoseDev* bg, FrameDev* objFrame, const FrameDev* bgFrame, PoseDev* host_mirror,
                        hipStream_t s);
 void launch_static_pose(PoseDev* obj, const PoseDev* bg, PoseDev* host_mirror, hipStream_t s);

@@ -152,7 +152,8 @@ __device__ __forceinline__ void global_scatter_body(Surfels src, const FrameDev*
                 const float3 diff = cp - h;
                 if (!(dot3(diff, diff) <= sqrRad)) continue;
                 if (!(cp.z > 0.f)) continue;
-                zmin_key(&keys[py * W + px], ((unsigned long long)__float_as_uint(cp.z) << 32) | payload);
+                if (kLanes > 1) zmin_key_pretested(&keys[py * W + px], ((unsigned long long)__float_as_uint(cp.z) << 32) | payload);   // (object models)
+                else zmin_key(&keys[py * W + px], ((unsigned long long)__float_as_uint(cp.z) << 32) | payload);
             }
     }
 }

@@ -80,6 +80,7 @@ struct BinArgs {
     int tile_cap;
     FrameDev* frame_rw;   // overflow flag (pad[1])
     float4* rec0; float4* rec1; short4* bbox;   // [surfels] sprite set-up kept for the tile pass: {h, r^2}, {n, h.n}, pixel box
+    const int* vis_list; const int* vis_count;  // nullptr: every surfel; else the runs of src (Surfels::box) k_cull listed -- no other run can draw
 };
 
 // Binning in one pass: every tile owns a fixed slice of `entries`, so no scan is needed.  A 1024-thread workgroup counts
@@ -97,14 +98,26 @@ __global__ __launch_bounds__(kBinThreads) void k_splat_bin(const BinArgs a) {
 #pragma unroll
     for (int q = 0; q < 9; ++q) Ri[q] = a.pose->Ri[q];
     const float3 ti = f3(a.pose->ti[0], a.pose->ti[1], a.pose->ti[2]);
-  for (int chunk = blockIdx.x; chunk * 2 * kBinThreads < n; chunk += gridDim.x) {
+  // a round = 2048 surfel slots: 2048 consecutive surfels of the buffer, or -- with a visibility list -- the next 2048 / kRun listed runs
+  constexpr int kRunsPerRound = 2 * kBinThreads / kRun;
+  const int rounds = a.vis_list ? (*a.vis_count + kRunsPerRound - 1) / kRunsPerRound : (n + 2 * kBinThreads - 1) / (2 * kBinThreads);
+  for (int chunk = blockIdx.x; chunk < rounds; chunk += gridDim.x) {
     for (int t = threadIdx.x; t < nt; t += kBinThreads) { s_cnt[t] = 0; s_fill[t] = 0; }
     __syncthreads();
     // 2 surfels per thread; their sprite boxes stay in registers between the two phases
     int idx[2]; short4 bb[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const int i = (chunk * 2 + r) * kBinThreads + threadIdx.x;
+        int i = (chunk * 2 + r) * kBinThreads + threadIdx.x;
+        if (a.vis_list) {
+            const int slot = r * kBinThreads + (int)threadIdx.x, v = chunk * kRunsPerRound + slot / kRun;
+            i = n;
+            if (v < *a.vis_count) {
+                const int run = a.vis_list[v];
+                const int beg = a.src.box[2 * run + 1].w, end = a.src.box[2 * run + 3].w;
+                if (beg + slot % kRun < end) i = beg + slot % kRun;
+            }
+        }
         idx[r] = i;
         bb[r] = make_short4(1, 0, 1, 0);
         if (i < n) {
@@ -150,6 +163,7 @@ struct TileArgs {
     float4* predV; float4* predN; uchar4* predImage; uint16_t* predTime;
     const uint8_t* rgb; uint8_t* predGray; uint8_t* fillGray;
     int fillPassthrough;             // fill_rgb.frag's `passthrough` (frameToFrameRGB, Model.cpp:981): the fill-in image is the raw frame everywhere
+    const int* vis_list; const int* vis_count;   // as BinArgs
     int advance; FrameAdvance adv;   // advance != 0: the last workgroup also runs the end-of-frame bookkeeping (k_frame_advance)
     unsigned long long* prof;        // optional ("splatProfile"): [tiles][8] shader-clock stamps of thread 0 + the tile's list length
 };
@@ -161,7 +175,8 @@ template <bool kIndexPayload, int kSpriteLanes>
 __device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* tile_count, const int* entries, int tile_cap,
                                            const FrameDev* frame, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                                            const short4* __restrict__ bbox, unsigned payload, unsigned long long* s_key, float4* s_ray,
-                                           int* s_range, bool prof, TileStamps& stamp) {
+                                           int* s_range, bool prof, TileStamps& stamp, const int* __restrict__ vis_list,
+                                           const int* __restrict__ vis_count, const int4* __restrict__ runs) {
     const int tx0 = (tile % tilesX) * kTile, ty0 = (tile / tilesX) * kTile;
     if (threadIdx.x < kTile * kTile) {
     s_key[threadIdx.x] = kEmptyKey;
@@ -179,8 +194,16 @@ __device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* ti
     __syncthreads();
     if (prof) { stamp.t[1] = __builtin_amdgcn_s_memtime(); stamp.t[6] = (unsigned long long)s_range[0]; }
     const bool overflow = s_range[0] > tile_cap;   // more sprites than list slots (the reference has no such limit): scan every box
-    const int cnt = overflow ? frame->count : s_range[0];
+    // (after an overflow: every surfel whose sprite box the binning pass wrote -- the whole buffer, or the runs of the visibility list)
+    const int cnt = overflow ? (vis_list ? *vis_count * kRun : frame->count) : s_range[0];
     const int* __restrict__ list = entries + (size_t)tile * tile_cap;
+    auto entry = [&](int e) -> int {
+        if (!overflow) return list[e];
+        if (!vis_list) return e;
+        const int run = vis_list[e / kRun];
+        const int i = runs[2 * run + 1].w + e % kRun;
+        return i < runs[2 * run + 3].w ? i : -1;
+    };
     // kSpriteLanes neighbouring lanes share one sprite and take every kSpriteLanes-th pixel of its clipped box (with one lane per sprite a
     // wavefront runs as long as its largest box).  The lanes read the same list entry / records (one request) and the z-test is order
     // independent, so the keys are the same bits.  Measured on MI355X (profiles/r03h_*): prediction stage 65.5 us with 1 lane,
@@ -196,8 +219,8 @@ __device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* ti
     const int stride = (int)blockDim.x / kSpriteLanes;   // blockDim.x = 256, 512 or 1024 ("tileThreads")
     const int e0 = threadIdx.x / kSpriteLanes;
     const short4 kNoBox = make_short4(1, 0, 1, 0);
-    int i0 = e0 < cnt ? (overflow ? e0 : list[e0]) : -1;
-    int i1 = e0 + stride < cnt ? (overflow ? e0 + stride : list[e0 + stride]) : -1;
+    int i0 = e0 < cnt ? entry(e0) : -1;
+    int i1 = e0 + stride < cnt ? entry(e0 + stride) : -1;
     short4 bb0 = i0 >= 0 ? bbox[i0] : kNoBox;
     float4 r0 = i0 >= 0 ? rec0[i0] : make_float4(0, 0, 0, 0), r1 = i0 >= 0 ? rec1[i0] : make_float4(0, 0, 0, 0);
     for (int e = e0; e < cnt; e += stride) {
@@ -206,7 +229,7 @@ __device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* ti
         const float4 c0 = r0, c1 = r1;
         // loads of the rounds to come (nothing below depends on them)
         const int e2 = e + 2 * stride;
-        const int i2 = e2 < cnt ? (overflow ? e2 : list[e2]) : -1;
+        const int i2 = e2 < cnt ? entry(e2) : -1;
         if (i1 >= 0) { bb0 = bbox[i1]; r0 = rec0[i1]; r1 = rec1[i1]; } else bb0 = kNoBox;
         i0 = i1; i1 = i2;
         const int x0 = max((int)bb.x, tx0), x1 = min((int)bb.y, tx0 + kTile - 1);
@@ -263,7 +286,7 @@ __global__ __launch_bounds__(1024) void k_splat_tile(const TileArgs a) {
         stamp.t[0] = __builtin_amdgcn_s_memtime();
     }
     if (live) tile_ztest<true, kSpriteLanes>(tile, a.tilesX, k, a.tile_count, a.entries, a.tile_cap, a.frame, a.rec0, a.rec1, a.bbox, 0u, s_key, s_ray, s_range,
-                                            prof, stamp);
+                                            prof, stamp, a.vis_list, a.vis_count, a.src.box);
     const int px = tx0 + (threadIdx.x & (kTile - 1)), py = ty0 + (threadIdx.x >> 4);
     int covered = 0;   // this pixel is one of the 20x down-sampled samples of MaskFusion::requiresFillIn and carries a colour
     if (live && threadIdx.x < kTile * kTile && px < a.W && py < a.H) {   // (threads beyond the tile's 256 pixels only helped with the list)
@@ -345,6 +368,7 @@ struct GlobalTileArgs {
     int* tile_count; const int* entries; int tile_cap;
     const float4* rec0; const float4* rec1; const short4* bbox;
     unsigned payload; unsigned long long* keys;
+    const int* vis_list; const int* vis_count; const int4* runs;   // as BinArgs (runs = src.box)
 };
 template <int kSpriteLanes>
 __global__ __launch_bounds__(1024) void k_global_tile(const GlobalTileArgs a) {
@@ -355,7 +379,7 @@ __global__ __launch_bounds__(1024) void k_global_tile(const GlobalTileArgs a) {
     if (tile >= a.tilesX * a.tilesY) return;
     TileStamps unused;
     tile_ztest<false, kSpriteLanes>(tile, a.tilesX, a.k, a.tile_count, a.entries, a.tile_cap, a.frame, a.rec0, a.rec1, a.bbox, a.payload, s_key, s_ray, s_range,
-                                    false, unused);
+                                    false, unused, a.vis_list, a.vis_count, a.runs);
     const int px = (tile % a.tilesX) * kTile + (threadIdx.x & (kTile - 1)), py = (tile / a.tilesX) * kTile + (threadIdx.x >> 4);
     if (threadIdx.x >= kTile * kTile || px >= a.W || py >= a.H) return;
     const unsigned long long key = s_key[threadIdx.x];
@@ -366,7 +390,7 @@ __global__ __launch_bounds__(1024) void k_global_tile(const GlobalTileArgs a) {
 
 int launch_global_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
                         int timeDelta, int order, int id, int* tile_count, int* entries, int entries_cap, float4* rec0, float4* rec1, void* bbox,
-                        unsigned long long* keys, hipStream_t s, SplatTuning tune) {
+                        unsigned long long* keys, hipStream_t s, SplatTuning tune, const VisList* vis) {
     const int tilesX = (W + kTile - 1) / kTile, tilesY = (H + kTile - 1) / kTile, nt = tilesX * tilesY;
     if (nt > kMaxTiles) return -1;
     const int g_sprite_lanes = splat_sprite_lanes(tune.sprite_lanes), g_tile_threads = splat_tile_threads(tune.tile_threads);
@@ -375,6 +399,7 @@ int launch_global_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W
     b.timeDelta = timeDelta; b.tilesX = tilesX; b.tilesY = tilesY; b.tile_count = tile_count;
     b.entries = entries; b.tile_cap = entries_cap / nt; b.frame_rw = frame;
     b.rec0 = rec0; b.rec1 = rec1; b.bbox = reinterpret_cast<short4*>(bbox);
+    b.vis_list = vis ? vis->list : nullptr; b.vis_count = vis ? vis->count : nullptr;
     // two 1024-thread workgroups fit on a CU (60 VGPRs): 512 workgroups are ONE round of chunks up to a million surfels (with 256 a
     // 0.6 M-surfel map was 293 chunks = two rounds, the second one on 37 CUs)
     const int nblocks = min(512, (src.cap + 2 * kBinThreads - 1) / (2 * kBinThreads));
@@ -383,6 +408,7 @@ int launch_global_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W
     t.frame = frame; t.W = W; t.H = H; t.k = k; t.tilesX = tilesX; t.tilesY = tilesY; t.tile_count = tile_count; t.entries = entries; t.tile_cap = b.tile_cap;
     t.rec0 = rec0; t.rec1 = rec1; t.bbox = reinterpret_cast<const short4*>(bbox);
     t.payload = ((unsigned)order << 8) | ((unsigned)id & 255u); t.keys = keys;
+    t.vis_list = b.vis_list; t.vis_count = b.vis_count; t.runs = src.box;
     switch (g_sprite_lanes) {
         case 1: hipLaunchKernelGGL(k_global_tile<1>, dim3(xcd_padded_grid(nt)), dim3(g_tile_threads), 0, s, t); break;
         case 2: hipLaunchKernelGGL(k_global_tile<2>, dim3(xcd_padded_grid(nt)), dim3(g_tile_threads), 0, s, t); break;
@@ -398,7 +424,7 @@ size_t splat_tiles_scratch_ints(int W, int H) { return (size_t)((W + kTile - 1) 
 int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
                        int timeDelta, int* tile_count, int* entries, int entries_cap, float4* rec0, float4* rec1, void* bbox, float4* predV,
                        float4* predN, uchar4* predImage, uint16_t* predTime, const uint8_t* rgb, uint8_t* predGray, uint8_t* fillGray, hipStream_t s,
-                       const FrameAdvance* advance, int fillPassthrough, unsigned long long* prof, SplatTuning tune) {
+                       const FrameAdvance* advance, int fillPassthrough, unsigned long long* prof, SplatTuning tune, const VisList* vis) {
     const int tilesX = (W + kTile - 1) / kTile, tilesY = (H + kTile - 1) / kTile, nt = tilesX * tilesY;
     if (nt > kMaxTiles) return -1;
     const int g_sprite_lanes = splat_sprite_lanes(tune.sprite_lanes), g_tile_threads = splat_tile_threads(tune.tile_threads);
@@ -407,6 +433,7 @@ int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W,
     b.timeDelta = timeDelta; b.tilesX = tilesX; b.tilesY = tilesY; b.tile_count = tile_count;
     b.entries = entries; b.tile_cap = entries_cap / nt; b.frame_rw = frame;
     b.rec0 = rec0; b.rec1 = rec1; b.bbox = reinterpret_cast<short4*>(bbox);
+    b.vis_list = vis ? vis->list : nullptr; b.vis_count = vis ? vis->count : nullptr;
     // two 1024-thread workgroups fit on a CU (60 VGPRs): 512 workgroups are ONE round of chunks up to a million surfels (with 256 a
     // 0.6 M-surfel map was 293 chunks = two rounds, the second one on 37 CUs)
     const int nblocks = min(512, (src.cap + 2 * kBinThreads - 1) / (2 * kBinThreads));
@@ -419,6 +446,7 @@ int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W,
     t.fillGray = fillGray;
     t.fillPassthrough = fillPassthrough;
     t.prof = prof;
+    t.vis_list = b.vis_list; t.vis_count = b.vis_count;
     t.advance = advance ? 1 : 0;
     t.adv = advance ? *advance : FrameAdvance{nullptr, nullptr, nullptr};
     switch (g_sprite_lanes) {

@@ -158,42 +158,173 @@ void launch_compact_records(const float4* rec, const uint8_t* flags, int n, Surf
 // ------------------------------------------------------------------------------------------------
 // (bodies are __device__ functions: the single-model kernels call them with their own arguments, the batched object-model kernels at the
 // end of this file with one model's arguments picked by blockIdx.z)
+__device__ __forceinline__ void index_scatter_one(const Surfels& src, int i, float time, const float* Ri, float3 ti, int W, int H, Intr k,
+                                                  float maxDepth, int timeDelta, unsigned long long* __restrict__ keys, int transposed,
+                                                  bool pretest = false) {
+    const float4 pc = src.pc[i];
+    const float lastTime = src.ct[i].w;
+    const float3 h = mul33(Ri, f3(pc.x, pc.y, pc.z)) + ti;
+    if (h.z > maxDepth || h.z <= 0 || time - lastTime > (float)timeDelta) return;  // index_map.vert:46
+    const float u = ((k.fx * h.x) / h.z) + k.cx;
+    const float v = ((k.fy * h.y) / h.z) + k.cy;
+    if (!(u >= 0.f && u < (float)W && v >= 0.f && v < (float)H)) return;
+    // transposed (column-major) texel order for the pass that feeds clean(): surfels are stored in column-major creation
+    // order (data.vert), so consecutive surfels then touch consecutive texels instead of one cache line per image row
+    const int p = transposed ? (int)floorf(u) * H + (int)floorf(v) : (int)floorf(v) * W + (int)floorf(u);
+    const unsigned long long key = ((unsigned long long)__float_as_uint(h.z) << 32) | (unsigned)i;
+    if (pretest) zmin_key_pretested(&keys[p], key);
+    else zmin_key(&keys[p], key);
+}
+
+// vis_list == nullptr: every surfel of the buffer; else only the runs k_cull listed (Surfels::box) -- the others hold no surfel that could
+// pass the tests above, so the keys are the same bits either way
 __device__ __forceinline__ void index_scatter_body(Surfels src, const FrameDev* __restrict__ frame,
                                                    const PoseDev* __restrict__ pose, int W, int H, Intr k, float maxDepth,
-                                                   int timeDelta, unsigned long long* __restrict__ keys, int transposed) {
+                                                   int timeDelta, unsigned long long* __restrict__ keys, int transposed,
+                                                   const int* __restrict__ vis_list = nullptr, const int* __restrict__ vis_count = nullptr,
+                                                   bool pretest = false) {
     const int n = frame->count;
     const float time = (float)frame->tick;
     float Ri[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) Ri[q] = pose->Ri[q];
     const float3 ti = f3(pose->ti[0], pose->ti[1], pose->ti[2]);
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const float4 pc = src.pc[i];
-        const float lastTime = src.ct[i].w;
-        const float3 h = mul33(Ri, f3(pc.x, pc.y, pc.z)) + ti;
-        if (h.z > maxDepth || h.z <= 0 || time - lastTime > (float)timeDelta) continue;  // index_map.vert:46
-        const float u = ((k.fx * h.x) / h.z) + k.cx;
-        const float v = ((k.fy * h.y) / h.z) + k.cy;
-        if (!(u >= 0.f && u < (float)W && v >= 0.f && v < (float)H)) continue;
-        // transposed (column-major) texel order for the pass that feeds clean(): surfels are stored in column-major creation
-        // order (data.vert), so consecutive surfels then touch consecutive texels instead of one cache line per image row
-        // (k_clean_flags: 157 MB -> L2-resident gathers, 53 -> 28 us; the scatter / resolve of that pass gain ~25 % too)
-        const int p = transposed ? (int)floorf(u) * H + (int)floorf(v) : (int)floorf(v) * W + (int)floorf(u);
-        const unsigned long long key = ((unsigned long long)__float_as_uint(h.z) << 32) | (unsigned)i;
-        zmin_key(&keys[p], key);
+    if (vis_list) {
+        const int nv = *vis_count;
+        for (int v = blockIdx.x; v < nv; v += gridDim.x) {
+            const int r = vis_list[v];
+            const int beg = src.box[2 * r + 1].w, end = min(n, src.box[2 * r + 3].w);
+            for (int i = beg + (int)threadIdx.x; i < end; i += 256) index_scatter_one(src, i, time, Ri, ti, W, H, k, maxDepth, timeDelta, keys, transposed);
+        }
+        return;
     }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+        index_scatter_one(src, i, time, Ri, ti, W, H, k, maxDepth, timeDelta, keys, transposed, pretest);
 }
 
 __global__ __launch_bounds__(256) void k_index_scatter(Surfels src, const FrameDev* __restrict__ frame,
                                                        const PoseDev* __restrict__ pose, int W, int H, Intr k, float maxDepth,
-                                                       int timeDelta, unsigned long long* __restrict__ keys, int transposed) {
-    index_scatter_body(src, frame, pose, W, H, k, maxDepth, timeDelta, keys, transposed);
+                                                       int timeDelta, unsigned long long* __restrict__ keys, int transposed,
+                                                       const int* __restrict__ vis_list, const int* __restrict__ vis_count) {
+    index_scatter_body(src, frame, pose, W, H, k, maxDepth, timeDelta, keys, transposed, vis_list, vis_count);
 }
 
 void launch_index_scatter(Surfels src, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth,
-                          int timeDelta, unsigned long long* keys, bool transposed, hipStream_t s, int blocks) {
+                          int timeDelta, unsigned long long* keys, bool transposed, hipStream_t s, int blocks, const VisList* vis) {
     hipLaunchKernelGGL(k_index_scatter, dim3(blocks), dim3(256), 0, s, src, frame, pose, W, H, k, maxDepth, timeDelta, keys,
-                       transposed ? 1 : 0);
+                       transposed ? 1 : 0, vis ? vis->list : nullptr, vis ? vis->count : nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// run table (Surfels::box) from scratch, and the visibility test over it
+// ------------------------------------------------------------------------------------------------
+// block reduction of one run's box: per-thread (already reduced over the thread's own surfels) -> int4 pair; s_red: 4 x 8 ints of LDS
+__device__ __forceinline__ void run_box_reduce(int (&lo)[3], int (&hi)[3], int tmax, int (*s_red)[8]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { lo[q] = wave_min_i(lo[q]); hi[q] = wave_max_i(hi[q]); }
+    tmax = wave_max_i(tmax);
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { s_red[wave][q] = lo[q]; s_red[wave][4 + q] = hi[q]; }
+        s_red[wave][3] = tmax;
+    }
+}
+__device__ __forceinline__ void run_box_accumulate(float4 pc, float lastTime, int (&lo)[3], int (&hi)[3], int& tmax) {
+    if (pc.x == pc.x && pc.y == pc.y && pc.z == pc.z) {   // (a NaN position is never in view)
+        const int ex = box_enc(pc.x), ey = box_enc(pc.y), ez = box_enc(pc.z);
+        lo[0] = min(lo[0], ex); lo[1] = min(lo[1], ey); lo[2] = min(lo[2], ez);
+        hi[0] = max(hi[0], ex); hi[1] = max(hi[1], ey); hi[2] = max(hi[2], ez);
+    }
+    if (lastTime == lastTime) tmax = max(tmax, box_enc(lastTime));
+}
+// thread 0 .. : the four wavefronts' partial boxes -> the table entry of run r starting at slot `start`
+__device__ __forceinline__ void run_box_store(int4* __restrict__ box, int r, int start, const int (*s_red)[8]) {
+    int4 a, b;
+    a.x = min(min(s_red[0][0], s_red[1][0]), min(s_red[2][0], s_red[3][0]));
+    a.y = min(min(s_red[0][1], s_red[1][1]), min(s_red[2][1], s_red[3][1]));
+    a.z = min(min(s_red[0][2], s_red[1][2]), min(s_red[2][2], s_red[3][2]));
+    a.w = max(max(s_red[0][3], s_red[1][3]), max(s_red[2][3], s_red[3][3]));
+    b.x = max(max(s_red[0][4], s_red[1][4]), max(s_red[2][4], s_red[3][4]));
+    b.y = max(max(s_red[0][5], s_red[1][5]), max(s_red[2][5], s_red[3][5]));
+    b.z = max(max(s_red[0][6], s_red[1][6]), max(s_red[2][6], s_red[3][6]));
+    b.w = start;
+    box[2 * r] = a; box[2 * r + 1] = b;
+}
+
+__global__ __launch_bounds__(256) void k_run_table(Surfels s, FrameDev* __restrict__ frame) {
+    __shared__ int s_red[4][8];
+    const int n = frame->count;
+    const int runs = (n + kRun - 1) / kRun;
+    for (int r = blockIdx.x; r < runs; r += gridDim.x) {
+        int lo[3] = {kBoxEmptyMin, kBoxEmptyMin, kBoxEmptyMin}, hi[3] = {kBoxEmptyMax, kBoxEmptyMax, kBoxEmptyMax}, tmax = kBoxEmptyMax;
+        for (int i = r * kRun + (int)threadIdx.x; i < min(n, (r + 1) * kRun); i += 256) run_box_accumulate(s.pc[i], s.ct[i].w, lo, hi, tmax);
+        run_box_reduce(lo, hi, tmax, s_red);
+        __syncthreads();
+        if (threadIdx.x == 0) run_box_store(s.box, r, r * kRun, s_red);
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        s.box[2 * runs + 1] = make_int4(0, 0, 0, n);   // end of the last run
+        frame->runs = runs;
+    }
+}
+void launch_run_table(Surfels s, FrameDev* frame, hipStream_t st) {
+    hipLaunchKernelGGL(k_run_table, dim3(1024), dim3(256), 0, st, s, frame);
+}
+size_t run_table_entries(long elements) { return (size_t)(2 * ((elements + kRun - 1) / kRun + 2)); }
+
+// One thread per run: conservative frustum test of the run's box under `pose` (the per-surfel tests of the passes that consume the list are
+// u in [0, W] x [0, H] and 0 <= z <= maxDepth on individually rounded floats: the box is tested against the image grown by 2 px and the depth
+// range grown by 1 cm -- metres against rounding errors of micrometres) and the activity test (no surfel seen within timeDelta: every pass
+// drops all of them, index_map.vert:46, splat.vert:58).  Runs that pass are appended to `list` in no particular order.
+__global__ __launch_bounds__(256) void k_cull(Surfels s, const FrameDev* __restrict__ frame, const PoseDev* __restrict__ pose, int W, int H, Intr k,
+                                              float maxDepth, int timeDelta, int* __restrict__ list, int* __restrict__ count, int* __restrict__ ctl) {
+    const int runs = frame->runs;
+    const float time = (float)frame->tick;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    bool vis = false;
+    if (r < runs) {
+        const int4 a = s.box[2 * r], b = s.box[2 * r + 1];
+        const int len = s.box[2 * r + 3].w - b.w;
+        if (len > 0 && a.x <= b.x && a.y <= b.y && a.z <= b.z && !(time - box_dec(a.w) > (float)timeDelta)) {
+            const float lo[3] = {box_dec(a.x), box_dec(a.y), box_dec(a.z)}, hi[3] = {box_dec(b.x), box_dec(b.y), box_dec(b.z)};
+            // every corner outside the SAME half-space => the whole box is: near / far, then the four image sides as planes through the eye
+            // (u < -2  <=>  fx x + (cx + 2) z < 0 for z > 0; points with z <= 0 fail the depth test anyway)
+            int out_near = 1, out_far = 1, out_l = 1, out_r = 1, out_t = 1, out_b = 1;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float3 p = f3((c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]);
+                const float3 h = mul33(pose->Ri, p) + f3(pose->ti[0], pose->ti[1], pose->ti[2]);
+                out_near &= h.z < -0.01f;
+                out_far &= h.z > maxDepth + 0.01f;
+                out_l &= k.fx * h.x + (k.cx + 2.f) * h.z < 0.f;
+                out_r &= k.fx * h.x + (k.cx - (float)W - 2.f) * h.z > 0.f;
+                out_t &= k.fy * h.y + (k.cy + 2.f) * h.z < 0.f;
+                out_b &= k.fy * h.y + (k.cy - (float)H - 2.f) * h.z > 0.f;
+            }
+            vis = !(out_near | out_far | out_l | out_r | out_t | out_b);
+        }
+    }
+    const unsigned long long m = __ballot(vis);
+    int base = 0;
+    if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(&ctl[0], __popcll(m));
+    base = __shfl(base, 0, 64);
+    if (vis) list[base + lane_rank(m)] = r;
+    // the last workgroup to finish publishes the count and re-arms the counters
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int done = __hip_atomic_fetch_add(&ctl[1], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (int)gridDim.x - 1) {
+            count[0] = __hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+void launch_cull(Surfels s, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, int timeDelta, int* list, int* count,
+                 int* ctl, int max_runs, hipStream_t st) {
+    hipLaunchKernelGGL(k_cull, dim3((max_runs + 255) / 256), dim3(256), 0, st, s, frame, pose, W, H, k, maxDepth, timeDelta, list, count, ctl);
 }
 
 // Two consumers, two output shapes (the index_map.frag attachments that each of them samples):
@@ -550,8 +681,10 @@ __device__ __forceinline__ bool clean_test(const CleanArgs& a, float4 pc, float4
 // terminates), and copies its survivors to their final slots -- the order of the output is the order of the input, as transform feedback
 // keeps it.  The records stay in registers between the test and the copy.
 // ------------------------------------------------------------------------------------------------
-constexpr int kCleanPerThread = 4;
+constexpr int kCleanPerThread = 2;
 constexpr int kCleanChunk = 256 * kCleanPerThread;
+static_assert(kCleanChunk == kRun, "a clean chunk's survivors are one run of the new buffer's run table");
+constexpr int kLookPerLane = 4;   // states of earlier chunks a lane reads per look-back step: 256 per step and wavefront
 constexpr unsigned kScanAggregate = 1u, kScanInclusive = 2u;
 
 __device__ __forceinline__ unsigned long long scan_load(const unsigned long long* p) {
@@ -561,31 +694,47 @@ __device__ __forceinline__ void scan_store(unsigned long long* p, unsigned long 
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// exclusive prefix of chunk `chunk` (> 0), by wavefront 0: lanes read the states of the 64 chunks before it, nearest first
+// exclusive prefix of chunk `chunk` (> 0), by wavefront 0.  A step reads the states of the 256 chunks before the part already summed -- lane l
+// those at distance 4 l .. 4 l + 3, nearest first -- waits until each of them has published something for THIS launch, and adds them up to and
+// including the nearest one that carries an inclusive prefix.  (Round 5, first version: 64 states per step.  Every step is a round trip to memory
+// -- the states are read at agent scope, past the non-coherent L2 -- and with ~1000 chunks in flight a chunk walked ~16 of them, ~25 us, before it
+// could write: the pass was bound by its look-back, 26 k chunks in ~0.9 ms.  256 per step cut the walk to four.)
 __device__ __forceinline__ int scan_look_back(const unsigned long long* __restrict__ state, int chunk, unsigned epoch, int& gave_up) {
     const int lane = threadIdx.x & 63;
     int exclusive = 0;
     int idx = chunk - 1;          // nearest chunk not yet accounted for
     for (;;) {
-        const int mine = idx - lane;
-        unsigned long long v = 0;
-        unsigned tag = 0;
+        unsigned long long v[kLookPerLane];
         int spins = 0;
-        for (;;) {    // every lane that has a chunk to read waits until that chunk has published something for THIS launch
-            if (mine >= 0) { v = scan_load(&state[mine]); tag = (unsigned)(v >> 32); }
-            const bool ready = mine < 0 || (tag >> 2) == epoch;
+        for (;;) {
+            bool ready = true;
+#pragma unroll
+            for (int q = 0; q < kLookPerLane; ++q) {
+                const int mine = idx - (lane * kLookPerLane + q);
+                v[q] = mine >= 0 ? scan_load(&state[mine]) : 0ull;
+                ready = ready && (mine < 0 || (unsigned)(v[q] >> 34) == epoch);
+            }
             if (__ballot(!ready) == 0ull) break;
             if (++spins > (1 << 22)) { gave_up = 1; break; }   // never in a correct run: a bounded wait cannot hang the GPU
             __builtin_amdgcn_s_sleep(1);
         }
-        const bool inclusive = mine >= 0 && (tag >> 2) == epoch && (tag & 3u) == kScanInclusive;
-        const unsigned long long incl_mask = __ballot(inclusive);
-        // lanes up to (and including) the nearest chunk that carries an inclusive prefix contribute; without one, all 64 do
+        // this lane's values up to and including its nearest inclusive entry (if it has one)
+        int mine_sum = 0;
+        bool has_incl = false;
+#pragma unroll
+        for (int q = 0; q < kLookPerLane; ++q) {
+            const int mine = idx - (lane * kLookPerLane + q);
+            const bool valid = mine >= 0 && (unsigned)(v[q] >> 34) == epoch;
+            if (valid && !has_incl) {
+                mine_sum += (int)(unsigned)(v[q] & 0xFFFFFFFFull);
+                has_incl = ((unsigned)(v[q] >> 32) & 3u) == kScanInclusive;
+            }
+        }
+        const unsigned long long incl_mask = __ballot(has_incl);
         const int stop = incl_mask ? __builtin_ctzll(incl_mask) : 63;
-        int contrib = (mine >= 0 && lane <= stop) ? (int)(unsigned)(v & 0xFFFFFFFFull) : 0;
-        exclusive += wave_sum_i(contrib);
-        if (incl_mask || idx - 64 < 0 || gave_up) break;
-        idx -= 64;
+        exclusive += wave_sum_i(lane <= stop ? mine_sum : 0);
+        if (incl_mask || idx - 64 * kLookPerLane < 0 || gave_up) break;
+        idx -= 64 * kLookPerLane;
     }
     return exclusive;
 }
@@ -594,6 +743,7 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
     __shared__ int s_chunk, s_base;
     __shared__ int s_cnt[kCleanPerThread][4];
     __shared__ int s_bb[6];
+    __shared__ int s_red[4][8];   // the run's box (Surfels::box of dst): per-wavefront partial results
     // Model::lastBoundingBox of an OBJECT model (Model.cpp:315-345 + draw_global_surface.vert:55-78: the box of the surfels the GUI draws --
     // confidence above the model's threshold -- in millimetres, truncated): accumulated here, where the frame's final records pass through
     // registers anyway; Model::fuse of the NEXT frame limits its depth with it (Model.cpp:480-501).  The background (id 0) never uses one.
@@ -632,6 +782,7 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
         }
         bool keep[kCleanPerThread];
         int rank[kCleanPerThread];
+        int rlo[3] = {kBoxEmptyMin, kBoxEmptyMin, kBoxEmptyMin}, rhi[3] = {kBoxEmptyMax, kBoxEmptyMax, kBoxEmptyMax}, rtime = kBoxEmptyMax;
 #pragma unroll
         for (int j = 0; j < kCleanPerThread; ++j) {
             float nc = 0.f;
@@ -642,10 +793,12 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
             }
             pc[j].w = nc;
             if (ct[j].w == -2.f) ct[j].w = time;  // copy_unstable.vert:131
+            if (keep[j]) run_box_accumulate(pc[j], ct[j].w, rlo, rhi, rtime);
             const unsigned long long m = __ballot(keep[j]);
             rank[j] = lane_rank(m);
             if (lane == 0) s_cnt[j][wave] = __popcll(m);
         }
+        run_box_reduce(rlo, rhi, rtime, s_red);   // the survivors of this chunk are run `chunk` of the new buffer
         __syncthreads();
         if (wave == 0) {
             int tot = 0;
@@ -661,7 +814,11 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
                 scan_store(&a.scan_state[chunk], tag | ((unsigned long long)kScanInclusive << 32) | (unsigned)(excl + tot));
                 s_base = excl;
                 if (gave_up) a.frame->pad[2] = 1;
-                if (chunk == nchunks - 1) __hip_atomic_store(&a.frame->countNext, min(excl + tot, a.dst.cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                run_box_store(a.dst.box, chunk, min(excl, a.dst.cap), s_red);
+                if (chunk == nchunks - 1) {
+                    a.dst.box[2 * nchunks + 1] = make_int4(0, 0, 0, min(excl + tot, a.dst.cap));   // end of the last run
+                    __hip_atomic_store(&a.frame->countNext, min(excl + tot, a.dst.cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
         __syncthreads();
@@ -700,6 +857,7 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
         if (done == (int)gridDim.x - 1) {
             const int n = __hip_atomic_load(&a.frame->countNext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             a.frame->count = n;
+            a.frame->runs = nchunks;
             if (a.host_count) *a.host_count = n;
             if (bbox_on) {   // the box of a frame is the box of its LAST clean pass (the reference's render pass sees the final buffer)
                 for (int q = 0; q < 6; ++q) {
@@ -783,7 +941,8 @@ __device__ __forceinline__ void splat_scatter_body(Surfels src, const FrameDev* 
                 if (!(dot3(diff, diff) <= sqrRad)) continue;
                 if (!(cp.z > 0.f)) continue;
                 const unsigned long long key = ((unsigned long long)__float_as_uint(cp.z) << 32) | (unsigned)i;
-                zmin_key(&keys[py * W + px], key);
+                if (kLanes > 1) zmin_key_pretested(&keys[py * W + px], key);   // (the object models' launches)
+                else zmin_key(&keys[py * W + px], key);
             }
         }
     }
@@ -922,7 +1081,7 @@ void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_obj_index_scatter(const ObjBatch b) {
     const ObjPassArgs& m = b.m[blockIdx.z];
-    index_scatter_body(m.a, m.frame, m.pose, b.W, b.H, b.k, b.maxDepthProcessed, b.timeDelta, m.keys, 0);
+    index_scatter_body(m.a, m.frame, m.pose, b.W, b.H, b.k, b.maxDepthProcessed, b.timeDelta, m.keys, 0, nullptr, nullptr, true);
 }
 __global__ __launch_bounds__(256) void k_obj_index_resolve(const ObjBatch b, int second) {
     const ObjPassArgs& m = b.m[blockIdx.z];
@@ -941,7 +1100,7 @@ __global__ __launch_bounds__(256) void k_obj_fuse_update(const ObjBatch b) {
 }
 __global__ __launch_bounds__(256) void k_obj_index_scatter2(const ObjBatch b) {   // predictIndices after fuse (MaskFusion.cpp:556), column-major texels
     const ObjPassArgs& m = b.m[blockIdx.z];
-    index_scatter_body(m.a, m.frame, m.pose, b.W, b.H, b.k, b.maxDepthProcessed, b.timeDelta, m.keys, 1);
+    index_scatter_body(m.a, m.frame, m.pose, b.W, b.H, b.k, b.maxDepthProcessed, b.timeDelta, m.keys, 1, nullptr, nullptr, true);
 }
 __device__ __forceinline__ CleanArgs obj_clean_args(const ObjBatch& b, const ObjPassArgs& m) {
     CleanArgs a;

@@ -394,3 +394,37 @@ def test_config2_standin_maskdir_one_moving_object_gui_defaults(hip, oracle, tmp
     mf.close(); o.close()
     print("configs[2] stand-in:", k + 1, "frames, models", n_models, "max pose difference", worst)
     assert k + 1 == n and n_models == 2
+
+
+def test_run_culling_changes_nothing(hip):
+    """`cullRuns` (round 5): the projection passes (index map x 2, prediction, GlobalProjection) only visit the runs of the surfel buffer whose
+    bounding box meets the viewing frustum.  On a pre-filled room map of which the camera sees a fraction, with culling on and off: poses,
+    counts, every surfel and the prediction maps bit-identical on every frame -- and the visibility list really is a fraction of the table."""
+    from maskfusion_amd import MaskFusion, synth
+    W, H, f = 320, 240, 264.0
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
+    frames = [st.frame(k) for k in range(8)]
+    room = synth.dense_room_map(st.scene, 600_000, last_time=1.0)
+
+    def run(cull):
+        mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=False, numGSurfels=1 << 20, initConfidenceGlobal=10.0)
+        mf.setParam("cullRuns", 1 if cull else 0)
+        out = []
+        for k, (rgb, d, _) in enumerate(frames):
+            mf.processFrame(rgb, d, timestamp=k)
+            if k == 0:
+                mf.getBackgroundModel().uploadMap(room)
+            bg = mf.getBackgroundModel()
+            out.append(dict(pose=mf.getCurrPose(), count=bg.lastCount(), pv=bg.debugRead("pred_vertex"), pi=bg.debugRead("pred_image")))
+        cloud = mf.getBackgroundModel().downloadMap()
+        vis, runs = mf.getParam("visibleRuns"), mf.getParam("backgroundRuns")
+        mf.close()
+        return out, cloud, vis, runs
+
+    (a, ca, vis, runs), (b, cb, _, _) = run(True), run(False)
+    print("visible runs", vis, "of", runs)
+    assert 0 < vis < 0.6 * runs and runs >= 600_000 / 512
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert x["count"] == y["count"] and np.array_equal(x["pose"], y["pose"]), k
+        assert np.array_equal(x["pv"], y["pv"], equal_nan=True) and np.array_equal(x["pi"], y["pi"]), k
+    assert np.array_equal(ca, cb, equal_nan=True)
