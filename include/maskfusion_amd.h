@@ -213,6 +213,8 @@ void* mf_get_input_stream(mf_ctx* ctx);
  * what: "depthF" (H*W f32), "vmap0".."vmap2", "nmap0".."nmap2" (3*h*w f32, current frame),
  *       "vmap_g0".."vmap_g2", "nmap_g0".."nmap_g2" (model side), "pred_vertex", "pred_normal" (H*W*4 f32),
  *       "pred_image" (H*W*4 u8), "pred_time" (H*W u16), "icp_log" (19*32 f32: per-iteration A-upper/b/res/inl),
+ *       "gn_trace" (20*64 f64, geometric loop: row r = the reduced system of iteration r as summed in fp64 [0..31], then resultRt [32..47],
+ *       Rcurr [48..56], tcurr [57..59] as iteration r used them; row 19 = the state after the last update),
  *       "edge_map" (H*W f32), "edge_binary" (H*W u8), "projected_ids" (H*W u8);
  *       index map of the last (pre-fusion) index pass, index_map.frag's attachments: "index" (H*W i32), "index_vc", "index_nr",
  *       "index_ct" (H*W*4 f32), "index_packed" (post-fusion pass: 2 float4 per texel, column-major texel order);

@@ -354,7 +354,7 @@ class MaskFusion:
         shapes = {"depthF": ((H, W), np.float32), "pred_vertex": ((H, W, 4), np.float32),
                   "pred_normal": ((H, W, 4), np.float32), "pred_image": ((H, W, 4), np.uint8), "pred_time": ((H, W), np.uint16),
                   "index": ((H, W), np.int32), "index_vc": ((H, W, 4), np.float32), "index_nr": ((H, W, 4), np.float32),
-                  "index_ct": ((H, W, 4), np.float32), "index_packed": ((W, H, 2, 4), np.float32), "icp_log": ((19, 32), np.float32),
+                  "index_ct": ((H, W, 4), np.float32), "index_packed": ((W, H, 2, 4), np.float32), "icp_log": ((19, 32), np.float32), "gn_trace": ((20, 64), np.float64),
                   "icp_prof": ((19, 16), np.uint64), "splat_prof": ((((H + 15) // 16) * ((W + 15) // 16), 8), np.uint64),
                   "edge_map": ((H, W), np.float32),
                   "edge_binary": ((H, W), np.uint8), "projected_ids": ((H, W), np.uint8)}

@@ -38,6 +38,7 @@ struct ModelState {
     float* d_vmap_g[3] = {}; float* d_nmap_g[3] = {}; GNState* d_gn = nullptr; float* d_partials[2] = {nullptr, nullptr};
     TrackModelDev* d_track = nullptr;      // the block the batched tracker kernels find all of that through
     float* d_icp_log = nullptr;            // [20][32] reduced systems of the model's last tracking step, one row per iteration (debug tap "icp_log")
+    double* d_gn_trace = nullptr;          // [20][kGnTraceRow] systems in fp64 + the state every iteration used (debug tap "gn_trace"; geometric loop)
     // object models: private scratch of the surfel passes, so that the passes of ALL objects of a frame can be one launch each ("batchObjectPasses")
     struct ObjScratch {
         unsigned long long* keys = nullptr; int* index = nullptr; float4* ivc = nullptr; float4* inr = nullptr; float4* iclean = nullptr;
@@ -228,7 +229,9 @@ struct mf_ctx {
     // visibility list of the projection passes (Surfels::box, k_cull): the runs of ONE buffer that can be in view under ONE pose; vis_tag says whose
     int* d_vis_list = nullptr; int* d_vis_count = nullptr; int* d_cull_ctl = nullptr; int vis_max_runs = 0;
     struct { const void* model = nullptr; long frame = -1; int cur = -1; } vis_tag;
+    int ticket_lanes = 1;                  // ticket counters of the clean pass: min(kCleanTicketLanes, compute units of the device)
     bool cull_runs = true;                 // "cullRuns": 0 = every projection pass streams the whole buffer (A/B switch, executable specification)
+    int cull_min_surfels = 2000000;        // "cullMinSurfels": maps below this size are streamed whole
     unsigned long long* d_icp_prof = nullptr;
     unsigned long long* d_splat_prof = nullptr; bool splat_prof_on = false;   // "splatProfile": [tiles][8] stamps of the background's tile pass
     // multi-model coupling
@@ -348,7 +351,7 @@ static int ensure_obj_scratch(mf_ctx* c, ModelState& m) {
     A(dev_alloc(c, m.allocs, &m.scr.upd_first, cap));
     A(dev_alloc(c, m.allocs, &m.scr.cand_best, P));
     A(dev_alloc(c, m.allocs, &m.scr.scan_state, clean_scan_entries((long)cap + (long)P)));
-    A(dev_alloc(c, m.allocs, &m.scr.clean_ctl, 2));
+    A(dev_alloc(c, m.allocs, &m.scr.clean_ctl, (size_t)kCleanCtlInts));
 #undef A
     launch_fill_int(m.scr.upd_first, kNoUpdate, (int)cap, c->stream);
     return MF_OK;
@@ -390,6 +393,7 @@ static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int 
     A(dev_alloc(c, m->allocs, &m->d_gn, 2));
     A(dev_alloc(c, m->allocs, &m->d_track, 1));
     A(dev_alloc(c, m->allocs, &m->d_icp_log, (size_t)20 * 32));
+    A(dev_alloc(c, m->allocs, &m->d_gn_trace, (size_t)20 * kGnTraceRow));
     if (!allowFillIn && with_scratch) A(ensure_obj_scratch(c, *m));
 #undef A
     {
@@ -399,6 +403,7 @@ static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int 
         for (int i = 0; i < 3; ++i) { t.vm[i] = m->d_vmap_g[i]; t.nm[i] = m->d_nmap_g[i]; }
         t.partials[0] = m->d_partials[0]; t.partials[1] = m->d_partials[1]; t.st = m->d_gn;
         t.log = m->d_icp_log;                                      // 128 B per iteration and model
+        t.trace = m->d_gn_trace;
         t.jump_limit = allowFillIn ? 0.f : 0.2f;                   // MaskFusion.cpp:268-272 applies to object models
         t.allow_fill = allowFillIn ? 1 : 0;
         m->track_host = t;
@@ -437,6 +442,11 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     c->K = Intr{cfg->fx, cfg->fy, cfg->cx, cfg->cy};
     auto fail = [&](int code) { mf_destroy(c); return code; };
     if (hipSetDevice(cfg->device) != hipSuccess) return fail(MF_ENODEV);
+    {
+        int cus = 1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess) { (void)hipGetLastError(); cus = 1; }
+        c->ticket_lanes = cus < 1 ? 1 : (cus > kCleanTicketLanes ? kCleanTicketLanes : cus);
+    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(MF_ENODEV);
     if (hipStreamCreateWithFlags(&c->stream_pre, hipStreamNonBlocking) != hipSuccess) return fail(MF_ENODEV);
     for (int i = 0; i < 2; ++i)
@@ -523,7 +533,7 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     A(dev_alloc(c, c->allocs, &c->d_block_counts, (size_t)kCompactBlocks));
     A(dev_alloc(c, c->allocs, &c->d_cand_best, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_scan_state, clean_scan_entries((long)c->cap_max + (long)P)));
-    A(dev_alloc(c, c->allocs, &c->d_clean_ctl, 2));
+    A(dev_alloc(c, c->allocs, &c->d_clean_ctl, (size_t)kCleanCtlInts));
     c->vis_max_runs = (int)(run_table_entries((long)c->cap_max + (long)P) / 2);
     A(dev_alloc(c, c->allocs, &c->d_vis_list, (size_t)c->vis_max_runs));
     A(dev_alloc(c, c->allocs, &c->d_vis_count, 1));
@@ -671,6 +681,7 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
             l.partials_out = m.d_partials[k & 1];
             l.state_in = &m.d_gn[k & 1]; l.state_out = &m.d_gn[(k + 1) & 1];
             l.log_out = (k > 0) ? m.d_icp_log + 32 * (k - 1) : nullptr;
+            l.trace = rgb ? nullptr : m.d_gn_trace; l.it = k;
             l.prof_out = (c->icp_prof_on && m.id == 0 && !rgb) ? c->d_icp_prof + 16 * k : nullptr;
             l.pose_in = (k == 0) ? m.d_pose : nullptr;
             l.so3_in = (k == 0) ? so3_seed : nullptr;
@@ -705,7 +716,7 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
     float* log_out = (k > 0) ? m.d_icp_log + 32 * (k - 1) : nullptr;
     if (!rgb)
         launch_icp_finalize(nb_prev ? m.d_partials[(k + 1) & 1] : nullptr, nb_prev, &m.d_gn[k & 1], m.d_pose, m.h_pose, log_out,
-                            jump_limit, so3_seed, s);
+                            jump_limit, so3_seed, s, m.d_gn_trace, k);
     else
         launch_rgbd_finalize(nb_prev ? m.d_partials[(k + 1) & 1] : nullptr, nb_prev ? c->d_rgb_partials[(k + 1) & 1] : nullptr,
                              nb_prev ? c->d_cnt[(k + 1) & 1] : nullptr, nb_prev, g.icp_weight, icp ? 1 : 0, g.rgb_only ? 1 : 0, 1,
@@ -767,7 +778,9 @@ static int surfel_blocks(const mf_ctx* c, const ModelState& m) {
 // that is not listed: only surfels the first index map drew are merged), the prediction after clean() gets its own (new buffer).
 // Depth range: the widest any consumer uses.  nullptr: culling is off.
 static const VisList* ensure_vis(mf_ctx* c, ModelState& m, VisList& out) {
-    if (!c->cull_runs) return nullptr;
+    // (a small map is cheaper to stream than to cull: the test is a launch of its own on a chain of launches that are each a few microseconds.
+    // The count is the pinned mirror as of the model's last clean pass; which side of the threshold a frame falls on changes no result)
+    if (!c->cull_runs || *m.h_count < c->cull_min_surfels) return nullptr;
     out.list = c->d_vis_list; out.count = c->d_vis_count;
     if (c->vis_tag.model == &m && c->vis_tag.frame == c->frame_no && c->vis_tag.cur == m.cur) return &out;
     const mf_config& g = c->cfg;
@@ -814,7 +827,7 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
     }
     launch_clean(m.surf[src], m.surf[dst], m.d_frame, m.d_pose, W, H, c->K, g.time_delta, m.confThr, g.outlier_coefficient, m.id,
                  c->d_index, c->d_ivc, c->d_ict, secondIndexPass ? c->d_iclean : nullptr, depthF, mask, c->d_cand_op, c->d_cand_rec, nullptr, nullptr,
-                 c->d_scan_state, c->d_clean_ctl, next_clean_epoch(c), clean_blocks(c, m), m.h_count, secondIndexPass, c->clean_literal, s);
+                 c->d_scan_state, c->d_clean_ctl, next_clean_epoch(c), clean_blocks(c, m), c->ticket_lanes, m.h_count, secondIndexPass, c->clean_literal, s);
     m.cur = dst;   // one copying pass per frame (clean): the live buffer alternates
 }
 
@@ -873,7 +886,7 @@ static int make_obj_batch(mf_ctx* c, const std::vector<ModelState*>& ms, const s
     MF_HIP(c, hipEventRecord(c->ev_obj_args[slot], c->stream));
     b.m = c->d_obj_args[slot]; b.n = (int)ms.size();
     b.W = c->W; b.H = c->H; b.k = c->K; b.maxDepthProcessed = g.max_depth_processed; b.globalMaxDepth = g.depth_cutoff; b.timeDelta = g.time_delta;
-    b.outlierCoeff = g.outlier_coefficient; b.cleanLiteral = c->clean_literal ? 1 : 0; b.bboxLimit = c->bbox_limit ? 1 : 0; b.cleanEpoch = 0;
+    b.outlierCoeff = g.outlier_coefficient; b.cleanLiteral = c->clean_literal ? 1 : 0; b.bboxLimit = c->bbox_limit ? 1 : 0; b.cleanEpoch = 0; b.cleanTicketLanes = 1;
     b.rgb = d_rgb; b.depthRaw = d_depth; b.depthF = depthF; b.mask = mask; b.bg_pose = c->models[0]->d_pose; b.global_keys = c->d_keys;
     return MF_OK;
 }
@@ -1029,7 +1042,9 @@ static int enqueue_fusion_loop(mf_ctx* c, size_t first, bool multi, const uint8_
         if (rc != MF_OK) return rc;
         ob.cleanEpoch = next_clean_epoch(c);
         int cblocks = 8;
+        ob.cleanTicketLanes = 1;
         for (ModelState* m : objs) cblocks = std::max(cblocks, clean_blocks(c, *m));
+        ob.cleanTicketLanes = std::min(c->ticket_lanes, cblocks);
         launch_obj_fuse_clean(ob, blocks, cblocks, c->stream);
         for (ModelState* m : objs) m->cur = 1 - m->cur;   // fuse in place, clean a -> b: b is the live buffer now
     }
@@ -1650,7 +1665,7 @@ extern "C" int mf_model_clean(mf_ctx* c, int32_t model, int32_t time, int32_t ti
     const bool packed = c->model_api_packed != 0;
     launch_clean(m->surf[src], m->surf[dst], m->d_frame, m->d_pose, c->W, c->H, c->K, time_delta, m->confThr, c->cfg.outlier_coefficient, m->id,
                  c->d_index, c->d_ivc, c->d_ict, packed ? c->d_iclean : nullptr, c->d_depthF[k % 3], current_mask(c), c->d_cand_op, c->d_cand_rec,
-                 c->d_flags, c->d_newconf, c->d_scan_state, c->d_clean_ctl, next_clean_epoch(c), clean_blocks(c, *m), m->h_count, packed, c->clean_literal,
+                 c->d_flags, c->d_newconf, c->d_scan_state, c->d_clean_ctl, next_clean_epoch(c), clean_blocks(c, *m), c->ticket_lanes, m->h_count, packed, c->clean_literal,
                  c->stream);
     m->cur = dst;
     return check_launch(c);
@@ -2309,6 +2324,12 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!strcmp(key, "objectScatterSplat")) { c->object_scatter_splat = value != 0; return MF_OK; }
     if (!strcmp(key, "globalTiles")) { c->global_tiles = value != 0; return MF_OK; }
     if (!strcmp(key, "cullRuns")) { c->cull_runs = value != 0; c->vis_tag.model = nullptr; return MF_OK; }
+    if (!strcmp(key, "cullMinSurfels")) { c->cull_min_surfels = (int)value; c->vis_tag.model = nullptr; return MF_OK; }
+    if (!strcmp(key, "rebuildRunTable")) {   // tooling: the background's run table from scratch (what an upload / Model::initialise does)
+        launch_run_table(c->models[0]->surf[c->models[0]->cur], c->models[0]->d_frame, c->stream);
+        c->vis_tag.model = nullptr;
+        return check_launch(c);
+    }
     if (!strcmp(key, "cleanLiteralWindow")) { c->clean_literal = value != 0; return MF_OK; }   // 0: the exact-arithmetic 4 x 4 window
     if (!strcmp(key, "earlyBackgroundFusion")) { c->early_bg_fusion = value != 0; return MF_OK; }
     if (!strcmp(key, "modelApiPackedIndex")) { c->model_api_packed = value != 0; return MF_OK; }   // 0: scatter + resolve form (specification)
@@ -2417,6 +2438,7 @@ static int debug_read_impl(mf_ctx* c, ModelState& mdl, const char* what, void* o
     else if (w == "clean_flags") { src = c->d_flags; bytes = (size_t)c->cap_max + P; variable = true; }
     else if (w == "clean_newconf") { src = c->d_newconf; bytes = ((size_t)c->cap_max + P) * 4; variable = true; }
     else if (w == "icp_log") { src = mdl.d_icp_log; bytes = 19 * 32 * 4; }
+    else if (w == "gn_trace") { src = mdl.d_gn_trace; bytes = 20 * kGnTraceRow * 8; }
     else if (w == "icp_prof") { src = c->d_icp_prof; bytes = 19 * 16 * 8; }
     else if (w == "splat_prof") {
         if (!c->d_splat_prof) { c->err = "splat_prof: switch splatProfile on first"; return MF_ESTATE; }

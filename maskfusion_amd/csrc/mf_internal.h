@@ -113,10 +113,12 @@ struct TrackModelDev {
     float* vm[3]; float* nm[3];                   // model-side vertex / normal pyramid (global frame)
     float* partials[2]; GNState* st;              // ping-pong per-workgroup partial sums [nb][32]; st[0], st[1]
     float* log;                                   // [19][32] reduced systems (background model) or nullptr
+    double* trace;                                // [20][kGnTraceRow] Gauss-Newton trace (mf_odometry.hip: gn_trace_write) or nullptr
     float jump_limit;                             // object models: 0.2 m rule of MaskFusion.cpp:268-272; background: 0
     int allow_fill;                               // Model::allowsFillIn (background only)
 };
 constexpr int kMaxTrackBatch = 32;
+constexpr int kGnTraceRow = 64;
 struct TrackBatch { const TrackModelDev* m[kMaxTrackBatch]; int n; };   // by value in the kernel arguments
 
 // ---------------- preprocessing ----------------
@@ -141,6 +143,7 @@ struct IcpLaunch {
     float* partials_out;
     const GNState* state_in; GNState* state_out;
     float* log_out;                              // optional [32] floats of the reduced system solved in this launch
+    double* trace = nullptr; int it = 0;         // optional: the model's Gauss-Newton trace ([20][kGnTraceRow]) and this launch's iteration index
     unsigned long long* prof_out = nullptr;      // optional [16] shader-clock stamps (workgroup 0)
     const PoseDev* pose_in = nullptr;            // first launch only: seed the Gauss-Newton state from this pose
     const So3Result* so3_in = nullptr;           // first launch only: SO(3) pre-alignment seeds resultRt's rotation
@@ -164,7 +167,8 @@ void launch_icp_batch_finalize(const TrackBatch& b, int n_it, int nb_in, const S
 // Last reduce+solve, then pose / lastPose / inverse / fusion weight update and host mirror.
 // jump_limit > 0: object-model rule of MaskFusion.cpp:268-272 (|increment translation| > limit => pose->alive = 0)
 void launch_icp_finalize(const float* partials_in, int nblocks_in, const GNState* state_in, PoseDev* pose,
-                         PoseDev* host_mirror, float* log_out, float jump_limit, const So3Result* so3, hipStream_t s);
+                         PoseDev* host_mirror, float* log_out, float jump_limit, const So3Result* so3, hipStream_t s,
+                         double* trace = nullptr, int n_it = 0);
 // Stand-alone icpStep (parity tests): host-provided poses, output 32 floats.
 void launch_icp_step_standalone(const float* Rcurr, const float* tcurr, const float* vc, const float* nc,
                                 const float* Rpi, const float* tprev, Intr k, const float* vp, const float* np,
@@ -249,15 +253,17 @@ void launch_fuse_update(Surfels s, const FrameDev* frame, int* upd_first, const 
                         int W, int H, hipStream_t st);
 // Model::clean in one launch (test + ordered compaction with a decoupled look-back, mf_surfel.hip).  flags / newconf: optional taps (nullptr
 // inside a frame); scan_state: clean_scan_entries(capacity + P) words, never reset (epoch must differ from launch to launch and be > 0);
-// ctl: two ints, zero between launches; blocks: clean_grid(elements expected)
+// ctl: kCleanCtlInts ints, zero between launches; blocks: clean_grid(elements expected)
 constexpr int kCleanGridMax = 2048;
+constexpr int kCleanTicketLanes = 32;
+constexpr int kCleanCtlInts = 1088;   // size of the control block `ctl` (finished-workgroup count + 32 ticket counters 128 B apart)
 int clean_grid(long elements);
 size_t clean_scan_entries(long max_elements);
 void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k,
                   int timeDelta, float confThreshold, float outlierCoeff, int maskID, const int* index,
                   const float4* vc, const float4* ct, const float4* packed /*or null*/, const float* depthF, const uint8_t* mask,
                   const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags /*or null*/, float* newconf /*or null*/,
-                  unsigned long long* scan_state, int* ctl, unsigned epoch, int blocks,
+                  unsigned long long* scan_state, int* ctl, unsigned epoch, int blocks, int ticket_lanes /* <= compute units, <= kCleanTicketLanes */,
                   int* host_count_mirror, bool transposed /*layout of index/vc/ct*/, bool literalWindow /*fp32 trip count of the shader*/,
                   hipStream_t s);
 // generic ordered compaction of [n_dev] records (3 x float4 each, record-major) -> surfels, sets frame->count
@@ -302,6 +308,7 @@ struct ObjBatch {
     const ObjPassArgs* m; int n;
     int W, H; Intr k; float maxDepthProcessed, globalMaxDepth; int timeDelta; float outlierCoeff; int cleanLiteral, bboxLimit;
     unsigned cleanEpoch;               // CleanArgs::epoch of this batch's clean launch
+    int cleanTicketLanes;              // CleanArgs::ticket_lanes
     const uint8_t* rgb; const float* depthRaw; const float* depthF; const uint8_t* mask; const PoseDev* bg_pose;
     unsigned long long* global_keys;
 };

@@ -485,6 +485,17 @@ static void icp_gates(float distThres, float angleThres, float& dist2Max, float&
     dist2Max = d2; sine2Min = s2;
 }
 
+// Gauss-Newton trace of a tracking step (debug tap "gn_trace", tests/test_gpu_parity_long.py): row r = [0..31] the reduced system of iteration r
+// as the device summed it (fp64: 27 packed products, sum r^2, inliers), [32..47] resultRt, [48..56] Rcurr, [57..59] tcurr as iteration r USED
+// them; row n_iterations holds the state after the last update.  Written by lanes u = 0..59 of whoever finishes an iteration.
+__device__ __forceinline__ void gn_trace_write(double* __restrict__ trace, int it, bool have_sys, const double* s_sys, const GNState* s_st, int u) {
+    if (!trace || u < 0) return;
+    if (u < 32) { if (have_sys) trace[kGnTraceRow * (it - 1) + u] = s_sys[u]; }
+    else if (u < 48) trace[kGnTraceRow * it + u] = s_st->resultRt[u - 32];
+    else if (u < 57) trace[kGnTraceRow * it + u] = (double)s_st->Rcurr[u - 48];
+    else if (u < 60) trace[kGnTraceRow * it + u] = (double)s_st->tcurr[u - 57];
+}
+
 struct IcpKArgs {
     const float* vc; const float* nc; const float* vp; const float* np;
     int W, H; Intr k;
@@ -493,6 +504,7 @@ struct IcpKArgs {
     float* partials_out;
     const GNState* st_in; GNState* st_out;
     float* log_out;
+    double* trace; int it;         // optional (parity tests): the model's Gauss-Newton trace (mf_internal.h: kGnTraceRow) and this launch's iteration
     unsigned long long* prof_out;  // optional: 16 shader-clock stamps of workgroup 0 / thread 0 (8 of the launch + 6 inside the solve)
     const PoseDev* pose_in;        // first launch of a tracking step: seed the state from the model pose
     const So3Result* so3_in;       // ... and resultRt's rotation from the SO(3) pre-alignment (RGBDOdometry.cpp:338-344)
@@ -677,6 +689,8 @@ __global__ __launch_bounds__(kT) void k_icp_iter(const IcpKArgs a) {
         static_assert(kWords + 32 <= kT, "state + log lanes");
         if (tid < kWords) reinterpret_cast<uint32_t*>(a.st_out)[tid] = reinterpret_cast<const uint32_t*>(&s_st)[tid];
         else if (tid < kWords + 32 && a.log_out && a.nb_in > 0) a.log_out[tid - kWords] = (float)s_sys[tid - kWords];
+        static_assert(kWords + 32 + 60 <= kT, "trace lanes");
+        gn_trace_write(a.trace, a.it, a.nb_in > 0, s_sys, &s_st, tid - (kWords + 32));
     }
 
     float Rc[9], Rpi[9];
@@ -758,6 +772,7 @@ void launch_icp_iteration(const IcpLaunch& l, hipStream_t s) {
     a.W = l.W; a.H = l.H; a.k = l.k; icp_gates(l.distThres, l.angleThres, a.dist2Max, a.sine2Min);
     a.partials_in = l.partials_in; a.nb_in = l.nblocks_in; a.partials_out = l.partials_out;
     a.st_in = l.state_in; a.st_out = l.state_out; a.log_out = l.log_out; a.prof_out = l.prof_out; a.pose_in = l.pose_in;
+    a.trace = l.trace; a.it = l.it;
     a.so3_in = l.so3_in;
     const dim3 grid(icp_geo_grid_blocks(l.W, l.H));
     const int px = icp_pixel_slots(l.W, l.H);
@@ -780,7 +795,7 @@ void launch_icp_iteration(const IcpLaunch& l, hipStream_t s) {
 __device__ __forceinline__ void icp_finalize_body(const float* __restrict__ partials_in, int nb_in, const GNState* st_in,
                                                   PoseDev* __restrict__ pose, PoseDev* __restrict__ host_mirror, float* __restrict__ log_out,
                                                   float jump_limit, const So3Result* __restrict__ so3, double* s_seg, double* s_sys,
-                                                  GNState* s_st, float* s_scr) {
+                                                  GNState* s_st, float* s_scr, double* __restrict__ trace = nullptr, int n_it = 0) {
     if (st_in != s_st && threadIdx.x < (int)(sizeof(GNState) / 4))
         reinterpret_cast<uint32_t*>(s_st)[threadIdx.x] = reinterpret_cast<const uint32_t*>(st_in)[threadIdx.x];
     if (nb_in > 0) {
@@ -789,6 +804,7 @@ __device__ __forceinline__ void icp_finalize_body(const float* __restrict__ part
         if (log_out && threadIdx.x >= 64 && threadIdx.x < 96) log_out[threadIdx.x - 64] = (float)s_sys[threadIdx.x - 64];
     }
     __syncthreads();
+    gn_trace_write(trace, n_it, nb_in > 0, s_sys, s_st, (int)threadIdx.x - 128);   // the last system and the state it led to
     if (threadIdx.x == 0) {
         const GNState& st = *s_st;
         PoseDev p = *pose;
@@ -811,18 +827,18 @@ __device__ __forceinline__ void icp_finalize_body(const float* __restrict__ part
 __global__ __launch_bounds__(256) void k_icp_finalize(const float* __restrict__ partials_in, int nb_in,
                                                        const GNState* __restrict__ st_in, PoseDev* __restrict__ pose,
                                                        PoseDev* __restrict__ host_mirror, float* __restrict__ log_out,
-                                                       float jump_limit, const So3Result* __restrict__ so3) {
+                                                       float jump_limit, const So3Result* __restrict__ so3, double* __restrict__ trace, int n_it) {
     __shared__ double s_seg[32 * 32];
     __shared__ double s_sys[32];
     __shared__ GNState s_st;
     __shared__ float s_scr[40];
-    icp_finalize_body(partials_in, nb_in, st_in, pose, host_mirror, log_out, jump_limit, so3, s_seg, s_sys, &s_st, s_scr);
+    icp_finalize_body(partials_in, nb_in, st_in, pose, host_mirror, log_out, jump_limit, so3, s_seg, s_sys, &s_st, s_scr, trace, n_it);
 }
 
 void launch_icp_finalize(const float* partials_in, int nblocks_in, const GNState* state_in, PoseDev* pose,
-                         PoseDev* host_mirror, float* log_out, float jump_limit, const So3Result* so3, hipStream_t s) {
+                         PoseDev* host_mirror, float* log_out, float jump_limit, const So3Result* so3, hipStream_t s, double* trace, int n_it) {
     hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(256), 0, s, partials_in, nblocks_in, state_in, pose, host_mirror,
-                       log_out, jump_limit, so3);
+                       log_out, jump_limit, so3, trace, n_it);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -845,6 +861,9 @@ __global__ __launch_bounds__(256) void k_icp_batch_solve(const IcpSolveArgs a) {
                 for (int r = 0; r < 3; ++r)
                     for (int c = 0; c < 3; ++c) s.resultRt[r * 4 + c] = a.so3->R[r * 3 + c];
             md->st[0] = s;
+            if (md->trace) {
+                for (int u = 32; u < 60; ++u) gn_trace_write(md->trace, 0, false, nullptr, &s, u);
+            }
         }
         return;
     }
@@ -857,6 +876,7 @@ __global__ __launch_bounds__(256) void k_icp_batch_solve(const IcpSolveArgs a) {
     constexpr int kWords = (int)(sizeof(GNState) / 4);
     if (tid < kWords) reinterpret_cast<uint32_t*>(md->st + (a.it & 1))[tid] = reinterpret_cast<const uint32_t*>(&s_st)[tid];
     else if (tid < kWords + 32 && md->log) md->log[32 * (a.it - 1) + tid - kWords] = (float)s_sys[tid - kWords];
+    gn_trace_write(md->trace, a.it, true, s_sys, &s_st, tid - (kWords + 32));
 }
 
 struct IcpPxArgs {
@@ -926,7 +946,7 @@ __global__ __launch_bounds__(256) void k_icp_batch_finalize(const IcpFinArgs a) 
     const TrackModelDev* __restrict__ md = a.b.m[blockIdx.x];
     const int last = (a.n_it - 1) & 1;
     icp_finalize_body(a.n_it > 0 ? md->partials[last] : nullptr, a.n_it > 0 ? a.nb_in : 0, md->st + (a.n_it > 0 ? last : 0), md->pose, md->pose_host,
-                      (md->log && a.n_it > 0) ? md->log + 32 * (a.n_it - 1) : nullptr, md->jump_limit, a.so3, s_seg, s_sys, &s_st, s_scr);
+                      (md->log && a.n_it > 0) ? md->log + 32 * (a.n_it - 1) : nullptr, md->jump_limit, a.so3, s_seg, s_sys, &s_st, s_scr, md->trace, a.n_it);
 }
 
 // Workgroups per model of the pixel pass: enough of them over all models to fill the GPU a few times over (there is no

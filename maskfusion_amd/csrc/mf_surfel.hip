@@ -158,22 +158,46 @@ void launch_compact_records(const float4* rec, const uint8_t* flags, int n, Surf
 // ------------------------------------------------------------------------------------------------
 // (bodies are __device__ functions: the single-model kernels call them with their own arguments, the batched object-model kernels at the
 // end of this file with one model's arguments picked by blockIdx.z)
-__device__ __forceinline__ void index_scatter_one(const Surfels& src, int i, float time, const float* Ri, float3 ti, int W, int H, Intr k,
+// One surfel per lane; `live` lanes hold a surfel index i (the others only take part in the wavefront exchange below).
+__device__ __forceinline__ void index_scatter_one(const Surfels& src, int i, bool live, float time, const float* Ri, float3 ti, int W, int H, Intr k,
                                                   float maxDepth, int timeDelta, unsigned long long* __restrict__ keys, int transposed,
                                                   bool pretest = false) {
-    const float4 pc = src.pc[i];
-    const float lastTime = src.ct[i].w;
-    const float3 h = mul33(Ri, f3(pc.x, pc.y, pc.z)) + ti;
-    if (h.z > maxDepth || h.z <= 0 || time - lastTime > (float)timeDelta) return;  // index_map.vert:46
-    const float u = ((k.fx * h.x) / h.z) + k.cx;
-    const float v = ((k.fy * h.y) / h.z) + k.cy;
-    if (!(u >= 0.f && u < (float)W && v >= 0.f && v < (float)H)) return;
-    // transposed (column-major) texel order for the pass that feeds clean(): surfels are stored in column-major creation
-    // order (data.vert), so consecutive surfels then touch consecutive texels instead of one cache line per image row
-    const int p = transposed ? (int)floorf(u) * H + (int)floorf(v) : (int)floorf(v) * W + (int)floorf(u);
-    const unsigned long long key = ((unsigned long long)__float_as_uint(h.z) << 32) | (unsigned)i;
-    if (pretest) zmin_key_pretested(&keys[p], key);
-    else zmin_key(&keys[p], key);
+    int p = -1;
+    unsigned long long key = kEmptyKey;
+    if (live) {
+        const float4 pc = src.pc[i];
+        const float lastTime = src.ct[i].w;
+        const float3 h = mul33(Ri, f3(pc.x, pc.y, pc.z)) + ti;
+        if (!(h.z > maxDepth || h.z <= 0 || time - lastTime > (float)timeDelta)) {  // index_map.vert:46
+            const float u = ((k.fx * h.x) / h.z) + k.cx;
+            const float v = ((k.fy * h.y) / h.z) + k.cy;
+            if (u >= 0.f && u < (float)W && v >= 0.f && v < (float)H) {
+                // transposed (column-major) texel order for the pass that feeds clean(): surfels are stored in column-major creation
+                // order (data.vert), so consecutive surfels then touch consecutive texels instead of one cache line per image row
+                p = transposed ? (int)floorf(u) * H + (int)floorf(v) : (int)floorf(v) * W + (int)floorf(u);
+                key = ((unsigned long long)__float_as_uint(h.z) << 32) | (unsigned)i;
+            }
+        }
+    }
+    // Neighbouring surfels of a buffer are neighbours in space (creation order), and in a dense map several in a row land on the SAME texel:
+    // each lane takes over the smaller key of the lanes 1, 2 and 4 below it that hit its texel, and only the last lane of such a group (of up
+    // to eight) goes to memory with the group's minimum -- the z-test is a minimum, so the keys in memory are the same bits, with a fraction of the
+    // device-scope atomics (which retire at a few tens of nanoseconds each when they meet on an address).
+#pragma unroll
+    for (int d = 1; d <= 4; d <<= 1) {
+        const int pn = __shfl_up(p, d, 64);
+        const unsigned lo = __shfl_up((unsigned)(key & 0xFFFFFFFFull), d, 64), hi = __shfl_up((unsigned)(key >> 32), d, 64);
+        const unsigned long long kn = ((unsigned long long)hi << 32) | lo;
+        if ((int)(threadIdx.x & 63) >= d && pn == p && kn < key) key = kn;
+    }
+    // (three steps cover the 7 lanes below: a lane writes when the next lane hits another texel, and every 8th lane writes in any case, so
+    // that a longer group is written in pieces none of whose members is lost)
+    const int p_next = __shfl_down(p, 1, 64);
+    const bool last_of_group = (threadIdx.x & 7) == 7 || p_next != p;
+    if (p >= 0 && last_of_group) {
+        if (pretest) zmin_key_pretested(&keys[p], key);
+        else zmin_key(&keys[p], key);
+    }
 }
 
 // vis_list == nullptr: every surfel of the buffer; else only the runs k_cull listed (Surfels::box) -- the others hold no surfel that could
@@ -194,12 +218,13 @@ __device__ __forceinline__ void index_scatter_body(Surfels src, const FrameDev* 
         for (int v = blockIdx.x; v < nv; v += gridDim.x) {
             const int r = vis_list[v];
             const int beg = src.box[2 * r + 1].w, end = min(n, src.box[2 * r + 3].w);
-            for (int i = beg + (int)threadIdx.x; i < end; i += 256) index_scatter_one(src, i, time, Ri, ti, W, H, k, maxDepth, timeDelta, keys, transposed);
+            for (int i0 = beg; i0 < end; i0 += 256)     // (wavefront-uniform bounds: every lane takes part in the exchange)
+                index_scatter_one(src, i0 + (int)threadIdx.x, i0 + (int)threadIdx.x < end, time, Ri, ti, W, H, k, maxDepth, timeDelta, keys, transposed, pretest);
         }
         return;
     }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
-        index_scatter_one(src, i, time, Ri, ti, W, H, k, maxDepth, timeDelta, keys, transposed, pretest);
+    for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256)
+        index_scatter_one(src, i0 + (int)threadIdx.x, i0 + (int)threadIdx.x < n, time, Ri, ti, W, H, k, maxDepth, timeDelta, keys, transposed, pretest);
 }
 
 __global__ __launch_bounds__(256) void k_index_scatter(Surfels src, const FrameDev* __restrict__ frame,
@@ -314,7 +339,8 @@ __global__ __launch_bounds__(256) void k_cull(Surfels s, const FrameDev* __restr
     // the last workgroup to finish publishes the count and re-arms the counters
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int done = __hip_atomic_fetch_add(&ctl[1], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        // (every workgroup's slot reservations have returned before its barrier: relaxed atomics suffice, an agent-scope release would write the L2 back)
+        const int done = atomicAdd(&ctl[1], 1);
         if (done == (int)gridDim.x - 1) {
             count[0] = __hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&ctl[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -564,8 +590,9 @@ struct CleanArgs {
     uint8_t* flags; float* newconf;    // optional taps (Model-level calls, tests): keep flag / new confidence per element; nullptr inside a frame
     int* host_count;
     unsigned long long* scan_state;    // [chunks] decoupled look-back: (launch epoch << 34 | status << 32 | survivors)
-    int* ctl;                          // {ticket, finished workgroups}; zero between launches
+    int* ctl;                          // kCleanCtlInts ints, zero between launches: finished workgroups + the ticket counters (clean_body)
     unsigned epoch;                    // distinguishes this launch's entries of scan_state from older ones (never reset)
+    int ticket_lanes;                  // counters the chunks are drawn from (1 .. kCleanTicketLanes, <= compute units and <= workgroups launched)
 };
 
 // The window of copy_unstable.vert:85-86 along one axis, exactly as the shader text walks it: `for (i = c - 2s; i < c + 2s; i += s)` on an
@@ -686,6 +713,7 @@ constexpr int kCleanChunk = 256 * kCleanPerThread;
 static_assert(kCleanChunk == kRun, "a clean chunk's survivors are one run of the new buffer's run table");
 constexpr int kLookPerLane = 4;   // states of earlier chunks a lane reads per look-back step: 256 per step and wavefront
 constexpr unsigned kScanAggregate = 1u, kScanInclusive = 2u;
+constexpr int kTicketStride = 32, kTicketBase = 32;   // ctl: [2..3] finished workgroups << 32 | survivors (64 bit), [kTicketBase + g kTicketStride] ticket counter of lane g (128 B apart)
 
 __device__ __forceinline__ unsigned long long scan_load(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -760,8 +788,16 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
     for (int q = 0; q < 9; ++q) Ri[q] = a.pose->Ri[q];
     const float3 ti = f3(a.pose->ti[0], a.pose->ti[1], a.pose->ti[2]);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // Chunks are handed out by `lanes` (<= kCleanTicketLanes) counters, lane g (= this workgroup's index mod lanes) serving chunks g, g + lanes, ...:
+    // one counter for all chunks made the pass as slow as its ticket -- device-scope atomics on ONE address retire at ~27 ns each on this GPU
+    // (26 k chunks: 0.7 ms; measured, profiles/r05b_*, r05c_*).  Forward progress: a chunk only ever waits for LOWER chunks; the lowest chunk not
+    // yet finished is either owned by a running workgroup or next in line on a lane whose workgroups (the first `lanes` workgroups of the
+    // grid are dispatched first, one per lane: the host keeps lanes <= the number of compute units) are all working on lower chunks, which finish.
+    const int lanes = a.ticket_lanes;
+    const int tlane = (int)(blockIdx.x % lanes);
+    int wg_kept = 0;          // survivors of the chunks this workgroup handled (thread 0's copy is the one that counts)
     for (;;) {
-        if (threadIdx.x == 0) s_chunk = atomicAdd(&a.ctl[0], 1);
+        if (threadIdx.x == 0) s_chunk = tlane + lanes * atomicAdd(&a.ctl[kTicketBase + tlane * kTicketStride], 1);
         __syncthreads();
         const int chunk = s_chunk;
         if (chunk >= nchunks) break;
@@ -813,12 +849,10 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
             if (lane == 0) {
                 scan_store(&a.scan_state[chunk], tag | ((unsigned long long)kScanInclusive << 32) | (unsigned)(excl + tot));
                 s_base = excl;
+                wg_kept += tot;
                 if (gave_up) a.frame->pad[2] = 1;
                 run_box_store(a.dst.box, chunk, min(excl, a.dst.cap), s_red);
-                if (chunk == nchunks - 1) {
-                    a.dst.box[2 * nchunks + 1] = make_int4(0, 0, 0, min(excl + tot, a.dst.cap));   // end of the last run
-                    __hip_atomic_store(&a.frame->countNext, min(excl + tot, a.dst.cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                if (chunk == nchunks - 1) a.dst.box[2 * nchunks + 1] = make_int4(0, 0, 0, min(excl + tot, a.dst.cap));   // end of the last run
             }
         }
         __syncthreads();
@@ -849,13 +883,17 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
         if (threadIdx.x < 3 && s_bb[threadIdx.x] != kBBoxEmptyMin) atomicMin(&a.frame->bbox_tmp[threadIdx.x], s_bb[threadIdx.x]);
         else if (threadIdx.x >= 3 && threadIdx.x < 6 && s_bb[threadIdx.x] != kBBoxEmptyMax) atomicMax(&a.frame->bbox_tmp[threadIdx.x], s_bb[threadIdx.x]);
     }
-    // The last workgroup to FINISH installs the launch's results: by then nobody reads frame->count or the ticket any more, and every
-    // workgroup's box contribution is in (its atomics precede its increment, which releases them).
+    // The last workgroup to FINISH installs the launch's results: by then nobody reads frame->count or the tickets any more.  One 64-bit atomic
+    // per workgroup carries both its "finished" ticket and the number of survivors it wrote: the value travels IN the atomic, so the
+    // workgroup that draws the last ticket holds the launch's total without any ordering between workgroups (an agent-scope release / acquire
+    // pair here cost an L2 write-back per workgroup); the box atomics of this workgroup have completed behind the barrier above.
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int done = __hip_atomic_fetch_add(&a.ctl[1], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (done == (int)gridDim.x - 1) {
-            const int n = __hip_atomic_load(&a.frame->countNext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long* done64 = reinterpret_cast<unsigned long long*>(a.ctl + 2);
+        const unsigned long long old = atomicAdd(done64, (1ull << 32) | (unsigned long long)(unsigned)wg_kept);
+        if ((unsigned)(old >> 32) == gridDim.x - 1u) {
+            const int n = min((int)(unsigned)(old & 0xFFFFFFFFull) + wg_kept, a.dst.cap);
+            a.frame->countNext = n;
             a.frame->count = n;
             a.frame->runs = nchunks;
             if (a.host_count) *a.host_count = n;
@@ -865,8 +903,8 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
                     __hip_atomic_store(&a.frame->bbox_tmp[q], q < 3 ? kBBoxEmptyMin : kBBoxEmptyMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            __hip_atomic_store(&a.ctl[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&a.ctl[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int g = 0; g < kCleanTicketLanes; ++g) __hip_atomic_store(&a.ctl[kTicketBase + g * kTicketStride], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(done64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -877,9 +915,10 @@ __global__ __launch_bounds__(256) void k_clean(const CleanArgs a) { clean_body(a
 // grid covers any count)
 int clean_grid(long elements) {
     const long chunks = (elements + kCleanChunk - 1) / kCleanChunk;
-    return (int)(chunks < 8 ? 8 : (chunks > kCleanGridMax ? kCleanGridMax : chunks));
+    return (int)(chunks < kCleanTicketLanes ? kCleanTicketLanes : (chunks > kCleanGridMax ? kCleanGridMax : chunks));
 }
 size_t clean_scan_entries(long max_elements) { return (size_t)((max_elements + kCleanChunk - 1) / kCleanChunk + 1); }
+static_assert(kTicketBase + kCleanTicketLanes * kTicketStride <= kCleanCtlInts, "ticket counters fit the control block");
 
 // ------------------------------------------------------------------------------------------------
 // splat prediction: scatter (per-surfel sprite loop, ray-disc test, 64-bit atomicMin) + resolve
@@ -1059,8 +1098,8 @@ void launch_pose_log(const PoseDev* pose, const PoseDev* bg_pose, float* slot, h
 void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, int timeDelta,
                   float confThreshold, float outlierCoeff, int maskID, const int* index, const float4* vc, const float4* ct,
                   const float4* packed, const float* depthF, const uint8_t* mask, const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags,
-                  float* newconf, unsigned long long* scan_state, int* ctl, unsigned epoch, int blocks, int* host_count_mirror, bool transposed,
-                  bool literalWindow, hipStream_t s) {
+                  float* newconf, unsigned long long* scan_state, int* ctl, unsigned epoch, int blocks, int ticket_lanes, int* host_count_mirror,
+                  bool transposed, bool literalWindow, hipStream_t s) {
     CleanArgs a;
     a.transposed = transposed ? 1 : 0;
     a.literal = literalWindow ? 1 : 0;
@@ -1069,7 +1108,7 @@ void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose
     a.packed = packed;
     a.depthF = depthF; a.mask = mask; a.cand_op = cand_op; a.cand_rec = cand_rec;
     a.flags = flags; a.newconf = newconf; a.host_count = host_count_mirror;
-    a.scan_state = scan_state; a.ctl = ctl; a.epoch = epoch;
+    a.scan_state = scan_state; a.ctl = ctl; a.epoch = epoch; a.ticket_lanes = min(ticket_lanes, blocks);
     hipLaunchKernelGGL(k_clean, dim3(blocks), dim3(256), 0, s, a);
 }
 
@@ -1108,7 +1147,7 @@ __device__ __forceinline__ CleanArgs obj_clean_args(const ObjBatch& b, const Obj
     a.confThreshold = m.confThreshold; a.outlierCoeff = b.outlierCoeff; a.maskID = m.maskID; a.transposed = 1; a.literal = b.cleanLiteral;
     a.index = m.index; a.vc = m.ivc; a.ct = nullptr; a.packed = m.iclean; a.depthF = b.depthF; a.mask = b.mask;
     a.cand_op = m.cand_op; a.cand_rec = m.cand_rec; a.flags = nullptr; a.newconf = nullptr; a.host_count = m.host_count;
-    a.scan_state = m.scan_state; a.ctl = m.clean_ctl; a.epoch = b.cleanEpoch;
+    a.scan_state = m.scan_state; a.ctl = m.clean_ctl; a.epoch = b.cleanEpoch; a.ticket_lanes = b.cleanTicketLanes;
     return a;
 }
 __global__ __launch_bounds__(256) void k_obj_clean(const ObjBatch b) { clean_body(obj_clean_args(b, b.m[blockIdx.z])); }

@@ -2325,6 +2325,7 @@ typedef struct {
     float trackedPose[16]; int trackedThisFrame;   /* what THIS side's tracking step returned from its own state (teacher forcing keeps it readable) */
     float trackedPoseAlt[16];                      /* ... and what it returns when the start pose is moved by one micrometre (its own sensitivity) */
     float trackLog[20][32]; int trackLogN;         /* reduced systems of the last tracking step, per iteration (mfo_last_track_log) */
+    float probeLog[20][32]; int probeLogN;         /* ... and the systems of the same step evaluated at poses handed in from outside (mfo_mm_set_probe_poses) */
 } mm_model;
 static void mm_bbox_reset(mm_model* m) { for (int k = 0; k < 3; ++k) { m->bbox[k] = 100000; m->bbox[3 + k] = -100000; } }
 /* Model::renderPointCloud (Model.cpp:287-346) + draw_global_surface.vert:55-78, as the GUI runs it after every frame with its defaults
@@ -2361,6 +2362,9 @@ struct mfo_mm {
     int32_t trackable[256]; int nTrackable;   /* MaskFusion::trackableClassIds (MaskFusion.cpp:261,940); empty: every class */
     /* test isolation ("teacher forcing"): poses another implementation obtained for this frame, by model id; consumed by the next frame */
     int32_t forceIDs[64]; float forcePoses[64][16]; int nForce; int forceOn;
+    /* per-iteration teacher forcing of the Gauss-Newton loop: for model ids probeIDs[k], the pose (Rcurr row-major 9, tcurr 3) another
+     * implementation used in each of its iterations; consumed by the next frame */
+    int32_t probeIDs[64]; float (*probePoses)[20][12]; int nProbe;
 };
 void mfo_mm_set_frame_to_frame_rgb(mfo_mm* x, int on) { x->frameToFrameRGB = on; }
 void mfo_mm_set_bbox_limit(mfo_mm* x, int on) { x->bboxLimit = on; }
@@ -2383,6 +2387,20 @@ void mfo_mm_force_tracking(mfo_mm* x, const int32_t* ids, const float* poses16, 
     x->nForce = n < 0 ? 0 : (n > 64 ? 64 : n);
     for (int i = 0; i < x->nForce; ++i) { x->forceIDs[i] = ids[i]; memcpy(x->forcePoses[i], poses16 + 16 * i, sizeof(float) * 16); }
     x->forceOn = 1;
+}
+/* Test isolation for the tracked models' Gauss-Newton loops: the NEXT mfo_mm_process_frame also evaluates, for every model listed here, the
+ * reduced normal equations (icpStep, reduce.cu:446-525) of each of its `n_it` iterations at the pose given for that iteration -- on this side's
+ * own maps, which teacher forcing keeps identical to the other implementation's.  Row k of mfo_mm_model_probe_log is then directly comparable
+ * with the other side's k-th system whatever its ill-conditioned steps did before: chaos cannot compound across iterations.
+ * poses: [n][20][12] floats (Rcurr row-major, tcurr). */
+void mfo_mm_set_probe_poses(mfo_mm* x, const int32_t* ids, const float* poses, int n) {
+    x->nProbe = n < 0 ? 0 : (n > 64 ? 64 : n);
+    if (!x->probePoses) x->probePoses = (float (*)[20][12])calloc(64, sizeof(float[20][12]));
+    for (int i = 0; i < x->nProbe; ++i) { x->probeIDs[i] = ids[i]; memcpy(x->probePoses[i], poses + (size_t)i * 240, sizeof(float) * 240); }
+}
+int mfo_mm_model_probe_log(const mfo_mm* x, int i, float* out /* [20][32] */) {
+    memcpy(out, x->models[i].probeLog, sizeof(x->models[i].probeLog));
+    return x->models[i].probeLogN;
 }
 static const float* mm_forced_pose(const mfo_mm* x, int id) {
     for (int i = 0; i < x->nForce; ++i) if (x->forceIDs[i] == id) return x->forcePoses[i];
@@ -2497,6 +2515,7 @@ void mfo_mm_destroy(mfo_mm* x) {
     free(x->cand_op); free(x->cand_best); free(x->cand_rec);
     free(x->edge); free(x->binEdge); free(x->ucharBuf); free(x->projIDs); free(x->ignoreMap); free(x->fullSeg);
     rgbd_scratch_free(&x->rs);
+    free(x->probePoses);
     free(x);
 }
 
@@ -2520,6 +2539,29 @@ static float mm_track(mfo_mm* x, mm_model* m, int allowFillIn) {
     const float* cn[3] = {x->nmap[0], x->nmap[1], x->nmap[2]};
     const float* pv[3] = {x->vmap_g[0], x->vmap_g[1], x->vmap_g[2]};
     const float* pn[3] = {x->nmap_g[0], x->nmap_g[1], x->nmap_g[2]};
+    m->probeLogN = 0;
+    for (int q = 0; q < x->nProbe; ++q) {
+        if (x->probeIDs[q] != m->id) continue;
+        /* the iteration schedule of RGBDOdometry.cpp:327-329 and the per-level intrinsics of :346-352, as mfo_track_icp walks them */
+        float Rpi[9];
+        m33_inverse(R, Rpi);
+        const int iters[3] = {g->fastOdom ? 3 : 10, g->pyramid ? 5 : 0, g->pyramid ? 4 : 0};
+        int it = 0;
+        for (int lv = 2; lv >= 0; --lv) {
+            const int div = 1 << lv;
+            for (int j = 0; j < iters[lv] && it < 20; ++j, ++it) {
+                float A[36], b[6], residual[2];
+                const float* p12 = x->probePoses[q][it];
+                mfo_icp_step(p12, p12 + 9, cv[lv], cn[lv], Rpi, t, g->fx / div, g->fy / div, g->cx / div, g->cy / div, pv[lv], pn[lv], 0.10f,
+                             sinf(20.f * 3.14159254f / 180.f), W >> lv, H >> lv, A, b, residual);
+                float* row = m->probeLog[it];
+                int k = 0;
+                for (int a2 = 0; a2 < 6; ++a2) { for (int c2 = a2; c2 < 6; ++c2) row[k++] = A[a2 * 6 + c2]; row[k++] = b[a2]; }
+                row[27] = residual[0]; row[28] = residual[1]; row[29] = row[30] = row[31] = 0.f;
+            }
+        }
+        m->probeLogN = it;
+    }
     mfo_track_stats st;
     /* only the background model allows fill-in (Model.cpp:400: frameToFrameRGB && allowsFillIn()) */
     track_model(g, &x->rs, cv, cn, pv, pn, doFillIn ? x->fillVertex : m->predVertex,
@@ -2708,6 +2750,7 @@ int mfo_mm_process_frame(mfo_mm* x, const uint8_t* rgb, const float* depth, cons
     for (int i = 1; i < x->nModels; ++i) mm_bbox_update(&x->models[i]);
     x->tick++;
     for (int i = 0; i < x->nModels; ++i) x->models[i].age++;
+    x->nProbe = 0;
     return 0;
 }
 

@@ -357,6 +357,9 @@ int     mfo_mm_model_track_log(const mfo_mm* x, int i, float* out_20x32);
 void    mfo_mm_model_tracked_pose_alt(const mfo_mm* x, int i, float* pose16);   /* the same step from a start pose shifted by 1e-6 m */
 int     mfo_mm_process_frame(mfo_mm* x, const uint8_t* rgb, const float* depth, const uint8_t* mask,
                              const int32_t* classIDs, int nMasks, float weightMultiplier);
+/* test tooling: per-iteration teacher forcing of the tracked models' Gauss-Newton loops (see mf_oracle.c) */
+void    mfo_mm_set_probe_poses(mfo_mm* x, const int32_t* ids, const float* poses /* [n][20][12] */, int n);
+int     mfo_mm_model_probe_log(const mfo_mm* x, int i, float* out /* [20][32] */);
 /* test tooling: replace model i's surfel buffer (twin of mf_model_upload_map); 0 or -1 */
 int     mfo_mm_upload_map(mfo_mm* x, int i, const float* surfels12, int count);
 int     mfo_mm_num_models(const mfo_mm* x);

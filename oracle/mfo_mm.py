@@ -70,6 +70,9 @@ def mm_lib():
     L.mfo_mm_model_track_log.argtypes = [C.c_void_p, C.c_int, f32p]
     L.mfo_mm_model_track_log.restype = C.c_int
     L.mfo_mm_model_tracked_pose_alt.argtypes = [C.c_void_p, C.c_int, f32p]
+    L.mfo_mm_set_probe_poses.argtypes = [C.c_void_p, i32p, f32p, C.c_int]
+    L.mfo_mm_model_probe_log.argtypes = [C.c_void_p, C.c_int, f32p]
+    L.mfo_mm_model_probe_log.restype = C.c_int
     L.mfo_mm_upload_map.argtypes = [C.c_void_p, C.c_int, f32p, C.c_int]
     L.mfo_mm_upload_map.restype = C.c_int
     L.mfo_mm_num_models.argtypes = [C.c_void_p]
@@ -245,6 +248,18 @@ class OracleMM:
         """reduced geometric systems of model i's last tracking step: (iterations, 32) in the device log's layout"""
         out = np.zeros((20, 32), np.float32)
         n = mm_lib().mfo_mm_model_track_log(self.h, i, out.reshape(-1))
+        return out[:n]
+
+    def set_probe_poses(self, ids, poses):
+        """per-iteration teacher forcing: poses[k] = (20, 12) float32, the (Rcurr row-major, tcurr) another implementation used in each
+        Gauss-Newton iteration of model ids[k]; the next frame evaluates this side's systems there (model_probe_log)"""
+        a = np.ascontiguousarray(list(ids) if len(ids) else [0], np.int32)
+        p = np.ascontiguousarray(np.stack(poses) if len(ids) else np.zeros((1, 20, 12)), np.float32)
+        mm_lib().mfo_mm_set_probe_poses(self.h, a, p.reshape(-1), len(ids))
+
+    def model_probe_log(self, i):
+        out = np.zeros((20, 32), np.float32)
+        n = mm_lib().mfo_mm_model_probe_log(self.h, i, out.reshape(-1))
         return out[:n]
 
     def model_step_sensitivity(self, i):

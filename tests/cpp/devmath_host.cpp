@@ -23,6 +23,8 @@ static inline int __builtin_amdgcn_mbcnt_hi(unsigned, int b) { return b; }
 static inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
 static inline double __builtin_amdgcn_rsq(double x) { return 1.0 / sqrt(x); }
 static inline unsigned long long atomicMin(unsigned long long* a, unsigned long long v) { unsigned long long o = *a; if (v < o) *a = v; return o; }
+#define __HIP_MEMORY_SCOPE_AGENT 3
+#define __hip_atomic_load(p, order, scope) (*(p))
 using std::min;
 using std::max;
 

@@ -346,6 +346,7 @@ hipError_t hipEventRecordWithFlags(hipEvent_t, hipStream_t, unsigned) { return h
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 1; return hipSuccess; }   // one "compute unit": workgroups run one after the other
 hipError_t hipSetDevice(int) { return hipSuccess; }
 hipError_t hipGetLastError() { return hipSuccess; }
 const char* hipGetErrorString(hipError_t) { return "hipcpu"; }

@@ -409,6 +409,7 @@ def test_run_culling_changes_nothing(hip):
     def run(cull):
         mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=False, numGSurfels=1 << 20, initConfidenceGlobal=10.0)
         mf.setParam("cullRuns", 1 if cull else 0)
+        mf.setParam("cullMinSurfels", 0)          # (by default maps below 2 M surfels are streamed whole)
         out = []
         for k, (rgb, d, _) in enumerate(frames):
             mf.processFrame(rgb, d, timestamp=k)
