@@ -570,6 +570,50 @@ def config4_scene(local_rank, frames, room_job, seconds=2.0, frames_per_rep=30, 
             "roofline_kernels": levels}
 
 
+def small_variant(cfg_key, local_rank, frames, n_timed, warm):
+    """frames/s of another configuration of the table through a fresh context, device-resident frames, ping-ponged: the figures the default
+    line carries beside `value` so that the driver times them too (`variants.multi_model_2s`: S2 on one GPU, background + object models,
+    batched Gauss-Newton loop; `variants.vga_1280x960`: the 1280x960 stream with its natural map)."""
+    import torch
+    from maskfusion_amd import MaskFusion
+    cfg = CONFIGS[cfg_key]
+    W, H, F = cfg["W"], cfg["H"], cfg["f"]
+    dev = torch.device("cuda", local_rank)
+    multi = cfg["n_objects"] > 0
+    if multi:
+        mf = MaskFusion(W, H, F, F, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, device=local_rank, enableMultipleModels=True, numGSurfels=cfg["surfels"],
+                        numOSurfels=1 << 20, trackAllModels=True, modelSpawnOffset=2, initConfidenceGlobal=10.0, initConfidenceObject=0.01)
+        for k, v in (("mfThreshold", 0.3), ("mfWeightDistance", 150.0), ("mfWeightConvexity", 2.8), ("mfMorphEdgeIterations", 0),
+                     ("mfMorphMaskIterations", 0), ("newModelMinRelativeSize", 0.004)):
+            mf.setParam(k, v)
+        mf.preallocateModels(cfg["n_objects"])
+        mf.setMaskClassIDs([0] + [41 + i for i in range(cfg["n_objects"])])
+    else:
+        mf = MaskFusion(W, H, F, F, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, device=local_rank, enableMultipleModels=False, numGSurfels=cfg["surfels"])
+    d = [tuple(torch.from_numpy(x).to(dev) for x in f) for f in frames]
+    order = pingpong(len(d), 1 << 16)
+    pos = 0
+
+    def step():
+        nonlocal pos
+        r, dd, m = d[order[pos % len(order)]]
+        pos += 1
+        mf.processFrameDevice(r.data_ptr(), dd.data_ptr(), m.data_ptr() if multi else 0)
+
+    for _ in range(warm):
+        step()
+    mf.sync()
+    t0 = time.perf_counter()
+    for _ in range(n_timed):
+        step()
+    mf.sync()
+    dt = time.perf_counter() - t0
+    counts = [m.lastCount() for m in mf.getModels()]
+    mf.close()
+    return {"workload": cfg["workload"], "value": n_timed / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / n_timed, "steps": n_timed, "warmup": warm,
+            "models": len(counts), "surfels": sum(counts)}
+
+
 def run_config4(args, local_rank, frames, room_job):
     """--config 4 as the bench's own line"""
     import torch
@@ -635,10 +679,13 @@ def main():
     # the dense configs[4] scenario rides along as a variant of the default line (and is --config 4's own line): its frames are ray-cast and
     # its background map generated (a forked child) before CUDA exists in this process
     with_c4 = rank == 0 and world == 1 and ((args.config == "1" and not args.no_variants and args.icp_weight >= 100.0 and not args.so3) or args.config == "4")
-    frames4 = room_job = None
+    frames4 = room_job = frames2s = frames4n = None
     if with_c4:
         room_job = RoomMapJob(4, fork=args.gen_workers != 1)
         frames4 = frames if args.config == "4" else gen_frames(CONFIGS["4"], C4_LEAD_IN + 12, args.gen_workers, args.frame_cache or None)[1]
+        if args.config == "1":   # the two small variants of the default line
+            frames2s = gen_frames(CONFIGS["2s"], 60, args.gen_workers, args.frame_cache or None)[1]
+            frames4n = gen_frames(CONFIGS["4n"], 40, args.gen_workers, args.frame_cache or None)[1]
     if args.config == "4":
         if world > 1:
             raise SystemExit("--config 4 is a one-GPU scenario (configs[4]'s per-GPU share); run it with --gpus 1")
@@ -846,6 +893,11 @@ def main():
         except Exception as e:   # a side measurement: never the reason the bench line is missing
             print(f"[bench] reference-default variant not measured: {e!r}", file=sys.stderr)
         if with_c4:
+            for name, key, fr, n_timed, warm in (("multi_model_2s", "2s", frames2s, 120, 60), ("vga_1280x960", "4n", frames4n, 120, 40)):
+                try:
+                    variants = dict(variants or {}, **{name: small_variant(key, local_rank, fr, n_timed, warm)})
+                except Exception as e:
+                    print(f"[bench] variant {name} not measured: {e!r}", file=sys.stderr)
             try:
                 mf.close()        # the dense scenario holds ~6 GB of maps: it gets the GPU to itself
                 d_rgb = d_depth = None

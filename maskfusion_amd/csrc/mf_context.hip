@@ -1000,6 +1000,11 @@ static int spawn_object(mf_ctx* c, int id, int classID) {
     nm->classID = classID;
     launch_spawn_pose(nm->d_pose, bg.d_pose, nm->d_frame, bg.d_frame, nm->h_pose, s);
     c->models.push_back(std::move(nm));
+    // the private scratch of the batched object passes (>= 2 objects) is allocated HERE, outside the enqueue path of a frame (hipMalloc
+    // synchronises the device); a failure only switches the batched passes off -- the model-by-model passes need no private scratch
+    if (c->batch_objects && c->models.size() >= 3)
+        for (size_t i = 1; i < c->models.size(); ++i)
+            if (ensure_obj_scratch(c, *c->models[i]) != MF_OK) { (void)hipGetLastError(); c->batch_objects = false; c->err.clear(); break; }
     return MF_OK;
 }
 
@@ -1102,9 +1107,9 @@ static int enqueue_predict_loop(mf_ctx* c, size_t first, bool may_batch, int64_t
 // later spawn gets is a fresh model either way: spawn_object re-initialises pose, frame state and counters on the stream).  Neither step
 // waits for the GPU: round 3 freed ~30 allocations here and allocated them again (plus a drained stream and a 2 MB read-back for the log) at
 // the next spawn -- 1.5 of the 2.4 ms of a frame of bench.py --config 2s, whose scene drops and re-spawns a tracked box every other frame.
+static int materialise_retired(mf_ctx* c);
 static int retire_model(mf_ctx* c, size_t i) {
-    std::unique_ptr<ModelState> m = std::move(c->models[i]);
-    c->models.erase(c->models.begin() + (long)i);
+    ModelState* m = c->models[i].get();   // (everything that can fail happens before the model leaves the list)
     const size_t cap = (size_t)c->cfg.pose_log_capacity, n_all = m->log_ts.size(), n = n_all < cap ? n_all : cap;
     if (m->d_poselog && n > 0) {
         mf_ctx::RetiredLog r;
@@ -1116,6 +1121,10 @@ static int retire_model(mf_ctx* c, size_t i) {
             void* q = nullptr;
             if (hipMalloc(&q, c->retired_cap * 8 * sizeof(float)) == hipSuccess) { c->d_retired = (float*)q; c->allocs.push_back(q); }
             else { (void)hipGetLastError(); c->retired_cap = 0; }
+        }
+        if (c->d_retired && c->retired_used + n > c->retired_cap && n <= c->retired_cap) {
+            int rc = materialise_retired(c);   // arena full: read it back once (a synchronisation every ~130 k retired entries) and start over
+            if (rc != MF_OK) return rc;
         }
         if (c->d_retired && c->retired_used + n <= c->retired_cap) {
             // chronological order: entries n_all - n .. n_all - 1 of a ring of `cap` slots -> at most two contiguous pieces
@@ -1132,9 +1141,13 @@ static int retire_model(mf_ctx* c, size_t i) {
         }
         c->retired.push_back(std::move(r));
     }
-    m->id = -1; m->classID = -1; m->age = 0; m->isStatic = true; m->log_ts.clear(); m->cur = 0; m->pred_gray_valid = false; m->maxDepth = FLT_MAX;
-    *m->h_count = 0;
-    c->pool.push_back(std::move(m));
+    std::unique_ptr<ModelState> owned = std::move(c->models[i]);
+    c->models.erase(c->models.begin() + (long)i);
+    owned->id = -1; owned->classID = -1; owned->age = 0; owned->isStatic = true; owned->log_ts.clear(); owned->cur = 0; owned->pred_gray_valid = false;
+    owned->maxDepth = FLT_MAX;
+    *owned->h_count = 0;
+    if (c->vis_tag.model == owned.get()) c->vis_tag.model = nullptr;
+    c->pool.push_back(std::move(owned));
     return MF_OK;
 }
 // the retired logs' entries on the host (export time: a synchronisation is fine there)
@@ -1151,6 +1164,7 @@ static int materialise_retired(mf_ctx* c) {
         for (size_t e = 0; e < r.n; ++e) r.p.insert(r.p.end(), raw.data() + e * 8, raw.data() + e * 8 + 7);
         r.in_arena = false;
     }
+    c->retired_used = 0;   // every entry is on the host now: the arena starts over
     return MF_OK;
 }
 

@@ -620,8 +620,9 @@ __device__ __forceinline__ void window_slots_literal(float c, int size, int (&u)
     }
 }
 
+// decay: which factor the mask-disagreement rule applied to the confidence (0 none, 1: k, 2: 0.25 k) -- clean_decayed() re-applies it
 __device__ __forceinline__ bool clean_test(const CleanArgs& a, float4 pc, float4 ct, float4 nr, float time, const float* Ri,
-                                           float3 ti, float& newconf) {
+                                           float3 ti, float& newconf, int& decay) {
     const int W = a.W, H = a.H;
     bool test = true;
     const float3 lp = mul33(Ri, f3(pc.x, pc.y, pc.z)) + ti;
@@ -688,29 +689,43 @@ __device__ __forceinline__ bool clean_test(const CleanArgs& a, float4 pc, float4
     const float wDepth = a.depthF[fy_ * W + fx_];
     const int maskValue = a.mask[fy_ * W + fx_];
     newconf = pc.w;
+    decay = 0;
     if (maskValue != a.maskID && maskValue < 255 && (wDepth > lp.z - 0.05f && wDepth < lp.z + 0.05f)) {
         const float kk = 0.5f + 0.5f * (1 - a.outlierCoeff / 10.0f);
-        if (maskValue == 0) newconf *= kk;
-        else if (a.maskID == 0) newconf *= 0.25f * kk;
-        else newconf *= kk;
+        if (maskValue == 0) { newconf *= kk; decay = 1; }
+        else if (a.maskID == 0) { newconf *= 0.25f * kk; decay = 2; }
+        else { newconf *= kk; decay = 1; }
     }
     return test;
 }
+// the confidence clean_test returned for a record, from the record and the decay code alone (the same float operations)
+__device__ __forceinline__ float clean_decayed(const CleanArgs& a, float conf, int decay) {
+    const float kk = 0.5f + 0.5f * (1 - a.outlierCoeff / 10.0f);
+    if (decay == 1) conf *= kk;
+    else if (decay == 2) conf *= 0.25f * kk;
+    return conf;
+}
 
 // ------------------------------------------------------------------------------------------------
-// clean (copy_unstable.vert:53-157) in ONE pass: test + ordered compaction with a decoupled look-back.
+// clean (copy_unstable.vert:53-157) in ONE launch: test + ordered compaction with a decoupled look-back.
 // Rounds 1-4 ran two launches (k_clean_flags: test -> keep flags + new confidences + per-workgroup counts; k_clean_compact: prefix of the
-// counts, ordered copy): every surfel was read twice and its flag / confidence took a round trip through HBM -- 154 B per surfel, of
-// which 96 are compulsory (read 48, write 48).  Here a workgroup draws a chunk of kCleanChunk consecutive elements (element i < count:
-// old surfel i; element count + c: candidate c, live only with op == 2) from a ticket counter, tests its elements, publishes the chunk's
-// number of survivors, obtains the number of survivors of all earlier chunks by looking back over the published values (Merrill & Garland's
-// decoupled look-back; the ticket order guarantees that every earlier chunk is owned by a workgroup that is already running, so the wait
-// terminates), and copies its survivors to their final slots -- the order of the output is the order of the input, as transform feedback
-// keeps it.  The records stay in registers between the test and the copy.
+// counts, ordered copy) over a static partition: the workgroups whose slice lay in view did all the window gathers while the others idled, and
+// every flag / confidence took a round trip through HBM (154 B per surfel moved, 0.95 + 0.53 ms on the 26.9 M-surfel map of configs[4]).
+// Here a workgroup draws a chunk of kCleanChunk consecutive elements (element i < count: old surfel i; element count + c: candidate c, live
+// only with op == 2) from a ticket counter, SWEEPS it once to test its elements -- keep bit and decay code stay in two registers per thread --
+// publishes the chunk's number of survivors, obtains the number of survivors of all earlier chunks by looking back over the published values
+// (Merrill & Garland's decoupled look-back; the ticket order guarantees that every earlier chunk is owned by a workgroup that is already
+// running, so the wait terminates), and SWEEPS the chunk again to copy the survivors to their final slots: the second read of the 96 KB comes
+// out of the L2 / the memory-side cache, the order of the output is the order of the input, as transform feedback keeps it.
+// (Round 5 history, profiles/r05b_* .. r05d_*: keeping the records in registers between test and copy held the chunk at 512-1024 elements;
+// a round -- ticket, loads, gathers, look-back, stores: ~20 us of dependent latency -- then moved 24-48 KB and the pass ran at 0.9-1.4 ms,
+// latency-bound, whatever was done to the ticket and the look-back.  2048 elements per round amortise the same latency over four times the bytes.)
 // ------------------------------------------------------------------------------------------------
-constexpr int kCleanPerThread = 2;
+constexpr int kCleanPerThread = 8;
 constexpr int kCleanChunk = 256 * kCleanPerThread;
-static_assert(kCleanChunk == kRun, "a clean chunk's survivors are one run of the new buffer's run table");
+constexpr int kSubRuns = kCleanChunk / kRun;   // the survivors of a chunk are kSubRuns consecutive runs of the new buffer's run table
+constexpr int kSlicesPerRun = kRun / 256;
+static_assert(kCleanChunk % kRun == 0 && kRun % 256 == 0, "runs are whole slices of a chunk");
 constexpr int kLookPerLane = 4;   // states of earlier chunks a lane reads per look-back step: 256 per step and wavefront
 constexpr unsigned kScanAggregate = 1u, kScanInclusive = 2u;
 constexpr int kTicketStride = 32, kTicketBase = 32;   // ctl: [2..3] finished workgroups << 32 | survivors (64 bit), [kTicketBase + g kTicketStride] ticket counter of lane g (128 B apart)
@@ -771,7 +786,7 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
     __shared__ int s_chunk, s_base;
     __shared__ int s_cnt[kCleanPerThread][4];
     __shared__ int s_bb[6];
-    __shared__ int s_red[4][8];   // the run's box (Surfels::box of dst): per-wavefront partial results
+    __shared__ int s_red[kSubRuns][4][8];   // the boxes of the chunk's runs (Surfels::box of dst): per-wavefront partial results
     // Model::lastBoundingBox of an OBJECT model (Model.cpp:315-345 + draw_global_surface.vert:55-78: the box of the surfels the GUI draws --
     // confidence above the model's threshold -- in millimetres, truncated): accumulated here, where the frame's final records pass through
     // registers anyway; Model::fuse of the NEXT frame limits its depth with it (Model.cpp:480-501).  The background (id 0) never uses one.
@@ -790,7 +805,7 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Chunks are handed out by `lanes` (<= kCleanTicketLanes) counters, lane g (= this workgroup's index mod lanes) serving chunks g, g + lanes, ...:
     // one counter for all chunks made the pass as slow as its ticket -- device-scope atomics on ONE address retire at ~27 ns each on this GPU
-    // (26 k chunks: 0.7 ms; measured, profiles/r05b_*, r05c_*).  Forward progress: a chunk only ever waits for LOWER chunks; the lowest chunk not
+    // (measured, profiles/r05b_*, r05c_*).  Forward progress: a chunk only ever waits for LOWER chunks; the lowest chunk not
     // yet finished is either owned by a running workgroup or next in line on a lane whose workgroups (the first `lanes` workgroups of the
     // grid are dispatched first, one per lane: the host keeps lanes <= the number of compute units) are all working on lower chunks, which finish.
     const int lanes = a.ticket_lanes;
@@ -801,40 +816,44 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
         __syncthreads();
         const int chunk = s_chunk;
         if (chunk >= nchunks) break;
-        // every record of the chunk is requested before anything depends on one of them
-        float4 pc[kCleanPerThread], ct[kCleanPerThread], nr[kCleanPerThread];
-        bool live[kCleanPerThread];
+        const int first = chunk * kCleanChunk + (int)threadIdx.x;
+        // ---- sweep 1: test.  Element j of this thread is first + 256 j; bit j of `keepmask` / bits 2 j, 2 j + 1 of `decay` are all that is kept
+        unsigned keepmask = 0u, decay = 0u;
+#pragma unroll 1
+        for (int sr = 0; sr < kSubRuns; ++sr) {
+            int rlo[3] = {kBoxEmptyMin, kBoxEmptyMin, kBoxEmptyMin}, rhi[3] = {kBoxEmptyMax, kBoxEmptyMax, kBoxEmptyMax}, rtime = kBoxEmptyMax;
+            float4 pc[kSlicesPerRun], ct[kSlicesPerRun], nr[kSlicesPerRun];
+            bool live[kSlicesPerRun];
 #pragma unroll
-        for (int j = 0; j < kCleanPerThread; ++j) {
-            const int i = chunk * kCleanChunk + j * 256 + (int)threadIdx.x;
-            live[j] = i < total;
-            pc[j] = ct[j] = nr[j] = make_float4(0, 0, 0, 0);
-            if (i < count) { pc[j] = a.src.pc[i]; ct[j] = a.src.ct[i]; nr[j] = a.src.nr[i]; }
-            else if (live[j]) {
-                const int c = i - count;
-                live[j] = a.cand_op[c] == 2;      // op == 1 records carry w = -1 and are dropped, op == 0 slots hold nothing
-                if (live[j]) { pc[j] = a.cand_rec[c * 3 + 0]; ct[j] = a.cand_rec[c * 3 + 1]; nr[j] = a.cand_rec[c * 3 + 2]; }
+            for (int q = 0; q < kSlicesPerRun; ++q) {   // the slices' records are requested before anything depends on one of them
+                const int i = first + 256 * (sr * kSlicesPerRun + q);
+                live[q] = i < total;
+                pc[q] = ct[q] = nr[q] = make_float4(0, 0, 0, 0);
+                if (i < count) { pc[q] = a.src.pc[i]; ct[q] = a.src.ct[i]; nr[q] = a.src.nr[i]; }
+                else if (live[q]) {
+                    const int c = i - count;
+                    live[q] = a.cand_op[c] == 2;      // op == 1 records carry w = -1 and are dropped, op == 0 slots hold nothing
+                    if (live[q]) { pc[q] = a.cand_rec[c * 3 + 0]; ct[q] = a.cand_rec[c * 3 + 1]; nr[q] = a.cand_rec[c * 3 + 2]; }
+                }
             }
-        }
-        bool keep[kCleanPerThread];
-        int rank[kCleanPerThread];
-        int rlo[3] = {kBoxEmptyMin, kBoxEmptyMin, kBoxEmptyMin}, rhi[3] = {kBoxEmptyMax, kBoxEmptyMax, kBoxEmptyMax}, rtime = kBoxEmptyMax;
 #pragma unroll
-        for (int j = 0; j < kCleanPerThread; ++j) {
-            float nc = 0.f;
-            keep[j] = live[j] && clean_test(a, pc[j], ct[j], nr[j], time, Ri, ti, nc);
-            if (a.flags) {
-                const int i = chunk * kCleanChunk + j * 256 + (int)threadIdx.x;
-                if (i < total) { a.flags[i] = keep[j] ? 1 : 0; a.newconf[i] = live[j] ? nc : 0.f; }
+            for (int q = 0; q < kSlicesPerRun; ++q) {
+                const int j = sr * kSlicesPerRun + q;
+                float nc = 0.f;
+                int dk = 0;
+                const bool keep = live[q] && clean_test(a, pc[q], ct[q], nr[q], time, Ri, ti, nc, dk);
+                if (a.flags) {
+                    const int i = first + 256 * j;
+                    if (i < total) { a.flags[i] = keep ? 1 : 0; a.newconf[i] = live[q] ? nc : 0.f; }
+                }
+                keepmask |= (keep ? 1u : 0u) << j;
+                decay |= (unsigned)dk << (2 * j);
+                if (keep) run_box_accumulate(pc[q], ct[q].w == -2.f ? time : ct[q].w, rlo, rhi, rtime);   // (copy_unstable.vert:131: -2 becomes the time)
+                const unsigned long long m = __ballot(keep);
+                if (lane == 0) s_cnt[j][wave] = __popcll(m);
             }
-            pc[j].w = nc;
-            if (ct[j].w == -2.f) ct[j].w = time;  // copy_unstable.vert:131
-            if (keep[j]) run_box_accumulate(pc[j], ct[j].w, rlo, rhi, rtime);
-            const unsigned long long m = __ballot(keep[j]);
-            rank[j] = lane_rank(m);
-            if (lane == 0) s_cnt[j][wave] = __popcll(m);
+            run_box_reduce(rlo, rhi, rtime, s_red[sr]);
         }
-        run_box_reduce(rlo, rhi, rtime, s_red);   // the survivors of this chunk are run `chunk` of the new buffer
         __syncthreads();
         if (wave == 0) {
             int tot = 0;
@@ -851,27 +870,43 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
                 s_base = excl;
                 wg_kept += tot;
                 if (gave_up) a.frame->pad[2] = 1;
-                run_box_store(a.dst.box, chunk, min(excl, a.dst.cap), s_red);
-                if (chunk == nchunks - 1) a.dst.box[2 * nchunks + 1] = make_int4(0, 0, 0, min(excl + tot, a.dst.cap));   // end of the last run
+                int start = excl;     // the chunk's survivors are kSubRuns consecutive runs of the new buffer
+                for (int sr = 0; sr < kSubRuns; ++sr) {
+                    run_box_store(a.dst.box, chunk * kSubRuns + sr, min(start, a.dst.cap), s_red[sr]);
+                    for (int q = 0; q < kSlicesPerRun; ++q) {
+                        const int j = sr * kSlicesPerRun + q;
+                        start += s_cnt[j][0] + s_cnt[j][1] + s_cnt[j][2] + s_cnt[j][3];
+                    }
+                }
+                if (chunk == nchunks - 1) a.dst.box[2 * nchunks * kSubRuns + 1] = make_int4(0, 0, 0, min(excl + tot, a.dst.cap));   // end of the last run
             }
         }
         __syncthreads();
+        // ---- sweep 2: copy.  The survivors' records are read again (the chunk's 96 KB are a few microseconds old) and go to their final slots
         int off = s_base;
-#pragma unroll
+#pragma unroll 2
         for (int j = 0; j < kCleanPerThread; ++j) {
-            int o = off + rank[j];
+            const bool keep = (keepmask >> j) & 1u;
+            const unsigned long long m = __ballot(keep);
+            int o = off + lane_rank(m);
             for (int w = 0; w < wave; ++w) o += s_cnt[j][w];
-            if (keep[j] && o < a.dst.cap) {
-                a.dst.pc[o] = pc[j]; a.dst.ct[o] = ct[j]; a.dst.nr[o] = nr[j];
-                if (bbox_on && pc[j].w > a.confThreshold) {   // draw_global_surface.vert:55 (unstable == 0), :69-78
-                    const int x = (int)(1000.f * pc[j].x), y = (int)(1000.f * pc[j].y), z = (int)(1000.f * pc[j].z);
+            if (keep && o < a.dst.cap) {
+                const int i = first + 256 * j;
+                float4 pc, ct, nr;
+                if (i < count) { pc = a.src.pc[i]; ct = a.src.ct[i]; nr = a.src.nr[i]; }
+                else { const int c = i - count; pc = a.cand_rec[c * 3 + 0]; ct = a.cand_rec[c * 3 + 1]; nr = a.cand_rec[c * 3 + 2]; }
+                pc.w = clean_decayed(a, pc.w, (int)((decay >> (2 * j)) & 3u));
+                if (ct.w == -2.f) ct.w = time;  // copy_unstable.vert:131
+                a.dst.pc[o] = pc; a.dst.ct[o] = ct; a.dst.nr[o] = nr;
+                if (bbox_on && pc.w > a.confThreshold) {   // draw_global_surface.vert:55 (unstable == 0), :69-78
+                    const int x = (int)(1000.f * pc.x), y = (int)(1000.f * pc.y), z = (int)(1000.f * pc.z);
                     bmin[0] = min(bmin[0], x); bmin[1] = min(bmin[1], y); bmin[2] = min(bmin[2], z);
                     bmax[0] = max(bmax[0], x); bmax[1] = max(bmax[1], y); bmax[2] = max(bmax[2], z);
                 }
             }
             off += s_cnt[j][0] + s_cnt[j][1] + s_cnt[j][2] + s_cnt[j][3];
         }
-        __syncthreads();   // s_chunk / s_cnt / s_base are rewritten by the next round
+        __syncthreads();   // s_chunk / s_cnt / s_base / s_red are rewritten by the next round
     }
     if (bbox_on) {
 #pragma unroll
@@ -895,7 +930,7 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
             const int n = min((int)(unsigned)(old & 0xFFFFFFFFull) + wg_kept, a.dst.cap);
             a.frame->countNext = n;
             a.frame->count = n;
-            a.frame->runs = nchunks;
+            a.frame->runs = nchunks * kSubRuns;
             if (a.host_count) *a.host_count = n;
             if (bbox_on) {   // the box of a frame is the box of its LAST clean pass (the reference's render pass sees the final buffer)
                 for (int q = 0; q < 6; ++q) {

@@ -3,7 +3,7 @@
 MaskFusion's per-model state (surfel map, tracker pyramids, pose) is independent (Core/Model/Model.h:271-323); what the
 models share is the incoming frame and, for multi-model scenes, the label image.  One process per GPU owns one model:
 
-    rank 0 owns the input stream  --broadcast(rgb 3P B + depth 4P B)-->  every rank tracks + fuses ITS model
+    rank 0 owns the input stream  --ONE broadcast(depth 4P B | rgb 3P B, packed)-->  every rank tracks + fuses ITS model
     every rank                    --gather(16 floats: pose, ICP error, inliers, surfels)-->  rank 0 (logging / decisions)
 
 xGMI is point to point (each peer has its own link to rank 0), so the rank-0-rooted broadcast of 2.15 MB (VGA) costs about
@@ -24,31 +24,40 @@ STATS_WIDTH = 16  # R(9) t(3) icpError icpCount surfels alive
 
 
 class FrameBroadcaster:
-    """Owns the per-rank frame buffers and moves frame k from rank `src` to every rank."""
+    """Owns the per-rank frame buffers and moves frame k from rank `src` to every rank: ONE broadcast of one packed buffer per frame
+    (depth 4P bytes | rgb 3P bytes, the layout mf_process_frame's own upload uses), as the north star names it."""
 
     RING = 3  # the library may still read frame k-2 while frame k is published (include/maskfusion_amd.h, input stream)
 
     def __init__(self, height: int, width: int, device: torch.device, src: int = 0):
         self.src = src
         self.device = device
-        self.rgbs = [torch.empty((height, width, 3), dtype=torch.uint8, device=device) for _ in range(self.RING)]
-        self.depths = [torch.empty((height, width), dtype=torch.float32, device=device) for _ in range(self.RING)]
+        self.P = height * width
+        self.shape = (height, width)
+        self.blocks = [torch.empty(7 * self.P, dtype=torch.uint8, device=device) for _ in range(self.RING)]
         self.k = 0
+        self.n_broadcasts = 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
+
+    def views(self, block: torch.Tensor):
+        """(rgb HxWx3 uint8, depth HxW float32) views into a packed block (depth first: its 4-byte alignment)"""
+        P, (H, W) = self.P, self.shape
+        return block[4 * P:].view(H, W, 3), block[:4 * P].view(torch.float32).view(H, W)
 
     def publish(self, rgb: Optional[torch.Tensor], depth: Optional[torch.Tensor]):
         """rank `src` passes its frame (already on `device`); the others pass None.  Returns (rgb, depth) buffers valid on
         every rank, ordered on the current stream."""
         if self.world == 1:
             return rgb, depth          # nothing to move: the model reads the caller's buffers
-        r, d = self.rgbs[self.k % self.RING], self.depths[self.k % self.RING]
+        blk = self.blocks[self.k % self.RING]
         self.k += 1
+        r, d = self.views(blk)
         if self.rank == self.src:
             r.copy_(rgb, non_blocking=True)
             d.copy_(depth, non_blocking=True)
-        dist.broadcast(r, self.src)
-        dist.broadcast(d, self.src)
+        dist.broadcast(blk, self.src)
+        self.n_broadcasts += 1
         return r, d
 
 

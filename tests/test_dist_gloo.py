@@ -48,7 +48,9 @@ def _worker(rank, world, port, out_dir):
         stats[9:12] = torch.from_numpy(T[:3, 3].astype(np.float32))
         stats[12], stats[13], stats[14], stats[15] = e, c, float(o.count), 1.0
 
-    gathered = mfd.run_steps(get_frame, model_step, N_STEPS, H, W, dev)
+    state = {}
+    gathered = mfd.run_steps(get_frame, model_step, N_STEPS, H, W, dev, state=state)
+    assert state["bc"].n_broadcasts == N_STEPS, "one packed broadcast per frame (rgb and depth travel together)"
     t = mfd.max_over_ranks(float(rank + 1), dev)
     assert t == float(world)
     if rank == 0:
