@@ -361,7 +361,7 @@ def rocprof_rows(names, pattern="r*kernel_stats.csv"):
         for r in rows:
             nm = r.get("Name", "")
             for want in names:
-                if want in nm and want not in out:
+                if (f"::{want}(" in nm or f"::{want}<" in nm or nm.startswith(want)) and want not in out:   # the function of that name, not one whose name contains it
                     try:
                         out[want] = {"us": float(r["AverageNs"]) / 1e3, "calls": int(r["Calls"]), "kernel": nm, "source": "profiles/" + os.path.basename(path)}
                     except Exception:
@@ -468,12 +468,11 @@ class RoomMapJob:
 # SURVEY.md 8d contract bytes of the surfel half, per surfel (N = live surfels of the model) and per pixel (P), by kernel: one read-modify-write
 # (update + clean) 96 B/surfel and two projections of 48 B/surfel each; image-side outputs 52 P per index map, 38 P for the prediction.
 C4_KERNEL_BYTES = {
-    "k_index_scatter": lambda N, P: 48.0 * N,                    # projection 1 (pre-fusion index map): the surfel stream
+    "k_index_scatter": lambda N, P: 48.0 * N,                    # a projection of the surfel stream (the pre-fusion index map; the post-fusion one is the same kernel)
     "k_index_resolve": lambda N, P: 52.0 * P,                    # ... its image-side outputs
-    "k_fuse_update": lambda N, P: 96.0 * N,                      # update: read 48 + write 48 (the second index scatter rides on it)
-    "k_clean_flags": lambda N, P: 48.0 * N,                      # clean, pass 1: the surfel stream (+ its window gathers, image side)
-    "k_clean_compact": lambda N, P: 96.0 * N,                    # clean, pass 2: read 48 + write 48
-    "k_splat_bin": lambda N, P: 48.0 * N,                        # projection 2 (prediction): the surfel stream
+    "k_clean": lambda N, P: 96.0 * N,                            # THE read-modify-write of the frame (update + clean): read 48 + write 48; update.vert itself runs
+                                                                 # in place on the merged surfels only (k_fuse_update, no N-sized traffic)
+    "k_splat_bin": lambda N, P: 48.0 * N,                        # a projection of the surfel stream (prediction; GlobalProjection's is the same kernel)
     "k_splat_tile": lambda N, P: 38.0 * P,                       # ... its image-side outputs
 }
 
@@ -557,8 +556,10 @@ def config4_scene(local_rank, frames, room_job, seconds=2.0, frames_per_rep=30, 
         for nm, r in rows.items():
             b = C4_KERNEL_BYTES[nm](N_bg, P)
             levels[nm] = dict(r, contract_bytes=b, frac=b / (r["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                              note="background model's launch (N = %d): average duration of ALL launches of this name in the named summary; "
-                                   "the object models' batched passes are the k_obj_* rows of the same file" % N_bg)
+                              note="background model's launch (N = %d): contract bytes of SURVEY.md 8d over the average duration of the launches of this "
+                                   "name on the full map in the named summary (`us`); with run culling (Surfels::box, k_cull) a projection pass "
+                                   "visits ~22 %% of the buffer, so its rate in contract bytes can exceed the HBM peak -- the HBM bytes per launch are "
+                                   "in profiles/r05_c4_hbm.json; the object models' batched passes are the k_obj_* rows of the same file" % N_bg)
     return {"workload": CONFIGS["4"]["workload"], "value": steps / dt, "unit": "frames/s", "ms_per_step": ms, "steps": steps, "repetitions": reps,
             "frames_per_repetition": frames_per_rep, "models": len(counts), "model_ids": ids, "surfels_at_start": fills_start, "surfels_at_end": counts,
             "fill_at_start": [c / cap for c, cap in zip(fills_start, caps)], "fill_at_end": [c / cap for c, cap in zip(counts, caps)],

@@ -262,10 +262,10 @@ size_t clean_scan_entries(long max_elements);
 void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k,
                   int timeDelta, float confThreshold, float outlierCoeff, int maskID, const int* index,
                   const float4* vc, const float4* ct, const float4* packed /*or null*/, const float* depthF, const uint8_t* mask,
-                  const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags /*or null*/, float* newconf /*or null*/,
+                  const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags /*or null*/, float* newconf /*or null*/, int* block_counts,
                   unsigned long long* scan_state, int* ctl, unsigned epoch, int blocks, int ticket_lanes /* <= compute units, <= kCleanTicketLanes */,
                   int* host_count_mirror, bool transposed /*layout of index/vc/ct*/, bool literalWindow /*fp32 trip count of the shader*/,
-                  hipStream_t s);
+                  bool small_map /* the two-launch form (needs flags, newconf, block_counts; writes no run table) */, hipStream_t s);
 // generic ordered compaction of [n_dev] records (3 x float4 each, record-major) -> surfels, sets frame->count
 void launch_compact_records(const float4* rec, const uint8_t* flags, int n, Surfels dst, FrameDev* frame,
                             int* block_counts, int* host_count_mirror, hipStream_t s);
@@ -300,6 +300,7 @@ struct ObjPassArgs {
     int maskID; float confThreshold, fuseMaxDepth, weightMultiplier;
     unsigned long long* keys; int* index; float4* ivc; float4* inr; float4* iclean;
     uint8_t* cand_op; float4* cand_rec; int* upd_first; int* cand_best; unsigned long long* scan_state; int* clean_ctl; int* host_count;
+    uint8_t* flags; float* newconf; int* block_counts;   // the two-launch clean form's intermediates
     float4* predV; float4* predN; uchar4* predImage; uint16_t* predTime; uint8_t* predGray;
     FrameDev* host_frame; float* log_slot;
     unsigned global_payload;           // GlobalProjection: order << 8 | id
@@ -309,6 +310,7 @@ struct ObjBatch {
     int W, H; Intr k; float maxDepthProcessed, globalMaxDepth; int timeDelta; float outlierCoeff; int cleanLiteral, bboxLimit;
     unsigned cleanEpoch;               // CleanArgs::epoch of this batch's clean launch
     int cleanTicketLanes;              // CleanArgs::ticket_lanes
+    int cleanSmall;                    // 1: every model of the batch is small -- the two-launch clean form
     const uint8_t* rgb; const float* depthRaw; const float* depthF; const uint8_t* mask; const PoseDev* bg_pose;
     unsigned long long* global_keys;
 };

@@ -587,7 +587,8 @@ struct CleanArgs {
     const float4* packed;                                    // {vertConf | initTime, lastTime, index, 0} per texel
     const float* depthF; const uint8_t* mask;
     const uint8_t* cand_op; const float4* cand_rec;
-    uint8_t* flags; float* newconf;    // optional taps (Model-level calls, tests): keep flag / new confidence per element; nullptr inside a frame
+    uint8_t* flags; float* newconf;    // keep flag / new confidence per element: the two-launch form's intermediate; for the one-launch form optional taps
+    int* block_counts;                 // [kCompactBlocks] survivors per workgroup (two-launch form)
     int* host_count;
     unsigned long long* scan_state;    // [chunks] decoupled look-back: (launch epoch << 34 | status << 32 | survivors)
     int* ctl;                          // kCleanCtlInts ints, zero between launches: finished workgroups + the ticket counters (clean_body)
@@ -705,6 +706,134 @@ __device__ __forceinline__ float clean_decayed(const CleanArgs& a, float conf, i
     else if (decay == 2) conf *= 0.25f * kk;
     return conf;
 }
+
+// ------------------------------------------------------------------------------------------------
+// clean, the form for SMALL maps: two launches over a static partition (rounds 1-4).  A round of the one-launch form below is ~100 us of
+// dependent latency whatever it moves; on a map of a few hundred thousand surfels that IS the pass (k_clean at VGA: 100 us against
+// 25 + 8 us for these two), on 27 M surfels it is amortised (1.04 against 0.95 + 0.53 ms).  launch_clean picks by the element count; the
+// surviving records, their order and the count are the same bits either way (tests/test_gpu_switches.py::test_clean_forms_agree).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void clean_small_flags_body(const CleanArgs& a) {
+    __shared__ int s_w[4];
+    const int count = a.frame->count;
+    const int total = count + cand_count(a.W, a.H, a.frame->tick);
+    const float time = (float)a.frame->tick;
+    float Ri[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) Ri[q] = a.pose->Ri[q];
+    const float3 ti = f3(a.pose->ti[0], a.pose->ti[1], a.pose->ti[2]);
+    const int chunk = chunk_size(total);
+    const int beg = blockIdx.x * chunk, end = min(total, beg + chunk);
+    int kept = 0;
+    for (int i = beg + threadIdx.x; i < end; i += 256) {
+        bool keep = false;
+        float nc = 0.f;
+        int dk = 0;
+        if (i < count) {
+            keep = clean_test(a, a.src.pc[i], a.src.ct[i], a.src.nr[i], time, Ri, ti, nc, dk);
+        } else {
+            const int c = i - count;
+            if (a.cand_op[c] == 2)
+                keep = clean_test(a, a.cand_rec[c * 3 + 0], a.cand_rec[c * 3 + 1], a.cand_rec[c * 3 + 2], time, Ri, ti, nc, dk);
+        }
+        a.flags[i] = keep ? 1 : 0;
+        a.newconf[i] = nc;
+        kept += keep ? 1 : 0;
+    }
+    const int tot = block_sum_i(kept, s_w);
+    if (threadIdx.x == 0) {
+        a.block_counts[blockIdx.x] = tot;
+        if (blockIdx.x == 0) {
+            a.frame->countNext = count;  // snapshot for pass 2 (see FrameDev)
+            if (a.maskID != 0)   // the compaction pass (next launch) accumulates this clean pass's box
+                for (int q = 0; q < 6; ++q) a.frame->bbox_acc[q] = q < 3 ? kBBoxEmptyMin : kBBoxEmptyMax;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_clean_small_flags(const CleanArgs a) { clean_small_flags_body(a); }
+
+__device__ __forceinline__ void clean_small_compact_body(const CleanArgs& a) {
+    __shared__ int s_w[4];
+    __shared__ int s_bb[6];
+    // Model::lastBoundingBox of an OBJECT model (Model.cpp:315-345 + draw_global_surface.vert:55-78: the box of the surfels the GUI draws --
+    // confidence above the model's threshold -- in millimetres, truncated): accumulated here, where the frame's final records pass through
+    // registers anyway; Model::fuse of the NEXT frame limits its depth with it (Model.cpp:480-501).  The background (id 0) never uses one.
+    const bool bbox_on = a.maskID != 0;
+    int bmin[3] = {kBBoxEmptyMin, kBBoxEmptyMin, kBBoxEmptyMin}, bmax[3] = {kBBoxEmptyMax, kBBoxEmptyMax, kBBoxEmptyMax};
+    if (bbox_on && threadIdx.x < 6) s_bb[threadIdx.x] = threadIdx.x < 3 ? kBBoxEmptyMin : kBBoxEmptyMax;
+    const int count = a.frame->countNext;
+    const int total = count + cand_count(a.W, a.H, a.frame->tick);
+    const float time = (float)a.frame->tick;
+    const int chunk = chunk_size(total);
+    const int beg = blockIdx.x * chunk, end = min(total, beg + chunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int base = 0;
+    for (int i0 = beg; i0 < end; i0 += 256) {
+        // every load of the slice is issued before anything depends on one of them (the keep flag, the record, the new
+        // confidence, and -- first slice -- the workgroup's base offset): one memory latency per slice instead of three
+        const int i = i0 + threadIdx.x;
+        const bool in = i < end;
+        uint8_t flag = 0;
+        float nc = 0.f;
+        float4 pc = make_float4(0, 0, 0, 0), ct = pc, nr = pc;
+        if (in) {
+            flag = a.flags[i];
+            nc = a.newconf[i];
+            if (i < count) { pc = a.src.pc[i]; ct = a.src.ct[i]; nr = a.src.nr[i]; }
+            else { const int c = i - count; pc = a.cand_rec[c * 3 + 0]; ct = a.cand_rec[c * 3 + 1]; nr = a.cand_rec[c * 3 + 2]; }
+        }
+        if (i0 == beg) base = block_base(a.block_counts, s_w);
+        const bool keep = in && flag;
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_w[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += s_w[w];
+        const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        if (keep) {
+            const int o = off + lane_rank(m);
+            pc.w = nc;
+            if (ct.w == -2.f) ct.w = time;  // copy_unstable.vert:131
+            if (o < a.dst.cap) {
+                a.dst.pc[o] = pc; a.dst.ct[o] = ct; a.dst.nr[o] = nr;
+                if (bbox_on && pc.w > a.confThreshold) {   // draw_global_surface.vert:55 (unstable == 0), :69-78
+                    const int x = (int)(1000.f * pc.x), y = (int)(1000.f * pc.y), z = (int)(1000.f * pc.z);
+                    bmin[0] = min(bmin[0], x); bmin[1] = min(bmin[1], y); bmin[2] = min(bmin[2], z);
+                    bmax[0] = max(bmax[0], x); bmax[1] = max(bmax[1], y); bmax[2] = max(bmax[2], z);
+                }
+            }
+        }
+        base += tot;
+        __syncthreads();
+    }
+    if (bbox_on) {   // (the loop's barriers order the initialisation of s_bb before these; a workgroup without elements skips both)
+        if (beg < end) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (bmin[q] != kBBoxEmptyMin) atomicMin(&s_bb[q], bmin[q]);
+                if (bmax[q] != kBBoxEmptyMax) atomicMax(&s_bb[3 + q], bmax[q]);
+            }
+            __syncthreads();
+            if (threadIdx.x < 3 && s_bb[threadIdx.x] != kBBoxEmptyMin) atomicMin(&a.frame->bbox_acc[threadIdx.x], s_bb[threadIdx.x]);
+            else if (threadIdx.x >= 3 && threadIdx.x < 6 && s_bb[threadIdx.x] != kBBoxEmptyMax) atomicMax(&a.frame->bbox_acc[threadIdx.x], s_bb[threadIdx.x]);
+        }
+    }
+    if (blockIdx.x != gridDim.x - 1) return;
+    if (beg >= end) base = block_base(a.block_counts, s_w);   // the last workgroup owns no elements: all threads take part
+    if (threadIdx.x == 0) {
+        a.frame->count = min(base, a.dst.cap);
+        a.frame->runs = 0;   // (this form writes no run table: the host does not cull a buffer it produced)
+        if (a.host_count) *a.host_count = min(base, a.dst.cap);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// splat prediction: scatter (per-surfel sprite loop, ray-disc test, 64-bit atomicMin) + resolve
+// Raster rule: sprite side s centred on (u,v) covers pixel (px,py) iff u - s/2 <= px + 0.5 < u + s/2; LESS on the
+// corrected z; lower index wins ties; sprites wider than 64 px are clamped.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_clean_small_compact(const CleanArgs a) { clean_small_compact_body(a); }
 
 // ------------------------------------------------------------------------------------------------
 // clean (copy_unstable.vert:53-157) in ONE launch: test + ordered compaction with a decoupled look-back.
@@ -1133,8 +1262,8 @@ void launch_pose_log(const PoseDev* pose, const PoseDev* bg_pose, float* slot, h
 void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, int timeDelta,
                   float confThreshold, float outlierCoeff, int maskID, const int* index, const float4* vc, const float4* ct,
                   const float4* packed, const float* depthF, const uint8_t* mask, const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags,
-                  float* newconf, unsigned long long* scan_state, int* ctl, unsigned epoch, int blocks, int ticket_lanes, int* host_count_mirror,
-                  bool transposed, bool literalWindow, hipStream_t s) {
+                  float* newconf, int* block_counts, unsigned long long* scan_state, int* ctl, unsigned epoch, int blocks, int ticket_lanes,
+                  int* host_count_mirror, bool transposed, bool literalWindow, bool small_map, hipStream_t s) {
     CleanArgs a;
     a.transposed = transposed ? 1 : 0;
     a.literal = literalWindow ? 1 : 0;
@@ -1142,8 +1271,13 @@ void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose
     a.confThreshold = confThreshold; a.outlierCoeff = outlierCoeff; a.maskID = maskID; a.index = index; a.vc = vc; a.ct = ct;
     a.packed = packed;
     a.depthF = depthF; a.mask = mask; a.cand_op = cand_op; a.cand_rec = cand_rec;
-    a.flags = flags; a.newconf = newconf; a.host_count = host_count_mirror;
+    a.flags = flags; a.newconf = newconf; a.block_counts = block_counts; a.host_count = host_count_mirror;
     a.scan_state = scan_state; a.ctl = ctl; a.epoch = epoch; a.ticket_lanes = min(ticket_lanes, blocks);
+    if (small_map) {
+        hipLaunchKernelGGL(k_clean_small_flags, dim3(kCompactBlocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_clean_small_compact, dim3(kCompactBlocks), dim3(256), 0, s, a);
+        return;
+    }
     hipLaunchKernelGGL(k_clean, dim3(blocks), dim3(256), 0, s, a);
 }
 
@@ -1181,11 +1315,14 @@ __device__ __forceinline__ CleanArgs obj_clean_args(const ObjBatch& b, const Obj
     a.src = m.a; a.dst = m.b; a.frame = m.frame; a.pose = m.pose; a.W = b.W; a.H = b.H; a.k = b.k; a.timeDelta = b.timeDelta;
     a.confThreshold = m.confThreshold; a.outlierCoeff = b.outlierCoeff; a.maskID = m.maskID; a.transposed = 1; a.literal = b.cleanLiteral;
     a.index = m.index; a.vc = m.ivc; a.ct = nullptr; a.packed = m.iclean; a.depthF = b.depthF; a.mask = b.mask;
-    a.cand_op = m.cand_op; a.cand_rec = m.cand_rec; a.flags = nullptr; a.newconf = nullptr; a.host_count = m.host_count;
+    a.cand_op = m.cand_op; a.cand_rec = m.cand_rec; a.flags = b.cleanSmall ? m.flags : nullptr; a.newconf = b.cleanSmall ? m.newconf : nullptr;
+    a.block_counts = m.block_counts; a.host_count = m.host_count;
     a.scan_state = m.scan_state; a.ctl = m.clean_ctl; a.epoch = b.cleanEpoch; a.ticket_lanes = b.cleanTicketLanes;
     return a;
 }
 __global__ __launch_bounds__(256) void k_obj_clean(const ObjBatch b) { clean_body(obj_clean_args(b, b.m[blockIdx.z])); }
+__global__ __launch_bounds__(256) void k_obj_clean_small_flags(const ObjBatch b) { clean_small_flags_body(obj_clean_args(b, b.m[blockIdx.z])); }
+__global__ __launch_bounds__(256) void k_obj_clean_small_compact(const ObjBatch b) { clean_small_compact_body(obj_clean_args(b, b.m[blockIdx.z])); }
 __global__ __launch_bounds__(256) void k_obj_splat_scatter(const ObjBatch b) {
     const ObjPassArgs& m = b.m[blockIdx.z];
     splat_scatter_body<4>(m.a, m.frame, m.pose, b.W, b.H, b.k, b.maxDepthProcessed, m.confThreshold, b.timeDelta, m.keys);
@@ -1209,7 +1346,12 @@ void launch_obj_fuse_clean(const ObjBatch& b, int blocks, int clean_blocks, hipS
     hipLaunchKernelGGL(k_obj_fuse_update, dim3(cand_blocks(b.W, b.H), 1, b.n), dim3(256), 0, s, b);
     hipLaunchKernelGGL(k_obj_index_scatter2, surfels, dim3(256), 0, s, b);
     hipLaunchKernelGGL(k_obj_index_resolve, pixels, dim3(256), 0, s, b, 1);
-    hipLaunchKernelGGL(k_obj_clean, compact, dim3(256), 0, s, b);
+    if (b.cleanSmall) {
+        hipLaunchKernelGGL(k_obj_clean_small_flags, dim3(kCompactBlocks, 1, b.n), dim3(256), 0, s, b);
+        hipLaunchKernelGGL(k_obj_clean_small_compact, dim3(kCompactBlocks, 1, b.n), dim3(256), 0, s, b);
+    } else {
+        hipLaunchKernelGGL(k_obj_clean, compact, dim3(256), 0, s, b);
+    }
 }
 void launch_obj_predict_advance(const ObjBatch& b, int blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_obj_splat_scatter, dim3(blocks, 1, b.n), dim3(256), 0, s, b);

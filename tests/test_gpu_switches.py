@@ -409,7 +409,7 @@ def test_run_culling_changes_nothing(hip):
     def run(cull):
         mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=False, numGSurfels=1 << 20, initConfidenceGlobal=10.0)
         mf.setParam("cullRuns", 1 if cull else 0)
-        mf.setParam("cullMinSurfels", 0)          # (by default maps below 2 M surfels are streamed whole)
+        mf.setParam("bigMapElements", 0)          # (by default only maps of >= 6 M surfels get the one-launch clean pass, its run table and the culling)
         out = []
         for k, (rgb, d, _) in enumerate(frames):
             mf.processFrame(rgb, d, timestamp=k)
@@ -429,3 +429,43 @@ def test_run_culling_changes_nothing(hip):
         assert x["count"] == y["count"] and np.array_equal(x["pose"], y["pose"]), k
         assert np.array_equal(x["pv"], y["pv"], equal_nan=True) and np.array_equal(x["pi"], y["pi"]), k
     assert np.array_equal(ca, cb, equal_nan=True)
+
+
+@pytest.mark.parametrize("multi", [False, True], ids=["single-model", "multi-model"])
+def test_clean_forms_agree(hip, multi):
+    """Model::clean has two forms (mf_surfel.hip): two launches over a static partition for small maps, one launch with a decoupled look-back
+    (which also writes the run table the projection passes cull by) from `bigMapElements` surfels on.  The same frames through both: model
+    list, counts, every surfel of every model in its slot, poses and label images bit-identical -- single model, and background + object
+    models (whose passes are batched: one launch per pass for all of them)."""
+    from maskfusion_amd import MaskFusion, synth
+    W, H, f = 320, 240, 264.0
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True, n_objects=3 if multi else 0, object_motion=0.0)
+    frames = [st.frame(k) for k in range(12)]
+
+    def run(big):
+        mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=multi, numGSurfels=1 << 19, numOSurfels=1 << 16,
+                        modelSpawnOffset=2, trackAllModels=False, initConfidenceGlobal=10.0, initConfidenceObject=0.01)
+        if multi:
+            for k, v in (("mfThreshold", 0.3), ("mfWeightDistance", 150.0), ("mfWeightConvexity", 2.8), ("mfMorphEdgeIterations", 0),
+                         ("mfMorphMaskIterations", 0), ("newModelMinRelativeSize", 0.004)):
+                mf.setParam(k, v)
+        mf.setParam("bigMapElements", big)
+        poses = []
+        for k, (rgb, d, m) in enumerate(frames):
+            mf.processFrame(rgb, d, mask=m if multi else None, classIDs=[0, 41, 42, 43] if multi else (), timestamp=k)
+            poses.append([x.getPose() for x in mf.getModels()])
+        ms = mf.getModels()
+        out = dict(poses=poses, ids=[x.getID() for x in ms], counts=[x.lastCount() for x in ms], clouds=[x.downloadMap() for x in ms],
+                   labels=mf.downloadSegmentation() if multi else None)
+        mf.close()
+        return out
+
+    a, b = run(0), run(1 << 30)
+    assert a["ids"] == b["ids"] and a["counts"] == b["counts"], (a["ids"], b["ids"], a["counts"], b["counts"])
+    if multi:
+        assert len(a["ids"]) >= 3, a["ids"]     # at least two objects: their passes really were batched
+        assert np.array_equal(a["labels"], b["labels"])
+    for pa, pb in zip(a["poses"], b["poses"]):
+        assert len(pa) == len(pb) and all(np.array_equal(x, y) for x, y in zip(pa, pb))
+    for x, y in zip(a["clouds"], b["clouds"]):
+        assert np.array_equal(x, y, equal_nan=True)

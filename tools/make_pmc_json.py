@@ -1,6 +1,7 @@
 """Builds profiles/<tag>_pmc.json (what bench.py's roofline.traffic reads) from the per-kernel PMC summaries of one profile round.
 
-usage: make_pmc_json.py <tag> <bench_fetch.csv> <bench_write.csv> <calib_fetch.csv> <calib_write.csv> <tree>
+usage: make_pmc_json.py <tag> <bench_fetch.csv> <bench_write.csv> <calib_fetch.csv> <calib_write.csv> <tree> [output file name]
+(default output profiles/<tag>_pmc.json = what bench.py reads for configs[1]; another workload's summary gets another name)
 
 Inputs are tools/pmc_summary.py outputs (kernel,counter,launches,mean,total) of separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 passes (no other trace domain than --kernel-trace).  FETCH_SIZE / WRITE_SIZE are reported in KiB per launch; the correction
@@ -14,7 +15,8 @@ import sys
 
 CALIB_BYTES = 256 * 1024 * 1024
 WIDE = ("k_fuse_update", "k_clean_compact", "k_index_scatter", "k_splat_bin", "k_clean_flags", "k_fuse_data", "k_index_resolve", "k_splat_tile",
-        "k_model_pyramid")   # float4 surfel / map streams
+        "k_model_pyramid", "k_clean", "k_clean_small_flags", "k_clean_small_compact", "k_cull", "k_run_table", "k_global_tile", "k_obj_clean",
+        "k_obj_index_scatter", "k_obj_index_scatter2", "k_obj_index_resolve", "k_obj_splat_scatter", "k_obj_global_scatter")   # float4 surfel / map streams
 
 
 def load(path):
@@ -40,6 +42,7 @@ def merged(table, prefix):
 
 def main():
     tag, bf, bw, cf, cw, tree = sys.argv[1:7]
+    out_name = sys.argv[7] if len(sys.argv) > 7 else f"profiles/{tag}_pmc.json"
     F, Wt, CF, CW = load(bf), load(bw), load(cf), load(cw)
     fac = {}
     for key, table in (("read4", CF), ("read16", CF), ("write4", CW), ("write16", CW)):
@@ -61,7 +64,7 @@ def main():
     out = {"tag": tag, "tree": tree, "calibration": {"bytes_per_launch": CALIB_BYTES, "factors": fac,
                                                       "method": "tools/micro/fetch_calib under the same two rocprofv3 --pmc passes"},
            "kernels": kernels}
-    json.dump(out, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
+    json.dump(out, open(out_name, "w"), indent=1)
     print(json.dumps({"factors": fac, "k_icp_iter": kernels.get("k_icp_iter")}, indent=1))
 
 
