@@ -212,7 +212,22 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
     launch_fuse_data(d_rgb, d_depth, depthF, mask, m.id, m.d_frame, m.d_pose, weightMultiplier, fminf(fuseDepthCutoff, m.maxDepth), W, H,
                      c->K, c->d_index, c->d_ivc, c->d_inr, c->d_cand_op, c->d_cand_rec, c->d_upd_first, c->d_cand_best, s, c->bbox_limit ? 1 : 0);
     if (marks) mark(c, 5);
-    // update.vert in place: only the surfels a candidate merged into are touched (the reference copies the whole buffer, Model.cpp:583-646)
+    if (small) {
+        // small map (rounds 1-4's passes): update.vert as a copy src -> dst with the second index scatter (:556) riding on it, clean dst -> src:
+        // two swaps leave the live buffer where it was
+        launch_fuse_update_copy(m.surf[src], m.surf[dst], m.d_frame, c->d_upd_first, c->d_cand_rec, m.d_pose, W, H, c->K, g.max_depth_processed,
+                                g.time_delta, secondIndexPass ? c->d_keys : nullptr, true, s, blocks);
+        if (marks) mark(c, 6);
+        if (secondIndexPass) launch_index_resolve(m.surf[dst], m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, s);
+        launch_clean(m.surf[dst], m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.time_delta, m.confThr, g.outlier_coefficient, m.id,
+                     c->d_index, c->d_ivc, c->d_ict, secondIndexPass ? c->d_iclean : nullptr, depthF, mask, c->d_cand_op, c->d_cand_rec,
+                     c->d_flags, c->d_newconf, c->d_block_counts, c->d_scan_state, c->d_clean_ctl, next_clean_epoch(c), clean_blocks(c, m),
+                     c->ticket_lanes, m.h_count, secondIndexPass, c->clean_literal, true, s);
+        m.table_valid = false;
+        return;
+    }
+    // big map: update.vert in place -- only the surfels a candidate merged into are touched (the reference copies the whole buffer,
+    // Model.cpp:583-646) --, the second index pass over the runs in view, the one-launch clean src -> dst (which writes dst's run table)
     launch_fuse_update(m.surf[src], m.d_frame, c->d_upd_first, c->d_cand_op, c->d_cand_best, c->d_cand_rec, W, H, s);
     if (marks) mark(c, 6);
     if (secondIndexPass) {   // predictIndices on the updated buffer (:556), column-major packed texels for clean's window gathers
@@ -221,10 +236,10 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
     }
     launch_clean(m.surf[src], m.surf[dst], m.d_frame, m.d_pose, W, H, c->K, g.time_delta, m.confThr, g.outlier_coefficient, m.id,
                  c->d_index, c->d_ivc, c->d_ict, secondIndexPass ? c->d_iclean : nullptr, depthF, mask, c->d_cand_op, c->d_cand_rec,
-                 small ? c->d_flags : nullptr, small ? c->d_newconf : nullptr, c->d_block_counts,
-                 c->d_scan_state, c->d_clean_ctl, next_clean_epoch(c), clean_blocks(c, m), c->ticket_lanes, m.h_count, secondIndexPass, c->clean_literal, small, s);
+                 nullptr, nullptr, c->d_block_counts, c->d_scan_state, c->d_clean_ctl, next_clean_epoch(c), clean_blocks(c, m), c->ticket_lanes,
+                 m.h_count, secondIndexPass, c->clean_literal, false, s);
     m.cur = dst;   // one copying pass per frame (clean): the live buffer alternates
-    m.table_valid = !small;
+    m.table_valid = true;
 }
 
 // MaskFusion::predict for one model: combinedPredict(maxDepthProcessed, tick, tick, timeDelta) -- the fill-in half
@@ -450,7 +465,10 @@ static int enqueue_fusion_loop(mf_ctx* c, size_t first, bool multi, const uint8_
         ob.cleanSmall = 1;
         for (ModelState* m : objs) if (!clean_small(c, *m)) ob.cleanSmall = 0;
         launch_obj_fuse_clean(ob, blocks, cblocks, c->stream);
-        for (ModelState* m : objs) { m->cur = 1 - m->cur; m->table_valid = !ob.cleanSmall; }   // fuse in place, clean a -> b: b is the live buffer now
+        for (ModelState* m : objs) {   // big models: fuse in place, clean a -> b -- b is the live buffer now; small ones: a -> b -> a
+            if (!ob.cleanSmall) m->cur = 1 - m->cur;
+            m->table_valid = !ob.cleanSmall;
+        }
     }
     return MF_OK;
 }

@@ -251,6 +251,11 @@ void launch_fuse_data(const uint8_t* rgb, const float* depthRaw, const float* de
 // update.vert IN PLACE: one thread per candidate, the winning candidate of a surfel (upd_first) merges into it where it stands
 void launch_fuse_update(Surfels s, const FrameDev* frame, int* upd_first, const uint8_t* cand_op, const int* cand_best, const float4* cand_rec,
                         int W, int H, hipStream_t st);
+// the same as a copy src -> dst over the whole buffer; keys_or_null != nullptr: the index-map scatter of the pass that feeds clean rides on it
+// (the form for small maps)
+void launch_fuse_update_copy(Surfels src, Surfels dst, const FrameDev* frame, int* upd_first, const float4* cand_rec, const PoseDev* pose,
+                             int W, int H, Intr k, float maxDepth, int timeDelta, unsigned long long* keys_or_null, bool transposed,
+                             hipStream_t s, int blocks = kSurfelGridBlocks);
 // Model::clean in one launch (test + ordered compaction with a decoupled look-back, mf_surfel.hip).  flags / newconf: optional taps (nullptr
 // inside a frame); scan_state: clean_scan_entries(capacity + P) words, never reset (epoch must differ from launch to launch and be > 0);
 // ctl: kCleanCtlInts ints, zero between launches; blocks: clean_grid(elements expected)
@@ -295,7 +300,8 @@ int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W,
 // round 2's profile).  The batched kernels are the single-model kernels' bodies called with one model's arguments, picked from a device
 // array by blockIdx.z; every model brings its own scratch (index maps, key image, candidate records, ...), which the single-model path shares.
 struct ObjPassArgs {
-    Surfels a, b;                      // live buffer when the frame's fusion starts / the other one (fuse: in place in a; clean: a -> b, then b is live)
+    Surfels a, b;                      // live buffer when the frame's fusion starts / the other one (big models: fuse in place in a, clean a -> b, then b is
+                                       // live; small ones: fuse a -> b, clean b -> a)
     FrameDev* frame; PoseDev* pose;
     int maskID; float confThreshold, fuseMaxDepth, weightMultiplier;
     unsigned long long* keys; int* index; float4* ivc; float4* inr; float4* iclean;

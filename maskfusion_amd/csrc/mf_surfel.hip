@@ -529,19 +529,8 @@ void launch_fuse_data(const uint8_t* rgb, const float* depthRaw, const float* de
 // the atomicMin of the association pass) and re-arms the surfel's merge slot; no surfel reads another, so the values are the ones the
 // copying form wrote (rounds 1-4: an N-sized pass of 100 B per surfel with the second index scatter riding on it).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fuse_update_body(Surfels s, const FrameDev* __restrict__ frame, int* __restrict__ upd_first,
-                                                 const uint8_t* __restrict__ cand_op, const int* __restrict__ cand_best,
-                                                 const float4* __restrict__ cand_rec, int W, int H) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cand_count(W, H, frame->tick)) return;
-    if (cand_op[c] != 1) return;
-    const int i = cand_best[c];
-    if (i < 0 || i >= frame->count) return;
-    if (upd_first[i] != c) return;          // an earlier candidate owns this surfel's merge
-    upd_first[i] = kNoUpdate;
-    const float time = (float)frame->tick;
-    float4 pc = s.pc[i], ct = s.ct[i], nr = s.nr[i];
-    const float4 mp = cand_rec[c * 3 + 0], mc = cand_rec[c * 3 + 1], mn = cand_rec[c * 3 + 2];
+// update.vert:40-96 for one surfel and the candidate merged into it (records in registers)
+__device__ __forceinline__ void surfel_merge(float4& pc, float4& ct, float4& nr, float4 mp, float4 mc, float4 mn, float time) {
     const float c_k = pc.w, a = mp.w;
     if (mn.w < (1.0f + 0.5f) * nr.w) {
         pc = make_float4(((c_k * pc.x) + (a * mp.x)) / (c_k + a), ((c_k * pc.y) + (a * mp.y)) / (c_k + a),
@@ -554,12 +543,72 @@ __device__ __forceinline__ void fuse_update_body(Surfels s, const FrameDev* __re
                                       ((c_k * nr.z) + (a * mn.z)) / (c_k + a), ((c_k * nr.w) + (a * mn.w)) / (c_k + a));
         const float3 nn = normalize_gl(f3(av.x, av.y, av.z));
         nr = make_float4(nn.x, nn.y, nn.z, av.w);
-        s.pc[i] = pc; s.ct[i] = ct; s.nr[i] = nr;
     } else {
         pc.w = c_k + a;
         ct.w = time;
-        s.pc[i] = pc; s.ct[i] = ct;
     }
+}
+
+__device__ __forceinline__ void fuse_update_body(Surfels s, const FrameDev* __restrict__ frame, int* __restrict__ upd_first,
+                                                 const uint8_t* __restrict__ cand_op, const int* __restrict__ cand_best,
+                                                 const float4* __restrict__ cand_rec, int W, int H) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cand_count(W, H, frame->tick)) return;
+    if (cand_op[c] != 1) return;
+    const int i = cand_best[c];
+    if (i < 0 || i >= frame->count) return;
+    if (upd_first[i] != c) return;          // an earlier candidate owns this surfel's merge
+    upd_first[i] = kNoUpdate;
+    float4 pc = s.pc[i], ct = s.ct[i], nr = s.nr[i];
+    surfel_merge(pc, ct, nr, cand_rec[c * 3 + 0], cand_rec[c * 3 + 1], cand_rec[c * 3 + 2], (float)frame->tick);
+    s.pc[i] = pc; s.ct[i] = ct; s.nr[i] = nr;
+}
+
+// The same as a COPY src -> dst over the whole buffer with the second index scatter (predictIndices after fuse, MaskFusion.cpp:556) riding on
+// the values just written (rounds 1-4): the form for SMALL maps, where one 12 us pass beats an in-place update + a scatter launch of its own
+// (8 + 10 us at VGA) and the whole frame is a chain of such launches; on a 26.9 M-surfel map the copy is 100 B per surfel, 0.56 ms.
+struct IndexScatterArgs { const PoseDev* pose; int W, H; Intr k; float maxDepth; int timeDelta; unsigned long long* keys; int transposed; };
+__device__ __forceinline__ void fuse_update_copy_body(Surfels src, Surfels dst, const FrameDev* __restrict__ frame, int* __restrict__ upd_first,
+                                                      const float4* __restrict__ cand_rec, const IndexScatterArgs& ix) {
+    const int n = frame->count;
+    const float time = (float)frame->tick;
+    float Ri[9];
+    float3 ti = f3(0, 0, 0);
+    if (ix.keys) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) Ri[q] = ix.pose->Ri[q];
+        ti = f3(ix.pose->ti[0], ix.pose->ti[1], ix.pose->ti[2]);
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float4 pc = src.pc[i], ct = src.ct[i], nr = src.nr[i];
+        const int m = upd_first[i];
+        if (m != kNoUpdate) {
+            upd_first[i] = kNoUpdate;
+            surfel_merge(pc, ct, nr, cand_rec[m * 3 + 0], cand_rec[m * 3 + 1], cand_rec[m * 3 + 2], time);
+        }
+        dst.pc[i] = pc; dst.ct[i] = ct; dst.nr[i] = nr;
+        if (ix.keys) {   // k_index_scatter on the updated surfel (index_map.vert:40-60)
+            const float3 h = mul33(Ri, f3(pc.x, pc.y, pc.z)) + ti;
+            if (!(h.z > ix.maxDepth || h.z <= 0 || time - ct.w > (float)ix.timeDelta)) {
+                const float u = ((ix.k.fx * h.x) / h.z) + ix.k.cx;
+                const float v = ((ix.k.fy * h.y) / h.z) + ix.k.cy;
+                if (u >= 0.f && u < (float)ix.W && v >= 0.f && v < (float)ix.H) {
+                    const int p = ix.transposed ? (int)floorf(u) * ix.H + (int)floorf(v) : (int)floorf(v) * ix.W + (int)floorf(u);
+                    zmin_key(&ix.keys[p], ((unsigned long long)__float_as_uint(h.z) << 32) | (unsigned)i);
+                }
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_fuse_update_copy(Surfels src, Surfels dst, const FrameDev* __restrict__ frame, int* __restrict__ upd_first,
+                                                          const float4* __restrict__ cand_rec, const IndexScatterArgs ix) {
+    fuse_update_copy_body(src, dst, frame, upd_first, cand_rec, ix);
+}
+void launch_fuse_update_copy(Surfels src, Surfels dst, const FrameDev* frame, int* upd_first, const float4* cand_rec, const PoseDev* pose,
+                             int W, int H, Intr k, float maxDepth, int timeDelta, unsigned long long* keys_or_null, bool transposed,
+                             hipStream_t s, int blocks) {
+    IndexScatterArgs ix{pose, W, H, k, maxDepth, timeDelta, keys_or_null, transposed ? 1 : 0};
+    hipLaunchKernelGGL(k_fuse_update_copy, dim3(blocks), dim3(256), 0, s, src, dst, frame, upd_first, cand_rec, ix);
 }
 
 __global__ __launch_bounds__(256) void k_fuse_update(Surfels s, const FrameDev* __restrict__ frame, int* __restrict__ upd_first,
@@ -1294,7 +1343,7 @@ __global__ __launch_bounds__(256) void k_obj_index_scatter(const ObjBatch b) {
 __global__ __launch_bounds__(256) void k_obj_index_resolve(const ObjBatch b, int second) {
     const ObjPassArgs& m = b.m[blockIdx.z];
     if (!second) index_resolve_body(m.a, m.pose, m.keys, b.W * b.H, m.index, m.ivc, m.inr, nullptr, nullptr);
-    else index_resolve_body(m.a, m.pose, m.keys, b.W * b.H, nullptr, nullptr, nullptr, nullptr, m.iclean);
+    else index_resolve_body(b.cleanSmall ? m.b : m.a, m.pose, m.keys, b.W * b.H, nullptr, nullptr, nullptr, nullptr, m.iclean);
 }
 __global__ __launch_bounds__(256) void k_obj_fuse_data(const ObjBatch b) {
     const ObjPassArgs& m = b.m[blockIdx.z];
@@ -1306,13 +1355,20 @@ __global__ __launch_bounds__(256) void k_obj_fuse_update(const ObjBatch b) {
     const ObjPassArgs& m = b.m[blockIdx.z];
     fuse_update_body(m.a, m.frame, m.upd_first, m.cand_op, m.cand_best, m.cand_rec, b.W, b.H);
 }
+__global__ __launch_bounds__(256) void k_obj_fuse_update_copy(const ObjBatch b) {   // small models: a -> b with the second index scatter riding
+    const ObjPassArgs& m = b.m[blockIdx.z];
+    const IndexScatterArgs ix{m.pose, b.W, b.H, b.k, b.maxDepthProcessed, b.timeDelta, m.keys, 1};
+    fuse_update_copy_body(m.a, m.b, m.frame, m.upd_first, m.cand_rec, ix);
+}
 __global__ __launch_bounds__(256) void k_obj_index_scatter2(const ObjBatch b) {   // predictIndices after fuse (MaskFusion.cpp:556), column-major texels
     const ObjPassArgs& m = b.m[blockIdx.z];
     index_scatter_body(m.a, m.frame, m.pose, b.W, b.H, b.k, b.maxDepthProcessed, b.timeDelta, m.keys, 1, nullptr, nullptr, true);
 }
 __device__ __forceinline__ CleanArgs obj_clean_args(const ObjBatch& b, const ObjPassArgs& m) {
     CleanArgs a;
-    a.src = m.a; a.dst = m.b; a.frame = m.frame; a.pose = m.pose; a.W = b.W; a.H = b.H; a.k = b.k; a.timeDelta = b.timeDelta;
+    // small models: fuse copied a -> b, clean goes b -> a (the live buffer stays); big ones: fuse ran in place, clean goes a -> b
+    a.src = b.cleanSmall ? m.b : m.a; a.dst = b.cleanSmall ? m.a : m.b;
+    a.frame = m.frame; a.pose = m.pose; a.W = b.W; a.H = b.H; a.k = b.k; a.timeDelta = b.timeDelta;
     a.confThreshold = m.confThreshold; a.outlierCoeff = b.outlierCoeff; a.maskID = m.maskID; a.transposed = 1; a.literal = b.cleanLiteral;
     a.index = m.index; a.vc = m.ivc; a.ct = nullptr; a.packed = m.iclean; a.depthF = b.depthF; a.mask = b.mask;
     a.cand_op = m.cand_op; a.cand_rec = m.cand_rec; a.flags = b.cleanSmall ? m.flags : nullptr; a.newconf = b.cleanSmall ? m.newconf : nullptr;
@@ -1343,8 +1399,12 @@ void launch_obj_fuse_clean(const ObjBatch& b, int blocks, int clean_blocks, hipS
     hipLaunchKernelGGL(k_obj_index_scatter, surfels, dim3(256), 0, s, b);
     hipLaunchKernelGGL(k_obj_index_resolve, pixels, dim3(256), 0, s, b, 0);
     hipLaunchKernelGGL(k_obj_fuse_data, cands, dim3(256), 0, s, b);
-    hipLaunchKernelGGL(k_obj_fuse_update, dim3(cand_blocks(b.W, b.H), 1, b.n), dim3(256), 0, s, b);
-    hipLaunchKernelGGL(k_obj_index_scatter2, surfels, dim3(256), 0, s, b);
+    if (b.cleanSmall) {
+        hipLaunchKernelGGL(k_obj_fuse_update_copy, surfels, dim3(256), 0, s, b);
+    } else {
+        hipLaunchKernelGGL(k_obj_fuse_update, dim3(cand_blocks(b.W, b.H), 1, b.n), dim3(256), 0, s, b);
+        hipLaunchKernelGGL(k_obj_index_scatter2, surfels, dim3(256), 0, s, b);
+    }
     hipLaunchKernelGGL(k_obj_index_resolve, pixels, dim3(256), 0, s, b, 1);
     if (b.cleanSmall) {
         hipLaunchKernelGGL(k_obj_clean_small_flags, dim3(kCompactBlocks, 1, b.n), dim3(256), 0, s, b);
