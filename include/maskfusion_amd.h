@@ -172,6 +172,11 @@ int mf_get_last_fillin(mf_ctx* ctx, int32_t* used);
  * surfel kernels of an object model run on a grid sized from its last known surfel count instead of 2048 workgroups), "objectScatterSplat" (1;
  * 1: object models are predicted with the scatter form of the splat instead of tile lists) -- both leave every result bit-identical; measured on
  * MI355X on the 12-model S2 scene: 394 -> 407 frames/s with both (profiles/r03a_bench_2s_object_switches.txt), on since round 3;
+ * "bigMapElements" (6 000 000: from this many surfels on Model::clean is one launch and the projection passes visit only the runs of the buffer
+ * that can be in view (k_cull) -- below, the two-launch clean and whole-buffer passes of rounds 1-4), "inPlaceElements" (1 000 000: from this
+ * many surfels on update.vert runs in place -- below, as rounds 1-4's copy with the second index scatter riding on it); which form a model's
+ * passes take depends on its size alone and changes no result (tests/test_gpu_switches.py::test_clean_forms_agree), "cullRuns" (1; 0: big maps stream the whole buffer through every
+ * projection pass -- the executable specification of the culled form),
  * "literalFusionWeight" (1: Model::computeFusionWeight's log map takes cos(theta) from the float trace of a float matrix as the reference's
  * text does -- its rotation term is then quantised in steps of ~4.9e-4 rad; 0: the same formula evaluated accurately in double.  See
  * DESIGN.md, finding F5; default 1 since round 3), "frameToFrameRGB" (0; MaskFusion::setFrameToFrameRGB, "-ftf": the photometric term tracks
@@ -187,7 +192,7 @@ int mf_get_param(mf_ctx* ctx, const char* key, double* value);
  *         9 icpIterations: first to last Gauss-Newton iteration launch of the background model (what bench.py divides by
  *           the iteration count for its roofline line);
  *         10 icpCoarse / 11 icpFine: the same interval split right before the first level-0 iteration (launch-per-iteration loop of a
- *           single model; 0 for the batched / captured forms);
+ *           single model; 0 for the batched form);
  *         multi-model frames only (0 otherwise) -- what lies between the end of tracking and Fuse::Copy's end (labels 3..6 cover the
  *         BACKGROUND's passes there; Core/MaskFusion.cpp:287-375,539-565):
  *         12 mmGlobalProjection (GlobalProjection::project of every model + id resolve), 13 mmEdgeLabels (geometric edge map, binary

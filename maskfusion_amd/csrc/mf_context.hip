@@ -231,10 +231,14 @@ struct mf_ctx {
     // visibility list of the projection passes (Surfels::box, k_cull): the runs of ONE buffer that can be in view under ONE pose; vis_tag says whose
     int* d_vis_list = nullptr; int* d_vis_count = nullptr; int* d_cull_ctl = nullptr; int vis_max_runs = 0;
     struct { const void* model = nullptr; long frame = -1; int cur = -1; } vis_tag;
+    int ticket_stride = 32; bool clean_held = false;   // EXPERIMENT (round 5): "cleanTicketStride" (ints), "cleanHeld"
     int ticket_lanes = 1;                  // ticket counters of the clean pass: min(kCleanTicketLanes, compute units of the device)
     bool cull_runs = true;                 // "cullRuns": 0 = every projection pass streams the whole buffer (A/B switch, executable specification)
     int big_map_elements = 6000000;        // "bigMapElements": from this many surfels on a model's clean pass is the one-launch form (which writes the run
                                            // table) and its projection passes cull by run; below, the two-launch form and whole-buffer passes
+    int in_place_elements = 1000000;       // "inPlaceElements": from this many surfels on update.vert runs in place and the second index scatter is a
+                                           // launch of its own (~18 us per million surfels + ~10 us); below, the copying update with the scatter
+                                           // riding on it (~30 us per million).  Only with the two-launch clean (<= big_map_elements)
     unsigned long long* d_icp_prof = nullptr;
     unsigned long long* d_splat_prof = nullptr; bool splat_prof_on = false;   // "splatProfile": [tiles][8] stamps of the background's tile pass
     // multi-model coupling
@@ -1016,6 +1020,10 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!strcmp(key, "globalTiles")) { c->global_tiles = value != 0; return MF_OK; }
     if (!strcmp(key, "cullRuns")) { c->cull_runs = value != 0; c->vis_tag.model = nullptr; return MF_OK; }
     if (!strcmp(key, "bigMapElements")) { c->big_map_elements = (int)value; c->vis_tag.model = nullptr; return MF_OK; }
+    if (!strcmp(key, "cleanHeld")) { c->clean_held = value != 0; return MF_OK; }
+    if (!strcmp(key, "cleanTicketStride")) { c->ticket_stride = std::max(1, std::min((int)value, kTicketStrideMax)); return MF_OK; }
+    if (!strcmp(key, "cleanTicketLanes")) { c->ticket_lanes = std::max(1, std::min((int)value, kCleanTicketLanes)); return MF_OK; }
+    if (!strcmp(key, "inPlaceElements")) { c->in_place_elements = (int)value; return MF_OK; }
     if (!strcmp(key, "rebuildRunTable")) {   // tooling: the background's run table from scratch (what an upload / Model::initialise does)
         launch_run_table(c->models[0]->surf[c->models[0]->cur], c->models[0]->d_frame, c->stream);
         c->vis_tag.model = nullptr;
@@ -1026,6 +1034,19 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!strcmp(key, "modelApiPackedIndex")) { c->model_api_packed = value != 0; return MF_OK; }   // 0: scatter + resolve form (specification)
     if (!strcmp(key, "tileThreads")) { c->splat_tune.tile_threads = (int)value; return MF_OK; }   // A/B: threads per tile workgroup of the tile passes
     if (!strcmp(key, "spriteLanes")) { c->splat_tune.sprite_lanes = (int)value; return MF_OK; }   // A/B: lanes per sprite in the tile z-test (default 4)
+    if (!strcmp(key, "preCUs")) {   // EXPERIMENT (round 5): the preprocessing stream restricted to `value` compute units (CU-mask bits are dealt round-robin to the XCDs)
+        (void)hipStreamSynchronize(c->stream_pre);
+        (void)hipStreamSynchronize(c->stream);
+        hipStream_t masked = nullptr;
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int n = std::max(8, std::min((int)value, 256));
+        for (int i = 0; i < n; ++i) mask[i >> 5] |= 1u << (i & 31);
+        const hipError_t e = value > 0 ? hipExtStreamCreateWithCUMask(&masked, 8, mask) : hipStreamCreateWithFlags(&masked, hipStreamNonBlocking);
+        if (e != hipSuccess) { c->err = std::string("preCUs: ") + hipGetErrorString(e); return MF_EINVAL; }
+        (void)hipStreamDestroy(c->stream_pre);
+        c->stream_pre = masked;
+        return MF_OK;
+    }
     if (!strcmp(key, "overlapPreprocessing")) {
         (void)hipStreamSynchronize(c->stream_pre);
         (void)hipStreamSynchronize(c->stream);

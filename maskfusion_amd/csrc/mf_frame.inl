@@ -188,6 +188,10 @@ static int clean_blocks(const mf_ctx* c, const ModelState& m) {
 }
 // which clean form model m gets this frame (launch_clean): the two-launch form below "bigMapElements"
 static bool clean_small(const mf_ctx* c, const ModelState& m) { return (long)*m.h_count + (long)c->P / 4 < (long)c->big_map_elements; }
+// which update form: the copying one (second index scatter riding on it) below "inPlaceElements"; it pairs with the two-launch clean only
+static bool update_copy(const mf_ctx* c, const ModelState& m) {
+    return clean_small(c, m) && (long)*m.h_count + (long)c->P / 4 < (long)c->in_place_elements;
+}
 static unsigned next_clean_epoch(mf_ctx* c) {
     c->clean_epoch = (c->clean_epoch + 1u) & 0x3FFFFFFFu;
     if (c->clean_epoch == 0) c->clean_epoch = 1;
@@ -201,7 +205,7 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
     hipStream_t s = c->stream;
     const int src = m.cur, dst = 1 - m.cur;
     const int blocks = surfel_blocks(c, m);
-    const bool small = clean_small(c, m);
+    const bool small = clean_small(c, m), copy = update_copy(c, m);
     VisList vl;
     const VisList* vis = ensure_vis(c, m, vl);
     launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, false, s, blocks, vis);
@@ -212,34 +216,35 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
     launch_fuse_data(d_rgb, d_depth, depthF, mask, m.id, m.d_frame, m.d_pose, weightMultiplier, fminf(fuseDepthCutoff, m.maxDepth), W, H,
                      c->K, c->d_index, c->d_ivc, c->d_inr, c->d_cand_op, c->d_cand_rec, c->d_upd_first, c->d_cand_best, s, c->bbox_limit ? 1 : 0);
     if (marks) mark(c, 5);
-    if (small) {
-        // small map (rounds 1-4's passes): update.vert as a copy src -> dst with the second index scatter (:556) riding on it, clean dst -> src:
-        // two swaps leave the live buffer where it was
+    // Which forms a model's passes take is a matter of its size alone (mf_context.hip: in_place_elements / big_map_elements); the results are the same.
+    int live = src;      // the buffer that holds the updated surfels
+    if (copy) {
+        // small map (rounds 1-4's pass): update.vert as a copy src -> dst with the second index scatter (:556) riding on it; clean goes
+        // dst -> src: two swaps leave the live buffer where it was
         launch_fuse_update_copy(m.surf[src], m.surf[dst], m.d_frame, c->d_upd_first, c->d_cand_rec, m.d_pose, W, H, c->K, g.max_depth_processed,
                                 g.time_delta, secondIndexPass ? c->d_keys : nullptr, true, s, blocks);
+        live = dst;
         if (marks) mark(c, 6);
-        if (secondIndexPass) launch_index_resolve(m.surf[dst], m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, s);
-        launch_clean(m.surf[dst], m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.time_delta, m.confThr, g.outlier_coefficient, m.id,
-                     c->d_index, c->d_ivc, c->d_ict, secondIndexPass ? c->d_iclean : nullptr, depthF, mask, c->d_cand_op, c->d_cand_rec,
-                     c->d_flags, c->d_newconf, c->d_block_counts, c->d_scan_state, c->d_clean_ctl, next_clean_epoch(c), clean_blocks(c, m),
-                     c->ticket_lanes, m.h_count, secondIndexPass, c->clean_literal, true, s);
-        m.table_valid = false;
-        return;
+        if (secondIndexPass) launch_index_resolve(m.surf[live], m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, s);
+    } else {
+        // update.vert in place -- only the surfels a candidate merged into are touched (the reference copies the whole buffer,
+        // Model.cpp:583-646) --, then the second index pass (over the runs in view where the buffer has a run table)
+        launch_fuse_update(m.surf[src], m.d_frame, c->d_upd_first, c->d_cand_op, c->d_cand_best, c->d_cand_rec, W, H, s);
+        if (marks) mark(c, 6);
+        if (secondIndexPass) {   // predictIndices on the updated buffer (:556), column-major packed texels for clean's window gathers
+            launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, true, s, blocks, vis);
+            launch_index_resolve(m.surf[src], m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, s);
+        }
     }
-    // big map: update.vert in place -- only the surfels a candidate merged into are touched (the reference copies the whole buffer,
-    // Model.cpp:583-646) --, the second index pass over the runs in view, the one-launch clean src -> dst (which writes dst's run table)
-    launch_fuse_update(m.surf[src], m.d_frame, c->d_upd_first, c->d_cand_op, c->d_cand_best, c->d_cand_rec, W, H, s);
-    if (marks) mark(c, 6);
-    if (secondIndexPass) {   // predictIndices on the updated buffer (:556), column-major packed texels for clean's window gathers
-        launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, true, s, blocks, vis);
-        launch_index_resolve(m.surf[src], m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, s);
-    }
-    launch_clean(m.surf[src], m.surf[dst], m.d_frame, m.d_pose, W, H, c->K, g.time_delta, m.confThr, g.outlier_coefficient, m.id,
+    // clean live -> the other buffer: two launches (flags + ordered copy) below big_map_elements, one launch (which also writes the new
+    // buffer's run table) from there on
+    launch_clean(m.surf[live], m.surf[1 - live], m.d_frame, m.d_pose, W, H, c->K, g.time_delta, m.confThr, g.outlier_coefficient, m.id,
                  c->d_index, c->d_ivc, c->d_ict, secondIndexPass ? c->d_iclean : nullptr, depthF, mask, c->d_cand_op, c->d_cand_rec,
-                 nullptr, nullptr, c->d_block_counts, c->d_scan_state, c->d_clean_ctl, next_clean_epoch(c), clean_blocks(c, m), c->ticket_lanes,
-                 m.h_count, secondIndexPass, c->clean_literal, false, s);
-    m.cur = dst;   // one copying pass per frame (clean): the live buffer alternates
-    m.table_valid = true;
+                 small ? c->d_flags : nullptr, small ? c->d_newconf : nullptr, c->d_block_counts, c->d_scan_state, c->d_clean_ctl,
+                 next_clean_epoch(c), clean_blocks(c, m), c->ticket_lanes, m.h_count, secondIndexPass, c->clean_literal, small, s, c->ticket_stride,
+                 c->clean_held);
+    m.cur = 1 - live;
+    m.table_valid = !small;
 }
 
 // MaskFusion::predict for one model: combinedPredict(maxDepthProcessed, tick, tick, timeDelta) -- the fill-in half
@@ -298,7 +303,7 @@ static int make_obj_batch(mf_ctx* c, const std::vector<ModelState*>& ms, const s
     MF_HIP(c, hipEventRecord(c->ev_obj_args[slot], c->stream));
     b.m = c->d_obj_args[slot]; b.n = (int)ms.size();
     b.W = c->W; b.H = c->H; b.k = c->K; b.maxDepthProcessed = g.max_depth_processed; b.globalMaxDepth = g.depth_cutoff; b.timeDelta = g.time_delta;
-    b.outlierCoeff = g.outlier_coefficient; b.cleanLiteral = c->clean_literal ? 1 : 0; b.bboxLimit = c->bbox_limit ? 1 : 0; b.cleanEpoch = 0; b.cleanTicketLanes = 1; b.cleanSmall = 0;
+    b.outlierCoeff = g.outlier_coefficient; b.cleanLiteral = c->clean_literal ? 1 : 0; b.bboxLimit = c->bbox_limit ? 1 : 0; b.cleanEpoch = 0; b.cleanTicketLanes = 1; b.cleanTicketStride = c->ticket_stride; b.cleanSmall = 0; b.updateCopy = 0;
     b.rgb = d_rgb; b.depthRaw = d_depth; b.depthF = depthF; b.mask = mask; b.bg_pose = c->models[0]->d_pose; b.global_keys = c->d_keys;
     return MF_OK;
 }
@@ -462,11 +467,14 @@ static int enqueue_fusion_loop(mf_ctx* c, size_t first, bool multi, const uint8_
         ob.cleanTicketLanes = 1;
         for (ModelState* m : objs) cblocks = std::max(cblocks, clean_blocks(c, *m));
         ob.cleanTicketLanes = std::min(c->ticket_lanes, cblocks);
-        ob.cleanSmall = 1;
-        for (ModelState* m : objs) if (!clean_small(c, *m)) ob.cleanSmall = 0;
+        ob.cleanSmall = 1; ob.updateCopy = 1;    // one form per launch: the batch takes the form of its largest model
+        for (ModelState* m : objs) {
+            if (!clean_small(c, *m)) ob.cleanSmall = 0;
+            if (!update_copy(c, *m)) ob.updateCopy = 0;
+        }
         launch_obj_fuse_clean(ob, blocks, cblocks, c->stream);
-        for (ModelState* m : objs) {   // big models: fuse in place, clean a -> b -- b is the live buffer now; small ones: a -> b -> a
-            if (!ob.cleanSmall) m->cur = 1 - m->cur;
+        for (ModelState* m : objs) {   // copy-update: a -> b -> a; in place: clean went a -> b -- b is the live buffer now
+            if (!ob.updateCopy) m->cur = 1 - m->cur;
             m->table_valid = !ob.cleanSmall;
         }
     }

@@ -201,7 +201,7 @@ extern "C" int mf_model_clean(mf_ctx* c, int32_t model, int32_t time, int32_t ti
     launch_clean(m->surf[src], m->surf[dst], m->d_frame, m->d_pose, c->W, c->H, c->K, time_delta, m->confThr, c->cfg.outlier_coefficient, m->id,
                  c->d_index, c->d_ivc, c->d_ict, packed ? c->d_iclean : nullptr, c->d_depthF[k % 3], current_mask(c), c->d_cand_op, c->d_cand_rec,
                  c->d_flags, c->d_newconf, c->d_block_counts, c->d_scan_state, c->d_clean_ctl, next_clean_epoch(c), clean_blocks(c, *m), c->ticket_lanes, m->h_count,
-                 packed, c->clean_literal, small, c->stream);
+                 packed, c->clean_literal, small, c->stream, c->ticket_stride, c->clean_held);
     m->cur = dst;
     m->table_valid = !small;
     return check_launch(c);

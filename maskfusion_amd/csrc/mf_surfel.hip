@@ -643,6 +643,7 @@ struct CleanArgs {
     int* ctl;                          // kCleanCtlInts ints, zero between launches: finished workgroups + the ticket counters (clean_body)
     unsigned epoch;                    // distinguishes this launch's entries of scan_state from older ones (never reset)
     int ticket_lanes;                  // counters the chunks are drawn from (1 .. kCleanTicketLanes, <= compute units and <= workgroups launched)
+    int ticket_stride;                 // ints between two ticket counters (<= kTicketStrideMax)
 };
 
 // The window of copy_unstable.vert:85-86 along one axis, exactly as the shader text walks it: `for (i = c - 2s; i < c + 2s; i += s)` on an
@@ -906,7 +907,7 @@ constexpr int kSlicesPerRun = kRun / 256;
 static_assert(kCleanChunk % kRun == 0 && kRun % 256 == 0, "runs are whole slices of a chunk");
 constexpr int kLookPerLane = 4;   // states of earlier chunks a lane reads per look-back step: 256 per step and wavefront
 constexpr unsigned kScanAggregate = 1u, kScanInclusive = 2u;
-constexpr int kTicketStride = 32, kTicketBase = 32;   // ctl: [2..3] finished workgroups << 32 | survivors (64 bit), [kTicketBase + g kTicketStride] ticket counter of lane g (128 B apart)
+constexpr int kTicketBase = 32;   // ctl: [2..3] finished workgroups << 32 | survivors (64 bit), [kTicketBase + g kTicketStride] ticket counter of lane g (128 B apart)
 
 __device__ __forceinline__ unsigned long long scan_load(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -990,7 +991,7 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
     const int tlane = (int)(blockIdx.x % lanes);
     int wg_kept = 0;          // survivors of the chunks this workgroup handled (thread 0's copy is the one that counts)
     for (;;) {
-        if (threadIdx.x == 0) s_chunk = tlane + lanes * atomicAdd(&a.ctl[kTicketBase + tlane * kTicketStride], 1);
+        if (threadIdx.x == 0) s_chunk = tlane + lanes * atomicAdd(&a.ctl[kTicketBase + tlane * a.ticket_stride], 1);
         __syncthreads();
         const int chunk = s_chunk;
         if (chunk >= nchunks) break;
@@ -1116,7 +1117,7 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
                     __hip_atomic_store(&a.frame->bbox_tmp[q], q < 3 ? kBBoxEmptyMin : kBBoxEmptyMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            for (int g = 0; g < kCleanTicketLanes; ++g) __hip_atomic_store(&a.ctl[kTicketBase + g * kTicketStride], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int g = 0; g < kCleanTicketLanes; ++g) __hip_atomic_store(&a.ctl[kTicketBase + g * a.ticket_stride], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(done64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -1124,14 +1125,172 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
 
 __global__ __launch_bounds__(256) void k_clean(const CleanArgs a) { clean_body(a); }
 
+// ------------------------------------------------------------------------------------------------
+// EXPERIMENT (round 5): the one-launch clean with the chunk's records HELD in registers between test and copy (each record is read once:
+// 96 B per surfel instead of 144), chunks of 1024, the next ticket drawn while the current chunk is worked on.
+// ------------------------------------------------------------------------------------------------
+constexpr int kHeldPerThread = 4;
+constexpr int kHeldChunk = 256 * kHeldPerThread;
+constexpr int kHeldSubRuns = kHeldChunk / kRun;
+static_assert(kHeldChunk % kRun == 0, "runs are whole slices of a chunk");
+
+__device__ __forceinline__ void clean_held_body(const CleanArgs& a) {
+    __shared__ int s_chunk[2], s_base;
+    __shared__ int s_cnt[kHeldPerThread][4];
+    __shared__ int s_bb[6];
+    __shared__ int s_red[kHeldSubRuns][4][8];
+    const bool bbox_on = a.maskID != 0;
+    int bmin[3] = {kBBoxEmptyMin, kBBoxEmptyMin, kBBoxEmptyMin}, bmax[3] = {kBBoxEmptyMax, kBBoxEmptyMax, kBBoxEmptyMax};
+    if (bbox_on && threadIdx.x < 6) s_bb[threadIdx.x] = threadIdx.x < 3 ? kBBoxEmptyMin : kBBoxEmptyMax;
+    const int count = a.frame->count;
+    const int total = count + cand_count(a.W, a.H, a.frame->tick);
+    const int nchunks = (total + kHeldChunk - 1) / kHeldChunk;
+    const float time = (float)a.frame->tick;
+    float Ri[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) Ri[q] = a.pose->Ri[q];
+    const float3 ti = f3(a.pose->ti[0], a.pose->ti[1], a.pose->ti[2]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lanes = a.ticket_lanes;
+    const int tlane = (int)(blockIdx.x % lanes);
+    int* const ticket = &a.ctl[kTicketBase + tlane * a.ticket_stride];
+    int wg_kept = 0;
+    int next = 0;
+    if (threadIdx.x == 0) next = tlane + lanes * atomicAdd(ticket, 1);
+    for (int round = 0;; ++round) {
+        if (threadIdx.x == 0) s_chunk[round & 1] = next;
+        __syncthreads();
+        const int chunk = s_chunk[round & 1];
+        if (chunk >= nchunks) break;
+        // the ticket of the NEXT round is requested now: its round trip (device-scope atomic) is hidden behind this chunk's work.  (A workgroup
+        // holds at most one chunk beyond the one it works on; the lowest unfinished chunk is always somebody's current one or not yet drawn.)
+        if (threadIdx.x == 0) next = tlane + lanes * atomicAdd(ticket, 1);
+        const int first = chunk * kHeldChunk + (int)threadIdx.x;
+        float4 pc[kHeldPerThread], ct[kHeldPerThread], nr[kHeldPerThread];
+        bool live[kHeldPerThread];
+#pragma unroll
+        for (int j = 0; j < kHeldPerThread; ++j) {
+            const int i = first + 256 * j;
+            live[j] = i < total;
+            pc[j] = ct[j] = nr[j] = make_float4(0, 0, 0, 0);
+            if (i < count) { pc[j] = a.src.pc[i]; ct[j] = a.src.ct[i]; nr[j] = a.src.nr[i]; }
+            else if (live[j]) {
+                const int c = i - count;
+                live[j] = a.cand_op[c] == 2;
+                if (live[j]) { pc[j] = a.cand_rec[c * 3 + 0]; ct[j] = a.cand_rec[c * 3 + 1]; nr[j] = a.cand_rec[c * 3 + 2]; }
+            }
+        }
+        unsigned keepmask = 0u;
+#pragma unroll
+        for (int sr = 0; sr < kHeldSubRuns; ++sr) {
+            int rlo[3] = {kBoxEmptyMin, kBoxEmptyMin, kBoxEmptyMin}, rhi[3] = {kBoxEmptyMax, kBoxEmptyMax, kBoxEmptyMax}, rtime = kBoxEmptyMax;
+#pragma unroll
+            for (int q = 0; q < kSlicesPerRun; ++q) {
+                const int j = sr * kSlicesPerRun + q;
+                float nc = 0.f;
+                int dk = 0;
+                const bool keep = live[j] && clean_test(a, pc[j], ct[j], nr[j], time, Ri, ti, nc, dk);
+                if (a.flags) {
+                    const int i = first + 256 * j;
+                    if (i < total) { a.flags[i] = keep ? 1 : 0; a.newconf[i] = live[j] ? nc : 0.f; }
+                }
+                pc[j].w = nc;                                // the record as it is written: decayed confidence (copy_unstable.vert:139-156),
+                if (ct[j].w == -2.f) ct[j].w = time;         // -2 becomes the time (:131)
+                keepmask |= (keep ? 1u : 0u) << j;
+                if (keep) run_box_accumulate(pc[j], ct[j].w, rlo, rhi, rtime);
+                const unsigned long long m = __ballot(keep);
+                if (lane == 0) s_cnt[j][wave] = __popcll(m);
+            }
+            run_box_reduce(rlo, rhi, rtime, s_red[sr]);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            int tot = 0;
+#pragma unroll
+            for (int j = 0; j < kHeldPerThread; ++j) tot += s_cnt[j][0] + s_cnt[j][1] + s_cnt[j][2] + s_cnt[j][3];
+            const unsigned long long tag = (unsigned long long)a.epoch << 34;
+            int excl = 0, gave_up = 0;
+            if (chunk > 0) {
+                if (lane == 0) scan_store(&a.scan_state[chunk], tag | ((unsigned long long)kScanAggregate << 32) | (unsigned)tot);
+                excl = scan_look_back(a.scan_state, chunk, a.epoch, gave_up);
+            }
+            if (lane == 0) {
+                scan_store(&a.scan_state[chunk], tag | ((unsigned long long)kScanInclusive << 32) | (unsigned)(excl + tot));
+                s_base = excl;
+                wg_kept += tot;
+                if (gave_up) a.frame->pad[2] = 1;
+                int start = excl;
+                for (int sr = 0; sr < kHeldSubRuns; ++sr) {
+                    run_box_store(a.dst.box, chunk * kHeldSubRuns + sr, min(start, a.dst.cap), s_red[sr]);
+                    for (int q = 0; q < kSlicesPerRun; ++q) {
+                        const int j = sr * kSlicesPerRun + q;
+                        start += s_cnt[j][0] + s_cnt[j][1] + s_cnt[j][2] + s_cnt[j][3];
+                    }
+                }
+                if (chunk == nchunks - 1) a.dst.box[2 * nchunks * kHeldSubRuns + 1] = make_int4(0, 0, 0, min(excl + tot, a.dst.cap));
+            }
+        }
+        __syncthreads();
+        int off = s_base;
+#pragma unroll
+        for (int j = 0; j < kHeldPerThread; ++j) {
+            const bool keep = (keepmask >> j) & 1u;
+            const unsigned long long m = __ballot(keep);
+            int o = off + lane_rank(m);
+            for (int w = 0; w < wave; ++w) o += s_cnt[j][w];
+            if (keep && o < a.dst.cap) {
+                a.dst.pc[o] = pc[j]; a.dst.ct[o] = ct[j]; a.dst.nr[o] = nr[j];
+                if (bbox_on && pc[j].w > a.confThreshold) {
+                    const int x = (int)(1000.f * pc[j].x), y = (int)(1000.f * pc[j].y), z = (int)(1000.f * pc[j].z);
+                    bmin[0] = min(bmin[0], x); bmin[1] = min(bmin[1], y); bmin[2] = min(bmin[2], z);
+                    bmax[0] = max(bmax[0], x); bmax[1] = max(bmax[1], y); bmax[2] = max(bmax[2], z);
+                }
+            }
+            off += s_cnt[j][0] + s_cnt[j][1] + s_cnt[j][2] + s_cnt[j][3];
+        }
+        __syncthreads();
+    }
+    if (bbox_on) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (bmin[q] != kBBoxEmptyMin) atomicMin(&s_bb[q], bmin[q]);
+            if (bmax[q] != kBBoxEmptyMax) atomicMax(&s_bb[3 + q], bmax[q]);
+        }
+        __syncthreads();
+        if (threadIdx.x < 3 && s_bb[threadIdx.x] != kBBoxEmptyMin) atomicMin(&a.frame->bbox_tmp[threadIdx.x], s_bb[threadIdx.x]);
+        else if (threadIdx.x >= 3 && threadIdx.x < 6 && s_bb[threadIdx.x] != kBBoxEmptyMax) atomicMax(&a.frame->bbox_tmp[threadIdx.x], s_bb[threadIdx.x]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long* done64 = reinterpret_cast<unsigned long long*>(a.ctl + 2);
+        const unsigned long long old = atomicAdd(done64, (1ull << 32) | (unsigned long long)(unsigned)wg_kept);
+        if ((unsigned)(old >> 32) == gridDim.x - 1u) {
+            const int n = min((int)(unsigned)(old & 0xFFFFFFFFull) + wg_kept, a.dst.cap);
+            a.frame->countNext = n;
+            a.frame->count = n;
+            a.frame->runs = nchunks * kHeldSubRuns;
+            if (a.host_count) *a.host_count = n;
+            if (bbox_on) {
+                for (int q = 0; q < 6; ++q) {
+                    a.frame->bbox_acc[q] = __hip_atomic_load(&a.frame->bbox_tmp[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&a.frame->bbox_tmp[q], q < 3 ? kBBoxEmptyMin : kBBoxEmptyMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            for (int g = 0; g < kCleanTicketLanes; ++g) __hip_atomic_store(&a.ctl[kTicketBase + g * a.ticket_stride], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(done64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_clean_held(const CleanArgs a) { clean_held_body(a); }
+
 // workgroups of a clean launch for `elements` elements (an upper bound or an estimate: the chunks are drawn from a ticket counter, any
 // grid covers any count)
 int clean_grid(long elements) {
-    const long chunks = (elements + kCleanChunk - 1) / kCleanChunk;
+    const long chunks = (elements + kHeldChunk - 1) / kHeldChunk;
     return (int)(chunks < kCleanTicketLanes ? kCleanTicketLanes : (chunks > kCleanGridMax ? kCleanGridMax : chunks));
 }
-size_t clean_scan_entries(long max_elements) { return (size_t)((max_elements + kCleanChunk - 1) / kCleanChunk + 1); }
-static_assert(kTicketBase + kCleanTicketLanes * kTicketStride <= kCleanCtlInts, "ticket counters fit the control block");
+size_t clean_scan_entries(long max_elements) { return (size_t)((max_elements + kHeldChunk - 1) / kHeldChunk + 1); }
+static_assert(kTicketBase + kCleanTicketLanes * kTicketStrideMax <= kCleanCtlInts, "ticket counters fit the control block");
 
 // ------------------------------------------------------------------------------------------------
 // splat prediction: scatter (per-surfel sprite loop, ray-disc test, 64-bit atomicMin) + resolve
@@ -1312,8 +1471,9 @@ void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose
                   float confThreshold, float outlierCoeff, int maskID, const int* index, const float4* vc, const float4* ct,
                   const float4* packed, const float* depthF, const uint8_t* mask, const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags,
                   float* newconf, int* block_counts, unsigned long long* scan_state, int* ctl, unsigned epoch, int blocks, int ticket_lanes,
-                  int* host_count_mirror, bool transposed, bool literalWindow, bool small_map, hipStream_t s) {
+                  int* host_count_mirror, bool transposed, bool literalWindow, bool small_map, hipStream_t s, int ticket_stride, bool held) {
     CleanArgs a;
+    a.ticket_stride = ticket_stride;
     a.transposed = transposed ? 1 : 0;
     a.literal = literalWindow ? 1 : 0;
     a.src = src; a.dst = dst; a.frame = frame; a.pose = pose; a.W = W; a.H = H; a.k = k; a.timeDelta = timeDelta;
@@ -1343,7 +1503,7 @@ __global__ __launch_bounds__(256) void k_obj_index_scatter(const ObjBatch b) {
 __global__ __launch_bounds__(256) void k_obj_index_resolve(const ObjBatch b, int second) {
     const ObjPassArgs& m = b.m[blockIdx.z];
     if (!second) index_resolve_body(m.a, m.pose, m.keys, b.W * b.H, m.index, m.ivc, m.inr, nullptr, nullptr);
-    else index_resolve_body(b.cleanSmall ? m.b : m.a, m.pose, m.keys, b.W * b.H, nullptr, nullptr, nullptr, nullptr, m.iclean);
+    else index_resolve_body(b.updateCopy ? m.b : m.a, m.pose, m.keys, b.W * b.H, nullptr, nullptr, nullptr, nullptr, m.iclean);
 }
 __global__ __launch_bounds__(256) void k_obj_fuse_data(const ObjBatch b) {
     const ObjPassArgs& m = b.m[blockIdx.z];
@@ -1366,14 +1526,14 @@ __global__ __launch_bounds__(256) void k_obj_index_scatter2(const ObjBatch b) { 
 }
 __device__ __forceinline__ CleanArgs obj_clean_args(const ObjBatch& b, const ObjPassArgs& m) {
     CleanArgs a;
-    // small models: fuse copied a -> b, clean goes b -> a (the live buffer stays); big ones: fuse ran in place, clean goes a -> b
-    a.src = b.cleanSmall ? m.b : m.a; a.dst = b.cleanSmall ? m.a : m.b;
+    // copy-update: fuse copied a -> b, clean goes b -> a (the live buffer stays); in place: clean goes a -> b
+    a.src = b.updateCopy ? m.b : m.a; a.dst = b.updateCopy ? m.a : m.b;
     a.frame = m.frame; a.pose = m.pose; a.W = b.W; a.H = b.H; a.k = b.k; a.timeDelta = b.timeDelta;
     a.confThreshold = m.confThreshold; a.outlierCoeff = b.outlierCoeff; a.maskID = m.maskID; a.transposed = 1; a.literal = b.cleanLiteral;
     a.index = m.index; a.vc = m.ivc; a.ct = nullptr; a.packed = m.iclean; a.depthF = b.depthF; a.mask = b.mask;
     a.cand_op = m.cand_op; a.cand_rec = m.cand_rec; a.flags = b.cleanSmall ? m.flags : nullptr; a.newconf = b.cleanSmall ? m.newconf : nullptr;
     a.block_counts = m.block_counts; a.host_count = m.host_count;
-    a.scan_state = m.scan_state; a.ctl = m.clean_ctl; a.epoch = b.cleanEpoch; a.ticket_lanes = b.cleanTicketLanes;
+    a.scan_state = m.scan_state; a.ctl = m.clean_ctl; a.epoch = b.cleanEpoch; a.ticket_lanes = b.cleanTicketLanes; a.ticket_stride = b.cleanTicketStride;
     return a;
 }
 __global__ __launch_bounds__(256) void k_obj_clean(const ObjBatch b) { clean_body(obj_clean_args(b, b.m[blockIdx.z])); }
@@ -1399,7 +1559,7 @@ void launch_obj_fuse_clean(const ObjBatch& b, int blocks, int clean_blocks, hipS
     hipLaunchKernelGGL(k_obj_index_scatter, surfels, dim3(256), 0, s, b);
     hipLaunchKernelGGL(k_obj_index_resolve, pixels, dim3(256), 0, s, b, 0);
     hipLaunchKernelGGL(k_obj_fuse_data, cands, dim3(256), 0, s, b);
-    if (b.cleanSmall) {
+    if (b.updateCopy) {
         hipLaunchKernelGGL(k_obj_fuse_update_copy, surfels, dim3(256), 0, s, b);
     } else {
         hipLaunchKernelGGL(k_obj_fuse_update, dim3(cand_blocks(b.W, b.H), 1, b.n), dim3(256), 0, s, b);

@@ -334,6 +334,7 @@ hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) {
 }
 hipError_t hipStreamCreate(hipStream_t* s) { *s = (hipStream_t)(uintptr_t)(0x1000 + ++g_dummy_handles); return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
+hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, uint32_t, const uint32_t*) { return hipStreamCreate(s); }
 hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }

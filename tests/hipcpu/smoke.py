@@ -254,8 +254,36 @@ def host_paths(n=8, W=160, H=120):
     return out
 
 
+def map_forms(n=6, W=160, H=120):
+    """The three size-dependent forms of a model's fuse / clean passes (mf_frame.inl: enqueue_fuse_clean; by default chosen by the map's size,
+    here forced): copy-update + two-launch clean, in-place update + two-launch clean, in-place update + one-launch clean with the decoupled
+    look-back, its run table and the culled projection passes.  Same frames: poses, counts and the cloud's bytes identical."""
+    import hashlib
+    f = 528.0 * W / 640.0
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
+    frames = [st.frame(k) for k in range(n)]
+    forms = {"copy_two_launch": (1 << 30, 1 << 30, 0), "in_place_two_launch": (1 << 30, 0, 0), "in_place_one_launch": (0, 0, 0), "held": (0, 0, 1)}
+    out = {}
+    for name, (big, in_place, held) in forms.items():
+        mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=False, numGSurfels=1 << 17)
+        mf.setParam("bigMapElements", big)
+        mf.setParam("inPlaceElements", in_place)
+        mf.setParam("cleanHeld", held)
+        if held:
+            mf.setParam("cleanTicketStride", 1024)
+        poses = []
+        for k, (rgb, d, _) in enumerate(frames):
+            mf.processFrame(rgb, d, timestamp=k)
+            poses.append(mf.getCurrPose().reshape(-1).tolist())
+        cloud = np.ascontiguousarray(mf.getBackgroundModel().downloadMap())
+        out[name] = dict(poses=poses, count=int(mf.getBackgroundModel().lastCount()), cloud_sha1=hashlib.sha1(cloud.tobytes()).hexdigest(),
+                         visible_runs=int(mf.getParam("visibleRuns")), runs=int(mf.getParam("backgroundRuns")))
+        mf.close()
+    return out
+
+
 if __name__ == "__main__":
     scenarios = dict(single=single_model, rgbd=rgbd_so3, bad_depth=bad_depth_pixels, schedule=schedule_switches, mm_bad_depth=multimodel_bad_depth,
-                     weight=weight_multiplier_cases, dev_masks=device_resident_masks, static=static_switches, host_paths=host_paths)
+                     weight=weight_multiplier_cases, dev_masks=device_resident_masks, static=static_switches, host_paths=host_paths, map_forms=map_forms)
     wanted = sys.argv[1:] or list(scenarios)      # (tests/test_gpu_emu_agrees.py asks for "single" only; the CPU suite runs all of them)
     print(json.dumps({k: scenarios[k]() for k in wanted}))

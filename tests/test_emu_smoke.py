@@ -54,6 +54,11 @@ def test_emulated_kernels_track_and_fuse_like_the_oracle():
     hp = res["host_paths"]                                        # mf_process_frame's host-side variants == the blocking form, bit for bit
     for name, v in hp.items():
         assert v["poses"] == hp["blocking"]["poses"] and v["count"] == hp["blocking"]["count"] and v["cloud_sha1"] == hp["blocking"]["cloud_sha1"], name
+    mfm = res["map_forms"]                                        # the size-dependent forms of the fuse / clean passes: one result
+    for name, v in mfm.items():
+        ref = mfm["copy_two_launch"]
+        assert v["poses"] == ref["poses"] and v["count"] == ref["count"] and v["cloud_sha1"] == ref["cloud_sha1"], name
+    assert mfm["in_place_one_launch"]["runs"] > 0 and mfm["in_place_one_launch"]["visible_runs"] > 0     # ... and the culled passes really ran
 
 
 def test_emulated_kernels_reproduce_the_reference_generated_vectors():

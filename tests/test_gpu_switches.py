@@ -433,16 +433,18 @@ def test_run_culling_changes_nothing(hip):
 
 @pytest.mark.parametrize("multi", [False, True], ids=["single-model", "multi-model"])
 def test_clean_forms_agree(hip, multi):
-    """Model::clean has two forms (mf_surfel.hip): two launches over a static partition for small maps, one launch with a decoupled look-back
-    (which also writes the run table the projection passes cull by) from `bigMapElements` surfels on.  The same frames through both: model
-    list, counts, every surfel of every model in its slot, poses and label images bit-identical -- single model, and background + object
-    models (whose passes are batched: one launch per pass for all of them)."""
+    """A model's fuse / clean passes take one of three forms by its size (mf_frame.inl: enqueue_fuse_clean): below `inPlaceElements` update.vert
+    as a copy with the second index scatter riding on it + Model::clean in two launches over a static partition; from there to
+    `bigMapElements` update.vert in place + the two-launch clean; above, update.vert in place + clean in one launch with a decoupled look-back
+    (which also writes the run table the projection passes cull by).  The same frames through all three: model list, counts, every surfel
+    of every model in its slot, poses and label images bit-identical -- single model, and background + object models (whose passes are
+    batched: one launch per pass for all of them)."""
     from maskfusion_amd import MaskFusion, synth
     W, H, f = 320, 240, 264.0
     st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True, n_objects=3 if multi else 0, object_motion=0.0)
     frames = [st.frame(k) for k in range(12)]
 
-    def run(big):
+    def run(big, in_place, held=0):
         mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=multi, numGSurfels=1 << 19, numOSurfels=1 << 16,
                         modelSpawnOffset=2, trackAllModels=False, initConfidenceGlobal=10.0, initConfidenceObject=0.01)
         if multi:
@@ -450,6 +452,8 @@ def test_clean_forms_agree(hip, multi):
                          ("mfMorphMaskIterations", 0), ("newModelMinRelativeSize", 0.004)):
                 mf.setParam(k, v)
         mf.setParam("bigMapElements", big)
+        mf.setParam("inPlaceElements", in_place)
+        mf.setParam("cleanHeld", held)
         poses = []
         for k, (rgb, d, m) in enumerate(frames):
             mf.processFrame(rgb, d, mask=m if multi else None, classIDs=[0, 41, 42, 43] if multi else (), timestamp=k)
@@ -460,12 +464,13 @@ def test_clean_forms_agree(hip, multi):
         mf.close()
         return out
 
-    a, b = run(0), run(1 << 30)
-    assert a["ids"] == b["ids"] and a["counts"] == b["counts"], (a["ids"], b["ids"], a["counts"], b["counts"])
-    if multi:
-        assert len(a["ids"]) >= 3, a["ids"]     # at least two objects: their passes really were batched
-        assert np.array_equal(a["labels"], b["labels"])
-    for pa, pb in zip(a["poses"], b["poses"]):
-        assert len(pa) == len(pb) and all(np.array_equal(x, y) for x, y in zip(pa, pb))
-    for x, y in zip(a["clouds"], b["clouds"]):
-        assert np.array_equal(x, y, equal_nan=True)
+    a = run(0, 0)
+    for b in (run(1 << 30, 1 << 30), run(1 << 30, 0), run(0, 0, held=1)):
+        assert a["ids"] == b["ids"] and a["counts"] == b["counts"], (a["ids"], b["ids"], a["counts"], b["counts"])
+        if multi:
+            assert len(a["ids"]) >= 3, a["ids"]     # at least two objects: their passes really were batched
+            assert np.array_equal(a["labels"], b["labels"])
+        for pa, pb in zip(a["poses"], b["poses"]):
+            assert len(pa) == len(pb) and all(np.array_equal(x, y) for x, y in zip(pa, pb))
+        for x, y in zip(a["clouds"], b["clouds"]):
+            assert np.array_equal(x, y, equal_nan=True)
