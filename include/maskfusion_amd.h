@@ -166,8 +166,8 @@ int mf_get_last_fillin(mf_ctx* ctx, int32_t* used);
  * "mfMorphEdgeIterations", "mfMorphEdgeRadius", "mfMorphMaskIterations", "mfMorphMaskRadius".
  * Implementation switches (defaults are the product; the alternatives exist for A/B measurements and as executable specifications):
  * "splatTiles" (1), "globalTiles" (1: GlobalProjection of the background through tile lists), "gpuLabels" (1: label stage on the
- * device), "batchTracking" (1: one Gauss-Newton launch serves every tracked model), "earlyBackgroundFusion" (1), "overlapPreprocessing"
- * (0), "cleanLiteralWindow" (1: Model::clean walks its window with copy_unstable.vert's own fp32 trip count, 4 or 5 taps per axis;
+ * device), "batchTracking" (1: one Gauss-Newton launch serves every tracked model), "earlyBackgroundFusion" (1),
+ * "cleanLiteralWindow" (1: Model::clean walks its window with copy_unstable.vert's own fp32 trip count, 4 or 5 taps per axis;
  * 0: 4 x 4), "timings", "icpProfile", "objectSmallGrids" (1; 1: the grid-stride
  * surfel kernels of an object model run on a grid sized from its last known surfel count instead of 2048 workgroups), "objectScatterSplat" (1;
  * 1: object models are predicted with the scatter form of the splat instead of tile lists) -- both leave every result bit-identical; measured on
@@ -204,14 +204,10 @@ int mf_get_param(mf_ctx* ctx, const char* key, double* value);
 int mf_get_timings(mf_ctx* ctx, float* ms /* [MF_N_TIMINGS] */);
 /* The context's HIP stream (hipStream_t), for callers that time with their own events. */
 void* mf_get_stream(mf_ctx* ctx);
-/* Stream on which rgb/depth/mask handed to mf_process_frame_dev are first read.  By default this is the main stream
- * (mf_get_stream): producers ordered on it need no further synchronisation.  With mf_set_param("overlapPreprocessing", 1)
- * the pose-independent preprocessing (bilateral filter, depth pyramid, vertex/normal maps) of frame k+1 runs on a second
- * stream under the tracking/fusion of frame k; the contract for device buffers then becomes:
- *   - their producers are complete, or ordered on the input stream, when the call is made;
- *   - they stay unmodified until that frame has completed on the main stream (producers ordered on the input stream may
- *     reuse a buffer three frames later -- a ring of 3 -- without further synchronisation).
- * Query the input stream AFTER setting the parameter.  (On MI355X the overlap measured no gain; see DESIGN.md.) */
+/* Stream on which rgb/depth/mask handed to mf_process_frame_dev are first read: the context's stream (mf_get_stream) -- producers ordered on
+ * it need no further synchronisation; a buffer stays unmodified until its frame has completed there.  (Rounds 2-4 could move the
+ * pose-independent preprocessing to a second stream, "overlapPreprocessing"; it never gained anything -- also not with that stream masked to
+ * a few compute units, round 5 -- and is gone.  The entry point stays so that callers written against it keep working.) */
 void* mf_get_input_stream(mf_ctx* ctx);
 
 /* debug / differential-test taps: copy a device-resident intermediate of the last frame to host.

@@ -129,24 +129,15 @@ struct mf_ctx {
     mf_config cfg;
     int W, H, P;
     Intr K;
-    hipStream_t stream = nullptr;      // tracking + fusion (everything that depends on the pose)
-    hipStream_t stream_pre = nullptr;  // per-frame preprocessing, which depends on nothing but the frame: it runs one frame
-                                       // ahead under the latency-bound Gauss-Newton loop of the previous frame
-    hipEvent_t ev_pre_done[2] = {nullptr, nullptr};    // preprocessing of frame k finished      (pre -> main)
-    hipEvent_t ev_main_done[2] = {nullptr, nullptr};   // frame k finished tracking (so k-1 is complete)  (main -> pre)
+    hipStream_t stream = nullptr;      // the frame's chain: preprocessing, tracking, fusion, prediction
     bool clean_literal = true;                         // Model::clean walks its window with the shader text's fp32 trip count ("cleanLiteralWindow")
     bool global_tiles = true;                          // A/B + test knob ("globalTiles"): 0 = every model through k_global_scatter
     bool early_bg_fusion = true;                       // A/B knob ("earlyBackgroundFusion"): 0 = the host visit drains the stream
     hipEvent_t ev_labels = nullptr;                    // the label stage of this frame has written its result words
-    hipEvent_t ev_staged = nullptr;                    // mf_stage_frame_dev: the producers of the staged buffers, ordered on `stream`, have run (main -> pre)
     long frame_no = 0;
     long bg_fused_frame = -1;          // mf_fuse_background has fused the background of this staged frame (mf_fuse_models then skips it)
     bool labels_pending = false;       // between mf_perform_segmentation_begin and _end
     int lastF = 0;
-    int overlap = 0;                   // 1: preprocessing on stream_pre, one frame ahead ("overlapPreprocessing").  Measured on
-                                       // MI355X (tools/host_rate.py, same box A/B): 473-483 us/frame either way -- the filter's
-                                       // waves delay the whole-CU Gauss-Newton / fusion workgroups (+30 us on the main chain)
-                                       // and the two cross-queue barriers cost the rest, so it is off by default.
     std::string err;
     int host_tick = 1;
     bool map_ready = false;            // the background map exists (first frame processed, Model::initialise or an uploaded map)
@@ -231,7 +222,6 @@ struct mf_ctx {
     // visibility list of the projection passes (Surfels::box, k_cull): the runs of ONE buffer that can be in view under ONE pose; vis_tag says whose
     int* d_vis_list = nullptr; int* d_vis_count = nullptr; int* d_cull_ctl = nullptr; int vis_max_runs = 0;
     struct { const void* model = nullptr; long frame = -1; int cur = -1; } vis_tag;
-    int ticket_stride = 32; bool clean_held = false;   // EXPERIMENT (round 5): "cleanTicketStride" (ints), "cleanHeld"
     int ticket_lanes = 1;                  // ticket counters of the clean pass: min(kCleanTicketLanes, compute units of the device)
     bool cull_runs = true;                 // "cullRuns": 0 = every projection pass streams the whole buffer (A/B switch, executable specification)
     int big_map_elements = 6000000;        // "bigMapElements": from this many surfels on a model's clean pass is the one-launch form (which writes the run
@@ -458,11 +448,6 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
         c->ticket_lanes = cus < 1 ? 1 : (cus > kCleanTicketLanes ? kCleanTicketLanes : cus);
     }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(MF_ENODEV);
-    if (hipStreamCreateWithFlags(&c->stream_pre, hipStreamNonBlocking) != hipSuccess) return fail(MF_ENODEV);
-    for (int i = 0; i < 2; ++i)
-        if (hipEventCreateWithFlags(&c->ev_pre_done[i], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_main_done[i], hipEventDisableTiming) != hipSuccess)
-            return fail(MF_ENODEV);
     const int W = c->W, H = c->H, P = c->P;
     const int cap_bg = surfel_capacity(cfg->num_gsurfels), cap_obj = surfel_capacity(cfg->num_osurfels);
     if (cap_bg <= 0 || cap_obj <= 0) return fail(MF_EINVAL);
@@ -587,7 +572,6 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
 
 extern "C" void mf_destroy(mf_ctx* c) {
     if (!c) return;
-    if (c->stream_pre) (void)hipStreamSynchronize(c->stream_pre);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->models.clear();
     for (void* p : c->allocs) (void)hipFree(p);
@@ -600,12 +584,7 @@ extern "C" void mf_destroy(mf_ctx* c) {
     if (c->ev_icp_mid) (void)hipEventDestroy(c->ev_icp_mid);
     for (int i = 0; i < 5; ++i)
         if (c->ev_mm[i]) (void)hipEventDestroy(c->ev_mm[i]);
-    for (int i = 0; i < 2; ++i) {
-        if (c->ev_pre_done[i]) (void)hipEventDestroy(c->ev_pre_done[i]);
-        if (c->ev_main_done[i]) (void)hipEventDestroy(c->ev_main_done[i]);
-    }
     if (c->ev_labels) (void)hipEventDestroy(c->ev_labels);
-    if (c->ev_staged) (void)hipEventDestroy(c->ev_staged);
     for (int i = 0; i < 2; ++i) {
         if (c->ev_in_copied[i]) (void)hipEventDestroy(c->ev_in_copied[i]);
         if (c->ev_in_consumed[i]) (void)hipEventDestroy(c->ev_in_consumed[i]);
@@ -616,7 +595,6 @@ extern "C" void mf_destroy(mf_ctx* c) {
         if (c->h_obj_args[i]) (void)hipHostFree(c->h_obj_args[i]);
         if (c->ev_obj_args[i]) (void)hipEventDestroy(c->ev_obj_args[i]);
     }
-    if (c->stream_pre) (void)hipStreamDestroy(c->stream_pre);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1020,9 +998,6 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!strcmp(key, "globalTiles")) { c->global_tiles = value != 0; return MF_OK; }
     if (!strcmp(key, "cullRuns")) { c->cull_runs = value != 0; c->vis_tag.model = nullptr; return MF_OK; }
     if (!strcmp(key, "bigMapElements")) { c->big_map_elements = (int)value; c->vis_tag.model = nullptr; return MF_OK; }
-    if (!strcmp(key, "cleanHeld")) { c->clean_held = value != 0; return MF_OK; }
-    if (!strcmp(key, "cleanTicketStride")) { c->ticket_stride = std::max(1, std::min((int)value, kTicketStrideMax)); return MF_OK; }
-    if (!strcmp(key, "cleanTicketLanes")) { c->ticket_lanes = std::max(1, std::min((int)value, kCleanTicketLanes)); return MF_OK; }
     if (!strcmp(key, "inPlaceElements")) { c->in_place_elements = (int)value; return MF_OK; }
     if (!strcmp(key, "rebuildRunTable")) {   // tooling: the background's run table from scratch (what an upload / Model::initialise does)
         launch_run_table(c->models[0]->surf[c->models[0]->cur], c->models[0]->d_frame, c->stream);
@@ -1034,25 +1009,6 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!strcmp(key, "modelApiPackedIndex")) { c->model_api_packed = value != 0; return MF_OK; }   // 0: scatter + resolve form (specification)
     if (!strcmp(key, "tileThreads")) { c->splat_tune.tile_threads = (int)value; return MF_OK; }   // A/B: threads per tile workgroup of the tile passes
     if (!strcmp(key, "spriteLanes")) { c->splat_tune.sprite_lanes = (int)value; return MF_OK; }   // A/B: lanes per sprite in the tile z-test (default 4)
-    if (!strcmp(key, "preCUs")) {   // EXPERIMENT (round 5): the preprocessing stream restricted to `value` compute units (CU-mask bits are dealt round-robin to the XCDs)
-        (void)hipStreamSynchronize(c->stream_pre);
-        (void)hipStreamSynchronize(c->stream);
-        hipStream_t masked = nullptr;
-        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const int n = std::max(8, std::min((int)value, 256));
-        for (int i = 0; i < n; ++i) mask[i >> 5] |= 1u << (i & 31);
-        const hipError_t e = value > 0 ? hipExtStreamCreateWithCUMask(&masked, 8, mask) : hipStreamCreateWithFlags(&masked, hipStreamNonBlocking);
-        if (e != hipSuccess) { c->err = std::string("preCUs: ") + hipGetErrorString(e); return MF_EINVAL; }
-        (void)hipStreamDestroy(c->stream_pre);
-        c->stream_pre = masked;
-        return MF_OK;
-    }
-    if (!strcmp(key, "overlapPreprocessing")) {
-        (void)hipStreamSynchronize(c->stream_pre);
-        (void)hipStreamSynchronize(c->stream);
-        c->overlap = value != 0;
-        return MF_OK;
-    }
     if (!strcmp(key, "confidenceThreshold")) { c->cfg.conf_global = (float)value; c->models[0]->confThr = (float)value; return MF_OK; }
     for (const ParamRef& p : kParams)
         if (!strcmp(key, p.key)) {
@@ -1115,7 +1071,7 @@ extern "C" int mf_get_timings(mf_ctx* c, float* ms) {
     return MF_OK;
 }
 extern "C" void* mf_get_stream(mf_ctx* c) { return c ? (void*)c->stream : nullptr; }
-extern "C" void* mf_get_input_stream(mf_ctx* c) { return c ? (void*)(c->overlap ? c->stream_pre : c->stream) : nullptr; }
+extern "C" void* mf_get_input_stream(mf_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 static int debug_read_impl(mf_ctx* c, ModelState& mdl, const char* what, void* out, uint64_t out_bytes) {
     int rc = mf_sync(c);

@@ -241,8 +241,7 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
     launch_clean(m.surf[live], m.surf[1 - live], m.d_frame, m.d_pose, W, H, c->K, g.time_delta, m.confThr, g.outlier_coefficient, m.id,
                  c->d_index, c->d_ivc, c->d_ict, secondIndexPass ? c->d_iclean : nullptr, depthF, mask, c->d_cand_op, c->d_cand_rec,
                  small ? c->d_flags : nullptr, small ? c->d_newconf : nullptr, c->d_block_counts, c->d_scan_state, c->d_clean_ctl,
-                 next_clean_epoch(c), clean_blocks(c, m), c->ticket_lanes, m.h_count, secondIndexPass, c->clean_literal, small, s, c->ticket_stride,
-                 c->clean_held);
+                 next_clean_epoch(c), clean_blocks(c, m), c->ticket_lanes, m.h_count, secondIndexPass, c->clean_literal, small, s);
     m.cur = 1 - live;
     m.table_valid = !small;
 }
@@ -303,7 +302,7 @@ static int make_obj_batch(mf_ctx* c, const std::vector<ModelState*>& ms, const s
     MF_HIP(c, hipEventRecord(c->ev_obj_args[slot], c->stream));
     b.m = c->d_obj_args[slot]; b.n = (int)ms.size();
     b.W = c->W; b.H = c->H; b.k = c->K; b.maxDepthProcessed = g.max_depth_processed; b.globalMaxDepth = g.depth_cutoff; b.timeDelta = g.time_delta;
-    b.outlierCoeff = g.outlier_coefficient; b.cleanLiteral = c->clean_literal ? 1 : 0; b.bboxLimit = c->bbox_limit ? 1 : 0; b.cleanEpoch = 0; b.cleanTicketLanes = 1; b.cleanTicketStride = c->ticket_stride; b.cleanSmall = 0; b.updateCopy = 0;
+    b.outlierCoeff = g.outlier_coefficient; b.cleanLiteral = c->clean_literal ? 1 : 0; b.bboxLimit = c->bbox_limit ? 1 : 0; b.cleanEpoch = 0; b.cleanTicketLanes = 1; b.cleanSmall = 0; b.updateCopy = 0;
     b.rgb = d_rgb; b.depthRaw = d_depth; b.depthF = depthF; b.mask = mask; b.bg_pose = c->models[0]->d_pose; b.global_keys = c->d_keys;
     return MF_OK;
 }
@@ -334,18 +333,15 @@ static int take_next_model_id(mf_ctx* c) {
 
 // filterDepth (Core/MaskFusion.cpp:217) + Model::generateCUDATextures (Model.cpp:350-389) + the frame's intensity pyramid and
 // derivative images, for frame index k (buffer set k & 1, filtered-depth ring slot k % 3).
-// With overlapPreprocessing it runs on its own stream and starts when frame k-1 has finished TRACKING: frame k-2 (the last
-// user of this buffer set and of depthF[k % 3]) is then complete, and the filter overlaps the atomic-/latency-bound fusion
-// kernels of frame k-1 rather than its Gauss-Newton launches, which need a whole CU per workgroup and stall behind resident
-// filter waves.
+// (It runs at the head of the frame's chain on the context's stream.  Running it one frame ahead on a stream of its own, beside the previous
+// frame's fusion kernels, lost in rounds 2 and 5 -- also with that stream masked to 16 / 32 / 64 compute units: DESIGN.md, "Measured and rejected".)
 static int enqueue_preprocess(mf_ctx* c, const uint8_t* d_rgb, const float* d_depth, long k, bool with_maps) {
     const int W = c->W, H = c->H, P = c->P;
     hipStream_t s = c->stream;
     const mf_config& g = c->cfg;
     const int set = (int)(k & 1);
     float* depthF = c->d_depthF[k % 3];
-    hipStream_t sp = c->overlap ? c->stream_pre : s;
-    if (c->overlap) MF_HIP(c, hipStreamWaitEvent(sp, c->ev_main_done[set ^ 1], 0));
+    hipStream_t sp = s;
     mark(c, 0, sp);
     launch_bilateral(d_depth, depthF, W, H, sp);
     if (with_maps) {   // the frame that initialises the map is never tracked against: no vertex / normal maps needed
@@ -369,10 +365,6 @@ static int enqueue_preprocess(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
         }
     }
     mark(c, 1, sp);
-    if (c->overlap) {
-        MF_HIP(c, hipEventRecord(c->ev_pre_done[set], sp));
-        MF_HIP(c, hipStreamWaitEvent(s, c->ev_pre_done[set], 0));
-    }
     return MF_OK;
 }
 
@@ -607,7 +599,6 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
     float* depthF = c->d_depthF[k % 3];
     float* depthF_prev = c->d_depthF[(k + 2) % 3];
     ModelState& bg = *c->models[0];
-    bool main_done_recorded = false;
     bool bg_fused = false;
     c->mm_marked = false;
 
@@ -641,7 +632,6 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
         enqueue_tracking_loop(c, 0, g.track_all_models != 0, depthF_prev, k);
         if (bootstrap && in_pose16) launch_override_pose(bg.d_pose, in_pose16, 1, bg.h_pose, s);   // :280-283 (after the object loop)
         mark(c, 3);
-        if (c->overlap) { MF_HIP(c, hipEventRecord(c->ev_main_done[set], s)); main_done_recorded = true; }
 
         if (multi) {
             // GlobalProjection::project(models, tick, tick, timeDelta, depthCutoff) (:289) with its fixed threshold 12
@@ -748,8 +738,6 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
         if (rc != MF_OK) return rc;
     }
     mark(c, 8);
-    // every branch records the event (the caller-supplied-pose branch and the first frame do it here, at the end of the frame)
-    if (c->overlap && !main_done_recorded) MF_HIP(c, hipEventRecord(c->ev_main_done[set], s));
     c->lastF = (int)(k % 3);
     c->frame_no++;
     c->host_tick++;
@@ -836,7 +824,6 @@ extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* dept
         // decision and has no time to spare: its upload stays a cross-queue wait under the previous frame's tail)
         if (c->host_wait_upload && c->host_lockstep && c->cfg.enable_multiple_models == 0) MF_HIP(c, hipEventSynchronize(c->ev_in_copied[slot]));
         else MF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_in_copied[slot], 0));
-        if (c->overlap) MF_HIP(c, hipStreamWaitEvent(c->stream_pre, c->ev_in_copied[slot], 0));
         const auto t_2 = std::chrono::steady_clock::now();
         int rc = process_frame_impl(c, c->d_in_rgb[slot], c->d_in_depth[slot], mask ? c->d_in_mask[slot] : nullptr, class_ids, n_masks,
                                     weight_multiplier, timestamp, in_pose16, bootstrap != 0);
@@ -847,7 +834,7 @@ extern "C" int mf_process_frame(mf_ctx* c, const uint8_t* rgb, const float* dept
         return rc;
     }
     // blocking form: staged on the input stream (the frame is first read there); the previous frame has completed (this call syncs)
-    hipStream_t sin = c->overlap ? c->stream_pre : c->stream;
+    hipStream_t sin = c->stream;
     MF_HIP(c, hipMemcpyAsync(c->d_rgb, rgb, (size_t)c->P * 3, hipMemcpyHostToDevice, sin));
     MF_HIP(c, hipMemcpyAsync(c->d_depth, depth, (size_t)c->P * sizeof(float), hipMemcpyHostToDevice, sin));
     if (mask) MF_HIP(c, hipMemcpyAsync(c->d_mask_in, mask, (size_t)c->P, hipMemcpyHostToDevice, sin));

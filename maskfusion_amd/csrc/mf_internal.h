@@ -261,8 +261,7 @@ void launch_fuse_update_copy(Surfels src, Surfels dst, const FrameDev* frame, in
 // ctl: kCleanCtlInts ints, zero between launches; blocks: clean_grid(elements expected)
 constexpr int kCleanGridMax = 2048;
 constexpr int kCleanTicketLanes = 32;
-constexpr int kTicketStrideMax = 16384;   // ints between two ticket counters, at most (64 KB)
-constexpr int kCleanCtlInts = 64 + 32 * kTicketStrideMax;   // size of the control block `ctl` (finished-workgroup count + 32 ticket counters)
+constexpr int kCleanCtlInts = 1088;   // size of the control block `ctl` (finished-workgroup count + 32 ticket counters 128 B apart)
 int clean_grid(long elements);
 size_t clean_scan_entries(long max_elements);
 void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k,
@@ -271,8 +270,7 @@ void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose
                   const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags /*or null*/, float* newconf /*or null*/, int* block_counts,
                   unsigned long long* scan_state, int* ctl, unsigned epoch, int blocks, int ticket_lanes /* <= compute units, <= kCleanTicketLanes */,
                   int* host_count_mirror, bool transposed /*layout of index/vc/ct*/, bool literalWindow /*fp32 trip count of the shader*/,
-                  bool small_map /* the two-launch form (needs flags, newconf, block_counts; writes no run table) */, hipStream_t s,
-                  int ticket_stride = 32 /* ints between ticket counters, <= kTicketStrideMax */, bool held = false);
+                  bool small_map /* the two-launch form (needs flags, newconf, block_counts; writes no run table) */, hipStream_t s);
 // generic ordered compaction of [n_dev] records (3 x float4 each, record-major) -> surfels, sets frame->count
 void launch_compact_records(const float4* rec, const uint8_t* flags, int n, Surfels dst, FrameDev* frame,
                             int* block_counts, int* host_count_mirror, hipStream_t s);
@@ -319,7 +317,6 @@ struct ObjBatch {
     unsigned cleanEpoch;               // CleanArgs::epoch of this batch's clean launch
     int cleanTicketLanes;              // CleanArgs::ticket_lanes
     int updateCopy;                    // 1: every model of the batch is below inPlaceElements -- update.vert as a copy a -> b, clean b -> a
-    int cleanTicketStride;             // ints between two ticket counters
     int cleanSmall;                    // 1: every model of the batch is small -- the two-launch clean form
     const uint8_t* rgb; const float* depthRaw; const float* depthF; const uint8_t* mask; const PoseDev* bg_pose;
     unsigned long long* global_keys;

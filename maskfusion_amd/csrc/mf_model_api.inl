@@ -27,7 +27,7 @@ static const uint8_t* current_mask(const mf_ctx* c) { return c->cfg.enable_multi
 extern "C" int mf_stage_frame(mf_ctx* c, const uint8_t* rgb, const float* depth, const uint8_t* mask) {
     if (c) c->vis_tag.model = nullptr;   // (a visibility list belongs to one frame and one pose)
     if (!c || !rgb || !depth) return MF_EINVAL;
-    hipStream_t sin = c->overlap ? c->stream_pre : c->stream;
+    hipStream_t sin = c->stream;
     MF_HIP(c, hipStreamSynchronize(c->stream));
     MF_HIP(c, hipMemcpyAsync(c->d_rgb, rgb, (size_t)c->P * 3, hipMemcpyHostToDevice, sin));
     MF_HIP(c, hipMemcpyAsync(c->d_depth, depth, (size_t)c->P * sizeof(float), hipMemcpyHostToDevice, sin));
@@ -46,13 +46,6 @@ extern "C" int mf_stage_frame_dev(mf_ctx* c, const uint8_t* d_rgb, const float* 
     if (c) c->vis_tag.model = nullptr;   // (a visibility list belongs to one frame and one pose)
     if (!c || !d_rgb || !d_depth) return MF_EINVAL;
     if (d_mask) MF_HIP(c, hipMemcpyAsync(c->d_mask_tex, d_mask, (size_t)c->P, hipMemcpyDeviceToDevice, c->stream));
-    if (c->overlap) {
-        // with overlapPreprocessing the filter / pyramid kernels run on stream_pre, which otherwise only waits for the previous frame's tracking:
-        // the buffers' producers (an RCCL broadcast, a copy) are ordered on `stream` by contract, so the preprocessing stream waits for them here
-        if (!c->ev_staged) MF_HIP(c, hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
-        MF_HIP(c, hipEventRecord(c->ev_staged, c->stream));
-        MF_HIP(c, hipStreamWaitEvent(c->stream_pre, c->ev_staged, 0));
-    }
     int rc = enqueue_preprocess(c, d_rgb, d_depth, c->frame_no, true);
     if (rc != MF_OK) return rc;
     c->lastF = (int)(c->frame_no % 3);
@@ -201,7 +194,7 @@ extern "C" int mf_model_clean(mf_ctx* c, int32_t model, int32_t time, int32_t ti
     launch_clean(m->surf[src], m->surf[dst], m->d_frame, m->d_pose, c->W, c->H, c->K, time_delta, m->confThr, c->cfg.outlier_coefficient, m->id,
                  c->d_index, c->d_ivc, c->d_ict, packed ? c->d_iclean : nullptr, c->d_depthF[k % 3], current_mask(c), c->d_cand_op, c->d_cand_rec,
                  c->d_flags, c->d_newconf, c->d_block_counts, c->d_scan_state, c->d_clean_ctl, next_clean_epoch(c), clean_blocks(c, *m), c->ticket_lanes, m->h_count,
-                 packed, c->clean_literal, small, c->stream, c->ticket_stride, c->clean_held);
+                 packed, c->clean_literal, small, c->stream);
     m->cur = dst;
     m->table_valid = !small;
     return check_launch(c);

@@ -643,7 +643,6 @@ struct CleanArgs {
     int* ctl;                          // kCleanCtlInts ints, zero between launches: finished workgroups + the ticket counters (clean_body)
     unsigned epoch;                    // distinguishes this launch's entries of scan_state from older ones (never reset)
     int ticket_lanes;                  // counters the chunks are drawn from (1 .. kCleanTicketLanes, <= compute units and <= workgroups launched)
-    int ticket_stride;                 // ints between two ticket counters (<= kTicketStrideMax)
 };
 
 // The window of copy_unstable.vert:85-86 along one axis, exactly as the shader text walks it: `for (i = c - 2s; i < c + 2s; i += s)` on an
@@ -672,16 +671,18 @@ __device__ __forceinline__ void window_slots_literal(float c, int size, int (&u)
 }
 
 // decay: which factor the mask-disagreement rule applied to the confidence (0 none, 1: k, 2: 0.25 k) -- clean_decayed() re-applies it
+// nr_lazy != nullptr: the surfel's normal / radius record is only fetched when the window is walked (it is not needed otherwise); `nr` is then ignored
 __device__ __forceinline__ bool clean_test(const CleanArgs& a, float4 pc, float4 ct, float4 nr, float time, const float* Ri,
-                                           float3 ti, float& newconf, int& decay) {
+                                           float3 ti, float& newconf, int& decay, const float4* nr_lazy = nullptr) {
     const int W = a.W, H = a.H;
     bool test = true;
     const float3 lp = mul33(Ri, f3(pc.x, pc.y, pc.z)) + ti;
     const float x = ((a.k.fx * lp.x) / lp.z) + a.k.cx;
     const float y = ((a.k.fy * lp.y) / lp.z) + a.k.cy;
-    const float3 ln = normalize_gl(mul33(Ri, f3(nr.x, nr.y, nr.z)));
     int count = 0, zCount = 0;
     if (time - ct.w < (float)a.timeDelta && lp.z > 0 && x > 0 && y > 0 && x < (float)W && y < (float)H) {
+        if (nr_lazy) nr = *nr_lazy;
+        const float3 ln = normalize_gl(mul33(Ri, f3(nr.x, nr.y, nr.z)));
         // copy_unstable.vert:86-87 samples a 4x4 window at offsets {-1,-0.5,0,+0.5} px; nearest fetches land on only 2 or
         // 3 distinct texels per axis, so the window is walked as <= 3x3 distinct texels weighted by their multiplicity
         // (identical counts, ~2.5x fewer gathers).
@@ -705,7 +706,7 @@ __device__ __forceinline__ bool clean_test(const CleanArgs& a, float4 pc, float4
             for (int ib = 0; ib < 3; ++ib) {
                 const int tp = a.transposed ? ux[ia] * H + uy[ib] : uy[ib] * W + ux[ia];
                 const int mult = mx[ia] * my[ib];
-                if (mult <= 0) continue;   // (loading all nine records up front was tried: 21 -> 25 us, the empty taps cost more)
+                if (mult <= 0) continue;   // (requesting the taps' records in groups before looking at any -- 6 + 3, all 9 -- was tried in rounds 2 and 5: slower at VGA, DESIGN.md "rejected")
                 float4 v, c;
                 int idx;
                 if (a.packed) {
@@ -878,36 +879,39 @@ __device__ __forceinline__ void clean_small_compact_body(const CleanArgs& a) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// splat prediction: scatter (per-surfel sprite loop, ray-disc test, 64-bit atomicMin) + resolve
-// Raster rule: sprite side s centred on (u,v) covers pixel (px,py) iff u - s/2 <= px + 0.5 < u + s/2; LESS on the
-// corrected z; lower index wins ties; sprites wider than 64 px are clamped.
-// ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_clean_small_compact(const CleanArgs a) { clean_small_compact_body(a); }
 
 // ------------------------------------------------------------------------------------------------
 // clean (copy_unstable.vert:53-157) in ONE launch: test + ordered compaction with a decoupled look-back.
 // Rounds 1-4 ran two launches (k_clean_flags: test -> keep flags + new confidences + per-workgroup counts; k_clean_compact: prefix of the
 // counts, ordered copy) over a static partition: the workgroups whose slice lay in view did all the window gathers while the others idled, and
-// every flag / confidence took a round trip through HBM (154 B per surfel moved, 0.95 + 0.53 ms on the 26.9 M-surfel map of configs[4]).
+// every flag / confidence took a round trip through HBM (154 B per surfel moved; 1.28 + 0.58 ms on the 26.9 M-surfel map of configs[4]).
 // Here a workgroup draws a chunk of kCleanChunk consecutive elements (element i < count: old surfel i; element count + c: candidate c, live
-// only with op == 2) from a ticket counter, SWEEPS it once to test its elements -- keep bit and decay code stay in two registers per thread --
-// publishes the chunk's number of survivors, obtains the number of survivors of all earlier chunks by looking back over the published values
-// (Merrill & Garland's decoupled look-back; the ticket order guarantees that every earlier chunk is owned by a workgroup that is already
-// running, so the wait terminates), and SWEEPS the chunk again to copy the survivors to their final slots: the second read of the 96 KB comes
-// out of the L2 / the memory-side cache, the order of the output is the order of the input, as transform feedback keeps it.
-// (Round 5 history, profiles/r05b_* .. r05d_*: keeping the records in registers between test and copy held the chunk at 512-1024 elements;
-// a round -- ticket, loads, gathers, look-back, stores: ~20 us of dependent latency -- then moved 24-48 KB and the pass ran at 0.9-1.4 ms,
-// latency-bound, whatever was done to the ticket and the look-back.  2048 elements per round amortise the same latency over four times the bytes.)
+// only with op == 2) from a ticket counter and
+//   sweep 1   fetches the half of each record the test needs (position + confidence, the two time stamps: 24 B), tests it -- keep bit and decay
+//             code stay in two registers per thread, the fetched half goes to the LDS --, and requests the other half of the survivors;
+//   look-back publishes the chunk's number of survivors and obtains the number of survivors of all earlier chunks from the published values
+//             (Merrill & Garland's decoupled look-back; the ticket order guarantees that every earlier chunk is owned by a workgroup that is
+//             already running, so the wait terminates);
+//   sweep 2   writes the survivors to their final slots -- the order of the output is the order of the input, as transform feedback keeps it --
+//             and the bounding boxes of the new buffer's runs (Surfels::box).
+// Every byte of the input is read ONCE: 96 B per surfel moved plus the window gathers of the surfels in view.
+// Round 5 history (profiles/r05b_* .. r05n_*; tools/clean_prof.py times the phases of every chunk with an instrumented build): records held in
+// registers, chunks of 512 / 1024: 1.2-1.9 ms; one ticket counter, 32 of them, 128 B .. 64 KB apart: no difference (a counter hands out a ticket
+// every 11 ns, 32 of them one every 0.5 ns: tools/micro/ticket_lanes); 2048 elements, both sweeps from memory (144 B per surfel): 1.33 ms;
+// all of a thread's loads in flight at once instead of four dependent batches: 1.35 ms; this form: 1.29 ms.  Whatever the form, a chunk's phases
+// stretch with the number of workgroups in flight -- a dependent round trip to memory takes 6-8 us while the pass runs, with 768 or 1024
+// workgroups -- and the pass ends up at ~10 chunks per microsecond: the memory system is saturated by ~3 TB/s of mixed traffic (reads of six
+// streams in 32 KB pieces whose order the tickets decide, writes, 64-byte gathers), not by this kernel's instruction stream.
 // ------------------------------------------------------------------------------------------------
 constexpr int kCleanPerThread = 8;
 constexpr int kCleanChunk = 256 * kCleanPerThread;
 constexpr int kSubRuns = kCleanChunk / kRun;   // the survivors of a chunk are kSubRuns consecutive runs of the new buffer's run table
 constexpr int kSlicesPerRun = kRun / 256;
 static_assert(kCleanChunk % kRun == 0 && kRun % 256 == 0, "runs are whole slices of a chunk");
-constexpr int kLookPerLane = 4;   // states of earlier chunks a lane reads per look-back step: 256 per step and wavefront
+constexpr int kLookPerLane = 4;   // states of earlier chunks a lane reads per look-back step: 256 per step and wavefront (16 per lane was slower: 27 against 17 us per look-back)
 constexpr unsigned kScanAggregate = 1u, kScanInclusive = 2u;
-constexpr int kTicketBase = 32;   // ctl: [2..3] finished workgroups << 32 | survivors (64 bit), [kTicketBase + g kTicketStride] ticket counter of lane g (128 B apart)
+constexpr int kTicketStride = 32, kTicketBase = 32;   // ctl: [2..3] finished workgroups << 32 | survivors (64 bit), [kTicketBase + g kTicketStride] ticket counter of lane g (128 B apart)
 
 __device__ __forceinline__ unsigned long long scan_load(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -961,11 +965,20 @@ __device__ __forceinline__ int scan_look_back(const unsigned long long* __restri
     return exclusive;
 }
 
+#ifdef MF_CLEAN_PROF
+// tooling build (tools/clean_prof.py): per chunk of the background's clean pass {chunk start, ticket, sweep 1, look-back, sweep 2} in 100 MHz ticks
+__device__ unsigned g_clean_prof[1 << 16][8];
+#define MF_PROF_T(x) const unsigned long long x = wall_clock64()
+#else
+#define MF_PROF_T(x)
+#endif
 __device__ __forceinline__ void clean_body(const CleanArgs& a) {
     __shared__ int s_chunk, s_base;
     __shared__ int s_cnt[kCleanPerThread][4];
     __shared__ int s_bb[6];
     __shared__ int s_red[kSubRuns][4][8];   // the boxes of the chunk's runs (Surfels::box of dst): per-wavefront partial results
+    __shared__ float4 s_pc[kCleanPerThread][256];   // the half of the chunk's records that sweep 1 fetched (48 KB with s_tm: three workgroups per CU)
+    __shared__ float2 s_tm[kCleanPerThread][256];
     // Model::lastBoundingBox of an OBJECT model (Model.cpp:315-345 + draw_global_surface.vert:55-78: the box of the surfels the GUI draws --
     // confidence above the model's threshold -- in millimetres, truncated): accumulated here, where the frame's final records pass through
     // registers anyway; Model::fuse of the NEXT frame limits its depth with it (Model.cpp:480-501).  The background (id 0) never uses one.
@@ -991,49 +1004,78 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
     const int tlane = (int)(blockIdx.x % lanes);
     int wg_kept = 0;          // survivors of the chunks this workgroup handled (thread 0's copy is the one that counts)
     for (;;) {
-        if (threadIdx.x == 0) s_chunk = tlane + lanes * atomicAdd(&a.ctl[kTicketBase + tlane * a.ticket_stride], 1);
+        MF_PROF_T(t_0);
+        if (threadIdx.x == 0) s_chunk = tlane + lanes * atomicAdd(&a.ctl[kTicketBase + tlane * kTicketStride], 1);
         __syncthreads();
         const int chunk = s_chunk;
         if (chunk >= nchunks) break;
+        MF_PROF_T(t_1);
         const int first = chunk * kCleanChunk + (int)threadIdx.x;
-        // ---- sweep 1: test.  Element j of this thread is first + 256 j; bit j of `keepmask` / bits 2 j, 2 j + 1 of `decay` are all that is kept
+        // ---- sweep 1: test.  Element j of this thread is first + 256 j.  The test needs HALF of a record -- position + confidence, the two time
+        // stamps: 24 of its 48 bytes; the normal / radius record only for an element in view (clean_test fetches it there) -- and that half stays
+        // in the LDS for sweep 2, which fetches the other half: every byte of the input is read once (96 B per surfel moved; rounds 1-4: 154).
         unsigned keepmask = 0u, decay = 0u;
 #pragma unroll 1
         for (int sr = 0; sr < kSubRuns; ++sr) {
             int rlo[3] = {kBoxEmptyMin, kBoxEmptyMin, kBoxEmptyMin}, rhi[3] = {kBoxEmptyMax, kBoxEmptyMax, kBoxEmptyMax}, rtime = kBoxEmptyMax;
-            float4 pc[kSlicesPerRun], ct[kSlicesPerRun], nr[kSlicesPerRun];
+            float4 pc[kSlicesPerRun];
+            float2 tm[kSlicesPerRun];
             bool live[kSlicesPerRun];
 #pragma unroll
             for (int q = 0; q < kSlicesPerRun; ++q) {   // the slices' records are requested before anything depends on one of them
                 const int i = first + 256 * (sr * kSlicesPerRun + q);
                 live[q] = i < total;
-                pc[q] = ct[q] = nr[q] = make_float4(0, 0, 0, 0);
-                if (i < count) { pc[q] = a.src.pc[i]; ct[q] = a.src.ct[i]; nr[q] = a.src.nr[i]; }
-                else if (live[q]) {
+                pc[q] = make_float4(0, 0, 0, 0); tm[q] = make_float2(0, 0);
+                if (i < count) {
+                    pc[q] = a.src.pc[i];
+                    tm[q] = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(&a.src.ct[i]) + 2);
+                } else if (live[q]) {
                     const int c = i - count;
                     live[q] = a.cand_op[c] == 2;      // op == 1 records carry w = -1 and are dropped, op == 0 slots hold nothing
-                    if (live[q]) { pc[q] = a.cand_rec[c * 3 + 0]; ct[q] = a.cand_rec[c * 3 + 1]; nr[q] = a.cand_rec[c * 3 + 2]; }
+                    if (live[q]) {
+                        pc[q] = a.cand_rec[c * 3 + 0];
+                        tm[q] = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(&a.cand_rec[c * 3 + 1]) + 2);
+                    }
                 }
             }
 #pragma unroll
             for (int q = 0; q < kSlicesPerRun; ++q) {
                 const int j = sr * kSlicesPerRun + q;
+                const int i = first + 256 * j;
+                const float4 ct = make_float4(0.f, 0.f, tm[q].x, tm[q].y);
+                const float4* nrp = i < count ? &a.src.nr[i] : &a.cand_rec[(i - count) * 3 + 2];
                 float nc = 0.f;
                 int dk = 0;
-                const bool keep = live[q] && clean_test(a, pc[q], ct[q], nr[q], time, Ri, ti, nc, dk);
+                const bool keep = live[q] && clean_test(a, pc[q], ct, make_float4(0, 0, 0, 0), time, Ri, ti, nc, dk, nrp);
                 if (a.flags) {
-                    const int i = first + 256 * j;
                     if (i < total) { a.flags[i] = keep ? 1 : 0; a.newconf[i] = live[q] ? nc : 0.f; }
                 }
+                s_pc[j][threadIdx.x] = pc[q];
+                s_tm[j][threadIdx.x] = tm[q];
                 keepmask |= (keep ? 1u : 0u) << j;
                 decay |= (unsigned)dk << (2 * j);
-                if (keep) run_box_accumulate(pc[q], ct[q].w == -2.f ? time : ct[q].w, rlo, rhi, rtime);   // (copy_unstable.vert:131: -2 becomes the time)
+                if (keep) run_box_accumulate(pc[q], ct.w == -2.f ? time : ct.w, rlo, rhi, rtime);   // (copy_unstable.vert:131: -2 becomes the time)
                 const unsigned long long m = __ballot(keep);
                 if (lane == 0) s_cnt[j][wave] = __popcll(m);
             }
             run_box_reduce(rlo, rhi, rtime, s_red[sr]);
         }
+        // The OTHER half of every surviving record (colour word + the unused word, normal + radius) is requested now: the loads travel while
+        // the workgroup waits for its place in the output.
+        float2 cus[kCleanPerThread];
+        float4 nrs[kCleanPerThread];
+#pragma unroll
+        for (int j = 0; j < kCleanPerThread; ++j) {
+            cus[j] = make_float2(0, 0); nrs[j] = make_float4(0, 0, 0, 0);
+            if ((keepmask >> j) & 1u) {
+                const int i = first + 256 * j;
+                const float4* rec1 = i < count ? &a.src.ct[i] : &a.cand_rec[(i - count) * 3 + 1];
+                cus[j] = *reinterpret_cast<const float2*>(rec1);
+                nrs[j] = i < count ? a.src.nr[i] : a.cand_rec[(i - count) * 3 + 2];
+            }
+        }
         __syncthreads();
+        MF_PROF_T(t_2);
         if (wave == 0) {
             int tot = 0;
 #pragma unroll
@@ -1061,22 +1103,21 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
             }
         }
         __syncthreads();
-        // ---- sweep 2: copy.  The survivors' records are read again (the chunk's 96 KB are a few microseconds old) and go to their final slots
+        MF_PROF_T(t_3);
+        // ---- sweep 2: the survivors go to their final slots, in order
         int off = s_base;
-#pragma unroll 2
+#pragma unroll
         for (int j = 0; j < kCleanPerThread; ++j) {
             const bool keep = (keepmask >> j) & 1u;
             const unsigned long long m = __ballot(keep);
             int o = off + lane_rank(m);
             for (int w = 0; w < wave; ++w) o += s_cnt[j][w];
             if (keep && o < a.dst.cap) {
-                const int i = first + 256 * j;
-                float4 pc, ct, nr;
-                if (i < count) { pc = a.src.pc[i]; ct = a.src.ct[i]; nr = a.src.nr[i]; }
-                else { const int c = i - count; pc = a.cand_rec[c * 3 + 0]; ct = a.cand_rec[c * 3 + 1]; nr = a.cand_rec[c * 3 + 2]; }
+                float4 pc = s_pc[j][threadIdx.x];
+                const float2 tm = s_tm[j][threadIdx.x];
                 pc.w = clean_decayed(a, pc.w, (int)((decay >> (2 * j)) & 3u));
-                if (ct.w == -2.f) ct.w = time;  // copy_unstable.vert:131
-                a.dst.pc[o] = pc; a.dst.ct[o] = ct; a.dst.nr[o] = nr;
+                const float4 ct = make_float4(cus[j].x, cus[j].y, tm.x, tm.y == -2.f ? time : tm.y);   // copy_unstable.vert:131
+                a.dst.pc[o] = pc; a.dst.ct[o] = ct; a.dst.nr[o] = nrs[j];
                 if (bbox_on && pc.w > a.confThreshold) {   // draw_global_surface.vert:55 (unstable == 0), :69-78
                     const int x = (int)(1000.f * pc.x), y = (int)(1000.f * pc.y), z = (int)(1000.f * pc.z);
                     bmin[0] = min(bmin[0], x); bmin[1] = min(bmin[1], y); bmin[2] = min(bmin[2], z);
@@ -1086,6 +1127,14 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
             off += s_cnt[j][0] + s_cnt[j][1] + s_cnt[j][2] + s_cnt[j][3];
         }
         __syncthreads();   // s_chunk / s_cnt / s_base / s_red are rewritten by the next round
+#ifdef MF_CLEAN_PROF
+        if (threadIdx.x == 0 && a.maskID == 0 && chunk < (1 << 16)) {
+            const unsigned long long t_4 = wall_clock64();
+            unsigned* o = g_clean_prof[chunk];
+            o[0] = (unsigned)t_0; o[1] = (unsigned)(t_1 - t_0); o[2] = (unsigned)(t_2 - t_1); o[3] = (unsigned)(t_3 - t_2); o[4] = (unsigned)(t_4 - t_3);
+            o[5] = blockIdx.x; o[6] = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xF; o[7] = (unsigned)s_base;
+        }
+#endif
     }
     if (bbox_on) {
 #pragma unroll
@@ -1117,180 +1166,30 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
                     __hip_atomic_store(&a.frame->bbox_tmp[q], q < 3 ? kBBoxEmptyMin : kBBoxEmptyMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            for (int g = 0; g < kCleanTicketLanes; ++g) __hip_atomic_store(&a.ctl[kTicketBase + g * a.ticket_stride], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int g = 0; g < kCleanTicketLanes; ++g) __hip_atomic_store(&a.ctl[kTicketBase + g * kTicketStride], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(done64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
 
 __global__ __launch_bounds__(256) void k_clean(const CleanArgs a) { clean_body(a); }
-
-// ------------------------------------------------------------------------------------------------
-// EXPERIMENT (round 5): the one-launch clean with the chunk's records HELD in registers between test and copy (each record is read once:
-// 96 B per surfel instead of 144), chunks of 1024, the next ticket drawn while the current chunk is worked on.
-// ------------------------------------------------------------------------------------------------
-constexpr int kHeldPerThread = 4;
-constexpr int kHeldChunk = 256 * kHeldPerThread;
-constexpr int kHeldSubRuns = kHeldChunk / kRun;
-static_assert(kHeldChunk % kRun == 0, "runs are whole slices of a chunk");
-
-__device__ __forceinline__ void clean_held_body(const CleanArgs& a) {
-    __shared__ int s_chunk[2], s_base;
-    __shared__ int s_cnt[kHeldPerThread][4];
-    __shared__ int s_bb[6];
-    __shared__ int s_red[kHeldSubRuns][4][8];
-    const bool bbox_on = a.maskID != 0;
-    int bmin[3] = {kBBoxEmptyMin, kBBoxEmptyMin, kBBoxEmptyMin}, bmax[3] = {kBBoxEmptyMax, kBBoxEmptyMax, kBBoxEmptyMax};
-    if (bbox_on && threadIdx.x < 6) s_bb[threadIdx.x] = threadIdx.x < 3 ? kBBoxEmptyMin : kBBoxEmptyMax;
-    const int count = a.frame->count;
-    const int total = count + cand_count(a.W, a.H, a.frame->tick);
-    const int nchunks = (total + kHeldChunk - 1) / kHeldChunk;
-    const float time = (float)a.frame->tick;
-    float Ri[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) Ri[q] = a.pose->Ri[q];
-    const float3 ti = f3(a.pose->ti[0], a.pose->ti[1], a.pose->ti[2]);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int lanes = a.ticket_lanes;
-    const int tlane = (int)(blockIdx.x % lanes);
-    int* const ticket = &a.ctl[kTicketBase + tlane * a.ticket_stride];
-    int wg_kept = 0;
-    int next = 0;
-    if (threadIdx.x == 0) next = tlane + lanes * atomicAdd(ticket, 1);
-    for (int round = 0;; ++round) {
-        if (threadIdx.x == 0) s_chunk[round & 1] = next;
-        __syncthreads();
-        const int chunk = s_chunk[round & 1];
-        if (chunk >= nchunks) break;
-        // the ticket of the NEXT round is requested now: its round trip (device-scope atomic) is hidden behind this chunk's work.  (A workgroup
-        // holds at most one chunk beyond the one it works on; the lowest unfinished chunk is always somebody's current one or not yet drawn.)
-        if (threadIdx.x == 0) next = tlane + lanes * atomicAdd(ticket, 1);
-        const int first = chunk * kHeldChunk + (int)threadIdx.x;
-        float4 pc[kHeldPerThread], ct[kHeldPerThread], nr[kHeldPerThread];
-        bool live[kHeldPerThread];
-#pragma unroll
-        for (int j = 0; j < kHeldPerThread; ++j) {
-            const int i = first + 256 * j;
-            live[j] = i < total;
-            pc[j] = ct[j] = nr[j] = make_float4(0, 0, 0, 0);
-            if (i < count) { pc[j] = a.src.pc[i]; ct[j] = a.src.ct[i]; nr[j] = a.src.nr[i]; }
-            else if (live[j]) {
-                const int c = i - count;
-                live[j] = a.cand_op[c] == 2;
-                if (live[j]) { pc[j] = a.cand_rec[c * 3 + 0]; ct[j] = a.cand_rec[c * 3 + 1]; nr[j] = a.cand_rec[c * 3 + 2]; }
-            }
-        }
-        unsigned keepmask = 0u;
-#pragma unroll
-        for (int sr = 0; sr < kHeldSubRuns; ++sr) {
-            int rlo[3] = {kBoxEmptyMin, kBoxEmptyMin, kBoxEmptyMin}, rhi[3] = {kBoxEmptyMax, kBoxEmptyMax, kBoxEmptyMax}, rtime = kBoxEmptyMax;
-#pragma unroll
-            for (int q = 0; q < kSlicesPerRun; ++q) {
-                const int j = sr * kSlicesPerRun + q;
-                float nc = 0.f;
-                int dk = 0;
-                const bool keep = live[j] && clean_test(a, pc[j], ct[j], nr[j], time, Ri, ti, nc, dk);
-                if (a.flags) {
-                    const int i = first + 256 * j;
-                    if (i < total) { a.flags[i] = keep ? 1 : 0; a.newconf[i] = live[j] ? nc : 0.f; }
-                }
-                pc[j].w = nc;                                // the record as it is written: decayed confidence (copy_unstable.vert:139-156),
-                if (ct[j].w == -2.f) ct[j].w = time;         // -2 becomes the time (:131)
-                keepmask |= (keep ? 1u : 0u) << j;
-                if (keep) run_box_accumulate(pc[j], ct[j].w, rlo, rhi, rtime);
-                const unsigned long long m = __ballot(keep);
-                if (lane == 0) s_cnt[j][wave] = __popcll(m);
-            }
-            run_box_reduce(rlo, rhi, rtime, s_red[sr]);
-        }
-        __syncthreads();
-        if (wave == 0) {
-            int tot = 0;
-#pragma unroll
-            for (int j = 0; j < kHeldPerThread; ++j) tot += s_cnt[j][0] + s_cnt[j][1] + s_cnt[j][2] + s_cnt[j][3];
-            const unsigned long long tag = (unsigned long long)a.epoch << 34;
-            int excl = 0, gave_up = 0;
-            if (chunk > 0) {
-                if (lane == 0) scan_store(&a.scan_state[chunk], tag | ((unsigned long long)kScanAggregate << 32) | (unsigned)tot);
-                excl = scan_look_back(a.scan_state, chunk, a.epoch, gave_up);
-            }
-            if (lane == 0) {
-                scan_store(&a.scan_state[chunk], tag | ((unsigned long long)kScanInclusive << 32) | (unsigned)(excl + tot));
-                s_base = excl;
-                wg_kept += tot;
-                if (gave_up) a.frame->pad[2] = 1;
-                int start = excl;
-                for (int sr = 0; sr < kHeldSubRuns; ++sr) {
-                    run_box_store(a.dst.box, chunk * kHeldSubRuns + sr, min(start, a.dst.cap), s_red[sr]);
-                    for (int q = 0; q < kSlicesPerRun; ++q) {
-                        const int j = sr * kSlicesPerRun + q;
-                        start += s_cnt[j][0] + s_cnt[j][1] + s_cnt[j][2] + s_cnt[j][3];
-                    }
-                }
-                if (chunk == nchunks - 1) a.dst.box[2 * nchunks * kHeldSubRuns + 1] = make_int4(0, 0, 0, min(excl + tot, a.dst.cap));
-            }
-        }
-        __syncthreads();
-        int off = s_base;
-#pragma unroll
-        for (int j = 0; j < kHeldPerThread; ++j) {
-            const bool keep = (keepmask >> j) & 1u;
-            const unsigned long long m = __ballot(keep);
-            int o = off + lane_rank(m);
-            for (int w = 0; w < wave; ++w) o += s_cnt[j][w];
-            if (keep && o < a.dst.cap) {
-                a.dst.pc[o] = pc[j]; a.dst.ct[o] = ct[j]; a.dst.nr[o] = nr[j];
-                if (bbox_on && pc[j].w > a.confThreshold) {
-                    const int x = (int)(1000.f * pc[j].x), y = (int)(1000.f * pc[j].y), z = (int)(1000.f * pc[j].z);
-                    bmin[0] = min(bmin[0], x); bmin[1] = min(bmin[1], y); bmin[2] = min(bmin[2], z);
-                    bmax[0] = max(bmax[0], x); bmax[1] = max(bmax[1], y); bmax[2] = max(bmax[2], z);
-                }
-            }
-            off += s_cnt[j][0] + s_cnt[j][1] + s_cnt[j][2] + s_cnt[j][3];
-        }
-        __syncthreads();
-    }
-    if (bbox_on) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            if (bmin[q] != kBBoxEmptyMin) atomicMin(&s_bb[q], bmin[q]);
-            if (bmax[q] != kBBoxEmptyMax) atomicMax(&s_bb[3 + q], bmax[q]);
-        }
-        __syncthreads();
-        if (threadIdx.x < 3 && s_bb[threadIdx.x] != kBBoxEmptyMin) atomicMin(&a.frame->bbox_tmp[threadIdx.x], s_bb[threadIdx.x]);
-        else if (threadIdx.x >= 3 && threadIdx.x < 6 && s_bb[threadIdx.x] != kBBoxEmptyMax) atomicMax(&a.frame->bbox_tmp[threadIdx.x], s_bb[threadIdx.x]);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long* done64 = reinterpret_cast<unsigned long long*>(a.ctl + 2);
-        const unsigned long long old = atomicAdd(done64, (1ull << 32) | (unsigned long long)(unsigned)wg_kept);
-        if ((unsigned)(old >> 32) == gridDim.x - 1u) {
-            const int n = min((int)(unsigned)(old & 0xFFFFFFFFull) + wg_kept, a.dst.cap);
-            a.frame->countNext = n;
-            a.frame->count = n;
-            a.frame->runs = nchunks * kHeldSubRuns;
-            if (a.host_count) *a.host_count = n;
-            if (bbox_on) {
-                for (int q = 0; q < 6; ++q) {
-                    a.frame->bbox_acc[q] = __hip_atomic_load(&a.frame->bbox_tmp[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&a.frame->bbox_tmp[q], q < 3 ? kBBoxEmptyMin : kBBoxEmptyMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            for (int g = 0; g < kCleanTicketLanes; ++g) __hip_atomic_store(&a.ctl[kTicketBase + g * a.ticket_stride], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(done64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+#ifdef MF_CLEAN_PROF
+}  // namespace mf
+extern "C" int mf_debug_clean_prof(unsigned* out, int chunks) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mf::g_clean_prof), (size_t)chunks * 32) == hipSuccess ? 0 : -1;
 }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_clean_held(const CleanArgs a) { clean_held_body(a); }
+namespace mf {
+#endif
 
 // workgroups of a clean launch for `elements` elements (an upper bound or an estimate: the chunks are drawn from a ticket counter, any
 // grid covers any count)
 int clean_grid(long elements) {
-    const long chunks = (elements + kHeldChunk - 1) / kHeldChunk;
+    const long chunks = (elements + kCleanChunk - 1) / kCleanChunk;
     return (int)(chunks < kCleanTicketLanes ? kCleanTicketLanes : (chunks > kCleanGridMax ? kCleanGridMax : chunks));
 }
-size_t clean_scan_entries(long max_elements) { return (size_t)((max_elements + kHeldChunk - 1) / kHeldChunk + 1); }
-static_assert(kTicketBase + kCleanTicketLanes * kTicketStrideMax <= kCleanCtlInts, "ticket counters fit the control block");
+size_t clean_scan_entries(long max_elements) { return (size_t)((max_elements + kCleanChunk - 1) / kCleanChunk + 1); }
+static_assert(kTicketBase + kCleanTicketLanes * kTicketStride <= kCleanCtlInts, "ticket counters fit the control block");
 
 // ------------------------------------------------------------------------------------------------
 // splat prediction: scatter (per-surfel sprite loop, ray-disc test, 64-bit atomicMin) + resolve
@@ -1471,9 +1370,8 @@ void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose
                   float confThreshold, float outlierCoeff, int maskID, const int* index, const float4* vc, const float4* ct,
                   const float4* packed, const float* depthF, const uint8_t* mask, const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags,
                   float* newconf, int* block_counts, unsigned long long* scan_state, int* ctl, unsigned epoch, int blocks, int ticket_lanes,
-                  int* host_count_mirror, bool transposed, bool literalWindow, bool small_map, hipStream_t s, int ticket_stride, bool held) {
+                  int* host_count_mirror, bool transposed, bool literalWindow, bool small_map, hipStream_t s) {
     CleanArgs a;
-    a.ticket_stride = ticket_stride;
     a.transposed = transposed ? 1 : 0;
     a.literal = literalWindow ? 1 : 0;
     a.src = src; a.dst = dst; a.frame = frame; a.pose = pose; a.W = W; a.H = H; a.k = k; a.timeDelta = timeDelta;
@@ -1533,7 +1431,7 @@ __device__ __forceinline__ CleanArgs obj_clean_args(const ObjBatch& b, const Obj
     a.index = m.index; a.vc = m.ivc; a.ct = nullptr; a.packed = m.iclean; a.depthF = b.depthF; a.mask = b.mask;
     a.cand_op = m.cand_op; a.cand_rec = m.cand_rec; a.flags = b.cleanSmall ? m.flags : nullptr; a.newconf = b.cleanSmall ? m.newconf : nullptr;
     a.block_counts = m.block_counts; a.host_count = m.host_count;
-    a.scan_state = m.scan_state; a.ctl = m.clean_ctl; a.epoch = b.cleanEpoch; a.ticket_lanes = b.cleanTicketLanes; a.ticket_stride = b.cleanTicketStride;
+    a.scan_state = m.scan_state; a.ctl = m.clean_ctl; a.epoch = b.cleanEpoch; a.ticket_lanes = b.cleanTicketLanes;
     return a;
 }
 __global__ __launch_bounds__(256) void k_obj_clean(const ObjBatch b) { clean_body(obj_clean_args(b, b.m[blockIdx.z])); }

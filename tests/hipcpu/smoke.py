@@ -262,15 +262,12 @@ def map_forms(n=6, W=160, H=120):
     f = 528.0 * W / 640.0
     st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
     frames = [st.frame(k) for k in range(n)]
-    forms = {"copy_two_launch": (1 << 30, 1 << 30, 0), "in_place_two_launch": (1 << 30, 0, 0), "in_place_one_launch": (0, 0, 0), "held": (0, 0, 1)}
+    forms = {"copy_two_launch": (1 << 30, 1 << 30), "in_place_two_launch": (1 << 30, 0), "in_place_one_launch": (0, 0)}
     out = {}
-    for name, (big, in_place, held) in forms.items():
+    for name, (big, in_place) in forms.items():
         mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=False, numGSurfels=1 << 17)
         mf.setParam("bigMapElements", big)
         mf.setParam("inPlaceElements", in_place)
-        mf.setParam("cleanHeld", held)
-        if held:
-            mf.setParam("cleanTicketStride", 1024)
         poses = []
         for k, (rgb, d, _) in enumerate(frames):
             mf.processFrame(rgb, d, timestamp=k)

@@ -444,7 +444,7 @@ def test_clean_forms_agree(hip, multi):
     st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True, n_objects=3 if multi else 0, object_motion=0.0)
     frames = [st.frame(k) for k in range(12)]
 
-    def run(big, in_place, held=0):
+    def run(big, in_place):
         mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=multi, numGSurfels=1 << 19, numOSurfels=1 << 16,
                         modelSpawnOffset=2, trackAllModels=False, initConfidenceGlobal=10.0, initConfidenceObject=0.01)
         if multi:
@@ -453,7 +453,6 @@ def test_clean_forms_agree(hip, multi):
                 mf.setParam(k, v)
         mf.setParam("bigMapElements", big)
         mf.setParam("inPlaceElements", in_place)
-        mf.setParam("cleanHeld", held)
         poses = []
         for k, (rgb, d, m) in enumerate(frames):
             mf.processFrame(rgb, d, mask=m if multi else None, classIDs=[0, 41, 42, 43] if multi else (), timestamp=k)
@@ -465,7 +464,7 @@ def test_clean_forms_agree(hip, multi):
         return out
 
     a = run(0, 0)
-    for b in (run(1 << 30, 1 << 30), run(1 << 30, 0), run(0, 0, held=1)):
+    for b in (run(1 << 30, 1 << 30), run(1 << 30, 0)):
         assert a["ids"] == b["ids"] and a["counts"] == b["counts"], (a["ids"], b["ids"], a["counts"], b["counts"])
         if multi:
             assert len(a["ids"]) >= 3, a["ids"]     # at least two objects: their passes really were batched

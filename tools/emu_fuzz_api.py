@@ -20,7 +20,7 @@ emu.activate()
 from maskfusion_amd import MaskFusion, synth  # noqa: E402
 from maskfusion_amd.lib import MFError  # noqa: E402
 
-SWITCHES = ["splatTiles", "globalTiles", "gpuLabels", "batchTracking", "earlyBackgroundFusion", "overlapPreprocessing", "cleanLiteralWindow",
+SWITCHES = ["splatTiles", "globalTiles", "gpuLabels", "batchTracking", "earlyBackgroundFusion", "cleanLiteralWindow",
             "timings"]
 
 
@@ -112,7 +112,6 @@ def one(seed, tmp):
         except MFError:
             pass                                                    # an error code is a fine answer to a nonsensical call; a crash is not
     # the context must still work
-    mf.setParam("overlapPreprocessing", 0)
     rgb, d, mask = st.frame(k % 16)
     if multi:
         mf.processFrame(rgb, d, mask=mask, classIDs=[0, 41, 42], timestamp=k + 1)

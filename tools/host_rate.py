@@ -25,11 +25,3 @@ for rep in range(3):
     mf.sync(); t2 = time.perf_counter()
     print("timed burst us/frame", 1e6*(t2-t0)/200, {k: round(v*1e3,1) for k, v in mf.timings().items()})
 mf.enableTimings(False)
-for mode in (0, 1, 0, 1):
-    mf.setParam("overlapPreprocessing", mode)
-    for i in range(30): mf.processFrameDevice(d_rgb[order[i]].data_ptr(), d_depth[order[i]].data_ptr())
-    mf.sync()
-    t0 = time.perf_counter()
-    for i in range(300): mf.processFrameDevice(d_rgb[order[30+i]].data_ptr(), d_depth[order[30+i]].data_ptr())
-    mf.sync(); t2 = time.perf_counter()
-    print("overlap", mode, "us/frame", 1e6*(t2-t0)/300)

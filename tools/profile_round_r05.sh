@@ -37,6 +37,16 @@ timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tm
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/prof_w -o w -- python $REPO/bench.py $B > /tmp/prof_w.log 2>&1
 timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_cf -o f -- $REPO/tools/micro/fetch_calib > /tmp/prof_cf.log 2>&1
 timeout 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/prof_cw -o w -- $REPO/tools/micro/fetch_calib > /tmp/prof_cw.log 2>&1
+# SQ / TCC / TCP counters of the configs[4] frame (what the waves of each kernel do with their time, L2 hit rate): three more passes
+for P in "sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
+         "sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM" \
+         "tcc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
+  set -- $P; n=$1; shift
+  rm -rf /tmp/prof_$n
+  timeout 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/prof_$n -o p -- python $REPO/bench.py $C4 > /tmp/prof_$n.log 2>&1
+  f=$(find /tmp/prof_$n -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python $REPO/tools/pmc_summary.py $f 30 > $REPO/gpurun_out/${TAG}_c4_pmc_$n.csv || echo "counter pass $n failed"
+done
 python $REPO/tools/pmc_summary.py $(find /tmp/prof_4f -name "*counter_collection.csv" | head -1) 30 > $REPO/gpurun_out/${TAG}_c4_pmc_fetch.csv
 python $REPO/tools/pmc_summary.py $(find /tmp/prof_4w -name "*counter_collection.csv" | head -1) 30 > $REPO/gpurun_out/${TAG}_c4_pmc_write.csv
 python $REPO/tools/pmc_summary.py $(find /tmp/prof_f -name "*counter_collection.csv" | head -1) 4000 > $REPO/gpurun_out/${TAG}_pmc_fetch.csv
@@ -47,6 +57,15 @@ cd $REPO
 TREE="$(git rev-parse --short HEAD 2>/dev/null || cat .tree_id 2>/dev/null)"
 python tools/make_pmc_json.py ${TAG} gpurun_out/${TAG}_pmc_fetch.csv gpurun_out/${TAG}_pmc_write.csv gpurun_out/${TAG}_calib_fetch.csv gpurun_out/${TAG}_calib_write.csv "$TREE" gpurun_out/${TAG}_pmc.json
 python tools/make_pmc_json.py ${TAG}_c4 gpurun_out/${TAG}_c4_pmc_fetch.csv gpurun_out/${TAG}_c4_pmc_write.csv gpurun_out/${TAG}_calib_fetch.csv gpurun_out/${TAG}_calib_write.csv "$TREE" gpurun_out/${TAG}_c4_hbm.json
+# phase times of every chunk of the background's clean pass (instrumented build of mf_surfel.hip, tools/clean_prof.py)
+if [ -f tools/ab/libmaskfusion_amd_prof.so ]; then
+  cp maskfusion_amd/libmaskfusion_amd.so /tmp/lib_product.so
+  cp tools/ab/libmaskfusion_amd_prof.so maskfusion_amd/libmaskfusion_amd.so
+  timeout 300 python tools/clean_prof.py ${TAG} > gpurun_out/${TAG}_clean_prof.txt 2>&1
+  cp /tmp/lib_product.so maskfusion_amd/libmaskfusion_amd.so
+  rm -f gpurun_out/${TAG}_clean_prof.npy
+  cat gpurun_out/${TAG}_clean_prof.txt | head -12
+fi
 tail -3 /tmp/prof_4f.log | cut -c1-200
 cut -c1-300 gpurun_out/${TAG}_bench.json
 cut -c1-300 gpurun_out/${TAG}_bench_c4.json
