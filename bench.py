@@ -194,11 +194,21 @@ def measured_copy_ceiling(dev, mib=1024, reps=10):
         return None
 
 
+def _newest_first(paths):
+    """profiles/rNN<letter>_* are the intermediate measurements of round NN in order, profiles/rNN_* its final summary: newest first"""
+    import re
+
+    def key(path):
+        m = re.match(r"r(\d+)([a-z0-9]*)_", os.path.basename(path))
+        return (int(m.group(1)), m.group(2) or "~") if m else (-1, "")
+    return sorted(paths, key=key, reverse=True)
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/r*_pmc.json: separate rocprofv3 --pmc passes,
     gfx950 corrections applied when the file was written; see profiles/README.md).  None when there is no such record."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+    for path in _newest_first(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json"))):
         try:
             doc = json.load(open(path))
             rec = doc["kernels"][kernel]
@@ -353,7 +363,9 @@ def rocprof_rows(names, pattern="r*kernel_stats.csv"):
     import csv
     import glob
     out = {}
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+    for path in _newest_first(glob.glob(os.path.join(ROOT, "profiles", pattern))):
+        if "_c4_" in os.path.basename(path) and "_c4_" not in pattern:      # (the configs[4] summaries are asked for by name)
+            continue
         try:
             rows = list(csv.DictReader(open(path)))
         except Exception:
