@@ -996,8 +996,9 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
     const float3 ti = f3(a.pose->ti[0], a.pose->ti[1], a.pose->ti[2]);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Chunks are handed out by `lanes` (<= kCleanTicketLanes) counters, lane g (= this workgroup's index mod lanes) serving chunks g, g + lanes, ...:
-    // one counter for all chunks made the pass as slow as its ticket -- device-scope atomics on ONE address retire at ~27 ns each on this GPU
-    // (measured, profiles/r05b_*, r05c_*).  Forward progress: a chunk only ever waits for LOWER chunks; the lowest chunk not
+    // one counter serves a ticket every ~11 ns, 32 of them one every 0.5 ns (tools/micro/ticket_lanes.hip).  (Handing the chunks out in blocks of
+    // 4 / 16 / 64 consecutive ones per XCD, so that an XCD's workgroups walk a contiguous piece of the buffer: 1.32 / 1.34 / 1.56 ms against 1.33 --
+    // the memory phases get a little shorter, the waits in the look-back longer.)  Forward progress: a chunk only ever waits for LOWER chunks; the lowest chunk not
     // yet finished is either owned by a running workgroup or next in line on a lane whose workgroups (the first `lanes` workgroups of the
     // grid are dispatched first, one per lane: the host keeps lanes <= the number of compute units) are all working on lower chunks, which finish.
     const int lanes = a.ticket_lanes;

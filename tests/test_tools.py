@@ -40,3 +40,29 @@ def test_host_trace_summary_on_a_fabricated_timeline(tmp_path):
     assert up["start_us_into_the_frame_it_runs_under"]["median"] == 20.0
     lines = tl.read_text().splitlines()
     assert lines[0] == "start_us,end_us,dur_us,what,where" and sum("UPLOAD" in ln for ln in lines) == 6
+
+
+def test_bench_reads_a_rounds_final_profile_before_its_intermediate_ones(tmp_path, monkeypatch):
+    """bench.py's roofline entries cite the newest committed summary: profiles/rNN_* is round NN's final one, rNN<letter>_* came before it
+    (plain reverse alphabetical order put r05e_* ahead of r05_*), and the configs[4] tables are only read when asked for by name."""
+    import csv
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+
+    def table(name, us):
+        with open(prof / name, "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+            w.writerow(["mf::k_clean(mf::CleanArgs)", 10, 10 * us * 1000, us * 1000, 1.0, 1, 1, 0])
+            w.writerow(["void mf::k_icp_iter<512, 3>(mf::IcpKArgs)", 10, 10 * us * 1000, us * 1000, 1.0, 1, 1, 0])
+    for name, us in (("r04_kernel_stats.csv", 4), ("r05e_kernel_stats.csv", 5), ("r05_kernel_stats.csv", 6), ("r05e_c4_kernel_stats.csv", 50), ("r05_c4_kernel_stats.csv", 60),
+                     ("r05_c4_kernel_stats_raw.csv", 70)):
+        table(name, us)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert [os.path.basename(p) for p in bench._newest_first([str(prof / n) for n in ("r04_x.csv", "r05_x.csv", "r05e_x.csv", "r05a_x.csv")])] == \
+        ["r05_x.csv", "r05e_x.csv", "r05a_x.csv", "r04_x.csv"]
+    rows = bench.rocprof_rows(["k_icp_iter<512, 3>"])
+    assert rows["k_icp_iter<512, 3>"]["source"] == "profiles/r05_kernel_stats.csv" and rows["k_icp_iter<512, 3>"]["us"] == 6.0
+    rows = bench.rocprof_rows(["k_clean"], pattern="r*_c4_kernel_stats.csv")
+    assert rows["k_clean"]["source"] == "profiles/r05_c4_kernel_stats.csv" and rows["k_clean"]["us"] == 60.0
