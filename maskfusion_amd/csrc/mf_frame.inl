@@ -208,9 +208,10 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
     const bool small = clean_small(c, m), copy = update_copy(c, m);
     VisList vl;
     const VisList* vis = ensure_vis(c, m, vl);
-    launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, false, s, blocks, vis);
+    // (column-major key images in both index passes of a model handled on its own: index_scatter_one; the resolve of this pass transposes)
+    launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, true, s, blocks, vis);
     launch_index_resolve(m.surf[src], m.d_pose, c->d_keys, W, H, c->d_index, c->d_ivc, c->d_inr, secondIndexPass ? nullptr : c->d_ict,
-                         nullptr, s);
+                         nullptr, true, s);
     if (marks) mark(c, 4);
     // Model::fuse maxDepth uniform: min(depthCutoff, model.maxDepth, bb_max_z) (Model.cpp:527); bb_max_z from the model's bounding box on the device
     launch_fuse_data(d_rgb, d_depth, depthF, mask, m.id, m.d_frame, m.d_pose, weightMultiplier, fminf(fuseDepthCutoff, m.maxDepth), W, H,
@@ -225,15 +226,15 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
                                 g.time_delta, secondIndexPass ? c->d_keys : nullptr, true, s, blocks);
         live = dst;
         if (marks) mark(c, 6);
-        if (secondIndexPass) launch_index_resolve(m.surf[live], m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, s);
+        if (secondIndexPass) launch_index_resolve(m.surf[live], m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, true, s);
     } else {
         // update.vert in place -- only the surfels a candidate merged into are touched (the reference copies the whole buffer,
         // Model.cpp:583-646) --, then the second index pass (over the runs in view where the buffer has a run table)
         launch_fuse_update(m.surf[src], m.d_frame, c->d_upd_first, c->d_cand_op, c->d_cand_best, c->d_cand_rec, W, H, s);
         if (marks) mark(c, 6);
-        if (secondIndexPass) {   // predictIndices on the updated buffer (:556), column-major packed texels for clean's window gathers
+        if (secondIndexPass) {   // predictIndices on the updated buffer (:556); its resolve writes the packed, column-major map of clean's window gathers
             launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, true, s, blocks, vis);
-            launch_index_resolve(m.surf[src], m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, s);
+            launch_index_resolve(m.surf[src], m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, true, s);
         }
     }
     // clean live -> the other buffer: two launches (flags + ordered copy) below big_map_elements, one launch (which also writes the new

@@ -232,7 +232,7 @@ void launch_init_surfels(const uint8_t* rgb, const float* depthRaw, const float*
 constexpr int kSurfelGridBlocks = 2048;
 // vis: nullptr = every surfel; else the runs launch_cull found possibly visible
 void launch_index_scatter(Surfels src, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k,
-                          float maxDepth, int timeDelta, unsigned long long* keys, bool transposed, hipStream_t s,
+                          float maxDepth, int timeDelta, unsigned long long* keys, bool transposed /* column-major key image */, hipStream_t s,
                           int blocks = kSurfelGridBlocks, const VisList* vis = nullptr);
 // run table of s from scratch: fixed runs of kRun slots (after Model::initialise / an uploaded map; the clean pass writes it afterwards)
 void launch_run_table(Surfels s, FrameDev* frame, hipStream_t st);
@@ -243,7 +243,8 @@ void launch_cull(Surfels s, const FrameDev* frame, const PoseDev* pose, int W, i
                  int* ctl, int max_runs, hipStream_t st);
 // packed == nullptr: index / vertConf / normRad (+ colorTime if ct != nullptr) images; else one 32 B record per texel
 void launch_index_resolve(Surfels src, const PoseDev* pose, unsigned long long* keys, int W, int H, int* index,
-                          float4* vc, float4* nr, float4* ct /*or null*/, float4* packed /*or null*/, hipStream_t s);
+                          float4* vc, float4* nr, float4* ct /*or null*/, float4* packed /*or null: the packed column-major map instead of the row-major maps*/,
+                          bool keys_transposed /* the order the scatter used */, hipStream_t s);
 void launch_fuse_data(const uint8_t* rgb, const float* depthRaw, const float* depthF, const uint8_t* mask,
                       int maskID, const FrameDev* frame, const PoseDev* pose, float weightMultiplier, float maxDepth,
                       int W, int H, Intr k, const int* index, const float4* vc, const float4* nr, uint8_t* cand_op,

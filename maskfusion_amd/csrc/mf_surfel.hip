@@ -172,8 +172,11 @@ __device__ __forceinline__ void index_scatter_one(const Surfels& src, int i, boo
             const float u = ((k.fx * h.x) / h.z) + k.cx;
             const float v = ((k.fy * h.y) / h.z) + k.cy;
             if (u >= 0.f && u < (float)W && v >= 0.f && v < (float)H) {
-                // transposed (column-major) texel order for the pass that feeds clean(): surfels are stored in column-major creation
-                // order (data.vert), so consecutive surfels then touch consecutive texels instead of one cache line per image row
+                // transposed: column-major key image.  Surfels are stored in column-major creation order (data.vert), so the surfels of a wavefront
+                // then meet in a few cache lines of keys instead of one line per image row: on the 26.9 M-surfel map of configs[4] the same pass takes
+                // 75 us column-major and 133-168 us row-major (profiles/r05_c4_kernel_stats.csv, r05p_c4_kernel_stats.csv), at VGA the copy-update with
+                // the scatter riding on it 17.4 against 23.2 us.  (The packed object maps of that scenario, ~85 surfels per pixel, behave the other way
+                // round -- 257 against 190 us -- and are scattered row-major.)  The RESOLVE brings the result into the order its consumer reads it in.
                 p = transposed ? (int)floorf(u) * H + (int)floorf(v) : (int)floorf(v) * W + (int)floorf(u);
                 key = ((unsigned long long)__float_as_uint(h.z) << 32) | (unsigned)i;
             }
@@ -357,50 +360,116 @@ void launch_cull(Surfels s, const FrameDev* frame, const PoseDev* pose, int W, i
 //   packed == nullptr (the pass that feeds fuse): index + vertConf + normRad as separate images;
 //   packed != nullptr (the pass that feeds clean): ONE 32 B record per texel {vertConf.xyzw | colorTime.z, colorTime.w,
 //     index bits, 0} -- clean gathers 9 texels per surfel, and three separate images cost it three cache lines per tap.
-__device__ __forceinline__ void index_resolve_body(Surfels src, const PoseDev* __restrict__ pose,
-                                                   unsigned long long* __restrict__ keys, int P, int* __restrict__ index,
-                                                   float4* __restrict__ vc, float4* __restrict__ nr, float4* __restrict__ ct,
-                                                   float4* __restrict__ packed) {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= P) return;
-    const unsigned long long key = keys[p];
-    keys[p] = kEmptyKey;  // ready for the next scatter: saves a separate clear pass
-    if (key == kEmptyKey) {
-        if (packed) { packed[2 * p] = packed[2 * p + 1] = make_float4(0, 0, 0, 0); }
-        else {
-            index[p] = 0; vc[p] = nr[p] = make_float4(0, 0, 0, 0);
-            if (ct) ct[p] = make_float4(0, 0, 0, 0);
-        }
-        return;
-    }
+// Resolve: the winning surfel of every texel -> the maps the consumer reads.  Two consumers, two orders: data.vert's window (fuse_data) reads
+// {index, vertConf, normRad(, colorTime)} row-major; copy_unstable.vert's window (clean) reads the packed map {position, confidence | initTime,
+// lastTime, index, 0} COLUMN-major (surfels are stored in column-major creation order: consecutive surfels then read consecutive texels).  The
+// key image comes in either order too (index_scatter_one).  Where the two orders agree a thread handles texel p of both; where they differ a
+// workgroup handles a 16 x 16-pixel tile and transposes it through the LDS: keys are read and records written in pieces of 128-512 bytes.
+// Every form also resets the key it read (ready for the next scatter: saves a separate clear pass).
+struct ResolvedTexel { int index; float4 vc, nr, ct, p0, p1; };
+template <bool kPacked>
+__device__ __forceinline__ ResolvedTexel resolve_texel(const Surfels& src, const PoseDev* __restrict__ pose, unsigned long long key, bool want_ct) {
+    ResolvedTexel r;
+    r.index = 0;
+    r.vc = r.nr = r.ct = r.p0 = r.p1 = make_float4(0, 0, 0, 0);
+    if (key == kEmptyKey) return r;
     const int i = (int)(unsigned)(key & 0xFFFFFFFFull);
     const float4 pc = src.pc[i];
     const float3 h = mul33(pose->Ri, f3(pc.x, pc.y, pc.z)) + f3(pose->ti[0], pose->ti[1], pose->ti[2]);
-    if (packed) {
+    if (kPacked) {
         const float4 c4 = src.ct[i];
-        packed[2 * p] = make_float4(h.x, h.y, h.z, pc.w);
-        packed[2 * p + 1] = make_float4(c4.z, c4.w, __int_as_float(i), 0.f);
+        r.p0 = make_float4(h.x, h.y, h.z, pc.w);
+        r.p1 = make_float4(c4.z, c4.w, __int_as_float(i), 0.f);
     } else {
         const float4 n4 = src.nr[i];
         const float3 n = normalize_gl(mul33(pose->Ri, f3(n4.x, n4.y, n4.z)));
-        index[p] = i;
-        vc[p] = make_float4(h.x, h.y, h.z, pc.w);
-        nr[p] = make_float4(n.x, n.y, n.z, n4.w);
-        if (ct) ct[p] = src.ct[i];   // colorTime image: only the clean pass of a freshly spawned model reads it from here
+        r.index = i;
+        r.vc = make_float4(h.x, h.y, h.z, pc.w);
+        r.nr = make_float4(n.x, n.y, n.z, n4.w);
+        if (want_ct) r.ct = src.ct[i];   // colorTime image: only the clean pass of a freshly spawned model reads it from here
+    }
+    return r;
+}
+struct ResolveOut { int* index; float4* vc; float4* nr; float4* ct; float4* packed; };
+
+// keys and outputs in the same order (row-major keys -> maps, column-major keys -> packed): texel p of the key image is texel p of the output
+template <bool kPacked>
+__device__ __forceinline__ void index_resolve_same_body(Surfels src, const PoseDev* __restrict__ pose, unsigned long long* __restrict__ keys, int P, ResolveOut o) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const unsigned long long key = keys[p];
+    keys[p] = kEmptyKey;
+    const ResolvedTexel r = resolve_texel<kPacked>(src, pose, key, o.ct != nullptr);
+    if (kPacked) { o.packed[2 * p] = r.p0; o.packed[2 * p + 1] = r.p1; }
+    else {
+        o.index[p] = r.index; o.vc[p] = r.vc; o.nr[p] = r.nr;
+        if (o.ct) o.ct[p] = r.ct;
     }
 }
-
-__global__ __launch_bounds__(256) void k_index_resolve(Surfels src, const PoseDev* __restrict__ pose,
-                                                       unsigned long long* __restrict__ keys, int P, int* __restrict__ index,
-                                                       float4* __restrict__ vc, float4* __restrict__ nr, float4* __restrict__ ct,
-                                                       float4* __restrict__ packed) {
-    index_resolve_body(src, pose, keys, P, index, vc, nr, ct, packed);
+// keys and outputs in different orders (column-major keys -> row-major maps, row-major keys -> column-major packed map): one tile per workgroup
+constexpr int kResolveTile = 16;
+template <bool kPacked>
+__device__ __forceinline__ void index_resolve_transposing_body(Surfels src, const PoseDev* __restrict__ pose, unsigned long long* __restrict__ keys, int W, int H,
+                                                               ResolveOut o, int tile) {
+    __shared__ float4 s_a[kResolveTile][kResolveTile + 1], s_b[kResolveTile][kResolveTile + 1], s_c[kPacked ? 1 : kResolveTile][kResolveTile + 1];
+    __shared__ int s_i[kPacked ? 1 : kResolveTile][kResolveTile + 1];
+    const int tilesX = (W + kResolveTile - 1) / kResolveTile;
+    const int x0 = (tile % tilesX) * kResolveTile, y0 = (tile / tilesX) * kResolveTile;
+    const int f = threadIdx.x & (kResolveTile - 1), g = threadIdx.x / kResolveTile;   // f: the fast coordinate of consecutive lanes
+    {   // read the keys in THEIR order: packed output <- row-major keys (x fast), maps <- column-major keys (y fast)
+        const int lx = kPacked ? f : g, ly = kPacked ? g : f;
+        const int x = x0 + lx, y = y0 + ly;
+        ResolvedTexel r = resolve_texel<kPacked>(src, pose, kEmptyKey, false);
+        if (x < W && y < H) {
+            const int p = kPacked ? y * W + x : x * H + y;
+            const unsigned long long key = keys[p];
+            keys[p] = kEmptyKey;
+            r = resolve_texel<kPacked>(src, pose, key, o.ct != nullptr);
+        }
+        if (kPacked) { s_a[lx][ly] = r.p0; s_b[lx][ly] = r.p1; }
+        else { s_i[lx][ly] = r.index; s_a[lx][ly] = r.vc; s_b[lx][ly] = r.nr; if (o.ct) s_c[lx][ly] = r.ct; }
+    }
+    __syncthreads();
+    {   // write the outputs in THEIR order: packed column-major (y fast), maps row-major (x fast)
+        const int lx = kPacked ? g : f, ly = kPacked ? f : g;
+        const int x = x0 + lx, y = y0 + ly;
+        if (x < W && y < H) {
+            if (kPacked) {
+                const int tp = x * H + y;
+                o.packed[2 * tp] = s_a[lx][ly];
+                o.packed[2 * tp + 1] = s_b[lx][ly];
+            } else {
+                const int p = y * W + x;
+                o.index[p] = s_i[lx][ly]; o.vc[p] = s_a[lx][ly]; o.nr[p] = s_b[lx][ly];
+                if (o.ct) o.ct[p] = s_c[lx][ly];
+            }
+        }
+    }
 }
+template <bool kPacked>
+__global__ __launch_bounds__(256) void k_index_resolve(Surfels src, const PoseDev* __restrict__ pose, unsigned long long* __restrict__ keys, int P, ResolveOut o) {
+    index_resolve_same_body<kPacked>(src, pose, keys, P, o);
+}
+template <bool kPacked>
+__global__ __launch_bounds__(256) void k_index_resolve_transposing(Surfels src, const PoseDev* __restrict__ pose, unsigned long long* __restrict__ keys, int W, int H,
+                                                                   ResolveOut o) {
+    index_resolve_transposing_body<kPacked>(src, pose, keys, W, H, o, (int)blockIdx.x);
+}
+int resolve_tiles(int W, int H) { return ((W + kResolveTile - 1) / kResolveTile) * ((H + kResolveTile - 1) / kResolveTile); }
 
+// packed != nullptr: the packed column-major map (index / vc / nr / ct unused); else the row-major maps.  keys_transposed: the order the scatter used.
 void launch_index_resolve(Surfels src, const PoseDev* pose, unsigned long long* keys, int W, int H, int* index, float4* vc,
-                          float4* nr, float4* ct, float4* packed, hipStream_t s) {
+                          float4* nr, float4* ct, float4* packed, bool keys_transposed, hipStream_t s) {
     const int P = W * H;
-    hipLaunchKernelGGL(k_index_resolve, dim3((P + 255) / 256), dim3(256), 0, s, src, pose, keys, P, index, vc, nr, ct, packed);
+    const ResolveOut o{index, vc, nr, ct, packed};
+    const dim3 flat((P + 255) / 256), tiles(resolve_tiles(W, H));
+    if (packed) {
+        if (keys_transposed) hipLaunchKernelGGL(k_index_resolve<true>, flat, dim3(256), 0, s, src, pose, keys, P, o);
+        else hipLaunchKernelGGL(k_index_resolve_transposing<true>, tiles, dim3(256), 0, s, src, pose, keys, W, H, o);
+    } else {
+        if (keys_transposed) hipLaunchKernelGGL(k_index_resolve_transposing<false>, tiles, dim3(256), 0, s, src, pose, keys, W, H, o);
+        else hipLaunchKernelGGL(k_index_resolve<false>, flat, dim3(256), 0, s, src, pose, keys, P, o);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1399,10 +1468,13 @@ __global__ __launch_bounds__(256) void k_obj_index_scatter(const ObjBatch b) {
     const ObjPassArgs& m = b.m[blockIdx.z];
     index_scatter_body(m.a, m.frame, m.pose, b.W, b.H, b.k, b.maxDepthProcessed, b.timeDelta, m.keys, 0, nullptr, nullptr, true);
 }
-__global__ __launch_bounds__(256) void k_obj_index_resolve(const ObjBatch b, int second) {
+__global__ __launch_bounds__(256) void k_obj_index_resolve(const ObjBatch b) {   // (the object models' keys are row-major in both passes)
     const ObjPassArgs& m = b.m[blockIdx.z];
-    if (!second) index_resolve_body(m.a, m.pose, m.keys, b.W * b.H, m.index, m.ivc, m.inr, nullptr, nullptr);
-    else index_resolve_body(b.updateCopy ? m.b : m.a, m.pose, m.keys, b.W * b.H, nullptr, nullptr, nullptr, nullptr, m.iclean);
+    index_resolve_same_body<false>(m.a, m.pose, m.keys, b.W * b.H, ResolveOut{m.index, m.ivc, m.inr, nullptr, nullptr});
+}
+__global__ __launch_bounds__(256) void k_obj_index_resolve_packed(const ObjBatch b) {   // the pass that feeds clean(): grid.x = 16 x 16-pixel tiles
+    const ObjPassArgs& m = b.m[blockIdx.z];
+    index_resolve_transposing_body<true>(b.updateCopy ? m.b : m.a, m.pose, m.keys, b.W, b.H, ResolveOut{nullptr, nullptr, nullptr, nullptr, m.iclean}, (int)blockIdx.x);
 }
 __global__ __launch_bounds__(256) void k_obj_fuse_data(const ObjBatch b) {
     const ObjPassArgs& m = b.m[blockIdx.z];
@@ -1416,12 +1488,8 @@ __global__ __launch_bounds__(256) void k_obj_fuse_update(const ObjBatch b) {
 }
 __global__ __launch_bounds__(256) void k_obj_fuse_update_copy(const ObjBatch b) {   // small models: a -> b with the second index scatter riding
     const ObjPassArgs& m = b.m[blockIdx.z];
-    const IndexScatterArgs ix{m.pose, b.W, b.H, b.k, b.maxDepthProcessed, b.timeDelta, m.keys, 1};
+    const IndexScatterArgs ix{m.pose, b.W, b.H, b.k, b.maxDepthProcessed, b.timeDelta, m.keys, 0};
     fuse_update_copy_body(m.a, m.b, m.frame, m.upd_first, m.cand_rec, ix);
-}
-__global__ __launch_bounds__(256) void k_obj_index_scatter2(const ObjBatch b) {   // predictIndices after fuse (MaskFusion.cpp:556), column-major texels
-    const ObjPassArgs& m = b.m[blockIdx.z];
-    index_scatter_body(m.a, m.frame, m.pose, b.W, b.H, b.k, b.maxDepthProcessed, b.timeDelta, m.keys, 1, nullptr, nullptr, true);
 }
 __device__ __forceinline__ CleanArgs obj_clean_args(const ObjBatch& b, const ObjPassArgs& m) {
     CleanArgs a;
@@ -1456,15 +1524,15 @@ void launch_obj_fuse_clean(const ObjBatch& b, int blocks, int clean_blocks, hipS
     const dim3 surfels(blocks, 1, b.n), pixels((P + 255) / 256, 1, b.n), compact(clean_blocks, 1, b.n);
     const dim3 cands(((b.W + 1) / 2 + 63) / 64, ((b.H + 1) / 2 + 3) / 4, b.n);
     hipLaunchKernelGGL(k_obj_index_scatter, surfels, dim3(256), 0, s, b);
-    hipLaunchKernelGGL(k_obj_index_resolve, pixels, dim3(256), 0, s, b, 0);
+    hipLaunchKernelGGL(k_obj_index_resolve, pixels, dim3(256), 0, s, b);
     hipLaunchKernelGGL(k_obj_fuse_data, cands, dim3(256), 0, s, b);
     if (b.updateCopy) {
         hipLaunchKernelGGL(k_obj_fuse_update_copy, surfels, dim3(256), 0, s, b);
     } else {
         hipLaunchKernelGGL(k_obj_fuse_update, dim3(cand_blocks(b.W, b.H), 1, b.n), dim3(256), 0, s, b);
-        hipLaunchKernelGGL(k_obj_index_scatter2, surfels, dim3(256), 0, s, b);
+        hipLaunchKernelGGL(k_obj_index_scatter, surfels, dim3(256), 0, s, b);   // predictIndices after fuse (MaskFusion.cpp:556): the same pass on the updated buffer
     }
-    hipLaunchKernelGGL(k_obj_index_resolve, pixels, dim3(256), 0, s, b, 1);
+    hipLaunchKernelGGL(k_obj_index_resolve_packed, dim3(resolve_tiles(b.W, b.H), 1, b.n), dim3(256), 0, s, b);
     if (b.cleanSmall) {
         hipLaunchKernelGGL(k_obj_clean_small_flags, dim3(kCompactBlocks, 1, b.n), dim3(256), 0, s, b);
         hipLaunchKernelGGL(k_obj_clean_small_compact, dim3(kCompactBlocks, 1, b.n), dim3(256), 0, s, b);

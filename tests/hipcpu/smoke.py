@@ -254,22 +254,25 @@ def host_paths(n=8, W=160, H=120):
     return out
 
 
-def map_forms(n=6, W=160, H=120):
+def map_forms(n=8, W=160, H=120):
     """The three size-dependent forms of a model's fuse / clean passes (mf_frame.inl: enqueue_fuse_clean; by default chosen by the map's size,
     here forced): copy-update + two-launch clean, in-place update + two-launch clean, in-place update + one-launch clean with the decoupled
-    look-back, its run table and the culled projection passes.  Same frames: poses, counts and the cloud's bytes identical."""
+    look-back, its run table and the culled projection passes -- and a run that changes form from frame to frame, as a map does that grows across
+    a threshold (the live buffer alternates or not, the run table comes and goes).  Same frames: poses, counts and the cloud's bytes identical."""
     import hashlib
     f = 528.0 * W / 640.0
     st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
     frames = [st.frame(k) for k in range(n)]
-    forms = {"copy_two_launch": (1 << 30, 1 << 30), "in_place_two_launch": (1 << 30, 0), "in_place_one_launch": (0, 0)}
+    forms = {"copy_two_launch": (1 << 30, 1 << 30), "in_place_two_launch": (1 << 30, 0), "in_place_one_launch": (0, 0), "changing": None}
+    cycle = [(1 << 30, 1 << 30), (0, 0), (1 << 30, 0), (0, 0), (1 << 30, 1 << 30), (1 << 30, 0)]   # a map that crosses the thresholds from frame to frame
     out = {}
-    for name, (big, in_place) in forms.items():
+    for name, form in forms.items():
         mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=False, numGSurfels=1 << 17)
-        mf.setParam("bigMapElements", big)
-        mf.setParam("inPlaceElements", in_place)
         poses = []
         for k, (rgb, d, _) in enumerate(frames):
+            big, in_place = form if form else cycle[k % len(cycle)]
+            mf.setParam("bigMapElements", big)
+            mf.setParam("inPlaceElements", in_place)
             mf.processFrame(rgb, d, timestamp=k)
             poses.append(mf.getCurrPose().reshape(-1).tolist())
         cloud = np.ascontiguousarray(mf.getBackgroundModel().downloadMap())

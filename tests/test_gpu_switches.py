@@ -438,13 +438,15 @@ def test_clean_forms_agree(hip, multi):
     `bigMapElements` update.vert in place + the two-launch clean; above, update.vert in place + clean in one launch with a decoupled look-back
     (which also writes the run table the projection passes cull by).  The same frames through all three: model list, counts, every surfel
     of every model in its slot, poses and label images bit-identical -- single model, and background + object models (whose passes are
-    batched: one launch per pass for all of them)."""
+    batched: one launch per pass for all of them) --, and through a run that changes form from frame to frame."""
     from maskfusion_amd import MaskFusion, synth
     W, H, f = 320, 240, 264.0
     st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True, n_objects=3 if multi else 0, object_motion=0.0)
     frames = [st.frame(k) for k in range(12)]
 
-    def run(big, in_place):
+    cycle = [(1 << 30, 1 << 30), (0, 0), (1 << 30, 0), (0, 0), (1 << 30, 1 << 30), (1 << 30, 0)]
+
+    def run(big, in_place, changing=False):
         mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=multi, numGSurfels=1 << 19, numOSurfels=1 << 16,
                         modelSpawnOffset=2, trackAllModels=False, initConfidenceGlobal=10.0, initConfidenceObject=0.01)
         if multi:
@@ -455,6 +457,9 @@ def test_clean_forms_agree(hip, multi):
         mf.setParam("inPlaceElements", in_place)
         poses = []
         for k, (rgb, d, m) in enumerate(frames):
+            if changing:      # a map that crosses the thresholds from frame to frame: the live buffer alternates or not, the run table comes and goes
+                mf.setParam("bigMapElements", cycle[k % len(cycle)][0])
+                mf.setParam("inPlaceElements", cycle[k % len(cycle)][1])
             mf.processFrame(rgb, d, mask=m if multi else None, classIDs=[0, 41, 42, 43] if multi else (), timestamp=k)
             poses.append([x.getPose() for x in mf.getModels()])
         ms = mf.getModels()
@@ -464,7 +469,7 @@ def test_clean_forms_agree(hip, multi):
         return out
 
     a = run(0, 0)
-    for b in (run(1 << 30, 1 << 30), run(1 << 30, 0)):
+    for b in (run(1 << 30, 1 << 30), run(1 << 30, 0), run(0, 0, changing=True)):
         assert a["ids"] == b["ids"] and a["counts"] == b["counts"], (a["ids"], b["ids"], a["counts"], b["counts"])
         if multi:
             assert len(a["ids"]) >= 3, a["ids"]     # at least two objects: their passes really were batched
