@@ -214,7 +214,8 @@ struct mf_ctx {
     std::vector<std::unique_ptr<ModelState>> pool;   // MaskFusion::preallocatedModels (buffers allocated ahead of the spawn)
     unsigned long long* d_keys = nullptr;
     int* d_index = nullptr; float4* d_ivc = nullptr; float4* d_ict = nullptr; float4* d_inr = nullptr;
-    float4* d_iclean = nullptr;            // packed column-major index map of the clean pass: 2 x float4 per texel
+    float4* d_iclean = nullptr;            // packed column-major index map of the clean pass: 2 x float4 per texel (the spare word carries the filtered depth)
+    uint8_t* d_maskT = nullptr;            // the frame's mask in the same column-major order (launch_index_resolve writes it, clean reads it)
     uint8_t* d_cand_op = nullptr; float4* d_cand_rec = nullptr; int* d_upd_first = nullptr;
     uint8_t* d_flags = nullptr; float* d_newconf = nullptr; int* d_block_counts = nullptr;
     int* d_cand_best = nullptr;            // surfel a merge candidate was associated with (fuse_data -> fuse_update)
@@ -519,6 +520,7 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     A(dev_alloc(c, c->allocs, &c->d_ivc, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_ict, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_iclean, (size_t)P * 2));
+    A(dev_alloc(c, c->allocs, &c->d_maskT, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_inr, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_cand_op, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_cand_rec, (size_t)P * 3));

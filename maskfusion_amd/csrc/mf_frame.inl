@@ -211,7 +211,7 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
     // (column-major key images in both index passes of a model handled on its own: index_scatter_one; the resolve of this pass transposes)
     launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, true, s, blocks, vis);
     launch_index_resolve(m.surf[src], m.d_pose, c->d_keys, W, H, c->d_index, c->d_ivc, c->d_inr, secondIndexPass ? nullptr : c->d_ict,
-                         nullptr, true, s);
+                         nullptr, nullptr, nullptr, nullptr, true, s);
     if (marks) mark(c, 4);
     // Model::fuse maxDepth uniform: min(depthCutoff, model.maxDepth, bb_max_z) (Model.cpp:527); bb_max_z from the model's bounding box on the device
     launch_fuse_data(d_rgb, d_depth, depthF, mask, m.id, m.d_frame, m.d_pose, weightMultiplier, fminf(fuseDepthCutoff, m.maxDepth), W, H,
@@ -226,7 +226,7 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
                                 g.time_delta, secondIndexPass ? c->d_keys : nullptr, true, s, blocks);
         live = dst;
         if (marks) mark(c, 6);
-        if (secondIndexPass) launch_index_resolve(m.surf[live], m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, true, s);
+        if (secondIndexPass) launch_index_resolve(m.surf[live], m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, depthF, mask, c->d_maskT, true, s);
     } else {
         // update.vert in place -- only the surfels a candidate merged into are touched (the reference copies the whole buffer,
         // Model.cpp:583-646) --, then the second index pass (over the runs in view where the buffer has a run table)
@@ -234,13 +234,13 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
         if (marks) mark(c, 6);
         if (secondIndexPass) {   // predictIndices on the updated buffer (:556); its resolve writes the packed, column-major map of clean's window gathers
             launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, true, s, blocks, vis);
-            launch_index_resolve(m.surf[src], m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, true, s);
+            launch_index_resolve(m.surf[src], m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, depthF, mask, c->d_maskT, true, s);
         }
     }
     // clean live -> the other buffer: two launches (flags + ordered copy) below big_map_elements, one launch (which also writes the new
     // buffer's run table) from there on
     launch_clean(m.surf[live], m.surf[1 - live], m.d_frame, m.d_pose, W, H, c->K, g.time_delta, m.confThr, g.outlier_coefficient, m.id,
-                 c->d_index, c->d_ivc, c->d_ict, secondIndexPass ? c->d_iclean : nullptr, depthF, mask, c->d_cand_op, c->d_cand_rec,
+                 c->d_index, c->d_ivc, c->d_ict, secondIndexPass ? c->d_iclean : nullptr, depthF, mask, c->d_maskT, c->d_cand_op, c->d_cand_rec,
                  small ? c->d_flags : nullptr, small ? c->d_newconf : nullptr, c->d_block_counts, c->d_scan_state, c->d_clean_ctl,
                  next_clean_epoch(c), clean_blocks(c, m), c->ticket_lanes, m.h_count, secondIndexPass, c->clean_literal, small, s);
     m.cur = 1 - live;
@@ -304,7 +304,7 @@ static int make_obj_batch(mf_ctx* c, const std::vector<ModelState*>& ms, const s
     b.m = c->d_obj_args[slot]; b.n = (int)ms.size();
     b.W = c->W; b.H = c->H; b.k = c->K; b.maxDepthProcessed = g.max_depth_processed; b.globalMaxDepth = g.depth_cutoff; b.timeDelta = g.time_delta;
     b.outlierCoeff = g.outlier_coefficient; b.cleanLiteral = c->clean_literal ? 1 : 0; b.bboxLimit = c->bbox_limit ? 1 : 0; b.cleanEpoch = 0; b.cleanTicketLanes = 1; b.cleanSmall = 0; b.updateCopy = 0;
-    b.rgb = d_rgb; b.depthRaw = d_depth; b.depthF = depthF; b.mask = mask; b.bg_pose = c->models[0]->d_pose; b.global_keys = c->d_keys;
+    b.rgb = d_rgb; b.depthRaw = d_depth; b.depthF = depthF; b.mask = mask; b.maskT = c->d_maskT; b.bg_pose = c->models[0]->d_pose; b.global_keys = c->d_keys;
     return MF_OK;
 }
 // every object model of the list, with its position in the list (the GlobalProjection payload)

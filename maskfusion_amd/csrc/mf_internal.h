@@ -244,6 +244,7 @@ void launch_cull(Surfels s, const FrameDev* frame, const PoseDev* pose, int W, i
 // packed == nullptr: index / vertConf / normRad (+ colorTime if ct != nullptr) images; else one 32 B record per texel
 void launch_index_resolve(Surfels src, const PoseDev* pose, unsigned long long* keys, int W, int H, int* index,
                           float4* vc, float4* nr, float4* ct /*or null*/, float4* packed /*or null: the packed column-major map instead of the row-major maps*/,
+                          const float* depthF, const uint8_t* mask, uint8_t* maskT /* with packed: the frame planes that travel with it */,
                           bool keys_transposed /* the order the scatter used */, hipStream_t s);
 void launch_fuse_data(const uint8_t* rgb, const float* depthRaw, const float* depthF, const uint8_t* mask,
                       int maskID, const FrameDev* frame, const PoseDev* pose, float weightMultiplier, float maxDepth,
@@ -268,6 +269,7 @@ size_t clean_scan_entries(long max_elements);
 void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k,
                   int timeDelta, float confThreshold, float outlierCoeff, int maskID, const int* index,
                   const float4* vc, const float4* ct, const float4* packed /*or null*/, const float* depthF, const uint8_t* mask,
+                  const uint8_t* maskT /* the mask in the packed map's order (with packed) */,
                   const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags /*or null*/, float* newconf /*or null*/, int* block_counts,
                   unsigned long long* scan_state, int* ctl, unsigned epoch, int blocks, int ticket_lanes /* <= compute units, <= kCleanTicketLanes */,
                   int* host_count_mirror, bool transposed /*layout of index/vc/ct*/, bool literalWindow /*fp32 trip count of the shader*/,
@@ -320,6 +322,7 @@ struct ObjBatch {
     int updateCopy;                    // 1: every model of the batch is below inPlaceElements -- update.vert as a copy a -> b, clean b -> a
     int cleanSmall;                    // 1: every model of the batch is small -- the two-launch clean form
     const uint8_t* rgb; const float* depthRaw; const float* depthF; const uint8_t* mask; const PoseDev* bg_pose;
+    uint8_t* maskT;                    // the mask in column-major order, beside the packed maps (every model's resolve writes the same bytes)
     unsigned long long* global_keys;
 };
 void launch_obj_global_scatter(const ObjBatch& b, int blocks, hipStream_t s);          // GlobalProjection of every object model (mf_segment.hip)

@@ -156,10 +156,11 @@ extern "C" int mf_model_predict_indices(mf_ctx* c, int32_t model, int32_t time, 
     hipStream_t s = c->stream;
     set_model_tick(c, *m, time);
     launch_index_scatter(m->surf[m->cur], m->d_frame, m->d_pose, c->W, c->H, c->K, max_depth, time_delta, c->d_keys, true, s);
-    launch_index_resolve(m->surf[m->cur], m->d_pose, c->d_keys, c->W, c->H, c->d_index, c->d_ivc, c->d_inr, c->d_ict, nullptr, true, s);
+    launch_index_resolve(m->surf[m->cur], m->d_pose, c->d_keys, c->W, c->H, c->d_index, c->d_ivc, c->d_inr, c->d_ict, nullptr, nullptr, nullptr, nullptr, true, s);
     if (c->model_api_packed) {   // the layout mf_process_frame feeds clean() with: packed records, column-major
         launch_index_scatter(m->surf[m->cur], m->d_frame, m->d_pose, c->W, c->H, c->K, max_depth, time_delta, c->d_keys, true, s);
-        launch_index_resolve(m->surf[m->cur], m->d_pose, c->d_keys, c->W, c->H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, true, s);
+        launch_index_resolve(m->surf[m->cur], m->d_pose, c->d_keys, c->W, c->H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, c->d_depthF[staged_frame(c) % 3],
+                             current_mask(c), c->d_maskT, true, s);
     }
     return check_launch(c);
 }
@@ -192,7 +193,7 @@ extern "C" int mf_model_clean(mf_ctx* c, int32_t model, int32_t time, int32_t ti
     const bool packed = c->model_api_packed != 0;
     const bool small = clean_small(c, *m);
     launch_clean(m->surf[src], m->surf[dst], m->d_frame, m->d_pose, c->W, c->H, c->K, time_delta, m->confThr, c->cfg.outlier_coefficient, m->id,
-                 c->d_index, c->d_ivc, c->d_ict, packed ? c->d_iclean : nullptr, c->d_depthF[k % 3], current_mask(c), c->d_cand_op, c->d_cand_rec,
+                 c->d_index, c->d_ivc, c->d_ict, packed ? c->d_iclean : nullptr, c->d_depthF[k % 3], current_mask(c), c->d_maskT, c->d_cand_op, c->d_cand_rec,
                  c->d_flags, c->d_newconf, c->d_block_counts, c->d_scan_state, c->d_clean_ctl, next_clean_epoch(c), clean_blocks(c, *m), c->ticket_lanes, m->h_count,
                  packed, c->clean_literal, small, c->stream);
     m->cur = dst;

@@ -390,21 +390,22 @@ __device__ __forceinline__ ResolvedTexel resolve_texel(const Surfels& src, const
     }
     return r;
 }
-struct ResolveOut { int* index; float4* vc; float4* nr; float4* ct; float4* packed; };
+// frame planes that travel with the packed map (copy_unstable.vert:139-156 looks the filtered depth and the mask up at the surfel's own texel: in the
+// packed, column-major order these are neighbours of its window taps; in the row-major images every lane pulled a sector of its own):
+// depthF -> the packed record's spare word, mask -> maskT (column-major bytes)
+struct ResolveOut { int* index; float4* vc; float4* nr; float4* ct; float4* packed; const float* depthF; const uint8_t* mask; uint8_t* maskT; };
 
-// keys and outputs in the same order (row-major keys -> maps, column-major keys -> packed): texel p of the key image is texel p of the output
+// row-major keys -> row-major maps: texel p of the key image is texel p of the outputs
 template <bool kPacked>
 __device__ __forceinline__ void index_resolve_same_body(Surfels src, const PoseDev* __restrict__ pose, unsigned long long* __restrict__ keys, int P, ResolveOut o) {
+    static_assert(!kPacked, "the packed map goes through a tile kernel");
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= P) return;
     const unsigned long long key = keys[p];
     keys[p] = kEmptyKey;
-    const ResolvedTexel r = resolve_texel<kPacked>(src, pose, key, o.ct != nullptr);
-    if (kPacked) { o.packed[2 * p] = r.p0; o.packed[2 * p + 1] = r.p1; }
-    else {
-        o.index[p] = r.index; o.vc[p] = r.vc; o.nr[p] = r.nr;
-        if (o.ct) o.ct[p] = r.ct;
-    }
+    const ResolvedTexel r = resolve_texel<false>(src, pose, key, o.ct != nullptr);
+    o.index[p] = r.index; o.vc[p] = r.vc; o.nr[p] = r.nr;
+    if (o.ct) o.ct[p] = r.ct;
 }
 // keys and outputs in different orders (column-major keys -> row-major maps, row-major keys -> column-major packed map): one tile per workgroup
 constexpr int kResolveTile = 16;
@@ -413,6 +414,7 @@ __device__ __forceinline__ void index_resolve_transposing_body(Surfels src, cons
                                                                ResolveOut o, int tile) {
     __shared__ float4 s_a[kResolveTile][kResolveTile + 1], s_b[kResolveTile][kResolveTile + 1], s_c[kPacked ? 1 : kResolveTile][kResolveTile + 1];
     __shared__ int s_i[kPacked ? 1 : kResolveTile][kResolveTile + 1];
+    __shared__ uint8_t s_mk[kPacked ? kResolveTile : 1][kResolveTile + 1];
     const int tilesX = (W + kResolveTile - 1) / kResolveTile;
     const int x0 = (tile % tilesX) * kResolveTile, y0 = (tile / tilesX) * kResolveTile;
     const int f = threadIdx.x & (kResolveTile - 1), g = threadIdx.x / kResolveTile;   // f: the fast coordinate of consecutive lanes
@@ -425,6 +427,7 @@ __device__ __forceinline__ void index_resolve_transposing_body(Surfels src, cons
             const unsigned long long key = keys[p];
             keys[p] = kEmptyKey;
             r = resolve_texel<kPacked>(src, pose, key, o.ct != nullptr);
+            if (kPacked) { r.p1.w = o.depthF[p]; s_mk[lx][ly] = o.mask[p]; }
         }
         if (kPacked) { s_a[lx][ly] = r.p0; s_b[lx][ly] = r.p1; }
         else { s_i[lx][ly] = r.index; s_a[lx][ly] = r.vc; s_b[lx][ly] = r.nr; if (o.ct) s_c[lx][ly] = r.ct; }
@@ -438,6 +441,7 @@ __device__ __forceinline__ void index_resolve_transposing_body(Surfels src, cons
                 const int tp = x * H + y;
                 o.packed[2 * tp] = s_a[lx][ly];
                 o.packed[2 * tp + 1] = s_b[lx][ly];
+                o.maskT[tp] = s_mk[lx][ly];
             } else {
                 const int p = y * W + x;
                 o.index[p] = s_i[lx][ly]; o.vc[p] = s_a[lx][ly]; o.nr[p] = s_b[lx][ly];
@@ -446,9 +450,37 @@ __device__ __forceinline__ void index_resolve_transposing_body(Surfels src, cons
         }
     }
 }
-template <bool kPacked>
+// column-major keys -> the packed column-major map: keys and records in the same order, only the frame planes are transposed
+__device__ __forceinline__ void index_resolve_packed_body(Surfels src, const PoseDev* __restrict__ pose, unsigned long long* __restrict__ keys, int W, int H,
+                                                          ResolveOut o, int tile) {
+    __shared__ float s_d[kResolveTile][kResolveTile + 1];
+    __shared__ uint8_t s_mk[kResolveTile][kResolveTile + 1];
+    const int tilesX = (W + kResolveTile - 1) / kResolveTile;
+    const int x0 = (tile % tilesX) * kResolveTile, y0 = (tile / tilesX) * kResolveTile;
+    const int f = threadIdx.x & (kResolveTile - 1), g = threadIdx.x / kResolveTile;
+    {
+        const int x = x0 + f, y = y0 + g;
+        if (x < W && y < H) { s_d[f][g] = o.depthF[y * W + x]; s_mk[f][g] = o.mask[y * W + x]; }
+    }
+    __syncthreads();
+    const int x = x0 + g, y = y0 + f;
+    if (x < W && y < H) {
+        const int tp = x * H + y;
+        const unsigned long long key = keys[tp];
+        keys[tp] = kEmptyKey;
+        ResolvedTexel r = resolve_texel<true>(src, pose, key, false);
+        r.p1.w = s_d[g][f];
+        o.packed[2 * tp] = r.p0;
+        o.packed[2 * tp + 1] = r.p1;
+        o.maskT[tp] = s_mk[g][f];
+    }
+}
 __global__ __launch_bounds__(256) void k_index_resolve(Surfels src, const PoseDev* __restrict__ pose, unsigned long long* __restrict__ keys, int P, ResolveOut o) {
-    index_resolve_same_body<kPacked>(src, pose, keys, P, o);
+    index_resolve_same_body<false>(src, pose, keys, P, o);
+}
+__global__ __launch_bounds__(256) void k_index_resolve_packed(Surfels src, const PoseDev* __restrict__ pose, unsigned long long* __restrict__ keys, int W, int H,
+                                                              ResolveOut o) {
+    index_resolve_packed_body(src, pose, keys, W, H, o, (int)blockIdx.x);
 }
 template <bool kPacked>
 __global__ __launch_bounds__(256) void k_index_resolve_transposing(Surfels src, const PoseDev* __restrict__ pose, unsigned long long* __restrict__ keys, int W, int H,
@@ -457,18 +489,20 @@ __global__ __launch_bounds__(256) void k_index_resolve_transposing(Surfels src, 
 }
 int resolve_tiles(int W, int H) { return ((W + kResolveTile - 1) / kResolveTile) * ((H + kResolveTile - 1) / kResolveTile); }
 
-// packed != nullptr: the packed column-major map (index / vc / nr / ct unused); else the row-major maps.  keys_transposed: the order the scatter used.
+// packed != nullptr: the packed column-major map (index / vc / nr / ct unused) with the frame's filtered depth in its spare word and the mask
+// transposed into maskT; else the row-major maps.  keys_transposed: the order the scatter used.
 void launch_index_resolve(Surfels src, const PoseDev* pose, unsigned long long* keys, int W, int H, int* index, float4* vc,
-                          float4* nr, float4* ct, float4* packed, bool keys_transposed, hipStream_t s) {
+                          float4* nr, float4* ct, float4* packed, const float* depthF, const uint8_t* mask, uint8_t* maskT, bool keys_transposed,
+                          hipStream_t s) {
     const int P = W * H;
-    const ResolveOut o{index, vc, nr, ct, packed};
+    const ResolveOut o{index, vc, nr, ct, packed, depthF, mask, maskT};
     const dim3 flat((P + 255) / 256), tiles(resolve_tiles(W, H));
     if (packed) {
-        if (keys_transposed) hipLaunchKernelGGL(k_index_resolve<true>, flat, dim3(256), 0, s, src, pose, keys, P, o);
+        if (keys_transposed) hipLaunchKernelGGL(k_index_resolve_packed, tiles, dim3(256), 0, s, src, pose, keys, W, H, o);
         else hipLaunchKernelGGL(k_index_resolve_transposing<true>, tiles, dim3(256), 0, s, src, pose, keys, W, H, o);
     } else {
         if (keys_transposed) hipLaunchKernelGGL(k_index_resolve_transposing<false>, tiles, dim3(256), 0, s, src, pose, keys, W, H, o);
-        else hipLaunchKernelGGL(k_index_resolve<false>, flat, dim3(256), 0, s, src, pose, keys, P, o);
+        else hipLaunchKernelGGL(k_index_resolve, flat, dim3(256), 0, s, src, pose, keys, P, o);
     }
 }
 
@@ -704,6 +738,7 @@ struct CleanArgs {
     const int* index; const float4* vc; const float4* ct;   // separate images (only when the packed map is absent)
     const float4* packed;                                    // {vertConf | initTime, lastTime, index, 0} per texel
     const float* depthF; const uint8_t* mask;
+    const uint8_t* maskT;                                    // the mask in the packed map's order (only with `packed`)
     const uint8_t* cand_op; const float4* cand_rec;
     uint8_t* flags; float* newconf;    // keep flag / new confidence per element: the two-launch form's intermediate; for the one-launch form optional taps
     int* block_counts;                 // [kCompactBlocks] survivors per workgroup (two-launch form)
@@ -807,8 +842,9 @@ __device__ __forceinline__ bool clean_test(const CleanArgs& a, float4 pc, float4
     // mask-disagreement decay, copy_unstable.vert:139-156 (nearest fetch, clamp to edge, NaN -> texel 0)
     const int fx_ = isnan(x) ? 0 : clampi((int)fminf(fmaxf(floorf(x), -1.f), (float)W), 0, W - 1);
     const int fy_ = isnan(y) ? 0 : clampi((int)fminf(fmaxf(floorf(y), -1.f), (float)H), 0, H - 1);
-    const float wDepth = a.depthF[fy_ * W + fx_];
-    const int maskValue = a.mask[fy_ * W + fx_];
+    // (with the packed map: the filtered depth rides in its spare word, the mask in the column-major plane beside it -- launch_index_resolve)
+    const float wDepth = a.packed ? a.packed[2 * (fx_ * H + fy_) + 1].w : a.depthF[fy_ * W + fx_];
+    const int maskValue = a.packed ? a.maskT[fx_ * H + fy_] : a.mask[fy_ * W + fx_];
     newconf = pc.w;
     decay = 0;
     if (maskValue != a.maskID && maskValue < 255 && (wDepth > lp.z - 0.05f && wDepth < lp.z + 0.05f)) {
@@ -1438,7 +1474,7 @@ void launch_pose_log(const PoseDev* pose, const PoseDev* bg_pose, float* slot, h
 
 void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, int timeDelta,
                   float confThreshold, float outlierCoeff, int maskID, const int* index, const float4* vc, const float4* ct,
-                  const float4* packed, const float* depthF, const uint8_t* mask, const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags,
+                  const float4* packed, const float* depthF, const uint8_t* mask, const uint8_t* maskT, const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags,
                   float* newconf, int* block_counts, unsigned long long* scan_state, int* ctl, unsigned epoch, int blocks, int ticket_lanes,
                   int* host_count_mirror, bool transposed, bool literalWindow, bool small_map, hipStream_t s) {
     CleanArgs a;
@@ -1447,7 +1483,7 @@ void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose
     a.src = src; a.dst = dst; a.frame = frame; a.pose = pose; a.W = W; a.H = H; a.k = k; a.timeDelta = timeDelta;
     a.confThreshold = confThreshold; a.outlierCoeff = outlierCoeff; a.maskID = maskID; a.index = index; a.vc = vc; a.ct = ct;
     a.packed = packed;
-    a.depthF = depthF; a.mask = mask; a.cand_op = cand_op; a.cand_rec = cand_rec;
+    a.depthF = depthF; a.mask = mask; a.maskT = maskT; a.cand_op = cand_op; a.cand_rec = cand_rec;
     a.flags = flags; a.newconf = newconf; a.block_counts = block_counts; a.host_count = host_count_mirror;
     a.scan_state = scan_state; a.ctl = ctl; a.epoch = epoch; a.ticket_lanes = min(ticket_lanes, blocks);
     if (small_map) {
@@ -1470,11 +1506,12 @@ __global__ __launch_bounds__(256) void k_obj_index_scatter(const ObjBatch b) {
 }
 __global__ __launch_bounds__(256) void k_obj_index_resolve(const ObjBatch b) {   // (the object models' keys are row-major in both passes)
     const ObjPassArgs& m = b.m[blockIdx.z];
-    index_resolve_same_body<false>(m.a, m.pose, m.keys, b.W * b.H, ResolveOut{m.index, m.ivc, m.inr, nullptr, nullptr});
+    index_resolve_same_body<false>(m.a, m.pose, m.keys, b.W * b.H, ResolveOut{m.index, m.ivc, m.inr, nullptr, nullptr, nullptr, nullptr, nullptr});
 }
 __global__ __launch_bounds__(256) void k_obj_index_resolve_packed(const ObjBatch b) {   // the pass that feeds clean(): grid.x = 16 x 16-pixel tiles
     const ObjPassArgs& m = b.m[blockIdx.z];
-    index_resolve_transposing_body<true>(b.updateCopy ? m.b : m.a, m.pose, m.keys, b.W, b.H, ResolveOut{nullptr, nullptr, nullptr, nullptr, m.iclean}, (int)blockIdx.x);
+    index_resolve_transposing_body<true>(b.updateCopy ? m.b : m.a, m.pose, m.keys, b.W, b.H,
+                                         ResolveOut{nullptr, nullptr, nullptr, nullptr, m.iclean, b.depthF, b.mask, b.maskT}, (int)blockIdx.x);
 }
 __global__ __launch_bounds__(256) void k_obj_fuse_data(const ObjBatch b) {
     const ObjPassArgs& m = b.m[blockIdx.z];
@@ -1497,7 +1534,7 @@ __device__ __forceinline__ CleanArgs obj_clean_args(const ObjBatch& b, const Obj
     a.src = b.updateCopy ? m.b : m.a; a.dst = b.updateCopy ? m.a : m.b;
     a.frame = m.frame; a.pose = m.pose; a.W = b.W; a.H = b.H; a.k = b.k; a.timeDelta = b.timeDelta;
     a.confThreshold = m.confThreshold; a.outlierCoeff = b.outlierCoeff; a.maskID = m.maskID; a.transposed = 1; a.literal = b.cleanLiteral;
-    a.index = m.index; a.vc = m.ivc; a.ct = nullptr; a.packed = m.iclean; a.depthF = b.depthF; a.mask = b.mask;
+    a.index = m.index; a.vc = m.ivc; a.ct = nullptr; a.packed = m.iclean; a.depthF = b.depthF; a.mask = b.mask; a.maskT = b.maskT;
     a.cand_op = m.cand_op; a.cand_rec = m.cand_rec; a.flags = b.cleanSmall ? m.flags : nullptr; a.newconf = b.cleanSmall ? m.newconf : nullptr;
     a.block_counts = m.block_counts; a.host_count = m.host_count;
     a.scan_state = m.scan_state; a.ctl = m.clean_ctl; a.epoch = b.cleanEpoch; a.ticket_lanes = b.cleanTicketLanes;
