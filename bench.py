@@ -482,7 +482,7 @@ class RoomMapJob:
 C4_KERNEL_BYTES = {
     "k_index_scatter": lambda N, P: 48.0 * N,                    # a projection of the surfel stream (the pre-fusion index map; the post-fusion one is the same kernel)
     "k_index_resolve_transposing": lambda N, P: 52.0 * P,        # ... its image-side outputs (column-major keys -> row-major maps, through the LDS)
-    "k_index_resolve": lambda N, P: 52.0 * P,                    # ... and those of the post-fusion pass (column-major keys -> the packed column-major map)
+    "k_index_resolve_packed": lambda N, P: 52.0 * P,             # ... and those of the post-fusion pass (column-major keys -> the packed column-major map)
     "k_clean": lambda N, P: 96.0 * N,                            # THE read-modify-write of the frame (update + clean): read 48 + write 48; update.vert itself runs
                                                                  # in place on the merged surfels only (k_fuse_update, no N-sized traffic)
     "k_splat_bin": lambda N, P: 48.0 * N,                        # a projection of the surfel stream (prediction; GlobalProjection's is the same kernel)

@@ -14,7 +14,7 @@ import json
 import sys
 
 CALIB_BYTES = 256 * 1024 * 1024
-WIDE = ("k_fuse_update", "k_clean_compact", "k_index_scatter", "k_splat_bin", "k_clean_flags", "k_fuse_data", "k_index_resolve", "k_index_resolve_transposing", "k_obj_index_resolve_packed", "k_splat_tile",
+WIDE = ("k_fuse_update", "k_clean_compact", "k_index_scatter", "k_splat_bin", "k_clean_flags", "k_fuse_data", "k_index_resolve", "k_index_resolve_transposing", "k_index_resolve_packed", "k_obj_index_resolve_packed", "k_splat_tile",
         "k_model_pyramid", "k_clean", "k_clean_small_flags", "k_clean_small_compact", "k_cull", "k_run_table", "k_global_tile", "k_obj_clean",
         "k_obj_index_scatter", "k_obj_index_scatter2", "k_obj_index_resolve", "k_obj_splat_scatter", "k_obj_global_scatter")   # float4 surfel / map streams
 
