@@ -159,7 +159,7 @@ int mf_write_png_gray8(const char* path, const uint8_t* img, int32_t width, int3
 int mf_get_last_fillin(mf_ctx* ctx, int32_t* used);
 
 /* The per-frame setters of MaskFusion (Core/MaskFusion.h:132-182,234-263).  Keys: "depthCutoff", "icpWeight",
- * "confidenceThreshold" (background), "outlierCoefficient", "fastOdom", "so3", "pyramid", "timeDelta",
+ * "confidenceThreshold" (background), "outlierCoefficient", "fastOdom", "so3", "rgbOnly" (setRgbOnly: photometric term only), "pyramid", "timeDelta",
  * "maxDepthProcessed", "enableMultipleModels", "trackAllModels", "modelSpawnOffset",
  * "newModelMinRelativeSize", "newModelMaxRelativeSize" (SegmentationPerformer.h:36-37) and the MfSegmentation tunables
  * (MaskFusion.h:234-263 / MfSegmentation.h:42-62): "mfThreshold", "mfWeightDistance", "mfWeightConvexity",
@@ -181,7 +181,16 @@ int mf_get_last_fillin(mf_ctx* ctx, int32_t* used);
  * text does -- its rotation term is then quantised in steps of ~4.9e-4 rad; 0: the same formula evaluated accurately in double.  See
  * DESIGN.md, finding F5; default 1 since round 3), "frameToFrameRGB" (0; MaskFusion::setFrameToFrameRGB, "-ftf": the photometric term tracks
  * against the previous RAW frame, Model.cpp:399-400,981), "objectBoundingBoxLimit" (1: Model::fuse limits an object model's depth by its
- * bounding box + 5 % as upstream does whenever its GUI draws the models, Model.cpp:480-501; 0: bb_max_z = FLT_MAX, a headless upstream). */
+ * bounding box + 5 % as upstream does whenever its GUI draws the models, Model.cpp:480-501; 0: bb_max_z = FLT_MAX, a headless upstream).
+ * Further switches and taps: "batchObjectPasses" (1: the surfel passes of all object models of a frame as one launch per pass; 0: model by
+ * model, the executable specification), "hostLockstep" (1: mf_process_frame waits for frame k-2 to have run before it enqueues frame k's
+ * upload), "hostWaitUpload" (1: ... and for its own upload: single-model frames), "modelApiPackedIndex" (0; 1: mf_model_predict_indices
+ * also builds the packed column-major map mf_process_frame feeds Model::clean with), "tileThreads" (512) / "spriteLanes" (4): launch shape of
+ * the tile passes (A/B), "splatTileEntries" (test knob: shrinks the tile lists to force their overflow path), "rebuildRunTable" (write-only:
+ * rebuilds the background's run table from scratch), "splatProfile" (1: per-tile stamps of the background's tile pass, debug tap
+ * "splat_prof").  Read-only (mf_get_param): "visibleRuns" / "backgroundRuns" (runs k_cull listed for the last pass / runs of the
+ * background's table), "hostWaitUs" | "hostStageUs" | "hostUploadUs" | "hostEnqueueUs" | "hostCallUs" (host clocks inside
+ * mf_process_frame, microseconds per call since mf_set_param("hostProfileReset", 1)). */
 int mf_set_param(mf_ctx* ctx, const char* key, double value);
 int mf_get_param(mf_ctx* ctx, const char* key, double* value);
 

@@ -107,3 +107,14 @@ def test_cpp_facade_host_semantics_without_gpu(tmp_path):
     assert r.returncode == 0, r.stderr
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "facade semantics ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_every_parameter_key_is_documented_in_the_header():
+    """every key mf_set_param / mf_get_param compares against appears in include/maskfusion_amd.h (rounds 3-5 added switches faster than the
+    header learnt of them)"""
+    import re
+    src = open(os.path.join(ROOT, "maskfusion_amd", "csrc", "mf_context.hip")).read()
+    header = open(os.path.join(ROOT, "include", "maskfusion_amd.h")).read()
+    keys = set(re.findall(r'strcmp\(key, "([A-Za-z0-9_]+)"\)', src)) | set(re.findall(r'\{"([A-Za-z0-9_]+)", \d, offsetof', src))
+    missing = sorted(k for k in keys if f'"{k}"' not in header)
+    assert len(keys) > 30 and not missing, missing
