@@ -37,19 +37,22 @@ def surfel_capacity(num: int) -> int:
 SCENE_BOXES = 6       # object boxes in the scene: with synth.Scene's ring of six, boxes 1..4 are all in view (in its ring of four, box 3 hides)
 
 
-def stream_kwargs(n_objects: int = 4, noise: bool = True) -> dict:
-    return dict(W=W, H=H, fx=F, fy=F, cx=W / 2.0, cy=H / 2.0, n_objects=SCENE_BOXES, noise=noise, object_motion=0.0, seed=1234, masked_objects=n_objects)
+def stream_kwargs(n_objects: int = 4, noise: bool = True, scale: int = 1) -> dict:
+    """scale > 1: the same scene at 1 / scale of the resolution (the CPU-executed rehearsal of the scenario, tests/test_emu_dense_maps.py)"""
+    w, h, f = W // scale, H // scale, F / scale
+    return dict(W=w, H=h, fx=f, fy=f, cx=w / 2.0, cy=h / 2.0, n_objects=SCENE_BOXES, noise=noise, object_motion=0.0, seed=1234, masked_objects=n_objects)
 
 
-def stream(n_objects: int = 4, noise: bool = True) -> synth.Stream:
+def stream(n_objects: int = 4, noise: bool = True, scale: int = 1) -> synth.Stream:
     """S3: the room with six standing boxes of which the first `n_objects` are instance-masked (the others are furniture)"""
-    return synth.Stream(**stream_kwargs(n_objects, noise))
+    return synth.Stream(**stream_kwargs(n_objects, noise, scale))
 
 
-def make_context(device: int = 0, num_g: int = NUM_GSURFELS, num_o: int = NUM_OSURFELS, n_objects: int = 4):
+def make_context(device: int = 0, num_g: int = NUM_GSURFELS, num_o: int = NUM_OSURFELS, n_objects: int = 4, scale: int = 1):
     """the product's context for the scenario (SURVEY.md 8d S2 / S3 settings: confG = 10, confO = 0.01, the GUI's segmentation parameters)"""
     from . import MaskFusion
-    mf = MaskFusion(W, H, F, F, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, device=device, enableMultipleModels=True, numGSurfels=num_g,
+    w, h, f = W // scale, H // scale, F / scale
+    mf = MaskFusion(w, h, f, f, w / 2.0, h / 2.0, icpThresh=100.0, so3=False, device=device, enableMultipleModels=True, numGSurfels=num_g,
                     numOSurfels=num_o, trackAllModels=False, modelSpawnOffset=2, initConfidenceGlobal=10.0, initConfidenceObject=0.01)
     for k, v in SEG_PARAMS:
         mf.setParam(k, v)

@@ -1,0 +1,21 @@
+"""configs[4]'s scenario on every CPU run: the parity test of the dense-map scenario (tests/test_gpu_parity_long.py::test_config4_dense_maps) at a
+quarter of the resolution and 1 / 128 of the surfel budgets, through the product's kernels EXECUTED ON THE CPU (tests/hipcpu) with the passes of
+FULL maps forced (one-launch clean with its decoupled look-back, run table + culled projection passes, in-place update): lead-in with a dense map
+uploaded behind every spawn, the dense room map, then three frames against OracleMM -- model list, every model's surfel count, label image exact,
+every surfel of every model in its slot.  A subprocess, as tests/test_emu_smoke.py: nothing of the emulator leaks into this process; the parity
+claim itself rests on the -m gpu run of the same test at the budgets the reference is compiled with."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_dense_map_scenario_on_the_cpu_executed_kernels():
+    env = dict(os.environ, MF_EMU="1", MF_PARITY_C4_SCALE="4", MF_PARITY_C4_OBJECTS="3", MF_PARITY_C4_GSURFELS=str(1 << 18), MF_PARITY_C4_OSURFELS=str(1 << 14),
+               MF_PARITY_C4_FORMS="big", MF_PARITY_C4_FRAMES="3", MF_NO_PREBUILD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity_long.py") + "::test_config4_dense_maps", "-q", "-m", "gpu",
+                        "-n", "0", "-x", "-s", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert "1 passed" in r.stdout and "every one in its slot" in r.stdout, tail

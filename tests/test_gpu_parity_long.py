@@ -465,24 +465,29 @@ def test_config4_dense_maps(hip, oracle):
     from oracle import mfo_mm
     n_dense = int(os.environ.get("MF_PARITY_C4_FRAMES", 5))
     num_g, num_o = int(os.environ.get("MF_PARITY_C4_GSURFELS", stress.NUM_GSURFELS)), int(os.environ.get("MF_PARITY_C4_OSURFELS", stress.NUM_OSURFELS))
-    st = stress.stream(4)
-    kw = stress.stream_kwargs(4)
+    scale = int(os.environ.get("MF_PARITY_C4_SCALE", 1))          # > 1: the scenario at 1 / scale of the resolution (tests/test_emu_dense_maps.py)
+    n_obj = int(os.environ.get("MF_PARITY_C4_OBJECTS", 4))
+    st = stress.stream(n_obj, scale=scale)
+    kw = stress.stream_kwargs(n_obj, scale=scale)
     max_lead = int(os.environ.get("MF_PARITY_C4_LEADIN", 16))
     frames = render(kw, max_lead + n_dense)
-    cls = [0] + [41 + i for i in range(4)]
+    cls = [0] + [41 + i for i in range(n_obj)]
     W, H, f = st.W, st.H, st.fx
     o = mfo_mm.OracleMM(W, H, f, f, W / 2.0, H / 2.0, icpWeight=100.0, so3=0, capacity=stress.surfel_capacity(num_g), capacityObject=stress.surfel_capacity(num_o),
                         modelSpawnOffset=2, trackAllModels=0, seg=SEG, confGlobal=10.0, confObject=0.01)
-    m = stress.make_context(0, num_g, num_o)
+    m = stress.make_context(0, num_g, num_o, n_objects=n_obj, scale=scale)
+    if os.environ.get("MF_PARITY_C4_FORMS") == "big":              # small budgets, the passes of FULL maps (one-launch clean, run table + culling, in-place update)
+        m.setParam("bigMapElements", 0)
+        m.setParam("inPlaceElements", 0)
 
     def oracle_frame(k, rgb, depth, mask):
         gm = m.getModels()
         o.force_tracking([x.getID() for x in gm], [x.getPose() for x in gm])
         o.process_frame(rgb, depth, mask, cls, depth_filtered=m.debugRead("depthF"))
 
-    k0, loaded = stress.lead_in(m, st, frames, cls, n_objects=4, on_frame=oracle_frame, on_upload=lambda i, s: o.upload_map(i, s), log=print, max_frames=max_lead)
-    assert len(loaded) == 5, loaded                                   # the background and four object models, each on its own box
-    assert loaded[0] >= 0.8 * stress.surfel_capacity(num_g) and min(loaded[i] for i in range(1, 5)) >= 0.8 * stress.surfel_capacity(num_o)
+    k0, loaded = stress.lead_in(m, st, frames, cls, n_objects=n_obj, on_frame=oracle_frame, on_upload=lambda i, s: o.upload_map(i, s), log=print, max_frames=max_lead)
+    assert len(loaded) == n_obj + 1, loaded                           # the background and four object models, each on its own box
+    assert loaded[0] >= 0.8 * stress.surfel_capacity(num_g) and min(loaded[i] for i in range(1, n_obj + 1)) >= 0.8 * stress.surfel_capacity(num_o)
     worst_lab = 0.0
     for k in range(k0, k0 + n_dense):
         rgb, depth, mask = frames[k]
