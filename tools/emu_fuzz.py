@@ -37,7 +37,9 @@ def one(seed):
     cap = 1 << 17
     o = mfo.Oracle(W, H, f, f, cx, cy, capacity=cap, icpWeight=icpw, so3=int(so3), fastOdom=int(fast))
     mf = MaskFusion(W, H, f, f, cx, cy, icpThresh=icpw, so3=so3, fastOdom=fast, enableMultipleModels=False, numGSurfels=cap)
-    desc = f"seed {seed}: {W}x{H} f={f:.1f} icpW={icpw} so3={so3} fast={fast} noise={noise} n={n} given={given}"
+    forms = [(1 << 30, 1 << 30), (1 << 30, 0), (0, 0)][int(rng.integers(0, 3))]     # the size-dependent forms of the fuse / clean passes (round 5): forced, any of the three
+    mf.setParam("bigMapElements", forms[0]); mf.setParam("inPlaceElements", forms[1])
+    desc = f"seed {seed}: {W}x{H} f={f:.1f} icpW={icpw} so3={so3} fast={fast} noise={noise} n={n} given={given} forms={forms}"
     bad = []
     for k in range(n):
         rgb, d, _ = st.frame(k)

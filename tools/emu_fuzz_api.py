@@ -58,7 +58,11 @@ def one(seed, tmp):
             elif op == 5:
                 mf.predict()
             elif op == 6:
-                mf.setParam(SWITCHES[int(rng.integers(0, len(SWITCHES)))], float(rng.integers(0, 2)))
+                if rng.integers(0, 3) == 0:      # the size thresholds of the fuse / clean forms (round 5): any combination, changed between frames
+                    mf.setParam(str(rng.choice(["bigMapElements", "inPlaceElements"])), float(rng.choice([0, 1 << 30])))
+                    mf.setParam("cullRuns", float(rng.integers(0, 2)))
+                else:
+                    mf.setParam(SWITCHES[int(rng.integers(0, len(SWITCHES)))], float(rng.integers(0, 2)))
             elif op == 7:
                 mf.setParam(str(rng.choice(["depthCutoff", "confidenceThreshold", "outlierCoefficient", "icpWeight", "fastOdom", "pyramid", "so3"])),
                             float(rng.choice([0.0, 0.5, 1.0, 3.0, 10.0, 100.0])))
