@@ -14,7 +14,7 @@ MF_EMU=1 python -m pytest tests -m gpu -q -p no:cacheprovider
 ASAN=$(gcc -print-file-name=libasan.so)
 LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 MF_EMU=1 MF_EMU_ASAN=1 python -m pytest tests -m gpu -q -p no:cacheprovider
 UBSAN_OPTIONS=print_stacktrace=1 MF_EMU=1 MF_EMU_UBSAN=1 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tee /tmp/ubsan.log; ! grep -q "runtime error" /tmp/ubsan.log
-python tools/emu_schedule_check.py
+python tools/emu_schedule_check.py; MF_BIG_FORMS=1 python tools/emu_schedule_check.py
 python tools/emu_fuzz.py 100 1000; FUZZ_ODD_SIZES=1 python tools/emu_fuzz.py 60 11000; python tools/emu_fuzz.py 30 7000 mm
 python tools/emu_fuzz_labels.py 300 100
 LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 MF_EMU_ASAN=1 python tools/emu_fuzz_api.py 30 700

@@ -1,7 +1,7 @@
 """Race check without a GPU: the same frames through the CPU-executed kernels (tests/hipcpu) under the forward and the REVERSED thread /
 workgroup schedule (HIPCPU_SCHEDULE=reverse).  A kernel whose result depends on the order in which the threads of a workgroup or the
 workgroups of a launch run -- a missing barrier, an unordered float atomic, a compaction that is not order-stable -- shows up as
-different bits.  Development tooling.   python tools/emu_schedule_check.py"""
+different bits.  Development tooling.   python tools/emu_schedule_check.py   (MF_BIG_FORMS=1: with the full-map forms of the fuse / clean passes forced)"""
 import os
 import pickle
 import subprocess
@@ -23,6 +23,8 @@ W, H = 240, 160
 f = 528.0 * W / 640.0
 st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
 mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=20.0, so3=True, enableMultipleModels=False, numGSurfels=1 << 17)
+if os.environ.get("MF_BIG_FORMS") == "1":   # the passes of full maps (one-launch clean with its look-back, run table + culling, in-place update) on these small ones
+    mf.setParam("bigMapElements", 0); mf.setParam("inPlaceElements", 0)
 for k in range(6):
     rgb, d, _ = st.frame(k)
     mf.processFrame(rgb, d, timestamp=k)
@@ -34,6 +36,8 @@ mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, numGSu
                 modelSpawnOffset=2, trackAllModels=True)
 for k, v in dict(mfThreshold=0.3, mfWeightDistance=150.0, mfWeightConvexity=2.8, mfMorphEdgeIterations=1, mfMorphMaskIterations=1, newModelMinRelativeSize=0.004).items():
     mf.setParam(k, v)
+if os.environ.get("MF_BIG_FORMS") == "1":
+    mf.setParam("bigMapElements", 0); mf.setParam("inPlaceElements", 0)
 segs = []
 for k in range(9):
     rgb, d, mask = st.frame(k)
