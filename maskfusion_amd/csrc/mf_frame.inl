@@ -768,6 +768,13 @@ extern "C" int mf_set_mask_class_ids(mf_ctx* c, const int32_t* class_ids, int32_
 extern "C" int mf_sync(mf_ctx* c) {
     if (!c) return MF_EINVAL;
     MF_HIP(c, hipStreamSynchronize(c->stream));
+    // the one-launch clean bounds its waits (a GPU must never hang on a look-back): a chunk that gave up leaves a sticky mark in the model's frame
+    // state, mirrored to the host with the end-of-frame bookkeeping -- that map is not valid any more, and every call that waits says so
+    for (auto& m : c->models)
+        if (m->h_frame && m->h_frame->pad[2]) {
+            c->err = "Model::clean: the ordered compaction of model id " + std::to_string(m->id) + " gave up waiting for an earlier chunk (internal error: its map is not valid)";
+            return MF_EHIP;
+        }
     if (c->timings_on) {
         // event i marks the START of stage i; stage i lasts until event i+1 (labels: see the header)
         float t[MF_N_TIMINGS] = {};
