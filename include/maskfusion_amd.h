@@ -93,6 +93,8 @@ int mf_process_frame_dev(mf_ctx* ctx, const uint8_t* d_rgb, const float* d_depth
 /* FrameData::classIDs (Core/FrameData.h:25-48) of the masks handed to mf_process_frame_dev: class_ids[v] = class of mask value v
  * (n <= 256; until it is called every mask value is class 0) */
 int mf_set_mask_class_ids(mf_ctx* ctx, const int32_t* class_ids, int32_t n);
+/* Waits for everything enqueued on the context's stream.  MF_EHIP (text in mf_last_error) for a HIP failure, and when the ordered compaction
+ * of a full map's Model::clean gave up one of its bounded waits (never in a correct run; that model's map is then not valid). */
 int mf_sync(mf_ctx* ctx);
 
 /* MaskFusion::setTick (Core/MaskFusion.h:206); only after the first frame (tick 1 initialises the map) */
