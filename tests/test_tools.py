@@ -66,3 +66,24 @@ def test_bench_reads_a_rounds_final_profile_before_its_intermediate_ones(tmp_pat
     assert rows["k_icp_iter<512, 3>"]["source"] == "profiles/r05_kernel_stats.csv" and rows["k_icp_iter<512, 3>"]["us"] == 6.0
     rows = bench.rocprof_rows(["k_clean"], pattern="r*_c4_kernel_stats.csv")
     assert rows["k_clean"]["source"] == "profiles/r05_c4_kernel_stats.csv" and rows["k_clean"]["us"] == 60.0
+
+
+def test_c4_dense_summary_keeps_the_launches_on_the_full_maps(tmp_path):
+    """tools/c4_dense_summary.py (the per-kernel table bench.py's roofline_kernels reads for configs[4]): from a fabricated kernel trace in which a
+    kernel runs 5 times on a small lead-in map (10-30 us) and 4 times on the full one (~1.3 ms), only the four long launches are averaged; a
+    kernel whose launches are all alike keeps them all."""
+    trace = tmp_path / "kernel_trace.csv"
+    with open(trace, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kind", "Agent_Id", "Queue_Id", "Kernel_Id", "Kernel_Name", "Correlation_Id", "Start_Timestamp", "End_Timestamp"])
+        t = 1000
+        for d in (10_000, 20_000, 30_000, 12_000, 15_000, 1_300_000, 1_310_000, 1_290_000, 1_300_000):
+            w.writerow(["KERNEL_DISPATCH", 1, 1, 7, "mf::k_clean(mf::CleanArgs)", 0, t, t + d]); t += d + 5000
+        for d in (7_000, 7_500, 8_000):
+            w.writerow(["KERNEL_DISPATCH", 1, 1, 8, "void mf::k_icp_iter<256, 1>(mf::IcpKArgs)", 0, t, t + d]); t += d + 5000
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "c4_dense_summary.py"), str(trace)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    rows = {row["Name"]: row for row in csv.DictReader(r.stdout.splitlines())}
+    clean, icp = rows["mf::k_clean(mf::CleanArgs)"], rows["void mf::k_icp_iter<256, 1>(mf::IcpKArgs)"]
+    assert int(clean["Calls"]) == 4 and int(clean["CallsInTrace"]) == 9 and abs(float(clean["AverageNs"]) - 1_300_000) < 1
+    assert int(icp["Calls"]) == 3 and abs(float(icp["AverageNs"]) - 7_500) < 1
