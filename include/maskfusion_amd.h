@@ -184,6 +184,8 @@ int mf_get_last_fillin(mf_ctx* ctx, int32_t* used);
  * DESIGN.md, finding F5; default 1 since round 3), "frameToFrameRGB" (0; MaskFusion::setFrameToFrameRGB, "-ftf": the photometric term tracks
  * against the previous RAW frame, Model.cpp:399-400,981), "objectBoundingBoxLimit" (1: Model::fuse limits an object model's depth by its
  * bounding box + 5 % as upstream does whenever its GUI draws the models, Model.cpp:480-501; 0: bb_max_z = FLT_MAX, a headless upstream).
+ * "fusedRgbPyramid" (1: the frame's intensity pyramid and its derivative / gate images -- photometric term, SO(3) -- as one LDS-tiled launch;
+ * 0: imageBGRToIntensity + 2 x pyrDownUcharGauss + computeDerivativeImages as four launches, the executable specification; same bytes).
  * Further switches and taps: "batchObjectPasses" (1: the surfel passes of all object models of a frame as one launch per pass; 0: model by
  * model, the executable specification), "hostLockstep" (1: mf_process_frame waits for frame k-2 to have run before it enqueues frame k's
  * upload), "hostWaitUpload" (1: ... and for its own upload: single-model frames), "modelApiPackedIndex" (0; 1: mf_model_predict_indices

@@ -358,6 +358,9 @@ class MaskFusion:
                   "icp_prof": ((19, 16), np.uint64), "splat_prof": ((((H + 15) // 16) * ((W + 15) // 16), 8), np.uint64),
                   "edge_map": ((H, W), np.float32),
                   "edge_binary": ((H, W), np.uint8), "projected_ids": ((H, W), np.uint8)}
+        for i in range(3):      # the frame's intensity pyramid and its derivative / gate images (photometric term, SO(3))
+            shapes.update({f"gray{i}": ((H >> i, W >> i), np.uint8), f"dIdx{i}": ((H >> i, W >> i), np.int16), f"dIdy{i}": ((H >> i, W >> i), np.int16),
+                           f"rgb_gate{i}": ((H >> i, W >> i), np.uint8)})
         if count is not None:
             shapes.update({"cand_op": ((count,), np.uint8), "cand_rec": ((count, 12), np.float32),
                            "clean_flags": ((count,), np.uint8), "clean_newconf": ((count,), np.float32)})

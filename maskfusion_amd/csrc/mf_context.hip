@@ -223,6 +223,7 @@ struct mf_ctx {
     // visibility list of the projection passes (Surfels::box, k_cull): the runs of ONE buffer that can be in view under ONE pose; vis_tag says whose
     int* d_vis_list = nullptr; int* d_vis_count = nullptr; int* d_cull_ctl = nullptr; int vis_max_runs = 0;
     struct { const void* model = nullptr; long frame = -1; int cur = -1; } vis_tag;
+    bool fused_rgb_pyramid = true;         // "fusedRgbPyramid": the frame's intensity pyramid + derivative / gate images as one launch (0: four launches, the executable specification)
     int ticket_lanes = 1;                  // ticket counters of the clean pass: min(kCleanTicketLanes, compute units of the device)
     bool cull_runs = true;                 // "cullRuns": 0 = every projection pass streams the whole buffer (A/B switch, executable specification)
     int big_map_elements = 6000000;        // "bigMapElements": from this many surfels on a model's clean pass is the one-launch form (which writes the run
@@ -1000,6 +1001,7 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!strcmp(key, "globalTiles")) { c->global_tiles = value != 0; return MF_OK; }
     if (!strcmp(key, "cullRuns")) { c->cull_runs = value != 0; c->vis_tag.model = nullptr; return MF_OK; }
     if (!strcmp(key, "bigMapElements")) { c->big_map_elements = (int)value; c->vis_tag.model = nullptr; return MF_OK; }
+    if (!strcmp(key, "fusedRgbPyramid")) { c->fused_rgb_pyramid = value != 0; return MF_OK; }
     if (!strcmp(key, "inPlaceElements")) { c->in_place_elements = (int)value; return MF_OK; }
     if (!strcmp(key, "rebuildRunTable")) {   // tooling: the background's run table from scratch (what an upload / Model::initialise does)
         launch_run_table(c->models[0]->surf[c->models[0]->cur], c->models[0]->d_frame, c->stream);
@@ -1092,7 +1094,19 @@ static int debug_read_impl(mf_ctx* c, ModelState& mdl, const char* what, void* o
         return false;
     };
     const int lastSet = (int)((c->frame_no + 1) & 1);  // buffer set of the last processed / staged frame
+    auto img = [&](const std::string& pre, const void* const arr[3], size_t elem) -> bool {   // frame-side intensity pyramid / derivative / gate images
+        for (int i = 0; i < 3; ++i)
+            if (w == pre + std::to_string(i)) {
+                src = arr[i]; bytes = (size_t)(c->W >> i) * (c->H >> i) * elem;
+                return true;
+            }
+        return false;
+    };
+    const void* const gray3[3] = {c->d_gray[lastSet][0], c->d_gray[lastSet][1], c->d_gray[lastSet][2]};
+    const void* const dx3[3] = {c->d_dIdx[0], c->d_dIdx[1], c->d_dIdx[2]}, * const dy3[3] = {c->d_dIdy[0], c->d_dIdy[1], c->d_dIdy[2]};
+    const void* const gate3[3] = {c->d_rgb_gate[0], c->d_rgb_gate[1], c->d_rgb_gate[2]};
     if (w == "depthF") { src = c->d_depthF[c->lastF]; bytes = P * 4; }
+    else if (img("gray", gray3, 1) || img("dIdx", dx3, 2) || img("dIdy", dy3, 2) || img("rgb_gate", gate3, 1)) {}
     else if (lvl("vmap_g", mdl.d_vmap_g) || lvl("nmap_g", mdl.d_nmap_g) || lvl("vmap", c->d_vmap[lastSet]) || lvl("nmap", c->d_nmap[lastSet])) {}
     else if (w == "pred_vertex") { src = mdl.d_predV; bytes = P * 16; }
     else if (w == "pred_normal") { src = mdl.d_predN; bytes = P * 16; }

@@ -353,6 +353,11 @@ static int enqueue_preprocess(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
     if (photometric_on(c) || g.so3) {
         // imageBGRToIntensity + pyrDownUcharGauss of the frame (initRGB / initFirstRGB) and, for the photometric term,
         // computeDerivativeImages (RGBDOdometry.cpp:245-250)
+        const float min_scale[3] = {rgb_min_scale(0), rgb_min_scale(1), rgb_min_scale(2)};
+        if (c->fused_rgb_pyramid && launch_rgb_pyramid(d_rgb, W, H, c->d_gray[set], c->d_dIdx, c->d_dIdy, c->d_rgb_gate, min_scale, photometric_on(c), sp)) {
+            c->gray_frame[set] = k;   // one launch: the three intensity levels and (photometric term) their derivative / gate images
+            if (photometric_on(c)) c->deriv_frame = k;
+        } else {
         launch_intensity(d_rgb, 3, c->d_gray[set][0], P, sp);
         for (int i = 0; i + 1 < 3; ++i) launch_pyrdown_u8(c->d_gray[set][i], c->d_gray[set][i + 1], W >> i, H >> i, sp);
         c->gray_frame[set] = k;
@@ -363,6 +368,7 @@ static int enqueue_preprocess(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
                 jobs.j[i] = SmallJob{2, c->d_gray[set][i], c->d_dIdx[i], c->d_dIdy[i], c->d_rgb_gate[i], W >> i, H >> i, rgb_min_scale(i)};
             launch_small_jobs(jobs, sp);
             c->deriv_frame = k;
+        }
         }
     }
     mark(c, 1, sp);

@@ -198,6 +198,9 @@ void launch_derivative(const uint8_t* src, int16_t* dx, int16_t* dy, int W, int 
 struct SmallJob { int kind; const void* src; void* dst; void* dst2; uint8_t* gate; int W, H; float minScale; };
 struct SmallJobs { SmallJob j[3]; int n; };
 void launch_small_jobs(const SmallJobs& a, hipStream_t s);
+// intensity pyramid (3 levels) + derivative / gate images of a frame in one launch; false (nothing launched) for sizes its tiling does not cover
+bool launch_rgb_pyramid(const uint8_t* rgb, int W, int H, uint8_t* const gray[3], int16_t* const dIdx[3], int16_t* const dIdy[3], uint8_t* const gate[3],
+                        const float minScale[3], bool derivatives, hipStream_t s);
 // level 0 of a model's "last" depth / intensity pyramids (populateRGBDData of initRGBModel; Q1: initRGB re-uses the depth)
 // frameToFrameRGB != 0 (and a fill-in image given): initRGBModel takes the fill-in image whatever the fill-in decision (Model.cpp:399-400)
 void launch_rgbd_last_l0(const float4* predV, const float* fillDepth, const uint8_t* predGray, const uint8_t* fillGray,

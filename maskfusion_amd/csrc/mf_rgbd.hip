@@ -162,6 +162,144 @@ void launch_small_jobs(const SmallJobs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_small_jobs, dim3(gx, gy, a.n), dim3(256), 0, s, a);
 }
 
+// ---------------- the frame's intensity pyramid, derivative and gate images in ONE launch ----------------
+// imageBGRToIntensity + 2 x pyrDownUcharGauss + computeDerivativeImages x 3 (+ the pose-independent gate of reduce.cu:823-851 x 3) were four
+// dependent launches of 7-8 us each on images of at most 0.3 M pixels (launch latency, not work).  Here a workgroup owns a 32 x 32-pixel tile of
+// level 0 (16 x 16 of level 1, 8 x 8 of level 2), computes the intensity of the tile and of the halo its coarser levels and their windows
+// need -- 57 x 57 texels of level 0 -> 27 x 27 of level 1 -> 12 x 12 of level 2 -- into the LDS, and runs the same per-pixel expressions as the
+// single kernels above on the LDS copies (the window rules depend on the pixel's GLOBAL coordinates only): same bytes, one launch.
+constexpr int kRpT2 = 8, kRpR2 = kRpT2 + 4, kRpR1 = 2 * kRpT2 + 11, kRpR0 = 4 * kRpT2 + 25;
+struct RgbPyrArgs {
+    const uint8_t* rgb; int W, H;
+    uint8_t* gray[3]; int16_t* dIdx[3]; int16_t* dIdy[3]; uint8_t* gate[3]; float minScale[3];
+    int derivatives;      // 0: the three intensity levels only (SO(3) without the photometric term)
+};
+// pyrdown_u8_body's pixel through an accessor (global level coordinates -> texel)
+template <class Src>
+__device__ __forceinline__ uint8_t pyrdown_u8_px(Src src, int sw, int sh, int x, int y) {
+    const int D = 5;
+    const int tx = min(2 * x - D / 2 + D, sw - 1), ty = min(2 * y - D / 2 + D, sh - 1);
+    float sum = 0.f;
+    int count = 0;
+    for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
+        for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
+            const int v = src(cx, cy);
+            if (v > 0) {
+                const float w = gauss5w(ty - cy - 1, tx - cx - 1);
+                sum += (float)v * w;
+                count += (int)w;
+            }
+        }
+    const float r = sum / (float)count;
+    return isnan(r) ? (uint8_t)0 : (uint8_t)(int)r;
+}
+// derivative_body's pixel (and its gate) through an accessor
+template <class Src>
+__device__ __forceinline__ void derivative_px(Src src, int W, int H, int x, int y, float minScale, int16_t& sx, int16_t& sy, bool& gate) {
+    const float gx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
+    const float gy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
+    float dxVal = 0.f, dyVal = 0.f;
+    int k = 8;
+    for (int j = max(y - 1, 0); j <= min(y + 1, H - 1); ++j)
+        for (int i = max(x - 1, 0); i <= min(x + 1, W - 1); ++i) {
+            const float sv = (float)src(i, j);
+            float wx = 0.f, wy = 0.f;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) { wx = (q == k) ? gx[q] : wx; wy = (q == k) ? gy[q] : wy; }
+            dxVal = fmaf(sv, wx, dxVal);
+            dyVal = fmaf(sv, wy, dyVal);
+            --k;
+        }
+    sx = (int16_t)dxVal; sy = (int16_t)dyVal;
+    // rgb_gate_px (mf_rgbd_device.h) on the accessor
+    gate = false;
+    if (x < W - 5 && y < H - 1) {
+        bool valid = true;
+        for (int u = max(y - 2, 0); u < min(y + 2, H); ++u)
+            for (int v = max(x - 2, 0); v < min(x + 2, W); ++v) valid = valid && (src(v, u) > 0);
+        if (valid) gate = (float)(((int)sx * (int)sx) + ((int)sy * (int)sy)) >= minScale;
+    }
+}
+__global__ __launch_bounds__(256) void k_rgb_pyramid(const RgbPyrArgs a) {
+    __shared__ uint8_t s_g0[kRpR0 * kRpR0], s_g1[kRpR1 * kRpR1], s_g2[kRpR2 * kRpR2];
+    const int W0 = a.W, H0 = a.H, W1 = W0 / 2, H1 = H0 / 2, W2 = W1 / 2, H2 = H1 / 2;
+    const int tilesX = (W2 + kRpT2 - 1) / kRpT2;
+    const int X2 = ((int)blockIdx.x % tilesX) * kRpT2, Y2 = ((int)blockIdx.x / tilesX) * kRpT2;
+    const int ox2 = X2 - 2, oy2 = Y2 - 2, ox1 = 2 * X2 - 6, oy1 = 2 * Y2 - 6, ox0 = 4 * X2 - 14, oy0 = 4 * Y2 - 14;
+    // level 0: intensity of the tile and its halo
+    for (int t = threadIdx.x; t < kRpR0 * kRpR0; t += 256) {
+        const int x = ox0 + t % kRpR0, y = oy0 + t / kRpR0;
+        uint8_t v = 0;
+        if (x >= 0 && y >= 0 && x < W0 && y < H0) {
+            const uint8_t* p = a.rgb + ((size_t)y * W0 + x) * 3;
+            v = intensity_of((float)p[0], (float)p[1], (float)p[2]);
+        }
+        s_g0[t] = v;
+    }
+    __syncthreads();
+    auto g0 = [&](int x, int y) -> int { return s_g0[(y - oy0) * kRpR0 + (x - ox0)]; };
+    for (int t = threadIdx.x; t < kRpR1 * kRpR1; t += 256) {
+        const int x = ox1 + t % kRpR1, y = oy1 + t / kRpR1;
+        s_g1[t] = (x >= 0 && y >= 0 && x < W1 && y < H1) ? pyrdown_u8_px(g0, W0, H0, x, y) : (uint8_t)0;
+    }
+    __syncthreads();
+    auto g1 = [&](int x, int y) -> int { return s_g1[(y - oy1) * kRpR1 + (x - ox1)]; };
+    for (int t = threadIdx.x; t < kRpR2 * kRpR2; t += 256) {
+        const int x = ox2 + t % kRpR2, y = oy2 + t / kRpR2;
+        s_g2[t] = (x >= 0 && y >= 0 && x < W2 && y < H2) ? pyrdown_u8_px(g1, W1, H1, x, y) : (uint8_t)0;
+    }
+    __syncthreads();
+    auto g2 = [&](int x, int y) -> int { return s_g2[(y - oy2) * kRpR2 + (x - ox2)]; };
+    // the tile's own pixels of the three levels: intensity out, derivative / gate images
+    for (int t = threadIdx.x; t < 16 * kRpT2 * kRpT2; t += 256) {
+        const int x = 4 * X2 + t % (4 * kRpT2), y = 4 * Y2 + t / (4 * kRpT2);
+        if (x < W0 && y < H0) {
+            a.gray[0][y * W0 + x] = (uint8_t)g0(x, y);
+            if (a.derivatives) {
+                int16_t sx, sy; bool gt;
+                derivative_px(g0, W0, H0, x, y, a.minScale[0], sx, sy, gt);
+                a.dIdx[0][y * W0 + x] = sx; a.dIdy[0][y * W0 + x] = sy;
+                if (a.gate[0]) a.gate[0][y * W0 + x] = gt ? 1 : 0;
+            }
+        }
+    }
+    for (int t = threadIdx.x; t < 4 * kRpT2 * kRpT2; t += 256) {
+        const int x = 2 * X2 + t % (2 * kRpT2), y = 2 * Y2 + t / (2 * kRpT2);
+        if (x < W1 && y < H1) {
+            a.gray[1][y * W1 + x] = (uint8_t)g1(x, y);
+            if (a.derivatives) {
+                int16_t sx, sy; bool gt;
+                derivative_px(g1, W1, H1, x, y, a.minScale[1], sx, sy, gt);
+                a.dIdx[1][y * W1 + x] = sx; a.dIdy[1][y * W1 + x] = sy;
+                if (a.gate[1]) a.gate[1][y * W1 + x] = gt ? 1 : 0;
+            }
+        }
+    }
+    for (int t = threadIdx.x; t < kRpT2 * kRpT2; t += 256) {
+        const int x = X2 + t % kRpT2, y = Y2 + t / kRpT2;
+        if (x < W2 && y < H2) {
+            a.gray[2][y * W2 + x] = (uint8_t)g2(x, y);
+            if (a.derivatives) {
+                int16_t sx, sy; bool gt;
+                derivative_px(g2, W2, H2, x, y, a.minScale[2], sx, sy, gt);
+                a.dIdx[2][y * W2 + x] = sx; a.dIdy[2][y * W2 + x] = sy;
+                if (a.gate[2]) a.gate[2][y * W2 + x] = gt ? 1 : 0;
+            }
+        }
+    }
+}
+// true when the launch was made (sizes the tiling covers: both halvings exact); false: the caller runs the single kernels
+bool launch_rgb_pyramid(const uint8_t* rgb, int W, int H, uint8_t* const gray[3], int16_t* const dIdx[3], int16_t* const dIdy[3], uint8_t* const gate[3],
+                        const float minScale[3], bool derivatives, hipStream_t s) {
+    if ((W & 3) || (H & 3)) return false;
+    RgbPyrArgs a;
+    a.rgb = rgb; a.W = W; a.H = H; a.derivatives = derivatives ? 1 : 0;
+    for (int i = 0; i < 3; ++i) { a.gray[i] = gray[i]; a.dIdx[i] = dIdx[i]; a.dIdy[i] = dIdy[i]; a.gate[i] = gate[i]; a.minScale[i] = minScale[i]; }
+    const int W2 = W / 4, H2 = H / 4;
+    hipLaunchKernelGGL(k_rgb_pyramid, dim3(((W2 + kRpT2 - 1) / kRpT2) * ((H2 + kRpT2 - 1) / kRpT2)), dim3(256), 0, s, a);
+    return true;
+}
+
 // ---------------- SO(3) pre-alignment: all iterations in one workgroup ----------------
 __device__ __forceinline__ void so3_bases(const double* R, Intr k, float* basis) {  // RGBDOdometry.cpp:290-302
     const double K[9] = {(double)k.fx, 0, (double)k.cx, 0, (double)k.fy, (double)k.cy, 0, 0, 1};

@@ -282,8 +282,36 @@ def map_forms(n=8, W=160, H=120):
     return out
 
 
+def rgb_pyramid(n=3):
+    """The frame's intensity pyramid + derivative / gate images: the one-launch form (k_rgb_pyramid, LDS-tiled) against the four single kernels it
+    replaces (mf_set_param "fusedRgbPyramid" 0), on sizes with partial tiles and colour images with zero patches (pyrDownUcharGauss skips zero
+    texels, the gate wants a 4 x 4 window > 0): every image of every level identical, and with them pose and map."""
+    out = {}
+    for (W, H) in ((160, 120), (200, 152), (136, 104)):
+        f = 528.0 * W / 640.0
+        st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
+        frames = [st.frame(k) for k in range(n)]
+        rgb2 = frames[-1][0].copy(); rgb2[10:30, 20:50] = 0; rgb2[H - 9:, :40] = 0; rgb2[:, W - 7:] = 0
+        frames[-1] = (rgb2, frames[-1][1], frames[-1][2])
+        res = []
+        for fused in (0, 1):
+            mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=20.0, so3=True, enableMultipleModels=False, numGSurfels=1 << 17)
+            mf.setParam("fusedRgbPyramid", fused)
+            taps = []
+            for k, (rgb, d, _) in enumerate(frames):
+                mf.processFrame(rgb, d, timestamp=k)
+                taps.append([mf.debugRead(f"{p}{i}").copy() for p in ("gray", "dIdx", "dIdy", "rgb_gate") for i in range(3)])
+            res.append((taps, mf.getCurrPose().copy(), mf.getBackgroundModel().downloadMap().copy()))
+            mf.close()
+        (ta, pa, ca), (tb, pb, cb) = res
+        out[f"{W}x{H}"] = dict(images_equal=all(np.array_equal(x, y) for fa, fb in zip(ta, tb) for x, y in zip(fa, fb)),
+                               pose_equal=bool(np.array_equal(pa, pb)), cloud_equal=bool(np.array_equal(ca, cb, equal_nan=True)),
+                               gate_pixels=int(ta[-1][9].sum()), zero_texels=int((ta[-1][0] == 0).sum()))
+    return out
+
+
 if __name__ == "__main__":
     scenarios = dict(single=single_model, rgbd=rgbd_so3, bad_depth=bad_depth_pixels, schedule=schedule_switches, mm_bad_depth=multimodel_bad_depth,
-                     weight=weight_multiplier_cases, dev_masks=device_resident_masks, static=static_switches, host_paths=host_paths, map_forms=map_forms)
+                     weight=weight_multiplier_cases, dev_masks=device_resident_masks, static=static_switches, host_paths=host_paths, map_forms=map_forms, rgb_pyramid=rgb_pyramid)
     wanted = sys.argv[1:] or list(scenarios)      # (tests/test_gpu_emu_agrees.py asks for "single" only; the CPU suite runs all of them)
     print(json.dumps({k: scenarios[k]() for k in wanted}))

@@ -478,3 +478,39 @@ def test_clean_forms_agree(hip, multi):
             assert len(pa) == len(pb) and all(np.array_equal(x, y) for x, y in zip(pa, pb))
         for x, y in zip(a["clouds"], b["clouds"]):
             assert np.array_equal(x, y, equal_nan=True)
+
+
+@pytest.mark.parametrize("size", [(640, 480), (200, 152)], ids=["vga", "200x152"])
+def test_fused_rgb_pyramid_equals_the_single_kernels(hip, size):
+    """`fusedRgbPyramid` (round 5): the frame's intensity pyramid and its derivative / gate images come out of ONE LDS-tiled launch instead of
+    imageBGRToIntensity + 2 x pyrDownUcharGauss + computeDerivativeImages x 3 (cudafuncs.cu:534-588,602-639,658-718; the single kernels are pinned
+    to the reference's vectors in test_gpu_ref_golden.py / test_gpu_rgbd.py).  Every image of every level identical on every frame -- a size
+    with partial tiles included, colour images with zero patches (the zero-skipping rule, the gate's 4 x 4 window) --, and with them poses and map."""
+    from maskfusion_amd import MaskFusion, synth
+    W, H = size
+    f = 528.0 * W / 640.0
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
+    frames = [st.frame(k) for k in range(6)]
+    rgb2 = frames[-1][0].copy(); rgb2[10:30, 20:50] = 0; rgb2[H - 9:, :40] = 0; rgb2[:, W - 7:] = 0
+    frames[-1] = (rgb2, frames[-1][1], frames[-1][2])
+    names = [f"{p}{i}" for p in ("gray", "dIdx", "dIdy", "rgb_gate") for i in range(3)]
+
+    def run(fused):
+        mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=20.0, so3=True, enableMultipleModels=False, numGSurfels=1 << 19)
+        mf.setParam("fusedRgbPyramid", fused)
+        taps, poses = [], []
+        for k, (rgb, d, _) in enumerate(frames):
+            mf.processFrame(rgb, d, timestamp=k)
+            taps.append({t: mf.debugRead(t).copy() for t in names})
+            poses.append(mf.getCurrPose().copy())
+        cloud = mf.getBackgroundModel().downloadMap().copy()
+        mf.close()
+        return taps, poses, cloud
+
+    (ta, pa, ca), (tb, pb, cb) = run(0), run(1)
+    for k in range(len(frames)):
+        for t in names:
+            assert np.array_equal(ta[k][t], tb[k][t]), (k, t, int((ta[k][t] != tb[k][t]).sum()))
+        assert np.array_equal(pa[k], pb[k]), k
+    assert np.array_equal(ca, cb, equal_nan=True)
+    assert int(ta[-1]["rgb_gate0"].sum()) > 100 and int((ta[-1]["gray0"] == 0).sum()) > 500
