@@ -168,6 +168,7 @@ void launch_small_jobs(const SmallJobs& a, hipStream_t s) {
 // level 0 (16 x 16 of level 1, 8 x 8 of level 2), computes the intensity of the tile and of the halo its coarser levels and their windows
 // need -- 57 x 57 texels of level 0 -> 27 x 27 of level 1 -> 12 x 12 of level 2 -- into the LDS, and runs the same per-pixel expressions as the
 // single kernels above on the LDS copies (the window rules depend on the pixel's GLOBAL coordinates only): same bytes, one launch.
+constexpr int kRpThreads = 1024;   // 256 threads took 43 us for what four launches do in 30 (a workgroup's phases are serial: 13 + 3 + 1 + 6 rounds per thread); 1024: a quarter of the rounds
 constexpr int kRpT2 = 8, kRpR2 = kRpT2 + 4, kRpR1 = 2 * kRpT2 + 11, kRpR0 = 4 * kRpT2 + 25;
 struct RgbPyrArgs {
     const uint8_t* rgb; int W, H;
@@ -220,14 +221,14 @@ __device__ __forceinline__ void derivative_px(Src src, int W, int H, int x, int 
         if (valid) gate = (float)(((int)sx * (int)sx) + ((int)sy * (int)sy)) >= minScale;
     }
 }
-__global__ __launch_bounds__(256) void k_rgb_pyramid(const RgbPyrArgs a) {
+__global__ __launch_bounds__(kRpThreads) void k_rgb_pyramid(const RgbPyrArgs a) {
     __shared__ uint8_t s_g0[kRpR0 * kRpR0], s_g1[kRpR1 * kRpR1], s_g2[kRpR2 * kRpR2];
     const int W0 = a.W, H0 = a.H, W1 = W0 / 2, H1 = H0 / 2, W2 = W1 / 2, H2 = H1 / 2;
     const int tilesX = (W2 + kRpT2 - 1) / kRpT2;
     const int X2 = ((int)blockIdx.x % tilesX) * kRpT2, Y2 = ((int)blockIdx.x / tilesX) * kRpT2;
     const int ox2 = X2 - 2, oy2 = Y2 - 2, ox1 = 2 * X2 - 6, oy1 = 2 * Y2 - 6, ox0 = 4 * X2 - 14, oy0 = 4 * Y2 - 14;
     // level 0: intensity of the tile and its halo
-    for (int t = threadIdx.x; t < kRpR0 * kRpR0; t += 256) {
+    for (int t = threadIdx.x; t < kRpR0 * kRpR0; t += kRpThreads) {
         const int x = ox0 + t % kRpR0, y = oy0 + t / kRpR0;
         uint8_t v = 0;
         if (x >= 0 && y >= 0 && x < W0 && y < H0) {
@@ -238,20 +239,20 @@ __global__ __launch_bounds__(256) void k_rgb_pyramid(const RgbPyrArgs a) {
     }
     __syncthreads();
     auto g0 = [&](int x, int y) -> int { return s_g0[(y - oy0) * kRpR0 + (x - ox0)]; };
-    for (int t = threadIdx.x; t < kRpR1 * kRpR1; t += 256) {
+    for (int t = threadIdx.x; t < kRpR1 * kRpR1; t += kRpThreads) {
         const int x = ox1 + t % kRpR1, y = oy1 + t / kRpR1;
         s_g1[t] = (x >= 0 && y >= 0 && x < W1 && y < H1) ? pyrdown_u8_px(g0, W0, H0, x, y) : (uint8_t)0;
     }
     __syncthreads();
     auto g1 = [&](int x, int y) -> int { return s_g1[(y - oy1) * kRpR1 + (x - ox1)]; };
-    for (int t = threadIdx.x; t < kRpR2 * kRpR2; t += 256) {
+    for (int t = threadIdx.x; t < kRpR2 * kRpR2; t += kRpThreads) {
         const int x = ox2 + t % kRpR2, y = oy2 + t / kRpR2;
         s_g2[t] = (x >= 0 && y >= 0 && x < W2 && y < H2) ? pyrdown_u8_px(g1, W1, H1, x, y) : (uint8_t)0;
     }
     __syncthreads();
     auto g2 = [&](int x, int y) -> int { return s_g2[(y - oy2) * kRpR2 + (x - ox2)]; };
     // the tile's own pixels of the three levels: intensity out, derivative / gate images
-    for (int t = threadIdx.x; t < 16 * kRpT2 * kRpT2; t += 256) {
+    for (int t = threadIdx.x; t < 16 * kRpT2 * kRpT2; t += kRpThreads) {
         const int x = 4 * X2 + t % (4 * kRpT2), y = 4 * Y2 + t / (4 * kRpT2);
         if (x < W0 && y < H0) {
             a.gray[0][y * W0 + x] = (uint8_t)g0(x, y);
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void k_rgb_pyramid(const RgbPyrArgs a) {
             }
         }
     }
-    for (int t = threadIdx.x; t < 4 * kRpT2 * kRpT2; t += 256) {
+    for (int t = threadIdx.x; t < 4 * kRpT2 * kRpT2; t += kRpThreads) {
         const int x = 2 * X2 + t % (2 * kRpT2), y = 2 * Y2 + t / (2 * kRpT2);
         if (x < W1 && y < H1) {
             a.gray[1][y * W1 + x] = (uint8_t)g1(x, y);
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256) void k_rgb_pyramid(const RgbPyrArgs a) {
             }
         }
     }
-    for (int t = threadIdx.x; t < kRpT2 * kRpT2; t += 256) {
+    for (int t = threadIdx.x; t < kRpT2 * kRpT2; t += kRpThreads) {
         const int x = X2 + t % kRpT2, y = Y2 + t / kRpT2;
         if (x < W2 && y < H2) {
             a.gray[2][y * W2 + x] = (uint8_t)g2(x, y);
@@ -296,7 +297,7 @@ bool launch_rgb_pyramid(const uint8_t* rgb, int W, int H, uint8_t* const gray[3]
     a.rgb = rgb; a.W = W; a.H = H; a.derivatives = derivatives ? 1 : 0;
     for (int i = 0; i < 3; ++i) { a.gray[i] = gray[i]; a.dIdx[i] = dIdx[i]; a.dIdy[i] = dIdy[i]; a.gate[i] = gate[i]; a.minScale[i] = minScale[i]; }
     const int W2 = W / 4, H2 = H / 4;
-    hipLaunchKernelGGL(k_rgb_pyramid, dim3(((W2 + kRpT2 - 1) / kRpT2) * ((H2 + kRpT2 - 1) / kRpT2)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_rgb_pyramid, dim3(((W2 + kRpT2 - 1) / kRpT2) * ((H2 + kRpT2 - 1) / kRpT2)), dim3(kRpThreads), 0, s, a);
     return true;
 }
 

@@ -3,7 +3,7 @@
 # reference-default bench line
 TAG=${1:-r05y}
 mkdir -p gpurun_out
-timeout 300 python -m pytest "tests/test_gpu_switches.py::test_fused_rgb_pyramid_equals_the_single_kernels" "tests/test_gpu_parity_long.py::test_long_horizon_ate_reference_defaults" tests/test_gpu_rgbd.py \
+timeout 300 python -m pytest "tests/test_gpu_switches.py::test_fused_rgb_pyramid_equals_the_single_kernels" ${MF_R05Y_MORE_TESTS} \
    -q -m gpu -n 4 -x > gpurun_out/${TAG}_pytest.log 2>&1
 echo "pytest rc=$?"; tail -3 gpurun_out/${TAG}_pytest.log | cut -c1-200
 rd() {
@@ -13,11 +13,10 @@ rd() {
 import json, sys
 try:
     d = json.load(open(sys.argv[2]))
-    print(f"reference-default {sys.argv[1]:10s} {d['value']:7.1f} frames/s  {d['ms_per_step']*1e3:.1f} us", {k: round(v * 1e3, 1) for k, v in d['roofline']['stage_ms'].items() if v and k in ('Preprocess', 'odom', 'Run')})
+    print(f"reference-default {sys.argv[1]:10s} {d['value']:7.1f} frames/s  {d['ms_per_step']*1e3:.1f} us")
 except Exception as e:
     print("rd", sys.argv[1], "FAILED", e)
 PY
 }
 rd fused
 rd single --param fusedRgbPyramid=0
-rd fused_again
