@@ -60,9 +60,11 @@ struct GNState {
 struct FrameDev {
     int tick;                  // MaskFusion::tick
     int count;                 // Model::count (live surfels)
-    int countNext;             // snapshot of `count` taken by clean pass 1 and read by pass 2, whose last workgroup then
-                               // rewrites `count` (no workgroup of pass 2 reads `count`, so no intra-launch ordering is assumed)
-    int runs;                  // entries of the live buffer's run table (Surfels::box)
+    int countNext;             // snapshot of `count` (dense buffer) / `phys` (sparse buffer) taken by clean pass 1 and read by pass 2, whose last
+                               // workgroup then rewrites them (no workgroup of pass 2 reads them, so no intra-launch ordering is assumed)
+    int runs;                  // entries of the live buffer's run table (Surfels::box); 0: the buffer is DENSE and has no table -- its surfels are
+                               // slots [0, count); > 0: the surfels are the slots [start_r, start_r + len_r) of the runs, in run order (a SPARSE
+                               // buffer once a run has lost surfels: Model::clean then works in place, mf_surfel.hip "clean, in place")
     int cover;                 // predicted-colour coverage count (requiresFillIn)
     int useFillIn;             // decision taken for the current tracking step
     int pad[3];
@@ -70,6 +72,9 @@ struct FrameDev {
     // the one being accumulated by this frame's clean pass (object models only; the frame advance moves it over)
     int bbox[6], bbox_acc[6];
     int bbox_tmp[6];           // ... and what the workgroups of a running clean launch have merged so far (empty between launches)
+    int phys;                  // first slot behind the last run (= count for a dense buffer): where Model::clean appends the frame's new surfels
+    int first;                 // slot of the FIRST live surfel (0 for a dense buffer): the surfel whose vertex id is 0 and which the index map
+                               // therefore cannot tell from "no surfel" (index_map.frag writes the id into a texture cleared to 0)
     unsigned long long done_cover;   // k_splat_tile: (workgroups finished << 32) | coverage count of this launch; zero between launches
 };
 
@@ -91,17 +96,22 @@ struct Surfels {               // SoA of float4, 48 B per surfel in three coales
     float4* ct;                // colour, unused, initTime, lastTime
     float4* nr;                // normal + radius
     int cap;                   // capacity in surfels (writes beyond it are dropped, like a full transform-feedback buffer)
-    // Run table: the buffer as consecutive RUNS of at most kRun surfels (run r = the survivors of the r-th chunk of the clean pass that wrote the
-    // buffer, or -- after Model::initialise / an uploaded map -- slots [r kRun, (r + 1) kRun)), two int4 per run:
-    //   {enc(min x), enc(min y), enc(min z), enc(newest lastTime)}, {enc(max x), enc(max y), enc(max z), first slot of the run}
-    // (enc: order-preserving float -> int, mf_device.h box_enc; entry [frame->runs] carries the buffer's count as the end of the last run).
+    // Run table: the buffer as consecutive RUNS of at most kRun slots (after Model::initialise / an uploaded map / a compaction: slots
+    // [r kRun, (r + 1) kRun); behind them the runs Model::clean appended, one frame's new surfels after the other), kBoxStride int4 per run:
+    //   {enc(min x), enc(min y), enc(min z), enc(newest lastTime)}, {enc(max x), enc(max y), enc(max z), first slot of the run},
+    //   {live surfels of the run (they are its FIRST slots, in order), enc(lowest confidence), 0, 0}
+    // (enc: order-preserving float -> int, mf_device.h box_enc).
     // Surfels are stored in creation order, i.e. in spatially coherent runs; a full map is mostly out of view (the 26.5 M-surfel map of
     // configs[4]: 86 %), and the projection passes (index map x 2, prediction, GlobalProjection) only visit the runs whose box meets the viewing
     // frustum and that hold a surfel seen within timeDelta (k_cull) -- the reference streams the whole buffer through every pass
-    // (ModelProjection.cpp:100-152,187-268).  Every frame's clean pass rewrites the buffer and with it the table.
+    // (ModelProjection.cpp:100-152,187-268).  Model::clean of a big map visits only the runs in which its tests can change something and
+    // compacts each of them where it stands: the order of the surfels (= the reference's transform-feedback order) is the order of the runs.
     int4* box;
 };
 constexpr int kRun = 512;
+constexpr int kBoxStride = 3;
+__host__ __device__ inline int run_start(const int4* box, int r) { return box[kBoxStride * r + 1].w; }
+__host__ __device__ inline int run_len(const int4* box, int r) { return box[kBoxStride * r + 2].x; }
 struct VisList { const int* list; const int* count; };   // device memory: run indices (any order) and how many (launch_cull)
 constexpr int kBoxEmptyMin = 0x7FFFFFFF, kBoxEmptyMax = (int)0x80000000;
 

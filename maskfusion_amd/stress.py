@@ -34,13 +34,18 @@ def surfel_capacity(num: int) -> int:
     return d * d
 
 
-SCENE_BOXES = 6       # object boxes in the scene: with synth.Scene's ring of six, boxes 1..4 are all in view (in its ring of four, box 3 hides)
+SCENE_BOXES = 6       # object boxes in the scene: with synth.Scene's ring of six, four boxes are in view with THREE faces each
+# The instance-masked boxes 1..4 stand on the ring positions from which the camera sees three of their faces (below and above its axis); the two
+# positions level with the camera (two faces: a Gauss-Newton system on a dense map's exact planes is rank 5 there -- the edge direction slides)
+# go to the unmasked boxes 5 and 6.  Round 6: S3 tracks its objects (track_objects), so their trackers have to be conditioned.
+RING_SLOTS = (1, 2, 4, 5, 0, 3)
 
 
 def stream_kwargs(n_objects: int = 4, noise: bool = True, scale: int = 1) -> dict:
     """scale > 1: the same scene at 1 / scale of the resolution (the CPU-executed rehearsal of the scenario, tests/test_emu_dense_maps.py)"""
     w, h, f = W // scale, H // scale, F / scale
-    return dict(W=w, H=h, fx=f, fy=f, cx=w / 2.0, cy=h / 2.0, n_objects=SCENE_BOXES, noise=noise, object_motion=0.0, seed=1234, masked_objects=n_objects)
+    return dict(W=w, H=h, fx=f, fy=f, cx=w / 2.0, cy=h / 2.0, n_objects=SCENE_BOXES, noise=noise, object_motion=0.0, seed=1234, masked_objects=n_objects,
+                ring_slots=RING_SLOTS)
 
 
 def stream(n_objects: int = 4, noise: bool = True, scale: int = 1) -> synth.Stream:
@@ -116,3 +121,16 @@ def lead_in(mf, st: synth.Stream, frames, cls, n_objects: int = 4, fill: float =
     if log:
         log(f"after frame {k - 1}: background map {len(bg)} surfels of {cap_g} ({len(bg) / cap_g:.1%}); {len(loaded) - 1} object models")
     return k, loaded
+
+
+def track_objects(mf, on_model=None):
+    """S3 = S2's settings at 1280x960, and S2 tracks every model: makes every object model of `mf` non-static
+    (Model::makeNonStatic, Core/Model/Model.h:263-268 -- from the next frame on MaskFusion.cpp:263-276 tracks it instead of moving it with the
+    camera).  The lead-in itself runs with standing objects: a fresh ~10^4-surfel model tracked before its dense map is loaded is at the mercy
+    of the 0.2 m rule.  on_model(index): called for every model switched (the parity test switches the oracle's model there)."""
+    for i, x in enumerate(mf.getModels()):
+        if i == 0:
+            continue
+        x.makeNonStatic()
+        if on_model:
+            on_model(i)

@@ -58,7 +58,7 @@ class Box:
 class Scene:
     """Room [-2.5,2.5] x [-1.5,1.2] x [-1.0, zback] seen from around the origin looking down +z (y down)."""
 
-    def __init__(self, n_objects: int = 0, seed: int = 1234, zback: float = 2.8, object_motion: float = 1.0):
+    def __init__(self, n_objects: int = 0, seed: int = 1234, zback: float = 2.8, object_motion: float = 1.0, ring_slots=()):
         rng = np.random.RandomState(seed)
         self.zback = zback
         self.planes = [  # (axis, value, base colour)
@@ -78,7 +78,10 @@ class Scene:
         for c, h in static:
             self.boxes.append(Box(np.array(c, float), np.array(h, float), rng.uniform(60, 220, 3)))
         for k in range(n_objects):
-            ang = 2 * np.pi * k / max(n_objects, 1)
+            # ring_slots: which position of the ring instance k + 1 stands on (default: its own).  A box level with the camera (slots 0 and
+            # n / 2 of the ring) shows TWO faces: a tracker on its exact planes is rank-deficient by construction (maskfusion_amd/stress.py)
+            slot = ring_slots[k] if k < len(ring_slots) else k
+            ang = 2 * np.pi * slot / max(n_objects, 1)
             c = np.array([1.1 * np.cos(ang) * 0.9, 0.15 + 0.45 * np.sin(ang), 1.45 + 0.25 * np.cos(2 * ang)])
             h = rng.uniform(0.10, 0.18, 3)
             self.boxes.append(Box(c, h, rng.uniform(60, 240, 3), instance=k + 1,
@@ -171,9 +174,10 @@ class Stream:
     max_depth: float = 0.0
     object_motion: float = 1.0   # 0 = the instance-masked boxes stand still
     masked_objects: int = -1     # >= 0: only instance ids 1..masked_objects carry a mask; the other object boxes are rendered as furniture (mask 0)
+    ring_slots: tuple = ()       # Scene: the ring position of every instance (default: instance k + 1 on position k)
 
     def __post_init__(self):
-        self.scene = Scene(self.n_objects, self.seed, object_motion=self.object_motion)
+        self.scene = Scene(self.n_objects, self.seed, object_motion=self.object_motion, ring_slots=tuple(self.ring_slots))
 
     def gt_pose(self, frame: int) -> np.ndarray:
         return camera_pose(frame, self.speed)

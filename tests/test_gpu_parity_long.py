@@ -324,6 +324,50 @@ def _log_system_diff(dev_row, orc_row):
     return int(dev_row[28]), int(orc_row[28]), float(np.abs(dev_row[:27] - orc_row[:27]).max() / scale)
 
 
+class _StepStats:
+    """running figures of _check_tracking_step over a test"""
+    def __init__(self):
+        self.worst_it0 = self.worst_sys = self.worst_rt = self.worst_rc = 0.0
+        self.n_systems = self.n_inlier_flips = 0
+
+
+def _check_tracking_step(oracle, m, o, i, tag, trace, start_pose, pose, stats):
+    """One tracked model's Gauss-Newton loop of the frame just processed, iteration by iteration on equal input (RGBDOdometry.cpp:339-474):
+    the first logged system against the oracle's own first system (inliers exact, A / b 2e-4), the oracle's normal equations at the device's
+    pose of each of the 19 iterations (OracleMM.set_probe_poses; inliers within two gate-boundary pixels, A / b 2e-4 of the largest entry),
+    every one of the device's 19 updates against the oracle's solve + computeUpdateSE3 of the device's own fp64 system (resultRt 1e-9,
+    Rcurr / tcurr 2e-6), the last one landing on the model's pose.  Returns the inlier count of the first system."""
+    dl, ol = m.debugRead("icp_log", model=i), o.model_track_log(i)
+    assert len(ol) == 19
+    gi, oi, rel = _log_system_diff(dl[0], ol[0])
+    assert gi == oi, (tag, i, "inliers of the first Gauss-Newton system", gi, oi)
+    assert rel < 2e-4, (tag, i, rel)
+    stats.worst_it0 = max(stats.worst_it0, rel)
+    pl = o.model_probe_log(i)
+    assert len(pl) == 19, (tag, i, len(pl))
+    for it in range(19):
+        gi_k, oi_k, rel_k = _log_system_diff(trace[it, :32].astype(np.float32), pl[it])
+        # (the oracle evaluates on ITS model-side maps, which equal the device's to 2e-6 relative, not bit for bit -- tests/test_gpu_kernels.py
+        # -- so a pixel within rounding of the 0.10 m / 20 degree gates may fall on the other side: at most two of them per system;
+        # the first hardware run had ONE such pixel, 59 806 against 59 805 inliers, in ~5 000 systems)
+        assert abs(gi_k - oi_k) <= 2, (tag, i, it, "inliers", gi_k, oi_k)
+        stats.n_inlier_flips += int(gi_k != oi_k)
+        assert rel_k < 2e-4, (tag, i, it, rel_k)
+        stats.worst_sys = max(stats.worst_sys, rel_k)
+        stats.n_systems += 1
+    Rprev, tprev = start_pose[:3, :3], start_pose[:3, 3]            # the pose the step started from
+    for it in range(19):
+        A, b = _unpack_system(trace[it, :32])
+        rt, Rc, tc = _gn_update(oracle, trace[it, 32:48].reshape(4, 4), A, b, Rprev, tprev)
+        scale = max(1.0, float(np.abs(rt).max()))
+        d_rt = float(np.abs(rt.reshape(-1) - trace[it + 1, 32:48]).max()) / scale
+        d_rc = max(float(np.abs(Rc.reshape(-1) - trace[it + 1, 48:57]).max()), float(np.abs(tc - trace[it + 1, 57:60]).max()))
+        assert d_rt < 1e-9 and d_rc < 2e-6, (tag, i, it, d_rt, d_rc)
+        stats.worst_rt, stats.worst_rc = max(stats.worst_rt, d_rt), max(stats.worst_rc, d_rc)
+    assert np.abs(trace[19, 48:57].reshape(3, 3) - pose[:3, :3]).max() < 1e-7 and np.abs(trace[19, 57:60] - pose[:3, 3]).max() < 1e-7, (tag, i)
+    return gi
+
+
 def test_s2_eight_objects_tracked_teacher_forced(hip, oracle):
     """The tracked 8-object scene with the chaos taken out: after every frame the oracle is handed the product's
     model list and poses (OracleMM.force_tracking: its own tracking steps still run from its own -- identical -- state and stay readable, its
@@ -359,8 +403,8 @@ def test_s2_eight_objects_tracked_teacher_forced(hip, oracle):
     for k, v in (("mfThreshold", SEG["threshold"]), ("mfWeightDistance", SEG["weightDistance"]), ("mfWeightConvexity", SEG["weightConvexity"]),
                  ("mfMorphEdgeIterations", 0), ("mfMorphMaskIterations", 0), ("newModelMinRelativeSize", SEG["minRelSizeNew"])):
         m.setParam(k, v)
-    n_obj_steps, worst_obj, worst_it0, worst_lab, worst_cloud, dropped, max_models = 0, 0.0, 0.0, 0.0, 0.0, 0, 0
-    worst_sys, worst_rt, worst_rc, n_systems, n_inlier_flips = 0.0, 0.0, 0.0, 0, 0
+    n_obj_steps, worst_obj, worst_lab, worst_cloud, dropped, max_models = 0, 0.0, 0.0, 0.0, 0, 0
+    stats = _StepStats()
     prev_ids = [0]
     prev_pose = {}
     for k, (rgb, depth, mask) in enumerate(frames):
@@ -400,37 +444,7 @@ def test_s2_eight_objects_tracked_teacher_forced(hip, oracle):
             own, tracked = o.model_tracked_pose(i)
             if not tracked:
                 continue          # spawned in this frame
-            dl, ol = m.debugRead("icp_log", model=i), o.model_track_log(i)
-            assert len(ol) == 19
-            gi, oi, rel = _log_system_diff(dl[0], ol[0])
-            assert gi == oi, (k, i, "inliers of the first Gauss-Newton system", gi, oi)
-            assert rel < 2e-4, (k, i, rel)
-            worst_it0 = max(worst_it0, rel)
-            # every iteration on equal input: the oracle's system at the device's pose of that iteration ...
-            tr, pl = traces[i], o.model_probe_log(i)
-            assert len(pl) == 19, (k, i, len(pl))
-            for it in range(19):
-                gi_k, oi_k, rel_k = _log_system_diff(tr[it, :32].astype(np.float32), pl[it])
-                # (the oracle evaluates on ITS model-side maps, which equal the device's to 2e-6 relative, not bit for bit -- tests/test_gpu_kernels.py
-                # -- so a pixel within rounding of the 0.10 m / 20 degree gates may fall on the other side: at most two of them per system;
-                # the first hardware run had ONE such pixel, 59 806 against 59 805 inliers, in ~5 000 systems)
-                assert abs(gi_k - oi_k) <= 2, (k, i, it, "inliers", gi_k, oi_k)
-                n_inlier_flips += int(gi_k != oi_k)
-                assert rel_k < 2e-4, (k, i, it, rel_k)
-                worst_sys = max(worst_sys, rel_k)
-                n_systems += 1
-            # ... and every update of the device = the oracle's solve + update of the device's own (fp64) system
-            start = prev_pose[ids[i]]                                  # the pose the step started from (Rprev, tprev)
-            Rprev, tprev = start[:3, :3], start[:3, 3]
-            for it in range(19):
-                A, b = _unpack_system(tr[it, :32])
-                rt, Rc, tc = _gn_update(oracle, tr[it, 32:48].reshape(4, 4), A, b, Rprev, tprev)
-                scale = max(1.0, float(np.abs(rt).max()))
-                d_rt = float(np.abs(rt.reshape(-1) - tr[it + 1, 32:48]).max()) / scale
-                d_rc = max(float(np.abs(Rc.reshape(-1) - tr[it + 1, 48:57]).max()), float(np.abs(tc - tr[it + 1, 57:60]).max()))
-                assert d_rt < 1e-9 and d_rc < 2e-6, (k, i, it, d_rt, d_rc)
-                worst_rt, worst_rc = max(worst_rt, d_rt), max(worst_rc, d_rc)
-            assert np.abs(tr[19, 48:57].reshape(3, 3) - poses[i][:3, :3]).max() < 1e-7 and np.abs(tr[19, 57:60] - poses[i][:3, 3]).max() < 1e-7, (k, i)
+            gi = _check_tracking_step(oracle, m, o, i, k, traces[i], prev_pose[ids[i]], poses[i], stats)
             dstep = float(np.abs(own - poses[i]).max())
             if i == 0:
                 assert dstep < 1e-5, (k, dstep)
@@ -448,19 +462,12 @@ def test_s2_eight_objects_tracked_teacher_forced(hip, oracle):
     print("teacher-forced: %d frames, up to %d models, %d drops followed, %d object tracking steps compared; %d Gauss-Newton systems compared iteration by "
           "iteration (%d of them with an inlier count off by one or two): worst A / b difference %.2e, worst update: resultRt %.2e, Rcurr / tcurr %.2e; "
           "free-running object step (report) %.2e; label image %.2e, cloud %.2e"
-          % (n_frames, max_models, dropped, n_obj_steps, n_systems, n_inlier_flips, worst_sys, worst_rt, worst_rc, worst_obj, worst_lab, worst_cloud))
+          % (n_frames, max_models, dropped, n_obj_steps, stats.n_systems, stats.n_inlier_flips, stats.worst_sys, stats.worst_rt, stats.worst_rc, worst_obj, worst_lab,
+             worst_cloud))
     assert max_models >= 8 and n_obj_steps >= 4 * (n_frames - 6)
 
 
-def test_config4_dense_maps(hip, oracle):
-    """configs[4] as BASELINE.json / SURVEY.md 8d S3 define it: 1280x960, MASKFUSION_NUM_GSURFELS = 32M / NUM_OSURFELS = 4M (capacities 5760^2 /
-    2048^2, Model.cpp:101-108), 4 object models, every map pre-filled to >= 80 % of its capacity (26.5 M background surfels, 3.4 M per
-    object: maskfusion_amd/stress.py loads generated maps where a long orbit would have grown them), then 5 frames against OracleMM fed the
-    same frames, the same uploaded maps, the product's filtered depth and -- teacher forcing, as in the tracked 8-object test -- the
-    product's poses, so that every surfel pass of every frame runs on equal input at the budgets the reference is compiled with
-    (Core/CMakeLists.txt:27-28).  Gated on every dense frame: model list, surfel count of every model EXACT, label image, the background's own
-    tracking step; on the last frame every surfel of every model in its slot (position / normal / radius 1e-6, confidence 1e-5 rel,
-    colour and time stamps exact)."""
+def _config4_dense_maps(hip, oracle, tracked):
     from maskfusion_amd import stress
     from oracle import mfo_mm
     n_dense = int(os.environ.get("MF_PARITY_C4_FRAMES", 5))
@@ -476,19 +483,26 @@ def test_config4_dense_maps(hip, oracle):
     o = mfo_mm.OracleMM(W, H, f, f, W / 2.0, H / 2.0, icpWeight=100.0, so3=0, capacity=stress.surfel_capacity(num_g), capacityObject=stress.surfel_capacity(num_o),
                         modelSpawnOffset=2, trackAllModels=0, seg=SEG, confGlobal=10.0, confObject=0.01)
     m = stress.make_context(0, num_g, num_o, n_objects=n_obj, scale=scale)
-    if os.environ.get("MF_PARITY_C4_FORMS") == "big":              # small budgets, the passes of FULL maps (one-launch clean, run table + culling, in-place update)
+    if os.environ.get("MF_PARITY_C4_FORMS") == "big":              # small budgets, the passes of FULL maps (run table + culling, in-place update and clean)
         m.setParam("bigMapElements", 0)
         m.setParam("inPlaceElements", 0)
 
     def oracle_frame(k, rgb, depth, mask):
         gm = m.getModels()
-        o.force_tracking([x.getID() for x in gm], [x.getPose() for x in gm])
+        ids = [x.getID() for x in gm]
+        o.force_tracking(ids, [x.getPose() for x in gm])
+        if tracked:          # the pose every iteration of every model ran at, on the device (debug tap "gn_trace")
+            o.set_probe_poses(ids, [m.debugRead("gn_trace", model=i)[:, 48:60] for i in range(len(gm))])
         o.process_frame(rgb, depth, mask, cls, depth_filtered=m.debugRead("depthF"))
 
     k0, loaded = stress.lead_in(m, st, frames, cls, n_objects=n_obj, on_frame=oracle_frame, on_upload=lambda i, s: o.upload_map(i, s), log=print, max_frames=max_lead)
     assert len(loaded) == n_obj + 1, loaded                           # the background and four object models, each on its own box
     assert loaded[0] >= 0.8 * stress.surfel_capacity(num_g) and min(loaded[i] for i in range(1, n_obj + 1)) >= 0.8 * stress.surfel_capacity(num_o)
-    worst_lab = 0.0
+    if tracked:              # S3 = S2's settings: every object model is tracked from here on (Model::makeNonStatic, Model.h:263-268)
+        stress.track_objects(m, on_model=lambda i: o.make_nonstatic(i))
+    worst_lab, n_obj_steps, worst_obj = 0.0, 0, 0.0
+    stats = _StepStats()
+    prev_pose = {x.getID(): x.getPose() for x in m.getModels()}
     for k in range(k0, k0 + n_dense):
         rgb, depth, mask = frames[k]
         m.processFrame(rgb, depth, mask=mask, classIDs=cls, timestamp=k)
@@ -499,13 +513,29 @@ def test_config4_dense_maps(hip, oracle):
         gc, oc = [x.lastCount() for x in gm], [o.model_count(i) for i in range(o.n_models)]
         lab = float((o.segmentation() != m.downloadSegmentation()).mean())
         worst_lab = max(worst_lab, lab)
-        own, tracked = o.model_tracked_pose(0)
+        own, was_tracked = o.model_tracked_pose(0)
         dstep = float(np.abs(own - gm[0].getPose()).max())
         print(f"dense frame {k}: ids {ids}, surfels hip {gc} oracle {oc}, label diff {lab:.2e}, background step |device - oracle's own| {dstep:.1e}")
         assert gc == oc, (k, gc, oc)
         assert lab < 1e-3, (k, lab)
-        assert tracked and dstep < 1e-5, (k, dstep)
+        assert was_tracked and dstep < 1e-5, (k, dstep)
         assert m.gnIllIterations(0) == 0, k
+        if tracked:          # all 19 systems and all 19 updates of ALL tracked models (the background and every object) on equal input
+            line = []
+            for i, x in enumerate(gm):
+                own_i, tr_i = o.model_tracked_pose(i)
+                if not tr_i or ids[i] not in prev_pose:
+                    continue      # spawned in this frame
+                assert i == 0 or x.isNonstatic(), (k, i)
+                pose = x.getPose()
+                gi = _check_tracking_step(oracle, m, o, i, k, m.debugRead("gn_trace", model=i), prev_pose[ids[i]], pose, stats)
+                if i > 0:
+                    n_obj_steps += 1
+                    d_own = float(np.abs(own_i - pose).max())
+                    worst_obj = max(worst_obj, d_own)
+                    line.append("%d: %.1e (%d inl, %d ill)" % (ids[i], d_own, gi, m.gnIllIterations(i)))
+            print("   tracked objects, free-running step |device - oracle's own| (inliers of the first system, iterations outside the solver's domain): " + "; ".join(line))
+        prev_pose = {x.getID(): x.getPose() for x in gm}
     assert gc[0] >= 0.8 * stress.surfel_capacity(num_g)               # the maps stayed dense through the clean passes
     for i, x in enumerate(m.getModels()):
         g, c = x.downloadMap(), o.model_surfels(i)
@@ -521,5 +551,35 @@ def test_config4_dense_maps(hip, oracle):
             assert dconf < 1e-5, (i, dconf)
         print(f"model {i} (id {x.getID()}): {len(g)} surfels, every one in its slot; max |position / normal / radius difference| {dpos:.2e}")
         assert dpos < 1e-6, (i, dpos)
+    n_models_end = len(m.getModels())
     o.close(); m.close()
-    print(f"configs[4] dense: {n_dense} frames at {gc[0]} + {gc[1:]} surfels, worst label difference {worst_lab:.2e}")
+    print(f"configs[4] dense{' (objects tracked)' if tracked else ''}: {n_dense} frames at {gc[0]} + {gc[1:]} surfels, worst label difference {worst_lab:.2e}")
+    if tracked:
+        print("   %d object tracking steps, %d Gauss-Newton systems compared iteration by iteration (%d with an inlier count off by one or two): worst A / b "
+              "difference %.2e (first system %.2e), worst update: resultRt %.2e, Rcurr / tcurr %.2e; free-running object step (report) %.2e"
+              % (n_obj_steps, stats.n_systems, stats.n_inlier_flips, stats.worst_sys, stats.worst_it0, stats.worst_rt, stats.worst_rc, worst_obj))
+        # every object is tracked on every dense frame unless the 0.2 m rule (MaskFusion.cpp:268-272) dropped it -- on both sides, the list is compared above
+        if scale == 1:       # (the quarter-resolution rehearsal on the CPU-executed kernels sees its ~1 k-pixel boxes dropped: both sides, same frames)
+            assert n_models_end == n_obj + 1 and n_obj_steps == n_obj * n_dense, (n_models_end, n_obj_steps)
+
+
+def test_config4_dense_maps(hip, oracle):
+    """configs[4] as BASELINE.json / SURVEY.md 8d S3 define it: 1280x960, MASKFUSION_NUM_GSURFELS = 32M / NUM_OSURFELS = 4M (capacities 5760^2 /
+    2048^2, Model.cpp:101-108), 4 object models, every map pre-filled to >= 80 % of its capacity (26.5 M background surfels, 3.4 M per
+    object: maskfusion_amd/stress.py loads generated maps where a long orbit would have grown them), then 5 frames against OracleMM fed the
+    same frames, the same uploaded maps, the product's filtered depth and -- teacher forcing, as in the tracked 8-object test -- the
+    product's poses, so that every surfel pass of every frame runs on equal input at the budgets the reference is compiled with
+    (Core/CMakeLists.txt:27-28).  Gated on every dense frame: model list, surfel count of every model EXACT, label image, the background's own
+    tracking step; on the last frame every surfel of every model in its slot (position / normal / radius 1e-6, confidence 1e-5 rel,
+    colour and time stamps exact).  Here the objects stand and follow the camera (trackAllModels off); the next test tracks them."""
+    _config4_dense_maps(hip, oracle, tracked=False)
+
+
+def test_config4_dense_maps_tracked(hip, oracle):
+    """S3 as SURVEY.md 8d defines it -- "S2 with 4 objects" at 1280x960, and S2 tracks every model: after the lead-in every object model is made
+    non-static (Model.h:263-268) on both sides, so that each dense frame runs FIVE Gauss-Newton loops (MaskFusion.cpp:263-276,
+    RGBDOdometry.cpp:227-497: the background's and the four objects', each against a 3.4 M-surfel map's prediction at 1280x960) through the
+    batched kernels.  Teacher-forced like test_s2_eight_objects_tracked_teacher_forced: on every dense frame all 19 systems of all 5 models
+    (inliers within two gate-boundary pixels, A / b 2e-4) and all 19 updates (resultRt 1e-9) on equal input, beside test_config4_dense_maps'
+    gates (model list, every count exact, label image; every surfel of every model in its slot on the last frame)."""
+    _config4_dense_maps(hip, oracle, tracked=True)
