@@ -174,11 +174,17 @@ int mf_get_last_fillin(mf_ctx* ctx, int32_t* used);
  * surfel kernels of an object model run on a grid sized from its last known surfel count instead of 2048 workgroups), "objectScatterSplat" (1;
  * 1: object models are predicted with the scatter form of the splat instead of tile lists) -- both leave every result bit-identical; measured on
  * MI355X on the 12-model S2 scene: 394 -> 407 frames/s with both (profiles/r03a_bench_2s_object_switches.txt), on since round 3;
- * "bigMapElements" (6 000 000: from this many surfels on Model::clean is one launch and the projection passes visit only the runs of the buffer
- * that can be in view (k_cull) -- below, the two-launch clean and whole-buffer passes of rounds 1-4), "inPlaceElements" (1 000 000: from this
+ * "bigMapElements" (6 000 000: from this many surfels on a model's buffer is kept as RUNS with a table (Surfels::box): Model::clean works in
+ * place on the runs in which its rules can change something (k_cull_clean / k_clean_runs, the frame's new surfels appended behind the last run)
+ * and the projection passes visit only the runs that can be in view (k_cull) -- below, the two-launch clean (a dense copy) and whole-buffer passes
+ * of rounds 1-4), "inPlaceElements" (1 000 000: from this
  * many surfels on update.vert runs in place -- below, as rounds 1-4's copy with the second index scatter riding on it); which form a model's
- * passes take depends on its size alone and changes no result (tests/test_gpu_switches.py::test_clean_forms_agree), "cullRuns" (1; 0: big maps stream the whole buffer through every
- * projection pass -- the executable specification of the culled form),
+ * passes take depends on its size alone and changes no result (tests/test_gpu_switches.py::test_clean_forms_agree), "cullRuns" (1; 0: big maps walk every run of
+ * the buffer in every projection pass and in Model::clean -- the executable specification of the culled forms), "densifyEvery" (0; n > 0: a
+ * sparse buffer is compacted every n frames whatever the host's bounds say -- a test switch; by default only when the slots behind the last run or
+ * the table entries could run out, before a download, before a model returns to the small-map forms); read-only: "densifyCount" (compactions so
+ * far), "cleanRuns" / "visibleRuns" / "backgroundRuns" (runs the last in-place clean visited / on the last visibility list / of the
+ * background's table),
  * "literalFusionWeight" (1: Model::computeFusionWeight's log map takes cos(theta) from the float trace of a float matrix as the reference's
  * text does -- its rotation term is then quantised in steps of ~4.9e-4 rad; 0: the same formula evaluated accurately in double.  See
  * DESIGN.md, finding F5; default 1 since round 3), "frameToFrameRGB" (0; MaskFusion::setFrameToFrameRGB, "-ftf": the photometric term tracks

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmaskfusion_amd.so")
 SOURCES = ["mf_preproc.hip", "mf_odometry.hip", "mf_rgbd.hip", "mf_surfel.hip", "mf_splat.hip", "mf_segment.hip", "mf_labels.hip", "mf_labels_gpu.hip", "mf_context.hip"]
-HEADERS = ["mf_internal.h", "mf_device.h", "mf_labels.h", os.path.join("..", "..", "include", "maskfusion_amd.h"), "mf_rgbd_device.h",
+HEADERS = ["mf_internal.h", "mf_device.h", "mf_labels.h", os.path.join("..", "..", "include", "maskfusion_amd.h"), "mf_rgbd_device.h", "mf_walk.h",
            "mf_frame.inl", "mf_model_api.inl", "mf_ktest.inl"]   # (the .inl files are parts of mf_context.hip)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 # per-file additions.  mf_odometry: the SLP vectoriser pairs the 28 upper-triangle products of the ICP row into v_pk_fma_f32 and then

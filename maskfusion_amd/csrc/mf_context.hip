@@ -30,7 +30,14 @@ struct ModelState {
     float confThr = 0.f, maxDepth = FLT_MAX;
     Surfels surf[2];
     int cur = 0, cap = 0;
-    bool table_valid = false;              // the live buffer's run table (Surfels::box) was written by whoever wrote the buffer (one-launch clean, upload, initialise)
+    bool table_valid = false;              // the live buffer has a run table (Surfels::box; device: frame->runs > 0): written by initialise / upload / launch_run_table,
+                                           // maintained by the in-place clean; the two-launch clean leaves a dense buffer without one
+    bool sparse = false;                   // ... and the buffer may have unused slots inside its runs: only the run-aware passes can read it (densify() first)
+    long phys_ub = -1, runs_ub = -1;       // upper bounds of frame->phys / frame->runs (the device appends up to P / 4 surfels in up to P / (4 kRun) + 1 runs per
+                                           // frame): the host compacts the buffer before the slots behind the last run or the table could run out; -1: unknown
+    unsigned long long* h_append = nullptr;   // pinned: append_mirror() of the last in-place clean pass that has RUN (mf_internal.h)
+    unsigned clean_seq = 0, mirror_from = 1;  // in-place clean passes enqueued so far on this model / the first one whose mirror describes the present buffer
+    unsigned gen = 0;                      // bumped whenever the buffer, its table, the pose or the tick may have changed (visibility lists are cached against it)
     PoseDev* d_pose = nullptr; FrameDev* d_frame = nullptr;
     float4* d_predV = nullptr; float4* d_predN = nullptr; uchar4* d_predImage = nullptr; uint16_t* d_predTime = nullptr;
     uint8_t* d_predGray = nullptr; uint8_t* d_fillGray = nullptr;  // intensity of the RGB projection / of the fill-in image
@@ -44,7 +51,7 @@ struct ModelState {
     struct ObjScratch {
         unsigned long long* keys = nullptr; int* index = nullptr; float4* ivc = nullptr; float4* inr = nullptr; float4* iclean = nullptr;
         uint8_t* cand_op = nullptr; float4* cand_rec = nullptr; int* upd_first = nullptr; int* cand_best = nullptr;
-        unsigned long long* scan_state = nullptr; int* clean_ctl = nullptr;
+        int* clean_ctl = nullptr;
         uint8_t* flags = nullptr; float* newconf = nullptr; int* block_counts = nullptr;   // the two-launch clean form (small maps)
     } scr;
     float* d_poselog = nullptr;            // Model::poseLog on the device: ring of [cap][8] floats (t, q xyzw, pad)
@@ -57,6 +64,7 @@ struct ModelState {
         if (h_pose) (void)hipHostFree(h_pose);
         if (h_frame) (void)hipHostFree(h_frame);
         if (h_count) (void)hipHostFree(h_count);
+        if (h_append) (void)hipHostFree(h_append);
     }
 };
 
@@ -219,15 +227,20 @@ struct mf_ctx {
     uint8_t* d_cand_op = nullptr; float4* d_cand_rec = nullptr; int* d_upd_first = nullptr;
     uint8_t* d_flags = nullptr; float* d_newconf = nullptr; int* d_block_counts = nullptr;
     int* d_cand_best = nullptr;            // surfel a merge candidate was associated with (fuse_data -> fuse_update)
-    unsigned long long* d_scan_state = nullptr; int* d_clean_ctl = nullptr; unsigned clean_epoch = 0;   // Model::clean's decoupled look-back (mf_surfel.hip)
+    int* d_clean_ctl = nullptr;            // Model::clean in place (mf_surfel.hip): finished-workgroup counter of k_clean_runs
+    int* d_clean_list = nullptr; int* d_clean_count = nullptr;   // ... the runs it has to visit (k_cull_clean)
+    int* d_decay_stats = nullptr;          // ... and the frame's mask-disagreement depth ranges the culling rests on (ResolveOut::decay_stats), armed between frames
+    int* d_run_offs = nullptr;             // compaction of a sparse buffer (launch_densify): exclusive scan of the run lengths
     // visibility list of the projection passes (Surfels::box, k_cull): the runs of ONE buffer that can be in view under ONE pose; vis_tag says whose
     int* d_vis_list = nullptr; int* d_vis_count = nullptr; int* d_cull_ctl = nullptr; int vis_max_runs = 0;
-    struct { const void* model = nullptr; long frame = -1; int cur = -1; } vis_tag;
+    struct { const void* model = nullptr; long frame = -1; int cur = -1; unsigned gen = 0; float max_depth = 0.f; int time_delta = 0; } vis_tag;
+    int densify_count = 0;                 // compactions of sparse buffers so far ("densifyCount", read-only: tests / bench)
     bool fused_rgb_pyramid = true;         // "fusedRgbPyramid": the frame's intensity pyramid + derivative / gate images as one launch (0: four launches, the executable specification)
-    int ticket_lanes = 1;                  // ticket counters of the clean pass: min(kCleanTicketLanes, compute units of the device)
+    int densify_every = 0;                 // "densifyEvery": > 0 = a model's sparse buffer is compacted every so many frames whatever its bounds say (tests)
     bool cull_runs = true;                 // "cullRuns": 0 = every projection pass streams the whole buffer (A/B switch, executable specification)
-    int big_map_elements = 6000000;        // "bigMapElements": from this many surfels on a model's clean pass is the one-launch form (which writes the run
-                                           // table) and its projection passes cull by run; below, the two-launch form and whole-buffer passes
+    int big_map_elements = 6000000;        // "bigMapElements": from this many surfels on a model's buffer is kept as runs (Surfels::box): its clean pass works in
+                                           // place on the runs its rules can touch and its projection passes cull by run; below, the two-launch clean (a dense
+                                           // copy) and whole-buffer passes
     int in_place_elements = 1000000;       // "inPlaceElements": from this many surfels on update.vert runs in place and the second index scatter is a
                                            // launch of its own (~18 us per million surfels + ~10 us); below, the copying update with the scatter
                                            // riding on it (~30 us per million).  Only with the two-launch clean (<= big_map_elements)
@@ -320,6 +333,7 @@ static __global__ void k_pose_identity(PoseDev* p, int weight_literal) {
 static __global__ void k_frame_init(FrameDev* f, int tick) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     f->tick = tick; f->count = 0; f->countNext = 0; f->runs = 0; f->cover = 0; f->useFillIn = 0;
+    f->phys = 0; f->first = 0; f->first_run = 0; f->runsNext = 0;
     f->pad[0] = f->pad[1] = f->pad[2] = 0;
     f->done_cover = 0ull;
     MF_FRAME_BBOX_RESET(f);
@@ -349,7 +363,6 @@ static int ensure_obj_scratch(mf_ctx* c, ModelState& m) {
     A(dev_alloc(c, m.allocs, &m.scr.cand_rec, P * 3));
     A(dev_alloc(c, m.allocs, &m.scr.upd_first, cap));
     A(dev_alloc(c, m.allocs, &m.scr.cand_best, P));
-    A(dev_alloc(c, m.allocs, &m.scr.scan_state, clean_scan_entries((long)cap + (long)P)));
     A(dev_alloc(c, m.allocs, &m.scr.clean_ctl, (size_t)kCleanCtlInts));
     A(dev_alloc(c, m.allocs, &m.scr.flags, cap + P));
     A(dev_alloc(c, m.allocs, &m.scr.newconf, cap + P));
@@ -369,7 +382,7 @@ static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int 
         A(dev_alloc(c, m->allocs, &m->surf[b].pc, (size_t)cap));
         A(dev_alloc(c, m->allocs, &m->surf[b].ct, (size_t)cap));
         A(dev_alloc(c, m->allocs, &m->surf[b].nr, (size_t)cap));
-        A(dev_alloc(c, m->allocs, &m->surf[b].box, run_table_entries((long)cap + (long)c->P)));
+        A(dev_alloc(c, m->allocs, &m->surf[b].box, run_table_entries((long)cap, (long)c->P)));
         m->surf[b].cap = cap;
     }
     A(dev_alloc(c, m->allocs, &m->d_pose, 1));
@@ -413,8 +426,9 @@ static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int 
     hipLaunchKernelGGL(k_pose_identity, dim3(1), dim3(64), 0, c->stream, m->d_pose, c->weight_literal ? 1 : 0);
     hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(64), 0, c->stream, m->d_frame, c->host_tick);
     if (hipHostMalloc((void**)&m->h_pose, sizeof(PoseDev)) != hipSuccess || hipHostMalloc((void**)&m->h_frame, sizeof(FrameDev)) != hipSuccess ||
-        hipHostMalloc((void**)&m->h_count, sizeof(int)) != hipSuccess)
+        hipHostMalloc((void**)&m->h_count, sizeof(int)) != hipSuccess || hipHostMalloc((void**)&m->h_append, sizeof(unsigned long long)) != hipSuccess)
         return MF_ENOMEM;
+    *m->h_append = 0ull;
     memset(m->h_pose, 0, sizeof(PoseDev));
     for (int k = 0; k < 9; ++k) m->h_pose->R[k] = m->h_pose->Ri[k] = (k % 4 == 0) ? 1.f : 0.f;
     m->h_pose->alive = 1;
@@ -444,11 +458,6 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     c->K = Intr{cfg->fx, cfg->fy, cfg->cx, cfg->cy};
     auto fail = [&](int code) { mf_destroy(c); return code; };
     if (hipSetDevice(cfg->device) != hipSuccess) return fail(MF_ENODEV);
-    {
-        int cus = 1;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess) { (void)hipGetLastError(); cus = 1; }
-        c->ticket_lanes = cus < 1 ? 1 : (cus > kCleanTicketLanes ? kCleanTicketLanes : cus);
-    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(MF_ENODEV);
     const int W = c->W, H = c->H, P = c->P;
     const int cap_bg = surfel_capacity(cfg->num_gsurfels), cap_obj = surfel_capacity(cfg->num_osurfels);
@@ -530,10 +539,14 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     A(dev_alloc(c, c->allocs, &c->d_newconf, (size_t)c->cap_max + P));
     A(dev_alloc(c, c->allocs, &c->d_block_counts, (size_t)kCompactBlocks));
     A(dev_alloc(c, c->allocs, &c->d_cand_best, (size_t)P));
-    A(dev_alloc(c, c->allocs, &c->d_scan_state, clean_scan_entries((long)c->cap_max + (long)P)));
     A(dev_alloc(c, c->allocs, &c->d_clean_ctl, (size_t)kCleanCtlInts));
-    c->vis_max_runs = (int)(run_table_entries((long)c->cap_max + (long)P) / 2);
+    c->vis_max_runs = (int)run_table_runs((long)c->cap_max, (long)P);
     A(dev_alloc(c, c->allocs, &c->d_vis_list, (size_t)c->vis_max_runs));
+    A(dev_alloc(c, c->allocs, &c->d_clean_list, (size_t)c->vis_max_runs));
+    A(dev_alloc(c, c->allocs, &c->d_clean_count, 1));
+    A(dev_alloc(c, c->allocs, &c->d_run_offs, (size_t)c->vis_max_runs + 1));
+    A(dev_alloc(c, c->allocs, &c->d_decay_stats, 4));
+    launch_arm_decay_stats(c->d_decay_stats, c->stream);
     A(dev_alloc(c, c->allocs, &c->d_vis_count, 1));
     A(dev_alloc(c, c->allocs, &c->d_cull_ctl, 2));
     A(dev_alloc(c, c->allocs, &c->d_icp_prof, (size_t)20 * 16));
@@ -910,6 +923,7 @@ extern "C" int mf_export_segmentation_png(mf_ctx* c, const char* path) {
 extern "C" int mf_download_map(mf_ctx* c, int32_t model, float* out, uint32_t max_count, uint32_t* count) {
     ModelState* ms = model_at(c, model);
     if (!ms || !out || !count) return MF_EINVAL;
+    require_dense(c, *ms);     // Model::downloadMap hands out the surfels in order, slot by slot: a sparse buffer is compacted first
     int rc = mf_sync(c);
     if (rc != MF_OK) return rc;
     const uint32_t n = (uint32_t)*ms->h_count;
@@ -1000,6 +1014,7 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!strcmp(key, "objectScatterSplat")) { c->object_scatter_splat = value != 0; return MF_OK; }
     if (!strcmp(key, "globalTiles")) { c->global_tiles = value != 0; return MF_OK; }
     if (!strcmp(key, "cullRuns")) { c->cull_runs = value != 0; c->vis_tag.model = nullptr; return MF_OK; }
+    if (!strcmp(key, "densifyEvery")) { c->densify_every = (int)value; return MF_OK; }
     if (!strcmp(key, "bigMapElements")) { c->big_map_elements = (int)value; c->vis_tag.model = nullptr; return MF_OK; }
     if (!strcmp(key, "fusedRgbPyramid")) { c->fused_rgb_pyramid = value != 0; return MF_OK; }
     if (!strcmp(key, "inPlaceElements")) { c->in_place_elements = (int)value; return MF_OK; }
@@ -1036,10 +1051,12 @@ extern "C" int mf_get_param(mf_ctx* c, const char* key, double* value) {
     if (!strcmp(key, "confidenceThreshold")) { *value = c->models[0]->confThr; return MF_OK; }
     if (!strcmp(key, "splatTileEntries")) { *value = c->tile_entries_cap; return MF_OK; }
     if (!strcmp(key, "cullRuns")) { *value = c->cull_runs ? 1 : 0; return MF_OK; }
-    if (!strcmp(key, "visibleRuns") || !strcmp(key, "backgroundRuns")) {   // test taps: size of the last visibility list / of the background's run table
-        MF_HIP(c, hipStreamSynchronize(c->stream));
+    if (!strcmp(key, "densifyCount")) { *value = (float)c->densify_count; return MF_OK; }
+    if (!strcmp(key, "visibleRuns") || !strcmp(key, "backgroundRuns") || !strcmp(key, "cleanRuns")) {   // test taps: size of the last visibility list / of the
+        MF_HIP(c, hipStreamSynchronize(c->stream));                                                      // background's run table / of the last clean list
         int v = 0;
         if (!strcmp(key, "visibleRuns")) MF_HIP(c, hipMemcpy(&v, c->d_vis_count, sizeof(int), hipMemcpyDeviceToHost));
+        else if (!strcmp(key, "cleanRuns")) MF_HIP(c, hipMemcpy(&v, c->d_clean_count, sizeof(int), hipMemcpyDeviceToHost));
         else { FrameDev f; MF_HIP(c, hipMemcpy(&f, c->models[0]->d_frame, sizeof(FrameDev), hipMemcpyDeviceToHost)); v = f.runs; }
         *value = v;
         return MF_OK;

@@ -23,6 +23,7 @@ static bool photometric_on(const mf_ctx* c) { return c->cfg.rgb_only != 0 || c->
 // SO(3) pre-alignment, then the Gauss-Newton loop (ICP only: one launch per iteration; with the photometric term: two).
 static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, float jump_limit, long frame_k) {
     const mf_config& g = c->cfg;
+    m.gen++;   // the pose changes: cached visibility lists are stale
     const int set = (int)(frame_k & 1);
     float* const* cur_vmap = c->d_vmap[set];
     float* const* cur_nmap = c->d_nmap[set];
@@ -162,71 +163,159 @@ static int surfel_blocks(const mf_ctx* c, const ModelState& m) {
     return (int)(b < 32 ? 32 : (b > kSurfelGridBlocks ? kSurfelGridBlocks : b));
 }
 
-// predictIndices -> fuse -> [predictIndices] -> clean for one model (Core/MaskFusion.cpp:541-563 / :344-353)
 // The runs of m's live buffer that can be in view under m's current pose (k_cull), for the projection passes of this frame: culled once per
-// buffer and pose -- GlobalProjection and the two index-map passes of a frame share one list (the in-place update moves no surfel of a run
-// that is not listed: only surfels the first index map drew are merged), the prediction after clean() gets its own (new buffer).
-// Depth range: the widest any consumer uses.  nullptr: culling is off.
+// buffer state and pose -- GlobalProjection and the two index-map passes of a frame share one list (the in-place update moves no surfel of a
+// run that is not listed: only surfels the first index map drew are merged), the prediction after clean() gets its own (the buffer changed).
+// Depth range: the widest any consumer uses.  nullptr: no list -- the passes walk every run of the table (or, a dense buffer without one, every slot).
 static const VisList* ensure_vis(mf_ctx* c, ModelState& m, VisList& out) {
-    // (a small map is cheaper to stream than to cull: the test is a launch of its own on a chain of launches that are each a few microseconds --
-    // and its clean pass, the two-launch form, writes no run table.  The count is the pinned mirror as of the model's last clean pass; which
-    // side of the threshold a frame falls on changes no result)
-    if (!c->cull_runs || !m.table_valid || *m.h_count < c->big_map_elements) return nullptr;
-    out.list = c->d_vis_list; out.count = c->d_vis_count;
-    if (c->vis_tag.model == &m && c->vis_tag.frame == c->frame_no && c->vis_tag.cur == m.cur) return &out;
+    // (a small map is cheaper to stream than to cull: the test is a launch of its own on a chain of launches that are each a few microseconds.
+    // The count is the pinned mirror as of the model's last clean pass; which side of the threshold a frame falls on changes no result)
+    if (!c->cull_runs || !m.table_valid || (!m.sparse && *m.h_count < c->big_map_elements)) return nullptr;
     const mf_config& g = c->cfg;
-    launch_cull(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, fmaxf(g.depth_cutoff, g.max_depth_processed), g.time_delta, c->d_vis_list,
-                c->d_vis_count, c->d_cull_ctl, (int)(run_table_entries((long)m.cap + (long)c->P) / 2), c->stream);
-    c->vis_tag.model = &m; c->vis_tag.frame = c->frame_no; c->vis_tag.cur = m.cur;
+    const float max_depth = fmaxf(g.depth_cutoff, g.max_depth_processed);
+    out.list = c->d_vis_list; out.count = c->d_vis_count;
+    // the list depends on the buffer and its table, the pose, the tick (all behind m.gen), the depth bound and timeDelta
+    if (c->vis_tag.model == &m && c->vis_tag.frame == c->frame_no && c->vis_tag.cur == m.cur && c->vis_tag.gen == m.gen && c->vis_tag.max_depth == max_depth &&
+        c->vis_tag.time_delta == g.time_delta)
+        return &out;
+    launch_cull(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, max_depth, g.time_delta, c->d_vis_list, c->d_vis_count, c->d_cull_ctl,
+                (int)run_table_runs((long)m.cap, (long)c->P), c->stream);
+    c->vis_tag.model = &m; c->vis_tag.frame = c->frame_no; c->vis_tag.cur = m.cur; c->vis_tag.gen = m.gen; c->vis_tag.max_depth = max_depth;
+    c->vis_tag.time_delta = g.time_delta;
     return &out;
 }
 
-// workgroups of a clean launch for model m: sized from its last known count (pinned mirror; the chunks are drawn from a ticket counter,
-// so a stale value costs a workgroup a few more rounds, never a result)
-static int clean_blocks(const mf_ctx* c, const ModelState& m) {
-    return clean_grid((long)*m.h_count + (long)c->P / 2);
-}
-// which clean form model m gets this frame (launch_clean): the two-launch form below "bigMapElements"
+// which clean form model m gets this frame: the two-launch form (a dense copy) below "bigMapElements", in place on the buffer's runs from there on
 static bool clean_small(const mf_ctx* c, const ModelState& m) { return (long)*m.h_count + (long)c->P / 4 < (long)c->big_map_elements; }
 // which update form: the copying one (second index scatter riding on it) below "inPlaceElements"; it pairs with the two-launch clean only
 static bool update_copy(const mf_ctx* c, const ModelState& m) {
     return clean_small(c, m) && (long)*m.h_count + (long)c->P / 4 < (long)c->in_place_elements;
 }
-static unsigned next_clean_epoch(mf_ctx* c) {
-    c->clean_epoch = (c->clean_epoch + 1u) & 0x3FFFFFFFu;
-    if (c->clean_epoch == 0) c->clean_epoch = 1;
-    return c->clean_epoch;
+// what a frame can append to a buffer: candidates (data.vert:117 takes every other pixel of every other row) and table entries for them
+static long cand_max(const mf_ctx* c) { return (long)((c->W + 1) / 2) * (long)((c->H + 1) / 2); }
+static long new_runs_max(const mf_ctx* c) { return (cand_max(c) + kRun - 1) / kRun + 1; }
+
+// (the mirror's bit fields hold buffers of up to 2^26 slots in up to 2^18 runs: 64 M surfels; beyond, the host's own bounds alone decide)
+static bool append_mirror_fits(const mf_ctx* c, const ModelState& m) {
+    return (long)m.cap < (1L << kAppendPhysBits) && (long)run_table_runs((long)m.cap, (long)c->P) < (1L << kAppendRunBits);
+}
+// compaction of m's sparse buffer: the surfels of its runs -> the other buffer, dense, no table (launch_densify); that one is live afterwards
+static void densify(mf_ctx* c, ModelState& m) {
+    launch_densify(m.surf[m.cur], m.surf[1 - m.cur], m.d_frame, c->d_run_offs, m.h_count, c->stream);
+    m.cur = 1 - m.cur;
+    m.sparse = false; m.table_valid = false; m.phys_ub = m.runs_ub = -1; m.gen++;
+    m.mirror_from = m.clean_seq + 1;      // (mirrors of earlier passes describe the buffer that was)
+    c->densify_count++;
+}
+// the passes that read a buffer slot by slot (copy-update, two-launch clean, download) need a dense one
+static void require_dense(mf_ctx* c, ModelState& m) { if (m.sparse) densify(c, m); }
+
+// Makes m ready for the in-place clean of this frame: a run table, and -- by the host's bounds on what the device has appended since the last exact
+// count -- room behind the last run and in the table for a frame's candidates.  When the bounds run out the buffer is compacted and the host reads
+// the exact count: ONE stream synchronisation per compaction (every (capacity - count) / (P / 4) frames or later).  ok = false: the (dense) buffer
+// is within a frame's candidates of its capacity -- the frame takes the two-launch form, whose ordered copy stops at the capacity exactly where the
+// reference's transform feedback does (tests/test_gpu_pipeline.py::test_full_map_clamps_like_the_oracle); such a map pays the synchronisation every frame.
+static int prepare_in_place(mf_ctx* c, ModelState& m, bool& ok) {
+    const long cm = cand_max(c), nr = new_runs_max(c), table = (long)run_table_runs((long)m.cap, (long)c->P);
+    ok = true;
+    if (c->densify_every > 0 && m.sparse && (c->frame_no % c->densify_every) == 0) densify(c, m);   // ("densifyEvery": tests)
+    // The host's own bounds grow by a frame's worth of CANDIDATES per pass, the buffer by the few that survive.  The device leaves where the buffer
+    // really ended behind every pass in pinned memory (append_mirror): bounds from the newest pass that has run are P / 4 per pass still in flight.
+    long pub = m.phys_ub, rub = m.runs_ub;
+    if (pub >= 0) {
+        const unsigned long long v = *(volatile unsigned long long*)m.h_append;
+        const unsigned mask = (1u << kAppendSeqBits) - 1u, seq = (unsigned)(v >> (kAppendRunBits + kAppendPhysBits)) & mask;
+        const unsigned behind = (m.clean_seq - seq) & mask, since = (seq - m.mirror_from) & mask;   // passes enqueued behind it / it is not older than the buffer
+        if (v != 0ull && behind < (mask >> 1) && since < (mask >> 1)) {
+            pub = std::min(pub, (long)(v & ((1ull << kAppendPhysBits) - 1ull)) + (long)behind * cm);
+            rub = std::min(rub, (long)((v >> kAppendPhysBits) & ((1ull << kAppendRunBits) - 1ull)) + (long)behind * nr);
+        }
+    }
+    if (pub < 0 || pub + cm > (long)m.cap || rub + nr > table) {
+        require_dense(c, m);
+        MF_HIP(c, hipStreamSynchronize(c->stream));
+        const long n = (long)*m.h_count;
+        m.phys_ub = n; m.runs_ub = (n + kRun - 1) / kRun;
+        if (n + cm > (long)m.cap) { ok = false; return MF_OK; }
+    }
+    if (!m.table_valid) {
+        launch_run_table(m.surf[m.cur], m.d_frame, c->stream);
+        m.table_valid = true; m.gen++;
+    }
+    return MF_OK;
+}
+// bookkeeping behind a model's clean pass
+static void after_clean(mf_ctx* c, ModelState& m, bool in_place) {
+    if (in_place) { m.sparse = true; m.table_valid = true; m.phys_ub += cand_max(c); m.runs_ub += new_runs_max(c); m.clean_seq++; }
+    else { m.sparse = false; m.table_valid = false; m.phys_ub = m.runs_ub = -1; m.mirror_from = m.clean_seq + 1; }
+    m.gen++;
+}
+// the arguments every clean form of model m shares (shared scratch of the single-model path)
+static CleanIn clean_in(mf_ctx* c, ModelState& m, int time_delta, bool packed, const float* depthF, const uint8_t* mask) {
+    CleanIn in;
+    in.frame = m.d_frame; in.pose = m.d_pose; in.W = c->W; in.H = c->H; in.k = c->K; in.timeDelta = time_delta; in.confThreshold = m.confThr;
+    in.outlierCoeff = c->cfg.outlier_coefficient; in.maskID = m.id;
+    in.index = c->d_index; in.vc = c->d_ivc; in.ct = c->d_ict; in.packed = packed ? c->d_iclean : nullptr; in.maskT = c->d_maskT;
+    in.depthF = depthF; in.mask = mask; in.cand_op = c->d_cand_op; in.cand_rec = c->d_cand_rec;
+    in.flags = c->d_flags; in.newconf = c->d_newconf; in.block_counts = c->d_block_counts; in.host_count = m.h_count;
+    in.host_append = append_mirror_fits(c, m) ? m.h_append : nullptr; in.seq = m.clean_seq + 1;     // (after_clean counts the pass)
+    in.transposed = packed; in.literalWindow = c->clean_literal;
+    return in;
+}
+// Model::clean of m in place (m has a run table): the buffer's own surfels run by run, then the frame's candidates appended.  cull: visit only the
+// runs in which a rule of the pass can apply (k_cull_clean; needs the decay statistics of THIS frame's packed resolve pass) -- the background;
+// an object model's launch visits every run (its bounding box is the box of all its drawn surfels)
+static void enqueue_clean_in_place(mf_ctx* c, ModelState& m, const CleanIn& in, bool cull) {
+    VisList cl{c->d_clean_list, c->d_clean_count};
+    if (cull)
+        launch_cull_clean(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, in.timeDelta, in.confThreshold, c->d_decay_stats, c->d_clean_list,
+                          c->d_clean_count, c->d_cull_ctl, (int)run_table_runs((long)m.cap, (long)c->P), c->stream);
+    launch_clean_runs(in, m.surf[m.cur], cull ? &cl : nullptr, c->d_clean_ctl, clean_runs_grid((long)*m.h_count + kRun), c->stream);
+    launch_clean_append(in, m.surf[m.cur], c->stream);
 }
 
-static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, const float* d_depth, const float* depthF,
-                               const uint8_t* mask, float fuseDepthCutoff, float weightMultiplier, bool secondIndexPass, bool marks) {
+// predictIndices -> fuse -> [predictIndices] -> clean for one model (Core/MaskFusion.cpp:541-563 / :344-353)
+static int enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, const float* d_depth, const float* depthF,
+                              const uint8_t* mask, float fuseDepthCutoff, float weightMultiplier, bool secondIndexPass, bool marks) {
     const mf_config& g = c->cfg;
     const int W = c->W, H = c->H;
     hipStream_t s = c->stream;
+    // Which forms a model's passes take is a matter of its size alone (mf_context.hip: in_place_elements / big_map_elements); the results are the same.
+    bool small = clean_small(c, m);
+    const bool copy = update_copy(c, m);
+    if (!small) {
+        bool ok = true;
+        int rc = prepare_in_place(c, m, ok);
+        if (rc != MF_OK) return rc;
+        small = !ok;
+    } else {
+        require_dense(c, m);
+    }
     const int src = m.cur, dst = 1 - m.cur;
     const int blocks = surfel_blocks(c, m);
-    const bool small = clean_small(c, m), copy = update_copy(c, m);
     VisList vl;
     const VisList* vis = ensure_vis(c, m, vl);
     // (column-major key images in both index passes of a model handled on its own: index_scatter_one; the resolve of this pass transposes)
     launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, true, s, blocks, vis);
-    launch_index_resolve(m.surf[src], m.d_pose, c->d_keys, W, H, c->d_index, c->d_ivc, c->d_inr, secondIndexPass ? nullptr : c->d_ict,
+    launch_index_resolve(m.surf[src], m.d_frame, m.d_pose, c->d_keys, W, H, c->d_index, c->d_ivc, c->d_inr, secondIndexPass ? nullptr : c->d_ict,
                          nullptr, nullptr, nullptr, nullptr, true, s);
     if (marks) mark(c, 4);
     // Model::fuse maxDepth uniform: min(depthCutoff, model.maxDepth, bb_max_z) (Model.cpp:527); bb_max_z from the model's bounding box on the device
     launch_fuse_data(d_rgb, d_depth, depthF, mask, m.id, m.d_frame, m.d_pose, weightMultiplier, fminf(fuseDepthCutoff, m.maxDepth), W, H,
                      c->K, c->d_index, c->d_ivc, c->d_inr, c->d_cand_op, c->d_cand_rec, c->d_upd_first, c->d_cand_best, s, c->bbox_limit ? 1 : 0);
     if (marks) mark(c, 5);
-    // Which forms a model's passes take is a matter of its size alone (mf_context.hip: in_place_elements / big_map_elements); the results are the same.
+    // the in-place clean of the background visits only the runs its rules can touch (k_cull_clean); the resolve pass that feeds clean gathers
+    // the frame's statistics for that test
+    const bool in_place = !small, cull_clean = in_place && c->cull_runs && secondIndexPass && m.id == 0;
     int live = src;      // the buffer that holds the updated surfels
-    if (copy) {
+    if (copy && small) {
         // small map (rounds 1-4's pass): update.vert as a copy src -> dst with the second index scatter (:556) riding on it; clean goes
         // dst -> src: two swaps leave the live buffer where it was
         launch_fuse_update_copy(m.surf[src], m.surf[dst], m.d_frame, c->d_upd_first, c->d_cand_rec, m.d_pose, W, H, c->K, g.max_depth_processed,
                                 g.time_delta, secondIndexPass ? c->d_keys : nullptr, true, s, blocks);
         live = dst;
         if (marks) mark(c, 6);
-        if (secondIndexPass) launch_index_resolve(m.surf[live], m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, depthF, mask, c->d_maskT, true, s);
+        if (secondIndexPass) launch_index_resolve(m.surf[live], m.d_frame, m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, depthF, mask, c->d_maskT, true, s);
     } else {
         // update.vert in place -- only the surfels a candidate merged into are touched (the reference copies the whole buffer,
         // Model.cpp:583-646) --, then the second index pass (over the runs in view where the buffer has a run table)
@@ -234,17 +323,20 @@ static void enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, c
         if (marks) mark(c, 6);
         if (secondIndexPass) {   // predictIndices on the updated buffer (:556); its resolve writes the packed, column-major map of clean's window gathers
             launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, true, s, blocks, vis);
-            launch_index_resolve(m.surf[src], m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, depthF, mask, c->d_maskT, true, s);
+            launch_index_resolve(m.surf[src], m.d_frame, m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, depthF, mask, c->d_maskT, true, s,
+                                 cull_clean ? c->d_decay_stats : nullptr, m.id);
         }
     }
-    // clean live -> the other buffer: two launches (flags + ordered copy) below big_map_elements, one launch (which also writes the new
-    // buffer's run table) from there on
-    launch_clean(m.surf[live], m.surf[1 - live], m.d_frame, m.d_pose, W, H, c->K, g.time_delta, m.confThr, g.outlier_coefficient, m.id,
-                 c->d_index, c->d_ivc, c->d_ict, secondIndexPass ? c->d_iclean : nullptr, depthF, mask, c->d_maskT, c->d_cand_op, c->d_cand_rec,
-                 small ? c->d_flags : nullptr, small ? c->d_newconf : nullptr, c->d_block_counts, c->d_scan_state, c->d_clean_ctl,
-                 next_clean_epoch(c), clean_blocks(c, m), c->ticket_lanes, m.h_count, secondIndexPass, c->clean_literal, small, s);
-    m.cur = 1 - live;
-    m.table_valid = !small;
+    // clean: two launches live -> the other buffer (a dense copy) below big_map_elements; from there on in place, run by run
+    const CleanIn in = clean_in(c, m, g.time_delta, secondIndexPass, depthF, mask);
+    if (in_place) {
+        enqueue_clean_in_place(c, m, in, cull_clean);
+    } else {
+        launch_clean_small(in, m.surf[live], m.surf[1 - live], s);
+        m.cur = 1 - live;
+    }
+    after_clean(c, m, in_place);
+    return MF_OK;
 }
 
 // MaskFusion::predict for one model: combinedPredict(maxDepthProcessed, tick, tick, timeDelta) -- the fill-in half
@@ -292,7 +384,8 @@ static int make_obj_batch(mf_ctx* c, const std::vector<ModelState*>& ms, const s
         a.maskID = m.id; a.confThreshold = m.confThr; a.fuseMaxDepth = fminf(g.depth_cutoff, m.maxDepth); a.weightMultiplier = weightMultiplier;
         a.keys = m.scr.keys; a.index = m.scr.index; a.ivc = m.scr.ivc; a.inr = m.scr.inr; a.iclean = m.scr.iclean;
         a.cand_op = m.scr.cand_op; a.cand_rec = m.scr.cand_rec; a.upd_first = m.scr.upd_first; a.cand_best = m.scr.cand_best;
-        a.scan_state = m.scr.scan_state; a.clean_ctl = m.scr.clean_ctl; a.host_count = m.h_count;
+        a.clean_ctl = m.scr.clean_ctl; a.host_count = m.h_count;
+        a.host_append = append_mirror_fits(c, m) ? m.h_append : nullptr; a.clean_seq = m.clean_seq + 1;
         a.flags = m.scr.flags; a.newconf = m.scr.newconf; a.block_counts = m.scr.block_counts;
         a.predV = m.d_predV; a.predN = m.d_predN; a.predImage = m.d_predImage; a.predTime = m.d_predTime; a.predGray = gray ? m.d_predGray : nullptr;
         a.host_frame = m.h_frame; a.log_slot = log_slots ? (*log_slots)[i] : nullptr;
@@ -303,7 +396,7 @@ static int make_obj_batch(mf_ctx* c, const std::vector<ModelState*>& ms, const s
     MF_HIP(c, hipEventRecord(c->ev_obj_args[slot], c->stream));
     b.m = c->d_obj_args[slot]; b.n = (int)ms.size();
     b.W = c->W; b.H = c->H; b.k = c->K; b.maxDepthProcessed = g.max_depth_processed; b.globalMaxDepth = g.depth_cutoff; b.timeDelta = g.time_delta;
-    b.outlierCoeff = g.outlier_coefficient; b.cleanLiteral = c->clean_literal ? 1 : 0; b.bboxLimit = c->bbox_limit ? 1 : 0; b.cleanEpoch = 0; b.cleanTicketLanes = 1; b.cleanSmall = 0; b.updateCopy = 0;
+    b.outlierCoeff = g.outlier_coefficient; b.cleanLiteral = c->clean_literal ? 1 : 0; b.bboxLimit = c->bbox_limit ? 1 : 0; b.cleanSmall = 0; b.updateCopy = 0;
     b.rgb = d_rgb; b.depthRaw = d_depth; b.depthF = depthF; b.mask = mask; b.maskT = c->d_maskT; b.bg_pose = c->models[0]->d_pose; b.global_keys = c->d_keys;
     return MF_OK;
 }
@@ -405,7 +498,7 @@ static int spawn_object(mf_ctx* c, int id, int classID) {
         c->pool.erase(c->pool.begin());
         nm->id = id;
         nm->confThr = g.conf_object;
-        nm->age = 0; nm->isStatic = true; nm->log_ts.clear(); nm->cur = 0; nm->table_valid = false;
+        nm->age = 0; nm->isStatic = true; nm->log_ts.clear(); nm->cur = 0; nm->table_valid = false; nm->sparse = false; nm->phys_ub = nm->runs_ub = -1; nm->gen++; nm->mirror_from = nm->clean_seq + 1;
         hipLaunchKernelGGL(k_pose_identity, dim3(1), dim3(64), 0, s, nm->d_pose, c->weight_literal ? 1 : 0);
         hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(64), 0, s, nm->d_frame, c->host_tick);
         nm->h_frame->tick = c->host_tick;
@@ -445,6 +538,7 @@ static void enqueue_tracking_loop(mf_ctx* c, size_t first, bool track_all, const
         for (ModelState* m : tracked) enqueue_track(c, *m, m == &bg ? depthF_prev : nullptr, m == &bg ? 0.f : 0.2f, k);
     }
     for (ModelState* m : follow) launch_static_pose(m->d_pose, bg.d_pose, m->h_pose, c->stream);   // updateStaticPose, :274
+    for (auto& m : c->models) m->gen++;   // the poses changed: cached visibility lists are stale
 }
 
 // The fusion loop of processFrame (Core/MaskFusion.cpp:539-565) over models[first..]: predictIndices -> fuse -> predictIndices -> clean;
@@ -453,28 +547,37 @@ static int enqueue_fusion_loop(mf_ctx* c, size_t first, bool multi, const uint8_
                                const uint8_t* mask, float weight_multiplier) {
     const mf_config& g = c->cfg;
     const bool batch = multi && batch_objects_now(c);
-    for (size_t i = first; i < (batch ? (size_t)1 : c->models.size()); ++i)
-        enqueue_fuse_clean(c, *c->models[i], d_rgb, d_depth, depthF, mask, g.depth_cutoff, weight_multiplier, true, i == 0);
+    for (size_t i = first; i < (batch ? (size_t)1 : c->models.size()); ++i) {
+        int rc = enqueue_fuse_clean(c, *c->models[i], d_rgb, d_depth, depthF, mask, g.depth_cutoff, weight_multiplier, true, i == 0);
+        if (rc != MF_OK) return rc;
+    }
     if (batch) {   // every object model: one launch per pass
         std::vector<ModelState*> objs; std::vector<int> orders;
         object_models(c, objs, orders);
+        // one form per launch: the batch takes the form of its largest model.  In place (every model keeps a run table) when a model is big and
+        // none of them is within a frame's candidates of its capacity; else the two-launch clean on dense buffers
+        bool any_big = false, in_place = true;
+        for (ModelState* m : objs) any_big |= !clean_small(c, *m);
+        if (any_big) {
+            for (ModelState* m : objs) {
+                bool ok = true;
+                int rc = prepare_in_place(c, *m, ok);
+                if (rc != MF_OK) return rc;
+                in_place &= ok;
+            }
+        } else in_place = false;
+        if (!in_place) for (ModelState* m : objs) require_dense(c, *m);
         ObjBatch ob; int blocks = 0;
-        int rc = make_obj_batch(c, objs, orders, d_rgb, d_depth, depthF, mask, weight_multiplier, nullptr, ob, blocks);
+        int rc = make_obj_batch(c, objs, orders, d_rgb, d_depth, depthF, mask, weight_multiplier, nullptr, ob, blocks);   // (after the compactions: they change the live buffer)
         if (rc != MF_OK) return rc;
-        ob.cleanEpoch = next_clean_epoch(c);
-        int cblocks = 8;
-        ob.cleanTicketLanes = 1;
-        for (ModelState* m : objs) cblocks = std::max(cblocks, clean_blocks(c, *m));
-        ob.cleanTicketLanes = std::min(c->ticket_lanes, cblocks);
-        ob.cleanSmall = 1; ob.updateCopy = 1;    // one form per launch: the batch takes the form of its largest model
-        for (ModelState* m : objs) {
-            if (!clean_small(c, *m)) ob.cleanSmall = 0;
-            if (!update_copy(c, *m)) ob.updateCopy = 0;
-        }
+        int cblocks = 64;
+        for (ModelState* m : objs) cblocks = std::max(cblocks, clean_runs_grid((long)*m->h_count + kRun));
+        ob.cleanSmall = in_place ? 0 : 1; ob.updateCopy = in_place ? 0 : 1;
+        if (!in_place) for (ModelState* m : objs) if (!update_copy(c, *m)) ob.updateCopy = 0;
         launch_obj_fuse_clean(ob, blocks, cblocks, c->stream);
-        for (ModelState* m : objs) {   // copy-update: a -> b -> a; in place: clean went a -> b -- b is the live buffer now
-            if (!ob.updateCopy) m->cur = 1 - m->cur;
-            m->table_valid = !ob.cleanSmall;
+        for (ModelState* m : objs) {   // copy-update: a -> b -> a; in-place update + two-launch clean: a -> b -- b is the live buffer now; in place: a
+            if (!in_place && !ob.updateCopy) m->cur = 1 - m->cur;
+            after_clean(c, *m, in_place);
         }
     }
     return MF_OK;
@@ -567,7 +670,7 @@ static int retire_model(mf_ctx* c, size_t i) {
     }
     std::unique_ptr<ModelState> owned = std::move(c->models[i]);
     c->models.erase(c->models.begin() + (long)i);
-    owned->id = -1; owned->classID = -1; owned->age = 0; owned->isStatic = true; owned->log_ts.clear(); owned->cur = 0; owned->table_valid = false; owned->pred_gray_valid = false;
+    owned->id = -1; owned->classID = -1; owned->age = 0; owned->isStatic = true; owned->log_ts.clear(); owned->cur = 0; owned->table_valid = false; owned->sparse = false; owned->phys_ub = owned->runs_ub = -1; owned->gen++; owned->mirror_from = owned->clean_seq + 1; owned->pred_gray_valid = false;
     owned->maxDepth = FLT_MAX;
     *owned->h_count = 0;
     if (c->vis_tag.model == owned.get()) c->vis_tag.model = nullptr;
@@ -620,24 +723,27 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
         bg.cur = 0;
         launch_compact_records(c->d_cand_rec, c->d_flags, P, bg.surf[0], bg.d_frame, c->d_block_counts, bg.h_count, s);
         launch_run_table(bg.surf[0], bg.d_frame, s);
-        bg.table_valid = true;
+        bg.table_valid = true; bg.sparse = false; bg.phys_ub = P; bg.runs_ub = ((long)P + kRun - 1) / kRun; bg.gen++; bg.mirror_from = bg.clean_seq + 1;
         mark(c, 7);
     } else if (in_pose16 && !bootstrap) {
         // the caller supplies the camera pose: no tracking, no segmentation, object poses untouched
         // (MaskFusion.cpp:243,413-415 -- the whole "regular" block is skipped)
         mark(c, 2);
         launch_override_pose(bg.d_pose, in_pose16, 0, bg.h_pose, s);
+        bg.gen++;
         mark(c, 3); mark(c, 4);
         if (!g.rgb_only)   // :539
-          for (size_t i = 0; i < c->models.size(); ++i)
-            enqueue_fuse_clean(c, *c->models[i], d_rgb, d_depth, depthF, mask, g.depth_cutoff, weight_multiplier, true, i == 0);
+          for (size_t i = 0; i < c->models.size(); ++i) {
+            int rc = enqueue_fuse_clean(c, *c->models[i], d_rgb, d_depth, depthF, mask, g.depth_cutoff, weight_multiplier, true, i == 0);
+            if (rc != MF_OK) return rc;
+          }
         mark(c, 7);
     } else {
         mark(c, 2);
         // tracking, :247-276.  Every model that is tracked this frame goes into one batch (geometric term) or is tracked on its
         // own (photometric term: its scratch images are shared); static objects then follow the background's NEW pose
         enqueue_tracking_loop(c, 0, g.track_all_models != 0, depthF_prev, k);
-        if (bootstrap && in_pose16) launch_override_pose(bg.d_pose, in_pose16, 1, bg.h_pose, s);   // :280-283 (after the object loop)
+        if (bootstrap && in_pose16) { launch_override_pose(bg.d_pose, in_pose16, 1, bg.h_pose, s); bg.gen++; }   // :280-283 (after the object loop)
         mark(c, 3);
 
         if (multi) {
@@ -685,7 +791,8 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
                 MF_HIP(c, hipEventRecord(c->ev_labels, s));
                 if (c->timings_on) (void)hipEventRecord(c->ev_mm[1], s);
                 if (!g.rgb_only && c->early_bg_fusion) {
-                    enqueue_fuse_clean(c, bg, d_rgb, d_depth, depthF, mask, g.depth_cutoff, weight_multiplier, true, true);
+                    int rc2 = enqueue_fuse_clean(c, bg, d_rgb, d_depth, depthF, mask, g.depth_cutoff, weight_multiplier, true, true);
+                    if (rc2 != MF_OK) return rc2;
                     bg_fused = true;
                 }
                 if (c->timings_on) (void)hipEventRecord(c->ev_mm[2], s);
@@ -727,8 +834,10 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
                 spawned = true;
             }
             for (size_t i = 1; i < c->models.size(); ++i) c->models[i]->maxDepth = 30.f + 30.f * 1.2f;  // :335-339 (depthMean = depthStd = 30)
-            if (spawned)  // :342-353: predictIndices; fuse(maxDepthProcessed, weight 100); clean (no second index pass)
-                enqueue_fuse_clean(c, *c->models.back(), d_rgb, d_depth, depthF, mask, g.max_depth_processed, 100.f, false, false);
+            if (spawned) {  // :342-353: predictIndices; fuse(maxDepthProcessed, weight 100); clean (no second index pass)
+                int rc = enqueue_fuse_clean(c, *c->models.back(), d_rgb, d_depth, depthF, mask, g.max_depth_processed, 100.f, false, false);
+                if (rc != MF_OK) return rc;
+            }
             for (size_t i = 1; i < c->models.size(); ++i)  // :369-374
                 c->models[i]->confThr = fminf(4.5f, (float)c->models[i]->age / 25.0f);
         }
@@ -774,13 +883,6 @@ extern "C" int mf_set_mask_class_ids(mf_ctx* c, const int32_t* class_ids, int32_
 extern "C" int mf_sync(mf_ctx* c) {
     if (!c) return MF_EINVAL;
     MF_HIP(c, hipStreamSynchronize(c->stream));
-    // the one-launch clean bounds its waits (a GPU must never hang on a look-back): a chunk that gave up leaves a sticky mark in the model's frame
-    // state, mirrored to the host with the end-of-frame bookkeeping -- that map is not valid any more, and every call that waits says so
-    for (auto& m : c->models)
-        if (m->h_frame && m->h_frame->pad[2]) {
-            c->err = "Model::clean: the ordered compaction of model id " + std::to_string(m->id) + " gave up waiting for an earlier chunk (internal error: its map is not valid)";
-            return MF_EHIP;
-        }
     if (c->timings_on) {
         // event i marks the START of stage i; stage i lasts until event i+1 (labels: see the header)
         float t[MF_N_TIMINGS] = {};

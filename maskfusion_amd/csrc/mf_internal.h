@@ -75,6 +75,8 @@ struct FrameDev {
     int phys;                  // first slot behind the last run (= count for a dense buffer): where Model::clean appends the frame's new surfels
     int first;                 // slot of the FIRST live surfel (0 for a dense buffer): the surfel whose vertex id is 0 and which the index map
                                // therefore cannot tell from "no surfel" (index_map.frag writes the id into a texture cleared to 0)
+    int runsNext;              // snapshot of `runs` taken by clean pass 1 for pass 2 (like countNext)
+    int first_run;             // ... and the run it starts (runs only ever lose surfels: the first non-empty run moves forward, never back)
     unsigned long long done_cover;   // k_splat_tile: (workgroups finished << 32) | coverage count of this launch; zero between launches
 };
 
@@ -247,18 +249,22 @@ constexpr int kSurfelGridBlocks = 2048;
 void launch_index_scatter(Surfels src, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k,
                           float maxDepth, int timeDelta, unsigned long long* keys, bool transposed /* column-major key image */, hipStream_t s,
                           int blocks = kSurfelGridBlocks, const VisList* vis = nullptr);
-// run table of s from scratch: fixed runs of kRun slots (after Model::initialise / an uploaded map; the clean pass writes it afterwards)
-void launch_run_table(Surfels s, FrameDev* frame, hipStream_t st);
-size_t run_table_entries(long capacity_plus_candidates);   // int4 entries of a run table (2 per run + the end marker)
+// run table of a DENSE buffer s (slots [0, frame->count)): fixed runs of kRun slots (after Model::initialise / an uploaded map / a compaction; the
+// in-place clean pass maintains it afterwards).  refresh: s has a table -- only the entries' contents are recomputed from the surfels
+void launch_run_table(Surfels s, FrameDev* frame, hipStream_t st, bool refresh = false);
+size_t run_table_runs(long capacity, long pixels);      // runs a buffer's table can hold (the host compacts the buffer before they run out)
+size_t run_table_entries(long capacity, long pixels);   // int4 entries of that table (kBoxStride per run)
 // the runs of s whose box meets the viewing frustum (image bounds + 2 px, -1 cm .. maxDepth + 1 cm) and that hold a surfel seen within
 // timeDelta: their indices -> list (any order), their number -> count[0]; ctl: 2 ints, zero between launches
 void launch_cull(Surfels s, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, int timeDelta, int* list, int* count,
                  int* ctl, int max_runs, hipStream_t st);
-// packed == nullptr: index / vertConf / normRad (+ colorTime if ct != nullptr) images; else one 32 B record per texel
-void launch_index_resolve(Surfels src, const PoseDev* pose, unsigned long long* keys, int W, int H, int* index,
+// packed == nullptr: index / vertConf / normRad (+ colorTime if ct != nullptr) images; else one 32 B record per texel.  decay_stats (with packed,
+// optional): 3 ints the pass accumulates the frame's mask-disagreement depth ranges into for launch_cull_clean (armed = {kBoxEmptyMin,
+// kBoxEmptyMax, kBoxEmptyMin}; maskID: the model's id)
+void launch_index_resolve(Surfels src, const FrameDev* frame, const PoseDev* pose, unsigned long long* keys, int W, int H, int* index,
                           float4* vc, float4* nr, float4* ct /*or null*/, float4* packed /*or null: the packed column-major map instead of the row-major maps*/,
                           const float* depthF, const uint8_t* mask, uint8_t* maskT /* with packed: the frame planes that travel with it */,
-                          bool keys_transposed /* the order the scatter used */, hipStream_t s);
+                          bool keys_transposed /* the order the scatter used */, hipStream_t s, int* decay_stats = nullptr, int maskID = 0);
 void launch_fuse_data(const uint8_t* rgb, const float* depthRaw, const float* depthF, const uint8_t* mask,
                       int maskID, const FrameDev* frame, const PoseDev* pose, float weightMultiplier, float maxDepth,
                       int W, int H, Intr k, const int* index, const float4* vc, const float4* nr, uint8_t* cand_op,
@@ -271,22 +277,45 @@ void launch_fuse_update(Surfels s, const FrameDev* frame, int* upd_first, const 
 void launch_fuse_update_copy(Surfels src, Surfels dst, const FrameDev* frame, int* upd_first, const float4* cand_rec, const PoseDev* pose,
                              int W, int H, Intr k, float maxDepth, int timeDelta, unsigned long long* keys_or_null, bool transposed,
                              hipStream_t s, int blocks = kSurfelGridBlocks);
-// Model::clean in one launch (test + ordered compaction with a decoupled look-back, mf_surfel.hip).  flags / newconf: optional taps (nullptr
-// inside a frame); scan_state: clean_scan_entries(capacity + P) words, never reset (epoch must differ from launch to launch and be > 0);
-// ctl: kCleanCtlInts ints, zero between launches; blocks: clean_grid(elements expected)
+// Model::clean (copy_unstable.vert:53-157, Model.cpp:649-772).  What every form is given: the shader's uniforms and textures + the frame's
+// candidates (new-surfel records of the association pass) + the two-launch form's intermediates
+struct CleanIn {
+    FrameDev* frame; const PoseDev* pose; int W, H; Intr k; int timeDelta; float confThreshold, outlierCoeff; int maskID;
+    const int* index; const float4* vc; const float4* ct;    // the index map as separate images, or
+    const float4* packed; const uint8_t* maskT;              // ... the packed column-major map with the mask beside it
+    const float* depthF; const uint8_t* mask;
+    const uint8_t* cand_op; const float4* cand_rec;
+    uint8_t* flags; float* newconf; int* block_counts;       // [elements], [elements], [kCompactBlocks]
+    int* host_count;                                         // pinned mirror of the surfel count
+    unsigned long long* host_append; unsigned seq;           // in place: pinned mirror of where the buffer ends after THIS pass, tagged with the pass's
+                                                             // sequence number (append_mirror() below); nullptr: none
+    bool transposed;                                         // layout of index / vc / ct / packed: column-major
+    bool literalWindow;                                      // the window walked with the shader's own fp32 trip count
+};
+// seq (20 bits) | runs of the table (18 bits) | first slot behind the last run (26 bits): one 64-bit store the host can read at any time --
+// its bounds on what the device has appended then start from a recent exact value instead of the last compaction (mf_frame.inl: prepare_in_place)
+constexpr int kAppendSeqBits = 20, kAppendRunBits = 18, kAppendPhysBits = 26;
+__host__ __device__ inline unsigned long long append_mirror(unsigned seq, int runs, int phys) {
+    return ((unsigned long long)(seq & ((1u << kAppendSeqBits) - 1u)) << (kAppendRunBits + kAppendPhysBits)) | ((unsigned long long)(unsigned)runs << kAppendPhysBits) |
+           (unsigned long long)(unsigned)phys;
+}
+// two launches (flags + ordered copy), src -> dst: dst is a DENSE buffer without a run table.  src must be dense.
+void launch_clean_small(const CleanIn& in, Surfels src, Surfels dst, hipStream_t s);
+// IN PLACE (mf_surfel.hip "clean, in place"; buf has a run table): launch_clean_runs tests the surfels of the listed runs (nullptr: of every run)
+// and compacts each run where it stands; launch_clean_append tests the frame's candidates and appends the survivors behind the last run.
+// ctl: kCleanCtlInts ints, zero between launches; blocks: clean_runs_grid(elements expected)
 constexpr int kCleanGridMax = 2048;
-constexpr int kCleanTicketLanes = 32;
-constexpr int kCleanCtlInts = 1088;   // size of the control block `ctl` (finished-workgroup count + 32 ticket counters 128 B apart)
-int clean_grid(long elements);
-size_t clean_scan_entries(long max_elements);
-void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k,
-                  int timeDelta, float confThreshold, float outlierCoeff, int maskID, const int* index,
-                  const float4* vc, const float4* ct, const float4* packed /*or null*/, const float* depthF, const uint8_t* mask,
-                  const uint8_t* maskT /* the mask in the packed map's order (with packed) */,
-                  const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags /*or null*/, float* newconf /*or null*/, int* block_counts,
-                  unsigned long long* scan_state, int* ctl, unsigned epoch, int blocks, int ticket_lanes /* <= compute units, <= kCleanTicketLanes */,
-                  int* host_count_mirror, bool transposed /*layout of index/vc/ct*/, bool literalWindow /*fp32 trip count of the shader*/,
-                  bool small_map /* the two-launch form (needs flags, newconf, block_counts; writes no run table) */, hipStream_t s);
+constexpr int kCleanCtlInts = 8;
+int clean_runs_grid(long elements);
+void launch_clean_runs(const CleanIn& in, Surfels buf, const VisList* runs, int* ctl, int blocks, hipStream_t s);
+void launch_clean_append(const CleanIn& in, Surfels buf, hipStream_t s);
+// the runs launch_clean_runs has to visit for the BACKGROUND-style culling of a model: those in which one of the pass's rules can apply at all
+// (decay_stats: launch_index_resolve's, re-armed here; list / count / ctl as launch_cull)
+void launch_arm_decay_stats(int* stats /*[3]*/, hipStream_t st);   // once, when the statistics block is allocated
+void launch_cull_clean(Surfels s, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, int timeDelta, float confThreshold, int* decay_stats,
+                       int* list, int* count, int* ctl, int max_runs, hipStream_t st);
+// compaction of a sparse buffer: the surfels of src's runs -> dst, dense (no table); offs: scratch of run_table_runs() + 1 ints
+void launch_densify(Surfels src, Surfels dst, FrameDev* frame, int* offs, int* host_count, hipStream_t st);
 // generic ordered compaction of [n_dev] records (3 x float4 each, record-major) -> surfels, sets frame->count
 void launch_compact_records(const float4* rec, const uint8_t* flags, int n, Surfels dst, FrameDev* frame,
                             int* block_counts, int* host_count_mirror, hipStream_t s);
@@ -316,12 +345,13 @@ int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W,
 // round 2's profile).  The batched kernels are the single-model kernels' bodies called with one model's arguments, picked from a device
 // array by blockIdx.z; every model brings its own scratch (index maps, key image, candidate records, ...), which the single-model path shares.
 struct ObjPassArgs {
-    Surfels a, b;                      // live buffer when the frame's fusion starts / the other one (big models: fuse in place in a, clean a -> b, then b is
-                                       // live; small ones: fuse a -> b, clean b -> a)
+    Surfels a, b;                      // live buffer when the frame's fusion starts / the other one (small models: fuse a -> b, clean b -> a; from
+                                       // inPlaceElements on: fuse in place in a, clean a -> b, then b is live; big ones: everything in place in a)
     FrameDev* frame; PoseDev* pose;
     int maskID; float confThreshold, fuseMaxDepth, weightMultiplier;
     unsigned long long* keys; int* index; float4* ivc; float4* inr; float4* iclean;
-    uint8_t* cand_op; float4* cand_rec; int* upd_first; int* cand_best; unsigned long long* scan_state; int* clean_ctl; int* host_count;
+    uint8_t* cand_op; float4* cand_rec; int* upd_first; int* cand_best; int* clean_ctl; int* host_count;
+    unsigned long long* host_append; unsigned clean_seq;   // CleanIn::host_append / seq
     uint8_t* flags; float* newconf; int* block_counts;   // the two-launch clean form's intermediates
     float4* predV; float4* predN; uchar4* predImage; uint16_t* predTime; uint8_t* predGray;
     FrameDev* host_frame; float* log_slot;
@@ -330,10 +360,8 @@ struct ObjPassArgs {
 struct ObjBatch {
     const ObjPassArgs* m; int n;
     int W, H; Intr k; float maxDepthProcessed, globalMaxDepth; int timeDelta; float outlierCoeff; int cleanLiteral, bboxLimit;
-    unsigned cleanEpoch;               // CleanArgs::epoch of this batch's clean launch
-    int cleanTicketLanes;              // CleanArgs::ticket_lanes
     int updateCopy;                    // 1: every model of the batch is below inPlaceElements -- update.vert as a copy a -> b, clean b -> a
-    int cleanSmall;                    // 1: every model of the batch is small -- the two-launch clean form
+    int cleanSmall;                    // 1: the two-launch clean form src -> dst; 0: every model of the batch has a run table -- clean in place
     const uint8_t* rgb; const float* depthRaw; const float* depthF; const uint8_t* mask; const PoseDev* bg_pose;
     uint8_t* maskT;                    // the mask in column-major order, beside the packed maps (every model's resolve writes the same bytes)
     unsigned long long* global_keys;

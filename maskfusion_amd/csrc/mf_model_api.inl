@@ -13,11 +13,17 @@ static ModelState* model_at(mf_ctx* c, int32_t i);
 // ------------------------------------------------------------------------------------------------
 static __global__ void k_set_count(FrameDev* f, int count, int* host_count) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    f->count = count; f->countNext = count;
+    f->count = count; f->countNext = count; f->phys = count; f->runs = 0; f->first = 0; f->first_run = 0;   // a dense buffer
     if (host_count) *host_count = count;
 }
 static void set_model_tick(mf_ctx* c, ModelState& m, int tick) {
     hipLaunchKernelGGL(k_set_tick, dim3(1), dim3(64), 0, c->stream, m.d_frame, tick, m.h_frame);
+    m.gen++;   // (what is "seen within timeDelta" changes with the tick: cached visibility lists are stale)
+}
+// bookkeeping behind a call that replaced m's buffer by a dense one of (at most) n surfels and built its run table
+static void fresh_table(mf_ctx* c, ModelState& m, long n) {
+    m.table_valid = true; m.sparse = false; m.phys_ub = n; m.runs_ub = (n + kRun - 1) / kRun; m.gen++; m.mirror_from = m.clean_seq + 1;
+    c->vis_tag.model = nullptr;
 }
 static long staged_frame(const mf_ctx* c) { return c->frame_no - 1; }   // index of the frame staged / processed last
 static const uint8_t* current_mask(const mf_ctx* c) { return c->cfg.enable_multiple_models ? c->d_mask_tex : c->d_zero_mask; }
@@ -62,8 +68,7 @@ extern "C" int mf_model_initialise(mf_ctx* c, int32_t model) {
                         c->d_flags, c->stream);
     launch_compact_records(c->d_cand_rec, c->d_flags, c->P, m->surf[m->cur], m->d_frame, c->d_block_counts, m->h_count, c->stream);
     launch_run_table(m->surf[m->cur], m->d_frame, c->stream);
-    m->table_valid = true;
-    c->vis_tag.model = nullptr;
+    fresh_table(c, *m, (long)c->P);
     if (model == 0) c->map_ready = true;
     return check_launch(c);
 }
@@ -87,8 +92,7 @@ extern "C" int mf_model_upload_map(mf_ctx* c, int32_t model, const float* surfel
     }
     hipLaunchKernelGGL(k_set_count, dim3(1), dim3(64), 0, c->stream, m->d_frame, (int)count, m->h_count);
     launch_run_table(m->surf[m->cur], m->d_frame, c->stream);
-    m->table_valid = true;
-    c->vis_tag.model = nullptr;
+    fresh_table(c, *m, (long)count);
     if (model == 0) c->map_ready = true;   // the map exists: the next mf_process_frame tracks instead of initialising
     return check_launch(c);
 }
@@ -98,6 +102,7 @@ extern "C" int mf_model_override_pose(mf_ctx* c, int32_t model, const float* pos
     ModelState* m = model_at(c, model);
     if (!m || !pose16) return MF_EINVAL;
     launch_override_pose(m->d_pose, pose16, 0, m->h_pose, c->stream);
+    m->gen++;
     c->vis_tag.model = nullptr;   // a visibility list belongs to ONE pose
     return check_launch(c);
 }
@@ -156,10 +161,10 @@ extern "C" int mf_model_predict_indices(mf_ctx* c, int32_t model, int32_t time, 
     hipStream_t s = c->stream;
     set_model_tick(c, *m, time);
     launch_index_scatter(m->surf[m->cur], m->d_frame, m->d_pose, c->W, c->H, c->K, max_depth, time_delta, c->d_keys, true, s);
-    launch_index_resolve(m->surf[m->cur], m->d_pose, c->d_keys, c->W, c->H, c->d_index, c->d_ivc, c->d_inr, c->d_ict, nullptr, nullptr, nullptr, nullptr, true, s);
+    launch_index_resolve(m->surf[m->cur], m->d_frame, m->d_pose, c->d_keys, c->W, c->H, c->d_index, c->d_ivc, c->d_inr, c->d_ict, nullptr, nullptr, nullptr, nullptr, true, s);
     if (c->model_api_packed) {   // the layout mf_process_frame feeds clean() with: packed records, column-major
         launch_index_scatter(m->surf[m->cur], m->d_frame, m->d_pose, c->W, c->H, c->K, max_depth, time_delta, c->d_keys, true, s);
-        launch_index_resolve(m->surf[m->cur], m->d_pose, c->d_keys, c->W, c->H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, c->d_depthF[staged_frame(c) % 3],
+        launch_index_resolve(m->surf[m->cur], m->d_frame, m->d_pose, c->d_keys, c->W, c->H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, c->d_depthF[staged_frame(c) % 3],
                              current_mask(c), c->d_maskT, true, s);
     }
     return check_launch(c);
@@ -178,6 +183,10 @@ extern "C" int mf_model_fuse(mf_ctx* c, int32_t model, int32_t time, float depth
                      fminf(depth_cutoff, m->maxDepth), c->W, c->H, c->K, c->d_index, c->d_ivc, c->d_inr, c->d_cand_op, c->d_cand_rec,
                      c->d_upd_first, c->d_cand_best, s, c->bbox_limit ? 1 : 0);
     launch_fuse_update(m->surf[m->cur], m->d_frame, c->d_upd_first, c->d_cand_op, c->d_cand_best, c->d_cand_rec, c->W, c->H, s);   // in place
+    // merged surfels moved and were seen now: the boxes and time stamps of their runs are refreshed (inside mf_process_frame the clean pass that
+    // follows rewrites the entries of every run it visits -- and it visits every run a merge can have touched)
+    if (m->table_valid) launch_run_table(m->surf[m->cur], m->d_frame, s, true);
+    m->gen++;
     return check_launch(c);
 }
 
@@ -189,15 +198,24 @@ extern "C" int mf_model_clean(mf_ctx* c, int32_t model, int32_t time, int32_t ti
     if (!m || c->frame_no == 0) return MF_EINVAL;
     const long k = staged_frame(c);
     set_model_tick(c, *m, time);
-    const int src = m->cur, dst = 1 - m->cur;
     const bool packed = c->model_api_packed != 0;
-    const bool small = clean_small(c, *m);
-    launch_clean(m->surf[src], m->surf[dst], m->d_frame, m->d_pose, c->W, c->H, c->K, time_delta, m->confThr, c->cfg.outlier_coefficient, m->id,
-                 c->d_index, c->d_ivc, c->d_ict, packed ? c->d_iclean : nullptr, c->d_depthF[k % 3], current_mask(c), c->d_maskT, c->d_cand_op, c->d_cand_rec,
-                 c->d_flags, c->d_newconf, c->d_block_counts, c->d_scan_state, c->d_clean_ctl, next_clean_epoch(c), clean_blocks(c, *m), c->ticket_lanes, m->h_count,
-                 packed, c->clean_literal, small, c->stream);
-    m->cur = dst;
-    m->table_valid = !small;
+    bool small = clean_small(c, *m);
+    if (!small) {
+        bool ok = true;
+        int rc = prepare_in_place(c, *m, ok);
+        if (rc != MF_OK) return rc;
+        small = !ok;
+    } else {
+        require_dense(c, *m);
+    }
+    CleanIn in = clean_in(c, *m, time_delta, packed, c->d_depthF[k % 3], current_mask(c));
+    if (small) {
+        launch_clean_small(in, m->surf[m->cur], m->surf[1 - m->cur], c->stream);
+        m->cur = 1 - m->cur;
+    } else {
+        enqueue_clean_in_place(c, *m, in, false);   // (no decay statistics outside a frame: every run is visited)
+    }
+    after_clean(c, *m, !small);
     return check_launch(c);
 }
 
@@ -266,8 +284,10 @@ extern "C" int mf_fuse_models(mf_ctx* c, int32_t first_model, float weight_multi
     const float* depthF = c->d_depthF[k % 3];
     const uint8_t* mask = current_mask(c);
     for (size_t i = 1; i < c->models.size(); ++i) c->models[i]->maxDepth = 30.f + 30.f * 1.2f;
-    if (spawned_model > 0)
-        enqueue_fuse_clean(c, *c->models[spawned_model], c->cur_rgb, c->cur_depth, depthF, mask, g.max_depth_processed, 100.f, false, false);
+    if (spawned_model > 0) {
+        int rc = enqueue_fuse_clean(c, *c->models[spawned_model], c->cur_rgb, c->cur_depth, depthF, mask, g.max_depth_processed, 100.f, false, false);
+        if (rc != MF_OK) return rc;
+    }
     for (size_t i = 1; i < c->models.size(); ++i) c->models[i]->confThr = fminf(4.5f, (float)c->models[i]->age / 25.0f);
     if (!g.rgb_only) {
         if (first_model == 0 && c->bg_fused_frame == k) first_model = 1;   // mf_fuse_background has run for this frame

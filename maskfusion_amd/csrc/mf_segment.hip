@@ -8,6 +8,7 @@
 //                                                       the 0.2 m jump test of MaskFusion.cpp:268-272
 #pragma clang fp contract(off)
 #include "mf_device.h"
+#include "mf_walk.h"
 
 namespace mf {
 
@@ -106,7 +107,6 @@ __device__ __forceinline__ void global_scatter_body(Surfels src, const FrameDev*
                                                     float confThreshold, int timeDelta, unsigned payload,
                                                     unsigned long long* __restrict__ keys) {
     if (pose->alive == 0) return;  // model dropped by the jump test earlier in this frame
-    const int n = frame->count;
     const float time = (float)frame->tick;
     float Ri[9];
 #pragma unroll
@@ -114,14 +114,15 @@ __device__ __forceinline__ void global_scatter_body(Surfels src, const FrameDev*
     const float3 ti = f3(pose->ti[0], pose->ti[1], pose->ti[2]);
     constexpr int kLX = kLanes >= 2 ? 2 : 1, kLY = kLanes / kLX;
     const int sub = threadIdx.x % kLanes, sx = sub % kLX, sy = sub / kLX;
-    for (int i = (blockIdx.x * 256 + threadIdx.x) / kLanes; i < n; i += gridDim.x * 256 / kLanes) {
+    for_each_surfel_slice<kLanes>(src, frame, nullptr, nullptr, [&](int i, bool live) {
+        if (!live) return;
         const float4 pc = src.pc[i];
-        if (pc.w < confThreshold) continue;
+        if (pc.w < confThreshold) return;
         const float lastTime = src.ct[i].w;
         const float3 h = mul33(Ri, f3(pc.x, pc.y, pc.z)) + ti;
-        if (h.z > maxDepth || h.z < 0 || time - lastTime > (float)timeDelta || lastTime > time) continue;  // splat_models.vert:57
+        if (h.z > maxDepth || h.z < 0 || time - lastTime > (float)timeDelta || lastTime > time) return;  // splat_models.vert:57
         const float u = ((k.fx * h.x) / h.z) + k.cx, v = ((k.fy * h.y) / h.z) + k.cy;
-        if (!(u >= 0.f && u <= (float)W && v >= 0.f && v <= (float)H)) continue;
+        if (!(u >= 0.f && u <= (float)W && v >= 0.f && v <= (float)H)) return;
         const float4 n4 = src.nr[i];
         const float3 nrm = normalize_gl(mul33(Ri, f3(n4.x, n4.y, n4.z)));
         const float rad = n4.w;
@@ -137,7 +138,7 @@ __device__ __forceinline__ void global_scatter_body(Surfels src, const FrameDev*
             ys0 = fminf(ys0, pyq); ys1 = fmaxf(ys1, pyq);
         }
         float size = fmaxf(0.f, fmaxf(fabsf(xs1 - xs0), fabsf(ys1 - ys0)));
-        if (!(size > 0.f)) continue;
+        if (!(size > 0.f)) return;
         size = fminf(fmaxf(size, 1.0f), 64.0f);   // GL clamps gl_PointSize to the point size range: at least 1 px (see mf_splat.hip)
         const float half = size * 0.5f;
         const int px0 = max(0, (int)ceilf(u - half - 0.5f)), px1 = min(W - 1, (int)ceilf(u + half - 0.5f) - 1);
@@ -155,7 +156,7 @@ __device__ __forceinline__ void global_scatter_body(Surfels src, const FrameDev*
                 if (kLanes > 1) zmin_key_pretested(&keys[py * W + px], ((unsigned long long)__float_as_uint(cp.z) << 32) | payload);   // (object models)
                 else zmin_key(&keys[py * W + px], ((unsigned long long)__float_as_uint(cp.z) << 32) | payload);
             }
-    }
+    });
 }
 
 __global__ __launch_bounds__(256) void k_global_scatter(Surfels src, const FrameDev* __restrict__ frame,
@@ -207,7 +208,7 @@ __global__ void k_spawn_pose(PoseDev* obj, const PoseDev* bg, FrameDev* objFrame
     const float3 v = mul33(q.initR, f3(bg->t[0], bg->t[1], bg->t[2]));
     q.initT[0] = -v.x; q.initT[1] = -v.y; q.initT[2] = -v.z;
     *obj = q;
-    objFrame->tick = bgFrame->tick; objFrame->count = 0; objFrame->countNext = 0; objFrame->cover = 0; objFrame->useFillIn = 0; objFrame->done_cover = 0ull;
+    objFrame->tick = bgFrame->tick; objFrame->count = 0; objFrame->countNext = 0; objFrame->phys = 0; objFrame->runs = 0; objFrame->first = 0; objFrame->first_run = 0; objFrame->cover = 0; objFrame->useFillIn = 0; objFrame->done_cover = 0ull;
     MF_FRAME_BBOX_RESET(objFrame);
     objFrame->pad[0] = objFrame->pad[1] = objFrame->pad[2] = 0;
     if (host_mirror) *host_mirror = q;

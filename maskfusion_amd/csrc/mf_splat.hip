@@ -92,7 +92,11 @@ __global__ __launch_bounds__(kBinThreads) void k_splat_bin(const BinArgs a) {
     const int nt = a.tilesX * a.tilesY;
     int* s_cnt = s_mem;           // [nt] this workgroup's entries per tile, then the start of its reserved range
     int* s_fill = s_mem + nt;     // [nt] slots handed out
-    const int n = a.frame->count;     // device-resident: the grid is fixed and walks the buffer in chunks of 2048 surfels
+    const int n = a.frame->phys;      // device-resident: the grid is fixed and walks the buffer in chunks of 2048 slots
+    // by runs: the listed ones (k_cull), or every run of the buffer's table; a dense buffer without a table: slot by slot
+    const int table_runs = a.frame->runs;
+    const bool by_runs = a.vis_list != nullptr || table_runs > 0;
+    const int nruns = a.vis_list ? *a.vis_count : table_runs;
     const float time = (float)a.frame->tick;
     float Ri[9];
 #pragma unroll
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(kBinThreads) void k_splat_bin(const BinArgs a) {
     const float3 ti = f3(a.pose->ti[0], a.pose->ti[1], a.pose->ti[2]);
   // a round = 2048 surfel slots: 2048 consecutive surfels of the buffer, or -- with a visibility list -- the next 2048 / kRun listed runs
   constexpr int kRunsPerRound = 2 * kBinThreads / kRun;
-  const int rounds = a.vis_list ? (*a.vis_count + kRunsPerRound - 1) / kRunsPerRound : (n + 2 * kBinThreads - 1) / (2 * kBinThreads);
+  const int rounds = by_runs ? (nruns + kRunsPerRound - 1) / kRunsPerRound : (n + 2 * kBinThreads - 1) / (2 * kBinThreads);
   for (int chunk = blockIdx.x; chunk < rounds; chunk += gridDim.x) {
     for (int t = threadIdx.x; t < nt; t += kBinThreads) { s_cnt[t] = 0; s_fill[t] = 0; }
     __syncthreads();
@@ -109,13 +113,13 @@ __global__ __launch_bounds__(kBinThreads) void k_splat_bin(const BinArgs a) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         int i = (chunk * 2 + r) * kBinThreads + threadIdx.x;
-        if (a.vis_list) {
+        if (by_runs) {
             const int slot = r * kBinThreads + (int)threadIdx.x, v = chunk * kRunsPerRound + slot / kRun;
             i = n;
-            if (v < *a.vis_count) {
-                const int run = a.vis_list[v];
-                const int beg = a.src.box[2 * run + 1].w, end = a.src.box[2 * run + 3].w;
-                if (beg + slot % kRun < end) i = beg + slot % kRun;
+            if (v < nruns) {
+                const int run = a.vis_list ? a.vis_list[v] : v;
+                const int beg = run_start(a.src.box, run), len = run_len(a.src.box, run);
+                if (slot % kRun < len) i = beg + slot % kRun;
             }
         }
         idx[r] = i;
@@ -194,15 +198,17 @@ __device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* ti
     __syncthreads();
     if (prof) { stamp.t[1] = __builtin_amdgcn_s_memtime(); stamp.t[6] = (unsigned long long)s_range[0]; }
     const bool overflow = s_range[0] > tile_cap;   // more sprites than list slots (the reference has no such limit): scan every box
-    // (after an overflow: every surfel whose sprite box the binning pass wrote -- the whole buffer, or the runs of the visibility list)
-    const int cnt = overflow ? (vis_list ? *vis_count * kRun : frame->count) : s_range[0];
+    // (after an overflow: every surfel whose sprite box the binning pass wrote -- the runs of the visibility list, every run of the table, or
+    // -- a dense buffer without a table -- every slot)
+    const int table_runs = frame->runs;
+    const bool by_runs = vis_list != nullptr || table_runs > 0;
+    const int cnt = overflow ? (by_runs ? (vis_list ? *vis_count : table_runs) * kRun : frame->count) : s_range[0];
     const int* __restrict__ list = entries + (size_t)tile * tile_cap;
     auto entry = [&](int e) -> int {
         if (!overflow) return list[e];
-        if (!vis_list) return e;
-        const int run = vis_list[e / kRun];
-        const int i = runs[2 * run + 1].w + e % kRun;
-        return i < runs[2 * run + 3].w ? i : -1;
+        if (!by_runs) return e;
+        const int run = vis_list ? vis_list[e / kRun] : e / kRun;
+        return e % kRun < run_len(runs, run) ? run_start(runs, run) + e % kRun : -1;
     };
     // kSpriteLanes neighbouring lanes share one sprite and take every kSpriteLanes-th pixel of its clipped box (with one lane per sprite a
     // wavefront runs as long as its largest box).  The lanes read the same list entry / records (one request) and the z-test is order

@@ -25,6 +25,7 @@
 // kernels within rounding of a plain reading of the shaders (the oracle is built with -ffp-contract=off).
 #pragma clang fp contract(off)
 #include "mf_device.h"
+#include "mf_walk.h"
 #include "mf_rgbd_device.h"
 
 namespace mf {
@@ -140,7 +141,8 @@ __global__ __launch_bounds__(256) void k_compact_records(const float4* __restric
         __syncthreads();
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-        frame->count = min(base, dst.cap);
+        frame->count = frame->phys = min(base, dst.cap);   // a dense buffer without a run table
+        frame->runs = 0; frame->first = 0; frame->first_run = 0;
         if (host_count) *host_count = min(base, dst.cap);
     }
 }
@@ -203,31 +205,19 @@ __device__ __forceinline__ void index_scatter_one(const Surfels& src, int i, boo
     }
 }
 
-// vis_list == nullptr: every surfel of the buffer; else only the runs k_cull listed (Surfels::box) -- the others hold no surfel that could
-// pass the tests above, so the keys are the same bits either way
 __device__ __forceinline__ void index_scatter_body(Surfels src, const FrameDev* __restrict__ frame,
                                                    const PoseDev* __restrict__ pose, int W, int H, Intr k, float maxDepth,
                                                    int timeDelta, unsigned long long* __restrict__ keys, int transposed,
                                                    const int* __restrict__ vis_list = nullptr, const int* __restrict__ vis_count = nullptr,
                                                    bool pretest = false) {
-    const int n = frame->count;
     const float time = (float)frame->tick;
     float Ri[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) Ri[q] = pose->Ri[q];
     const float3 ti = f3(pose->ti[0], pose->ti[1], pose->ti[2]);
-    if (vis_list) {
-        const int nv = *vis_count;
-        for (int v = blockIdx.x; v < nv; v += gridDim.x) {
-            const int r = vis_list[v];
-            const int beg = src.box[2 * r + 1].w, end = min(n, src.box[2 * r + 3].w);
-            for (int i0 = beg; i0 < end; i0 += 256)     // (wavefront-uniform bounds: every lane takes part in the exchange)
-                index_scatter_one(src, i0 + (int)threadIdx.x, i0 + (int)threadIdx.x < end, time, Ri, ti, W, H, k, maxDepth, timeDelta, keys, transposed, pretest);
-        }
-        return;
-    }
-    for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256)
-        index_scatter_one(src, i0 + (int)threadIdx.x, i0 + (int)threadIdx.x < n, time, Ri, ti, W, H, k, maxDepth, timeDelta, keys, transposed, pretest);
+    for_each_surfel_slice<1>(src, frame, vis_list, vis_count, [&](int i, bool live) {
+        index_scatter_one(src, i, live, time, Ri, ti, W, H, k, maxDepth, timeDelta, keys, transposed, pretest);
+    });
 }
 
 __global__ __launch_bounds__(256) void k_index_scatter(Surfels src, const FrameDev* __restrict__ frame,
@@ -246,28 +236,36 @@ void launch_index_scatter(Surfels src, const FrameDev* frame, const PoseDev* pos
 // ------------------------------------------------------------------------------------------------
 // run table (Surfels::box) from scratch, and the visibility test over it
 // ------------------------------------------------------------------------------------------------
-// block reduction of one run's box: per-thread (already reduced over the thread's own surfels) -> int4 pair; s_red: 4 x 8 ints of LDS
-__device__ __forceinline__ void run_box_reduce(int (&lo)[3], int (&hi)[3], int tmax, int (*s_red)[8]) {
+// what a run's table entry says about its surfels, per thread: box of the positions, newest lastTime, lowest confidence (order-preserving ints)
+struct RunAcc {
+    int lo[3], hi[3], tmax, cmin;
+    __device__ __forceinline__ void reset() { lo[0] = lo[1] = lo[2] = kBoxEmptyMin; hi[0] = hi[1] = hi[2] = kBoxEmptyMax; tmax = kBoxEmptyMax; cmin = kBoxEmptyMin; }
+    __device__ __forceinline__ void add(float4 pc, float lastTime) {
+        if (pc.x == pc.x && pc.y == pc.y && pc.z == pc.z) {   // (a NaN position is never in view)
+            const int ex = box_enc(pc.x), ey = box_enc(pc.y), ez = box_enc(pc.z);
+            lo[0] = min(lo[0], ex); lo[1] = min(lo[1], ey); lo[2] = min(lo[2], ez);
+            hi[0] = max(hi[0], ex); hi[1] = max(hi[1], ey); hi[2] = max(hi[2], ez);
+        }
+        // (a NaN time stamp passes every "seen within timeDelta" test of the passes -- !(time - NaN > delta) -- : such a surfel counts as seen now)
+        tmax = max(tmax, lastTime == lastTime ? box_enc(lastTime) : 0x7F800000);
+        if (pc.w == pc.w) cmin = min(cmin, box_enc(pc.w));   // (a NaN confidence is below no threshold: the age rule of clean never drops it)
+    }
+};
+// block reduction of one run's entry: per-thread (already reduced over the thread's own surfels) -> s_red[wavefront][8]
+__device__ __forceinline__ void run_box_reduce(const RunAcc& t, int (*s_red)[8]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int lo[3], hi[3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) { lo[q] = wave_min_i(lo[q]); hi[q] = wave_max_i(hi[q]); }
-    tmax = wave_max_i(tmax);
+    for (int q = 0; q < 3; ++q) { lo[q] = wave_min_i(t.lo[q]); hi[q] = wave_max_i(t.hi[q]); }
+    const int tmax = wave_max_i(t.tmax), cmin = wave_min_i(t.cmin);
     if (lane == 0) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) { s_red[wave][q] = lo[q]; s_red[wave][4 + q] = hi[q]; }
-        s_red[wave][3] = tmax;
+        s_red[wave][3] = tmax; s_red[wave][7] = cmin;
     }
 }
-__device__ __forceinline__ void run_box_accumulate(float4 pc, float lastTime, int (&lo)[3], int (&hi)[3], int& tmax) {
-    if (pc.x == pc.x && pc.y == pc.y && pc.z == pc.z) {   // (a NaN position is never in view)
-        const int ex = box_enc(pc.x), ey = box_enc(pc.y), ez = box_enc(pc.z);
-        lo[0] = min(lo[0], ex); lo[1] = min(lo[1], ey); lo[2] = min(lo[2], ez);
-        hi[0] = max(hi[0], ex); hi[1] = max(hi[1], ey); hi[2] = max(hi[2], ez);
-    }
-    if (lastTime == lastTime) tmax = max(tmax, box_enc(lastTime));
-}
-// thread 0 .. : the four wavefronts' partial boxes -> the table entry of run r starting at slot `start`
-__device__ __forceinline__ void run_box_store(int4* __restrict__ box, int r, int start, const int (*s_red)[8]) {
+// one thread: the four wavefronts' partial results -> the table entry of run r (start slot, live surfels)
+__device__ __forceinline__ void run_box_store(int4* __restrict__ box, int r, int start, int len, const int (*s_red)[8]) {
     int4 a, b;
     a.x = min(min(s_red[0][0], s_red[1][0]), min(s_red[2][0], s_red[3][0]));
     a.y = min(min(s_red[0][1], s_red[1][1]), min(s_red[2][1], s_red[3][1]));
@@ -277,35 +275,82 @@ __device__ __forceinline__ void run_box_store(int4* __restrict__ box, int r, int
     b.y = max(max(s_red[0][5], s_red[1][5]), max(s_red[2][5], s_red[3][5]));
     b.z = max(max(s_red[0][6], s_red[1][6]), max(s_red[2][6], s_red[3][6]));
     b.w = start;
-    box[2 * r] = a; box[2 * r + 1] = b;
+    const int cmin = min(min(s_red[0][7], s_red[1][7]), min(s_red[2][7], s_red[3][7]));
+    box[kBoxStride * r] = a; box[kBoxStride * r + 1] = b; box[kBoxStride * r + 2] = make_int4(len, cmin, 0, 0);
 }
 
-__global__ __launch_bounds__(256) void k_run_table(Surfels s, FrameDev* __restrict__ frame) {
+// A DENSE buffer (slots [0, count)) gets its table: fixed runs of kRun slots.  refresh != 0: the buffer HAS a table (frame->runs > 0) and only the
+// entries' contents are recomputed from the surfels (after an in-place update outside a frame: merged surfels moved, their time stamps changed).
+__global__ __launch_bounds__(256) void k_run_table(Surfels s, FrameDev* __restrict__ frame, int refresh) {
     __shared__ int s_red[4][8];
     const int n = frame->count;
-    const int runs = (n + kRun - 1) / kRun;
+    const int runs = refresh ? frame->runs : (n + kRun - 1) / kRun;
     for (int r = blockIdx.x; r < runs; r += gridDim.x) {
-        int lo[3] = {kBoxEmptyMin, kBoxEmptyMin, kBoxEmptyMin}, hi[3] = {kBoxEmptyMax, kBoxEmptyMax, kBoxEmptyMax}, tmax = kBoxEmptyMax;
-        for (int i = r * kRun + (int)threadIdx.x; i < min(n, (r + 1) * kRun); i += 256) run_box_accumulate(s.pc[i], s.ct[i].w, lo, hi, tmax);
-        run_box_reduce(lo, hi, tmax, s_red);
+        const int start = refresh ? run_start(s.box, r) : r * kRun, len = refresh ? run_len(s.box, r) : min(n - r * kRun, kRun);
+        RunAcc acc;
+        acc.reset();
+        for (int i = start + (int)threadIdx.x; i < start + len; i += 256) acc.add(s.pc[i], s.ct[i].w);
+        run_box_reduce(acc, s_red);
         __syncthreads();
-        if (threadIdx.x == 0) run_box_store(s.box, r, r * kRun, s_red);
+        if (threadIdx.x == 0) run_box_store(s.box, r, start, len, s_red);
         __syncthreads();
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        s.box[2 * runs + 1] = make_int4(0, 0, 0, n);   // end of the last run
-        frame->runs = runs;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !refresh) {
+        frame->runs = runs; frame->phys = n; frame->first = 0; frame->first_run = 0;
     }
 }
-void launch_run_table(Surfels s, FrameDev* frame, hipStream_t st) {
-    hipLaunchKernelGGL(k_run_table, dim3(1024), dim3(256), 0, st, s, frame);
+void launch_run_table(Surfels s, FrameDev* frame, hipStream_t st, bool refresh) {
+    hipLaunchKernelGGL(k_run_table, dim3(1024), dim3(256), 0, st, s, frame, refresh ? 1 : 0);
 }
-size_t run_table_entries(long elements) { return (size_t)(2 * ((elements + kRun - 1) / kRun + 2)); }
+// entries of a buffer's run table: the fixed runs of a full buffer + the runs Model::clean appends, one frame's new surfels after the other
+// (<= P / 4 surfels in <= P / (4 kRun) + 1 runs per frame), until the host compacts the buffer (mf_frame.inl: runs_ub)
+size_t run_table_runs(long capacity, long pixels) { return (size_t)(2 * ((capacity + kRun - 1) / kRun) + 4 * ((pixels / 4 + kRun - 1) / kRun + 2) + 64); }
+size_t run_table_entries(long capacity, long pixels) { return (size_t)kBoxStride * run_table_runs(capacity, pixels); }
 
-// One thread per run: conservative frustum test of the run's box under `pose` (the per-surfel tests of the passes that consume the list are
-// u in [0, W] x [0, H] and 0 <= z <= maxDepth on individually rounded floats: the box is tested against the image grown by 2 px and the depth
-// range grown by 1 cm -- metres against rounding errors of micrometres) and the activity test (no surfel seen within timeDelta: every pass
-// drops all of them, index_map.vert:46, splat.vert:58).  Runs that pass are appended to `list` in no particular order.
+// every corner of a run's box outside the SAME half-space => the whole box is: near / far, then the four image sides as planes through the eye
+// (u < -2  <=>  fx x + (cx + 2) z < 0 for z > 0).  The per-surfel tests of the passes are u in [0, W] x [0, H] and 0 <= z <= maxDepth on individually
+// rounded floats: the box is tested against the image grown by 2 px and the depth range grown by 1 cm -- metres against rounding errors of
+// micrometres.  zlo / zhi: the depth range of the box's corners in the camera frame.
+__device__ __forceinline__ bool run_box_in_frustum(int4 a, int4 b, const PoseDev* __restrict__ pose, int W, int H, Intr k, float maxDepth, float& zlo, float& zhi) {
+    const float lo[3] = {box_dec(a.x), box_dec(a.y), box_dec(a.z)}, hi[3] = {box_dec(b.x), box_dec(b.y), box_dec(b.z)};
+    int out_near = 1, out_far = 1, out_l = 1, out_r = 1, out_t = 1, out_b = 1;
+    zlo = INFINITY; zhi = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float3 p = f3((c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]);
+        const float3 h = mul33(pose->Ri, p) + f3(pose->ti[0], pose->ti[1], pose->ti[2]);
+        zlo = fminf(zlo, h.z); zhi = fmaxf(zhi, h.z);
+        out_near &= h.z < -0.01f;
+        out_far &= h.z > maxDepth + 0.01f;
+        out_l &= k.fx * h.x + (k.cx + 2.f) * h.z < 0.f;
+        out_r &= k.fx * h.x + (k.cx - (float)W - 2.f) * h.z > 0.f;
+        out_t &= k.fy * h.y + (k.cy + 2.f) * h.z < 0.f;
+        out_b &= k.fy * h.y + (k.cy - (float)H - 2.f) * h.z > 0.f;
+    }
+    return !(out_near | out_far | out_l | out_r | out_t | out_b);
+}
+// the listed runs go to `list` in no particular order; the last workgroup to finish publishes their number and re-arms the counters
+__device__ __forceinline__ void run_list_append(bool listed, int r, int* __restrict__ list, int* __restrict__ count, int* __restrict__ ctl) {
+    const unsigned long long m = __ballot(listed);
+    int base = 0;
+    if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(&ctl[0], __popcll(m));
+    base = __shfl(base, 0, 64);
+    if (listed) list[base + lane_rank(m)] = r;
+}
+__device__ __forceinline__ bool run_list_finish(int* __restrict__ count, int* __restrict__ ctl) {
+    __syncthreads();
+    if (threadIdx.x != 0) return false;
+    // (every workgroup's slot reservations have returned before its barrier: relaxed atomics suffice, an agent-scope release would write the L2 back)
+    const int done = atomicAdd(&ctl[1], 1);
+    if (done != (int)gridDim.x - 1) return false;
+    count[0] = __hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ctl[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ctl[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
+// One thread per run: conservative frustum test of the run's box under `pose` and the activity test (no surfel seen within timeDelta: every
+// projection pass drops all of them, index_map.vert:46, splat.vert:58).
 __global__ __launch_bounds__(256) void k_cull(Surfels s, const FrameDev* __restrict__ frame, const PoseDev* __restrict__ pose, int W, int H, Intr k,
                                               float maxDepth, int timeDelta, int* __restrict__ list, int* __restrict__ count, int* __restrict__ ctl) {
     const int runs = frame->runs;
@@ -313,43 +358,14 @@ __global__ __launch_bounds__(256) void k_cull(Surfels s, const FrameDev* __restr
     const int r = blockIdx.x * 256 + threadIdx.x;
     bool vis = false;
     if (r < runs) {
-        const int4 a = s.box[2 * r], b = s.box[2 * r + 1];
-        const int len = s.box[2 * r + 3].w - b.w;
-        if (len > 0 && a.x <= b.x && a.y <= b.y && a.z <= b.z && !(time - box_dec(a.w) > (float)timeDelta)) {
-            const float lo[3] = {box_dec(a.x), box_dec(a.y), box_dec(a.z)}, hi[3] = {box_dec(b.x), box_dec(b.y), box_dec(b.z)};
-            // every corner outside the SAME half-space => the whole box is: near / far, then the four image sides as planes through the eye
-            // (u < -2  <=>  fx x + (cx + 2) z < 0 for z > 0; points with z <= 0 fail the depth test anyway)
-            int out_near = 1, out_far = 1, out_l = 1, out_r = 1, out_t = 1, out_b = 1;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float3 p = f3((c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]);
-                const float3 h = mul33(pose->Ri, p) + f3(pose->ti[0], pose->ti[1], pose->ti[2]);
-                out_near &= h.z < -0.01f;
-                out_far &= h.z > maxDepth + 0.01f;
-                out_l &= k.fx * h.x + (k.cx + 2.f) * h.z < 0.f;
-                out_r &= k.fx * h.x + (k.cx - (float)W - 2.f) * h.z > 0.f;
-                out_t &= k.fy * h.y + (k.cy + 2.f) * h.z < 0.f;
-                out_b &= k.fy * h.y + (k.cy - (float)H - 2.f) * h.z > 0.f;
-            }
-            vis = !(out_near | out_far | out_l | out_r | out_t | out_b);
+        const int4 a = s.box[kBoxStride * r], b = s.box[kBoxStride * r + 1];
+        if (run_len(s.box, r) > 0 && a.x <= b.x && a.y <= b.y && a.z <= b.z && !(time - box_dec(a.w) > (float)timeDelta)) {
+            float zlo, zhi;
+            vis = run_box_in_frustum(a, b, pose, W, H, k, maxDepth, zlo, zhi);
         }
     }
-    const unsigned long long m = __ballot(vis);
-    int base = 0;
-    if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(&ctl[0], __popcll(m));
-    base = __shfl(base, 0, 64);
-    if (vis) list[base + lane_rank(m)] = r;
-    // the last workgroup to finish publishes the count and re-arms the counters
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // (every workgroup's slot reservations have returned before its barrier: relaxed atomics suffice, an agent-scope release would write the L2 back)
-        const int done = atomicAdd(&ctl[1], 1);
-        if (done == (int)gridDim.x - 1) {
-            count[0] = __hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ctl[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ctl[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    run_list_append(vis, r, list, count, ctl);
+    (void)run_list_finish(count, ctl);
 }
 void launch_cull(Surfels s, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, int timeDelta, int* list, int* count,
                  int* ctl, int max_runs, hipStream_t st) {
@@ -368,22 +384,26 @@ void launch_cull(Surfels s, const FrameDev* frame, const PoseDev* pose, int W, i
 // Every form also resets the key it read (ready for the next scatter: saves a separate clear pass).
 struct ResolvedTexel { int index; float4 vc, nr, ct, p0, p1; };
 template <bool kPacked>
-__device__ __forceinline__ ResolvedTexel resolve_texel(const Surfels& src, const PoseDev* __restrict__ pose, unsigned long long key, bool want_ct) {
+__device__ __forceinline__ ResolvedTexel resolve_texel(const Surfels& src, const PoseDev* __restrict__ pose, unsigned long long key, bool want_ct, int first) {
     ResolvedTexel r;
     r.index = 0;
     r.vc = r.nr = r.ct = r.p0 = r.p1 = make_float4(0, 0, 0, 0);
     if (key == kEmptyKey) return r;
     const int i = (int)(unsigned)(key & 0xFFFFFFFFull);
+    // The index image holds the VERTEX ID of the winner (index_map.frag), and vertex 0 -- the first surfel of the buffer -- cannot be told from
+    // the cleared texture: it occludes like any other surfel and is then read as "no surfel" (data.vert, copy_unstable.vert test index > 0).  In a
+    // sparse buffer the first surfel is slot frame->first.
+    const int id = i == first ? 0 : i;
     const float4 pc = src.pc[i];
     const float3 h = mul33(pose->Ri, f3(pc.x, pc.y, pc.z)) + f3(pose->ti[0], pose->ti[1], pose->ti[2]);
     if (kPacked) {
         const float4 c4 = src.ct[i];
         r.p0 = make_float4(h.x, h.y, h.z, pc.w);
-        r.p1 = make_float4(c4.z, c4.w, __int_as_float(i), 0.f);
+        r.p1 = make_float4(c4.z, c4.w, __int_as_float(id), 0.f);
     } else {
         const float4 n4 = src.nr[i];
         const float3 n = normalize_gl(mul33(pose->Ri, f3(n4.x, n4.y, n4.z)));
-        r.index = i;
+        r.index = id;
         r.vc = make_float4(h.x, h.y, h.z, pc.w);
         r.nr = make_float4(n.x, n.y, n.z, n4.w);
         if (want_ct) r.ct = src.ct[i];   // colorTime image: only the clean pass of a freshly spawned model reads it from here
@@ -393,7 +413,26 @@ __device__ __forceinline__ ResolvedTexel resolve_texel(const Surfels& src, const
 // frame planes that travel with the packed map (copy_unstable.vert:139-156 looks the filtered depth and the mask up at the surfel's own texel: in the
 // packed, column-major order these are neighbours of its window taps; in the row-major images every lane pulled a sector of its own):
 // depthF -> the packed record's spare word, mask -> maskT (column-major bytes)
-struct ResolveOut { int* index; float4* vc; float4* nr; float4* ct; float4* packed; const float* depthF; const uint8_t* mask; uint8_t* maskT; };
+struct ResolveOut {
+    int* index; float4* vc; float4* nr; float4* ct; float4* packed; const float* depthF; const uint8_t* mask; uint8_t* maskT;
+    const FrameDev* frame;    // the buffer's frame state (`first`)
+    // with `packed`, optional: what Model::clean's mask-disagreement rule (copy_unstable.vert:139-156) can meet in this frame, for the run culling of
+    // the in-place clean (k_cull_clean): order-preserving ints {min, max filtered depth over the BORDER texels whose mask is foreign to the model
+    // (neither its id nor >= 255), min filtered depth over ALL foreign texels}; armed (empty) between frames
+    int* decay_stats; int maskID;
+};
+// a workgroup's texels -> the decay statistics (one atomic per statistic and wavefront that saw a foreign texel)
+__device__ __forceinline__ void decay_stats_add(const ResolveOut& o, bool in_image, int x, int y, int W, int H, float depth, int maskValue) {
+    if (!o.decay_stats) return;
+    const bool foreign = in_image && maskValue != o.maskID && maskValue < 255 && depth == depth;
+    const bool border = foreign && (x == 0 || y == 0 || x == W - 1 || y == H - 1);
+    const int e = box_enc(depth);
+    const int bmin = wave_min_i(border ? e : kBoxEmptyMin), bmax = wave_max_i(border ? e : kBoxEmptyMax), amin = wave_min_i(foreign ? e : kBoxEmptyMin);
+    if ((threadIdx.x & 63) == 0) {
+        if (bmin != kBoxEmptyMin) { atomicMin(&o.decay_stats[0], bmin); atomicMax(&o.decay_stats[1], bmax); }
+        if (amin != kBoxEmptyMin) atomicMin(&o.decay_stats[2], amin);
+    }
+}
 
 // row-major keys -> row-major maps: texel p of the key image is texel p of the outputs
 template <bool kPacked>
@@ -403,7 +442,7 @@ __device__ __forceinline__ void index_resolve_same_body(Surfels src, const PoseD
     if (p >= P) return;
     const unsigned long long key = keys[p];
     keys[p] = kEmptyKey;
-    const ResolvedTexel r = resolve_texel<false>(src, pose, key, o.ct != nullptr);
+    const ResolvedTexel r = resolve_texel<false>(src, pose, key, o.ct != nullptr, o.frame->first);
     o.index[p] = r.index; o.vc[p] = r.vc; o.nr[p] = r.nr;
     if (o.ct) o.ct[p] = r.ct;
 }
@@ -421,14 +460,16 @@ __device__ __forceinline__ void index_resolve_transposing_body(Surfels src, cons
     {   // read the keys in THEIR order: packed output <- row-major keys (x fast), maps <- column-major keys (y fast)
         const int lx = kPacked ? f : g, ly = kPacked ? g : f;
         const int x = x0 + lx, y = y0 + ly;
-        ResolvedTexel r = resolve_texel<kPacked>(src, pose, kEmptyKey, false);
+        ResolvedTexel r = resolve_texel<kPacked>(src, pose, kEmptyKey, false, 0);
+        int mk = 0;
         if (x < W && y < H) {
             const int p = kPacked ? y * W + x : x * H + y;
             const unsigned long long key = keys[p];
             keys[p] = kEmptyKey;
-            r = resolve_texel<kPacked>(src, pose, key, o.ct != nullptr);
-            if (kPacked) { r.p1.w = o.depthF[p]; s_mk[lx][ly] = o.mask[p]; }
+            r = resolve_texel<kPacked>(src, pose, key, o.ct != nullptr, o.frame->first);
+            if (kPacked) { r.p1.w = o.depthF[p]; mk = o.mask[p]; s_mk[lx][ly] = (uint8_t)mk; }
         }
+        if (kPacked) decay_stats_add(o, x < W && y < H, x, y, W, H, r.p1.w, mk);
         if (kPacked) { s_a[lx][ly] = r.p0; s_b[lx][ly] = r.p1; }
         else { s_i[lx][ly] = r.index; s_a[lx][ly] = r.vc; s_b[lx][ly] = r.nr; if (o.ct) s_c[lx][ly] = r.ct; }
     }
@@ -460,7 +501,10 @@ __device__ __forceinline__ void index_resolve_packed_body(Surfels src, const Pos
     const int f = threadIdx.x & (kResolveTile - 1), g = threadIdx.x / kResolveTile;
     {
         const int x = x0 + f, y = y0 + g;
-        if (x < W && y < H) { s_d[f][g] = o.depthF[y * W + x]; s_mk[f][g] = o.mask[y * W + x]; }
+        float d = 0.f;
+        int mk = 0;
+        if (x < W && y < H) { d = o.depthF[y * W + x]; mk = o.mask[y * W + x]; s_d[f][g] = d; s_mk[f][g] = (uint8_t)mk; }
+        decay_stats_add(o, x < W && y < H, x, y, W, H, d, mk);
     }
     __syncthreads();
     const int x = x0 + g, y = y0 + f;
@@ -468,7 +512,7 @@ __device__ __forceinline__ void index_resolve_packed_body(Surfels src, const Pos
         const int tp = x * H + y;
         const unsigned long long key = keys[tp];
         keys[tp] = kEmptyKey;
-        ResolvedTexel r = resolve_texel<true>(src, pose, key, false);
+        ResolvedTexel r = resolve_texel<true>(src, pose, key, false, o.frame->first);
         r.p1.w = s_d[g][f];
         o.packed[2 * tp] = r.p0;
         o.packed[2 * tp + 1] = r.p1;
@@ -491,11 +535,11 @@ int resolve_tiles(int W, int H) { return ((W + kResolveTile - 1) / kResolveTile)
 
 // packed != nullptr: the packed column-major map (index / vc / nr / ct unused) with the frame's filtered depth in its spare word and the mask
 // transposed into maskT; else the row-major maps.  keys_transposed: the order the scatter used.
-void launch_index_resolve(Surfels src, const PoseDev* pose, unsigned long long* keys, int W, int H, int* index, float4* vc,
+void launch_index_resolve(Surfels src, const FrameDev* frame, const PoseDev* pose, unsigned long long* keys, int W, int H, int* index, float4* vc,
                           float4* nr, float4* ct, float4* packed, const float* depthF, const uint8_t* mask, uint8_t* maskT, bool keys_transposed,
-                          hipStream_t s) {
+                          hipStream_t s, int* decay_stats, int maskID) {
     const int P = W * H;
-    const ResolveOut o{index, vc, nr, ct, packed, depthF, mask, maskT};
+    const ResolveOut o{index, vc, nr, ct, packed, depthF, mask, maskT, frame, packed ? decay_stats : nullptr, maskID};
     const dim3 flat((P + 255) / 256), tiles(resolve_tiles(W, H));
     if (packed) {
         if (keys_transposed) hipLaunchKernelGGL(k_index_resolve_packed, tiles, dim3(256), 0, s, src, pose, keys, W, H, o);
@@ -659,7 +703,7 @@ __device__ __forceinline__ void fuse_update_body(Surfels s, const FrameDev* __re
     if (c >= cand_count(W, H, frame->tick)) return;
     if (cand_op[c] != 1) return;
     const int i = cand_best[c];
-    if (i < 0 || i >= frame->count) return;
+    if (i < 0 || i >= frame->phys) return;
     if (upd_first[i] != c) return;          // an earlier candidate owns this surfel's merge
     upd_first[i] = kNoUpdate;
     float4 pc = s.pc[i], ct = s.ct[i], nr = s.nr[i];
@@ -740,13 +784,14 @@ struct CleanArgs {
     const float* depthF; const uint8_t* mask;
     const uint8_t* maskT;                                    // the mask in the packed map's order (only with `packed`)
     const uint8_t* cand_op; const float4* cand_rec;
-    uint8_t* flags; float* newconf;    // keep flag / new confidence per element: the two-launch form's intermediate; for the one-launch form optional taps
+    uint8_t* flags; float* newconf;    // keep flag / new confidence per element: pass 1 -> pass 2 of the two-launch form
     int* block_counts;                 // [kCompactBlocks] survivors per workgroup (two-launch form)
     int* host_count;
-    unsigned long long* scan_state;    // [chunks] decoupled look-back: (launch epoch << 34 | status << 32 | survivors)
-    int* ctl;                          // kCleanCtlInts ints, zero between launches: finished workgroups + the ticket counters (clean_body)
-    unsigned epoch;                    // distinguishes this launch's entries of scan_state from older ones (never reset)
-    int ticket_lanes;                  // counters the chunks are drawn from (1 .. kCleanTicketLanes, <= compute units and <= workgroups launched)
+    unsigned long long* host_append; unsigned seq;   // append: CleanIn::host_append / seq
+    int append;                        // two-launch form, 1: the buffer's own surfels have been cleaned where they stand (k_clean_runs) -- the two passes
+                                       // handle the frame's candidates only and append the survivors at frame->phys (dst = src)
+    const int* run_list; const int* run_count;   // k_clean_runs: the runs to visit (k_cull_clean); nullptr: every run of the table
+    int* ctl;                          // k_clean_runs: kCleanCtlInts ints, zero between launches
 };
 
 // The window of copy_unstable.vert:85-86 along one axis, exactly as the shader text walks it: `for (i = c - 2s; i < c + 2s; i += s)` on an
@@ -864,22 +909,26 @@ __device__ __forceinline__ float clean_decayed(const CleanArgs& a, float conf, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// clean, the form for SMALL maps: two launches over a static partition (rounds 1-4).  A round of the one-launch form below is ~100 us of
-// dependent latency whatever it moves; on a map of a few hundred thousand surfels that IS the pass (k_clean at VGA: 100 us against
-// 25 + 8 us for these two), on 27 M surfels it is amortised (1.04 against 0.95 + 0.53 ms).  launch_clean picks by the element count; the
-// surviving records, their order and the count are the same bits either way (tests/test_gpu_switches.py::test_clean_forms_agree).
+// clean, two launches over a static partition: pass 1 = per-element test + new confidence + per-workgroup counts, pass 2 = ordered copy.
+//   * SMALL maps (append == 0; rounds 1-4): every element -- the buffer's surfels and the frame's candidates -- src -> dst, a dense buffer;
+//   * the tail of the IN-PLACE clean of big maps (append == 1, below): the candidates only; their survivors are appended behind the buffer's last
+//     run, and their runs to its table.
+// The surviving records, their order and the count are the same bits either way (tests/test_gpu_switches.py::test_clean_forms_agree).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void clean_small_flags_body(const CleanArgs& a) {
     __shared__ int s_w[4];
-    const int count = a.frame->count;
-    const int total = count + cand_count(a.W, a.H, a.frame->tick);
+    // elements below `count` are the buffer's slots, the others the candidates; `first`: the first element these passes handle
+    const int count = a.append ? a.frame->phys : a.frame->count;
+    const int first = a.append ? count : 0;
+    const int ncand = cand_count(a.W, a.H, a.frame->tick);
+    const int total = count + ncand;
     const float time = (float)a.frame->tick;
     float Ri[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) Ri[q] = a.pose->Ri[q];
     const float3 ti = f3(a.pose->ti[0], a.pose->ti[1], a.pose->ti[2]);
-    const int chunk = chunk_size(total);
-    const int beg = blockIdx.x * chunk, end = min(total, beg + chunk);
+    const int chunk = chunk_size(total - first);
+    const int beg = first + blockIdx.x * chunk, end = min(total, beg + chunk);
     int kept = 0;
     for (int i = beg + threadIdx.x; i < end; i += 256) {
         bool keep = false;
@@ -892,17 +941,27 @@ __device__ __forceinline__ void clean_small_flags_body(const CleanArgs& a) {
             if (a.cand_op[c] == 2)
                 keep = clean_test(a, a.cand_rec[c * 3 + 0], a.cand_rec[c * 3 + 1], a.cand_rec[c * 3 + 2], time, Ri, ti, nc, dk);
         }
-        a.flags[i] = keep ? 1 : 0;
-        a.newconf[i] = nc;
+        a.flags[i - first] = keep ? 1 : 0;
+        a.newconf[i - first] = nc;
         kept += keep ? 1 : 0;
     }
     const int tot = block_sum_i(kept, s_w);
     if (threadIdx.x == 0) {
         a.block_counts[blockIdx.x] = tot;
         if (blockIdx.x == 0) {
-            a.frame->countNext = count;  // snapshot for pass 2 (see FrameDev)
-            if (a.maskID != 0)   // the compaction pass (next launch) accumulates this clean pass's box
+            a.frame->countNext = count;  // snapshots for pass 2 (see FrameDev)
+            a.frame->runsNext = a.frame->runs;
+            if (a.maskID != 0 && !a.append)   // the compaction pass (next launch) accumulates this clean pass's box (append: on top of k_clean_runs')
                 for (int q = 0; q < 6; ++q) a.frame->bbox_acc[q] = q < 3 ? kBBoxEmptyMin : kBBoxEmptyMax;
+        }
+    }
+    if (a.append) {
+        // the table entries pass 2 fills: new run j holds the output slots [count + j kRun, count + (j + 1) kRun)
+        const int r0 = a.frame->runs, nnew = (ncand + kRun - 1) / kRun + 1;
+        for (int j = blockIdx.x * 256 + threadIdx.x; j < nnew; j += gridDim.x * 256) {
+            a.dst.box[kBoxStride * (r0 + j)] = make_int4(kBoxEmptyMin, kBoxEmptyMin, kBoxEmptyMin, kBoxEmptyMax);
+            a.dst.box[kBoxStride * (r0 + j) + 1] = make_int4(kBoxEmptyMax, kBoxEmptyMax, kBoxEmptyMax, count + j * kRun);
+            a.dst.box[kBoxStride * (r0 + j) + 2] = make_int4(0, kBoxEmptyMin, 0, 0);
         }
     }
 }
@@ -919,10 +978,12 @@ __device__ __forceinline__ void clean_small_compact_body(const CleanArgs& a) {
     int bmin[3] = {kBBoxEmptyMin, kBBoxEmptyMin, kBBoxEmptyMin}, bmax[3] = {kBBoxEmptyMax, kBBoxEmptyMax, kBBoxEmptyMax};
     if (bbox_on && threadIdx.x < 6) s_bb[threadIdx.x] = threadIdx.x < 3 ? kBBoxEmptyMin : kBBoxEmptyMax;
     const int count = a.frame->countNext;
+    const int first = a.append ? count : 0;
     const int total = count + cand_count(a.W, a.H, a.frame->tick);
+    const int r0 = a.frame->runsNext;     // (append) the table entry of the first new run
     const float time = (float)a.frame->tick;
-    const int chunk = chunk_size(total);
-    const int beg = blockIdx.x * chunk, end = min(total, beg + chunk);
+    const int chunk = chunk_size(total - first);
+    const int beg = first + blockIdx.x * chunk, end = min(total, beg + chunk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int base = 0;
     for (int i0 = beg; i0 < end; i0 += 256) {
@@ -934,12 +995,12 @@ __device__ __forceinline__ void clean_small_compact_body(const CleanArgs& a) {
         float nc = 0.f;
         float4 pc = make_float4(0, 0, 0, 0), ct = pc, nr = pc;
         if (in) {
-            flag = a.flags[i];
-            nc = a.newconf[i];
+            flag = a.flags[i - first];
+            nc = a.newconf[i - first];
             if (i < count) { pc = a.src.pc[i]; ct = a.src.ct[i]; nr = a.src.nr[i]; }
             else { const int c = i - count; pc = a.cand_rec[c * 3 + 0]; ct = a.cand_rec[c * 3 + 1]; nr = a.cand_rec[c * 3 + 2]; }
         }
-        if (i0 == beg) base = block_base(a.block_counts, s_w);
+        if (i0 == beg) base = block_base(a.block_counts, s_w) + first;
         const bool keep = in && flag;
         const unsigned long long m = __ballot(keep);
         if (lane == 0) s_w[wave] = __popcll(m);
@@ -947,16 +1008,39 @@ __device__ __forceinline__ void clean_small_compact_body(const CleanArgs& a) {
         int off = base;
         for (int w = 0; w < wave; ++w) off += s_w[w];
         const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-        if (keep) {
-            const int o = off + lane_rank(m);
+        const int o = off + lane_rank(m);
+        const bool written = keep && o < a.dst.cap;
+        if (written) {
             pc.w = nc;
             if (ct.w == -2.f) ct.w = time;  // copy_unstable.vert:131
-            if (o < a.dst.cap) {
-                a.dst.pc[o] = pc; a.dst.ct[o] = ct; a.dst.nr[o] = nr;
-                if (bbox_on && pc.w > a.confThreshold) {   // draw_global_surface.vert:55 (unstable == 0), :69-78
-                    const int x = (int)(1000.f * pc.x), y = (int)(1000.f * pc.y), z = (int)(1000.f * pc.z);
-                    bmin[0] = min(bmin[0], x); bmin[1] = min(bmin[1], y); bmin[2] = min(bmin[2], z);
-                    bmax[0] = max(bmax[0], x); bmax[1] = max(bmax[1], y); bmax[2] = max(bmax[2], z);
+            a.dst.pc[o] = pc; a.dst.ct[o] = ct; a.dst.nr[o] = nr;
+            if (bbox_on && pc.w > a.confThreshold) {   // draw_global_surface.vert:55 (unstable == 0), :69-78
+                const int x = (int)(1000.f * pc.x), y = (int)(1000.f * pc.y), z = (int)(1000.f * pc.z);
+                bmin[0] = min(bmin[0], x); bmin[1] = min(bmin[1], y); bmin[2] = min(bmin[2], z);
+                bmax[0] = max(bmax[0], x); bmax[1] = max(bmax[1], y); bmax[2] = max(bmax[2], z);
+            }
+        }
+        if (a.append) {
+            // the appended surfels' runs: a wavefront's survivors are consecutive output slots, in at most two runs
+            const int j = written ? (o - count) / kRun : 0x7FFFFFFF;
+            const int j0 = wave_min_i(j);
+            if (j0 != 0x7FFFFFFF) {
+                for (int g = 0; g < 2; ++g) {
+                    const bool mine = written && j == j0 + g;
+                    const unsigned long long mm = __ballot(mine);
+                    if (mm == 0ull) continue;
+                    RunAcc acc;
+                    acc.reset();
+                    if (mine) acc.add(pc, ct.w);
+                    int v[8] = {acc.lo[0], acc.lo[1], acc.lo[2], acc.tmax, acc.hi[0], acc.hi[1], acc.hi[2], acc.cmin};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = (q < 3 || q == 7) ? wave_min_i(v[q]) : wave_max_i(v[q]);
+                    if (lane == 0) {
+                        int* e = reinterpret_cast<int*>(&a.dst.box[kBoxStride * (r0 + j0 + g)]);
+                        atomicMin(&e[0], v[0]); atomicMin(&e[1], v[1]); atomicMin(&e[2], v[2]); atomicMax(&e[3], v[3]);
+                        atomicMax(&e[4], v[4]); atomicMax(&e[5], v[5]); atomicMax(&e[6], v[6]);
+                        atomicAdd(&e[8], __popcll(mm)); atomicMin(&e[9], v[7]);
+                    }
                 }
             }
         }
@@ -976,271 +1060,196 @@ __device__ __forceinline__ void clean_small_compact_body(const CleanArgs& a) {
         }
     }
     if (blockIdx.x != gridDim.x - 1) return;
-    if (beg >= end) base = block_base(a.block_counts, s_w);   // the last workgroup owns no elements: all threads take part
+    if (beg >= end) base = block_base(a.block_counts, s_w) + first;   // the last workgroup owns no elements: all threads take part
     if (threadIdx.x == 0) {
-        a.frame->count = min(base, a.dst.cap);
-        a.frame->runs = 0;   // (this form writes no run table: the host does not cull a buffer it produced)
-        if (a.host_count) *a.host_count = min(base, a.dst.cap);
+        const int end_slot = min(base, a.dst.cap);
+        if (a.append) {
+            // (nobody else reads these during the launch: the other workgroups work from the snapshots)
+            const int n = a.frame->count + (end_slot - count);
+            a.frame->count = n;
+            a.frame->phys = end_slot;
+            a.frame->runs = r0 + (end_slot - count + kRun - 1) / kRun;
+            // the first live surfel: runs only lose surfels, so the first non-empty run moves forward only; if every old run is empty it is the first
+            // appended surfel (an empty map has none: the value is never used)
+            int fr = a.frame->first_run;
+            while (fr < r0 && run_len(a.dst.box, fr) == 0) ++fr;
+            a.frame->first_run = fr;
+            a.frame->first = fr < r0 ? run_start(a.dst.box, fr) : count;
+            if (a.host_count) *a.host_count = n;
+            if (a.host_append) *a.host_append = append_mirror(a.seq, r0 + (end_slot - count + kRun - 1) / kRun, end_slot);
+        } else {
+            a.frame->count = a.frame->phys = end_slot;
+            a.frame->runs = 0;   // a dense buffer; this form writes no run table
+            a.frame->first = 0; a.frame->first_run = 0;
+            if (a.host_count) *a.host_count = end_slot;
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void k_clean_small_compact(const CleanArgs a) { clean_small_compact_body(a); }
 
 // ------------------------------------------------------------------------------------------------
-// clean (copy_unstable.vert:53-157) in ONE launch: test + ordered compaction with a decoupled look-back.
-// Rounds 1-4 ran two launches (k_clean_flags: test -> keep flags + new confidences + per-workgroup counts; k_clean_compact: prefix of the
-// counts, ordered copy) over a static partition: the workgroups whose slice lay in view did all the window gathers while the others idled, and
-// every flag / confidence took a round trip through HBM (154 B per surfel moved; 1.28 + 0.58 ms on the 26.9 M-surfel map of configs[4]).
-// Here a workgroup draws a chunk of kCleanChunk consecutive elements (element i < count: old surfel i; element count + c: candidate c, live
-// only with op == 2) from a ticket counter and
-//   sweep 1   fetches the half of each record the test needs (position + confidence, the two time stamps: 24 B), tests it -- keep bit and decay
-//             code stay in two registers per thread, the fetched half goes to the LDS --, and requests the other half of the survivors;
-//   look-back publishes the chunk's number of survivors and obtains the number of survivors of all earlier chunks from the published values
-//             (Merrill & Garland's decoupled look-back; the ticket order guarantees that every earlier chunk is owned by a workgroup that is
-//             already running, so the wait terminates);
-//   sweep 2   writes the survivors to their final slots -- the order of the output is the order of the input, as transform feedback keeps it --
-//             and the bounding boxes of the new buffer's runs (Surfels::box).
-// Every byte of the input is read ONCE: 96 B per surfel moved plus the window gathers of the surfels in view.
-// Round 5 history (profiles/r05b_* .. r05n_*; tools/clean_prof.py times the phases of every chunk with an instrumented build): records held in
-// registers, chunks of 512 / 1024: 1.2-1.9 ms; one ticket counter, 32 of them, 128 B .. 64 KB apart: no difference (a counter hands out a ticket
-// every 11 ns, 32 of them one every 0.5 ns: tools/micro/ticket_lanes); 2048 elements, both sweeps from memory (144 B per surfel): 1.33 ms;
-// all of a thread's loads in flight at once instead of four dependent batches: 1.35 ms; this form: 1.29 ms.  Whatever the form, a chunk's phases
-// stretch with the number of workgroups in flight -- a dependent round trip to memory takes 6-8 us while the pass runs, with 768 or 1024
-// workgroups -- and the pass ends up at ~10 chunks per microsecond: the memory system is saturated by ~3 TB/s of mixed traffic (reads of six
-// streams in 32 KB pieces whose order the tickets decide, writes, 64-byte gathers), not by this kernel's instruction stream.
+// clean, IN PLACE (round 6): Model::clean of a big map as O(surfels its tests can change), not O(N).
+// The reference streams the whole buffer through transform feedback every frame (Model.cpp:649-772: N x 48 B read, N' x 48 B written), and so did
+// rounds 1-5 here (round 5: one launch with a decoupled look-back, 3.6 GB moved in 1.28 ms on the 26.9 M-surfel map of configs[4], >= 78 % of it
+// copies of surfels no test of copy_unstable.vert:53-157 can touch).  What the pass can do to a surfel of the buffer:
+//   (a) drop it by the window rules (:77-106)          -- only a surfel inside the image, in front of the camera, seen within timeDelta;
+//   (b) drop it by the age rule (:118-125)             -- only an UNSTABLE surfel (confidence below the threshold) last seen within timeDelta;
+//   (c) lower its confidence, mask disagreement (:139-156) -- a surfel whose texel (clamped to the image border when it projects outside) carries a
+//       foreign mask value and a filtered depth within 5 cm of its own.
+// The buffer is kept as RUNS (Surfels::box): k_cull_clean lists the runs in which (a), (b) or (c) can apply at all -- from the run's box, its newest
+// time stamp, its lowest confidence, and the frame's border / foreign-mask depth ranges (ResolveOut::decay_stats) -- and k_clean_runs visits only
+// those: tests every surfel, and where a run loses surfels moves its survivors up INSIDE the run (their order is kept; the slots behind them stay
+// unused).  The order of the surfels -- the reference's transform-feedback order, which decides z-test ties and which surfel is vertex 0 -- is the
+// order of the runs; nothing ever moves between runs, so no workgroup waits for another (the round-5 look-back and its ticket order are gone).
+// The frame's new surfels are appended behind the last run by the two-launch form above (append = 1).  When the slots behind the last run, or
+// the table, run out, the host compacts the buffer (k_run_offsets + k_densify, mf_frame.inl) -- a copy of the live surfels, every few dozen frames.
 // ------------------------------------------------------------------------------------------------
-constexpr int kCleanPerThread = 8;
-constexpr int kCleanChunk = 256 * kCleanPerThread;
-constexpr int kSubRuns = kCleanChunk / kRun;   // the survivors of a chunk are kSubRuns consecutive runs of the new buffer's run table
-constexpr int kSlicesPerRun = kRun / 256;
-static_assert(kCleanChunk % kRun == 0 && kRun % 256 == 0, "runs are whole slices of a chunk");
-constexpr int kLookPerLane = 4;   // states of earlier chunks a lane reads per look-back step: 256 per step and wavefront (16 per lane was slower: 27 against 17 us per look-back)
-constexpr unsigned kScanAggregate = 1u, kScanInclusive = 2u;
-constexpr int kTicketStride = 32, kTicketBase = 32;   // ctl: [2..3] finished workgroups << 32 | survivors (64 bit), [kTicketBase + g kTicketStride] ticket counter of lane g (128 B apart)
-
-__device__ __forceinline__ unsigned long long scan_load(const unsigned long long* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void scan_store(unsigned long long* p, unsigned long long v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// exclusive prefix of chunk `chunk` (> 0), by wavefront 0.  A step reads the states of the 256 chunks before the part already summed -- lane l
-// those at distance 4 l .. 4 l + 3, nearest first -- waits until each of them has published something for THIS launch, and adds them up to and
-// including the nearest one that carries an inclusive prefix.  (Round 5, first version: 64 states per step.  Every step is a round trip to memory
-// -- the states are read at agent scope, past the non-coherent L2 -- and with ~1000 chunks in flight a chunk walked ~16 of them, ~25 us, before it
-// could write: the pass was bound by its look-back, 26 k chunks in ~0.9 ms.  256 per step cut the walk to four.)
-__device__ __forceinline__ int scan_look_back(const unsigned long long* __restrict__ state, int chunk, unsigned epoch, int& gave_up) {
-    const int lane = threadIdx.x & 63;
-    int exclusive = 0;
-    int idx = chunk - 1;          // nearest chunk not yet accounted for
-    for (;;) {
-        unsigned long long v[kLookPerLane];
-        int spins = 0;
-        for (;;) {
-            bool ready = true;
-#pragma unroll
-            for (int q = 0; q < kLookPerLane; ++q) {
-                const int mine = idx - (lane * kLookPerLane + q);
-                v[q] = mine >= 0 ? scan_load(&state[mine]) : 0ull;
-                ready = ready && (mine < 0 || (unsigned)(v[q] >> 34) == epoch);
-            }
-            if (__ballot(!ready) == 0ull) break;
-            if (++spins > (1 << 22)) { gave_up = 1; break; }   // never in a correct run: a bounded wait cannot hang the GPU
-            __builtin_amdgcn_s_sleep(1);
-        }
-        // this lane's values up to and including its nearest inclusive entry (if it has one)
-        int mine_sum = 0;
-        bool has_incl = false;
-#pragma unroll
-        for (int q = 0; q < kLookPerLane; ++q) {
-            const int mine = idx - (lane * kLookPerLane + q);
-            const bool valid = mine >= 0 && (unsigned)(v[q] >> 34) == epoch;
-            if (valid && !has_incl) {
-                mine_sum += (int)(unsigned)(v[q] & 0xFFFFFFFFull);
-                has_incl = ((unsigned)(v[q] >> 32) & 3u) == kScanInclusive;
+__global__ __launch_bounds__(256) void k_cull_clean(Surfels s, const FrameDev* __restrict__ frame, const PoseDev* __restrict__ pose, int W, int H, Intr k,
+                                                    int timeDelta, float confThreshold, int* __restrict__ decay_stats, int* __restrict__ list,
+                                                    int* __restrict__ count, int* __restrict__ ctl) {
+    const int runs = frame->runs;
+    const float time = (float)frame->tick;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    // what the frame holds for rule (c): filtered depth of the border texels with a foreign mask, lowest filtered depth of ANY foreign texel
+    const int e_bmin = decay_stats[0], e_bmax = decay_stats[1], e_amin = decay_stats[2];
+    const bool has_border = e_bmin != kBoxEmptyMin, has_any = e_amin != kBoxEmptyMin;
+    bool visit = false;
+    if (r < runs) {
+        const int4 a = s.box[kBoxStride * r], b = s.box[kBoxStride * r + 1], c = s.box[kBoxStride * r + 2];
+        if (c.x > 0) {
+            const bool recent = !(time - box_dec(a.w) > (float)timeDelta);
+            if (c.y != kBoxEmptyMin && box_dec(c.y) < confThreshold && recent) visit = true;              // (b)
+            else if (a.x <= b.x && a.y <= b.y && a.z <= b.z) {     // (a run of NaN positions only: every comparison of (a) and (c) fails)
+                float zlo, zhi;
+                if (run_box_in_frustum(a, b, pose, W, H, k, INFINITY, zlo, zhi)) visit = true;           // (a), and (c) inside the image
+                else if (zlo > 0.06f)        // in front of the camera and outside the image: every surfel's texel is a BORDER texel
+                    visit = has_border && !(box_dec(e_bmax) <= zlo - 0.06f || box_dec(e_bmin) >= zhi + 0.06f);
+                else if (zhi < -0.06f)       // behind the camera: any texel, but only a NEGATIVE filtered depth is within 5 cm (the filter writes none)
+                    visit = has_any && box_dec(e_amin) < zhi + 0.06f;
+                else visit = has_any;        // around the camera plane: any texel, depths around zero
             }
         }
-        const unsigned long long incl_mask = __ballot(has_incl);
-        const int stop = incl_mask ? __builtin_ctzll(incl_mask) : 63;
-        exclusive += wave_sum_i(lane <= stop ? mine_sum : 0);
-        if (incl_mask || idx - 64 * kLookPerLane < 0 || gave_up) break;
-        idx -= 64 * kLookPerLane;
     }
-    return exclusive;
+    run_list_append(visit, r, list, count, ctl);
+    if (run_list_finish(count, ctl)) {       // every workgroup has read the statistics: armed for the next frame's resolve pass
+        __hip_atomic_store(&decay_stats[0], kBoxEmptyMin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&decay_stats[1], kBoxEmptyMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&decay_stats[2], kBoxEmptyMin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__global__ void k_arm_decay_stats(int* st) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { st[0] = kBoxEmptyMin; st[1] = kBoxEmptyMax; st[2] = kBoxEmptyMin; }
+}
+void launch_arm_decay_stats(int* stats, hipStream_t st) { hipLaunchKernelGGL(k_arm_decay_stats, dim3(1), dim3(64), 0, st, stats); }
+void launch_cull_clean(Surfels s, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, int timeDelta, float confThreshold, int* decay_stats,
+                       int* list, int* count, int* ctl, int max_runs, hipStream_t st) {
+    hipLaunchKernelGGL(k_cull_clean, dim3((max_runs + 255) / 256), dim3(256), 0, st, s, frame, pose, W, H, k, timeDelta, confThreshold, decay_stats, list,
+                       count, ctl);
 }
 
-#ifdef MF_CLEAN_PROF
-// tooling build (tools/clean_prof.py): per chunk of the background's clean pass {chunk start, ticket, sweep 1, look-back, sweep 2} in 100 MHz ticks
-__device__ unsigned g_clean_prof[1 << 16][8];
-#define MF_PROF_T(x) const unsigned long long x = wall_clock64()
-#else
-#define MF_PROF_T(x)
-#endif
-__device__ __forceinline__ void clean_body(const CleanArgs& a) {
-    __shared__ int s_chunk, s_base;
-    __shared__ int s_cnt[kCleanPerThread][4];
+// One run per workgroup and round (its <= kRun slots: two per thread); the runs are dealt round-robin over the grid (the listed runs come in no
+// particular order, expensive -- in view -- and cheap ones mixed).
+__device__ __forceinline__ void clean_runs_body(const CleanArgs& a) {
+    __shared__ int s_cnt[2][4];
+    __shared__ int s_red[4][8];
     __shared__ int s_bb[6];
-    __shared__ int s_red[kSubRuns][4][8];   // the boxes of the chunk's runs (Surfels::box of dst): per-wavefront partial results
-    __shared__ float4 s_pc[kCleanPerThread][256];   // the half of the chunk's records that sweep 1 fetched (48 KB with s_tm: three workgroups per CU)
-    __shared__ float2 s_tm[kCleanPerThread][256];
-    // Model::lastBoundingBox of an OBJECT model (Model.cpp:315-345 + draw_global_surface.vert:55-78: the box of the surfels the GUI draws --
-    // confidence above the model's threshold -- in millimetres, truncated): accumulated here, where the frame's final records pass through
-    // registers anyway; Model::fuse of the NEXT frame limits its depth with it (Model.cpp:480-501).  The background (id 0) never uses one.
+    static_assert(kRun == 512, "two slots per thread");
+    // Model::lastBoundingBox of an OBJECT model: see clean_small_compact_body (here: the box of the buffer's own survivors; the append pass adds
+    // the new surfels').  An object model's launch therefore visits EVERY run.
     const bool bbox_on = a.maskID != 0;
     int bmin[3] = {kBBoxEmptyMin, kBBoxEmptyMin, kBBoxEmptyMin}, bmax[3] = {kBBoxEmptyMax, kBBoxEmptyMax, kBBoxEmptyMax};
     if (bbox_on && threadIdx.x < 6) s_bb[threadIdx.x] = threadIdx.x < 3 ? kBBoxEmptyMin : kBBoxEmptyMax;
-    // frame->count stays what it is for the whole launch: the new count is installed by the LAST workgroup to finish (below)
-    const int count = a.frame->count;
-    const int total = count + cand_count(a.W, a.H, a.frame->tick);
-    const int nchunks = (total + kCleanChunk - 1) / kCleanChunk;
+    const int nlist = a.run_list ? *a.run_count : a.frame->runs;     // (frame->runs / count change behind this launch only)
     const float time = (float)a.frame->tick;
     float Ri[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) Ri[q] = a.pose->Ri[q];
     const float3 ti = f3(a.pose->ti[0], a.pose->ti[1], a.pose->ti[2]);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // Chunks are handed out by `lanes` (<= kCleanTicketLanes) counters, lane g (= this workgroup's index mod lanes) serving chunks g, g + lanes, ...:
-    // one counter serves a ticket every ~11 ns, 32 of them one every 0.5 ns (tools/micro/ticket_lanes.hip).  (Handing the chunks out in blocks of
-    // 4 / 16 / 64 consecutive ones per XCD, so that an XCD's workgroups walk a contiguous piece of the buffer: 1.32 / 1.34 / 1.56 ms against 1.33 --
-    // the memory phases get a little shorter, the waits in the look-back longer.)  Forward progress: a chunk only ever waits for LOWER chunks; the lowest chunk not
-    // yet finished is either owned by a running workgroup or next in line on a lane whose workgroups (the first `lanes` workgroups of the
-    // grid are dispatched first, one per lane: the host keeps lanes <= the number of compute units) are all working on lower chunks, which finish.
-    const int lanes = a.ticket_lanes;
-    const int tlane = (int)(blockIdx.x % lanes);
-    int wg_kept = 0;          // survivors of the chunks this workgroup handled (thread 0's copy is the one that counts)
-    for (;;) {
-        MF_PROF_T(t_0);
-        if (threadIdx.x == 0) s_chunk = tlane + lanes * atomicAdd(&a.ctl[kTicketBase + tlane * kTicketStride], 1);
-        __syncthreads();
-        const int chunk = s_chunk;
-        if (chunk >= nchunks) break;
-        MF_PROF_T(t_1);
-        const int first = chunk * kCleanChunk + (int)threadIdx.x;
-        // ---- sweep 1: test.  Element j of this thread is first + 256 j.  The test needs HALF of a record -- position + confidence, the two time
-        // stamps: 24 of its 48 bytes; the normal / radius record only for an element in view (clean_test fetches it there) -- and that half stays
-        // in the LDS for sweep 2, which fetches the other half: every byte of the input is read once (96 B per surfel moved; rounds 1-4: 154).
-        unsigned keepmask = 0u, decay = 0u;
-#pragma unroll 1
-        for (int sr = 0; sr < kSubRuns; ++sr) {
-            int rlo[3] = {kBoxEmptyMin, kBoxEmptyMin, kBoxEmptyMin}, rhi[3] = {kBoxEmptyMax, kBoxEmptyMax, kBoxEmptyMax}, rtime = kBoxEmptyMax;
-            float4 pc[kSlicesPerRun];
-            float2 tm[kSlicesPerRun];
-            bool live[kSlicesPerRun];
+    int wg_died = 0;          // surfels this workgroup dropped (thread 0's copy is the one that counts)
+    for (int v = blockIdx.x; v < nlist; v += gridDim.x) {
+        const int r = a.run_list ? a.run_list[v] : v;
+        const int start = run_start(a.src.box, r), len = run_len(a.src.box, r);
+        // The test needs HALF of a record -- position + confidence, the two time stamps: 24 of its 48 bytes; the normal / radius record only for a
+        // surfel in view (clean_test fetches it there), the rest only for a survivor that moves.
+        float4 pc[2];
+        float2 tm[2];
+        bool live[2];
 #pragma unroll
-            for (int q = 0; q < kSlicesPerRun; ++q) {   // the slices' records are requested before anything depends on one of them
-                const int i = first + 256 * (sr * kSlicesPerRun + q);
-                live[q] = i < total;
-                pc[q] = make_float4(0, 0, 0, 0); tm[q] = make_float2(0, 0);
-                if (i < count) {
-                    pc[q] = a.src.pc[i];
-                    tm[q] = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(&a.src.ct[i]) + 2);
-                } else if (live[q]) {
-                    const int c = i - count;
-                    live[q] = a.cand_op[c] == 2;      // op == 1 records carry w = -1 and are dropped, op == 0 slots hold nothing
-                    if (live[q]) {
-                        pc[q] = a.cand_rec[c * 3 + 0];
-                        tm[q] = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(&a.cand_rec[c * 3 + 1]) + 2);
-                    }
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < kSlicesPerRun; ++q) {
-                const int j = sr * kSlicesPerRun + q;
-                const int i = first + 256 * j;
-                const float4 ct = make_float4(0.f, 0.f, tm[q].x, tm[q].y);
-                const float4* nrp = i < count ? &a.src.nr[i] : &a.cand_rec[(i - count) * 3 + 2];
-                float nc = 0.f;
-                int dk = 0;
-                const bool keep = live[q] && clean_test(a, pc[q], ct, make_float4(0, 0, 0, 0), time, Ri, ti, nc, dk, nrp);
-                if (a.flags) {
-                    if (i < total) { a.flags[i] = keep ? 1 : 0; a.newconf[i] = live[q] ? nc : 0.f; }
-                }
-                s_pc[j][threadIdx.x] = pc[q];
-                s_tm[j][threadIdx.x] = tm[q];
-                keepmask |= (keep ? 1u : 0u) << j;
-                decay |= (unsigned)dk << (2 * j);
-                if (keep) run_box_accumulate(pc[q], ct.w == -2.f ? time : ct.w, rlo, rhi, rtime);   // (copy_unstable.vert:131: -2 becomes the time)
-                const unsigned long long m = __ballot(keep);
-                if (lane == 0) s_cnt[j][wave] = __popcll(m);
-            }
-            run_box_reduce(rlo, rhi, rtime, s_red[sr]);
-        }
-        // The OTHER half of every surviving record (colour word + the unused word, normal + radius) is requested now: the loads travel while
-        // the workgroup waits for its place in the output.
-        float2 cus[kCleanPerThread];
-        float4 nrs[kCleanPerThread];
-#pragma unroll
-        for (int j = 0; j < kCleanPerThread; ++j) {
-            cus[j] = make_float2(0, 0); nrs[j] = make_float4(0, 0, 0, 0);
-            if ((keepmask >> j) & 1u) {
-                const int i = first + 256 * j;
-                const float4* rec1 = i < count ? &a.src.ct[i] : &a.cand_rec[(i - count) * 3 + 1];
-                cus[j] = *reinterpret_cast<const float2*>(rec1);
-                nrs[j] = i < count ? a.src.nr[i] : a.cand_rec[(i - count) * 3 + 2];
+        for (int q = 0; q < 2; ++q) {
+            const int off = q * 256 + (int)threadIdx.x;
+            live[q] = off < len;
+            pc[q] = make_float4(0, 0, 0, 0); tm[q] = make_float2(0, 0);
+            if (live[q]) {
+                pc[q] = a.src.pc[start + off];
+                tm[q] = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(&a.src.ct[start + off]) + 2);
             }
         }
-        __syncthreads();
-        MF_PROF_T(t_2);
-        if (wave == 0) {
-            int tot = 0;
+        bool keep[2];
+        float nc[2];
+        int o[2];
+        RunAcc acc;
+        acc.reset();
 #pragma unroll
-            for (int j = 0; j < kCleanPerThread; ++j) tot += s_cnt[j][0] + s_cnt[j][1] + s_cnt[j][2] + s_cnt[j][3];
-            const unsigned long long tag = (unsigned long long)a.epoch << 34;
-            int excl = 0, gave_up = 0;
-            if (chunk > 0) {
-                if (lane == 0) scan_store(&a.scan_state[chunk], tag | ((unsigned long long)kScanAggregate << 32) | (unsigned)tot);
-                excl = scan_look_back(a.scan_state, chunk, a.epoch, gave_up);
-            }
-            if (lane == 0) {
-                scan_store(&a.scan_state[chunk], tag | ((unsigned long long)kScanInclusive << 32) | (unsigned)(excl + tot));
-                s_base = excl;
-                wg_kept += tot;
-                if (gave_up) a.frame->pad[2] = 1;
-                int start = excl;     // the chunk's survivors are kSubRuns consecutive runs of the new buffer
-                for (int sr = 0; sr < kSubRuns; ++sr) {
-                    run_box_store(a.dst.box, chunk * kSubRuns + sr, min(start, a.dst.cap), s_red[sr]);
-                    for (int q = 0; q < kSlicesPerRun; ++q) {
-                        const int j = sr * kSlicesPerRun + q;
-                        start += s_cnt[j][0] + s_cnt[j][1] + s_cnt[j][2] + s_cnt[j][3];
-                    }
-                }
-                if (chunk == nchunks - 1) a.dst.box[2 * nchunks * kSubRuns + 1] = make_int4(0, 0, 0, min(excl + tot, a.dst.cap));   // end of the last run
-            }
+        for (int q = 0; q < 2; ++q) {
+            const int i = start + q * 256 + (int)threadIdx.x;
+            int dk = 0;
+            nc[q] = 0.f;
+            keep[q] = live[q] && clean_test(a, pc[q], make_float4(0.f, 0.f, tm[q].x, tm[q].y), make_float4(0, 0, 0, 0), time, Ri, ti, nc[q], dk, &a.src.nr[i]);
+            if (keep[q]) acc.add(make_float4(pc[q].x, pc[q].y, pc[q].z, nc[q]), tm[q].y);
+            const unsigned long long m = __ballot(keep[q]);
+            if (lane == 0) s_cnt[q][wave] = __popcll(m);
+            o[q] = lane_rank(m);
         }
+        run_box_reduce(acc, s_red);
         __syncthreads();
-        MF_PROF_T(t_3);
-        // ---- sweep 2: the survivors go to their final slots, in order
-        int off = s_base;
+        const int c0 = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
+        const int kept = c0 + s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
+        for (int w = 0; w < wave; ++w) { o[0] += s_cnt[0][w]; o[1] += s_cnt[1][w]; }
+        o[1] += c0;
+        if (kept != len) {
+            // the run lost surfels: its survivors behind the first hole move up, whole records, in order
+            float4 c4[2], n4[2];
+            bool mv[2];
 #pragma unroll
-        for (int j = 0; j < kCleanPerThread; ++j) {
-            const bool keep = (keepmask >> j) & 1u;
-            const unsigned long long m = __ballot(keep);
-            int o = off + lane_rank(m);
-            for (int w = 0; w < wave; ++w) o += s_cnt[j][w];
-            if (keep && o < a.dst.cap) {
-                float4 pc = s_pc[j][threadIdx.x];
-                const float2 tm = s_tm[j][threadIdx.x];
-                pc.w = clean_decayed(a, pc.w, (int)((decay >> (2 * j)) & 3u));
-                const float4 ct = make_float4(cus[j].x, cus[j].y, tm.x, tm.y == -2.f ? time : tm.y);   // copy_unstable.vert:131
-                a.dst.pc[o] = pc; a.dst.ct[o] = ct; a.dst.nr[o] = nrs[j];
-                if (bbox_on && pc.w > a.confThreshold) {   // draw_global_surface.vert:55 (unstable == 0), :69-78
-                    const int x = (int)(1000.f * pc.x), y = (int)(1000.f * pc.y), z = (int)(1000.f * pc.z);
+            for (int q = 0; q < 2; ++q) {
+                const int off = q * 256 + (int)threadIdx.x;
+                mv[q] = keep[q] && o[q] != off;
+                if (mv[q]) { c4[q] = a.src.ct[start + off]; n4[q] = a.src.nr[start + off]; }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every record that moves is in registers before any slot of the run is rewritten
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int off = q * 256 + (int)threadIdx.x;
+                if (mv[q]) {
+                    a.src.pc[start + o[q]] = make_float4(pc[q].x, pc[q].y, pc[q].z, nc[q]);
+                    a.src.ct[start + o[q]] = c4[q];
+                    a.src.nr[start + o[q]] = n4[q];
+                } else if (keep[q] && __float_as_int(nc[q]) != __float_as_int(pc[q].w)) {
+                    reinterpret_cast<float*>(&a.src.pc[start + off])[3] = nc[q];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)    // nobody moves: only a decayed confidence is written
+                if (keep[q] && __float_as_int(nc[q]) != __float_as_int(pc[q].w)) reinterpret_cast<float*>(&a.src.pc[start + q * 256 + (int)threadIdx.x])[3] = nc[q];
+        }
+        if (threadIdx.x == 0) {
+            run_box_store(a.src.box, r, start, kept, s_red);
+            wg_died += len - kept;
+        }
+        if (bbox_on) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (keep[q] && nc[q] > a.confThreshold) {   // draw_global_surface.vert:55 (unstable == 0), :69-78
+                    const int x = (int)(1000.f * pc[q].x), y = (int)(1000.f * pc[q].y), z = (int)(1000.f * pc[q].z);
                     bmin[0] = min(bmin[0], x); bmin[1] = min(bmin[1], y); bmin[2] = min(bmin[2], z);
                     bmax[0] = max(bmax[0], x); bmax[1] = max(bmax[1], y); bmax[2] = max(bmax[2], z);
                 }
-            }
-            off += s_cnt[j][0] + s_cnt[j][1] + s_cnt[j][2] + s_cnt[j][3];
         }
-        __syncthreads();   // s_chunk / s_cnt / s_base / s_red are rewritten by the next round
-#ifdef MF_CLEAN_PROF
-        if (threadIdx.x == 0 && a.maskID == 0 && chunk < (1 << 16)) {
-            const unsigned long long t_4 = wall_clock64();
-            unsigned* o = g_clean_prof[chunk];
-            o[0] = (unsigned)t_0; o[1] = (unsigned)(t_1 - t_0); o[2] = (unsigned)(t_2 - t_1); o[3] = (unsigned)(t_3 - t_2); o[4] = (unsigned)(t_4 - t_3);
-            o[5] = blockIdx.x; o[6] = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xF; o[7] = (unsigned)s_base;
-        }
-#endif
+        __syncthreads();   // s_cnt / s_red are rewritten by the next round
     }
     if (bbox_on) {
 #pragma unroll
@@ -1249,22 +1258,23 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
             if (bmax[q] != kBBoxEmptyMax) atomicMax(&s_bb[3 + q], bmax[q]);
         }
         __syncthreads();
-        if (threadIdx.x < 3 && s_bb[threadIdx.x] != kBBoxEmptyMin) atomicMin(&a.frame->bbox_tmp[threadIdx.x], s_bb[threadIdx.x]);
-        else if (threadIdx.x >= 3 && threadIdx.x < 6 && s_bb[threadIdx.x] != kBBoxEmptyMax) atomicMax(&a.frame->bbox_tmp[threadIdx.x], s_bb[threadIdx.x]);
+        // (RETURNING atomics whose results are waited for: the "finished" ticket below must not overtake them -- a fire-and-forget atomic is not
+        // ordered against a later one to another address)
+        int seen = 0;
+        if (threadIdx.x < 3 && s_bb[threadIdx.x] != kBBoxEmptyMin) seen = atomicMin(&a.frame->bbox_tmp[threadIdx.x], s_bb[threadIdx.x]);
+        else if (threadIdx.x >= 3 && threadIdx.x < 6 && s_bb[threadIdx.x] != kBBoxEmptyMax) seen = atomicMax(&a.frame->bbox_tmp[threadIdx.x], s_bb[threadIdx.x]);
+        if (threadIdx.x < 6) s_bb[threadIdx.x] = seen;      // (consumes the returned values)
     }
-    // The last workgroup to FINISH installs the launch's results: by then nobody reads frame->count or the tickets any more.  One 64-bit atomic
-    // per workgroup carries both its "finished" ticket and the number of survivors it wrote: the value travels IN the atomic, so the
-    // workgroup that draws the last ticket holds the launch's total without any ordering between workgroups (an agent-scope release / acquire
-    // pair here cost an L2 write-back per workgroup); the box atomics of this workgroup have completed behind the barrier above.
+    // The last workgroup to FINISH installs the launch's results: one 64-bit atomic per workgroup carries both its "finished" ticket and the number
+    // of surfels it dropped -- the value travels IN the atomic, so the workgroup that draws the last ticket holds the launch's total without any
+    // ordering between workgroups.
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long* done64 = reinterpret_cast<unsigned long long*>(a.ctl + 2);
-        const unsigned long long old = atomicAdd(done64, (1ull << 32) | (unsigned long long)(unsigned)wg_kept);
+        const unsigned long long old = atomicAdd(done64, (1ull << 32) | (unsigned long long)(unsigned)wg_died);
         if ((unsigned)(old >> 32) == gridDim.x - 1u) {
-            const int n = min((int)(unsigned)(old & 0xFFFFFFFFull) + wg_kept, a.dst.cap);
-            a.frame->countNext = n;
+            const int n = a.frame->count - ((int)(unsigned)(old & 0xFFFFFFFFull) + wg_died);
             a.frame->count = n;
-            a.frame->runs = nchunks * kSubRuns;
             if (a.host_count) *a.host_count = n;
             if (bbox_on) {   // the box of a frame is the box of its LAST clean pass (the reference's render pass sees the final buffer)
                 for (int q = 0; q < 6; ++q) {
@@ -1272,30 +1282,70 @@ __device__ __forceinline__ void clean_body(const CleanArgs& a) {
                     __hip_atomic_store(&a.frame->bbox_tmp[q], q < 3 ? kBBoxEmptyMin : kBBoxEmptyMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            for (int g = 0; g < kCleanTicketLanes; ++g) __hip_atomic_store(&a.ctl[kTicketBase + g * kTicketStride], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(done64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_clean(const CleanArgs a) { clean_body(a); }
-#ifdef MF_CLEAN_PROF
-}  // namespace mf
-extern "C" int mf_debug_clean_prof(unsigned* out, int chunks) {
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mf::g_clean_prof), (size_t)chunks * 32) == hipSuccess ? 0 : -1;
-}
-namespace mf {
-#endif
+__global__ __launch_bounds__(256) void k_clean_runs(const CleanArgs a) { clean_runs_body(a); }
 
-// workgroups of a clean launch for `elements` elements (an upper bound or an estimate: the chunks are drawn from a ticket counter, any
-// grid covers any count)
-int clean_grid(long elements) {
-    const long chunks = (elements + kCleanChunk - 1) / kCleanChunk;
-    return (int)(chunks < kCleanTicketLanes ? kCleanTicketLanes : (chunks > kCleanGridMax ? kCleanGridMax : chunks));
+// workgroups of a k_clean_runs launch for a buffer of ~`elements` surfels: the runs are dealt round-robin, any grid covers any table
+int clean_runs_grid(long elements) {
+    const long runs = (elements + kRun - 1) / kRun;
+    return (int)(runs < 64 ? 64 : (runs > kCleanGridMax ? kCleanGridMax : runs));
 }
-size_t clean_scan_entries(long max_elements) { return (size_t)((max_elements + kCleanChunk - 1) / kCleanChunk + 1); }
-static_assert(kTicketBase + kCleanTicketLanes * kTicketStride <= kCleanCtlInts, "ticket counters fit the control block");
+
+// ------------------------------------------------------------------------------------------------
+// compaction of a sparse buffer: src's runs -> dst, dense (slots [0, count), no table).  Host-driven (mf_frame.inl: densify), when the slots
+// behind the last run or the table entries run out, before a download, before a model's passes return to the small-map forms.
+// ------------------------------------------------------------------------------------------------
+// offs[r] = live surfels of the runs before run r (offs[runs] = all of them): one workgroup
+__global__ __launch_bounds__(1024) void k_run_offsets(Surfels s, const FrameDev* __restrict__ frame, int* __restrict__ offs) {
+    __shared__ int s_w[16];
+    const int runs = frame->runs;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int carry = 0;
+    for (int base = 0; base < runs; base += 1024) {
+        const int r = base + (int)threadIdx.x;
+        const int v = r < runs ? run_len(s.box, r) : 0;
+        int x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wave) before += s_w[w]; total += s_w[w]; }
+        if (r < runs) offs[r] = carry + before + x - v;
+        carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offs[runs] = carry;
+}
+__global__ __launch_bounds__(256) void k_densify(Surfels src, Surfels dst, const FrameDev* __restrict__ frame, const int* __restrict__ offs) {
+    const int runs = frame->runs;
+    for (int r = blockIdx.x; r < runs; r += gridDim.x) {
+        const int start = run_start(src.box, r), len = run_len(src.box, r), o = offs[r];
+        for (int q = threadIdx.x; q < len; q += 256) {
+            if (o + q >= dst.cap) break;
+            dst.pc[o + q] = src.pc[start + q]; dst.ct[o + q] = src.ct[start + q]; dst.nr[o + q] = src.nr[start + q];
+        }
+    }
+}
+__global__ void k_densify_finish(FrameDev* __restrict__ frame, const int* __restrict__ offs, int cap, int* __restrict__ host_count) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int n = min(offs[frame->runs], cap);
+    frame->count = frame->phys = n;
+    frame->runs = 0; frame->first = 0; frame->first_run = 0;
+    if (host_count) *host_count = n;
+}
+void launch_densify(Surfels src, Surfels dst, FrameDev* frame, int* offs, int* host_count, hipStream_t st) {
+    hipLaunchKernelGGL(k_run_offsets, dim3(1), dim3(1024), 0, st, src, frame, offs);
+    hipLaunchKernelGGL(k_densify, dim3(2048), dim3(256), 0, st, src, dst, frame, offs);
+    hipLaunchKernelGGL(k_densify_finish, dim3(1), dim3(64), 0, st, frame, offs, dst.cap, host_count);
+}
 
 // ------------------------------------------------------------------------------------------------
 // splat prediction: scatter (per-surfel sprite loop, ray-disc test, 64-bit atomicMin) + resolve
@@ -1310,7 +1360,6 @@ template <int kLanes>
 __device__ __forceinline__ void splat_scatter_body(Surfels src, const FrameDev* __restrict__ frame,
                                                    const PoseDev* __restrict__ pose, int W, int H, Intr k, float maxDepth,
                                                    float confThreshold, int timeDelta, unsigned long long* __restrict__ keys) {
-    const int n = frame->count;
     const float time = (float)frame->tick;  // combinedPredict(time = tick, maxTime = tick)
     float Ri[9];
 #pragma unroll
@@ -1318,14 +1367,15 @@ __device__ __forceinline__ void splat_scatter_body(Surfels src, const FrameDev* 
     const float3 ti = f3(pose->ti[0], pose->ti[1], pose->ti[2]);
     constexpr int kLX = kLanes >= 2 ? 2 : 1, kLY = kLanes / kLX;
     const int sub = threadIdx.x % kLanes, sx = sub % kLX, sy = sub / kLX;
-    for (int i = (blockIdx.x * 256 + threadIdx.x) / kLanes; i < n; i += gridDim.x * 256 / kLanes) {
+    for_each_surfel_slice<kLanes>(src, frame, nullptr, nullptr, [&](int i, bool live) {
+        if (!live) return;
         const float4 pc = src.pc[i];
-        if (pc.w < confThreshold) continue;
+        if (pc.w < confThreshold) return;
         const float lastTime = src.ct[i].w;
         const float3 h = mul33(Ri, f3(pc.x, pc.y, pc.z)) + ti;
-        if (h.z > maxDepth || h.z < 0 || time - lastTime > (float)timeDelta || lastTime > time) continue;  // splat.vert:58
+        if (h.z > maxDepth || h.z < 0 || time - lastTime > (float)timeDelta || lastTime > time) return;  // splat.vert:58
         const float u = ((k.fx * h.x) / h.z) + k.cx, v = ((k.fy * h.y) / h.z) + k.cy;
-        if (!(u >= 0.f && u <= (float)W && v >= 0.f && v <= (float)H)) continue;
+        if (!(u >= 0.f && u <= (float)W && v >= 0.f && v <= (float)H)) return;
         const float4 n4 = src.nr[i];
         const float3 nrm = normalize_gl(mul33(Ri, f3(n4.x, n4.y, n4.z)));
         const float rad = n4.w;
@@ -1341,7 +1391,7 @@ __device__ __forceinline__ void splat_scatter_body(Surfels src, const FrameDev* 
             ys0 = fminf(ys0, pyq); ys1 = fmaxf(ys1, pyq);
         }
         float size = fmaxf(0.f, fmaxf(fabsf(xs1 - xs0), fabsf(ys1 - ys0)));
-        if (!(size > 0.f)) continue;
+        if (!(size > 0.f)) return;
         size = fminf(fmaxf(size, 1.0f), 64.0f);   // GL clamps gl_PointSize to the point size range: at least 1 px (see mf_splat.hip)
         const float half = size * 0.5f;
         const int px0 = max(0, (int)ceilf(u - half - 0.5f)), px1 = min(W - 1, (int)ceilf(u + half - 0.5f) - 1);
@@ -1361,7 +1411,7 @@ __device__ __forceinline__ void splat_scatter_body(Surfels src, const FrameDev* 
                 else zmin_key(&keys[py * W + px], key);
             }
         }
-    }
+    });
 }
 
 __global__ __launch_bounds__(256) void k_splat_scatter(Surfels src, const FrameDev* __restrict__ frame,
@@ -1472,26 +1522,35 @@ void launch_pose_log(const PoseDev* pose, const PoseDev* bg_pose, float* slot, h
     hipLaunchKernelGGL(k_pose_log, dim3(1), dim3(64), 0, s, pose, bg_pose, slot);
 }
 
-void launch_clean(Surfels src, Surfels dst, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, int timeDelta,
-                  float confThreshold, float outlierCoeff, int maskID, const int* index, const float4* vc, const float4* ct,
-                  const float4* packed, const float* depthF, const uint8_t* mask, const uint8_t* maskT, const uint8_t* cand_op, const float4* cand_rec, uint8_t* flags,
-                  float* newconf, int* block_counts, unsigned long long* scan_state, int* ctl, unsigned epoch, int blocks, int ticket_lanes,
-                  int* host_count_mirror, bool transposed, bool literalWindow, bool small_map, hipStream_t s) {
+static CleanArgs clean_args(const CleanIn& in, Surfels src, Surfels dst) {
     CleanArgs a;
-    a.transposed = transposed ? 1 : 0;
-    a.literal = literalWindow ? 1 : 0;
-    a.src = src; a.dst = dst; a.frame = frame; a.pose = pose; a.W = W; a.H = H; a.k = k; a.timeDelta = timeDelta;
-    a.confThreshold = confThreshold; a.outlierCoeff = outlierCoeff; a.maskID = maskID; a.index = index; a.vc = vc; a.ct = ct;
-    a.packed = packed;
-    a.depthF = depthF; a.mask = mask; a.maskT = maskT; a.cand_op = cand_op; a.cand_rec = cand_rec;
-    a.flags = flags; a.newconf = newconf; a.block_counts = block_counts; a.host_count = host_count_mirror;
-    a.scan_state = scan_state; a.ctl = ctl; a.epoch = epoch; a.ticket_lanes = min(ticket_lanes, blocks);
-    if (small_map) {
-        hipLaunchKernelGGL(k_clean_small_flags, dim3(kCompactBlocks), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(k_clean_small_compact, dim3(kCompactBlocks), dim3(256), 0, s, a);
-        return;
-    }
-    hipLaunchKernelGGL(k_clean, dim3(blocks), dim3(256), 0, s, a);
+    a.transposed = in.transposed ? 1 : 0;
+    a.literal = in.literalWindow ? 1 : 0;
+    a.src = src; a.dst = dst; a.frame = in.frame; a.pose = in.pose; a.W = in.W; a.H = in.H; a.k = in.k; a.timeDelta = in.timeDelta;
+    a.confThreshold = in.confThreshold; a.outlierCoeff = in.outlierCoeff; a.maskID = in.maskID; a.index = in.index; a.vc = in.vc; a.ct = in.ct;
+    a.packed = in.packed;
+    a.depthF = in.depthF; a.mask = in.mask; a.maskT = in.maskT; a.cand_op = in.cand_op; a.cand_rec = in.cand_rec;
+    a.flags = in.flags; a.newconf = in.newconf; a.block_counts = in.block_counts; a.host_count = in.host_count;
+    a.host_append = in.host_append; a.seq = in.seq;
+    a.append = 0; a.run_list = nullptr; a.run_count = nullptr; a.ctl = nullptr;
+    return a;
+}
+void launch_clean_small(const CleanIn& in, Surfels src, Surfels dst, hipStream_t s) {
+    const CleanArgs a = clean_args(in, src, dst);
+    hipLaunchKernelGGL(k_clean_small_flags, dim3(kCompactBlocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_clean_small_compact, dim3(kCompactBlocks), dim3(256), 0, s, a);
+}
+void launch_clean_runs(const CleanIn& in, Surfels buf, const VisList* runs, int* ctl, int blocks, hipStream_t s) {
+    CleanArgs a = clean_args(in, buf, buf);
+    a.run_list = runs ? runs->list : nullptr; a.run_count = runs ? runs->count : nullptr; a.ctl = ctl;
+    hipLaunchKernelGGL(k_clean_runs, dim3(blocks), dim3(256), 0, s, a);
+}
+void launch_clean_append(const CleanIn& in, Surfels buf, hipStream_t s) {
+    CleanArgs a = clean_args(in, buf, buf);
+    a.append = 1;
+    // (the candidates are <= P / 4 elements: a grid of one 256-element slice per workgroup, at most kCompactBlocks of them)
+    hipLaunchKernelGGL(k_clean_small_flags, dim3(kCompactBlocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_clean_small_compact, dim3(kCompactBlocks), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1506,12 +1565,12 @@ __global__ __launch_bounds__(256) void k_obj_index_scatter(const ObjBatch b) {
 }
 __global__ __launch_bounds__(256) void k_obj_index_resolve(const ObjBatch b) {   // (the object models' keys are row-major in both passes)
     const ObjPassArgs& m = b.m[blockIdx.z];
-    index_resolve_same_body<false>(m.a, m.pose, m.keys, b.W * b.H, ResolveOut{m.index, m.ivc, m.inr, nullptr, nullptr, nullptr, nullptr, nullptr});
+    index_resolve_same_body<false>(m.a, m.pose, m.keys, b.W * b.H, ResolveOut{m.index, m.ivc, m.inr, nullptr, nullptr, nullptr, nullptr, nullptr, m.frame, nullptr, 0});
 }
 __global__ __launch_bounds__(256) void k_obj_index_resolve_packed(const ObjBatch b) {   // the pass that feeds clean(): grid.x = 16 x 16-pixel tiles
     const ObjPassArgs& m = b.m[blockIdx.z];
     index_resolve_transposing_body<true>(b.updateCopy ? m.b : m.a, m.pose, m.keys, b.W, b.H,
-                                         ResolveOut{nullptr, nullptr, nullptr, nullptr, m.iclean, b.depthF, b.mask, b.maskT}, (int)blockIdx.x);
+                                         ResolveOut{nullptr, nullptr, nullptr, nullptr, m.iclean, b.depthF, b.mask, b.maskT, m.frame, nullptr, 0}, (int)blockIdx.x);
 }
 __global__ __launch_bounds__(256) void k_obj_fuse_data(const ObjBatch b) {
     const ObjPassArgs& m = b.m[blockIdx.z];
@@ -1528,21 +1587,23 @@ __global__ __launch_bounds__(256) void k_obj_fuse_update_copy(const ObjBatch b) 
     const IndexScatterArgs ix{m.pose, b.W, b.H, b.k, b.maxDepthProcessed, b.timeDelta, m.keys, 0};
     fuse_update_copy_body(m.a, m.b, m.frame, m.upd_first, m.cand_rec, ix);
 }
-__device__ __forceinline__ CleanArgs obj_clean_args(const ObjBatch& b, const ObjPassArgs& m) {
+__device__ __forceinline__ CleanArgs obj_clean_args(const ObjBatch& b, const ObjPassArgs& m, int append) {
     CleanArgs a;
-    // copy-update: fuse copied a -> b, clean goes b -> a (the live buffer stays); in place: clean goes a -> b
-    a.src = b.updateCopy ? m.b : m.a; a.dst = b.updateCopy ? m.a : m.b;
+    // copy-update: fuse copied a -> b, clean goes b -> a (the live buffer stays); in-place update + two-launch clean: clean goes a -> b;
+    // in-place clean (cleanSmall == 0): everything happens in a
+    a.src = b.updateCopy ? m.b : m.a; a.dst = b.updateCopy ? m.a : (b.cleanSmall ? m.b : m.a);
     a.frame = m.frame; a.pose = m.pose; a.W = b.W; a.H = b.H; a.k = b.k; a.timeDelta = b.timeDelta;
     a.confThreshold = m.confThreshold; a.outlierCoeff = b.outlierCoeff; a.maskID = m.maskID; a.transposed = 1; a.literal = b.cleanLiteral;
     a.index = m.index; a.vc = m.ivc; a.ct = nullptr; a.packed = m.iclean; a.depthF = b.depthF; a.mask = b.mask; a.maskT = b.maskT;
-    a.cand_op = m.cand_op; a.cand_rec = m.cand_rec; a.flags = b.cleanSmall ? m.flags : nullptr; a.newconf = b.cleanSmall ? m.newconf : nullptr;
+    a.cand_op = m.cand_op; a.cand_rec = m.cand_rec; a.flags = m.flags; a.newconf = m.newconf;
     a.block_counts = m.block_counts; a.host_count = m.host_count;
-    a.scan_state = m.scan_state; a.ctl = m.clean_ctl; a.epoch = b.cleanEpoch; a.ticket_lanes = b.cleanTicketLanes;
+    a.host_append = m.host_append; a.seq = m.clean_seq;
+    a.append = append; a.run_list = nullptr; a.run_count = nullptr; a.ctl = m.clean_ctl;
     return a;
 }
-__global__ __launch_bounds__(256) void k_obj_clean(const ObjBatch b) { clean_body(obj_clean_args(b, b.m[blockIdx.z])); }
-__global__ __launch_bounds__(256) void k_obj_clean_small_flags(const ObjBatch b) { clean_small_flags_body(obj_clean_args(b, b.m[blockIdx.z])); }
-__global__ __launch_bounds__(256) void k_obj_clean_small_compact(const ObjBatch b) { clean_small_compact_body(obj_clean_args(b, b.m[blockIdx.z])); }
+__global__ __launch_bounds__(256) void k_obj_clean_runs(const ObjBatch b) { clean_runs_body(obj_clean_args(b, b.m[blockIdx.z], 0)); }
+__global__ __launch_bounds__(256) void k_obj_clean_small_flags(const ObjBatch b) { clean_small_flags_body(obj_clean_args(b, b.m[blockIdx.z], b.cleanSmall ? 0 : 1)); }
+__global__ __launch_bounds__(256) void k_obj_clean_small_compact(const ObjBatch b) { clean_small_compact_body(obj_clean_args(b, b.m[blockIdx.z], b.cleanSmall ? 0 : 1)); }
 __global__ __launch_bounds__(256) void k_obj_splat_scatter(const ObjBatch b) {
     const ObjPassArgs& m = b.m[blockIdx.z];
     splat_scatter_body<4>(m.a, m.frame, m.pose, b.W, b.H, b.k, b.maxDepthProcessed, m.confThreshold, b.timeDelta, m.keys);
@@ -1570,12 +1631,11 @@ void launch_obj_fuse_clean(const ObjBatch& b, int blocks, int clean_blocks, hipS
         hipLaunchKernelGGL(k_obj_index_scatter, surfels, dim3(256), 0, s, b);   // predictIndices after fuse (MaskFusion.cpp:556): the same pass on the updated buffer
     }
     hipLaunchKernelGGL(k_obj_index_resolve_packed, dim3(resolve_tiles(b.W, b.H), 1, b.n), dim3(256), 0, s, b);
-    if (b.cleanSmall) {
-        hipLaunchKernelGGL(k_obj_clean_small_flags, dim3(kCompactBlocks, 1, b.n), dim3(256), 0, s, b);
-        hipLaunchKernelGGL(k_obj_clean_small_compact, dim3(kCompactBlocks, 1, b.n), dim3(256), 0, s, b);
-    } else {
-        hipLaunchKernelGGL(k_obj_clean, compact, dim3(256), 0, s, b);
-    }
+    // two-launch form src -> dst, or (big models) the buffer's own surfels in place, run by run -- an object model's launch visits every run: its
+    // bounding box is the box of ALL its drawn surfels -- and then the frame's candidates appended by the two-launch form
+    if (!b.cleanSmall) hipLaunchKernelGGL(k_obj_clean_runs, compact, dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_obj_clean_small_flags, dim3(kCompactBlocks, 1, b.n), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_obj_clean_small_compact, dim3(kCompactBlocks, 1, b.n), dim3(256), 0, s, b);
 }
 void launch_obj_predict_advance(const ObjBatch& b, int blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_obj_splat_scatter, dim3(blocks, 1, b.n), dim3(256), 0, s, b);

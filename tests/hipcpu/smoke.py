@@ -256,14 +256,14 @@ def host_paths(n=8, W=160, H=120):
 
 def map_forms(n=8, W=160, H=120):
     """The three size-dependent forms of a model's fuse / clean passes (mf_frame.inl: enqueue_fuse_clean; by default chosen by the map's size,
-    here forced): copy-update + two-launch clean, in-place update + two-launch clean, in-place update + one-launch clean with the decoupled
-    look-back, its run table and the culled projection passes -- and a run that changes form from frame to frame, as a map does that grows across
-    a threshold (the live buffer alternates or not, the run table comes and goes).  Same frames: poses, counts and the cloud's bytes identical."""
+    here forced): copy-update + two-launch clean, in-place update + two-launch clean, in-place update + in-place clean on the buffer's runs
+    (run table, culled projection passes, the buffer sparse) -- and a run that changes form from frame to frame, as a map does that grows across
+    a threshold (the live buffer alternates or not, the run table comes and goes, a sparse buffer is compacted).  Same frames: poses, counts and the cloud's bytes identical."""
     import hashlib
     f = 528.0 * W / 640.0
     st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
     frames = [st.frame(k) for k in range(n)]
-    forms = {"copy_two_launch": (1 << 30, 1 << 30), "in_place_two_launch": (1 << 30, 0), "in_place_one_launch": (0, 0), "changing": None}
+    forms = {"copy_two_launch": (1 << 30, 1 << 30), "in_place_two_launch": (1 << 30, 0), "in_place_runs": (0, 0), "changing": None}
     cycle = [(1 << 30, 1 << 30), (0, 0), (1 << 30, 0), (0, 0), (1 << 30, 1 << 30), (1 << 30, 0)]   # a map that crosses the thresholds from frame to frame
     out = {}
     for name, form in forms.items():
@@ -275,9 +275,9 @@ def map_forms(n=8, W=160, H=120):
             mf.setParam("inPlaceElements", in_place)
             mf.processFrame(rgb, d, timestamp=k)
             poses.append(mf.getCurrPose().reshape(-1).tolist())
+        taps = dict(visible_runs=int(mf.getParam("visibleRuns")), runs=int(mf.getParam("backgroundRuns")), clean_runs=int(mf.getParam("cleanRuns")))   # (before the download: it compacts)
         cloud = np.ascontiguousarray(mf.getBackgroundModel().downloadMap())
-        out[name] = dict(poses=poses, count=int(mf.getBackgroundModel().lastCount()), cloud_sha1=hashlib.sha1(cloud.tobytes()).hexdigest(),
-                         visible_runs=int(mf.getParam("visibleRuns")), runs=int(mf.getParam("backgroundRuns")))
+        out[name] = dict(poses=poses, count=int(mf.getBackgroundModel().lastCount()), cloud_sha1=hashlib.sha1(cloud.tobytes()).hexdigest(), **taps)
         mf.close()
     return out
 

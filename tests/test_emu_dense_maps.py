@@ -1,6 +1,6 @@
 """configs[4]'s scenario on every CPU run: the parity test of the dense-map scenario (tests/test_gpu_parity_long.py::test_config4_dense_maps) at a
 quarter of the resolution and 1 / 128 of the surfel budgets, through the product's kernels EXECUTED ON THE CPU (tests/hipcpu) with the passes of
-FULL maps forced (one-launch clean with its decoupled look-back, run table + culled projection passes, in-place update): lead-in with a dense map
+FULL maps forced (run table + culled projection passes, in-place update, in-place clean on the runs its rules can touch): lead-in with a dense map
 uploaded behind every spawn, the dense room map, then three frames against OracleMM -- model list, every model's surfel count, label image exact,
 every surfel of every model in its slot.  A subprocess, as tests/test_emu_smoke.py: nothing of the emulator leaks into this process; the parity
 claim itself rests on the -m gpu run of the same test at the budgets the reference is compiled with."""

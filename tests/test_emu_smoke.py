@@ -58,7 +58,7 @@ def test_emulated_kernels_track_and_fuse_like_the_oracle():
     for name, v in mfm.items():
         ref = mfm["copy_two_launch"]
         assert v["poses"] == ref["poses"] and v["count"] == ref["count"] and v["cloud_sha1"] == ref["cloud_sha1"], name
-    assert mfm["in_place_one_launch"]["runs"] > 0 and mfm["in_place_one_launch"]["visible_runs"] > 0     # ... and the culled passes really ran
+    assert mfm["in_place_runs"]["runs"] > 0 and mfm["in_place_runs"]["visible_runs"] > 0 and mfm["in_place_runs"]["clean_runs"] > 0   # ... and the culled passes really ran
     for size, v in res["rgb_pyramid"].items():                    # one-launch intensity pyramid + derivative / gate images == the four single kernels
         assert v["images_equal"] and v["pose_equal"] and v["cloud_equal"], (size, v)
         assert v["gate_pixels"] > 100 and v["zero_texels"] > 500, (size, v)      # ... on images that exercise the gate and the zero-skipping rule

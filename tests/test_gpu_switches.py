@@ -398,8 +398,9 @@ def test_config2_standin_maskdir_one_moving_object_gui_defaults(hip, oracle, tmp
 
 def test_run_culling_changes_nothing(hip):
     """`cullRuns` (round 5): the projection passes (index map x 2, prediction, GlobalProjection) only visit the runs of the surfel buffer whose
-    bounding box meets the viewing frustum.  On a pre-filled room map of which the camera sees a fraction, with culling on and off: poses,
-    counts, every surfel and the prediction maps bit-identical on every frame -- and the visibility list really is a fraction of the table."""
+    bounding box meets the viewing frustum; round 6: Model::clean in place only those in which one of its rules can apply (k_cull_clean).  On a
+    pre-filled room map of which the camera sees a fraction, with culling on and off: poses, counts, every surfel and the prediction maps
+    bit-identical on every frame -- and the visibility list and the clean list really are fractions of the table."""
     from maskfusion_amd import MaskFusion, synth
     W, H, f = 320, 240, 264.0
     st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
@@ -409,7 +410,7 @@ def test_run_culling_changes_nothing(hip):
     def run(cull):
         mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=False, numGSurfels=1 << 20, initConfidenceGlobal=10.0)
         mf.setParam("cullRuns", 1 if cull else 0)
-        mf.setParam("bigMapElements", 0)          # (by default only maps of >= 6 M surfels get the one-launch clean pass, its run table and the culling)
+        mf.setParam("bigMapElements", 0)          # (by default only maps of >= 6 M surfels are kept as runs: in-place clean, culled passes)
         out = []
         for k, (rgb, d, _) in enumerate(frames):
             mf.processFrame(rgb, d, timestamp=k)
@@ -417,14 +418,17 @@ def test_run_culling_changes_nothing(hip):
                 mf.getBackgroundModel().uploadMap(room)
             bg = mf.getBackgroundModel()
             out.append(dict(pose=mf.getCurrPose(), count=bg.lastCount(), pv=bg.debugRead("pred_vertex"), pi=bg.debugRead("pred_image")))
+        vis, runs, cleaned = mf.getParam("visibleRuns"), mf.getParam("backgroundRuns"), mf.getParam("cleanRuns")   # (before the download: it compacts the buffer)
         cloud = mf.getBackgroundModel().downloadMap()
-        vis, runs = mf.getParam("visibleRuns"), mf.getParam("backgroundRuns")
         mf.close()
-        return out, cloud, vis, runs
+        return out, cloud, vis, runs, cleaned
 
-    (a, ca, vis, runs), (b, cb, _, _) = run(True), run(False)
-    print("visible runs", vis, "of", runs)
+    (a, ca, vis, runs, cleaned), (b, cb, _, _, _) = run(True), run(False)
+    print("visible runs", vis, "of", runs, "-- runs the in-place clean visited:", cleaned)
     assert 0 < vis < 0.6 * runs and runs >= 600_000 / 512
+    # Model::clean in place: the runs in view (no far limit) + those holding young unstable surfels (the visibility list is the prediction's, taken
+    # after the frame's new surfels were appended: a few runs more)
+    assert vis - 8 <= cleaned < 0.7 * runs
     for k, (x, y) in enumerate(zip(a, b)):
         assert x["count"] == y["count"] and np.array_equal(x["pose"], y["pose"]), k
         assert np.array_equal(x["pv"], y["pv"], equal_nan=True) and np.array_equal(x["pi"], y["pi"]), k
@@ -435,10 +439,11 @@ def test_run_culling_changes_nothing(hip):
 def test_clean_forms_agree(hip, multi):
     """A model's fuse / clean passes take one of three forms by its size (mf_frame.inl: enqueue_fuse_clean): below `inPlaceElements` update.vert
     as a copy with the second index scatter riding on it + Model::clean in two launches over a static partition; from there to
-    `bigMapElements` update.vert in place + the two-launch clean; above, update.vert in place + clean in one launch with a decoupled look-back
-    (which also writes the run table the projection passes cull by).  The same frames through all three: model list, counts, every surfel
-    of every model in its slot, poses and label images bit-identical -- single model, and background + object models (whose passes are
-    batched: one launch per pass for all of them) --, and through a run that changes form from frame to frame."""
+    `bigMapElements` update.vert in place + the two-launch clean; above, update.vert in place + clean IN PLACE on the buffer's runs (round 6:
+    k_cull_clean + k_clean_runs, the frame's new surfels appended; the buffer becomes sparse and is read through its run table).  The same
+    frames through all three: model list, counts, every surfel of every model in its slot, poses and label images bit-identical -- single
+    model, and background + object models (whose passes are batched: one launch per pass for all of them) --, and through a run that
+    changes form from frame to frame (a sparse buffer is compacted on its way back to the small forms)."""
     from maskfusion_amd import MaskFusion, synth
     W, H, f = 320, 240, 264.0
     st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True, n_objects=3 if multi else 0, object_motion=0.0)
@@ -478,6 +483,97 @@ def test_clean_forms_agree(hip, multi):
             assert len(pa) == len(pb) and all(np.array_equal(x, y) for x, y in zip(pa, pb))
         for x, y in zip(a["clouds"], b["clouds"]):
             assert np.array_equal(x, y, equal_nan=True)
+
+
+@pytest.mark.parametrize("multi", [False, True], ids=["single-model", "multi-model"])
+def test_in_place_clean_compaction_paths(hip, multi):
+    """Model::clean in place appends a frame's new surfels behind the buffer's last run and leaves holes inside the runs that lose surfels; the
+    host compacts the buffer when its bounds on the used slots / table entries run out (mf_frame.inl: prepare_in_place), and a map within a
+    frame's candidates of its capacity takes the two-launch form, whose ordered copy stops at the capacity like the reference's transform
+    feedback.  A background map that grows INTO its capacity (320 x 240: 19 200 candidates per frame against 102 400 slots; 80 k surfels loaded
+    behind the first frame) goes through all of that: in place until the slots behind the last run could run out, a compaction, in place again,
+    then the near-full regime.  Against the small-map forms on the same frames, and with a compaction forced on every frame: counts and poses
+    on every frame, every surfel of every model in its slot bit-identical."""
+    from maskfusion_amd import MaskFusion, synth
+    W, H, f = 320, 240, 264.0
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True, n_objects=3 if multi else 0, object_motion=0.0)
+    frames = [st.frame(k) for k in range(26)]
+    room = synth.dense_room_map(st.scene, 80_000, last_time=1.0)
+
+    def run(big, every=0):
+        mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=multi, numGSurfels=1 << 17, numOSurfels=1 << 15,
+                        modelSpawnOffset=2, trackAllModels=False, initConfidenceGlobal=10.0, initConfidenceObject=0.01)
+        if multi:
+            for k, v in (("mfThreshold", 0.3), ("mfWeightDistance", 150.0), ("mfWeightConvexity", 2.8), ("mfMorphEdgeIterations", 0),
+                         ("mfMorphMaskIterations", 0), ("newModelMinRelativeSize", 0.004)):
+                mf.setParam(k, v)
+        mf.setParam("bigMapElements", big)
+        mf.setParam("inPlaceElements", big)
+        mf.setParam("densifyEvery", every)
+        per_frame = []
+        for k, (rgb, d, m) in enumerate(frames):
+            mf.processFrame(rgb, d, mask=m if multi else None, classIDs=[0, 41, 42, 43] if multi else (), timestamp=k)
+            if k == 0:
+                mf.getBackgroundModel().uploadMap(room)
+            per_frame.append(([x.getID() for x in mf.getModels()], [x.lastCount() for x in mf.getModels()], [x.getPose() for x in mf.getModels()]))
+        compactions = mf.getParam("densifyCount")
+        clouds = [x.downloadMap() for x in mf.getModels()]
+        mf.close()
+        return per_frame, clouds, compactions
+
+    (pa, ca, na), (pb, cb, nb), (pc, cc, nc) = run(0), run(1 << 30), run(0, every=1)
+    print("compactions: in place", na, "-- small forms", nb, "-- in place, forced every frame", nc, "; final counts", pa[-1][1])
+    assert nb == 0 and na >= 1 and nc > na
+    assert pa[-1][1][0] + (W // 2) * (H // 2) > (64 * int(np.sqrt(float(1 << 17)) / 64)) ** 2       # the background ended within a frame's candidates of its capacity
+    for other, clouds in ((pb, cb), (pc, cc)):
+        for k, ((ia, na_, qa), (ib, nb_, qb)) in enumerate(zip(pa, other)):
+            assert ia == ib and na_ == nb_, (k, ia, ib, na_, nb_)
+            assert all(np.array_equal(x, y) for x, y in zip(qa, qb)), k
+        assert len(ca) == len(clouds)
+        for x, y in zip(ca, clouds):
+            assert np.array_equal(x, y, equal_nan=True)
+
+
+def test_in_place_clean_first_surfel_rule(hip):
+    """The first surfel of a buffer is vertex 0, which the index map cannot tell from "no surfel" (index_map.frag writes the vertex id into a texture
+    cleared to 0; data.vert / copy_unstable.vert test `> 0`): it occludes but is never merged into and never counted in Model::clean's window.
+    In a sparse buffer that surfel is the first live slot (FrameDev::first), and it moves when the first run loses surfels or empties.  A map
+    whose first 700 surfels (more than a run) are unstable, out of view, and die by the age rule in the first frame, followed by surfels in
+    view: in place against the small-map forms, every frame's count and pose, every surfel in its slot."""
+    from maskfusion_amd import MaskFusion, synth
+    W, H, f = 320, 240, 264.0
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
+    frames = [st.frame(k) for k in range(6)]
+    room = synth.dense_room_map(st.scene, 150_000, last_time=40.0)
+    z = room[:, 2]
+    u, v = f * room[:, 0] / np.maximum(z, 1e-3) + W / 2.0, f * room[:, 1] / np.maximum(z, 1e-3) + H / 2.0
+    inview = (z > 0.3) & (u > 8) & (u < W - 8) & (v > 8) & (v < H - 8)
+    out = room[~inview]
+    room = np.concatenate([out[:700], room[inview], out[700:]])    # 700 surfels out of view (nothing merges into them), then the part in view
+    room[:700, 3] = 1.0            # unstable (confidence threshold 10) ...
+    room[:700, 7] = 10.0           # ... and last seen 31 frames before tick 41: dropped by the age rule (copy_unstable.vert:118-125)
+
+    def run(big):
+        mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=False, numGSurfels=1 << 20, initConfidenceGlobal=10.0)
+        mf.setParam("bigMapElements", big)
+        mf.setParam("inPlaceElements", big)
+        mf.processFrame(*frames[0][:2], timestamp=0)
+        mf.getBackgroundModel().uploadMap(room)
+        mf.setTick(41)
+        out = []
+        for k, (rgb, d, _) in enumerate(frames[1:]):
+            mf.processFrame(rgb, d, timestamp=k + 1)
+            out.append((mf.getBackgroundModel().lastCount(), mf.getCurrPose()))
+        cloud = mf.getBackgroundModel().downloadMap()
+        mf.close()
+        return out, cloud
+
+    (a, ca), (b, cb) = run(0), run(1 << 30)
+    print("counts", [n for n, _ in a], "of", len(room), "uploaded")
+    assert a[0][0] < len(room) - 300            # the unstable head is gone after the first frame (a few hundred new surfels came in)
+    for k, ((na, pa), (nb, pb)) in enumerate(zip(a, b)):
+        assert na == nb and np.array_equal(pa, pb), (k, na, nb)
+    assert np.array_equal(ca, cb, equal_nan=True)
 
 
 @pytest.mark.parametrize("size", [(640, 480), (200, 152)], ids=["vga", "200x152"])

@@ -23,7 +23,7 @@ W, H = 240, 160
 f = 528.0 * W / 640.0
 st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
 mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=20.0, so3=True, enableMultipleModels=False, numGSurfels=1 << 17)
-if os.environ.get("MF_BIG_FORMS") == "1":   # the passes of full maps (one-launch clean with its look-back, run table + culling, in-place update) on these small ones
+if os.environ.get("MF_BIG_FORMS") == "1":   # the passes of full maps (run table + culling, in-place update, in-place clean) on these small ones
     mf.setParam("bigMapElements", 0); mf.setParam("inPlaceElements", 0)
 for k in range(6):
     rgb, d, _ = st.frame(k)
