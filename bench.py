@@ -58,7 +58,7 @@ CONFIGS = {
               workload="configs[4] on one GPU (SURVEY.md 8d S3): synthetic 1280x960 RGB-D stream with 4 instance-masked objects, MASKFUSION_NUM_GSURFELS=32M / "
                        "NUM_OSURFELS=4M, every map pre-filled to >= 80 % of its capacity (26.5 M background surfels, 3.4 M per object model: generated on "
                        "the scene's surfaces and loaded with Model.uploadMap, maskfusion_amd/stress.py), icpWeight=100, global projection + label stage + "
-                       "per-model fusion; the objects stand and follow the camera (trackAllModels off)"),
+                       "per-model fusion"),
     "4n": dict(W=1280, H=960, f=1056.0, surfels=32 * 1024 * 1024, n_objects=0, frames=200,
                workload="1280x960 stream, natural map: synthetic 1280x960 RGB-D stream (S3 scaling of S1), 1 background model, NUM_GSURFELS=32M budget "
                         "(the map grows to its natural size, ~1.4 M surfels), icpWeight=100 + surfel fusion, empty masks"),
@@ -477,27 +477,37 @@ class RoomMapJob:
         return m
 
 
-# SURVEY.md 8d contract bytes of the surfel half, per surfel (N = live surfels of the model) and per pixel (P), by kernel: one read-modify-write
-# (update + clean) 96 B/surfel and two projections of 48 B/surfel each; image-side outputs 52 P per index map, 38 P for the prediction.
-C4_KERNEL_BYTES = {
-    "k_index_scatter": lambda N, P: 48.0 * N,                    # a projection of the surfel stream (the pre-fusion index map; the post-fusion one is the same kernel)
-    "k_index_resolve_transposing": lambda N, P: 52.0 * P,        # ... its image-side outputs (column-major keys -> row-major maps, through the LDS)
-    "k_index_resolve_packed": lambda N, P: 52.0 * P,             # ... and those of the post-fusion pass (column-major keys -> the packed column-major map)
-    "k_clean": lambda N, P: 96.0 * N,                            # THE read-modify-write of the frame (update + clean): read 48 + write 48; update.vert itself runs
-                                                                 # in place on the merged surfels only (k_fuse_update, no N-sized traffic)
-    "k_splat_bin": lambda N, P: 48.0 * N,                        # a projection of the surfel stream (prediction; GlobalProjection's is the same kernel)
-    "k_splat_tile": lambda N, P: 38.0 * P,                       # ... its image-side outputs
+# SURVEY.md 8d contract bytes of the surfel half per PASS (mf_get_pass_timings: the passes as the driver run itself times them, HIP events around each
+# pass's launches): one read-modify-write (update + clean) 96 B/surfel and two projections of 48 B/surfel each per model and frame (+ GlobalProjection's
+# 48 B/surfel); image-side outputs 52 P per index map, 38 P for the prediction.  N: surfels of the model(s) the pass serves, V: surfels of the runs
+# the pass actually VISITS (the buffer is kept as runs of <= 512 surfels, Surfels::box: the projection passes visit the runs k_cull lists, Model::clean
+# in place those k_cull_clean lists) -- `visited_bytes` is what a roofline fraction is taken over, `contract_bytes` what the reference's dataflow moves.
+C4_PASS_BYTES = {
+    "bgGlobalProjection": lambda N, V, P, n: (48.0 * N, 48.0 * V),
+    "bgIndexMap": lambda N, V, P, n: (48.0 * N + 52.0 * P, 48.0 * V + 52.0 * P),
+    "bgFuseData": lambda N, V, P, n: (P / 4 * 48.0 + 27.0 * 36.0 * P / 4, P / 4 * 48.0 + 27.0 * 36.0 * P / 4),     # candidates: 48 B records + the 27 window taps of 36 B
+    "bgFuseUpdate": lambda N, V, P, n: (48.0 * N, 0.0),                            # update.vert: the reference copies the buffer; here only merged surfels move
+    "bgIndexMap2": lambda N, V, P, n: (48.0 * N + 52.0 * P, 48.0 * V + 52.0 * P),
+    "bgClean": lambda N, V, P, n: (96.0 * N, 48.0 * V),                            # THE read-modify-write of the frame; in place: the listed runs are read, what changes is written
+    "bgAppend": lambda N, V, P, n: (0.0, P / 4 * 48.0),
+    "bgPredict": lambda N, V, P, n: (48.0 * N + 38.0 * P, 48.0 * V + 38.0 * P),
+    "objGlobalProjection": lambda N, V, P, n: (48.0 * N, 48.0 * V),
+    "objFuseClean": lambda N, V, P, n: (192.0 * N + 104.0 * P * n, 192.0 * V + 104.0 * P * n),
+    "objPredict": lambda N, V, P, n: (48.0 * N + 38.0 * P * n, 48.0 * V + 38.0 * P * n),
 }
+C4_BG_LISTS = {"bgGlobalProjection": "visible", "bgIndexMap": "visible", "bgIndexMap2": "visible", "bgPredict": "visible", "bgClean": "clean"}
 
 
-def config4_scene(local_rank, frames, room_job, seconds=2.0, frames_per_rep=30, stages_frames=10, params=(), max_reps=64):
+def config4_scene(local_rank, frames, room_job, seconds=2.0, frames_per_rep=30, stages_frames=10, params=(), max_reps=64, tracked=True):
     """The dense configs[4] scenario on one GPU.  One repetition = a fresh context taken through the lead-in and the map uploads of
     maskfusion_amd/stress.py (untimed), 4 untimed frames, then `frames_per_rep` timed frames over device-resident inputs (ping-ponged)
-    between two synchronisations.  The timed window is short on purpose: the scene is not stationary -- over hundreds of frames
-    Model::clean's mask-disagreement decay (copy_unstable.vert:139-156) thins the object maps out and the label stage spawns further models
-    -- and the figure is meant for maps that ARE >= 80 % full.  Repetitions are added until `seconds` of timed frames have run.  The last
-    repetition is followed by an instrumented pass (stage timings); per-kernel roofline rows come from the newest committed rocprofv3 summary
-    of this scenario (profiles/r*_c4_kernel_stats.csv), each with its SURVEY.md 8d contract bytes."""
+    between two synchronisations.  tracked (S3 as SURVEY.md 8d defines it: "S2 with 4 objects", and S2 tracks every model): after the lead-in every
+    object model is made non-static -- each frame then runs FIVE Gauss-Newton loops (the batched kernels) before its surfel passes.  The timed
+    window is short on purpose: the scene is not stationary -- over hundreds of frames Model::clean's mask-disagreement decay
+    (copy_unstable.vert:139-156) thins the object maps out and the label stage spawns further models -- and the figure is meant for maps that ARE
+    >= 80 % full.  Repetitions are added until `seconds` of timed frames have run.  The last repetition is followed by an instrumented pass of
+    `stages_frames` frames IN THIS RUN: stage timings (mf_get_timings) and the surfel passes one by one (mf_get_pass_timings), each with its SURVEY.md 8d
+    contract bytes and the bytes of the runs it visited."""
     import torch
     from maskfusion_amd import stress
     dev = torch.device("cuda", local_rank)
@@ -515,6 +525,8 @@ def config4_scene(local_rank, frames, room_job, seconds=2.0, frames_per_rep=30, 
         t0 = time.perf_counter()
         k0, loaded = stress.lead_in(mf, st, frames, cls, n_objects=4, max_frames=C4_LEAD_IN, room_map=room,
                                     log=(lambda m: print("[bench c4] " + m, file=sys.stderr)) if reps == 1 else None)
+        if tracked:
+            stress.track_objects(mf)
         mf.sync()
         t_setup += time.perf_counter() - t0
         if d is None:
@@ -543,17 +555,27 @@ def config4_scene(local_rank, frames, room_job, seconds=2.0, frames_per_rep=30, 
         if dt >= seconds or reps >= max_reps:
             break
         mf.close()
+    models_timed = len(mf.getModels())
+    compactions = mf.getParam("densifyCount")
     mf.enableTimings(True)
-    acc = {}
+    mf.setParam("passTimings", 1)
+    acc, pacc, lists = {}, {}, {"visible": 0.0, "clean": 0.0, "table": 0.0}
     for _ in range(stages_frames):
         step()
         for kx, v in mf.timings().items():
             acc[kx] = acc.get(kx, 0.0) + v
+        for kx, v in mf.passTimings().items():
+            pacc[kx] = pacc.get(kx, 0.0) + v
+        lists["visible"] += mf.getParam("visibleRuns"); lists["clean"] += mf.getParam("cleanRuns"); lists["table"] += mf.getParam("backgroundRuns")
     mf.enableTimings(False)
+    mf.setParam("passTimings", 0)
     stages = {kx: v / stages_frames for kx, v in acc.items()}
+    passes = {kx: v / stages_frames for kx, v in pacc.items()}
+    lists = {kx: v / stages_frames for kx, v in lists.items()}
     models = mf.getModels()
     counts = [m.lastCount() for m in models]
     ids = [m.getID() for m in models]
+    n_nonstatic = sum(1 for m in models[1:] if m.isNonstatic())
     drift = float(np.linalg.norm(mf.getCurrPose()[:3, 3] - st.gt_pose(k0 + order[(pos - 1) % len(order)])[:3, 3]))
     caps = [stress.surfel_capacity(stress.NUM_GSURFELS)] + [stress.surfel_capacity(stress.NUM_OSURFELS)] * (len(counts) - 1)
     mf.close()
@@ -561,27 +583,38 @@ def config4_scene(local_rank, frames, room_job, seconds=2.0, frames_per_rep=30, 
     P = stress.W * stress.H
     ms = 1e3 * dt / steps
     N_bg, N_all = fills_start[0], sum(fills_start)
-    frame_bytes = 741.0 * P + 192.0 * N_all            # one tracked model (the background) + the surfel half of every model
-    rows = rocprof_rows(list(C4_KERNEL_BYTES), pattern="r*_c4_kernel_stats.csv")
-    levels = None
-    if rows:
-        levels = {}
-        for nm, r in rows.items():
-            b = C4_KERNEL_BYTES[nm](N_bg, P)
-            levels[nm] = dict(r, contract_bytes=b, frac=b / (r["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                              note="background model's launch (N = %d): contract bytes of SURVEY.md 8d over the average duration of the launches of this "
-                                   "name on the full map in the named summary (`us`); with run culling (Surfels::box, k_cull) a projection pass "
-                                   "visits ~22 %% of the buffer, so its rate in contract bytes can exceed the HBM peak -- the HBM bytes per launch are "
-                                   "in profiles/r05_c4_hbm.json; the object models' batched passes are the k_obj_* rows of the same file" % N_bg)
-    return {"workload": CONFIGS["4"]["workload"], "value": steps / dt, "unit": "frames/s", "ms_per_step": ms, "steps": steps, "repetitions": reps,
-            "frames_per_repetition": frames_per_rep, "models": len(counts), "model_ids": ids, "surfels_at_start": fills_start, "surfels_at_end": counts,
+    n_tracked = 1 + (len(fills_start) - 1 if tracked else 0)
+    frame_bytes = 741.0 * P * n_tracked + 192.0 * N_all            # every tracked model's odometry + the surfel half of every model
+    rows = {}
+    N_obj, n_obj = sum(counts[1:]), len(counts) - 1
+    for name, ms_p in passes.items():
+        if name not in C4_PASS_BYTES or ms_p <= 0.0:
+            continue
+        bg = name.startswith("bg")
+        N = counts[0] if bg else N_obj
+        V = min(N, 512.0 * lists[C4_BG_LISTS[name]]) if name in C4_BG_LISTS else N      # object models: every run is visited
+        contract, visited = C4_PASS_BYTES[name](N, V, P, n_obj)
+        rows[name] = {"ms": ms_p, "contract_bytes": contract, "visited_bytes": visited, "achieved_GBps": visited / (ms_p * 1e-3) / 1e9,
+                      "frac": visited / (ms_p * 1e-3) / 1e9 / HBM_PEAK_GBS, "contract_GBps": contract / (ms_p * 1e-3) / 1e9}
+    return {"workload": CONFIGS["4"]["workload"] + ("; the four object models TRACKED (non-static: five Gauss-Newton loops per frame)" if tracked else
+                                                    "; the objects stand and follow the camera (static)"),
+            "value": steps / dt, "unit": "frames/s", "ms_per_step": ms, "steps": steps, "repetitions": reps,
+            "frames_per_repetition": frames_per_rep, "models": len(counts), "models_through_the_timed_window": models_timed, "model_ids": ids,
+            "tracked_models": 1 + n_nonstatic, "surfels_at_start": fills_start, "surfels_at_end": counts,
             "fill_at_start": [c / cap for c, cap in zip(fills_start, caps)], "fill_at_end": [c / cap for c, cap in zip(counts, caps)],
-            "pose_drift_vs_gt_m": drift, "setup_seconds": t_setup, "lead_in_frames": k0, "stage_ms": stages,
+            "pose_drift_vs_gt_m": drift, "setup_seconds": t_setup, "lead_in_frames": k0, "stage_ms": stages, "compactions": compactions,
             "roofline_frame": {"bound": "hbm", "algorithmic_bytes": frame_bytes, "ms": ms, "achieved": frame_bytes / (ms * 1e-3) / 1e9,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frame_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               "note": "(741 P for the tracked background + 192 N over every model's surfels at the start of the timed window) bytes per "
-                                       "frame, SURVEY.md 8d"},
-            "roofline_kernels": levels}
+                               "note": "(741 P per tracked model (%d) + 192 N over every model's surfels at the start of the timed window) bytes per "
+                                       "frame, SURVEY.md 8d" % n_tracked},
+            "runs": {"background_table": lists["table"], "visible": lists["visible"], "clean_in_place": lists["clean"],
+                     "note": "runs of <= 512 surfels (Surfels::box): of the background's table / on the visibility list of its projection passes / "
+                             "visited by its in-place clean pass; averages over the instrumented frames"},
+            "roofline_passes": {"source": "mf_get_pass_timings in THIS run: HIP events around each pass's launches, mean of %d frames" % stages_frames,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "passes": rows,
+                                "note": "frac = visited_bytes / time / peak: the bytes of the surfels in the runs the pass visits (48 B each; the passes "
+                                        "of the object models visit every run) + its image-side bytes; contract_bytes: SURVEY.md 8d's figure for the "
+                                        "reference's dataflow, which streams every buffer whole"}}
 
 
 def small_variant(cfg_key, local_rank, frames, n_timed, warm):
@@ -633,7 +666,7 @@ def run_config4(args, local_rank, frames, room_job):
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path)")
-    res = config4_scene(local_rank, frames, room_job, seconds=args.min_seconds, frames_per_rep=max(10, min(args.steps, 60)),
+    res = config4_scene(local_rank, frames, room_job, seconds=args.min_seconds, frames_per_rep=max(10, min(args.steps, 60)), tracked=not args.static_objects,
                         params=[tuple((kv.partition("=")[0], float(kv.partition("=")[2]))) for kv in args.param])
     out = {"metric": f"frames/sec (1280x960 RGB-D, background + {res['models'] - 1} object models, 32M / 4M surfel budgets filled >= 80 %, ICP + surfel fusion)",
            "value": res["value"], "unit": "frames/s", "n_gpus": 1, "steps": res["steps"], "steps_requested": args.steps, "warmup": 4,
@@ -644,7 +677,8 @@ def run_config4(args, local_rank, frames, room_job):
                       "repetitions": res["repetitions"], "frames_per_repetition": res["frames_per_repetition"],
                       "pose_drift_vs_gt_m": res["pose_drift_vs_gt_m"], "parallelism": "one context, one GPU",
                       **({"params": {kv.partition("=")[0]: float(kv.partition("=")[2]) for kv in args.param}} if args.param else {})},
-           "roofline": None, "roofline_frame": res["roofline_frame"], "roofline_kernels": res["roofline_kernels"], "stage_ms": res["stage_ms"],
+           "roofline": None, "roofline_frame": res["roofline_frame"], "roofline_passes": res["roofline_passes"], "runs": res["runs"], "stage_ms": res["stage_ms"],
+           "compactions": res["compactions"], "tracked_models": res["tracked_models"],
            "setup_seconds": res["setup_seconds"], "host_input": None, "cpu_baseline": None, "ranks_seen": ranks_seen(1, local_rank)}
     print(json.dumps(out))
 
@@ -667,6 +701,8 @@ def main():
     ap.add_argument("--param", action="append", default=[], metavar="KEY=VALUE",
                     help="mf_set_param(KEY, VALUE) on the context before the run (A/B of implementation switches, e.g. persistentIcp=1); "
                          "recorded in config.params")
+    ap.add_argument("--static-objects", action="store_true", help="config 4: the object models stand and follow the camera (rounds 4-5's scenario) instead of "
+                                                                  "being tracked (S3 as SURVEY.md 8d defines it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host-input", action="store_true")

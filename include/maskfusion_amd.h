@@ -170,7 +170,7 @@ int mf_get_last_fillin(mf_ctx* ctx, int32_t* used);
  * "splatTiles" (1), "globalTiles" (1: GlobalProjection of the background through tile lists), "gpuLabels" (1: label stage on the
  * device), "batchTracking" (1: one Gauss-Newton launch serves every tracked model), "earlyBackgroundFusion" (1),
  * "cleanLiteralWindow" (1: Model::clean walks its window with copy_unstable.vert's own fp32 trip count, 4 or 5 taps per axis;
- * 0: 4 x 4), "timings", "icpProfile", "objectSmallGrids" (1; 1: the grid-stride
+ * 0: 4 x 4), "timings", "passTimings" (mf_get_pass_timings), "icpProfile", "objectSmallGrids" (1; 1: the grid-stride
  * surfel kernels of an object model run on a grid sized from its last known surfel count instead of 2048 workgroups), "objectScatterSplat" (1;
  * 1: object models are predicted with the scatter form of the splat instead of tile lists) -- both leave every result bit-identical; measured on
  * MI355X on the 12-model S2 scene: 394 -> 407 frames/s with both (profiles/r03a_bench_2s_object_switches.txt), on since round 3;
@@ -221,6 +221,23 @@ int mf_get_param(mf_ctx* ctx, const char* key, double* value);
  *         17 mmHostWaitMs (HOST wall-clock milliseconds spent in the event wait behind the label stage) */
 #define MF_N_TIMINGS 18
 int mf_get_timings(mf_ctx* ctx, float* ms /* [MF_N_TIMINGS] */);
+/* The surfel passes of the last frame one by one (Core/Model/Model.cpp:466-772, ModelProjection.cpp:100-268, GlobalProjection.cpp:43-107): GPU
+ * milliseconds between two HIP events recorded around each pass's launches, enabled by mf_set_param("passTimings", 1).  `bg`: the background
+ * model (or any model handled on its own); `obj`: every object model, one launch per pass for all of them.
+ *   0 bgGlobalProjection   k_cull + k_splat_bin + k_global_tile
+ *   1 bgIndexMap           k_cull (if not shared) + k_index_scatter + resolve: predictIndices before fuse
+ *   2 bgFuseData           k_fuse_data: association
+ *   3 bgFuseUpdate         k_fuse_update[_copy]: update.vert
+ *   4 bgIndexMap2          k_index_scatter + packed resolve: predictIndices after fuse (rides on the copy-update of small maps)
+ *   5 bgClean              Model::clean of the buffer's own surfels: k_cull_clean + k_clean_runs (in place) / the two-launch form (everything)
+ *   6 bgAppend             ... and of the frame's candidates, appended (in-place form only)
+ *   7 bgPredict            combinedPredict: k_cull + k_splat_bin + k_splat_tile (+ the end-of-frame bookkeeping)
+ *   8 objGlobalProjection  9 objFuseClean (predictIndices, fuse, predictIndices, clean)   10 objPredict
+ *   11 compaction          launch_densify + the run table of the compacted buffer (0 in a frame without one) */
+#define MF_N_PASSES 12
+enum { MF_PASS_BG_GLOBAL = 0, MF_PASS_BG_INDEX, MF_PASS_BG_FUSE_DATA, MF_PASS_BG_FUSE_UPDATE, MF_PASS_BG_INDEX2, MF_PASS_BG_CLEAN, MF_PASS_BG_APPEND,
+       MF_PASS_BG_PREDICT, MF_PASS_OBJ_GLOBAL, MF_PASS_OBJ_FUSE_CLEAN, MF_PASS_OBJ_PREDICT, MF_PASS_COMPACTION };
+int mf_get_pass_timings(mf_ctx* ctx, float* ms /* [MF_N_PASSES] */);
 /* The context's HIP stream (hipStream_t), for callers that time with their own events. */
 void* mf_get_stream(mf_ctx* ctx);
 /* Stream on which rgb/depth/mask handed to mf_process_frame_dev are first read: the context's stream (mf_get_stream) -- producers ordered on

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import numpy as np
 
-from .lib import load, MFError, Config, ModelInfo, MF_N_TIMINGS, TIMING_LABELS
+from .lib import load, MFError, Config, ModelInfo, MF_N_TIMINGS, TIMING_LABELS, MF_N_PASSES, PASS_LABELS
 
 
 class Model:
@@ -339,6 +339,12 @@ class MaskFusion:
         t = np.zeros(MF_N_TIMINGS, np.float32)
         self._chk(self._L.mf_get_timings(self._h, t.ctypes.data))
         return dict(zip(TIMING_LABELS, t.tolist()))
+
+    def passTimings(self) -> dict:
+        """GPU milliseconds of the surfel passes of the last frame, pass by pass (setParam("passTimings", 1); labels: maskfusion_amd.h MF_PASS_*)"""
+        t = np.zeros(MF_N_PASSES, np.float32)
+        self._chk(self._L.mf_get_pass_timings(self._h, t.ctypes.data))
+        return dict(zip(PASS_LABELS, t.tolist()))
 
     def stream(self) -> int:
         return int(self._L.mf_get_stream(self._h) or 0)

@@ -262,6 +262,12 @@ struct mf_ctx {
     hipEvent_t ev_mm[5] = {};                    // multi-model frame: after global projection | label stage | background fuse+clean | first object pass | (spare)
     bool mm_marked = false; float mm_host_wait_ms = 0.f;
     hipEvent_t ev_icp[2] = {nullptr, nullptr};   // first / after-last Gauss-Newton launch of the background model
+    // "passTimings": GPU milliseconds of the surfel passes of the last frame, pass by pass (mf_get_pass_timings; labels in maskfusion_amd.h) -- an
+    // event pair around each, created on first use; what bench.py's configs[4] line builds its per-pass roofline rows from IN THE TIMED RUN
+    bool pass_timings_on = false;
+    hipEvent_t ev_pass[MF_N_PASSES][2] = {};
+    bool pass_recorded[MF_N_PASSES] = {};
+    float pass_ms[MF_N_PASSES] = {};
     hipEvent_t ev_icp_mid = nullptr;             // ... and right before its first level-0 iteration (coarse levels | level 0)
     bool icp_mid_recorded = false;
     float last_ms[MF_N_TIMINGS] = {};
@@ -595,8 +601,10 @@ extern "C" void mf_destroy(mf_ctx* c) {
     for (void* p : c->host_allocs) (void)hipHostFree(p);
     for (int i = 0; i <= MF_N_TIMINGS; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
         if (c->ev_icp[i]) (void)hipEventDestroy(c->ev_icp[i]);
+        for (int q = 0; q < MF_N_PASSES; ++q) if (c->ev_pass[q][i]) (void)hipEventDestroy(c->ev_pass[q][i]);
+    }
     if (c->ev_icp_mid) (void)hipEventDestroy(c->ev_icp_mid);
     for (int i = 0; i < 5; ++i)
         if (c->ev_mm[i]) (void)hipEventDestroy(c->ev_mm[i]);
@@ -978,6 +986,11 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!c || !key) return MF_EINVAL;
     if (!strcmp(key, "hostProfileReset")) { for (double& v : c->host_us) v = 0; c->host_calls = 0; return MF_OK; }
     if (!strcmp(key, "timings")) { c->timings_on = value != 0; return MF_OK; }
+    if (!strcmp(key, "passTimings")) {
+        c->pass_timings_on = value != 0;
+        for (int q = 0; q < MF_N_PASSES; ++q) { c->pass_recorded[q] = false; c->pass_ms[q] = 0.f; }
+        return MF_OK;
+    }
     if (!strcmp(key, "icpProfile")) { c->icp_prof_on = value != 0; return MF_OK; }
     if (!strcmp(key, "hostInputAsync")) {   // 0: mf_process_frame blocks until the frame is fused (rounds 1-3); 1: returns when it is enqueued
         if (hipStreamSynchronize(c->stream) != hipSuccess || hipStreamSynchronize(c->stream_in) != hipSuccess) return MF_EHIP;
@@ -1089,6 +1102,13 @@ extern "C" int mf_get_timings(mf_ctx* c, float* ms) {
     int rc = mf_sync(c);
     if (rc != MF_OK) return rc;
     memcpy(ms, c->last_ms, sizeof(c->last_ms));
+    return MF_OK;
+}
+extern "C" int mf_get_pass_timings(mf_ctx* c, float* ms) {
+    if (!c || !ms) return MF_EINVAL;
+    int rc = mf_sync(c);
+    if (rc != MF_OK) return rc;
+    memcpy(ms, c->pass_ms, sizeof(c->pass_ms));
     return MF_OK;
 }
 extern "C" void* mf_get_stream(mf_ctx* c) { return c ? (void*)c->stream : nullptr; }

@@ -6,6 +6,22 @@
 static void mark(mf_ctx* c, int i, hipStream_t s = nullptr) {
     if (c->timings_on) (void)hipEventRecord(c->ev[i], s ? s : c->stream);
 }
+// "passTimings": an event pair around the launches of one surfel pass (labels: maskfusion_amd.h, MF_PASS_*); a pass that runs several times in a
+// frame (object models handled one by one) keeps its last run
+struct PassTimer {
+    mf_ctx* c; int id;
+    PassTimer(mf_ctx* c_, int id_) : c(c_), id(id_) {
+        if (!c->pass_timings_on || id < 0) return;
+        for (int q = 0; q < 2; ++q)
+            if (!c->ev_pass[id][q] && hipEventCreate(&c->ev_pass[id][q]) != hipSuccess) { (void)hipGetLastError(); c->ev_pass[id][q] = nullptr; }
+        if (c->ev_pass[id][0]) (void)hipEventRecord(c->ev_pass[id][0], c->stream);
+    }
+    ~PassTimer() {
+        if (!c->pass_timings_on || id < 0 || !c->ev_pass[id][0] || !c->ev_pass[id][1]) return;
+        (void)hipEventRecord(c->ev_pass[id][1], c->stream);
+        c->pass_recorded[id] = true;
+    }
+};
 
 // ------------------------------------------------------------------------------------------------
 // per-model stages
@@ -231,6 +247,7 @@ static int prepare_in_place(mf_ctx* c, ModelState& m, bool& ok) {
             rub = std::min(rub, (long)((v >> kAppendPhysBits) & ((1ull << kAppendRunBits) - 1ull)) + (long)behind * nr);
         }
     }
+    PassTimer timer(c, (m.sparse || !m.table_valid) ? MF_PASS_COMPACTION : -1);
     if (pub < 0 || pub + cm > (long)m.cap || rub + nr > table) {
         require_dense(c, m);
         MF_HIP(c, hipStreamSynchronize(c->stream));
@@ -265,12 +282,16 @@ static CleanIn clean_in(mf_ctx* c, ModelState& m, int time_delta, bool packed, c
 // Model::clean of m in place (m has a run table): the buffer's own surfels run by run, then the frame's candidates appended.  cull: visit only the
 // runs in which a rule of the pass can apply (k_cull_clean; needs the decay statistics of THIS frame's packed resolve pass) -- the background;
 // an object model's launch visits every run (its bounding box is the box of all its drawn surfels)
-static void enqueue_clean_in_place(mf_ctx* c, ModelState& m, const CleanIn& in, bool cull) {
+static void enqueue_clean_in_place(mf_ctx* c, ModelState& m, const CleanIn& in, bool cull, bool timed = false) {
     VisList cl{c->d_clean_list, c->d_clean_count};
-    if (cull)
-        launch_cull_clean(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, in.timeDelta, in.confThreshold, c->d_decay_stats, c->d_clean_list,
-                          c->d_clean_count, c->d_cull_ctl, (int)run_table_runs((long)m.cap, (long)c->P), c->stream);
-    launch_clean_runs(in, m.surf[m.cur], cull ? &cl : nullptr, c->d_clean_ctl, clean_runs_grid((long)*m.h_count + kRun), c->stream);
+    {
+        PassTimer t(c, timed ? MF_PASS_BG_CLEAN : -1);
+        if (cull)
+            launch_cull_clean(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, in.timeDelta, in.confThreshold, c->d_decay_stats, c->d_clean_list,
+                              c->d_clean_count, c->d_cull_ctl, (int)run_table_runs((long)m.cap, (long)c->P), c->stream);
+        launch_clean_runs(in, m.surf[m.cur], cull ? &cl : nullptr, c->d_clean_ctl, clean_runs_grid((long)*m.h_count + kRun), c->stream);
+    }
+    PassTimer t(c, timed ? MF_PASS_BG_APPEND : -1);
     launch_clean_append(in, m.surf[m.cur], c->stream);
 }
 
@@ -293,16 +314,24 @@ static int enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, co
     }
     const int src = m.cur, dst = 1 - m.cur;
     const int blocks = surfel_blocks(c, m);
+    const bool timed = m.id == 0;       // "passTimings": the background's passes one by one
     VisList vl;
-    const VisList* vis = ensure_vis(c, m, vl);
-    // (column-major key images in both index passes of a model handled on its own: index_scatter_one; the resolve of this pass transposes)
-    launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, true, s, blocks, vis);
-    launch_index_resolve(m.surf[src], m.d_frame, m.d_pose, c->d_keys, W, H, c->d_index, c->d_ivc, c->d_inr, secondIndexPass ? nullptr : c->d_ict,
-                         nullptr, nullptr, nullptr, nullptr, true, s);
+    const VisList* vis = nullptr;
+    {
+        PassTimer t(c, timed ? MF_PASS_BG_INDEX : -1);
+        vis = ensure_vis(c, m, vl);
+        // (column-major key images in both index passes of a model handled on its own: index_scatter_one; the resolve of this pass transposes)
+        launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, true, s, blocks, vis);
+        launch_index_resolve(m.surf[src], m.d_frame, m.d_pose, c->d_keys, W, H, c->d_index, c->d_ivc, c->d_inr, secondIndexPass ? nullptr : c->d_ict,
+                             nullptr, nullptr, nullptr, nullptr, true, s);
+    }
     if (marks) mark(c, 4);
     // Model::fuse maxDepth uniform: min(depthCutoff, model.maxDepth, bb_max_z) (Model.cpp:527); bb_max_z from the model's bounding box on the device
-    launch_fuse_data(d_rgb, d_depth, depthF, mask, m.id, m.d_frame, m.d_pose, weightMultiplier, fminf(fuseDepthCutoff, m.maxDepth), W, H,
-                     c->K, c->d_index, c->d_ivc, c->d_inr, c->d_cand_op, c->d_cand_rec, c->d_upd_first, c->d_cand_best, s, c->bbox_limit ? 1 : 0);
+    {
+        PassTimer t(c, timed ? MF_PASS_BG_FUSE_DATA : -1);
+        launch_fuse_data(d_rgb, d_depth, depthF, mask, m.id, m.d_frame, m.d_pose, weightMultiplier, fminf(fuseDepthCutoff, m.maxDepth), W, H,
+                         c->K, c->d_index, c->d_ivc, c->d_inr, c->d_cand_op, c->d_cand_rec, c->d_upd_first, c->d_cand_best, s, c->bbox_limit ? 1 : 0);
+    }
     if (marks) mark(c, 5);
     // the in-place clean of the background visits only the runs its rules can touch (k_cull_clean); the resolve pass that feeds clean gathers
     // the frame's statistics for that test
@@ -311,17 +340,27 @@ static int enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, co
     if (copy && small) {
         // small map (rounds 1-4's pass): update.vert as a copy src -> dst with the second index scatter (:556) riding on it; clean goes
         // dst -> src: two swaps leave the live buffer where it was
-        launch_fuse_update_copy(m.surf[src], m.surf[dst], m.d_frame, c->d_upd_first, c->d_cand_rec, m.d_pose, W, H, c->K, g.max_depth_processed,
-                                g.time_delta, secondIndexPass ? c->d_keys : nullptr, true, s, blocks);
+        {
+            PassTimer t(c, timed ? MF_PASS_BG_FUSE_UPDATE : -1);
+            launch_fuse_update_copy(m.surf[src], m.surf[dst], m.d_frame, c->d_upd_first, c->d_cand_rec, m.d_pose, W, H, c->K, g.max_depth_processed,
+                                    g.time_delta, secondIndexPass ? c->d_keys : nullptr, true, s, blocks);
+        }
         live = dst;
         if (marks) mark(c, 6);
-        if (secondIndexPass) launch_index_resolve(m.surf[live], m.d_frame, m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, depthF, mask, c->d_maskT, true, s);
+        if (secondIndexPass) {
+            PassTimer t(c, timed ? MF_PASS_BG_INDEX2 : -1);
+            launch_index_resolve(m.surf[live], m.d_frame, m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, depthF, mask, c->d_maskT, true, s);
+        }
     } else {
         // update.vert in place -- only the surfels a candidate merged into are touched (the reference copies the whole buffer,
         // Model.cpp:583-646) --, then the second index pass (over the runs in view where the buffer has a run table)
-        launch_fuse_update(m.surf[src], m.d_frame, c->d_upd_first, c->d_cand_op, c->d_cand_best, c->d_cand_rec, W, H, s);
+        {
+            PassTimer t(c, timed ? MF_PASS_BG_FUSE_UPDATE : -1);
+            launch_fuse_update(m.surf[src], m.d_frame, c->d_upd_first, c->d_cand_op, c->d_cand_best, c->d_cand_rec, W, H, s);
+        }
         if (marks) mark(c, 6);
         if (secondIndexPass) {   // predictIndices on the updated buffer (:556); its resolve writes the packed, column-major map of clean's window gathers
+            PassTimer t(c, timed ? MF_PASS_BG_INDEX2 : -1);
             launch_index_scatter(m.surf[src], m.d_frame, m.d_pose, W, H, c->K, g.max_depth_processed, g.time_delta, c->d_keys, true, s, blocks, vis);
             launch_index_resolve(m.surf[src], m.d_frame, m.d_pose, c->d_keys, W, H, nullptr, nullptr, nullptr, nullptr, c->d_iclean, depthF, mask, c->d_maskT, true, s,
                                  cull_clean ? c->d_decay_stats : nullptr, m.id);
@@ -330,8 +369,9 @@ static int enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, co
     // clean: two launches live -> the other buffer (a dense copy) below big_map_elements; from there on in place, run by run
     const CleanIn in = clean_in(c, m, g.time_delta, secondIndexPass, depthF, mask);
     if (in_place) {
-        enqueue_clean_in_place(c, m, in, cull_clean);
+        enqueue_clean_in_place(c, m, in, cull_clean, timed);
     } else {
+        PassTimer t(c, timed ? MF_PASS_BG_CLEAN : -1);
         launch_clean_small(in, m.surf[live], m.surf[1 - live], s);
         m.cur = 1 - live;
     }
@@ -344,6 +384,7 @@ static int enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, co
 // advance: the end-of-frame bookkeeping of this model (processFrame's tail); the tiled prediction runs it as its epilogue, the scatter
 // form is followed by k_frame_advance.
 static void enqueue_predict(mf_ctx* c, ModelState& m, const FrameAdvance* advance = nullptr) {
+    PassTimer timer(c, m.id == 0 ? MF_PASS_BG_PREDICT : -1);
     m.pred_gray_valid = photometric_on(c);
     if (c->splat_tiles && !(c->object_scatter_splat && m.id != 0)) {
         const bool gray = photometric_on(c);
@@ -397,6 +438,8 @@ static int make_obj_batch(mf_ctx* c, const std::vector<ModelState*>& ms, const s
     b.m = c->d_obj_args[slot]; b.n = (int)ms.size();
     b.W = c->W; b.H = c->H; b.k = c->K; b.maxDepthProcessed = g.max_depth_processed; b.globalMaxDepth = g.depth_cutoff; b.timeDelta = g.time_delta;
     b.outlierCoeff = g.outlier_coefficient; b.cleanLiteral = c->clean_literal ? 1 : 0; b.bboxLimit = c->bbox_limit ? 1 : 0; b.cleanSmall = 0; b.updateCopy = 0;
+    b.denseSprites = 0;
+    for (ModelState* m : ms) if ((long)*m->h_count >= (long)c->in_place_elements) b.denseSprites = 1;
     b.rgb = d_rgb; b.depthRaw = d_depth; b.depthF = depthF; b.mask = mask; b.maskT = c->d_maskT; b.bg_pose = c->models[0]->d_pose; b.global_keys = c->d_keys;
     return MF_OK;
 }
@@ -475,6 +518,7 @@ static int download_pose_log(mf_ctx* c, ModelState& m, std::vector<int64_t>& ts,
 // object models (a few thousand sprites) keep the scatter form, which costs them one short launch.  Both write the same keys.
 static void enqueue_global_projection(mf_ctx* c, ModelState& m, int order) {
     const mf_config& g = c->cfg;
+    PassTimer timer(c, m.id == 0 ? MF_PASS_BG_GLOBAL : -1);
     if (m.id == 0 && c->splat_tiles && c->global_tiles) {
         VisList vl;
         const VisList* vis = ensure_vis(c, m, vl);
@@ -574,7 +618,10 @@ static int enqueue_fusion_loop(mf_ctx* c, size_t first, bool multi, const uint8_
         for (ModelState* m : objs) cblocks = std::max(cblocks, clean_runs_grid((long)*m->h_count + kRun));
         ob.cleanSmall = in_place ? 0 : 1; ob.updateCopy = in_place ? 0 : 1;
         if (!in_place) for (ModelState* m : objs) if (!update_copy(c, *m)) ob.updateCopy = 0;
-        launch_obj_fuse_clean(ob, blocks, cblocks, c->stream);
+        {
+            PassTimer timer(c, MF_PASS_OBJ_FUSE_CLEAN);
+            launch_obj_fuse_clean(ob, blocks, cblocks, c->stream);
+        }
         for (ModelState* m : objs) {   // copy-update: a -> b -> a; in-place update + two-launch clean: a -> b -- b is the live buffer now; in place: a
             if (!in_place && !ob.updateCopy) m->cur = 1 - m->cur;
             after_clean(c, *m, in_place);
@@ -617,6 +664,7 @@ static int enqueue_predict_loop(mf_ctx* c, size_t first, bool may_batch, int64_t
         ObjBatch ob; int blocks = 0;
         int rc = make_obj_batch(c, objs, orders, d_rgb, d_depth, depthF, mask, weight_multiplier, &slots, ob, blocks);
         if (rc != MF_OK) return rc;
+        PassTimer timer(c, MF_PASS_OBJ_PREDICT);
         launch_obj_predict_advance(ob, blocks, c->stream);
         return MF_OK;
     }
@@ -755,6 +803,7 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
                 ObjBatch ob; int blocks = 0;
                 int rc = make_obj_batch(c, objs, orders, d_rgb, d_depth, depthF, mask, weight_multiplier, nullptr, ob, blocks);
                 if (rc != MF_OK) return rc;
+                PassTimer timer(c, MF_PASS_OBJ_GLOBAL);
                 launch_obj_global_scatter(ob, blocks, s);
             } else {
                 for (size_t i = 0; i < c->models.size(); ++i) enqueue_global_projection(c, *c->models[i], (int)i);
@@ -883,6 +932,11 @@ extern "C" int mf_set_mask_class_ids(mf_ctx* c, const int32_t* class_ids, int32_
 extern "C" int mf_sync(mf_ctx* c) {
     if (!c) return MF_EINVAL;
     MF_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->pass_timings_on)
+        for (int q = 0; q < MF_N_PASSES; ++q) {
+            float ms = 0.f;
+            if (c->pass_recorded[q] && hipEventElapsedTime(&ms, c->ev_pass[q][0], c->ev_pass[q][1]) == hipSuccess) c->pass_ms[q] = ms;
+        }
     if (c->timings_on) {
         // event i marks the START of stage i; stage i lasts until event i+1 (labels: see the header)
         float t[MF_N_TIMINGS] = {};

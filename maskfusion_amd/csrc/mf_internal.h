@@ -360,6 +360,8 @@ struct ObjPassArgs {
 struct ObjBatch {
     const ObjPassArgs* m; int n;
     int W, H; Intr k; float maxDepthProcessed, globalMaxDepth; int timeDelta; float outlierCoeff; int cleanLiteral, bboxLimit;
+    int denseSprites;                  // 1: a model of the batch is above inPlaceElements -- the sprite passes (prediction, GlobalProjection) run one thread
+                                       // per surfel: such a map holds sub-pixel sprites, and four lanes per surfel repeat its set-up four times
     int updateCopy;                    // 1: every model of the batch is below inPlaceElements -- update.vert as a copy a -> b, clean b -> a
     int cleanSmall;                    // 1: the two-launch clean form src -> dst; 0: every model of the batch has a run table -- clean in place
     const uint8_t* rgb; const float* depthRaw; const float* depthF; const uint8_t* mask; const PoseDev* bg_pose;

@@ -105,7 +105,7 @@ template <int kLanes>
 __device__ __forceinline__ void global_scatter_body(Surfels src, const FrameDev* __restrict__ frame,
                                                     const PoseDev* __restrict__ pose, int W, int H, Intr k, float maxDepth,
                                                     float confThreshold, int timeDelta, unsigned payload,
-                                                    unsigned long long* __restrict__ keys) {
+                                                    unsigned long long* __restrict__ keys, bool pretest = false) {
     if (pose->alive == 0) return;  // model dropped by the jump test earlier in this frame
     const float time = (float)frame->tick;
     float Ri[9];
@@ -153,7 +153,7 @@ __device__ __forceinline__ void global_scatter_body(Surfels src, const FrameDev*
                 const float3 diff = cp - h;
                 if (!(dot3(diff, diff) <= sqrRad)) continue;
                 if (!(cp.z > 0.f)) continue;
-                if (kLanes > 1) zmin_key_pretested(&keys[py * W + px], ((unsigned long long)__float_as_uint(cp.z) << 32) | payload);   // (object models)
+                if (pretest) zmin_key_pretested(&keys[py * W + px], ((unsigned long long)__float_as_uint(cp.z) << 32) | payload);   // (object models)
                 else zmin_key(&keys[py * W + px], ((unsigned long long)__float_as_uint(cp.z) << 32) | payload);
             }
     });
@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256) void k_global_scatter(Surfels src, const Frame
 // every object model of the list in one launch (grid.z = model; ObjBatch, mf_internal.h): all of them z-test into the one key image
 __global__ __launch_bounds__(256) void k_obj_global_scatter(const ObjBatch b) {
     const ObjPassArgs& m = b.m[blockIdx.z];
-    global_scatter_body<4>(m.a, m.frame, m.pose, b.W, b.H, b.k, b.globalMaxDepth, 12.0f, b.timeDelta, m.global_payload, b.global_keys);
+    if (b.denseSprites) global_scatter_body<1>(m.a, m.frame, m.pose, b.W, b.H, b.k, b.globalMaxDepth, 12.0f, b.timeDelta, m.global_payload, b.global_keys, true);
+    else global_scatter_body<4>(m.a, m.frame, m.pose, b.W, b.H, b.k, b.globalMaxDepth, 12.0f, b.timeDelta, m.global_payload, b.global_keys, true);
 }
 void launch_obj_global_scatter(const ObjBatch& b, int blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_obj_global_scatter, dim3(blocks, 1, b.n), dim3(256), 0, s, b);

@@ -1359,7 +1359,7 @@ void launch_densify(Surfels src, Surfels dst, FrameDev* frame, int* offs, int* h
 template <int kLanes>
 __device__ __forceinline__ void splat_scatter_body(Surfels src, const FrameDev* __restrict__ frame,
                                                    const PoseDev* __restrict__ pose, int W, int H, Intr k, float maxDepth,
-                                                   float confThreshold, int timeDelta, unsigned long long* __restrict__ keys) {
+                                                   float confThreshold, int timeDelta, unsigned long long* __restrict__ keys, bool pretest = false) {
     const float time = (float)frame->tick;  // combinedPredict(time = tick, maxTime = tick)
     float Ri[9];
 #pragma unroll
@@ -1407,7 +1407,7 @@ __device__ __forceinline__ void splat_scatter_body(Surfels src, const FrameDev* 
                 if (!(dot3(diff, diff) <= sqrRad)) continue;
                 if (!(cp.z > 0.f)) continue;
                 const unsigned long long key = ((unsigned long long)__float_as_uint(cp.z) << 32) | (unsigned)i;
-                if (kLanes > 1) zmin_key_pretested(&keys[py * W + px], key);   // (the object models' launches)
+                if (pretest) zmin_key_pretested(&keys[py * W + px], key);   // (the object models' launches)
                 else zmin_key(&keys[py * W + px], key);
             }
         }
@@ -1606,7 +1606,9 @@ __global__ __launch_bounds__(256) void k_obj_clean_small_flags(const ObjBatch b)
 __global__ __launch_bounds__(256) void k_obj_clean_small_compact(const ObjBatch b) { clean_small_compact_body(obj_clean_args(b, b.m[blockIdx.z], b.cleanSmall ? 0 : 1)); }
 __global__ __launch_bounds__(256) void k_obj_splat_scatter(const ObjBatch b) {
     const ObjPassArgs& m = b.m[blockIdx.z];
-    splat_scatter_body<4>(m.a, m.frame, m.pose, b.W, b.H, b.k, b.maxDepthProcessed, m.confThreshold, b.timeDelta, m.keys);
+    // (both forms write the same keys: the z-test is a minimum)
+    if (b.denseSprites) splat_scatter_body<1>(m.a, m.frame, m.pose, b.W, b.H, b.k, b.maxDepthProcessed, m.confThreshold, b.timeDelta, m.keys, true);
+    else splat_scatter_body<4>(m.a, m.frame, m.pose, b.W, b.H, b.k, b.maxDepthProcessed, m.confThreshold, b.timeDelta, m.keys, true);
 }
 __global__ __launch_bounds__(256) void k_obj_splat_resolve(const ObjBatch b) {
     const ObjPassArgs& m = b.m[blockIdx.z];

@@ -14,6 +14,11 @@ TIMING_LABELS = ["Preprocess", "odomInit", "odom", "indexMap", "Fuse::Data", "Fu
                  "mmGlobalProjection", "mmEdgeLabels", "mmBackgroundFuseClean", "mmHostStall", "mmObjectFuseClean", "mmHostWaitMs"]
 
 
+MF_N_PASSES = 12
+PASS_LABELS = ["bgGlobalProjection", "bgIndexMap", "bgFuseData", "bgFuseUpdate", "bgIndexMap2", "bgClean", "bgAppend", "bgPredict",
+               "objGlobalProjection", "objFuseClean", "objPredict", "compaction"]
+
+
 class MFError(RuntimeError):
     pass
 
@@ -87,6 +92,7 @@ SYMBOLS = {
     "mf_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "mf_get_param": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]),
     "mf_get_timings": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mf_get_pass_timings": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mf_get_stream": (C.c_void_p, [C.c_void_p]),
     "mf_get_input_stream": (C.c_void_p, [C.c_void_p]),
     "mf_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]),
