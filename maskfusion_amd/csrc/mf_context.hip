@@ -551,7 +551,7 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     A(dev_alloc(c, c->allocs, &c->d_clean_list, (size_t)c->vis_max_runs));
     A(dev_alloc(c, c->allocs, &c->d_clean_count, 1));
     A(dev_alloc(c, c->allocs, &c->d_run_offs, (size_t)c->vis_max_runs + 1));
-    A(dev_alloc(c, c->allocs, &c->d_decay_stats, 4));
+    A(dev_alloc(c, c->allocs, &c->d_decay_stats, (size_t)kDecayStats + 3));
     launch_arm_decay_stats(c->d_decay_stats, c->stream);
     A(dev_alloc(c, c->allocs, &c->d_vis_count, 1));
     A(dev_alloc(c, c->allocs, &c->d_cull_ctl, 2));

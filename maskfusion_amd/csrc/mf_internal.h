@@ -259,8 +259,8 @@ size_t run_table_entries(long capacity, long pixels);   // int4 entries of that 
 void launch_cull(Surfels s, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, int timeDelta, int* list, int* count,
                  int* ctl, int max_runs, hipStream_t st);
 // packed == nullptr: index / vertConf / normRad (+ colorTime if ct != nullptr) images; else one 32 B record per texel.  decay_stats (with packed,
-// optional): 3 ints the pass accumulates the frame's mask-disagreement depth ranges into for launch_cull_clean (armed = {kBoxEmptyMin,
-// kBoxEmptyMax, kBoxEmptyMin}; maskID: the model's id)
+// optional): kDecayStats ints the pass accumulates the frame's mask-disagreement depth ranges into for launch_cull_clean (armed by
+// launch_arm_decay_stats / k_cull_clean; maskID: the model's id)
 void launch_index_resolve(Surfels src, const FrameDev* frame, const PoseDev* pose, unsigned long long* keys, int W, int H, int* index,
                           float4* vc, float4* nr, float4* ct /*or null*/, float4* packed /*or null: the packed column-major map instead of the row-major maps*/,
                           const float* depthF, const uint8_t* mask, uint8_t* maskT /* with packed: the frame planes that travel with it */,
@@ -311,7 +311,8 @@ void launch_clean_runs(const CleanIn& in, Surfels buf, const VisList* runs, int*
 void launch_clean_append(const CleanIn& in, Surfels buf, hipStream_t s);
 // the runs launch_clean_runs has to visit for the BACKGROUND-style culling of a model: those in which one of the pass's rules can apply at all
 // (decay_stats: launch_index_resolve's, re-armed here; list / count / ctl as launch_cull)
-void launch_arm_decay_stats(int* stats /*[3]*/, hipStream_t st);   // once, when the statistics block is allocated
+constexpr int kDecayStats = 9;     // ResolveOut::decay_stats (mf_surfel.hip): {min, max} x {left, right, top, bottom border} + min over all foreign texels
+void launch_arm_decay_stats(int* stats /*[kDecayStats]*/, hipStream_t st);   // once, when the statistics block is allocated
 void launch_cull_clean(Surfels s, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, int timeDelta, float confThreshold, int* decay_stats,
                        int* list, int* count, int* ctl, int max_runs, hipStream_t st);
 // compaction of a sparse buffer: the surfels of src's runs -> dst, dense (no table); offs: scratch of run_table_runs() + 1 ints

@@ -311,7 +311,9 @@ size_t run_table_entries(long capacity, long pixels) { return (size_t)kBoxStride
 // (u < -2  <=>  fx x + (cx + 2) z < 0 for z > 0).  The per-surfel tests of the passes are u in [0, W] x [0, H] and 0 <= z <= maxDepth on individually
 // rounded floats: the box is tested against the image grown by 2 px and the depth range grown by 1 cm -- metres against rounding errors of
 // micrometres.  zlo / zhi: the depth range of the box's corners in the camera frame.
-__device__ __forceinline__ bool run_box_in_frustum(int4 a, int4 b, const PoseDev* __restrict__ pose, int W, int H, Intr k, float maxDepth, float& zlo, float& zhi) {
+// outside (optional): bit q set = the whole box lies outside the image on side q (0 left, 1 right, 2 top, 3 bottom)
+__device__ __forceinline__ bool run_box_in_frustum(int4 a, int4 b, const PoseDev* __restrict__ pose, int W, int H, Intr k, float maxDepth, float& zlo, float& zhi,
+                                                   int* outside = nullptr) {
     const float lo[3] = {box_dec(a.x), box_dec(a.y), box_dec(a.z)}, hi[3] = {box_dec(b.x), box_dec(b.y), box_dec(b.z)};
     int out_near = 1, out_far = 1, out_l = 1, out_r = 1, out_t = 1, out_b = 1;
     zlo = INFINITY; zhi = -INFINITY;
@@ -327,6 +329,7 @@ __device__ __forceinline__ bool run_box_in_frustum(int4 a, int4 b, const PoseDev
         out_t &= k.fy * h.y + (k.cy + 2.f) * h.z < 0.f;
         out_b &= k.fy * h.y + (k.cy - (float)H - 2.f) * h.z > 0.f;
     }
+    if (outside) *outside = out_l | (out_r << 1) | (out_t << 2) | (out_b << 3);
     return !(out_near | out_far | out_l | out_r | out_t | out_b);
 }
 // the listed runs go to `list` in no particular order; the last workgroup to finish publishes their number and re-arms the counters
@@ -417,23 +420,28 @@ struct ResolveOut {
     int* index; float4* vc; float4* nr; float4* ct; float4* packed; const float* depthF; const uint8_t* mask; uint8_t* maskT;
     const FrameDev* frame;    // the buffer's frame state (`first`)
     // with `packed`, optional: what Model::clean's mask-disagreement rule (copy_unstable.vert:139-156) can meet in this frame, for the run culling of
-    // the in-place clean (k_cull_clean): order-preserving ints {min, max filtered depth over the BORDER texels whose mask is foreign to the model
-    // (neither its id nor >= 255), min filtered depth over ALL foreign texels}; armed (empty) between frames
+    // the in-place clean (k_cull_clean): order-preserving ints -- {min, max} filtered depth over the texels of the LEFT column, the RIGHT column, the
+    // TOP row, the BOTTOM row whose mask is foreign to the model (neither its id nor >= 255), then the min over ALL foreign texels (kDecayStats
+    // ints); armed (empty) between frames
     int* decay_stats; int maskID;
 };
-// a workgroup's texels -> the decay statistics (one atomic per statistic and wavefront that saw a foreign texel)
+// a workgroup's texels -> the decay statistics (one atomic per statistic and wavefront that saw such a texel)
 __device__ __forceinline__ void decay_stats_add(const ResolveOut& o, bool in_image, int x, int y, int W, int H, float depth, int maskValue) {
     if (!o.decay_stats) return;
     const bool foreign = in_image && maskValue != o.maskID && maskValue < 255 && depth == depth;
-    const bool border = foreign && (x == 0 || y == 0 || x == W - 1 || y == H - 1);
     const int e = box_enc(depth);
-    const int bmin = wave_min_i(border ? e : kBoxEmptyMin), bmax = wave_max_i(border ? e : kBoxEmptyMax), amin = wave_min_i(foreign ? e : kBoxEmptyMin);
-    if ((threadIdx.x & 63) == 0) {
-        if (bmin != kBoxEmptyMin) { atomicMin(&o.decay_stats[0], bmin); atomicMax(&o.decay_stats[1], bmax); }
-        if (amin != kBoxEmptyMin) atomicMin(&o.decay_stats[2], amin);
+    const bool side[4] = {foreign && x == 0, foreign && x == W - 1, foreign && y == 0, foreign && y == H - 1};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (__ballot(side[q]) == 0ull) continue;      // (wavefront-uniform: most wavefronts hold no border texel at all)
+        const int lo = wave_min_i(side[q] ? e : kBoxEmptyMin), hi = wave_max_i(side[q] ? e : kBoxEmptyMax);
+        if ((threadIdx.x & 63) == 0) { atomicMin(&o.decay_stats[2 * q], lo); atomicMax(&o.decay_stats[2 * q + 1], hi); }
+    }
+    if (__ballot(foreign) != 0ull) {
+        const int amin = wave_min_i(foreign ? e : kBoxEmptyMin);
+        if ((threadIdx.x & 63) == 0) atomicMin(&o.decay_stats[8], amin);
     }
 }
-
 // row-major keys -> row-major maps: texel p of the key image is texel p of the outputs
 template <bool kPacked>
 __device__ __forceinline__ void index_resolve_same_body(Surfels src, const PoseDev* __restrict__ pose, unsigned long long* __restrict__ keys, int P, ResolveOut o) {
@@ -821,6 +829,11 @@ __device__ __forceinline__ void window_slots_literal(float c, int size, int (&u)
 
 // decay: which factor the mask-disagreement rule applied to the confidence (0 none, 1: k, 2: 0.25 k) -- clean_decayed() re-applies it
 // nr_lazy != nullptr: the surfel's normal / radius record is only fetched when the window is walked (it is not needed otherwise); `nr` is then ignored
+// kBurst (the in-place clean of big maps, k_clean_runs): every load of the test -- the normal / radius record, the nine window records, the texel
+// of the mask rule -- is requested before any of them is looked at: one round trip to memory instead of a dozen in a row, for ~60 more registers.
+// (On a VGA map that costs more than it saves: rounds 2 and 5, DESIGN.md "rejected" -- the small-map forms keep the serial walk.)  Same operations
+// on the same values either way.
+template <bool kBurst = false>
 __device__ __forceinline__ bool clean_test(const CleanArgs& a, float4 pc, float4 ct, float4 nr, float time, const float* Ri,
                                            float3 ti, float& newconf, int& decay, const float4* nr_lazy = nullptr) {
     const int W = a.W, H = a.H;
@@ -829,6 +842,15 @@ __device__ __forceinline__ bool clean_test(const CleanArgs& a, float4 pc, float4
     const float x = ((a.k.fx * lp.x) / lp.z) + a.k.cx;
     const float y = ((a.k.fy * lp.y) / lp.z) + a.k.cy;
     int count = 0, zCount = 0;
+    // mask-disagreement rule, copy_unstable.vert:139-156 (nearest fetch, clamp to edge, NaN -> texel 0): its texel
+    const int fx_ = isnan(x) ? 0 : clampi((int)fminf(fmaxf(floorf(x), -1.f), (float)W), 0, W - 1);
+    const int fy_ = isnan(y) ? 0 : clampi((int)fminf(fmaxf(floorf(y), -1.f), (float)H), 0, H - 1);
+    float wDepth = 0.f;
+    int maskValue = 0;
+    if (kBurst) {   // (with the packed map: the filtered depth rides in its spare word, the mask in the column-major plane beside it -- launch_index_resolve)
+        wDepth = a.packed ? a.packed[2 * (fx_ * H + fy_) + 1].w : a.depthF[fy_ * W + fx_];
+        maskValue = a.packed ? a.maskT[fx_ * H + fy_] : a.mask[fy_ * W + fx_];
+    }
     if (time - ct.w < (float)a.timeDelta && lp.z > 0 && x > 0 && y > 0 && x < (float)W && y < (float)H) {
         if (nr_lazy) nr = *nr_lazy;
         const float3 ln = normalize_gl(mul33(Ri, f3(nr.x, nr.y, nr.z)));
@@ -849,6 +871,40 @@ __device__ __forceinline__ bool clean_test(const CleanArgs& a, float4 pc, float4
             window_slots_literal(x / (float)W, W, ux, mx);
             window_slots_literal(y / (float)H, H, uy, my);
         }
+        if (kBurst) {
+            // all nine texels' records requested together (a slot nobody uses -- multiplicity 0 -- reads texel 0 of its axis: a valid address)
+            float4 v9[9];
+            float cz9[9], cw9[9];
+            int idx9[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const int ia = q / 3, ib = q % 3;
+                const int tp = a.transposed ? ux[ia] * H + uy[ib] : uy[ib] * W + ux[ia];
+                if (a.packed) {
+                    v9[q] = a.packed[2 * tp];
+                    const float4 r1 = a.packed[2 * tp + 1];
+                    cz9[q] = r1.x; cw9[q] = r1.y; idx9[q] = __float_as_int(r1.z);
+                } else {
+                    idx9[q] = a.index[tp];
+                    v9[q] = a.vc[tp];
+                    const float4 c = a.ct[tp];
+                    cz9[q] = c.z; cw9[q] = c.w;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const int mult = mx[q / 3] * my[q % 3];
+                const float4 v = v9[q];
+                if (mult > 0 && idx9[q] > 0) {
+                    const float dx = v.x - lp.x, dy = v.y - lp.y;
+                    if (cz9[q] < ct.z && v.w > a.confThreshold && v.z > lp.z && v.z - lp.z < 0.01f &&
+                        sqrtf(dx * dx + dy * dy) < nr.w * 1.4f)
+                        count += mult;
+                    if (cw9[q] == time && v.w > a.confThreshold && v.z > lp.z && v.z - lp.z > 0.01f && fabsf(ln.z) > 0.85f)
+                        zCount += mult;
+                }
+            }
+        } else {
 #pragma unroll
         for (int ia = 0; ia < 3; ++ia) {
 #pragma unroll
@@ -878,18 +934,17 @@ __device__ __forceinline__ bool clean_test(const CleanArgs& a, float4 pc, float4
                 }
             }
         }
+        }
     }
     if (count > 8 || zCount > 4) test = false;
     float w = ct.w;
     if (w == -2.f) w = time;
     if (w == -1.f || ((time - w) > 20 && pc.w < a.confThreshold)) test = false;
     if (w > 0 && time - w > (float)a.timeDelta) test = true;
-    // mask-disagreement decay, copy_unstable.vert:139-156 (nearest fetch, clamp to edge, NaN -> texel 0)
-    const int fx_ = isnan(x) ? 0 : clampi((int)fminf(fmaxf(floorf(x), -1.f), (float)W), 0, W - 1);
-    const int fy_ = isnan(y) ? 0 : clampi((int)fminf(fmaxf(floorf(y), -1.f), (float)H), 0, H - 1);
-    // (with the packed map: the filtered depth rides in its spare word, the mask in the column-major plane beside it -- launch_index_resolve)
-    const float wDepth = a.packed ? a.packed[2 * (fx_ * H + fy_) + 1].w : a.depthF[fy_ * W + fx_];
-    const int maskValue = a.packed ? a.maskT[fx_ * H + fy_] : a.mask[fy_ * W + fx_];
+    if (!kBurst) {
+        wDepth = a.packed ? a.packed[2 * (fx_ * H + fy_) + 1].w : a.depthF[fy_ * W + fx_];
+        maskValue = a.packed ? a.maskT[fx_ * H + fy_] : a.mask[fy_ * W + fx_];
+    }
     newconf = pc.w;
     decay = 0;
     if (maskValue != a.maskID && maskValue < 255 && (wDepth > lp.z - 0.05f && wDepth < lp.z + 0.05f)) {
@@ -1111,9 +1166,12 @@ __global__ __launch_bounds__(256) void k_cull_clean(Surfels s, const FrameDev* _
     const int runs = frame->runs;
     const float time = (float)frame->tick;
     const int r = blockIdx.x * 256 + threadIdx.x;
-    // what the frame holds for rule (c): filtered depth of the border texels with a foreign mask, lowest filtered depth of ANY foreign texel
-    const int e_bmin = decay_stats[0], e_bmax = decay_stats[1], e_amin = decay_stats[2];
-    const bool has_border = e_bmin != kBoxEmptyMin, has_any = e_amin != kBoxEmptyMin;
+    // what the frame holds for rule (c): filtered depth of the border texels with a foreign mask, side by side; lowest filtered depth of ANY foreign texel
+    int e_side[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) e_side[q] = decay_stats[q];
+    const int e_amin = decay_stats[8];
+    const bool has_any = e_amin != kBoxEmptyMin;
     bool visit = false;
     if (r < runs) {
         const int4 a = s.box[kBoxStride * r], b = s.box[kBoxStride * r + 1], c = s.box[kBoxStride * r + 2];
@@ -1122,10 +1180,21 @@ __global__ __launch_bounds__(256) void k_cull_clean(Surfels s, const FrameDev* _
             if (c.y != kBoxEmptyMin && box_dec(c.y) < confThreshold && recent) visit = true;              // (b)
             else if (a.x <= b.x && a.y <= b.y && a.z <= b.z) {     // (a run of NaN positions only: every comparison of (a) and (c) fails)
                 float zlo, zhi;
-                if (run_box_in_frustum(a, b, pose, W, H, k, INFINITY, zlo, zhi)) visit = true;           // (a), and (c) inside the image
-                else if (zlo > 0.06f)        // in front of the camera and outside the image: every surfel's texel is a BORDER texel
-                    visit = has_border && !(box_dec(e_bmax) <= zlo - 0.06f || box_dec(e_bmin) >= zhi + 0.06f);
-                else if (zhi < -0.06f)       // behind the camera: any texel, but only a NEGATIVE filtered depth is within 5 cm (the filter writes none)
+                int outside = 0;
+                if (run_box_in_frustum(a, b, pose, W, H, k, INFINITY, zlo, zhi, &outside)) visit = true;  // (a), and (c) inside the image
+                else if (zlo > 0.06f) {
+                    // In front of the camera and outside the image: every surfel's texel is clamped to the border.  A box that lies beyond the LEFT
+                    // edge as a whole puts all of them into the left column (any row), and so on: rule (c) needs a foreign texel THERE whose depth is
+                    // within 5 cm of a surfel's -- one side that rules it out is enough.
+                    visit = true;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if ((outside >> q) & 1) {
+                            const bool has = e_side[2 * q] != kBoxEmptyMin;
+                            if (!has || box_dec(e_side[2 * q + 1]) <= zlo - 0.06f || box_dec(e_side[2 * q]) >= zhi + 0.06f) visit = false;
+                        }
+                    if (outside == 0) visit = has_any;      // (outside by the near plane only: cannot happen with zlo > 0 -- kept conservative)
+                } else if (zhi < -0.06f)     // behind the camera: any texel, but only a NEGATIVE filtered depth is within 5 cm (the filter writes none)
                     visit = has_any && box_dec(e_amin) < zhi + 0.06f;
                 else visit = has_any;        // around the camera plane: any texel, depths around zero
             }
@@ -1133,13 +1202,13 @@ __global__ __launch_bounds__(256) void k_cull_clean(Surfels s, const FrameDev* _
     }
     run_list_append(visit, r, list, count, ctl);
     if (run_list_finish(count, ctl)) {       // every workgroup has read the statistics: armed for the next frame's resolve pass
-        __hip_atomic_store(&decay_stats[0], kBoxEmptyMin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&decay_stats[1], kBoxEmptyMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&decay_stats[2], kBoxEmptyMin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 0; q < kDecayStats; ++q)
+            __hip_atomic_store(&decay_stats[q], (q == 8 || (q & 1) == 0) ? kBoxEmptyMin : kBoxEmptyMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 __global__ void k_arm_decay_stats(int* st) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { st[0] = kBoxEmptyMin; st[1] = kBoxEmptyMax; st[2] = kBoxEmptyMin; }
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        for (int q = 0; q < kDecayStats; ++q) st[q] = (q == 8 || (q & 1) == 0) ? kBoxEmptyMin : kBoxEmptyMax;
 }
 void launch_arm_decay_stats(int* stats, hipStream_t st) { hipLaunchKernelGGL(k_arm_decay_stats, dim3(1), dim3(64), 0, st, stats); }
 void launch_cull_clean(Surfels s, const FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, int timeDelta, float confThreshold, int* decay_stats,
@@ -1172,82 +1241,64 @@ __device__ __forceinline__ void clean_runs_body(const CleanArgs& a) {
         const int r = a.run_list ? a.run_list[v] : v;
         const int start = run_start(a.src.box, r), len = run_len(a.src.box, r);
         // The test needs HALF of a record -- position + confidence, the two time stamps: 24 of its 48 bytes; the normal / radius record only for a
-        // surfel in view (clean_test fetches it there), the rest only for a survivor that moves.
-        float4 pc[2];
-        float2 tm[2];
-        bool live[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int off = q * 256 + (int)threadIdx.x;
-            live[q] = off < len;
-            pc[q] = make_float4(0, 0, 0, 0); tm[q] = make_float2(0, 0);
-            if (live[q]) {
-                pc[q] = a.src.pc[start + off];
-                tm[q] = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(&a.src.ct[start + off]) + 2);
-            }
-        }
-        bool keep[2];
-        float nc[2];
-        int o[2];
+        // surfel in view (clean_test fetches it there), the rest only for a survivor that moves.  Slots threadIdx.x and 256 + threadIdx.x of the run.
+        const int off0 = (int)threadIdx.x, off1 = 256 + (int)threadIdx.x;
+        const bool live0 = off0 < len, live1 = off1 < len;
+        float4 pc0 = make_float4(0, 0, 0, 0), pc1 = pc0;
+        float2 tm0 = make_float2(0, 0), tm1 = tm0;
+        if (live0) { pc0 = a.src.pc[start + off0]; tm0 = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(&a.src.ct[start + off0]) + 2); }
+        if (live1) { pc1 = a.src.pc[start + off1]; tm1 = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(&a.src.ct[start + off1]) + 2); }
+        // one element after the other: the burst form of the test holds nine window records in registers while it looks at them
+        float nc0 = 0.f, nc1 = 0.f;
+        int dk = 0;
+        const bool keep0 = live0 && clean_test<true>(a, pc0, make_float4(0.f, 0.f, tm0.x, tm0.y), make_float4(0, 0, 0, 0), time, Ri, ti, nc0, dk, &a.src.nr[start + off0]);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool keep1 = live1 && clean_test<true>(a, pc1, make_float4(0.f, 0.f, tm1.x, tm1.y), make_float4(0, 0, 0, 0), time, Ri, ti, nc1, dk, &a.src.nr[start + off1]);
         RunAcc acc;
         acc.reset();
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int i = start + q * 256 + (int)threadIdx.x;
-            int dk = 0;
-            nc[q] = 0.f;
-            keep[q] = live[q] && clean_test(a, pc[q], make_float4(0.f, 0.f, tm[q].x, tm[q].y), make_float4(0, 0, 0, 0), time, Ri, ti, nc[q], dk, &a.src.nr[i]);
-            if (keep[q]) acc.add(make_float4(pc[q].x, pc[q].y, pc[q].z, nc[q]), tm[q].y);
-            const unsigned long long m = __ballot(keep[q]);
-            if (lane == 0) s_cnt[q][wave] = __popcll(m);
-            o[q] = lane_rank(m);
-        }
+        if (keep0) acc.add(make_float4(pc0.x, pc0.y, pc0.z, nc0), tm0.y);
+        if (keep1) acc.add(make_float4(pc1.x, pc1.y, pc1.z, nc1), tm1.y);
+        const unsigned long long m0 = __ballot(keep0), m1 = __ballot(keep1);
+        if (lane == 0) { s_cnt[0][wave] = __popcll(m0); s_cnt[1][wave] = __popcll(m1); }
+        int o0 = lane_rank(m0), o1 = lane_rank(m1);
         run_box_reduce(acc, s_red);
         __syncthreads();
         const int c0 = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
         const int kept = c0 + s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
-        for (int w = 0; w < wave; ++w) { o[0] += s_cnt[0][w]; o[1] += s_cnt[1][w]; }
-        o[1] += c0;
+        for (int w = 0; w < wave; ++w) { o0 += s_cnt[0][w]; o1 += s_cnt[1][w]; }
+        o1 += c0;
+        const bool conf0 = keep0 && __float_as_int(nc0) != __float_as_int(pc0.w), conf1 = keep1 && __float_as_int(nc1) != __float_as_int(pc1.w);
         if (kept != len) {
             // the run lost surfels: its survivors behind the first hole move up, whole records, in order
-            float4 c4[2], n4[2];
-            bool mv[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int off = q * 256 + (int)threadIdx.x;
-                mv[q] = keep[q] && o[q] != off;
-                if (mv[q]) { c4[q] = a.src.ct[start + off]; n4[q] = a.src.nr[start + off]; }
-            }
+            const bool mv0 = keep0 && o0 != off0, mv1 = keep1 && o1 != off1;
+            float4 c40 = make_float4(0, 0, 0, 0), n40 = c40, c41 = c40, n41 = c40;
+            if (mv0) { c40 = a.src.ct[start + off0]; n40 = a.src.nr[start + off0]; }
+            if (mv1) { c41 = a.src.ct[start + off1]; n41 = a.src.nr[start + off1]; }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every record that moves is in registers before any slot of the run is rewritten
             __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int off = q * 256 + (int)threadIdx.x;
-                if (mv[q]) {
-                    a.src.pc[start + o[q]] = make_float4(pc[q].x, pc[q].y, pc[q].z, nc[q]);
-                    a.src.ct[start + o[q]] = c4[q];
-                    a.src.nr[start + o[q]] = n4[q];
-                } else if (keep[q] && __float_as_int(nc[q]) != __float_as_int(pc[q].w)) {
-                    reinterpret_cast<float*>(&a.src.pc[start + off])[3] = nc[q];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 2; ++q)    // nobody moves: only a decayed confidence is written
-                if (keep[q] && __float_as_int(nc[q]) != __float_as_int(pc[q].w)) reinterpret_cast<float*>(&a.src.pc[start + q * 256 + (int)threadIdx.x])[3] = nc[q];
+            if (mv0) { a.src.pc[start + o0] = make_float4(pc0.x, pc0.y, pc0.z, nc0); a.src.ct[start + o0] = c40; a.src.nr[start + o0] = n40; }
+            else if (conf0) reinterpret_cast<float*>(&a.src.pc[start + off0])[3] = nc0;
+            if (mv1) { a.src.pc[start + o1] = make_float4(pc1.x, pc1.y, pc1.z, nc1); a.src.ct[start + o1] = c41; a.src.nr[start + o1] = n41; }
+            else if (conf1) reinterpret_cast<float*>(&a.src.pc[start + off1])[3] = nc1;
+        } else {     // nobody moves: only a decayed confidence is written
+            if (conf0) reinterpret_cast<float*>(&a.src.pc[start + off0])[3] = nc0;
+            if (conf1) reinterpret_cast<float*>(&a.src.pc[start + off1])[3] = nc1;
         }
         if (threadIdx.x == 0) {
             run_box_store(a.src.box, r, start, kept, s_red);
             wg_died += len - kept;
         }
-        if (bbox_on) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                if (keep[q] && nc[q] > a.confThreshold) {   // draw_global_surface.vert:55 (unstable == 0), :69-78
-                    const int x = (int)(1000.f * pc[q].x), y = (int)(1000.f * pc[q].y), z = (int)(1000.f * pc[q].z);
-                    bmin[0] = min(bmin[0], x); bmin[1] = min(bmin[1], y); bmin[2] = min(bmin[2], z);
-                    bmax[0] = max(bmax[0], x); bmax[1] = max(bmax[1], y); bmax[2] = max(bmax[2], z);
-                }
+        if (bbox_on) {   // draw_global_surface.vert:55 (unstable == 0), :69-78
+            if (keep0 && nc0 > a.confThreshold) {
+                const int x = (int)(1000.f * pc0.x), y = (int)(1000.f * pc0.y), z = (int)(1000.f * pc0.z);
+                bmin[0] = min(bmin[0], x); bmin[1] = min(bmin[1], y); bmin[2] = min(bmin[2], z);
+                bmax[0] = max(bmax[0], x); bmax[1] = max(bmax[1], y); bmax[2] = max(bmax[2], z);
+            }
+            if (keep1 && nc1 > a.confThreshold) {
+                const int x = (int)(1000.f * pc1.x), y = (int)(1000.f * pc1.y), z = (int)(1000.f * pc1.z);
+                bmin[0] = min(bmin[0], x); bmin[1] = min(bmin[1], y); bmin[2] = min(bmin[2], z);
+                bmax[0] = max(bmax[0], x); bmax[1] = max(bmax[1], y); bmax[2] = max(bmax[2], z);
+            }
         }
         __syncthreads();   // s_cnt / s_red are rewritten by the next round
     }

@@ -73,6 +73,7 @@ static inline void __threadfence() {}
 static inline void __threadfence_block() {}
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define __builtin_amdgcn_s_sleep(n) hipcpu::yield()
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)   // (a scheduling fence of the device compiler: no meaning here)
 static inline unsigned long long __builtin_amdgcn_s_memtime() { return hipcpu::clock(); }
 long long hipcpu_wall_clock();   // real time at 1 MHz: the device counter runs at 100 MHz, so a time-out written for the GPU is 100x longer here
 static inline long long wall_clock64() { return hipcpu_wall_clock(); }
