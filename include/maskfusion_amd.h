@@ -180,7 +180,9 @@ int mf_get_last_fillin(mf_ctx* ctx, int32_t* used);
  * of rounds 1-4), "inPlaceElements" (1 000 000: from this
  * many surfels on update.vert runs in place -- below, as rounds 1-4's copy with the second index scatter riding on it); which form a model's
  * passes take depends on its size alone and changes no result (tests/test_gpu_switches.py::test_clean_forms_agree), "cullRuns" (1; 0: big maps walk every run of
- * the buffer in every projection pass and in Model::clean -- the executable specification of the culled forms), "densifyEvery" (0; n > 0: a
+ * the buffer in every projection pass and in Model::clean -- the executable specification of the culled forms), "slabCulling" (1: the
+ * batched Gauss-Newton pixel pass skips the workgroups none of whose pixels can project onto a model's normals -- exact, mf_odometry.hip; 0: every
+ * workgroup walks its pixels), "densifyEvery" (0; n > 0: a
  * sparse buffer is compacted every n frames whatever the host's bounds say -- a test switch; by default only when the slots behind the last run or
  * the table entries could run out, before a download, before a model returns to the small-map forms); read-only: "densifyCount" (compactions so
  * far), "cleanRuns" / "visibleRuns" / "backgroundRuns" (runs the last in-place clean visited / on the last visibility list / of the

@@ -45,6 +45,7 @@ struct ModelState {
     // RGBDOdometry of the model (Model::frameToModel): model-side pyramid, Gauss-Newton state, per-workgroup partial sums
     float* d_vmap_g[3] = {}; float* d_nmap_g[3] = {}; GNState* d_gn = nullptr; float* d_partials[2] = {nullptr, nullptr};
     TrackModelDev* d_track = nullptr;      // the block the batched tracker kernels find all of that through
+    int* d_track_rect = nullptr;           // TrackModelDev::rect
     float* d_icp_log = nullptr;            // [20][32] reduced systems of the model's last tracking step, one row per iteration (debug tap "icp_log")
     double* d_gn_trace = nullptr;          // [20][kGnTraceRow] systems in fp64 + the state every iteration used (debug tap "gn_trace"; geometric loop)
     // object models: private scratch of the surfel passes, so that the passes of ALL objects of a frame can be one launch each ("batchObjectPasses")
@@ -236,6 +237,8 @@ struct mf_ctx {
     struct { const void* model = nullptr; long frame = -1; int cur = -1; unsigned gen = 0; float max_depth = 0.f; int time_delta = 0; } vis_tag;
     int densify_count = 0;                 // compactions of sparse buffers so far ("densifyCount", read-only: tests / bench)
     bool fused_rgb_pyramid = true;         // "fusedRgbPyramid": the frame's intensity pyramid + derivative / gate images as one launch (0: four launches, the executable specification)
+    float2* d_row_z = nullptr;             // batched Gauss-Newton loop: depth range of every row of the frame's vertex maps (launch_row_zrange)
+    bool slab_culling = true;              // "slabCulling": the batched pixel pass skips the workgroups whose pixels cannot project onto a model's normals (exact)
     int densify_every = 0;                 // "densifyEvery": > 0 = a model's sparse buffer is compacted every so many frames whatever its bounds say (tests)
     bool cull_runs = true;                 // "cullRuns": 0 = every projection pass streams the whole buffer (A/B switch, executable specification)
     int big_map_elements = 6000000;        // "bigMapElements": from this many surfels on a model's buffer is kept as runs (Surfels::box): its clean pass works in
@@ -413,6 +416,7 @@ static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int 
     }
     A(dev_alloc(c, m->allocs, &m->d_gn, 2));
     A(dev_alloc(c, m->allocs, &m->d_track, 1));
+    A(dev_alloc(c, m->allocs, &m->d_track_rect, 12));
     A(dev_alloc(c, m->allocs, &m->d_icp_log, (size_t)20 * 32));
     A(dev_alloc(c, m->allocs, &m->d_gn_trace, (size_t)20 * kGnTraceRow));
     if (!allowFillIn && with_scratch) A(ensure_obj_scratch(c, *m));
@@ -427,6 +431,7 @@ static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int 
         t.trace = m->d_gn_trace;
         t.jump_limit = allowFillIn ? 0.f : 0.2f;                   // MaskFusion.cpp:268-272 applies to object models
         t.allow_fill = allowFillIn ? 1 : 0;
+        t.rect = m->d_track_rect;
         m->track_host = t;
     }
     hipLaunchKernelGGL(k_pose_identity, dim3(1), dim3(64), 0, c->stream, m->d_pose, c->weight_literal ? 1 : 0);
@@ -445,6 +450,11 @@ static int create_model(mf_ctx* c, int id, float confThr, bool allowFillIn, int 
     *m->h_count = 0;
     m->track_host.pose_host = m->h_pose;
     MF_HIP(c, hipMemcpyAsync(m->d_track, &m->track_host, sizeof(TrackModelDev), hipMemcpyHostToDevice, c->stream));
+    {
+        int armed[12];   // (armed: the batched finalize re-arms it after every frame)
+        for (int q = 0; q < 12; ++q) armed[q] = (q & 2) ? (int)0x80000000 : 0x7FFFFFFF;
+        MF_HIP(c, hipMemcpyAsync(m->d_track_rect, armed, sizeof(armed), hipMemcpyHostToDevice, c->stream));
+    }
     MF_HIP(c, hipStreamSynchronize(c->stream));   // track_host is pageable: the copy must not outlive a moved ModelState
     out = std::move(m);
     return MF_OK;
@@ -546,6 +556,7 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     A(dev_alloc(c, c->allocs, &c->d_block_counts, (size_t)kCompactBlocks));
     A(dev_alloc(c, c->allocs, &c->d_cand_best, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_clean_ctl, (size_t)kCleanCtlInts));
+    A(dev_alloc(c, c->allocs, &c->d_row_z, (size_t)(c->H + (c->H >> 1) + (c->H >> 2))));
     c->vis_max_runs = (int)run_table_runs((long)c->cap_max, (long)P);
     A(dev_alloc(c, c->allocs, &c->d_vis_list, (size_t)c->vis_max_runs));
     A(dev_alloc(c, c->allocs, &c->d_clean_list, (size_t)c->vis_max_runs));
@@ -1028,6 +1039,7 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!strcmp(key, "globalTiles")) { c->global_tiles = value != 0; return MF_OK; }
     if (!strcmp(key, "cullRuns")) { c->cull_runs = value != 0; c->vis_tag.model = nullptr; return MF_OK; }
     if (!strcmp(key, "densifyEvery")) { c->densify_every = (int)value; return MF_OK; }
+    if (!strcmp(key, "slabCulling")) { c->slab_culling = value != 0; return MF_OK; }
     if (!strcmp(key, "bigMapElements")) { c->big_map_elements = (int)value; c->vis_tag.model = nullptr; return MF_OK; }
     if (!strcmp(key, "fusedRgbPyramid")) { c->fused_rgb_pyramid = value != 0; return MF_OK; }
     if (!strcmp(key, "inPlaceElements")) { c->in_place_elements = (int)value; return MF_OK; }

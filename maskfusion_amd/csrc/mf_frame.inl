@@ -153,13 +153,17 @@ static void enqueue_track_batch(mf_ctx* c, const std::vector<ModelState*>& ms, c
     const int iters[3] = {g.fast_odom ? 3 : 10, g.pyramid ? 5 : 0, g.pyramid ? 4 : 0};
     const bool timed = c->timings_on && ms[0] == c->models[0].get();
     if (timed) { (void)hipEventRecord(c->ev_icp[0], s); c->tracked_once = true; c->icp_mid_recorded = false; }
+    // slab culling of the pixel pass (mf_odometry.hip: k_icp_batch_pixels): the depth range of every row of the frame's vertex maps, once per frame
+    if (c->slab_culling) launch_row_zrange(c->d_vmap[set], W, H, c->d_row_z, s);
+    const int row_base[3] = {0, H, H + (H >> 1)};
     int it = 0, nb_prev = 0;
     for (int lvl = 2; lvl >= 0; --lvl) {
         const float div = (float)(1 << lvl);
         for (int j = 0; j < iters[lvl]; ++j) {
             launch_icp_batch_solve(b, it, nb_prev, it == 0 ? so3_seed : nullptr, s);
             launch_icp_batch_pixels(b, it, lvl, c->d_vmap[set][lvl], c->d_nmap[set][lvl], W >> lvl, H >> lvl,
-                                    Intr{g.fx / div, g.fy / div, g.cx / div, g.cy / div}, 0.10f, sinf(20.f * 3.14159254f / 180.f), s);
+                                    Intr{g.fx / div, g.fy / div, g.cx / div, g.cy / div}, 0.10f, sinf(20.f * 3.14159254f / 180.f), s,
+                                    c->slab_culling ? c->d_row_z + row_base[lvl] : nullptr);
             nb_prev = icp_batch_blocks(W >> lvl, H >> lvl, b.n);
             ++it;
         }

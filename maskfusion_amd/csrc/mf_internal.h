@@ -128,6 +128,9 @@ struct TrackModelDev {
     double* trace;                                // [20][kGnTraceRow] Gauss-Newton trace (mf_odometry.hip: gn_trace_write) or nullptr
     float jump_limit;                             // object models: 0.2 m rule of MaskFusion.cpp:268-272; background: 0
     int allow_fill;                               // Model::allowsFillIn (background only)
+    int* rect;                                    // [3][4] per pyramid level {x0, y0, x1, y1}: the pixels of nm[level] that hold a normal (an object's
+                                                  // prediction is NaN outside the object, Q3) -- written by the batched model pyramid, read by the batched
+                                                  // pixel pass (slab culling), re-armed {INT_MAX, INT_MAX, INT_MIN, INT_MIN} by the batched finalize
 };
 constexpr int kMaxTrackBatch = 32;
 constexpr int kGnTraceRow = 64;
@@ -172,8 +175,12 @@ int icp_batch_blocks(int W, int H, int n_models);             // workgroups per 
 void launch_model_pyramid_batch(const TrackBatch& b, const float* fillDepth, int W, int H, Intr k, hipStream_t s);
 // it = 0 seeds the states from the model poses (+ SO(3) rotation); it >= 1 finishes iteration it-1 whose pixel pass used nb_in blocks
 void launch_icp_batch_solve(const TrackBatch& b, int it, int nb_in, const So3Result* so3_or_null, hipStream_t s);
+// row_z: launch_row_zrange's output for this level (nullptr: no culling -- every workgroup walks its pixels)
 void launch_icp_batch_pixels(const TrackBatch& b, int it, int level, const float* vmap_curr, const float* nmap_curr, int W, int H, Intr k,
-                             float distThres, float angleThres, hipStream_t s);
+                             float distThres, float angleThres, hipStream_t s, const float2* row_z = nullptr);
+// depth range of every row of the frame's three vertex maps: out[0 .. H) level 0, [H .. H + H/2) level 1, [.. + H/4) level 2: {min z, max z} over the
+// row's valid vertices ({+inf, -inf}: none)
+void launch_row_zrange(const float* const vmap[3], int W, int H, float2* out, hipStream_t s);
 // last solve (iteration n_it - 1) + Model pose / lastPose / statistics / jump rule
 void launch_icp_batch_finalize(const TrackBatch& b, int n_it, int nb_in, const So3Result* so3_or_null, hipStream_t s);
 // Last reduce+solve, then pose / lastPose / inverse / fusion weight update and host mirror.

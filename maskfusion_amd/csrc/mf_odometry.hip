@@ -885,7 +885,28 @@ struct IcpPxArgs {
     int W, H; Intr k;
     float dist2Max, sine2Min;
     int level, parity, chunk;
+    const float2* row_z;      // [H] {min z, max z} of the valid vertices of every row of vc (launch_row_zrange); nullptr: no slab culling
 };
+
+// {min z, max z} over the valid vertices of every row of the three levels' vertex maps (planar [3][H][W]: z is plane 2)
+struct RowZArgs { const float* vm[3]; int W, H; float2* out; };
+__global__ __launch_bounds__(64) void k_row_zrange(const RowZArgs a) {
+    int row = blockIdx.x, level = 0, W = a.W, H = a.H, base = 0;
+    while (level < 2 && row >= H) { row -= H; base += H; W >>= 1; H >>= 1; ++level; }
+    const float* __restrict__ z = a.vm[level] + 2 * (size_t)W * H + (size_t)row * W;
+    float lo = INFINITY, hi = -INFINITY;
+    for (int x = threadIdx.x; x < W; x += 64) {
+        const float v = z[x];
+        if (v == v) { lo = fminf(lo, v); hi = fmaxf(hi, v); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); }
+    if (threadIdx.x == 0) a.out[base + row] = make_float2(lo, hi);
+}
+void launch_row_zrange(const float* const vmap[3], int W, int H, float2* out, hipStream_t s) {
+    RowZArgs a{{vmap[0], vmap[1], vmap[2]}, W, H, out};
+    hipLaunchKernelGGL(k_row_zrange, dim3(H + (H >> 1) + (H >> 2)), dim3(64), 0, s, a);
+}
 constexpr int kBatchThreads = 256;
 constexpr int kBatchPx = 3;   // pixels per thread and round: all their gathers are in flight together
 
@@ -903,6 +924,53 @@ __global__ __launch_bounds__(kBatchThreads) void k_icp_batch_pixels(const IcpPxA
     const int tid = threadIdx.x;
     const int P = a.W * a.H;
     const int beg = blockIdx.x * a.chunk, end = min(P, beg + a.chunk);
+    // Slab culling (exact).  A frame pixel contributes only if it projects onto a pixel of the model's maps that holds a normal (reduce.cu:316-352:
+    // everything else is a NaN reject), and an OBJECT's maps hold normals on the object alone -- ~1 % of the image (Q3).  The workgroup's pixels
+    // are rows r0 .. r1 of the frame's vertex map; every valid vertex of those rows lies on the ray of its pixel at a depth inside the rows' range
+    // [zmin, zmax] (row_z), i.e. inside the frustum section spanned by the four corner rays of the row band between those depths -- a convex
+    // set, the hull of its eight corners.  The iteration's relative pose maps it to the hull of the transformed corners; if all of them lie in front
+    // of the model camera, the projection of a convex set is inside the convex hull of the projected corners, hence inside their bounding box.
+    // If that box (grown by 2 px against the rounding of the per-pixel arithmetic) misses the model's rectangle of normals (TrackModelDev::rect,
+    // grown likewise), no pixel of the workgroup can find a correspondence: its partial sums are zero, written without touching a map.
+    __shared__ int s_skip;
+    if (a.row_z && beg < end) {
+        if (tid < 64) {
+            const int r0 = beg / a.W, r1 = (end - 1) / a.W;
+            float zlo = INFINITY, zhi = -INFINITY;
+            for (int r = r0 + tid; r <= r1; r += 64) { const float2 z = a.row_z[r]; zlo = fminf(zlo, z.x); zhi = fmaxf(zhi, z.y); }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { zlo = fminf(zlo, __shfl_xor(zlo, off, 64)); zhi = fmaxf(zhi, __shfl_xor(zhi, off, 64)); }
+            // lanes 0..7: corner (x side, row side, depth end) of the slab
+            const float cxs = (tid & 1) ? (float)(a.W - 1) : 0.f, cys = (tid & 2) ? (float)r1 : (float)r0, cz = (tid & 4) ? zhi : zlo;
+            const float3 p = f3(cz * (cxs - a.k.cx) / a.k.fx, cz * (cys - a.k.cy) / a.k.fy, cz);           // createVMap, cudafuncs.cu:118-123
+            const float3 g = icp_mul33(Rc, p);
+            const float3 q = icp_mul33(Rpi, f3(g.x + tc.x - tp.x, g.y + tc.y - tp.y, g.z + tc.z - tp.z));
+            const bool front = q.z > 1e-3f;
+            float u = front ? q.x * a.k.fx / q.z + a.k.cx : 0.f, v = front ? q.y * a.k.fy / q.z + a.k.cy : 0.f;
+            float ulo = tid < 8 ? u : INFINITY, uhi = tid < 8 ? u : -INFINITY, vlo = tid < 8 ? v : INFINITY, vhi = tid < 8 ? v : -INFINITY;
+            int all_front = (tid >= 8 || front) ? 1 : 0;
+#pragma unroll
+            for (int off = 4; off > 0; off >>= 1) {
+                ulo = fminf(ulo, __shfl_xor(ulo, off, 64)); uhi = fmaxf(uhi, __shfl_xor(uhi, off, 64));
+                vlo = fminf(vlo, __shfl_xor(vlo, off, 64)); vhi = fmaxf(vhi, __shfl_xor(vhi, off, 64));
+                all_front &= __shfl_xor(all_front, off, 64);
+            }
+            if (tid == 0) {
+                const int* __restrict__ rc = md->rect + a.level * 4;
+                bool skip = !(zlo <= zhi);                                        // no valid vertex in these rows at all
+                if (!skip && all_front && ulo == ulo && uhi == uhi && vlo == vlo && vhi == vhi) {
+                    const bool empty = rc[0] > rc[2] || rc[1] > rc[3];           // the model's maps hold no normal at this level
+                    skip = empty || uhi + 2.5f < (float)rc[0] || ulo - 2.5f > (float)rc[2] || vhi + 2.5f < (float)rc[1] || vlo - 2.5f > (float)rc[3];
+                }
+                s_skip = skip ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        if (s_skip) {
+            if (tid < kIcpSlots) md->partials[a.parity][blockIdx.x * kIcpSlots + tid] = 0.f;
+            return;
+        }
+    }
     float acc[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) acc[k] = 0.f;
@@ -947,6 +1015,7 @@ __global__ __launch_bounds__(256) void k_icp_batch_finalize(const IcpFinArgs a) 
     const int last = (a.n_it - 1) & 1;
     icp_finalize_body(a.n_it > 0 ? md->partials[last] : nullptr, a.n_it > 0 ? a.nb_in : 0, md->st + (a.n_it > 0 ? last : 0), md->pose, md->pose_host,
                       (md->log && a.n_it > 0) ? md->log + 32 * (a.n_it - 1) : nullptr, md->jump_limit, a.so3, s_seg, s_sys, &s_st, s_scr, md->trace, a.n_it);
+    if (threadIdx.x < 12) md->rect[threadIdx.x] = (threadIdx.x & 2) ? (int)0x80000000 : 0x7FFFFFFF;   // armed for the next frame's model pyramid
 }
 
 // Workgroups per model of the pixel pass: enough of them over all models to fill the GPU a few times over (there is no
@@ -968,8 +1037,9 @@ void launch_icp_batch_solve(const TrackBatch& b, int it, int nb_in, const So3Res
     hipLaunchKernelGGL(k_icp_batch_solve, dim3(b.n), dim3(256), 0, s, a);
 }
 void launch_icp_batch_pixels(const TrackBatch& b, int it, int level, const float* vmap_curr, const float* nmap_curr, int W, int H, Intr k,
-                             float distThres, float angleThres, hipStream_t s) {
+                             float distThres, float angleThres, hipStream_t s, const float2* row_z) {
     IcpPxArgs a;
+    a.row_z = row_z;
     a.b = b; a.vc = vmap_curr; a.nc = nmap_curr; a.W = W; a.H = H; a.k = k; icp_gates(distThres, angleThres, a.dist2Max, a.sine2Min);
     a.level = level; a.parity = it & 1; a.chunk = icp_batch_chunk(W * H, b.n);
     hipLaunchKernelGGL(k_icp_batch_pixels, dim3(icp_batch_blocks(W, H, b.n), b.n), dim3(kBatchThreads), 0, s, a);
@@ -1469,6 +1539,8 @@ __global__ __launch_bounds__(256) void k_model_pyramid(const PyrArgs a0) {
 
     float3 v1 = f3(qnan(), qnan(), qnan()), n1 = v1;
     bool v1ok = false, n1ok = false;
+    bool n0any = false;                       // (batched tracker) this thread's level-0 pixels that hold a normal: their box
+    int n0x0 = 0, n0y0 = 0, n0x1 = 0, n0y1 = 0;
     if (inside) {
         MapPx px[4];
 #pragma unroll
@@ -1479,6 +1551,10 @@ __global__ __launch_bounds__(256) void k_model_pyramid(const PyrArgs a0) {
                 px[dy * 2 + dx] = load_model_px(a.predV, a.predN, a.fillDepth, useFill, x, y, W, H, a.k);
                 store_tx(a.vm[0], a.nm[0], P0, y * W + x, px[dy * 2 + dx].v, px[dy * 2 + dx].vok, px[dy * 2 + dx].n,
                          px[dy * 2 + dx].nok, R, t);
+                if (px[dy * 2 + dx].nok) {
+                    n0x0 = n0any ? min(n0x0, x) : x; n0y0 = n0any ? min(n0y0, y) : y; n0x1 = n0any ? max(n0x1, x) : x; n0y1 = n0any ? max(n0y1, y) : y;
+                    n0any = true;
+                }
             }
         // resizeMapKernel<false/true>, cudafuncs.cu:366-417: order x00 + x01 + x10 + x11
         v1ok = px[0].vok && px[1].vok && px[2].vok && px[3].vok;
@@ -1498,15 +1574,41 @@ __global__ __launch_bounds__(256) void k_model_pyramid(const PyrArgs a0) {
     const float okv = v1ok ? 1.f : 0.f, okn = n1ok ? 1.f : 0.f;
     const float3 va = quad_bcast3<0>(v1), vb = quad_bcast3<1>(v1), vc = quad_bcast3<2>(v1), vd = quad_bcast3<3>(v1);
     const float3 na = quad_bcast3<0>(n1), nb = quad_bcast3<1>(n1), nc = quad_bcast3<2>(n1), nd = quad_bcast3<3>(n1);
-    const bool v2ok = quad_bcast<0>(okv) != 0.f && quad_bcast<1>(okv) != 0.f && quad_bcast<2>(okv) != 0.f && quad_bcast<3>(okv) != 0.f;
-    bool n2ok = quad_bcast<0>(okn) != 0.f && quad_bcast<1>(okn) != 0.f && quad_bcast<2>(okn) != 0.f && quad_bcast<3>(okn) != 0.f;
-    if (!inside || b != 0) return;
-    float3 v2 = f3((va.x + vb.x + vc.x + vd.x) / 4, (va.y + vb.y + vc.y + vd.y) / 4, (va.z + vb.z + vc.z + vd.z) / 4);
-    float3 n2 = normalized_rsqrt(f3((na.x + nb.x + nc.x + nd.x) / 4, (na.y + nb.y + nc.y + nd.y) / 4, (na.z + nb.z + nc.z + nd.z) / 4));
-    if (!v2ok) v2 = f3(qnan(), qnan(), qnan());
-    if (!n2ok) n2 = f3(qnan(), qnan(), qnan());
-    n2ok = n2ok && !isnan(n2.x);
-    store_tx(a.vm[2], a.nm[2], P2, y2 * W2 + x2, v2, v2ok, n2, n2ok, R, t);
+    // (every broadcast is executed by every lane -- no short-circuit: the wavefront reductions below need the lanes in step)
+    const float ov0 = quad_bcast<0>(okv), ov1 = quad_bcast<1>(okv), ov2 = quad_bcast<2>(okv), ov3 = quad_bcast<3>(okv);
+    const float on0 = quad_bcast<0>(okn), on1 = quad_bcast<1>(okn), on2 = quad_bcast<2>(okn), on3 = quad_bcast<3>(okn);
+    const bool v2ok = (ov0 != 0.f) & (ov1 != 0.f) & (ov2 != 0.f) & (ov3 != 0.f);
+    bool n2ok = (on0 != 0.f) & (on1 != 0.f) & (on2 != 0.f) & (on3 != 0.f);
+    bool wrote2 = false;
+    if (inside && b == 0) {
+        float3 v2 = f3((va.x + vb.x + vc.x + vd.x) / 4, (va.y + vb.y + vc.y + vd.y) / 4, (va.z + vb.z + vc.z + vd.z) / 4);
+        float3 n2 = normalized_rsqrt(f3((na.x + nb.x + nc.x + nd.x) / 4, (na.y + nb.y + nc.y + nd.y) / 4, (na.z + nb.z + nc.z + nd.z) / 4));
+        if (!v2ok) v2 = f3(qnan(), qnan(), qnan());
+        if (!n2ok) n2 = f3(qnan(), qnan(), qnan());
+        n2ok = n2ok && !isnan(n2.x);
+        store_tx(a.vm[2], a.nm[2], P2, y2 * W2 + x2, v2, v2ok, n2, n2ok, R, t);
+        wrote2 = n2ok;
+    }
+    if (a0.b.n > 0) {
+        // batched tracker: the rectangle of pixels that hold a normal, per level (TrackModelDev::rect) -- a superset of the pixels store_tx wrote a
+        // normal to (it writes NaN wherever the flag is off), which is all the pixel pass of the Gauss-Newton loop can pair a frame pixel with
+        int* __restrict__ rect = a0.b.m[blockIdx.z]->rect;
+        int lo[3][2], hi[3][2];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) { lo[l][0] = lo[l][1] = 0x7FFFFFFF; hi[l][0] = hi[l][1] = (int)0x80000000; }
+        if (inside) {
+            if (n0any) { lo[0][0] = n0x0; lo[0][1] = n0y0; hi[0][0] = n0x1; hi[0][1] = n0y1; }
+            if (n1ok) { lo[1][0] = hi[1][0] = 2 * x2 + bx; lo[1][1] = hi[1][1] = 2 * y2 + by; }
+            if (wrote2) { lo[2][0] = hi[2][0] = x2; lo[2][1] = hi[2][1] = y2; }
+        }
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const int x0 = wave_min_i(lo[l][0]), y0 = wave_min_i(lo[l][1]), x1 = wave_max_i(hi[l][0]), y1 = wave_max_i(hi[l][1]);
+            if (lane == 0 && x0 <= x1) {
+                atomicMin(&rect[l * 4 + 0], x0); atomicMin(&rect[l * 4 + 1], y0); atomicMax(&rect[l * 4 + 2], x1); atomicMax(&rect[l * 4 + 3], y1);
+            }
+        }
+    }
 }
 
 void launch_model_pyramid(const float4* predV, const float4* predN, const float* fillDepth, const FrameDev* frame,

@@ -829,11 +829,6 @@ __device__ __forceinline__ void window_slots_literal(float c, int size, int (&u)
 
 // decay: which factor the mask-disagreement rule applied to the confidence (0 none, 1: k, 2: 0.25 k) -- clean_decayed() re-applies it
 // nr_lazy != nullptr: the surfel's normal / radius record is only fetched when the window is walked (it is not needed otherwise); `nr` is then ignored
-// kBurst (the in-place clean of big maps, k_clean_runs): every load of the test -- the normal / radius record, the nine window records, the texel
-// of the mask rule -- is requested before any of them is looked at: one round trip to memory instead of a dozen in a row, for ~60 more registers.
-// (On a VGA map that costs more than it saves: rounds 2 and 5, DESIGN.md "rejected" -- the small-map forms keep the serial walk.)  Same operations
-// on the same values either way.
-template <bool kBurst = false>
 __device__ __forceinline__ bool clean_test(const CleanArgs& a, float4 pc, float4 ct, float4 nr, float time, const float* Ri,
                                            float3 ti, float& newconf, int& decay, const float4* nr_lazy = nullptr) {
     const int W = a.W, H = a.H;
@@ -842,15 +837,6 @@ __device__ __forceinline__ bool clean_test(const CleanArgs& a, float4 pc, float4
     const float x = ((a.k.fx * lp.x) / lp.z) + a.k.cx;
     const float y = ((a.k.fy * lp.y) / lp.z) + a.k.cy;
     int count = 0, zCount = 0;
-    // mask-disagreement rule, copy_unstable.vert:139-156 (nearest fetch, clamp to edge, NaN -> texel 0): its texel
-    const int fx_ = isnan(x) ? 0 : clampi((int)fminf(fmaxf(floorf(x), -1.f), (float)W), 0, W - 1);
-    const int fy_ = isnan(y) ? 0 : clampi((int)fminf(fmaxf(floorf(y), -1.f), (float)H), 0, H - 1);
-    float wDepth = 0.f;
-    int maskValue = 0;
-    if (kBurst) {   // (with the packed map: the filtered depth rides in its spare word, the mask in the column-major plane beside it -- launch_index_resolve)
-        wDepth = a.packed ? a.packed[2 * (fx_ * H + fy_) + 1].w : a.depthF[fy_ * W + fx_];
-        maskValue = a.packed ? a.maskT[fx_ * H + fy_] : a.mask[fy_ * W + fx_];
-    }
     if (time - ct.w < (float)a.timeDelta && lp.z > 0 && x > 0 && y > 0 && x < (float)W && y < (float)H) {
         if (nr_lazy) nr = *nr_lazy;
         const float3 ln = normalize_gl(mul33(Ri, f3(nr.x, nr.y, nr.z)));
@@ -871,40 +857,6 @@ __device__ __forceinline__ bool clean_test(const CleanArgs& a, float4 pc, float4
             window_slots_literal(x / (float)W, W, ux, mx);
             window_slots_literal(y / (float)H, H, uy, my);
         }
-        if (kBurst) {
-            // all nine texels' records requested together (a slot nobody uses -- multiplicity 0 -- reads texel 0 of its axis: a valid address)
-            float4 v9[9];
-            float cz9[9], cw9[9];
-            int idx9[9];
-#pragma unroll
-            for (int q = 0; q < 9; ++q) {
-                const int ia = q / 3, ib = q % 3;
-                const int tp = a.transposed ? ux[ia] * H + uy[ib] : uy[ib] * W + ux[ia];
-                if (a.packed) {
-                    v9[q] = a.packed[2 * tp];
-                    const float4 r1 = a.packed[2 * tp + 1];
-                    cz9[q] = r1.x; cw9[q] = r1.y; idx9[q] = __float_as_int(r1.z);
-                } else {
-                    idx9[q] = a.index[tp];
-                    v9[q] = a.vc[tp];
-                    const float4 c = a.ct[tp];
-                    cz9[q] = c.z; cw9[q] = c.w;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 9; ++q) {
-                const int mult = mx[q / 3] * my[q % 3];
-                const float4 v = v9[q];
-                if (mult > 0 && idx9[q] > 0) {
-                    const float dx = v.x - lp.x, dy = v.y - lp.y;
-                    if (cz9[q] < ct.z && v.w > a.confThreshold && v.z > lp.z && v.z - lp.z < 0.01f &&
-                        sqrtf(dx * dx + dy * dy) < nr.w * 1.4f)
-                        count += mult;
-                    if (cw9[q] == time && v.w > a.confThreshold && v.z > lp.z && v.z - lp.z > 0.01f && fabsf(ln.z) > 0.85f)
-                        zCount += mult;
-                }
-            }
-        } else {
 #pragma unroll
         for (int ia = 0; ia < 3; ++ia) {
 #pragma unroll
@@ -934,17 +886,18 @@ __device__ __forceinline__ bool clean_test(const CleanArgs& a, float4 pc, float4
                 }
             }
         }
-        }
     }
     if (count > 8 || zCount > 4) test = false;
     float w = ct.w;
     if (w == -2.f) w = time;
     if (w == -1.f || ((time - w) > 20 && pc.w < a.confThreshold)) test = false;
     if (w > 0 && time - w > (float)a.timeDelta) test = true;
-    if (!kBurst) {
-        wDepth = a.packed ? a.packed[2 * (fx_ * H + fy_) + 1].w : a.depthF[fy_ * W + fx_];
-        maskValue = a.packed ? a.maskT[fx_ * H + fy_] : a.mask[fy_ * W + fx_];
-    }
+    // mask-disagreement decay, copy_unstable.vert:139-156 (nearest fetch, clamp to edge, NaN -> texel 0)
+    const int fx_ = isnan(x) ? 0 : clampi((int)fminf(fmaxf(floorf(x), -1.f), (float)W), 0, W - 1);
+    const int fy_ = isnan(y) ? 0 : clampi((int)fminf(fmaxf(floorf(y), -1.f), (float)H), 0, H - 1);
+    // (with the packed map: the filtered depth rides in its spare word, the mask in the column-major plane beside it -- launch_index_resolve)
+    const float wDepth = a.packed ? a.packed[2 * (fx_ * H + fy_) + 1].w : a.depthF[fy_ * W + fx_];
+    const int maskValue = a.packed ? a.maskT[fx_ * H + fy_] : a.mask[fy_ * W + fx_];
     newconf = pc.w;
     decay = 0;
     if (maskValue != a.maskID && maskValue < 255 && (wDepth > lp.z - 0.05f && wDepth < lp.z + 0.05f)) {
@@ -1248,12 +1201,12 @@ __device__ __forceinline__ void clean_runs_body(const CleanArgs& a) {
         float2 tm0 = make_float2(0, 0), tm1 = tm0;
         if (live0) { pc0 = a.src.pc[start + off0]; tm0 = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(&a.src.ct[start + off0]) + 2); }
         if (live1) { pc1 = a.src.pc[start + off1]; tm1 = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(&a.src.ct[start + off1]) + 2); }
-        // one element after the other: the burst form of the test holds nine window records in registers while it looks at them
+        // (Requesting every load of an element's test at once -- normal / radius, the nine window records, the mask texel: 135 registers -- changed
+        // nothing on the configs[4] maps, 0.43 ms either way: the pass is bound by the instructions of the test, ~2 000 per surfel in view.)
         float nc0 = 0.f, nc1 = 0.f;
         int dk = 0;
-        const bool keep0 = live0 && clean_test<true>(a, pc0, make_float4(0.f, 0.f, tm0.x, tm0.y), make_float4(0, 0, 0, 0), time, Ri, ti, nc0, dk, &a.src.nr[start + off0]);
-        __builtin_amdgcn_sched_barrier(0);
-        const bool keep1 = live1 && clean_test<true>(a, pc1, make_float4(0.f, 0.f, tm1.x, tm1.y), make_float4(0, 0, 0, 0), time, Ri, ti, nc1, dk, &a.src.nr[start + off1]);
+        const bool keep0 = live0 && clean_test(a, pc0, make_float4(0.f, 0.f, tm0.x, tm0.y), make_float4(0, 0, 0, 0), time, Ri, ti, nc0, dk, &a.src.nr[start + off0]);
+        const bool keep1 = live1 && clean_test(a, pc1, make_float4(0.f, 0.f, tm1.x, tm1.y), make_float4(0, 0, 0, 0), time, Ri, ti, nc1, dk, &a.src.nr[start + off1]);
         RunAcc acc;
         acc.reset();
         if (keep0) acc.add(make_float4(pc0.x, pc0.y, pc0.z, nc0), tm0.y);

@@ -176,6 +176,42 @@ def test_batched_tracking_matches_model_by_model_tracking(hip):
     assert max(len(r["ids"]) for r in runs[0]) >= 2
 
 
+def test_slab_culling_changes_nothing(hip):
+    """`slabCulling` (round 6): a workgroup of the batched Gauss-Newton pixel pass whose pixels cannot project onto a pixel of the model's maps that
+    holds a normal writes zero partial sums without reading a map -- the projected corners of the frustum section its rows span bound every
+    projection (mf_odometry.hip: k_icp_batch_pixels).  An exact rule: with it on and off the reduced system of EVERY iteration of every tracked
+    model (debug tap "icp_log": 19 rows of 29 sums) is bit-identical, and so are poses, counts and the label image, frame by frame -- moving,
+    tracked objects that are spawned and dropped along the way."""
+    from maskfusion_amd import MaskFusion, synth
+    st = synth.Stream(W=640, H=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, n_objects=3, noise=True, object_motion=1.0)
+    frames = [st.frame(k) for k in range(12)]
+    runs = []
+    for cull in (1, 0):
+        m = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=100.0, so3=False, numGSurfels=1 << 20, numOSurfels=1 << 18,
+                       enableMultipleModels=True, modelSpawnOffset=2, trackAllModels=True, initConfidenceGlobal=10.0, initConfidenceObject=0.01)
+        for k, v in (("mfThreshold", SEG["threshold"]), ("mfWeightDistance", SEG["weightDistance"]), ("mfWeightConvexity", SEG["weightConvexity"]),
+                     ("mfMorphEdgeIterations", 0), ("mfMorphMaskIterations", 0), ("newModelMinRelativeSize", SEG["minRelSizeNew"]),
+                     ("slabCulling", cull)):
+            m.setParam(k, v)
+        rec = []
+        for k, (rgb, depth, mask) in enumerate(frames):
+            m.processFrame(rgb, depth, mask=mask, classIDs=[0, 41, 42, 43], timestamp=k)
+            gm = m.getModels()
+            rec.append(dict(ids=[x.getID() for x in gm], poses=[x.getPose() for x in gm], counts=[x.lastCount() for x in gm],
+                            logs=[m.debugRead("icp_log", model=i).copy() for i in range(len(gm))], labels=m.downloadSegmentation().copy()))
+        m.close()
+        runs.append(rec)
+    tracked_steps = 0
+    for k, (a, b) in enumerate(zip(*runs)):
+        assert a["ids"] == b["ids"] and a["counts"] == b["counts"], (k, a["ids"], b["ids"], a["counts"], b["counts"])
+        assert np.array_equal(a["labels"], b["labels"]), k
+        for i, (p, q, la, lb) in enumerate(zip(a["poses"], b["poses"], a["logs"], b["logs"])):
+            assert np.array_equal(p, q), (k, i)
+            assert np.array_equal(la, lb, equal_nan=True), (k, i)
+            tracked_steps += int(i > 0)
+    assert max(len(r["ids"]) for r in runs[0]) >= 3 and tracked_steps >= 10
+
+
 def test_tiled_global_projection_equals_scatter_form(hip):
     """GlobalProjection of the background model through the tile lists (mf_splat.hip: k_global_tile) against the scatter form
     (k_global_scatter, one global atomicMin per covered pixel; the executable specification): the projected-id image, the label
