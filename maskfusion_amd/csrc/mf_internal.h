@@ -128,9 +128,10 @@ struct TrackModelDev {
     double* trace;                                // [20][kGnTraceRow] Gauss-Newton trace (mf_odometry.hip: gn_trace_write) or nullptr
     float jump_limit;                             // object models: 0.2 m rule of MaskFusion.cpp:268-272; background: 0
     int allow_fill;                               // Model::allowsFillIn (background only)
-    int* rect;                                    // [3][4] per pyramid level {x0, y0, x1, y1}: the pixels of nm[level] that hold a normal (an object's
-                                                  // prediction is NaN outside the object, Q3) -- written by the batched model pyramid, read by the batched
-                                                  // pixel pass (slab culling), re-armed {INT_MAX, INT_MAX, INT_MIN, INT_MIN} by the batched finalize
+    int* rect;                                    // {x0, y0, x1, y1}: the pixels of nm[0] that hold a normal (an object's prediction is NaN outside the object,
+                                                  // Q3; the coarser levels' normals lie inside it shifted by the level) -- written by the batched model
+                                                  // pyramid for object models, read by the batched pixel pass (slab culling), re-armed {INT_MAX, INT_MAX,
+                                                  // INT_MIN, INT_MIN} by the batched finalize
 };
 constexpr int kMaxTrackBatch = 32;
 constexpr int kGnTraceRow = 64;

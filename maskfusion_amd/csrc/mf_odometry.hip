@@ -933,7 +933,7 @@ __global__ __launch_bounds__(kBatchThreads) void k_icp_batch_pixels(const IcpPxA
     // If that box (grown by 2 px against the rounding of the per-pixel arithmetic) misses the model's rectangle of normals (TrackModelDev::rect,
     // grown likewise), no pixel of the workgroup can find a correspondence: its partial sums are zero, written without touching a map.
     __shared__ int s_skip;
-    if (a.row_z && beg < end) {
+    if (a.row_z && beg < end && !md->allow_fill) {     // (the background's prediction covers the image: nothing to cull)
         if (tid < 64) {
             const int r0 = beg / a.W, r1 = (end - 1) / a.W;
             float zlo = INFINITY, zhi = -INFINITY;
@@ -956,11 +956,13 @@ __global__ __launch_bounds__(kBatchThreads) void k_icp_batch_pixels(const IcpPxA
                 all_front &= __shfl_xor(all_front, off, 64);
             }
             if (tid == 0) {
-                const int* __restrict__ rc = md->rect + a.level * 4;
+                // (level-0 rectangle: a coarser level's normals lie inside it shifted right by the level -- k_model_pyramid)
+                const int rc0 = md->rect[0], rc1 = md->rect[1], rc2 = md->rect[2], rc3 = md->rect[3];
                 bool skip = !(zlo <= zhi);                                        // no valid vertex in these rows at all
                 if (!skip && all_front && ulo == ulo && uhi == uhi && vlo == vlo && vhi == vhi) {
-                    const bool empty = rc[0] > rc[2] || rc[1] > rc[3];           // the model's maps hold no normal at this level
-                    skip = empty || uhi + 2.5f < (float)rc[0] || ulo - 2.5f > (float)rc[2] || vhi + 2.5f < (float)rc[1] || vlo - 2.5f > (float)rc[3];
+                    const bool empty = rc0 > rc2 || rc1 > rc3;                   // the model's maps hold no normal
+                    skip = empty || uhi + 2.5f < (float)(rc0 >> a.level) || ulo - 2.5f > (float)(rc2 >> a.level) || vhi + 2.5f < (float)(rc1 >> a.level) ||
+                           vlo - 2.5f > (float)(rc3 >> a.level);
                 }
                 s_skip = skip ? 1 : 0;
             }
@@ -1015,7 +1017,7 @@ __global__ __launch_bounds__(256) void k_icp_batch_finalize(const IcpFinArgs a) 
     const int last = (a.n_it - 1) & 1;
     icp_finalize_body(a.n_it > 0 ? md->partials[last] : nullptr, a.n_it > 0 ? a.nb_in : 0, md->st + (a.n_it > 0 ? last : 0), md->pose, md->pose_host,
                       (md->log && a.n_it > 0) ? md->log + 32 * (a.n_it - 1) : nullptr, md->jump_limit, a.so3, s_seg, s_sys, &s_st, s_scr, md->trace, a.n_it);
-    if (threadIdx.x < 12) md->rect[threadIdx.x] = (threadIdx.x & 2) ? (int)0x80000000 : 0x7FFFFFFF;   // armed for the next frame's model pyramid
+    if (threadIdx.x < 4) md->rect[threadIdx.x] = (threadIdx.x & 2) ? (int)0x80000000 : 0x7FFFFFFF;   // armed for the next frame's model pyramid
 }
 
 // Workgroups per model of the pixel pass: enough of them over all models to fill the GPU a few times over (there is no
@@ -1579,7 +1581,6 @@ __global__ __launch_bounds__(256) void k_model_pyramid(const PyrArgs a0) {
     const float on0 = quad_bcast<0>(okn), on1 = quad_bcast<1>(okn), on2 = quad_bcast<2>(okn), on3 = quad_bcast<3>(okn);
     const bool v2ok = (ov0 != 0.f) & (ov1 != 0.f) & (ov2 != 0.f) & (ov3 != 0.f);
     bool n2ok = (on0 != 0.f) & (on1 != 0.f) & (on2 != 0.f) & (on3 != 0.f);
-    bool wrote2 = false;
     if (inside && b == 0) {
         float3 v2 = f3((va.x + vb.x + vc.x + vd.x) / 4, (va.y + vb.y + vc.y + vd.y) / 4, (va.z + vb.z + vc.z + vd.z) / 4);
         float3 n2 = normalized_rsqrt(f3((na.x + nb.x + nc.x + nd.x) / 4, (na.y + nb.y + nc.y + nd.y) / 4, (na.z + nb.z + nc.z + nd.z) / 4));
@@ -1587,26 +1588,18 @@ __global__ __launch_bounds__(256) void k_model_pyramid(const PyrArgs a0) {
         if (!n2ok) n2 = f3(qnan(), qnan(), qnan());
         n2ok = n2ok && !isnan(n2.x);
         store_tx(a.vm[2], a.nm[2], P2, y2 * W2 + x2, v2, v2ok, n2, n2ok, R, t);
-        wrote2 = n2ok;
     }
-    if (a0.b.n > 0) {
-        // batched tracker: the rectangle of pixels that hold a normal, per level (TrackModelDev::rect) -- a superset of the pixels store_tx wrote a
-        // normal to (it writes NaN wherever the flag is off), which is all the pixel pass of the Gauss-Newton loop can pair a frame pixel with
-        int* __restrict__ rect = a0.b.m[blockIdx.z]->rect;
-        int lo[3][2], hi[3][2];
-#pragma unroll
-        for (int l = 0; l < 3; ++l) { lo[l][0] = lo[l][1] = 0x7FFFFFFF; hi[l][0] = hi[l][1] = (int)0x80000000; }
-        if (inside) {
-            if (n0any) { lo[0][0] = n0x0; lo[0][1] = n0y0; hi[0][0] = n0x1; hi[0][1] = n0y1; }
-            if (n1ok) { lo[1][0] = hi[1][0] = 2 * x2 + bx; lo[1][1] = hi[1][1] = 2 * y2 + by; }
-            if (wrote2) { lo[2][0] = hi[2][0] = x2; lo[2][1] = hi[2][1] = y2; }
-        }
-#pragma unroll
-        for (int l = 0; l < 3; ++l) {
-            const int x0 = wave_min_i(lo[l][0]), y0 = wave_min_i(lo[l][1]), x1 = wave_max_i(hi[l][0]), y1 = wave_max_i(hi[l][1]);
-            if (lane == 0 && x0 <= x1) {
-                atomicMin(&rect[l * 4 + 0], x0); atomicMin(&rect[l * 4 + 1], y0); atomicMax(&rect[l * 4 + 2], x1); atomicMax(&rect[l * 4 + 3], y1);
-            }
+    if (a0.b.n > 0 && !a0.b.m[blockIdx.z]->allow_fill) {
+        // batched tracker, object models: the rectangle of level-0 pixels that hold a normal (TrackModelDev::rect) -- a superset of the pixels store_tx
+        // wrote a normal to (it writes NaN wherever the flag is off), which is all the pixel pass of the Gauss-Newton loop can pair a frame pixel
+        // with.  A level-1 / level-2 normal needs all four normals below it (resizeMapKernel), so the rectangle shifted right by the level bounds
+        // those levels too.  An object covers ~1 % of the image: nearly every wavefront sees no normal at all and leaves after one ballot.
+        if (__ballot(inside && n0any) != 0ull) {
+            int* __restrict__ rect = a0.b.m[blockIdx.z]->rect;
+            const bool on = inside && n0any;
+            const int x0 = wave_min_i(on ? n0x0 : 0x7FFFFFFF), y0 = wave_min_i(on ? n0y0 : 0x7FFFFFFF);
+            const int x1 = wave_max_i(on ? n0x1 : (int)0x80000000), y1 = wave_max_i(on ? n0y1 : (int)0x80000000);
+            if (lane == 0) { atomicMin(&rect[0], x0); atomicMin(&rect[1], y0); atomicMax(&rect[2], x1); atomicMax(&rect[3], y1); }
         }
     }
 }
