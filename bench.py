@@ -951,7 +951,18 @@ def main():
             try:
                 mf.close()        # the dense scenario holds ~6 GB of maps: it gets the GPU to itself
                 d_rgb = d_depth = None
-                variants = dict(variants or {}, config4_stress=config4_scene(local_rank, frames4, room_job, seconds=0.0, frames_per_rep=30))
+                room4 = room_job.result() if room_job is not None else None
+
+                class _Room:          # (the generated map is handed to both runs)
+                    def result(self):
+                        return room4
+                c4 = config4_scene(local_rank, frames4, _Room(), seconds=0.0, frames_per_rep=30, tracked=True)
+                try:                  # rounds 4-5's scenario beside it: the objects stand and follow the camera (one Gauss-Newton loop per frame)
+                    st4 = config4_scene(local_rank, frames4, _Room(), seconds=0.0, frames_per_rep=30, stages_frames=4, tracked=False)
+                    c4["static_objects"] = {k: st4[k] for k in ("workload", "value", "unit", "ms_per_step", "steps", "tracked_models", "surfels_at_start", "roofline_frame")}
+                except Exception as e:
+                    print(f"[bench] configs[4] with static objects not measured: {e!r}", file=sys.stderr)
+                variants = dict(variants or {}, config4_stress=c4)
             except Exception as e:
                 print(f"[bench] configs[4] stress variant not measured: {e!r}", file=sys.stderr)
 

@@ -200,7 +200,8 @@ __device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* ti
     const bool overflow = s_range[0] > tile_cap;   // more sprites than list slots (the reference has no such limit): scan every box
     // (after an overflow: every surfel whose sprite box the binning pass wrote -- the runs of the visibility list, every run of the table, or
     // -- a dense buffer without a table -- every slot)
-    const int table_runs = frame->runs;
+    // (looked at after an overflow only: the common path waits for nothing but its list)
+    const int table_runs = overflow ? frame->runs : 0;
     const bool by_runs = vis_list != nullptr || table_runs > 0;
     const int cnt = overflow ? (by_runs ? (vis_list ? *vis_count : table_runs) * kRun : frame->count) : s_range[0];
     const int* __restrict__ list = entries + (size_t)tile * tile_cap;
