@@ -1,15 +1,15 @@
 #!/bin/bash
-# Measurement artefacts of round 5 (run through gpurun from the repo root; one call).
+# Measurement artefacts of round 6 (run through gpurun from the repo root; one call).
 #   gpurun_out/<tag>_pytest.log                the whole -m gpu suite as the driver runs it (pytest.ini: 6 xdist workers), with its wall time
 #   gpurun_out/<tag>_bench.json                bench.py as the driver runs it (--steps 20 --warmup 5), with its `variants`
 #   gpurun_out/<tag>_bench_c4.json             bench.py --config 4: configs[4] as specified (dense maps)
 #   gpurun_out/<tag>_kernel_stats.csv          rocprofv3 --kernel-trace --stats, configs[1]
 #   gpurun_out/<tag>_c4_kernel_stats_raw.csv   the same for --config 4 (lead-in launches included)
-#   gpurun_out/<tag>_c4_kernel_stats.csv       ... its dense phase only (tools/c4_dense_summary.py over the kernel trace): what bench.py's roofline_kernels reads
+#   gpurun_out/<tag>_c4_kernel_stats.csv       ... its dense phase only (tools/c4_dense_summary.py over the kernel trace): the per-kernel table DESIGN.md section 4 quotes
 #   gpurun_out/<tag>_c4_pmc_fetch.csv / _c4_pmc_write.csv / _calib_*.csv / <tag>_c4_hbm.json   separate --pmc FETCH_SIZE / WRITE_SIZE passes over --config 4
 #                                              (dense launches: the last 30 of each kernel) + calibration
 #   gpurun_out/<tag>_pmc_fetch.csv / _pmc_write.csv / <tag>_pmc.json     the same two passes over configs[1] (what bench.py's roofline.traffic reads)
-TAG=${1:-r05}
+TAG=${1:-r06}
 REPO=$(pwd)
 CACHE=/tmp/mf_frames
 mkdir -p gpurun_out
@@ -57,15 +57,6 @@ cd $REPO
 TREE="$(git rev-parse --short HEAD 2>/dev/null || cat .tree_id 2>/dev/null)"
 python tools/make_pmc_json.py ${TAG} gpurun_out/${TAG}_pmc_fetch.csv gpurun_out/${TAG}_pmc_write.csv gpurun_out/${TAG}_calib_fetch.csv gpurun_out/${TAG}_calib_write.csv "$TREE" gpurun_out/${TAG}_pmc.json
 python tools/make_pmc_json.py ${TAG}_c4 gpurun_out/${TAG}_c4_pmc_fetch.csv gpurun_out/${TAG}_c4_pmc_write.csv gpurun_out/${TAG}_calib_fetch.csv gpurun_out/${TAG}_calib_write.csv "$TREE" gpurun_out/${TAG}_c4_hbm.json
-# phase times of every chunk of the background's clean pass (instrumented build of mf_surfel.hip, tools/clean_prof.py)
-if [ -f tools/ab/libmaskfusion_amd_prof.so ]; then
-  cp maskfusion_amd/libmaskfusion_amd.so /tmp/lib_product.so
-  cp tools/ab/libmaskfusion_amd_prof.so maskfusion_amd/libmaskfusion_amd.so
-  timeout 300 python tools/clean_prof.py ${TAG} > gpurun_out/${TAG}_clean_prof.txt 2>&1
-  cp /tmp/lib_product.so maskfusion_amd/libmaskfusion_amd.so
-  rm -f gpurun_out/${TAG}_clean_prof.npy
-  cat gpurun_out/${TAG}_clean_prof.txt | head -12
-fi
 tail -3 /tmp/prof_4f.log | cut -c1-200
 cut -c1-300 gpurun_out/${TAG}_bench.json
 cut -c1-300 gpurun_out/${TAG}_bench_c4.json
