@@ -485,7 +485,7 @@ class RoomMapJob:
 C4_PASS_BYTES = {
     "bgGlobalProjection": lambda N, V, P, n: (48.0 * N, 48.0 * V),
     "bgIndexMap": lambda N, V, P, n: (48.0 * N + 52.0 * P, 48.0 * V + 52.0 * P),
-    "bgFuseData": lambda N, V, P, n: (P / 4 * 48.0 + 27.0 * 36.0 * P / 4, P / 4 * 48.0 + 27.0 * 36.0 * P / 4),     # candidates: 48 B records + the 27 window taps of 36 B
+    "bgFuseData": lambda N, V, P, n: (76.0 * P, 76.0 * P),                         # the frame (rgb 3 + raw / filtered depth 8 + mask 1), the index map's 52 P, candidate records 48 B x P / 4
     "bgFuseUpdate": lambda N, V, P, n: (48.0 * N, 0.0),                            # update.vert: the reference copies the buffer; here only merged surfels move
     "bgIndexMap2": lambda N, V, P, n: (48.0 * N + 52.0 * P, 48.0 * V + 52.0 * P),
     "bgClean": lambda N, V, P, n: (96.0 * N, 48.0 * V),                            # THE read-modify-write of the frame; in place: the listed runs are read, what changes is written
