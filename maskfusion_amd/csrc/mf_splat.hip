@@ -70,7 +70,7 @@ int splat_sprite_lanes(int n) { return (n == 1 || n == 2 || n == 8 || n == 16) ?
 // chain of the pixel test (tools/splat_prof.py: a tile workgroup lives ~32 k cycles, ~4 k of them issuing)
 // Measured (profiles/r03k_*, prediction stage incl. binning): 256 threads 62.6 us, 512 threads 58.0 us, 1024 threads 65.9 us (4 lanes per
 // sprite each) -- 512 is the default.
-int splat_tile_threads(int n) { return (n == 256 || n == 1024) ? n : 512; }
+int splat_tile_threads(int n) { return (n == 256 || n == 320 || n == 384 || n == 1024) ? n : 512; }
 
 struct BinArgs {
     Surfels src; const FrameDev* frame; const PoseDev* pose; int W, H; Intr k; float maxDepth, confThreshold; int timeDelta;
