@@ -165,6 +165,16 @@ struct mf_ctx {
     static constexpr int kObjArgSlots = 8;             // argument arrays of the batched launches: pinned staging + device copy, a small ring (two per frame)
     ObjPassArgs* d_obj_args[kObjArgSlots] = {}; ObjPassArgs* h_obj_args[kObjArgSlots] = {}; hipEvent_t ev_obj_args[kObjArgSlots] = {};
     unsigned obj_arg_slot = 0;
+    // "objectStream": inside mf_process_frame the batched passes of the object models (fuse / clean chain, prediction) go to a stream of their own
+    // and run BESIDE the background's chain on the main stream -- the two touch disjoint buffers (an object model's private scratch, its own maps) and
+    // share read-only inputs (frame, label image, poses).  Fork: behind the label stage (the host has waited for it); join: the end of the frame.
+    // obj_s: where the batched object passes are enqueued right now (the main stream outside that window); obj_dep_main: main-stream work the object
+    // chain depends on has been enqueued since the fork (a spawn, a compaction) -- the object stream waits for it first.
+    bool object_stream = true;
+    hipStream_t stream_obj = nullptr, obj_s = nullptr;
+    hipEvent_t ev_obj_dep = nullptr, ev_obj_done = nullptr;
+    bool obj_dep_main = false;
+    uint8_t* d_maskT_obj = nullptr;                    // the object chain's own copy of d_maskT (every packed resolve pass writes the whole plane)
     bool ftf_rgb = false;                              // MaskFusion::frameToFrameRGB ("-ftf"; Model.cpp:399-400,981): the photometric term tracks against the previous RAW frame
     double host_us[5] = {0, 0, 0, 0, 0}; long host_calls = 0;   // mf_process_frame's host time: wait for the slot + staging copy | upload enqueue | frame enqueue | whole call | the wait alone ("hostStageUs" ... "hostWaitUs")
     // "hostLockstep" (default on): the call waits for frame k-2 to have RUN before it enqueues frame k's upload, so the host is at most two
@@ -499,6 +509,10 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
             hipEventCreateWithFlags(&c->ev_in_consumed[i], hipEventDisableTiming) != hipSuccess) return fail(MF_EHIP);
     }
     if (hipStreamCreateWithFlags(&c->stream_in, hipStreamNonBlocking) != hipSuccess) return fail(MF_EHIP);
+    if (hipStreamCreateWithFlags(&c->stream_obj, hipStreamNonBlocking) != hipSuccess) return fail(MF_EHIP);
+    if (hipEventCreateWithFlags(&c->ev_obj_dep, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_obj_done, hipEventDisableTiming) != hipSuccess) return fail(MF_EHIP);
+    c->obj_s = c->stream;
     A(dev_alloc(c, c->allocs, &c->d_zero_mask, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_mask_tex, (size_t)P));
     for (int b = 0; b < 3; ++b) A(dev_alloc(c, c->allocs, &c->d_depthF[b], (size_t)P));
@@ -547,6 +561,7 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     A(dev_alloc(c, c->allocs, &c->d_ict, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_iclean, (size_t)P * 2));
     A(dev_alloc(c, c->allocs, &c->d_maskT, (size_t)P));
+    A(dev_alloc(c, c->allocs, &c->d_maskT_obj, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_inr, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_cand_op, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_cand_rec, (size_t)P * 3));
@@ -625,6 +640,9 @@ extern "C" void mf_destroy(mf_ctx* c) {
         if (c->ev_in_consumed[i]) (void)hipEventDestroy(c->ev_in_consumed[i]);
     }
     if (c->stream_in) { (void)hipStreamSynchronize(c->stream_in); (void)hipStreamDestroy(c->stream_in); }
+    if (c->stream_obj) { (void)hipStreamSynchronize(c->stream_obj); (void)hipStreamDestroy(c->stream_obj); }
+    if (c->ev_obj_dep) (void)hipEventDestroy(c->ev_obj_dep);
+    if (c->ev_obj_done) (void)hipEventDestroy(c->ev_obj_done);
     for (int i = 0; i < mf_ctx::kObjArgSlots; ++i) {
         if (c->d_obj_args[i]) (void)hipFree(c->d_obj_args[i]);
         if (c->h_obj_args[i]) (void)hipHostFree(c->h_obj_args[i]);
@@ -1026,6 +1044,7 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     }
     if (!strcmp(key, "batchTracking")) { c->batch_tracking = value != 0; return MF_OK; }
     if (!strcmp(key, "frameToFrameRGB")) { c->ftf_rgb = value != 0; return MF_OK; }         // MaskFusion::setFrameToFrameRGB (Core/MaskFusion.cpp:910)
+    if (!strcmp(key, "objectStream")) { c->object_stream = value != 0; return MF_OK; }   // 0: the object models' batched passes on the main stream, behind the background's
     if (!strcmp(key, "batchObjectPasses")) { c->batch_objects = value != 0; return MF_OK; }  // 0: the object models' surfel passes model by model
     if (!strcmp(key, "objectBoundingBoxLimit")) { c->bbox_limit = value != 0; return MF_OK; }   // 0: a headless upstream that never renders (bb_max_z = FLT_MAX)
     if (!strcmp(key, "literalFusionWeight")) {

@@ -9,19 +9,49 @@ static void mark(mf_ctx* c, int i, hipStream_t s = nullptr) {
 // "passTimings": an event pair around the launches of one surfel pass (labels: maskfusion_amd.h, MF_PASS_*); a pass that runs several times in a
 // frame (object models handled one by one) keeps its last run
 struct PassTimer {
-    mf_ctx* c; int id;
-    PassTimer(mf_ctx* c_, int id_) : c(c_), id(id_) {
+    mf_ctx* c; int id; hipStream_t s;
+    PassTimer(mf_ctx* c_, int id_, hipStream_t s_ = nullptr) : c(c_), id(id_), s(s_ ? s_ : c_->stream) {
         if (!c->pass_timings_on || id < 0) return;
         for (int q = 0; q < 2; ++q)
             if (!c->ev_pass[id][q] && hipEventCreate(&c->ev_pass[id][q]) != hipSuccess) { (void)hipGetLastError(); c->ev_pass[id][q] = nullptr; }
-        if (c->ev_pass[id][0]) (void)hipEventRecord(c->ev_pass[id][0], c->stream);
+        if (c->ev_pass[id][0]) (void)hipEventRecord(c->ev_pass[id][0], s);
     }
     ~PassTimer() {
         if (!c->pass_timings_on || id < 0 || !c->ev_pass[id][0] || !c->ev_pass[id][1]) return;
-        (void)hipEventRecord(c->ev_pass[id][1], c->stream);
+        (void)hipEventRecord(c->ev_pass[id][1], s);
         c->pass_recorded[id] = true;
     }
 };
+
+// "objectStream": the window of a frame in which the batched object passes go to their own stream (mf_context.hip).  begin: behind the label
+// stage, which the host has waited for -- nothing the object chain reads is still being written on the main stream unless obj_dep_main says so.
+// The destructor joins: the main stream waits for the object stream, so that everything behind the frame (the next frame, every getter) sees
+// one stream again.
+struct ObjStreamWindow {
+    mf_ctx* c; bool open = false;
+    explicit ObjStreamWindow(mf_ctx* c_) : c(c_) {}
+    void begin() {
+        if (open || !c->object_stream || !c->stream_obj || c->timings_on) return;   // (the stage timings bracket the main stream: one stream while they are on)
+        open = true;
+        c->obj_s = c->stream_obj;
+        c->obj_dep_main = false;
+    }
+    ~ObjStreamWindow() {
+        if (!open) return;
+        (void)hipEventRecord(c->ev_obj_done, c->stream_obj);
+        (void)hipStreamWaitEvent(c->stream, c->ev_obj_done, 0);
+        c->obj_s = c->stream;
+        c->obj_dep_main = false;
+    }
+};
+// before the object chain's launches: if main-stream work it depends on was enqueued inside the window (a spawned model's first fusion, a
+// compaction, a fresh run table), the object stream waits for the main stream as it stands now
+static void obj_stream_catch_up(mf_ctx* c) {
+    if (c->obj_s == c->stream || !c->obj_dep_main) return;
+    (void)hipEventRecord(c->ev_obj_dep, c->stream);
+    (void)hipStreamWaitEvent(c->obj_s, c->ev_obj_dep, 0);
+    c->obj_dep_main = false;
+}
 
 // ------------------------------------------------------------------------------------------------
 // per-model stages
@@ -222,6 +252,7 @@ static bool append_mirror_fits(const mf_ctx* c, const ModelState& m) {
 // compaction of m's sparse buffer: the surfels of its runs -> the other buffer, dense, no table (launch_densify); that one is live afterwards
 static void densify(mf_ctx* c, ModelState& m) {
     launch_densify(m.surf[m.cur], m.surf[1 - m.cur], m.d_frame, c->d_run_offs, m.h_count, c->stream);
+    c->obj_dep_main = true;
     m.cur = 1 - m.cur;
     m.sparse = false; m.table_valid = false; m.phys_ub = m.runs_ub = -1; m.gen++;
     m.mirror_from = m.clean_seq + 1;      // (mirrors of earlier passes describe the buffer that was)
@@ -261,6 +292,7 @@ static int prepare_in_place(mf_ctx* c, ModelState& m, bool& ok) {
     }
     if (!m.table_valid) {
         launch_run_table(m.surf[m.cur], m.d_frame, c->stream);
+        c->obj_dep_main = true;
         m.table_valid = true; m.gen++;
     }
     return MF_OK;
@@ -413,8 +445,10 @@ static void enqueue_predict(mf_ctx* c, ModelState& m, const FrameAdvance* advanc
 // device on the stream; the slot's event guards its reuse (the host is at most a frame ahead in a multi-model scene: it waits for the
 // label stage every frame).  weightMultiplier / log slots are filled by the caller where they matter.
 static int make_obj_batch(mf_ctx* c, const std::vector<ModelState*>& ms, const std::vector<int>& orders, const uint8_t* d_rgb, const float* d_depth,
-                          const float* depthF, const uint8_t* mask, float weightMultiplier, const std::vector<float*>* log_slots, ObjBatch& b, int& blocks) {
+                          const float* depthF, const uint8_t* mask, float weightMultiplier, const std::vector<float*>* log_slots, ObjBatch& b, int& blocks,
+                          hipStream_t s = nullptr) {
     const mf_config& g = c->cfg;
+    if (!s) s = c->stream;
     const int slot = (int)(c->obj_arg_slot++ % mf_ctx::kObjArgSlots);
     MF_HIP(c, hipEventSynchronize(c->ev_obj_args[slot]));
     ObjPassArgs* h = c->h_obj_args[slot];
@@ -437,14 +471,14 @@ static int make_obj_batch(mf_ctx* c, const std::vector<ModelState*>& ms, const s
         a.global_payload = ((unsigned)orders[i] << 8) | ((unsigned)m.id & 255u);
         blocks = std::max(blocks, surfel_blocks(c, m));
     }
-    MF_HIP(c, hipMemcpyAsync(c->d_obj_args[slot], h, sizeof(ObjPassArgs) * ms.size(), hipMemcpyHostToDevice, c->stream));
-    MF_HIP(c, hipEventRecord(c->ev_obj_args[slot], c->stream));
+    MF_HIP(c, hipMemcpyAsync(c->d_obj_args[slot], h, sizeof(ObjPassArgs) * ms.size(), hipMemcpyHostToDevice, s));
+    MF_HIP(c, hipEventRecord(c->ev_obj_args[slot], s));
     b.m = c->d_obj_args[slot]; b.n = (int)ms.size();
     b.W = c->W; b.H = c->H; b.k = c->K; b.maxDepthProcessed = g.max_depth_processed; b.globalMaxDepth = g.depth_cutoff; b.timeDelta = g.time_delta;
     b.outlierCoeff = g.outlier_coefficient; b.cleanLiteral = c->clean_literal ? 1 : 0; b.bboxLimit = c->bbox_limit ? 1 : 0; b.cleanSmall = 0; b.updateCopy = 0;
     b.denseSprites = 0;
     for (ModelState* m : ms) if ((long)*m->h_count >= (long)c->in_place_elements) b.denseSprites = 1;
-    b.rgb = d_rgb; b.depthRaw = d_depth; b.depthF = depthF; b.mask = mask; b.maskT = c->d_maskT; b.bg_pose = c->models[0]->d_pose; b.global_keys = c->d_keys;
+    b.rgb = d_rgb; b.depthRaw = d_depth; b.depthF = depthF; b.mask = mask; b.maskT = s == c->stream ? c->d_maskT : c->d_maskT_obj; b.bg_pose = c->models[0]->d_pose; b.global_keys = c->d_keys;
     return MF_OK;
 }
 // every object model of the list, with its position in the list (the GlobalProjection payload)
@@ -616,15 +650,16 @@ static int enqueue_fusion_loop(mf_ctx* c, size_t first, bool multi, const uint8_
         } else in_place = false;
         if (!in_place) for (ModelState* m : objs) require_dense(c, *m);
         ObjBatch ob; int blocks = 0;
-        int rc = make_obj_batch(c, objs, orders, d_rgb, d_depth, depthF, mask, weight_multiplier, nullptr, ob, blocks);   // (after the compactions: they change the live buffer)
+        obj_stream_catch_up(c);
+        int rc = make_obj_batch(c, objs, orders, d_rgb, d_depth, depthF, mask, weight_multiplier, nullptr, ob, blocks, c->obj_s);   // (after the compactions: they change the live buffer)
         if (rc != MF_OK) return rc;
         int cblocks = 64;
         for (ModelState* m : objs) cblocks = std::max(cblocks, clean_runs_grid((long)*m->h_count + kRun));
         ob.cleanSmall = in_place ? 0 : 1; ob.updateCopy = in_place ? 0 : 1;
         if (!in_place) for (ModelState* m : objs) if (!update_copy(c, *m)) ob.updateCopy = 0;
         {
-            PassTimer timer(c, MF_PASS_OBJ_FUSE_CLEAN);
-            launch_obj_fuse_clean(ob, blocks, cblocks, c->stream);
+            PassTimer timer(c, MF_PASS_OBJ_FUSE_CLEAN, c->obj_s);
+            launch_obj_fuse_clean(ob, blocks, cblocks, c->obj_s);
         }
         for (ModelState* m : objs) {   // copy-update: a -> b -> a; in-place update + two-launch clean: a -> b -- b is the live buffer now; in place: a
             if (!in_place && !ob.updateCopy) m->cur = 1 - m->cur;
@@ -666,10 +701,11 @@ static int enqueue_predict_loop(mf_ctx* c, size_t first, bool may_batch, int64_t
             m->age++;
         }
         ObjBatch ob; int blocks = 0;
-        int rc = make_obj_batch(c, objs, orders, d_rgb, d_depth, depthF, mask, weight_multiplier, &slots, ob, blocks);
+        obj_stream_catch_up(c);
+        int rc = make_obj_batch(c, objs, orders, d_rgb, d_depth, depthF, mask, weight_multiplier, &slots, ob, blocks, c->obj_s);
         if (rc != MF_OK) return rc;
-        PassTimer timer(c, MF_PASS_OBJ_PREDICT);
-        launch_obj_predict_advance(ob, blocks, c->stream);
+        PassTimer timer(c, MF_PASS_OBJ_PREDICT, c->obj_s);
+        launch_obj_predict_advance(ob, blocks, c->obj_s);
         return MF_OK;
     }
     for (size_t i = first; i < c->models.size(); ++i) {
@@ -763,6 +799,7 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
     ModelState& bg = *c->models[0];
     bool bg_fused = false;
     c->mm_marked = false;
+    ObjStreamWindow obj_window(c);   // (joins on every way out of this function)
 
     int prc = enqueue_preprocess(c, d_rgb, d_depth, k, c->map_ready);
     if (prc != MF_OK) return prc;
@@ -863,6 +900,8 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
                 if (haveMasks) MF_HIP(c, hipMemcpyAsync(c->h_mask, d_mask_in, (size_t)P, hipMemcpyDeviceToHost, s));
                 MF_HIP(c, hipStreamSynchronize(s));  // the one host visit of a multi-model frame (the reference leaves the GPU here too)
             }
+            // the label image is complete and the host knows it: from here on the object models' batched passes have a stream of their own
+            obj_window.begin();
 
             // inactivateModel for objects the jump rule dropped (:268-272); data is deleted (no re-detection upstream)
             for (size_t i = 1; i < c->models.size();) {
@@ -878,11 +917,13 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
                 segmentation_host(c->seg, W, H, c->h_bin, c->h_depth, c->h_mask, haveMasks ? class_ids : kNoClass, haveMasks ? n_masks : 0,
                                   c->h_ids, infos, c->nextID, c->spawnOffset >= g.model_spawn_offset, c->ignoreMap, c->h_full, res);
                 MF_HIP(c, hipMemcpyAsync(c->d_mask_tex, c->h_full, (size_t)P, hipMemcpyHostToDevice, s));  // :297
+                c->obj_dep_main = true;   // (the label image arrives on the main stream)
             }
             bool spawned = false;
             if (res.hasNewLabel && (int)c->models.size() < g.max_models) {
                 int rc = spawn_object(c, take_next_model_id(c), res.newClassID);
                 if (rc != MF_OK) return rc;
+                c->obj_dep_main = true;   // (its initialisation and first fusion are main-stream work the object chain has to see)
                 c->spawnOffset = 0;
                 spawned = true;
             }

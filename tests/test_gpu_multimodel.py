@@ -287,3 +287,12 @@ def test_object_model_launch_switches_change_nothing(hip):
     assert same(base, run(**dict(off, batchObjectPasses=1)))
     assert same(base, run())          # the defaults since round 3: all three on
     assert same(run(track_all=True, **off), run(track_all=True))   # ... and with the objects tracked (spawns, drops by the jump rule)
+    # "objectStream" (round 6): the batched object passes on a stream of their own, beside the background's chain -- disjoint buffers, the same bits;
+    # repeated, since what it could break is an ordering between two streams
+    one_stream = run(objectStream=0)
+    assert same(base, one_stream)
+    for _ in range(3):
+        assert same(one_stream, run(objectStream=1))
+    tracked_one = run(track_all=True, objectStream=0)
+    for _ in range(2):
+        assert same(tracked_one, run(track_all=True, objectStream=1))
