@@ -170,6 +170,10 @@ struct mf_ctx {
     // share read-only inputs (frame, label image, poses).  Fork: behind the label stage (the host has waited for it); join: the end of the frame.
     // obj_s: where the batched object passes are enqueued right now (the main stream outside that window); obj_dep_main: main-stream work the object
     // chain depends on has been enqueued since the fork (a spawn, a compaction) -- the object stream waits for it first.
+    // "fusedPreprocessLaunch": a single tracked background's model-side pyramid is built in the depth filter's launch (k_bilateral_model_pyramid);
+    // pyr_done: the model whose pyramid of THIS frame that launch has built (enqueue_track then skips its own launch)
+    bool fused_preprocess = true;
+    ModelState* pyr_done = nullptr;
     bool object_stream = true;
     hipStream_t stream_obj = nullptr, obj_s = nullptr;
     hipEvent_t ev_obj_dep = nullptr, ev_obj_done = nullptr;
@@ -1044,6 +1048,7 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     }
     if (!strcmp(key, "batchTracking")) { c->batch_tracking = value != 0; return MF_OK; }
     if (!strcmp(key, "frameToFrameRGB")) { c->ftf_rgb = value != 0; return MF_OK; }         // MaskFusion::setFrameToFrameRGB (Core/MaskFusion.cpp:910)
+    if (!strcmp(key, "fusedPreprocessLaunch")) { c->fused_preprocess = value != 0; return MF_OK; }   // 0: k_bilateral and k_model_pyramid as two launches
     if (!strcmp(key, "objectStream")) { c->object_stream = value != 0; return MF_OK; }   // 0: the object models' batched passes on the main stream, behind the background's
     if (!strcmp(key, "batchObjectPasses")) { c->batch_objects = value != 0; return MF_OK; }  // 0: the object models' surfel passes model by model
     if (!strcmp(key, "objectBoundingBoxLimit")) { c->bbox_limit = value != 0; return MF_OK; }   // 0: a headless upstream that never renders (bb_max_z = FLT_MAX)

@@ -75,8 +75,9 @@ static void enqueue_track(mf_ctx* c, ModelState& m, const float* fillDepth, floa
     float* const* cur_nmap = c->d_nmap[set];
     const int W = c->W, H = c->H;
     hipStream_t s = c->stream;
-    launch_model_pyramid(m.d_predV, m.d_predN, m.allowFillIn ? fillDepth : nullptr, m.d_frame, m.d_pose, nullptr, m.d_vmap_g,
-                         m.d_nmap_g, W, H, c->K, s);
+    if (c->pyr_done == &m) c->pyr_done = nullptr;   // built beside the frame's depth filter (enqueue_preprocess, "fusedPreprocessLaunch")
+    else launch_model_pyramid(m.d_predV, m.d_predN, m.allowFillIn ? fillDepth : nullptr, m.d_frame, m.d_pose, nullptr, m.d_vmap_g,
+                              m.d_nmap_g, W, H, c->K, s);
     const bool rgb = photometric_on(c);
     const bool icp = !g.rgb_only && g.icp_weight > 0.f;
     // the previous frame's intensity pyramid is RGBDOdometry::lastNextImage (identical for every tracked model)
@@ -510,7 +511,10 @@ static int take_next_model_id(mf_ctx* c) {
 // derivative images, for frame index k (buffer set k & 1, filtered-depth ring slot k % 3).
 // (It runs at the head of the frame's chain on the context's stream.  Running it one frame ahead on a stream of its own, beside the previous
 // frame's fusion kernels, lost in rounds 2 and 5 -- also with that stream masked to 16 / 32 / 64 compute units: DESIGN.md, "Measured and rejected".)
-static int enqueue_preprocess(mf_ctx* c, const uint8_t* d_rgb, const float* d_depth, long k, bool with_maps) {
+// pyr_model: the model whose tracking step follows on this stream with nothing in between that its model-side pyramid depends on -- the pyramid
+// (launch_model_pyramid's arguments, as enqueue_track passes them) is then built in the filter's launch
+static int enqueue_preprocess(mf_ctx* c, const uint8_t* d_rgb, const float* d_depth, long k, bool with_maps, ModelState* pyr_model = nullptr,
+                              const float* pyr_fill_depth = nullptr) {
     const int W = c->W, H = c->H, P = c->P;
     hipStream_t s = c->stream;
     const mf_config& g = c->cfg;
@@ -518,7 +522,14 @@ static int enqueue_preprocess(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
     float* depthF = c->d_depthF[k % 3];
     hipStream_t sp = s;
     mark(c, 0, sp);
-    launch_bilateral(d_depth, depthF, W, H, sp);
+    if (pyr_model) {
+        ModelState& m = *pyr_model;
+        launch_bilateral_model_pyramid(d_depth, depthF, m.d_predV, m.d_predN, m.allowFillIn ? pyr_fill_depth : nullptr, m.d_frame, m.d_pose, m.d_vmap_g,
+                                       m.d_nmap_g, W, H, c->K, sp);
+        c->pyr_done = pyr_model;
+    } else {
+        launch_bilateral(d_depth, depthF, W, H, sp);
+    }
     if (with_maps) {   // the frame that initialises the map is never tracked against: no vertex / normal maps needed
         launch_frame_pyramid(depthF, c->d_vmap[set], c->d_nmap[set], W, H, c->K, g.depth_cutoff, sp);
     }
@@ -602,9 +613,10 @@ static int spawn_object(mf_ctx* c, int id, int classID) {
 // The tracking loop of processFrame (Core/MaskFusion.cpp:247-276) over models[first..]: every model that is tracked this frame goes
 // into one batch (geometric term) or is tracked on its own (photometric term: its scratch images are shared); static objects then follow
 // the background's NEW pose (models[0]'s pose: on a context that holds only objects the caller has overridden it with the owner's).
-static void enqueue_tracking_loop(mf_ctx* c, size_t first, bool track_all, const float* depthF_prev, long k) {
+// which models the tracking loop tracks and which follow the background (MaskFusion.cpp:261-274); true: the tracked ones go through the batched loop
+static bool tracking_plan(mf_ctx* c, size_t first, bool track_all, std::vector<ModelState*>& tracked, std::vector<ModelState*>& follow) {
     ModelState& bg = *c->models[0];
-    std::vector<ModelState*> tracked, follow;
+    tracked.clear(); follow.clear();
     if (first == 0) tracked.push_back(&bg);
     for (size_t i = 1; i < c->models.size(); ++i) {
         ModelState& m = *c->models[i];
@@ -614,7 +626,12 @@ static void enqueue_tracking_loop(mf_ctx* c, size_t first, bool track_all, const
         if ((!m.isStatic || track_all) && trackable) tracked.push_back(&m);   // jump rule of :268-272 in the finalize step
         else follow.push_back(&m);
     }
-    if (!photometric_on(c) && tracked.size() >= 2 && (int)tracked.size() <= kMaxTrackBatch && c->batch_tracking) {
+    return !photometric_on(c) && tracked.size() >= 2 && (int)tracked.size() <= kMaxTrackBatch && c->batch_tracking;
+}
+static void enqueue_tracking_loop(mf_ctx* c, size_t first, bool track_all, const float* depthF_prev, long k) {
+    ModelState& bg = *c->models[0];
+    std::vector<ModelState*> tracked, follow;
+    if (tracking_plan(c, first, track_all, tracked, follow)) {
         enqueue_track_batch(c, tracked, depthF_prev, k);
     } else {
         for (ModelState* m : tracked) enqueue_track(c, *m, m == &bg ? depthF_prev : nullptr, m == &bg ? 0.f : 0.2f, k);
@@ -801,7 +818,15 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
     c->mm_marked = false;
     ObjStreamWindow obj_window(c);   // (joins on every way out of this function)
 
-    int prc = enqueue_preprocess(c, d_rgb, d_depth, k, c->map_ready);
+    // the background's tracking step follows the preprocessing directly (model by model: the batched loop builds every model's pyramid in its own
+    // launch): its model-side pyramid rides in the depth filter's launch
+    ModelState* pyr_model = nullptr;
+    c->pyr_done = nullptr;
+    if (c->fused_preprocess && c->map_ready && !(in_pose16 && !bootstrap)) {
+        std::vector<ModelState*> tracked, follow;
+        if (!tracking_plan(c, 0, g.track_all_models != 0, tracked, follow)) pyr_model = &bg;
+    }
+    int prc = enqueue_preprocess(c, d_rgb, d_depth, k, c->map_ready, pyr_model, depthF_prev);
     if (prc != MF_OK) return prc;
 
     if (!c->map_ready) {

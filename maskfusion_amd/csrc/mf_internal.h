@@ -138,6 +138,9 @@ constexpr int kGnTraceRow = 64;
 struct TrackBatch { const TrackModelDev* m[kMaxTrackBatch]; int n; };   // by value in the kernel arguments
 
 // ---------------- preprocessing ----------------
+void launch_bilateral_model_pyramid(const float* depth, float* depthF, const float4* predV, const float4* predN, const float* fillDepth,
+                                    const FrameDev* frame, const PoseDev* pose, float* const vmaps[3], float* const nmaps[3], int W, int H, Intr k,
+                                    hipStream_t s);   // the filter + launch_model_pyramid's work in one launch (mf_odometry.hip)
 void launch_bilateral(const float* depth, float* out, int W, int H, hipStream_t s);
 void launch_pyrdown_f(const float* src, float* dst, int sw, int sh, hipStream_t s);
 void launch_vmap_nmap(const float* depth, float* vmap, float* nmap, int W, int H, Intr k, float cutoff, hipStream_t s);

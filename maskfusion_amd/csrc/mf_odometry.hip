@@ -21,6 +21,7 @@
 #include "mf_internal.h"
 #include "mf_device.h"
 #include "mf_rgbd_device.h"
+#include "mf_bilateral_device.h"
 
 namespace mf {
 
@@ -1480,12 +1481,22 @@ __device__ __forceinline__ MapPx load_model_px(const float4* __restrict__ predV,
     return r;
 }
 
+// R a with the fused multiply-adds written out.  This file allows contraction, and under "fast" the back end decides per use WHICH product of
+// (R0 ax + R1 ay) + R2 az keeps its own rounding -- by operand order after scheduling: moving this kernel's body into a function (round 6) turned
+// the level-2 normals' R1 ay into R0 ax and every fifth normal moved by an ulp, enough to shift a tracked pose by 1e-7 and flip a surfel of a
+// count-exact test.  The form below is the one every use of the kernel compiled to through rounds 1-5; written out it no longer depends on context.
+__device__ __forceinline__ float3 mul33_fixed(const float* R, float3 a) {
+#pragma clang fp contract(off)
+    return f3(fmaf(R[2], a.z, fmaf(R[0], a.x, R[1] * a.y)), fmaf(R[5], a.z, fmaf(R[3], a.x, R[4] * a.y)),
+              fmaf(R[8], a.z, fmaf(R[6], a.x, R[7] * a.y)));
+}
+
 __device__ __forceinline__ void store_tx(float* __restrict__ vm, float* __restrict__ nm, int P, int i, float3 v, bool vok,
                                          float3 n, bool nok, const float* R, float3 t) {
     // tranformMapsKernel, cudafuncs.cu:207-249
     float3 vd = f3(qnan(), qnan(), qnan()), nd = vd;
-    if (vok) vd = mul33(R, v) + t;
-    if (nok) nd = mul33(R, n);
+    if (vok) vd = mul33_fixed(R, v) + t;
+    if (nok) nd = mul33_fixed(R, n);
     vm[i] = vd.x; vm[P + i] = vd.y; vm[2 * P + i] = vd.z;
     nm[i] = nd.x; nm[P + i] = nd.y; nm[2 * P + i] = nd.z;
 }
@@ -1510,10 +1521,10 @@ __device__ __forceinline__ float3 quad_bcast3(float3 v) { return f3(quad_bcast<k
 // pixel and exchange their values with quad broadcasts, so the averages keep the reference's operation order
 // ((x00 + x01 + x10 + x11) / 4, level 2 from level-1 values).  (A thread per level-2 pixel -- 19 200 threads walking 16
 // pixels each -- left three quarters of the CUs idle: 15 us.)
-__global__ __launch_bounds__(256) void k_model_pyramid(const PyrArgs a0) {
+__device__ __forceinline__ void model_pyramid_body(const PyrArgs& a0, const int blk_x, const int blk_y, const int blk_z) {
     PyrArgs a = a0;
     if (a0.b.n > 0) {
-        const TrackModelDev* __restrict__ md = a0.b.m[blockIdx.z];
+        const TrackModelDev* __restrict__ md = a0.b.m[blk_z];
         a.predV = md->predV; a.predN = md->predN; a.frame = md->frame; a.pose = md->pose; a.hostPose = 0;
         a.fillDepth = md->allow_fill ? a0.fillDepth : nullptr;
 #pragma unroll
@@ -1522,8 +1533,8 @@ __global__ __launch_bounds__(256) void k_model_pyramid(const PyrArgs a0) {
     const int W2 = a.W >> 2, H2 = a.H >> 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = lane & 3, bx = b & 1, by = b >> 1;
-    const int x2 = blockIdx.x * 16 + (lane >> 2);
-    const int y2 = blockIdx.y * 4 + wave;
+    const int x2 = blk_x * 16 + (lane >> 2);
+    const int y2 = blk_y * 4 + wave;
     const bool inside = x2 < W2 && y2 < H2;   // whole quads are in or out: the DPP exchanges below stay well defined
     float R[9]; float3 t;
     if (a.hostPose) {
@@ -1589,19 +1600,35 @@ __global__ __launch_bounds__(256) void k_model_pyramid(const PyrArgs a0) {
         n2ok = n2ok && !isnan(n2.x);
         store_tx(a.vm[2], a.nm[2], P2, y2 * W2 + x2, v2, v2ok, n2, n2ok, R, t);
     }
-    if (a0.b.n > 0 && !a0.b.m[blockIdx.z]->allow_fill) {
+    if (a0.b.n > 0 && !a0.b.m[blk_z]->allow_fill) {
         // batched tracker, object models: the rectangle of level-0 pixels that hold a normal (TrackModelDev::rect) -- a superset of the pixels store_tx
         // wrote a normal to (it writes NaN wherever the flag is off), which is all the pixel pass of the Gauss-Newton loop can pair a frame pixel
         // with.  A level-1 / level-2 normal needs all four normals below it (resizeMapKernel), so the rectangle shifted right by the level bounds
         // those levels too.  An object covers ~1 % of the image: nearly every wavefront sees no normal at all and leaves after one ballot.
         if (__ballot(inside && n0any) != 0ull) {
-            int* __restrict__ rect = a0.b.m[blockIdx.z]->rect;
+            int* __restrict__ rect = a0.b.m[blk_z]->rect;
             const bool on = inside && n0any;
             const int x0 = wave_min_i(on ? n0x0 : 0x7FFFFFFF), y0 = wave_min_i(on ? n0y0 : 0x7FFFFFFF);
             const int x1 = wave_max_i(on ? n0x1 : (int)0x80000000), y1 = wave_max_i(on ? n0y1 : (int)0x80000000);
             if (lane == 0) { atomicMin(&rect[0], x0); atomicMin(&rect[1], y0); atomicMax(&rect[2], x1); atomicMax(&rect[3], y1); }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_model_pyramid(const PyrArgs a) { model_pyramid_body(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z); }
+
+// The depth filter of the frame and the model-side pyramid of the same frame's tracking step in ONE launch ("fusedPreprocessLaunch"): the two are
+// independent -- the filter reads the new depth image, the pyramid the previous frame's prediction -- and complement each other (the filter is
+// VALU-bound on 1 208 workgroups at VGA, the pyramid a 20 MB stream on 300), but on one stream two launches run one after the other.  Workgroups
+// below nbil run bilateral_body (mf_bilateral_device.h), the others model_pyramid_body with their index as the 2-D block of k_model_pyramid:
+// the same instructions on the same data as the two kernels, hence the same bits.
+// (six wavefronts per SIMD = six workgroups per compute unit: at VGA all 1 508 workgroups are resident at once; the pyramid half would take 83 registers)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bilateral_model_pyramid(const float* __restrict__ depth, float* __restrict__ out, int W, int H, int nbil,
+                                                                 const PyrArgs a) {
+    __shared__ float tile[kBLdsH * kBLdsW];
+    if ((int)blockIdx.x < nbil) { bilateral_body(depth, out, W, H, tile, (int)blockIdx.x); return; }
+    const int j = (int)blockIdx.x - nbil, gx = ((W >> 2) + 15) / 16;
+    model_pyramid_body(a, j % gx, j / gx, 0);
 }
 
 void launch_model_pyramid(const float4* predV, const float4* predN, const float* fillDepth, const FrameDev* frame,
@@ -1617,6 +1644,21 @@ void launch_model_pyramid(const float4* predV, const float4* predN, const float*
     a.b.n = 0;
     dim3 grid(((W >> 2) + 15) / 16, ((H >> 2) + 3) / 4);
     hipLaunchKernelGGL(k_model_pyramid, grid, dim3(256), 0, s, a);
+}
+
+void launch_bilateral_model_pyramid(const float* depth, float* depthF, const float4* predV, const float4* predN, const float* fillDepth,
+                                    const FrameDev* frame, const PoseDev* pose, float* const vmaps[3], float* const nmaps[3], int W, int H, Intr k,
+                                    hipStream_t s) {
+    PyrArgs a;
+    a.predV = predV; a.predN = predN; a.fillDepth = fillDepth; a.frame = frame; a.pose = pose;
+    a.hostPose = 0;
+    for (int i = 0; i < 9; ++i) a.R[i] = 0.f;
+    for (int i = 0; i < 3; ++i) a.t[i] = 0.f;
+    for (int i = 0; i < 3; ++i) { a.vm[i] = vmaps[i]; a.nm[i] = nmaps[i]; }
+    a.W = W; a.H = H; a.k = k;
+    a.b.n = 0;
+    const int nbil = bilateral_grid(W, H), npyr = (((W >> 2) + 15) / 16) * (((H >> 2) + 3) / 4);
+    hipLaunchKernelGGL(k_bilateral_model_pyramid, dim3(nbil + npyr), dim3(256), 0, s, depth, depthF, W, H, nbil, a);
 }
 
 void launch_model_pyramid_batch(const TrackBatch& b, const float* fillDepth, int W, int H, Intr k, hipStream_t s) {

@@ -10,75 +10,18 @@
 // pixels of the 8-object scene.
 #pragma clang fp contract(off)
 #include "mf_device.h"
+#include "mf_bilateral_device.h"
 
 namespace mf {
 
-// ------------------------------------------------------------------------------------------------
-// 13x13 bilateral.  One 256-thread workgroup (4 wavefronts, 64 lanes along x) filters a 64x4 tile staged through LDS
-// with a 6-pixel halo: HBM/L2 traffic is 4 B out per pixel and the 169 taps come from LDS (row-contiguous ds_read_b32,
-// conflict free).  The kernel is VALU/latency bound (169 exp per pixel), so the tile is kept small: 1200 workgroups
-// give every SIMD 4-5 resident wavefronts to hide the dependent exp/fma chains (a 64x16 tile = 300 workgroups ran 4x
-// slower at one wavefront per SIMD).
-// ------------------------------------------------------------------------------------------------
-constexpr int kBR = 6;
-constexpr int kBTileW = 64, kBTileH = 4;
-constexpr int kBLdsW = kBTileW + 2 * kBR;  // 76
-constexpr int kBLdsH = kBTileH + 2 * kBR;  // 16
-constexpr float kBOutside = 1e15f;
-
-// The range/space weight exp(-(s2 * a + c2 * b)) is evaluated as 2^-(s2 * a' + c2 * b') with log2(e) folded into the
-// constants and the hardware v_exp_f32 (1 ulp on 2^t; the argument carries |t| * 2^-24 <= 1e-6 relative for every weight
-// above 1e-6).  libm's expf cost ~25 instructions x 169 taps and made the kernel VALU bound at 40 us.  The filter output
-// is a weighted MEAN of nearly equal depths, so a 1e-6 relative weight error moves it by ~1e-9 relative: the measured
-// difference to the oracle's expf path is a few ulp (tests/test_gpu_kernels.py::test_bilateral).
-// (Two pixels per thread with 2-wide packed fp32 math -- 6.5 instead of 10 VALU instructions per tap -- was tried: 31 us
-// against 19 us; half as many wavefronts left the exp / LDS latencies exposed.)
+// 13x13 bilateral: the body lives in mf_bilateral_device.h (shared with the launch that runs it beside the model-side pyramid)
 __global__ __launch_bounds__(256) void k_bilateral(const float* __restrict__ depth, float* __restrict__ out, int W, int H) {
     __shared__ float tile[kBLdsH * kBLdsW];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int tiles_x = (W + kBTileW - 1) / kBTileW, tiles = tiles_x * ((H + kBTileH - 1) / kBTileH);
-    const int tile_id = xcd_contiguous_tile(blockIdx.x, tiles);   // each XCD's L2 fetches its own band of the image (+ halo), not all of it
-    if (tile_id >= tiles) return;
-    const int x0 = (tile_id % tiles_x) * kBTileW, y0 = (tile_id / tiles_x) * kBTileH;
-    // stage.  The shader clips its loops at the image border; here an out-of-image tap holds kBOutside = 1e15: its range term is
-    // -8e32, 2^that is exactly 0, and it adds tmp * 0 = +0 to both sums -- the same bits as skipping it, without a compare, an exec
-    // mask and a branch per tap (round 3: the 169 branches also kept every ds_read on its own s_waitcnt).
-    for (int i = threadIdx.x; i < kBLdsH * kBLdsW; i += 256) {
-        const int ly = i / kBLdsW, lx = i - ly * kBLdsW;
-        const int gx = x0 + lx - kBR, gy = y0 + ly - kBR;
-        tile[i] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? depth[gy * W + gx] : kBOutside;
-    }
-    __syncthreads();
-    const float sigma_space2_inv_half = 0.024691358f * 1.44269504088896340736f;   // x log2(e)
-    const float sigma_color2_inv_half = 555.556f * 1.44269504088896340736f;
-    const int gx = x0 + tx, gy = y0 + ty;
-    if (gx >= W || gy >= H) return;
-    const float value = tile[(ty + kBR) * kBLdsW + tx + kBR];
-    float res = 0.f;
-    if (!(value <= 0.03f)) {   // the shader's gate as written (`if (value <= 0.03f) 0 else filter`, :34): a NaN centre is filtered, to NaN
-        float sum1 = 0.f, sum2 = 0.f;
-#pragma unroll
-        for (int dy = -kBR; dy <= kBR; ++dy) {
-            const float* row = &tile[(ty + kBR + dy) * kBLdsW + tx + kBR];
-            const float fy2 = (float)(dy * dy);
-#pragma unroll
-            for (int dx = -kBR; dx <= kBR; ++dx) {
-                const float tmp = row[dx];
-                const float space_term = -(((float)(dx * dx) + fy2) * sigma_space2_inv_half);   // compile-time constant
-                const float color2 = (value - tmp) * (value - tmp);
-                const float weight = __builtin_amdgcn_exp2f(space_term - color2 * sigma_color2_inv_half);   // exactly 0 for an outside tap
-                sum1 += tmp * weight;
-                sum2 += weight;
-            }
-        }
-        res = sum1 / sum2;
-    }
-    out[gy * W + gx] = res;
+    bilateral_body(depth, out, W, H, tile, (int)blockIdx.x);
 }
 
 void launch_bilateral(const float* depth, float* out, int W, int H, hipStream_t s) {
-    const int tiles = ((W + kBTileW - 1) / kBTileW) * ((H + kBTileH - 1) / kBTileH);
-    hipLaunchKernelGGL(k_bilateral, dim3(xcd_padded_grid(tiles)), dim3(256), 0, s, depth, out, W, H);
+    hipLaunchKernelGGL(k_bilateral, dim3(bilateral_grid(W, H)), dim3(256), 0, s, depth, out, W, H);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -169,6 +112,24 @@ __device__ __forceinline__ float pyrdown_px(const float* __restrict__ src /*LDS*
     const int ty = min(2 * y + 3, sh - 1);
     float sum = 0.f;
     int count = 0;
+    if (2 * x >= 2 && 2 * y >= 2 && tx == 2 * x + 3 && ty == 2 * y + 3) {
+        // away from the image border the loops below are the full 5 x 5 window with the binomial weights in their natural order: the same taps in
+        // the same order, unrolled and without a branch per tap -- a NaN tap adds +0 to the sum (which is never -0: it starts at +0 and every
+        // addend is a depth >= 0 times a weight) and 0 to the count, i.e. nothing, as when it is skipped
+        const float* p = src + (2 * y - 2 - oy) * ldw + (2 * x - 2 - ox);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const float v = p[j * ldw + i];
+                const float w = gauss5(4 - j) * gauss5(4 - i);     // compile-time constant
+                const bool ok = !isnan(v);
+                sum += ok ? v * w : 0.f;
+                count += ok ? (int)w : 0;
+            }
+        }
+        return sum / (float)count;
+    }
     for (int cy = max(0, 2 * y - 2); cy < ty; ++cy) {
         for (int cx = max(0, 2 * x - 2); cx < tx; ++cx) {
             const float v = src[(cy - oy) * ldw + (cx - ox)];
@@ -225,19 +186,7 @@ __global__ __launch_bounds__(256) void k_frame_pyramid(const FramePyrArgs a) {
         s0[i] = (gx >= 0 && gx < W0 && gy >= 0 && gy < H0) ? a.depth[gy * W0 + gx] : qnan();
     }
     __syncthreads();
-    for (int i = tid; i < kFpL1 * kFpL1; i += 256) {
-        const int ly = i / kFpL1, lx = i - ly * kFpL1;
-        const int gx = ox1 + lx, gy = oy1 + ly;
-        s1[i] = (gx >= 0 && gx < W1 && gy >= 0 && gy < H1) ? pyrdown_px(s0, kFpL0, ox0, oy0, gx, gy, W0, H0) : qnan();
-    }
-    __syncthreads();
-    for (int i = tid; i < kFpL2 * kFpL2; i += 256) {
-        const int ly = i / kFpL2, lx = i - ly * kFpL2;
-        const int gx = X2 + lx, gy = Y2 + ly;
-        s2[i] = (gx < W2 && gy < H2) ? pyrdown_px(s1, kFpL1, ox1, oy1, gx, gy, W1, H1) : qnan();
-    }
-    __syncthreads();
-    // vertex / normal maps of the three tiles
+    // (each level's vertex / normal maps are written as soon as its depths stand in LDS: their stores drain under the next level's arithmetic)
     const Intr k0 = a.k;
     const Intr k1 = Intr{a.k.fx / 2.f, a.k.fy / 2.f, a.k.cx / 2.f, a.k.cy / 2.f};
     const Intr k2 = Intr{a.k.fx / 4.f, a.k.fy / 4.f, a.k.cx / 4.f, a.k.cy / 4.f};
@@ -245,10 +194,22 @@ __global__ __launch_bounds__(256) void k_frame_pyramid(const FramePyrArgs a) {
         const int u = 4 * X2 + l % (4 * kFpT2), v = 4 * Y2 + l / (4 * kFpT2);
         if (u < W0 && v < H0) vmap_nmap_px(s0, kFpL0, ox0, oy0, u, v, W0, H0, k0, a.cutoff, a.vmap[0], a.nmap[0]);
     }
+    for (int i = tid; i < kFpL1 * kFpL1; i += 256) {
+        const int ly = i / kFpL1, lx = i - ly * kFpL1;
+        const int gx = ox1 + lx, gy = oy1 + ly;
+        s1[i] = (gx >= 0 && gx < W1 && gy >= 0 && gy < H1) ? pyrdown_px(s0, kFpL0, ox0, oy0, gx, gy, W0, H0) : qnan();
+    }
+    __syncthreads();
     for (int l = tid; l < 4 * kFpT2 * kFpT2; l += 256) {
         const int u = 2 * X2 + l % (2 * kFpT2), v = 2 * Y2 + l / (2 * kFpT2);
         if (u < W1 && v < H1) vmap_nmap_px(s1, kFpL1, ox1, oy1, u, v, W1, H1, k1, a.cutoff, a.vmap[1], a.nmap[1]);
     }
+    for (int i = tid; i < kFpL2 * kFpL2; i += 256) {
+        const int ly = i / kFpL2, lx = i - ly * kFpL2;
+        const int gx = X2 + lx, gy = Y2 + ly;
+        s2[i] = (gx < W2 && gy < H2) ? pyrdown_px(s1, kFpL1, ox1, oy1, gx, gy, W1, H1) : qnan();
+    }
+    __syncthreads();
     for (int l = tid; l < kFpT2 * kFpT2; l += 256) {
         const int u = X2 + l % kFpT2, v = Y2 + l / kFpT2;
         if (u < W2 && v < H2) vmap_nmap_px(s2, kFpL2, X2, Y2, u, v, W2, H2, k2, a.cutoff, a.vmap[2], a.nmap[2]);

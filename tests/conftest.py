@@ -70,3 +70,20 @@ def hip():
     assert torch.cuda.is_available(), "GPU test selected but no GPU visible"
     from maskfusion_amd.lib import load
     return load()
+
+
+def pytest_sessionstart(session):
+    """MF_TEST_PARAMS="key=value,key=value": implementation switches (mf_set_param) applied to every context the tests create -- tooling for
+    bisecting a failure to a switch on the GPU box (e.g. MF_TEST_PARAMS=objectStream=0,fusedPreprocessLaunch=0); unset in every regular run."""
+    spec = os.environ.get("MF_TEST_PARAMS", "")
+    if not spec:
+        return
+    from maskfusion_amd import api
+    pairs = [(kv.partition("=")[0], float(kv.partition("=")[2])) for kv in spec.split(",") if kv]
+    orig = api.MaskFusion.__init__
+
+    def patched(self, *a, **k):
+        orig(self, *a, **k)
+        for key, val in pairs:
+            self.setParam(key, val)
+    api.MaskFusion.__init__ = patched

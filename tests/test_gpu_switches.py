@@ -610,3 +610,75 @@ def test_fused_rgb_pyramid_equals_the_single_kernels(hip, size):
         assert np.array_equal(pa[k], pb[k]), k
     assert np.array_equal(ca, cb, equal_nan=True)
     assert int(ta[-1]["rgb_gate0"].sum()) > 100 and int((ta[-1]["gray0"] == 0).sum()) > 500
+
+
+@pytest.mark.parametrize("size", [(640, 480), (200, 152)], ids=["vga", "200x152"])
+def test_fused_preprocess_launch_equals_the_two_kernels(hip, size):
+    """`fusedPreprocessLaunch` (round 6): the frame's depth filter (depth_bilateral_metric.frag) and the model-side pyramid of the same frame's tracking
+    step (initICPModel: copyMaps + 2 resizes + 3 transforms + fill-in, RGBDOdometry.cpp:153-185) run as the two halves of ONE launch instead of
+    k_bilateral followed by k_model_pyramid -- the same bodies on the same data.  Filtered depth, all six model-side maps, poses and the map must be
+    the same bits on every frame; a size with partial tiles included, and a stream whose holes switch the fill-in on."""
+    from maskfusion_amd import MaskFusion, synth
+    W, H = size
+    f = 528.0 * W / 640.0
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
+    frames = [st.frame(k) for k in range(8)]
+    names = ["depthF"] + [f"{p}{i}" for p in ("vmap_g", "nmap_g") for i in range(3)]
+
+    def run(fused):
+        mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=False, numGSurfels=1 << 19)
+        mf.setParam("fusedPreprocessLaunch", fused)
+        taps, poses, fill = [], [], []
+        for k, (rgb, d, _) in enumerate(frames):
+            if k == 5:
+                d = d.copy(); d[: H // 2] = 0.0          # half the image without depth: the next frame's prediction is sparse -> fill-in
+            mf.processFrame(rgb, d, timestamp=k)
+            taps.append({t: mf.debugRead(t).copy() for t in names})
+            poses.append(mf.getCurrPose().copy())
+        cloud = mf.getBackgroundModel().downloadMap().copy()
+        mf.close()
+        return taps, poses, cloud
+
+    (ta, pa, ca), (tb, pb, cb) = run(0), run(1)
+    for k in range(len(frames)):
+        for t in names:
+            assert np.array_equal(ta[k][t], tb[k][t], equal_nan=True), (k, t, int((ta[k][t] != tb[k][t]).sum()))
+        assert np.array_equal(pa[k], pb[k]), k
+    assert np.array_equal(ca, cb, equal_nan=True)
+    assert np.isfinite(ta[-1]["vmap_g0"]).sum() > W * H        # the model-side maps hold a surface
+
+
+@pytest.mark.parametrize("size", [(640, 480), (200, 152), (168, 136)], ids=["vga", "200x152", "168x136"])
+def test_frame_pyramid_launch_equals_the_level_kernels(hip, size):
+    """k_frame_pyramid (Model::generateCUDATextures in one LDS-tiled launch: pyrDownGaussF x 2 + createVMap / createNMap x 3, Model.cpp:350-389) against
+    the level-by-level kernels (mf_k_pyrdown_f, mf_k_vmap_nmap -- each pinned to the oracle / the reference's vectors in test_gpu_kernels.py and
+    test_gpu_ref_golden.py) on the context's own filtered depth: all six maps the same bits.  Round 6 gave the launch an unrolled branch-free
+    interior path for the 5 x 5 window; the border quirk, holes (NaN-skipping: the filtered depth of a hole is 0, the vertex map's NaN
+    never enters a pyramid level, so holes are cut into the level-0 depth as NaNs too) and sizes with partial tiles are what could tell them apart."""
+    from gpu_util import dev, empty, host
+    from maskfusion_amd import MaskFusion, synth
+    W, H = size
+    f = 528.0 * W / 640.0
+    st = synth.Stream(W=W, H=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, noise=True)
+    mf = MaskFusion(W, H, f, f, W / 2.0, H / 2.0, icpThresh=100.0, so3=False, enableMultipleModels=False, numGSurfels=1 << 19)
+    for k in range(3):
+        rgb, d, _ = st.frame(k)
+        if k == 2:
+            d = d.copy(); d[H // 3: H // 3 + 9, W // 4: W // 4 + 31] = np.nan; d[:3, :] = np.nan; d[:, W - 2:] = np.nan   # NaNs the filter passes on
+        mf.processFrame(rgb, d, timestamp=k)
+    depthF = mf.debugRead("depthF").reshape(H, W).copy()
+    got = {f"{p}{i}": mf.debugRead(f"{p}{i}").copy() for p in ("vmap", "nmap") for i in range(3)}
+    mf.close()
+    assert np.isnan(depthF).any(), "the scenario must push NaNs through the pyramid"
+    lvl = dev(depthF)
+    for i in range(3):
+        w, h = W >> i, H >> i
+        v, n = empty((3, h, w)), empty((3, h, w))
+        assert hip.mf_k_vmap_nmap(lvl.data_ptr(), v.data_ptr(), n.data_ptr(), w, h, f / (1 << i), f / (1 << i), (W / 2.0) / (1 << i), (H / 2.0) / (1 << i), 3.0, None) == 0
+        assert np.array_equal(host(v).reshape(-1), got[f"vmap{i}"].reshape(-1), equal_nan=True), ("vmap", i)
+        assert np.array_equal(host(n).reshape(-1), got[f"nmap{i}"].reshape(-1), equal_nan=True), ("nmap", i)
+        if i < 2:
+            nxt = empty((h >> 1, w >> 1))
+            assert hip.mf_k_pyrdown_f(lvl.data_ptr(), nxt.data_ptr(), w, h, None) == 0
+            host(nxt)   # (synchronises)
+            lvl = nxt
