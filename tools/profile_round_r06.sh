@@ -25,7 +25,9 @@ echo "bench c4 rc=$?"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_s /tmp/prof_c4 /tmp/prof_f /tmp/prof_w /tmp/prof_cf /tmp/prof_cw /tmp/prof_4f /tmp/prof_4w
 B="--frame-cache $CACHE --gen-workers 1 --min-seconds 0 --no-cpu-baseline --no-host-input --no-roofline --no-variants --steps 600 --warmup 60"   # no fork under the profiler
-C4="--config 4 --frame-cache $CACHE --gen-workers 1 --min-seconds 0 --steps 20"
+# (the profiler passes of --config 4 run on ONE stream -- objectStream 0 --: the per-kernel rows are kernels on their own, as DESIGN.md's tables describe
+# them; the timing lines above run the default, the object models' passes beside the background's)
+C4="--config 4 --frame-cache $CACHE --gen-workers 1 --min-seconds 0 --steps 20 --param objectStream=0"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s -o s -- python $REPO/bench.py $B > /tmp/prof_s.log 2>&1
 cp $(find /tmp/prof_s -name "*kernel_stats.csv" | head -1) $REPO/gpurun_out/${TAG}_kernel_stats.csv
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c4 -o s -- python $REPO/bench.py $C4 > /tmp/prof_c4.log 2>&1
