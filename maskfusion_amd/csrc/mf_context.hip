@@ -173,10 +173,11 @@ struct mf_ctx {
     // "fusedPreprocessLaunch": a single tracked background's model-side pyramid is built in the depth filter's launch (k_bilateral_model_pyramid);
     // pyr_done: the model whose pyramid of THIS frame that launch has built (enqueue_track then skips its own launch)
     bool fused_preprocess = true;
-    ModelState* pyr_done = nullptr;
+    ModelState* pyr_done = nullptr; bool pyr_batch_done = false;   // (... or the batched tracker's pyramids of this frame)
     bool object_stream = true;
     hipStream_t stream_obj = nullptr, obj_s = nullptr;
-    hipEvent_t ev_obj_dep = nullptr, ev_obj_done = nullptr;
+    hipEvent_t ev_obj_dep = nullptr, ev_obj_done = nullptr, ev_obj_global = nullptr;
+    int global_overlap_elements = 1 << 20;             // "globalOverlapElements": from this many object surfels on, their GlobalProjection scatter runs beside the background's binning
     bool obj_dep_main = false;
     uint8_t* d_maskT_obj = nullptr;                    // the object chain's own copy of d_maskT (every packed resolve pass writes the whole plane)
     bool ftf_rgb = false;                              // MaskFusion::frameToFrameRGB ("-ftf"; Model.cpp:399-400,981): the photometric term tracks against the previous RAW frame
@@ -224,6 +225,7 @@ struct mf_ctx {
     float4* d_splat_rec0 = nullptr; float4* d_splat_rec1 = nullptr; uint2* d_splat_bbox = nullptr;   // per-surfel sprite set-up
     const uint8_t* cur_rgb = nullptr;      // device rgb of the frame being processed (fill-in intensity at predict time)
     const float* cur_depth = nullptr;      // device raw depth of the frame being processed / staged (Model-level entry points)
+    bool batch_solve_fused = true;         // "batchSolveInPixelPass": the batched Gauss-Newton loop as ONE launch per iteration (k_icp_batch_pixels with k_icp_batch_solve's work as its prologue); 0: two
     int batch_tracking = 1;                // 0: track the models one after the other even when a batch is possible ("batchTracking")
     int model_api_packed = 0;              // mf_model_predict_indices also builds the packed column-major map clean() uses in-frame
     std::vector<int32_t> mask_classes;     // FrameData::classIDs for mf_process_frame_dev (mf_set_mask_class_ids)
@@ -515,7 +517,8 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     if (hipStreamCreateWithFlags(&c->stream_in, hipStreamNonBlocking) != hipSuccess) return fail(MF_EHIP);
     if (hipStreamCreateWithFlags(&c->stream_obj, hipStreamNonBlocking) != hipSuccess) return fail(MF_EHIP);
     if (hipEventCreateWithFlags(&c->ev_obj_dep, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_obj_done, hipEventDisableTiming) != hipSuccess) return fail(MF_EHIP);
+        hipEventCreateWithFlags(&c->ev_obj_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_obj_global, hipEventDisableTiming) != hipSuccess) return fail(MF_EHIP);
     c->obj_s = c->stream;
     A(dev_alloc(c, c->allocs, &c->d_zero_mask, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_mask_tex, (size_t)P));
@@ -647,6 +650,7 @@ extern "C" void mf_destroy(mf_ctx* c) {
     if (c->stream_obj) { (void)hipStreamSynchronize(c->stream_obj); (void)hipStreamDestroy(c->stream_obj); }
     if (c->ev_obj_dep) (void)hipEventDestroy(c->ev_obj_dep);
     if (c->ev_obj_done) (void)hipEventDestroy(c->ev_obj_done);
+    if (c->ev_obj_global) (void)hipEventDestroy(c->ev_obj_global);
     for (int i = 0; i < mf_ctx::kObjArgSlots; ++i) {
         if (c->d_obj_args[i]) (void)hipFree(c->d_obj_args[i]);
         if (c->h_obj_args[i]) (void)hipHostFree(c->h_obj_args[i]);
@@ -1048,7 +1052,9 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     }
     if (!strcmp(key, "batchTracking")) { c->batch_tracking = value != 0; return MF_OK; }
     if (!strcmp(key, "frameToFrameRGB")) { c->ftf_rgb = value != 0; return MF_OK; }         // MaskFusion::setFrameToFrameRGB (Core/MaskFusion.cpp:910)
+    if (!strcmp(key, "batchSolveInPixelPass")) { c->batch_solve_fused = value != 0; return MF_OK; }   // 0: k_icp_batch_solve + k_icp_batch_pixels per iteration (the executable specification)
     if (!strcmp(key, "fusedPreprocessLaunch")) { c->fused_preprocess = value != 0; return MF_OK; }   // 0: k_bilateral and k_model_pyramid as two launches
+    if (!strcmp(key, "globalOverlapElements")) { c->global_overlap_elements = (int)value; return MF_OK; }
     if (!strcmp(key, "objectStream")) { c->object_stream = value != 0; return MF_OK; }   // 0: the object models' batched passes on the main stream, behind the background's
     if (!strcmp(key, "batchObjectPasses")) { c->batch_objects = value != 0; return MF_OK; }  // 0: the object models' surfel passes model by model
     if (!strcmp(key, "objectBoundingBoxLimit")) { c->bbox_limit = value != 0; return MF_OK; }   // 0: a headless upstream that never renders (bb_max_z = FLT_MAX)

@@ -175,7 +175,8 @@ static void enqueue_track_batch(mf_ctx* c, const std::vector<ModelState*>& ms, c
     memset(&b, 0, sizeof(b));
     b.n = (int)ms.size();
     for (int i = 0; i < b.n; ++i) b.m[i] = ms[i]->d_track;
-    launch_model_pyramid_batch(b, fillDepth, W, H, c->K, s);
+    if (c->pyr_batch_done) c->pyr_batch_done = false;   // built beside the frame's depth filter (enqueue_preprocess, "fusedPreprocessLaunch")
+    else launch_model_pyramid_batch(b, fillDepth, W, H, c->K, s);
     const bool so3 = g.so3 != 0 && c->gray_frame[set ^ 1] == frame_k - 1 && c->gray_frame[set] == frame_k;
     if (so3)   // one pre-alignment serves every model: it only looks at the two frames (RGBDOdometry.cpp:264-324)
         (void)launch_so3_prealign(c->d_gray[set ^ 1][2], c->d_gray[set][2], W >> 2, H >> 2, Intr{g.fx / 4, g.fy / 4, g.cx / 4, g.cy / 4},
@@ -191,10 +192,11 @@ static void enqueue_track_batch(mf_ctx* c, const std::vector<ModelState*>& ms, c
     for (int lvl = 2; lvl >= 0; --lvl) {
         const float div = (float)(1 << lvl);
         for (int j = 0; j < iters[lvl]; ++j) {
-            launch_icp_batch_solve(b, it, nb_prev, it == 0 ? so3_seed : nullptr, s);
+            // one launch per iteration ("batchSolveInPixelPass", default): the pixel pass finishes the previous iteration in its prologue; else two
+            if (!c->batch_solve_fused) launch_icp_batch_solve(b, it, nb_prev, it == 0 ? so3_seed : nullptr, s);
             launch_icp_batch_pixels(b, it, lvl, c->d_vmap[set][lvl], c->d_nmap[set][lvl], W >> lvl, H >> lvl,
                                     Intr{g.fx / div, g.fy / div, g.cx / div, g.cy / div}, 0.10f, sinf(20.f * 3.14159254f / 180.f), s,
-                                    c->slab_culling ? c->d_row_z + row_base[lvl] : nullptr);
+                                    c->slab_culling ? c->d_row_z + row_base[lvl] : nullptr, c->batch_solve_fused, nb_prev, it == 0 ? so3_seed : nullptr);
             nb_prev = icp_batch_blocks(W >> lvl, H >> lvl, b.n);
             ++it;
         }
@@ -514,7 +516,7 @@ static int take_next_model_id(mf_ctx* c) {
 // pyr_model: the model whose tracking step follows on this stream with nothing in between that its model-side pyramid depends on -- the pyramid
 // (launch_model_pyramid's arguments, as enqueue_track passes them) is then built in the filter's launch
 static int enqueue_preprocess(mf_ctx* c, const uint8_t* d_rgb, const float* d_depth, long k, bool with_maps, ModelState* pyr_model = nullptr,
-                              const float* pyr_fill_depth = nullptr) {
+                              const float* pyr_fill_depth = nullptr, const std::vector<ModelState*>* pyr_batch = nullptr) {
     const int W = c->W, H = c->H, P = c->P;
     hipStream_t s = c->stream;
     const mf_config& g = c->cfg;
@@ -527,6 +529,13 @@ static int enqueue_preprocess(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
         launch_bilateral_model_pyramid(d_depth, depthF, m.d_predV, m.d_predN, m.allowFillIn ? pyr_fill_depth : nullptr, m.d_frame, m.d_pose, m.d_vmap_g,
                                        m.d_nmap_g, W, H, c->K, sp);
         c->pyr_done = pyr_model;
+    } else if (pyr_batch) {   // the batched tracker's pyramids (enqueue_track_batch's first launch) beside the filter
+        TrackBatch b;
+        memset(&b, 0, sizeof(b));
+        b.n = (int)pyr_batch->size();
+        for (int i = 0; i < b.n; ++i) b.m[i] = (*pyr_batch)[i]->d_track;
+        launch_bilateral_model_pyramid_batch(d_depth, depthF, b, pyr_fill_depth, W, H, c->K, sp);
+        c->pyr_batch_done = true;
     } else {
         launch_bilateral(d_depth, depthF, W, H, sp);
     }
@@ -565,7 +574,9 @@ static int download_pose_log(mf_ctx* c, ModelState& m, std::vector<int64_t>& ts,
 // GlobalProjection::project for one model (fixed confidence threshold 12, GlobalProjection.cpp:43-107).  The background model goes
 // through the tile lists (its ~10^5..10^6 sprites cover millions of pixels: one memory-side atomic each in the scatter form);
 // object models (a few thousand sprites) keep the scatter form, which costs them one short launch.  Both write the same keys.
-static void enqueue_global_projection(mf_ctx* c, ModelState& m, int order) {
+// between / between_ctx: enqueued between the binning pass and the tile pass of the background's tiled form (launch_global_tiled); false: the scatter form
+// ran (or will run) instead and the caller enqueues `between` itself
+static bool enqueue_global_projection(mf_ctx* c, ModelState& m, int order, void (*between)(void*) = nullptr, void* between_ctx = nullptr) {
     const mf_config& g = c->cfg;
     PassTimer timer(c, m.id == 0 ? MF_PASS_BG_GLOBAL : -1);
     if (m.id == 0 && c->splat_tiles && c->global_tiles) {
@@ -573,11 +584,13 @@ static void enqueue_global_projection(mf_ctx* c, ModelState& m, int order) {
         const VisList* vis = ensure_vis(c, m, vl);
         if (launch_global_tiled(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, g.depth_cutoff, 12.0f, g.time_delta, order, m.id, c->d_tile_count,
                                 c->d_tile_entries, c->tile_entries_cap, c->d_splat_rec0, c->d_splat_rec1, c->d_splat_bbox, c->d_keys, c->stream, c->splat_tune,
-                                vis) == 0)
-            return;
+                                vis, between, between_ctx) == 0)
+            return true;
     }
+    if (between) between(between_ctx);
     launch_global_scatter(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, g.depth_cutoff, 12.0f, g.time_delta, order, m.id, c->d_keys,
                           c->stream, surfel_blocks(c, m));
+    return false;
 }
 
 // spawnObjectModel (Core/MaskFusion.cpp:671-684): pose = I, makeStatic(globalPose); moveNewModelToList
@@ -821,12 +834,14 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
     // the background's tracking step follows the preprocessing directly (model by model: the batched loop builds every model's pyramid in its own
     // launch): its model-side pyramid rides in the depth filter's launch
     ModelState* pyr_model = nullptr;
-    c->pyr_done = nullptr;
+    std::vector<ModelState*> pyr_tracked, pyr_follow;
+    bool pyr_batch = false;
+    c->pyr_done = nullptr; c->pyr_batch_done = false;
     if (c->fused_preprocess && c->map_ready && !(in_pose16 && !bootstrap)) {
-        std::vector<ModelState*> tracked, follow;
-        if (!tracking_plan(c, 0, g.track_all_models != 0, tracked, follow)) pyr_model = &bg;
+        if (tracking_plan(c, 0, g.track_all_models != 0, pyr_tracked, pyr_follow)) pyr_batch = true;   // ... or every tracked model's, batched
+        else pyr_model = &bg;
     }
-    int prc = enqueue_preprocess(c, d_rgb, d_depth, k, c->map_ready, pyr_model, depthF_prev);
+    int prc = enqueue_preprocess(c, d_rgb, d_depth, k, c->map_ready, pyr_model, depthF_prev, pyr_batch ? &pyr_tracked : nullptr);
     if (prc != MF_OK) return prc;
 
     if (!c->map_ready) {
@@ -862,24 +877,52 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
 
         if (multi) {
             // GlobalProjection::project(models, tick, tick, timeDelta, depthCutoff) (:289) with its fixed threshold 12
+            bool edges_done = false;
             if (batch_objects_now(c)) {
-                enqueue_global_projection(c, bg, 0);
                 std::vector<ModelState*> objs; std::vector<int> orders;
                 object_models(c, objs, orders);
+                long obj_surfels = 0;
+                for (ModelState* m : objs) obj_surfels += (long)*m->h_count;
+                // Big object maps ("globalOverlapElements"): their scatter (atomic minima on the key image) runs on the object stream BESIDE the background's
+                // culling and binning passes and the frame's edge maps, none of which touches the keys; the background's tile pass -- a plain
+                // read-modify-write per pixel -- waits for it.  min is min in either order: the same keys.  Two cross-queue dependencies (~10 us each)
+                // buy ~0.2 ms on configs[4]; on a scene of small objects they would cost more than the 36 us scatter they hide.
+                const bool overlap = c->object_stream && c->stream_obj && !c->timings_on && !c->pass_timings_on && obj_surfels >= (long)c->global_overlap_elements;
                 ObjBatch ob; int blocks = 0;
-                int rc = make_obj_batch(c, objs, orders, d_rgb, d_depth, depthF, mask, weight_multiplier, nullptr, ob, blocks);
-                if (rc != MF_OK) return rc;
-                PassTimer timer(c, MF_PASS_OBJ_GLOBAL);
-                launch_obj_global_scatter(ob, blocks, s);
+                if (overlap) {
+                    (void)hipEventRecord(c->ev_obj_dep, s);                       // tracking has finished: the objects' poses stand
+                    (void)hipStreamWaitEvent(c->stream_obj, c->ev_obj_dep, 0);
+                    int rc = make_obj_batch(c, objs, orders, d_rgb, d_depth, depthF, mask, weight_multiplier, nullptr, ob, blocks, c->stream_obj);
+                    if (rc != MF_OK) return rc;
+                    launch_obj_global_scatter(ob, blocks, c->stream_obj);
+                    (void)hipEventRecord(c->ev_obj_global, c->stream_obj);
+                    struct Mid { mf_ctx* c; int set, W, H; hipStream_t s; } mid{c, set, W, H, s};
+                    enqueue_global_projection(c, bg, 0, [](void* p) {
+                        Mid& q = *static_cast<Mid*>(p);
+                        launch_edge_map(q.c->d_vmap[q.set][0], q.c->d_nmap[q.set][0], q.c->d_edge, q.W, q.H, q.c->seg.weightDistance, q.c->seg.weightConvexity, q.s);
+                        launch_edge_binary(q.c->d_edge, q.c->d_bin, q.c->d_tmp_u8, q.W, q.H, q.c->seg.threshold, q.c->seg.morphEdgeRadius,
+                                           q.c->seg.morphEdgeIterations, q.s);
+                        (void)hipStreamWaitEvent(q.s, q.c->ev_obj_global, 0);
+                    }, &mid);
+                    edges_done = true;
+                } else {
+                    enqueue_global_projection(c, bg, 0);
+                    int rc = make_obj_batch(c, objs, orders, d_rgb, d_depth, depthF, mask, weight_multiplier, nullptr, ob, blocks);
+                    if (rc != MF_OK) return rc;
+                    PassTimer timer(c, MF_PASS_OBJ_GLOBAL);
+                    launch_obj_global_scatter(ob, blocks, s);
+                }
             } else {
                 for (size_t i = 0; i < c->models.size(); ++i) enqueue_global_projection(c, *c->models[i], (int)i);
             }
             launch_global_resolve(c->d_keys, c->d_proj_ids, P, s);
             if (c->timings_on) (void)hipEventRecord(c->ev_mm[0], s);
             // MfSegmentation::performSegmentation, device half (MfSegmentation.cpp:149-208)
-            launch_edge_map(c->d_vmap[set][0], c->d_nmap[set][0], c->d_edge, W, H, c->seg.weightDistance, c->seg.weightConvexity, s);
-            launch_edge_binary(c->d_edge, c->d_bin, c->d_tmp_u8, W, H, c->seg.threshold, c->seg.morphEdgeRadius,
-                               c->seg.morphEdgeIterations, s);
+            if (!edges_done) {
+                launch_edge_map(c->d_vmap[set][0], c->d_nmap[set][0], c->d_edge, W, H, c->seg.weightDistance, c->seg.weightConvexity, s);
+                launch_edge_binary(c->d_edge, c->d_bin, c->d_tmp_u8, W, H, c->seg.threshold, c->seg.morphEdgeRadius,
+                                   c->seg.morphEdgeIterations, s);
+            }
             const bool haveMasks = d_mask_in && class_ids && n_masks > 0;
             static const int32_t kNoClass[1] = {0};
             SegResult res;

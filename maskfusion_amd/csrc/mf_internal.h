@@ -177,11 +177,14 @@ void launch_icp_iteration(const IcpLaunch& a, hipStream_t s);
 int icp_batch_max_blocks(int W, int H);                       // upper bound of workgroups per model of launch_icp_batch_pixels
 int icp_batch_blocks(int W, int H, int n_models);             // workgroups per model it will use for this image size
 void launch_model_pyramid_batch(const TrackBatch& b, const float* fillDepth, int W, int H, Intr k, hipStream_t s);
+void launch_bilateral_model_pyramid_batch(const float* depth, float* depthF, const TrackBatch& b, const float* fillDepth, int W, int H, Intr k,
+                                          hipStream_t s);   // the depth filter + launch_model_pyramid_batch's work in one launch
 // it = 0 seeds the states from the model poses (+ SO(3) rotation); it >= 1 finishes iteration it-1 whose pixel pass used nb_in blocks
 void launch_icp_batch_solve(const TrackBatch& b, int it, int nb_in, const So3Result* so3_or_null, hipStream_t s);
 // row_z: launch_row_zrange's output for this level (nullptr: no culling -- every workgroup walks its pixels)
 void launch_icp_batch_pixels(const TrackBatch& b, int it, int level, const float* vmap_curr, const float* nmap_curr, int W, int H, Intr k,
-                             float distThres, float angleThres, hipStream_t s, const float2* row_z = nullptr);
+                             float distThres, float angleThres, hipStream_t s, const float2* row_z = nullptr, bool fused = false, int nb_in = 0,
+                             const So3Result* so3_or_null = nullptr);   // fused: launch_icp_batch_solve(b, it, nb_in, so3) is this launch's prologue
 // depth range of every row of the frame's three vertex maps: out[0 .. H) level 0, [H .. H + H/2) level 1, [.. + H/4) level 2: {min z, max z} over the
 // row's valid vertices ({+inf, -inf}: none)
 void launch_row_zrange(const float* const vmap[3], int W, int H, float2* out, hipStream_t s);
@@ -397,7 +400,8 @@ int gn_solve_standalone(const double* sys29, const double* resultRt16, const flo
                         double* resultRt_out, float* Rcurr9, float* tcurr3, float* stats2, hipStream_t s);
 int launch_global_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
                         int timeDelta, int order, int id, int* tile_count, int* entries, int entries_cap, float4* rec0, float4* rec1, void* bbox,
-                        unsigned long long* keys, hipStream_t s, SplatTuning tune = SplatTuning(), const VisList* vis = nullptr);
+                        unsigned long long* keys, hipStream_t s, SplatTuning tune = SplatTuning(), const VisList* vis = nullptr,
+                        void (*between_bin_and_tile)(void*) = nullptr, void* between_ctx = nullptr);
 void launch_spawn_pose(PoseDev* obj, const PoseDev* bg, FrameDev* objFrame, const FrameDev* bgFrame, PoseDev* host_mirror,
                        hipStream_t s);
 void launch_static_pose(PoseDev* obj, const PoseDev* bg, PoseDev* host_mirror, hipStream_t s);

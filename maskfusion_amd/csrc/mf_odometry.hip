@@ -887,6 +887,9 @@ struct IcpPxArgs {
     float dist2Max, sine2Min;
     int level, parity, chunk;
     const float2* row_z;      // [H] {min z, max z} of the valid vertices of every row of vc (launch_row_zrange); nullptr: no slab culling
+    // fused != 0 ("batchSolveInPixelPass"): the launch finishes the previous iteration itself -- every workgroup of a model reduces that model's partial
+    // sums and solves, identically, as k_icp_iter's prologue does for a single model -- instead of reading the state k_icp_batch_solve wrote
+    int fused, it, nb_in; const So3Result* so3;
 };
 
 // {min z, max z} over the valid vertices of every row of the three levels' vertex maps (planar [3][H][W]: z is plane 2)
@@ -913,16 +916,55 @@ constexpr int kBatchPx = 3;   // pixels per thread and round: all their gathers 
 
 __global__ __launch_bounds__(kBatchThreads) void k_icp_batch_pixels(const IcpPxArgs a) {
     __shared__ float s_red[29 * (kBatchThreads / 2)];
+    __shared__ double s_seg[32 * 32];
+    __shared__ double s_sys[32];
+    __shared__ GNState s_st;
+    __shared__ float s_scr[40];
     const TrackModelDev* __restrict__ md = a.b.m[blockIdx.y];
-    const GNState* __restrict__ st = md->st + a.parity;
     const float* __restrict__ vp = md->vm[a.level];
     const float* __restrict__ np = md->nm[a.level];
+    const int tid = threadIdx.x;
+    constexpr int kWords = (int)(sizeof(GNState) / 4);
+    static_assert(kWords + 32 + 60 <= kBatchThreads, "state + log + trace lanes");
+    if (a.fused) {
+        // k_icp_batch_solve's work as this launch's prologue (the same functions on the same data in the same order: the same bits), in every workgroup
+        // of the model; workgroup 0 of the model publishes state, log and trace for the next launch and the finalize step.  One launch per iteration
+        // instead of two: a dependent launch is 3.4 us before it does anything
+        if (a.it == 0) {
+            if (tid == 0) {
+                seed_state(*md->pose, s_st);
+                if (a.so3)
+                    for (int r = 0; r < 3; ++r)
+                        for (int c = 0; c < 3; ++c) s_st.resultRt[r * 4 + c] = a.so3->R[r * 3 + c];
+            }
+            __syncthreads();
+            if (blockIdx.x == 0) {
+                if (tid < kWords) reinterpret_cast<uint32_t*>(md->st)[tid] = reinterpret_cast<const uint32_t*>(&s_st)[tid];
+                if (tid == 0 && md->trace)
+                    for (int u = 32; u < 60; ++u) gn_trace_write(md->trace, 0, false, nullptr, &s_st, u);
+            }
+        } else {
+            const int prev = (a.it - 1) & 1;
+            if (tid < kWords) reinterpret_cast<uint32_t*>(&s_st)[tid] = reinterpret_cast<const uint32_t*>(md->st + prev)[tid];
+            reduce_partials(md->partials[prev], a.nb_in, s_seg, s_sys);   // (its barriers also publish s_st)
+            gn_finish_wg(s_sys, &s_st, s_scr, s_scr + 24);
+            __syncthreads();
+            if (blockIdx.x == 0) {
+                if (tid < kWords) reinterpret_cast<uint32_t*>(md->st + (a.it & 1))[tid] = reinterpret_cast<const uint32_t*>(&s_st)[tid];
+                else if (tid < kWords + 32 && md->log) md->log[32 * (a.it - 1) + tid - kWords] = (float)s_sys[tid - kWords];
+                gn_trace_write(md->trace, a.it, true, s_sys, &s_st, tid - (kWords + 32));
+            }
+        }
+    } else {
+        if (tid < kWords) reinterpret_cast<uint32_t*>(&s_st)[tid] = reinterpret_cast<const uint32_t*>(md->st + a.parity)[tid];
+        __syncthreads();
+    }
+    const GNState* st = &s_st;
     float Rc[9], Rpi[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) { Rc[k] = st->Rcurr[k]; Rpi[k] = st->Rprev_inv[k]; }
     const float3 tc = f3(st->tcurr[0], st->tcurr[1], st->tcurr[2]);
     const float3 tp = f3(st->tprev[0], st->tprev[1], st->tprev[2]);
-    const int tid = threadIdx.x;
     const int P = a.W * a.H;
     const int beg = blockIdx.x * a.chunk, end = min(P, beg + a.chunk);
     // Slab culling (exact).  A frame pixel contributes only if it projects onto a pixel of the model's maps that holds a normal (reduce.cu:316-352:
@@ -1040,9 +1082,10 @@ void launch_icp_batch_solve(const TrackBatch& b, int it, int nb_in, const So3Res
     hipLaunchKernelGGL(k_icp_batch_solve, dim3(b.n), dim3(256), 0, s, a);
 }
 void launch_icp_batch_pixels(const TrackBatch& b, int it, int level, const float* vmap_curr, const float* nmap_curr, int W, int H, Intr k,
-                             float distThres, float angleThres, hipStream_t s, const float2* row_z) {
+                             float distThres, float angleThres, hipStream_t s, const float2* row_z, bool fused, int nb_in, const So3Result* so3) {
     IcpPxArgs a;
     a.row_z = row_z;
+    a.fused = fused ? 1 : 0; a.it = it; a.nb_in = nb_in; a.so3 = so3;
     a.b = b; a.vc = vmap_curr; a.nc = nmap_curr; a.W = W; a.H = H; a.k = k; icp_gates(distThres, angleThres, a.dist2Max, a.sine2Min);
     a.level = level; a.parity = it & 1; a.chunk = icp_batch_chunk(W * H, b.n);
     hipLaunchKernelGGL(k_icp_batch_pixels, dim3(icp_batch_blocks(W, H, b.n), b.n), dim3(kBatchThreads), 0, s, a);
@@ -1627,8 +1670,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                                                                  const PyrArgs a) {
     __shared__ float tile[kBLdsH * kBLdsW];
     if ((int)blockIdx.x < nbil) { bilateral_body(depth, out, W, H, tile, (int)blockIdx.x); return; }
-    const int j = (int)blockIdx.x - nbil, gx = ((W >> 2) + 15) / 16;
-    model_pyramid_body(a, j % gx, j / gx, 0);
+    // (a.b.n > 0: the batched tracker's pyramids, model by model -- k_model_pyramid's grid.z unrolled behind the filter's workgroups)
+    const int j = (int)blockIdx.x - nbil, gx = ((W >> 2) + 15) / 16, gy = ((H >> 2) + 3) / 4, per = gx * gy;
+    model_pyramid_body(a, (j % per) % gx, (j % per) / gx, j / per);
 }
 
 void launch_model_pyramid(const float4* predV, const float4* predN, const float* fillDepth, const FrameDev* frame,
@@ -1658,6 +1702,16 @@ void launch_bilateral_model_pyramid(const float* depth, float* depthF, const flo
     a.W = W; a.H = H; a.k = k;
     a.b.n = 0;
     const int nbil = bilateral_grid(W, H), npyr = (((W >> 2) + 15) / 16) * (((H >> 2) + 3) / 4);
+    hipLaunchKernelGGL(k_bilateral_model_pyramid, dim3(nbil + npyr), dim3(256), 0, s, depth, depthF, W, H, nbil, a);
+}
+
+// ... and for the batched tracker: the filter beside launch_model_pyramid_batch's work
+void launch_bilateral_model_pyramid_batch(const float* depth, float* depthF, const TrackBatch& b, const float* fillDepth, int W, int H, Intr k,
+                                          hipStream_t s) {
+    PyrArgs a;
+    memset(&a, 0, sizeof(a));
+    a.fillDepth = fillDepth; a.W = W; a.H = H; a.k = k; a.b = b;
+    const int nbil = bilateral_grid(W, H), npyr = (((W >> 2) + 15) / 16) * (((H >> 2) + 3) / 4) * b.n;
     hipLaunchKernelGGL(k_bilateral_model_pyramid, dim3(nbil + npyr), dim3(256), 0, s, depth, depthF, W, H, nbil, a);
 }
 

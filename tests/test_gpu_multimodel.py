@@ -177,6 +177,18 @@ def test_batched_tracking_matches_model_by_model_tracking(hip):
 
 
 def test_slab_culling_changes_nothing(hip):
+    _batched_loop_switch_is_exact("slabCulling")
+
+
+def test_batch_solve_in_pixel_pass_changes_nothing(hip):
+    """`batchSolveInPixelPass` (round 6): an iteration of the batched Gauss-Newton loop as ONE launch -- every workgroup of a model reduces the
+    previous iteration's partial sums and solves in its prologue (reduce.cu:441-525 + RGBDOdometry.cpp:419-474, as k_icp_iter does for a single
+    model) -- against the two-launch form (k_icp_batch_solve + k_icp_batch_pixels): the same functions on the same data in the same order, so the
+    reduced system of every iteration of every tracked model, poses, counts and labels must be the same bits (scenario and gates of the test above)."""
+    _batched_loop_switch_is_exact("batchSolveInPixelPass")
+
+
+def _batched_loop_switch_is_exact(switch):
     """`slabCulling` (round 6): a workgroup of the batched Gauss-Newton pixel pass whose pixels cannot project onto a pixel of the model's maps that
     holds a normal writes zero partial sums without reading a map -- the projected corners of the frustum section its rows span bound every
     projection (mf_odometry.hip: k_icp_batch_pixels).  An exact rule: with it on and off the reduced system of EVERY iteration of every tracked
@@ -191,7 +203,7 @@ def test_slab_culling_changes_nothing(hip):
                        enableMultipleModels=True, modelSpawnOffset=2, trackAllModels=True, initConfidenceGlobal=10.0, initConfidenceObject=0.01)
         for k, v in (("mfThreshold", SEG["threshold"]), ("mfWeightDistance", SEG["weightDistance"]), ("mfWeightConvexity", SEG["weightConvexity"]),
                      ("mfMorphEdgeIterations", 0), ("mfMorphMaskIterations", 0), ("newModelMinRelativeSize", SEG["minRelSizeNew"]),
-                     ("slabCulling", cull)):
+                     (switch, cull)):
             m.setParam(k, v)
         rec = []
         for k, (rgb, depth, mask) in enumerate(frames):
@@ -296,3 +308,12 @@ def test_object_model_launch_switches_change_nothing(hip):
     tracked_one = run(track_all=True, objectStream=0)
     for _ in range(2):
         assert same(tracked_one, run(track_all=True, objectStream=1))
+    # "globalOverlapElements" = 0: the objects' GlobalProjection scatter on the object stream beside the background's binning, whatever their size
+    for _ in range(2):
+        assert same(one_stream, run(globalOverlapElements=0))
+    assert same(tracked_one, run(track_all=True, globalOverlapElements=0))
+    # "fusedPreprocessLaunch" with a batched tracker: every tracked model's pyramid beside the depth filter (k_bilateral_model_pyramid, grid.z unrolled);
+    # "batchSolveInPixelPass": one launch per iteration of the batched loop
+    assert same(tracked_one, run(track_all=True, objectStream=0, fusedPreprocessLaunch=0))
+    assert same(tracked_one, run(track_all=True, objectStream=0, batchSolveInPixelPass=0))
+    assert same(tracked_one, run(track_all=True, objectStream=0, fusedPreprocessLaunch=0, batchSolveInPixelPass=0))
