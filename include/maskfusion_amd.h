@@ -201,8 +201,6 @@ int mf_get_last_fillin(mf_ctx* ctx, int32_t* used);
  * iteration in its prologue, as the single-model kernel does; 0: a solve launch and a pixel launch per iteration; same bytes),
  * "fusedPreprocessLaunch" (1: when only the background is tracked model by model, its model-side pyramid is built in the depth filter's launch --
  * two independent kernels of a frame side by side; 0: two launches; same bytes),
- * "globalOverlapElements" (2^20: from this many object surfels on, the objects' GlobalProjection scatter runs on the object stream beside the
- * background's culling / binning passes and the frame's edge maps; the background's tile pass waits for it; same keys),
  * "hostLockstep" (1: mf_process_frame waits for frame k-2 to have run before it enqueues frame k's
  * upload), "hostWaitUpload" (1: ... and for its own upload: single-model frames), "modelApiPackedIndex" (0; 1: mf_model_predict_indices
  * also builds the packed column-major map mf_process_frame feeds Model::clean with), "tileThreads" (512) / "spriteLanes" (4): launch shape of

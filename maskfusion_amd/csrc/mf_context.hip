@@ -176,8 +176,7 @@ struct mf_ctx {
     ModelState* pyr_done = nullptr; bool pyr_batch_done = false;   // (... or the batched tracker's pyramids of this frame)
     bool object_stream = true;
     hipStream_t stream_obj = nullptr, obj_s = nullptr;
-    hipEvent_t ev_obj_dep = nullptr, ev_obj_done = nullptr, ev_obj_global = nullptr;
-    int global_overlap_elements = 1 << 20;             // "globalOverlapElements": from this many object surfels on, their GlobalProjection scatter runs beside the background's binning
+    hipEvent_t ev_obj_dep = nullptr, ev_obj_done = nullptr;
     bool obj_dep_main = false;
     uint8_t* d_maskT_obj = nullptr;                    // the object chain's own copy of d_maskT (every packed resolve pass writes the whole plane)
     bool ftf_rgb = false;                              // MaskFusion::frameToFrameRGB ("-ftf"; Model.cpp:399-400,981): the photometric term tracks against the previous RAW frame
@@ -517,8 +516,7 @@ extern "C" int mf_create(const mf_config* cfg, mf_ctx** out) {
     if (hipStreamCreateWithFlags(&c->stream_in, hipStreamNonBlocking) != hipSuccess) return fail(MF_EHIP);
     if (hipStreamCreateWithFlags(&c->stream_obj, hipStreamNonBlocking) != hipSuccess) return fail(MF_EHIP);
     if (hipEventCreateWithFlags(&c->ev_obj_dep, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_obj_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_obj_global, hipEventDisableTiming) != hipSuccess) return fail(MF_EHIP);
+        hipEventCreateWithFlags(&c->ev_obj_done, hipEventDisableTiming) != hipSuccess) return fail(MF_EHIP);
     c->obj_s = c->stream;
     A(dev_alloc(c, c->allocs, &c->d_zero_mask, (size_t)P));
     A(dev_alloc(c, c->allocs, &c->d_mask_tex, (size_t)P));
@@ -650,7 +648,6 @@ extern "C" void mf_destroy(mf_ctx* c) {
     if (c->stream_obj) { (void)hipStreamSynchronize(c->stream_obj); (void)hipStreamDestroy(c->stream_obj); }
     if (c->ev_obj_dep) (void)hipEventDestroy(c->ev_obj_dep);
     if (c->ev_obj_done) (void)hipEventDestroy(c->ev_obj_done);
-    if (c->ev_obj_global) (void)hipEventDestroy(c->ev_obj_global);
     for (int i = 0; i < mf_ctx::kObjArgSlots; ++i) {
         if (c->d_obj_args[i]) (void)hipFree(c->d_obj_args[i]);
         if (c->h_obj_args[i]) (void)hipHostFree(c->h_obj_args[i]);
@@ -1054,7 +1051,6 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!strcmp(key, "frameToFrameRGB")) { c->ftf_rgb = value != 0; return MF_OK; }         // MaskFusion::setFrameToFrameRGB (Core/MaskFusion.cpp:910)
     if (!strcmp(key, "batchSolveInPixelPass")) { c->batch_solve_fused = value != 0; return MF_OK; }   // 0: k_icp_batch_solve + k_icp_batch_pixels per iteration (the executable specification)
     if (!strcmp(key, "fusedPreprocessLaunch")) { c->fused_preprocess = value != 0; return MF_OK; }   // 0: k_bilateral and k_model_pyramid as two launches
-    if (!strcmp(key, "globalOverlapElements")) { c->global_overlap_elements = (int)value; return MF_OK; }
     if (!strcmp(key, "objectStream")) { c->object_stream = value != 0; return MF_OK; }   // 0: the object models' batched passes on the main stream, behind the background's
     if (!strcmp(key, "batchObjectPasses")) { c->batch_objects = value != 0; return MF_OK; }  // 0: the object models' surfel passes model by model
     if (!strcmp(key, "objectBoundingBoxLimit")) { c->bbox_limit = value != 0; return MF_OK; }   // 0: a headless upstream that never renders (bb_max_z = FLT_MAX)

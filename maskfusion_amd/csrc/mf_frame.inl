@@ -574,9 +574,7 @@ static int download_pose_log(mf_ctx* c, ModelState& m, std::vector<int64_t>& ts,
 // GlobalProjection::project for one model (fixed confidence threshold 12, GlobalProjection.cpp:43-107).  The background model goes
 // through the tile lists (its ~10^5..10^6 sprites cover millions of pixels: one memory-side atomic each in the scatter form);
 // object models (a few thousand sprites) keep the scatter form, which costs them one short launch.  Both write the same keys.
-// between / between_ctx: enqueued between the binning pass and the tile pass of the background's tiled form (launch_global_tiled); false: the scatter form
-// ran (or will run) instead and the caller enqueues `between` itself
-static bool enqueue_global_projection(mf_ctx* c, ModelState& m, int order, void (*between)(void*) = nullptr, void* between_ctx = nullptr) {
+static void enqueue_global_projection(mf_ctx* c, ModelState& m, int order) {
     const mf_config& g = c->cfg;
     PassTimer timer(c, m.id == 0 ? MF_PASS_BG_GLOBAL : -1);
     if (m.id == 0 && c->splat_tiles && c->global_tiles) {
@@ -584,13 +582,11 @@ static bool enqueue_global_projection(mf_ctx* c, ModelState& m, int order, void 
         const VisList* vis = ensure_vis(c, m, vl);
         if (launch_global_tiled(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, g.depth_cutoff, 12.0f, g.time_delta, order, m.id, c->d_tile_count,
                                 c->d_tile_entries, c->tile_entries_cap, c->d_splat_rec0, c->d_splat_rec1, c->d_splat_bbox, c->d_keys, c->stream, c->splat_tune,
-                                vis, between, between_ctx) == 0)
-            return true;
+                                vis) == 0)
+            return;
     }
-    if (between) between(between_ctx);
     launch_global_scatter(m.surf[m.cur], m.d_frame, m.d_pose, c->W, c->H, c->K, g.depth_cutoff, 12.0f, g.time_delta, order, m.id, c->d_keys,
                           c->stream, surfel_blocks(c, m));
-    return false;
 }
 
 // spawnObjectModel (Core/MaskFusion.cpp:671-684): pose = I, makeStatic(globalPose); moveNewModelToList
@@ -877,52 +873,26 @@ static int process_frame_impl(mf_ctx* c, const uint8_t* d_rgb, const float* d_de
 
         if (multi) {
             // GlobalProjection::project(models, tick, tick, timeDelta, depthCutoff) (:289) with its fixed threshold 12
-            bool edges_done = false;
             if (batch_objects_now(c)) {
+                // (the objects' scatter on the object stream beside the background's culling / binning passes and the edge maps -- "globalOverlapElements",
+                // round 6 -- gave 4.158 -> 4.134 ms on configs[4] and lost 2 % on S2: removed, DESIGN.md "Measured and rejected")
+                enqueue_global_projection(c, bg, 0);
                 std::vector<ModelState*> objs; std::vector<int> orders;
                 object_models(c, objs, orders);
-                long obj_surfels = 0;
-                for (ModelState* m : objs) obj_surfels += (long)*m->h_count;
-                // Big object maps ("globalOverlapElements"): their scatter (atomic minima on the key image) runs on the object stream BESIDE the background's
-                // culling and binning passes and the frame's edge maps, none of which touches the keys; the background's tile pass -- a plain
-                // read-modify-write per pixel -- waits for it.  min is min in either order: the same keys.  Two cross-queue dependencies (~10 us each)
-                // buy ~0.2 ms on configs[4]; on a scene of small objects they would cost more than the 36 us scatter they hide.
-                const bool overlap = c->object_stream && c->stream_obj && !c->timings_on && !c->pass_timings_on && obj_surfels >= (long)c->global_overlap_elements;
                 ObjBatch ob; int blocks = 0;
-                if (overlap) {
-                    (void)hipEventRecord(c->ev_obj_dep, s);                       // tracking has finished: the objects' poses stand
-                    (void)hipStreamWaitEvent(c->stream_obj, c->ev_obj_dep, 0);
-                    int rc = make_obj_batch(c, objs, orders, d_rgb, d_depth, depthF, mask, weight_multiplier, nullptr, ob, blocks, c->stream_obj);
-                    if (rc != MF_OK) return rc;
-                    launch_obj_global_scatter(ob, blocks, c->stream_obj);
-                    (void)hipEventRecord(c->ev_obj_global, c->stream_obj);
-                    struct Mid { mf_ctx* c; int set, W, H; hipStream_t s; } mid{c, set, W, H, s};
-                    enqueue_global_projection(c, bg, 0, [](void* p) {
-                        Mid& q = *static_cast<Mid*>(p);
-                        launch_edge_map(q.c->d_vmap[q.set][0], q.c->d_nmap[q.set][0], q.c->d_edge, q.W, q.H, q.c->seg.weightDistance, q.c->seg.weightConvexity, q.s);
-                        launch_edge_binary(q.c->d_edge, q.c->d_bin, q.c->d_tmp_u8, q.W, q.H, q.c->seg.threshold, q.c->seg.morphEdgeRadius,
-                                           q.c->seg.morphEdgeIterations, q.s);
-                        (void)hipStreamWaitEvent(q.s, q.c->ev_obj_global, 0);
-                    }, &mid);
-                    edges_done = true;
-                } else {
-                    enqueue_global_projection(c, bg, 0);
-                    int rc = make_obj_batch(c, objs, orders, d_rgb, d_depth, depthF, mask, weight_multiplier, nullptr, ob, blocks);
-                    if (rc != MF_OK) return rc;
-                    PassTimer timer(c, MF_PASS_OBJ_GLOBAL);
-                    launch_obj_global_scatter(ob, blocks, s);
-                }
+                int rc = make_obj_batch(c, objs, orders, d_rgb, d_depth, depthF, mask, weight_multiplier, nullptr, ob, blocks);
+                if (rc != MF_OK) return rc;
+                PassTimer timer(c, MF_PASS_OBJ_GLOBAL);
+                launch_obj_global_scatter(ob, blocks, s);
             } else {
                 for (size_t i = 0; i < c->models.size(); ++i) enqueue_global_projection(c, *c->models[i], (int)i);
             }
             launch_global_resolve(c->d_keys, c->d_proj_ids, P, s);
             if (c->timings_on) (void)hipEventRecord(c->ev_mm[0], s);
             // MfSegmentation::performSegmentation, device half (MfSegmentation.cpp:149-208)
-            if (!edges_done) {
-                launch_edge_map(c->d_vmap[set][0], c->d_nmap[set][0], c->d_edge, W, H, c->seg.weightDistance, c->seg.weightConvexity, s);
-                launch_edge_binary(c->d_edge, c->d_bin, c->d_tmp_u8, W, H, c->seg.threshold, c->seg.morphEdgeRadius,
-                                   c->seg.morphEdgeIterations, s);
-            }
+            launch_edge_map(c->d_vmap[set][0], c->d_nmap[set][0], c->d_edge, W, H, c->seg.weightDistance, c->seg.weightConvexity, s);
+            launch_edge_binary(c->d_edge, c->d_bin, c->d_tmp_u8, W, H, c->seg.threshold, c->seg.morphEdgeRadius,
+                               c->seg.morphEdgeIterations, s);
             const bool haveMasks = d_mask_in && class_ids && n_masks > 0;
             static const int32_t kNoClass[1] = {0};
             SegResult res;

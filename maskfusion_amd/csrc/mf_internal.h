@@ -400,8 +400,7 @@ int gn_solve_standalone(const double* sys29, const double* resultRt16, const flo
                         double* resultRt_out, float* Rcurr9, float* tcurr3, float* stats2, hipStream_t s);
 int launch_global_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
                         int timeDelta, int order, int id, int* tile_count, int* entries, int entries_cap, float4* rec0, float4* rec1, void* bbox,
-                        unsigned long long* keys, hipStream_t s, SplatTuning tune = SplatTuning(), const VisList* vis = nullptr,
-                        void (*between_bin_and_tile)(void*) = nullptr, void* between_ctx = nullptr);
+                        unsigned long long* keys, hipStream_t s, SplatTuning tune = SplatTuning(), const VisList* vis = nullptr);
 void launch_spawn_pose(PoseDev* obj, const PoseDev* bg, FrameDev* objFrame, const FrameDev* bgFrame, PoseDev* host_mirror,
                        hipStream_t s);
 void launch_static_pose(PoseDev* obj, const PoseDev* bg, PoseDev* host_mirror, hipStream_t s);

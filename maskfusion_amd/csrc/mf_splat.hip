@@ -400,7 +400,7 @@ __global__ __launch_bounds__(1024) void k_global_tile(const GlobalTileArgs a) {
 
 int launch_global_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
                         int timeDelta, int order, int id, int* tile_count, int* entries, int entries_cap, float4* rec0, float4* rec1, void* bbox,
-                        unsigned long long* keys, hipStream_t s, SplatTuning tune, const VisList* vis, void (*between)(void*), void* between_ctx) {
+                        unsigned long long* keys, hipStream_t s, SplatTuning tune, const VisList* vis) {
     const int tilesX = (W + kTile - 1) / kTile, tilesY = (H + kTile - 1) / kTile, nt = tilesX * tilesY;
     if (nt > kMaxTiles) return -1;
     const int g_sprite_lanes = splat_sprite_lanes(tune.sprite_lanes), g_tile_threads = splat_tile_threads(tune.tile_threads);
@@ -414,9 +414,6 @@ int launch_global_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W
     // 0.6 M-surfel map was 293 chunks = two rounds, the second one on 37 CUs)
     const int nblocks = min(512, (src.cap + 2 * kBinThreads - 1) / (2 * kBinThreads));
     hipLaunchKernelGGL(k_splat_bin, dim3(nblocks), dim3(kBinThreads), (size_t)2 * nt * sizeof(int), s, b);
-    // (the binning pass does not touch the key image, the tile pass merges into it: a caller that lets the object models' scatter run beside the
-    // binning puts its wait -- and whatever else is independent of the keys -- here)
-    if (between) between(between_ctx);
     GlobalTileArgs t;
     t.frame = frame; t.W = W; t.H = H; t.k = k; t.tilesX = tilesX; t.tilesY = tilesY; t.tile_count = tile_count; t.entries = entries; t.tile_cap = b.tile_cap;
     t.rec0 = rec0; t.rec1 = rec1; t.bbox = reinterpret_cast<const short4*>(bbox);

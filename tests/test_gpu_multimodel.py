@@ -308,10 +308,6 @@ def test_object_model_launch_switches_change_nothing(hip):
     tracked_one = run(track_all=True, objectStream=0)
     for _ in range(2):
         assert same(tracked_one, run(track_all=True, objectStream=1))
-    # "globalOverlapElements" = 0: the objects' GlobalProjection scatter on the object stream beside the background's binning, whatever their size
-    for _ in range(2):
-        assert same(one_stream, run(globalOverlapElements=0))
-    assert same(tracked_one, run(track_all=True, globalOverlapElements=0))
     # "fusedPreprocessLaunch" with a batched tracker: every tracked model's pyramid beside the depth filter (k_bilateral_model_pyramid, grid.z unrolled);
     # "batchSolveInPixelPass": one launch per iteration of the batched loop
     assert same(tracked_one, run(track_all=True, objectStream=0, fusedPreprocessLaunch=0))
