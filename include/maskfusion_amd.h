@@ -241,7 +241,10 @@ int mf_get_timings(mf_ctx* ctx, float* ms /* [MF_N_TIMINGS] */);
  *   6 bgAppend             ... and of the frame's candidates, appended (in-place form only)
  *   7 bgPredict            combinedPredict: k_cull + k_splat_bin + k_splat_tile (+ the end-of-frame bookkeeping)
  *   8 objGlobalProjection  9 objFuseClean (predictIndices, fuse, predictIndices, clean)   10 objPredict
- *   11 compaction          launch_densify + the run table of the compacted buffer (0 in a frame without one) */
+ *   11 compaction          launch_densify + the run table of the compacted buffer (0 in a frame without one)
+ * With "objectStream" on, rows 9 and 10 are timed on the object stream, where they run BESIDE rows 1-7: each row is then longer than the pass on
+ * its own and the rows no longer add up to the frame.  For passes on their own, switch the stage timings on as well ("timings": they keep the frame
+ * on one stream) or set "objectStream" to 0 -- bench.py's roofline_passes does the former. */
 #define MF_N_PASSES 12
 enum { MF_PASS_BG_GLOBAL = 0, MF_PASS_BG_INDEX, MF_PASS_BG_FUSE_DATA, MF_PASS_BG_FUSE_UPDATE, MF_PASS_BG_INDEX2, MF_PASS_BG_CLEAN, MF_PASS_BG_APPEND,
        MF_PASS_BG_PREDICT, MF_PASS_OBJ_GLOBAL, MF_PASS_OBJ_FUSE_CLEAN, MF_PASS_OBJ_PREDICT, MF_PASS_COMPACTION };
