@@ -1,3 +1,5 @@
+"""Per array of two .npz files (tools/state_dump2.py): NaN-pattern differences, number and size of value differences, byte equality.
+    python tools/state_cmp.py a.npz b.npz"""
 import numpy as np, sys
 a = np.load(sys.argv[1]); b = np.load(sys.argv[2])
 for t in a.files:

@@ -1,3 +1,6 @@
+"""The six model-side maps and the pose of the background after three frames of the scenario of tools/state_dump.py, saved as an .npz -- run in two
+trees (or with switches: `key=value,...` as the second argument), compare with tools/state_cmp.py.
+    PYTHONPATH=<tree> python tools/state_dump2.py out.npz [fusedPreprocessLaunch=0,...]"""
 import sys
 import numpy as np
 from maskfusion_amd import MaskFusion, synth
