@@ -65,9 +65,12 @@ struct LabTables {          // small device-resident tables
 
 __global__ void k_lab_models(LabTables* T, const int* ids, const int* cls, const PoseDev* const* poses, int nModels, const int* classIDs,
                              int nMasks) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0) return;
+    // (the four 256-entry tables are cleared by the whole wavefront: one thread walking them was 8 of this launch's 11 us)
+    for (int k = threadIdx.x; k < 256; k += blockDim.x) { T->idToIndex[k] = 0; T->idExact[k] = -1; T->maskPixels[k] = 0; T->classIDs[k] = 0; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     int n = 0;
-    for (int k = 0; k < 256; ++k) { T->idToIndex[k] = 0; T->idExact[k] = -1; T->maskPixels[k] = 0; T->classIDs[k] = 0; }
     for (int m = 0; m < nModels; ++m) {
         if (m > 0 && poses[m]->alive == 0) continue;   // dropped by the jump rule in this frame (MaskFusion.cpp:268-272)
         T->liveId[n] = ids[m]; T->liveCls[n] = cls[m];
