@@ -1077,6 +1077,7 @@ extern "C" int mf_set_param(mf_ctx* c, const char* key, double value) {
     if (!strcmp(key, "cleanLiteralWindow")) { c->clean_literal = value != 0; return MF_OK; }   // 0: the exact-arithmetic 4 x 4 window
     if (!strcmp(key, "earlyBackgroundFusion")) { c->early_bg_fusion = value != 0; return MF_OK; }
     if (!strcmp(key, "modelApiPackedIndex")) { c->model_api_packed = value != 0; return MF_OK; }   // 0: scatter + resolve form (specification)
+    if (!strcmp(key, "tileHeight")) { c->splat_tune.tile_h = (int)value; return MF_OK; }   // A/B: 16 x 24 (default), 16 x 20 or 16 x 16 pixel tiles
     if (!strcmp(key, "tileThreads")) { c->splat_tune.tile_threads = (int)value; return MF_OK; }   // A/B: threads per tile workgroup of the tile passes
     if (!strcmp(key, "spriteLanes")) { c->splat_tune.sprite_lanes = (int)value; return MF_OK; }   // A/B: lanes per sprite in the tile z-test (default 4)
     if (!strcmp(key, "confidenceThreshold")) { c->cfg.conf_global = (float)value; c->models[0]->confThr = (float)value; return MF_OK; }

@@ -345,7 +345,7 @@ void launch_splat_resolve(Surfels src, const PoseDev* pose, unsigned long long* 
 // tile_count must be zero on the first call (it is left zero).  Returns -1 if the image has too many tiles for the LDS
 // histograms (use the scatter form then).
 size_t splat_tiles_scratch_ints(int W, int H);
-struct SplatTuning { int sprite_lanes = 4, tile_threads = 512; };   // A/B knobs of the tile passes ("spriteLanes", "tileThreads"), owned by the context
+struct SplatTuning { int sprite_lanes = 4, tile_threads = 512, tile_h = 24; };   // A/B knobs of the tile passes ("spriteLanes", "tileThreads"), owned by the context
 // The end-of-frame bookkeeping (k_frame_advance: pose log entry, fill-in decision for the next tracking step, tick++, host mirror) as
 // the epilogue of the tiled prediction: its last workgroup to finish runs it, one launch less per model and frame.
 struct FrameAdvance { FrameDev* host_mirror; const PoseDev* bg_pose; float* log_slot; };

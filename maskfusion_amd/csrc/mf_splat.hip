@@ -17,7 +17,10 @@
 
 namespace mf {
 
-constexpr int kTile = 16;
+constexpr int kTile = 16;                // tile width in pixels
+constexpr int kTileHMax = 24;            // tile height: 24 (default since round 6), 20 or 16 pixels ("tileHeight", SplatTuning::tile_h) -- a launch parameter.
+                                         // 1 200 workgroups of 16 x 16 tiles at VGA are more than the 1 024 that are resident at once; 800 of 16 x 24 are one
+                                         // round: prediction stage 53.0 -> 50.8 us at VGA, the 1280 x 960 frame 861 -> 848 us (profiles/r06zj_ab.txt)
 constexpr int kBinThreads = 1024;
 constexpr int kMaxTiles = 8192;          // bounds the LDS histograms (VGA: 1200 tiles, 1280x960: 4800); larger images use the scatter form
 
@@ -71,10 +74,12 @@ int splat_sprite_lanes(int n) { return (n == 1 || n == 2 || n == 8 || n == 16) ?
 // Measured (profiles/r03k_*, prediction stage incl. binning): 256 threads 62.6 us, 512 threads 58.0 us, 1024 threads 65.9 us (4 lanes per
 // sprite each) -- 512 is the default.
 int splat_tile_threads(int n) { return (n == 256 || n == 320 || n == 384 || n == 1024) ? n : 512; }
+// tile height ("tileHeight"): 16, 20 or 24 rows of 16 pixels; the tile's pixels need a thread each
+int splat_tile_height(int h) { return (h == 16 || h == 20) ? h : 24; }
 
 struct BinArgs {
     Surfels src; const FrameDev* frame; const PoseDev* pose; int W, H; Intr k; float maxDepth, confThreshold; int timeDelta;
-    int tilesX, tilesY;
+    int tilesX, tilesY, tileH;
     int* tile_count;      // [tiles]  zero on entry (each tile workgroup re-zeroes its own counter when it is done)
     int* entries;         // [tiles][tile_cap]
     int tile_cap;
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(kBinThreads) void k_splat_bin(const BinArgs a) {
                 // repeating its ~300 instructions (ten IEEE divisions) each time
                 a.rec0[i] = make_float4(su.h.x, su.h.y, su.h.z, su.sqrRad);
                 a.rec1[i] = make_float4(su.nrm.x, su.nrm.y, su.nrm.z, su.pn);
-                for (int ty = su.py0 / kTile; ty <= su.py1 / kTile; ++ty)
+                for (int ty = su.py0 / a.tileH; ty <= su.py1 / a.tileH; ++ty)
                     for (int tx = su.px0 / kTile; tx <= su.px1 / kTile; ++tx) atomicAdd(&s_cnt[ty * a.tilesX + tx], 1);
             }
             a.bbox[i] = bb[r];   // also for surfels that draw nothing (empty box): the overflow path of the tile pass scans every box
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(kBinThreads) void k_splat_bin(const BinArgs a) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         if (bb[r].x > bb[r].y) continue;
-        for (int ty = bb[r].z / kTile; ty <= bb[r].w / kTile; ++ty)
+        for (int ty = bb[r].z / a.tileH; ty <= bb[r].w / a.tileH; ++ty)
             for (int tx = bb[r].x / kTile; tx <= bb[r].y / kTile; ++tx) {
                 const int t = ty * a.tilesX + tx;
                 const int slot = s_cnt[t] + atomicAdd(&s_fill[t], 1);
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(kBinThreads) void k_splat_bin(const BinArgs a) {
 
 struct TileArgs {
     Surfels src; FrameDev* frame; const PoseDev* pose; int W, H; Intr k; float maxDepth, confThreshold; int timeDelta;
-    int tilesX, tilesY;
+    int tilesX, tilesY, tileH;
     int* tile_count; const int* entries; int tile_cap;
     const float4* rec0; const float4* rec1; const short4* bbox;
     float4* predV; float4* predN; uchar4* predImage; uint16_t* predTime;
@@ -176,13 +181,13 @@ struct TileArgs {
 // model order / id): rays of the tile's pixels, the tile's sprite list (or, after a list overflow, every sprite box of the map),
 // ds_min_u64 per covered pixel.  On return s_key[pixel of the tile] holds the winning key (all threads have passed a barrier).
 template <bool kIndexPayload, int kSpriteLanes>
-__device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* tile_count, const int* entries, int tile_cap,
+__device__ __forceinline__ void tile_ztest(int tile, int tilesX, int tileH, Intr k, int* tile_count, const int* entries, int tile_cap,
                                            const FrameDev* frame, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                                            const short4* __restrict__ bbox, unsigned payload, unsigned long long* s_key, float4* s_ray,
                                            int* s_range, bool prof, TileStamps& stamp, const int* __restrict__ vis_list,
                                            const int* __restrict__ vis_count, const int4* __restrict__ runs) {
-    const int tx0 = (tile % tilesX) * kTile, ty0 = (tile / tilesX) * kTile;
-    if (threadIdx.x < kTile * kTile) {
+    const int tx0 = (tile % tilesX) * kTile, ty0 = (tile / tilesX) * tileH;
+    if ((int)threadIdx.x < kTile * tileH) {
     s_key[threadIdx.x] = kEmptyKey;
     {   // the viewing ray of every pixel of the tile, once (combo_splat.frag:40-42); the per-surfel loops below re-used to
         // spend two thirds of their instructions recomputing it (two divisions + a normalisation per covered pixel)
@@ -240,7 +245,7 @@ __device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* ti
         if (i1 >= 0) { bb0 = bbox[i1]; r0 = rec0[i1]; r1 = rec1[i1]; } else bb0 = kNoBox;
         i0 = i1; i1 = i2;
         const int x0 = max((int)bb.x, tx0), x1 = min((int)bb.y, tx0 + kTile - 1);
-        const int y0 = max((int)bb.z, ty0), y1 = min((int)bb.w, ty0 + kTile - 1);
+        const int y0 = max((int)bb.z, ty0), y1 = min((int)bb.w, ty0 + tileH - 1);
         if (x0 > x1 || y0 > y1) continue;
         SplatSetup su;
         su.h = f3(c0.x, c0.y, c0.z); su.sqrRad = c0.w; su.nrm = f3(c1.x, c1.y, c1.z); su.pn = c1.w;
@@ -273,8 +278,8 @@ __device__ __forceinline__ void tile_ztest(int tile, int tilesX, Intr k, int* ti
 // (combo_splat.frag) of every pixel of the tile.
 template <int kSpriteLanes>
 __global__ __launch_bounds__(1024) void k_splat_tile(const TileArgs a) {
-    __shared__ unsigned long long s_key[kTile * kTile];
-    __shared__ float4 s_ray[kTile * kTile];
+    __shared__ unsigned long long s_key[kTile * kTileHMax];
+    __shared__ float4 s_ray[kTile * kTileHMax];
     __shared__ int s_range[1];
     __shared__ int s_cover;
     // XCD k draws the k-th contiguous eighth of the tile list (mf_device.h): a sprite overlaps 1.8 tiles on average, and neighbouring
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(1024) void k_splat_tile(const TileArgs a) {
     // takes its ticket below.
     const int tile = xcd_contiguous_tile(blockIdx.x, a.tilesX * a.tilesY);
     const bool live = tile < a.tilesX * a.tilesY;
-    const int tx0 = (tile % a.tilesX) * kTile, ty0 = (tile / a.tilesX) * kTile;
+    const int tx0 = (tile % a.tilesX) * kTile, ty0 = (tile / a.tilesX) * a.tileH;
     const Intr k = a.k;
     if (threadIdx.x == 0) s_cover = 0;   // (ordered before its use by the barriers inside tile_ztest)
     TileStamps stamp;
@@ -292,14 +297,14 @@ __global__ __launch_bounds__(1024) void k_splat_tile(const TileArgs a) {
         for (int q = 0; q < 8; ++q) stamp.t[q] = 0;
         stamp.t[0] = __builtin_amdgcn_s_memtime();
     }
-    if (live) tile_ztest<true, kSpriteLanes>(tile, a.tilesX, k, a.tile_count, a.entries, a.tile_cap, a.frame, a.rec0, a.rec1, a.bbox, 0u, s_key, s_ray, s_range,
+    if (live) tile_ztest<true, kSpriteLanes>(tile, a.tilesX, a.tileH, k, a.tile_count, a.entries, a.tile_cap, a.frame, a.rec0, a.rec1, a.bbox, 0u, s_key, s_ray, s_range,
                                             prof, stamp, a.vis_list, a.vis_count, a.src.box);
     const int px = tx0 + (threadIdx.x & (kTile - 1)), py = ty0 + (threadIdx.x >> 4);
     int covered = 0;   // this pixel is one of the 20x down-sampled samples of MaskFusion::requiresFillIn and carries a colour
     // (gathering the winners' records along the tile's COLUMNS and transposing the outputs through the LDS -- what made the index map's resolve
     // twice as fast -- changes nothing here: 61.3 against 60.0 us for the stage, profiles/r05r_ab.txt; a sprite covers ~4 x 4 pixels, neighbouring
     // pixels share their winner either way)
-    if (live && threadIdx.x < kTile * kTile && px < a.W && py < a.H) {   // (threads beyond the tile's 256 pixels only helped with the list)
+    if (live && (int)threadIdx.x < kTile * a.tileH && px < a.W && py < a.H) {   // (threads beyond the tile's 256 pixels only helped with the list)
       const int p = py * a.W + px;
       const unsigned long long key = s_key[threadIdx.x];
       if (key == kEmptyKey) {
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(1024) void k_splat_tile(const TileArgs a) {
 // as k_global_scatter (mf_segment.hip), which stays for small (object) models: one global atomic per covered pixel is memory-side
 // work (see the header) and cost ~170 us per frame for a 250 k-surfel background model against ~25 us here.
 struct GlobalTileArgs {
-    const FrameDev* frame; int W, H; Intr k; int tilesX, tilesY;
+    const FrameDev* frame; int W, H; Intr k; int tilesX, tilesY, tileH;
     int* tile_count; const int* entries; int tile_cap;
     const float4* rec0; const float4* rec1; const short4* bbox;
     unsigned payload; unsigned long long* keys;
@@ -382,16 +387,16 @@ struct GlobalTileArgs {
 };
 template <int kSpriteLanes>
 __global__ __launch_bounds__(1024) void k_global_tile(const GlobalTileArgs a) {
-    __shared__ unsigned long long s_key[kTile * kTile];
-    __shared__ float4 s_ray[kTile * kTile];
+    __shared__ unsigned long long s_key[kTile * kTileHMax];
+    __shared__ float4 s_ray[kTile * kTileHMax];
     __shared__ int s_range[1];
     const int tile = xcd_contiguous_tile(blockIdx.x, a.tilesX * a.tilesY);
     if (tile >= a.tilesX * a.tilesY) return;
     TileStamps unused;
-    tile_ztest<false, kSpriteLanes>(tile, a.tilesX, a.k, a.tile_count, a.entries, a.tile_cap, a.frame, a.rec0, a.rec1, a.bbox, a.payload, s_key, s_ray, s_range,
+    tile_ztest<false, kSpriteLanes>(tile, a.tilesX, a.tileH, a.k, a.tile_count, a.entries, a.tile_cap, a.frame, a.rec0, a.rec1, a.bbox, a.payload, s_key, s_ray, s_range,
                                     false, unused, a.vis_list, a.vis_count, a.runs);
-    const int px = (tile % a.tilesX) * kTile + (threadIdx.x & (kTile - 1)), py = (tile / a.tilesX) * kTile + (threadIdx.x >> 4);
-    if (threadIdx.x >= kTile * kTile || px >= a.W || py >= a.H) return;
+    const int px = (tile % a.tilesX) * kTile + (threadIdx.x & (kTile - 1)), py = (tile / a.tilesX) * a.tileH + (threadIdx.x >> 4);
+    if ((int)threadIdx.x >= kTile * a.tileH || px >= a.W || py >= a.H) return;
     const unsigned long long key = s_key[threadIdx.x];
     if (key == kEmptyKey) return;
     const int p = py * a.W + px;
@@ -401,12 +406,13 @@ __global__ __launch_bounds__(1024) void k_global_tile(const GlobalTileArgs a) {
 int launch_global_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W, int H, Intr k, float maxDepth, float confThreshold,
                         int timeDelta, int order, int id, int* tile_count, int* entries, int entries_cap, float4* rec0, float4* rec1, void* bbox,
                         unsigned long long* keys, hipStream_t s, SplatTuning tune, const VisList* vis) {
-    const int tilesX = (W + kTile - 1) / kTile, tilesY = (H + kTile - 1) / kTile, nt = tilesX * tilesY;
+    const int tileH = splat_tile_height(tune.tile_h);
+    const int tilesX = (W + kTile - 1) / kTile, tilesY = (H + tileH - 1) / tileH, nt = tilesX * tilesY;
     if (nt > kMaxTiles) return -1;
-    const int g_sprite_lanes = splat_sprite_lanes(tune.sprite_lanes), g_tile_threads = splat_tile_threads(tune.tile_threads);
+    const int g_sprite_lanes = splat_sprite_lanes(tune.sprite_lanes), g_tile_threads = std::max(splat_tile_threads(tune.tile_threads), ((kTile * tileH + 63) / 64) * 64);
     BinArgs b;
     b.src = src; b.frame = frame; b.pose = pose; b.W = W; b.H = H; b.k = k; b.maxDepth = maxDepth; b.confThreshold = confThreshold;
-    b.timeDelta = timeDelta; b.tilesX = tilesX; b.tilesY = tilesY; b.tile_count = tile_count;
+    b.timeDelta = timeDelta; b.tilesX = tilesX; b.tilesY = tilesY; b.tileH = tileH; b.tile_count = tile_count;
     b.entries = entries; b.tile_cap = entries_cap / nt; b.frame_rw = frame;
     b.rec0 = rec0; b.rec1 = rec1; b.bbox = reinterpret_cast<short4*>(bbox);
     b.vis_list = vis ? vis->list : nullptr; b.vis_count = vis ? vis->count : nullptr;
@@ -415,7 +421,7 @@ int launch_global_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W
     const int nblocks = min(512, (src.cap + 2 * kBinThreads - 1) / (2 * kBinThreads));
     hipLaunchKernelGGL(k_splat_bin, dim3(nblocks), dim3(kBinThreads), (size_t)2 * nt * sizeof(int), s, b);
     GlobalTileArgs t;
-    t.frame = frame; t.W = W; t.H = H; t.k = k; t.tilesX = tilesX; t.tilesY = tilesY; t.tile_count = tile_count; t.entries = entries; t.tile_cap = b.tile_cap;
+    t.frame = frame; t.W = W; t.H = H; t.k = k; t.tilesX = tilesX; t.tilesY = tilesY; t.tileH = tileH; t.tile_count = tile_count; t.entries = entries; t.tile_cap = b.tile_cap;
     t.rec0 = rec0; t.rec1 = rec1; t.bbox = reinterpret_cast<const short4*>(bbox);
     t.payload = ((unsigned)order << 8) | ((unsigned)id & 255u); t.keys = keys;
     t.vis_list = b.vis_list; t.vis_count = b.vis_count; t.runs = src.box;
@@ -435,12 +441,13 @@ int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W,
                        int timeDelta, int* tile_count, int* entries, int entries_cap, float4* rec0, float4* rec1, void* bbox, float4* predV,
                        float4* predN, uchar4* predImage, uint16_t* predTime, const uint8_t* rgb, uint8_t* predGray, uint8_t* fillGray, hipStream_t s,
                        const FrameAdvance* advance, int fillPassthrough, unsigned long long* prof, SplatTuning tune, const VisList* vis) {
-    const int tilesX = (W + kTile - 1) / kTile, tilesY = (H + kTile - 1) / kTile, nt = tilesX * tilesY;
+    const int tileH = splat_tile_height(tune.tile_h);
+    const int tilesX = (W + kTile - 1) / kTile, tilesY = (H + tileH - 1) / tileH, nt = tilesX * tilesY;
     if (nt > kMaxTiles) return -1;
-    const int g_sprite_lanes = splat_sprite_lanes(tune.sprite_lanes), g_tile_threads = splat_tile_threads(tune.tile_threads);
+    const int g_sprite_lanes = splat_sprite_lanes(tune.sprite_lanes), g_tile_threads = std::max(splat_tile_threads(tune.tile_threads), ((kTile * tileH + 63) / 64) * 64);
     BinArgs b;
     b.src = src; b.frame = frame; b.pose = pose; b.W = W; b.H = H; b.k = k; b.maxDepth = maxDepth; b.confThreshold = confThreshold;
-    b.timeDelta = timeDelta; b.tilesX = tilesX; b.tilesY = tilesY; b.tile_count = tile_count;
+    b.timeDelta = timeDelta; b.tilesX = tilesX; b.tilesY = tilesY; b.tileH = tileH; b.tile_count = tile_count;
     b.entries = entries; b.tile_cap = entries_cap / nt; b.frame_rw = frame;
     b.rec0 = rec0; b.rec1 = rec1; b.bbox = reinterpret_cast<short4*>(bbox);
     b.vis_list = vis ? vis->list : nullptr; b.vis_count = vis ? vis->count : nullptr;
@@ -450,7 +457,7 @@ int launch_splat_tiled(Surfels src, FrameDev* frame, const PoseDev* pose, int W,
     hipLaunchKernelGGL(k_splat_bin, dim3(nblocks), dim3(kBinThreads), (size_t)2 * nt * sizeof(int), s, b);
     TileArgs t;
     t.src = src; t.frame = frame; t.pose = pose; t.W = W; t.H = H; t.k = k; t.maxDepth = maxDepth; t.confThreshold = confThreshold;
-    t.timeDelta = timeDelta; t.tilesX = tilesX; t.tilesY = tilesY; t.tile_count = tile_count;
+    t.timeDelta = timeDelta; t.tilesX = tilesX; t.tilesY = tilesY; t.tileH = tileH; t.tile_count = tile_count;
     t.entries = entries; t.tile_cap = b.tile_cap; t.rec0 = rec0; t.rec1 = rec1; t.bbox = reinterpret_cast<const short4*>(bbox);
     t.predV = predV; t.predN = predN; t.predImage = predImage; t.predTime = predTime; t.rgb = rgb; t.predGray = predGray;
     t.fillGray = fillGray;

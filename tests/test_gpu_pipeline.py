@@ -141,12 +141,16 @@ def test_tile_pass_launch_shapes_change_nothing(hip):
     from maskfusion_amd import MaskFusion
     st, fr = scene_frames(8, noise=True)
     runs = []
-    shapes = [(None, None, 0), (4, 256, 1), (1, 256, 1), (2, 512, 1), (4, 1024, 1), (8, 1024, 1), (16, 512, 1)]
+    # (lanes per sprite, threads per tile workgroup, tile passes on, tile height: round 6 -- 16 x 20 / 16 x 24 pixel tiles, also with workgroups smaller
+    # than a tile has pixels asked for)
+    shapes = [(None, None, 0, 16), (4, 256, 1, 16), (1, 256, 1, 16), (2, 512, 1, 16), (4, 1024, 1, 16), (8, 1024, 1, 16), (16, 512, 1, 16),
+              (4, 512, 1, 20), (4, 256, 1, 20), (2, 384, 1, 24), (4, 1024, 1, 24)]
     try:
-        for lanes, threads, tiles in shapes:
+        for lanes, threads, tiles, height in shapes:
             mf = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=10.0, so3=True, enableMultipleModels=False,
                             numGSurfels=1 << 20, initConfidenceGlobal=2.0)
             mf.setParam("splatTiles", tiles)
+            mf.setParam("tileHeight", height)
             if lanes:
                 mf.setParam("spriteLanes", lanes)
                 mf.setParam("tileThreads", threads)
@@ -160,6 +164,7 @@ def test_tile_pass_launch_shapes_change_nothing(hip):
         mf = M(st.W, st.H, st.fx, st.fy, st.cx, st.cy, enableMultipleModels=False, numGSurfels=1 << 16)
         mf.setParam("spriteLanes", 4)
         mf.setParam("tileThreads", 512)
+        mf.setParam("tileHeight", 24)
         mf.close()
     ref = runs[0]
     assert (ref["v"][..., 2] > 0).mean() > 0.2
