@@ -203,7 +203,7 @@ int mf_get_last_fillin(mf_ctx* ctx, int32_t* used);
  * two independent kernels of a frame side by side; 0: two launches; same bytes),
  * "hostLockstep" (1: mf_process_frame waits for frame k-2 to have run before it enqueues frame k's
  * upload), "hostWaitUpload" (1: ... and for its own upload: single-model frames), "modelApiPackedIndex" (0; 1: mf_model_predict_indices
- * also builds the packed column-major map mf_process_frame feeds Model::clean with), "tileThreads" (512) / "spriteLanes" (4) / "tileHeight" (24; 16, 20: tiles of 16 x 24 / 16 x 16 / 16 x 20 pixels): launch shape of
+ * also builds the packed column-major map mf_process_frame feeds Model::clean with), "tileThreads" (512) / "spriteLanes" (4) / "tileHeight" (24; 16, 20, 32: tiles of 16 pixels by that many rows): launch shape of
  * the tile passes (A/B), "splatTileEntries" (test knob: shrinks the tile lists to force their overflow path), "rebuildRunTable" (write-only:
  * rebuilds the background's run table from scratch), "splatProfile" (1: per-tile stamps of the background's tile pass, debug tap
  * "splat_prof").  Read-only (mf_get_param): "visibleRuns" / "backgroundRuns" (runs k_cull listed for the last pass / runs of the

@@ -18,9 +18,10 @@
 namespace mf {
 
 constexpr int kTile = 16;                // tile width in pixels
-constexpr int kTileHMax = 24;            // tile height: 24 (default since round 6), 20 or 16 pixels ("tileHeight", SplatTuning::tile_h) -- a launch parameter.
+constexpr int kTileHMax = 32;            // tile height: 24 (default since round 6), 16, 20 or 32 pixels ("tileHeight", SplatTuning::tile_h) -- a launch parameter.
                                          // 1 200 workgroups of 16 x 16 tiles at VGA are more than the 1 024 that are resident at once; 800 of 16 x 24 are one
-                                         // round: prediction stage 53.0 -> 50.8 us at VGA, the 1280 x 960 frame 861 -> 848 us (profiles/r06zj_ab.txt)
+                                         // round: prediction stage 53.0 -> 50.8 us at VGA, the 1280 x 960 frame 861 -> 848 us (profiles/r06zj_ab.txt); 16 x 32: 52.6 us at VGA, 843 us at
+                                         // 1280 x 960, configs[4] unchanged (r06zk_ab.txt)
 constexpr int kBinThreads = 1024;
 constexpr int kMaxTiles = 8192;          // bounds the LDS histograms (VGA: 1200 tiles, 1280x960: 4800); larger images use the scatter form
 
@@ -75,7 +76,7 @@ int splat_sprite_lanes(int n) { return (n == 1 || n == 2 || n == 8 || n == 16) ?
 // sprite each) -- 512 is the default.
 int splat_tile_threads(int n) { return (n == 256 || n == 320 || n == 384 || n == 1024) ? n : 512; }
 // tile height ("tileHeight"): 16, 20 or 24 rows of 16 pixels; the tile's pixels need a thread each
-int splat_tile_height(int h) { return (h == 16 || h == 20) ? h : 24; }
+int splat_tile_height(int h) { return (h == 16 || h == 20 || h == 32) ? h : 24; }
 
 struct BinArgs {
     Surfels src; const FrameDev* frame; const PoseDev* pose; int W, H; Intr k; float maxDepth, confThreshold; int timeDelta;

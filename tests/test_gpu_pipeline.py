@@ -141,10 +141,10 @@ def test_tile_pass_launch_shapes_change_nothing(hip):
     from maskfusion_amd import MaskFusion
     st, fr = scene_frames(8, noise=True)
     runs = []
-    # (lanes per sprite, threads per tile workgroup, tile passes on, tile height: round 6 -- 16 x 20 / 16 x 24 pixel tiles, also with workgroups smaller
+    # (lanes per sprite, threads per tile workgroup, tile passes on, tile height: round 6 -- 16 x 20 / 16 x 24 / 16 x 32 pixel tiles, also with workgroups smaller
     # than a tile has pixels asked for)
     shapes = [(None, None, 0, 16), (4, 256, 1, 16), (1, 256, 1, 16), (2, 512, 1, 16), (4, 1024, 1, 16), (8, 1024, 1, 16), (16, 512, 1, 16),
-              (4, 512, 1, 20), (4, 256, 1, 20), (2, 384, 1, 24), (4, 1024, 1, 24)]
+              (4, 512, 1, 20), (4, 256, 1, 20), (2, 384, 1, 24), (4, 1024, 1, 24), (4, 512, 1, 32), (8, 256, 1, 32)]
     try:
         for lanes, threads, tiles, height in shapes:
             mf = MaskFusion(st.W, st.H, st.fx, st.fy, st.cx, st.cy, icpThresh=10.0, so3=True, enableMultipleModels=False,
