@@ -18,3 +18,5 @@ python tools/emu_schedule_check.py; MF_BIG_FORMS=1 python tools/emu_schedule_che
 python tools/emu_fuzz.py 100 1000; FUZZ_ODD_SIZES=1 python tools/emu_fuzz.py 60 11000; python tools/emu_fuzz.py 30 7000 mm
 python tools/emu_fuzz_labels.py 300 100
 LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 MF_EMU_ASAN=1 python tools/emu_fuzz_api.py 30 700
+# (gpurun refuses a snapshot that holds -fsanitize objects, whatever .gpurunignore says: the sanitizer builds do not outlive this script)
+rm -f tests/_build/emua_* tests/_build/emuca_* tests/_build/*asan* tests/_build/*ubsan*
