@@ -1669,9 +1669,16 @@ __global__ __launch_bounds__(256) void k_model_pyramid(const PyrArgs a) { model_
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bilateral_model_pyramid(const float* __restrict__ depth, float* __restrict__ out, int W, int H, int nbil,
                                                                  const PyrArgs a) {
     __shared__ float tile[kBLdsH * kBLdsW];
-    if ((int)blockIdx.x < nbil) { bilateral_body(depth, out, W, H, tile, (int)blockIdx.x); return; }
-    // (a.b.n > 0: the batched tracker's pyramids, model by model -- k_model_pyramid's grid.z unrolled behind the filter's workgroups)
-    const int j = (int)blockIdx.x - nbil, gx = ((W >> 2) + 15) / 16, gy = ((H >> 2) + 3) / 4, per = gx * gy;
+    // Which half a workgroup belongs to.  Workgroups are dispatched in index order: with the filter's first and the pyramids' behind them, a launch
+    // that does not fit the GPU at once (1280 x 960: 4 808 + 1 200 per tracked model) ran the two halves one after the other.  The pyramids' workgroups
+    // are therefore spread evenly among the filter's (a Bresenham walk: workgroup b is a pyramid workgroup when floor((b + 1) npyr / total) steps),
+    // so that the VALU-bound half and the bandwidth-bound half are in flight together from the first round on.
+    const int gx = ((W >> 2) + 15) / 16, gy = ((H >> 2) + 3) / 4, per = gx * gy;
+    const int total = (int)gridDim.x, npyr = total - nbil, b = (int)blockIdx.x;
+    const int before = (int)(((long long)b * npyr) / total), after = (int)(((long long)(b + 1) * npyr) / total);
+    if (after == before) { bilateral_body(depth, out, W, H, tile, b - before); return; }
+    // (a.b.n > 0: the batched tracker's pyramids, model by model -- k_model_pyramid's grid.z unrolled)
+    const int j = before;
     model_pyramid_body(a, (j % per) % gx, (j % per) / gx, j / per);
 }
 
