@@ -411,7 +411,7 @@ static int enqueue_fuse_clean(mf_ctx* c, ModelState& m, const uint8_t* d_rgb, co
         enqueue_clean_in_place(c, m, in, cull_clean, timed);
     } else {
         PassTimer t(c, timed ? MF_PASS_BG_CLEAN : -1);
-        launch_clean_small(in, m.surf[live], m.surf[1 - live], s);
+        launch_clean_small(in, m.surf[live], m.surf[1 - live], s, compact_blocks_for((long)*m.h_count + cand_max(c)));
         m.cur = 1 - live;
     }
     after_clean(c, m, in_place);
@@ -685,7 +685,9 @@ static int enqueue_fusion_loop(mf_ctx* c, size_t first, bool multi, const uint8_
         if (!in_place) for (ModelState* m : objs) if (!update_copy(c, *m)) ob.updateCopy = 0;
         {
             PassTimer timer(c, MF_PASS_OBJ_FUSE_CLEAN, c->obj_s);
-            launch_obj_fuse_clean(ob, blocks, cblocks, c->obj_s);
+            long most = 0;
+            for (ModelState* m : objs) most = std::max(most, (long)*m->h_count);
+            launch_obj_fuse_clean(ob, blocks, cblocks, c->obj_s, in_place ? kCompactBlocks : compact_blocks_for(most + cand_max(c)));
         }
         for (ModelState* m : objs) {   // copy-update: a -> b -> a; in-place update + two-launch clean: a -> b -- b is the live buffer now; in place: a
             if (!in_place && !ob.updateCopy) m->cur = 1 - m->cur;

@@ -314,7 +314,8 @@ __host__ __device__ inline unsigned long long append_mirror(unsigned seq, int ru
            (unsigned long long)(unsigned)phys;
 }
 // two launches (flags + ordered copy), src -> dst: dst is a DENSE buffer without a run table.  src must be dense.
-void launch_clean_small(const CleanIn& in, Surfels src, Surfels dst, hipStream_t s);
+int compact_blocks_for(long elements);   // workgroups of an ordered-compaction launch for that many elements (<= kCompactBlocks)
+void launch_clean_small(const CleanIn& in, Surfels src, Surfels dst, hipStream_t s, int blocks = kCompactBlocks);
 // IN PLACE (mf_surfel.hip "clean, in place"; buf has a run table): launch_clean_runs tests the surfels of the listed runs (nullptr: of every run)
 // and compacts each run where it stands; launch_clean_append tests the frame's candidates and appends the survivors behind the last run.
 // ctl: kCleanCtlInts ints, zero between launches; blocks: clean_runs_grid(elements expected)
@@ -384,7 +385,7 @@ struct ObjBatch {
     unsigned long long* global_keys;
 };
 void launch_obj_global_scatter(const ObjBatch& b, int blocks, hipStream_t s);          // GlobalProjection of every object model (mf_segment.hip)
-void launch_obj_fuse_clean(const ObjBatch& b, int blocks, int clean_blocks, hipStream_t s);   // predictIndices -> fuse -> predictIndices -> clean
+void launch_obj_fuse_clean(const ObjBatch& b, int blocks, int clean_blocks, hipStream_t s, int compact_blocks = kCompactBlocks);   // predictIndices -> fuse -> predictIndices -> clean
 void launch_obj_predict_advance(const ObjBatch& b, int blocks, hipStream_t s);         // combinedPredict (scatter form) + the end-of-frame bookkeeping
 void launch_fill_keys(unsigned long long* keys, int n, hipStream_t s);
 void launch_fill_int(int* p, int v, int n, hipStream_t s);

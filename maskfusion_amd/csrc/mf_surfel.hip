@@ -55,8 +55,11 @@ __device__ __forceinline__ int cand_count(int W, int H, int tick) {
     return ((W - par + 1) / 2) * ((H - par + 1) / 2);
 }
 
+// (the grid of an ordered-compaction launch is at most kCompactBlocks workgroups -- the size of its count array -- and the host's choice below that:
+// compact_blocks_for)
 __device__ __forceinline__ int chunk_size(int n) {
-    const int c = (n + kCompactBlocks - 1) / kCompactBlocks;
+    const int blocks = (int)gridDim.x;
+    const int c = (n + blocks - 1) / blocks;
     return ((c + 255) / 256) * 256;
 }
 
@@ -1539,10 +1542,15 @@ static CleanArgs clean_args(const CleanIn& in, Surfels src, Surfels dst) {
     a.append = 0; a.run_list = nullptr; a.run_count = nullptr; a.ctl = nullptr;
     return a;
 }
-void launch_clean_small(const CleanIn& in, Surfels src, Surfels dst, hipStream_t s) {
+// Workgroups of the two ordered-compaction launches for `elements` elements (the host's last known count: any grid is correct).  A VGA map
+// (0.75 M elements) is fastest on 2 048 (303.6 against 309-313 us per frame on 1 024 and 305.0 on 4 096); from ~1.5 M elements on, 1 024 workgroups
+// with longer slices win: 1280 x 960 on its natural map 847 -> 835 us, the four 3.7 M-element object maps of configs[4] 4.16 -> 4.07-4.12 ms
+// (profiles/r06zo_ab.txt, r06zp_ab.txt).
+int compact_blocks_for(long elements) { return elements >= 1500000L ? kCompactBlocks / 2 : kCompactBlocks; }
+void launch_clean_small(const CleanIn& in, Surfels src, Surfels dst, hipStream_t s, int blocks) {
     const CleanArgs a = clean_args(in, src, dst);
-    hipLaunchKernelGGL(k_clean_small_flags, dim3(kCompactBlocks), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_clean_small_compact, dim3(kCompactBlocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_clean_small_flags, dim3(blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_clean_small_compact, dim3(blocks), dim3(256), 0, s, a);
 }
 void launch_clean_runs(const CleanIn& in, Surfels buf, const VisList* runs, int* ctl, int blocks, hipStream_t s) {
     CleanArgs a = clean_args(in, buf, buf);
@@ -1623,7 +1631,7 @@ __global__ void k_obj_frame_advance(const ObjBatch b) {
     frame_advance_body(m.frame, b.W, b.H, m.host_frame, m.pose, b.bg_pose, m.log_slot);
 }
 
-void launch_obj_fuse_clean(const ObjBatch& b, int blocks, int clean_blocks, hipStream_t s) {
+void launch_obj_fuse_clean(const ObjBatch& b, int blocks, int clean_blocks, hipStream_t s, int compact_blocks) {
     const int P = b.W * b.H;
     const dim3 surfels(blocks, 1, b.n), pixels((P + 255) / 256, 1, b.n), compact(clean_blocks, 1, b.n);
     const dim3 cands(((b.W + 1) / 2 + 63) / 64, ((b.H + 1) / 2 + 3) / 4, b.n);
@@ -1640,8 +1648,8 @@ void launch_obj_fuse_clean(const ObjBatch& b, int blocks, int clean_blocks, hipS
     // two-launch form src -> dst, or (big models) the buffer's own surfels in place, run by run -- an object model's launch visits every run: its
     // bounding box is the box of ALL its drawn surfels -- and then the frame's candidates appended by the two-launch form
     if (!b.cleanSmall) hipLaunchKernelGGL(k_obj_clean_runs, compact, dim3(256), 0, s, b);
-    hipLaunchKernelGGL(k_obj_clean_small_flags, dim3(kCompactBlocks, 1, b.n), dim3(256), 0, s, b);
-    hipLaunchKernelGGL(k_obj_clean_small_compact, dim3(kCompactBlocks, 1, b.n), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_obj_clean_small_flags, dim3(compact_blocks, 1, b.n), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_obj_clean_small_compact, dim3(compact_blocks, 1, b.n), dim3(256), 0, s, b);
 }
 void launch_obj_predict_advance(const ObjBatch& b, int blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_obj_splat_scatter, dim3(blocks, 1, b.n), dim3(256), 0, s, b);
