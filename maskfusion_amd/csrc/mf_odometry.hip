@@ -1667,15 +1667,19 @@ __global__ __launch_bounds__(256) void k_model_pyramid(const PyrArgs a) { model_
 // the same instructions on the same data as the two kernels, hence the same bits.
 // (six wavefronts per SIMD = six workgroups per compute unit: at VGA all 1 508 workgroups are resident at once; the pyramid half would take 83 registers)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bilateral_model_pyramid(const float* __restrict__ depth, float* __restrict__ out, int W, int H, int nbil,
-                                                                 const PyrArgs a) {
+                                                                 int interleave, const PyrArgs a) {
     __shared__ float tile[kBLdsH * kBLdsW];
     // Which half a workgroup belongs to.  Workgroups are dispatched in index order: with the filter's first and the pyramids' behind them, a launch
     // that does not fit the GPU at once (1280 x 960: 4 808 + 1 200 per tracked model) ran the two halves one after the other.  The pyramids' workgroups
     // are therefore spread evenly among the filter's (a Bresenham walk: workgroup b is a pyramid workgroup when floor((b + 1) npyr / total) steps),
     // so that the VALU-bound half and the bandwidth-bound half are in flight together from the first round on.
     const int gx = ((W >> 2) + 15) / 16, gy = ((H >> 2) + 3) / 4, per = gx * gy;
+    // (a launch that IS resident at once -- VGA, one tracked model: 1 508 workgroups -- keeps the filter's workgroups first: their index is what
+    // places a tile on the XCD that holds its neighbours' halo rows, worth 1 us there)
     const int total = (int)gridDim.x, npyr = total - nbil, b = (int)blockIdx.x;
-    const int before = (int)(((long long)b * npyr) / total), after = (int)(((long long)(b + 1) * npyr) / total);
+    int before, after;
+    if (interleave) { before = (int)(((long long)b * npyr) / total); after = (int)(((long long)(b + 1) * npyr) / total); }
+    else { before = b < nbil ? 0 : b - nbil; after = b < nbil ? 0 : b - nbil + 1; }
     if (after == before) { bilateral_body(depth, out, W, H, tile, b - before); return; }
     // (a.b.n > 0: the batched tracker's pyramids, model by model -- k_model_pyramid's grid.z unrolled)
     const int j = before;
@@ -1709,7 +1713,7 @@ void launch_bilateral_model_pyramid(const float* depth, float* depthF, const flo
     a.W = W; a.H = H; a.k = k;
     a.b.n = 0;
     const int nbil = bilateral_grid(W, H), npyr = (((W >> 2) + 15) / 16) * (((H >> 2) + 3) / 4);
-    hipLaunchKernelGGL(k_bilateral_model_pyramid, dim3(nbil + npyr), dim3(256), 0, s, depth, depthF, W, H, nbil, a);
+    hipLaunchKernelGGL(k_bilateral_model_pyramid, dim3(nbil + npyr), dim3(256), 0, s, depth, depthF, W, H, nbil, (nbil + npyr > 1536) ? 1 : 0, a);
 }
 
 // ... and for the batched tracker: the filter beside launch_model_pyramid_batch's work
@@ -1719,7 +1723,7 @@ void launch_bilateral_model_pyramid_batch(const float* depth, float* depthF, con
     memset(&a, 0, sizeof(a));
     a.fillDepth = fillDepth; a.W = W; a.H = H; a.k = k; a.b = b;
     const int nbil = bilateral_grid(W, H), npyr = (((W >> 2) + 15) / 16) * (((H >> 2) + 3) / 4) * b.n;
-    hipLaunchKernelGGL(k_bilateral_model_pyramid, dim3(nbil + npyr), dim3(256), 0, s, depth, depthF, W, H, nbil, a);
+    hipLaunchKernelGGL(k_bilateral_model_pyramid, dim3(nbil + npyr), dim3(256), 0, s, depth, depthF, W, H, nbil, (nbil + npyr > 1536) ? 1 : 0, a);
 }
 
 void launch_model_pyramid_batch(const TrackBatch& b, const float* fillDepth, int W, int H, Intr k, hipStream_t s) {
