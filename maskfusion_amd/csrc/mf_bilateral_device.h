@@ -50,7 +50,10 @@ __device__ __forceinline__ void bilateral_body(const float* __restrict__ depth, 
     const float value = tile[(ty + kBR) * kBLdsW + tx + kBR];
     float res = 0.f;
     if (!(value <= 0.03f)) {   // the shader's gate as written (`if (value <= 0.03f) 0 else filter`, :34): a NaN centre is filtered, to NaN
-        float sum1 = 0.f, sum2 = 0.f;
+        // {sum of tap * weight, sum of weights} as ONE two-lane value: the two additions of a tap are a single v_pk_add_f32 -- two independent IEEE
+        // additions, the same bits -- whether or not the including file lets the SLP vectoriser find the pair (mf_odometry.hip does not)
+        typedef float pair_t __attribute__((vector_size(8)));
+        pair_t acc = {0.f, 0.f};
 #pragma unroll
         for (int dy = -kBR; dy <= kBR; ++dy) {
             const float* row = &tile[(ty + kBR + dy) * kBLdsW + tx + kBR];
@@ -61,11 +64,11 @@ __device__ __forceinline__ void bilateral_body(const float* __restrict__ depth, 
                 const float space_term = -(((float)(dx * dx) + fy2) * sigma_space2_inv_half);   // compile-time constant
                 const float color2 = (value - tmp) * (value - tmp);
                 const float weight = __builtin_amdgcn_exp2f(space_term - color2 * sigma_color2_inv_half);   // exactly 0 for an outside tap
-                sum1 += tmp * weight;
-                sum2 += weight;
+                const pair_t add = {tmp * weight, weight};
+                acc += add;
             }
         }
-        res = sum1 / sum2;
+        res = acc[0] / acc[1];
     }
     out[gy * W + gx] = res;
 }
